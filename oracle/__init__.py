@@ -1,0 +1,21 @@
+"""CPU oracle for the ViT-with-token-reduction hot path.  TEST INFRASTRUCTURE ONLY.
+
+This package restates, in plain torch-CPU fp32 (functional, no nn.Module, no timm),
+the algorithm of the reference's `model.forward()` for the families on the hot path
+(SURVEY.md section 8a).  Every function cites the reference file:line it follows.
+
+Who may import it: `tests/`, `__graft_entry__.smoke()` and the `cpu_baseline` leg of
+`bench.py` -- as the checker / reported CPU baseline, never as the thing shipped.
+The product package `tokenreduction_amd` must not import anything from here and has
+no CPU fallback: it raises when the HIP library is missing.
+
+Pinning: the reference has no tests/golden vectors of its own, so
+the oracle is pinned against outputs of the reference itself, run in the build
+container through a test-only timm stand-in (`tests/golden/gen_golden.py`, vectors
+committed under `tests/golden/*.npz`, checked by `tests/test_oracle_golden.py`).
+"""
+from .vit import (  # noqa: F401
+    VitConfig, vit_forward, block_forward, attention, layer_norm, mlp, gelu_erf,
+    patch_embed, embed_tokens, head, cls_topk_select, cls_scores_from_heads,
+    gather_compact, complement_idx, evit_fuse, stage_keep_counts, round_bf16,
+)

@@ -1,0 +1,90 @@
+"""Deterministic synthetic weights / inputs shared by the golden generator and the tests.
+
+Fixtures store only seeds + expected outputs; the weights are re-created from the seed
+(numpy PCG64 `standard_normal` is stable across numpy versions), so the .npz stay small.
+Key names are the reference's state-dict names.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def _normal(rng, shape, std):
+    return torch.from_numpy((rng.standard_normal(shape) * std).astype(np.float32))
+
+
+def make_params(cfg, seed: int, qkv_gain: float = 1.0):
+    """cfg: anything with embed_dim, depth, num_heads, mlp_ratio, num_classes, img_size,
+    patch_size, in_chans.  All biases and LN affine terms are non-trivial on purpose so every
+    epilogue path is exercised.  qkv_gain>1 gives 'peaky' attention (realistic score spread)."""
+    rng = np.random.default_rng(seed)
+    D = cfg.embed_dim
+    Hd = int(D * cfg.mlp_ratio)
+    P = (cfg.img_size // cfg.patch_size) ** 2
+    p = {}
+    p["cls_token"] = _normal(rng, (1, 1, D), 0.02)
+    p["pos_embed"] = _normal(rng, (1, P + 1, D), 0.02)
+    p["patch_embed.proj.weight"] = _normal(rng, (D, cfg.in_chans, cfg.patch_size, cfg.patch_size), 0.02)
+    p["patch_embed.proj.bias"] = _normal(rng, (D,), 0.02)
+    for i in range(cfg.depth):
+        b = f"blocks.{i}."
+        p[b + "norm1.weight"] = 1.0 + _normal(rng, (D,), 0.1)
+        p[b + "norm1.bias"] = _normal(rng, (D,), 0.05)
+        p[b + "attn.qkv.weight"] = _normal(rng, (3 * D, D), 0.02 * qkv_gain)
+        p[b + "attn.qkv.bias"] = _normal(rng, (3 * D,), 0.02)
+        p[b + "attn.proj.weight"] = _normal(rng, (D, D), 0.02)
+        p[b + "attn.proj.bias"] = _normal(rng, (D,), 0.02)
+        p[b + "norm2.weight"] = 1.0 + _normal(rng, (D,), 0.1)
+        p[b + "norm2.bias"] = _normal(rng, (D,), 0.05)
+        p[b + "mlp.fc1.weight"] = _normal(rng, (Hd, D), 0.02)
+        p[b + "mlp.fc1.bias"] = _normal(rng, (Hd,), 0.02)
+        p[b + "mlp.fc2.weight"] = _normal(rng, (D, Hd), 0.02)
+        p[b + "mlp.fc2.bias"] = _normal(rng, (D,), 0.02)
+    p["norm.weight"] = 1.0 + _normal(rng, (D,), 0.1)
+    p["norm.bias"] = _normal(rng, (D,), 0.05)
+    p["head.weight"] = _normal(rng, (cfg.num_classes, D), 0.02)
+    p["head.bias"] = _normal(rng, (cfg.num_classes,), 0.02)
+    return p
+
+
+def make_images(batch: int, img_size: int, seed: int, in_chans: int = 3):
+    rng = np.random.default_rng(seed)
+    return torch.from_numpy(rng.standard_normal((batch, in_chans, img_size, img_size)).astype(np.float32))
+
+
+# The golden cases (name -> kwargs).  Used by tests/golden/gen_golden.py to drive the reference
+# and by tests to drive the oracle / HIP path on identical inputs.
+GOLDEN_CASES = {
+    # micro models built straight from the reference classes (dh = 64 like every DeiT size)
+    "topk_micro": dict(family="topk", embed_dim=128, depth=4, num_heads=2, num_classes=16,
+                       keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=11, xseed=12, qkv_gain=6.0),
+    "evit_micro": dict(family="evit", embed_dim=128, depth=4, num_heads=2, num_classes=16,
+                       keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=21, xseed=22, qkv_gain=6.0),
+    "deit_micro": dict(family="deit", embed_dim=128, depth=3, num_heads=2, num_classes=16,
+                       keep_rate=[1.0], reduction_loc=[], batch=2, wseed=31, xseed=32, qkv_gain=6.0),
+    # explicit per-stage ratios incl. a repeated one: evit.py:79-80 early-out (K == N-1) at blk 2
+    "evit_micro_explicit": dict(family="evit", embed_dim=128, depth=4, num_heads=2, num_classes=16,
+                                keep_rate=[0.6, 0.6, 0.3], reduction_loc=[0, 2, 3], batch=2,
+                                wseed=41, xseed=42, qkv_gain=6.0),
+    # BASELINE.json configs[0] / configs[1] at full DeiT-S size through the factory names
+    "topk_small_kr09": dict(family="topk", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
+                            keep_rate=[0.9], reduction_loc=[3, 6, 9], batch=2, wseed=51, xseed=52,
+                            qkv_gain=4.0, factory="topk_small_patch16_224"),
+    "topk_small_kr07": dict(family="topk", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
+                            keep_rate=[0.7], reduction_loc=[3, 6, 9], batch=2, wseed=61, xseed=62,
+                            qkv_gain=4.0, factory="topk_small_patch16_224"),
+    "evit_small_kr07": dict(family="evit", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
+                            keep_rate=[0.7], reduction_loc=[3, 6, 9], batch=2, wseed=71, xseed=72,
+                            qkv_gain=4.0, factory="evit_small_patch16_224"),
+    "deit_small": dict(family="deit", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
+                       keep_rate=[1.0], reduction_loc=[], batch=2, wseed=81, xseed=82,
+                       qkv_gain=4.0, factory="deit_small_patch16_224_local"),
+}
+
+
+def case_config(case: dict):
+    from oracle import VitConfig
+    return VitConfig(family=case["family"], embed_dim=case["embed_dim"], depth=case["depth"],
+                     num_heads=case["num_heads"], num_classes=case["num_classes"],
+                     keep_rate=list(case["keep_rate"]), reduction_loc=list(case["reduction_loc"]))

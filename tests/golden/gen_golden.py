@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by RUNNING THE REFERENCE (build container only).
+
+    python tests/golden/gen_golden.py            # writes tests/golden/*.npz
+
+The reference (/root/reference, read-only) is imported unmodified through the test-only
+timm stand-in in tests/golden/timm_shim (timm==0.4.12 is not installed).  Nothing of the
+reference is copied: the fixtures hold seeds + expected OUTPUTS only (logits, kept-token
+indices, complement indices, final token features, per-op outputs).  Weights/inputs are
+re-created from the seeds by tests/_params.py.
+
+Every index fixture is checked tie-free (unique scores, and the K-th/K+1-th gap recorded)
+before it is saved, because torch.topk's CPU tie order is unspecified.
+"""
+import contextlib
+import io
+import os
+import sys
+import types
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(HERE, "timm_shim"))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+with contextlib.redirect_stdout(io.StringIO()):
+    import models_act  # noqa: E402,F401  (registers the factories)
+from timm.models import create_model  # noqa: E402
+from models.topk import TopKVisionTransformer, Attention_TopK  # noqa: E402
+from models.evit import EfficientVisionTransformer, Block_EVIT, complement_idx  # noqa: E402
+from models.deit_viz import VisionTransformer as DeitViz  # noqa: E402
+
+from tests._params import GOLDEN_CASES, make_params, make_images  # noqa: E402
+
+CLASSES = {"topk": TopKVisionTransformer, "evit": EfficientVisionTransformer, "deit": DeitViz}
+
+
+class TopkSpy:
+    """Wraps torch.topk to record the scores the reference selects on (tie check)."""
+
+    def __init__(self):
+        self.calls = []
+        self._orig = torch.topk
+
+    def __enter__(self):
+        def spy(inp, k, *a, **kw):
+            self.calls.append((inp.detach().clone(), k))
+            return self._orig(inp, k, *a, **kw)
+        torch.topk = spy
+        return self
+
+    def __exit__(self, *exc):
+        torch.topk = self._orig
+
+
+def build_reference(case):
+    args = types.SimpleNamespace(keep_rate=list(case["keep_rate"]), reduction_loc=list(case["reduction_loc"]),
+                                 viz_mode=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        if "factory" in case:
+            m = create_model(case["factory"], pretrained=False, num_classes=case["num_classes"], drop_rate=0.0,
+                             drop_path_rate=0.0, drop_block_rate=None, img_size=224, args=args)
+        else:
+            kw = dict(patch_size=16, embed_dim=case["embed_dim"], depth=case["depth"], num_heads=case["num_heads"],
+                      mlp_ratio=4, qkv_bias=True, num_classes=case["num_classes"], args=args)
+            m = CLASSES[case["family"]](**kw)
+    m.viz_mode = True
+    cfg = types.SimpleNamespace(embed_dim=case["embed_dim"], depth=case["depth"], num_heads=case["num_heads"],
+                                mlp_ratio=4, num_classes=case["num_classes"], img_size=224, patch_size=16, in_chans=3)
+    params = make_params(cfg, case["wseed"], case.get("qkv_gain", 1.0))
+    missing, unexpected = m.load_state_dict(params, strict=True)
+    assert not missing and not unexpected
+    return m.eval(), params
+
+
+def run_case(name, case):
+    m, _ = build_reference(case)
+    x = make_images(case["batch"], 224, case["xseed"])
+    with TopkSpy() as spy, torch.no_grad():
+        out = m(x)
+    logits, viz = out if isinstance(out, tuple) else (out, {})
+    rec = {"logits": logits.numpy()}
+    gaps = []
+    for scores, k in spy.calls:
+        for b in range(scores.shape[0]):
+            s = scores[b]
+            assert torch.unique(s).numel() == s.numel(), f"{name}: tied scores - pick another seed"
+            srt = torch.sort(s, descending=True).values
+            gaps.append(((srt[k - 1] - srt[k]) / srt[k - 1]).item())
+    rec["min_rel_gap_at_k"] = np.array(min(gaps) if gaps else np.inf, dtype=np.float64)
+    for blk, idx in viz.get("Kept_Tokens", {}).items():
+        rec[f"kept_{blk}"] = idx.astype(np.int64)
+    for blk, c in viz.get("Fusion_Assign", {}).items():
+        rec[f"compl_{blk}"] = c.astype(np.int64)
+    feats = viz.get("Features", {})
+    if feats:
+        last = max(feats.keys())
+        rec["final_tokens"] = feats[last][:, :8].astype(np.float32)   # CLS + first 7 tokens of the last block
+        rec["token_counts"] = np.array([feats[k].shape[1] for k in sorted(feats.keys())], dtype=np.int64)
+        rec["token_count_blocks"] = np.array(sorted(feats.keys()), dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **rec)
+    print(f"{name}: logits {logits.shape} |max| {logits.abs().max():.3f}  min rel gap@K {rec['min_rel_gap_at_k']:.2e}"
+          f"  kept {[v.shape for k, v in rec.items() if k.startswith('kept_')]}")
+
+
+def run_ops():
+    """Op-level vectors straight from the reference's modules/functions."""
+    rng = np.random.default_rng(1234)
+    rec = {}
+    # (a6) Attention_TopK: proj(attn@v) and idx for one reduction block, D=128, H=2, N=197
+    D, H, N, B = 128, 2, 197, 2
+    att = Attention_TopK(D, num_heads=H, qkv_bias=True, keep_rate=0.5).eval()
+    sd = {"qkv.weight": torch.from_numpy((rng.standard_normal((3 * D, D)) * 0.12).astype(np.float32)),
+          "qkv.bias": torch.from_numpy((rng.standard_normal((3 * D,)) * 0.02).astype(np.float32)),
+          "proj.weight": torch.from_numpy((rng.standard_normal((D, D)) * 0.02).astype(np.float32)),
+          "proj.bias": torch.from_numpy((rng.standard_normal((D,)) * 0.02).astype(np.float32))}
+    att.load_state_dict(sd)
+    xin = torch.from_numpy(rng.standard_normal((B, N, D)).astype(np.float32))
+    with TopkSpy() as spy, torch.no_grad():
+        out, _, idx = att(xin)
+    s = spy.calls[0][0]
+    assert all(torch.unique(s[b]).numel() == s.shape[1] for b in range(B))
+    rec.update({"att_" + k.replace(".", "_"): v.numpy() for k, v in sd.items()})
+    rec.update(att_x=xin.numpy(), att_out=out.numpy(), att_scores=s.numpy(), att_idx=idx.numpy().astype(np.int64))
+    # (a8) complement_idx on random distinct indices, several shapes incl. K=1 and K=P-1
+    for j, (P, K) in enumerate([(196, 137), (138, 96), (97, 67), (12, 1), (12, 11)]):
+        idx = torch.stack([torch.from_numpy(rng.permutation(P)[:K].astype(np.int64)) for _ in range(3)])
+        rec[f"compl{j}_idx"] = idx.numpy()
+        rec[f"compl{j}_out"] = complement_idx(idx, P).numpy().astype(np.int64)
+        rec[f"compl{j}_P"] = np.array(P)
+    # (a9) Block_EVIT on a random residual stream: x', idx, compl  (D=128, H=2, keep 0.5 -> K=98)
+    blk = Block_EVIT(D, H, mlp_ratio=4.0, qkv_bias=True, norm_layer=lambda d: torch.nn.LayerNorm(d, eps=1e-6),
+                     keep_rate=0.5).eval()
+    cfg = types.SimpleNamespace(embed_dim=D, depth=1, num_heads=H, mlp_ratio=4, num_classes=4, img_size=224,
+                                patch_size=16, in_chans=3)
+    p = make_params(cfg, 4321, qkv_gain=6.0)
+    blk.load_state_dict({k[len("blocks.0."):]: v for k, v in p.items() if k.startswith("blocks.0.")})
+    with torch.no_grad():
+        xo, _, idx, compl = blk(xin)
+    rec.update(evitblk_x=xin.numpy(), evitblk_out=xo.numpy(), evitblk_idx=idx.numpy().astype(np.int64),
+               evitblk_compl=compl.numpy().astype(np.int64))
+    np.savez_compressed(os.path.join(HERE, "ops.npz"), **rec)
+    print("ops: ", {k: v.shape for k, v in rec.items() if k.endswith(("out", "idx", "compl"))})
+
+
+if __name__ == "__main__":
+    only = sys.argv[1:]
+    for name, case in GOLDEN_CASES.items():
+        if only and name not in only:
+            continue
+        run_case(name, case)
+    if not only or "ops" in only:
+        run_ops()

@@ -1,0 +1,102 @@
+"""Pin the oracle (oracle/vit.py) against vectors produced by the reference itself
+(tests/golden/gen_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from tests._params import GOLDEN_CASES, case_config, make_images, make_params
+
+FP_TOL = 2e-5   # fp32 CPU: different op order (im2col GEMM vs conv, fused softmax) only
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"))
+
+
+@pytest.mark.parametrize("name", list(GOLDEN_CASES))
+def test_model_matches_reference(golden_dir, name):
+    case = GOLDEN_CASES[name]
+    g = _load(golden_dir, name)
+    cfg = case_config(case)
+    params = make_params(cfg, case["wseed"], case.get("qkv_gain", 1.0))
+    x = make_images(case["batch"], 224, case["xseed"])
+    logits, viz = oracle.vit_forward(params, x, cfg, return_viz=True)
+    # integer outputs: bit-exact
+    kept_keys = sorted(k for k in g.files if k.startswith("kept_"))
+    assert len(kept_keys) == len(viz["Kept_Tokens"])
+    for k in kept_keys:
+        blk = int(k.split("_")[1])
+        np.testing.assert_array_equal(viz["Kept_Tokens"][blk], g[k])
+    for k in (k for k in g.files if k.startswith("compl_")):
+        blk = int(k.split("_")[1])
+        np.testing.assert_array_equal(viz["Fusion_Assign"][blk], g[k])
+    # floating point outputs
+    np.testing.assert_allclose(logits.numpy(), g["logits"], atol=FP_TOL, rtol=0)
+    if "final_tokens" in g.files:
+        np.testing.assert_allclose(viz["Final_Tokens"][:, :8].numpy(), g["final_tokens"], atol=1e-4, rtol=0)
+    if "token_counts" in g.files:
+        for blk, n in zip(g["token_count_blocks"], g["token_counts"]):
+            assert viz["Tokens"][int(blk)] == int(n)
+
+
+def test_attention_and_select_op(golden_dir):
+    g = _load(golden_dir, "ops")
+    x = torch.from_numpy(g["att_x"])
+    out, cls_rows = oracle.attention(x, torch.from_numpy(g["att_qkv_weight"]), torch.from_numpy(g["att_qkv_bias"]),
+                                     torch.from_numpy(g["att_proj_weight"]), torch.from_numpy(g["att_proj_bias"]), 2)
+    np.testing.assert_allclose(out.numpy(), g["att_out"], atol=FP_TOL, rtol=0)
+    scores = oracle.cls_scores_from_heads(cls_rows)
+    np.testing.assert_allclose(scores.numpy(), g["att_scores"], atol=1e-7, rtol=1e-5)
+    # same scores in -> same indices out, bit exact (op-boundary pin, SURVEY section 7 "hard parts")
+    idx = oracle.cls_topk_select(torch.from_numpy(g["att_scores"]), g["att_idx"].shape[1])
+    np.testing.assert_array_equal(idx.numpy(), g["att_idx"])
+    np.testing.assert_array_equal(oracle.cls_topk_select(scores, g["att_idx"].shape[1]).numpy(), g["att_idx"])
+
+
+def test_complement_idx(golden_dir):
+    g = _load(golden_dir, "ops")
+    for j in range(5):
+        out = oracle.complement_idx(torch.from_numpy(g[f"compl{j}_idx"]), int(g[f"compl{j}_P"]))
+        np.testing.assert_array_equal(out.numpy(), g[f"compl{j}_out"])
+
+
+def test_evit_block(golden_dir):
+    g = _load(golden_dir, "ops")
+    from types import SimpleNamespace
+    cfgp = SimpleNamespace(embed_dim=128, depth=1, num_heads=2, mlp_ratio=4, num_classes=4, img_size=224,
+                           patch_size=16, in_chans=3)
+    p = make_params(cfgp, 4321, qkv_gain=6.0)
+    cfg = oracle.VitConfig(family="evit", embed_dim=128, depth=1, num_heads=2, keep_rate=[0.5], reduction_loc=[0])
+    xo, idx, compl = oracle.block_forward(torch.from_numpy(g["evitblk_x"]), p, 0, cfg, keep=98)
+    idx = torch.cat([idx, torch.full((idx.shape[0], 1), -1)], dim=1)
+    np.testing.assert_array_equal(idx.numpy(), g["evitblk_idx"])
+    np.testing.assert_array_equal(compl.numpy(), g["evitblk_compl"])
+    np.testing.assert_allclose(xo.numpy(), g["evitblk_out"], atol=FP_TOL, rtol=0)
+
+
+def test_tie_rule_lowest_index_first():
+    s = torch.tensor([[0.1, 0.5, 0.5, 0.2, 0.5]])
+    assert oracle.cls_topk_select(s, 3).tolist() == [[1, 2, 4]]
+    assert oracle.cls_topk_select(s, 4).tolist() == [[1, 2, 4, 3]]
+
+
+def test_stage_keep_counts():
+    cfg = oracle.VitConfig(family="topk", keep_rate=[0.7], reduction_loc=[3, 6, 9])
+    assert oracle.stage_keep_counts(cfg) == {3: 137, 6: 96, 9: 67}
+    cfg = oracle.VitConfig(family="topk", keep_rate=[0.9], reduction_loc=[3, 6, 9])
+    assert oracle.stage_keep_counts(cfg) == {3: 176, 6: 158, 9: 142}
+    cfg = oracle.VitConfig(family="topk", keep_rate=[0.5], reduction_loc=[3, 6, 9])
+    assert oracle.stage_keep_counts(cfg) == {3: 98, 6: 49, 9: 24}
+
+
+def test_bf16_mode_close_to_fp32():
+    case = GOLDEN_CASES["deit_micro"]
+    cfg = case_config(case)
+    params = make_params(cfg, case["wseed"], case["qkv_gain"])
+    x = make_images(2, 224, case["xseed"])
+    a = oracle.vit_forward(params, x, cfg)
+    b = oracle.vit_forward(params, x, cfg, precision="bf16")
+    assert (a - b).abs().max().item() < 2e-2
