@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/s of the DeiT-S Top-K (keep_rate 0.7, reduction_loc 3,6,9) forward pass on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path (model.forward through the native executor) over one synthetic batch of
+256 images already resident in HBM (BASELINE.json configs[1]).  Data-parallel inference shards images over
+ranks with no data-path collective: every rank runs its own batch of 256 -> weak scaling.
+Rank 0 prints ONE JSON line.  Extra legs (rank 0, N=1 only, outside the timed region):
+  roofline      per-launch HIP-event timing of the same forward, kernel by kernel, on the launch stream
+  cpu_baseline  the oracle (fp32 torch-CPU restatement of the reference) timed on this box's host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+BATCH = 256
+MODEL = "topk_small_patch16_224"
+KEEP_RATE, REDUCTION_LOC = [0.7], [3, 6, 9]
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md chip table)
+PEAK_HBM_GBPS = 8000.0
+
+
+def build_model(name=MODEL, keep_rate=KEEP_RATE, loc=REDUCTION_LOC, device="cuda"):
+    import tokenreduction_amd as tra
+    torch.manual_seed(0)
+    args = types.SimpleNamespace(keep_rate=list(keep_rate), reduction_loc=list(loc))
+    m = tra.create_model(name, pretrained=False, num_classes=1000, drop_rate=0.0, drop_path_rate=0.0,
+                         drop_block_rate=None, img_size=224, args=args)
+    with torch.no_grad():                       # "peaky" attention so the Top-K sees a realistic score spread
+        for blk in m.blocks:
+            blk.attn.qkv.weight.mul_(4.0)
+    return m.to(device).eval()
+
+
+def model_flops_per_image(tokens_per_block, D=384, P=196, classes=1000, n0=197):
+    """patch-embed + sum_blocks[8 D^2 N_attn + 4 N_attn^2 D + 16 D^2 N_mlp] + head."""
+    f = 2.0 * P * 768 * D + 2.0 * D * classes
+    n_attn = n0
+    for n_mlp in tokens_per_block:
+        f += 8.0 * D * D * n_attn + 4.0 * n_attn * n_attn * D + 16.0 * D * D * n_mlp
+        n_attn = n_mlp
+    return f
+
+
+def roofline_leg(model, x, reps=3):
+    from tokenreduction_amd.stepwise import Trace, forward_stepwise
+    agg = {}
+    for _ in range(reps):
+        tr = Trace(timing=True)
+        forward_stepwise(model, x, tr)
+        for l in tr.launches:
+            a = agg.setdefault(l["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            a["ms"] += l["ms"]; a["flops"] += l["flops"]; a["bytes"] += l["bytes"]; a["launches"] += 1
+    total_ms = sum(a["ms"] for a in agg.values())
+    table = {}
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+        t = a["ms"] * 1e-3
+        table[k] = dict(share=round(a["ms"] / total_ms, 4), launches_per_fwd=a["launches"] // reps,
+                        avg_us=round(1e3 * a["ms"] / a["launches"], 2),
+                        tflops=round(a["flops"] / t / 1e12, 2), gbps=round(a["bytes"] / t / 1e9, 1))
+    dom = max(agg, key=lambda k: agg[k]["ms"])
+    a = agg[dom]
+    if a["flops"] > 0:
+        ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
+        roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                    frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=None,
+                    flops_per_launch=a["flops"] / a["launches"], avg_launch_us=round(1e3 * a["ms"] / a["launches"], 2))
+    else:
+        ach = a["bytes"] / (a["ms"] * 1e-3) / 1e9
+        roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
+                    frac=round(ach / PEAK_HBM_GBPS, 4), traffic=None,
+                    bytes_per_launch=a["bytes"] / a["launches"], avg_launch_us=round(1e3 * a["ms"] / a["launches"], 2))
+    return roof, table, total_ms / reps
+
+
+def cpu_baseline_leg(model, budget_s=12.0):
+    """The oracle (port of the reference's eval forward, fp32, torch CPU) on a bounded sample of the same workload."""
+    import oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    params = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    cfg = oracle.VitConfig(family="topk", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
+                           keep_rate=list(KEEP_RATE), reduction_loc=list(REDUCTION_LOC))
+    bs = 32
+    x = torch.randn(bs, 3, 224, 224, generator=torch.Generator().manual_seed(1))
+    oracle.vit_forward(params, x, cfg)            # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        oracle.vit_forward(params, x, cfg)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 40:
+            break
+    return dict(value=round(bs * n / el, 1), unit="images/s", cores=cores, kind="port",
+                sample=f"{n} forward passes of batch {bs} (same model/config, fp32 torch-CPU oracle), {el:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-extra", action="store_true", help="skip the roofline / cpu_baseline legs")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+
+    model = build_model(device=dev)
+    x = torch.randn(BATCH, 3, 224, 224, generator=torch.Generator().manual_seed(100 + rank)).to(dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        model(x)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = model(x)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = t.item()
+        dist.barrier()
+    assert torch.isfinite(out).all()
+
+    if rank == 0:
+        ips = world * BATCH * a.steps / el
+        tokens = model._last_tokens
+        gflop = model_flops_per_image(tokens) / 1e9
+        rec = {
+            "metric": "images/sec DeiT-S Top-K keep_rate=0.7 forward (aggregate over n_gpus; per-GPU = value/n_gpus)",
+            "value": round(ips, 1), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1e3 * el / a.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{MODEL} keep_rate=0.7 reduction_loc=3,6,9 batch={BATCH}/GPU 224x224 eval forward "
+                                   f"(BASELINE.json configs[1])", "global_batch": BATCH * world,
+                       "tokens_per_block": tokens, "gflop_per_image": round(gflop, 3), "parallelism": f"dp{world}"},
+            "model_tflops": round(ips * gflop / 1e3, 1),
+            "model_mfma_frac": round(ips * gflop / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
+        }
+        if world == 1 and not a.no_extra:
+            roof, table, step_ms = roofline_leg(model, x)
+            rec["roofline"] = roof
+            rec["kernels"] = table
+            rec["stepwise_ms_per_step"] = round(step_ms, 3)
+            # no-reduction DeiT-S through the same kernels: the baseline the north_star's speed-up is quoted against
+            dense = build_model("deit_small_patch16_224_local", [1.0], [], dev)
+            for _ in range(3):
+                dense(x)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                dense(x)
+            torch.cuda.synchronize()
+            d_ips = BATCH * 10 / (time.perf_counter() - t1)
+            rec["dense_deit_s_images_per_s"] = round(d_ips, 1)
+            rec["speedup_vs_dense"] = round(ips / d_ips, 3)
+            rec["cpu_baseline"] = cpu_baseline_leg(model)
+        print(json.dumps(rec), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,134 @@
+/*
+ * tokenreduction_hip.h -- C ABI of the MI355X (gfx950) ViT-with-token-reduction hot path.
+ *
+ * The reference (JoakimHaurum/TokenReduction) is pure PyTorch and has NO native boundary
+ * (SURVEY.md section 2a); its hot path is model.forward() of models/{deit_viz,topk,evit}.py.
+ * This header is the native boundary this build introduces under the reference's Python
+ * plugin API.  Each entry point names the reference lines it replaces.
+ *
+ * Conventions (every entry point):
+ *   - all data pointers are DEVICE pointers owned by the caller (e.g. the PyTorch allocator);
+ *     outputs and workspace are pre-allocated by the caller; nothing is allocated or freed here;
+ *   - work is enqueued on the caller's stream (`tr_stream_t` = hipStream_t); no call synchronises,
+ *     so every call is hipGraph-capturable; no global mutable state (re-entrant per stream);
+ *   - bf16 tensors are passed as uint16_t* (raw bits); row-major, innermost dimension contiguous;
+ *   - return value: 0 = ok, <0 = error (TR_ERR_*); tr_last_error() gives a thread-local message;
+ *   - head_dim is 64 for every DeiT size (models_act.py:1087,1120,1153) and is required.
+ */
+#ifndef TOKENREDUCTION_HIP_H
+#define TOKENREDUCTION_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* tr_stream_t; /* hipStream_t */
+
+#define TR_OK 0
+#define TR_ERR_SHAPE (-1)     /* unsupported / inconsistent shape */
+#define TR_ERR_ALIGN (-2)     /* pointer or leading dimension not 16-byte aligned */
+#define TR_ERR_NULL (-3)      /* required pointer is NULL */
+#define TR_ERR_LAUNCH (-4)    /* hipLaunch failed (message has hipGetErrorString) */
+#define TR_ERR_CONFIG (-5)    /* invalid tr_vit_config */
+
+/* GEMM epilogues: out = epilogue(A[M,K] * W[N,K]^T + bias[N]) */
+#define TR_EPI_BF16 0       /* out bf16 [M,N]                            (qkv Linear, topk.py:44)          */
+#define TR_EPI_GELU_BF16 1  /* out bf16 [M,N] = gelu_erf(.)              (timm Mlp fc1+act)                */
+#define TR_EPI_RESID_F32 2  /* out fp32 [M,N] += (.)  (in-place residual: topk.py:87 / :95)                */
+#define TR_EPI_F32 3        /* out fp32 [M,N]                            (head, topk.py:203)               */
+#define TR_EPI_PATCH_F32 4  /* out fp32 token rows: row m=(b,p) -> out[(b*(P+1)+1+p), :] = (.) + pos[1+p,:]
+                               (PatchEmbed + pos_embed, topk.py:181-186); aux = pos_embed, aux_i = P        */
+
+int tr_version(void);
+const char* tr_last_error(void);
+
+/* a1 (PatchEmbed, call site topk.py:181): unfold 16x16 patches.  img fp32 [B,C,H,W] ->
+ * cols bf16 [B*(H/p)*(W/p), C*p*p], column order (c, iy, ix) = Conv2d weight.view(D,-1) order. */
+int tr_im2col_bf16(const float* img, uint16_t* cols, int B, int C, int H, int W, int patch, tr_stream_t s);
+
+/* a2 (topk.py:183-186): x[b*N + 0, :] = cls_token + pos_embed[0] for every image (fp32). */
+int tr_cls_pos_rows(const float* cls_token, const float* pos_embed, float* x, int B, int N, int D, tr_stream_t s);
+
+/* a3/a4 Linear layers (nn.Linear: y = x W^T + b, W is [N,K] row-major like the state dict).
+ * A bf16 [M,K], W bf16 [N,K], bias fp32 [N]; K % 64 == 0, N % 4 == 0.  `out` dtype/meaning per epilogue;
+ * aux/aux_i only for TR_EPI_PATCH_F32. */
+int tr_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* bias, void* out, const float* aux, int aux_i,
+                 int M, int N, int K, int epilogue, tr_stream_t s);
+
+/* a4 nn.LayerNorm(D, eps) rows of a fp32 residual stream -> bf16 (topk.py:86 norm1, :95 norm2, :201 norm).
+ * x fp32 rows at stride ldx (floats); y bf16 [M,D].  D % 4 == 0, D <= 1024. */
+int tr_layernorm_bf16(const float* x, long ldx, const float* gamma, const float* beta, uint16_t* y, int M, int D,
+                      float eps, tr_stream_t s);
+
+/* a3 (topk.py:44-51 == deit_viz.py:43-51): softmax(q k^T / sqrt(64)) v for every (image, head).
+ * qkv bf16 [B*N, 3*H*64] (columns [q|k|v], head-major), out bf16 [B*N, H*64].
+ * cls_rows (nullable) fp32 [B,H,N]: the CLS query's softmax row (attn[:, :, 0, :], topk.py:59) --
+ * the only part of the N x N matrix the reduction reads, so the matrix is never materialised.
+ * N <= 224 in this round (whole score row in registers); larger N returns TR_ERR_SHAPE. */
+int tr_attention_bf16(const uint16_t* qkv, uint16_t* out, float* cls_rows, int B, int N, int H, tr_stream_t s);
+
+/* a6 (topk.py:55-65 == evit.py:77-87) + a8 (evit.py:25-46 complement_idx):
+ * scores[b,j] = mean_h cls_rows[b,h,1+j] (j < P = N-1); idx[b,:K] = indices of the K largest scores in
+ * DESCENDING score order (ties: lowest index first -- torch.topk's CPU tie order is unspecified);
+ * compl (nullable) [B,P-K] = indices not selected, ascending.  scores (nullable) fp32 [B,P]. int32 indices. */
+int tr_cls_topk(const float* cls_rows, int32_t* idx, int32_t* compl_idx, float* scores, int B, int H, int N, int K,
+                tr_stream_t s);
+
+/* a7 (topk.py:89-93) [+ a9 evit.py:111-123] fused with norm2 (topk.py:95):
+ * x_out[b,0]=x[b,0]; x_out[b,1+r]=x[b,1+idx[b,r]] (r<K); if compl_idx: x_out[b,K+1]=sum_j x[b,1+compl[b,j]]*scores[b,compl[b,j]].
+ * Also y = LayerNorm(x_out) in bf16.  x fp32 [B,N,D] -> x_out fp32 [B,N_out,D], y bf16 [B,N_out,D],
+ * N_out = K+1 (+1 with fuse).  idx == NULL means identity (N_out = N, x_out may be NULL -> only y written). */
+int tr_gather_layernorm_bf16(const float* x, const int32_t* idx, const int32_t* compl_idx, const float* scores,
+                             const float* gamma, const float* beta, float* x_out, uint16_t* y, int B, int N, int K,
+                             int D, float eps, tr_stream_t s);
+
+/* ---- whole-model executor: TopKVisionTransformer.forward topk.py:179-212,
+ *      EfficientVisionTransformer.forward evit.py:209-244, deit_viz.VisionTransformer.forward :186-212 (eval) ---- */
+#define TR_FAMILY_DEIT 0
+#define TR_FAMILY_TOPK 1
+#define TR_FAMILY_EVIT 2
+#define TR_MAX_DEPTH 32
+
+typedef struct {
+  const float* ln1_g; const float* ln1_b;
+  const uint16_t* qkv_w; const float* qkv_b;     /* [3D,D] bf16, [3D] */
+  const uint16_t* proj_w; const float* proj_b;   /* [D,D], [D] */
+  const float* ln2_g; const float* ln2_b;
+  const uint16_t* fc1_w; const float* fc1_b;     /* [Hd,D], [Hd] */
+  const uint16_t* fc2_w; const float* fc2_b;     /* [D,Hd], [D] */
+} tr_block_weights;
+
+typedef struct {
+  const uint16_t* patch_w; const float* patch_b; /* [D, C*p*p] bf16, [D] */
+  const float* cls_token; const float* pos_embed;/* [D], [(P+1), D] fp32 */
+  const float* norm_g; const float* norm_b;
+  const uint16_t* head_w; const float* head_b;   /* [classes, D] bf16, [classes] */
+  tr_block_weights blocks[TR_MAX_DEPTH];
+} tr_vit_weights;
+
+typedef struct {
+  int family;                 /* TR_FAMILY_* */
+  int img_size, patch, in_chans;
+  int embed_dim, depth, num_heads, mlp_hidden, num_classes;
+  float ln_eps;
+  int keep[TR_MAX_DEPTH];     /* per block: K patch tokens kept by that block's Top-K, 0 = plain block */
+} tr_vit_config;
+
+/* Bytes of workspace tr_vit_forward needs for batch B (0 on invalid config). */
+size_t tr_vit_workspace_bytes(const tr_vit_config* cfg, int B);
+
+/* img fp32 [B,C,S,S] -> logits fp32 [B,classes].  kept_idx (nullable): device int32 slab of depth*B*P entries;
+ * reduction block blk writes its contiguous [B,K_blk] idx array at offset blk*B*P (Kept_Tokens, topk.py:196).
+ * compl_idx (nullable, EViT): same slab shape, block blk writes [B,P_in-K_blk] at offset blk*B*P
+ * (Fusion_Assign, evit.py:229).  tokens_out (nullable, HOST pointer, int[depth]): token count after each block. */
+int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits,
+                   void* workspace, size_t workspace_bytes, int32_t* kept_idx, int32_t* compl_idx,
+                   int* tokens_out, int B, tr_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOKENREDUCTION_HIP_H */

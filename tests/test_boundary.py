@@ -1,0 +1,122 @@
+"""CPU-side checks of the drop-in boundary: the registry surface, state-dict keys, the C-ABI symbols,
+and that the product path fails loudly instead of falling back."""
+import ctypes
+import os
+import re
+import types
+
+import pytest
+import torch
+
+import tokenreduction_amd as tra
+from tokenreduction_amd import _lib
+from tests._params import make_params
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# models_act.py:8-51 __all__
+REFERENCE_NAMES = [f"{fam}_{size}_patch16_224{suf}"
+                   for size in ("tiny", "small", "base")
+                   for fam, suf in (("deit", "_local"), ("deit", "_local_viz"), ("dpcknn", ""), ("dyvit", ""),
+                                    ("dyvit", "_teacher"), ("kmedoids", ""), ("patchmerger", ""), ("sinkhorn", ""),
+                                    ("ats", ""), ("heuristic", ""), ("topk", ""), ("evit", ""), ("tome", ""), ("sit", ""))]
+
+
+def _args(**kw):
+    return types.SimpleNamespace(**kw)
+
+
+def test_registry_has_every_reference_name():
+    assert len(REFERENCE_NAMES) == 42
+    for n in REFERENCE_NAMES:
+        assert tra.is_model(n), n
+
+
+def test_unbuilt_families_fail_loudly():
+    with pytest.raises(NotImplementedError):
+        tra.create_model("tome_small_patch16_224", args=_args(keep_rate=[0.7], reduction_loc=[3, 6, 9]))
+
+
+@pytest.mark.parametrize("name,dims", [("topk_tiny_patch16_224", (192, 3)), ("evit_small_patch16_224", (384, 6)),
+                                       ("deit_small_patch16_224_local", (384, 6))])
+def test_factory_dims_and_state_dict_keys(name, dims):
+    m = tra.create_model(name, pretrained=False, num_classes=1000, drop_rate=0.0, drop_path_rate=0.1,
+                         drop_block_rate=None, img_size=224, args=_args(keep_rate=[0.7], reduction_loc=[3, 6, 9]))
+    assert (m.embed_dim, m.num_heads, m.depth) == (dims[0], dims[1], 12)
+    cfg = types.SimpleNamespace(embed_dim=dims[0], depth=12, num_heads=dims[1], mlp_ratio=4, num_classes=1000,
+                                img_size=224, patch_size=16, in_chans=3)
+    ref_keys = set(make_params(cfg, 0).keys())          # the reference's key names (checked against it in gen_golden)
+    assert set(m.state_dict().keys()) == ref_keys
+    m.load_state_dict(make_params(cfg, 0), strict=True)
+    assert m.patch_embed.num_patches == 196 and m.pos_embed.shape == (1, 197, dims[0])
+    assert m.no_weight_decay() == {'pos_embed', 'cls_token', 'dist_token'}
+    assert m.get_new_module_names() == []
+    m.reset_classifier(10)
+    assert m.head.out_features == 10
+
+
+def test_keep_schedule_matches_reference_rule():
+    m = tra.create_model("topk_small_patch16_224", args=_args(keep_rate=[0.7], reduction_loc=[3, 6, 9]))
+    assert [m._keep[i] for i in (3, 6, 9)] == [137, 96, 67] and m.get_reduction_count() == [3, 6, 9]
+    assert m.token_ratio == pytest.approx([0.7, 0.49, 0.343])
+    m = tra.create_model("evit_small_patch16_224", args=_args(keep_rate=[0.9, 0.8, 0.5], reduction_loc=[1, 2, 3]))
+    assert [m._keep[i] for i in (1, 2, 3)] == [176, 156, 98]
+    with pytest.raises(AssertionError):
+        tra.create_model("topk_small_patch16_224", args=_args(keep_rate=[0.7, 0.5], reduction_loc=[3, 6, 9]))
+
+
+def test_create_model_drops_none_kwargs():
+    m = tra.create_model("deit_tiny_patch16_224_local", pretrained=False, num_classes=5, drop_block_rate=None,
+                         args=_args())
+    assert m.num_classes == 5
+
+
+def test_no_cpu_path_and_no_training_path():
+    m = tra.create_model("topk_tiny_patch16_224", args=_args(keep_rate=[0.7], reduction_loc=[3, 6, 9]))
+    with pytest.raises(NotImplementedError):
+        m.train()(torch.zeros(1, 3, 224, 224))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m.eval()(torch.zeros(1, 3, 224, 224))
+
+
+def test_pretrained_offline_fails_loudly(tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    with pytest.raises(RuntimeError, match="deit_weights"):
+        tra.create_model("topk_small_patch16_224", pretrained=True, args=_args(keep_rate=[0.7], reduction_loc=[3, 6, 9]))
+
+
+def test_library_exports_every_declared_symbol():
+    """Every function declared in include/tokenreduction_hip.h is exported by the built .so and bound in _lib."""
+    hdr = open(os.path.join(ROOT, "include", "tokenreduction_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(tr_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load()                                   # raises if the .so is not built
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.tr_version() >= 100
+
+
+def test_struct_layout_matches_header():
+    assert ctypes.sizeof(_lib.TrBlockWeights) == 12 * 8
+    assert ctypes.sizeof(_lib.TrVitWeights) == 8 * 8 + 32 * 12 * 8
+    assert ctypes.sizeof(_lib.TrVitConfig) == (9 + 1 + 32) * 4
+
+
+def test_argument_validation_without_gpu():
+    """Shape/null checks run on the host before any launch, so they are testable without a GPU."""
+    lib = _lib.load()
+    assert lib.tr_gemm_bf16(None, None, None, None, None, 0, 1, 1, 1, 0, None) == -3
+    assert b"null" in lib.tr_last_error()
+    buf = (ctypes.c_char * 4096)()
+    p = ctypes.addressof(buf)
+    p = (p + 255) // 256 * 256
+    assert lib.tr_gemm_bf16(p, p, p, p, None, 0, 8, 8, 48, 0, None) == -1          # K % 64
+    assert lib.tr_attention_bf16(p, p, None, 1, 300, 1, None) == -1                  # N > 224
+    assert lib.tr_cls_topk(p, p, None, None, 1, 1, 10, 10, None) == -1               # K > P
+    cfg = _lib.TrVitConfig()
+    assert lib.tr_vit_workspace_bytes(ctypes.byref(cfg), 4) == 0
+    cfg.family, cfg.img_size, cfg.patch, cfg.in_chans = 1, 224, 16, 3
+    cfg.embed_dim, cfg.depth, cfg.num_heads, cfg.mlp_hidden, cfg.num_classes = 384, 12, 6, 1536, 1000
+    n = lib.tr_vit_workspace_bytes(ctypes.byref(cfg), 256)
+    assert 0 < n < 2 ** 31

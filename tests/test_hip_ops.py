@@ -1,0 +1,256 @@
+"""GPU parity tests, op level: every HIP kernel (through the C ABI via tokenreduction_amd.ops) against the
+oracle on the same inputs.  Integer outputs are bit-exact; floating-point tolerances are written per test.
+
+bf16 kernels take bf16 operands, so the oracle is fed the SAME bf16-rounded operands (as fp32) and accumulates
+in fp32 on the CPU; what remains is accumulation order (<= 1e-5 relative) and, for bf16 outputs, one final
+rounding (1 bf16 ulp = 2^-8 relative).
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from tests._params import make_params
+
+pytestmark = pytest.mark.gpu
+
+BF16_ULP = 2.0 ** -8
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tokenreduction_amd import ops as _ops
+    return _ops
+
+
+def _rng(seed):
+    return np.random.default_rng(seed)
+
+
+def _randn(rng, *shape, scale=1.0):
+    return torch.from_numpy((rng.standard_normal(shape) * scale).astype(np.float32))
+
+
+def _bf(t):
+    return oracle.round_bf16(t)
+
+
+def assert_close_bf16(got, want, what, ulps=1.0, abs_floor=1e-5):
+    got, want = got.float().cpu(), want.float().cpu()
+    tol = ulps * BF16_ULP * want.abs() + abs_floor
+    bad = (got - want).abs() > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max abs err {(got - want).abs().max():.3e}"
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 1152, 384), (197 * 3, 384, 1536), (256, 1000, 384), (5, 16, 128),
+                                   (1000, 1536, 384)])
+@pytest.mark.parametrize("epi", ["bf16", "gelu", "resid", "f32"])
+def test_gemm(ops, M, N, K, epi):
+    rng = _rng(M * 7 + N * 3 + K)
+    a, w, b = _bf(_randn(rng, M, K)), _bf(_randn(rng, N, K, scale=0.05)), _randn(rng, N, scale=0.1)
+    ref = a.double() @ w.double().t() + b.double()
+    ad, wd, bd = a.cuda().bfloat16(), w.cuda().bfloat16(), b.cuda()
+    if epi == "bf16":
+        out = ops.gemm(ad, wd, bd, ops.TR_EPI_BF16)
+        assert_close_bf16(out, ref.float(), "gemm bf16", ulps=1.01, abs_floor=2e-4)
+    elif epi == "gelu":
+        out = ops.gemm(ad, wd, bd, ops.TR_EPI_GELU_BF16)
+        assert_close_bf16(out, oracle.gelu_erf(ref).float(), "gemm gelu", ulps=1.01, abs_floor=3e-4)
+    elif epi == "resid":
+        r = _randn(rng, M, N)
+        out = r.clone().cuda()
+        ops.gemm(ad, wd, bd, ops.TR_EPI_RESID_F32, out=out)
+        torch.testing.assert_close(out.cpu(), (ref + r.double()).float(), atol=2e-4, rtol=1e-5)
+    else:
+        out = ops.gemm(ad, wd, bd, ops.TR_EPI_F32)
+        torch.testing.assert_close(out.cpu(), ref.float(), atol=2e-4, rtol=1e-5)
+
+
+def test_gemm_operand_roles_not_transposed(ops):
+    """A = I-like probe with an ASYMMETRIC weight: catches a swapped row/col map in the accumulator write."""
+    M = N = K = 128
+    a = torch.eye(M, K)
+    w = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251) / 256.0   # exactly representable in bf16
+    out = ops.gemm(a.cuda().bfloat16(), w.cuda().bfloat16(), torch.zeros(N).cuda(), ops.TR_EPI_F32)
+    torch.testing.assert_close(out.cpu(), w.t().contiguous(), atol=0, rtol=0)
+
+
+def test_patch_embed(ops):
+    """im2col + PATCH epilogue + cls/pos rows against oracle.patch_embed/embed_tokens (bf16 operands)."""
+    rng = _rng(5)
+    B, D = 3, 128
+    img = _randn(rng, B, 3, 224, 224)
+    w, b = _randn(rng, D, 3, 16, 16, scale=0.02), _randn(rng, D, scale=0.02)
+    cls, pos = _randn(rng, 1, 1, D, scale=0.02), _randn(rng, 1, 197, D, scale=0.02)
+    want = oracle.embed_tokens(oracle.patch_embed(img, w, b, 16, precision="bf16"), cls, pos)
+    cols = ops.im2col(img.cuda(), 16)
+    x = torch.empty(B * 197, D, device="cuda")
+    ops.gemm(cols, w.reshape(D, -1).cuda().bfloat16(), b.cuda(), ops.TR_EPI_PATCH_F32, out=x, aux=pos.reshape(197, D).cuda(), aux_i=196)
+    ops.cls_pos_rows(cls.reshape(-1).cuda(), pos.reshape(197, D).cuda(), x, B, 197, D)
+    torch.testing.assert_close(x.cpu().view(B, 197, D), want, atol=1e-4, rtol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("M,D", [(7, 128), (394, 384), (33, 768), (5, 192), (3, 1024)])
+def test_layernorm(ops, M, D):
+    rng = _rng(M + D)
+    x, g, b = _randn(rng, M, D) * 3 + 0.5, 1 + _randn(rng, D, scale=0.1), _randn(rng, D, scale=0.1)
+    want = torch.nn.functional.layer_norm(x.double(), (D,), g.double(), b.double(), 1e-6).float()
+    got = ops.layernorm(x.cuda(), g.cuda(), b.cuda(), 1e-6)
+    assert_close_bf16(got, want, "layernorm", ulps=1.01, abs_floor=1e-4)
+
+
+def test_layernorm_strided_rows(ops):
+    rng = _rng(9)
+    B, N, D = 4, 69, 384
+    x, g, b = _randn(rng, B, N, D), 1 + _randn(rng, D, scale=0.1), _randn(rng, D, scale=0.1)
+    want = torch.nn.functional.layer_norm(x[:, 0].double(), (D,), g.double(), b.double(), 1e-6).float()
+    got = ops.layernorm(x.cuda(), g.cuda(), b.cuda(), 1e-6, rows=B, ldx=N * D)
+    assert_close_bf16(got, want, "layernorm cls rows", ulps=1.01, abs_floor=1e-4)
+
+
+# ------------------------------------------------------------------------------------------ attention
+def _attention_ref(qkv, B, N, H):
+    """softmax(q k^T / 8) v in fp64 from bf16-valued qkv; P rounded to bf16 like the kernel (oracle bf16 mode)."""
+    q, k, v = qkv.double().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-2, -1)) * 0.125
+    p = torch.exp(s - s.amax(-1, keepdim=True))
+    l = p.sum(-1, keepdim=True)
+    o = (oracle.round_bf16(p.float()).double() @ v) / l
+    return o.transpose(1, 2).reshape(B * N, H * 64).float(), (p / l)[:, :, 0, :].float()
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 197, 6), (3, 138, 2), (2, 97, 3), (2, 68, 2), (1, 224, 1), (2, 33, 2), (1, 7, 1),
+                                   (2, 139, 6), (2, 160, 1), (1, 192, 2)])
+def test_attention(ops, B, N, H):
+    rng = _rng(N * 13 + H)
+    qkv = _bf(_randn(rng, B * N, 3 * H * 64, scale=1.5))
+    want_o, want_cls = _attention_ref(qkv, B, N, H)
+    got_o, got_cls = ops.attention(qkv.cuda().bfloat16(), B, N, H, want_cls=True)
+    # P is rounded to bf16 at a value that depends on fp32-vs-fp64 exp in the last bit: allow 2 ulps + small floor
+    assert_close_bf16(got_o, want_o, "attention out", ulps=2.0, abs_floor=2e-3)
+    torch.testing.assert_close(got_cls.cpu(), want_cls, atol=1e-6, rtol=2e-4)
+    got_o2, none = ops.attention(qkv.cuda().bfloat16(), B, N, H, want_cls=False)
+    assert none is None and torch.equal(got_o2, got_o)
+
+
+def test_attention_matches_reference_module(ops, golden_dir):
+    """Golden vector from the reference's Attention_TopK (fp32): qkv GEMM + attention + proj through the HIP ops."""
+    g = np.load(os.path.join(golden_dir, "ops.npz"))
+    x = torch.from_numpy(g["att_x"])
+    B, N, D = x.shape
+    qkv = ops.gemm(x.reshape(B * N, D).cuda().bfloat16(), torch.from_numpy(g["att_qkv_weight"]).cuda().bfloat16(),
+                   torch.from_numpy(g["att_qkv_bias"]).cuda(), ops.TR_EPI_BF16)
+    ao, cls_rows = ops.attention(qkv, B, N, 2, want_cls=True)
+    out = ops.gemm(ao, torch.from_numpy(g["att_proj_weight"]).cuda().bfloat16(), torch.from_numpy(g["att_proj_bias"]).cuda(),
+                   ops.TR_EPI_F32)
+    # bf16 operands vs the fp32 reference: tolerance 2e-2 abs on outputs of magnitude ~0.3
+    torch.testing.assert_close(out.cpu().view(B, N, D), torch.from_numpy(g["att_out"]), atol=2e-2, rtol=0)
+    idx, _, scores = ops.cls_topk(cls_rows, g["att_idx"].shape[1])
+    torch.testing.assert_close(scores.cpu(), torch.from_numpy(g["att_scores"]), atol=0, rtol=5e-2)
+    overlap = np.mean([len(set(idx[b].tolist()) & set(g["att_idx"][b].tolist())) / idx.shape[1] for b in range(B)])
+    assert overlap > 0.9, overlap
+
+
+# ------------------------------------------------------------------------------------------ Top-K / complement
+def test_cls_topk_bit_exact_on_golden_scores(ops, golden_dir):
+    """Same scores in -> same indices out, bit exact, against the reference's own torch.topk output."""
+    g = np.load(os.path.join(golden_dir, "ops.npz"))
+    scores = torch.from_numpy(g["att_scores"])                 # [B,P] from the reference
+    B, P = scores.shape
+    cls_rows = torch.zeros(B, 1, P + 1)
+    cls_rows[:, 0, 1:] = scores                                 # H=1: the head-mean is the identity
+    K = g["att_idx"].shape[1]
+    idx, compl, sc = ops.cls_topk(cls_rows.cuda(), K, want_compl=True)
+    assert torch.equal(sc.cpu(), scores)
+    np.testing.assert_array_equal(idx.cpu().numpy().astype(np.int64), g["att_idx"])
+    np.testing.assert_array_equal(compl.cpu().numpy().astype(np.int64),
+                                  oracle.complement_idx(torch.from_numpy(g["att_idx"]), P).numpy())
+
+
+@pytest.mark.parametrize("B,H,N,K", [(4, 6, 197, 137), (3, 6, 138, 96), (2, 3, 97, 67), (2, 12, 197, 98), (5, 2, 13, 1),
+                                     (2, 2, 13, 11), (2, 6, 577, 144), (1, 1, 1025, 500)])
+def test_cls_topk_random(ops, B, H, N, K):
+    rng = _rng(N + K)
+    rows = torch.from_numpy(rng.random((B, H, N)).astype(np.float32))
+    idx, compl, sc = ops.cls_topk(rows.cuda(), K, want_compl=True)
+    # head mean: sequential fp32 sum over heads then divide, as the kernel documents
+    acc = torch.zeros(B, N - 1)
+    for h in range(H):
+        acc = acc + rows[:, h, 1:]
+    want_scores = acc / H
+    assert torch.equal(sc.cpu(), want_scores)
+    want_idx = oracle.cls_topk_select(want_scores, K)
+    np.testing.assert_array_equal(idx.cpu().numpy(), want_idx.numpy())
+    np.testing.assert_array_equal(compl.cpu().numpy(), oracle.complement_idx(want_idx, N - 1).numpy())
+    # and against torch's mean (what the reference calls): identical or within 1 ulp
+    torch.testing.assert_close(sc.cpu(), rows[:, :, 1:].mean(1), atol=0, rtol=2e-7)
+
+
+def test_cls_topk_ties_lowest_index_first(ops):
+    rows = torch.zeros(1, 1, 9)
+    rows[0, 0, 1:] = torch.tensor([0.1, 0.5, 0.5, 0.2, 0.5, 0.1, 0.7, 0.2])
+    idx, compl, _ = ops.cls_topk(rows.cuda(), 5, want_compl=True)
+    assert idx.cpu().tolist() == [[6, 1, 2, 4, 3]]
+    assert compl.cpu().tolist() == [[0, 5, 7]]
+
+
+# ------------------------------------------------------------------------------------------ gather (+fuse) + LN2
+@pytest.mark.parametrize("fuse", [False, True])
+@pytest.mark.parametrize("B,N,K,D", [(3, 197, 137, 384), (2, 138, 96, 128), (2, 98, 67, 768), (1, 5, 1, 192)])
+def test_gather_layernorm(ops, fuse, B, N, K, D):
+    rng = _rng(N + K + D + fuse)
+    x = _randn(rng, B, N, D)
+    scores = torch.from_numpy(rng.random((B, N - 1)).astype(np.float32))
+    g, b = 1 + _randn(rng, D, scale=0.1), _randn(rng, D, scale=0.1)
+    idx = oracle.cls_topk_select(scores, K)
+    if fuse:
+        want_x, compl = oracle.evit_fuse(x, idx, scores)
+    else:
+        want_x, compl = oracle.gather_compact(x, idx), None
+    got_x, got_y = ops.gather_layernorm(x.cuda(), idx.int().cuda(), None if compl is None else compl.int().cuda(),
+                                        scores.cuda() if fuse else None, g.cuda(), b.cuda(), 1e-6)
+    # gathered rows are pure copies: bit exact; the fused row is a (P-K)-term fp32 sum: 1e-5 relative
+    assert torch.equal(got_x.cpu()[:, :K + 1], want_x[:, :K + 1])
+    if fuse:
+        torch.testing.assert_close(got_x.cpu()[:, K + 1], want_x[:, K + 1], atol=1e-5, rtol=1e-5)
+    want_y = torch.nn.functional.layer_norm(got_x.cpu().double(), (D,), g.double(), b.double(), 1e-6).float()
+    assert_close_bf16(got_y, want_y, "gather+ln", ulps=1.01, abs_floor=1e-4)
+
+
+def test_evit_block_against_reference_golden(ops, golden_dir):
+    """One full EViT block (evit.py:105-129) through the HIP ops vs the reference's Block_EVIT output (fp32 golden)."""
+    from types import SimpleNamespace
+    g = np.load(os.path.join(golden_dir, "ops.npz"))
+    cfgp = SimpleNamespace(embed_dim=128, depth=1, num_heads=2, mlp_ratio=4, num_classes=4, img_size=224, patch_size=16, in_chans=3)
+    p = {k: v.cuda() for k, v in make_params(cfgp, 4321, qkv_gain=6.0).items()}
+    x = torch.from_numpy(g["evitblk_x"]).cuda()
+    B, N, D = x.shape
+    h = x.reshape(B * N, D).clone()
+    pre = "blocks.0."
+    xn = ops.layernorm(h, p[pre + "norm1.weight"], p[pre + "norm1.bias"], 1e-6)
+    qkv = ops.gemm(xn, p[pre + "attn.qkv.weight"].bfloat16(), p[pre + "attn.qkv.bias"], ops.TR_EPI_BF16)
+    ao, cls_rows = ops.attention(qkv, B, N, 2, want_cls=True)
+    ops.gemm(ao, p[pre + "attn.proj.weight"].bfloat16(), p[pre + "attn.proj.bias"], ops.TR_EPI_RESID_F32, out=h)
+    idx, compl, scores = ops.cls_topk(cls_rows, 98, want_compl=True)
+    h2, xn2 = ops.gather_layernorm(h.view(B, N, D), idx, compl, scores, p[pre + "norm2.weight"], p[pre + "norm2.bias"], 1e-6)
+    hid = ops.gemm(xn2.view(-1, D), p[pre + "mlp.fc1.weight"].bfloat16(), p[pre + "mlp.fc1.bias"], ops.TR_EPI_GELU_BF16)
+    h2 = h2.view(-1, D)
+    ops.gemm(hid, p[pre + "mlp.fc2.weight"].bfloat16(), p[pre + "mlp.fc2.bias"], ops.TR_EPI_RESID_F32, out=h2)
+    want_idx = g["evitblk_idx"][:, :-1]
+    same = (idx.cpu().numpy() == want_idx).all(axis=1)
+    # where bf16 scores reproduce the reference's selection exactly, the block output must match to bf16 accuracy
+    got = h2.view(B, 100, D).cpu()
+    want = torch.from_numpy(g["evitblk_out"])
+    for b in range(B):
+        overlap = len(set(idx[b].tolist()) & set(want_idx[b].tolist())) / 98
+        assert overlap >= 0.95, overlap
+        if same[b]:
+            torch.testing.assert_close(got[b], want[b], atol=3e-2, rtol=0)
+    torch.testing.assert_close(got[:, 0], want[:, 0], atol=3e-2, rtol=0)    # CLS row is order-independent

@@ -1,0 +1,87 @@
+"""ctypes binding of the C-ABI library (include/tokenreduction_hip.h).
+
+The library is the product: there is NO CPU / PyTorch-eager fallback.  If the shared object is
+missing or a symbol is absent, importing the ops raises -- loudly -- with the build command.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libtokenreduction_hip.so")
+
+TR_MAX_DEPTH = 32
+TR_EPI_BF16, TR_EPI_GELU_BF16, TR_EPI_RESID_F32, TR_EPI_F32, TR_EPI_PATCH_F32 = 0, 1, 2, 3, 4
+TR_FAMILY_DEIT, TR_FAMILY_TOPK, TR_FAMILY_EVIT = 0, 1, 2
+
+_vp, _i, _f, _l, _sz = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t
+
+
+class TrBlockWeights(C.Structure):
+    _fields_ = [(n, _vp) for n in ("ln1_g", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
+                                   "ln2_g", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
+class TrVitWeights(C.Structure):
+    _fields_ = [(n, _vp) for n in ("patch_w", "patch_b", "cls_token", "pos_embed", "norm_g", "norm_b",
+                                   "head_w", "head_b")] + [("blocks", TrBlockWeights * TR_MAX_DEPTH)]
+
+
+class TrVitConfig(C.Structure):
+    _fields_ = [("family", _i), ("img_size", _i), ("patch", _i), ("in_chans", _i), ("embed_dim", _i),
+                ("depth", _i), ("num_heads", _i), ("mlp_hidden", _i), ("num_classes", _i), ("ln_eps", _f),
+                ("keep", _i * TR_MAX_DEPTH)]
+
+
+# every symbol include/tokenreduction_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "tr_version": (_i, []),
+    "tr_last_error": (C.c_char_p, []),
+    "tr_im2col_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "tr_cls_pos_rows": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "tr_gemm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "tr_layernorm_bf16": (_i, [_vp, _l, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "tr_attention_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "tr_cls_topk": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "tr_gather_layernorm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "tr_vit_workspace_bytes": (_sz, [C.POINTER(TrVitConfig), _i]),
+    "tr_vit_forward": (_i, [C.POINTER(TrVitConfig), C.POINTER(TrVitWeights), _vp, _vp, _vp, _sz, _vp, _vp,
+                            C.POINTER(_i), _i, _vp]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and type the library.  Raises HipLibraryError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} is missing: the HIP extension is the only compute path of tokenreduction_amd "
+            f"(no CPU fallback). Build it with `make -C {os.path.dirname(LIB_PATH)}` "
+            f"or `python -c 'import __graft_entry__ as g; g.build()'`.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 not found
+        raise HipLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().tr_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")

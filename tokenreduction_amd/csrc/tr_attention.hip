@@ -1,0 +1,179 @@
+// Multi-head self-attention for short ViT sequences (N <= 224 tokens, head_dim 64) on gfx950 MFMA.
+//
+// Replaces  attn = softmax(q k^T * dh^-0.5); x = attn @ v   (topk.py:44-51 == evit.py:66-73 == deit_viz.py:43-51)
+// and emits the CLS query's softmax row per head (attn[:, :, 0, :], topk.py:59) as a side output, so the
+// B*H*N*N matrix the reference keeps alive for the Top-K score is never materialised.
+//
+// One workgroup (4 waves) per (image, head).  K [N][64] is staged once into LDS row-major with the
+// 16-byte chunk index XOR-swizzled by (key>>1)&7; V is staged TRANSPOSED (Vt[d][key]) so that both
+// MFMA operands are 16-byte LDS reads (tools/lds_sim.py: all reads/writes conflict-free).
+// Each wave owns 32-query blocks and keeps the WHOLE score row in registers (no online softmax):
+//   S^T[key][q] = K Q^T       v_mfma_f32_32x32x16_bf16, lane = query, 16 keys per lane per 32-key block
+//   softmax over keys         lane-local over registers + one exchange with lane^32
+//   O^T[d][q]  = Vt P^T       the exponentiated S^T accumulator is fed straight back as the MFMA B operand
+//                             ("accumulator tile as the next MFMA's operand", cdna guide section 3); the k-order
+//                             permutation this implies (key bits 2<->3 inside each 32-key block) is applied
+//                             once, when V is transposed into LDS.
+// Arithmetic: bf16 operands, fp32 accumulate/softmax; P is rounded to bf16 for P.V, the normaliser is the
+// fp32 sum of the un-rounded exponentials (same rounding points as oracle precision="bf16").
+#include "tr_common.h"
+
+namespace {
+
+__device__ __forceinline__ int kswz(int key, int chunk) { return key * 128 + ((chunk ^ ((key >> 1) & 7)) << 4); }
+__device__ __forceinline__ int swap23(int k) { return (k & ~0xC) | ((k & 4) << 1) | ((k & 8) >> 1); }
+
+template <int NKB>
+__global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
+                                                           float* __restrict__ cls_rows, int N, int H) {
+  constexpr int RS = NKB * 64 + 16;  // Vt row stride in bytes: odd multiple of 16 -> conflict-free b128 column reads
+  __shared__ __attribute__((aligned(16))) unsigned char sK[NKB * 32 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char sVt[64 * RS];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int ldq = 3 * H * 64;
+  const uint16_t* base = qkv + (size_t)b * N * ldq;
+  const int qcol = h * 64, kcol = H * 64 + h * 64, vcol = 2 * H * 64 + h * 64;
+
+  // ---- stage K (row-major, swizzled); keys >= N are zero rows
+  for (int g = tid; g < NKB * 32 * 8; g += 256) {
+    const int key = g >> 3, c = g & 7;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (key < N) v = *reinterpret_cast<const uint4*>(base + (size_t)key * ldq + kcol + c * 8);
+    *reinterpret_cast<uint4*>(sK + kswz(key, c)) = v;
+  }
+  // ---- stage V transposed: lanes 0-31 take the 32 keys of a block for d-chunk c, lanes 32-63 chunk c+1
+  for (int u = wave; u < NKB * 4; u += 4) {
+    const int kb = u >> 2, c = 2 * (u & 3) + (lane >> 5);
+    const int kl = lane & 31, key = kb * 32 + kl;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (key < N) v = *reinterpret_cast<const uint4*>(base + (size_t)key * ldq + vcol + c * 8);
+    unsigned short* dst = reinterpret_cast<unsigned short*>(sVt + (8 * c) * RS + (kb * 32 + swap23(kl)) * 2);
+    const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned int word = w[e >> 1];
+      dst[(e * RS) >> 1] = (unsigned short)((e & 1) ? (word >> 16) : (word & 0xffffu));
+    }
+  }
+  __syncthreads();
+
+  const int ql = lane & 31, hh = lane >> 5;
+  const int nqb = (N + 31) >> 5;
+  const float c_exp = 0.125f * 1.44269504088896340736f;  // dh^-0.5 * log2(e), dh = 64
+
+  for (int qb = wave; qb < nqb; qb += 4) {
+    const int q = qb * 32 + ql;
+    const uint16_t* qrow = base + (size_t)min(q, N - 1) * ldq + qcol + 8 * hh;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qrow + 16 * s);
+
+    f32x16 sacc[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + kswz(kb * 32 + ql, 2 * s + hh));
+        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kb], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep K-fragment reads per key block: bounds live registers
+    }
+    // ---- softmax over keys (rows of S^T): registers of this lane + the other half-wave
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (kb == NKB - 1) {
+          const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (key >= N) sacc[kb][r] = -INFINITY;
+        }
+        mx = fmaxf(mx, sacc[kb][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f((sacc[kb][r] - mx) * c_exp);
+        sacc[kb][r] = p;
+        l += p;
+      }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+
+    // ---- O^T = Vt P^T
+    f32x16 o[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (__bf16)sacc[kb][8 * s + j];
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sVt + (db * 32 + ql) * RS + (kb * 32 + 16 * s + 8 * hh) * 2);
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+
+    if (q < N) {
+      uint16_t* orow = out + ((size_t)b * N + q) * (H * 64) + h * 64 + 4 * hh;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint2 pk;
+          pk.x = pack_bf16x2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
+          pk.y = pack_bf16x2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+          *reinterpret_cast<uint2*>(orow + db * 32 + 8 * g) = pk;
+        }
+    }
+    if (cls_rows != nullptr && qb == 0 && ql == 0) {
+      float* crow = cls_rows + ((size_t)b * H + h) * N;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (key < N) crow[key] = sacc[kb][r] * inv;
+        }
+    }
+  }
+}
+
+template <int NKB>
+int launch_attention(const uint16_t* qkv, uint16_t* out, float* cls_rows, int B, int N, int H, hipStream_t st) {
+  hipLaunchKernelGGL(attention_kernel<NKB>, dim3(B * H), dim3(256), 0, st, qkv, out, cls_rows, N, H);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int tr_attention_bf16(const uint16_t* qkv, uint16_t* out, float* cls_rows, int B, int N, int H, tr_stream_t s) {
+  TR_REQUIRE(qkv && out, TR_ERR_NULL, "tr_attention_bf16: null pointer");
+  TR_REQUIRE(B > 0 && H > 0 && N >= 1, TR_ERR_SHAPE, "tr_attention_bf16: bad shape B=%d N=%d H=%d", B, N, H);
+  TR_REQUIRE(N <= 224, TR_ERR_SHAPE, "tr_attention_bf16: N=%d > 224 not supported yet (register-resident score row)", N);
+  TR_REQUIRE(tr_aligned16(qkv) && tr_aligned16(out), TR_ERR_ALIGN, "tr_attention_bf16: pointers must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(s);
+  switch ((N + 31) / 32) {
+    case 1: launch_attention<1>(qkv, out, cls_rows, B, N, H, st); break;
+    case 2: launch_attention<2>(qkv, out, cls_rows, B, N, H, st); break;
+    case 3: launch_attention<3>(qkv, out, cls_rows, B, N, H, st); break;
+    case 4: launch_attention<4>(qkv, out, cls_rows, B, N, H, st); break;
+    case 5: launch_attention<5>(qkv, out, cls_rows, B, N, H, st); break;
+    case 6: launch_attention<6>(qkv, out, cls_rows, B, N, H, st); break;
+    default: launch_attention<7>(qkv, out, cls_rows, B, N, H, st); break;
+  }
+  TR_CHECK_LAUNCH("tr_attention_bf16");
+  return TR_OK;
+}

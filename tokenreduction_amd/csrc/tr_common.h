@@ -1,0 +1,64 @@
+// Internal helpers shared by the gfx950 kernels (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/tokenreduction_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define TR_WAVE 64
+
+// thread-local error text behind tr_last_error()
+void tr_set_error(const char* fmt, ...);
+
+#define TR_REQUIRE(cond, code, ...)        \
+  do {                                     \
+    if (!(cond)) {                         \
+      tr_set_error(__VA_ARGS__);           \
+      return (code);                       \
+    }                                      \
+  } while (0)
+
+#define TR_CHECK_LAUNCH(name)                                                   \
+  do {                                                                          \
+    hipError_t e__ = hipGetLastError();                                         \
+    if (e__ != hipSuccess) {                                                    \
+      tr_set_error("%s: launch failed: %s", (name), hipGetErrorString(e__));    \
+      return TR_ERR_LAUNCH;                                                     \
+    }                                                                           \
+  } while (0)
+
+static inline bool tr_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- device helpers -------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short h) {
+  return __builtin_bit_cast(float, (unsigned int)h << 16);
+}
+
+// two floats -> packed bf16x2 (RNE; a plain cast lowers to v_cvt_pk_bf16_f32 and keeps NaN a NaN)
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+  bf16x2 v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(unsigned int, v);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// XCD-aware bijective remap of a linear block id (cdna guide T1): blocks b and b+8 share an XCD/L2, so give
+// each XCD a CONTIGUOUS chunk of the logical tile order.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + slot;
+}

@@ -1,0 +1,205 @@
+// Row-wise kernels on the fp32 residual stream (HBM-bound; one wave per token row, 16-byte accesses):
+//   tr_layernorm_bf16         nn.LayerNorm(eps=1e-6) -> bf16          (topk.py:86 norm1, :201 norm)
+//   tr_gather_layernorm_bf16  Top-K gather/compact (topk.py:89-93) [+ EViT fused token evit.py:111-123]
+//                             fused with norm2 (topk.py:95): the compacted residual stream and its
+//                             normalised bf16 copy are produced in ONE pass over the kept rows.
+//   tr_im2col_bf16            PatchEmbed unfold (timm PatchEmbed, call site topk.py:181)
+//   tr_cls_pos_rows           cls_token + pos_embed[0] (topk.py:183-186)
+#include "tr_common.h"
+
+namespace {
+
+constexpr int LN_MAX_CHUNKS = 4;  // float4 chunks per lane -> D <= 1024
+
+// Normalise one row held as `nch` float4 chunks per lane; two-pass (mean, then centred variance) in registers.
+__device__ __forceinline__ void ln_row_store(float4 (&v)[LN_MAX_CHUNKS], int nchunks, int lane, int D, float eps,
+                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                             uint16_t* __restrict__ yrow) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+    if (lane + 64 * c < nchunks) s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+    if (lane + 64 * c < nchunks) {
+      const float a = v[c].x - mean, b = v[c].y - mean, cc = v[c].z - mean, d = v[c].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nchunks) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * ch);
+      const float4 b = *reinterpret_cast<const float4*>(beta + 4 * ch);
+      uint2 pk;
+      pk.x = pack_bf16x2((v[c].x - mean) * rstd * g.x + b.x, (v[c].y - mean) * rstd * g.y + b.y);
+      pk.y = pack_bf16x2((v[c].z - mean) * rstd * g.z + b.z, (v[c].w - mean) * rstd * g.w + b.w);
+      *reinterpret_cast<uint2*>(yrow + 4 * ch) = pk;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, uint16_t* __restrict__ y, int M, int D,
+                                                        float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nchunks = D >> 2;
+  const float* xr = x + (size_t)row * ldx;
+  float4 v[LN_MAX_CHUNKS];
+#pragma unroll
+  for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+    if (lane + 64 * c < nchunks) v[c] = *reinterpret_cast<const float4*>(xr + 4 * (lane + 64 * c));
+  ln_row_store(v, nchunks, lane, D, eps, gamma, beta, y + (size_t)row * D);
+}
+
+// grid: B * ceil(N_out/4) blocks; wave w of block handles output row r = 4*blk + w of image b.
+__global__ __launch_bounds__(256) void gather_layernorm_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
+                                                               const int32_t* __restrict__ compl_idx,
+                                                               const float* __restrict__ scores,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float* __restrict__ x_out, uint16_t* __restrict__ y, int N, int K,
+                                                               int N_out, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int rblocks = (N_out + 3) >> 2;
+  const int b = blockIdx.x / rblocks;
+  const int r = (blockIdx.x % rblocks) * 4 + (threadIdx.x >> 6);
+  if (r >= N_out) return;
+  const int nchunks = D >> 2;
+  const int P = N - 1;
+  const float* xb = x + (size_t)b * N * D;
+  float4 v[LN_MAX_CHUNKS];
+  if (idx != nullptr && r == K + 1) {
+    // EViT fused token: sum over the NOT-kept tokens, weighted by their (un-normalised) CLS attention
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int32_t* cb = compl_idx + (size_t)b * (P - K);
+    const float* sb = scores + (size_t)b * P;
+    for (int j = 0; j < P - K; ++j) {
+      const int t = cb[j];
+      const float w = sb[t];
+      const float* xr = xb + (size_t)(1 + t) * D;
+#pragma unroll
+      for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+        if (lane + 64 * c < nchunks) {
+          const float4 a = *reinterpret_cast<const float4*>(xr + 4 * (lane + 64 * c));
+          v[c].x += a.x * w; v[c].y += a.y * w; v[c].z += a.z * w; v[c].w += a.w * w;
+        }
+    }
+  } else {
+    int src = r;
+    if (idx != nullptr && r > 0) src = 1 + idx[(size_t)b * K + (r - 1)];
+    const float* xr = xb + (size_t)src * D;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+      if (lane + 64 * c < nchunks) v[c] = *reinterpret_cast<const float4*>(xr + 4 * (lane + 64 * c));
+  }
+  const size_t orow = (size_t)b * N_out + r;
+  if (x_out != nullptr) {
+    float* xo = x_out + orow * D;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+      if (lane + 64 * c < nchunks) *reinterpret_cast<float4*>(xo + 4 * (lane + 64 * c)) = v[c];
+  }
+  ln_row_store(v, nchunks, lane, D, eps, gamma, beta, y + orow * D);
+}
+
+// one thread = 8 consecutive pixels of one patch row -> one 16-byte bf16 store
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, uint16_t* __restrict__ cols, int B, int C, int H,
+                                                     int W, int patch, long total) {
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= total) return;
+  const int per_row = patch >> 3;          // 8-pixel groups per patch row
+  const int kcols = C * patch * patch;     // im2col row length
+  const int groups_per_row = kcols >> 3;
+  const long rowid = t / groups_per_row;   // (b, py, px)
+  const int g = (int)(t - rowid * groups_per_row);
+  const int gw = W / patch, gh = H / patch;
+  const int b = (int)(rowid / (gh * gw));
+  const int pp = (int)(rowid - (long)b * gh * gw);
+  const int py = pp / gw, px = pp - py * gw;
+  const int c = g / (patch * per_row);
+  const int rem = g - c * patch * per_row;
+  const int iy = rem / per_row, ixg = rem - iy * per_row;
+  const float* src = img + (((size_t)b * C + c) * H + (size_t)py * patch + iy) * W + (size_t)px * patch + ixg * 8;
+  const float4 a = *reinterpret_cast<const float4*>(src);
+  const float4 d = *reinterpret_cast<const float4*>(src + 4);
+  uint4 pk;
+  pk.x = pack_bf16x2(a.x, a.y); pk.y = pack_bf16x2(a.z, a.w);
+  pk.z = pack_bf16x2(d.x, d.y); pk.w = pack_bf16x2(d.z, d.w);
+  *reinterpret_cast<uint4*>(cols + rowid * kcols + (size_t)g * 8) = pk;
+}
+
+__global__ __launch_bounds__(256) void cls_pos_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ x,
+                                                      int B, int N, int D) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= B * D) return;
+  const int b = t / D, d = t - b * D;
+  x[(size_t)b * N * D + d] = cls[d] + pos[d];
+}
+
+}  // namespace
+
+extern "C" int tr_layernorm_bf16(const float* x, long ldx, const float* gamma, const float* beta, uint16_t* y, int M, int D,
+                                 float eps, tr_stream_t s) {
+  TR_REQUIRE(x && gamma && beta && y, TR_ERR_NULL, "tr_layernorm_bf16: null pointer");
+  TR_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAX_CHUNKS && ldx % 4 == 0 && ldx >= D, TR_ERR_SHAPE,
+             "tr_layernorm_bf16: need D %% 4 == 0, D <= 1024, ldx %% 4 == 0 (M=%d D=%d ldx=%ld)", M, D, ldx);
+  TR_REQUIRE(tr_aligned16(x) && tr_aligned16(gamma) && tr_aligned16(beta) && tr_aligned16(y), TR_ERR_ALIGN,
+             "tr_layernorm_bf16: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(s), x, ldx, gamma, beta, y, M, D, eps);
+  TR_CHECK_LAUNCH("tr_layernorm_bf16");
+  return TR_OK;
+}
+
+extern "C" int tr_gather_layernorm_bf16(const float* x, const int32_t* idx, const int32_t* compl_idx, const float* scores,
+                                        const float* gamma, const float* beta, float* x_out, uint16_t* y, int B, int N, int K,
+                                        int D, float eps, tr_stream_t s) {
+  TR_REQUIRE(x && gamma && beta && y, TR_ERR_NULL, "tr_gather_layernorm_bf16: null pointer");
+  TR_REQUIRE(B > 0 && N > 1 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAX_CHUNKS, TR_ERR_SHAPE,
+             "tr_gather_layernorm_bf16: bad shape B=%d N=%d D=%d", B, N, D);
+  int N_out = N;
+  if (idx != nullptr) {
+    TR_REQUIRE(K >= 1 && K <= N - 1, TR_ERR_SHAPE, "tr_gather_layernorm_bf16: K=%d out of range for N=%d", K, N);
+    TR_REQUIRE(x_out != nullptr && x_out != x, TR_ERR_NULL, "tr_gather_layernorm_bf16: gather needs a distinct x_out");
+    N_out = K + 1;
+    if (compl_idx != nullptr) {
+      TR_REQUIRE(scores != nullptr, TR_ERR_NULL, "tr_gather_layernorm_bf16: fuse needs scores");
+      N_out = K + 2;
+    }
+  } else {
+    TR_REQUIRE(compl_idx == nullptr, TR_ERR_SHAPE, "tr_gather_layernorm_bf16: compl_idx without idx");
+  }
+  TR_REQUIRE(tr_aligned16(x) && tr_aligned16(gamma) && tr_aligned16(beta) && tr_aligned16(y) && tr_aligned16(x_out),
+             TR_ERR_ALIGN, "tr_gather_layernorm_bf16: pointers must be 16-byte aligned");
+  const int rblocks = (N_out + 3) / 4;
+  hipLaunchKernelGGL(gather_layernorm_kernel, dim3(B * rblocks), dim3(256), 0, static_cast<hipStream_t>(s), x, idx, compl_idx,
+                     scores, gamma, beta, x_out, y, N, K, N_out, D, eps);
+  TR_CHECK_LAUNCH("tr_gather_layernorm_bf16");
+  return TR_OK;
+}
+
+extern "C" int tr_im2col_bf16(const float* img, uint16_t* cols, int B, int C, int H, int W, int patch, tr_stream_t s) {
+  TR_REQUIRE(img && cols, TR_ERR_NULL, "tr_im2col_bf16: null pointer");
+  TR_REQUIRE(B > 0 && C > 0 && patch >= 8 && patch % 8 == 0 && H % patch == 0 && W % patch == 0, TR_ERR_SHAPE,
+             "tr_im2col_bf16: need patch %% 8 == 0 and H,W multiples of patch (H=%d W=%d patch=%d)", H, W, patch);
+  TR_REQUIRE(tr_aligned16(img) && tr_aligned16(cols), TR_ERR_ALIGN, "tr_im2col_bf16: pointers must be 16-byte aligned");
+  const long total = (long)B * C * H * W / 8;
+  hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(s), img, cols, B, C,
+                     H, W, patch, total);
+  TR_CHECK_LAUNCH("tr_im2col_bf16");
+  return TR_OK;
+}
+
+extern "C" int tr_cls_pos_rows(const float* cls_token, const float* pos_embed, float* x, int B, int N, int D, tr_stream_t s) {
+  TR_REQUIRE(cls_token && pos_embed && x, TR_ERR_NULL, "tr_cls_pos_rows: null pointer");
+  TR_REQUIRE(B > 0 && N > 0 && D > 0, TR_ERR_SHAPE, "tr_cls_pos_rows: bad shape");
+  hipLaunchKernelGGL(cls_pos_kernel, dim3((B * D + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(s), cls_token, pos_embed, x,
+                     B, N, D);
+  TR_CHECK_LAUNCH("tr_cls_pos_rows");
+  return TR_OK;
+}

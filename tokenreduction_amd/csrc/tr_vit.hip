@@ -1,0 +1,150 @@
+// Whole-model executor: enqueues the DeiT / Top-K / EViT forward pass on the caller's stream.
+//
+// Follows TopKVisionTransformer.forward (topk.py:179-212), EfficientVisionTransformer.forward
+// (evit.py:209-244) and deit_viz.VisionTransformer.forward (:186-212), eval mode:
+//   patch_embed -> cat(cls) + pos_embed -> 12 x Block -> norm -> x[:,0] -> head
+// with Block_TopK.forward (topk.py:83-99):  x += attn(norm1(x)); [Top-K gather]; x += mlp(norm2(x)).
+//
+// Host-side only: shape bookkeeping and kernel launches (no allocation, no synchronisation, no
+// device->host copies), so one call is a fixed launch sequence that a caller may capture in a hipGraph.
+// Token counts are static per (config) -- topk.py:56 int(ratio*196) -- so every buffer size is known up front.
+#include <stdarg.h>
+#include <string.h>
+#include "tr_common.h"
+
+static thread_local char g_err[512] = "";
+
+void tr_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* tr_last_error(void) { return g_err; }
+extern "C" int tr_version(void) { return 100; }
+
+namespace {
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+struct Plan {
+  int P, N0, D, H, Hd, C, kcols;
+  size_t off_x0, off_x1, off_xn, off_qkv, off_ao, off_h, off_cols, off_cls, off_scores, off_idx, off_compl, off_xcls, total;
+};
+
+bool make_plan(const tr_vit_config* c, int B, Plan* p) {
+  if (!c || B <= 0) return false;
+  if (c->patch <= 0 || c->img_size <= 0 || c->img_size % c->patch != 0) return false;
+  if (c->depth <= 0 || c->depth > TR_MAX_DEPTH) return false;
+  if (c->num_heads <= 0 || c->embed_dim != c->num_heads * 64) return false;
+  if (c->family < TR_FAMILY_DEIT || c->family > TR_FAMILY_EVIT) return false;
+  const int g = c->img_size / c->patch;
+  p->P = g * g;
+  p->N0 = p->P + 1;
+  p->D = c->embed_dim;
+  p->H = c->num_heads;
+  p->Hd = c->mlp_hidden;
+  p->C = c->num_classes;
+  p->kcols = c->in_chans * c->patch * c->patch;
+  if (p->kcols % 64 || p->D % 64 || p->Hd % 64 || p->C % 4 || p->Hd <= 0 || p->C <= 0) return false;
+  const size_t T = (size_t)B * p->N0;  // max tokens
+  size_t o = 0;
+  p->off_x0 = o;     o += align_up(T * p->D * 4);
+  p->off_x1 = o;     o += align_up(T * p->D * 4);
+  p->off_xn = o;     o += align_up(T * p->D * 2);
+  p->off_qkv = o;    o += align_up(T * 3 * p->D * 2);
+  p->off_ao = o;     o += align_up(T * p->D * 2);
+  p->off_h = o;      o += align_up(T * p->Hd * 2);
+  p->off_cols = o;   o += align_up((size_t)B * p->P * p->kcols * 2);
+  p->off_cls = o;    o += align_up((size_t)B * p->H * p->N0 * 4);
+  p->off_scores = o; o += align_up((size_t)B * p->P * 4);
+  p->off_idx = o;    o += align_up((size_t)B * p->P * 4);
+  p->off_compl = o;  o += align_up((size_t)B * p->P * 4);
+  p->off_xcls = o;   o += align_up((size_t)B * p->D * 2);
+  p->total = o;
+  return true;
+}
+
+}  // namespace
+
+extern "C" size_t tr_vit_workspace_bytes(const tr_vit_config* cfg, int B) {
+  Plan p;
+  if (!make_plan(cfg, B, &p)) return 0;
+  return p.total;
+}
+
+#define TR_TRY(call)            \
+  do {                          \
+    int rc__ = (call);          \
+    if (rc__ != TR_OK) return rc__; \
+  } while (0)
+
+extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits, void* workspace,
+                              size_t workspace_bytes, int32_t* kept_idx, int32_t* compl_idx, int* tokens_out, int B,
+                              tr_stream_t s) {
+  Plan p;
+  TR_REQUIRE(cfg && w && img && logits && workspace, TR_ERR_NULL, "tr_vit_forward: null pointer");
+  TR_REQUIRE(make_plan(cfg, B, &p), TR_ERR_CONFIG,
+             "tr_vit_forward: invalid config (need embed_dim == 64*heads, dims %% 64 == 0, classes %% 4 == 0, depth <= %d)",
+             TR_MAX_DEPTH);
+  TR_REQUIRE(workspace_bytes >= p.total, TR_ERR_SHAPE, "tr_vit_forward: workspace too small (%zu < %zu)", workspace_bytes, p.total);
+  TR_REQUIRE(tr_aligned16(workspace), TR_ERR_ALIGN, "tr_vit_forward: workspace must be 16-byte aligned");
+
+  char* ws = static_cast<char*>(workspace);
+  float* x = reinterpret_cast<float*>(ws + p.off_x0);
+  float* x_alt = reinterpret_cast<float*>(ws + p.off_x1);
+  uint16_t* xn = reinterpret_cast<uint16_t*>(ws + p.off_xn);
+  uint16_t* qkv = reinterpret_cast<uint16_t*>(ws + p.off_qkv);
+  uint16_t* ao = reinterpret_cast<uint16_t*>(ws + p.off_ao);
+  uint16_t* hbuf = reinterpret_cast<uint16_t*>(ws + p.off_h);
+  uint16_t* cols = reinterpret_cast<uint16_t*>(ws + p.off_cols);
+  float* cls_rows = reinterpret_cast<float*>(ws + p.off_cls);
+  float* scores = reinterpret_cast<float*>(ws + p.off_scores);
+  int32_t* idx_ws = reinterpret_cast<int32_t*>(ws + p.off_idx);
+  int32_t* compl_ws = reinterpret_cast<int32_t*>(ws + p.off_compl);
+  uint16_t* xcls = reinterpret_cast<uint16_t*>(ws + p.off_xcls);
+
+  const int D = p.D, H = p.H;
+  // a1 + a2: patch embedding, CLS token, position embedding
+  TR_TRY(tr_im2col_bf16(img, cols, B, cfg->in_chans, cfg->img_size, cfg->img_size, cfg->patch, s));
+  TR_TRY(tr_gemm_bf16(cols, w->patch_w, w->patch_b, x, w->pos_embed, p.P, B * p.P, D, p.kcols, TR_EPI_PATCH_F32, s));
+  TR_TRY(tr_cls_pos_rows(w->cls_token, w->pos_embed, x, B, p.N0, D, s));
+
+  int N = p.N0;
+  for (int i = 0; i < cfg->depth; ++i) {
+    const tr_block_weights* bw = &w->blocks[i];
+    int K = (cfg->family == TR_FAMILY_DEIT) ? 0 : cfg->keep[i];
+    TR_REQUIRE(K >= 0 && K <= N - 1, TR_ERR_CONFIG, "tr_vit_forward: block %d keeps %d of %d patch tokens", i, K, N - 1);
+    if (K == N - 1) K = 0;  // topk.py:57 / evit.py:79: left_tokens == N-1 -> plain block
+    const int M = B * N;
+    // x += proj(attn(norm1(x)))
+    TR_TRY(tr_layernorm_bf16(x, D, bw->ln1_g, bw->ln1_b, xn, M, D, cfg->ln_eps, s));
+    TR_TRY(tr_gemm_bf16(xn, bw->qkv_w, bw->qkv_b, qkv, nullptr, 0, M, 3 * D, D, TR_EPI_BF16, s));
+    TR_TRY(tr_attention_bf16(qkv, ao, K > 0 ? cls_rows : nullptr, B, N, H, s));
+    TR_TRY(tr_gemm_bf16(ao, bw->proj_w, bw->proj_b, x, nullptr, 0, M, D, D, TR_EPI_RESID_F32, s));
+    int Nn = N;
+    if (K > 0) {
+      // Top-K on the CLS attention, then gather/compact (+ EViT fused token) fused with norm2
+      const bool fuse = cfg->family == TR_FAMILY_EVIT;
+      int32_t* idx_dst = kept_idx ? kept_idx + (size_t)i * B * p.P : idx_ws;
+      int32_t* compl_dst = fuse ? (compl_idx ? compl_idx + (size_t)i * B * p.P : compl_ws) : nullptr;
+      TR_TRY(tr_cls_topk(cls_rows, idx_dst, compl_dst, scores, B, H, N, K, s));
+      TR_TRY(tr_gather_layernorm_bf16(x, idx_dst, compl_dst, scores, bw->ln2_g, bw->ln2_b, x_alt, xn, B, N, K, D, cfg->ln_eps, s));
+      float* t = x; x = x_alt; x_alt = t;
+      Nn = K + 1 + (fuse ? 1 : 0);
+    } else {
+      TR_TRY(tr_layernorm_bf16(x, D, bw->ln2_g, bw->ln2_b, xn, M, D, cfg->ln_eps, s));
+    }
+    N = Nn;
+    const int M2 = B * N;
+    // x += fc2(gelu(fc1(norm2(x))))
+    TR_TRY(tr_gemm_bf16(xn, bw->fc1_w, bw->fc1_b, hbuf, nullptr, 0, M2, p.Hd, D, TR_EPI_GELU_BF16, s));
+    TR_TRY(tr_gemm_bf16(hbuf, bw->fc2_w, bw->fc2_b, x, nullptr, 0, M2, D, p.Hd, TR_EPI_RESID_F32, s));
+    if (tokens_out) tokens_out[i] = N;
+  }
+  // a5: norm on the CLS rows only (LayerNorm is per-row), then the classifier
+  TR_TRY(tr_layernorm_bf16(x, (long)N * D, w->norm_g, w->norm_b, xcls, B, D, cfg->ln_eps, s));
+  TR_TRY(tr_gemm_bf16(xcls, w->head_w, w->head_b, logits, nullptr, 0, B, p.C, D, TR_EPI_F32, s));
+  return TR_OK;
+}

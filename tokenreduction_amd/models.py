@@ -1,0 +1,331 @@
+"""Host-side mirror of the reference's model classes for the hot path.
+
+Same constructor signature, attribute names, state-dict keys, helper methods and forward return
+contract as
+    models/deit_viz.py:75-212   VisionTransformer            (timm-0.4.12 ViT, the DeiT trunk)
+    models/topk.py:102-212      TopKVisionTransformer
+    models/evit.py:132-244      EfficientVisionTransformer
+so a `train.py` / `validate.py`-style driver can swap `timm.models.create_model` for
+`tokenreduction_amd.create_model` unchanged.  The nn.Modules below only HOLD parameters (so
+load_state_dict / state_dict / optimizers see the reference's key names); `forward` never calls
+them: it hands the image batch to the gfx950 executor (csrc/tr_vit.hip) through the C ABI.
+
+There is no CPU path: forward() on a CPU tensor raises.  Training (autograd through the HIP
+kernels) is not built yet and raises NotImplementedError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from functools import partial
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def _pair(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+
+class PatchEmbed(nn.Module):
+    """Parameter holder with timm PatchEmbed's attribute surface (num_patches, grid_size, proj)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768):
+        super().__init__()
+        self.img_size, self.patch_size = _pair(img_size), _pair(patch_size)
+        self.grid_size = (self.img_size[0] // self.patch_size[0], self.img_size[1] // self.patch_size[1])
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.patch_size)
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc2 = nn.Linear(hidden_features, in_features)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, num_heads, qkv_bias=True, keep_rate=1.0):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        self.keep_rate = keep_rate
+        self.init_n = 14 * 14   # topk.py:40 -- hard-coded in the reference, independent of img_size
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=True, norm_layer=nn.LayerNorm, keep_rate=1.0):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads, qkv_bias, keep_rate)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+
+
+def _init_vit_weights(m: nn.Module):
+    """deit_viz.py:215-247 with name='' / jax_impl=False (what `self.apply(self._init_weights)` does)."""
+    if isinstance(m, nn.Linear):
+        nn.init.trunc_normal_(m.weight, std=0.02)
+        if m.bias is not None:
+            nn.init.zeros_(m.bias)
+    elif isinstance(m, nn.LayerNorm):
+        nn.init.zeros_(m.bias)
+        nn.init.ones_(m.weight)
+
+
+class VisionTransformer(nn.Module):
+    """DeiT trunk, no reduction (deit_viz.py:75-212); also the base class of the reduction models."""
+
+    _family = _lib.TR_FAMILY_DEIT
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4., qkv_bias=True, representation_size=None, distilled=False,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0., embed_layer=None, norm_layer=None,
+                 act_layer=None, weight_init='', args=None):
+        super().__init__()
+        if distilled:
+            # the reference's reduction forwards only ever concatenate cls_token
+            raise NotImplementedError("distilled (dist_token) models are not on the hot path")
+        if representation_size:
+            raise NotImplementedError("representation_size / pre_logits is not used by any registered factory")
+        if not qkv_bias:
+            raise NotImplementedError("every registered factory uses qkv_bias=True")
+        if act_layer not in (None, nn.GELU):
+            raise NotImplementedError("only nn.GELU (erf) is implemented in the fc1 epilogue")
+        if embed_dim != 64 * num_heads:
+            raise ValueError("head_dim must be 64 (192/3, 384/6, 768/12 in models_act.py)")
+        self.num_classes = num_classes
+        self.num_features = self.embed_dim = embed_dim
+        self.num_tokens = 1
+        self.depth = depth
+        self.num_heads = num_heads
+        self.drop_rate, self.attn_drop_rate, self.drop_path_rate = drop_rate, attn_drop_rate, drop_path_rate
+        norm_layer = norm_layer or partial(nn.LayerNorm, eps=1e-6)
+        self.patch_embed = PatchEmbed(img_size, patch_size, in_chans, embed_dim)
+        num_patches = self.patch_embed.num_patches
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.dist_token = None
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + self.num_tokens, embed_dim))
+        self.mlp_ratio, self.qkv_bias, self._norm_layer = mlp_ratio, qkv_bias, norm_layer
+        self.blocks = nn.ModuleList([Block(embed_dim, num_heads, mlp_ratio, qkv_bias, norm_layer) for _ in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.pre_logits = nn.Identity()
+        self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+        self.viz_mode = getattr(args, 'viz_mode', False)
+        self._keep = [0] * depth
+        self._packed = None
+        self._ws = {}
+        nn.init.trunc_normal_(self.pos_embed, std=.02)
+        nn.init.trunc_normal_(self.cls_token, std=.02)
+        self.apply(_init_vit_weights)
+
+    # ---- reference helper surface -------------------------------------------------------------
+    def _init_weights(self, m):
+        _init_vit_weights(m)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'pos_embed', 'cls_token', 'dist_token'}
+
+    def get_classifier(self):
+        return self.head
+
+    def reset_classifier(self, num_classes, global_pool=''):
+        self.num_classes = num_classes
+        dev = self.pos_embed.device
+        self.head = (nn.Linear(self.embed_dim, num_classes) if num_classes > 0 else nn.Identity()).to(dev)
+        self._packed = None
+
+    def get_new_module_names(self):
+        return []
+
+    def get_reduction_count(self):
+        return getattr(self, "pruning_loc", [])
+
+    # ---- packing: bf16 weight copies + the C structs ------------------------------------------------
+    def _param_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def _pack(self):
+        key = self._param_key()
+        if self._packed is not None and self._packed["key"] == key:
+            return self._packed
+        dev = self.pos_embed.device
+        if dev.type != "cuda":
+            raise RuntimeError(f"model is on {dev}: tokenreduction_amd runs on MI355X only (no CPU path); call .cuda()")
+        if not isinstance(self.head, nn.Linear):
+            raise NotImplementedError("num_classes == 0 (headless) is not supported by the executor")
+        keep_alive = []
+
+        def w16(t):
+            c = t.detach().to(torch.bfloat16).contiguous()
+            keep_alive.append(c)
+            return c.data_ptr()
+
+        def f32(t):
+            c = t.detach().to(torch.float32).contiguous()
+            keep_alive.append(c)
+            return c.data_ptr()
+
+        W = _lib.TrVitWeights()
+        D = self.embed_dim
+        W.patch_w = w16(self.patch_embed.proj.weight.reshape(D, -1))
+        W.patch_b = f32(self.patch_embed.proj.bias)
+        W.cls_token = f32(self.cls_token.reshape(-1))
+        W.pos_embed = f32(self.pos_embed.reshape(-1, D))
+        W.norm_g, W.norm_b = f32(self.norm.weight), f32(self.norm.bias)
+        W.head_w, W.head_b = w16(self.head.weight), f32(self.head.bias)
+        for i, blk in enumerate(self.blocks):
+            b = W.blocks[i]
+            b.ln1_g, b.ln1_b = f32(blk.norm1.weight), f32(blk.norm1.bias)
+            b.qkv_w, b.qkv_b = w16(blk.attn.qkv.weight), f32(blk.attn.qkv.bias)
+            b.proj_w, b.proj_b = w16(blk.attn.proj.weight), f32(blk.attn.proj.bias)
+            b.ln2_g, b.ln2_b = f32(blk.norm2.weight), f32(blk.norm2.bias)
+            b.fc1_w, b.fc1_b = w16(blk.mlp.fc1.weight), f32(blk.mlp.fc1.bias)
+            b.fc2_w, b.fc2_b = w16(blk.mlp.fc2.weight), f32(blk.mlp.fc2.bias)
+        cfg = _lib.TrVitConfig()
+        cfg.family = self._family
+        cfg.img_size, cfg.patch = self.patch_embed.img_size[0], self.patch_embed.patch_size[0]
+        cfg.in_chans = self.patch_embed.proj.in_channels
+        cfg.embed_dim, cfg.depth, cfg.num_heads = D, self.depth, self.num_heads
+        cfg.mlp_hidden = self.blocks[0].mlp.fc1.out_features
+        cfg.num_classes = self.num_classes
+        cfg.ln_eps = float(self.norm.eps)
+        for i in range(self.depth):
+            cfg.keep[i] = int(self._keep[i])
+        self._packed = dict(key=key, W=W, cfg=cfg, keep_alive=keep_alive)
+        self._ws = {}
+        return self._packed
+
+    def _workspace(self, B, dev):
+        ws = self._ws.get(B)
+        if ws is None:
+            pk = self._packed
+            nbytes = _lib.load().tr_vit_workspace_bytes(C.byref(pk["cfg"]), B)
+            if nbytes == 0:
+                raise RuntimeError("tr_vit_workspace_bytes rejected the model configuration (dims must be multiples of 64, "
+                                   "classes of 4, head_dim 64)")
+            P = self.patch_embed.num_patches
+            ws = dict(buf=torch.empty(nbytes, dtype=torch.uint8, device=dev), nbytes=nbytes,
+                      kept=torch.empty(self.depth * B * P, dtype=torch.int32, device=dev),
+                      compl=torch.empty(self.depth * B * P, dtype=torch.int32, device=dev))
+            self._ws = {B: ws}   # keep one batch size resident
+        return ws
+
+    # ---- forward ------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor):
+        if self.training:
+            raise NotImplementedError("training through the HIP kernels is not built yet (inference/eval path only); "
+                                      "call model.eval()")
+        if not x.is_cuda:
+            raise RuntimeError(f"input is on {x.device}: tokenreduction_amd has no CPU path (HIP kernels only)")
+        lib = _lib.load()
+        pk = self._pack()
+        cfg = pk["cfg"]
+        B, Cc, Hh, Ww = x.shape
+        if (Cc, Hh, Ww) != (cfg.in_chans, cfg.img_size, cfg.img_size):
+            raise ValueError(f"expected [B,{cfg.in_chans},{cfg.img_size},{cfg.img_size}], got {tuple(x.shape)}")
+        x = x.detach().to(torch.float32).contiguous()
+        ws = self._workspace(B, x.device)
+        logits = torch.empty(B, self.num_classes, dtype=torch.float32, device=x.device)
+        tokens = (C.c_int * self.depth)()
+        with torch.cuda.device(x.device):
+            rc = lib.tr_vit_forward(C.byref(cfg), C.byref(pk["W"]), x.data_ptr(), logits.data_ptr(), ws["buf"].data_ptr(),
+                                    ws["nbytes"], ws["kept"].data_ptr(), ws["compl"].data_ptr(), tokens, B,
+                                    torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "tr_vit_forward")
+        self._last_tokens = list(tokens)
+        if self.viz_mode:
+            return logits, self._viz_data(ws, B, list(tokens))
+        return logits
+
+    def _viz_data(self, ws, B, tokens):
+        return {"Features": {}}
+
+    def _stage_indices(self, ws, B, tokens):
+        """Per reduction block: (blk, N_in, K) from the static per-stage shapes."""
+        P = self.patch_embed.num_patches
+        out = []
+        n_in = P + 1
+        for i in range(self.depth):
+            K = self._keep[i]
+            if K and K != n_in - 1:
+                out.append((i, n_in, K))
+            n_in = tokens[i]
+        return out
+
+
+class _TopKBase(VisionTransformer):
+    """Shared ctor logic of topk.py:108-171 / evit.py:138-201."""
+
+    def __init__(self, *a, args=None, dyvit_distillation=False, **kw):
+        super().__init__(*a, args=args, **kw)
+        token_ratio = list(args.keep_rate)
+        pruning_loc = list(args.reduction_loc)
+        if len(token_ratio) == 1:
+            token_ratio = [token_ratio[0] ** (idx + 1) for idx in range(len(pruning_loc))]   # topk.py:141-142
+        assert len(token_ratio) == len(pruning_loc), \
+            f"Mismatch between the pruning location ({pruning_loc}) and token ratios ({token_ratio})"
+        self.num_patches = self.patch_embed.num_patches
+        self.deit_distillation = False
+        self.pruning_loc = pruning_loc
+        self.token_ratio = token_ratio
+        for r, loc in zip(token_ratio, pruning_loc):
+            assert 0 < r <= 1, "keep_rate must > 0 and <= 1, got {0}".format(r)   # topk.py:39
+            self.blocks[loc].attn.keep_rate = r
+            self._keep[loc] = int(r * 196) if r < 1 else 0     # topk.py:56 (196 hard-coded)
+        self._check_static_shapes()
+
+    def _check_static_shapes(self):
+        n = self.num_patches + 1
+        for i in range(self.depth):
+            K = self._keep[i]
+            if K and K != n - 1:
+                if not 1 <= K < n - 1:
+                    raise ValueError(f"block {i}: cannot keep {K} of {n - 1} patch tokens")
+                n = self._tokens_after(K)
+
+    def get_reduction_count(self):
+        return self.pruning_loc
+
+
+class TopKVisionTransformer(_TopKBase):
+    """models/topk.py:102-212."""
+    _family = _lib.TR_FAMILY_TOPK
+
+    def _tokens_after(self, K):
+        return K + 1
+
+    def _viz_data(self, ws, B, tokens):
+        P = self.patch_embed.num_patches
+        kept = ws["kept"].cpu().numpy()
+        decisions = {}
+        for blk, n_in, K in self._stage_indices(ws, B, tokens):
+            decisions[blk] = kept[blk * B * P: blk * B * P + B * K].reshape(B, K).astype(np.int64)
+        return {"Kept_Tokens": decisions, "Features": {}}
+
+
+class EfficientVisionTransformer(_TopKBase):
+    """models/evit.py:132-244."""
+    _family = _lib.TR_FAMILY_EVIT
+
+    def _tokens_after(self, K):
+        return K + 2
+
+    def _viz_data(self, ws, B, tokens):
+        P = self.patch_embed.num_patches
+        kept = ws["kept"].cpu().numpy()
+        compl = ws["compl"].cpu().numpy()
+        decisions, fusion = {}, {}
+        for blk, n_in, K in self._stage_indices(ws, B, tokens):
+            idx = kept[blk * B * P: blk * B * P + B * K].reshape(B, K).astype(np.int64)
+            decisions[blk] = np.concatenate([idx, -np.ones((B, 1), dtype=np.int64)], axis=1)   # evit.py:123
+            nc = n_in - 1 - K
+            fusion[blk] = compl[blk * B * P: blk * B * P + B * nc].reshape(B, nc).astype(np.int64)
+        return {"Kept_Tokens": decisions, "Fusion_Assign": fusion, "Features": {}}

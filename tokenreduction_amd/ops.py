@@ -1,0 +1,114 @@
+"""Thin tensor-level wrappers over the C ABI (one per SURVEY.md section 8a row group).
+
+PyTorch is plumbing here: it owns device memory and the stream; every byte of arithmetic happens
+in the hand-written gfx950 kernels behind include/tokenreduction_hip.h.  All tensors must live
+on a ROCm device -- there is no CPU path.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import (TR_EPI_BF16, TR_EPI_F32, TR_EPI_GELU_BF16, TR_EPI_PATCH_F32,  # noqa: F401
+                   TR_EPI_RESID_F32)
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, dtype, name: str) -> int:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: tensor is on {t.device}; tokenreduction_amd has no CPU path (HIP kernels only)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def _opt(t, dtype, name):
+    return None if t is None else _dev(t, dtype, name)
+
+
+def im2col(img: torch.Tensor, patch: int) -> torch.Tensor:
+    """PatchEmbed unfold (topk.py:181): fp32 [B,C,H,W] -> bf16 [B*P, C*p*p]."""
+    B, Cc, H, W = img.shape
+    cols = torch.empty(B * (H // patch) * (W // patch), Cc * patch * patch, dtype=torch.bfloat16, device=img.device)
+    _lib.check(_lib.load().tr_im2col_bf16(_dev(img, torch.float32, "img"), cols.data_ptr(), B, Cc, H, W, patch, _stream()),
+               "tr_im2col_bf16")
+    return cols
+
+
+def cls_pos_rows(cls_token, pos_embed, x, B, N, D):
+    _lib.check(_lib.load().tr_cls_pos_rows(_dev(cls_token, torch.float32, "cls_token"), _dev(pos_embed, torch.float32, "pos_embed"),
+                                           _dev(x, torch.float32, "x"), B, N, D, _stream()), "tr_cls_pos_rows")
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, epilogue: int, out: torch.Tensor = None,
+         aux: torch.Tensor = None, aux_i: int = 0) -> torch.Tensor:
+    """nn.Linear on MFMA: epilogue(a[M,K] @ w[N,K]^T + bias).  For RESID/PATCH `out` is required (updated in place)."""
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        if epilogue in (TR_EPI_BF16, TR_EPI_GELU_BF16):
+            out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+        elif epilogue == TR_EPI_F32:
+            out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+        else:
+            raise ValueError("this epilogue needs an explicit `out`")
+    odt = torch.bfloat16 if epilogue in (TR_EPI_BF16, TR_EPI_GELU_BF16) else torch.float32
+    _lib.check(_lib.load().tr_gemm_bf16(_dev(a, torch.bfloat16, "a"), _dev(w, torch.bfloat16, "w"), _dev(bias, torch.float32, "bias"),
+                                        _dev(out, odt, "out"), _opt(aux, torch.float32, "aux"), aux_i, M, N, K, epilogue, _stream()),
+               "tr_gemm_bf16")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma, beta, eps: float, rows: int = None, ldx: int = None) -> torch.Tensor:
+    """nn.LayerNorm over the last dim of a fp32 [M,D] tensor -> bf16 [M,D] (optionally `rows` rows at stride ldx)."""
+    D = x.shape[-1]
+    M = rows if rows is not None else x.numel() // D
+    ld = ldx if ldx is not None else D
+    y = torch.empty(M, D, dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.load().tr_layernorm_bf16(_dev(x, torch.float32, "x"), ld, _dev(gamma, torch.float32, "gamma"),
+                                             _dev(beta, torch.float32, "beta"), y.data_ptr(), M, D, eps, _stream()),
+               "tr_layernorm_bf16")
+    return y
+
+
+def attention(qkv: torch.Tensor, B: int, N: int, H: int, want_cls: bool = False):
+    """softmax(q k^T / 8) v per (image, head) (topk.py:44-51).  qkv bf16 [B*N, 3*H*64] -> (out bf16 [B*N, H*64], cls_rows|None)."""
+    out = torch.empty(B * N, H * 64, dtype=torch.bfloat16, device=qkv.device)
+    cls_rows = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device) if want_cls else None
+    _lib.check(_lib.load().tr_attention_bf16(_dev(qkv, torch.bfloat16, "qkv"), out.data_ptr(),
+                                             None if cls_rows is None else cls_rows.data_ptr(), B, N, H, _stream()),
+               "tr_attention_bf16")
+    return out, cls_rows
+
+
+def cls_topk(cls_rows: torch.Tensor, K: int, want_compl: bool = False):
+    """Top-K over head-mean CLS attention (topk.py:59-61) -> (idx int32 [B,K], compl int32 [B,P-K]|None, scores fp32 [B,P])."""
+    B, H, N = cls_rows.shape
+    P = N - 1
+    idx = torch.empty(B, K, dtype=torch.int32, device=cls_rows.device)
+    compl = torch.empty(B, P - K, dtype=torch.int32, device=cls_rows.device) if want_compl else None
+    scores = torch.empty(B, P, dtype=torch.float32, device=cls_rows.device)
+    _lib.check(_lib.load().tr_cls_topk(_dev(cls_rows, torch.float32, "cls_rows"), idx.data_ptr(),
+                                       None if compl is None else compl.data_ptr(), scores.data_ptr(), B, H, N, K, _stream()),
+               "tr_cls_topk")
+    return idx, compl, scores
+
+
+def gather_layernorm(x: torch.Tensor, idx, compl, scores, gamma, beta, eps: float):
+    """Top-K gather/compact (topk.py:89-93) [+ EViT fused token evit.py:111-123] fused with norm2.
+    x fp32 [B,N,D] -> (x_out fp32 [B,N_out,D], y bf16 [B,N_out,D])."""
+    B, N, D = x.shape
+    K = idx.shape[1]
+    N_out = K + 1 + (1 if compl is not None else 0)
+    x_out = torch.empty(B, N_out, D, dtype=torch.float32, device=x.device)
+    y = torch.empty(B, N_out, D, dtype=torch.bfloat16, device=x.device)
+    _lib.check(_lib.load().tr_gather_layernorm_bf16(
+        _dev(x, torch.float32, "x"), _dev(idx, torch.int32, "idx"), _opt(compl, torch.int32, "compl"),
+        _opt(scores, torch.float32, "scores"), _dev(gamma, torch.float32, "gamma"), _dev(beta, torch.float32, "beta"),
+        x_out.data_ptr(), y.data_ptr(), B, N, K, D, eps, _stream()), "tr_gather_layernorm_bf16")
+    return x_out, y

@@ -1,0 +1,118 @@
+"""Kernel-by-kernel forward through the per-op C-ABI entry points.
+
+Same launch sequence as the native executor (csrc/tr_vit.hip -> tr_vit_forward), but driven from Python
+so a caller can (a) time every launch with events on the launch stream (bench.py roofline leg) and
+(b) look at every intermediate (parity tests: op-boundary checks against the oracle).
+HIP kernels only -- no CPU path.  Results are bit-identical to tr_vit_forward (same kernels, same order).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import ops
+from .models import VisionTransformer
+
+
+class Trace:
+    """Collects (kernel name, flops, bytes, elapsed_ms) per launch when timing is enabled, and named intermediates."""
+
+    def __init__(self, timing: bool = False, keep: bool = False):
+        self.timing, self.keep = timing, keep
+        self.launches: List[dict] = []
+        self.tensors: Dict[str, torch.Tensor] = {}
+        self._pending = []
+
+    def run(self, name: str, flops: float, nbytes: float, fn: Callable):
+        if not self.timing:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self._pending.append((name, flops, nbytes, e0, e1))
+        return out
+
+    def finish(self):
+        torch.cuda.synchronize()
+        for name, flops, nbytes, e0, e1 in self._pending:
+            self.launches.append(dict(kernel=name, flops=flops, bytes=nbytes, ms=e0.elapsed_time(e1)))
+        self._pending = []
+
+    def save(self, name: str, t: torch.Tensor):
+        if self.keep:
+            self.tensors[name] = t.clone()
+
+
+_EPI_NAME = {ops.TR_EPI_BF16: "gemm_bf16_kernel<EPI_BF16>", ops.TR_EPI_GELU_BF16: "gemm_bf16_kernel<EPI_GELU_BF16>",
+             ops.TR_EPI_RESID_F32: "gemm_bf16_kernel<EPI_RESID_F32>", ops.TR_EPI_F32: "gemm_bf16_kernel<EPI_F32>",
+             ops.TR_EPI_PATCH_F32: "gemm_bf16_kernel<EPI_PATCH_F32>"}
+
+
+def _gemm(tr: Trace, a, w, b, epi, out=None, aux=None, aux_i=0):
+    M, K = a.shape
+    N = w.shape[0]
+    obytes = 2 if epi in (ops.TR_EPI_BF16, ops.TR_EPI_GELU_BF16) else (8 if epi == ops.TR_EPI_RESID_F32 else 4)
+    nbytes = 2.0 * M * K + 2.0 * N * K + float(obytes) * M * N
+    return tr.run(_EPI_NAME[epi], 2.0 * M * N * K, nbytes, lambda: ops.gemm(a, w, b, epi, out=out, aux=aux, aux_i=aux_i))
+
+
+@torch.no_grad()
+def forward_stepwise(model: VisionTransformer, x: torch.Tensor, trace: Optional[Trace] = None):
+    """Returns (logits, info) with info = dict(kept={blk: idx}, compl={blk: compl}, scores={blk: scores}, tokens=[...])."""
+    tr = trace or Trace()
+    pk = model._pack()
+    cfg = pk["cfg"]
+    B = x.shape[0]
+    D, H, P = cfg.embed_dim, cfg.num_heads, model.patch_embed.num_patches
+    N = P + 1
+    dev = x.device
+    bf = lambda t: t.detach().to(torch.bfloat16).contiguous()
+    f32 = lambda t: t.detach().to(torch.float32).contiguous()
+    x = f32(x)
+    cols = tr.run("im2col_kernel", 0.0, 4.0 * x.numel() + 2.0 * x.numel(), lambda: ops.im2col(x, cfg.patch))
+    h = torch.empty(B * N, D, dtype=torch.float32, device=dev)
+    pos = f32(model.pos_embed.reshape(-1, D))
+    _gemm(tr, cols, bf(model.patch_embed.proj.weight.reshape(D, -1)), f32(model.patch_embed.proj.bias), ops.TR_EPI_PATCH_F32,
+          out=h, aux=pos, aux_i=P)
+    tr.run("cls_pos_kernel", 0.0, 12.0 * B * D, lambda: ops.cls_pos_rows(f32(model.cls_token.reshape(-1)), pos, h, B, N, D))
+    tr.save("embed", h.view(B, N, D))
+    info = dict(kept={}, compl={}, scores={}, tokens=[])
+    eps = float(model.norm.eps)
+    fuse = cfg.family == 2
+    for i, blk in enumerate(model.blocks):
+        K = 0 if cfg.family == 0 else int(cfg.keep[i])
+        if K == N - 1:
+            K = 0
+        M = B * N
+        xn = tr.run("layernorm_kernel", 0.0, 6.0 * M * D, lambda: ops.layernorm(h, f32(blk.norm1.weight), f32(blk.norm1.bias), eps))
+        qkv = _gemm(tr, xn, bf(blk.attn.qkv.weight), f32(blk.attn.qkv.bias), ops.TR_EPI_BF16)
+        ao, cls_rows = tr.run("attention_kernel", 4.0 * B * H * N * N * 64, 2.0 * M * 4 * D,
+                              lambda: ops.attention(qkv, B, N, H, want_cls=K > 0))
+        tr.save(f"attn_out_{i}", ao)
+        _gemm(tr, ao, bf(blk.attn.proj.weight), f32(blk.attn.proj.bias), ops.TR_EPI_RESID_F32, out=h)
+        if K > 0:
+            idx, compl, scores = tr.run("cls_topk_kernel", 0.0, 4.0 * B * (H * N + N),
+                                        lambda: ops.cls_topk(cls_rows, K, want_compl=fuse))
+            info["kept"][i], info["compl"][i], info["scores"][i] = idx, compl, scores
+            tr.save(f"pre_gather_{i}", h.view(B, N, D))
+            Nn = K + 1 + (1 if fuse else 0)
+            h3, xn = tr.run("gather_layernorm_kernel", 0.0, 10.0 * B * Nn * D,
+                            lambda: ops.gather_layernorm(h.view(B, N, D), idx, compl, scores if fuse else None,
+                                                         f32(blk.norm2.weight), f32(blk.norm2.bias), eps))
+            h = h3.view(B * Nn, D)
+            xn = xn.view(B * Nn, D)
+            N = Nn
+        else:
+            xn = tr.run("layernorm_kernel", 0.0, 6.0 * M * D, lambda: ops.layernorm(h, f32(blk.norm2.weight), f32(blk.norm2.bias), eps))
+        hid = _gemm(tr, xn, bf(blk.mlp.fc1.weight), f32(blk.mlp.fc1.bias), ops.TR_EPI_GELU_BF16)
+        _gemm(tr, hid, bf(blk.mlp.fc2.weight), f32(blk.mlp.fc2.bias), ops.TR_EPI_RESID_F32, out=h)
+        info["tokens"].append(N)
+        tr.save(f"block_{i}", h.view(B, N, D))
+    xc = tr.run("layernorm_kernel", 0.0, 6.0 * B * D,
+                lambda: ops.layernorm(h, f32(model.norm.weight), f32(model.norm.bias), eps, rows=B, ldx=N * D))
+    logits = _gemm(tr, xc, bf(model.head.weight), f32(model.head.bias), ops.TR_EPI_F32)
+    if tr.timing:
+        tr.finish()
+    return logits, info
