@@ -123,40 +123,57 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t* __res
 
 #undef GLOAD
 #undef LSTORE
-  // ---- epilogue: lane holds D[n = 4*fq + r][m = frow] of each 16x16 tile -> 4 consecutive output columns
+  // ---- epilogue: lane holds D[n = 4*fq + r][m = frow] of each 16x16 tile -> 4 consecutive output columns.
+  // All loads (bias, residual / pos_embed) are issued UNCONDITIONALLY from clamped addresses before any use, so the
+  // 16 read-modify-write groups overlap instead of paying one dependent HBM round trip each; stores are predicated.
+  float4 bv[4];
+  int ncol[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    ncol[i] = n0 + wn * 64 + i * 16 + 4 * fq;
+    bv[i] = *reinterpret_cast<const float4*>(bias + min(ncol[i], N - 4));
+  }
+  size_t orow[4];
+  float4 rv[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int mc = min(m0 + wm * 64 + j * 16 + frow, M - 1);
+    orow[j] = (size_t)mc;
+    const float* posrow = nullptr;
+    if (EPI == TR_EPI_PATCH_F32) {
+      const int b = mc / aux_i, p = mc - b * aux_i;
+      orow[j] = (size_t)b * (aux_i + 1) + 1 + p;
+      posrow = aux + (size_t)(1 + p) * N;
+    }
+    if (EPI == TR_EPI_RESID_F32 || EPI == TR_EPI_PATCH_F32) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int nc = min(ncol[i], N - 4);
+        rv[j][i] = (EPI == TR_EPI_RESID_F32)
+                       ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(outp) + orow[j] * N + nc)
+                       : *reinterpret_cast<const float4*>(posrow + nc);
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int m = m0 + wm * 64 + j * 16 + frow;
-    if (m >= M) continue;
-    size_t orow = (size_t)m;
-    const float* posrow = nullptr;
-    if (EPI == TR_EPI_PATCH_F32) {
-      const int b = m / aux_i, p = m - b * aux_i;
-      orow = (size_t)b * (aux_i + 1) + 1 + p;
-      posrow = aux + (size_t)(1 + p) * N;
-    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int n = n0 + wn * 64 + i * 16 + 4 * fq;
-      if (n >= N) continue;
-      const float4 bv = *reinterpret_cast<const float4*>(bias + n);
-      float v0 = acc[i][j][0] + bv.x, v1 = acc[i][j][1] + bv.y, v2 = acc[i][j][2] + bv.z, v3 = acc[i][j][3] + bv.w;
+      const int n = ncol[i];
+      float v0 = acc[i][j][0] + bv[i].x, v1 = acc[i][j][1] + bv[i].y, v2 = acc[i][j][2] + bv[i].z, v3 = acc[i][j][3] + bv[i].w;
+      const bool ok = (m < M) && (n < N);
       if (EPI == TR_EPI_BF16 || EPI == TR_EPI_GELU_BF16) {
         if (EPI == TR_EPI_GELU_BF16) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
         uint2 pk;
         pk.x = pack_bf16x2(v0, v1);
         pk.y = pack_bf16x2(v2, v3);
-        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(outp) + orow * N + n) = pk;
+        if (ok) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(outp) + orow[j] * N + n) = pk;
       } else {
-        float* o = reinterpret_cast<float*>(outp) + orow * N + n;
-        if (EPI == TR_EPI_RESID_F32) {
-          const float4 r = *reinterpret_cast<const float4*>(o);
-          v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
-        } else if (EPI == TR_EPI_PATCH_F32) {
-          const float4 r = *reinterpret_cast<const float4*>(posrow + n);
-          v0 += r.x; v1 += r.y; v2 += r.z; v3 += r.w;
+        if (EPI == TR_EPI_RESID_F32 || EPI == TR_EPI_PATCH_F32) {
+          v0 += rv[j][i].x; v1 += rv[j][i].y; v2 += rv[j][i].z; v3 += rv[j][i].w;
         }
-        *reinterpret_cast<float4*>(o) = make_float4(v0, v1, v2, v3);
+        if (ok) *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + orow[j] * N + n) = make_float4(v0, v1, v2, v3);
       }
     }
   }
