@@ -49,9 +49,16 @@ def assert_close_bf16(got, want, what, ulps=1.0, abs_floor=1e-5):
 
 # ------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 1152, 384), (197 * 3, 384, 1536), (256, 1000, 384), (5, 16, 128),
-                                   (1000, 1536, 384)])
+                                   (1000, 1536, 384), (70000, 384, 384), (513, 192, 192), (50432, 384, 128), (1, 64, 64)])
 @pytest.mark.parametrize("epi", ["bf16", "gelu", "resid", "f32"])
 def test_gemm(ops, M, N, K, epi):
+    if epi == "resid" and N % 64:
+        # the in-place residual epilogue is only ever used with N = embed_dim (a multiple of 64); the C ABI rejects others
+        a = torch.zeros(M, K, dtype=torch.bfloat16, device="cuda")
+        w = torch.zeros(N, K, dtype=torch.bfloat16, device="cuda")
+        with pytest.raises(RuntimeError, match="N % 64"):
+            ops.gemm(a, w, torch.zeros(N, device="cuda"), ops.TR_EPI_RESID_F32, out=torch.zeros(M, N, device="cuda"))
+        return
     rng = _rng(M * 7 + N * 3 + K)
     a, w, b = _bf(_randn(rng, M, K)), _bf(_randn(rng, N, K, scale=0.05)), _randn(rng, N, scale=0.1)
     ref = a.double() @ w.double().t() + b.double()

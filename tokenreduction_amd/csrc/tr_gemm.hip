@@ -5,85 +5,238 @@
 //   mlp.fc1  timm Mlp + GELU (TR_EPI_GELU_BF16)    mlp.fc2  + residual topk.py:95     (TR_EPI_RESID_F32)
 //   head     topk.py:203    (TR_EPI_F32)           patch_embed.proj topk.py:181-186   (TR_EPI_PATCH_F32)
 //
-// Design (cdna_hip_programming.md section 5): 128x128x64 tile, 256 threads = 4 waves (2x2), each wave 64x64 as 4x4
-// v_mfma_f32_16x16x32_bf16.  Both operands are K-contiguous (nn.Linear stores W as [N,K]), so both fragments
-// are plain 16-byte LDS reads.  W is the MFMA "A" operand and the activation the "B" operand: the accumulator
-// then holds 4 CONSECUTIVE output columns per lane -> 8/16-byte epilogue stores.  LDS rows are 128 B with the
-// 16-byte chunk index XOR-swizzled by (row>>1)&7: conflict-free for the ds_read_b128 lane groups and for the
-// ds_write_b128 staging (tools/lds_sim.py).  Register-staged double buffering, one barrier per K-step:
-// global loads of tile t+1 are issued before the MFMAs of tile t and written to LDS after them (T14).
-// Block ids are remapped so every XCD walks a contiguous run of tiles that share the activation rows (T1).
+// Structure (cdna_hip_programming.md section 5, "Pipelining across barriers", T1-T4):
+//   * ONE persistent 512-thread workgroup per CU walks a list of 256x128 output tiles; 8 waves as 4(M) x 2(N), each
+//     wave 64x64 = 4x4 v_mfma_f32_16x16x32_bf16.  W is the MFMA "A" operand and the activation the "B" operand, so a
+//     lane's accumulator holds 4 CONSECUTIVE output columns -> 8/16-byte epilogue stores.
+//   * Operands go global -> LDS by LDS-DMA (`global_load_lds_dwordx4`, no VGPR staging) into a 3-slot ring of 48-KiB
+//     K-steps (BK = 64; 144 KiB of the 160 KiB LDS).  Two K-steps (96 KiB) are always in flight behind a COUNTED
+//     `s_waitcnt vmcnt(N)`, one raw `s_barrier` per K-step, and the ring runs ACROSS tile boundaries (K is only 384
+//     for three of the four block GEMMs = 6 K-steps per tile, so a per-tile pipeline fill would dominate).
+//   * LDS rows are 128 B; the 16-byte chunk index is XOR-swizzled by (row>>1)&7 -- conflict-free ds_read_b128
+//     fragment reads (tools/lds_sim.py).  LDS-DMA writes lane-linearly, so the swizzle is applied to the per-lane
+//     SOURCE address and again on the read (guide rule 21).
+//   * vmcnt is one in-order counter for loads, stores and LDS-DMA on gfx950.  Everything that touches it in the K-loop
+//     is therefore hand-counted: the DMA and the epilogue's bias/residual loads are inline asm (invisible to hipcc's
+//     own waitcnt insertion, which would otherwise drain the ring with vmcnt(0) once per tile), the loads are issued
+//     BEFORE the next K-step's DMA so waiting for them leaves that DMA in flight, and the 16 epilogue stores per lane
+//     are branch-free buffer stores (out-of-range lanes are dropped by the descriptor's bounds check), so the number
+//     of stores younger than a DMA group is exact and can be added to the allowed count.
+//     Ablation history (what each change bought): profiles/r01_gemm_lab.md.
+//   * Tile order: tile(i) = i*G + (bid%8)*(G/8) + bid/8: the 32 workgroups that share an XCD (blocks b, b+8, ...) work
+//     on 32 consecutive tiles (n fastest) at a time, so an activation row panel is fetched into that XCD's L2 once.
 #include "tr_common.h"
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = 128 * BK * 2;  // 16 KiB per operand tile
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+constexpr int BK = 64;
+constexpr int PBM = 256, PBN = 128;
+constexpr int P_STAGE_BYTES = (PBM + PBN) * 128;  // 48 KiB: A rows then W rows, 128 B (64 bf16) per row
+constexpr int P_NSTAGE = 3;
+constexpr int DMA_PER_STEP = 6;                   // LDS-DMA pieces per wave and K-step: 4 of A, 2 of W
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-__device__ __forceinline__ float gelu_erf(float x) {
-  // 0.5 x (1 + erf(x/sqrt2)); erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below bf16 resolution)
-  const float z = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
-  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  const float e = 1.0f - poly * __expf(-z * z);
-  const float erfv = x < 0.0f ? -e : e;
-  return 0.5f * x * (1.0f + erfv);
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// GELU(x) = x * Phi(x) (the exact-erf form nn.GELU() computes) with Phi(x) ~= sigmoid(a1 x + a3 x^3 + a5 x^5), a minimax fit
+// over [-8, 8]: |gelu_fit - gelu_erf| <= 2.6e-5 absolute everywhere (tools/fit_gelu.py) -- 100x below the bf16 resolution of
+// the hidden activations it is rounded to.  9 VALU ops per element, written on float2 so hipcc emits v_pk_{mul,fma,add}_f32.
+// (The Abramowitz-Stegun erf used in the first version cost ~27 ops/element: in-kernel stamps showed the GELU epilogue at
+// ~8k cycles per 256x128 tile, as much as the tile's whole K-loop.)
+__device__ __forceinline__ f32x2 gelu2(f32x2 x) {
+  constexpr float L2E = 1.44269504088896340736f;
+  constexpr float C1 = -1.59501577f * L2E, C3 = -7.40112920e-02f * L2E, C5 = 7.03033576e-04f * L2E;
+  f32x2 xc;
+  xc[0] = __builtin_amdgcn_fmed3f(x[0], -8.0f, 8.0f);
+  xc[1] = __builtin_amdgcn_fmed3f(x[1], -8.0f, 8.0f);
+  const f32x2 x2 = xc * xc;
+  f32x2 p = x2 * C5 + C3;
+  p = p * x2 + C1;
+  const f32x2 z = p * xc;                               // -log2(e) * (a1 x + a3 x^3 + a5 x^5)
+  f32x2 e;
+  e[0] = __builtin_amdgcn_exp2f(z[0]);
+  e[1] = __builtin_amdgcn_exp2f(z[1]);
+  e = e + 1.0f;
+  f32x2 r;
+  r[0] = __builtin_amdgcn_rcpf(e[0]);
+  r[1] = __builtin_amdgcn_rcpf(e[1]);
+  return x * r;
 }
 
+// six 1-KiB LDS-DMA pieces per wave and K-step: 4 of A (rows w*32 + 8j .. +7), 2 of W (rows w*16 + 8j .. +7).
+// Source = scalar base + per-lane 32-bit byte offset (saddr form: half the address VGPRs of 64-bit pointers).
+// M0 carries the wave-uniform LDS destination; it is compiler-reserved, so it is saved and restored in the statement.
+__device__ __forceinline__ void issue_stage(const uint16_t* A, const uint16_t* W, unsigned oa0, unsigned oa1, unsigned oa2,
+                                            unsigned oa3, unsigned ow0, unsigned ow1, unsigned lds_a, unsigned lds_w) {
+#ifndef TR_ABLATE_NO_DMA
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %[keep], m0\n\t"
+      "s_mov_b32 m0, %[la]\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %[a0], %[A]\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %[a1], %[A]\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %[a2], %[A]\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %[a3], %[A]\n\t"
+      "s_mov_b32 m0, %[lw]\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %[w0], %[W]\n\t"
+      "s_add_u32 m0, m0, 0x400\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %[w1], %[W]\n\t"
+      "s_mov_b32 m0, %[keep]"
+      : [keep] "=&s"(keep)
+      : [a0] "v"(oa0), [a1] "v"(oa1), [a2] "v"(oa2), [a3] "v"(oa3), [w0] "v"(ow0), [w1] "v"(ow1), [A] "s"(A), [W] "s"(W),
+        [la] "s"(lds_a), [lw] "s"(lds_w)
+      : "memory", "scc");
+#endif
+}
+
+// one 1-KiB piece; used to spread a K-step's six pieces between its MFMA groups.  A wave issues in order, and the CU's
+// address path takes ~30 cycles per piece (48 pieces per K-step): issued back to back at the top of the step they
+// back-pressure every wave for about as long as the step's MFMAs take, so DMA and matrix work serialise
+// (profiles/r01_gemm_lab.md: 25.6 us DMA-only + 26.1 us MFMA-only = 49 us together on the qkv shape).
+__device__ __forceinline__ void issue_piece(const uint16_t* sbase, unsigned voff, unsigned lds_dst) {
+#ifndef TR_ABLATE_NO_DMA
+  // M0 is clobbered, not saved/restored (2 scalar instructions less per piece, 12 per K-step and wave): nothing else in this
+  // kernel uses M0 -- gfx9 LDS instructions do not read it -- and the bulk issue_stage() sets it itself.
+  asm volatile(
+      "s_mov_b32 m0, %[ld]\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %[o], %[b]"
+      :
+      : [o] "v"(voff), [b] "s"(sbase), [ld] "s"(lds_dst)
+      : "memory", "m0");
+#endif
+}
+
+// `n` is wave-uniform: DMA_PER_STEP + {0,1,2} * ST (ST = buffer stores per lane in one epilogue: 8 bf16 / 16 fp32)
+template <int ST>
+__device__ __forceinline__ void wait_vmcnt(int n) {
+  if (n == DMA_PER_STEP) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if (n == DMA_PER_STEP + ST) {
+    if (ST == 8) asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+  } else {
+    if (ST == 8) asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
+  }
+}
+
+// loads hipcc must not count (see header): the destination is valid only after the matching EPI_WAIT statement.
+__device__ __forceinline__ f32x4 asm_load16(const float* p) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+// scalar base + per-lane byte offset + immediate (one offset VGPR serves the four 64-byte-spaced column groups of a row)
+template <int IMM>
+__device__ __forceinline__ f32x4 asm_load16_so(const float* sbase, unsigned voff) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(sbase), "i"(IMM) : "memory");
+  return v;
+}
+
+#define EPI_WAIT_B(N, b) asm volatile("s_waitcnt vmcnt(" #N ")" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3])::"memory")
+#define EPI_WAIT_R(N, r)                                                                                                 \
+  asm volatile("s_waitcnt vmcnt(" #N ")"                                                                                 \
+               : "+v"(r[0][0]), "+v"(r[0][1]), "+v"(r[0][2]), "+v"(r[0][3]), "+v"(r[1][0]), "+v"(r[1][1]), "+v"(r[1][2]),  \
+                 "+v"(r[1][3]), "+v"(r[2][0]), "+v"(r[2][1]), "+v"(r[2][2]), "+v"(r[2][3]), "+v"(r[3][0]), "+v"(r[3][1]),  \
+                 "+v"(r[3][2]), "+v"(r[3][3])::"memory")
+
 template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
-                                                           const float* __restrict__ bias, void* __restrict__ outp,
-                                                           const float* __restrict__ aux, int aux_i, int M, int N, int K) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];  // [buf][A|W]
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+__global__ __launch_bounds__(512, 2) void gemm_bf16_persistent(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
+                                                               const float* __restrict__ bias, void* __restrict__ outp,
+                                                               const float* __restrict__ aux, int aux_i, int M, int N, int K,
+                                                               int nMt, int nNt, unsigned out_bytes) {
+  constexpr bool HAS_RV = (EPI == TR_EPI_RESID_F32 || EPI == TR_EPI_PATCH_F32);
+  constexpr bool OUT_BF16 = (EPI == TR_EPI_BF16 || EPI == TR_EPI_GELU_BF16);
+  constexpr int STORES_PER_TILE = OUT_BF16 ? 8 : 16;   // buffer stores per lane in one epilogue (all 16-byte, whole 128-B lines)
+  // 144 KiB ring + 8 x 2 KiB wave-private epilogue staging = the whole 160 KiB LDS
+  __shared__ __attribute__((aligned(16))) unsigned char smem[P_NSTAGE * P_STAGE_BYTES + 8 * 2048];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;          // 4 x 2 waves, 64 x 64 outputs each
+  const int frow = lane & 15, fq = lane >> 4;
+  const int nk = K / BK;
 
-  const int nNt = (N + BN - 1) / BN;
-  const int nMt = (M + BM - 1) / BM;
-  const int logical = xcd_remap(blockIdx.x, nMt * nNt);
-  const int m0 = (logical / nNt) * BM;
-  const int n0 = (logical % nNt) * BN;
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int T = nMt * nNt;
+  const int toff = (bid & 7) * (G >> 3) + (bid >> 3);
+  if (toff >= T) return;
+  const int my_tiles = (T - toff + G - 1) / G;
+  const int S = my_tiles * nk;                      // flattened K-steps of this workgroup
 
-  // ---- staging assignment: 4 chunks of A and 4 of W per thread per K-step (chunk g = tid + 256*i)
-  const int srow = tid >> 3, sc = tid & 7;
-  const uint16_t* a_src0 = A + (size_t)min(m0 + srow, M - 1) * K + sc * 8;
-  const uint16_t* a_src1 = A + (size_t)min(m0 + srow + 32, M - 1) * K + sc * 8;
-  const uint16_t* a_src2 = A + (size_t)min(m0 + srow + 64, M - 1) * K + sc * 8;
-  const uint16_t* a_src3 = A + (size_t)min(m0 + srow + 96, M - 1) * K + sc * 8;
-  const uint16_t* w_src0 = W + (size_t)min(n0 + srow, N - 1) * K + sc * 8;
-  const uint16_t* w_src1 = W + (size_t)min(n0 + srow + 32, N - 1) * K + sc * 8;
-  const uint16_t* w_src2 = W + (size_t)min(n0 + srow + 64, N - 1) * K + sc * 8;
-  const uint16_t* w_src3 = W + (size_t)min(n0 + srow + 96, N - 1) * K + sc * 8;
-  // rows srow+32*i keep (row>>1)&7 == (srow>>1)&7, so all four chunks share one swizzled offset + 32 rows * 128 B
-  const int lds_off0 = swz(srow, sc);
-  uint4 ra0, ra1, ra2, ra3, rw0, rw1, rw2, rw3;
-#define GLOAD(k0)                                              \
-  do {                                                         \
-    ra0 = *reinterpret_cast<const uint4*>(a_src0 + (k0));      \
-    ra1 = *reinterpret_cast<const uint4*>(a_src1 + (k0));      \
-    ra2 = *reinterpret_cast<const uint4*>(a_src2 + (k0));      \
-    ra3 = *reinterpret_cast<const uint4*>(a_src3 + (k0));      \
-    rw0 = *reinterpret_cast<const uint4*>(w_src0 + (k0));      \
-    rw1 = *reinterpret_cast<const uint4*>(w_src1 + (k0));      \
-    rw2 = *reinterpret_cast<const uint4*>(w_src2 + (k0));      \
-    rw3 = *reinterpret_cast<const uint4*>(w_src3 + (k0));      \
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned lds_a_w = lds0 + wave * 4096;              // this wave's A pieces inside a stage
+  const unsigned lds_w_w = lds0 + PBM * 128 + wave * 2048;  // this wave's W pieces
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(outp, 0, (int)out_bytes, 0x00020000);
+
+  // per-lane source mapping of one DMA piece (8 rows x 8 chunks): LDS position (row, chunk pc) must hold LOGICAL chunk
+  // pc ^ ((row>>1)&7)
+  const int l3 = lane >> 3, pc = lane & 7;
+  int ca[4], cw[2], ra[4], rw[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    ra[j] = wave * 32 + j * 8 + l3;
+    ca[j] = (pc ^ ((ra[j] >> 1) & 7)) * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    rw[j] = wave * 16 + j * 8 + l3;
+    cw[j] = (pc ^ ((rw[j] >> 1) & 7)) * 8;
+  }
+
+  // ---- load-side cursor (runs P_NSTAGE-1 K-steps ahead of the compute cursor)
+  int l_tile = toff, l_kt = 0, l_slot = 0, l_step = 0;
+  unsigned oa0, oa1, oa2, oa3, ow0, ow1;   // per-lane byte offsets into A / W of the next K-step to load
+#define SET_TILE_PTRS(tile)                                                   \
+  do {                                                                        \
+    const int tm0_ = ((tile) / nNt) * PBM, tn0_ = ((tile) % nNt) * PBN;       \
+    oa0 = ((unsigned)min(tm0_ + ra[0], M - 1) * K + ca[0]) * 2u;              \
+    oa1 = ((unsigned)min(tm0_ + ra[1], M - 1) * K + ca[1]) * 2u;              \
+    oa2 = ((unsigned)min(tm0_ + ra[2], M - 1) * K + ca[2]) * 2u;              \
+    oa3 = ((unsigned)min(tm0_ + ra[3], M - 1) * K + ca[3]) * 2u;              \
+    ow0 = ((unsigned)min(tn0_ + rw[0], N - 1) * K + cw[0]) * 2u;              \
+    ow1 = ((unsigned)min(tn0_ + rw[1], N - 1) * K + cw[1]) * 2u;              \
   } while (0)
-#define LSTORE(buf)                                                          \
-  do {                                                                       \
-    unsigned char* sa_ = smem + (buf) * 2 * TILE_BYTES + lds_off0;           \
-    unsigned char* sw_ = sa_ + TILE_BYTES;                                   \
-    *reinterpret_cast<uint4*>(sa_) = ra0;                                    \
-    *reinterpret_cast<uint4*>(sa_ + 32 * 128) = ra1;                         \
-    *reinterpret_cast<uint4*>(sa_ + 64 * 128) = ra2;                         \
-    *reinterpret_cast<uint4*>(sa_ + 96 * 128) = ra3;                         \
-    *reinterpret_cast<uint4*>(sw_) = rw0;                                    \
-    *reinterpret_cast<uint4*>(sw_ + 32 * 128) = rw1;                         \
-    *reinterpret_cast<uint4*>(sw_ + 64 * 128) = rw2;                         \
-    *reinterpret_cast<uint4*>(sw_ + 96 * 128) = rw3;                         \
+// Every K-step issues exactly DMA_PER_STEP pieces: the next K-step to load, or -- once this workgroup has nothing left to
+// load -- dummy pieces (lane-invariant source A[0..7]) into ring slot l_slot, which is free by then (it belonged to
+// K-step S-3).  So every counted wait below is ONE asm statement with ONE immediate.  (Two statements on an if/else made
+// hipcc copy the asm-loaded registers on one path BEFORE the wait -- garbage; cdna guide section 5.7 item 1.)
+#define ADVANCE_LOAD_CURSOR()                                                                                           \
+  do {                                                                                                                  \
+    if (l_step < S) {                                                                                                   \
+      ++l_step;                                                                                                         \
+      l_slot = (l_slot == P_NSTAGE - 1) ? 0 : l_slot + 1;                                                               \
+      if (++l_kt == nk) {                                                                                               \
+        l_kt = 0;                                                                                                       \
+        l_tile += G;                                                                                                    \
+        if (l_step < S) SET_TILE_PTRS(l_tile);                                                                          \
+      } else {                                                                                                          \
+        oa0 += 2 * BK; oa1 += 2 * BK; oa2 += 2 * BK; oa3 += 2 * BK; ow0 += 2 * BK; ow1 += 2 * BK;                        \
+      }                                                                                                                 \
+    }                                                                                                                   \
   } while (0)
+#define ISSUE_NEXT()                                                                                                    \
+  do {                                                                                                                  \
+    const bool real_ = l_step < S;                                                                                      \
+    issue_stage(A, real_ ? W : A, real_ ? oa0 : 0u, real_ ? oa1 : 0u, real_ ? oa2 : 0u, real_ ? oa3 : 0u,                \
+                real_ ? ow0 : 0u, real_ ? ow1 : 0u, lds_a_w + l_slot * P_STAGE_BYTES, lds_w_w + l_slot * P_STAGE_BYTES); \
+    ADVANCE_LOAD_CURSOR();                                                                                              \
+  } while (0)
+
+  SET_TILE_PTRS(l_tile);
+#pragma unroll
+  for (int p = 0; p < P_NSTAGE - 1; ++p) ISSUE_NEXT();
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -91,92 +244,195 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const uint16_t* __res
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int frow = lane & 15, fq = lane >> 4;
-  const int nk = K / BK;
 
-  GLOAD(0);
-  LSTORE(0);
-  __syncthreads();
+  int c_tile = toff, c_kt = 0, c_slot = 0;
+  int st1 = 0, st2 = 0;   // epilogue stores issued at the end of K-step g-1 / g-2 (all younger than DMA group g)
+  for (int g = 0; g < S; ++g) {
+    // DMA group g has landed once only the ops issued after it remain: group g+1 (real or dummy) and recent epilogue stores
+#ifdef TR_DIAG_STAMPS
+    unsigned long long ts0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    wait_vmcnt<STORES_PER_TILE>(DMA_PER_STEP + st1 + st2);
+#ifdef TR_DIAG_STAMPS
+    unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
+    __builtin_amdgcn_s_barrier();   // everyone's pieces of K-step g landed; everyone is done reading the slot of K-step g-1
+#ifdef TR_DIAG_STAMPS
+    unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+#endif
+    st2 = st1;
+    st1 = 0;
+    const bool tile_end = (c_kt == nk - 1);
+    const bool tile_begin = (c_kt == 0);
+    // per-iteration scope on purpose: declared outside the loop these would be loop-carried and cost ~90 VGPRs everywhere
+    f32x4 bv[4];                      // bias of this tile's columns (last K-step only)
+    f32x4 rv[4][4];                   // residual / pos_embed rows (first K-step only)
+    // All epilogue-side loads are issued BEFORE this K-step's DMA, so waiting for them leaves that DMA in flight.
+    if (HAS_RV && tile_begin) {
+      // residual (or pos_embed) rows of this tile: fetched during its FIRST K-step and folded into the accumulator at
+      // the end of that step, so the 64 registers are not live together with the epilogue's
+      const int m0 = (c_tile / nNt) * PBM, n0 = (c_tile % nNt) * PBN;
+      // N % 64 == 0 for these epilogues (checked by the launcher): a wave's 64 columns are all valid or all invalid, so the
+      // column base is clamped once and the four column groups are immediates
+      const unsigned cbase = (unsigned)min(n0 + wn * 64, N - 64) + 4 * fq;
+      const float* rbase = (EPI == TR_EPI_PATCH_F32) ? aux : reinterpret_cast<const float*>(outp);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int mc = min(m0 + wm * 64 + j * 16 + frow, M - 1);
+        const unsigned rrow = (EPI == TR_EPI_PATCH_F32) ? (unsigned)(1 + mc % aux_i) : (unsigned)mc;
+        const unsigned voff = (rrow * (unsigned)N + cbase) * 4u;
+        rv[j][0] = asm_load16_so<0>(rbase, voff);
+        rv[j][1] = asm_load16_so<64>(rbase, voff);
+        rv[j][2] = asm_load16_so<128>(rbase, voff);
+        rv[j][3] = asm_load16_so<192>(rbase, voff);
+      }
+    }
+    if (tile_end) {
+      const int n0 = (c_tile % nNt) * PBN;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bv[i] = asm_load16(bias + min(n0 + wn * 64 + i * 16 + 4 * fq, N - 4));
+    }
+    // this K-step's six DMA pieces (the K-step two ahead, into the slot K-step g-1 used; dummies in the tail) are issued
+    // one by one BETWEEN the MFMA groups below
+    const bool real = l_step < S;
+    const uint16_t* srcW = real ? W : A;
+    const unsigned q0 = real ? oa0 : 0u, q1 = real ? oa1 : 0u, q2 = real ? oa2 : 0u, q3 = real ? oa3 : 0u;
+    const unsigned q4 = real ? ow0 : 0u, q5 = real ? ow1 : 0u;
+    const unsigned dA = lds_a_w + l_slot * P_STAGE_BYTES, dW = lds_w_w + l_slot * P_STAGE_BYTES;
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) GLOAD((kt + 1) * BK);
-    const unsigned char* sa = smem + buf * 2 * TILE_BYTES;
-    const unsigned char* sw = sa + TILE_BYTES;
+    const unsigned char* sa = smem + c_slot * P_STAGE_BYTES;
+    const unsigned char* sw = sa + PBM * 128;
+#ifndef TR_ABLATE_NO_LDS
+    // all 16 fragment reads of the K-step are issued up front (both 32-deep halves): the second half's reads fly under the
+    // first half's MFMAs; hipcc places the counted lgkmcnt waits
+    bf16x8 wf[2][4], af[2][4];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        wf[ks][i] = *reinterpret_cast<const bf16x8*>(sw + swz(wn * 64 + i * 16 + frow, 4 * ks + fq));
+        af[ks][i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * 64 + i * 16 + frow, 4 * ks + fq));
+      }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 wf[4], af[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        wf[i] = *reinterpret_cast<const bf16x8*>(sw + swz(wn * 64 + i * 16 + frow, 4 * ks + fq));
-        af[i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * 64 + i * 16 + frow, 4 * ks + fq));
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
+#ifdef TR_ABLATE_NO_MFMA
+        asm volatile("" ::"v"(wf[ks][i]), "v"(af[ks][i]));
+#else
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < nk) LSTORE(buf ^ 1);
-    __syncthreads();
-  }
-
-#undef GLOAD
-#undef LSTORE
-  // ---- epilogue: lane holds D[n = 4*fq + r][m = frow] of each 16x16 tile -> 4 consecutive output columns.
-  // All loads (bias, residual / pos_embed) are issued UNCONDITIONALLY from clamped addresses before any use, so the
-  // 16 read-modify-write groups overlap instead of paying one dependent HBM round trip each; stores are predicated.
-  float4 bv[4];
-  int ncol[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    ncol[i] = n0 + wn * 64 + i * 16 + 4 * fq;
-    bv[i] = *reinterpret_cast<const float4*>(bias + min(ncol[i], N - 4));
-  }
-  size_t orow[4];
-  float4 rv[4][4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int mc = min(m0 + wm * 64 + j * 16 + frow, M - 1);
-    orow[j] = (size_t)mc;
-    const float* posrow = nullptr;
-    if (EPI == TR_EPI_PATCH_F32) {
-      const int b = mc / aux_i, p = mc - b * aux_i;
-      orow[j] = (size_t)b * (aux_i + 1) + 1 + p;
-      posrow = aux + (size_t)(1 + p) * N;
-    }
-    if (EPI == TR_EPI_RESID_F32 || EPI == TR_EPI_PATCH_F32) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int nc = min(ncol[i], N - 4);
-        rv[j][i] = (EPI == TR_EPI_RESID_F32)
-                       ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(outp) + orow[j] * N + nc)
-                       : *reinterpret_cast<const float4*>(posrow + nc);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], af[ks][j], acc[i][j], 0, 0, 0);
+#endif
+        // one DMA piece after each of the first six 4-MFMA groups of the K-step
+        const int gi = ks * 4 + i;
+        if (gi == 0) issue_piece(A, q0, dA);
+        if (gi == 1) issue_piece(A, q1, dA + 1024);
+        if (gi == 2) issue_piece(A, q2, dA + 2048);
+        if (gi == 3) issue_piece(A, q3, dA + 3072);
+        if (gi == 4) issue_piece(srcW, q4, dW);
+        if (gi == 5) issue_piece(srcW, q5, dW + 1024);
+        __builtin_amdgcn_sched_barrier(0);   // keep the pieces where they are: hipcc may move register-only MFMAs over asm
       }
     }
-  }
+#else
+    asm volatile("" ::"v"(sa), "v"(sw));
+    issue_stage(A, srcW, q0, q1, q2, q3, q4, q5, dA, dW);
+#endif
+    ADVANCE_LOAD_CURSOR();
+#ifdef TR_DIAG_STAMPS
+    {
+      unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+      if (aux != nullptr && bid == 8 && g < 64 && lane == 0 && (wave == 0 || wave == 7)) {
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(const_cast<float*>(aux)) + ((wave ? 64 : 0) + g) * 5;
+        st[0] = ts0; st[1] = ts1; st[2] = ts2; st[3] = ts3; st[4] = tr0;
+      }
+    }
+#endif
+    c_slot = (c_slot == P_NSTAGE - 1) ? 0 : c_slot + 1;
+    if (HAS_RV && tile_begin) {
+      // the residual loads are older than this K-step's 6 DMA pieces and had the step to land
+      EPI_WAIT_R(6, rv);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = m0 + wm * 64 + j * 16 + frow;
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int n = ncol[i];
-      float v0 = acc[i][j][0] + bv[i].x, v1 = acc[i][j][1] + bv[i].y, v2 = acc[i][j][2] + bv[i].z, v3 = acc[i][j][3] + bv[i].w;
-      const bool ok = (m < M) && (n < N);
-      if (EPI == TR_EPI_BF16 || EPI == TR_EPI_GELU_BF16) {
-        if (EPI == TR_EPI_GELU_BF16) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
-        uint2 pk;
-        pk.x = pack_bf16x2(v0, v1);
-        pk.y = pack_bf16x2(v2, v3);
-        if (ok) *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(outp) + orow[j] * N + n) = pk;
-      } else {
-        if (EPI == TR_EPI_RESID_F32 || EPI == TR_EPI_PATCH_F32) {
-          v0 += rv[j][i].x; v1 += rv[j][i].y; v2 += rv[j][i].z; v3 += rv[j][i].w;
+        for (int i = 0; i < 4; ++i) acc[i][j] += rv[j][i];
+    }
+    if (!tile_end) {
+      ++c_kt;
+      continue;
+    }
+    // ---- epilogue: bias loads are older than this K-step's DMA too
+    EPI_WAIT_B(6, bv);
+#ifdef TR_ABLATE_NO_EPI
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(acc[i][j]), "v"(bv[i])); acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    c_kt = 0;
+    c_tile += G;
+    continue;
+#endif
+    // The accumulator layout (lane = row, 4 consecutive columns) would store 16 rows x 32 B per instruction; the store path
+    // prices an instruction by the LINES it touches (stamps: 16 such stores per lane = ~7.8k cycles per tile, half the tile).
+    // So each 16-row slab goes through 2 KiB of wave-private LDS (16-byte chunk index XOR row&7: conflict-free for the
+    // b128 traffic, 2-way for the bf16 b64 writes) and leaves as 16-byte stores covering whole 128-byte lines, 8 rows each.
+    {
+      unsigned char* stg = smem + P_NSTAGE * P_STAGE_BYTES + wave * 2048;
+      const int m0 = (c_tile / nNt) * PBM, n0 = (c_tile % nNt) * PBN;
+      const int rrow = lane >> 3, rch = lane & 7;             // read-back mapping: 8 rows x 8 chunks per instruction
+      constexpr int NPASS = OUT_BF16 ? 1 : 2;                 // a slab row is 64 bf16 = 128 B, or 2 x (32 fp32 = 128 B)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int ip = 0; ip < NPASS; ++ip) {
+#pragma unroll
+          for (int ii = 0; ii < (OUT_BF16 ? 4 : 2); ++ii) {
+            const int i = OUT_BF16 ? ii : 2 * ip + ii;
+            float v0 = acc[i][j][0] + bv[i][0], v1 = acc[i][j][1] + bv[i][1], v2 = acc[i][j][2] + bv[i][2], v3 = acc[i][j][3] + bv[i][3];
+            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (OUT_BF16) {
+#ifndef TR_ABLATE_NO_GELU
+              if (EPI == TR_EPI_GELU_BF16) {
+                const f32x2 g01 = gelu2(f32x2{v0, v1}), g23 = gelu2(f32x2{v2, v3});
+                v0 = g01[0]; v1 = g01[1]; v2 = g23[0]; v3 = g23[1];
+              }
+#endif
+              u32x2 pk;
+              pk[0] = pack_bf16x2(v0, v1);
+              pk[1] = pack_bf16x2(v2, v3);
+              *reinterpret_cast<u32x2*>(stg + frow * 128 + (((2 * i + (fq >> 1)) ^ (frow & 7)) << 4) + (fq & 1) * 8) = pk;
+            } else {
+              *reinterpret_cast<f32x4*>(stg + frow * 128 + (((4 * ii + fq) ^ (frow & 7)) << 4)) = f32x4{v0, v1, v2, v3};
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int row = r * 8 + rrow;
+            const u32x4 pk = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((rch ^ (row & 7)) << 4));
+            const int m = m0 + wm * 64 + j * 16 + row;
+            const int n = n0 + wn * 64 + (OUT_BF16 ? rch * 8 : ip * 32 + rch * 4);
+            size_t orow = (size_t)m;
+            if (EPI == TR_EPI_PATCH_F32) orow = orow + orow / aux_i + 1;   // row (b,p) -> b*(P+1) + 1 + p
+            bool ok = (m < M) && (n < N);
+#ifdef TR_ABLATE_NO_STORE
+            ok = ok && (aux_i == 0x7fffffff);
+#endif
+            // out-of-range lanes get an offset beyond num_records: the buffer bounds check drops their store
+            const unsigned off = ok ? (unsigned)((orow * N + n) * (OUT_BF16 ? 2 : 4)) : 0x80000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(pk, orsrc, off, 0, 0);
+          }
         }
-        if (ok) *reinterpret_cast<float4*>(reinterpret_cast<float*>(outp) + orow[j] * N + n) = make_float4(v0, v1, v2, v3);
       }
     }
+    st1 = STORES_PER_TILE;
+    c_kt = 0;
+    c_tile += G;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // dummy DMA into this workgroup's LDS must not outlive it
+#undef SET_TILE_PTRS
+#undef ISSUE_NEXT
+#undef ADVANCE_LOAD_CURSOR
 }
 
 }  // namespace
@@ -189,20 +445,37 @@ extern "C" int tr_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* b
   TR_REQUIRE(N % 4 == 0, TR_ERR_SHAPE, "tr_gemm_bf16: N=%d must be a multiple of 4", N);
   TR_REQUIRE(tr_aligned16(A) && tr_aligned16(W) && tr_aligned16(bias) && tr_aligned16(out), TR_ERR_ALIGN,
              "tr_gemm_bf16: pointers must be 16-byte aligned");
-  if (epilogue == TR_EPI_PATCH_F32)
+  size_t out_rows = (size_t)M;
+  if (epilogue == TR_EPI_PATCH_F32) {
     TR_REQUIRE(aux && aux_i > 0 && M % aux_i == 0 && tr_aligned16(aux), TR_ERR_SHAPE,
                "tr_gemm_bf16: PATCH epilogue needs pos_embed and P | M");
-  const int nblocks = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    out_rows = (size_t)(M / aux_i) * (aux_i + 1);
+  }
+  const size_t esz = (epilogue == TR_EPI_BF16 || epilogue == TR_EPI_GELU_BF16) ? 2 : 4;
+  const size_t out_bytes = out_rows * (size_t)N * esz;
+  TR_REQUIRE(out_bytes < ((size_t)1 << 31), TR_ERR_SHAPE, "tr_gemm_bf16: output of %zu bytes exceeds the 2 GiB range of the store offsets",
+             out_bytes);
+  TR_REQUIRE((size_t)M * K * 2 < ((size_t)1 << 32) && (size_t)N * K * 2 < ((size_t)1 << 32), TR_ERR_SHAPE,
+             "tr_gemm_bf16: operands must be smaller than 4 GiB (32-bit DMA offsets)");
+  if (esz == 2) TR_REQUIRE(N % 8 == 0, TR_ERR_SHAPE, "tr_gemm_bf16: bf16 outputs need N %% 8 == 0 (got %d)", N);
+  if (epilogue == TR_EPI_RESID_F32 || epilogue == TR_EPI_PATCH_F32)
+    TR_REQUIRE(N % 64 == 0, TR_ERR_SHAPE, "tr_gemm_bf16: residual/patch epilogues need N %% 64 == 0 (got %d)", N);
   hipStream_t st = static_cast<hipStream_t>(s);
-  dim3 grid(nblocks), block(256);
+  const int nMt = (M + PBM - 1) / PBM, nNt = (N + PBN - 1) / PBN;
+  // one persistent 512-thread workgroup per CU (144 KiB LDS each); 256 CUs on MI355X.  A multiple of 8 keeps the XCD grouping.
+  dim3 grid(256), block(512);
+#define TR_LAUNCH(E)                                                                                                  \
+  hipLaunchKernelGGL(gemm_bf16_persistent<E>, grid, block, 0, st, A, W, bias, out, aux, aux_i, M, N, K, nMt, nNt, \
+                     (unsigned)out_bytes)
   switch (epilogue) {
-    case TR_EPI_BF16: hipLaunchKernelGGL(gemm_bf16_kernel<TR_EPI_BF16>, grid, block, 0, st, A, W, bias, out, aux, aux_i, M, N, K); break;
-    case TR_EPI_GELU_BF16: hipLaunchKernelGGL(gemm_bf16_kernel<TR_EPI_GELU_BF16>, grid, block, 0, st, A, W, bias, out, aux, aux_i, M, N, K); break;
-    case TR_EPI_RESID_F32: hipLaunchKernelGGL(gemm_bf16_kernel<TR_EPI_RESID_F32>, grid, block, 0, st, A, W, bias, out, aux, aux_i, M, N, K); break;
-    case TR_EPI_F32: hipLaunchKernelGGL(gemm_bf16_kernel<TR_EPI_F32>, grid, block, 0, st, A, W, bias, out, aux, aux_i, M, N, K); break;
-    case TR_EPI_PATCH_F32: hipLaunchKernelGGL(gemm_bf16_kernel<TR_EPI_PATCH_F32>, grid, block, 0, st, A, W, bias, out, aux, aux_i, M, N, K); break;
+    case TR_EPI_BF16: TR_LAUNCH(TR_EPI_BF16); break;
+    case TR_EPI_GELU_BF16: TR_LAUNCH(TR_EPI_GELU_BF16); break;
+    case TR_EPI_RESID_F32: TR_LAUNCH(TR_EPI_RESID_F32); break;
+    case TR_EPI_F32: TR_LAUNCH(TR_EPI_F32); break;
+    case TR_EPI_PATCH_F32: TR_LAUNCH(TR_EPI_PATCH_F32); break;
     default: TR_REQUIRE(false, TR_ERR_SHAPE, "tr_gemm_bf16: unknown epilogue %d", epilogue);
   }
+#undef TR_LAUNCH
   TR_CHECK_LAUNCH("tr_gemm_bf16");
   return TR_OK;
 }
