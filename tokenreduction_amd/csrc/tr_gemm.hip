@@ -36,7 +36,7 @@ constexpr int BK = 64;
 constexpr int PBM = 256, PBN = 128;
 constexpr int P_STAGE_BYTES = (PBM + PBN) * 128;  // 48 KiB: A rows then W rows, 128 B (64 bf16) per row
 constexpr int P_NSTAGE = 3;
-constexpr int DMA_PER_STEP = 6;                   // LDS-DMA pieces per wave and K-step: 4 of A, 2 of W
+constexpr int DMA_PER_STEP = 6;                   // LDS-DMA pieces per wave and K-step: 4 of A, 2 of W (documentation of the vmcnt immediates)
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -120,15 +120,12 @@ __device__ __forceinline__ void issue_piece(const uint16_t* sbase, unsigned voff
 #endif
 }
 
-// `n` is wave-uniform: DMA_PER_STEP + {0,1,2} * ST (ST = buffer stores per lane in one epilogue: 8 bf16 / 16 fp32)
+// mid-step wait when the previous K-step's epilogue stores (ST per lane) are younger than the DMA group waited for:
+// allowed outstanding = 4 pieces of this step + ST stores
 template <int ST>
-__device__ __forceinline__ void wait_vmcnt(int n) {
-  if (n == DMA_PER_STEP) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if (n == DMA_PER_STEP + ST) {
-    if (ST == 8) asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
-  } else {
-    if (ST == 8) asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
-  }
+__device__ __forceinline__ void wait_mid() {
+  if (ST == 8) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
 }
 
 // loads hipcc must not count (see header): the destination is valid only after the matching EPI_WAIT statement.
@@ -244,192 +241,209 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persistent(const uint16_t* _
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Fragment registers: the first 32-deep half of a K-step (ks = 0) is read one half-step AHEAD, right after the barrier that
+  // publishes its slot (which sits in the MIDDLE of the previous K-step); the second half (ks = 1) is read at the top of
+  // its own K-step and used after the mid-step barrier.  So every LDS read has 16 MFMAs (x2 waves per SIMD) to hide under,
+  // instead of all eight waves reading at once behind a top-of-step barrier with the matrix pipe idle (in-kernel stamps:
+  // ~500 of ~1700 cycles per K-step).
+  bf16x8 wA[4], aA[4], wC[4], aC[4];
+#define READ_FRAGS(WF, AF, slot, ks)                                                                          \
+  do {                                                                                                        \
+    const unsigned char* sa_ = smem + (slot) * P_STAGE_BYTES;                                                 \
+    const unsigned char* sw_ = sa_ + PBM * 128;                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
+      WF[i_] = *reinterpret_cast<const bf16x8*>(sw_ + swz(wn * 64 + i_ * 16 + frow, 4 * (ks) + fq));          \
+      AF[i_] = *reinterpret_cast<const bf16x8*>(sa_ + swz(wm * 64 + i_ * 16 + frow, 4 * (ks) + fq));          \
+    }                                                                                                         \
+  } while (0)
+#ifdef TR_ABLATE_NO_MFMA
+#define MFMA_GROUP(WF, AF, i_) asm volatile("" ::"v"(WF[i_]), "v"(AF[i_]))
+#else
+#define MFMA_GROUP(WF, AF, i_)                                                                               \
+  _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                            \
+      acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[i_], AF[j_], acc[i_][j_], 0, 0, 0)
+#endif
 
   int c_tile = toff, c_kt = 0, c_slot = 0;
-  int st1 = 0, st2 = 0;   // epilogue stores issued at the end of K-step g-1 / g-2 (all younger than DMA group g)
-  for (int g = 0; g < S; ++g) {
-    // DMA group g has landed once only the ops issued after it remain: group g+1 (real or dummy) and recent epilogue stores
-#ifdef TR_DIAG_STAMPS
-    unsigned long long ts0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    wait_vmcnt<STORES_PER_TILE>(DMA_PER_STEP + st1 + st2);
-#ifdef TR_DIAG_STAMPS
-    unsigned long long ts1 = __builtin_amdgcn_s_memtime();
-#endif
-    __builtin_amdgcn_s_barrier();   // everyone's pieces of K-step g landed; everyone is done reading the slot of K-step g-1
-#ifdef TR_DIAG_STAMPS
-    unsigned long long ts2 = __builtin_amdgcn_s_memtime();
-#endif
-    st2 = st1;
-    st1 = 0;
-    const bool tile_end = (c_kt == nk - 1);
-    const bool tile_begin = (c_kt == 0);
-    // per-iteration scope on purpose: declared outside the loop these would be loop-carried and cost ~90 VGPRs everywhere
-    f32x4 bv[4];                      // bias of this tile's columns (last K-step only)
-    f32x4 rv[4][4];                   // residual / pos_embed rows (first K-step only)
-    // All epilogue-side loads are issued BEFORE this K-step's DMA, so waiting for them leaves that DMA in flight.
-    if (HAS_RV && tile_begin) {
-      // residual (or pos_embed) rows of this tile: fetched during its FIRST K-step and folded into the accumulator at
-      // the end of that step, so the 64 registers are not live together with the epilogue's
-      const int m0 = (c_tile / nNt) * PBM, n0 = (c_tile % nNt) * PBN;
-      // N % 64 == 0 for these epilogues (checked by the launcher): a wave's 64 columns are all valid or all invalid, so the
-      // column base is clamped once and the four column groups are immediates
-      const unsigned cbase = (unsigned)min(n0 + wn * 64, N - 64) + 4 * fq;
-      const float* rbase = (EPI == TR_EPI_PATCH_F32) ? aux : reinterpret_cast<const float*>(outp);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int mc = min(m0 + wm * 64 + j * 16 + frow, M - 1);
-        const unsigned rrow = (EPI == TR_EPI_PATCH_F32) ? (unsigned)(1 + mc % aux_i) : (unsigned)mc;
-        const unsigned voff = (rrow * (unsigned)N + cbase) * 4u;
-        rv[j][0] = asm_load16_so<0>(rbase, voff);
-        rv[j][1] = asm_load16_so<64>(rbase, voff);
-        rv[j][2] = asm_load16_so<128>(rbase, voff);
-        rv[j][3] = asm_load16_so<192>(rbase, voff);
-      }
-    }
-    if (tile_end) {
-      const int n0 = (c_tile % nNt) * PBN;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) bv[i] = asm_load16(bias + min(n0 + wn * 64 + i * 16 + 4 * fq, N - 4));
-    }
-    // this K-step's six DMA pieces (the K-step two ahead, into the slot K-step g-1 used; dummies in the tail) are issued
-    // one by one BETWEEN the MFMA groups below
-    const bool real = l_step < S;
-    const uint16_t* srcW = real ? W : A;
-    const unsigned q0 = real ? oa0 : 0u, q1 = real ? oa1 : 0u, q2 = real ? oa2 : 0u, q3 = real ? oa3 : 0u;
-    const unsigned q4 = real ? ow0 : 0u, q5 = real ? ow1 : 0u;
-    const unsigned dA = lds_a_w + l_slot * P_STAGE_BYTES, dW = lds_w_w + l_slot * P_STAGE_BYTES;
+  int st_prev = 0;        // epilogue stores issued at the END of the previous K-step (younger than every DMA piece before them)
 
-    const unsigned char* sa = smem + c_slot * P_STAGE_BYTES;
-    const unsigned char* sw = sa + PBM * 128;
-#ifndef TR_ABLATE_NO_LDS
-    // all 16 fragment reads of the K-step are issued up front (both 32-deep halves): the second half's reads fly under the
-    // first half's MFMAs; hipcc places the counted lgkmcnt waits
-    bf16x8 wf[2][4], af[2][4];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        wf[ks][i] = *reinterpret_cast<const bf16x8*>(sw + swz(wn * 64 + i * 16 + frow, 4 * ks + fq));
-        af[ks][i] = *reinterpret_cast<const bf16x8*>(sa + swz(wm * 64 + i * 16 + frow, 4 * ks + fq));
-      }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-#ifdef TR_ABLATE_NO_MFMA
-        asm volatile("" ::"v"(wf[ks][i]), "v"(af[ks][i]));
-#else
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], af[ks][j], acc[i][j], 0, 0, 0);
-#endif
-        // one DMA piece after each of the first six 4-MFMA groups of the K-step
-        const int gi = ks * 4 + i;
-        if (gi == 0) issue_piece(A, q0, dA);
-        if (gi == 1) issue_piece(A, q1, dA + 1024);
-        if (gi == 2) issue_piece(A, q2, dA + 2048);
-        if (gi == 3) issue_piece(A, q3, dA + 3072);
-        if (gi == 4) issue_piece(srcW, q4, dW);
-        if (gi == 5) issue_piece(srcW, q5, dW + 1024);
-        __builtin_amdgcn_sched_barrier(0);   // keep the pieces where they are: hipcc may move register-only MFMAs over asm
-      }
-    }
-#else
-    asm volatile("" ::"v"(sa), "v"(sw));
-    issue_stage(A, srcW, q0, q1, q2, q3, q4, q5, dA, dW);
-#endif
-    ADVANCE_LOAD_CURSOR();
+  // K-step 0: its DMA group is the older of the two just issued
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  READ_FRAGS(wA, aA, 0, 0);
+
+// One K-step.  (W0,A0): this step's ks=0 fragments, already (being) read; (W0N,A0N): the next step's, read at the mid barrier.
+#define GEMM_STEP(W0, A0, W0N, A0N)                                                                                          \
+  do {                                                                                                                       \
+    const bool tile_end = (c_kt == nk - 1);                                                                                  \
+    const bool tile_begin = (c_kt == 0);                                                                                     \
+    f32x4 bv[4];     /* bias of this tile's columns (last K-step only) */                                                    \
+    f32x4 rv[4][4];  /* residual / pos_embed rows (first K-step only)   */                                                   \
+    STAMP(0);                                                                                                                \
+    READ_FRAGS(wC, aC, c_slot, 1);                                                                                           \
+    /* this K-step's six DMA pieces (the K-step two ahead, into the slot K-step g-1 used; dummies in the tail) */            \
+    const bool real = l_step < S;                                                                                            \
+    const uint16_t* srcW = real ? W : A;                                                                                     \
+    const unsigned q0 = real ? oa0 : 0u, q1 = real ? oa1 : 0u, q2 = real ? oa2 : 0u, q3 = real ? oa3 : 0u;                   \
+    const unsigned q4 = real ? ow0 : 0u, q5 = real ? ow1 : 0u;                                                               \
+    const unsigned dA = lds_a_w + l_slot * P_STAGE_BYTES, dW = lds_w_w + l_slot * P_STAGE_BYTES;                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                                       \
+    MFMA_GROUP(W0, A0, 0); issue_piece(A, q0, dA);        __builtin_amdgcn_sched_barrier(0);                                 \
+    MFMA_GROUP(W0, A0, 1); issue_piece(A, q1, dA + 1024); __builtin_amdgcn_sched_barrier(0);                                 \
+    MFMA_GROUP(W0, A0, 2); issue_piece(A, q2, dA + 2048); __builtin_amdgcn_sched_barrier(0);                                 \
+    MFMA_GROUP(W0, A0, 3); issue_piece(A, q3, dA + 3072); __builtin_amdgcn_sched_barrier(0);                                 \
+    STAMP(1);                                                                                                                \
+    const int next_slot = (c_slot == P_NSTAGE - 1) ? 0 : c_slot + 1;                                                         \
+    if (g + 1 < S) {                                                                                                         \
+      /* DMA group g+1 (issued during K-step g-1) has landed once only the ops issued after it remain: the 4 pieces above */ \
+      /* and the previous K-step's epilogue stores, if it ended a tile */                                                    \
+      if (st_prev) wait_mid<STORES_PER_TILE>(); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                        \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  /* own reads of slot g are done: it may be refilled after this */ \
+      __builtin_amdgcn_s_barrier();                                                                                          \
+      asm volatile("" ::: "memory");                                                                                         \
+      STAMP(2);                                                                                                              \
+    }                                                                                                                        \
+    /* unconditional on purpose (after the last K-step it reads a stale slot, unused): a conditional assignment would keep */ \
+    /* BOTH ks=0 register sets live around the whole loop */                                                                 \
+    READ_FRAGS(W0N, A0N, next_slot, 0);                                                                                      \
+    /* epilogue-side loads: issued HERE, i.e. older than pieces 4,5 below, so waiting for them at the end of the step */     \
+    /* is vmcnt(2) and they never enter a DMA count (they are older than this group's last piece) */                         \
+    if (HAS_RV && tile_begin) {                                                                                              \
+      const int m0 = (c_tile / nNt) * PBM, n0 = (c_tile % nNt) * PBN;                                                        \
+      /* N % 64 == 0 here (launcher): a wave's 64 columns are all valid or all invalid -> one clamped base + immediates */   \
+      const unsigned cbase = (unsigned)min(n0 + wn * 64, N - 64) + 4 * fq;                                                   \
+      const float* rbase = (EPI == TR_EPI_PATCH_F32) ? aux : reinterpret_cast<const float*>(outp);                           \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                        \
+        const int mc = min(m0 + wm * 64 + j * 16 + frow, M - 1);                                                             \
+        const unsigned rrow = (EPI == TR_EPI_PATCH_F32) ? (unsigned)(1 + mc % aux_i) : (unsigned)mc;                         \
+        const unsigned voff = (rrow * (unsigned)N + cbase) * 4u;                                                             \
+        rv[j][0] = asm_load16_so<0>(rbase, voff);                                                                            \
+        rv[j][1] = asm_load16_so<64>(rbase, voff);                                                                           \
+        rv[j][2] = asm_load16_so<128>(rbase, voff);                                                                          \
+        rv[j][3] = asm_load16_so<192>(rbase, voff);                                                                          \
+      }                                                                                                                      \
+    }                                                                                                                        \
+    if (tile_end) {                                                                                                          \
+      const int n0 = (c_tile % nNt) * PBN;                                                                                   \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) bv[i] = asm_load16(bias + min(n0 + wn * 64 + i * 16 + 4 * fq, N - 4));   \
+    }                                                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                                       \
+    MFMA_GROUP(wC, aC, 0); issue_piece(srcW, q4, dW);        __builtin_amdgcn_sched_barrier(0);                              \
+    MFMA_GROUP(wC, aC, 1); issue_piece(srcW, q5, dW + 1024); __builtin_amdgcn_sched_barrier(0);                              \
+    MFMA_GROUP(wC, aC, 2);                                                                                                   \
+    MFMA_GROUP(wC, aC, 3);                                                                                                   \
+    STAMP(3);                                                                                                                \
+    ADVANCE_LOAD_CURSOR();                                                                                                   \
+    c_slot = next_slot;                                                                                                      \
+    st_prev = 0;                                                                                                             \
+    if (HAS_RV && tile_begin) {                                                                                              \
+      EPI_WAIT_R(2, rv);                                                                                                     \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) acc[i][j] += rv[j][i];                                                 \
+    }                                                                                                                        \
+    if (!tile_end) {                                                                                                         \
+      ++c_kt;                                                                                                                \
+    } else {                                                                                                                 \
+      EPI_WAIT_B(2, bv);                                                                                                     \
+      epilogue_store(bv);                                                                                                    \
+      st_prev = 1;                                                                                                           \
+      c_kt = 0;                                                                                                              \
+      c_tile += G;                                                                                                           \
+    }                                                                                                                        \
+    STAMP(4);                                                                                                                \
+  } while (0)
+
 #ifdef TR_DIAG_STAMPS
-    {
-      unsigned long long ts3 = __builtin_amdgcn_s_memtime();
-      if (aux != nullptr && bid == 8 && g < 64 && lane == 0 && (wave == 0 || wave == 7)) {
-        unsigned long long* st = reinterpret_cast<unsigned long long*>(const_cast<float*>(aux)) + ((wave ? 64 : 0) + g) * 5;
-        st[0] = ts0; st[1] = ts1; st[2] = ts2; st[3] = ts3; st[4] = tr0;
-      }
-    }
+  unsigned long long ts_[5];
+#define STAMP(k) ts_[k] = __builtin_amdgcn_s_memtime()
+#else
+#define STAMP(k) do { } while (0)
 #endif
-    c_slot = (c_slot == P_NSTAGE - 1) ? 0 : c_slot + 1;
-    if (HAS_RV && tile_begin) {
-      // the residual loads are older than this K-step's 6 DMA pieces and had the step to land
-      EPI_WAIT_R(6, rv);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] += rv[j][i];
-    }
-    if (!tile_end) {
-      ++c_kt;
-      continue;
-    }
-    // ---- epilogue: bias loads are older than this K-step's DMA too
-    EPI_WAIT_B(6, bv);
+
+  // The accumulator layout (lane = row, 4 consecutive columns) would store 16 rows x 32 B per instruction; the store path
+  // prices an instruction by the LINES it touches (stamps: 16 such stores per lane = ~7.8k cycles per tile, half the tile).
+  // So each 16-row slab goes through 2 KiB of wave-private LDS (16-byte chunk index XOR row&7: conflict-free for the
+  // b128 traffic, 2-way for the bf16 b64 writes) and leaves as 16-byte stores covering whole 128-byte lines, 8 rows each.
+  auto epilogue_store = [&](f32x4 (&bv)[4]) __attribute__((always_inline)) {
 #ifdef TR_ABLATE_NO_EPI
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(acc[i][j]), "v"(bv[i])); acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    c_kt = 0;
-    c_tile += G;
-    continue;
-#endif
-    // The accumulator layout (lane = row, 4 consecutive columns) would store 16 rows x 32 B per instruction; the store path
-    // prices an instruction by the LINES it touches (stamps: 16 such stores per lane = ~7.8k cycles per tile, half the tile).
-    // So each 16-row slab goes through 2 KiB of wave-private LDS (16-byte chunk index XOR row&7: conflict-free for the
-    // b128 traffic, 2-way for the bf16 b64 writes) and leaves as 16-byte stores covering whole 128-byte lines, 8 rows each.
-    {
-      unsigned char* stg = smem + P_NSTAGE * P_STAGE_BYTES + wave * 2048;
-      const int m0 = (c_tile / nNt) * PBM, n0 = (c_tile % nNt) * PBN;
-      const int rrow = lane >> 3, rch = lane & 7;             // read-back mapping: 8 rows x 8 chunks per instruction
-      constexpr int NPASS = OUT_BF16 ? 1 : 2;                 // a slab row is 64 bf16 = 128 B, or 2 x (32 fp32 = 128 B)
+#else
+    unsigned char* stg = smem + P_NSTAGE * P_STAGE_BYTES + wave * 2048;
+    const int m0 = (c_tile / nNt) * PBM, n0 = (c_tile % nNt) * PBN;
+    const int rrow = lane >> 3, rch = lane & 7;             // read-back mapping: 8 rows x 8 chunks per instruction
+    constexpr int NPASS = OUT_BF16 ? 1 : 2;                 // a slab row is 64 bf16 = 128 B, or 2 x (32 fp32 = 128 B)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 4; ++j) {
 #pragma unroll
-        for (int ip = 0; ip < NPASS; ++ip) {
+      for (int ip = 0; ip < NPASS; ++ip) {
 #pragma unroll
-          for (int ii = 0; ii < (OUT_BF16 ? 4 : 2); ++ii) {
-            const int i = OUT_BF16 ? ii : 2 * ip + ii;
-            float v0 = acc[i][j][0] + bv[i][0], v1 = acc[i][j][1] + bv[i][1], v2 = acc[i][j][2] + bv[i][2], v3 = acc[i][j][3] + bv[i][3];
-            acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (OUT_BF16) {
+        for (int ii = 0; ii < (OUT_BF16 ? 4 : 2); ++ii) {
+          const int i = OUT_BF16 ? ii : 2 * ip + ii;
+          float v0 = acc[i][j][0] + bv[i][0], v1 = acc[i][j][1] + bv[i][1], v2 = acc[i][j][2] + bv[i][2], v3 = acc[i][j][3] + bv[i][3];
+          acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (OUT_BF16) {
 #ifndef TR_ABLATE_NO_GELU
-              if (EPI == TR_EPI_GELU_BF16) {
-                const f32x2 g01 = gelu2(f32x2{v0, v1}), g23 = gelu2(f32x2{v2, v3});
-                v0 = g01[0]; v1 = g01[1]; v2 = g23[0]; v3 = g23[1];
-              }
-#endif
-              u32x2 pk;
-              pk[0] = pack_bf16x2(v0, v1);
-              pk[1] = pack_bf16x2(v2, v3);
-              *reinterpret_cast<u32x2*>(stg + frow * 128 + (((2 * i + (fq >> 1)) ^ (frow & 7)) << 4) + (fq & 1) * 8) = pk;
-            } else {
-              *reinterpret_cast<f32x4*>(stg + frow * 128 + (((4 * ii + fq) ^ (frow & 7)) << 4)) = f32x4{v0, v1, v2, v3};
+            if (EPI == TR_EPI_GELU_BF16) {
+              const f32x2 g01 = gelu2(f32x2{v0, v1}), g23 = gelu2(f32x2{v2, v3});
+              v0 = g01[0]; v1 = g01[1]; v2 = g23[0]; v3 = g23[1];
             }
-          }
-#pragma unroll
-          for (int r = 0; r < 2; ++r) {
-            const int row = r * 8 + rrow;
-            const u32x4 pk = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((rch ^ (row & 7)) << 4));
-            const int m = m0 + wm * 64 + j * 16 + row;
-            const int n = n0 + wn * 64 + (OUT_BF16 ? rch * 8 : ip * 32 + rch * 4);
-            size_t orow = (size_t)m;
-            if (EPI == TR_EPI_PATCH_F32) orow = orow + orow / aux_i + 1;   // row (b,p) -> b*(P+1) + 1 + p
-            bool ok = (m < M) && (n < N);
-#ifdef TR_ABLATE_NO_STORE
-            ok = ok && (aux_i == 0x7fffffff);
 #endif
-            // out-of-range lanes get an offset beyond num_records: the buffer bounds check drops their store
-            const unsigned off = ok ? (unsigned)((orow * N + n) * (OUT_BF16 ? 2 : 4)) : 0x80000000u;
-            __builtin_amdgcn_raw_buffer_store_b128(pk, orsrc, off, 0, 0);
+            u32x2 pk;
+            pk[0] = pack_bf16x2(v0, v1);
+            pk[1] = pack_bf16x2(v2, v3);
+            *reinterpret_cast<u32x2*>(stg + frow * 128 + (((2 * i + (fq >> 1)) ^ (frow & 7)) << 4) + (fq & 1) * 8) = pk;
+          } else {
+            *reinterpret_cast<f32x4*>(stg + frow * 128 + (((4 * ii + fq) ^ (frow & 7)) << 4)) = f32x4{v0, v1, v2, v3};
           }
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int row = r * 8 + rrow;
+          const u32x4 pk = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((rch ^ (row & 7)) << 4));
+          const int m = m0 + wm * 64 + j * 16 + row;
+          const int n = n0 + wn * 64 + (OUT_BF16 ? rch * 8 : ip * 32 + rch * 4);
+          size_t orow = (size_t)m;
+          if (EPI == TR_EPI_PATCH_F32) orow = orow + orow / aux_i + 1;   // row (b,p) -> b*(P+1) + 1 + p
+          bool ok = (m < M) && (n < N);
+#ifdef TR_ABLATE_NO_STORE
+          ok = ok && (aux_i == 0x7fffffff);
+#endif
+          // out-of-range lanes get an offset beyond num_records: the buffer bounds check drops their store
+          const unsigned off = ok ? (unsigned)((orow * N + n) * (OUT_BF16 ? 2 : 4)) : 0x80000000u;
+          __builtin_amdgcn_raw_buffer_store_b128(pk, orsrc, off, 0, 0);
         }
       }
     }
-    st1 = STORES_PER_TILE;
-    c_kt = 0;
-    c_tile += G;
+#endif
+  };
+
+#ifdef TR_DIAG_STAMPS
+#define DUMP_STAMPS()                                                                                         \
+  do {                                                                                                        \
+    if (aux != nullptr && bid == 8 && g < 64 && lane == 0 && (wave == 0 || wave == 7)) {                      \
+      unsigned long long* st = reinterpret_cast<unsigned long long*>(const_cast<float*>(aux)) + ((wave ? 64 : 0) + g) * 5; \
+      st[0] = ts_[0]; st[1] = ts_[1]; st[2] = ts_[2]; st[3] = ts_[3]; st[4] = ts_[4];                        \
+    }                                                                                                         \
+  } while (0)
+#else
+#define DUMP_STAMPS() do { } while (0)
+#endif
+
+  for (int g = 0; g < S; ++g) {
+    // the ks=0 registers are dead after the first four MFMA groups, so the read-ahead at the mid barrier refills them in place
+    GEMM_STEP(wA, aA, wA, aA);
+    DUMP_STAMPS();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // dummy DMA into this workgroup's LDS must not outlive it
+#undef GEMM_STEP
+#undef READ_FRAGS
+#undef MFMA_GROUP
+#undef STAMP
+#undef DUMP_STAMPS
 #undef SET_TILE_PTRS
 #undef ISSUE_NEXT
 #undef ADVANCE_LOAD_CURSOR

@@ -45,9 +45,9 @@ class Trace:
             self.tensors[name] = t.clone()
 
 
-_EPI_NAME = {ops.TR_EPI_BF16: "gemm_bf16_kernel<EPI_BF16>", ops.TR_EPI_GELU_BF16: "gemm_bf16_kernel<EPI_GELU_BF16>",
-             ops.TR_EPI_RESID_F32: "gemm_bf16_kernel<EPI_RESID_F32>", ops.TR_EPI_F32: "gemm_bf16_kernel<EPI_F32>",
-             ops.TR_EPI_PATCH_F32: "gemm_bf16_kernel<EPI_PATCH_F32>"}
+_EPI_NAME = {ops.TR_EPI_BF16: "gemm_bf16_persistent<EPI_BF16>", ops.TR_EPI_GELU_BF16: "gemm_bf16_persistent<EPI_GELU_BF16>",
+             ops.TR_EPI_RESID_F32: "gemm_bf16_persistent<EPI_RESID_F32>", ops.TR_EPI_F32: "gemm_bf16_persistent<EPI_F32>",
+             ops.TR_EPI_PATCH_F32: "gemm_bf16_persistent<EPI_PATCH_F32>"}
 
 
 def _gemm(tr: Trace, a, w, b, epi, out=None, aux=None, aux_i=0):

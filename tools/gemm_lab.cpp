@@ -31,11 +31,11 @@ int main(int argc, char** argv) {
       std::vector<unsigned long long> hs(128 * 5);
       hipMemcpy(hs.data(), stamps, 128 * 5 * 8, hipMemcpyDeviceToHost);
       for (int w = 0; w < 2; ++w) {
-        printf("  wave %d: step: wait_vmcnt  barrier  body(compute+epi)  | total   (shader cycles)\n", w ? 7 : 0);
+        printf("  wave %d: step: H1   mid-wait+barrier   H2   END(epilogue)   loop-back | total   (shader cycles)\n", w ? 7 : 0);
         for (int g = 0; g < 26; ++g) {
           unsigned long long* t = &hs[(w * 64 + g) * 5];
           unsigned long long* tn = &hs[(w * 64 + g + 1) * 5];
-          printf("   g=%2d  %6llu  %6llu  %6llu | %6llu  (100MHz ticks to next %llu)\n", g, t[1] - t[0], t[2] - t[1], t[3] - t[2], tn[0] - t[0], tn[4] - t[4]);
+          printf("   g=%2d  %6llu  %6llu  %6llu  %6llu  %6llu | %6llu\n", g, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[4] - t[3], tn[0] - t[4], tn[0] - t[0]);
         }
       }
       hipFree(stamps);
