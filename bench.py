@@ -120,50 +120,88 @@ def cpu_baseline_leg(model, budget_s=12.0):
                 sample=f"{n} forward passes of batch {bs} (same model/config, fp32 torch-CPU oracle), {el:.1f} s")
 
 
+def timed_steps(step, steps, warmup, dist, sync, device):
+    """W untimed + K timed steps bracketed by barrier + device sync on both sides; returns MAX-over-ranks seconds."""
+    for _ in range(warmup):
+        step()
+    if dist is not None:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    sync()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = t.item()
+        dist.barrier()
+    return el
+
+
+def pmc_traffic(kernel_label):
+    """HBM bytes per launch of `kernel_label` from the committed PMC summary (tools/prof_summary.py), or None."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    tbl = json.load(open(files[-1]))
+    epi = {"EPI_BF16": 0, "EPI_GELU_BF16": 1, "EPI_RESID_F32": 2, "EPI_F32": 3, "EPI_PATCH_F32": 4}
+    m = re.match(r"(\w+)<(\w+)>", kernel_label)
+    key = f"{m.group(1)}<{epi[m.group(2)]}>" if m and m.group(2) in epi else kernel_label
+    v = tbl.get(key)
+    return None if v is None else dict(hbm_bytes_per_launch=v["hbm_bytes_per_launch"], source=os.path.basename(files[-1]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-extra", action="store_true", help="skip the roofline / cpu_baseline legs")
+    ap.add_argument("--selftest-gloo", action="store_true",
+                    help="CPU-only check of the multi-process harness (gloo, no model): each rank's step sleeps 10 ms x (rank+1)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if a.selftest_gloo:
+        if dist is not None:
+            dist.init_process_group("gloo")
+        el = timed_steps(lambda: time.sleep(0.01 * (rank + 1)), a.steps, a.warmup, dist, lambda: None, torch.device("cpu"))
+        if rank == 0:
+            print(json.dumps({"metric": "selftest", "value": round(world * BATCH * a.steps / el, 1), "unit": "images/s",
+                              "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                              "ms_per_step": round(1e3 * el / a.steps, 3), "scaling": "weak"}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    if dist is not None:
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dev = torch.device("cuda", local_rank if world > 1 else 0)
 
+    # data-parallel inference: every rank owns its own shard of images (one batch of 256), weights replicated, no collective
+    # on the data path (SURVEY.md 8e)
     model = build_model(device=dev)
     x = torch.randn(BATCH, 3, 224, 224, generator=torch.Generator().manual_seed(100 + rank)).to(dev)
+    out = [None]
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def step():
+        out[0] = model(x)
 
-    for _ in range(a.warmup):
-        model(x)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = model(x)
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = t.item()
-        dist.barrier()
-    assert torch.isfinite(out).all()
+    el = timed_steps(step, a.steps, a.warmup, dist, torch.cuda.synchronize, dev)
+    assert torch.isfinite(out[0]).all()
 
     if rank == 0:
         ips = world * BATCH * a.steps / el
@@ -182,6 +220,7 @@ def main():
         }
         if world == 1 and not a.no_extra:
             roof, table, step_ms = roofline_leg(model, x)
+            roof["traffic"] = pmc_traffic(roof["kernel"])
             rec["roofline"] = roof
             rec["kernels"] = table
             rec["stepwise_ms_per_step"] = round(step_ms, 3)

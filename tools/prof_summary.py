@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output (gpurun_out/) into the committed summaries under profiles/.
+
+  python tools/prof_summary.py <tag> <kernel_stats.csv> <pmc_fetch counter_collection.csv> <pmc_write counter_collection.csv>
+
+Writes profiles/<tag>_kernel_stats.csv (verbatim copy of rocprofv3 --kernel-trace --stats), and
+profiles/<tag>_pmc_traffic.json: per kernel, HBM-side bytes per launch from the TCC counters, collected in SEPARATE
+--pmc passes (FETCH_SIZE and WRITE_SIZE do not fit one pass) and corrected as MI355X_MICROARCH.md section HBM prescribes:
+counter unit = KiB; on gfx950 FETCH_SIZE tallies the 128-B requests of wide coalesced reads at 64 B -> doubled;
+WRITE_SIZE is exact for 16-B-per-lane stores.
+"""
+import collections
+import csv
+import json
+import re
+import shutil
+import sys
+
+tag, stats, fetch, write = sys.argv[1:5]
+shutil.copy(stats, f"profiles/{tag}_kernel_stats.csv")
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    return re.sub(r"\(.*", "", name)
+
+
+def per_kernel(path, counter):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        a = acc[short(r["Kernel_Name"])]
+        a[0] += float(r["Counter_Value"])
+        a[1] += 1
+    return acc
+
+
+f, w = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
+out = {}
+for k in sorted(set(f) | set(w)):
+    if not k.startswith(("gemm", "attention", "layernorm", "gather", "cls_", "im2col")):
+        continue
+    fb = 2.0 * 1024.0 * f[k][0] / max(f[k][1], 1)      # gfx950: x2
+    wb = 1024.0 * w[k][0] / max(w[k][1], 1)
+    out[k] = dict(launches_profiled=f[k][1], fetch_bytes_per_launch=round(fb), write_bytes_per_launch=round(wb),
+                  hbm_bytes_per_launch=round(fb + wb))
+json.dump(out, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
+for k, v in out.items():
+    print(f"{k:45s} fetch {v['fetch_bytes_per_launch']/1e6:9.2f} MB  write {v['write_bytes_per_launch']/1e6:9.2f} MB  (avg per launch, {v['launches_profiled']} launches)")
