@@ -57,8 +57,10 @@ def model_flops_per_image(tokens_per_block, D=384, P=196, classes=1000, n0=197):
 def roofline_leg(model, x, reps=3):
     from tokenreduction_amd.stepwise import Trace, forward_stepwise
     agg = {}
+    tr = Trace(timing=True)
+    forward_stepwise(model, x, tr)          # untimed pass: fills the trace's buffer cache
     for _ in range(reps):
-        tr = Trace(timing=True)
+        tr.launches = []
         forward_stepwise(model, x, tr)
         for l in tr.launches:
             a = agg.setdefault(l["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))

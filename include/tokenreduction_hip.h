@@ -58,10 +58,12 @@ int tr_cls_pos_rows(const float* cls_token, const float* pos_embed, float* x, in
 int tr_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* bias, void* out, const float* aux, int aux_i,
                  int M, int N, int K, int epilogue, tr_stream_t s);
 
-/* a4 nn.LayerNorm(D, eps) rows of a fp32 residual stream -> bf16 (topk.py:86 norm1, :95 norm2, :201 norm).
+/* a4 nn.LayerNorm(D, eps) rows of the fp32 residual stream -> bf16 (topk.py:86 norm1, :95 norm2, :201 norm), with the
+ * PENDING residual add folded in: if delta != NULL (bf16 rows at stride ldd: the output of attn.proj / mlp.fc2),
+ * x[row] += delta[row] is written back first (`x = x + drop_path(...)`, topk.py:87 / :95), then y[row] = LN(x[row]).
  * x fp32 rows at stride ldx (floats); y bf16 [M,D].  D % 4 == 0, D <= 1024. */
-int tr_layernorm_bf16(const float* x, long ldx, const float* gamma, const float* beta, uint16_t* y, int M, int D,
-                      float eps, tr_stream_t s);
+int tr_layernorm_bf16(float* x, long ldx, const uint16_t* delta, long ldd, const float* gamma, const float* beta, uint16_t* y,
+                      int M, int D, float eps, tr_stream_t s);
 
 /* a3 (topk.py:44-51 == deit_viz.py:43-51): softmax(q k^T / sqrt(64)) v for every (image, head).
  * qkv bf16 [B*N, 3*H*64] (columns [q|k|v], head-major), out bf16 [B*N, H*64].
@@ -78,10 +80,11 @@ int tr_cls_topk(const float* cls_rows, int32_t* idx, int32_t* compl_idx, float* 
                 tr_stream_t s);
 
 /* a7 (topk.py:89-93) [+ a9 evit.py:111-123] fused with norm2 (topk.py:95):
+ * with x := x + delta when delta != NULL (bf16 [B,N,D], the pending attn.proj output -- topk.py:87 precedes the gather):
  * x_out[b,0]=x[b,0]; x_out[b,1+r]=x[b,1+idx[b,r]] (r<K); if compl_idx: x_out[b,K+1]=sum_j x[b,1+compl[b,j]]*scores[b,compl[b,j]].
  * Also y = LayerNorm(x_out) in bf16.  x fp32 [B,N,D] -> x_out fp32 [B,N_out,D], y bf16 [B,N_out,D],
  * N_out = K+1 (+1 with fuse).  idx == NULL means identity (N_out = N, x_out may be NULL -> only y written). */
-int tr_gather_layernorm_bf16(const float* x, const int32_t* idx, const int32_t* compl_idx, const float* scores,
+int tr_gather_layernorm_bf16(const float* x, const uint16_t* delta, const int32_t* idx, const int32_t* compl_idx, const float* scores,
                              const float* gamma, const float* beta, float* x_out, uint16_t* y, int B, int N, int K,
                              int D, float eps, tr_stream_t s);
 

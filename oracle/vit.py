@@ -133,14 +133,14 @@ def attention(xn: Tensor, qkv_w: Tensor, qkv_b: Tensor, proj_w: Tensor, proj_b: 
         attn = s.softmax(dim=-1)
         o = attn @ v
     o = _r(o.transpose(1, 2).reshape(B, N, D), precision)
-    out = o @ _r(proj_w, precision).t() + proj_b
+    out = _r(o @ _r(proj_w, precision).t() + proj_b, precision)   # bf16 mode: the Linear output is stored in bf16
     return out, attn[:, :, 0, :]
 
 
 def mlp(xn: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, precision: str = "fp32") -> Tensor:
     """timm Mlp: fc1 -> GELU(erf) -> fc2 (dropouts are identity in eval)."""
     h = _r(gelu_erf(xn @ _r(w1, precision).t() + b1), precision)
-    return h @ _r(w2, precision).t() + b2
+    return _r(h @ _r(w2, precision).t() + b2, precision)
 
 
 def head(x: Tensor, norm_w: Tensor, norm_b: Tensor, head_w: Tensor, head_b: Tensor,

@@ -113,6 +113,20 @@ def test_layernorm(ops, M, D):
     assert_close_bf16(got, want, "layernorm", ulps=1.01, abs_floor=1e-4)
 
 
+@pytest.mark.parametrize("M,D", [(394, 384), (9, 768), (5, 128)])
+def test_layernorm_with_pending_residual(ops, M, D):
+    """x += delta (bf16 Linear output) written back, then LayerNorm: `x = x + drop_path(...)` folded into the next norm."""
+    rng = _rng(M * 3 + D)
+    x, d = _randn(rng, M, D), _bf(_randn(rng, M, D, scale=0.3))
+    g, b = 1 + _randn(rng, D, scale=0.1), _randn(rng, D, scale=0.1)
+    xd = x.clone().cuda()
+    got = ops.layernorm(xd, g.cuda(), b.cuda(), 1e-6, delta=d.cuda().bfloat16())
+    want_x = x + d                                        # exact in fp32: one add
+    assert torch.equal(xd.cpu(), want_x)
+    want = torch.nn.functional.layer_norm(want_x.double(), (D,), g.double(), b.double(), 1e-6).float()
+    assert_close_bf16(got, want, "add+layernorm", ulps=1.01, abs_floor=1e-4)
+
+
 def test_layernorm_strided_rows(ops):
     rng = _rng(9)
     B, N, D = 4, 69, 384
@@ -120,6 +134,12 @@ def test_layernorm_strided_rows(ops):
     want = torch.nn.functional.layer_norm(x[:, 0].double(), (D,), g.double(), b.double(), 1e-6).float()
     got = ops.layernorm(x.cuda(), g.cuda(), b.cuda(), 1e-6, rows=B, ldx=N * D)
     assert_close_bf16(got, want, "layernorm cls rows", ulps=1.01, abs_floor=1e-4)
+    d = _bf(_randn(rng, B, N, D, scale=0.2))
+    xd = x.clone().cuda()
+    got = ops.layernorm(xd, g.cuda(), b.cuda(), 1e-6, rows=B, ldx=N * D, delta=d.cuda().bfloat16(), ldd=N * D)
+    want = torch.nn.functional.layer_norm((x[:, 0] + d[:, 0]).double(), (D,), g.double(), b.double(), 1e-6).float()
+    assert_close_bf16(got, want, "add+layernorm cls rows", ulps=1.01, abs_floor=1e-4)
+    assert torch.equal(xd.cpu()[:, 0], x[:, 0] + d[:, 0]) and torch.equal(xd.cpu()[:, 1:], x[:, 1:])
 
 
 # ------------------------------------------------------------------------------------------ attention
@@ -209,11 +229,16 @@ def test_cls_topk_ties_lowest_index_first(ops):
 
 
 # ------------------------------------------------------------------------------------------ gather (+fuse) + LN2
+@pytest.mark.parametrize("with_delta", [False, True])
 @pytest.mark.parametrize("fuse", [False, True])
 @pytest.mark.parametrize("B,N,K,D", [(3, 197, 137, 384), (2, 138, 96, 128), (2, 98, 67, 768), (1, 5, 1, 192)])
-def test_gather_layernorm(ops, fuse, B, N, K, D):
+def test_gather_layernorm(ops, fuse, with_delta, B, N, K, D):
     rng = _rng(N + K + D + fuse)
     x = _randn(rng, B, N, D)
+    delta = _bf(_randn(rng, B, N, D, scale=0.3)) if with_delta else None
+    x_in = x
+    if with_delta:
+        x = x + delta          # what the kernel must gather from (exact fp32 add)
     scores = torch.from_numpy(rng.random((B, N - 1)).astype(np.float32))
     g, b = 1 + _randn(rng, D, scale=0.1), _randn(rng, D, scale=0.1)
     idx = oracle.cls_topk_select(scores, K)
@@ -221,8 +246,9 @@ def test_gather_layernorm(ops, fuse, B, N, K, D):
         want_x, compl = oracle.evit_fuse(x, idx, scores)
     else:
         want_x, compl = oracle.gather_compact(x, idx), None
-    got_x, got_y = ops.gather_layernorm(x.cuda(), idx.int().cuda(), None if compl is None else compl.int().cuda(),
-                                        scores.cuda() if fuse else None, g.cuda(), b.cuda(), 1e-6)
+    got_x, got_y = ops.gather_layernorm(x_in.cuda(), idx.int().cuda(), None if compl is None else compl.int().cuda(),
+                                        scores.cuda() if fuse else None, g.cuda(), b.cuda(), 1e-6,
+                                        delta=None if delta is None else delta.cuda().bfloat16())
     # gathered rows are pure copies: bit exact; the fused row is a (P-K)-term fp32 sum: 1e-5 relative
     assert torch.equal(got_x.cpu()[:, :K + 1], want_x[:, :K + 1])
     if fuse:

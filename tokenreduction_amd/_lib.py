@@ -41,10 +41,10 @@ SIGNATURES = {
     "tr_im2col_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tr_cls_pos_rows": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "tr_gemm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "tr_layernorm_bf16": (_i, [_vp, _l, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "tr_layernorm_bf16": (_i, [_vp, _l, _vp, _l, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "tr_attention_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "tr_cls_topk": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "tr_gather_layernorm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    "tr_gather_layernorm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "tr_vit_workspace_bytes": (_sz, [C.POINTER(TrVitConfig), _i]),
     "tr_vit_forward": (_i, [C.POINTER(TrVitConfig), C.POINTER(TrVitWeights), _vp, _vp, _vp, _sz, _vp, _vp,
                             C.POINTER(_i), _i, _vp]),

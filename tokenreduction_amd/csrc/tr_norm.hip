@@ -1,5 +1,5 @@
 // Row-wise kernels on the fp32 residual stream (HBM-bound; one wave per token row, 16-byte accesses):
-//   tr_layernorm_bf16         nn.LayerNorm(eps=1e-6) -> bf16          (topk.py:86 norm1, :201 norm)
+//   tr_layernorm_bf16         [x += pending bf16 residual;] nn.LayerNorm(eps=1e-6) -> bf16   (topk.py:86 norm1, :201 norm)
 //   tr_gather_layernorm_bf16  Top-K gather/compact (topk.py:89-93) [+ EViT fused token evit.py:111-123]
 //                             fused with norm2 (topk.py:95): the compacted residual stream and its
 //                             normalised bf16 copy are produced in ONE pass over the kept rows.
@@ -42,23 +42,43 @@ __device__ __forceinline__ void ln_row_store(float4 (&v)[LN_MAX_CHUNKS], int nch
   }
 }
 
-__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long ldx, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, uint16_t* __restrict__ y, int M, int D,
-                                                        float eps) {
+// 4 bf16 -> 4 fp32
+__device__ __forceinline__ float4 bf16x4_to_f32(uint2 u) {
+  return make_float4(bf16_bits_to_f32((unsigned short)(u.x & 0xffffu)), bf16_bits_to_f32((unsigned short)(u.x >> 16)),
+                     bf16_bits_to_f32((unsigned short)(u.y & 0xffffu)), bf16_bits_to_f32((unsigned short)(u.y >> 16)));
+}
+
+// x[row] (+= delta[row], written back) -> y[row] = LayerNorm(x[row]).  delta is the bf16 output of the preceding Linear
+// (attn.proj or mlp.fc2): the residual add `x = x + drop_path(...)` (topk.py:87 / :95) is folded into the norm that
+// reads x next, so the GEMMs never read-modify-write the fp32 stream.
+__global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, long ldx, const uint16_t* __restrict__ delta, long ldd,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        uint16_t* __restrict__ y, int M, int D, float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int nchunks = D >> 2;
-  const float* xr = x + (size_t)row * ldx;
+  float* xr = x + (size_t)row * ldx;
   float4 v[LN_MAX_CHUNKS];
 #pragma unroll
   for (int c = 0; c < LN_MAX_CHUNKS; ++c)
     if (lane + 64 * c < nchunks) v[c] = *reinterpret_cast<const float4*>(xr + 4 * (lane + 64 * c));
+  if (delta != nullptr) {
+    const uint16_t* dr = delta + (size_t)row * ldd;
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+      if (lane + 64 * c < nchunks) {
+        const float4 d = bf16x4_to_f32(*reinterpret_cast<const uint2*>(dr + 4 * (lane + 64 * c)));
+        v[c].x += d.x; v[c].y += d.y; v[c].z += d.z; v[c].w += d.w;
+        *reinterpret_cast<float4*>(xr + 4 * (lane + 64 * c)) = v[c];
+      }
+  }
   ln_row_store(v, nchunks, lane, D, eps, gamma, beta, y + (size_t)row * D);
 }
 
 // grid: B * ceil(N_out/4) blocks; wave w of block handles output row r = 4*blk + w of image b.
-__global__ __launch_bounds__(256) void gather_layernorm_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
+__global__ __launch_bounds__(256) void gather_layernorm_kernel(const float* __restrict__ x, const uint16_t* __restrict__ delta,
+                                                               const int32_t* __restrict__ idx,
                                                                const int32_t* __restrict__ compl_idx,
                                                                const float* __restrict__ scores,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -72,6 +92,7 @@ __global__ __launch_bounds__(256) void gather_layernorm_kernel(const float* __re
   const int nchunks = D >> 2;
   const int P = N - 1;
   const float* xb = x + (size_t)b * N * D;
+  const uint16_t* db = delta ? delta + (size_t)b * N * D : nullptr;   // pending residual (bf16 proj output), same row layout
   float4 v[LN_MAX_CHUNKS];
   if (idx != nullptr && r == K + 1) {
     // EViT fused token: sum over the NOT-kept tokens, weighted by their (un-normalised) CLS attention
@@ -86,7 +107,11 @@ __global__ __launch_bounds__(256) void gather_layernorm_kernel(const float* __re
 #pragma unroll
       for (int c = 0; c < LN_MAX_CHUNKS; ++c)
         if (lane + 64 * c < nchunks) {
-          const float4 a = *reinterpret_cast<const float4*>(xr + 4 * (lane + 64 * c));
+          float4 a = *reinterpret_cast<const float4*>(xr + 4 * (lane + 64 * c));
+          if (db) {
+            const float4 d = bf16x4_to_f32(*reinterpret_cast<const uint2*>(db + (size_t)(1 + t) * D + 4 * (lane + 64 * c)));
+            a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+          }
           v[c].x += a.x * w; v[c].y += a.y * w; v[c].z += a.z * w; v[c].w += a.w * w;
         }
     }
@@ -96,7 +121,13 @@ __global__ __launch_bounds__(256) void gather_layernorm_kernel(const float* __re
     const float* xr = xb + (size_t)src * D;
 #pragma unroll
     for (int c = 0; c < LN_MAX_CHUNKS; ++c)
-      if (lane + 64 * c < nchunks) v[c] = *reinterpret_cast<const float4*>(xr + 4 * (lane + 64 * c));
+      if (lane + 64 * c < nchunks) {
+        v[c] = *reinterpret_cast<const float4*>(xr + 4 * (lane + 64 * c));
+        if (db) {
+          const float4 d = bf16x4_to_f32(*reinterpret_cast<const uint2*>(db + (size_t)src * D + 4 * (lane + 64 * c)));
+          v[c].x += d.x; v[c].y += d.y; v[c].z += d.z; v[c].w += d.w;
+        }
+      }
   }
   const size_t orow = (size_t)b * N_out + r;
   if (x_out != nullptr) {
@@ -144,19 +175,20 @@ __global__ __launch_bounds__(256) void cls_pos_kernel(const float* __restrict__ 
 
 }  // namespace
 
-extern "C" int tr_layernorm_bf16(const float* x, long ldx, const float* gamma, const float* beta, uint16_t* y, int M, int D,
-                                 float eps, tr_stream_t s) {
+extern "C" int tr_layernorm_bf16(float* x, long ldx, const uint16_t* delta, long ldd, const float* gamma, const float* beta,
+                                 uint16_t* y, int M, int D, float eps, tr_stream_t s) {
   TR_REQUIRE(x && gamma && beta && y, TR_ERR_NULL, "tr_layernorm_bf16: null pointer");
   TR_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAX_CHUNKS && ldx % 4 == 0 && ldx >= D, TR_ERR_SHAPE,
              "tr_layernorm_bf16: need D %% 4 == 0, D <= 1024, ldx %% 4 == 0 (M=%d D=%d ldx=%ld)", M, D, ldx);
+  if (delta) TR_REQUIRE(ldd % 4 == 0 && ldd >= D && ((uintptr_t)delta & 7u) == 0, TR_ERR_SHAPE, "tr_layernorm_bf16: bad delta stride %ld", ldd);
   TR_REQUIRE(tr_aligned16(x) && tr_aligned16(gamma) && tr_aligned16(beta) && tr_aligned16(y), TR_ERR_ALIGN,
              "tr_layernorm_bf16: pointers must be 16-byte aligned");
-  hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(s), x, ldx, gamma, beta, y, M, D, eps);
+  hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(s), x, ldx, delta, ldd, gamma, beta, y, M, D, eps);
   TR_CHECK_LAUNCH("tr_layernorm_bf16");
   return TR_OK;
 }
 
-extern "C" int tr_gather_layernorm_bf16(const float* x, const int32_t* idx, const int32_t* compl_idx, const float* scores,
+extern "C" int tr_gather_layernorm_bf16(const float* x, const uint16_t* delta, const int32_t* idx, const int32_t* compl_idx, const float* scores,
                                         const float* gamma, const float* beta, float* x_out, uint16_t* y, int B, int N, int K,
                                         int D, float eps, tr_stream_t s) {
   TR_REQUIRE(x && gamma && beta && y, TR_ERR_NULL, "tr_gather_layernorm_bf16: null pointer");
@@ -174,10 +206,11 @@ extern "C" int tr_gather_layernorm_bf16(const float* x, const int32_t* idx, cons
   } else {
     TR_REQUIRE(compl_idx == nullptr, TR_ERR_SHAPE, "tr_gather_layernorm_bf16: compl_idx without idx");
   }
-  TR_REQUIRE(tr_aligned16(x) && tr_aligned16(gamma) && tr_aligned16(beta) && tr_aligned16(y) && tr_aligned16(x_out),
+  TR_REQUIRE(tr_aligned16(x) && tr_aligned16(gamma) && tr_aligned16(beta) && tr_aligned16(y) && tr_aligned16(x_out) &&
+                 tr_aligned16(delta),
              TR_ERR_ALIGN, "tr_gather_layernorm_bf16: pointers must be 16-byte aligned");
   const int rblocks = (N_out + 3) / 4;
-  hipLaunchKernelGGL(gather_layernorm_kernel, dim3(B * rblocks), dim3(256), 0, static_cast<hipStream_t>(s), x, idx, compl_idx,
+  hipLaunchKernelGGL(gather_layernorm_kernel, dim3(B * rblocks), dim3(256), 0, static_cast<hipStream_t>(s), x, delta, idx, compl_idx,
                      scores, gamma, beta, x_out, y, N, K, N_out, D, eps);
   TR_CHECK_LAUNCH("tr_gather_layernorm_bf16");
   return TR_OK;

@@ -30,7 +30,7 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 struct Plan {
   int P, N0, D, H, Hd, C, kcols;
-  size_t off_x0, off_x1, off_xn, off_qkv, off_ao, off_h, off_cols, off_cls, off_scores, off_idx, off_compl, off_xcls, total;
+  size_t off_x0, off_x1, off_xn, off_qkv, off_ao, off_h, off_d, off_cols, off_cls, off_scores, off_idx, off_compl, off_xcls, total;
 };
 
 bool make_plan(const tr_vit_config* c, int B, Plan* p) {
@@ -56,6 +56,7 @@ bool make_plan(const tr_vit_config* c, int B, Plan* p) {
   p->off_qkv = o;    o += align_up(T * 3 * p->D * 2);
   p->off_ao = o;     o += align_up(T * p->D * 2);
   p->off_h = o;      o += align_up(T * p->Hd * 2);
+  p->off_d = o;      o += align_up(T * p->D * 2);
   p->off_cols = o;   o += align_up((size_t)B * p->P * p->kcols * 2);
   p->off_cls = o;    o += align_up((size_t)B * p->H * p->N0 * 4);
   p->off_scores = o; o += align_up((size_t)B * p->P * 4);
@@ -98,6 +99,7 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
   uint16_t* qkv = reinterpret_cast<uint16_t*>(ws + p.off_qkv);
   uint16_t* ao = reinterpret_cast<uint16_t*>(ws + p.off_ao);
   uint16_t* hbuf = reinterpret_cast<uint16_t*>(ws + p.off_h);
+  uint16_t* dbuf = reinterpret_cast<uint16_t*>(ws + p.off_d);   // bf16 output of proj / fc2, added to x by the NEXT norm
   uint16_t* cols = reinterpret_cast<uint16_t*>(ws + p.off_cols);
   float* cls_rows = reinterpret_cast<float*>(ws + p.off_cls);
   float* scores = reinterpret_cast<float*>(ws + p.off_scores);
@@ -112,39 +114,41 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
   TR_TRY(tr_cls_pos_rows(w->cls_token, w->pos_embed, x, B, p.N0, D, s));
 
   int N = p.N0;
+  const uint16_t* pending = nullptr;   // residual not yet added to x (the previous block's fc2 output)
   for (int i = 0; i < cfg->depth; ++i) {
     const tr_block_weights* bw = &w->blocks[i];
     int K = (cfg->family == TR_FAMILY_DEIT) ? 0 : cfg->keep[i];
     TR_REQUIRE(K >= 0 && K <= N - 1, TR_ERR_CONFIG, "tr_vit_forward: block %d keeps %d of %d patch tokens", i, K, N - 1);
     if (K == N - 1) K = 0;  // topk.py:57 / evit.py:79: left_tokens == N-1 -> plain block
     const int M = B * N;
-    // x += proj(attn(norm1(x)))
-    TR_TRY(tr_layernorm_bf16(x, D, bw->ln1_g, bw->ln1_b, xn, M, D, cfg->ln_eps, s));
+    // x (+= previous mlp output); attn(norm1(x)) -> dbuf   [x + dbuf is the reference's post-attention x, topk.py:87]
+    TR_TRY(tr_layernorm_bf16(x, D, pending, D, bw->ln1_g, bw->ln1_b, xn, M, D, cfg->ln_eps, s));
     TR_TRY(tr_gemm_bf16(xn, bw->qkv_w, bw->qkv_b, qkv, nullptr, 0, M, 3 * D, D, TR_EPI_BF16, s));
     TR_TRY(tr_attention_bf16(qkv, ao, K > 0 ? cls_rows : nullptr, B, N, H, s));
-    TR_TRY(tr_gemm_bf16(ao, bw->proj_w, bw->proj_b, x, nullptr, 0, M, D, D, TR_EPI_RESID_F32, s));
+    TR_TRY(tr_gemm_bf16(ao, bw->proj_w, bw->proj_b, dbuf, nullptr, 0, M, D, D, TR_EPI_BF16, s));
     int Nn = N;
     if (K > 0) {
-      // Top-K on the CLS attention, then gather/compact (+ EViT fused token) fused with norm2
+      // Top-K on the CLS attention, then residual add + gather/compact (+ EViT fused token) + norm2 in one pass
       const bool fuse = cfg->family == TR_FAMILY_EVIT;
       int32_t* idx_dst = kept_idx ? kept_idx + (size_t)i * B * p.P : idx_ws;
       int32_t* compl_dst = fuse ? (compl_idx ? compl_idx + (size_t)i * B * p.P : compl_ws) : nullptr;
       TR_TRY(tr_cls_topk(cls_rows, idx_dst, compl_dst, scores, B, H, N, K, s));
-      TR_TRY(tr_gather_layernorm_bf16(x, idx_dst, compl_dst, scores, bw->ln2_g, bw->ln2_b, x_alt, xn, B, N, K, D, cfg->ln_eps, s));
+      TR_TRY(tr_gather_layernorm_bf16(x, dbuf, idx_dst, compl_dst, scores, bw->ln2_g, bw->ln2_b, x_alt, xn, B, N, K, D, cfg->ln_eps, s));
       float* t = x; x = x_alt; x_alt = t;
       Nn = K + 1 + (fuse ? 1 : 0);
     } else {
-      TR_TRY(tr_layernorm_bf16(x, D, bw->ln2_g, bw->ln2_b, xn, M, D, cfg->ln_eps, s));
+      TR_TRY(tr_layernorm_bf16(x, D, dbuf, D, bw->ln2_g, bw->ln2_b, xn, M, D, cfg->ln_eps, s));
     }
     N = Nn;
     const int M2 = B * N;
-    // x += fc2(gelu(fc1(norm2(x))))
+    // mlp(norm2(x)) -> dbuf, added to x by the next block's norm1 (or the final norm)
     TR_TRY(tr_gemm_bf16(xn, bw->fc1_w, bw->fc1_b, hbuf, nullptr, 0, M2, p.Hd, D, TR_EPI_GELU_BF16, s));
-    TR_TRY(tr_gemm_bf16(hbuf, bw->fc2_w, bw->fc2_b, x, nullptr, 0, M2, D, p.Hd, TR_EPI_RESID_F32, s));
+    TR_TRY(tr_gemm_bf16(hbuf, bw->fc2_w, bw->fc2_b, dbuf, nullptr, 0, M2, D, p.Hd, TR_EPI_BF16, s));
+    pending = dbuf;
     if (tokens_out) tokens_out[i] = N;
   }
-  // a5: norm on the CLS rows only (LayerNorm is per-row), then the classifier
-  TR_TRY(tr_layernorm_bf16(x, (long)N * D, w->norm_g, w->norm_b, xcls, B, D, cfg->ln_eps, s));
+  // a5: (x += last mlp output and) norm on the CLS rows only (LayerNorm is per-row), then the classifier
+  TR_TRY(tr_layernorm_bf16(x, (long)N * D, pending, (long)N * D, w->norm_g, w->norm_b, xcls, B, D, cfg->ln_eps, s));
   TR_TRY(tr_gemm_bf16(xcls, w->head_w, w->head_b, logits, nullptr, 0, B, p.C, D, TR_EPI_F32, s));
   return TR_OK;
 }

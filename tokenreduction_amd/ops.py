@@ -64,13 +64,16 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, epilogue: int, ou
     return out
 
 
-def layernorm(x: torch.Tensor, gamma, beta, eps: float, rows: int = None, ldx: int = None) -> torch.Tensor:
-    """nn.LayerNorm over the last dim of a fp32 [M,D] tensor -> bf16 [M,D] (optionally `rows` rows at stride ldx)."""
+def layernorm(x: torch.Tensor, gamma, beta, eps: float, rows: int = None, ldx: int = None, delta: torch.Tensor = None,
+              ldd: int = None) -> torch.Tensor:
+    """[x += delta (bf16, written back);] nn.LayerNorm over the last dim of fp32 x -> bf16 [M,D]
+    (optionally only `rows` rows at stride ldx / ldd)."""
     D = x.shape[-1]
     M = rows if rows is not None else x.numel() // D
     ld = ldx if ldx is not None else D
     y = torch.empty(M, D, dtype=torch.bfloat16, device=x.device)
-    _lib.check(_lib.load().tr_layernorm_bf16(_dev(x, torch.float32, "x"), ld, _dev(gamma, torch.float32, "gamma"),
+    _lib.check(_lib.load().tr_layernorm_bf16(_dev(x, torch.float32, "x"), ld, _opt(delta, torch.bfloat16, "delta"),
+                                             ldd if ldd is not None else D, _dev(gamma, torch.float32, "gamma"),
                                              _dev(beta, torch.float32, "beta"), y.data_ptr(), M, D, eps, _stream()),
                "tr_layernorm_bf16")
     return y
@@ -99,8 +102,9 @@ def cls_topk(cls_rows: torch.Tensor, K: int, want_compl: bool = False):
     return idx, compl, scores
 
 
-def gather_layernorm(x: torch.Tensor, idx, compl, scores, gamma, beta, eps: float):
+def gather_layernorm(x: torch.Tensor, idx, compl, scores, gamma, beta, eps: float, delta: torch.Tensor = None):
     """Top-K gather/compact (topk.py:89-93) [+ EViT fused token evit.py:111-123] fused with norm2.
+    With delta (bf16 [B,N,D], pending attn.proj output) the gather reads x + delta.
     x fp32 [B,N,D] -> (x_out fp32 [B,N_out,D], y bf16 [B,N_out,D])."""
     B, N, D = x.shape
     K = idx.shape[1]
@@ -108,7 +112,7 @@ def gather_layernorm(x: torch.Tensor, idx, compl, scores, gamma, beta, eps: floa
     x_out = torch.empty(B, N_out, D, dtype=torch.float32, device=x.device)
     y = torch.empty(B, N_out, D, dtype=torch.bfloat16, device=x.device)
     _lib.check(_lib.load().tr_gather_layernorm_bf16(
-        _dev(x, torch.float32, "x"), _dev(idx, torch.int32, "idx"), _opt(compl, torch.int32, "compl"),
+        _dev(x, torch.float32, "x"), _opt(delta, torch.bfloat16, "delta"), _dev(idx, torch.int32, "idx"), _opt(compl, torch.int32, "compl"),
         _opt(scores, torch.float32, "scores"), _dev(gamma, torch.float32, "gamma"), _dev(beta, torch.float32, "beta"),
         x_out.data_ptr(), y.data_ptr(), B, N, K, D, eps, _stream()), "tr_gather_layernorm_bf16")
     return x_out, y

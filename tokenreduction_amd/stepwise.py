@@ -23,6 +23,7 @@ class Trace:
         self.launches: List[dict] = []
         self.tensors: Dict[str, torch.Tensor] = {}
         self._pending = []
+        self._bufs = {}
 
     def run(self, name: str, flops: float, nbytes: float, fn: Callable):
         if not self.timing:
@@ -40,6 +41,14 @@ class Trace:
             self.launches.append(dict(kernel=name, flops=flops, bytes=nbytes, ms=e0.elapsed_time(e1)))
         self._pending = []
 
+    def buf(self, name: str, shape, dtype, device):
+        """Reusable output buffer: keeps torch's allocator (and its hipMalloc/hipFree stalls) out of the timed launches."""
+        key = (name, tuple(shape), dtype)
+        t = self._bufs.get(key)
+        if t is None:
+            t = self._bufs[key] = torch.empty(shape, dtype=dtype, device=device)
+        return t
+
     def save(self, name: str, t: torch.Tensor):
         if self.keep:
             self.tensors[name] = t.clone()
@@ -50,9 +59,12 @@ _EPI_NAME = {ops.TR_EPI_BF16: "gemm_bf16_persistent<EPI_BF16>", ops.TR_EPI_GELU_
              ops.TR_EPI_PATCH_F32: "gemm_bf16_persistent<EPI_PATCH_F32>"}
 
 
-def _gemm(tr: Trace, a, w, b, epi, out=None, aux=None, aux_i=0):
+def _gemm(tr: Trace, a, w, b, epi, out=None, aux=None, aux_i=0, tag=""):
     M, K = a.shape
     N = w.shape[0]
+    if out is None:
+        out = tr.buf("gemm" + tag, (M, N), torch.bfloat16 if epi in (ops.TR_EPI_BF16, ops.TR_EPI_GELU_BF16) else torch.float32,
+                     a.device)
     obytes = 2 if epi in (ops.TR_EPI_BF16, ops.TR_EPI_GELU_BF16) else (8 if epi == ops.TR_EPI_RESID_F32 else 4)
     nbytes = 2.0 * M * K + 2.0 * N * K + float(obytes) * M * N
     return tr.run(_EPI_NAME[epi], 2.0 * M * N * K, nbytes, lambda: ops.gemm(a, w, b, epi, out=out, aux=aux, aux_i=aux_i))
@@ -81,37 +93,40 @@ def forward_stepwise(model: VisionTransformer, x: torch.Tensor, trace: Optional[
     info = dict(kept={}, compl={}, scores={}, tokens=[])
     eps = float(model.norm.eps)
     fuse = cfg.family == 2
+    pending = None     # bf16 residual not yet added to h (previous block's fc2 output)
     for i, blk in enumerate(model.blocks):
         K = 0 if cfg.family == 0 else int(cfg.keep[i])
         if K == N - 1:
             K = 0
         M = B * N
-        xn = tr.run("layernorm_kernel", 0.0, 6.0 * M * D, lambda: ops.layernorm(h, f32(blk.norm1.weight), f32(blk.norm1.bias), eps))
-        qkv = _gemm(tr, xn, bf(blk.attn.qkv.weight), f32(blk.attn.qkv.bias), ops.TR_EPI_BF16)
+        xn = tr.run("layernorm_kernel", 0.0, (6.0 if pending is None else 12.0) * M * D,
+                    lambda: ops.layernorm(h, f32(blk.norm1.weight), f32(blk.norm1.bias), eps, delta=pending))
+        qkv = _gemm(tr, xn, bf(blk.attn.qkv.weight), f32(blk.attn.qkv.bias), ops.TR_EPI_BF16, tag="qkv")
         ao, cls_rows = tr.run("attention_kernel", 4.0 * B * H * N * N * 64, 2.0 * M * 4 * D,
                               lambda: ops.attention(qkv, B, N, H, want_cls=K > 0))
         tr.save(f"attn_out_{i}", ao)
-        _gemm(tr, ao, bf(blk.attn.proj.weight), f32(blk.attn.proj.bias), ops.TR_EPI_RESID_F32, out=h)
+        d1 = _gemm(tr, ao, bf(blk.attn.proj.weight), f32(blk.attn.proj.bias), ops.TR_EPI_BF16, tag="d1")
         if K > 0:
             idx, compl, scores = tr.run("cls_topk_kernel", 0.0, 4.0 * B * (H * N + N),
                                         lambda: ops.cls_topk(cls_rows, K, want_compl=fuse))
             info["kept"][i], info["compl"][i], info["scores"][i] = idx, compl, scores
-            tr.save(f"pre_gather_{i}", h.view(B, N, D))
             Nn = K + 1 + (1 if fuse else 0)
-            h3, xn = tr.run("gather_layernorm_kernel", 0.0, 10.0 * B * Nn * D,
+            h3, xn = tr.run("gather_layernorm_kernel", 0.0, 12.0 * B * Nn * D,
                             lambda: ops.gather_layernorm(h.view(B, N, D), idx, compl, scores if fuse else None,
-                                                         f32(blk.norm2.weight), f32(blk.norm2.bias), eps))
+                                                         f32(blk.norm2.weight), f32(blk.norm2.bias), eps, delta=d1.view(B, N, D)))
             h = h3.view(B * Nn, D)
             xn = xn.view(B * Nn, D)
             N = Nn
         else:
-            xn = tr.run("layernorm_kernel", 0.0, 6.0 * M * D, lambda: ops.layernorm(h, f32(blk.norm2.weight), f32(blk.norm2.bias), eps))
-        hid = _gemm(tr, xn, bf(blk.mlp.fc1.weight), f32(blk.mlp.fc1.bias), ops.TR_EPI_GELU_BF16)
-        _gemm(tr, hid, bf(blk.mlp.fc2.weight), f32(blk.mlp.fc2.bias), ops.TR_EPI_RESID_F32, out=h)
+            xn = tr.run("layernorm_kernel", 0.0, 12.0 * M * D,
+                        lambda: ops.layernorm(h, f32(blk.norm2.weight), f32(blk.norm2.bias), eps, delta=d1))
+        hid = _gemm(tr, xn, bf(blk.mlp.fc1.weight), f32(blk.mlp.fc1.bias), ops.TR_EPI_GELU_BF16, tag="hid")
+        pending = _gemm(tr, hid, bf(blk.mlp.fc2.weight), f32(blk.mlp.fc2.bias), ops.TR_EPI_BF16, tag="d2")
         info["tokens"].append(N)
         tr.save(f"block_{i}", h.view(B, N, D))
-    xc = tr.run("layernorm_kernel", 0.0, 6.0 * B * D,
-                lambda: ops.layernorm(h, f32(model.norm.weight), f32(model.norm.bias), eps, rows=B, ldx=N * D))
+    xc = tr.run("layernorm_kernel", 0.0, 12.0 * B * D,
+                lambda: ops.layernorm(h, f32(model.norm.weight), f32(model.norm.bias), eps, rows=B, ldx=N * D, delta=pending,
+                                      ldd=N * D))
     logits = _gemm(tr, xc, bf(model.head.weight), f32(model.head.bias), ops.TR_EPI_F32)
     if tr.timing:
         tr.finish()
