@@ -48,6 +48,7 @@ const char* tr_last_error(void);
 /* a1 (PatchEmbed, call site topk.py:181): unfold 16x16 patches.  img fp32 [B,C,H,W] ->
  * cols bf16 [B*(H/p)*(W/p), C*p*p], column order (c, iy, ix) = Conv2d weight.view(D,-1) order. */
 int tr_im2col_bf16(const float* img, uint16_t* cols, int B, int C, int H, int W, int patch, tr_stream_t s);
+int tr_im2col_f32(const float* img, float* cols, int B, int C, int H, int W, int patch, tr_stream_t s);   /* fp32 validation path */
 
 /* a2 (topk.py:183-186): x[b*N + 0, :] = cls_token + pos_embed[0] for every image (fp32). */
 int tr_cls_pos_rows(const float* cls_token, const float* pos_embed, float* x, int B, int N, int D, tr_stream_t s);
@@ -64,6 +65,8 @@ int tr_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* bias, void* 
  * x fp32 rows at stride ldx (floats); y bf16 [M,D].  D % 4 == 0, D <= 1024. */
 int tr_layernorm_bf16(float* x, long ldx, const uint16_t* delta, long ldd, const float* gamma, const float* beta, uint16_t* y,
                       int M, int D, float eps, tr_stream_t s);
+int tr_layernorm_f32(float* x, long ldx, const float* delta, long ldd, const float* gamma, const float* beta, float* y, int M,
+                     int D, float eps, tr_stream_t s);                                                  /* fp32 validation path */
 
 /* a3 (topk.py:44-51 == deit_viz.py:43-51): softmax(q k^T / sqrt(64)) v for every (image, head).
  * qkv bf16 [B*N, 3*H*64] (columns [q|k|v], head-major), out bf16 [B*N, H*64].
@@ -71,6 +74,8 @@ int tr_layernorm_bf16(float* x, long ldx, const uint16_t* delta, long ldd, const
  * the only part of the N x N matrix the reduction reads, so the matrix is never materialised.
  * N <= 224 in this round (whole score row in registers); larger N returns TR_ERR_SHAPE. */
 int tr_attention_bf16(const uint16_t* qkv, uint16_t* out, float* cls_rows, int B, int N, int H, tr_stream_t s);
+/* fp32 validation path (N <= 256): same contract in the reference's arithmetic (expf softmax, fp32 everywhere). */
+int tr_attention_f32(const float* qkv, float* out, float* cls_rows, int B, int N, int H, tr_stream_t s);
 
 /* a6 (topk.py:55-65 == evit.py:77-87) + a8 (evit.py:25-46 complement_idx):
  * scores[b,j] = mean_h cls_rows[b,h,1+j] (j < P = N-1); idx[b,:K] = indices of the K largest scores in
@@ -87,6 +92,14 @@ int tr_cls_topk(const float* cls_rows, int32_t* idx, int32_t* compl_idx, float* 
 int tr_gather_layernorm_bf16(const float* x, const uint16_t* delta, const int32_t* idx, const int32_t* compl_idx, const float* scores,
                              const float* gamma, const float* beta, float* x_out, uint16_t* y, int B, int N, int K,
                              int D, float eps, tr_stream_t s);
+int tr_gather_layernorm_f32(const float* x, const float* delta, const int32_t* idx, const int32_t* compl_idx, const float* scores,
+                            const float* gamma, const float* beta, float* x_out, float* y, int B, int N, int K, int D,
+                            float eps, tr_stream_t s);                                                  /* fp32 validation path */
+
+/* fp32 validation path of the Linear layers: A fp32 [M,K], W fp32 [N,K], out fp32; K % 16 == 0.
+ * epilogue: TR_EPI_F32 (bias), TR_EPI_GELU_BF16 (bias + exact-erf GELU, fp32 out), TR_EPI_PATCH_F32. */
+int tr_gemm_f32(const float* A, const float* W, const float* bias, float* out, const float* aux, int aux_i, int M, int N, int K,
+                int epilogue, tr_stream_t s);
 
 /* ---- whole-model executor: TopKVisionTransformer.forward topk.py:179-212,
  *      EfficientVisionTransformer.forward evit.py:209-244, deit_viz.VisionTransformer.forward :186-212 (eval) ---- */
@@ -94,21 +107,24 @@ int tr_gather_layernorm_bf16(const float* x, const uint16_t* delta, const int32_
 #define TR_FAMILY_TOPK 1
 #define TR_FAMILY_EVIT 2
 #define TR_MAX_DEPTH 32
+#define TR_PREC_BF16 0   /* the product path: bf16 MFMA operands, fp32 accumulate / residual / statistics */
+#define TR_PREC_FP32 1   /* validation path: the reference's own arithmetic on the GPU (bit-exact indices vs its golden vectors) */
 
+/* Weight MATRICES are bf16 (uint16_t bits) when cfg.precision == TR_PREC_BF16 and fp32 when TR_PREC_FP32; vectors are fp32. */
 typedef struct {
   const float* ln1_g; const float* ln1_b;
-  const uint16_t* qkv_w; const float* qkv_b;     /* [3D,D] bf16, [3D] */
-  const uint16_t* proj_w; const float* proj_b;   /* [D,D], [D] */
+  const void* qkv_w; const float* qkv_b;     /* [3D,D], [3D] */
+  const void* proj_w; const float* proj_b;   /* [D,D], [D] */
   const float* ln2_g; const float* ln2_b;
-  const uint16_t* fc1_w; const float* fc1_b;     /* [Hd,D], [Hd] */
-  const uint16_t* fc2_w; const float* fc2_b;     /* [D,Hd], [D] */
+  const void* fc1_w; const float* fc1_b;     /* [Hd,D], [Hd] */
+  const void* fc2_w; const float* fc2_b;     /* [D,Hd], [D] */
 } tr_block_weights;
 
 typedef struct {
-  const uint16_t* patch_w; const float* patch_b; /* [D, C*p*p] bf16, [D] */
+  const void* patch_w; const float* patch_b;     /* [D, C*p*p], [D] */
   const float* cls_token; const float* pos_embed;/* [D], [(P+1), D] fp32 */
   const float* norm_g; const float* norm_b;
-  const uint16_t* head_w; const float* head_b;   /* [classes, D] bf16, [classes] */
+  const void* head_w; const float* head_b;       /* [classes, D], [classes] */
   tr_block_weights blocks[TR_MAX_DEPTH];
 } tr_vit_weights;
 
@@ -118,6 +134,7 @@ typedef struct {
   int embed_dim, depth, num_heads, mlp_hidden, num_classes;
   float ln_eps;
   int keep[TR_MAX_DEPTH];     /* per block: K patch tokens kept by that block's Top-K, 0 = plain block */
+  int precision;              /* TR_PREC_* */
 } tr_vit_config;
 
 /* Bytes of workspace tr_vit_forward needs for batch B (0 on invalid config). */

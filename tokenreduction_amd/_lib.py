@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libtokenreduction_hip.so")
 TR_MAX_DEPTH = 32
 TR_EPI_BF16, TR_EPI_GELU_BF16, TR_EPI_RESID_F32, TR_EPI_F32, TR_EPI_PATCH_F32 = 0, 1, 2, 3, 4
 TR_FAMILY_DEIT, TR_FAMILY_TOPK, TR_FAMILY_EVIT = 0, 1, 2
+TR_PREC_BF16, TR_PREC_FP32 = 0, 1
 
 _vp, _i, _f, _l, _sz = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t
 
@@ -31,7 +32,7 @@ class TrVitWeights(C.Structure):
 class TrVitConfig(C.Structure):
     _fields_ = [("family", _i), ("img_size", _i), ("patch", _i), ("in_chans", _i), ("embed_dim", _i),
                 ("depth", _i), ("num_heads", _i), ("mlp_hidden", _i), ("num_classes", _i), ("ln_eps", _f),
-                ("keep", _i * TR_MAX_DEPTH)]
+                ("keep", _i * TR_MAX_DEPTH), ("precision", _i)]
 
 
 # every symbol include/tokenreduction_hip.h declares: name -> (restype, argtypes)
@@ -39,6 +40,11 @@ SIGNATURES = {
     "tr_version": (_i, []),
     "tr_last_error": (C.c_char_p, []),
     "tr_im2col_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "tr_im2col_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "tr_gemm_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "tr_layernorm_f32": (_i, [_vp, _l, _vp, _l, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "tr_attention_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "tr_gather_layernorm_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "tr_cls_pos_rows": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "tr_gemm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tr_layernorm_bf16": (_i, [_vp, _l, _vp, _l, _vp, _vp, _vp, _i, _i, _f, _vp]),

@@ -449,6 +449,202 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persistent(const uint16_t* _
 #undef ADVANCE_LOAD_CURSOR
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Producer/consumer variant for the bf16-output epilogues (qkv, proj, fc1+GELU, fc2 -- every per-block GEMM).
+//
+// Same tiles, ring, swizzle and epilogue as gemm_bf16_persistent above, but the DMA is issued by FOUR DEDICATED LOADER
+// WAVES (waves 8-11, one per SIMD) and the eight MFMA waves never touch the vector-memory pipe inside the K-loop.
+// Why: a wave issues in order, and the CU's address path needs ~27 cycles per 1-KiB piece -- 48 pieces per K-step =
+// 1300-1440 cycles, more than the step's 1024 MFMA cycles.  With the pieces inside the MFMA waves' streams (even
+// one piece per 4-MFMA group) every wave keeps stalling on a full address queue with its MFMAs queued behind the stall
+// (profiles/r01_gemm_lab.md: main loop 40.4 us with DMA vs 25.4 us without, DMA alone 25.6 us).  A loader wave can sit
+// in that stall all day.  Three waves per SIMD -> 168 VGPRs per wave, which the bf16 epilogues fit (no residual registers).
+// Barrier protocol (one s_barrier per K-step, all 12 waves): at barrier B_g the loaders have waited for DMA group g
+// (vmcnt(12): group g+1 may still fly) and the MFMA waves have finished READING slot (g-1)%3 (lgkmcnt(0));
+// after it the loaders refill that slot with group g+2 and the MFMA waves read slot g%3.
+template <int EPI>
+__global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
+                                                       const float* __restrict__ bias, uint16_t* __restrict__ outp, int M, int N,
+                                                       int K, int nMt, int nNt, unsigned out_bytes) {
+  static_assert(EPI == TR_EPI_BF16 || EPI == TR_EPI_GELU_BF16, "bf16-output epilogues only");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[P_NSTAGE * P_STAGE_BYTES + 8 * 2048];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nk = K / BK;
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int T = nMt * nNt;
+  const int toff = (bid & 7) * (G >> 3) + (bid >> 3);
+  if (toff >= T) return;
+  const int my_tiles = (T - toff + G - 1) / G;
+  const int S = my_tiles * nk;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+  if (wave >= 8) {
+    // ================================ loader wave: 12 pieces per K-step (A rows lw*64.., W rows lw*32..)
+    const int lw = wave - 8;
+    const int l3 = lane >> 3, pc = lane & 7;
+    // LDS position (row, chunk pc) must hold LOGICAL chunk pc ^ ((row>>1)&7); rows lw*64 + 8j + l3 and lw*32 + 8j + l3:
+    // (row>>1)&7 = (4j + (l3>>1)) & 7 for both (lw*64, lw*32 are multiples of 16)
+    unsigned o[12];
+    int l_tile = toff, l_kt = 0, l_slot = 0, l_step = 0;
+    auto set_tile = [&](int tile) __attribute__((always_inline)) {
+      const int tm0 = (tile / nNt) * PBM, tn0 = (tile % nNt) * PBN;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = (pc ^ ((4 * j + (l3 >> 1)) & 7)) * 8;
+        o[j] = ((unsigned)min(tm0 + lw * 64 + 8 * j + l3, M - 1) * K + c) * 2u;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = (pc ^ ((4 * j + (l3 >> 1)) & 7)) * 8;
+        o[8 + j] = ((unsigned)min(tn0 + lw * 32 + 8 * j + l3, N - 1) * K + c) * 2u;
+      }
+    };
+    auto issue_group = [&]() __attribute__((always_inline)) {
+      const bool real = l_step < S;
+      const unsigned da = lds0 + l_slot * P_STAGE_BYTES + lw * 8192;
+      const unsigned dw = lds0 + l_slot * P_STAGE_BYTES + PBM * 128 + lw * 4096;
+      const uint16_t* sW = real ? W : A;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) issue_piece(A, real ? o[j] : 0u, da + j * 1024);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) issue_piece(sW, real ? o[8 + j] : 0u, dw + j * 1024);
+      if (real) {
+        ++l_step;
+        l_slot = (l_slot == P_NSTAGE - 1) ? 0 : l_slot + 1;
+        if (++l_kt == nk) {
+          l_kt = 0;
+          l_tile += G;
+          if (l_step < S) set_tile(l_tile);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 12; ++j) o[j] += 2 * BK;
+        }
+      }
+    };
+    set_tile(l_tile);
+    issue_group();      // group 0 -> slot 0
+    issue_group();      // group 1 -> slot 1   (dummies if S < 2)
+    for (int g = 0; g < S; ++g) {
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");    // group g landed (group g+1 -- real or dummy -- may still fly)
+      __builtin_amdgcn_s_barrier();                        // B_g: the MFMA waves are done reading slot (g-1)%3 == (g+2)%3
+      if (g + 1 < S) issue_group();                        // group g+2 -> that slot (dummy pieces once nothing is left to load)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+
+  // ================================ MFMA wave
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 15, fq = lane >> 4;
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(outp, 0, (int)out_bytes, 0x00020000);
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8 wA[4], aA[4], wC[4], aC[4];
+#define READ_FRAGS(WF, AF, slot, ks)                                                                          \
+  do {                                                                                                        \
+    const unsigned char* sa_ = smem + (slot) * P_STAGE_BYTES;                                                 \
+    const unsigned char* sw_ = sa_ + PBM * 128;                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                        \
+      WF[i_] = *reinterpret_cast<const bf16x8*>(sw_ + swz(wn * 64 + i_ * 16 + frow, 4 * (ks) + fq));          \
+      AF[i_] = *reinterpret_cast<const bf16x8*>(sa_ + swz(wm * 64 + i_ * 16 + frow, 4 * (ks) + fq));          \
+    }                                                                                                         \
+  } while (0)
+#ifdef TR_ABLATE_NO_MFMA
+#define MFMA_GROUP(WF, AF, i_) asm volatile("" ::"v"(WF[i_]), "v"(AF[i_]))
+#else
+#define MFMA_GROUP(WF, AF, i_)                                                                               \
+  _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                                            \
+      acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[i_], AF[j_], acc[i_][j_], 0, 0, 0)
+#endif
+
+  int c_tile = toff, c_kt = 0, c_slot = 0;
+#ifdef TR_DIAG_CLOCK
+  const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  __builtin_amdgcn_s_barrier();            // B_0
+  asm volatile("" ::: "memory");
+  READ_FRAGS(wA, aA, 0, 0);
+  for (int g = 0; g < S; ++g) {
+    const bool tile_end = (c_kt == nk - 1);
+    READ_FRAGS(wC, aC, c_slot, 1);
+    f32x4 bv[4];
+    if (tile_end) {
+      const int n0 = (c_tile % nNt) * PBN;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const f32x4*>(bias + min(n0 + wn * 64 + i * 16 + 4 * fq, N - 4));
+    }
+    MFMA_GROUP(wA, aA, 0);
+    MFMA_GROUP(wA, aA, 1);
+    MFMA_GROUP(wA, aA, 2);
+    MFMA_GROUP(wA, aA, 3);
+    const int next_slot = (c_slot == P_NSTAGE - 1) ? 0 : c_slot + 1;
+    if (g + 1 < S) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own reads of slot g%3 are done: the loaders may refill it after B_{g+2}
+      __builtin_amdgcn_s_barrier();                        // B_{g+1}: group g+1 has landed
+      asm volatile("" ::: "memory");
+    }
+    READ_FRAGS(wA, aA, next_slot, 0);      // unconditional: after the last K-step it reads a stale slot, unused
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA_GROUP(wC, aC, 0);
+    MFMA_GROUP(wC, aC, 1);
+    MFMA_GROUP(wC, aC, 2);
+    MFMA_GROUP(wC, aC, 3);
+    c_slot = next_slot;
+    if (!tile_end) {
+      ++c_kt;
+      continue;
+    }
+    // ---- epilogue (same LDS-staged full-line stores as gemm_bf16_persistent)
+    {
+      unsigned char* stg = smem + P_NSTAGE * P_STAGE_BYTES + wave * 2048;
+      const int m0 = (c_tile / nNt) * PBM, n0 = (c_tile % nNt) * PBN;
+      const int rrow = lane >> 3, rch = lane & 7;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float v0 = acc[i][j][0] + bv[i][0], v1 = acc[i][j][1] + bv[i][1], v2 = acc[i][j][2] + bv[i][2], v3 = acc[i][j][3] + bv[i][3];
+          acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (EPI == TR_EPI_GELU_BF16) {
+            const f32x2 g01 = gelu2(f32x2{v0, v1}), g23 = gelu2(f32x2{v2, v3});
+            v0 = g01[0]; v1 = g01[1]; v2 = g23[0]; v3 = g23[1];
+          }
+          u32x2 pk;
+          pk[0] = pack_bf16x2(v0, v1);
+          pk[1] = pack_bf16x2(v2, v3);
+          *reinterpret_cast<u32x2*>(stg + frow * 128 + (((2 * i + (fq >> 1)) ^ (frow & 7)) << 4) + (fq & 1) * 8) = pk;
+        }
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          const int row = r * 8 + rrow;
+          const u32x4 pk = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((rch ^ (row & 7)) << 4));
+          const int m = m0 + wm * 64 + j * 16 + row;
+          const int n = n0 + wn * 64 + rch * 8;
+          const bool ok = (m < M) && (n < N);
+          const unsigned off = ok ? (unsigned)(((size_t)m * N + n) * 2) : 0x80000000u;
+          __builtin_amdgcn_raw_buffer_store_b128(pk, orsrc, off, 0, 0);
+        }
+      }
+    }
+    c_kt = 0;
+    c_tile += G;
+  }
+#ifdef TR_DIAG_CLOCK
+  if (bid == 8 && tid == 0) {   // diagnostic build only: shader clock = d(memtime) / d(memrealtime) * 100 MHz (lab allocates 4 B/elem)
+    unsigned long long* st = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(outp) + (size_t)out_bytes);
+    st[0] = __builtin_amdgcn_s_memtime() - ck0;
+    st[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+  }
+#endif
+#undef READ_FRAGS
+#undef MFMA_GROUP
+}
+
 }  // namespace
 
 extern "C" int tr_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* bias, void* out, const float* aux,
@@ -476,8 +672,19 @@ extern "C" int tr_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* b
     TR_REQUIRE(N % 64 == 0, TR_ERR_SHAPE, "tr_gemm_bf16: residual/patch epilogues need N %% 64 == 0 (got %d)", N);
   hipStream_t st = static_cast<hipStream_t>(s);
   const int nMt = (M + PBM - 1) / PBM, nNt = (N + PBN - 1) / PBN;
-  // one persistent 512-thread workgroup per CU (144 KiB LDS each); 256 CUs on MI355X.  A multiple of 8 keeps the XCD grouping.
+  // one persistent workgroup per CU (all 160 KiB of LDS each); 256 CUs on MI355X.  A multiple of 8 keeps the XCD grouping.
   dim3 grid(256), block(512);
+  if (epilogue == TR_EPI_BF16 || epilogue == TR_EPI_GELU_BF16) {
+    // the per-block GEMMs: 8 MFMA waves + 4 loader waves
+    if (epilogue == TR_EPI_BF16)
+      hipLaunchKernelGGL(gemm_bf16_pc<TR_EPI_BF16>, grid, dim3(768), 0, st, A, W, bias, static_cast<uint16_t*>(out), M, N, K, nMt, nNt,
+                         (unsigned)out_bytes);
+    else
+      hipLaunchKernelGGL(gemm_bf16_pc<TR_EPI_GELU_BF16>, grid, dim3(768), 0, st, A, W, bias, static_cast<uint16_t*>(out), M, N, K, nMt,
+                         nNt, (unsigned)out_bytes);
+    TR_CHECK_LAUNCH("tr_gemm_bf16");
+    return TR_OK;
+  }
 #define TR_LAUNCH(E)                                                                                                  \
   hipLaunchKernelGGL(gemm_bf16_persistent<E>, grid, block, 0, st, A, W, bias, out, aux, aux_i, M, N, K, nMt, nNt, \
                      (unsigned)out_bytes)

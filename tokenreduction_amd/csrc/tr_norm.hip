@@ -12,9 +12,10 @@ namespace {
 constexpr int LN_MAX_CHUNKS = 4;  // float4 chunks per lane -> D <= 1024
 
 // Normalise one row held as `nch` float4 chunks per lane; two-pass (mean, then centred variance) in registers.
+template <bool F32>
 __device__ __forceinline__ void ln_row_store(float4 (&v)[LN_MAX_CHUNKS], int nchunks, int lane, int D, float eps,
                                              const float* __restrict__ gamma, const float* __restrict__ beta,
-                                             uint16_t* __restrict__ yrow) {
+                                             void* __restrict__ yrow_) {
   float s = 0.f;
 #pragma unroll
   for (int c = 0; c < LN_MAX_CHUNKS; ++c)
@@ -27,17 +28,23 @@ __device__ __forceinline__ void ln_row_store(float4 (&v)[LN_MAX_CHUNKS], int nch
       const float a = v[c].x - mean, b = v[c].y - mean, cc = v[c].z - mean, d = v[c].w - mean;
       q += (a * a + b * b) + (cc * cc + d * d);
     }
-  const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+  const float rstd = F32 ? 1.0f / sqrtf(wave_sum(q) / (float)D + eps) : rsqrtf(wave_sum(q) / (float)D + eps);
 #pragma unroll
   for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
     const int ch = lane + 64 * c;
     if (ch < nchunks) {
       const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * ch);
       const float4 b = *reinterpret_cast<const float4*>(beta + 4 * ch);
-      uint2 pk;
-      pk.x = pack_bf16x2((v[c].x - mean) * rstd * g.x + b.x, (v[c].y - mean) * rstd * g.y + b.y);
-      pk.y = pack_bf16x2((v[c].z - mean) * rstd * g.z + b.z, (v[c].w - mean) * rstd * g.w + b.w);
-      *reinterpret_cast<uint2*>(yrow + 4 * ch) = pk;
+      const float o0 = (v[c].x - mean) * rstd * g.x + b.x, o1 = (v[c].y - mean) * rstd * g.y + b.y;
+      const float o2 = (v[c].z - mean) * rstd * g.z + b.z, o3 = (v[c].w - mean) * rstd * g.w + b.w;
+      if (F32) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(yrow_) + 4 * ch) = make_float4(o0, o1, o2, o3);
+      } else {
+        uint2 pk;
+        pk.x = pack_bf16x2(o0, o1);
+        pk.y = pack_bf16x2(o2, o3);
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(yrow_) + 4 * ch) = pk;
+      }
     }
   }
 }
@@ -48,12 +55,20 @@ __device__ __forceinline__ float4 bf16x4_to_f32(uint2 u) {
                      bf16_bits_to_f32((unsigned short)(u.y & 0xffffu)), bf16_bits_to_f32((unsigned short)(u.y >> 16)));
 }
 
+// pending-residual chunk: bf16 (fast path) or fp32 (validation path)
+template <bool F32>
+__device__ __forceinline__ float4 load_delta4(const void* base, size_t elem) {
+  if (F32) return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem);
+  return bf16x4_to_f32(*reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + elem));
+}
+
 // x[row] (+= delta[row], written back) -> y[row] = LayerNorm(x[row]).  delta is the bf16 output of the preceding Linear
 // (attn.proj or mlp.fc2): the residual add `x = x + drop_path(...)` (topk.py:87 / :95) is folded into the norm that
 // reads x next, so the GEMMs never read-modify-write the fp32 stream.
-__global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, long ldx, const uint16_t* __restrict__ delta, long ldd,
+template <bool F32>
+__global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, long ldx, const void* __restrict__ delta, long ldd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                        uint16_t* __restrict__ y, int M, int D, float eps) {
+                                                        void* __restrict__ y, int M, int D, float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -64,25 +79,26 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, l
   for (int c = 0; c < LN_MAX_CHUNKS; ++c)
     if (lane + 64 * c < nchunks) v[c] = *reinterpret_cast<const float4*>(xr + 4 * (lane + 64 * c));
   if (delta != nullptr) {
-    const uint16_t* dr = delta + (size_t)row * ldd;
 #pragma unroll
     for (int c = 0; c < LN_MAX_CHUNKS; ++c)
       if (lane + 64 * c < nchunks) {
-        const float4 d = bf16x4_to_f32(*reinterpret_cast<const uint2*>(dr + 4 * (lane + 64 * c)));
+        const float4 d = load_delta4<F32>(delta, (size_t)row * ldd + 4 * (lane + 64 * c));
         v[c].x += d.x; v[c].y += d.y; v[c].z += d.z; v[c].w += d.w;
         *reinterpret_cast<float4*>(xr + 4 * (lane + 64 * c)) = v[c];
       }
   }
-  ln_row_store(v, nchunks, lane, D, eps, gamma, beta, y + (size_t)row * D);
+  ln_row_store<F32>(v, nchunks, lane, D, eps, gamma, beta,
+                    F32 ? (void*)(reinterpret_cast<float*>(y) + (size_t)row * D) : (void*)(reinterpret_cast<uint16_t*>(y) + (size_t)row * D));
 }
 
 // grid: B * ceil(N_out/4) blocks; wave w of block handles output row r = 4*blk + w of image b.
-__global__ __launch_bounds__(256) void gather_layernorm_kernel(const float* __restrict__ x, const uint16_t* __restrict__ delta,
+template <bool F32>
+__global__ __launch_bounds__(256) void gather_layernorm_kernel(const float* __restrict__ x, const void* __restrict__ delta,
                                                                const int32_t* __restrict__ idx,
                                                                const int32_t* __restrict__ compl_idx,
                                                                const float* __restrict__ scores,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                               float* __restrict__ x_out, uint16_t* __restrict__ y, int N, int K,
+                                                               float* __restrict__ x_out, void* __restrict__ y, int N, int K,
                                                                int N_out, int D, float eps) {
   const int lane = threadIdx.x & 63;
   const int rblocks = (N_out + 3) >> 2;
@@ -92,7 +108,8 @@ __global__ __launch_bounds__(256) void gather_layernorm_kernel(const float* __re
   const int nchunks = D >> 2;
   const int P = N - 1;
   const float* xb = x + (size_t)b * N * D;
-  const uint16_t* db = delta ? delta + (size_t)b * N * D : nullptr;   // pending residual (bf16 proj output), same row layout
+  const bool has_d = delta != nullptr;                 // pending residual (proj output), same row layout as x
+  const size_t dbase = (size_t)b * N * D;
   float4 v[LN_MAX_CHUNKS];
   if (idx != nullptr && r == K + 1) {
     // EViT fused token: sum over the NOT-kept tokens, weighted by their (un-normalised) CLS attention
@@ -108,8 +125,8 @@ __global__ __launch_bounds__(256) void gather_layernorm_kernel(const float* __re
       for (int c = 0; c < LN_MAX_CHUNKS; ++c)
         if (lane + 64 * c < nchunks) {
           float4 a = *reinterpret_cast<const float4*>(xr + 4 * (lane + 64 * c));
-          if (db) {
-            const float4 d = bf16x4_to_f32(*reinterpret_cast<const uint2*>(db + (size_t)(1 + t) * D + 4 * (lane + 64 * c)));
+          if (has_d) {
+            const float4 d = load_delta4<F32>(delta, dbase + (size_t)(1 + t) * D + 4 * (lane + 64 * c));
             a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
           }
           v[c].x += a.x * w; v[c].y += a.y * w; v[c].z += a.z * w; v[c].w += a.w * w;
@@ -123,8 +140,8 @@ __global__ __launch_bounds__(256) void gather_layernorm_kernel(const float* __re
     for (int c = 0; c < LN_MAX_CHUNKS; ++c)
       if (lane + 64 * c < nchunks) {
         v[c] = *reinterpret_cast<const float4*>(xr + 4 * (lane + 64 * c));
-        if (db) {
-          const float4 d = bf16x4_to_f32(*reinterpret_cast<const uint2*>(db + (size_t)src * D + 4 * (lane + 64 * c)));
+        if (has_d) {
+          const float4 d = load_delta4<F32>(delta, dbase + (size_t)src * D + 4 * (lane + 64 * c));
           v[c].x += d.x; v[c].y += d.y; v[c].z += d.z; v[c].w += d.w;
         }
       }
@@ -136,11 +153,13 @@ __global__ __launch_bounds__(256) void gather_layernorm_kernel(const float* __re
     for (int c = 0; c < LN_MAX_CHUNKS; ++c)
       if (lane + 64 * c < nchunks) *reinterpret_cast<float4*>(xo + 4 * (lane + 64 * c)) = v[c];
   }
-  ln_row_store(v, nchunks, lane, D, eps, gamma, beta, y + orow * D);
+  ln_row_store<F32>(v, nchunks, lane, D, eps, gamma, beta,
+                    F32 ? (void*)(reinterpret_cast<float*>(y) + orow * D) : (void*)(reinterpret_cast<uint16_t*>(y) + orow * D));
 }
 
 // one thread = 8 consecutive pixels of one patch row -> one 16-byte bf16 store
-__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, uint16_t* __restrict__ cols, int B, int C, int H,
+template <bool F32>
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, void* __restrict__ cols, int B, int C, int H,
                                                      int W, int patch, long total) {
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
   if (t >= total) return;
@@ -159,10 +178,16 @@ __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ i
   const float* src = img + (((size_t)b * C + c) * H + (size_t)py * patch + iy) * W + (size_t)px * patch + ixg * 8;
   const float4 a = *reinterpret_cast<const float4*>(src);
   const float4 d = *reinterpret_cast<const float4*>(src + 4);
-  uint4 pk;
-  pk.x = pack_bf16x2(a.x, a.y); pk.y = pack_bf16x2(a.z, a.w);
-  pk.z = pack_bf16x2(d.x, d.y); pk.w = pack_bf16x2(d.z, d.w);
-  *reinterpret_cast<uint4*>(cols + rowid * kcols + (size_t)g * 8) = pk;
+  if (F32) {
+    float* o = reinterpret_cast<float*>(cols) + rowid * kcols + (size_t)g * 8;
+    *reinterpret_cast<float4*>(o) = a;
+    *reinterpret_cast<float4*>(o + 4) = d;
+  } else {
+    uint4 pk;
+    pk.x = pack_bf16x2(a.x, a.y); pk.y = pack_bf16x2(a.z, a.w);
+    pk.z = pack_bf16x2(d.x, d.y); pk.w = pack_bf16x2(d.z, d.w);
+    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(cols) + rowid * kcols + (size_t)g * 8) = pk;
+  }
 }
 
 __global__ __launch_bounds__(256) void cls_pos_kernel(const float* __restrict__ cls, const float* __restrict__ pos, float* __restrict__ x,
@@ -175,57 +200,92 @@ __global__ __launch_bounds__(256) void cls_pos_kernel(const float* __restrict__ 
 
 }  // namespace
 
-extern "C" int tr_layernorm_bf16(float* x, long ldx, const uint16_t* delta, long ldd, const float* gamma, const float* beta,
-                                 uint16_t* y, int M, int D, float eps, tr_stream_t s) {
-  TR_REQUIRE(x && gamma && beta && y, TR_ERR_NULL, "tr_layernorm_bf16: null pointer");
+static int layernorm_impl(bool f32, float* x, long ldx, const void* delta, long ldd, const float* gamma, const float* beta, void* y,
+                          int M, int D, float eps, tr_stream_t s) {
+  TR_REQUIRE(x && gamma && beta && y, TR_ERR_NULL, "tr_layernorm: null pointer");
   TR_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAX_CHUNKS && ldx % 4 == 0 && ldx >= D, TR_ERR_SHAPE,
-             "tr_layernorm_bf16: need D %% 4 == 0, D <= 1024, ldx %% 4 == 0 (M=%d D=%d ldx=%ld)", M, D, ldx);
-  if (delta) TR_REQUIRE(ldd % 4 == 0 && ldd >= D && ((uintptr_t)delta & 7u) == 0, TR_ERR_SHAPE, "tr_layernorm_bf16: bad delta stride %ld", ldd);
+             "tr_layernorm: need D %% 4 == 0, D <= 1024, ldx %% 4 == 0 (M=%d D=%d ldx=%ld)", M, D, ldx);
+  if (delta) TR_REQUIRE(ldd % 4 == 0 && ldd >= D && ((uintptr_t)delta & 7u) == 0, TR_ERR_SHAPE, "tr_layernorm: bad delta stride %ld", ldd);
   TR_REQUIRE(tr_aligned16(x) && tr_aligned16(gamma) && tr_aligned16(beta) && tr_aligned16(y), TR_ERR_ALIGN,
-             "tr_layernorm_bf16: pointers must be 16-byte aligned");
-  hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(s), x, ldx, delta, ldd, gamma, beta, y, M, D, eps);
-  TR_CHECK_LAUNCH("tr_layernorm_bf16");
+             "tr_layernorm: pointers must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(s);
+  if (f32) hipLaunchKernelGGL(layernorm_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, x, ldx, delta, ldd, gamma, beta, y, M, D, eps);
+  else hipLaunchKernelGGL(layernorm_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, x, ldx, delta, ldd, gamma, beta, y, M, D, eps);
+  TR_CHECK_LAUNCH("tr_layernorm");
   return TR_OK;
 }
 
-extern "C" int tr_gather_layernorm_bf16(const float* x, const uint16_t* delta, const int32_t* idx, const int32_t* compl_idx, const float* scores,
-                                        const float* gamma, const float* beta, float* x_out, uint16_t* y, int B, int N, int K,
-                                        int D, float eps, tr_stream_t s) {
-  TR_REQUIRE(x && gamma && beta && y, TR_ERR_NULL, "tr_gather_layernorm_bf16: null pointer");
+extern "C" int tr_layernorm_bf16(float* x, long ldx, const uint16_t* delta, long ldd, const float* gamma, const float* beta,
+                                 uint16_t* y, int M, int D, float eps, tr_stream_t s) {
+  return layernorm_impl(false, x, ldx, delta, ldd, gamma, beta, y, M, D, eps, s);
+}
+extern "C" int tr_layernorm_f32(float* x, long ldx, const float* delta, long ldd, const float* gamma, const float* beta, float* y,
+                                int M, int D, float eps, tr_stream_t s) {
+  return layernorm_impl(true, x, ldx, delta, ldd, gamma, beta, y, M, D, eps, s);
+}
+
+static int gather_layernorm_impl(bool f32, const float* x, const void* delta, const int32_t* idx, const int32_t* compl_idx,
+                                 const float* scores, const float* gamma, const float* beta, float* x_out, void* y, int B, int N,
+                                 int K, int D, float eps, tr_stream_t s) {
+  TR_REQUIRE(x && gamma && beta && y, TR_ERR_NULL, "tr_gather_layernorm: null pointer");
   TR_REQUIRE(B > 0 && N > 1 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAX_CHUNKS, TR_ERR_SHAPE,
-             "tr_gather_layernorm_bf16: bad shape B=%d N=%d D=%d", B, N, D);
+             "tr_gather_layernorm: bad shape B=%d N=%d D=%d", B, N, D);
   int N_out = N;
   if (idx != nullptr) {
-    TR_REQUIRE(K >= 1 && K <= N - 1, TR_ERR_SHAPE, "tr_gather_layernorm_bf16: K=%d out of range for N=%d", K, N);
-    TR_REQUIRE(x_out != nullptr && x_out != x, TR_ERR_NULL, "tr_gather_layernorm_bf16: gather needs a distinct x_out");
+    TR_REQUIRE(K >= 1 && K <= N - 1, TR_ERR_SHAPE, "tr_gather_layernorm: K=%d out of range for N=%d", K, N);
+    TR_REQUIRE(x_out != nullptr && x_out != x, TR_ERR_NULL, "tr_gather_layernorm: gather needs a distinct x_out");
     N_out = K + 1;
     if (compl_idx != nullptr) {
-      TR_REQUIRE(scores != nullptr, TR_ERR_NULL, "tr_gather_layernorm_bf16: fuse needs scores");
+      TR_REQUIRE(scores != nullptr, TR_ERR_NULL, "tr_gather_layernorm: fuse needs scores");
       N_out = K + 2;
     }
   } else {
-    TR_REQUIRE(compl_idx == nullptr, TR_ERR_SHAPE, "tr_gather_layernorm_bf16: compl_idx without idx");
+    TR_REQUIRE(compl_idx == nullptr, TR_ERR_SHAPE, "tr_gather_layernorm: compl_idx without idx");
   }
   TR_REQUIRE(tr_aligned16(x) && tr_aligned16(gamma) && tr_aligned16(beta) && tr_aligned16(y) && tr_aligned16(x_out) &&
                  tr_aligned16(delta),
-             TR_ERR_ALIGN, "tr_gather_layernorm_bf16: pointers must be 16-byte aligned");
+             TR_ERR_ALIGN, "tr_gather_layernorm: pointers must be 16-byte aligned");
   const int rblocks = (N_out + 3) / 4;
-  hipLaunchKernelGGL(gather_layernorm_kernel, dim3(B * rblocks), dim3(256), 0, static_cast<hipStream_t>(s), x, delta, idx, compl_idx,
-                     scores, gamma, beta, x_out, y, N, K, N_out, D, eps);
-  TR_CHECK_LAUNCH("tr_gather_layernorm_bf16");
+  hipStream_t st = static_cast<hipStream_t>(s);
+  if (f32)
+    hipLaunchKernelGGL(gather_layernorm_kernel<true>, dim3(B * rblocks), dim3(256), 0, st, x, delta, idx, compl_idx, scores, gamma,
+                       beta, x_out, y, N, K, N_out, D, eps);
+  else
+    hipLaunchKernelGGL(gather_layernorm_kernel<false>, dim3(B * rblocks), dim3(256), 0, st, x, delta, idx, compl_idx, scores, gamma,
+                       beta, x_out, y, N, K, N_out, D, eps);
+  TR_CHECK_LAUNCH("tr_gather_layernorm");
+  return TR_OK;
+}
+
+extern "C" int tr_gather_layernorm_bf16(const float* x, const uint16_t* delta, const int32_t* idx, const int32_t* compl_idx,
+                                        const float* scores, const float* gamma, const float* beta, float* x_out, uint16_t* y, int B,
+                                        int N, int K, int D, float eps, tr_stream_t s) {
+  return gather_layernorm_impl(false, x, delta, idx, compl_idx, scores, gamma, beta, x_out, y, B, N, K, D, eps, s);
+}
+extern "C" int tr_gather_layernorm_f32(const float* x, const float* delta, const int32_t* idx, const int32_t* compl_idx,
+                                       const float* scores, const float* gamma, const float* beta, float* x_out, float* y, int B, int N,
+                                       int K, int D, float eps, tr_stream_t s) {
+  return gather_layernorm_impl(true, x, delta, idx, compl_idx, scores, gamma, beta, x_out, y, B, N, K, D, eps, s);
+}
+
+static int im2col_impl(bool f32, const float* img, void* cols, int B, int C, int H, int W, int patch, tr_stream_t s) {
+  TR_REQUIRE(img && cols, TR_ERR_NULL, "tr_im2col: null pointer");
+  TR_REQUIRE(B > 0 && C > 0 && patch >= 8 && patch % 8 == 0 && H % patch == 0 && W % patch == 0, TR_ERR_SHAPE,
+             "tr_im2col: need patch %% 8 == 0 and H,W multiples of patch (H=%d W=%d patch=%d)", H, W, patch);
+  TR_REQUIRE(tr_aligned16(img) && tr_aligned16(cols), TR_ERR_ALIGN, "tr_im2col: pointers must be 16-byte aligned");
+  const long total = (long)B * C * H * W / 8;
+  hipStream_t st = static_cast<hipStream_t>(s);
+  if (f32) hipLaunchKernelGGL(im2col_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, img, cols, B, C, H, W, patch, total);
+  else hipLaunchKernelGGL(im2col_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, img, cols, B, C, H, W, patch, total);
+  TR_CHECK_LAUNCH("tr_im2col");
   return TR_OK;
 }
 
 extern "C" int tr_im2col_bf16(const float* img, uint16_t* cols, int B, int C, int H, int W, int patch, tr_stream_t s) {
-  TR_REQUIRE(img && cols, TR_ERR_NULL, "tr_im2col_bf16: null pointer");
-  TR_REQUIRE(B > 0 && C > 0 && patch >= 8 && patch % 8 == 0 && H % patch == 0 && W % patch == 0, TR_ERR_SHAPE,
-             "tr_im2col_bf16: need patch %% 8 == 0 and H,W multiples of patch (H=%d W=%d patch=%d)", H, W, patch);
-  TR_REQUIRE(tr_aligned16(img) && tr_aligned16(cols), TR_ERR_ALIGN, "tr_im2col_bf16: pointers must be 16-byte aligned");
-  const long total = (long)B * C * H * W / 8;
-  hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(s), img, cols, B, C,
-                     H, W, patch, total);
-  TR_CHECK_LAUNCH("tr_im2col_bf16");
-  return TR_OK;
+  return im2col_impl(false, img, cols, B, C, H, W, patch, s);
+}
+extern "C" int tr_im2col_f32(const float* img, float* cols, int B, int C, int H, int W, int patch, tr_stream_t s) {
+  return im2col_impl(true, img, cols, B, C, H, W, patch, s);
 }
 
 extern "C" int tr_cls_pos_rows(const float* cls_token, const float* pos_embed, float* x, int B, int N, int D, tr_stream_t s) {

@@ -35,6 +35,8 @@ struct Plan {
 
 bool make_plan(const tr_vit_config* c, int B, Plan* p) {
   if (!c || B <= 0) return false;
+  if (c->precision != TR_PREC_BF16 && c->precision != TR_PREC_FP32) return false;
+  const size_t es = c->precision == TR_PREC_FP32 ? 4 : 2;   // activation element size
   if (c->patch <= 0 || c->img_size <= 0 || c->img_size % c->patch != 0) return false;
   if (c->depth <= 0 || c->depth > TR_MAX_DEPTH) return false;
   if (c->num_heads <= 0 || c->embed_dim != c->num_heads * 64) return false;
@@ -52,19 +54,48 @@ bool make_plan(const tr_vit_config* c, int B, Plan* p) {
   size_t o = 0;
   p->off_x0 = o;     o += align_up(T * p->D * 4);
   p->off_x1 = o;     o += align_up(T * p->D * 4);
-  p->off_xn = o;     o += align_up(T * p->D * 2);
-  p->off_qkv = o;    o += align_up(T * 3 * p->D * 2);
-  p->off_ao = o;     o += align_up(T * p->D * 2);
-  p->off_h = o;      o += align_up(T * p->Hd * 2);
-  p->off_d = o;      o += align_up(T * p->D * 2);
-  p->off_cols = o;   o += align_up((size_t)B * p->P * p->kcols * 2);
+  p->off_xn = o;     o += align_up(T * p->D * es);
+  p->off_qkv = o;    o += align_up(T * 3 * p->D * es);
+  p->off_ao = o;     o += align_up(T * p->D * es);
+  p->off_h = o;      o += align_up(T * p->Hd * es);
+  p->off_d = o;      o += align_up(T * p->D * es);
+  p->off_cols = o;   o += align_up((size_t)B * p->P * p->kcols * es);
   p->off_cls = o;    o += align_up((size_t)B * p->H * p->N0 * 4);
   p->off_scores = o; o += align_up((size_t)B * p->P * 4);
   p->off_idx = o;    o += align_up((size_t)B * p->P * 4);
   p->off_compl = o;  o += align_up((size_t)B * p->P * 4);
-  p->off_xcls = o;   o += align_up((size_t)B * p->D * 2);
+  p->off_xcls = o;   o += align_up((size_t)B * p->D * es);
   p->total = o;
   return true;
+}
+
+// ---- precision dispatch: the executor is one launch sequence; TR_PREC_FP32 swaps every op for its fp32 validation twin
+inline int op_im2col(bool f32, const float* img, void* cols, int B, int C, int H, int W, int patch, tr_stream_t s) {
+  return f32 ? tr_im2col_f32(img, static_cast<float*>(cols), B, C, H, W, patch, s)
+             : tr_im2col_bf16(img, static_cast<uint16_t*>(cols), B, C, H, W, patch, s);
+}
+inline int op_gemm(bool f32, const void* A, const void* W, const float* bias, void* out, const float* aux, int aux_i, int M, int N,
+                   int K, int epi, tr_stream_t s) {
+  if (!f32) return tr_gemm_bf16(static_cast<const uint16_t*>(A), static_cast<const uint16_t*>(W), bias, out, aux, aux_i, M, N, K, epi, s);
+  const int e32 = (epi == TR_EPI_BF16) ? TR_EPI_F32 : epi;      // "store bf16" becomes "store fp32"; GELU / PATCH / F32 keep their meaning
+  return tr_gemm_f32(static_cast<const float*>(A), static_cast<const float*>(W), bias, static_cast<float*>(out), aux, aux_i, M, N, K,
+                     e32, s);
+}
+inline int op_ln(bool f32, float* x, long ldx, const void* d, long ldd, const float* g, const float* b, void* y, int M, int D,
+                 float eps, tr_stream_t s) {
+  return f32 ? tr_layernorm_f32(x, ldx, static_cast<const float*>(d), ldd, g, b, static_cast<float*>(y), M, D, eps, s)
+             : tr_layernorm_bf16(x, ldx, static_cast<const uint16_t*>(d), ldd, g, b, static_cast<uint16_t*>(y), M, D, eps, s);
+}
+inline int op_attn(bool f32, const void* qkv, void* out, float* cls_rows, int B, int N, int H, tr_stream_t s) {
+  return f32 ? tr_attention_f32(static_cast<const float*>(qkv), static_cast<float*>(out), cls_rows, B, N, H, s)
+             : tr_attention_bf16(static_cast<const uint16_t*>(qkv), static_cast<uint16_t*>(out), cls_rows, B, N, H, s);
+}
+inline int op_gather(bool f32, const float* x, const void* d, const int32_t* idx, const int32_t* cidx, const float* scores,
+                     const float* g, const float* b, float* x_out, void* y, int B, int N, int K, int D, float eps, tr_stream_t s) {
+  return f32 ? tr_gather_layernorm_f32(x, static_cast<const float*>(d), idx, cidx, scores, g, b, x_out, static_cast<float*>(y), B, N, K,
+                                       D, eps, s)
+             : tr_gather_layernorm_bf16(x, static_cast<const uint16_t*>(d), idx, cidx, scores, g, b, x_out, static_cast<uint16_t*>(y),
+                                        B, N, K, D, eps, s);
 }
 
 }  // namespace
@@ -95,26 +126,27 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
   char* ws = static_cast<char*>(workspace);
   float* x = reinterpret_cast<float*>(ws + p.off_x0);
   float* x_alt = reinterpret_cast<float*>(ws + p.off_x1);
-  uint16_t* xn = reinterpret_cast<uint16_t*>(ws + p.off_xn);
-  uint16_t* qkv = reinterpret_cast<uint16_t*>(ws + p.off_qkv);
-  uint16_t* ao = reinterpret_cast<uint16_t*>(ws + p.off_ao);
-  uint16_t* hbuf = reinterpret_cast<uint16_t*>(ws + p.off_h);
-  uint16_t* dbuf = reinterpret_cast<uint16_t*>(ws + p.off_d);   // bf16 output of proj / fc2, added to x by the NEXT norm
-  uint16_t* cols = reinterpret_cast<uint16_t*>(ws + p.off_cols);
+  void* xn = static_cast<void*>(ws + p.off_xn);
+  void* qkv = static_cast<void*>(ws + p.off_qkv);
+  void* ao = static_cast<void*>(ws + p.off_ao);
+  void* hbuf = static_cast<void*>(ws + p.off_h);
+  void* dbuf = static_cast<void*>(ws + p.off_d);   // bf16 output of proj / fc2, added to x by the NEXT norm
+  void* cols = static_cast<void*>(ws + p.off_cols);
   float* cls_rows = reinterpret_cast<float*>(ws + p.off_cls);
   float* scores = reinterpret_cast<float*>(ws + p.off_scores);
   int32_t* idx_ws = reinterpret_cast<int32_t*>(ws + p.off_idx);
   int32_t* compl_ws = reinterpret_cast<int32_t*>(ws + p.off_compl);
-  uint16_t* xcls = reinterpret_cast<uint16_t*>(ws + p.off_xcls);
+  void* xcls = static_cast<void*>(ws + p.off_xcls);
 
   const int D = p.D, H = p.H;
+  const bool f32 = cfg->precision == TR_PREC_FP32;
   // a1 + a2: patch embedding, CLS token, position embedding
-  TR_TRY(tr_im2col_bf16(img, cols, B, cfg->in_chans, cfg->img_size, cfg->img_size, cfg->patch, s));
-  TR_TRY(tr_gemm_bf16(cols, w->patch_w, w->patch_b, x, w->pos_embed, p.P, B * p.P, D, p.kcols, TR_EPI_PATCH_F32, s));
+  TR_TRY(op_im2col(f32, img, cols, B, cfg->in_chans, cfg->img_size, cfg->img_size, cfg->patch, s));
+  TR_TRY(op_gemm(f32, cols, w->patch_w, w->patch_b, x, w->pos_embed, p.P, B * p.P, D, p.kcols, TR_EPI_PATCH_F32, s));
   TR_TRY(tr_cls_pos_rows(w->cls_token, w->pos_embed, x, B, p.N0, D, s));
 
   int N = p.N0;
-  const uint16_t* pending = nullptr;   // residual not yet added to x (the previous block's fc2 output)
+  const void* pending = nullptr;   // residual not yet added to x (the previous block's fc2 output)
   for (int i = 0; i < cfg->depth; ++i) {
     const tr_block_weights* bw = &w->blocks[i];
     int K = (cfg->family == TR_FAMILY_DEIT) ? 0 : cfg->keep[i];
@@ -122,10 +154,10 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
     if (K == N - 1) K = 0;  // topk.py:57 / evit.py:79: left_tokens == N-1 -> plain block
     const int M = B * N;
     // x (+= previous mlp output); attn(norm1(x)) -> dbuf   [x + dbuf is the reference's post-attention x, topk.py:87]
-    TR_TRY(tr_layernorm_bf16(x, D, pending, D, bw->ln1_g, bw->ln1_b, xn, M, D, cfg->ln_eps, s));
-    TR_TRY(tr_gemm_bf16(xn, bw->qkv_w, bw->qkv_b, qkv, nullptr, 0, M, 3 * D, D, TR_EPI_BF16, s));
-    TR_TRY(tr_attention_bf16(qkv, ao, K > 0 ? cls_rows : nullptr, B, N, H, s));
-    TR_TRY(tr_gemm_bf16(ao, bw->proj_w, bw->proj_b, dbuf, nullptr, 0, M, D, D, TR_EPI_BF16, s));
+    TR_TRY(op_ln(f32, x, D, pending, D, bw->ln1_g, bw->ln1_b, xn, M, D, cfg->ln_eps, s));
+    TR_TRY(op_gemm(f32, xn, bw->qkv_w, bw->qkv_b, qkv, nullptr, 0, M, 3 * D, D, TR_EPI_BF16, s));
+    TR_TRY(op_attn(f32, qkv, ao, K > 0 ? cls_rows : nullptr, B, N, H, s));
+    TR_TRY(op_gemm(f32, ao, bw->proj_w, bw->proj_b, dbuf, nullptr, 0, M, D, D, TR_EPI_BF16, s));
     int Nn = N;
     if (K > 0) {
       // Top-K on the CLS attention, then residual add + gather/compact (+ EViT fused token) + norm2 in one pass
@@ -133,22 +165,22 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
       int32_t* idx_dst = kept_idx ? kept_idx + (size_t)i * B * p.P : idx_ws;
       int32_t* compl_dst = fuse ? (compl_idx ? compl_idx + (size_t)i * B * p.P : compl_ws) : nullptr;
       TR_TRY(tr_cls_topk(cls_rows, idx_dst, compl_dst, scores, B, H, N, K, s));
-      TR_TRY(tr_gather_layernorm_bf16(x, dbuf, idx_dst, compl_dst, scores, bw->ln2_g, bw->ln2_b, x_alt, xn, B, N, K, D, cfg->ln_eps, s));
+      TR_TRY(op_gather(f32, x, dbuf, idx_dst, compl_dst, scores, bw->ln2_g, bw->ln2_b, x_alt, xn, B, N, K, D, cfg->ln_eps, s));
       float* t = x; x = x_alt; x_alt = t;
       Nn = K + 1 + (fuse ? 1 : 0);
     } else {
-      TR_TRY(tr_layernorm_bf16(x, D, dbuf, D, bw->ln2_g, bw->ln2_b, xn, M, D, cfg->ln_eps, s));
+      TR_TRY(op_ln(f32, x, D, dbuf, D, bw->ln2_g, bw->ln2_b, xn, M, D, cfg->ln_eps, s));
     }
     N = Nn;
     const int M2 = B * N;
     // mlp(norm2(x)) -> dbuf, added to x by the next block's norm1 (or the final norm)
-    TR_TRY(tr_gemm_bf16(xn, bw->fc1_w, bw->fc1_b, hbuf, nullptr, 0, M2, p.Hd, D, TR_EPI_GELU_BF16, s));
-    TR_TRY(tr_gemm_bf16(hbuf, bw->fc2_w, bw->fc2_b, dbuf, nullptr, 0, M2, D, p.Hd, TR_EPI_BF16, s));
+    TR_TRY(op_gemm(f32, xn, bw->fc1_w, bw->fc1_b, hbuf, nullptr, 0, M2, p.Hd, D, TR_EPI_GELU_BF16, s));
+    TR_TRY(op_gemm(f32, hbuf, bw->fc2_w, bw->fc2_b, dbuf, nullptr, 0, M2, D, p.Hd, TR_EPI_BF16, s));
     pending = dbuf;
     if (tokens_out) tokens_out[i] = N;
   }
   // a5: (x += last mlp output and) norm on the CLS rows only (LayerNorm is per-row), then the classifier
-  TR_TRY(tr_layernorm_bf16(x, (long)N * D, pending, (long)N * D, w->norm_g, w->norm_b, xcls, B, D, cfg->ln_eps, s));
-  TR_TRY(tr_gemm_bf16(xcls, w->head_w, w->head_b, logits, nullptr, 0, B, p.C, D, TR_EPI_F32, s));
+  TR_TRY(op_ln(f32, x, (long)N * D, pending, (long)N * D, w->norm_g, w->norm_b, xcls, B, D, cfg->ln_eps, s));
+  TR_TRY(op_gemm(f32, xcls, w->head_w, w->head_b, logits, nullptr, 0, B, p.C, D, TR_EPI_F32, s));
   return TR_OK;
 }

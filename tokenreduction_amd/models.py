@@ -119,6 +119,7 @@ class VisionTransformer(nn.Module):
         self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
         self.viz_mode = getattr(args, 'viz_mode', False)
         self._keep = [0] * depth
+        self.precision = "bf16"      # "bf16" = the product path; "fp32" = validation path (reference arithmetic on the GPU)
         self._packed = None
         self._ws = {}
         nn.init.trunc_normal_(self.pos_embed, std=.02)
@@ -153,7 +154,9 @@ class VisionTransformer(nn.Module):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _pack(self):
-        key = self._param_key()
+        if self.precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        key = (self.precision,) + self._param_key()
         if self._packed is not None and self._packed["key"] == key:
             return self._packed
         dev = self.pos_embed.device
@@ -163,8 +166,10 @@ class VisionTransformer(nn.Module):
             raise NotImplementedError("num_classes == 0 (headless) is not supported by the executor")
         keep_alive = []
 
-        def w16(t):
-            c = t.detach().to(torch.bfloat16).contiguous()
+        wdt = torch.float32 if self.precision == "fp32" else torch.bfloat16
+
+        def w16(t):      # weight matrix in the executor's operand type
+            c = t.detach().to(wdt).contiguous()
             keep_alive.append(c)
             return c.data_ptr()
 
@@ -197,6 +202,7 @@ class VisionTransformer(nn.Module):
         cfg.mlp_hidden = self.blocks[0].mlp.fc1.out_features
         cfg.num_classes = self.num_classes
         cfg.ln_eps = float(self.norm.eps)
+        cfg.precision = _lib.TR_PREC_FP32 if self.precision == "fp32" else _lib.TR_PREC_BF16
         for i in range(self.depth):
             cfg.keep[i] = int(self._keep[i])
         self._packed = dict(key=key, W=W, cfg=cfg, keep_alive=keep_alive)

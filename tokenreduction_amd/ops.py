@@ -116,3 +116,35 @@ def gather_layernorm(x: torch.Tensor, idx, compl, scores, gamma, beta, eps: floa
         _opt(scores, torch.float32, "scores"), _dev(gamma, torch.float32, "gamma"), _dev(beta, torch.float32, "beta"),
         x_out.data_ptr(), y.data_ptr(), B, N, K, D, eps, _stream()), "tr_gather_layernorm_bf16")
     return x_out, y
+
+
+# ---------------------------------------------------------------------------------------- fp32 validation path
+def gemm_f32(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, epilogue: int = TR_EPI_F32, out: torch.Tensor = None,
+             aux: torch.Tensor = None, aux_i: int = 0) -> torch.Tensor:
+    """nn.Linear in the reference's arithmetic (fp32 operands): epilogue TR_EPI_F32 | TR_EPI_GELU_BF16 (GELU, fp32 out) | PATCH."""
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    _lib.check(_lib.load().tr_gemm_f32(_dev(a, torch.float32, "a"), _dev(w, torch.float32, "w"), _dev(bias, torch.float32, "bias"),
+                                       _dev(out, torch.float32, "out"), _opt(aux, torch.float32, "aux"), aux_i, M, N, K, epilogue,
+                                       _stream()), "tr_gemm_f32")
+    return out
+
+
+def layernorm_f32(x: torch.Tensor, gamma, beta, eps: float, delta: torch.Tensor = None) -> torch.Tensor:
+    D = x.shape[-1]
+    M = x.numel() // D
+    y = torch.empty(M, D, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().tr_layernorm_f32(_dev(x, torch.float32, "x"), D, _opt(delta, torch.float32, "delta"), D,
+                                            _dev(gamma, torch.float32, "gamma"), _dev(beta, torch.float32, "beta"), y.data_ptr(), M, D,
+                                            eps, _stream()), "tr_layernorm_f32")
+    return y
+
+
+def attention_f32(qkv: torch.Tensor, B: int, N: int, H: int, want_cls: bool = False):
+    out = torch.empty(B * N, H * 64, dtype=torch.float32, device=qkv.device)
+    cls_rows = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device) if want_cls else None
+    _lib.check(_lib.load().tr_attention_f32(_dev(qkv, torch.float32, "qkv"), out.data_ptr(),
+                                            None if cls_rows is None else cls_rows.data_ptr(), B, N, H, _stream()), "tr_attention_f32")
+    return out, cls_rows

@@ -50,7 +50,15 @@ int main(int argc, char** argv) {
     hipEventRecord(e1, nullptr); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     double us = 1e3 * ms / iters, tf = 2.0 * sh.M * sh.N * sh.K / (us * 1e-6) / 1e12;
-    printf("%-8s M=%6d N=%5d K=%5d  %8.1f us  %7.1f TFLOP/s\n", sh.name, sh.M, sh.N, sh.K, us, tf);
+    printf("%-8s M=%6d N=%5d K=%5d  %8.1f us  %7.1f TFLOP/s", sh.name, sh.M, sh.N, sh.K, us, tf);
+#ifdef TR_DIAG_CLOCK
+    if (sh.epi <= TR_EPI_GELU_BF16) {
+      unsigned long long hs[2];
+      hipMemcpy(hs, (char*)out + (size_t)sh.M * sh.N * 2, 16, hipMemcpyDeviceToHost);
+      printf("   [WG 8: %llu shader cycles in %.2f us -> %.0f MHz]", hs[0], hs[1] / 100.0, hs[0] / (hs[1] / 100.0));
+    }
+#endif
+    printf("\n");
     hipFree(A); hipFree(W); hipFree(bias); hipFree(out);
   }
   return 0;
