@@ -18,4 +18,5 @@ from .vit import (  # noqa: F401
     VitConfig, vit_forward, block_forward, attention, layer_norm, mlp, gelu_erf,
     patch_embed, embed_tokens, head, cls_topk_select, cls_scores_from_heads,
     gather_compact, complement_idx, evit_fuse, stage_keep_counts, round_bf16,
+    tome_schedule, tome_block_r, tome_attention, tome_match, tome_merge, tome_assignment, tome_block_forward, tome_forward,
 )

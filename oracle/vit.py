@@ -251,3 +251,142 @@ def vit_forward(params: Dict[str, Tensor], x: Tensor, cfg: VitConfig, precision:
         viz["Final_Tokens"] = h
         return logits, viz
     return logits
+
+
+# =========================================================================== ToMe (models/tome.py)
+def tome_schedule(cfg: VitConfig) -> Dict[int, int]:
+    """block index -> r (tokens to remove in that block), tome.py:145-156.
+
+    One keep_rate -> targets int(P0 * kr**(i+1)); several -> ABSOLUTE patch-token counts used verbatim (cast to int: the
+    CLI delivers floats, which crash the reference's slicing -- SURVEY App. A.4).  r_i = previous target - target_i; the
+    per-call clamp min(r, (N-1)//2) (tome.py:253) is applied where the token count is known (tome_block_r)."""
+    targets = list(cfg.keep_rate)
+    loc = list(cfg.reduction_loc)
+    if len(targets) == 1:
+        targets = [int(cfg.num_patches * targets[0] ** (i + 1)) for i in range(len(loc))]
+    assert len(targets) == len(loc), "keep_rate / reduction_loc length mismatch"
+    out, prev = {}, cfg.num_patches
+    for t, l in zip(targets, loc):
+        out[int(l)] = prev - int(t)
+        prev = int(t)
+    return out
+
+
+def tome_block_r(r: int, n_tokens: int) -> int:
+    """tome.py:252-253: at most 50 % of the non-CLS tokens can be merged in one call."""
+    return max(0, min(int(r), (n_tokens - 1) // 2))
+
+
+def tome_attention(xn: Tensor, qkv_w: Tensor, qkv_b: Tensor, proj_w: Tensor, proj_b: Tensor, num_heads: int,
+                   size: Optional[Tensor], precision: str = "fp32") -> Tuple[Tensor, Tensor]:
+    """Attention_ToMe.forward tome.py:41-58: attention + log(size) added to the logits of every KEY (proportional attention,
+    only once a merge has happened), returns (proj output, metric = k.mean(1) [B,N,dh])."""
+    B, N, D = xn.shape
+    dh = D // num_heads
+    qkv = _r(xn @ _r(qkv_w, precision).t() + qkv_b, precision)
+    qkv = qkv.reshape(B, N, 3, num_heads, dh).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    s = (q @ k.transpose(-2, -1)) * (dh ** -0.5)
+    if size is not None:
+        s = s + size.log()[:, None, None, :, 0]
+    if precision == "bf16":
+        m = s.amax(dim=-1, keepdim=True)
+        p = torch.exp(s - m)
+        o = (round_bf16(p) @ v) / p.sum(dim=-1, keepdim=True)
+    else:
+        o = s.softmax(dim=-1) @ v
+    o = _r(o.transpose(1, 2).reshape(B, N, D), precision)
+    out = _r(o @ _r(proj_w, precision).t() + proj_b, precision)
+    return out, k.mean(1)
+
+
+def tome_match(metric: Tensor, r: int) -> Tuple[Tensor, Tensor, Tensor]:
+    """bipartite_soft_matching tome.py:230-277 with class_token=True: returns (unm_idx [B,na-r], src_idx [B,r], dst_idx [B,r]),
+    indices into the EVEN-position set A (unm, src) / the ODD-position set B (dst).  unm is sorted ascending so CLS (A[0],
+    whose scores are -inf) stays first.  Tie rules of this build: row maximum -> first index (as torch's CPU max); the
+    descending argsort of the row maxima -> lowest index first (torch's order is unspecified; fixtures are tie-free)."""
+    metric = metric / metric.norm(dim=-1, keepdim=True)
+    a, b = metric[..., ::2, :], metric[..., 1::2, :]
+    scores = a @ b.transpose(-1, -2)
+    scores[..., 0, :] = -math.inf
+    node_max, node_idx = scores.max(dim=-1)
+    edge = torch.sort(node_max, dim=-1, descending=True, stable=True).indices
+    unm = edge[..., r:].sort(dim=1)[0]
+    src = edge[..., :r]
+    dst = node_idx.gather(dim=-1, index=src)
+    return unm, src, dst
+
+
+def tome_merge(x: Tensor, size: Optional[Tensor], unm: Tensor, src: Tensor, dst: Tensor) -> Tuple[Tensor, Tensor]:
+    """merge_wavg tome.py:309-323 over the `merge` closure tome.py:279-289: size-weighted sums scattered into the odd tokens,
+    divided by the summed sizes.  Output order: unmerged even tokens (ascending), then ALL odd tokens."""
+    if size is None:
+        size = torch.ones_like(x[..., 0, None])
+
+    def merge(t):
+        s_, d_ = t[..., ::2, :], t[..., 1::2, :]
+        n, t1, c = s_.shape
+        u = s_.gather(dim=-2, index=unm[..., None].expand(n, unm.shape[1], c))
+        sr = s_.gather(dim=-2, index=src[..., None].expand(n, src.shape[1], c))
+        d_ = d_.scatter_add(-2, dst[..., None].expand(n, dst.shape[1], c), sr)
+        return torch.cat([u, d_], dim=1)
+
+    xs = merge(x * size)
+    sz = merge(size)
+    return xs / sz, sz
+
+
+def tome_assignment(unm: Tensor, src: Tensor, dst: Tensor, n_tokens: int) -> Tensor:
+    """Assignment_Maps entry of tome.py:91-99 (what merge_source + amax computes through a B*N*N eye): for every input PATCH
+    token (CLS dropped), the index of its output token minus 1."""
+    B = unm.shape[0]
+    na = (n_tokens + 1) // 2
+    n_unm = unm.shape[1]
+    out = torch.empty(B, n_tokens, dtype=torch.int64)
+    pos_unm = torch.zeros(B, na, dtype=torch.int64)
+    pos_unm.scatter_(1, unm, torch.arange(n_unm).expand(B, n_unm))
+    pos_unm.scatter_(1, src, n_unm + dst)
+    out[:, 0::2] = pos_unm
+    out[:, 1::2] = n_unm + torch.arange(n_tokens // 2)
+    return (out - 1)[:, 1:]
+
+
+def tome_block_forward(x: Tensor, size: Optional[Tensor], p: Dict[str, Tensor], i: int, cfg: VitConfig, r: int,
+                       precision: str = "fp32"):
+    """Block_ToMe.forward tome.py:83-104.  Returns (x, size, assignment|None)."""
+    pre = f"blocks.{i}."
+    xn = layer_norm(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"], cfg.ln_eps, precision)
+    a, metric = tome_attention(xn, p[pre + "attn.qkv.weight"], p[pre + "attn.qkv.bias"], p[pre + "attn.proj.weight"],
+                               p[pre + "attn.proj.bias"], cfg.num_heads, size, precision)
+    x = x + a
+    assign = None
+    r = tome_block_r(r, x.shape[1])
+    if r > 0:
+        unm, src, dst = tome_match(metric, r)
+        assign = tome_assignment(unm, src, dst, x.shape[1])
+        x, size = tome_merge(x, size, unm, src, dst)
+    xn2 = layer_norm(x, p[pre + "norm2.weight"], p[pre + "norm2.bias"], cfg.ln_eps, precision)
+    x = x + mlp(xn2, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"], p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"],
+                precision)
+    return x, size, assign
+
+
+@torch.no_grad()
+def tome_forward(params: Dict[str, Tensor], x: Tensor, cfg: VitConfig, precision: str = "fp32", return_viz: bool = False):
+    """ToMeVisionTransformer.forward tome.py:183-223 (eval)."""
+    p = params
+    tok = patch_embed(x, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], cfg.patch_size, precision)
+    h = embed_tokens(tok, p["cls_token"], p["pos_embed"])
+    sched = tome_schedule(cfg)
+    size = None
+    viz = {"Assignment_Maps": {}, "Tokens": {}}
+    for i in range(cfg.depth):
+        h, size, assign = tome_block_forward(h, size, p, i, cfg, sched.get(i, 0), precision)
+        viz["Tokens"][i] = h.shape[1]
+        if assign is not None and i in sched:
+            viz["Assignment_Maps"][i] = assign.numpy()
+    logits = head(h, p["norm.weight"], p["norm.bias"], p["head.weight"], p["head.bias"], cfg.ln_eps, precision)
+    if return_viz:
+        viz["Final_Tokens"] = h
+        return logits, viz
+    return logits

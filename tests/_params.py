@@ -77,6 +77,15 @@ GOLDEN_CASES = {
     "evit_small_kr07": dict(family="evit", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
                             keep_rate=[0.7], reduction_loc=[3, 6, 9], batch=2, wseed=71, xseed=72,
                             qkv_gain=4.0, factory="evit_small_patch16_224"),
+    # ToMe (models/tome.py): geometric keep_rate, and BASELINE configs[2] "r=16 every block" = explicit absolute counts
+    "tome_micro": dict(family="tome", embed_dim=128, depth=4, num_heads=2, num_classes=16,
+                       keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=91, xseed=92, qkv_gain=6.0),
+    "tome_small_kr07": dict(family="tome", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
+                            keep_rate=[0.7], reduction_loc=[3, 6, 9], batch=2, wseed=93, xseed=94,
+                            qkv_gain=4.0, factory="tome_small_patch16_224"),
+    "tome_small_r16": dict(family="tome", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
+                           keep_rate=[196 - 16 * (i + 1) for i in range(12)], reduction_loc=list(range(12)), batch=2,
+                           wseed=95, xseed=96, qkv_gain=4.0, factory="tome_small_patch16_224"),
     "deit_small": dict(family="deit", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
                        keep_rate=[1.0], reduction_loc=[], batch=2, wseed=81, xseed=82,
                        qkv_gain=4.0, factory="deit_small_patch16_224_local"),

@@ -37,10 +37,12 @@ from timm.models import create_model  # noqa: E402
 from models.topk import TopKVisionTransformer, Attention_TopK  # noqa: E402
 from models.evit import EfficientVisionTransformer, Block_EVIT, complement_idx  # noqa: E402
 from models.deit_viz import VisionTransformer as DeitViz  # noqa: E402
+from models.tome import ToMeVisionTransformer  # noqa: E402
+import models.tome as ref_tome  # noqa: E402
 
 from tests._params import GOLDEN_CASES, make_params, make_images  # noqa: E402
 
-CLASSES = {"topk": TopKVisionTransformer, "evit": EfficientVisionTransformer, "deit": DeitViz}
+CLASSES = {"topk": TopKVisionTransformer, "evit": EfficientVisionTransformer, "deit": DeitViz, "tome": ToMeVisionTransformer}
 
 
 class TopkSpy:
@@ -59,6 +61,28 @@ class TopkSpy:
 
     def __exit__(self, *exc):
         torch.topk = self._orig
+
+
+class ArgsortSpy:
+    """Records the row maxima ToMe ranks (tome.py:265 node_max.argsort) for the tie check."""
+
+    def __init__(self):
+        self.calls = []
+
+    def __enter__(self):
+        orig = torch.Tensor.argsort
+        self._orig = orig
+        spy_self = self
+
+        def spy(t, *a, **kw):
+            if t.dtype.is_floating_point:
+                spy_self.calls.append(t.detach().clone())
+            return orig(t, *a, **kw)
+        torch.Tensor.argsort = spy
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.argsort = self._orig
 
 
 def build_reference(case):
@@ -84,10 +108,21 @@ def build_reference(case):
 def run_case(name, case):
     m, _ = build_reference(case)
     x = make_images(case["batch"], 224, case["xseed"])
-    with TopkSpy() as spy, torch.no_grad():
+    with TopkSpy() as spy, ArgsortSpy() as aspy, torch.no_grad():
         out = m(x)
     logits, viz = out if isinstance(out, tuple) else (out, {})
     rec = {"logits": logits.numpy()}
+    tome_gaps = []
+    for nm in aspy.calls:                      # ToMe: ranked row maxima must be tie-free (CLS row is -inf, unique)
+        for b in range(nm.shape[0]):
+            v = nm[b][torch.isfinite(nm[b])]
+            assert torch.unique(v).numel() == v.numel(), f"{name}: tied ToMe row maxima - pick another seed"
+            srt = torch.sort(v, descending=True).values
+            tome_gaps.append((srt[:-1] - srt[1:]).min().item())
+    if tome_gaps:
+        rec["min_abs_gap_node_max"] = np.array(min(tome_gaps), dtype=np.float64)
+    for blk, a in viz.get("Assignment_Maps", {}).items():
+        rec[f"assign_{blk}"] = a.astype(np.int64)
     gaps = []
     for scores, k in spy.calls:
         for b in range(scores.shape[0]):
@@ -107,6 +142,9 @@ def run_case(name, case):
         rec["token_counts"] = np.array([feats[k].shape[1] for k in sorted(feats.keys())], dtype=np.int64)
         rec["token_count_blocks"] = np.array(sorted(feats.keys()), dtype=np.int64)
     np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **rec)
+    if tome_gaps:
+        print(f"   ToMe: min abs gap between ranked row maxima {min(tome_gaps):.2e}; "
+              f"assignment maps {[v.shape for k, v in rec.items() if k.startswith('assign_')]}")
     print(f"{name}: logits {logits.shape} |max| {logits.abs().max():.3f}  min rel gap@K {rec['min_rel_gap_at_k']:.2e}"
           f"  kept {[v.shape for k, v in rec.items() if k.startswith('kept_')]}")
 

@@ -23,6 +23,17 @@ def test_model_matches_reference(golden_dir, name):
     cfg = case_config(case)
     params = make_params(cfg, case["wseed"], case.get("qkv_gain", 1.0))
     x = make_images(case["batch"], 224, case["xseed"])
+    if case["family"] == "tome":
+        logits, viz = oracle.tome_forward(params, x, cfg, return_viz=True)
+        akeys = sorted(k for k in g.files if k.startswith("assign_"))
+        assert len(akeys) == len(viz["Assignment_Maps"]) > 0
+        for k in akeys:                                   # Assignment_Maps (tome.py:91-99): bit-exact
+            np.testing.assert_array_equal(viz["Assignment_Maps"][int(k.split("_")[1])], g[k])
+        np.testing.assert_allclose(logits.numpy(), g["logits"], atol=FP_TOL, rtol=0)
+        np.testing.assert_allclose(viz["Final_Tokens"][:, :8].numpy(), g["final_tokens"], atol=1e-4, rtol=0)
+        for blk, n in zip(g["token_count_blocks"], g["token_counts"]):
+            assert viz["Tokens"][int(blk)] == int(n)
+        return
     logits, viz = oracle.vit_forward(params, x, cfg, return_viz=True)
     # integer outputs: bit-exact
     kept_keys = sorted(k for k in g.files if k.startswith("kept_"))
@@ -75,6 +86,23 @@ def test_evit_block(golden_dir):
     np.testing.assert_array_equal(idx.numpy(), g["evitblk_idx"])
     np.testing.assert_array_equal(compl.numpy(), g["evitblk_compl"])
     np.testing.assert_allclose(xo.numpy(), g["evitblk_out"], atol=FP_TOL, rtol=0)
+
+
+def test_tome_schedule_and_clamp():
+    cfg = oracle.VitConfig(family="tome", keep_rate=[0.7], reduction_loc=[3, 6, 9])
+    assert oracle.tome_schedule(cfg) == {3: 196 - 137, 6: 137 - 96, 9: 96 - 67}
+    cfg = oracle.VitConfig(family="tome", keep_rate=[196 - 16 * (i + 1) for i in range(12)], reduction_loc=list(range(12)))
+    n, seen = 197, []
+    for i in range(12):                                   # BASELINE configs[2]: r=16 per block; SURVEY App. B token table
+        n -= oracle.tome_block_r(oracle.tome_schedule(cfg)[i], n)
+        seen.append(n)
+    assert seen == [181, 165, 149, 133, 117, 101, 85, 69, 53, 37, 21, 11]
+    cfg = oracle.VitConfig(family="tome", keep_rate=[0.25], reduction_loc=[3, 6, 9])     # 50 % cap: 99/62/53, not 50/13/4
+    n, seen = 197, []
+    for i in (3, 6, 9):
+        n -= oracle.tome_block_r(oracle.tome_schedule(cfg)[i], n)
+        seen.append(n)
+    assert seen == [99, 62, 53]
 
 
 def test_tie_rule_lowest_index_first():

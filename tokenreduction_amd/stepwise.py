@@ -54,7 +54,7 @@ class Trace:
             self.tensors[name] = t.clone()
 
 
-_EPI_NAME = {ops.TR_EPI_BF16: "gemm_bf16_persistent<EPI_BF16>", ops.TR_EPI_GELU_BF16: "gemm_bf16_persistent<EPI_GELU_BF16>",
+_EPI_NAME = {ops.TR_EPI_BF16: "gemm_bf16_pc<EPI_BF16>", ops.TR_EPI_GELU_BF16: "gemm_bf16_pc<EPI_GELU_BF16>",
              ops.TR_EPI_RESID_F32: "gemm_bf16_persistent<EPI_RESID_F32>", ops.TR_EPI_F32: "gemm_bf16_persistent<EPI_F32>",
              ops.TR_EPI_PATCH_F32: "gemm_bf16_persistent<EPI_PATCH_F32>"}
 
