@@ -72,10 +72,12 @@ int tr_layernorm_f32(float* x, long ldx, const float* delta, long ldd, const flo
  * qkv bf16 [B*N, 3*H*64] (columns [q|k|v], head-major), out bf16 [B*N, H*64].
  * cls_rows (nullable) fp32 [B,H,N]: the CLS query's softmax row (attn[:, :, 0, :], topk.py:59) --
  * the only part of the N x N matrix the reduction reads, so the matrix is never materialised.
+ * size (nullable) fp32 [B,N]: ToMe's proportional attention (Attention_ToMe.forward tome.py:48-49): log(size[key]) is added
+ * to every query's logit for that key.
  * N <= 224 in this round (whole score row in registers); larger N returns TR_ERR_SHAPE. */
-int tr_attention_bf16(const uint16_t* qkv, uint16_t* out, float* cls_rows, int B, int N, int H, tr_stream_t s);
+int tr_attention_bf16(const uint16_t* qkv, uint16_t* out, float* cls_rows, const float* size, int B, int N, int H, tr_stream_t s);
 /* fp32 validation path (N <= 256): same contract in the reference's arithmetic (expf softmax, fp32 everywhere). */
-int tr_attention_f32(const float* qkv, float* out, float* cls_rows, int B, int N, int H, tr_stream_t s);
+int tr_attention_f32(const float* qkv, float* out, float* cls_rows, const float* size, int B, int N, int H, tr_stream_t s);
 
 /* a6 (topk.py:55-65 == evit.py:77-87) + a8 (evit.py:25-46 complement_idx):
  * scores[b,j] = mean_h cls_rows[b,h,1+j] (j < P = N-1); idx[b,:K] = indices of the K largest scores in
@@ -101,11 +103,28 @@ int tr_gather_layernorm_f32(const float* x, const float* delta, const int32_t* i
 int tr_gemm_f32(const float* A, const float* W, const float* bias, float* out, const float* aux, int aux_i, int M, int N, int K,
                 int epilogue, tr_stream_t s);
 
+/* a13 bipartite_soft_matching (tome.py:230-277, class_token=True) on metric = k.mean(1) (tome.py:58), read straight from the
+ * K third of qkv ([B*N, 3*H*64]; bf16, or fp32 when qkv_is_f32).  Tokens at even positions form set A (CLS = A[0], never
+ * merged), odd positions set B.  Outputs (int32): src_idx [B,r] = the r A-tokens with the largest best-match score, in
+ * descending order; dst_idx [B,r] = the B-token each is merged into; unm_idx [B, ceil(N/2)-r] = the other A-tokens, ascending.
+ * 3 <= N <= 224, 1 <= r <= (N-1)/2 (tome.py:253). */
+int tr_tome_match(const void* qkv, int qkv_is_f32, int32_t* unm_idx, int32_t* src_idx, int32_t* dst_idx, int B, int N, int H,
+                  int r, tr_stream_t s);
+
+/* a14 merge_wavg (tome.py:309-323) over the merge closure (tome.py:279-289), with the pending residual (delta: bf16, or fp32
+ * when f32_path) added first and norm2 (tome.py:101) applied after: x_out [B,N-r,D] = merge((x+delta)*size)/merge(size) in the
+ * order [unmerged A-tokens | all B-tokens]; size_out [B,N-r]; y = LayerNorm(x_out) (bf16, or fp32 when f32_path).
+ * size_in == NULL means all ones (first merge, tome.py:318-319). */
+int tr_tome_merge_layernorm(const float* x, const void* delta, int f32_path, const float* size_in, const int32_t* unm_idx,
+                            const int32_t* src_idx, const int32_t* dst_idx, const float* gamma, const float* beta, float* x_out,
+                            float* size_out, void* y, int B, int N, int r, int D, float eps, tr_stream_t s);
+
 /* ---- whole-model executor: TopKVisionTransformer.forward topk.py:179-212,
  *      EfficientVisionTransformer.forward evit.py:209-244, deit_viz.VisionTransformer.forward :186-212 (eval) ---- */
 #define TR_FAMILY_DEIT 0
 #define TR_FAMILY_TOPK 1
 #define TR_FAMILY_EVIT 2
+#define TR_FAMILY_TOME 3   /* keep[blk] = r requested for that block (tome.py:152-155); clamped per call to (N-1)/2 */
 #define TR_MAX_DEPTH 32
 #define TR_PREC_BF16 0   /* the product path: bf16 MFMA operands, fp32 accumulate / residual / statistics */
 #define TR_PREC_FP32 1   /* validation path: the reference's own arithmetic on the GPU (bit-exact indices vs its golden vectors) */
@@ -140,9 +159,10 @@ typedef struct {
 /* Bytes of workspace tr_vit_forward needs for batch B (0 on invalid config). */
 size_t tr_vit_workspace_bytes(const tr_vit_config* cfg, int B);
 
-/* img fp32 [B,C,S,S] -> logits fp32 [B,classes].  kept_idx (nullable): device int32 slab of depth*B*P entries;
- * reduction block blk writes its contiguous [B,K_blk] idx array at offset blk*B*P (Kept_Tokens, topk.py:196).
- * compl_idx (nullable, EViT): same slab shape, block blk writes [B,P_in-K_blk] at offset blk*B*P
+/* img fp32 [B,C,S,S] -> logits fp32 [B,classes].  kept_idx (nullable): device int32 slab of depth*B*(P+1) entries;
+ * reduction block blk writes its contiguous [B,K_blk] idx array at offset blk*B*(P+1) (Kept_Tokens, topk.py:196); ToMe
+ * writes [unm_idx | src_idx | dst_idx] there ([B,na-r], [B,r], [B,r] back to back).  The slab holds depth*B*(P+1) entries.
+ * compl_idx (nullable, EViT): same slab shape, block blk writes [B,P_in-K_blk] at offset blk*B*(P+1)
  * (Fusion_Assign, evit.py:229).  tokens_out (nullable, HOST pointer, int[depth]): token count after each block. */
 int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits,
                    void* workspace, size_t workspace_bytes, int32_t* kept_idx, int32_t* compl_idx,

@@ -196,9 +196,12 @@ def evit_fuse(x: Tensor, idx: Tensor, scores: Tensor) -> Tuple[Tensor, Tensor]:
 
 # --------------------------------------------------------------------------- block / model
 def block_forward(x: Tensor, p: Dict[str, Tensor], i: int, cfg: VitConfig, keep: Optional[int],
-                  precision: str = "fp32"):
+                  precision: str = "fp32", forced_idx: Optional[Tensor] = None):
     """Block_TopK.forward topk.py:83-99 / Block_EVIT.forward evit.py:105-129 /
-    deit_viz.Block.forward :69-72 (keep=None).  Returns (x, idx|None, compl|None)."""
+    deit_viz.Block.forward :69-72 (keep=None).  Returns (x, idx|None, compl|None).
+
+    forced_idx (tests only): use this selection instead of the block's own top-k ("teacher forcing"): isolates the
+    continuous arithmetic from the discrete decisions when a bf16 pipeline is compared with this restatement."""
     pre = f"blocks.{i}."
     xn = layer_norm(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"], cfg.ln_eps, precision)
     a, cls_rows = attention(xn, p[pre + "attn.qkv.weight"], p[pre + "attn.qkv.bias"],
@@ -211,7 +214,8 @@ def block_forward(x: Tensor, p: Dict[str, Tensor], i: int, cfg: VitConfig, keep:
     if keep is not None and keep != N - 1:
         assert 1 <= keep < N - 1
         scores = cls_scores_from_heads(cls_rows)
-        idx = cls_topk_select(scores, keep)
+        idx = cls_topk_select(scores, keep) if forced_idx is None else forced_idx
+        assert idx.shape == (x.shape[0], keep)
         if cfg.family == "evit":
             x, compl = evit_fuse(x, idx, scores)
         else:
@@ -224,7 +228,7 @@ def block_forward(x: Tensor, p: Dict[str, Tensor], i: int, cfg: VitConfig, keep:
 
 @torch.no_grad()
 def vit_forward(params: Dict[str, Tensor], x: Tensor, cfg: VitConfig, precision: str = "fp32",
-                return_viz: bool = False):
+                return_viz: bool = False, forced: Optional[Dict[int, Tensor]] = None):
     """TopKVisionTransformer.forward topk.py:179-212 / EfficientVisionTransformer.forward
     evit.py:209-244 / deit_viz.VisionTransformer.forward :186-212 (eval mode).
 
@@ -239,7 +243,7 @@ def vit_forward(params: Dict[str, Tensor], x: Tensor, cfg: VitConfig, precision:
     keeps = stage_keep_counts(cfg) if cfg.family in ("topk", "evit") else {}
     viz = {"Kept_Tokens": {}, "Fusion_Assign": {}, "Tokens": {}}
     for i in range(cfg.depth):
-        h, idx, compl = block_forward(h, p, i, cfg, keeps.get(i), precision)
+        h, idx, compl = block_forward(h, p, i, cfg, keeps.get(i), precision, None if forced is None else forced.get(i))
         viz["Tokens"][i] = h.shape[1]
         if idx is not None:
             if cfg.family == "evit":
@@ -352,8 +356,9 @@ def tome_assignment(unm: Tensor, src: Tensor, dst: Tensor, n_tokens: int) -> Ten
 
 
 def tome_block_forward(x: Tensor, size: Optional[Tensor], p: Dict[str, Tensor], i: int, cfg: VitConfig, r: int,
-                       precision: str = "fp32"):
-    """Block_ToMe.forward tome.py:83-104.  Returns (x, size, assignment|None)."""
+                       precision: str = "fp32", forced=None):
+    """Block_ToMe.forward tome.py:83-104.  Returns (x, size, assignment|None).  forced = (unm, src, dst) replaces the block's
+    own matching (tests only, see block_forward)."""
     pre = f"blocks.{i}."
     xn = layer_norm(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"], cfg.ln_eps, precision)
     a, metric = tome_attention(xn, p[pre + "attn.qkv.weight"], p[pre + "attn.qkv.bias"], p[pre + "attn.proj.weight"],
@@ -362,7 +367,8 @@ def tome_block_forward(x: Tensor, size: Optional[Tensor], p: Dict[str, Tensor], 
     assign = None
     r = tome_block_r(r, x.shape[1])
     if r > 0:
-        unm, src, dst = tome_match(metric, r)
+        unm, src, dst = tome_match(metric, r) if forced is None else forced
+        assert src.shape == (x.shape[0], r)
         assign = tome_assignment(unm, src, dst, x.shape[1])
         x, size = tome_merge(x, size, unm, src, dst)
     xn2 = layer_norm(x, p[pre + "norm2.weight"], p[pre + "norm2.bias"], cfg.ln_eps, precision)
@@ -372,7 +378,8 @@ def tome_block_forward(x: Tensor, size: Optional[Tensor], p: Dict[str, Tensor], 
 
 
 @torch.no_grad()
-def tome_forward(params: Dict[str, Tensor], x: Tensor, cfg: VitConfig, precision: str = "fp32", return_viz: bool = False):
+def tome_forward(params: Dict[str, Tensor], x: Tensor, cfg: VitConfig, precision: str = "fp32", return_viz: bool = False,
+                 forced=None):
     """ToMeVisionTransformer.forward tome.py:183-223 (eval)."""
     p = params
     tok = patch_embed(x, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], cfg.patch_size, precision)
@@ -381,7 +388,8 @@ def tome_forward(params: Dict[str, Tensor], x: Tensor, cfg: VitConfig, precision
     size = None
     viz = {"Assignment_Maps": {}, "Tokens": {}}
     for i in range(cfg.depth):
-        h, size, assign = tome_block_forward(h, size, p, i, cfg, sched.get(i, 0), precision)
+        h, size, assign = tome_block_forward(h, size, p, i, cfg, sched.get(i, 0), precision,
+                                             None if forced is None else forced.get(i))
         viz["Tokens"][i] = h.shape[1]
         if assign is not None and i in sched:
             viz["Assignment_Maps"][i] = assign.numpy()

@@ -1,7 +1,7 @@
 """GPU parity tests of the fp32 VALIDATION path (precision="fp32": the reference's own arithmetic on the GPU).
 
 This is the end-to-end pin the bf16 product path cannot give: against the golden vectors recorded from the
-reference itself, every Top-K / EViT index array and complement array must be BIT-EXACT and the logits within 2e-4 abs
+reference itself, every Top-K / EViT index array, complement array and ToMe assignment map must be BIT-EXACT and the logits within 2e-4 abs
 (fp32 summation order only; |logit| ~ 1)."""
 import os
 
@@ -74,6 +74,12 @@ def test_model_fp32_matches_reference_golden(golden_dir, name):
         np.testing.assert_array_equal(viz["Kept_Tokens"][int(k.split("_")[1])], g[k])
     for k in (k for k in g.files if k.startswith("compl_")):
         np.testing.assert_array_equal(viz["Fusion_Assign"][int(k.split("_")[1])], g[k])
+    akeys = sorted((k for k in g.files if k.startswith("assign_")), key=lambda k: int(k.split("_")[1]))
+    if case["family"] == "tome":
+        assert sorted(viz["Assignment_Maps"].keys()) == [int(k.split("_")[1]) for k in akeys]
+    for k in akeys:                                         # ToMe: every merge decision of every stage, bit-exact
+        np.testing.assert_array_equal(viz["Assignment_Maps"][int(k.split("_")[1])], g[k])
+    kept_keys = kept_keys + akeys
     d = (logits.cpu() - torch.from_numpy(g["logits"])).abs().max().item()
     print(f"\n[{name}] fp32 path: max|logit - reference| = {d:.2e}; indices exact at blocks {[int(k.split('_')[1]) for k in kept_keys]}")
     assert d < 2e-4, d

@@ -27,7 +27,8 @@ from tests._params import GOLDEN_CASES, case_config, make_images, make_params
 
 pytestmark = pytest.mark.gpu
 
-FAM = {"deit": "VisionTransformer", "topk": "TopKVisionTransformer", "evit": "EfficientVisionTransformer"}
+FAM = {"deit": "VisionTransformer", "topk": "TopKVisionTransformer", "evit": "EfficientVisionTransformer",
+       "tome": "ToMeVisionTransformer"}
 
 
 def build_model(case):
@@ -54,6 +55,10 @@ def _need_gpu():
         pytest.skip("needs a GPU")
 
 
+# relative L2 of the logits, bf16 HIP path vs the oracle with the same rounding points and the same discrete decisions
+FORCED_TOL = 3e-2   # measured 0.6e-2 .. 1.6e-2 over the golden cases (DeiT-S depth 12 without any decision: 1.2e-2)
+
+
 def _overlap(a, b):
     return float(np.mean([len(set(x.tolist()) & set(y.tolist())) / len(x) for x, y in zip(a, b)]))
 
@@ -71,10 +76,16 @@ def test_model_parity(golden_dir, name):
     assert logits.shape == g["logits"].shape and torch.isfinite(logits).all()
 
     # (1) executor vs stepwise op sequence: bit identical
-    l2, info = forward_stepwise(model, x.cuda())
+    from tokenreduction_amd.stepwise import Trace
+    trace = Trace(keep=True)
+    l2, info = forward_stepwise(model, x.cuda(), trace)
+    info["trace"] = trace
     assert torch.equal(l2.cpu(), logits)
     for blk, idx in info["kept"].items():
         np.testing.assert_array_equal(viz["Kept_Tokens"][blk][:, :idx.shape[1]], idx.cpu().numpy())
+
+    if case["family"] == "tome":
+        return _tome_parity(name, case, g, model, params, cfg, x, logits, viz, info)
 
     # (2) op-boundary pin: the device's own scores -> oracle selection == device selection, bit exact
     for blk, idx in info["kept"].items():
@@ -112,11 +123,77 @@ def test_model_parity(golden_dir, name):
     print(f"   relative L2 error of the logits: vs oracle_bf16 {rel_bf:.3e}, vs reference fp32 {rel_ref:.3e}")
     # bf16 pipeline vs fp32 reference on ill-conditioned synthetic models (see module docstring): relative L2 of the whole
     # logit vector is the stable statistic; max-abs over 2000 logits is printed above for information only
+    # (5) teacher-forced: the oracle (HIP rounding points) given the DEVICE's selections -- (2) already pinned those bit-exact
+    # to the device's own scores -- so what is left is continuous arithmetic only: accumulation order + bf16 rounding flips
+    forced = {blk: idx.cpu().long() for blk, idx in info["kept"].items()}
+    lf = oracle.vit_forward(params, x, cfg, precision="bf16", forced=forced)
+    rel_forced = ((logits - lf).norm() / lf.norm()).item()
+    print(f"   teacher-forced (device selections into the oracle_bf16): relative L2 {rel_forced:.3e}, "
+          f"max abs {(logits - lf).abs().max().item():.2e}")
+    assert rel_forced < FORCED_TOL, rel_forced
     tol = 0.05 if case["embed_dim"] <= 128 else 0.12
     assert rel_bf < tol, rel_bf
     assert rel_ref < tol, rel_ref
     assert all(o >= 0.70 for o in ov_bf + ov_ref), (ov_bf, ov_ref)
     assert all(o[0] >= 0.95 for o in (ov_bf, ov_ref) if o), (ov_bf, ov_ref)
+
+
+def _agree(a, b):
+    return float((np.asarray(a) == np.asarray(b)).mean())
+
+
+def _tome_parity(name, case, g, model, params, cfg, x, logits, viz, info):
+    """ToMe leg of test_model_parity: executor == stepwise on (unm, src, dst); viz contract; bf16 statistics."""
+    B = x.shape[0]
+    n_in = 197
+    sched = oracle.tome_schedule(cfg)
+    forced = {}
+    for blk in range(cfg.depth):
+        r = oracle.tome_block_r(sched.get(blk, 0), n_in)
+        if r > 0:
+            unm, src, dst = info["tome"][blk]
+            forced[blk] = (unm.cpu().long(), src.cpu().long(), dst.cpu().long())
+            # op-boundary pin: the oracle's matching on the device's own K (bf16) == the device's matching, bit exact
+            k = info["trace"].tensors[f"qkv_{blk}"].float().cpu().reshape(B, n_in, 3, cfg.num_heads, 64)[:, :, 1].permute(0, 2, 1, 3)
+            for got, want in zip(forced[blk], oracle.tome_match(k.mean(1), r)):
+                np.testing.assert_array_equal(got.numpy(), want.numpy())
+            a = oracle.tome_assignment(unm.cpu().long(), src.cpu().long(), dst.cpu().long(), n_in).numpy()
+            np.testing.assert_array_equal(viz["Assignment_Maps"][blk], a)      # executor slab == stepwise, via the oracle's map
+            # structure: unm ascending with CLS first, src/unm a partition of the even set, dst inside the odd set
+            u, s_ = unm.cpu().numpy(), src.cpu().numpy()
+            assert (u[:, 0] == 0).all() and (np.diff(u, axis=1) > 0).all()
+            both = np.sort(np.concatenate([u, s_], axis=1), axis=1)
+            np.testing.assert_array_equal(both, np.broadcast_to(np.arange((n_in + 1) // 2), both.shape))
+            assert (dst.cpu().numpy() >= 0).all() and (dst.cpu().numpy() < n_in // 2).all()
+        n_in -= r
+        assert model._last_tokens[blk] == n_in
+    akeys = sorted((k for k in g.files if k.startswith("assign_")), key=lambda k: int(k.split("_")[1]))
+    assert sorted(viz["Assignment_Maps"].keys()) == [int(k.split("_")[1]) for k in akeys]
+    for k in akeys:
+        blk = int(k.split("_")[1])
+        assert viz["Assignment_Maps"][blk].shape == g[k].shape and viz["Assignment_Maps"][blk].dtype == np.int64
+    lb, vb = oracle.tome_forward(params, x, cfg, precision="bf16", return_viz=True)
+    ref = torch.from_numpy(g["logits"])
+    rel_bf = ((logits - lb).norm() / lb.norm()).item()
+    rel_ref = ((logits - ref).norm() / ref.norm()).item()
+    ag_bf = [_agree(viz["Assignment_Maps"][b], vb["Assignment_Maps"][b]) for b in sorted(vb["Assignment_Maps"])]
+    ag_ref = [_agree(viz["Assignment_Maps"][int(k.split("_")[1])], g[k]) for k in akeys]
+    print(f"\n[{name}] relative L2 of logits: vs oracle_bf16 {rel_bf:.3e}, vs reference fp32 {rel_ref:.3e}; "
+          f"assignment agreement vs oracle_bf16 {ag_bf} vs reference {ag_ref}")
+    # teacher-forced: the oracle (HIP rounding points) given the DEVICE's merge decisions, which the loop above pinned
+    # bit-exact to the device's own K -- continuous arithmetic only
+    lf = oracle.tome_forward(params, x, cfg, precision="bf16", forced=forced)
+    rel_forced = ((logits - lf).norm() / lf.norm()).item()
+    print(f"   teacher-forced (device matchings into the oracle_bf16): relative L2 {rel_forced:.3e}, "
+          f"max abs {(logits - lf).abs().max().item():.2e}")
+    assert rel_forced < FORCED_TOL, rel_forced
+    # free-running: every flipped merge changes the token set of all later blocks, and these synthetic models (random
+    # weights, qkv_gain 4-6) are ill-conditioned, so free-running logits are informative only at the coarse level; the
+    # fp32 validation path (tests/test_hip_fp32.py) is the end-to-end pin: every assignment map bit-exact
+    tol = 0.05 if case["embed_dim"] <= 128 else 0.35
+    assert rel_bf < tol and rel_ref < tol, (rel_bf, rel_ref)
+    # the first merge sees identical inputs up to bf16 rounding; later stages drift with the token set (printed above)
+    assert ag_bf[0] >= 0.90 and ag_ref[0] >= 0.80, (ag_bf, ag_ref)
 
 
 def test_batch_independence():

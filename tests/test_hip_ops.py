@@ -287,3 +287,81 @@ def test_evit_block_against_reference_golden(ops, golden_dir):
         if same[b]:
             torch.testing.assert_close(got[b], want[b], atol=3e-2, rtol=0)
     torch.testing.assert_close(got[:, 0], want[:, 0], atol=3e-2, rtol=0)    # CLS row is order-independent
+
+
+# ---------------------------------------------------------------------------------------- ToMe (tome.py)
+@pytest.mark.parametrize("B,N,H", [(2, 197, 6), (2, 138, 2), (3, 98, 3), (1, 7, 1)])
+def test_attention_proportional(ops, B, N, H):
+    """tome.py:48-49: + log(size) on every key's logit.  bf16 kernel vs fp64 on the same bf16 operands."""
+    rng = _rng(70 + N)
+    qkv = _bf(_randn(rng, B * N, 3 * H * 64, scale=1.5))
+    size = torch.from_numpy(rng.integers(1, 6, size=(B, N)).astype(np.float32))
+    q, k, v = qkv.double().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    attn = ((q @ k.transpose(-2, -1)) * 0.125 + size.double().log()[:, None, None, :]).softmax(-1)
+    want = (attn @ v).transpose(1, 2).reshape(B * N, H * 64).float()
+    got, _ = ops.attention(qkv.bfloat16().cuda(), B, N, H, size=size.cuda())
+    # P is rounded to bf16 before P.V (as in the size-free kernel): 2^-8 relative on O(1) values
+    torch.testing.assert_close(got.float().cpu(), want, atol=3e-2, rtol=2e-2)
+    got32, _ = ops.attention_f32(qkv.cuda(), B, N, H, size=size.cuda())
+    torch.testing.assert_close(got32.cpu(), want, atol=2e-5, rtol=2e-5)
+
+
+@pytest.mark.parametrize("f32", [False, True])
+@pytest.mark.parametrize("B,N,H,r", [(3, 197, 6, 59), (2, 197, 2, 98), (2, 138, 3, 41), (2, 98, 6, 1), (1, 5, 1, 2), (2, 8, 2, 3)])
+def test_tome_match_bit_exact(ops, f32, B, N, H, r):
+    """bipartite_soft_matching: integer outputs, bit-exact against the oracle on the device's own K (bf16-rounded for the
+    bf16 path).  Random gaussians: score gaps are far above fp32 accumulation-order noise, checked below."""
+    rng = _rng(1000 + N + r)
+    qkv = _randn(rng, B * N, 3 * H * 64)
+    if not f32:
+        qkv = _bf(qkv)
+    k = qkv.reshape(B, N, 3, H, 64)[:, :, 1].permute(0, 2, 1, 3)            # [B,H,N,64]
+    metric = k.mean(1)
+    unm_w, src_w, dst_w = oracle.tome_match(metric, r)
+    # tie-freeness of the oracle's decision inputs (else the test would be testing the tie rule, covered separately)
+    m = metric / metric.norm(dim=-1, keepdim=True)
+    sc = m[:, ::2] @ m[:, 1::2].transpose(-1, -2)
+    top2 = sc[:, 1:].topk(min(2, sc.shape[-1]), dim=-1).values
+    if top2.shape[-1] == 2:
+        assert (top2[..., 0] - top2[..., 1]).min() > 2e-6
+    unm, src, dst = ops.tome_match((qkv if f32 else qkv.bfloat16()).cuda(), B, N, H, r)
+    np.testing.assert_array_equal(unm.cpu().numpy(), unm_w.numpy())
+    np.testing.assert_array_equal(src.cpu().numpy(), src_w.numpy())
+    np.testing.assert_array_equal(dst.cpu().numpy(), dst_w.numpy())
+
+
+def test_tome_match_ties(ops):
+    """Identical tokens: every score ties.  Row argmax -> first index; rank -> lowest index first; CLS never merged."""
+    B, N, H, r = 1, 9, 1, 2
+    qkv = torch.ones(B * N, 3 * 64)
+    unm, src, dst = ops.tome_match(qkv.cuda(), B, N, H, r)
+    assert src.cpu().tolist() == [[1, 2]] and dst.cpu().tolist() == [[0, 0]] and unm.cpu().tolist() == [[0, 3, 4]]
+
+
+@pytest.mark.parametrize("f32", [False, True])
+@pytest.mark.parametrize("with_size", [False, True])
+@pytest.mark.parametrize("B,N,r,D", [(3, 197, 59, 384), (2, 138, 41, 128), (2, 8, 3, 64), (1, 197, 98, 768)])
+def test_tome_merge_layernorm(ops, f32, with_size, B, N, r, D):
+    rng = _rng(2000 + N + D)
+    x = _randn(rng, B, N, D)
+    delta = _randn(rng, B, N, D, scale=0.3)
+    if not f32:
+        delta = _bf(delta)
+    size = torch.from_numpy(rng.integers(1, 5, size=(B, N, 1)).astype(np.float32)) if with_size else None
+    na, nb = (N + 1) // 2, N // 2
+    perm = np.stack([1 + rng.permutation(na - 1) for _ in range(B)])           # even-set indices 1..na-1, CLS excluded
+    src = torch.from_numpy(perm[:, :r].astype(np.int64))
+    unm = torch.from_numpy(np.sort(np.concatenate([np.zeros((B, 1), dtype=np.int64), perm[:, r:]], axis=1), axis=1))
+    dst = torch.from_numpy(rng.integers(0, max(1, nb // 3), size=(B, r)).astype(np.int64))   # many sources share a destination
+    g, b = 1 + _randn(rng, D, scale=0.1), _randn(rng, D, scale=0.05)
+    xw, sw = oracle.tome_merge(x + delta, size, unm, src, dst)
+    yw = oracle.layer_norm(xw, g, b, 1e-6)
+    xo, so, y = ops.tome_merge_layernorm(x.cuda(), (delta if f32 else delta.bfloat16()).cuda(), None if size is None else size[..., 0].cuda(),
+                                         unm.int().cuda(), src.int().cuda(), dst.int().cuda(), g.cuda(), b.cuda(), 1e-6, f32=f32)
+    assert torch.equal(so.cpu(), sw[..., 0])                                  # sizes are small integers: exact
+    # same fp32 operations in the same (edge) order as torch's scatter_add; only fma contraction may differ
+    torch.testing.assert_close(xo.cpu(), xw, atol=2e-6, rtol=2e-6)
+    if f32:
+        torch.testing.assert_close(y.cpu(), yw, atol=1e-5, rtol=1e-5)
+    else:
+        torch.testing.assert_close(y.float().cpu(), yw, atol=2 * BF16_ULP, rtol=BF16_ULP)

@@ -25,10 +25,12 @@ __device__ __forceinline__ int swap23(int k) { return (k & ~0xC) | ((k & 4) << 1
 
 template <int NKB>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
-                                                           float* __restrict__ cls_rows, int N, int H) {
+                                                           float* __restrict__ cls_rows, const float* __restrict__ size, int N,
+                                                           int H) {
   constexpr int RS = NKB * 64 + 16;  // Vt row stride in bytes: odd multiple of 16 -> conflict-free b128 column reads
   __shared__ __attribute__((aligned(16))) unsigned char sK[NKB * 32 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char sVt[64 * RS];
+  __shared__ float sLB[NKB * 32];   // log2(size[key]): ToMe's proportional attention (tome.py:48-49), 0 without sizes
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
@@ -57,6 +59,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
       dst[(e * RS) >> 1] = (unsigned short)((e & 1) ? (word >> 16) : (word & 0xffffu));
     }
   }
+  for (int key = tid; key < NKB * 32; key += 256)
+    sLB[key] = (size != nullptr && key < N) ? __builtin_amdgcn_logf(size[(size_t)b * N + key]) : 0.f;   // v_log_f32 = log2
   __syncthreads();
 
   const int ql = lane & 31, hh = lane >> 5;
@@ -88,10 +92,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        if (kb == NKB - 1) {
-          const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          if (key >= N) sacc[kb][r] = -INFINITY;
-        }
+        const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        // logits in the log2 domain: (q.k) * dh^-0.5 * log2(e) + log2(size[key])
+        sacc[kb][r] = sacc[kb][r] * c_exp + sLB[key];
+        if (kb == NKB - 1 && key >= N) sacc[kb][r] = -INFINITY;
         mx = fmaxf(mx, sacc[kb][r]);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f((sacc[kb][r] - mx) * c_exp);
+        const float p = __builtin_amdgcn_exp2f(sacc[kb][r] - mx);
         sacc[kb][r] = p;
         l += p;
       }
@@ -152,27 +156,28 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
 }
 
 template <int NKB>
-int launch_attention(const uint16_t* qkv, uint16_t* out, float* cls_rows, int B, int N, int H, hipStream_t st) {
-  hipLaunchKernelGGL(attention_kernel<NKB>, dim3(B * H), dim3(256), 0, st, qkv, out, cls_rows, N, H);
+int launch_attention(const uint16_t* qkv, uint16_t* out, float* cls_rows, const float* size, int B, int N, int H, hipStream_t st) {
+  hipLaunchKernelGGL(attention_kernel<NKB>, dim3(B * H), dim3(256), 0, st, qkv, out, cls_rows, size, N, H);
   return 0;
 }
 
 }  // namespace
 
-extern "C" int tr_attention_bf16(const uint16_t* qkv, uint16_t* out, float* cls_rows, int B, int N, int H, tr_stream_t s) {
+extern "C" int tr_attention_bf16(const uint16_t* qkv, uint16_t* out, float* cls_rows, const float* size, int B, int N, int H,
+                                 tr_stream_t s) {
   TR_REQUIRE(qkv && out, TR_ERR_NULL, "tr_attention_bf16: null pointer");
   TR_REQUIRE(B > 0 && H > 0 && N >= 1, TR_ERR_SHAPE, "tr_attention_bf16: bad shape B=%d N=%d H=%d", B, N, H);
   TR_REQUIRE(N <= 224, TR_ERR_SHAPE, "tr_attention_bf16: N=%d > 224 not supported yet (register-resident score row)", N);
   TR_REQUIRE(tr_aligned16(qkv) && tr_aligned16(out), TR_ERR_ALIGN, "tr_attention_bf16: pointers must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(s);
   switch ((N + 31) / 32) {
-    case 1: launch_attention<1>(qkv, out, cls_rows, B, N, H, st); break;
-    case 2: launch_attention<2>(qkv, out, cls_rows, B, N, H, st); break;
-    case 3: launch_attention<3>(qkv, out, cls_rows, B, N, H, st); break;
-    case 4: launch_attention<4>(qkv, out, cls_rows, B, N, H, st); break;
-    case 5: launch_attention<5>(qkv, out, cls_rows, B, N, H, st); break;
-    case 6: launch_attention<6>(qkv, out, cls_rows, B, N, H, st); break;
-    default: launch_attention<7>(qkv, out, cls_rows, B, N, H, st); break;
+    case 1: launch_attention<1>(qkv, out, cls_rows, size, B, N, H, st); break;
+    case 2: launch_attention<2>(qkv, out, cls_rows, size, B, N, H, st); break;
+    case 3: launch_attention<3>(qkv, out, cls_rows, size, B, N, H, st); break;
+    case 4: launch_attention<4>(qkv, out, cls_rows, size, B, N, H, st); break;
+    case 5: launch_attention<5>(qkv, out, cls_rows, size, B, N, H, st); break;
+    case 6: launch_attention<6>(qkv, out, cls_rows, size, B, N, H, st); break;
+    default: launch_attention<7>(qkv, out, cls_rows, size, B, N, H, st); break;
   }
   TR_CHECK_LAUNCH("tr_attention_bf16");
   return TR_OK;

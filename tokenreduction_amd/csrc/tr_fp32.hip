@@ -75,7 +75,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 // One workgroup per (image, head); one wave per query row at a time.  K is kept TRANSPOSED in LDS (Kt[d][key]) so the lanes
 // of a wave (= keys) read consecutive addresses; V row-major (lane = d for the P.V product).
 __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                            float* __restrict__ cls_rows, int N, int H) {
+                                                            float* __restrict__ cls_rows, const float* __restrict__ size, int N,
+                                                            int H) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int NP = (N + 63) & ~63;
   float* sKt = sm;                       // [64][NP]
@@ -108,7 +109,8 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
         float acc = 0.f;
 #pragma unroll 16
         for (int d = 0; d < 64; ++d) acc = fmaf(sQ[wave * 64 + d], sKt[d * NP + key], acc);
-        acc = key < N ? acc * 0.125f : -INFINITY;      // (q @ k^T) * scale, scale = 64^-0.5
+        // (q @ k^T) * scale [+ size.log(), tome.py:48-49], scale = 64^-0.5
+        acc = key < N ? acc * 0.125f + (size ? logf(size[(size_t)b * N + key]) : 0.f) : -INFINITY;
         s[c] = acc;
         mx = fmaxf(mx, acc);
       }
@@ -162,7 +164,8 @@ extern "C" int tr_gemm_f32(const float* A, const float* W, const float* bias, fl
   return TR_OK;
 }
 
-extern "C" int tr_attention_f32(const float* qkv, float* out, float* cls_rows, int B, int N, int H, tr_stream_t s) {
+extern "C" int tr_attention_f32(const float* qkv, float* out, float* cls_rows, const float* size, int B, int N, int H,
+                                tr_stream_t s) {
   TR_REQUIRE(qkv && out, TR_ERR_NULL, "tr_attention_f32: null pointer");
   TR_REQUIRE(B > 0 && H > 0 && N >= 1 && N <= 256, TR_ERR_SHAPE, "tr_attention_f32: need 1 <= N <= 256 (N=%d)", N);
   const int NP = (N + 63) & ~63;
@@ -170,7 +173,7 @@ extern "C" int tr_attention_f32(const float* qkv, float* out, float* cls_rows, i
   hipStream_t st = static_cast<hipStream_t>(s);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_attention_f32: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-  hipLaunchKernelGGL(attention_f32_kernel, dim3(B * H), dim3(256), lds, st, qkv, out, cls_rows, N, H);
+  hipLaunchKernelGGL(attention_f32_kernel, dim3(B * H), dim3(256), lds, st, qkv, out, cls_rows, size, N, H);
   TR_CHECK_LAUNCH("tr_attention_f32");
   return TR_OK;
 }

@@ -30,7 +30,7 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 struct Plan {
   int P, N0, D, H, Hd, C, kcols;
-  size_t off_x0, off_x1, off_xn, off_qkv, off_ao, off_h, off_d, off_cols, off_cls, off_scores, off_idx, off_compl, off_xcls, total;
+  size_t off_x0, off_x1, off_xn, off_qkv, off_ao, off_h, off_d, off_cols, off_cls, off_scores, off_idx, off_compl, off_xcls, off_size0, off_size1, total;
 };
 
 bool make_plan(const tr_vit_config* c, int B, Plan* p) {
@@ -40,7 +40,7 @@ bool make_plan(const tr_vit_config* c, int B, Plan* p) {
   if (c->patch <= 0 || c->img_size <= 0 || c->img_size % c->patch != 0) return false;
   if (c->depth <= 0 || c->depth > TR_MAX_DEPTH) return false;
   if (c->num_heads <= 0 || c->embed_dim != c->num_heads * 64) return false;
-  if (c->family < TR_FAMILY_DEIT || c->family > TR_FAMILY_EVIT) return false;
+  if (c->family < TR_FAMILY_DEIT || c->family > TR_FAMILY_TOME) return false;
   const int g = c->img_size / c->patch;
   p->P = g * g;
   p->N0 = p->P + 1;
@@ -62,8 +62,10 @@ bool make_plan(const tr_vit_config* c, int B, Plan* p) {
   p->off_cols = o;   o += align_up((size_t)B * p->P * p->kcols * es);
   p->off_cls = o;    o += align_up((size_t)B * p->H * p->N0 * 4);
   p->off_scores = o; o += align_up((size_t)B * p->P * 4);
-  p->off_idx = o;    o += align_up((size_t)B * p->P * 4);
-  p->off_compl = o;  o += align_up((size_t)B * p->P * 4);
+  p->off_idx = o;    o += align_up((size_t)B * p->N0 * 4);
+  p->off_compl = o;  o += align_up((size_t)B * p->N0 * 4);
+  p->off_size0 = o;  o += align_up((size_t)B * p->N0 * 4);
+  p->off_size1 = o;  o += align_up((size_t)B * p->N0 * 4);
   p->off_xcls = o;   o += align_up((size_t)B * p->D * es);
   p->total = o;
   return true;
@@ -86,9 +88,9 @@ inline int op_ln(bool f32, float* x, long ldx, const void* d, long ldd, const fl
   return f32 ? tr_layernorm_f32(x, ldx, static_cast<const float*>(d), ldd, g, b, static_cast<float*>(y), M, D, eps, s)
              : tr_layernorm_bf16(x, ldx, static_cast<const uint16_t*>(d), ldd, g, b, static_cast<uint16_t*>(y), M, D, eps, s);
 }
-inline int op_attn(bool f32, const void* qkv, void* out, float* cls_rows, int B, int N, int H, tr_stream_t s) {
-  return f32 ? tr_attention_f32(static_cast<const float*>(qkv), static_cast<float*>(out), cls_rows, B, N, H, s)
-             : tr_attention_bf16(static_cast<const uint16_t*>(qkv), static_cast<uint16_t*>(out), cls_rows, B, N, H, s);
+inline int op_attn(bool f32, const void* qkv, void* out, float* cls_rows, const float* size, int B, int N, int H, tr_stream_t s) {
+  return f32 ? tr_attention_f32(static_cast<const float*>(qkv), static_cast<float*>(out), cls_rows, size, B, N, H, s)
+             : tr_attention_bf16(static_cast<const uint16_t*>(qkv), static_cast<uint16_t*>(out), cls_rows, size, B, N, H, s);
 }
 inline int op_gather(bool f32, const float* x, const void* d, const int32_t* idx, const int32_t* cidx, const float* scores,
                      const float* g, const float* b, float* x_out, void* y, int B, int N, int K, int D, float eps, tr_stream_t s) {
@@ -137,6 +139,9 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
   int32_t* idx_ws = reinterpret_cast<int32_t*>(ws + p.off_idx);
   int32_t* compl_ws = reinterpret_cast<int32_t*>(ws + p.off_compl);
   void* xcls = static_cast<void*>(ws + p.off_xcls);
+  float* size_cur = nullptr;                                            // ToMe token sizes: none until the first merge (tome.py:185)
+  float* size_a = reinterpret_cast<float*>(ws + p.off_size0);
+  float* size_b = reinterpret_cast<float*>(ws + p.off_size1);
 
   const int D = p.D, H = p.H;
   const bool f32 = cfg->precision == TR_PREC_FP32;
@@ -149,25 +154,45 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
   const void* pending = nullptr;   // residual not yet added to x (the previous block's fc2 output)
   for (int i = 0; i < cfg->depth; ++i) {
     const tr_block_weights* bw = &w->blocks[i];
-    int K = (cfg->family == TR_FAMILY_DEIT) ? 0 : cfg->keep[i];
+    const bool tome = cfg->family == TR_FAMILY_TOME;
+    int K = (cfg->family == TR_FAMILY_DEIT || tome) ? 0 : cfg->keep[i];
     TR_REQUIRE(K >= 0 && K <= N - 1, TR_ERR_CONFIG, "tr_vit_forward: block %d keeps %d of %d patch tokens", i, K, N - 1);
     if (K == N - 1) K = 0;  // topk.py:57 / evit.py:79: left_tokens == N-1 -> plain block
+    int r = 0;              // ToMe: tokens merged away by this block, r = min(r, (N - protected) // 2)  (tome.py:253)
+    if (tome) {
+      TR_REQUIRE(cfg->keep[i] >= 0, TR_ERR_CONFIG, "tr_vit_forward: block %d has negative ToMe r", i);
+      r = cfg->keep[i] < (N - 1) / 2 ? cfg->keep[i] : (N - 1) / 2;
+    }
     const int M = B * N;
     // x (+= previous mlp output); attn(norm1(x)) -> dbuf   [x + dbuf is the reference's post-attention x, topk.py:87]
     TR_TRY(op_ln(f32, x, D, pending, D, bw->ln1_g, bw->ln1_b, xn, M, D, cfg->ln_eps, s));
     TR_TRY(op_gemm(f32, xn, bw->qkv_w, bw->qkv_b, qkv, nullptr, 0, M, 3 * D, D, TR_EPI_BF16, s));
-    TR_TRY(op_attn(f32, qkv, ao, K > 0 ? cls_rows : nullptr, B, N, H, s));
+    TR_TRY(op_attn(f32, qkv, ao, K > 0 ? cls_rows : nullptr, tome ? size_cur : nullptr, B, N, H, s));
     TR_TRY(op_gemm(f32, ao, bw->proj_w, bw->proj_b, dbuf, nullptr, 0, M, D, D, TR_EPI_BF16, s));
     int Nn = N;
     if (K > 0) {
       // Top-K on the CLS attention, then residual add + gather/compact (+ EViT fused token) + norm2 in one pass
       const bool fuse = cfg->family == TR_FAMILY_EVIT;
-      int32_t* idx_dst = kept_idx ? kept_idx + (size_t)i * B * p.P : idx_ws;
-      int32_t* compl_dst = fuse ? (compl_idx ? compl_idx + (size_t)i * B * p.P : compl_ws) : nullptr;
+      int32_t* idx_dst = kept_idx ? kept_idx + (size_t)i * B * p.N0 : idx_ws;
+      int32_t* compl_dst = fuse ? (compl_idx ? compl_idx + (size_t)i * B * p.N0 : compl_ws) : nullptr;
       TR_TRY(tr_cls_topk(cls_rows, idx_dst, compl_dst, scores, B, H, N, K, s));
       TR_TRY(op_gather(f32, x, dbuf, idx_dst, compl_dst, scores, bw->ln2_g, bw->ln2_b, x_alt, xn, B, N, K, D, cfg->ln_eps, s));
       float* t = x; x = x_alt; x_alt = t;
       Nn = K + 1 + (fuse ? 1 : 0);
+    } else if (r > 0) {
+      // ToMe: bipartite matching on mean-over-heads K, then residual add + size-weighted merge + norm2 in one pass
+      const int na = (N + 1) / 2;
+      int32_t* slab = kept_idx ? kept_idx + (size_t)i * B * p.N0 : idx_ws;
+      int32_t* unm = slab;
+      int32_t* src = slab + (size_t)B * (na - r);
+      int32_t* dst = src + (size_t)B * r;
+      float* size_next = (size_cur == size_a) ? size_b : size_a;
+      TR_TRY(tr_tome_match(qkv, f32 ? 1 : 0, unm, src, dst, B, N, H, r, s));
+      TR_TRY(tr_tome_merge_layernorm(x, dbuf, f32 ? 1 : 0, size_cur, unm, src, dst, bw->ln2_g, bw->ln2_b, x_alt, size_next, xn, B, N, r,
+                                     D, cfg->ln_eps, s));
+      float* t = x; x = x_alt; x_alt = t;
+      size_cur = size_next;
+      Nn = N - r;
     } else {
       TR_TRY(op_ln(f32, x, D, dbuf, D, bw->ln2_g, bw->ln2_b, xn, M, D, cfg->ln_eps, s));
     }

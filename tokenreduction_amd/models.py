@@ -219,8 +219,8 @@ class VisionTransformer(nn.Module):
                                    "classes of 4, head_dim 64)")
             P = self.patch_embed.num_patches
             ws = dict(buf=torch.empty(nbytes, dtype=torch.uint8, device=dev), nbytes=nbytes,
-                      kept=torch.empty(self.depth * B * P, dtype=torch.int32, device=dev),
-                      compl=torch.empty(self.depth * B * P, dtype=torch.int32, device=dev))
+                      kept=torch.empty(self.depth * B * (P + 1), dtype=torch.int32, device=dev),
+                      compl=torch.empty(self.depth * B * (P + 1), dtype=torch.int32, device=dev))
             self._ws = {B: ws}   # keep one batch size resident
         return ws
 
@@ -313,7 +313,7 @@ class TopKVisionTransformer(_TopKBase):
         kept = ws["kept"].cpu().numpy()
         decisions = {}
         for blk, n_in, K in self._stage_indices(ws, B, tokens):
-            decisions[blk] = kept[blk * B * P: blk * B * P + B * K].reshape(B, K).astype(np.int64)
+            decisions[blk] = kept[blk * B * (P + 1): blk * B * (P + 1) + B * K].reshape(B, K).astype(np.int64)
         return {"Kept_Tokens": decisions, "Features": {}}
 
 
@@ -330,8 +330,66 @@ class EfficientVisionTransformer(_TopKBase):
         compl = ws["compl"].cpu().numpy()
         decisions, fusion = {}, {}
         for blk, n_in, K in self._stage_indices(ws, B, tokens):
-            idx = kept[blk * B * P: blk * B * P + B * K].reshape(B, K).astype(np.int64)
+            idx = kept[blk * B * (P + 1): blk * B * (P + 1) + B * K].reshape(B, K).astype(np.int64)
             decisions[blk] = np.concatenate([idx, -np.ones((B, 1), dtype=np.int64)], axis=1)   # evit.py:123
             nc = n_in - 1 - K
-            fusion[blk] = compl[blk * B * P: blk * B * P + B * nc].reshape(B, nc).astype(np.int64)
+            fusion[blk] = compl[blk * B * (P + 1): blk * B * (P + 1) + B * nc].reshape(B, nc).astype(np.int64)
         return {"Kept_Tokens": decisions, "Fusion_Assign": fusion, "Features": {}}
+
+
+class ToMeVisionTransformer(VisionTransformer):
+    """models/tome.py:107-223: bipartite soft matching + size-weighted merge between attention and MLP, proportional attention."""
+    _family = _lib.TR_FAMILY_TOME
+
+    def __init__(self, *a, args=None, **kw):
+        super().__init__(*a, args=args, **kw)
+        token_ratio = list(args.keep_rate)
+        pruning_loc = list(args.reduction_loc)
+        P0 = self.patch_embed.num_patches
+        if len(token_ratio) == 1:
+            token_ratio = [int(P0 * token_ratio[0] ** (idx + 1)) for idx in range(len(pruning_loc))]      # tome.py:145-146
+        assert len(token_ratio) == len(pruning_loc), \
+            f"Mismatch between the pruning location ({pruning_loc}) and token ratios ({token_ratio})"
+        # explicit values are ABSOLUTE patch-token counts; the CLI delivers floats, which crash the reference's slicing
+        # (SURVEY App. A.4) -- cast to int here
+        token_ratio = [int(t) for t in token_ratio]
+        prev = P0
+        for t, loc in zip(token_ratio, pruning_loc):                                                        # tome.py:152-155
+            self._keep[loc] = prev - t
+            self.blocks[loc].r = prev - t
+            prev = t
+        if any(k < 0 for k in self._keep):
+            raise ValueError(f"ToMe token counts must be non-increasing, got {token_ratio}")
+        self.num_patches = P0
+        self.deit_distillation = False
+        self.pruning_loc = pruning_loc
+        self.token_ratio = token_ratio
+        self.prop_attn = True
+
+    def get_reduction_count(self):
+        return self.pruning_loc
+
+    def _viz_data(self, ws, B, tokens):
+        """Assignment_Maps[blk] (tome.py:91-99): for every input patch token, the index of its output token minus 1 -- derived
+        from the device's (unm, src, dst) instead of pushing a B*N*N identity through the merge like the reference does."""
+        N0 = self.patch_embed.num_patches + 1
+        slab = ws["kept"].cpu().numpy()
+        maps = {}
+        n_in = N0
+        for blk in range(self.depth):
+            r = min(self._keep[blk], (n_in - 1) // 2)
+            if r > 0 and blk in self.pruning_loc:
+                na, nb = (n_in + 1) // 2, n_in // 2
+                base = blk * B * N0
+                unm = slab[base: base + B * (na - r)].reshape(B, na - r).astype(np.int64)
+                src = slab[base + B * (na - r): base + B * na].reshape(B, r).astype(np.int64)
+                dst = slab[base + B * na: base + B * (na + r)].reshape(B, r).astype(np.int64)
+                pos_a = np.zeros((B, na), dtype=np.int64)
+                np.put_along_axis(pos_a, unm, np.broadcast_to(np.arange(na - r), (B, na - r)), axis=1)
+                np.put_along_axis(pos_a, src, (na - r) + dst, axis=1)
+                out = np.empty((B, n_in), dtype=np.int64)
+                out[:, 0::2] = pos_a
+                out[:, 1::2] = (na - r) + np.arange(nb)
+                maps[blk] = (out - 1)[:, 1:]
+            n_in = tokens[blk]
+        return {"Assignment_Maps": maps, "Features": {}}

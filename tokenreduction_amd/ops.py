@@ -79,12 +79,13 @@ def layernorm(x: torch.Tensor, gamma, beta, eps: float, rows: int = None, ldx: i
     return y
 
 
-def attention(qkv: torch.Tensor, B: int, N: int, H: int, want_cls: bool = False):
+def attention(qkv: torch.Tensor, B: int, N: int, H: int, want_cls: bool = False, size: torch.Tensor = None):
     """softmax(q k^T / 8) v per (image, head) (topk.py:44-51).  qkv bf16 [B*N, 3*H*64] -> (out bf16 [B*N, H*64], cls_rows|None)."""
     out = torch.empty(B * N, H * 64, dtype=torch.bfloat16, device=qkv.device)
     cls_rows = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device) if want_cls else None
     _lib.check(_lib.load().tr_attention_bf16(_dev(qkv, torch.bfloat16, "qkv"), out.data_ptr(),
-                                             None if cls_rows is None else cls_rows.data_ptr(), B, N, H, _stream()),
+                                             None if cls_rows is None else cls_rows.data_ptr(), _opt(size, torch.float32, "size"),
+                                             B, N, H, _stream()),
                "tr_attention_bf16")
     return out, cls_rows
 
@@ -142,9 +143,41 @@ def layernorm_f32(x: torch.Tensor, gamma, beta, eps: float, delta: torch.Tensor 
     return y
 
 
-def attention_f32(qkv: torch.Tensor, B: int, N: int, H: int, want_cls: bool = False):
+def attention_f32(qkv: torch.Tensor, B: int, N: int, H: int, want_cls: bool = False, size: torch.Tensor = None):
     out = torch.empty(B * N, H * 64, dtype=torch.float32, device=qkv.device)
     cls_rows = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device) if want_cls else None
     _lib.check(_lib.load().tr_attention_f32(_dev(qkv, torch.float32, "qkv"), out.data_ptr(),
-                                            None if cls_rows is None else cls_rows.data_ptr(), B, N, H, _stream()), "tr_attention_f32")
+                                            None if cls_rows is None else cls_rows.data_ptr(), _opt(size, torch.float32, "size"),
+                                            B, N, H, _stream()), "tr_attention_f32")
     return out, cls_rows
+
+
+# ---------------------------------------------------------------------------------------- ToMe (models/tome.py)
+def tome_match(qkv: torch.Tensor, B: int, N: int, H: int, r: int):
+    """bipartite_soft_matching (tome.py:230-277) on metric = k.mean(1): qkv bf16|fp32 [B*N, 3*H*64] ->
+    (unm_idx [B, ceil(N/2)-r], src_idx [B,r], dst_idx [B,r]) int32."""
+    if qkv.dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError("qkv must be bf16 or fp32")
+    na = (N + 1) // 2
+    unm = torch.empty(B, na - r, dtype=torch.int32, device=qkv.device)
+    src = torch.empty(B, r, dtype=torch.int32, device=qkv.device)
+    dst = torch.empty(B, r, dtype=torch.int32, device=qkv.device)
+    _lib.check(_lib.load().tr_tome_match(_dev(qkv, qkv.dtype, "qkv"), int(qkv.dtype == torch.float32), unm.data_ptr(), src.data_ptr(),
+                                         dst.data_ptr(), B, N, H, r, _stream()), "tr_tome_match")
+    return unm, src, dst
+
+
+def tome_merge_layernorm(x: torch.Tensor, delta, size, unm, src, dst, gamma, beta, eps: float, f32: bool = False):
+    """merge_wavg (tome.py:309-323) of x (+ delta) with norm2 fused: -> (x_out fp32 [B,N-r,D], size_out fp32 [B,N-r], y)."""
+    B, N, D = x.shape
+    r = src.shape[1]
+    x_out = torch.empty(B, N - r, D, dtype=torch.float32, device=x.device)
+    size_out = torch.empty(B, N - r, dtype=torch.float32, device=x.device)
+    y = torch.empty(B, N - r, D, dtype=torch.float32 if f32 else torch.bfloat16, device=x.device)
+    ddt = torch.float32 if f32 else torch.bfloat16
+    _lib.check(_lib.load().tr_tome_merge_layernorm(
+        _dev(x, torch.float32, "x"), _opt(delta, ddt, "delta"), int(f32), _opt(size, torch.float32, "size"), _dev(unm, torch.int32, "unm"),
+        _dev(src, torch.int32, "src"), _dev(dst, torch.int32, "dst"), _dev(gamma, torch.float32, "gamma"),
+        _dev(beta, torch.float32, "beta"), x_out.data_ptr(), size_out.data_ptr(), y.data_ptr(), B, N, r, D, eps, _stream()),
+        "tr_tome_merge_layernorm")
+    return x_out, size_out, y

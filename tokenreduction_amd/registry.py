@@ -17,7 +17,7 @@ from functools import partial
 import torch
 import torch.nn as nn
 
-from .models import EfficientVisionTransformer, TopKVisionTransformer, VisionTransformer
+from .models import EfficientVisionTransformer, ToMeVisionTransformer, TopKVisionTransformer, VisionTransformer
 
 _model_entrypoints = {}
 
@@ -93,11 +93,12 @@ for _size in _DIMS:
     for _name, _cls, _drop in ((f"deit_{_size}_patch16_224_local", VisionTransformer, True),
                                (f"deit_{_size}_patch16_224_local_viz", VisionTransformer, False),
                                (f"topk_{_size}_patch16_224", TopKVisionTransformer, False),
-                               (f"evit_{_size}_patch16_224", EfficientVisionTransformer, False)):
+                               (f"evit_{_size}_patch16_224", EfficientVisionTransformer, False),
+                               (f"tome_{_size}_patch16_224", ToMeVisionTransformer, False)):
         _f = _make(_cls, _size, _name, _drop)
         _f.__name__ = _name
         register_model(_f)
-    for _fam, _row in (("tome", "a12-a15"), ("ats", "a16-a18"), ("dpcknn", "a19-a20"), ("kmedoids", "a21"),
+    for _fam, _row in (("ats", "a16-a18"), ("dpcknn", "a19-a20"), ("kmedoids", "a21"),
                        ("sinkhorn", "a22"), ("sit", "a23"), ("dyvit", "a10-a11"), ("patchmerger", "f4"),
                        ("heuristic", "f4")):
         _f = _planned(_fam, _row)

@@ -94,16 +94,20 @@ def forward_stepwise(model: VisionTransformer, x: torch.Tensor, trace: Optional[
     eps = float(model.norm.eps)
     fuse = cfg.family == 2
     pending = None     # bf16 residual not yet added to h (previous block's fc2 output)
+    tome = cfg.family == 3
+    size = None        # ToMe token sizes [B, N] (None until the first merge)
+    info["tome"] = {}
     for i, blk in enumerate(model.blocks):
-        K = 0 if cfg.family == 0 else int(cfg.keep[i])
+        K = 0 if cfg.family == 0 or tome else int(cfg.keep[i])
         if K == N - 1:
             K = 0
+        r = min(int(cfg.keep[i]), (N - 1) // 2) if tome else 0
         M = B * N
         xn = tr.run("layernorm_kernel", 0.0, (6.0 if pending is None else 12.0) * M * D,
                     lambda: ops.layernorm(h, f32(blk.norm1.weight), f32(blk.norm1.bias), eps, delta=pending))
         qkv = _gemm(tr, xn, bf(blk.attn.qkv.weight), f32(blk.attn.qkv.bias), ops.TR_EPI_BF16, tag="qkv")
         ao, cls_rows = tr.run("attention_kernel", 4.0 * B * H * N * N * 64, 2.0 * M * 4 * D,
-                              lambda: ops.attention(qkv, B, N, H, want_cls=K > 0))
+                              lambda: ops.attention(qkv, B, N, H, want_cls=K > 0, size=size))
         tr.save(f"attn_out_{i}", ao)
         d1 = _gemm(tr, ao, bf(blk.attn.proj.weight), f32(blk.attn.proj.bias), ops.TR_EPI_BF16, tag="d1")
         if K > 0:
@@ -117,6 +121,17 @@ def forward_stepwise(model: VisionTransformer, x: torch.Tensor, trace: Optional[
             h = h3.view(B * Nn, D)
             xn = xn.view(B * Nn, D)
             N = Nn
+        elif r > 0:
+            unm, src, dst = tr.run("tome_match_kernel", 2.0 * B * (N // 2) * ((N + 1) // 2) * 64, 2.0 * M * D,
+                                   lambda: ops.tome_match(qkv, B, N, H, r))
+            info["tome"][i] = (unm, src, dst)
+            tr.save(f"qkv_{i}", qkv)
+            h3, size, xn = tr.run("tome_merge_layernorm_kernel", 0.0, 6.0 * M * D + 6.0 * B * (N - r) * D,
+                                  lambda: ops.tome_merge_layernorm(h.view(B, N, D), d1.view(B, N, D), size, unm, src, dst,
+                                                                   f32(blk.norm2.weight), f32(blk.norm2.bias), eps))
+            N = N - r
+            h = h3.view(B * N, D)
+            xn = xn.view(B * N, D)
         else:
             xn = tr.run("layernorm_kernel", 0.0, 12.0 * M * D,
                         lambda: ops.layernorm(h, f32(blk.norm2.weight), f32(blk.norm2.bias), eps, delta=d1))
