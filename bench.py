@@ -238,6 +238,25 @@ def main():
             d_ips = BATCH * 10 / (time.perf_counter() - t1)
             rec["dense_deit_s_images_per_s"] = round(d_ips, 1)
             rec["speedup_vs_dense"] = round(ips / d_ips, 3)
+            # the other single-GPU BASELINE configs, same batch, same kernels (informational; `value` stays configs[1] Top-K)
+            others = {}
+            for label, name, kr, loc in (("evit_small kr0.7 (configs[1])", "evit_small_patch16_224", [0.7], [3, 6, 9]),
+                                         ("tome_small r16 every block (configs[2])", "tome_small_patch16_224",
+                                          [196 - 16 * (i + 1) for i in range(12)], list(range(12))),
+                                         ("topk_small kr0.5 (north_star speed-up target)", MODEL, [0.5], [3, 6, 9])):
+                m2 = build_model(name, kr, loc, dev)
+                for _ in range(3):
+                    m2(x)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    m2(x)
+                torch.cuda.synchronize()
+                o_ips = BATCH * 10 / (time.perf_counter() - t1)
+                others[label] = {"images_per_s": round(o_ips, 1), "speedup_vs_dense": round(o_ips / d_ips, 3),
+                                 "tokens_per_block": m2._last_tokens}
+                del m2
+            rec["other_configs"] = others
             rec["cpu_baseline"] = cpu_baseline_leg(model)
         print(json.dumps(rec), flush=True)
     if dist is not None:

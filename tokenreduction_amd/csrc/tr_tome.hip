@@ -3,7 +3,7 @@
 //   tr_tome_match             bipartite_soft_matching (tome.py:230-277, class_token=True) on metric = k.mean(1) (tome.py:58):
 //                             cosine scores between even- and odd-position tokens, row max/argmax, descending rank of the
 //                             row maxima, split into merged (src -> dst) and unmerged tokens.  One workgroup per image; the
-//                             whole problem (<= 113 x 112 x 64 MACs) lives in LDS.  Integer outputs; ties: row argmax ->
+//                             whole problem (<= 113 x 112 x 64 MACs) lives in LDS, scores in 4x4 register tiles.  Integer outputs; ties: row argmax ->
 //                             first index (torch CPU max), rank -> lowest index first (torch's argsort order is unspecified).
 //   tr_tome_merge_layernorm   merge_wavg (tome.py:309-323): x = merge(x*size) / merge(size), size = merge(size), with the
 //                             pending residual add (x + attn.proj output, tome.py:84) in front and norm2 (tome.py:101) behind,
@@ -18,10 +18,11 @@ namespace {
 constexpr int TOME_MAX_N = 224;      // tokens incl. CLS (224^2 inputs: 197)
 constexpr int MST = 65;              // metric row stride in floats (odd: conflict-free column walks)
 
-template <bool F32>
-__device__ __forceinline__ float load_k(const void* qkv, size_t elem) {
-  if (F32) return reinterpret_cast<const float*>(qkv)[elem];
-  return bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(qkv)[elem]);
+// order-preserving map float -> uint32 (a < b  <=>  key(a) < key(b)), so (score, lowest j) maxima reduce with one ds_max_u64
+__device__ __forceinline__ unsigned long long score_key(float v, int j) {
+  unsigned int u = __float_as_uint(v);
+  u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;
+  return ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - (unsigned int)j);
 }
 
 template <bool F32>
@@ -29,68 +30,140 @@ __global__ __launch_bounds__(256) void tome_match_kernel(const void* __restrict_
                                                          int32_t* __restrict__ src_idx, int32_t* __restrict__ dst_idx, int N, int H,
                                                          int r) {
   __shared__ float s_m[TOME_MAX_N * MST];
-  __shared__ float s_max[(TOME_MAX_N + 1) / 2];
-  __shared__ int s_arg[(TOME_MAX_N + 1) / 2];
+  __shared__ unsigned long long s_key[(TOME_MAX_N + 1) / 2];
   __shared__ int s_edge[(TOME_MAX_N + 1) / 2];
   __shared__ unsigned char s_unm[(TOME_MAX_N + 1) / 2];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int na = (N + 1) >> 1, nb = N >> 1;
   const int ldq = 3 * H * 64;
-  // metric = mean over heads of K (post-bias): sequential fp32 sum over h, then / H, like a strided torch mean
-  for (int e = tid; e < N * 64; e += 256) {
-    const int n = e >> 6, d = e & 63;
-    float acc = 0.f;
-    for (int h = 0; h < H; ++h) acc += load_k<F32>(qkv, ((size_t)b * N + n) * ldq + H * 64 + h * 64 + d);
-    s_m[n * MST + d] = acc / (float)H;
-  }
-  __syncthreads();
-  // metric / metric.norm(dim=-1)
-  for (int n = tid; n < N; n += 256) {
-    // validation path: accumulate in fp64 and round once -- within 0.5 ulp of the exact value, so the ranking can only differ
-    // from the reference's fp32 matmul where its own rounding (a few ulp) decides, i.e. on near-ties below ~4e-7
+  // metric = mean over heads of K (post-bias), then metric / metric.norm(dim=-1)  (tome.py:58, :255).  One 8-wide chunk of a
+  // token per lane (16-B loads for bf16), head sum sequential in fp32 like a strided torch mean; the 8 lanes of a token
+  // share the sum of squares through the wave.
+  for (int item = tid; item < N * 8; item += 256) {
+    const int n = item >> 3, c = item & 7;
+    float m[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[k] = 0.f;
+    const size_t e0 = ((size_t)b * N + n) * ldq + H * 64 + c * 8;
+    for (int h = 0; h < H; ++h) {
+      if (F32) {
+        const float4 u0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(qkv) + e0 + h * 64);
+        const float4 u1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(qkv) + e0 + h * 64 + 4);
+        m[0] += u0.x; m[1] += u0.y; m[2] += u0.z; m[3] += u0.w; m[4] += u1.x; m[5] += u1.y; m[6] += u1.z; m[7] += u1.w;
+      } else {
+        const uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(qkv) + e0 + h * 64);
+        m[0] += __uint_as_float(u.x << 16); m[1] += __uint_as_float(u.x & 0xffff0000u);
+        m[2] += __uint_as_float(u.y << 16); m[3] += __uint_as_float(u.y & 0xffff0000u);
+        m[4] += __uint_as_float(u.z << 16); m[5] += __uint_as_float(u.z & 0xffff0000u);
+        m[6] += __uint_as_float(u.w << 16); m[7] += __uint_as_float(u.w & 0xffff0000u);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[k] = m[k] / (float)H;
     float nrm;
     if (F32) {
+      // validation path: fp64 sums rounded once -- within 0.5 ulp of exact, so the ranking can only differ from the
+      // reference's fp32 matmul where its own rounding (a few ulp) decides, i.e. on near-ties below ~4e-7
       double ss = 0.0;
-      for (int d = 0; d < 64; ++d) ss += (double)s_m[n * MST + d] * (double)s_m[n * MST + d];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) ss += (double)m[k] * (double)m[k];
+      ss += __shfl_xor(ss, 1, 64);
+      ss += __shfl_xor(ss, 2, 64);
+      ss += __shfl_xor(ss, 4, 64);
       nrm = (float)sqrt(ss);
     } else {
       float ss = 0.f;
-      for (int d = 0; d < 64; ++d) ss = fmaf(s_m[n * MST + d], s_m[n * MST + d], ss);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) ss = fmaf(m[k], m[k], ss);
+      ss += __shfl_xor(ss, 1, 64);
+      ss += __shfl_xor(ss, 2, 64);
+      ss += __shfl_xor(ss, 4, 64);
       nrm = sqrtf(ss);
     }
-    for (int d = 0; d < 64; ++d) s_m[n * MST + d] = s_m[n * MST + d] / nrm;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s_m[n * MST + c * 8 + k] = m[k] / nrm;
   }
+  for (int i = tid; i < na; i += 256) s_key[i] = score_key(-INFINITY, 0);    // row 0 (CLS) stays -inf: never merged (tome.py:259)
   __syncthreads();
-  // row i of scores = a_i . b_j (a = even tokens, b = odd tokens); row 0 is CLS: -inf (never merged)
-  for (int i = tid; i < na; i += 256) {
-    float best = -INFINITY;
-    int arg = 0;
-    if (i > 0) {
-      const float* ai = s_m + (2 * i) * MST;
-      for (int j = 0; j < nb; ++j) {
-        const float* bj = s_m + (2 * j + 1) * MST;
-        float acc;
-        if (F32) {
-          double a64 = 0.0;
-          for (int d = 0; d < 64; ++d) a64 += (double)ai[d] * (double)bj[d];
-          acc = (float)a64;
-        } else {
-          acc = 0.f;
-          for (int d = 0; d < 64; ++d) acc = fmaf(ai[d], bj[d], acc);
+  // scores[i][j] = a_i . b_j (a = even tokens, b = odd tokens) in 4x4 register tiles, rows/columns STRIDED over the tile grid
+  // (i = ti + nti*ii, j = tj + ntj*jj) so the lanes of a wave read consecutive b rows (conflict-free, a rows broadcast);
+  // row max/argmax (ties -> lowest j, torch's CPU max) through ds_max_u64 on an order-preserving (score, ~j) key
+  const int nti = (na + 3) >> 2, ntj = (nb + 3) >> 2;
+  for (int t = tid; t < nti * ntj; t += 256) {
+    const int ti = t / ntj, tj = t - ti * ntj;
+    const float* ap[4];
+    const float* bp[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      ap[q] = s_m + (size_t)(2 * min(ti + nti * q, na - 1)) * MST;
+      bp[q] = s_m + (size_t)(2 * min(tj + ntj * q, nb - 1) + 1) * MST;
+    }
+    float best[4];
+    int arg[4];
+    if (F32) {
+      double acc[4][4];
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = 0.0;
+      for (int d = 0; d < 64; ++d) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { av[q] = (double)ap[q][d]; bv[q] = (double)bp[q][d]; }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) acc[ii][jj] += av[ii] * bv[jj];
+      }
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        best[ii] = -INFINITY; arg[ii] = 0;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int j = tj + ntj * jj;
+          const float v = (float)acc[ii][jj];
+          if (j < nb && v > best[ii]) { best[ii] = v; arg[ii] = j; }     // j ascending, strict >: first index wins ties
         }
-        if (acc > best) { best = acc; arg = j; }     // strict >: first index wins ties
+      }
+    } else {
+      float acc[4][4];
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = 0.f;
+#pragma unroll 8
+      for (int d = 0; d < 64; ++d) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { av[q] = ap[q][d]; bv[q] = bp[q][d]; }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = fmaf(av[ii], bv[jj], acc[ii][jj]);
+      }
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        best[ii] = -INFINITY; arg[ii] = 0;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int j = tj + ntj * jj;
+          if (j < nb && acc[ii][jj] > best[ii]) { best[ii] = acc[ii][jj]; arg[ii] = j; }
+        }
       }
     }
-    s_max[i] = best;
-    s_arg[i] = arg;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      const int i = ti + nti * ii;
+      if (i > 0 && i < na) atomicMax(&s_key[i], score_key(best[ii], arg[ii]));
+    }
   }
   __syncthreads();
-  // descending rank of the row maxima (ties: lowest index first) = argsort(descending)
+  // descending rank of the row maxima (ties: lowest index first) = argsort(descending); keys order exactly like the floats
   for (int i = tid; i < na; i += 256) {
-    const float vi = s_max[i];
+    const unsigned int vi = (unsigned int)(s_key[i] >> 32);
     int rank = 0;
     for (int j = 0; j < na; ++j) {
-      const float vj = s_max[j];
+      const unsigned int vj = (unsigned int)(s_key[j] >> 32);
       rank += (vj > vi) || (vj == vi && j < i);
     }
     s_edge[rank] = i;
@@ -100,7 +173,7 @@ __global__ __launch_bounds__(256) void tome_match_kernel(const void* __restrict_
   for (int e = tid; e < r; e += 256) {
     const int i = s_edge[e];
     src_idx[(size_t)b * r + e] = i;
-    dst_idx[(size_t)b * r + e] = s_arg[i];
+    dst_idx[(size_t)b * r + e] = (int)(0xffffffffu - (unsigned int)(s_key[i] & 0xffffffffull));
   }
   // unmerged tokens, ascending (tome.py:275-277: keeps the class token first)
   for (int i = tid; i < na; i += 256) {
@@ -216,6 +289,7 @@ extern "C" int tr_tome_match(const void* qkv, int qkv_is_f32, int32_t* unm_idx, 
   TR_REQUIRE(qkv && unm_idx && src_idx && dst_idx, TR_ERR_NULL, "tr_tome_match: null pointer");
   TR_REQUIRE(B > 0 && H > 0 && N >= 3 && N <= TOME_MAX_N, TR_ERR_SHAPE, "tr_tome_match: need 3 <= N <= %d (N=%d)", TOME_MAX_N, N);
   TR_REQUIRE(r >= 1 && r <= (N - 1) / 2, TR_ERR_SHAPE, "tr_tome_match: r=%d must be in [1, (N-1)/2] for N=%d (tome.py:253)", r, N);
+  TR_REQUIRE(tr_aligned16(qkv), TR_ERR_ALIGN, "tr_tome_match: qkv must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(s);
   if (qkv_is_f32) hipLaunchKernelGGL(tome_match_kernel<true>, dim3(B), dim3(256), 0, st, qkv, unm_idx, src_idx, dst_idx, N, H, r);
   else hipLaunchKernelGGL(tome_match_kernel<false>, dim3(B), dim3(256), 0, st, qkv, unm_idx, src_idx, dst_idx, N, H, r);
