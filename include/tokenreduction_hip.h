@@ -103,6 +103,18 @@ int tr_gather_layernorm_f32(const float* x, const float* delta, const int32_t* i
 int tr_gemm_f32(const float* A, const float* W, const float* bias, float* out, const float* aux, int aux_i, int M, int N, int K,
                 int epilogue, tr_stream_t s);
 
+/* ---- reducers that run before a block (csrc/tr_prune.hip) ------------------------------------------------------------
+ * tr_pool_broadcast: PredictorLG.forward dyvit.py:115-118 with policy == 1 (eval): h [B,N,C] (bf16, or fp32 when is_f32), in
+ *   place: channels C/2..C-1 of every row become mean over the image's PATCH rows (1..N-1) of that channel + eps.
+ * tr_dyvit_score: out_conv.4 + LogSoftmax + [:,:,0] (dyvit.py:108-109,231): h [M,C] -> scores fp32 [M]; w fp32 [2,C], bias [2].
+ * tr_sit_merge: TokenSlimmingModule.forward sit.py:37-39: logits fp32 [B,N,ldl] (row 0 of an image = CLS, ignored; first K
+ *   columns used), softmax(logits*scale) over the patch-token axis, x_out[b,1+k,:] = sum_p w[b,p,k] x[b,1+p,:]; x_out[b,0] =
+ *   x[b,0]; x, x_out fp32 [B,N,D] / [B,K+1,D].  soft (nullable): fp32 [B,K,N-1]. */
+int tr_pool_broadcast(void* h, int is_f32, int B, int N, int C, float eps, tr_stream_t s);
+int tr_dyvit_score(const void* h, int is_f32, const float* w, const float* bias, float* scores, int M, int C, tr_stream_t s);
+int tr_sit_merge(const float* logits, int ldl, float scale, const float* x, float* x_out, float* soft, int B, int N, int K,
+                 int D, tr_stream_t s);
+
 /* a13 bipartite_soft_matching (tome.py:230-277, class_token=True) on metric = k.mean(1) (tome.py:58), read straight from the
  * K third of qkv ([B*N, 3*H*64]; bf16, or fp32 when qkv_is_f32).  Tokens at even positions form set A (CLS = A[0], never
  * merged), odd positions set B.  Outputs (int32): src_idx [B,r] = the r A-tokens with the largest best-match score, in
@@ -125,6 +137,8 @@ int tr_tome_merge_layernorm(const float* x, const void* delta, int f32_path, con
 #define TR_FAMILY_TOPK 1
 #define TR_FAMILY_EVIT 2
 #define TR_FAMILY_TOME 3   /* keep[blk] = r requested for that block (tome.py:152-155); clamped per call to (N-1)/2 */
+#define TR_FAMILY_DYVIT 4  /* eval path of models/dyvit.py: predictor scores -> top-K -> gather BEFORE the block */
+#define TR_FAMILY_SIT 5    /* models/sit.py: soft token slimming BEFORE the block */
 #define TR_MAX_DEPTH 32
 #define TR_PREC_BF16 0   /* the product path: bf16 MFMA operands, fp32 accumulate / residual / statistics */
 #define TR_PREC_FP32 1   /* validation path: the reference's own arithmetic on the GPU (bit-exact indices vs its golden vectors) */
@@ -139,12 +153,27 @@ typedef struct {
   const void* fc2_w; const float* fc2_b;     /* [D,Hd], [D] */
 } tr_block_weights;
 
+/* Learned reduction module of one block (families that own one); unused pointers NULL.
+ *   DyViT PredictorLG (dyvit.py:96-110): ln = in_conv.0 (eps 1e-5), w0/b0 = in_conv.1 [D,D], w1/b1 = out_conv.0 [D/2,D],
+ *     w2/b2 = out_conv.2 [D/4,D/2], w3/b3 = out_conv.4 [2,D/4] (fp32 in both precisions).
+ *   SiT TokenSlimmingModule (sit.py:29-34): ln = weight.0 (eps 1e-5), w0/b0 = weight.1 [D/2,D], w1/b1 = weight.3 zero-padded
+ *     to n_pad rows ([n_pad, D/2], n_pad = K rounded up to 8), scale = the module's scalar. */
+typedef struct {
+  const float* ln_g; const float* ln_b;
+  const void* w0; const float* b0;
+  const void* w1; const float* b1;
+  const void* w2; const float* b2;
+  const float* w3; const float* b3;
+  float scale; int n_pad;
+} tr_stage_weights;
+
 typedef struct {
   const void* patch_w; const float* patch_b;     /* [D, C*p*p], [D] */
   const float* cls_token; const float* pos_embed;/* [D], [(P+1), D] fp32 */
   const float* norm_g; const float* norm_b;
   const void* head_w; const float* head_b;       /* [classes, D], [classes] */
   tr_block_weights blocks[TR_MAX_DEPTH];
+  tr_stage_weights stage[TR_MAX_DEPTH];          /* indexed by BLOCK; read only where keep[blk] > 0 (DyViT, SiT) */
 } tr_vit_weights;
 
 typedef struct {
@@ -152,7 +181,8 @@ typedef struct {
   int img_size, patch, in_chans;
   int embed_dim, depth, num_heads, mlp_hidden, num_classes;
   float ln_eps;
-  int keep[TR_MAX_DEPTH];     /* per block: K patch tokens kept by that block's Top-K, 0 = plain block */
+  int keep[TR_MAX_DEPTH];     /* per block, 0 = plain block.  Top-K/EViT/DyViT: K patch tokens kept; ToMe: r tokens merged
+                                 away; SiT: K output tokens of the slimming module */
   int precision;              /* TR_PREC_* */
 } tr_vit_config;
 
@@ -163,9 +193,10 @@ size_t tr_vit_workspace_bytes(const tr_vit_config* cfg, int B);
  * reduction block blk writes its contiguous [B,K_blk] idx array at offset blk*B*(P+1) (Kept_Tokens, topk.py:196); ToMe
  * writes [unm_idx | src_idx | dst_idx] there ([B,na-r], [B,r], [B,r] back to back).  The slab holds depth*B*(P+1) entries.
  * compl_idx (nullable, EViT): same slab shape, block blk writes [B,P_in-K_blk] at offset blk*B*(P+1)
- * (Fusion_Assign, evit.py:229).  tokens_out (nullable, HOST pointer, int[depth]): token count after each block. */
+ * (Fusion_Assign, evit.py:229).  soft_out (nullable, SiT): fp32, the stages' soft assignments [B,K,P_in] back to back in
+ * block order (Soft_Assignment_Maps, sit.py:124).  tokens_out (nullable, HOST pointer, int[depth]): token count after each block. */
 int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits,
-                   void* workspace, size_t workspace_bytes, int32_t* kept_idx, int32_t* compl_idx,
+                   void* workspace, size_t workspace_bytes, int32_t* kept_idx, int32_t* compl_idx, float* soft_out,
                    int* tokens_out, int B, tr_stream_t s);
 
 #ifdef __cplusplus

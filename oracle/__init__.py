@@ -20,3 +20,18 @@ from .vit import (  # noqa: F401
     gather_compact, complement_idx, evit_fuse, stage_keep_counts, round_bf16,
     tome_schedule, tome_block_r, tome_attention, tome_match, tome_merge, tome_assignment, tome_block_forward, tome_forward,
 )
+from .prune_before import (  # noqa: F401
+    dyvit_keep_counts, dyvit_predictor_scores, dyvit_select, dyvit_forward, sit_cluster_counts, sit_slim, sit_forward,
+)
+
+
+def forward(params, x, cfg, precision="fp32", return_viz=False, forced=None):
+    """Family dispatch used by the tests."""
+    if cfg.family == "tome":
+        return tome_forward(params, x, cfg, precision, return_viz, forced)
+    if cfg.family == "dyvit":
+        return dyvit_forward(params, x, cfg, precision, return_viz, forced)
+    if cfg.family == "sit":
+        assert forced is None
+        return sit_forward(params, x, cfg, precision, return_viz)
+    return vit_forward(params, x, cfg, precision, return_viz, forced)

@@ -48,6 +48,39 @@ def make_params(cfg, seed: int, qkv_gain: float = 1.0):
     return p
 
 
+def make_stage_params(cfg, case: dict):
+    """Extra per-stage weights of the families that own learned reduction modules (state-dict names of the reference):
+    DyViT score_predictor.{j}.* (dyvit.py:96-110), SiT cluster_layers.{j}.* (sit.py:29-34).  Separate generator
+    (wseed + 1000), so the trunk weights of a case do not depend on its family."""
+    fam = case["family"]
+    rng = np.random.default_rng(case["wseed"] + 1000)
+    D = cfg.embed_dim
+    p = {}
+    n_stages = len(case["reduction_loc"])
+    if fam == "dyvit":
+        for j in range(n_stages):
+            b = f"score_predictor.{j}."
+            p[b + "in_conv.0.weight"] = 1.0 + _normal(rng, (D,), 0.1)
+            p[b + "in_conv.0.bias"] = _normal(rng, (D,), 0.05)
+            for name, (o, i) in (("in_conv.1", (D, D)), ("out_conv.0", (D // 2, D)), ("out_conv.2", (D // 4, D // 2)),
+                                 ("out_conv.4", (2, D // 4))):
+                p[b + name + ".weight"] = _normal(rng, (o, i), 0.08)
+                p[b + name + ".bias"] = _normal(rng, (o,), 0.02)
+    elif fam == "sit":
+        from oracle.prune_before import sit_cluster_counts
+        counts = sit_cluster_counts(cfg)
+        for j, loc in enumerate(case["reduction_loc"]):
+            b = f"cluster_layers.{j}."
+            p[b + "weight.0.weight"] = 1.0 + _normal(rng, (D,), 0.1)
+            p[b + "weight.0.bias"] = _normal(rng, (D,), 0.05)
+            p[b + "weight.1.weight"] = _normal(rng, (D // 2, D), 0.08)
+            p[b + "weight.1.bias"] = _normal(rng, (D // 2,), 0.02)
+            p[b + "weight.3.weight"] = _normal(rng, (counts[loc], D // 2), 0.08)
+            p[b + "weight.3.bias"] = _normal(rng, (counts[loc],), 0.02)
+            p[b + "scale"] = torch.full((1, 1, 1), 1.5 + 0.25 * j, dtype=torch.float32)
+    return p
+
+
 def make_images(batch: int, img_size: int, seed: int, in_chans: int = 3):
     rng = np.random.default_rng(seed)
     return torch.from_numpy(rng.standard_normal((batch, in_chans, img_size, img_size)).astype(np.float32))
@@ -86,10 +119,30 @@ GOLDEN_CASES = {
     "tome_small_r16": dict(family="tome", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
                            keep_rate=[196 - 16 * (i + 1) for i in range(12)], reduction_loc=list(range(12)), batch=2,
                            wseed=95, xseed=96, qkv_gain=4.0, factory="tome_small_patch16_224"),
+    # DyViT eval path (models/dyvit.py): predictor MLP scores -> argsort -> gather BEFORE the block
+    "dyvit_micro": dict(family="dyvit", embed_dim=128, depth=4, num_heads=2, num_classes=16,
+                        keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=101, xseed=102, qkv_gain=6.0),
+    "dyvit_small_kr07": dict(family="dyvit", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
+                             keep_rate=[0.7], reduction_loc=[3, 6, 9], batch=2, wseed=103, xseed=104,
+                             qkv_gain=4.0, factory="dyvit_small_patch16_224"),
+    # SiT (models/sit.py): soft assignment (softmax over tokens) BEFORE the block
+    "sit_micro": dict(family="sit", embed_dim=128, depth=4, num_heads=2, num_classes=16,
+                      keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=111, xseed=112, qkv_gain=6.0),
+    "sit_small_kr07": dict(family="sit", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
+                           keep_rate=[0.7], reduction_loc=[3, 6, 9], batch=2, wseed=113, xseed=114,
+                           qkv_gain=4.0, factory="sit_small_patch16_224"),
     "deit_small": dict(family="deit", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
                        keep_rate=[1.0], reduction_loc=[], batch=2, wseed=81, xseed=82,
                        qkv_gain=4.0, factory="deit_small_patch16_224_local"),
 }
+
+
+def case_params(case: dict):
+    """(cfg, params) of a golden case: trunk + the family's stage modules."""
+    cfg = case_config(case)
+    params = make_params(cfg, case["wseed"], case.get("qkv_gain", 1.0))
+    params.update(make_stage_params(cfg, case))
+    return cfg, params
 
 
 def case_config(case: dict):
@@ -97,3 +150,20 @@ def case_config(case: dict):
     return VitConfig(family=case["family"], embed_dim=case["embed_dim"], depth=case["depth"],
                      num_heads=case["num_heads"], num_classes=case["num_classes"],
                      keep_rate=list(case["keep_rate"]), reduction_loc=list(case["reduction_loc"]))
+
+
+def assert_valid_ranking(idx, ref_scores, tol):
+    """idx [B,K] is a correct descending top-K ordering of ref_scores [B,P] up to fp noise `tol`: consecutive picks never
+    increase by more than tol, and nothing left out beats the last pick by more than tol.  (Exact equality with the
+    reference's argsort is only defined where its own fp32 rounding does not decide: adjacent gaps of ~1e-6 are natural
+    among 196 scores, SURVEY App. D.)"""
+    idx = np.asarray(idx)
+    ref_scores = np.asarray(ref_scores)
+    B, K = idx.shape
+    for b in range(B):
+        assert len(set(idx[b].tolist())) == K, "duplicate token index"
+        picked = ref_scores[b][idx[b]]
+        assert (picked[:-1] - picked[1:] >= -tol).all(), "order violates the reference scores beyond fp noise"
+        rest = np.delete(ref_scores[b], idx[b])
+        if rest.size:
+            assert rest.max() <= picked.min() + tol, "a dropped token outranks a kept one beyond fp noise"

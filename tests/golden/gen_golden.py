@@ -38,11 +38,14 @@ from models.topk import TopKVisionTransformer, Attention_TopK  # noqa: E402
 from models.evit import EfficientVisionTransformer, Block_EVIT, complement_idx  # noqa: E402
 from models.deit_viz import VisionTransformer as DeitViz  # noqa: E402
 from models.tome import ToMeVisionTransformer  # noqa: E402
-import models.tome as ref_tome  # noqa: E402
+import models.tome as ref_tome  # noqa: E402,F401
+from models.dyvit import DynamicVisionTransformer  # noqa: E402
+from models.sit import SelfSlimmedVisionTransformer  # noqa: E402
 
-from tests._params import GOLDEN_CASES, make_params, make_images  # noqa: E402
+from tests._params import GOLDEN_CASES, make_params, make_stage_params, make_images, case_config  # noqa: E402
 
-CLASSES = {"topk": TopKVisionTransformer, "evit": EfficientVisionTransformer, "deit": DeitViz, "tome": ToMeVisionTransformer}
+CLASSES = {"topk": TopKVisionTransformer, "evit": EfficientVisionTransformer, "deit": DeitViz, "tome": ToMeVisionTransformer,
+           "dyvit": DynamicVisionTransformer, "sit": SelfSlimmedVisionTransformer}
 
 
 class TopkSpy:
@@ -79,15 +82,23 @@ class ArgsortSpy:
                 spy_self.calls.append(t.detach().clone())
             return orig(t, *a, **kw)
         torch.Tensor.argsort = spy
+        self._orig_fn = torch.argsort
+
+        def spy_fn(t, *a, **kw):                # DyViT calls the function form (dyvit.py:233)
+            if t.dtype.is_floating_point:
+                spy_self.calls.append(t.detach().clone())
+            return spy_self._orig_fn(t, *a, **kw)
+        torch.argsort = spy_fn
         return self
 
     def __exit__(self, *exc):
         torch.Tensor.argsort = self._orig
+        torch.argsort = self._orig_fn
 
 
 def build_reference(case):
     args = types.SimpleNamespace(keep_rate=list(case["keep_rate"]), reduction_loc=list(case["reduction_loc"]),
-                                 viz_mode=True)
+                                 viz_mode=True, dyvit_distill=False)
     with contextlib.redirect_stdout(io.StringIO()):
         if "factory" in case:
             m = create_model(case["factory"], pretrained=False, num_classes=case["num_classes"], drop_rate=0.0,
@@ -100,6 +111,7 @@ def build_reference(case):
     cfg = types.SimpleNamespace(embed_dim=case["embed_dim"], depth=case["depth"], num_heads=case["num_heads"],
                                 mlp_ratio=4, num_classes=case["num_classes"], img_size=224, patch_size=16, in_chans=3)
     params = make_params(cfg, case["wseed"], case.get("qkv_gain", 1.0))
+    params.update(make_stage_params(case_config(case), case))
     missing, unexpected = m.load_state_dict(params, strict=True)
     assert not missing and not unexpected
     return m.eval(), params
@@ -113,16 +125,23 @@ def run_case(name, case):
     logits, viz = out if isinstance(out, tuple) else (out, {})
     rec = {"logits": logits.numpy()}
     tome_gaps = []
-    for nm in aspy.calls:                      # ToMe: ranked row maxima must be tie-free (CLS row is -inf, unique)
+    for nm in aspy.calls:                      # ToMe row maxima / DyViT scores: the ranked values must be tie-free
         for b in range(nm.shape[0]):
             v = nm[b][torch.isfinite(nm[b])]
-            assert torch.unique(v).numel() == v.numel(), f"{name}: tied ToMe row maxima - pick another seed"
+            assert torch.unique(v).numel() == v.numel(), f"{name}: tied ranked values - pick another seed"
             srt = torch.sort(v, descending=True).values
             tome_gaps.append((srt[:-1] - srt[1:]).min().item())
+    if case["family"] == "dyvit":                # the ranked predictor scores themselves: lets a test accept exactly the
+        for blk, sc in zip(sorted(viz["Kept_Tokens"]), aspy.calls):       # orderings that differ by fp noise and no others
+            rec[f"scores_{blk}"] = sc.numpy().astype(np.float32)
     if tome_gaps:
         rec["min_abs_gap_node_max"] = np.array(min(tome_gaps), dtype=np.float64)
     for blk, a in viz.get("Assignment_Maps", {}).items():
         rec[f"assign_{blk}"] = a.astype(np.int64)
+    for blk, a in viz.get("Soft_Assignment_Maps", {}).items():          # SiT: [B,K,P] soft assignment; keep 8 clusters
+        rec[f"soft_{blk}"] = a[:, :8].astype(np.float32)
+        top2 = np.sort(a, axis=1)[:, -2:]                                # hard assignment = argmax over clusters: record its margin
+        rec[f"soft_margin_{blk}"] = np.array((top2[:, 1] - top2[:, 0]).min(), dtype=np.float64)
     gaps = []
     for scores, k in spy.calls:
         for b in range(scores.shape[0]):
@@ -143,7 +162,7 @@ def run_case(name, case):
         rec["token_count_blocks"] = np.array(sorted(feats.keys()), dtype=np.int64)
     np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **rec)
     if tome_gaps:
-        print(f"   ToMe: min abs gap between ranked row maxima {min(tome_gaps):.2e}; "
+        print(f"   argsort inputs: min abs gap between ranked values {min(tome_gaps):.2e}; "
               f"assignment maps {[v.shape for k, v in rec.items() if k.startswith('assign_')]}")
     print(f"{name}: logits {logits.shape} |max| {logits.abs().max():.3f}  min rel gap@K {rec['min_rel_gap_at_k']:.2e}"
           f"  kept {[v.shape for k, v in rec.items() if k.startswith('kept_')]}")

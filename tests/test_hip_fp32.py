@@ -10,7 +10,7 @@ import pytest
 import torch
 
 import oracle
-from tests._params import GOLDEN_CASES, make_images
+from tests._params import GOLDEN_CASES, assert_valid_ranking, make_images
 from tests.test_hip_model import build_model
 
 pytestmark = pytest.mark.gpu
@@ -71,14 +71,30 @@ def test_model_fp32_matches_reference_golden(golden_dir, name):
     kept_keys = sorted(k for k in g.files if k.startswith("kept_"))
     assert sorted(viz.get("Kept_Tokens", {}).keys()) == [int(k.split("_")[1]) for k in kept_keys]
     for k in kept_keys:                                     # bit-exact token indices, every reduction stage, end to end
-        np.testing.assert_array_equal(viz["Kept_Tokens"][int(k.split("_")[1])], g[k])
+        blk = int(k.split("_")[1])
+        if case["family"] == "dyvit":
+            # 196 MLP scores per image have adjacent gaps of ~1e-6 (recorded with the fixture), i.e. at the level of fp32
+            # summation order: the kept SET is exact, the ORDER is the reference's wherever its scores differ by > 2e-5
+            np.testing.assert_array_equal(np.sort(viz["Kept_Tokens"][blk], axis=1), np.sort(g[k], axis=1))
+            assert_valid_ranking(viz["Kept_Tokens"][blk], g[f"scores_{blk}"], tol=2e-5)
+            continue
+        np.testing.assert_array_equal(viz["Kept_Tokens"][blk], g[k])
     for k in (k for k in g.files if k.startswith("compl_")):
         np.testing.assert_array_equal(viz["Fusion_Assign"][int(k.split("_")[1])], g[k])
     akeys = sorted((k for k in g.files if k.startswith("assign_")), key=lambda k: int(k.split("_")[1]))
-    if case["family"] == "tome":
+    if case["family"] in ("tome", "sit"):
         assert sorted(viz["Assignment_Maps"].keys()) == [int(k.split("_")[1]) for k in akeys]
     for k in akeys:                                         # ToMe: every merge decision of every stage, bit-exact
-        np.testing.assert_array_equal(viz["Assignment_Maps"][int(k.split("_")[1])], g[k])
+        blk = int(k.split("_")[1])
+        if case["family"] == "sit":                         # soft assignment to 1e-5 of its max; hard = argmax where no near-tie
+            soft = viz["Soft_Assignment_Maps"][blk]
+            np.testing.assert_allclose(soft[:, :8], g[f"soft_{blk}"], atol=2e-6, rtol=1e-4)
+            if float(g[f"soft_margin_{blk}"]) > 1e-5:
+                np.testing.assert_array_equal(viz["Assignment_Maps"][blk], g[k])
+            else:
+                assert (viz["Assignment_Maps"][blk] == g[k]).mean() > 0.995
+            continue
+        np.testing.assert_array_equal(viz["Assignment_Maps"][blk], g[k])
     kept_keys = kept_keys + akeys
     d = (logits.cpu() - torch.from_numpy(g["logits"])).abs().max().item()
     print(f"\n[{name}] fp32 path: max|logit - reference| = {d:.2e}; indices exact at blocks {[int(k.split('_')[1]) for k in kept_keys]}")

@@ -23,17 +23,18 @@ import pytest
 import torch
 
 import oracle
-from tests._params import GOLDEN_CASES, case_config, make_images, make_params
+from tests._params import GOLDEN_CASES, case_config, case_params, make_images, make_params
 
 pytestmark = pytest.mark.gpu
 
 FAM = {"deit": "VisionTransformer", "topk": "TopKVisionTransformer", "evit": "EfficientVisionTransformer",
-       "tome": "ToMeVisionTransformer"}
+       "tome": "ToMeVisionTransformer", "dyvit": "DynamicVisionTransformer", "sit": "SelfSlimmedVisionTransformer"}
 
 
 def build_model(case):
     import tokenreduction_amd as tra
-    args = types.SimpleNamespace(keep_rate=list(case["keep_rate"]), reduction_loc=list(case["reduction_loc"]), viz_mode=True)
+    args = types.SimpleNamespace(keep_rate=list(case["keep_rate"]), reduction_loc=list(case["reduction_loc"]), viz_mode=True,
+                                 dyvit_distill=False)
     if "factory" in case:
         m = tra.create_model(case["factory"].replace("_local", "_local_viz") if case["family"] == "deit" else case["factory"],
                              pretrained=False, num_classes=case["num_classes"], drop_rate=0.0,
@@ -42,8 +43,7 @@ def build_model(case):
         cls = getattr(tra, FAM[case["family"]])
         m = cls(patch_size=16, embed_dim=case["embed_dim"], depth=case["depth"], num_heads=case["num_heads"], mlp_ratio=4,
                 qkv_bias=True, num_classes=case["num_classes"], args=args)
-    cfg = case_config(case)
-    params = make_params(cfg, case["wseed"], case.get("qkv_gain", 1.0))
+    cfg, params = case_params(case)
     m.load_state_dict(params, strict=True)
     m.viz_mode = True
     return m.cuda().eval(), params, cfg
@@ -86,6 +86,8 @@ def test_model_parity(golden_dir, name):
 
     if case["family"] == "tome":
         return _tome_parity(name, case, g, model, params, cfg, x, logits, viz, info)
+    if case["family"] == "sit":
+        return _sit_parity(name, case, g, model, params, cfg, x, logits, viz, info)
 
     # (2) op-boundary pin: the device's own scores -> oracle selection == device selection, bit exact
     for blk, idx in info["kept"].items():
@@ -109,7 +111,7 @@ def test_model_parity(golden_dir, name):
             assert model._last_tokens[int(blk)] == int(n)
 
     # (4) vs oracle with the HIP rounding points, and vs the reference's fp32 golden
-    lb, vb = oracle.vit_forward(params, x, cfg, precision="bf16", return_viz=True)
+    lb, vb = oracle.forward(params, x, cfg, precision="bf16", return_viz=True)
     d_bf = (logits - lb).abs().max().item()
     d_ref = (logits - torch.from_numpy(g["logits"])).abs().max().item()
     ov_bf = [_overlap(viz["Kept_Tokens"][b], vb["Kept_Tokens"][b]) for b in vb["Kept_Tokens"]]
@@ -126,16 +128,50 @@ def test_model_parity(golden_dir, name):
     # (5) teacher-forced: the oracle (HIP rounding points) given the DEVICE's selections -- (2) already pinned those bit-exact
     # to the device's own scores -- so what is left is continuous arithmetic only: accumulation order + bf16 rounding flips
     forced = {blk: idx.cpu().long() for blk, idx in info["kept"].items()}
-    lf = oracle.vit_forward(params, x, cfg, precision="bf16", forced=forced)
+    lf = oracle.forward(params, x, cfg, precision="bf16", forced=forced)
     rel_forced = ((logits - lf).norm() / lf.norm()).item()
     print(f"   teacher-forced (device selections into the oracle_bf16): relative L2 {rel_forced:.3e}, "
           f"max abs {(logits - lf).abs().max().item():.2e}")
     assert rel_forced < FORCED_TOL, rel_forced
     tol = 0.05 if case["embed_dim"] <= 128 else 0.12
+    if case["family"] == "dyvit":
+        # the predictor ranks 196 MLP scores whose neighbours are ~1e-6 apart: many more bf16-level flips than CLS-attention
+        # top-k, and every flip changes the token set of all later blocks (free-running numbers are informational; the
+        # teacher-forced one above and the fp32 path's exact kept sets are the pins)
+        tol = 0.2 if case["embed_dim"] <= 128 else 0.35
     assert rel_bf < tol, rel_bf
     assert rel_ref < tol, rel_ref
     assert all(o >= 0.70 for o in ov_bf + ov_ref), (ov_bf, ov_ref)
     assert all(o[0] >= 0.95 for o in (ov_bf, ov_ref) if o), (ov_bf, ov_ref)
+
+
+def _sit_parity(name, case, g, model, params, cfg, x, logits, viz, info):
+    """SiT leg: no discrete decision anywhere, so the free-running logits are held to the teacher-forced tolerance."""
+    for blk, soft in info["soft"].items():
+        np.testing.assert_array_equal(viz["Soft_Assignment_Maps"][blk], soft.cpu().numpy())     # executor == stepwise
+    lb, vb = oracle.forward(params, x, cfg, precision="bf16", return_viz=True)
+    ref = torch.from_numpy(g["logits"])
+    rel_bf = ((logits - lb).norm() / lb.norm()).item()
+    rel_ref = ((logits - ref).norm() / ref.norm()).item()
+    akeys = sorted((k for k in g.files if k.startswith("assign_")), key=lambda k: int(k.split("_")[1]))
+    assert sorted(viz["Assignment_Maps"].keys()) == [int(k.split("_")[1]) for k in akeys]
+    ag, dsoft = [], []
+    for k in akeys:
+        blk = int(k.split("_")[1])
+        got = viz["Soft_Assignment_Maps"][blk]
+        assert viz["Assignment_Maps"][blk].shape == g[k].shape and viz["Assignment_Maps"][blk].dtype == np.int64
+        np.testing.assert_allclose(got.sum(axis=2), 1.0, atol=1e-5)             # softmax over the token axis
+        dsoft.append(float(np.abs(got - vb["Soft_Assignment_Maps"][blk]).max() / vb["Soft_Assignment_Maps"][blk].max()))
+        ag.append(_agree(viz["Assignment_Maps"][blk], g[k]))
+    print(f"\n[{name}] relative L2 of logits: vs oracle_bf16 {rel_bf:.3e}, vs reference fp32 {rel_ref:.3e}; soft assignment "
+          f"max err / max vs oracle_bf16 {dsoft}; hard-assignment agreement vs reference {ag}")
+    for blk, n in zip(g["token_count_blocks"], g["token_counts"]):
+        assert model._last_tokens[int(blk)] == int(n)
+    assert rel_bf < FORCED_TOL, rel_bf
+    assert rel_ref < 0.05, rel_ref
+    # hard assignment = argmax over K clusters of nearly equal soft weights at the late stages: noise-dominated in bf16
+    # (printed); the fp32 path pins it (tests/test_hip_fp32.py)
+    assert max(dsoft) < 0.05 and ag[0] > 0.9, (dsoft, ag)
 
 
 def _agree(a, b):

@@ -365,3 +365,49 @@ def test_tome_merge_layernorm(ops, f32, with_size, B, N, r, D):
         torch.testing.assert_close(y.cpu(), yw, atol=1e-5, rtol=1e-5)
     else:
         torch.testing.assert_close(y.float().cpu(), yw, atol=2 * BF16_ULP, rtol=BF16_ULP)
+
+
+# ---------------------------------------------------------------------------------------- DyViT / SiT pieces
+@pytest.mark.parametrize("f32", [False, True])
+@pytest.mark.parametrize("B,N,C", [(3, 197, 384), (2, 138, 128), (2, 5, 64), (1, 97, 768)])
+def test_pool_broadcast(ops, f32, B, N, C):
+    rng = _rng(300 + N)
+    h = _randn(rng, B, N, C)
+    if not f32:
+        h = _bf(h)
+    want = h.clone()
+    g = h[:, 1:, C // 2:].double().mean(dim=1, keepdim=True).float() + 1e-6          # patch rows only, eps outside (dyvit.py:117)
+    want[:, :, C // 2:] = g if f32 else _bf(g)
+    got = ops.pool_broadcast((h if f32 else h.bfloat16()).cuda().reshape(B * N, C), B, N).float().cpu().reshape(B, N, C)
+    assert torch.equal(got[:, :, :C // 2], want[:, :, :C // 2])                      # local half untouched
+    torch.testing.assert_close(got[:, :, C // 2:], want[:, :, C // 2:], atol=(1e-6 if f32 else BF16_ULP * 0.1), rtol=(1e-5 if f32 else BF16_ULP))
+
+
+@pytest.mark.parametrize("f32", [False, True])
+@pytest.mark.parametrize("M,C", [(3 * 197, 96), (2 * 138, 32), (7, 192), (1000, 48)])
+def test_dyvit_score(ops, f32, M, C):
+    rng = _rng(400 + C)
+    h = _randn(rng, M, C)
+    if not f32:
+        h = _bf(h)
+    w, b = _randn(rng, 2, C, scale=0.3), _randn(rng, 2, scale=0.1)
+    want = torch.log_softmax(h.double() @ w.double().t() + b.double(), dim=-1)[:, 0].float()
+    got = ops.dyvit_score((h if f32 else h.bfloat16()).cuda(), w.cuda(), b.cuda()).cpu()
+    torch.testing.assert_close(got, want, atol=2e-6, rtol=2e-6)
+
+
+@pytest.mark.parametrize("B,N,K,D,ldl", [(3, 197, 137, 384, 144), (2, 138, 96, 128, 96), (2, 97, 67, 768, 72), (1, 9, 3, 64, 8),
+                                         (2, 197, 176, 192, 176)])
+def test_sit_merge(ops, B, N, K, D, ldl):
+    rng = _rng(500 + N + K)
+    logits = _randn(rng, B, N, ldl, scale=2.0)
+    x = _randn(rng, B, N, D)
+    scale = 1.7
+    w = torch.softmax(logits[:, 1:, :K].double() * scale, dim=1).transpose(2, 1)      # sit.py:38
+    want = torch.cat([x[:, :1].double(), torch.bmm(w, x[:, 1:].double())], dim=1).float()
+    got, soft = ops.sit_merge(logits.cuda(), scale, x.cuda(), K, want_soft=True)
+    torch.testing.assert_close(soft.cpu(), w.float(), atol=1e-7, rtol=2e-5)
+    torch.testing.assert_close(got.cpu(), want, atol=2e-5, rtol=2e-5)
+    assert torch.equal(got[:, 0].cpu(), x[:, 0])
+    got2, none = ops.sit_merge(logits.cuda(), scale, x.cuda(), K)
+    assert none is None and torch.equal(got2, got)

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import oracle
-from tests._params import GOLDEN_CASES, case_config, make_images, make_params
+from tests._params import GOLDEN_CASES, assert_valid_ranking, case_config, case_params, make_images, make_params
 
 FP_TOL = 2e-5   # fp32 CPU: different op order (im2col GEMM vs conv, fused softmax) only
 
@@ -34,6 +34,8 @@ def test_model_matches_reference(golden_dir, name):
         for blk, n in zip(g["token_count_blocks"], g["token_counts"]):
             assert viz["Tokens"][int(blk)] == int(n)
         return
+    if case["family"] in ("dyvit", "sit"):
+        return _check_prune_before(case, g, x)
     logits, viz = oracle.vit_forward(params, x, cfg, return_viz=True)
     # integer outputs: bit-exact
     kept_keys = sorted(k for k in g.files if k.startswith("kept_"))
@@ -51,6 +53,39 @@ def test_model_matches_reference(golden_dir, name):
     if "token_counts" in g.files:
         for blk, n in zip(g["token_count_blocks"], g["token_counts"]):
             assert viz["Tokens"][int(blk)] == int(n)
+
+
+def _check_prune_before(case, g, x):
+    cfg, params = case_params(case)
+    logits, viz = oracle.forward(params, x, cfg, return_viz=True)
+    np.testing.assert_allclose(logits.numpy(), g["logits"], atol=FP_TOL, rtol=0)
+    np.testing.assert_allclose(viz["Final_Tokens"][:, :8].numpy(), g["final_tokens"], atol=1e-4, rtol=0)
+    for blk, n in zip(g["token_count_blocks"], g["token_counts"]):
+        assert viz["Tokens"][int(blk)] == int(n)
+    if case["family"] == "dyvit":
+        kept_keys = [k for k in g.files if k.startswith("kept_")]
+        assert len(kept_keys) == len(viz["Kept_Tokens"]) > 0
+        for k in kept_keys:
+            blk = int(k.split("_")[1])
+            ref_scores = g[f"scores_{blk}"]
+            np.testing.assert_allclose(viz["Scores"][blk].numpy(), ref_scores, atol=1e-5, rtol=0)
+            # same scores in -> same indices out, bit exact (op-boundary pin)
+            np.testing.assert_array_equal(oracle.dyvit_select(torch.from_numpy(ref_scores), g[k].shape[1]).numpy(), g[k])
+            # end to end: the oracle's own ordering is the reference's up to fp noise in the scores; identical kept SETS
+            assert_valid_ranking(viz["Kept_Tokens"][blk], ref_scores, tol=2e-5)
+            np.testing.assert_array_equal(np.sort(viz["Kept_Tokens"][blk], axis=1), np.sort(g[k], axis=1))
+    else:
+        akeys = [k for k in g.files if k.startswith("assign_")]
+        assert len(akeys) == len(viz["Assignment_Maps"]) > 0
+        for k in akeys:
+            blk = int(k.split("_")[1])
+            np.testing.assert_allclose(viz["Soft_Assignment_Maps"][blk][:, :8], g[f"soft_{blk}"], atol=1e-6, rtol=1e-4)
+            got, want = viz["Assignment_Maps"][blk], g[k]
+            assert got.shape == want.shape
+            if float(g[f"soft_margin_{blk}"]) > 1e-6:      # hard assignment = argmax over clusters: exact when no near-tie
+                np.testing.assert_array_equal(got, want)
+            else:
+                assert (got == want).mean() > 0.995
 
 
 def test_attention_and_select_op(golden_dir):

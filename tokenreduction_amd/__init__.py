@@ -4,6 +4,7 @@ Drop-in for the reference's timm-style factory (`create_model(name, ..., args=ar
 runs in hand-written HIP kernels behind the C ABI in include/tokenreduction_hip.h.
 """
 from .registry import create_model, register_model, list_models, is_model  # noqa: F401
-from .models import VisionTransformer, TopKVisionTransformer, EfficientVisionTransformer, ToMeVisionTransformer  # noqa: F401
+from .models import (VisionTransformer, TopKVisionTransformer, EfficientVisionTransformer, ToMeVisionTransformer,  # noqa: F401
+                     DynamicVisionTransformer, SelfSlimmedVisionTransformer)
 
 __version__ = "0.1.0"

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libtokenreduction_hip.so")
 
 TR_MAX_DEPTH = 32
 TR_EPI_BF16, TR_EPI_GELU_BF16, TR_EPI_RESID_F32, TR_EPI_F32, TR_EPI_PATCH_F32 = 0, 1, 2, 3, 4
-TR_FAMILY_DEIT, TR_FAMILY_TOPK, TR_FAMILY_EVIT, TR_FAMILY_TOME = 0, 1, 2, 3
+TR_FAMILY_DEIT, TR_FAMILY_TOPK, TR_FAMILY_EVIT, TR_FAMILY_TOME, TR_FAMILY_DYVIT, TR_FAMILY_SIT = 0, 1, 2, 3, 4, 5
 TR_PREC_BF16, TR_PREC_FP32 = 0, 1
 
 _vp, _i, _f, _l, _sz = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t
@@ -24,9 +24,14 @@ class TrBlockWeights(C.Structure):
                                    "ln2_g", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
 
 
+class TrStageWeights(C.Structure):
+    _fields_ = [(n, _vp) for n in ("ln_g", "ln_b", "w0", "b0", "w1", "b1", "w2", "b2", "w3", "b3")] + [("scale", _f), ("n_pad", _i)]
+
+
 class TrVitWeights(C.Structure):
     _fields_ = [(n, _vp) for n in ("patch_w", "patch_b", "cls_token", "pos_embed", "norm_g", "norm_b",
-                                   "head_w", "head_b")] + [("blocks", TrBlockWeights * TR_MAX_DEPTH)]
+                                   "head_w", "head_b")] + [("blocks", TrBlockWeights * TR_MAX_DEPTH),
+                                                           ("stage", TrStageWeights * TR_MAX_DEPTH)]
 
 
 class TrVitConfig(C.Structure):
@@ -54,7 +59,10 @@ SIGNATURES = {
     "tr_cls_topk": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tr_gather_layernorm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "tr_vit_workspace_bytes": (_sz, [C.POINTER(TrVitConfig), _i]),
-    "tr_vit_forward": (_i, [C.POINTER(TrVitConfig), C.POINTER(TrVitWeights), _vp, _vp, _vp, _sz, _vp, _vp,
+    "tr_pool_broadcast": (_i, [_vp, _i, _i, _i, _i, _f, _vp]),
+    "tr_dyvit_score": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
+    "tr_sit_merge": (_i, [_vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "tr_vit_forward": (_i, [C.POINTER(TrVitConfig), C.POINTER(TrVitWeights), _vp, _vp, _vp, _sz, _vp, _vp, _vp,
                             C.POINTER(_i), _i, _vp]),
 }
 

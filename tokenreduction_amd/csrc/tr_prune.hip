@@ -1,0 +1,215 @@
+// Reducers that run BEFORE a block: DyViT's score predictor tail (models/dyvit.py) and SiT's token slimming (models/sit.py).
+// The GEMMs of both modules go through tr_gemm_*; this file holds the three non-GEMM pieces, all HBM-bound:
+//
+//   tr_pool_broadcast    PredictorLG.forward dyvit.py:115-118 with policy == 1 (eval): the second half of the channels is
+//                        replaced, in place, by its mean over the image's patch tokens (+ eps outside the fraction).
+//   tr_dyvit_score       out_conv.4 + LogSoftmax dyvit.py:108-109 and score = pred_score[:,:,0] dyvit.py:231: two dot products
+//                        per token, log-softmax over the pair, first component -> scores [B,N] fp32 (column 0 = CLS, unused).
+//   tr_sit_merge         TokenSlimmingModule.forward sit.py:37-39: softmax(logits * scale) over the TOKEN axis, out = W^T x,
+//                        CLS row copied through (sit.py:117-119); optional soft-assignment output [B,K,P] (viz, sit.py:124).
+#include "tr_common.h"
+
+namespace {
+
+template <bool F32>
+__device__ __forceinline__ float load1(const void* p, size_t e) {
+  if (F32) return reinterpret_cast<const float*>(p)[e];
+  return bf16_bits_to_f32(reinterpret_cast<const uint16_t*>(p)[e]);
+}
+template <bool F32>
+__device__ __forceinline__ void store1(void* p, size_t e, float v) {
+  if (F32) reinterpret_cast<float*>(p)[e] = v;
+  else reinterpret_cast<uint16_t*>(p)[e] = (uint16_t)(pack_bf16x2(v, 0.f) & 0xffffu);
+}
+
+// grid (ceil(C/2 / 64), B); lanes = adjacent channels (coalesced rows), 4 waves split the tokens
+template <bool F32>
+__global__ __launch_bounds__(256) void pool_broadcast_kernel(void* __restrict__ h, int N, int C, float eps) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y;
+  const int c = C / 2 + blockIdx.x * 64 + lane;
+  const bool ok = c < C;
+  const size_t base = (size_t)b * N * C;
+  float acc = 0.f;
+  if (ok)
+    for (int n = 1 + wave; n < N; n += 4) acc += load1<F32>(h, base + (size_t)n * C + c);    // patch tokens only (x[:, 1:])
+  part[wave][lane] = acc;
+  __syncthreads();
+  const float g = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) / (float)(N - 1) + eps;
+  if (ok)
+    for (int n = wave; n < N; n += 4) store1<F32>(h, base + (size_t)n * C + c, g);
+}
+
+// 16 lanes per token row, 4 rows per wave
+template <bool F32>
+__global__ __launch_bounds__(256) void dyvit_score_kernel(const void* __restrict__ h, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ scores, int M,
+                                                          int C) {
+  const int sub = threadIdx.x & 15;
+  const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+  float a0 = 0.f, a1 = 0.f;
+  if (row < M)
+    for (int c = sub; c < C; c += 16) {
+      const float v = load1<F32>(h, (size_t)row * C + c);
+      a0 = fmaf(v, w[c], a0);
+      a1 = fmaf(v, w[C + c], a1);
+    }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    a0 += __shfl_xor(a0, o, 64);
+    a1 += __shfl_xor(a1, o, 64);
+  }
+  if (row < M && sub == 0) {
+    const float l0 = a0 + bias[0], l1 = a1 + bias[1];
+    const float m = fmaxf(l0, l1);
+    // torch log_softmax: x - max - log(sum(exp(x - max)))
+    scores[row] = (l0 - m) - logf(expf(l0 - m) + expf(l1 - m));
+  }
+}
+
+constexpr int SKC = 32;    // clusters per workgroup
+constexpr int SJ_MAX = 4;  // D columns per thread (D <= 1024)
+
+// grid (ceil(K/32), B), 256 threads, SJ = ceil(D/256) columns per thread.  Dynamic LDS: w[P][SKC] fp32.
+template <int SJ>
+__global__ __launch_bounds__(256) void sit_merge_kernel(const float* __restrict__ logits, int ldl, float scale,
+                                                        const float* __restrict__ x, float* __restrict__ x_out,
+                                                        float* __restrict__ soft, int N, int K, int D) {
+  extern __shared__ __attribute__((aligned(16))) float s_w[];     // [P][SKC]
+  __shared__ float s_red[8][SKC];
+  __shared__ float s_max[SKC], s_inv[SKC];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y, k0 = blockIdx.x * SKC;
+  const int P = N - 1;
+  const int kk = tid & 31, pg = tid >> 5;                         // column kk, token group pg (8 groups)
+  const bool kval = k0 + kk < K;
+  const float* lg = logits + ((size_t)b * N + 1) * ldl + k0;      // patch rows only
+  // softmax over tokens of (logit * scale), column by column (F.softmax(weight * self.scale, dim=1), sit.py:38)
+  float mx = -INFINITY;
+  for (int p = pg; p < P; p += 8) {
+    const float v = kval ? lg[(size_t)p * ldl + kk] * scale : 0.f;
+    s_w[p * SKC + kk] = v;
+    mx = fmaxf(mx, v);
+  }
+  s_red[pg][kk] = mx;
+  __syncthreads();
+  if (tid < SKC) {
+    float m = s_red[0][tid];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) m = fmaxf(m, s_red[g][tid]);
+    s_max[tid] = m;
+  }
+  __syncthreads();
+  float sum = 0.f;
+  const float m = s_max[kk];
+  for (int p = pg; p < P; p += 8) {
+    const float e = expf(s_w[p * SKC + kk] - m);
+    s_w[p * SKC + kk] = e;
+    sum += e;
+  }
+  s_red[pg][kk] = sum;
+  __syncthreads();
+  if (tid < SKC) {
+    float t = s_red[0][tid];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) t += s_red[g][tid];
+    s_inv[tid] = 1.0f / t;
+  }
+  __syncthreads();
+  const float inv = s_inv[kk];
+  for (int p = pg; p < P; p += 8) s_w[p * SKC + kk] *= inv;
+  __syncthreads();
+  if (soft != nullptr)                                            // [B,K,P], lanes along p
+    for (int e = tid; e < SKC * P; e += 256) {
+      const int k = e / P, p = e - k * P;
+      if (k0 + k < K) soft[((size_t)b * K + k0 + k) * P + p] = s_w[p * SKC + k];
+    }
+  // out[k][d] = sum_p w[p][k] * x[1+p][d]   (torch.bmm(weight, x), sit.py:39), p ascending in fp32
+  float acc[SJ][SKC];
+#pragma unroll
+  for (int j = 0; j < SJ; ++j)
+#pragma unroll
+    for (int k = 0; k < SKC; ++k) acc[j][k] = 0.f;
+  const float* xb = x + ((size_t)b * N + 1) * D;
+  for (int p = 0; p < P; ++p) {
+    float xv[SJ];
+#pragma unroll
+    for (int j = 0; j < SJ; ++j) xv[j] = (tid + 256 * j < D) ? xb[(size_t)p * D + tid + 256 * j] : 0.f;
+#pragma unroll
+    for (int k4 = 0; k4 < SKC / 4; ++k4) {
+      const float4 wv = *reinterpret_cast<const float4*>(&s_w[p * SKC + 4 * k4]);
+#pragma unroll
+      for (int j = 0; j < SJ; ++j) {
+        acc[j][4 * k4 + 0] = fmaf(wv.x, xv[j], acc[j][4 * k4 + 0]);
+        acc[j][4 * k4 + 1] = fmaf(wv.y, xv[j], acc[j][4 * k4 + 1]);
+        acc[j][4 * k4 + 2] = fmaf(wv.z, xv[j], acc[j][4 * k4 + 2]);
+        acc[j][4 * k4 + 3] = fmaf(wv.w, xv[j], acc[j][4 * k4 + 3]);
+      }
+    }
+  }
+  float* ob = x_out + ((size_t)b * (K + 1) + 1 + k0) * D;
+#pragma unroll
+  for (int j = 0; j < SJ; ++j) {
+    const int d = tid + 256 * j;
+    if (d < D) {
+#pragma unroll
+      for (int k = 0; k < SKC; ++k)
+        if (k0 + k < K) ob[(size_t)k * D + d] = acc[j][k];
+      if (blockIdx.x == 0) x_out[(size_t)b * (K + 1) * D + d] = x[(size_t)b * N * D + d];     // global (CLS) token
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int tr_pool_broadcast(void* h, int is_f32, int B, int N, int C, float eps, tr_stream_t s) {
+  TR_REQUIRE(h, TR_ERR_NULL, "tr_pool_broadcast: null pointer");
+  TR_REQUIRE(B > 0 && N >= 2 && C >= 2 && C % 2 == 0, TR_ERR_SHAPE, "tr_pool_broadcast: bad shape B=%d N=%d C=%d", B, N, C);
+  const dim3 grid((C / 2 + 63) / 64, B);
+  hipStream_t st = static_cast<hipStream_t>(s);
+  if (is_f32) hipLaunchKernelGGL(pool_broadcast_kernel<true>, grid, dim3(256), 0, st, h, N, C, eps);
+  else hipLaunchKernelGGL(pool_broadcast_kernel<false>, grid, dim3(256), 0, st, h, N, C, eps);
+  TR_CHECK_LAUNCH("tr_pool_broadcast");
+  return TR_OK;
+}
+
+extern "C" int tr_dyvit_score(const void* h, int is_f32, const float* w, const float* bias, float* scores, int M, int C,
+                              tr_stream_t s) {
+  TR_REQUIRE(h && w && bias && scores, TR_ERR_NULL, "tr_dyvit_score: null pointer");
+  TR_REQUIRE(M > 0 && C > 0, TR_ERR_SHAPE, "tr_dyvit_score: bad shape M=%d C=%d", M, C);
+  hipStream_t st = static_cast<hipStream_t>(s);
+  const int nblocks = (M + 15) / 16;
+  if (is_f32) hipLaunchKernelGGL(dyvit_score_kernel<true>, dim3(nblocks), dim3(256), 0, st, h, w, bias, scores, M, C);
+  else hipLaunchKernelGGL(dyvit_score_kernel<false>, dim3(nblocks), dim3(256), 0, st, h, w, bias, scores, M, C);
+  TR_CHECK_LAUNCH("tr_dyvit_score");
+  return TR_OK;
+}
+
+extern "C" int tr_sit_merge(const float* logits, int ldl, float scale, const float* x, float* x_out, float* soft, int B, int N,
+                            int K, int D, tr_stream_t s) {
+  TR_REQUIRE(logits && x && x_out, TR_ERR_NULL, "tr_sit_merge: null pointer");
+  TR_REQUIRE(B > 0 && N >= 2 && K >= 1 && D >= 1 && D <= 256 * SJ_MAX && ldl >= K, TR_ERR_SHAPE,
+             "tr_sit_merge: bad shape B=%d N=%d K=%d D=%d ldl=%d (D <= %d)", B, N, K, D, ldl, 256 * SJ_MAX);
+  TR_REQUIRE(x_out != x, TR_ERR_SHAPE, "tr_sit_merge: needs a distinct x_out");
+  const size_t lds = (size_t)(N - 1) * SKC * sizeof(float);
+  TR_REQUIRE(lds <= 150 * 1024, TR_ERR_SHAPE, "tr_sit_merge: %d tokens need %zu B of LDS (max 150 KiB)", N - 1, lds);
+  hipStream_t st = static_cast<hipStream_t>(s);
+  const dim3 grid((K + SKC - 1) / SKC, B);
+#define TR_SIT_LAUNCH(J)                                                                                                          \
+  do {                                                                                                                            \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sit_merge_kernel<J>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)lds);                                                                                 \
+    TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_sit_merge: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));       \
+    hipLaunchKernelGGL(sit_merge_kernel<J>, grid, dim3(256), lds, st, logits, ldl, scale, x, x_out, soft, N, K, D);               \
+  } while (0)
+  switch ((D + 255) / 256) {
+    case 1: TR_SIT_LAUNCH(1); break;
+    case 2: TR_SIT_LAUNCH(2); break;
+    case 3: TR_SIT_LAUNCH(3); break;
+    default: TR_SIT_LAUNCH(4); break;
+  }
+#undef TR_SIT_LAUNCH
+  TR_CHECK_LAUNCH("tr_sit_merge");
+  return TR_OK;
+}

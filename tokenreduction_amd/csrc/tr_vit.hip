@@ -40,7 +40,7 @@ bool make_plan(const tr_vit_config* c, int B, Plan* p) {
   if (c->patch <= 0 || c->img_size <= 0 || c->img_size % c->patch != 0) return false;
   if (c->depth <= 0 || c->depth > TR_MAX_DEPTH) return false;
   if (c->num_heads <= 0 || c->embed_dim != c->num_heads * 64) return false;
-  if (c->family < TR_FAMILY_DEIT || c->family > TR_FAMILY_TOME) return false;
+  if (c->family < TR_FAMILY_DEIT || c->family > TR_FAMILY_SIT) return false;
   const int g = c->img_size / c->patch;
   p->P = g * g;
   p->N0 = p->P + 1;
@@ -61,7 +61,7 @@ bool make_plan(const tr_vit_config* c, int B, Plan* p) {
   p->off_d = o;      o += align_up(T * p->D * es);
   p->off_cols = o;   o += align_up((size_t)B * p->P * p->kcols * es);
   p->off_cls = o;    o += align_up((size_t)B * p->H * p->N0 * 4);
-  p->off_scores = o; o += align_up((size_t)B * p->P * 4);
+  p->off_scores = o; o += align_up((size_t)B * p->N0 * 4);
   p->off_idx = o;    o += align_up((size_t)B * p->N0 * 4);
   p->off_compl = o;  o += align_up((size_t)B * p->N0 * 4);
   p->off_size0 = o;  o += align_up((size_t)B * p->N0 * 4);
@@ -115,8 +115,8 @@ extern "C" size_t tr_vit_workspace_bytes(const tr_vit_config* cfg, int B) {
   } while (0)
 
 extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits, void* workspace,
-                              size_t workspace_bytes, int32_t* kept_idx, int32_t* compl_idx, int* tokens_out, int B,
-                              tr_stream_t s) {
+                              size_t workspace_bytes, int32_t* kept_idx, int32_t* compl_idx, float* soft_out, int* tokens_out,
+                              int B, tr_stream_t s) {
   Plan p;
   TR_REQUIRE(cfg && w && img && logits && workspace, TR_ERR_NULL, "tr_vit_forward: null pointer");
   TR_REQUIRE(make_plan(cfg, B, &p), TR_ERR_CONFIG,
@@ -155,7 +155,44 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
   for (int i = 0; i < cfg->depth; ++i) {
     const tr_block_weights* bw = &w->blocks[i];
     const bool tome = cfg->family == TR_FAMILY_TOME;
-    int K = (cfg->family == TR_FAMILY_DEIT || tome) ? 0 : cfg->keep[i];
+    bool have_xn = false;   // norm1(x) already in xn (written by a pre-block reducer)
+    if ((cfg->family == TR_FAMILY_DYVIT || cfg->family == TR_FAMILY_SIT) && cfg->keep[i] > 0) {
+      const tr_stage_weights* sw = &w->stage[i];
+      const int Kc = cfg->keep[i], M = B * N;
+      TR_REQUIRE(Kc <= N - 1, TR_ERR_CONFIG, "tr_vit_forward: block %d asks for %d of %d patch tokens", i, Kc, N - 1);
+      TR_REQUIRE(sw->ln_g && sw->ln_b && sw->w0 && sw->b0 && sw->w1 && sw->b1, TR_ERR_NULL,
+                 "tr_vit_forward: block %d has no reduction-module weights (tr_vit_weights.stage)", i);
+      // x (+= previous mlp output), module's own LayerNorm (nn.LayerNorm default eps 1e-5: dyvit.py:97, sit.py:30)
+      TR_TRY(op_ln(f32, x, D, pending, D, sw->ln_g, sw->ln_b, xn, M, D, 1e-5f, s));
+      pending = nullptr;
+      if (cfg->family == TR_FAMILY_DYVIT) {
+        // a10: PredictorLG (dyvit.py:113-119, policy == 1 in eval) -> score -> argsort(desc)[:K] -> batch_index_select
+        TR_REQUIRE(sw->w2 && sw->b2 && sw->w3 && sw->b3, TR_ERR_NULL, "tr_vit_forward: block %d predictor weights missing", i);
+        TR_REQUIRE(D % 128 == 0 || f32, TR_ERR_CONFIG, "tr_vit_forward: DyViT predictor needs embed_dim %% 128 == 0 on the bf16 path (D=%d)", D);
+        TR_TRY(op_gemm(f32, xn, sw->w0, sw->b0, ao, nullptr, 0, M, D, D, TR_EPI_GELU_BF16, s));
+        TR_TRY(tr_pool_broadcast(ao, f32 ? 1 : 0, B, N, D, 1e-6f, s));
+        TR_TRY(op_gemm(f32, ao, sw->w1, sw->b1, qkv, nullptr, 0, M, D / 2, D, TR_EPI_GELU_BF16, s));
+        TR_TRY(op_gemm(f32, qkv, sw->w2, sw->b2, hbuf, nullptr, 0, M, D / 4, D / 2, TR_EPI_GELU_BF16, s));
+        TR_TRY(tr_dyvit_score(hbuf, f32 ? 1 : 0, sw->w3, sw->b3, cls_rows, M, D / 4, s));
+        int32_t* idx_dst = kept_idx ? kept_idx + (size_t)i * B * p.N0 : idx_ws;
+        TR_TRY(tr_cls_topk(cls_rows, idx_dst, nullptr, scores, B, 1, N, Kc, s));
+        TR_TRY(op_gather(f32, x, nullptr, idx_dst, nullptr, nullptr, bw->ln1_g, bw->ln1_b, x_alt, xn, B, N, Kc, D, cfg->ln_eps, s));
+        have_xn = true;
+      } else {
+        // a23: TokenSlimmingModule (sit.py:36-40)
+        TR_REQUIRE(sw->n_pad >= Kc && sw->n_pad % 8 == 0 && (size_t)sw->n_pad * 4 <= (size_t)p.Hd * (f32 ? 4 : 2), TR_ERR_CONFIG,
+                   "tr_vit_forward: block %d SiT n_pad=%d invalid for K=%d", i, sw->n_pad, Kc);
+        TR_REQUIRE(D % 128 == 0 || f32, TR_ERR_CONFIG, "tr_vit_forward: SiT needs embed_dim %% 128 == 0 on the bf16 path (D=%d)", D);
+        TR_TRY(op_gemm(f32, xn, sw->w0, sw->b0, ao, nullptr, 0, M, D / 2, D, TR_EPI_GELU_BF16, s));
+        TR_TRY(op_gemm(f32, ao, sw->w1, sw->b1, hbuf, nullptr, 0, M, sw->n_pad, D / 2, TR_EPI_F32, s));
+        TR_TRY(tr_sit_merge(static_cast<const float*>(hbuf), sw->n_pad, sw->scale, x, x_alt, soft_out, B, N, Kc, D, s));
+        if (soft_out) soft_out += (size_t)B * Kc * (N - 1);
+      }
+      float* t = x; x = x_alt; x_alt = t;
+      N = Kc + 1;
+    }
+    const bool in_block = cfg->family == TR_FAMILY_TOPK || cfg->family == TR_FAMILY_EVIT;
+    int K = in_block ? cfg->keep[i] : 0;
     TR_REQUIRE(K >= 0 && K <= N - 1, TR_ERR_CONFIG, "tr_vit_forward: block %d keeps %d of %d patch tokens", i, K, N - 1);
     if (K == N - 1) K = 0;  // topk.py:57 / evit.py:79: left_tokens == N-1 -> plain block
     int r = 0;              // ToMe: tokens merged away by this block, r = min(r, (N - protected) // 2)  (tome.py:253)
@@ -165,7 +202,7 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
     }
     const int M = B * N;
     // x (+= previous mlp output); attn(norm1(x)) -> dbuf   [x + dbuf is the reference's post-attention x, topk.py:87]
-    TR_TRY(op_ln(f32, x, D, pending, D, bw->ln1_g, bw->ln1_b, xn, M, D, cfg->ln_eps, s));
+    if (!have_xn) TR_TRY(op_ln(f32, x, D, pending, D, bw->ln1_g, bw->ln1_b, xn, M, D, cfg->ln_eps, s));
     TR_TRY(op_gemm(f32, xn, bw->qkv_w, bw->qkv_b, qkv, nullptr, 0, M, 3 * D, D, TR_EPI_BF16, s));
     TR_TRY(op_attn(f32, qkv, ao, K > 0 ? cls_rows : nullptr, tome ? size_cur : nullptr, B, N, H, s));
     TR_TRY(op_gemm(f32, ao, bw->proj_w, bw->proj_b, dbuf, nullptr, 0, M, D, D, TR_EPI_BF16, s));

@@ -194,6 +194,7 @@ class VisionTransformer(nn.Module):
             b.ln2_g, b.ln2_b = f32(blk.norm2.weight), f32(blk.norm2.bias)
             b.fc1_w, b.fc1_b = w16(blk.mlp.fc1.weight), f32(blk.mlp.fc1.bias)
             b.fc2_w, b.fc2_b = w16(blk.mlp.fc2.weight), f32(blk.mlp.fc2.bias)
+        self._pack_stages(W, w16, f32, keep_alive)
         cfg = _lib.TrVitConfig()
         cfg.family = self._family
         cfg.img_size, cfg.patch = self.patch_embed.img_size[0], self.patch_embed.patch_size[0]
@@ -209,6 +210,13 @@ class VisionTransformer(nn.Module):
         self._ws = {}
         return self._packed
 
+    def _pack_stages(self, W, w16, f32, keep_alive):
+        """Families with learned reduction modules fill W.stage[blk] (tr_stage_weights) here."""
+
+    def _soft_elems(self, B):
+        """fp32 elements of the soft-assignment output (SiT), 0 for families without one."""
+        return 0
+
     def _workspace(self, B, dev):
         ws = self._ws.get(B)
         if ws is None:
@@ -220,7 +228,9 @@ class VisionTransformer(nn.Module):
             P = self.patch_embed.num_patches
             ws = dict(buf=torch.empty(nbytes, dtype=torch.uint8, device=dev), nbytes=nbytes,
                       kept=torch.empty(self.depth * B * (P + 1), dtype=torch.int32, device=dev),
-                      compl=torch.empty(self.depth * B * (P + 1), dtype=torch.int32, device=dev))
+                      compl=torch.empty(self.depth * B * (P + 1), dtype=torch.int32, device=dev), soft=None)
+            if self.viz_mode and self._soft_elems(B):
+                ws["soft"] = torch.empty(self._soft_elems(B), dtype=torch.float32, device=dev)
             self._ws = {B: ws}   # keep one batch size resident
         return ws
 
@@ -239,11 +249,14 @@ class VisionTransformer(nn.Module):
             raise ValueError(f"expected [B,{cfg.in_chans},{cfg.img_size},{cfg.img_size}], got {tuple(x.shape)}")
         x = x.detach().to(torch.float32).contiguous()
         ws = self._workspace(B, x.device)
+        if self.viz_mode and self._soft_elems(B) and ws.get("soft") is None:      # viz_mode switched on after the first call
+            ws["soft"] = torch.empty(self._soft_elems(B), dtype=torch.float32, device=x.device)
         logits = torch.empty(B, self.num_classes, dtype=torch.float32, device=x.device)
         tokens = (C.c_int * self.depth)()
         with torch.cuda.device(x.device):
             rc = lib.tr_vit_forward(C.byref(cfg), C.byref(pk["W"]), x.data_ptr(), logits.data_ptr(), ws["buf"].data_ptr(),
-                                    ws["nbytes"], ws["kept"].data_ptr(), ws["compl"].data_ptr(), tokens, B,
+                                    ws["nbytes"], ws["kept"].data_ptr(), ws["compl"].data_ptr(),
+                                    None if ws.get("soft") is None else ws["soft"].data_ptr(), tokens, B,
                                     torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "tr_vit_forward")
         self._last_tokens = list(tokens)
@@ -393,3 +406,147 @@ class ToMeVisionTransformer(VisionTransformer):
                 maps[blk] = (out - 1)[:, 1:]
             n_in = tokens[blk]
         return {"Assignment_Maps": maps, "Features": {}}
+
+
+def _ln_default(dim):
+    return nn.LayerNorm(dim)          # eps 1e-5: the reduction modules use nn.LayerNorm's default (dyvit.py:97, sit.py:30)
+
+
+class PredictorLG(nn.Module):
+    """Parameter holder with the reference's module tree (dyvit.py:90-110); evaluated by the HIP executor."""
+
+    def __init__(self, embed_dim=384, eps=1e-6):
+        super().__init__()
+        self.in_conv = nn.Sequential(_ln_default(embed_dim), nn.Linear(embed_dim, embed_dim), nn.GELU())
+        self.out_conv = nn.Sequential(nn.Linear(embed_dim, embed_dim // 2), nn.GELU(), nn.Linear(embed_dim // 2, embed_dim // 4),
+                                      nn.GELU(), nn.Linear(embed_dim // 4, 2), nn.LogSoftmax(dim=-1))
+        self.eps = eps
+
+
+class DynamicVisionTransformer(VisionTransformer):
+    """models/dyvit.py:122-263, eval path: per pruning block, PredictorLG scores the patch tokens, the best int(P0*ratio) are
+    gathered (argsort order) BEFORE the block runs.  Training (gumbel + policy softmax, dyvit.py:221-229) is not built."""
+    _family = _lib.TR_FAMILY_DYVIT
+
+    def __init__(self, *a, args=None, dyvit_distillation=False, **kw):
+        distilled = kw.pop("distilled", False)
+        super().__init__(*a, args=args, **kw)
+        assert (dyvit_distillation & distilled) is False, "Cannot have both DeiT Distillation token and DyViT Distillation scheme"
+        if distilled:
+            raise NotImplementedError("the distillation token is not built")
+        token_ratio = list(args.keep_rate)
+        pruning_loc = list(args.reduction_loc)
+        if len(token_ratio) == 1:
+            token_ratio = [token_ratio[0] ** (idx + 1) for idx in range(len(pruning_loc))]                 # dyvit.py:175-176
+        assert len(token_ratio) == len(pruning_loc), \
+            f"Mismatch between the pruning location ({pruning_loc}) and token ratios ({token_ratio})"
+        self.num_patches = self.patch_embed.num_patches
+        self.score_predictor = nn.ModuleList([PredictorLG(self.embed_dim) for _ in range(len(pruning_loc))])
+        for m in self.score_predictor.modules():
+            _init_vit_weights(m)
+        for ratio, loc in zip(token_ratio, pruning_loc):
+            self._keep[loc] = int(self.num_patches * ratio)                                               # dyvit.py:232
+        self.deit_distillation = False
+        self.dyvit_distillation = dyvit_distillation
+        self.pruning_loc = pruning_loc
+        self.token_ratio = token_ratio
+
+    def get_new_module_names(self):
+        return ["score_predictor"]
+
+    def get_reduction_count(self):
+        return self.pruning_loc
+
+    def _pack_stages(self, W, w16, f32, keep_alive):
+        for j, loc in enumerate(self.pruning_loc):
+            sp, st = self.score_predictor[j], W.stage[loc]
+            st.ln_g, st.ln_b = f32(sp.in_conv[0].weight), f32(sp.in_conv[0].bias)
+            st.w0, st.b0 = w16(sp.in_conv[1].weight), f32(sp.in_conv[1].bias)
+            st.w1, st.b1 = w16(sp.out_conv[0].weight), f32(sp.out_conv[0].bias)
+            st.w2, st.b2 = w16(sp.out_conv[2].weight), f32(sp.out_conv[2].bias)
+            st.w3, st.b3 = f32(sp.out_conv[4].weight), f32(sp.out_conv[4].bias)
+
+    def _viz_data(self, ws, B, tokens):
+        P1 = self.patch_embed.num_patches + 1
+        kept = ws["kept"].cpu().numpy()
+        decisions = {}
+        for blk in self.pruning_loc:
+            K = self._keep[blk]
+            decisions[blk] = kept[blk * B * P1: blk * B * P1 + B * K].reshape(B, K).astype(np.int64)
+        return {"Kept_Tokens": decisions, "Features": {}}
+
+
+class TokenSlimmingModule(nn.Module):
+    """Parameter holder (sit.py:25-34)."""
+
+    def __init__(self, embed_dim, cluster_centers, ratio=0.5):
+        super().__init__()
+        hidden_dim = int(embed_dim * ratio)
+        self.weight = nn.Sequential(_ln_default(embed_dim), nn.Linear(embed_dim, hidden_dim), nn.GELU(),
+                                    nn.Linear(hidden_dim, cluster_centers))
+        self.scale = nn.Parameter(torch.ones(1, 1, 1))
+
+
+class SelfSlimmedVisionTransformer(VisionTransformer):
+    """models/sit.py:43-150: a TokenSlimmingModule softly assigns the patch tokens to K outputs before each block in
+    reduction_loc."""
+    _family = _lib.TR_FAMILY_SIT
+
+    def __init__(self, *a, args=None, **kw):
+        super().__init__(*a, args=args, **kw)
+        self.cluster_loc = list(args.reduction_loc)
+        self.cluster_count = list(args.keep_rate)
+        P0 = self.patch_embed.num_patches
+        if len(self.cluster_count) == 1:
+            self.cluster_count = [int(P0 * (args.keep_rate[0] ** (idx + 1))) for idx in range(len(self.cluster_loc))]   # sit.py:80-81
+        assert len(self.cluster_count) == len(self.cluster_loc), \
+            f"Mismatch between the cluster location ({self.cluster_loc}) and cluster centers ({self.cluster_count})"
+        self.cluster_count = [int(c) for c in self.cluster_count]
+        self.cluster_layers = nn.ModuleList([TokenSlimmingModule(self.embed_dim, c) for c in self.cluster_count])
+        for m in self.cluster_layers.modules():
+            _init_vit_weights(m)
+        for c, loc in zip(self.cluster_count, self.cluster_loc):
+            self._keep[loc] = c
+
+    def get_new_module_names(self):
+        return ["cluster_layers"]
+
+    def get_reduction_count(self):
+        return self.cluster_loc
+
+    def _pack_stages(self, W, w16, f32, keep_alive):
+        for j, loc in enumerate(self.cluster_loc):
+            m, st = self.cluster_layers[j], W.stage[loc]
+            K = self.cluster_count[j]
+            n_pad = (K + 7) // 8 * 8
+            w1 = torch.zeros(n_pad, m.weight[3].in_features, dtype=torch.float32, device=m.weight[3].weight.device)
+            w1[:K] = m.weight[3].weight.detach()
+            b1 = torch.zeros(n_pad, dtype=torch.float32, device=w1.device)
+            b1[:K] = m.weight[3].bias.detach()
+            st.ln_g, st.ln_b = f32(m.weight[0].weight), f32(m.weight[0].bias)
+            st.w0, st.b0 = w16(m.weight[1].weight), f32(m.weight[1].bias)
+            st.w1, st.b1 = w16(w1), f32(b1)
+            st.scale = float(m.scale.detach().reshape(-1)[0])
+            st.n_pad = n_pad
+
+    def _stage_shapes(self):
+        """[(blk, K, P_in)] per slimming stage."""
+        out, p_in = [], self.patch_embed.num_patches
+        for K, loc in sorted(zip(self.cluster_count, self.cluster_loc), key=lambda t: t[1]):
+            out.append((loc, K, p_in))
+            p_in = K
+        return out
+
+    def _soft_elems(self, B):
+        return sum(B * K * P for _, K, P in self._stage_shapes())
+
+    def _viz_data(self, ws, B, tokens):
+        soft = ws["soft"].cpu().numpy()
+        assignments, hard = {}, {}
+        off = 0
+        for blk, K, P in self._stage_shapes():
+            a = soft[off: off + B * K * P].reshape(B, K, P)
+            off += B * K * P
+            assignments[blk] = a
+            hard[blk] = np.argmax(a, axis=-2).astype(np.int64)                       # sit.py:122
+        return {"Assignment_Maps": hard, "Soft_Assignment_Maps": assignments, "Features": {}}

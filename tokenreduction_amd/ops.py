@@ -181,3 +181,36 @@ def tome_merge_layernorm(x: torch.Tensor, delta, size, unm, src, dst, gamma, bet
         _dev(beta, torch.float32, "beta"), x_out.data_ptr(), size_out.data_ptr(), y.data_ptr(), B, N, r, D, eps, _stream()),
         "tr_tome_merge_layernorm")
     return x_out, size_out, y
+
+
+# ---------------------------------------------------------------------------------------- DyViT / SiT (reduce before the block)
+def pool_broadcast(h: torch.Tensor, B: int, N: int, eps: float = 1e-6):
+    """PredictorLG global feature (dyvit.py:115-118, policy == 1): in place on h bf16|fp32 [B*N, C]."""
+    if h.dtype not in (torch.bfloat16, torch.float32):
+        raise TypeError("h must be bf16 or fp32")
+    C_ = h.shape[-1]
+    _lib.check(_lib.load().tr_pool_broadcast(_dev(h, h.dtype, "h"), int(h.dtype == torch.float32), B, N, C_, eps, _stream()),
+               "tr_pool_broadcast")
+    return h
+
+
+def dyvit_score(h: torch.Tensor, w: torch.Tensor, b: torch.Tensor):
+    """out_conv.4 + LogSoftmax + [..., 0] (dyvit.py:108-109, 231): h bf16|fp32 [M, C], w fp32 [2, C] -> scores fp32 [M]."""
+    M, C_ = h.shape
+    scores = torch.empty(M, dtype=torch.float32, device=h.device)
+    _lib.check(_lib.load().tr_dyvit_score(_dev(h, h.dtype, "h"), int(h.dtype == torch.float32), _dev(w, torch.float32, "w"),
+                                          _dev(b, torch.float32, "b"), scores.data_ptr(), M, C_, _stream()), "tr_dyvit_score")
+    return scores
+
+
+def sit_merge(logits: torch.Tensor, scale: float, x: torch.Tensor, K: int, want_soft: bool = False):
+    """TokenSlimmingModule tail (sit.py:38-39): logits fp32 [B,N,ldl] (first K columns), x fp32 [B,N,D] ->
+    (x_out fp32 [B,K+1,D], soft fp32 [B,K,N-1] | None)."""
+    B, N, D = x.shape
+    ldl = logits.shape[-1]
+    x_out = torch.empty(B, K + 1, D, dtype=torch.float32, device=x.device)
+    soft = torch.empty(B, K, N - 1, dtype=torch.float32, device=x.device) if want_soft else None
+    _lib.check(_lib.load().tr_sit_merge(_dev(logits, torch.float32, "logits"), ldl, float(scale), _dev(x, torch.float32, "x"),
+                                        x_out.data_ptr(), None if soft is None else soft.data_ptr(), B, N, K, D, _stream()),
+               "tr_sit_merge")
+    return x_out, soft

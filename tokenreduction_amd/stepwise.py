@@ -97,14 +97,57 @@ def forward_stepwise(model: VisionTransformer, x: torch.Tensor, trace: Optional[
     tome = cfg.family == 3
     size = None        # ToMe token sizes [B, N] (None until the first merge)
     info["tome"] = {}
+    info["soft"] = {}
     for i, blk in enumerate(model.blocks):
-        K = 0 if cfg.family == 0 or tome else int(cfg.keep[i])
+        xn = None
+        if cfg.family in (4, 5) and int(cfg.keep[i]) > 0:
+            # DyViT / SiT: the reduction module runs on x BEFORE the block (dyvit.py:218-239, sit.py:116-119)
+            Kc, M = int(cfg.keep[i]), B * N
+            j = (model.pruning_loc if cfg.family == 4 else model.cluster_loc).index(i)
+            if cfg.family == 4:
+                sp = model.score_predictor[j]
+                y = tr.run("layernorm_kernel", 0.0, (6.0 if pending is None else 12.0) * M * D,
+                           lambda: ops.layernorm(h, f32(sp.in_conv[0].weight), f32(sp.in_conv[0].bias), 1e-5, delta=pending))
+                pending = None
+                h1 = _gemm(tr, y, bf(sp.in_conv[1].weight), f32(sp.in_conv[1].bias), ops.TR_EPI_GELU_BF16, tag="p0")
+                tr.run("pool_broadcast_kernel", 0.0, 2.0 * M * D, lambda: ops.pool_broadcast(h1, B, N))
+                h2 = _gemm(tr, h1, bf(sp.out_conv[0].weight), f32(sp.out_conv[0].bias), ops.TR_EPI_GELU_BF16, tag="p1")
+                h3 = _gemm(tr, h2, bf(sp.out_conv[2].weight), f32(sp.out_conv[2].bias), ops.TR_EPI_GELU_BF16, tag="p2")
+                sc = tr.run("dyvit_score_kernel", 0.0, 0.5 * M * D,
+                            lambda: ops.dyvit_score(h3, f32(sp.out_conv[4].weight), f32(sp.out_conv[4].bias)))
+                idx, _, scores = tr.run("cls_topk_kernel", 0.0, 8.0 * M, lambda: ops.cls_topk(sc.view(B, 1, N), Kc))
+                info["kept"][i], info["compl"][i], info["scores"][i] = idx, None, scores
+                h3_, xn = tr.run("gather_layernorm_kernel", 0.0, 10.0 * B * (Kc + 1) * D,
+                                 lambda: ops.gather_layernorm(h.view(B, N, D), idx, None, None, f32(blk.norm1.weight),
+                                                              f32(blk.norm1.bias), eps))
+                N = Kc + 1
+                h, xn = h3_.view(B * N, D), xn.view(B * N, D)
+            else:
+                m = model.cluster_layers[j]
+                y = tr.run("layernorm_kernel", 0.0, (6.0 if pending is None else 12.0) * M * D,
+                           lambda: ops.layernorm(h, f32(m.weight[0].weight), f32(m.weight[0].bias), 1e-5, delta=pending))
+                pending = None
+                h1 = _gemm(tr, y, bf(m.weight[1].weight), f32(m.weight[1].bias), ops.TR_EPI_GELU_BF16, tag="s0")
+                n_pad = (Kc + 7) // 8 * 8
+                w1 = torch.zeros(n_pad, m.weight[3].in_features, dtype=torch.float32, device=dev)
+                w1[:Kc] = m.weight[3].weight.detach()
+                b1 = torch.zeros(n_pad, dtype=torch.float32, device=dev)
+                b1[:Kc] = m.weight[3].bias.detach()
+                lg = _gemm(tr, h1, bf(w1), b1, ops.TR_EPI_F32, tag="s1")
+                scale = float(m.scale.detach().reshape(-1)[0])
+                h3_, soft = tr.run("sit_merge_kernel", 2.0 * B * Kc * (N - 1) * D, 4.0 * B * (N + Kc) * D,
+                                   lambda: ops.sit_merge(lg.view(B, N, n_pad), scale, h.view(B, N, D), Kc, want_soft=tr.keep))
+                info["soft"][i] = soft
+                N = Kc + 1
+                h = h3_.view(B * N, D)
+        K = int(cfg.keep[i]) if cfg.family in (1, 2) else 0
         if K == N - 1:
             K = 0
         r = min(int(cfg.keep[i]), (N - 1) // 2) if tome else 0
         M = B * N
-        xn = tr.run("layernorm_kernel", 0.0, (6.0 if pending is None else 12.0) * M * D,
-                    lambda: ops.layernorm(h, f32(blk.norm1.weight), f32(blk.norm1.bias), eps, delta=pending))
+        if xn is None:
+            xn = tr.run("layernorm_kernel", 0.0, (6.0 if pending is None else 12.0) * M * D,
+                        lambda: ops.layernorm(h, f32(blk.norm1.weight), f32(blk.norm1.bias), eps, delta=pending))
         qkv = _gemm(tr, xn, bf(blk.attn.qkv.weight), f32(blk.attn.qkv.bias), ops.TR_EPI_BF16, tag="qkv")
         ao, cls_rows = tr.run("attention_kernel", 4.0 * B * H * N * N * 64, 2.0 * M * 4 * D,
                               lambda: ops.attention(qkv, B, N, H, want_cls=K > 0, size=size))
