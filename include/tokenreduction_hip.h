@@ -115,6 +115,22 @@ int tr_dyvit_score(const void* h, int is_f32, const float* w, const float* bias,
 int tr_sit_merge(const float* logits, int ldl, float scale, const float* x, float* x_out, float* soft, int B, int N, int K,
                  int D, tr_stream_t s);
 
+/* ---- DPC-KNN (csrc/tr_cluster.hip) --------------------------------------------------------------------------------------
+ * tr_dpcknn_cluster: cluster_dpc_knn dpcknn.py:44-100 (token_mask=None) on the patch rows of x fp32 [B,N,D] (row 0 = CLS,
+ *   ignored): centers int32 [B,K] = topk(score, K) in descending-score order (index_down), idx_cluster int32 [B,N-1],
+ *   scores fp32 [B,N-1] (distance-to-denser-token * density).  noise (nullable) fp32 [B,N-1]: the uniform [0,1) draws the
+ *   reference adds * 1e-6 to the densities (dpcknn.py:71-72); NULL = none.  k = nearest neighbours (args.k_neighbors).
+ *   ws: tr_dpcknn_workspace_floats(B,N) floats of scratch.
+ * tr_cluster_merge_layernorm: merge_tokens dpcknn.py:103-132 with token_weight = exp(x . score_w + score_b) (CTM, :155-157;
+ *   score_w NULL = equal weights), then LayerNorm(gamma, beta, eps) of the merged tokens: x_out fp32 [B,K+1,D] (row 0 = CLS
+ *   copied), y = LN(x_out) bf16 (fp32 when y_is_f32).  w_ws: [B,N-1] floats of scratch (token weights). */
+size_t tr_dpcknn_workspace_floats(int B, int N);
+int tr_dpcknn_cluster(const float* x, const float* noise, float* ws, int32_t* centers, int32_t* idx_cluster, float* scores,
+                      int B, int N, int D, int K, int k, tr_stream_t s);
+int tr_cluster_merge_layernorm(const float* x, const float* score_w, const float* score_b, float* w_ws,
+                               const int32_t* idx_cluster, const float* gamma, const float* beta, float* x_out, void* y,
+                               int y_is_f32, int B, int N, int K, int D, float eps, tr_stream_t s);
+
 /* a13 bipartite_soft_matching (tome.py:230-277, class_token=True) on metric = k.mean(1) (tome.py:58), read straight from the
  * K third of qkv ([B*N, 3*H*64]; bf16, or fp32 when qkv_is_f32).  Tokens at even positions form set A (CLS = A[0], never
  * merged), odd positions set B.  Outputs (int32): src_idx [B,r] = the r A-tokens with the largest best-match score, in
@@ -139,6 +155,7 @@ int tr_tome_merge_layernorm(const float* x, const void* delta, int f32_path, con
 #define TR_FAMILY_TOME 3   /* keep[blk] = r requested for that block (tome.py:152-155); clamped per call to (N-1)/2 */
 #define TR_FAMILY_DYVIT 4  /* eval path of models/dyvit.py: predictor scores -> top-K -> gather BEFORE the block */
 #define TR_FAMILY_SIT 5    /* models/sit.py: soft token slimming BEFORE the block */
+#define TR_FAMILY_DPCKNN 6 /* models/dpcknn.py: DPC-KNN clustering + weighted merge BEFORE the block; keep[blk] = clusters */
 #define TR_MAX_DEPTH 32
 #define TR_PREC_BF16 0   /* the product path: bf16 MFMA operands, fp32 accumulate / residual / statistics */
 #define TR_PREC_FP32 1   /* validation path: the reference's own arithmetic on the GPU (bit-exact indices vs its golden vectors) */
@@ -157,7 +174,8 @@ typedef struct {
  *   DyViT PredictorLG (dyvit.py:96-110): ln = in_conv.0 (eps 1e-5), w0/b0 = in_conv.1 [D,D], w1/b1 = out_conv.0 [D/2,D],
  *     w2/b2 = out_conv.2 [D/4,D/2], w3/b3 = out_conv.4 [2,D/4] (fp32 in both precisions).
  *   SiT TokenSlimmingModule (sit.py:29-34): ln = weight.0 (eps 1e-5), w0/b0 = weight.1 [D/2,D], w1/b1 = weight.3 zero-padded
- *     to n_pad rows ([n_pad, D/2], n_pad = K rounded up to 8), scale = the module's scalar. */
+ *     to n_pad rows ([n_pad, D/2], n_pad = K rounded up to 8), scale = the module's scalar.
+ *   DPC-KNN CTM (dpcknn.py:150-151): w3/b3 = score.weight [1,D] / score.bias [1] (fp32); NULL = args.equal_weight. */
 typedef struct {
   const float* ln_g; const float* ln_b;
   const void* w0; const float* b0;
@@ -184,6 +202,7 @@ typedef struct {
   int keep[TR_MAX_DEPTH];     /* per block, 0 = plain block.  Top-K/EViT/DyViT: K patch tokens kept; ToMe: r tokens merged
                                  away; SiT: K output tokens of the slimming module */
   int precision;              /* TR_PREC_* */
+  int knn_k;                  /* DPC-KNN: neighbours of the local density (args.k_neighbors, train.py:221 default 5) */
 } tr_vit_config;
 
 /* Bytes of workspace tr_vit_forward needs for batch B (0 on invalid config). */
@@ -194,10 +213,12 @@ size_t tr_vit_workspace_bytes(const tr_vit_config* cfg, int B);
  * writes [unm_idx | src_idx | dst_idx] there ([B,na-r], [B,r], [B,r] back to back).  The slab holds depth*B*(P+1) entries.
  * compl_idx (nullable, EViT): same slab shape, block blk writes [B,P_in-K_blk] at offset blk*B*(P+1)
  * (Fusion_Assign, evit.py:229).  soft_out (nullable, SiT): fp32, the stages' soft assignments [B,K,P_in] back to back in
- * block order (Soft_Assignment_Maps, sit.py:124).  tokens_out (nullable, HOST pointer, int[depth]): token count after each block. */
+ * block order (Soft_Assignment_Maps, sit.py:124).  DPC-KNN: kept_idx gets the centres [B,K] (Kept_Tokens), compl_idx the
+ * assignment [B,P_in] (Assignment_Maps); noise_in (nullable): fp32, the stages' density noise [B,P_in] back to back in block
+ * order (dpcknn.py:71-72; NULL = no noise).  tokens_out (nullable, HOST pointer, int[depth]): token count after each block. */
 int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits,
                    void* workspace, size_t workspace_bytes, int32_t* kept_idx, int32_t* compl_idx, float* soft_out,
-                   int* tokens_out, int B, tr_stream_t s);
+                   const float* noise_in, int* tokens_out, int B, tr_stream_t s);
 
 #ifdef __cplusplus
 }

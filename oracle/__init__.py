@@ -23,10 +23,16 @@ from .vit import (  # noqa: F401
 from .prune_before import (  # noqa: F401
     dyvit_keep_counts, dyvit_predictor_scores, dyvit_select, dyvit_forward, sit_cluster_counts, sit_slim, sit_forward,
 )
+from .cluster import (  # noqa: F401
+    dpcknn_cluster_counts, dpcknn_distances, dpcknn_scores, dpcknn_assign, dpcknn_cluster, dpcknn_merge, dpcknn_ctm,
+    dpcknn_forward,
+)
 
 
-def forward(params, x, cfg, precision="fp32", return_viz=False, forced=None):
+def forward(params, x, cfg, precision="fp32", return_viz=False, forced=None, noise=None):
     """Family dispatch used by the tests."""
+    if cfg.family == "dpcknn":
+        return dpcknn_forward(params, x, cfg, noise, precision, return_viz, forced)
     if cfg.family == "tome":
         return tome_forward(params, x, cfg, precision, return_viz, forced)
     if cfg.family == "dyvit":

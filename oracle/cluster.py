@@ -1,0 +1,122 @@
+"""Oracle: clustering-based token merging before a block -- DPC-KNN (models/dpcknn.py).  TEST INFRASTRUCTURE ONLY
+(see oracle/__init__.py).  torch-CPU fp32, functional; reference = /root/reference (read-only):
+
+  models/dpcknn.py   cluster_dpc_knn :44-100, merge_tokens :103-140, CTM.forward :153-172,
+                     DPCKNNVisionTransformer.forward :229-290
+
+Extra state-dict keys: cluster_layers.{j}.score.{weight [1,D], bias [1]} (absent with args.equal_weight).
+
+The reference perturbs the densities with `torch.rand(...) * 1e-6` (dpcknn.py:71-72), i.e. it is not a function of its
+inputs.  The restatement takes that noise as an INPUT (`noise[blk]`, uniform [0,1) of shape [B,P_in]); fixtures record the
+draws the reference made (tests/golden/gen_golden.py spies torch.rand).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from .vit import VitConfig, block_forward, embed_tokens, head, patch_embed
+
+Tensor = torch.Tensor
+
+
+def dpcknn_cluster_counts(cfg: VitConfig) -> Dict[int, int]:
+    """dpcknn.py:214-215: one keep_rate -> int(P0 * kr**(i+1)); several -> ABSOLUTE counts verbatim."""
+    counts = list(cfg.keep_rate)
+    loc = list(cfg.reduction_loc)
+    if len(counts) == 1:
+        counts = [int(cfg.num_patches * counts[0] ** (i + 1)) for i in range(len(loc))]
+    assert len(counts) == len(loc), "keep_rate / reduction_loc length mismatch"
+    return {int(l): int(c) for c, l in zip(counts, loc)}
+
+
+def dpcknn_distances(x: Tensor) -> Tensor:
+    """dpcknn.py:59: torch.cdist(x, x) / sqrt(C).  cdist takes its matmul path for P > 25 (|a|^2 + |b|^2 - 2ab, clamped at
+    1e-30, sqrt), so the diagonal is rounding residue, not 0 -- kept as is: the k nearest neighbours include the token itself."""
+    return torch.cdist(x, x) / (x.shape[-1] ** 0.5)
+
+
+def dpcknn_scores(dist: Tensor, noise: Tensor, k: int = 5):
+    """dpcknn.py:68-88 from a distance matrix: (density [B,P], parent distance [B,P], score [B,P])."""
+    dist_nearest, _ = torch.topk(dist, k=k, dim=-1, largest=False)
+    density = (-(dist_nearest ** 2).mean(dim=-1)).exp()
+    density = density + noise * 1e-6
+    mask = (density[:, None, :] > density[:, :, None]).type(dist.dtype)
+    dist_max = dist.flatten(1).max(dim=-1)[0][:, None, None]
+    parent, _ = (dist * mask + dist_max * (1 - mask)).min(dim=-1)
+    return density, parent, parent * density
+
+
+def dpcknn_assign(dist: Tensor, centers: Tensor) -> Tensor:
+    """dpcknn.py:90-98: every token goes to its nearest centre (first on ties); centres go to themselves."""
+    B, K = centers.shape
+    d = torch.gather(dist, 1, centers[:, :, None].expand(B, K, dist.shape[-1]))      # index_points(dist_matrix, index_down)
+    idx_cluster = d.argmin(dim=1)
+    idx_cluster.scatter_(1, centers, torch.arange(K).expand(B, K))
+    return idx_cluster
+
+
+def dpcknn_cluster(x: Tensor, cluster_num: int, noise: Tensor, k: int = 5, forced_centers: Optional[Tensor] = None):
+    """cluster_dpc_knn dpcknn.py:44-100 (token_mask=None).  Returns (idx_cluster [B,P], index_down [B,K], score [B,P])."""
+    dist = dpcknn_distances(x)
+    _, _, score = dpcknn_scores(dist, noise, k)
+    centers = torch.sort(score, dim=-1, descending=True, stable=True).indices[:, :cluster_num] if forced_centers is None \
+        else forced_centers
+    return dpcknn_assign(dist, centers), centers, score
+
+
+def dpcknn_merge(x: Tensor, idx_cluster: Tensor, cluster_num: int, token_weight: Optional[Tensor]) -> Tensor:
+    """merge_tokens dpcknn.py:103-132 (the idx_token / agg_weight bookkeeping never reaches an output): weighted mean of
+    each cluster's tokens, weights normalised by (cluster sum + 1e-6)."""
+    B, N, C = x.shape
+    if token_weight is None:
+        token_weight = x.new_ones(B, N, 1)
+    idx = (idx_cluster + torch.arange(B)[:, None] * cluster_num).reshape(B * N)
+    all_weight = token_weight.new_zeros(B * cluster_num, 1)
+    all_weight.index_add_(0, idx, token_weight.reshape(B * N, 1))
+    all_weight = all_weight + 1e-6
+    norm_weight = token_weight / all_weight[idx].reshape(B, N, 1)
+    merged = x.new_zeros(B * cluster_num, C)
+    merged.index_add_(0, idx, (x * norm_weight).reshape(B * N, C))
+    return merged.reshape(B, cluster_num, C)
+
+
+def dpcknn_ctm(x_sp: Tensor, p: Dict[str, Tensor], j: int, cluster_num: int, noise: Tensor, k: int = 5,
+               forced_centers: Optional[Tensor] = None):
+    """CTM.forward dpcknn.py:153-172.  Returns (x [B,K,D], idx_centers, idx_cluster, score)."""
+    key = f"cluster_layers.{j}.score.weight"
+    token_weight = None
+    if key in p:                                                                         # not equal_weight
+        token_weight = (x_sp @ p[key].t() + p[f"cluster_layers.{j}.score.bias"]).exp()
+    idx_cluster, centers, score = dpcknn_cluster(x_sp, cluster_num, noise, k, forced_centers)
+    return dpcknn_merge(x_sp, idx_cluster, cluster_num, token_weight), centers, idx_cluster, score
+
+
+@torch.no_grad()
+def dpcknn_forward(params: Dict[str, Tensor], x: Tensor, cfg: VitConfig, noise: Dict[int, Tensor], precision: str = "fp32",
+                   return_viz: bool = False, forced: Optional[Dict[int, Tensor]] = None, k: int = 5):
+    """DPCKNNVisionTransformer.forward dpcknn.py:229-290, eval mode.  The clustering itself is fp32 in both precisions (the
+    HIP path clusters on the fp32 residual stream); `precision` only moves the trunk's rounding points."""
+    p = params
+    tok = patch_embed(x, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], cfg.patch_size, precision)
+    h = embed_tokens(tok, p["cls_token"], p["pos_embed"])
+    counts = dpcknn_cluster_counts(cfg)
+    viz = {"Kept_Tokens": {}, "Assignment_Maps": {}, "Scores": {}, "Tokens": {}}
+    j = 0
+    for i in range(cfg.depth):
+        if i in counts:
+            xs, centers, idx_cluster, score = dpcknn_ctm(h[:, 1:], p, j, counts[i], noise[i], k,
+                                                         None if forced is None else forced[i])
+            h = torch.cat([h[:, :1], xs], dim=1)
+            viz["Kept_Tokens"][i] = centers.numpy()
+            viz["Assignment_Maps"][i] = idx_cluster.numpy()
+            viz["Scores"][i] = score
+            j += 1
+        h, _, _ = block_forward(h, p, i, cfg, None, precision)
+        viz["Tokens"][i] = h.shape[1]
+    logits = head(h, p["norm.weight"], p["norm.bias"], p["head.weight"], p["head.bias"], cfg.ln_eps, precision)
+    if return_viz:
+        viz["Final_Tokens"] = h
+        return logits, viz
+    return logits

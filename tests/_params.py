@@ -66,6 +66,10 @@ def make_stage_params(cfg, case: dict):
                                  ("out_conv.4", (2, D // 4))):
                 p[b + name + ".weight"] = _normal(rng, (o, i), 0.08)
                 p[b + name + ".bias"] = _normal(rng, (o,), 0.02)
+    elif fam == "dpcknn" and not case.get("equal_weight", False):
+        for j in range(n_stages):
+            p[f"cluster_layers.{j}.score.weight"] = _normal(rng, (1, D), 0.05)
+            p[f"cluster_layers.{j}.score.bias"] = _normal(rng, (1,), 0.02)
     elif fam == "sit":
         from oracle.prune_before import sit_cluster_counts
         counts = sit_cluster_counts(cfg)
@@ -125,6 +129,14 @@ GOLDEN_CASES = {
     "dyvit_small_kr07": dict(family="dyvit", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
                              keep_rate=[0.7], reduction_loc=[3, 6, 9], batch=2, wseed=103, xseed=104,
                              qkv_gain=4.0, factory="dyvit_small_patch16_224"),
+    # DPC-KNN (models/dpcknn.py): density-peak clustering + weighted merge BEFORE the block (noise recorded in the fixture)
+    "dpcknn_micro": dict(family="dpcknn", embed_dim=128, depth=4, num_heads=2, num_classes=16,
+                         keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=121, xseed=122, qkv_gain=6.0),
+    "dpcknn_small_kr07": dict(family="dpcknn", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
+                              keep_rate=[0.7], reduction_loc=[3, 6, 9], batch=2, wseed=123, xseed=124,
+                              qkv_gain=4.0, factory="dpcknn_small_patch16_224"),
+    "dpcknn_micro_equal": dict(family="dpcknn", embed_dim=128, depth=4, num_heads=2, num_classes=16, equal_weight=True,
+                               keep_rate=[0.5], reduction_loc=[0, 2], batch=2, wseed=125, xseed=126, qkv_gain=6.0),
     # SiT (models/sit.py): soft assignment (softmax over tokens) BEFORE the block
     "sit_micro": dict(family="sit", embed_dim=128, depth=4, num_heads=2, num_classes=16,
                       keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=111, xseed=112, qkv_gain=6.0),

@@ -41,11 +41,12 @@ from models.tome import ToMeVisionTransformer  # noqa: E402
 import models.tome as ref_tome  # noqa: E402,F401
 from models.dyvit import DynamicVisionTransformer  # noqa: E402
 from models.sit import SelfSlimmedVisionTransformer  # noqa: E402
+from models.dpcknn import DPCKNNVisionTransformer  # noqa: E402
 
 from tests._params import GOLDEN_CASES, make_params, make_stage_params, make_images, case_config  # noqa: E402
 
 CLASSES = {"topk": TopKVisionTransformer, "evit": EfficientVisionTransformer, "deit": DeitViz, "tome": ToMeVisionTransformer,
-           "dyvit": DynamicVisionTransformer, "sit": SelfSlimmedVisionTransformer}
+           "dyvit": DynamicVisionTransformer, "sit": SelfSlimmedVisionTransformer, "dpcknn": DPCKNNVisionTransformer}
 
 
 class TopkSpy:
@@ -96,9 +97,29 @@ class ArgsortSpy:
         torch.argsort = self._orig_fn
 
 
+class RandSpy:
+    """Records torch.rand draws (DPC-KNN's density noise, dpcknn.py:71-72) so the oracle / HIP path can be fed the same."""
+
+    def __init__(self):
+        self.calls = []
+        self._orig = torch.rand
+
+    def __enter__(self):
+        def spy(*a, **kw):
+            out = self._orig(*a, **kw)
+            self.calls.append(out.detach().clone())
+            return out
+        torch.rand = spy
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand = self._orig
+
+
 def build_reference(case):
     args = types.SimpleNamespace(keep_rate=list(case["keep_rate"]), reduction_loc=list(case["reduction_loc"]),
-                                 viz_mode=True, dyvit_distill=False)
+                                 viz_mode=True, dyvit_distill=False, k_neighbors=5,
+                                 equal_weight=bool(case.get("equal_weight", False)))
     with contextlib.redirect_stdout(io.StringIO()):
         if "factory" in case:
             m = create_model(case["factory"], pretrained=False, num_classes=case["num_classes"], drop_rate=0.0,
@@ -120,7 +141,8 @@ def build_reference(case):
 def run_case(name, case):
     m, _ = build_reference(case)
     x = make_images(case["batch"], 224, case["xseed"])
-    with TopkSpy() as spy, ArgsortSpy() as aspy, torch.no_grad():
+    torch.manual_seed(case["xseed"])
+    with TopkSpy() as spy, ArgsortSpy() as aspy, RandSpy() as rspy, torch.no_grad():
         out = m(x)
     logits, viz = out if isinstance(out, tuple) else (out, {})
     rec = {"logits": logits.numpy()}
@@ -131,6 +153,14 @@ def run_case(name, case):
             assert torch.unique(v).numel() == v.numel(), f"{name}: tied ranked values - pick another seed"
             srt = torch.sort(v, descending=True).values
             tome_gaps.append((srt[:-1] - srt[1:]).min().item())
+    if case["family"] == "dpcknn":
+        # spy.calls alternates (kNN smallest-5 on dist, top-K on score) per stage; keep the scores and the noise draws
+        blks = sorted(viz["Kept_Tokens"])
+        assert len(rspy.calls) == len(blks) and len(spy.calls) == 2 * len(blks)
+        for n, blk in enumerate(blks):
+            rec[f"noise_{blk}"] = rspy.calls[n].numpy().astype(np.float32)
+            rec[f"scores_{blk}"] = spy.calls[2 * n + 1][0].numpy().astype(np.float32)
+        spy.calls = [c for n, c in enumerate(spy.calls) if n % 2 == 1]      # tie check below: the centre selection only
     if case["family"] == "dyvit":                # the ranked predictor scores themselves: lets a test accept exactly the
         for blk, sc in zip(sorted(viz["Kept_Tokens"]), aspy.calls):       # orderings that differ by fp noise and no others
             rec[f"scores_{blk}"] = sc.numpy().astype(np.float32)

@@ -411,3 +411,54 @@ def test_sit_merge(ops, B, N, K, D, ldl):
     assert torch.equal(got[:, 0].cpu(), x[:, 0])
     got2, none = ops.sit_merge(logits.cuda(), scale, x.cuda(), K)
     assert none is None and torch.equal(got2, got)
+
+
+# ---------------------------------------------------------------------------------------- DPC-KNN
+@pytest.mark.parametrize("B,N,D,K,k", [(3, 197, 384, 137, 5), (2, 138, 128, 96, 5), (2, 50, 64, 7, 3), (1, 197, 768, 98, 5),
+                                       (2, 9, 64, 8, 2)])
+def test_dpcknn_cluster(ops, B, N, D, K, k):
+    """Integer outputs of a floating-point pipeline: checked against the oracle's fp32 scores/distances up to fp noise --
+    centres must be a valid descending top-K of the oracle's scores, assignments the nearest centre wherever the two
+    nearest centres differ by more than the noise."""
+    rng = _rng(600 + N + D)
+    x = _randn(rng, B, N, D)
+    noise = torch.from_numpy(rng.random((B, N - 1)).astype(np.float32))
+    dist = oracle.dpcknn_distances(x[:, 1:])
+    _, _, score = oracle.dpcknn_scores(dist, noise, k)
+    centers, assign, score_dev = ops.dpcknn_cluster(x.cuda(), K, noise.cuda(), k)
+    centers, assign = centers.cpu().long(), assign.cpu().long()
+    scale = float(score.abs().max())
+    torch.testing.assert_close(score_dev.cpu(), score, atol=2e-5 * scale, rtol=2e-5)
+    from tests._params import assert_valid_ranking
+    assert_valid_ranking(centers.numpy(), score.numpy(), tol=4e-5 * scale)
+    want = oracle.dpcknn_assign(dist, centers)                       # the oracle's assignment for the device's centres
+    d = torch.gather(dist, 1, centers[:, :, None].expand(B, K, N - 1))
+    top2 = d.topk(min(2, K), dim=1, largest=False).values
+    decided = (top2[:, -1] - top2[:, 0] > 1e-5) if K > 1 else torch.ones(B, N - 1, dtype=torch.bool)
+    is_center = torch.zeros(B, N - 1, dtype=torch.bool).scatter_(1, centers, True)
+    ok = (assign == want) | (~decided & ~is_center)
+    assert ok.all(), f"{(~ok).sum().item()} assignments differ beyond fp noise"
+    np.testing.assert_array_equal(torch.gather(assign, 1, centers).numpy(), np.broadcast_to(np.arange(K), (B, K)))
+
+
+@pytest.mark.parametrize("f32", [False, True])
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("B,N,K,D", [(3, 197, 137, 384), (2, 138, 40, 128), (2, 9, 3, 64), (1, 197, 98, 768)])
+def test_cluster_merge_layernorm(ops, f32, weighted, B, N, K, D):
+    rng = _rng(700 + N + K)
+    x = _randn(rng, B, N, D)
+    P = N - 1
+    assign = np.stack([np.concatenate([np.arange(K), rng.integers(0, K, size=P - K)])[rng.permutation(P)] for _ in range(B)])
+    assign = torch.from_numpy(assign.astype(np.int64))                # every cluster non-empty
+    sw, sb = _randn(rng, 1, D, scale=0.05), _randn(rng, 1, scale=0.1)
+    tw = (x[:, 1:] @ sw.t() + sb).exp() if weighted else None
+    xm = torch.cat([x[:, :1], oracle.dpcknn_merge(x[:, 1:], assign, K, tw)], dim=1)
+    g, b = 1 + _randn(rng, D, scale=0.1), _randn(rng, D, scale=0.05)
+    yw = oracle.layer_norm(xm, g, b, 1e-6)
+    xo, y = ops.cluster_merge_layernorm(x.cuda(), assign.int().cuda(), K, g.cuda(), b.cuda(), 1e-6,
+                                        sw.cuda() if weighted else None, sb.cuda() if weighted else None, f32=f32)
+    torch.testing.assert_close(xo.cpu(), xm, atol=3e-6, rtol=3e-6)
+    if f32:
+        torch.testing.assert_close(y.cpu(), yw, atol=2e-5, rtol=2e-5)
+    else:
+        torch.testing.assert_close(y.float().cpu(), yw, atol=2 * BF16_ULP, rtol=BF16_ULP)

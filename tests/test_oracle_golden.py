@@ -36,6 +36,8 @@ def test_model_matches_reference(golden_dir, name):
         return
     if case["family"] in ("dyvit", "sit"):
         return _check_prune_before(case, g, x)
+    if case["family"] == "dpcknn":
+        return _check_dpcknn(case, g, x)
     logits, viz = oracle.vit_forward(params, x, cfg, return_viz=True)
     # integer outputs: bit-exact
     kept_keys = sorted(k for k in g.files if k.startswith("kept_"))
@@ -53,6 +55,26 @@ def test_model_matches_reference(golden_dir, name):
     if "token_counts" in g.files:
         for blk, n in zip(g["token_count_blocks"], g["token_counts"]):
             assert viz["Tokens"][int(blk)] == int(n)
+
+
+def golden_noise(g):
+    return {int(k.split("_")[1]): torch.from_numpy(g[k]) for k in g.files if k.startswith("noise_")}
+
+
+def _check_dpcknn(case, g, x):
+    cfg, params = case_params(case)
+    logits, viz = oracle.forward(params, x, cfg, return_viz=True, noise=golden_noise(g))
+    kept_keys = [k for k in g.files if k.startswith("kept_")]
+    assert len(kept_keys) == len(viz["Kept_Tokens"]) > 0
+    for k in kept_keys:                                   # same cdist, same noise -> same centres and assignment, bit-exact
+        blk = int(k.split("_")[1])
+        np.testing.assert_allclose(viz["Scores"][blk].numpy(), g[f"scores_{blk}"], atol=1e-6, rtol=1e-5)
+        np.testing.assert_array_equal(viz["Kept_Tokens"][blk], g[k])
+        np.testing.assert_array_equal(viz["Assignment_Maps"][blk], g[f"assign_{blk}"])
+    np.testing.assert_allclose(logits.numpy(), g["logits"], atol=FP_TOL, rtol=0)
+    np.testing.assert_allclose(viz["Final_Tokens"][:, :8].numpy(), g["final_tokens"], atol=1e-4, rtol=0)
+    for blk, n in zip(g["token_count_blocks"], g["token_counts"]):
+        assert viz["Tokens"][int(blk)] == int(n)
 
 
 def _check_prune_before(case, g, x):

@@ -1,0 +1,362 @@
+// DPC-KNN token clustering (models/dpcknn.py) on gfx950.  Everything here is fp32 on the fp32 residual stream, in both
+// executor precisions: the outputs are INTEGER decisions (cluster centres, assignments) taken on distance differences.
+//
+//   tr_dpcknn_cluster          cluster_dpc_knn dpcknn.py:44-100: pairwise distances (matmul form, like torch.cdist's mm path),
+//                              k-nearest-neighbour density (+ caller-supplied noise, dpcknn.py:71-72), distance to the nearest
+//                              denser token, score = distance * density, top-K centres (tr_cls_topk), nearest-centre assignment.
+//   tr_cluster_merge_layernorm merge_tokens dpcknn.py:103-132 + CTM's token weight exp(Linear(D,1)) dpcknn.py:155-157, fused
+//                              with the next block's norm1: one wave per output cluster, members added in token order (= the
+//                              order torch's CPU index_add_ applies them).
+// HBM: the [B,P,P] distance matrix is written once and read three times (density, parent distance, assignment) --
+// 4*P*P*4 B per image (0.6 MB at P=196), against 2*P*P*D flops of the Gram product.
+#include "tr_common.h"
+
+extern "C" int tr_cls_topk(const float* cls_rows, int32_t* idx, int32_t* compl_idx, float* scores, int B, int H, int N, int K,
+                           tr_stream_t s);
+
+namespace {
+
+constexpr int CT = 64, CK = 16;   // 64x64 distance tile, 16-deep slabs of D
+
+// one wave per token: squared norm
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x, float* __restrict__ nrm, int B, int N, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int P = N - 1;
+  if (row >= B * P) return;
+  const int b = row / P, p = row - b * P;
+  const float* xr = x + ((size_t)b * N + 1 + p) * D;
+  float acc = 0.f;
+  for (int d = lane; d < D; d += 64) acc = fmaf(xr[d], xr[d], acc);
+  acc = wave_sum(acc);
+  if (lane == 0) nrm[row] = acc;
+}
+
+// dist[b][i][j] = sqrt(max(|x_i|^2 + |x_j|^2 - 2 x_i.x_j, 1e-30)) / sqrt(D);  grid (tiles, B).
+// DIRECT: sqrt(sum (x_i - x_j)^2) / sqrt(D) -- torch.cdist only takes the matmul form when P > 25
+// (use_mm_for_euclid_dist_if_necessary); small late stages (P <= 25) get exact zeros on the diagonal like the reference.
+template <bool DIRECT>
+__global__ __launch_bounds__(256) void dist_kernel(const float* __restrict__ x, const float* __restrict__ nrm,
+                                                   float* __restrict__ dist, int N, int D, float sqrt_d) {
+  __shared__ float sA[CK][CT + 4];
+  __shared__ float sB[CK][CT + 4];
+  const int P = N - 1;
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int nt = (P + CT - 1) / CT;
+  const int i0 = (blockIdx.x / nt) * CT, j0 = (blockIdx.x % nt) * CT;
+  const int b = blockIdx.y;
+  const float* xb = x + ((size_t)b * N + 1) * D;
+  const int lr = tid >> 2, lk = (tid & 3) * 4;
+  const float* ap = xb + (size_t)min(i0 + lr, P - 1) * D + lk;
+  const float* bp = xb + (size_t)min(j0 + lr, P - 1) * D + lk;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int k0 = 0; k0 < D; k0 += CK) {
+    const float4 a = *reinterpret_cast<const float4*>(ap + k0);
+    const float4 w = *reinterpret_cast<const float4*>(bp + k0);
+    __syncthreads();
+    sA[lk + 0][lr] = a.x; sA[lk + 1][lr] = a.y; sA[lk + 2][lr] = a.z; sA[lk + 3][lr] = a.w;
+    sB[lk + 0][lr] = w.x; sB[lk + 1][lr] = w.y; sB[lk + 2][lr] = w.z; sB[lk + 3][lr] = w.w;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CK; ++k) {
+      const float4 av = *reinterpret_cast<const float4*>(&sA[k][ty * 4]);
+      const float4 wv = *reinterpret_cast<const float4*>(&sB[k][tx * 4]);
+      const float a4[4] = {av.x, av.y, av.z, av.w}, w4[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (DIRECT) {
+            const float df = a4[i] - w4[j];
+            acc[i][j] = fmaf(df, df, acc[i][j]);
+          } else {
+            acc[i][j] = fmaf(a4[i], w4[j], acc[i][j]);
+          }
+        }
+    }
+  }
+  const float* nb = nrm + (size_t)b * P;
+  float* db = dist + (size_t)b * P * P;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int gi = i0 + ty * 4 + i;
+    if (gi >= P) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int gj = j0 + tx * 4 + j;
+      if (gj >= P) continue;
+      const float d2 = DIRECT ? acc[i][j] : fmaxf((nb[gi] + nb[gj]) - 2.0f * acc[i][j], 1e-30f);
+      db[(size_t)gi * P + gj] = sqrtf(d2) / sqrt_d;
+    }
+  }
+}
+
+constexpr int KNN_MAX = 8;
+constexpr int PER_LANE = 16;      // P <= 1024
+
+__device__ __forceinline__ void wave_min_pair(float& v, int& i) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o, 64);
+    const int oi = __shfl_xor(i, o, 64);
+    if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+}
+
+// one wave per row: density = exp(-mean(k smallest d^2)) + noise*1e-6; per-image max distance via atomicMax on the bits
+__global__ __launch_bounds__(256) void density_kernel(const float* __restrict__ dist, const float* __restrict__ noise,
+                                                      float* __restrict__ density, int* __restrict__ dmax_bits, int B, int P,
+                                                      int k) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B * P) return;
+  const int b = row / P;
+  const float* dr = dist + (size_t)row * P;
+  float v[PER_LANE];
+  float mx = 0.f;
+#pragma unroll
+  for (int c = 0; c < PER_LANE; ++c) {
+    const int j = c * 64 + lane;
+    v[c] = j < P ? dr[j] : INFINITY;
+    if (j < P) mx = fmaxf(mx, v[c]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if (lane == 0) atomicMax(&dmax_bits[b], __float_as_int(mx));          // distances are >= 0: int order == float order
+  float ss = 0.f;
+  for (int t = 0; t < k; ++t) {                                          // ascending extraction = torch.topk(largest=False) order
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int c = 0; c < PER_LANE; ++c)
+      if (v[c] < best) { best = v[c]; bi = c * 64 + lane; }
+    wave_min_pair(best, bi);
+    ss += best * best;
+#pragma unroll
+    for (int c = 0; c < PER_LANE; ++c)
+      if (c * 64 + lane == bi) v[c] = INFINITY;
+  }
+  if (lane == 0) density[row] = expf(-(ss / (float)k)) + (noise ? noise[row] * 1e-6f : 0.f);
+}
+
+// one wave per row: distance to the nearest token of higher density (else the image's max distance); score = that * density,
+// written in [B,N] layout (column 0 = CLS slot, unused) for tr_cls_topk
+__global__ __launch_bounds__(256) void parent_score_kernel(const float* __restrict__ dist, const float* __restrict__ density,
+                                                           const int* __restrict__ dmax_bits, float* __restrict__ score_rows, int B,
+                                                           int P) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B * P) return;
+  const int b = row / P, i = row - b * P;
+  const float* dr = dist + (size_t)row * P;
+  const float* db = density + (size_t)b * P;
+  const float dmax = __int_as_float(dmax_bits[b]);
+  const float di = db[i];
+  float mn = INFINITY;
+  for (int j = lane; j < P; j += 64) mn = fminf(mn, db[j] > di ? dr[j] : dmax);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o, 64));
+  if (lane == 0) {
+    score_rows[(size_t)b * (P + 1) + 1 + i] = mn * di;
+    if (i == 0) score_rows[(size_t)b * (P + 1)] = 0.f;
+  }
+}
+
+// one workgroup per image: nearest centre per token (first on ties), then centres to themselves
+__global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ dist, const int32_t* __restrict__ centers,
+                                                     int32_t* __restrict__ idx_cluster, int P, int K) {
+  extern __shared__ int s_c[];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int k = tid; k < K; k += 256) s_c[k] = centers[(size_t)b * K + k];
+  __syncthreads();
+  const float* db = dist + (size_t)b * P * P;
+  for (int p = tid; p < P; p += 256) {
+    float best = INFINITY;
+    int arg = 0;
+    for (int k = 0; k < K; ++k) {
+      const float d = db[(size_t)s_c[k] * P + p];
+      if (d < best) { best = d; arg = k; }
+    }
+    idx_cluster[(size_t)b * P + p] = arg;
+  }
+  __syncthreads();
+  for (int k = tid; k < K; k += 256) idx_cluster[(size_t)b * P + s_c[k]] = k;
+}
+
+// one wave per token: w = exp(x . ws + bs)   (CTM.score, dpcknn.py:155-157)
+__global__ __launch_bounds__(256) void token_weight_kernel(const float* __restrict__ x, const float* __restrict__ ws,
+                                                           const float* __restrict__ bs, float* __restrict__ w, int B, int N,
+                                                           int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int P = N - 1;
+  if (row >= B * P) return;
+  const int b = row / P, p = row - b * P;
+  const float* xr = x + ((size_t)b * N + 1 + p) * D;
+  float acc = 0.f;
+  for (int d = lane; d < D; d += 64) acc = fmaf(xr[d], ws[d], acc);
+  acc = wave_sum(acc);
+  if (lane == 0) w[row] = expf(acc + bs[0]);
+}
+
+constexpr int LNC = 4;   // float4 chunks per lane -> D <= 1024
+
+// one wave per output row (row 0 = CLS copy, row 1+c = cluster c), fused with the following LayerNorm
+template <bool F32>
+__global__ __launch_bounds__(256) void cluster_merge_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                      const int32_t* __restrict__ idx_cluster,
+                                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                      float* __restrict__ x_out, void* __restrict__ y, int N, int K,
+                                                                      int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int rblocks = (K + 1 + 3) >> 2;
+  const int b = blockIdx.x / rblocks;
+  const int r = (blockIdx.x % rblocks) * 4 + (threadIdx.x >> 6);
+  if (r > K) return;
+  const int P = N - 1, nchunks = D >> 2;
+  const float* xb = x + (size_t)b * N * D;
+  float4 v[LNC];
+#pragma unroll
+  for (int c = 0; c < LNC; ++c) v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r == 0) {
+#pragma unroll
+    for (int c = 0; c < LNC; ++c)
+      if (lane + 64 * c < nchunks) v[c] = *reinterpret_cast<const float4*>(xb + 4 * (lane + 64 * c));
+  } else {
+    const int cl = r - 1;
+    const int32_t* ic = idx_cluster + (size_t)b * P;
+    const float* wb = w ? w + (size_t)b * P : nullptr;
+    // all_weight = sum of member weights in token order + 1e-6 (index_add_ then + 1e-6, dpcknn.py:123-126)
+    float aw = 0.f;
+    for (int p0 = 0; p0 < P; p0 += 64) {
+      const int p = p0 + lane;
+      const bool m = p < P && ic[p] == cl;
+      unsigned long long mask = __ballot(m);
+      while (mask) {
+        const int q = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        aw += wb ? wb[p0 + q] : 1.0f;
+      }
+    }
+    aw += 1e-6f;
+    for (int p0 = 0; p0 < P; p0 += 64) {
+      const int p = p0 + lane;
+      const bool m = p < P && ic[p] == cl;
+      unsigned long long mask = __ballot(m);
+      while (mask) {
+        const int q = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        const float nw = (wb ? wb[p0 + q] : 1.0f) / aw;                      // norm_weight = token_weight / all_weight[idx]
+        const float* xr = xb + (size_t)(1 + p0 + q) * D;
+#pragma unroll
+        for (int c = 0; c < LNC; ++c)
+          if (lane + 64 * c < nchunks) {
+            const float4 a = *reinterpret_cast<const float4*>(xr + 4 * (lane + 64 * c));
+            v[c].x += a.x * nw; v[c].y += a.y * nw; v[c].z += a.z * nw; v[c].w += a.w * nw;
+          }
+      }
+    }
+  }
+  const size_t orow = (size_t)b * (K + 1) + r;
+#pragma unroll
+  for (int c = 0; c < LNC; ++c)
+    if (lane + 64 * c < nchunks) *reinterpret_cast<float4*>(x_out + orow * D + 4 * (lane + 64 * c)) = v[c];
+  float s1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < LNC; ++c)
+    if (lane + 64 * c < nchunks) s1 += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+  const float mean = wave_sum(s1) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < LNC; ++c)
+    if (lane + 64 * c < nchunks) {
+      const float a = v[c].x - mean, bb = v[c].y - mean, cc = v[c].z - mean, d = v[c].w - mean;
+      q += (a * a + bb * bb) + (cc * cc + d * d);
+    }
+  const float var = wave_sum(q) / (float)D + eps;
+  const float rstd = F32 ? 1.0f / sqrtf(var) : rsqrtf(var);
+#pragma unroll
+  for (int c = 0; c < LNC; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nchunks) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * ch);
+      const float4 be = *reinterpret_cast<const float4*>(beta + 4 * ch);
+      const float o0 = (v[c].x - mean) * rstd * g.x + be.x, o1 = (v[c].y - mean) * rstd * g.y + be.y;
+      const float o2 = (v[c].z - mean) * rstd * g.z + be.z, o3 = (v[c].w - mean) * rstd * g.w + be.w;
+      if (F32) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + orow * D + 4 * ch) = make_float4(o0, o1, o2, o3);
+      } else {
+        uint2 pk;
+        pk.x = pack_bf16x2(o0, o1);
+        pk.y = pack_bf16x2(o2, o3);
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(y) + orow * D + 4 * ch) = pk;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t tr_dpcknn_workspace_floats(int B, int N) {
+  const size_t P = N > 1 ? N - 1 : 0;
+  return (size_t)B * P * P + (size_t)B * (3 * P + N) + 64 + (size_t)B;
+}
+
+extern "C" int tr_dpcknn_cluster(const float* x, const float* noise, float* ws, int32_t* centers, int32_t* idx_cluster,
+                                 float* scores, int B, int N, int D, int K, int k, tr_stream_t s) {
+  TR_REQUIRE(x && ws && centers && idx_cluster && scores, TR_ERR_NULL, "tr_dpcknn_cluster: null pointer");
+  const int P = N - 1;
+  TR_REQUIRE(B > 0 && P >= 2 && P <= 64 * PER_LANE && D > 0 && D % CK == 0, TR_ERR_SHAPE,
+             "tr_dpcknn_cluster: need 2 <= P <= %d and D %% %d == 0 (N=%d D=%d)", 64 * PER_LANE, CK, N, D);
+  TR_REQUIRE(K >= 1 && K <= P && k >= 1 && k <= KNN_MAX && k <= P, TR_ERR_SHAPE, "tr_dpcknn_cluster: bad K=%d / k=%d for P=%d", K, k, P);
+  TR_REQUIRE(tr_aligned16(x) && tr_aligned16(ws), TR_ERR_ALIGN, "tr_dpcknn_cluster: pointers must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(s);
+  float* dist = ws;
+  float* nrm = dist + (size_t)B * P * P;
+  float* density = nrm + (size_t)B * P;
+  float* score_rows = density + (size_t)B * P;                  // [B,N]
+  int* dmax = reinterpret_cast<int*>(score_rows + (size_t)B * N + 16);
+  hipError_t e = hipMemsetAsync(dmax, 0, sizeof(int) * B, st);
+  TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_dpcknn_cluster: memset failed: %s", hipGetErrorString(e));
+  const int rows = B * P, rb = (rows + 3) / 4;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(rb), dim3(256), 0, st, x, nrm, B, N, D);
+  const int nt = (P + CT - 1) / CT;
+  if (P > 25) hipLaunchKernelGGL(dist_kernel<false>, dim3(nt * nt, B), dim3(256), 0, st, x, nrm, dist, N, D, (float)sqrt((double)D));
+  else hipLaunchKernelGGL(dist_kernel<true>, dim3(nt * nt, B), dim3(256), 0, st, x, nrm, dist, N, D, (float)sqrt((double)D));
+  hipLaunchKernelGGL(density_kernel, dim3(rb), dim3(256), 0, st, dist, noise, density, dmax, B, P, k);
+  hipLaunchKernelGGL(parent_score_kernel, dim3(rb), dim3(256), 0, st, dist, density, dmax, score_rows, B, P);
+  TR_CHECK_LAUNCH("tr_dpcknn_cluster");
+  int rc = tr_cls_topk(score_rows, centers, nullptr, scores, B, 1, N, K, s);      // topk(score, K), sorted descending
+  if (rc != TR_OK) return rc;
+  hipLaunchKernelGGL(assign_kernel, dim3(B), dim3(256), sizeof(int) * K, st, dist, centers, idx_cluster, P, K);
+  TR_CHECK_LAUNCH("tr_dpcknn_cluster");
+  return TR_OK;
+}
+
+extern "C" int tr_cluster_merge_layernorm(const float* x, const float* score_w, const float* score_b, float* w_ws,
+                                          const int32_t* idx_cluster, const float* gamma, const float* beta, float* x_out, void* y,
+                                          int y_is_f32, int B, int N, int K, int D, float eps, tr_stream_t s) {
+  TR_REQUIRE(x && idx_cluster && gamma && beta && x_out && y, TR_ERR_NULL, "tr_cluster_merge_layernorm: null pointer");
+  TR_REQUIRE((score_w == nullptr) == (score_b == nullptr) && (score_w == nullptr || w_ws != nullptr), TR_ERR_NULL,
+             "tr_cluster_merge_layernorm: score weight, bias and the [B,P] weight scratch go together");
+  TR_REQUIRE(B > 0 && N >= 2 && K >= 1 && K <= N - 1 && D > 0 && D % 4 == 0 && D <= 256 * LNC, TR_ERR_SHAPE,
+             "tr_cluster_merge_layernorm: bad shape B=%d N=%d K=%d D=%d", B, N, K, D);
+  TR_REQUIRE(x_out != x, TR_ERR_SHAPE, "tr_cluster_merge_layernorm: needs a distinct x_out");
+  TR_REQUIRE(tr_aligned16(x) && tr_aligned16(x_out) && tr_aligned16(y) && tr_aligned16(gamma) && tr_aligned16(beta), TR_ERR_ALIGN,
+             "tr_cluster_merge_layernorm: pointers must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(s);
+  if (score_w) hipLaunchKernelGGL(token_weight_kernel, dim3((B * (N - 1) + 3) / 4), dim3(256), 0, st, x, score_w, score_b, w_ws, B, N, D);
+  const int rblocks = (K + 1 + 3) / 4;
+  if (y_is_f32)
+    hipLaunchKernelGGL(cluster_merge_layernorm_kernel<true>, dim3(B * rblocks), dim3(256), 0, st, x, score_w ? w_ws : nullptr,
+                       idx_cluster, gamma, beta, x_out, y, N, K, D, eps);
+  else
+    hipLaunchKernelGGL(cluster_merge_layernorm_kernel<false>, dim3(B * rblocks), dim3(256), 0, st, x, score_w ? w_ws : nullptr,
+                       idx_cluster, gamma, beta, x_out, y, N, K, D, eps);
+  TR_CHECK_LAUNCH("tr_cluster_merge_layernorm");
+  return TR_OK;
+}

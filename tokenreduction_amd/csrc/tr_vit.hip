@@ -30,7 +30,7 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 struct Plan {
   int P, N0, D, H, Hd, C, kcols;
-  size_t off_x0, off_x1, off_xn, off_qkv, off_ao, off_h, off_d, off_cols, off_cls, off_scores, off_idx, off_compl, off_xcls, off_size0, off_size1, total;
+  size_t off_x0, off_x1, off_xn, off_qkv, off_ao, off_h, off_d, off_cols, off_cls, off_scores, off_idx, off_compl, off_xcls, off_size0, off_size1, off_cluster, total;
 };
 
 bool make_plan(const tr_vit_config* c, int B, Plan* p) {
@@ -40,7 +40,7 @@ bool make_plan(const tr_vit_config* c, int B, Plan* p) {
   if (c->patch <= 0 || c->img_size <= 0 || c->img_size % c->patch != 0) return false;
   if (c->depth <= 0 || c->depth > TR_MAX_DEPTH) return false;
   if (c->num_heads <= 0 || c->embed_dim != c->num_heads * 64) return false;
-  if (c->family < TR_FAMILY_DEIT || c->family > TR_FAMILY_SIT) return false;
+  if (c->family < TR_FAMILY_DEIT || c->family > TR_FAMILY_DPCKNN) return false;
   const int g = c->img_size / c->patch;
   p->P = g * g;
   p->N0 = p->P + 1;
@@ -67,6 +67,8 @@ bool make_plan(const tr_vit_config* c, int B, Plan* p) {
   p->off_size0 = o;  o += align_up((size_t)B * p->N0 * 4);
   p->off_size1 = o;  o += align_up((size_t)B * p->N0 * 4);
   p->off_xcls = o;   o += align_up((size_t)B * p->D * es);
+  p->off_cluster = o;
+  if (c->family == TR_FAMILY_DPCKNN) o += align_up(tr_dpcknn_workspace_floats(B, p->N0) * 4 + (size_t)B * p->N0 * 4);
   p->total = o;
   return true;
 }
@@ -115,8 +117,8 @@ extern "C" size_t tr_vit_workspace_bytes(const tr_vit_config* cfg, int B) {
   } while (0)
 
 extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits, void* workspace,
-                              size_t workspace_bytes, int32_t* kept_idx, int32_t* compl_idx, float* soft_out, int* tokens_out,
-                              int B, tr_stream_t s) {
+                              size_t workspace_bytes, int32_t* kept_idx, int32_t* compl_idx, float* soft_out,
+                              const float* noise_in, int* tokens_out, int B, tr_stream_t s) {
   Plan p;
   TR_REQUIRE(cfg && w && img && logits && workspace, TR_ERR_NULL, "tr_vit_forward: null pointer");
   TR_REQUIRE(make_plan(cfg, B, &p), TR_ERR_CONFIG,
@@ -156,6 +158,25 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
     const tr_block_weights* bw = &w->blocks[i];
     const bool tome = cfg->family == TR_FAMILY_TOME;
     bool have_xn = false;   // norm1(x) already in xn (written by a pre-block reducer)
+    if (cfg->family == TR_FAMILY_DPCKNN && cfg->keep[i] > 0) {
+      // a19 + a20: CTM (dpcknn.py:153-172) on x[:, 1:] BEFORE the block; merge fused with the block's norm1
+      const tr_stage_weights* sw = &w->stage[i];
+      const int Kc = cfg->keep[i], M = B * N;
+      TR_REQUIRE(Kc <= N - 1, TR_ERR_CONFIG, "tr_vit_forward: block %d asks for %d clusters of %d patch tokens", i, Kc, N - 1);
+      if (pending) TR_TRY(op_ln(f32, x, D, pending, D, bw->ln1_g, bw->ln1_b, xn, M, D, cfg->ln_eps, s));   // x += previous mlp output
+      pending = nullptr;
+      float* cws = reinterpret_cast<float*>(ws + p.off_cluster);
+      float* wtok = cws + tr_dpcknn_workspace_floats(B, p.N0);
+      int32_t* centers = kept_idx ? kept_idx + (size_t)i * B * p.N0 : idx_ws;
+      int32_t* assign = compl_idx ? compl_idx + (size_t)i * B * p.N0 : compl_ws;
+      TR_TRY(tr_dpcknn_cluster(x, noise_in, cws, centers, assign, scores, B, N, D, Kc, cfg->knn_k > 0 ? cfg->knn_k : 5, s));
+      if (noise_in) noise_in += (size_t)B * (N - 1);
+      TR_TRY(tr_cluster_merge_layernorm(x, sw->w3, sw->b3, wtok, assign, bw->ln1_g, bw->ln1_b, x_alt, xn, f32 ? 1 : 0, B, N, Kc, D,
+                                        cfg->ln_eps, s));
+      float* t = x; x = x_alt; x_alt = t;
+      N = Kc + 1;
+      have_xn = true;
+    }
     if ((cfg->family == TR_FAMILY_DYVIT || cfg->family == TR_FAMILY_SIT) && cfg->keep[i] > 0) {
       const tr_stage_weights* sw = &w->stage[i];
       const int Kc = cfg->keep[i], M = B * N;

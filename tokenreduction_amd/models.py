@@ -204,6 +204,7 @@ class VisionTransformer(nn.Module):
         cfg.num_classes = self.num_classes
         cfg.ln_eps = float(self.norm.eps)
         cfg.precision = _lib.TR_PREC_FP32 if self.precision == "fp32" else _lib.TR_PREC_BF16
+        cfg.knn_k = int(getattr(self, "k_neighbors", 0))
         for i in range(self.depth):
             cfg.keep[i] = int(self._keep[i])
         self._packed = dict(key=key, W=W, cfg=cfg, keep_alive=keep_alive)
@@ -212,6 +213,10 @@ class VisionTransformer(nn.Module):
 
     def _pack_stages(self, W, w16, f32, keep_alive):
         """Families with learned reduction modules fill W.stage[blk] (tr_stage_weights) here."""
+
+    def _noise_ptr(self, B, dev):
+        """Device pointer of the per-stage random inputs (DPC-KNN density noise), None for deterministic families."""
+        return None
 
     def _soft_elems(self, B):
         """fp32 elements of the soft-assignment output (SiT), 0 for families without one."""
@@ -256,7 +261,8 @@ class VisionTransformer(nn.Module):
         with torch.cuda.device(x.device):
             rc = lib.tr_vit_forward(C.byref(cfg), C.byref(pk["W"]), x.data_ptr(), logits.data_ptr(), ws["buf"].data_ptr(),
                                     ws["nbytes"], ws["kept"].data_ptr(), ws["compl"].data_ptr(),
-                                    None if ws.get("soft") is None else ws["soft"].data_ptr(), tokens, B,
+                                    None if ws.get("soft") is None else ws["soft"].data_ptr(), self._noise_ptr(B, x.device),
+                                    tokens, B,
                                     torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "tr_vit_forward")
         self._last_tokens = list(tokens)
@@ -537,6 +543,10 @@ class SelfSlimmedVisionTransformer(VisionTransformer):
             p_in = K
         return out
 
+    def _noise_ptr(self, B, dev):
+        """Device pointer of the per-stage random inputs (DPC-KNN density noise), None for deterministic families."""
+        return None
+
     def _soft_elems(self, B):
         return sum(B * K * P for _, K, P in self._stage_shapes())
 
@@ -550,3 +560,80 @@ class SelfSlimmedVisionTransformer(VisionTransformer):
             assignments[blk] = a
             hard[blk] = np.argmax(a, axis=-2).astype(np.int64)                       # sit.py:122
         return {"Assignment_Maps": hard, "Soft_Assignment_Maps": assignments, "Features": {}}
+
+
+class CTM(nn.Module):
+    """Parameter holder (dpcknn.py:143-151)."""
+
+    def __init__(self, embed_dim, cluster_num, k=5, equal_weight=False):
+        super().__init__()
+        self.cluster_num, self.equal_weight, self.k = cluster_num, equal_weight, k
+        if not self.equal_weight:
+            self.score = nn.Linear(embed_dim, 1)
+
+
+class DPCKNNVisionTransformer(VisionTransformer):
+    """models/dpcknn.py:175-290: before each block in reduction_loc the patch tokens are clustered by DPC-KNN and every cluster
+    is replaced by the exp(score)-weighted mean of its tokens.
+
+    The reference adds `torch.rand * 1e-6` to the densities (dpcknn.py:71-72).  Here the draws come from torch.rand on the
+    device each forward, or from `self.density_noise = {blk: tensor[B,P_in]}` when set (tests feed the reference's draws)."""
+    _family = _lib.TR_FAMILY_DPCKNN
+
+    def __init__(self, *a, args=None, **kw):
+        super().__init__(*a, args=args, **kw)
+        self.cluster_loc = list(args.reduction_loc)
+        self.cluster_count = list(args.keep_rate)
+        self.k_neighbors = int(args.k_neighbors)
+        self.equal_weight = bool(args.equal_weight)
+        P0 = self.patch_embed.num_patches
+        if len(self.cluster_count) == 1:
+            self.cluster_count = [int(P0 * (args.keep_rate[0] ** (idx + 1))) for idx in range(len(self.cluster_loc))]   # dpcknn.py:214-215
+        assert len(self.cluster_count) == len(self.cluster_loc), \
+            f"Mismatch between the cluster location ({self.cluster_loc}) and cluster centers ({self.cluster_count})"
+        self.cluster_count = [int(c) for c in self.cluster_count]
+        self.cluster_layers = nn.ModuleList([CTM(self.embed_dim, c, self.k_neighbors, self.equal_weight) for c in self.cluster_count])
+        for m in self.cluster_layers.modules():
+            _init_vit_weights(m)
+        for c, loc in zip(self.cluster_count, self.cluster_loc):
+            self._keep[loc] = c
+        self.density_noise = None
+        self._noise_buf = None
+
+    def get_new_module_names(self):
+        return ["cluster_layers"]
+
+    def get_reduction_count(self):
+        return self.cluster_loc
+
+    def _pack_stages(self, W, w16, f32, keep_alive):
+        if self.equal_weight:
+            return
+        for j, loc in enumerate(self.cluster_loc):
+            st = W.stage[loc]
+            st.w3, st.b3 = f32(self.cluster_layers[j].score.weight), f32(self.cluster_layers[j].score.bias)
+
+    def _stage_shapes(self):
+        out, p_in = [], self.patch_embed.num_patches
+        for K, loc in sorted(zip(self.cluster_count, self.cluster_loc), key=lambda t: t[1]):
+            out.append((loc, K, p_in))
+            p_in = K
+        return out
+
+    def _noise_ptr(self, B, dev):
+        shapes = self._stage_shapes()
+        if self.density_noise is not None:
+            parts = [self.density_noise[blk].to(device=dev, dtype=torch.float32).reshape(B, P) for blk, _, P in shapes]
+            self._noise_buf = torch.cat([t.reshape(-1) for t in parts]).contiguous()
+        else:
+            self._noise_buf = torch.rand(sum(B * P for _, _, P in shapes), dtype=torch.float32, device=dev)
+        return self._noise_buf.data_ptr()
+
+    def _viz_data(self, ws, B, tokens):
+        P1 = self.patch_embed.num_patches + 1
+        kept, assign = ws["kept"].cpu().numpy(), ws["compl"].cpu().numpy()
+        decisions, assignments = {}, {}
+        for blk, K, P in self._stage_shapes():
+            decisions[blk] = kept[blk * B * P1: blk * B * P1 + B * K].reshape(B, K).astype(np.int64)
+            assignments[blk] = assign[blk * B * P1: blk * B * P1 + B * P].reshape(B, P).astype(np.int64)
+        return {"Kept_Tokens": decisions, "Assignment_Maps": assignments, "Center_Feats": {}, "Features": {}}

@@ -214,3 +214,35 @@ def sit_merge(logits: torch.Tensor, scale: float, x: torch.Tensor, K: int, want_
                                         x_out.data_ptr(), None if soft is None else soft.data_ptr(), B, N, K, D, _stream()),
                "tr_sit_merge")
     return x_out, soft
+
+
+# ---------------------------------------------------------------------------------------- DPC-KNN (models/dpcknn.py)
+def dpcknn_cluster(x: torch.Tensor, K: int, noise: torch.Tensor = None, k: int = 5):
+    """cluster_dpc_knn (dpcknn.py:44-100) on the patch rows of x fp32 [B,N,D] ->
+    (centers int32 [B,K] in descending-score order, idx_cluster int32 [B,N-1], scores fp32 [B,N-1])."""
+    B, N, D = x.shape
+    lib = _lib.load()
+    ws = torch.empty(lib.tr_dpcknn_workspace_floats(B, N), dtype=torch.float32, device=x.device)
+    centers = torch.empty(B, K, dtype=torch.int32, device=x.device)
+    idx_cluster = torch.empty(B, N - 1, dtype=torch.int32, device=x.device)
+    scores = torch.empty(B, N - 1, dtype=torch.float32, device=x.device)
+    _lib.check(lib.tr_dpcknn_cluster(_dev(x, torch.float32, "x"), _opt(noise, torch.float32, "noise"), ws.data_ptr(),
+                                     centers.data_ptr(), idx_cluster.data_ptr(), scores.data_ptr(), B, N, D, K, k, _stream()),
+               "tr_dpcknn_cluster")
+    return centers, idx_cluster, scores
+
+
+def cluster_merge_layernorm(x: torch.Tensor, idx_cluster: torch.Tensor, K: int, gamma, beta, eps: float, score_w=None, score_b=None,
+                            f32: bool = False):
+    """merge_tokens (dpcknn.py:103-132) with token_weight = exp(Linear(D,1)(x)) (None = equal weights) + the next LayerNorm:
+    x fp32 [B,N,D] -> (x_out fp32 [B,K+1,D], y [B,K+1,D])."""
+    B, N, D = x.shape
+    x_out = torch.empty(B, K + 1, D, dtype=torch.float32, device=x.device)
+    y = torch.empty(B, K + 1, D, dtype=torch.float32 if f32 else torch.bfloat16, device=x.device)
+    wws = torch.empty(B, N - 1, dtype=torch.float32, device=x.device) if score_w is not None else None
+    _lib.check(_lib.load().tr_cluster_merge_layernorm(
+        _dev(x, torch.float32, "x"), _opt(score_w, torch.float32, "score_w"), _opt(score_b, torch.float32, "score_b"),
+        None if wws is None else wws.data_ptr(), _dev(idx_cluster, torch.int32, "idx_cluster"), _dev(gamma, torch.float32, "gamma"),
+        _dev(beta, torch.float32, "beta"), x_out.data_ptr(), y.data_ptr(), int(f32), B, N, K, D, eps, _stream()),
+        "tr_cluster_merge_layernorm")
+    return x_out, y

@@ -98,8 +98,35 @@ def forward_stepwise(model: VisionTransformer, x: torch.Tensor, trace: Optional[
     size = None        # ToMe token sizes [B, N] (None until the first merge)
     info["tome"] = {}
     info["soft"] = {}
+    noise_parts = None
+    if cfg.family == 6:       # DPC-KNN: the same density noise the executor would use (model.density_noise or fresh draws)
+        model._noise_ptr(B, dev)
+        noise_parts, off = [], 0
+        for _, _, P_in in model._stage_shapes():
+            noise_parts.append(model._noise_buf[off: off + B * P_in].reshape(B, P_in))
+            off += B * P_in
     for i, blk in enumerate(model.blocks):
         xn = None
+        if cfg.family == 6 and int(cfg.keep[i]) > 0:
+            # DPC-KNN: cluster + merge BEFORE the block (dpcknn.py:258-262), merge fused with norm1
+            Kc, M = int(cfg.keep[i]), B * N
+            j = model.cluster_loc.index(i)
+            if pending is not None:
+                tr.run("layernorm_kernel", 0.0, 12.0 * M * D,
+                       lambda: ops.layernorm(h, f32(blk.norm1.weight), f32(blk.norm1.bias), eps, delta=pending))
+                pending = None
+            noise = None if noise_parts is None else noise_parts[j]
+            centers, assign, score = tr.run("dpcknn_cluster", 2.0 * B * (N - 1) * (N - 1) * D, 16.0 * B * (N - 1) * (N - 1),
+                                            lambda: ops.dpcknn_cluster(h.view(B, N, D), Kc, noise, model.k_neighbors))
+            info["kept"][i], info["compl"][i], info["scores"][i] = centers, assign, score
+            ctm = model.cluster_layers[j]
+            sw = None if model.equal_weight else f32(ctm.score.weight)
+            sb = None if model.equal_weight else f32(ctm.score.bias)
+            h3_, xn = tr.run("cluster_merge_layernorm_kernel", 0.0, 4.0 * M * D + 6.0 * B * (Kc + 1) * D,
+                             lambda: ops.cluster_merge_layernorm(h.view(B, N, D), assign, Kc, f32(blk.norm1.weight),
+                                                                 f32(blk.norm1.bias), eps, sw, sb))
+            N = Kc + 1
+            h, xn = h3_.view(B * N, D), xn.view(B * N, D)
         if cfg.family in (4, 5) and int(cfg.keep[i]) > 0:
             # DyViT / SiT: the reduction module runs on x BEFORE the block (dyvit.py:218-239, sit.py:116-119)
             Kc, M = int(cfg.keep[i]), B * N
