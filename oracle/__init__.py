@@ -27,10 +27,15 @@ from .cluster import (  # noqa: F401
     dpcknn_cluster_counts, dpcknn_distances, dpcknn_scores, dpcknn_assign, dpcknn_cluster, dpcknn_merge, dpcknn_ctm,
     dpcknn_forward,
 )
+from .ats import (  # noqa: F401
+    ats_sample_counts, ats_sample_steps, ats_scores, ats_cdf, ats_ids_from_cdf, ats_sample_ids, ats_block_forward, ats_forward,
+)
 
 
 def forward(params, x, cfg, precision="fp32", return_viz=False, forced=None, noise=None):
     """Family dispatch used by the tests."""
+    if cfg.family == "ats":
+        return ats_forward(params, x, cfg, precision, return_viz, static_pad=False, forced=forced)
     if cfg.family == "dpcknn":
         return dpcknn_forward(params, x, cfg, noise, precision, return_viz, forced)
     if cfg.family == "tome":

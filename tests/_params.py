@@ -137,6 +137,15 @@ GOLDEN_CASES = {
                               qkv_gain=4.0, factory="dpcknn_small_patch16_224"),
     "dpcknn_micro_equal": dict(family="dpcknn", embed_dim=128, depth=4, num_heads=2, num_classes=16, equal_weight=True,
                                keep_rate=[0.5], reduction_loc=[0, 2], batch=2, wseed=125, xseed=126, qkv_gain=6.0),
+    # ATS (models/ats.py): inverse-CDF sampling on CLS attention x |v| inside the attention
+    "ats_micro": dict(family="ats", embed_dim=128, depth=4, num_heads=2, num_classes=16,
+                      keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=131, xseed=132, qkv_gain=6.0),
+    "ats_small_kr07": dict(family="ats", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
+                           keep_rate=[0.7], reduction_loc=[3, 6, 9], batch=2, wseed=133, xseed=134,
+                           qkv_gain=4.0, factory="ats_small_patch16_224"),
+    "ats_small_kr05": dict(family="ats", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
+                           keep_rate=[0.5], reduction_loc=[3, 6, 9], batch=3, wseed=135, xseed=136,
+                           qkv_gain=4.0, factory="ats_small_patch16_224"),
     # SiT (models/sit.py): soft assignment (softmax over tokens) BEFORE the block
     "sit_micro": dict(family="sit", embed_dim=128, depth=4, num_heads=2, num_classes=16,
                       keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=111, xseed=112, qkv_gain=6.0),
@@ -179,3 +188,18 @@ def assert_valid_ranking(idx, ref_scores, tol):
         rest = np.delete(ref_scores[b], idx[b])
         if rest.size:
             assert rest.max() <= picked.min() + tol, "a dropped token outranks a kept one beyond fp noise"
+
+
+def assert_valid_sampling(kept, cdf, steps, tol):
+    """ATS (ats.py:73-77): `kept` [B,W] (0-based patch ids, -1 = pad) is a correct set of inverse-CDF samples of `cdf` [B,P]
+    up to `tol` in the distance |step - cdf|: every grid point has a kept id within tol of its nearest cdf entry, and every
+    kept id is within tol of nearest for some grid point.  (The reference's cdist takes its matmul form, whose fp32 rounding
+    decides among candidates closer than ~3e-4 to a grid point.)"""
+    kept, cdf, steps = np.asarray(kept), np.asarray(cdf, dtype=np.float64), np.asarray(steps, dtype=np.float64)
+    for b in range(kept.shape[0]):
+        ids = kept[b][kept[b] >= 0]
+        assert (np.diff(ids) > 0).all(), "ids must be sorted and unique"
+        d = np.abs(steps[:, None] - cdf[b][None, :])                    # [steps, P]
+        ok = d <= d.min(axis=1, keepdims=True) + tol
+        assert ok[:, ids].any(axis=1).all(), "a grid point has no kept id among its nearest cdf entries"
+        assert ok[:, ids].any(axis=0).all(), "a kept id is nearest (within tol) to no grid point"

@@ -42,11 +42,12 @@ import models.tome as ref_tome  # noqa: E402,F401
 from models.dyvit import DynamicVisionTransformer  # noqa: E402
 from models.sit import SelfSlimmedVisionTransformer  # noqa: E402
 from models.dpcknn import DPCKNNVisionTransformer  # noqa: E402
+from models.ats import ATSVisionTransformer  # noqa: E402
 
 from tests._params import GOLDEN_CASES, make_params, make_stage_params, make_images, case_config  # noqa: E402
 
 CLASSES = {"topk": TopKVisionTransformer, "evit": EfficientVisionTransformer, "deit": DeitViz, "tome": ToMeVisionTransformer,
-           "dyvit": DynamicVisionTransformer, "sit": SelfSlimmedVisionTransformer, "dpcknn": DPCKNNVisionTransformer}
+           "dyvit": DynamicVisionTransformer, "sit": SelfSlimmedVisionTransformer, "dpcknn": DPCKNNVisionTransformer, "ats": ATSVisionTransformer}
 
 
 class TopkSpy:
@@ -97,6 +98,24 @@ class ArgsortSpy:
         torch.argsort = self._orig_fn
 
 
+class CdistSpy:
+    """Records torch.cdist's second argument: ATS's cdf (ats.py:73), the input of its sampling decision."""
+
+    def __init__(self):
+        self.calls = []
+        self._orig = torch.cdist
+
+    def __enter__(self):
+        def spy(a, b, *args, **kw):
+            self.calls.append(b.detach().clone())
+            return self._orig(a, b, *args, **kw)
+        torch.cdist = spy
+        return self
+
+    def __exit__(self, *exc):
+        torch.cdist = self._orig
+
+
 class RandSpy:
     """Records torch.rand draws (DPC-KNN's density noise, dpcknn.py:71-72) so the oracle / HIP path can be fed the same."""
 
@@ -142,7 +161,7 @@ def run_case(name, case):
     m, _ = build_reference(case)
     x = make_images(case["batch"], 224, case["xseed"])
     torch.manual_seed(case["xseed"])
-    with TopkSpy() as spy, ArgsortSpy() as aspy, RandSpy() as rspy, torch.no_grad():
+    with TopkSpy() as spy, ArgsortSpy() as aspy, RandSpy() as rspy, CdistSpy() as cspy, torch.no_grad():
         out = m(x)
     logits, viz = out if isinstance(out, tuple) else (out, {})
     rec = {"logits": logits.numpy()}
@@ -153,6 +172,11 @@ def run_case(name, case):
             assert torch.unique(v).numel() == v.numel(), f"{name}: tied ranked values - pick another seed"
             srt = torch.sort(v, descending=True).values
             tome_gaps.append((srt[:-1] - srt[1:]).min().item())
+    if case["family"] == "ats":
+        blks = sorted(viz["Kept_Tokens"])
+        assert len(cspy.calls) == len(blks)
+        for blk, c in zip(blks, cspy.calls):
+            rec[f"cdf_{blk}"] = c.squeeze(-1).numpy().astype(np.float32)
     if case["family"] == "dpcknn":
         # spy.calls alternates (kNN smallest-5 on dist, top-K on score) per stage; keep the scores and the noise draws
         blks = sorted(viz["Kept_Tokens"])

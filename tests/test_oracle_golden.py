@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import oracle
-from tests._params import GOLDEN_CASES, assert_valid_ranking, case_config, case_params, make_images, make_params
+from tests._params import GOLDEN_CASES, assert_valid_ranking, assert_valid_sampling, case_config, case_params, make_images, make_params
 
 FP_TOL = 2e-5   # fp32 CPU: different op order (im2col GEMM vs conv, fused softmax) only
 
@@ -38,6 +38,8 @@ def test_model_matches_reference(golden_dir, name):
         return _check_prune_before(case, g, x)
     if case["family"] == "dpcknn":
         return _check_dpcknn(case, g, x)
+    if case["family"] == "ats":
+        return _check_ats(case, g, x)
     logits, viz = oracle.vit_forward(params, x, cfg, return_viz=True)
     # integer outputs: bit-exact
     kept_keys = sorted(k for k in g.files if k.startswith("kept_"))
@@ -55,6 +57,44 @@ def test_model_matches_reference(golden_dir, name):
     if "token_counts" in g.files:
         for blk, n in zip(g["token_count_blocks"], g["token_counts"]):
             assert viz["Tokens"][int(blk)] == int(n)
+
+
+def _check_ats(case, g, x):
+    cfg, params = case_params(case)
+    counts = oracle.ats_sample_counts(cfg)
+    kept_keys = sorted((k for k in g.files if k.startswith("kept_")), key=lambda k: int(k.split("_")[1]))
+    # (1) the sampling op on the reference's own cdf: ids incl. pads and batch-max width, bit-exact
+    for k in kept_keys:
+        blk = int(k.split("_")[1])
+        ids, _ = oracle.ats_ids_from_cdf(torch.from_numpy(g[f"cdf_{blk}"]), oracle.ats_sample_steps(counts[blk]))
+        np.testing.assert_array_equal((ids[:, 1:] - 1).numpy(), g[k])
+    # (2) teacher-forced with the reference's ids: every stage's cdf and the logits match the reference to fp32 noise
+    forced = {int(k.split("_")[1]): torch.from_numpy(np.concatenate([np.zeros((g[k].shape[0], 1), np.int64), g[k] + 1], axis=1))
+              for k in kept_keys}
+    logits, viz = oracle.ats_forward(params, x, cfg, return_viz=True, forced=forced)
+    for k in kept_keys:
+        blk = int(k.split("_")[1])
+        np.testing.assert_allclose(viz["Cdf"][blk].numpy(), g[f"cdf_{blk}"], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(logits.numpy(), g["logits"], atol=FP_TOL, rtol=0)
+    np.testing.assert_allclose(viz["Final_Tokens"][:, :8].numpy(), g["final_tokens"], atol=1e-4, rtol=0)
+    for blk, n in zip(g["token_count_blocks"], g["token_counts"]):
+        assert viz["Tokens"][int(blk)] == int(n)
+    # (3) free-running: the first stage samples the same token set, so its ids must be valid samples of the REFERENCE's cdf
+    # up to the rounding plateau of the matmul-form cdist; later stages are printed (their token sets may differ by a neighbour)
+    l_free, v_free = oracle.ats_forward(params, x, cfg, return_viz=True)
+    blk0 = int(kept_keys[0].split("_")[1])
+    assert_valid_sampling(v_free["Kept_Tokens"][blk0], g[f"cdf_{blk0}"], oracle.ats_sample_steps(counts[blk0]).numpy(), tol=5e-4)
+    agree = [float(np.mean([len(set(a[a >= 0].tolist()) & set(b[b >= 0].tolist())) / max(1, (b >= 0).sum())
+                            for a, b in zip(v_free["Kept_Tokens"][int(k.split("_")[1])], g[k])])) for k in kept_keys]
+    assert agree[0] > 0.95, agree       # later stages index into a token list that may already differ by a neighbour
+    # (4) static padding to the bound K (the HIP layout) changes no valid row: same ids where valid, same logits
+    l2, v2 = oracle.ats_forward(params, x, cfg, return_viz=True, static_pad=True)
+    np.testing.assert_allclose(l2.numpy(), l_free.numpy(), atol=2e-6, rtol=0)
+    for blk, kt in v_free["Kept_Tokens"].items():
+        w = kt.shape[1]
+        assert v2["Kept_Tokens"][blk].shape[1] == counts[blk] - 1
+        np.testing.assert_array_equal(v2["Kept_Tokens"][blk][:, :w], kt)
+        assert (v2["Kept_Tokens"][blk][:, w:] == -1).all()
 
 
 def golden_noise(g):
