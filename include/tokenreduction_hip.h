@@ -131,6 +131,19 @@ int tr_cluster_merge_layernorm(const float* x, const float* score_w, const float
                                const int32_t* idx_cluster, const float* gamma, const float* beta, float* x_out, void* y,
                                int y_is_f32, int B, int N, int K, int D, float eps, tr_stream_t s);
 
+/* ---- ATS (csrc/tr_ats.hip) ----------------------------------------------------------------------------------------------
+ * tr_ats_sample: AdaptiveTokenSampling.forward ats.py:52-84.  cls_rows fp32 [B,H,N] (softmax row of the CLS query),
+ *   qkv [B*N, 3*H*64] (bf16, or fp32 when qkv_is_f32; only V is read), mask (nullable = all valid) fp32 [B,N] of 1/0,
+ *   steps fp32 [n_steps] = the module's sample_steps (ats.py:48).  ids int32 [B,K]: id 0 (CLS) first, then the sorted unique
+ *   sampled token ids (1-based positions), then 0 padding up to the static bound K; new_mask fp32 [B,K] of 1/0
+ *   (ids != 0, CLS 1).  cdf_out (nullable) fp32 [B,N-1]: the cdf the samples were taken on.
+ * tr_ats_gather: x_out[b,t] = x[b, ids[b,t]] (fp32 [B,K,D], ats.py:157) and ao_out[b,t] = ao[b, ids[b,t]] (the rows of
+ *   attn @ v the sampled queries keep, ats.py:86,129); ao bf16 (fp32 when ao_is_f32). */
+int tr_ats_sample(const float* cls_rows, const void* qkv, int qkv_is_f32, const float* mask, const float* steps, int n_steps,
+                  int32_t* ids, float* new_mask, float* cdf_out, int B, int N, int H, int K, tr_stream_t s);
+int tr_ats_gather(const float* x, const void* ao, int ao_is_f32, const int32_t* ids, float* x_out, void* ao_out, int B, int N,
+                  int K, int D, tr_stream_t s);
+
 /* a13 bipartite_soft_matching (tome.py:230-277, class_token=True) on metric = k.mean(1) (tome.py:58), read straight from the
  * K third of qkv ([B*N, 3*H*64]; bf16, or fp32 when qkv_is_f32).  Tokens at even positions form set A (CLS = A[0], never
  * merged), odd positions set B.  Outputs (int32): src_idx [B,r] = the r A-tokens with the largest best-match score, in
@@ -155,6 +168,8 @@ int tr_tome_merge_layernorm(const float* x, const void* delta, int f32_path, con
 #define TR_FAMILY_TOME 3   /* keep[blk] = r requested for that block (tome.py:152-155); clamped per call to (N-1)/2 */
 #define TR_FAMILY_DYVIT 4  /* eval path of models/dyvit.py: predictor scores -> top-K -> gather BEFORE the block */
 #define TR_FAMILY_SIT 5    /* models/sit.py: soft token slimming BEFORE the block */
+#define TR_FAMILY_ATS 7    /* models/ats.py: inverse-CDF token sampling inside the attention; keep[blk] = sample_count K (static
+                              token bound of the block's output; padded rows are masked keys) */
 #define TR_FAMILY_DPCKNN 6 /* models/dpcknn.py: DPC-KNN clustering + weighted merge BEFORE the block; keep[blk] = clusters */
 #define TR_MAX_DEPTH 32
 #define TR_PREC_BF16 0   /* the product path: bf16 MFMA operands, fp32 accumulate / residual / statistics */
@@ -175,6 +190,7 @@ typedef struct {
  *     w2/b2 = out_conv.2 [D/4,D/2], w3/b3 = out_conv.4 [2,D/4] (fp32 in both precisions).
  *   SiT TokenSlimmingModule (sit.py:29-34): ln = weight.0 (eps 1e-5), w0/b0 = weight.1 [D/2,D], w1/b1 = weight.3 zero-padded
  *     to n_pad rows ([n_pad, D/2], n_pad = K rounded up to 8), scale = the module's scalar.
+ *   ATS (ats.py:48): w3 = sample_steps fp32 [n_pad], n_pad = their count (K-1).
  *   DPC-KNN CTM (dpcknn.py:150-151): w3/b3 = score.weight [1,D] / score.bias [1] (fp32); NULL = args.equal_weight. */
 typedef struct {
   const float* ln_g; const float* ln_b;
@@ -214,7 +230,7 @@ size_t tr_vit_workspace_bytes(const tr_vit_config* cfg, int B);
  * compl_idx (nullable, EViT): same slab shape, block blk writes [B,P_in-K_blk] at offset blk*B*(P+1)
  * (Fusion_Assign, evit.py:229).  soft_out (nullable, SiT): fp32, the stages' soft assignments [B,K,P_in] back to back in
  * block order (Soft_Assignment_Maps, sit.py:124).  DPC-KNN: kept_idx gets the centres [B,K] (Kept_Tokens), compl_idx the
- * assignment [B,P_in] (Assignment_Maps); noise_in (nullable): fp32, the stages' density noise [B,P_in] back to back in block
+ * assignment [B,P_in] (Assignment_Maps); ATS: kept_idx gets ids [B,K] (CLS id 0 first, 1-based token ids, 0 padding); noise_in (nullable): fp32, the stages' density noise [B,P_in] back to back in block
  * order (dpcknn.py:71-72; NULL = no noise).  tokens_out (nullable, HOST pointer, int[depth]): token count after each block. */
 int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits,
                    void* workspace, size_t workspace_bytes, int32_t* kept_idx, int32_t* compl_idx, float* soft_out,

@@ -462,3 +462,62 @@ def test_cluster_merge_layernorm(ops, f32, weighted, B, N, K, D):
         torch.testing.assert_close(y.cpu(), yw, atol=2e-5, rtol=2e-5)
     else:
         torch.testing.assert_close(y.float().cpu(), yw, atol=2 * BF16_ULP, rtol=BF16_ULP)
+
+
+# ---------------------------------------------------------------------------------------- ATS
+@pytest.mark.parametrize("B,N,H", [(2, 197, 6), (3, 138, 2), (1, 40, 3)])
+def test_attention_key_mask(ops, B, N, H):
+    """ats.py:117-120: masked keys get exactly zero weight (mask passed as the 1/0 `size` of the attention kernels)."""
+    rng = _rng(800 + N)
+    qkv = _bf(_randn(rng, B * N, 3 * H * 64, scale=1.5))
+    mask = torch.ones(B, N)
+    for b in range(B):
+        mask[b, N - 1 - rng.integers(3, N // 2):] = 0
+    q, k, v = qkv.double().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    dots = (q @ k.transpose(-2, -1)) * 0.125
+    dots = dots.masked_fill(~(mask.bool()[:, None, None, :]), -torch.finfo(torch.float32).max)
+    attn = dots.softmax(-1)
+    want = (attn @ v).transpose(1, 2).reshape(B * N, H * 64).float()
+    got, cls = ops.attention(qkv.bfloat16().cuda(), B, N, H, want_cls=True, size=mask.cuda())
+    torch.testing.assert_close(got.float().cpu(), want, atol=3e-2, rtol=2e-2)
+    assert (cls.cpu()[mask[:, None, :].expand(B, H, N) == 0] == 0).all()           # exactly zero, like the underflowing softmax
+    got32, cls32 = ops.attention_f32(qkv.cuda(), B, N, H, want_cls=True, size=mask.cuda())
+    torch.testing.assert_close(got32.cpu(), want, atol=2e-5, rtol=2e-5)
+    torch.testing.assert_close(cls32.cpu(), attn[:, :, 0, :].float(), atol=1e-7, rtol=2e-5)
+
+
+@pytest.mark.parametrize("f32", [False, True])
+@pytest.mark.parametrize("B,N,H,K,masked", [(3, 197, 6, 138, False), (2, 138, 6, 97, True), (2, 97, 2, 68, True), (2, 40, 3, 11, False)])
+def test_ats_sample(ops, f32, B, N, H, K, masked):
+    from tests._params import assert_valid_sampling
+    rng = _rng(900 + N + K)
+    qkv = _randn(rng, B * N, 3 * H * 64)
+    if not f32:
+        qkv = _bf(qkv)
+    mask = torch.ones(B, N)
+    if masked:
+        for b in range(B):
+            mask[b, N - rng.integers(2, N // 3):] = 0
+    cls = torch.softmax(_randn(rng, B, H, N, scale=2.0).masked_fill(mask[:, None, :] == 0, -1e30), dim=-1)
+    v = qkv.reshape(B, N, 3, H, 64)[:, :, 2].permute(0, 2, 1, 3)
+    steps = oracle.ats_sample_steps(K)
+    cdf = oracle.ats_cdf(oracle.ats_scores(cls, v), mask.bool())
+    ids, new_mask, cdf_dev = ops.ats_sample(cls.cuda(), (qkv if f32 else qkv.bfloat16()).cuda(), mask.cuda() if masked else None,
+                                            steps.cuda(), K, want_cdf=True)
+    ids, cdf_dev = ids.cpu().long(), cdf_dev.cpu()
+    torch.testing.assert_close(cdf_dev, cdf, atol=2e-6, rtol=0)
+    # the sampling decision on the device's own cdf: torch's cdist/argmin/unique give the same ids, bit exact
+    want, want_mask = oracle.ats_ids_from_cdf(cdf_dev, steps, pad_to=K)
+    np.testing.assert_array_equal(ids.numpy(), want.numpy())
+    np.testing.assert_array_equal(new_mask.cpu().numpy(), want_mask.float().numpy())
+    assert_valid_sampling((ids[:, 1:] - 1).numpy(), cdf.numpy(), steps.numpy(), tol=5e-4)
+
+
+def test_ats_gather(ops):
+    rng = _rng(77)
+    B, N, K, D = 3, 50, 20, 128
+    x, ao = _randn(rng, B, N, D), _bf(_randn(rng, B * N, D))
+    ids = torch.from_numpy(np.stack([np.concatenate([[0], np.sort(rng.permutation(N - 1)[:K - 4] + 1), [0, 0, 0]]) for _ in range(B)]))
+    xo, ao2 = ops.ats_gather(x.cuda(), ao.bfloat16().cuda(), ids.int().cuda())
+    assert torch.equal(xo.cpu(), torch.gather(x, 1, ids[:, :, None].expand(B, K, D)))
+    assert torch.equal(ao2.float().cpu().reshape(B, K, D), torch.gather(ao.reshape(B, N, D), 1, ids[:, :, None].expand(B, K, D)))

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libtokenreduction_hip.so")
 TR_MAX_DEPTH = 32
 TR_EPI_BF16, TR_EPI_GELU_BF16, TR_EPI_RESID_F32, TR_EPI_F32, TR_EPI_PATCH_F32 = 0, 1, 2, 3, 4
 TR_FAMILY_DEIT, TR_FAMILY_TOPK, TR_FAMILY_EVIT, TR_FAMILY_TOME, TR_FAMILY_DYVIT, TR_FAMILY_SIT, \
-    TR_FAMILY_DPCKNN = 0, 1, 2, 3, 4, 5, 6
+    TR_FAMILY_DPCKNN, TR_FAMILY_ATS = 0, 1, 2, 3, 4, 5, 6, 7
 TR_PREC_BF16, TR_PREC_FP32 = 0, 1
 
 _vp, _i, _f, _l, _sz = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t
@@ -63,6 +63,8 @@ SIGNATURES = {
     "tr_pool_broadcast": (_i, [_vp, _i, _i, _i, _i, _f, _vp]),
     "tr_dyvit_score": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "tr_sit_merge": (_i, [_vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "tr_ats_sample": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "tr_ats_gather": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tr_dpcknn_workspace_floats": (_sz, [_i, _i]),
     "tr_dpcknn_cluster": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tr_cluster_merge_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),

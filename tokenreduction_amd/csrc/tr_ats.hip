@@ -1,0 +1,182 @@
+// Adaptive Token Sampling (models/ats.py) on gfx950.
+//
+//   tr_ats_sample   AdaptiveTokenSampling.forward ats.py:52-84 for one block: significance score = sum_h cls_attn_h * |v_h|
+//                   over the patch tokens, normalised; running sum (cdf), +0.1 on masked positions; for every point of the
+//                   inverse-CDF grid the nearest cdf entry; per-image sorted unique; CLS id 0 in front.  The reference pads
+//                   to the batch maximum (data dependent shape, ats.py:78); here every image is padded with id 0 to the static
+//                   bound K -- padded rows are masked keys with exactly zero softmax weight, so valid rows are unchanged.
+//                   One workgroup per image; everything after the |v| pass lives in LDS.
+//   tr_ats_gather   x = batched_index_select(x, ids) (ats.py:157) and new_attn @ v = rows `ids` of attn @ v (ats.py:86,129):
+//                   row gather of the fp32 residual stream and of the attention output.
+// The nearest-entry search mirrors torch.cdist's matmul form (|a|^2 + |b|^2 - 2ab as a 3-term dot product, clamp 1e-30, sqrt):
+// its fp32 rounding -- not the exact |a - b| -- decides among candidates closer than ~3e-4 to a grid point.
+#include "tr_common.h"
+
+namespace {
+
+constexpr int ATS_MAX_P = 1024;
+
+template <bool F32>
+__global__ __launch_bounds__(256) void ats_sample_kernel(const float* __restrict__ cls_rows, const void* __restrict__ qkv,
+                                                         const float* __restrict__ mask, const float* __restrict__ steps,
+                                                         int n_steps, int32_t* __restrict__ ids, float* __restrict__ new_mask,
+                                                         float* __restrict__ cdf_out, int N, int H, int K, float eps) {
+  __shared__ float s_sig[ATS_MAX_P];
+  __shared__ float s_cdf[ATS_MAX_P];
+  __shared__ int s_flag[ATS_MAX_P + 1];
+  __shared__ float s_total;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int P = N - 1;
+  const int ldq = 3 * H * 64;
+  // sig[p] = sum_h attn[b,h,0,1+p] * ||v[b,h,1+p,:]||_2     (heads summed in order, ats.py:58-63)
+  for (int p = tid; p < P; p += 256) {
+    float sig = 0.f;
+    for (int h = 0; h < H; ++h) {
+      const size_t e0 = ((size_t)b * N + 1 + p) * ldq + 2 * H * 64 + h * 64;
+      float ss = 0.f;
+      if (F32) {
+        const float4* vp = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(qkv) + e0);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const float4 u = vp[c];
+          ss = fmaf(u.x, u.x, ss); ss = fmaf(u.y, u.y, ss); ss = fmaf(u.z, u.z, ss); ss = fmaf(u.w, u.w, ss);
+        }
+      } else {
+        const uint4* vp = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(qkv) + e0);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const uint4 u = vp[c];
+          const unsigned int w4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float lo = __uint_as_float(w4[q] << 16), hi = __uint_as_float(w4[q] & 0xffff0000u);
+            ss = fmaf(lo, lo, ss);
+            ss = fmaf(hi, hi, ss);
+          }
+        }
+      }
+      sig += cls_rows[((size_t)b * H + h) * N + 1 + p] * sqrtf(ss);
+    }
+    s_sig[p] = sig;
+    s_flag[p + 1] = 0;
+  }
+  if (tid == 0) s_flag[0] = 0;
+  __syncthreads();
+  if (tid < 64) {                                    // sig.sum(-1)
+    float t = 0.f;
+    for (int p = tid; p < P; p += 64) t += s_sig[p];
+    t = wave_sum(t);
+    if (tid == 0) s_total = t + eps;
+  }
+  __syncthreads();
+  const float denom = s_total;
+  if (tid == 0) {                                    // cumsum in token order, then +0.1 on masked positions (ats.py:69-70)
+    float run = 0.f;
+    for (int p = 0; p < P; ++p) {
+      run += s_sig[p] / denom;
+      s_cdf[p] = run;
+    }
+  }
+  __syncthreads();
+  for (int p = tid; p < P; p += 256) {
+    float c = s_cdf[p];
+    if (mask != nullptr && mask[(size_t)b * N + 1 + p] == 0.f) c += 0.1f;
+    s_cdf[p] = c;
+    if (cdf_out != nullptr) cdf_out[(size_t)b * P + p] = c;
+  }
+  __syncthreads();
+  // nearest cdf entry per grid point; torch.cdist matmul form: [-2s, s^2, 1] . [c, 1, c^2], clamp_min(1e-30), sqrt; argmin
+  // keeps the first minimum
+  for (int t = tid; t < n_steps; t += 256) {
+    const float s = steps[t];
+    const float a0 = -2.0f * s, a1 = __fmul_rn(s, s);
+    float best = INFINITY;
+    int arg = 0;
+    for (int p = 0; p < P; ++p) {
+      const float c = s_cdf[p];
+      // k = 0,1,2 of the 3-term dot product, each product/sum rounded once (no contraction: c^2 is a rounded operand)
+      float r = __fmul_rn(a0, c);
+      r = __fadd_rn(r, a1);
+      r = __fadd_rn(r, __fmul_rn(c, c));
+      const float d = sqrtf(fmaxf(r, 1e-30f));
+      if (d < best) { best = d; arg = p; }
+    }
+    s_flag[arg + 1] = 1;                             // sampled_token_ids = argmin + 1
+  }
+  __syncthreads();
+  // sorted unique ids, CLS id 0 in front, zero padding to K; new_mask = ids != 0 (CLS True)   (ats.py:77-84)
+  for (int t = tid; t < K; t += 256) {
+    ids[(size_t)b * K + t] = 0;
+    new_mask[(size_t)b * K + t] = t == 0 ? 1.f : 0.f;
+  }
+  __syncthreads();
+  for (int p = tid; p < P; p += 256) {
+    if (!s_flag[p + 1]) continue;
+    int pos = 1;
+    for (int q = 0; q < p; ++q) pos += s_flag[q + 1];
+    if (pos < K) {
+      ids[(size_t)b * K + pos] = p + 1;
+      new_mask[(size_t)b * K + pos] = 1.f;
+    }
+  }
+}
+
+// one wave per output row
+template <bool F32>
+__global__ __launch_bounds__(256) void ats_gather_kernel(const float* __restrict__ x, const void* __restrict__ ao,
+                                                         const int32_t* __restrict__ ids, float* __restrict__ x_out,
+                                                         void* __restrict__ ao_out, int B, int N, int K, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B * K) return;
+  const int b = row / K;
+  const size_t src = (size_t)b * N + ids[row];
+  const float4* xs = reinterpret_cast<const float4*>(x + src * D);
+  float4* xd = reinterpret_cast<float4*>(x_out + (size_t)row * D);
+  for (int c = lane; c < D / 4; c += 64) xd[c] = xs[c];
+  if (F32) {
+    const float4* as = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(ao) + src * D);
+    float4* ad = reinterpret_cast<float4*>(reinterpret_cast<float*>(ao_out) + (size_t)row * D);
+    for (int c = lane; c < D / 4; c += 64) ad[c] = as[c];
+  } else {
+    const uint4* as = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(ao) + src * D);
+    uint4* ad = reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(ao_out) + (size_t)row * D);
+    for (int c = lane; c < D / 8; c += 64) ad[c] = as[c];
+  }
+}
+
+}  // namespace
+
+extern "C" int tr_ats_sample(const float* cls_rows, const void* qkv, int qkv_is_f32, const float* mask, const float* steps,
+                             int n_steps, int32_t* ids, float* new_mask, float* cdf_out, int B, int N, int H, int K,
+                             tr_stream_t s) {
+  TR_REQUIRE(cls_rows && qkv && steps && ids && new_mask, TR_ERR_NULL, "tr_ats_sample: null pointer");
+  TR_REQUIRE(B > 0 && H > 0 && N >= 2 && N - 1 <= ATS_MAX_P, TR_ERR_SHAPE, "tr_ats_sample: need 2 <= N <= %d (N=%d)", ATS_MAX_P + 1, N);
+  TR_REQUIRE(K >= 2 && n_steps >= 1 && n_steps <= K - 1, TR_ERR_SHAPE,
+             "tr_ats_sample: %d grid points cannot exceed K-1 = %d (at most one new token per point, ats.py:48)", n_steps, K - 1);
+  TR_REQUIRE(tr_aligned16(qkv), TR_ERR_ALIGN, "tr_ats_sample: qkv must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(s);
+  if (qkv_is_f32)
+    hipLaunchKernelGGL(ats_sample_kernel<true>, dim3(B), dim3(256), 0, st, cls_rows, qkv, mask, steps, n_steps, ids, new_mask, cdf_out, N,
+                       H, K, 1e-6f);
+  else
+    hipLaunchKernelGGL(ats_sample_kernel<false>, dim3(B), dim3(256), 0, st, cls_rows, qkv, mask, steps, n_steps, ids, new_mask, cdf_out,
+                       N, H, K, 1e-6f);
+  TR_CHECK_LAUNCH("tr_ats_sample");
+  return TR_OK;
+}
+
+extern "C" int tr_ats_gather(const float* x, const void* ao, int ao_is_f32, const int32_t* ids, float* x_out, void* ao_out, int B,
+                             int N, int K, int D, tr_stream_t s) {
+  TR_REQUIRE(x && ao && ids && x_out && ao_out, TR_ERR_NULL, "tr_ats_gather: null pointer");
+  TR_REQUIRE(B > 0 && N >= 1 && K >= 1 && D > 0 && D % 8 == 0, TR_ERR_SHAPE, "tr_ats_gather: bad shape B=%d N=%d K=%d D=%d", B, N, K, D);
+  TR_REQUIRE(x_out != x && ao_out != ao, TR_ERR_SHAPE, "tr_ats_gather: needs distinct outputs");
+  TR_REQUIRE(tr_aligned16(x) && tr_aligned16(ao) && tr_aligned16(x_out) && tr_aligned16(ao_out), TR_ERR_ALIGN,
+             "tr_ats_gather: pointers must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(s);
+  const int nblocks = (B * K + 3) / 4;
+  if (ao_is_f32) hipLaunchKernelGGL(ats_gather_kernel<true>, dim3(nblocks), dim3(256), 0, st, x, ao, ids, x_out, ao_out, B, N, K, D);
+  else hipLaunchKernelGGL(ats_gather_kernel<false>, dim3(nblocks), dim3(256), 0, st, x, ao, ids, x_out, ao_out, B, N, K, D);
+  TR_CHECK_LAUNCH("tr_ats_gather");
+  return TR_OK;
+}

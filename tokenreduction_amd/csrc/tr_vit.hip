@@ -40,7 +40,7 @@ bool make_plan(const tr_vit_config* c, int B, Plan* p) {
   if (c->patch <= 0 || c->img_size <= 0 || c->img_size % c->patch != 0) return false;
   if (c->depth <= 0 || c->depth > TR_MAX_DEPTH) return false;
   if (c->num_heads <= 0 || c->embed_dim != c->num_heads * 64) return false;
-  if (c->family < TR_FAMILY_DEIT || c->family > TR_FAMILY_DPCKNN) return false;
+  if (c->family < TR_FAMILY_DEIT || c->family > TR_FAMILY_ATS) return false;
   const int g = c->img_size / c->patch;
   p->P = g * g;
   p->N0 = p->P + 1;
@@ -212,6 +212,8 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
       float* t = x; x = x_alt; x_alt = t;
       N = Kc + 1;
     }
+    const bool ats = cfg->family == TR_FAMILY_ATS;
+    const int Ks = ats ? cfg->keep[i] : 0;      // ATS sample_count of this block (0 = plain block)
     const bool in_block = cfg->family == TR_FAMILY_TOPK || cfg->family == TR_FAMILY_EVIT;
     int K = in_block ? cfg->keep[i] : 0;
     TR_REQUIRE(K >= 0 && K <= N - 1, TR_ERR_CONFIG, "tr_vit_forward: block %d keeps %d of %d patch tokens", i, K, N - 1);
@@ -225,9 +227,26 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
     // x (+= previous mlp output); attn(norm1(x)) -> dbuf   [x + dbuf is the reference's post-attention x, topk.py:87]
     if (!have_xn) TR_TRY(op_ln(f32, x, D, pending, D, bw->ln1_g, bw->ln1_b, xn, M, D, cfg->ln_eps, s));
     TR_TRY(op_gemm(f32, xn, bw->qkv_w, bw->qkv_b, qkv, nullptr, 0, M, 3 * D, D, TR_EPI_BF16, s));
-    TR_TRY(op_attn(f32, qkv, ao, K > 0 ? cls_rows : nullptr, tome ? size_cur : nullptr, B, N, H, s));
-    TR_TRY(op_gemm(f32, ao, bw->proj_w, bw->proj_b, dbuf, nullptr, 0, M, D, D, TR_EPI_BF16, s));
+    // ToMe: log(size) bias on the keys; ATS: key mask as a 1/0 "size" (log 0 = -inf -> exactly zero weight, like
+    // masked_fill(-finfo.max) underflowing in the reference's softmax, ats.py:117-120)
+    TR_TRY(op_attn(f32, qkv, ao, (K > 0 || Ks > 0) ? cls_rows : nullptr, (tome || ats) ? size_cur : nullptr, B, N, H, s));
     int Nn = N;
+    if (Ks > 0) {
+      // a16-a18: sample token ids on the CLS attention x |v|, keep those rows of x and of attn @ v
+      const tr_stage_weights* sw = &w->stage[i];
+      TR_REQUIRE(Ks >= 2 && Ks <= N, TR_ERR_CONFIG, "tr_vit_forward: block %d ATS sample_count %d out of range for %d tokens", i, Ks, N);
+      TR_REQUIRE(sw->w3 && sw->n_pad >= 1, TR_ERR_NULL, "tr_vit_forward: block %d has no ATS sample grid (tr_vit_weights.stage)", i);
+      int32_t* ids = kept_idx ? kept_idx + (size_t)i * B * p.N0 : idx_ws;
+      float* mask_next = (size_cur == size_a) ? size_b : size_a;
+      TR_TRY(tr_ats_sample(cls_rows, qkv, f32 ? 1 : 0, size_cur, sw->w3, sw->n_pad, ids, mask_next, nullptr, B, N, H, Ks, s));
+      TR_TRY(tr_ats_gather(x, ao, f32 ? 1 : 0, ids, x_alt, xn, B, N, Ks, D, s));
+      float* t = x; x = x_alt; x_alt = t;
+      size_cur = mask_next;
+      Nn = Ks;
+      TR_TRY(op_gemm(f32, xn, bw->proj_w, bw->proj_b, dbuf, nullptr, 0, B * Nn, D, D, TR_EPI_BF16, s));
+    } else {
+      TR_TRY(op_gemm(f32, ao, bw->proj_w, bw->proj_b, dbuf, nullptr, 0, M, D, D, TR_EPI_BF16, s));
+    }
     if (K > 0) {
       // Top-K on the CLS attention, then residual add + gather/compact (+ EViT fused token) + norm2 in one pass
       const bool fuse = cfg->family == TR_FAMILY_EVIT;
@@ -252,7 +271,7 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
       size_cur = size_next;
       Nn = N - r;
     } else {
-      TR_TRY(op_ln(f32, x, D, dbuf, D, bw->ln2_g, bw->ln2_b, xn, M, D, cfg->ln_eps, s));
+      TR_TRY(op_ln(f32, x, D, dbuf, D, bw->ln2_g, bw->ln2_b, xn, B * Nn, D, cfg->ln_eps, s));
     }
     N = Nn;
     const int M2 = B * N;

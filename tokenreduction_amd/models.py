@@ -637,3 +637,56 @@ class DPCKNNVisionTransformer(VisionTransformer):
             decisions[blk] = kept[blk * B * P1: blk * B * P1 + B * K].reshape(B, K).astype(np.int64)
             assignments[blk] = assign[blk * B * P1: blk * B * P1 + B * P].reshape(B, P).astype(np.int64)
         return {"Kept_Tokens": decisions, "Assignment_Maps": assignments, "Center_Feats": {}, "Features": {}}
+
+
+class ATSVisionTransformer(VisionTransformer):
+    """models/ats.py:166-271: blocks in reduction_loc sample tokens by inverse-transform sampling on the CLS attention weighted
+    by the value norms.  The reference's token count after such a block is data dependent (batch maximum of unique samples,
+    ats.py:78); here it is the static bound K = sample_count, the surplus rows being masked keys (zero attention weight), which
+    leaves every valid token and the logits unchanged.  Kept_Tokens is trimmed to the reference's batch-maximum width."""
+    _family = _lib.TR_FAMILY_ATS
+
+    def __init__(self, *a, args=None, **kw):
+        super().__init__(*a, args=args, **kw)
+        self.sample_loc = list(args.reduction_loc)
+        sample_count = list(args.keep_rate)
+        if len(sample_count) == 1:
+            sample_count = [int(args.keep_rate[0] ** (idx + 1) * self.patch_embed.num_patches) + 1
+                            for idx in range(len(self.sample_loc))]                                        # ats.py:204-205
+        assert len(sample_count) == len(self.sample_loc), \
+            f"Mismatch between the sample location ({self.sample_loc}) and sample centers ({sample_count})"
+        cnt = 0
+        self.sample_count = [0] * self.depth
+        for idx in range(self.depth):
+            if idx in self.sample_loc:
+                self.sample_count[idx] = int(sample_count[cnt])
+                cnt += 1
+        self._keep = list(self.sample_count)
+
+    def get_reduction_count(self):
+        return self.sample_loc
+
+    @staticmethod
+    def sample_steps(sample_count):
+        """ats.py:48, verbatim."""
+        return torch.arange(1 / (2 * sample_count), (2 * sample_count - 1) / (2 * sample_count), 2 / (2 * sample_count))
+
+    def _pack_stages(self, W, w16, f32, keep_alive):
+        for blk, K in enumerate(self.sample_count):
+            if K:
+                steps = self.sample_steps(K).to(self.pos_embed.device)
+                if steps.numel() > K - 1:
+                    raise ValueError(f"sample_count {K}: the grid has {steps.numel()} points, more than K-1")
+                W.stage[blk].w3 = f32(steps)
+                W.stage[blk].n_pad = steps.numel()
+
+    def _viz_data(self, ws, B, tokens):
+        P1 = self.patch_embed.num_patches + 1
+        kept = ws["kept"].cpu().numpy()
+        decisions = {}
+        for blk, K in enumerate(self.sample_count):
+            if K:
+                ids = kept[blk * B * P1: blk * B * P1 + B * K].reshape(B, K).astype(np.int64)
+                width = int((ids[:, 1:] != 0).sum(axis=1).max())                      # pad_sequence to the batch maximum, ats.py:78
+                decisions[blk] = ids[:, 1:1 + width] - 1                              # ats.py:253
+        return {"Kept_Tokens": decisions, "Features": {}}

@@ -246,3 +246,30 @@ def cluster_merge_layernorm(x: torch.Tensor, idx_cluster: torch.Tensor, K: int, 
         _dev(beta, torch.float32, "beta"), x_out.data_ptr(), y.data_ptr(), int(f32), B, N, K, D, eps, _stream()),
         "tr_cluster_merge_layernorm")
     return x_out, y
+
+
+# ---------------------------------------------------------------------------------------- ATS (models/ats.py)
+def ats_sample(cls_rows: torch.Tensor, qkv: torch.Tensor, mask, steps: torch.Tensor, K: int, want_cdf: bool = False):
+    """AdaptiveTokenSampling (ats.py:52-84): cls_rows fp32 [B,H,N], qkv bf16|fp32 [B*N, 3*H*64], mask fp32 [B,N] of 1/0 or None
+    -> (ids int32 [B,K] (CLS 0 first, 1-based ids, 0 padding), new_mask fp32 [B,K], cdf fp32 [B,N-1] | None)."""
+    B, H, N = cls_rows.shape
+    ids = torch.empty(B, K, dtype=torch.int32, device=qkv.device)
+    new_mask = torch.empty(B, K, dtype=torch.float32, device=qkv.device)
+    cdf = torch.empty(B, N - 1, dtype=torch.float32, device=qkv.device) if want_cdf else None
+    _lib.check(_lib.load().tr_ats_sample(_dev(cls_rows, torch.float32, "cls_rows"), _dev(qkv, qkv.dtype, "qkv"),
+                                         int(qkv.dtype == torch.float32), _opt(mask, torch.float32, "mask"),
+                                         _dev(steps, torch.float32, "steps"), steps.numel(), ids.data_ptr(), new_mask.data_ptr(),
+                                         None if cdf is None else cdf.data_ptr(), B, N, H, K, _stream()), "tr_ats_sample")
+    return ids, new_mask, cdf
+
+
+def ats_gather(x: torch.Tensor, ao: torch.Tensor, ids: torch.Tensor):
+    """x fp32 [B,N,D], ao bf16|fp32 [B*N, D], ids int32 [B,K] -> (x_out fp32 [B,K,D], ao_out [B*K, D]) rows ids (ats.py:86,157)."""
+    B, N, D = x.shape
+    K = ids.shape[1]
+    x_out = torch.empty(B, K, D, dtype=torch.float32, device=x.device)
+    ao_out = torch.empty(B * K, D, dtype=ao.dtype, device=x.device)
+    _lib.check(_lib.load().tr_ats_gather(_dev(x, torch.float32, "x"), _dev(ao, ao.dtype, "ao"), int(ao.dtype == torch.float32),
+                                         _dev(ids, torch.int32, "ids"), x_out.data_ptr(), ao_out.data_ptr(), B, N, K, D, _stream()),
+               "tr_ats_gather")
+    return x_out, ao_out

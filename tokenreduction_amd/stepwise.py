@@ -71,7 +71,7 @@ def _gemm(tr: Trace, a, w, b, epi, out=None, aux=None, aux_i=0, tag=""):
 
 
 @torch.no_grad()
-def forward_stepwise(model: VisionTransformer, x: torch.Tensor, trace: Optional[Trace] = None):
+def forward_stepwise(model: VisionTransformer, x: torch.Tensor, trace: Optional[Trace] = None, forced_ids: Optional[dict] = None):
     """Returns (logits, info) with info = dict(kept={blk: idx}, compl={blk: compl}, scores={blk: scores}, tokens=[...])."""
     tr = trace or Trace()
     pk = model._pack()
@@ -168,6 +168,7 @@ def forward_stepwise(model: VisionTransformer, x: torch.Tensor, trace: Optional[
                 N = Kc + 1
                 h = h3_.view(B * N, D)
         K = int(cfg.keep[i]) if cfg.family in (1, 2) else 0
+        Ks = int(cfg.keep[i]) if cfg.family == 7 else 0          # ATS sample_count
         if K == N - 1:
             K = 0
         r = min(int(cfg.keep[i]), (N - 1) // 2) if tome else 0
@@ -177,8 +178,22 @@ def forward_stepwise(model: VisionTransformer, x: torch.Tensor, trace: Optional[
                         lambda: ops.layernorm(h, f32(blk.norm1.weight), f32(blk.norm1.bias), eps, delta=pending))
         qkv = _gemm(tr, xn, bf(blk.attn.qkv.weight), f32(blk.attn.qkv.bias), ops.TR_EPI_BF16, tag="qkv")
         ao, cls_rows = tr.run("attention_kernel", 4.0 * B * H * N * N * 64, 2.0 * M * 4 * D,
-                              lambda: ops.attention(qkv, B, N, H, want_cls=K > 0, size=size))
+                              lambda: ops.attention(qkv, B, N, H, want_cls=K > 0 or Ks > 0, size=size))
         tr.save(f"attn_out_{i}", ao)
+        if Ks > 0:
+            # ATS: sample ids on CLS attention x |v|, keep those rows of x and of attn @ v (ats.py:52-89,157)
+            steps = model.sample_steps(Ks).to(dev)
+            ids, new_mask, cdf = tr.run("ats_sample_kernel", 0.0, 2.0 * M * D, lambda: ops.ats_sample(cls_rows, qkv, size, steps, Ks, want_cdf=tr.keep))
+            if forced_ids is not None and i in forced_ids:        # tests: teacher forcing (ids [B,Ks] incl. CLS 0 and 0 padding)
+                ids = forced_ids[i].to(device=dev, dtype=torch.int32).contiguous()
+                new_mask = (ids != 0).float()
+                new_mask[:, 0] = 1.0
+            info["kept"][i], info["compl"][i], info["scores"][i] = ids, None, cdf
+            h3_, ao = tr.run("ats_gather_kernel", 0.0, 12.0 * B * Ks * D, lambda: ops.ats_gather(h.view(B, N, D), ao, ids))
+            size = new_mask
+            N = Ks
+            M = B * N
+            h = h3_.view(M, D)
         d1 = _gemm(tr, ao, bf(blk.attn.proj.weight), f32(blk.attn.proj.bias), ops.TR_EPI_BF16, tag="d1")
         if K > 0:
             idx, compl, scores = tr.run("cls_topk_kernel", 0.0, 4.0 * B * (H * N + N),
