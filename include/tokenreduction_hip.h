@@ -109,12 +109,22 @@ int tr_gemm_f32(const float* A, const float* W, const float* bias, float* out, c
  * tr_dyvit_score: out_conv.4 + LogSoftmax + [:,:,0] (dyvit.py:108-109,231): h [M,C] -> scores fp32 [M]; w fp32 [2,C], bias [2].
  * tr_sit_merge: TokenSlimmingModule.forward sit.py:37-39: logits fp32 [B,N,ldl] (row 0 of an image = CLS, ignored; first K
  *   columns used), softmax(logits*scale) over the patch-token axis, x_out[b,1+k,:] = sum_p w[b,p,k] x[b,1+p,:]; x_out[b,0] =
- *   x[b,0]; x, x_out fp32 [B,N,D] / [B,K+1,D].  soft (nullable): fp32 [B,K,N-1]. */
+ *   x[b,0]; x, x_out fp32 [B,N,D] / [B,K+1,D].  soft (nullable): fp32 [B,K,N-1].
+ * tr_rownorm: F.normalize(x, dim=-1) (sinkhorn.py:70): x fp32 [M,D] -> xh fp32 [M,D] and the same rows as a GEMM operand
+ *   (bf16, fp32 when lp_is_f32).
+ * tr_sinkhorn: log_optimal_transport (sinkhorn.py:41-56) per image on scores fp32 [B,N,ldl] (row 0 = CLS ignored; columns
+ *   0..K-1 = token . centre): wt (may alias scores) gets the transport plan token-major [B,N,ldl], soft (nullable) the same
+ *   cluster-major [B,K,N-1] (Soft_Assignment_Maps).  K*(N-1) floats must fit LDS.
+ * tr_weighted_merge: x_out[b,1+k,:] = sum_p wt[b,1+p,k] * src[b,1+p,:]; x_out[b,0] = x[b,0]   (sinkhorn.py:83 with
+ *   src = unit-norm tokens). */
 int tr_pool_broadcast(void* h, int is_f32, int B, int N, int C, float eps, tr_stream_t s);
+int tr_rownorm(const float* x, float* xh, void* xh_lp, int lp_is_f32, int M, int D, tr_stream_t s);
+int tr_sinkhorn(const float* scores, int ldl, float eps, int iters, float* wt, float* soft, int B, int N, int K, tr_stream_t s);
+int tr_weighted_merge(const float* wt, int ldl, const float* x, const float* src, float* x_out, int B, int N, int K, int D,
+                      tr_stream_t s);
 int tr_dyvit_score(const void* h, int is_f32, const float* w, const float* bias, float* scores, int M, int C, tr_stream_t s);
 int tr_sit_merge(const float* logits, int ldl, float scale, const float* x, float* x_out, float* soft, int B, int N, int K,
                  int D, tr_stream_t s);
-
 /* ---- DPC-KNN (csrc/tr_cluster.hip) --------------------------------------------------------------------------------------
  * tr_dpcknn_cluster: cluster_dpc_knn dpcknn.py:44-100 (token_mask=None) on the patch rows of x fp32 [B,N,D] (row 0 = CLS,
  *   ignored): centers int32 [B,K] = topk(score, K) in descending-score order (index_down), idx_cluster int32 [B,N-1],
@@ -170,6 +180,7 @@ int tr_tome_merge_layernorm(const float* x, const void* delta, int f32_path, con
 #define TR_FAMILY_SIT 5    /* models/sit.py: soft token slimming BEFORE the block */
 #define TR_FAMILY_ATS 7    /* models/ats.py: inverse-CDF token sampling inside the attention; keep[blk] = sample_count K (static
                               token bound of the block's output; padded rows are masked keys) */
+#define TR_FAMILY_SINKHORN 8 /* models/sinkhorn.py: optimal-transport soft assignment to learned centres BEFORE the block */
 #define TR_FAMILY_DPCKNN 6 /* models/dpcknn.py: DPC-KNN clustering + weighted merge BEFORE the block; keep[blk] = clusters */
 #define TR_MAX_DEPTH 32
 #define TR_PREC_BF16 0   /* the product path: bf16 MFMA operands, fp32 accumulate / residual / statistics */
@@ -190,6 +201,7 @@ typedef struct {
  *     w2/b2 = out_conv.2 [D/4,D/2], w3/b3 = out_conv.4 [2,D/4] (fp32 in both precisions).
  *   SiT TokenSlimmingModule (sit.py:29-34): ln = weight.0 (eps 1e-5), w0/b0 = weight.1 [D/2,D], w1/b1 = weight.3 zero-padded
  *     to n_pad rows ([n_pad, D/2], n_pad = K rounded up to 8), scale = the module's scalar.
+ *   Sinkhorn (sinkhorn.py:62,73-76): w1 = F.normalize(v) zero-padded to n_pad rows [n_pad, D], b1 = zeros [n_pad].
  *   ATS (ats.py:48): w3 = sample_steps fp32 [n_pad], n_pad = their count (K-1).
  *   DPC-KNN CTM (dpcknn.py:150-151): w3/b3 = score.weight [1,D] / score.bias [1] (fp32); NULL = args.equal_weight. */
 typedef struct {
@@ -219,6 +231,8 @@ typedef struct {
                                  away; SiT: K output tokens of the slimming module */
   int precision;              /* TR_PREC_* */
   int knn_k;                  /* DPC-KNN: neighbours of the local density (args.k_neighbors, train.py:221 default 5) */
+  int cluster_iters;          /* Sinkhorn iterations (args.cluster_iters, train.py:232 default 3) */
+  float sinkhorn_eps;         /* Sinkhorn temperature (args.sinkhorn_eps, train.py:229 default 1.0) */
 } tr_vit_config;
 
 /* Bytes of workspace tr_vit_forward needs for batch B (0 on invalid config). */

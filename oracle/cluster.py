@@ -16,7 +16,9 @@ from typing import Dict, Optional
 
 import torch
 
-from .vit import VitConfig, block_forward, embed_tokens, head, patch_embed
+import torch.nn.functional as F
+
+from .vit import VitConfig, _r, block_forward, embed_tokens, head, patch_embed
 
 Tensor = torch.Tensor
 
@@ -112,6 +114,64 @@ def dpcknn_forward(params: Dict[str, Tensor], x: Tensor, cfg: VitConfig, noise: 
             viz["Kept_Tokens"][i] = centers.numpy()
             viz["Assignment_Maps"][i] = idx_cluster.numpy()
             viz["Scores"][i] = score
+            j += 1
+        h, _, _ = block_forward(h, p, i, cfg, None, precision)
+        viz["Tokens"][i] = h.shape[1]
+    logits = head(h, p["norm.weight"], p["norm.bias"], p["head.weight"], p["head.bias"], cfg.ln_eps, precision)
+    if return_viz:
+        viz["Final_Tokens"] = h
+        return logits, viz
+    return logits
+
+
+# =========================================================================================== Sinkhorn (models/sinkhorn.py)
+def sinkhorn_log_iterations(Z: Tensor, log_mu: Tensor, log_nu: Tensor, iters: int) -> Tensor:
+    """log_sinkhorn_iterations sinkhorn.py:25-38."""
+    u, v = torch.zeros_like(log_mu), torch.zeros_like(log_nu)
+    for _ in range(iters):
+        u = log_mu - torch.logsumexp(Z + v.unsqueeze(1), dim=2)
+        v = log_nu - torch.logsumexp(Z + u.unsqueeze(2), dim=1)
+    return Z + u.unsqueeze(2) + v.unsqueeze(1)
+
+
+def sinkhorn_transport(scores: Tensor, eps: float, iters: int) -> Tensor:
+    """log_optimal_transport sinkhorn.py:41-56: scores [B,K,P] -> transport plan [B,K,P] scaled by (K+P)."""
+    b, m, n = scores.shape
+    one = scores.new_tensor(1)
+    norm = -((m * one) + (n * one)).log()
+    log_mu = norm.expand(m)[None].expand(b, -1)
+    log_nu = norm.expand(n)[None].expand(b, -1)
+    Z = sinkhorn_log_iterations(scores / eps, log_mu, log_nu, iters)
+    return (Z - norm).exp()
+
+
+def sinkhorn_layer(x_sp: Tensor, centers: Tensor, eps: float, iters: int, precision: str = "fp32"):
+    """Sinkhorn.forward sinkhorn.py:66-86: unit-norm tokens against unit-norm centres, Sinkhorn-normalised soft assignment,
+    output = assignment-weighted sum of the NORMALISED tokens.  Returns (x [B,K,D], soft [B,K,P])."""
+    xh = F.normalize(x_sp, p=2, dim=-1)
+    w = F.normalize(centers, p=2, dim=-1)
+    scores = torch.bmm(_r(xh, precision), _r(w, precision)[None].expand(x_sp.shape[0], -1, -1).transpose(1, 2))
+    weights = sinkhorn_transport(scores.transpose(1, 2), eps, iters).transpose(1, 2)
+    out = torch.bmm(xh.transpose(1, 2), weights).transpose(1, 2)
+    return out, weights.transpose(1, 2)
+
+
+@torch.no_grad()
+def sinkhorn_forward(params: Dict[str, Tensor], x: Tensor, cfg: VitConfig, precision: str = "fp32", return_viz: bool = False,
+                     eps: float = 1.0, iters: int = 3):
+    """SinkhornVisionTransformer.forward sinkhorn.py:147-200, eval mode (cluster counts as sit/dpcknn: sinkhorn.py:128-129)."""
+    p = params
+    tok = patch_embed(x, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], cfg.patch_size, precision)
+    h = embed_tokens(tok, p["cls_token"], p["pos_embed"])
+    counts = dpcknn_cluster_counts(cfg)
+    viz = {"Assignment_Maps": {}, "Soft_Assignment_Maps": {}, "Tokens": {}}
+    j = 0
+    for i in range(cfg.depth):
+        if i in counts:
+            xs, soft = sinkhorn_layer(h[:, 1:], p[f"cluster_layers.{j}.v"], eps, iters, precision)
+            h = torch.cat([h[:, :1], xs], dim=1)
+            viz["Soft_Assignment_Maps"][i] = soft.numpy()
+            viz["Assignment_Maps"][i] = torch.argmax(soft, dim=-2).numpy()            # sinkhorn.py:173
             j += 1
         h, _, _ = block_forward(h, p, i, cfg, None, precision)
         viz["Tokens"][i] = h.shape[1]

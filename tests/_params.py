@@ -70,6 +70,11 @@ def make_stage_params(cfg, case: dict):
         for j in range(n_stages):
             p[f"cluster_layers.{j}.score.weight"] = _normal(rng, (1, D), 0.05)
             p[f"cluster_layers.{j}.score.bias"] = _normal(rng, (1,), 0.02)
+    elif fam == "sinkhorn":
+        from oracle.cluster import dpcknn_cluster_counts
+        counts = dpcknn_cluster_counts(cfg)
+        for j, loc in enumerate(case["reduction_loc"]):
+            p[f"cluster_layers.{j}.v"] = _normal(rng, (counts[loc], D), 1.0)          # sinkhorn.py:62 randn
     elif fam == "sit":
         from oracle.prune_before import sit_cluster_counts
         counts = sit_cluster_counts(cfg)
@@ -146,6 +151,12 @@ GOLDEN_CASES = {
     "ats_small_kr05": dict(family="ats", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
                            keep_rate=[0.5], reduction_loc=[3, 6, 9], batch=3, wseed=135, xseed=136,
                            qkv_gain=4.0, factory="ats_small_patch16_224"),
+    # Sinkhorn (models/sinkhorn.py): optimal-transport soft assignment to learned centres BEFORE the block
+    "sinkhorn_micro": dict(family="sinkhorn", embed_dim=128, depth=4, num_heads=2, num_classes=16,
+                           keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=141, xseed=142, qkv_gain=6.0),
+    "sinkhorn_small_kr07": dict(family="sinkhorn", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
+                                keep_rate=[0.7], reduction_loc=[3, 6, 9], batch=2, wseed=143, xseed=144,
+                                qkv_gain=4.0, factory="sinkhorn_small_patch16_224"),
     # SiT (models/sit.py): soft assignment (softmax over tokens) BEFORE the block
     "sit_micro": dict(family="sit", embed_dim=128, depth=4, num_heads=2, num_classes=16,
                       keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=111, xseed=112, qkv_gain=6.0),

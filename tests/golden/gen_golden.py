@@ -43,11 +43,12 @@ from models.dyvit import DynamicVisionTransformer  # noqa: E402
 from models.sit import SelfSlimmedVisionTransformer  # noqa: E402
 from models.dpcknn import DPCKNNVisionTransformer  # noqa: E402
 from models.ats import ATSVisionTransformer  # noqa: E402
+from models.sinkhorn import SinkhornVisionTransformer  # noqa: E402
 
 from tests._params import GOLDEN_CASES, make_params, make_stage_params, make_images, case_config  # noqa: E402
 
 CLASSES = {"topk": TopKVisionTransformer, "evit": EfficientVisionTransformer, "deit": DeitViz, "tome": ToMeVisionTransformer,
-           "dyvit": DynamicVisionTransformer, "sit": SelfSlimmedVisionTransformer, "dpcknn": DPCKNNVisionTransformer, "ats": ATSVisionTransformer}
+           "dyvit": DynamicVisionTransformer, "sit": SelfSlimmedVisionTransformer, "dpcknn": DPCKNNVisionTransformer, "ats": ATSVisionTransformer, "sinkhorn": SinkhornVisionTransformer}
 
 
 class TopkSpy:
@@ -138,7 +139,7 @@ class RandSpy:
 def build_reference(case):
     args = types.SimpleNamespace(keep_rate=list(case["keep_rate"]), reduction_loc=list(case["reduction_loc"]),
                                  viz_mode=True, dyvit_distill=False, k_neighbors=5,
-                                 equal_weight=bool(case.get("equal_weight", False)))
+                                 equal_weight=bool(case.get("equal_weight", False)), sinkhorn_eps=1.0, cluster_iters=3)
     with contextlib.redirect_stdout(io.StringIO()):
         if "factory" in case:
             m = create_model(case["factory"], pretrained=False, num_classes=case["num_classes"], drop_rate=0.0,

@@ -521,3 +521,34 @@ def test_ats_gather(ops):
     xo, ao2 = ops.ats_gather(x.cuda(), ao.bfloat16().cuda(), ids.int().cuda())
     assert torch.equal(xo.cpu(), torch.gather(x, 1, ids[:, :, None].expand(B, K, D)))
     assert torch.equal(ao2.float().cpu().reshape(B, K, D), torch.gather(ao.reshape(B, N, D), 1, ids[:, :, None].expand(B, K, D)))
+
+
+# ---------------------------------------------------------------------------------------- Sinkhorn
+def test_rownorm(ops):
+    rng = _rng(31)
+    x = _randn(rng, 300, 384) * 3
+    x[5] = 0                                                     # F.normalize clamps the norm at 1e-12: zero row stays zero
+    want = torch.nn.functional.normalize(x, p=2, dim=-1)
+    xh, lp = ops.rownorm(x.cuda())
+    torch.testing.assert_close(xh.cpu(), want, atol=1e-7, rtol=2e-6)
+    torch.testing.assert_close(lp.float().cpu(), want, atol=1e-7, rtol=BF16_ULP)
+
+
+@pytest.mark.parametrize("B,N,K,ldl,iters", [(3, 197, 137, 144, 3), (2, 138, 96, 96, 3), (2, 97, 67, 72, 5), (1, 9, 3, 8, 1), (1, 30, 7, 8, 0)])
+def test_sinkhorn(ops, B, N, K, ldl, iters):
+    rng = _rng(40 + N)
+    scores = _randn(rng, B, N, ldl, scale=0.5).clamp(-1, 1)
+    want = oracle.sinkhorn_transport(scores[:, 1:, :K].transpose(1, 2).contiguous(), 0.7, iters)      # [B,K,P]
+    wt, soft = ops.sinkhorn(scores.cuda(), K, 0.7, iters, want_soft=True)
+    torch.testing.assert_close(soft.cpu(), want, atol=1e-6, rtol=2e-5)
+    torch.testing.assert_close(wt.cpu()[:, 1:, :K], want.transpose(1, 2), atol=1e-6, rtol=2e-5)
+
+
+@pytest.mark.parametrize("B,N,K,D,ldl", [(3, 197, 137, 384, 144), (2, 97, 67, 768, 72), (1, 9, 3, 64, 8)])
+def test_weighted_merge(ops, B, N, K, D, ldl):
+    rng = _rng(50 + N)
+    wt = torch.from_numpy(rng.random((B, N, ldl)).astype(np.float32))
+    x, src = _randn(rng, B, N, D), _randn(rng, B, N, D)
+    want = torch.cat([x[:, :1].double(), torch.bmm(wt[:, 1:, :K].double().transpose(1, 2), src[:, 1:].double())], dim=1).float()
+    got = ops.weighted_merge(wt.cuda(), x.cuda(), src.cuda(), K)
+    torch.testing.assert_close(got.cpu(), want, atol=5e-5, rtol=2e-5)

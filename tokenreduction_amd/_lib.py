@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libtokenreduction_hip.so")
 TR_MAX_DEPTH = 32
 TR_EPI_BF16, TR_EPI_GELU_BF16, TR_EPI_RESID_F32, TR_EPI_F32, TR_EPI_PATCH_F32 = 0, 1, 2, 3, 4
 TR_FAMILY_DEIT, TR_FAMILY_TOPK, TR_FAMILY_EVIT, TR_FAMILY_TOME, TR_FAMILY_DYVIT, TR_FAMILY_SIT, \
-    TR_FAMILY_DPCKNN, TR_FAMILY_ATS = 0, 1, 2, 3, 4, 5, 6, 7
+    TR_FAMILY_DPCKNN, TR_FAMILY_ATS, TR_FAMILY_SINKHORN = 0, 1, 2, 3, 4, 5, 6, 7, 8
 TR_PREC_BF16, TR_PREC_FP32 = 0, 1
 
 _vp, _i, _f, _l, _sz = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t
@@ -38,7 +38,7 @@ class TrVitWeights(C.Structure):
 class TrVitConfig(C.Structure):
     _fields_ = [("family", _i), ("img_size", _i), ("patch", _i), ("in_chans", _i), ("embed_dim", _i),
                 ("depth", _i), ("num_heads", _i), ("mlp_hidden", _i), ("num_classes", _i), ("ln_eps", _f),
-                ("keep", _i * TR_MAX_DEPTH), ("precision", _i), ("knn_k", _i)]
+                ("keep", _i * TR_MAX_DEPTH), ("precision", _i), ("knn_k", _i), ("cluster_iters", _i), ("sinkhorn_eps", _f)]
 
 
 # every symbol include/tokenreduction_hip.h declares: name -> (restype, argtypes)
@@ -63,6 +63,9 @@ SIGNATURES = {
     "tr_pool_broadcast": (_i, [_vp, _i, _i, _i, _i, _f, _vp]),
     "tr_dyvit_score": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "tr_sit_merge": (_i, [_vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "tr_rownorm": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "tr_sinkhorn": (_i, [_vp, _i, _f, _i, _vp, _vp, _i, _i, _i, _vp]),
+    "tr_weighted_merge": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tr_ats_sample": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tr_ats_gather": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tr_dpcknn_workspace_floats": (_sz, [_i, _i]),

@@ -72,10 +72,12 @@ constexpr int SKC = 32;    // clusters per workgroup
 constexpr int SJ_MAX = 4;  // D columns per thread (D <= 1024)
 
 // grid (ceil(K/32), B), 256 threads, SJ = ceil(D/256) columns per thread.  Dynamic LDS: w[P][SKC] fp32.
-template <int SJ>
+// SOFTMAX (SiT): w = softmax over tokens of logits*scale.  !SOFTMAX (Sinkhorn): `logits` already holds the weights [B,N,ldl].
+// src = the rows that are summed (x for SiT, the unit-norm tokens for Sinkhorn); the CLS row always comes from x.
+template <int SJ, bool SOFTMAX>
 __global__ __launch_bounds__(256) void sit_merge_kernel(const float* __restrict__ logits, int ldl, float scale,
-                                                        const float* __restrict__ x, float* __restrict__ x_out,
-                                                        float* __restrict__ soft, int N, int K, int D) {
+                                                        const float* __restrict__ x, const float* __restrict__ src,
+                                                        float* __restrict__ x_out, float* __restrict__ soft, int N, int K, int D) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];     // [P][SKC]
   __shared__ float s_red[8][SKC];
   __shared__ float s_max[SKC], s_inv[SKC];
@@ -92,6 +94,7 @@ __global__ __launch_bounds__(256) void sit_merge_kernel(const float* __restrict_
     s_w[p * SKC + kk] = v;
     mx = fmaxf(mx, v);
   }
+  if (SOFTMAX) {
   s_red[pg][kk] = mx;
   __syncthreads();
   if (tid < SKC) {
@@ -119,6 +122,7 @@ __global__ __launch_bounds__(256) void sit_merge_kernel(const float* __restrict_
   __syncthreads();
   const float inv = s_inv[kk];
   for (int p = pg; p < P; p += 8) s_w[p * SKC + kk] *= inv;
+  }
   __syncthreads();
   if (soft != nullptr)                                            // [B,K,P], lanes along p
     for (int e = tid; e < SKC * P; e += 256) {
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(256) void sit_merge_kernel(const float* __restrict_
   for (int j = 0; j < SJ; ++j)
 #pragma unroll
     for (int k = 0; k < SKC; ++k) acc[j][k] = 0.f;
-  const float* xb = x + ((size_t)b * N + 1) * D;
+  const float* xb = src + ((size_t)b * N + 1) * D;
   for (int p = 0; p < P; ++p) {
     float xv[SJ];
 #pragma unroll
@@ -158,6 +162,84 @@ __global__ __launch_bounds__(256) void sit_merge_kernel(const float* __restrict_
         if (k0 + k < K) ob[(size_t)k * D + d] = acc[j][k];
       if (blockIdx.x == 0) x_out[(size_t)b * (K + 1) * D + d] = x[(size_t)b * N * D + d];     // global (CLS) token
     }
+  }
+}
+
+// ---- Sinkhorn (models/sinkhorn.py) ------------------------------------------------------------------------------------
+// one wave per token row: xh = x / max(|x|_2, 1e-12)   (F.normalize, sinkhorn.py:70), fp32 copy + GEMM-operand copy
+template <bool F32>
+__global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ x, float* __restrict__ xh, void* __restrict__ xh_lp,
+                                                      int M, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * D;
+  float ss = 0.f;
+  for (int d = lane; d < D; d += 64) ss = fmaf(xr[d], xr[d], ss);
+  ss = wave_sum(ss);
+  const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+  for (int d = lane; d < D; d += 64) {
+    const float v = xr[d] / nrm;
+    xh[(size_t)row * D + d] = v;
+    store1<F32>(xh_lp, (size_t)row * D + d, v);
+  }
+}
+
+// one workgroup per image; Z[k][p] = scores[p][k] / eps lives in LDS (K*P floats) through the iterations
+// (log_optimal_transport sinkhorn.py:41-56 over log_sinkhorn_iterations :25-38)
+__global__ __launch_bounds__(256) void sinkhorn_kernel(const float* __restrict__ scores, int ldl, float eps, int iters,
+                                                       float* __restrict__ wt, float* __restrict__ soft, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) float s_z[];      // [K][P], then u[K], v[P]
+  const int P = N - 1;
+  float* s_u = s_z + (size_t)K * P;
+  float* s_v = s_u + K;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x;
+  const float* sc = scores + ((size_t)b * N + 1) * ldl;
+  for (int e = tid; e < K * P; e += 256) {
+    const int p = e / K, k = e - p * K;                            // lanes along k: coalesced global reads
+    s_z[k * P + p] = sc[(size_t)p * ldl + k] / eps;
+  }
+  for (int p = tid; p < P; p += 256) s_v[p] = 0.f;
+  const float norm = -logf((float)K + (float)P);                   // log_mu = log_nu = -log(m + n)
+  __syncthreads();
+  for (int it = 0; it < iters; ++it) {
+    for (int k = wave; k < K; k += 4) {                            // u = log_mu - logsumexp_p(Z + v)
+      const float* zr = s_z + (size_t)k * P;
+      float m = -INFINITY;
+      for (int p = lane; p < P; p += 64) m = fmaxf(m, zr[p] + s_v[p]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      float t = 0.f;
+      for (int p = lane; p < P; p += 64) t += expf(zr[p] + s_v[p] - m);
+      t = wave_sum(t);
+      if (lane == 0) s_u[k] = norm - (m + logf(t));
+    }
+    __syncthreads();
+    for (int p = tid; p < P; p += 256) {                           // v = log_nu - logsumexp_k(Z + u)
+      float m = -INFINITY;
+      for (int k = 0; k < K; ++k) m = fmaxf(m, s_z[k * P + p] + s_u[k]);
+      float t = 0.f;
+      for (int k = 0; k < K; ++k) t += expf(s_z[k * P + p] + s_u[k] - m);
+      s_v[p] = norm - (m + logf(t));
+    }
+    __syncthreads();
+  }
+  if (iters == 0)
+    for (int k = tid; k < K; k += 256) s_u[k] = 0.f;
+  __syncthreads();
+  // W = exp(Z + u + v - norm): token-major copy for the merge, cluster-major copy for Soft_Assignment_Maps
+  for (int e = tid; e < K * P; e += 256) {
+    const int k = e / P, p = e - k * P;
+    const float w = expf(s_z[e] + s_u[k] + s_v[p] - norm);
+    s_z[e] = w;
+    if (soft != nullptr) soft[((size_t)b * K + k) * P + p] = w;
+  }
+  __syncthreads();
+  float* wb = wt + ((size_t)b * N + 1) * ldl;
+  for (int e = tid; e < K * P; e += 256) {
+    const int p = e / K, k = e - p * K;
+    wb[(size_t)p * ldl + k] = s_z[k * P + p];
   }
 }
 
@@ -198,10 +280,10 @@ extern "C" int tr_sit_merge(const float* logits, int ldl, float scale, const flo
   const dim3 grid((K + SKC - 1) / SKC, B);
 #define TR_SIT_LAUNCH(J)                                                                                                          \
   do {                                                                                                                            \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sit_merge_kernel<J>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                       (int)lds);                                                                                 \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sit_merge_kernel<J, true>),                                  \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
     TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_sit_merge: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));       \
-    hipLaunchKernelGGL(sit_merge_kernel<J>, grid, dim3(256), lds, st, logits, ldl, scale, x, x_out, soft, N, K, D);               \
+    hipLaunchKernelGGL((sit_merge_kernel<J, true>), grid, dim3(256), lds, st, logits, ldl, scale, x, x, x_out, soft, N, K, D);    \
   } while (0)
   switch ((D + 255) / 256) {
     case 1: TR_SIT_LAUNCH(1); break;
@@ -211,5 +293,59 @@ extern "C" int tr_sit_merge(const float* logits, int ldl, float scale, const flo
   }
 #undef TR_SIT_LAUNCH
   TR_CHECK_LAUNCH("tr_sit_merge");
+  return TR_OK;
+}
+
+extern "C" int tr_rownorm(const float* x, float* xh, void* xh_lp, int lp_is_f32, int M, int D, tr_stream_t s) {
+  TR_REQUIRE(x && xh && xh_lp, TR_ERR_NULL, "tr_rownorm: null pointer");
+  TR_REQUIRE(M > 0 && D > 0, TR_ERR_SHAPE, "tr_rownorm: bad shape M=%d D=%d", M, D);
+  hipStream_t st = static_cast<hipStream_t>(s);
+  if (lp_is_f32) hipLaunchKernelGGL(rownorm_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, x, xh, xh_lp, M, D);
+  else hipLaunchKernelGGL(rownorm_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, x, xh, xh_lp, M, D);
+  TR_CHECK_LAUNCH("tr_rownorm");
+  return TR_OK;
+}
+
+extern "C" int tr_sinkhorn(const float* scores, int ldl, float eps, int iters, float* wt, float* soft, int B, int N, int K,
+                           tr_stream_t s) {
+  TR_REQUIRE(scores && wt, TR_ERR_NULL, "tr_sinkhorn: null pointer");
+  TR_REQUIRE(B > 0 && N >= 2 && K >= 1 && ldl >= K && iters >= 0 && eps > 0.f, TR_ERR_SHAPE,
+             "tr_sinkhorn: bad arguments B=%d N=%d K=%d ldl=%d iters=%d eps=%g", B, N, K, ldl, iters, (double)eps);
+  const size_t lds = ((size_t)K * (N - 1) + K + (N - 1)) * sizeof(float);
+  TR_REQUIRE(lds <= 158 * 1024, TR_ERR_SHAPE, "tr_sinkhorn: K*P = %d*%d floats do not fit LDS (%zu B > 158 KiB)", K, N - 1, lds);
+  hipStream_t st = static_cast<hipStream_t>(s);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sinkhorn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_sinkhorn: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+  hipLaunchKernelGGL(sinkhorn_kernel, dim3(B), dim3(256), lds, st, scores, ldl, eps, iters, wt, soft, N, K);
+  TR_CHECK_LAUNCH("tr_sinkhorn");
+  return TR_OK;
+}
+
+extern "C" int tr_weighted_merge(const float* wt, int ldl, const float* x, const float* src, float* x_out, int B, int N, int K,
+                                 int D, tr_stream_t s) {
+  TR_REQUIRE(wt && x && src && x_out, TR_ERR_NULL, "tr_weighted_merge: null pointer");
+  TR_REQUIRE(B > 0 && N >= 2 && K >= 1 && D >= 1 && D <= 256 * SJ_MAX && ldl >= K, TR_ERR_SHAPE,
+             "tr_weighted_merge: bad shape B=%d N=%d K=%d D=%d ldl=%d", B, N, K, D, ldl);
+  TR_REQUIRE(x_out != x && x_out != src, TR_ERR_SHAPE, "tr_weighted_merge: needs a distinct x_out");
+  const size_t lds = (size_t)(N - 1) * SKC * sizeof(float);
+  TR_REQUIRE(lds <= 150 * 1024, TR_ERR_SHAPE, "tr_weighted_merge: %d tokens need %zu B of LDS (max 150 KiB)", N - 1, lds);
+  hipStream_t st = static_cast<hipStream_t>(s);
+  const dim3 grid((K + SKC - 1) / SKC, B);
+#define TR_WM_LAUNCH(J)                                                                                                           \
+  do {                                                                                                                            \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sit_merge_kernel<J, false>),                                 \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
+    TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_weighted_merge: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));  \
+    hipLaunchKernelGGL((sit_merge_kernel<J, false>), grid, dim3(256), lds, st, wt, ldl, 1.0f, x, src, x_out,                      \
+                       static_cast<float*>(nullptr), N, K, D);                                                                    \
+  } while (0)
+  switch ((D + 255) / 256) {
+    case 1: TR_WM_LAUNCH(1); break;
+    case 2: TR_WM_LAUNCH(2); break;
+    case 3: TR_WM_LAUNCH(3); break;
+    default: TR_WM_LAUNCH(4); break;
+  }
+#undef TR_WM_LAUNCH
+  TR_CHECK_LAUNCH("tr_weighted_merge");
   return TR_OK;
 }

@@ -205,6 +205,8 @@ class VisionTransformer(nn.Module):
         cfg.ln_eps = float(self.norm.eps)
         cfg.precision = _lib.TR_PREC_FP32 if self.precision == "fp32" else _lib.TR_PREC_BF16
         cfg.knn_k = int(getattr(self, "k_neighbors", 0))
+        cfg.cluster_iters = int(getattr(self, "sinkhorn_iters", 0))
+        cfg.sinkhorn_eps = float(getattr(self, "sinkhorn_eps", 0.0))
         for i in range(self.depth):
             cfg.keep[i] = int(self._keep[i])
         self._packed = dict(key=key, W=W, cfg=cfg, keep_alive=keep_alive)
@@ -690,3 +692,52 @@ class ATSVisionTransformer(VisionTransformer):
                 width = int((ids[:, 1:] != 0).sum(axis=1).max())                      # pad_sequence to the batch maximum, ats.py:78
                 decisions[blk] = ids[:, 1:1 + width] - 1                              # ats.py:253
         return {"Kept_Tokens": decisions, "Features": {}}
+
+
+class Sinkhorn(nn.Module):
+    """Parameter holder (sinkhorn.py:59-64): cluster centres v ~ N(0, 1)."""
+
+    def __init__(self, embed_dim, cluster_centers, eps, iters):
+        super().__init__()
+        self.v = nn.Parameter(torch.randn(cluster_centers, embed_dim))
+        self.eps, self.iters = eps, iters
+
+
+class SinkhornVisionTransformer(SelfSlimmedVisionTransformer):
+    """models/sinkhorn.py:89-200: before each block in reduction_loc the unit-norm patch tokens are softly assigned to K
+    unit-norm learned centres by `cluster_iters` log-domain Sinkhorn iterations; outputs are assignment-weighted sums of the
+    unit-norm tokens.  (The reference re-normalises `v` in place every forward, sinkhorn.py:73-76; here the normalised copy is
+    made when the weights are packed and the parameter is left untouched.)"""
+    _family = _lib.TR_FAMILY_SINKHORN
+
+    def __init__(self, *a, args=None, **kw):
+        VisionTransformer.__init__(self, *a, args=args, **kw)
+        self.cluster_loc = list(args.reduction_loc)
+        self.cluster_count = list(args.keep_rate)
+        self.sinkhorn_eps = float(args.sinkhorn_eps)
+        self.sinkhorn_iters = int(args.cluster_iters)
+        P0 = self.patch_embed.num_patches
+        if len(self.cluster_count) == 1:
+            self.cluster_count = [int(P0 * (args.keep_rate[0] ** (idx + 1))) for idx in range(len(self.cluster_loc))]   # sinkhorn.py:128-129
+        assert len(self.cluster_count) == len(self.cluster_loc), \
+            f"Mismatch between the cluster location ({self.cluster_loc}) and cluster centers ({self.cluster_count})"
+        self.cluster_count = [int(c) for c in self.cluster_count]
+        self.cluster_layers = nn.ModuleList([Sinkhorn(self.embed_dim, c, self.sinkhorn_eps, self.sinkhorn_iters)
+                                             for c in self.cluster_count])
+        for c, loc in zip(self.cluster_count, self.cluster_loc):
+            self._keep[loc] = c
+
+    def _pack_stages(self, W, w16, f32, keep_alive):
+        for j, loc in enumerate(self.cluster_loc):
+            v, st = self.cluster_layers[j].v.detach(), W.stage[loc]
+            K = self.cluster_count[j]
+            n_pad = (K + 7) // 8 * 8
+            w1 = torch.zeros(n_pad, v.shape[1], dtype=torch.float32, device=v.device)
+            w1[:K] = torch.nn.functional.normalize(v.float(), p=2, dim=-1)
+            st.w1, st.b1 = w16(w1), f32(torch.zeros(n_pad, dtype=torch.float32, device=v.device))
+            st.n_pad = n_pad
+
+    def _viz_data(self, ws, B, tokens):
+        out = super()._viz_data(ws, B, tokens)
+        out["Center_Feats"] = {}
+        return out

@@ -273,3 +273,33 @@ def ats_gather(x: torch.Tensor, ao: torch.Tensor, ids: torch.Tensor):
                                          _dev(ids, torch.int32, "ids"), x_out.data_ptr(), ao_out.data_ptr(), B, N, K, D, _stream()),
                "tr_ats_gather")
     return x_out, ao_out
+
+
+# ---------------------------------------------------------------------------------------- Sinkhorn (models/sinkhorn.py)
+def rownorm(x: torch.Tensor, f32: bool = False):
+    """F.normalize(x, dim=-1): x fp32 [M,D] -> (xh fp32 [M,D], xh as GEMM operand bf16|fp32)."""
+    M, D = x.shape
+    xh = torch.empty_like(x)
+    lp = torch.empty(M, D, dtype=torch.float32 if f32 else torch.bfloat16, device=x.device)
+    _lib.check(_lib.load().tr_rownorm(_dev(x, torch.float32, "x"), xh.data_ptr(), lp.data_ptr(), int(f32), M, D, _stream()), "tr_rownorm")
+    return xh, lp
+
+
+def sinkhorn(scores: torch.Tensor, K: int, eps: float, iters: int, want_soft: bool = False):
+    """log_optimal_transport (sinkhorn.py:41-56): scores fp32 [B,N,ldl] -> (wt fp32 [B,N,ldl] token-major plan, soft [B,K,N-1]|None)."""
+    B, N, ldl = scores.shape
+    wt = torch.zeros_like(scores)
+    soft = torch.empty(B, K, N - 1, dtype=torch.float32, device=scores.device) if want_soft else None
+    _lib.check(_lib.load().tr_sinkhorn(_dev(scores, torch.float32, "scores"), ldl, float(eps), int(iters), wt.data_ptr(),
+                                       None if soft is None else soft.data_ptr(), B, N, K, _stream()), "tr_sinkhorn")
+    return wt, soft
+
+
+def weighted_merge(wt: torch.Tensor, x: torch.Tensor, src: torch.Tensor, K: int):
+    """x_out[b,1+k] = sum_p wt[b,1+p,k] * src[b,1+p]; x_out[b,0] = x[b,0]  (sinkhorn.py:83)."""
+    B, N, D = x.shape
+    x_out = torch.empty(B, K + 1, D, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().tr_weighted_merge(_dev(wt, torch.float32, "wt"), wt.shape[-1], _dev(x, torch.float32, "x"),
+                                             _dev(src, torch.float32, "src"), x_out.data_ptr(), B, N, K, D, _stream()),
+               "tr_weighted_merge")
+    return x_out

@@ -127,6 +127,26 @@ def forward_stepwise(model: VisionTransformer, x: torch.Tensor, trace: Optional[
                                                                  f32(blk.norm1.bias), eps, sw, sb))
             N = Kc + 1
             h, xn = h3_.view(B * N, D), xn.view(B * N, D)
+        if cfg.family == 8 and int(cfg.keep[i]) > 0:
+            # Sinkhorn: soft assignment to unit-norm centres BEFORE the block (sinkhorn.py:66-86)
+            Kc, M = int(cfg.keep[i]), B * N
+            j = model.cluster_loc.index(i)
+            if pending is not None:
+                tr.run("layernorm_kernel", 0.0, 12.0 * M * D,
+                       lambda: ops.layernorm(h, f32(blk.norm1.weight), f32(blk.norm1.bias), eps, delta=pending))
+                pending = None
+            xh, xlp = tr.run("rownorm_kernel", 0.0, 10.0 * M * D, lambda: ops.rownorm(h))
+            n_pad = (Kc + 7) // 8 * 8
+            w1 = torch.zeros(n_pad, D, dtype=torch.float32, device=dev)
+            w1[:Kc] = torch.nn.functional.normalize(model.cluster_layers[j].v.detach().float(), p=2, dim=-1)
+            sc = _gemm(tr, xlp, bf(w1), torch.zeros(n_pad, dtype=torch.float32, device=dev), ops.TR_EPI_F32, tag="sk")
+            wt, soft = tr.run("sinkhorn_kernel", 0.0, 8.0 * M * n_pad,
+                              lambda: ops.sinkhorn(sc.view(B, N, n_pad), Kc, model.sinkhorn_eps, model.sinkhorn_iters, want_soft=tr.keep))
+            info["soft"][i] = soft
+            h3_ = tr.run("sit_merge_kernel", 2.0 * B * Kc * (N - 1) * D, 4.0 * B * (N + Kc) * D,
+                         lambda: ops.weighted_merge(wt, h.view(B, N, D), xh.view(B, N, D), Kc))
+            N = Kc + 1
+            h = h3_.view(B * N, D)
         if cfg.family in (4, 5) and int(cfg.keep[i]) > 0:
             # DyViT / SiT: the reduction module runs on x BEFORE the block (dyvit.py:218-239, sit.py:116-119)
             Kc, M = int(cfg.keep[i]), B * N
