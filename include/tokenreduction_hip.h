@@ -73,11 +73,16 @@ int tr_layernorm_f32(float* x, long ldx, const float* delta, long ldd, const flo
  * cls_rows (nullable) fp32 [B,H,N]: the CLS query's softmax row (attn[:, :, 0, :], topk.py:59) --
  * the only part of the N x N matrix the reduction reads, so the matrix is never materialised.
  * size (nullable) fp32 [B,N]: ToMe's proportional attention (Attention_ToMe.forward tome.py:48-49): log(size[key]) is added
- * to every query's logit for that key.
+ * to every query's logit for that key; a 1/0 key mask works the same way (ATS, ats.py:117-120: log 0 = -inf -> weight 0).
+ * colsum_part (nullable) fp32 [B,H,4,N]: column sums of the softmax matrix, one partial per wave of the workgroup -- summed
+ * over (H, 4) they are K-Medoids' token weights sum_h sum_q attn[b,h,q,:] (kmedoids.py:240); partials keep the summation
+ * order fixed (no float atomics).
  * N <= 224 in this round (whole score row in registers); larger N returns TR_ERR_SHAPE. */
-int tr_attention_bf16(const uint16_t* qkv, uint16_t* out, float* cls_rows, const float* size, int B, int N, int H, tr_stream_t s);
+int tr_attention_bf16(const uint16_t* qkv, uint16_t* out, float* cls_rows, const float* size, float* colsum_part, int B, int N,
+                      int H, tr_stream_t s);
 /* fp32 validation path (N <= 256): same contract in the reference's arithmetic (expf softmax, fp32 everywhere). */
-int tr_attention_f32(const float* qkv, float* out, float* cls_rows, const float* size, int B, int N, int H, tr_stream_t s);
+int tr_attention_f32(const float* qkv, float* out, float* cls_rows, const float* size, float* colsum_part, int B, int N, int H,
+                     tr_stream_t s);
 
 /* a6 (topk.py:55-65 == evit.py:77-87) + a8 (evit.py:25-46 complement_idx):
  * scores[b,j] = mean_h cls_rows[b,h,1+j] (j < P = N-1); idx[b,:K] = indices of the K largest scores in
@@ -133,8 +138,15 @@ int tr_sit_merge(const float* logits, int ldl, float scale, const float* x, floa
  *   ws: tr_dpcknn_workspace_floats(B,N) floats of scratch.
  * tr_cluster_merge_layernorm: merge_tokens dpcknn.py:103-132 with token_weight = exp(x . score_w + score_b) (CTM, :155-157;
  *   score_w NULL = equal weights), then LayerNorm(gamma, beta, eps) of the merged tokens: x_out fp32 [B,K+1,D] (row 0 = CLS
- *   copied), y = LN(x_out) bf16 (fp32 when y_is_f32).  w_ws: [B,N-1] floats of scratch (token weights). */
+ *   copied), y = LN(x_out) bf16 (fp32 when y_is_f32).  w_ws: [B,N-1] floats of scratch (token weights).
+ * tr_kmedoids: k_medoids_fit kmedoids.py:40-85 with token weights (the equal_weight branch draws from the numpy global RNG and
+ *   is not built): colsum_part fp32 [B,H,4,N] from the PREVIOUS block's attention -> w = its sum over (H,4) on the patch
+ *   columns; initial medoids = topk(w, K); `iters` rounds of {assign to the nearest medoid; medoid k = the member with the
+ *   smallest w_i * sum_j dist_ij, index 0 if the cluster is empty (kmedoids.py:74-79)}; final assignment.
+ *   centers int32 [B,K] (cluster_idx), assign int32 [B,N-1].  ws: tr_dpcknn_workspace_floats(B,N) floats. */
 size_t tr_dpcknn_workspace_floats(int B, int N);
+int tr_kmedoids(const float* x, const float* colsum_part, float* ws, int32_t* centers, int32_t* assign, int B, int N, int D, int H,
+                int K, int iters, tr_stream_t s);
 int tr_dpcknn_cluster(const float* x, const float* noise, float* ws, int32_t* centers, int32_t* idx_cluster, float* scores,
                       int B, int N, int D, int K, int k, tr_stream_t s);
 int tr_cluster_merge_layernorm(const float* x, const float* score_w, const float* score_b, float* w_ws,
@@ -181,6 +193,7 @@ int tr_tome_merge_layernorm(const float* x, const void* delta, int f32_path, con
 #define TR_FAMILY_ATS 7    /* models/ats.py: inverse-CDF token sampling inside the attention; keep[blk] = sample_count K (static
                               token bound of the block's output; padded rows are masked keys) */
 #define TR_FAMILY_SINKHORN 8 /* models/sinkhorn.py: optimal-transport soft assignment to learned centres BEFORE the block */
+#define TR_FAMILY_KMEDOIDS 9 /* models/kmedoids.py: weighted K-Medoids on the patch tokens BEFORE the block, medoids kept */
 #define TR_FAMILY_DPCKNN 6 /* models/dpcknn.py: DPC-KNN clustering + weighted merge BEFORE the block; keep[blk] = clusters */
 #define TR_MAX_DEPTH 32
 #define TR_PREC_BF16 0   /* the product path: bf16 MFMA operands, fp32 accumulate / residual / statistics */
@@ -231,7 +244,7 @@ typedef struct {
                                  away; SiT: K output tokens of the slimming module */
   int precision;              /* TR_PREC_* */
   int knn_k;                  /* DPC-KNN: neighbours of the local density (args.k_neighbors, train.py:221 default 5) */
-  int cluster_iters;          /* Sinkhorn iterations (args.cluster_iters, train.py:232 default 3) */
+  int cluster_iters;          /* Sinkhorn / K-Medoids iterations (args.cluster_iters, train.py:232 default 3) */
   float sinkhorn_eps;         /* Sinkhorn temperature (args.sinkhorn_eps, train.py:229 default 1.0) */
 } tr_vit_config;
 
@@ -244,7 +257,7 @@ size_t tr_vit_workspace_bytes(const tr_vit_config* cfg, int B);
  * compl_idx (nullable, EViT): same slab shape, block blk writes [B,P_in-K_blk] at offset blk*B*(P+1)
  * (Fusion_Assign, evit.py:229).  soft_out (nullable, SiT): fp32, the stages' soft assignments [B,K,P_in] back to back in
  * block order (Soft_Assignment_Maps, sit.py:124).  DPC-KNN: kept_idx gets the centres [B,K] (Kept_Tokens), compl_idx the
- * assignment [B,P_in] (Assignment_Maps); ATS: kept_idx gets ids [B,K] (CLS id 0 first, 1-based token ids, 0 padding); noise_in (nullable): fp32, the stages' density noise [B,P_in] back to back in block
+ * assignment [B,P_in] (Assignment_Maps), K-Medoids likewise (medoid ids, assignment); ATS: kept_idx gets ids [B,K] (CLS id 0 first, 1-based token ids, 0 padding); noise_in (nullable): fp32, the stages' density noise [B,P_in] back to back in block
  * order (dpcknn.py:71-72; NULL = no noise).  tokens_out (nullable, HOST pointer, int[depth]): token count after each block. */
 int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits,
                    void* workspace, size_t workspace_bytes, int32_t* kept_idx, int32_t* compl_idx, float* soft_out,

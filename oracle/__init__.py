@@ -25,7 +25,7 @@ from .prune_before import (  # noqa: F401
 )
 from .cluster import (  # noqa: F401
     dpcknn_cluster_counts, dpcknn_distances, dpcknn_scores, dpcknn_assign, dpcknn_cluster, dpcknn_merge, dpcknn_ctm,
-    dpcknn_forward, sinkhorn_log_iterations, sinkhorn_transport, sinkhorn_layer, sinkhorn_forward,
+    dpcknn_forward, kmedoids_token_weights, kmedoids_fit, kmedoids_block_forward, kmedoids_forward, sinkhorn_log_iterations, sinkhorn_transport, sinkhorn_layer, sinkhorn_forward,
 )
 from .ats import (  # noqa: F401
     ats_sample_counts, ats_sample_steps, ats_scores, ats_cdf, ats_ids_from_cdf, ats_sample_ids, ats_block_forward, ats_forward,
@@ -34,6 +34,8 @@ from .ats import (  # noqa: F401
 
 def forward(params, x, cfg, precision="fp32", return_viz=False, forced=None, noise=None):
     """Family dispatch used by the tests."""
+    if cfg.family == "kmedoids":
+        return kmedoids_forward(params, x, cfg, precision, return_viz, forced=forced)
     if cfg.family == "sinkhorn":
         assert forced is None
         return sinkhorn_forward(params, x, cfg, precision, return_viz)

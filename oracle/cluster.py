@@ -180,3 +180,91 @@ def sinkhorn_forward(params: Dict[str, Tensor], x: Tensor, cfg: VitConfig, preci
         viz["Final_Tokens"] = h
         return logits, viz
     return logits
+
+
+# =========================================================================================== K-Medoids (models/kmedoids.py)
+def kmedoids_token_weights(attn: Tensor) -> Tensor:
+    """kmedoids.py:240: sum over heads, then over queries, of the previous block's softmax matrix; patch columns. -> [B,P,1]"""
+    return torch.sum(torch.sum(attn, dim=1), dim=1)[:, 1:].unsqueeze(2)
+
+
+def kmedoids_fit(x: Tensor, cluster_num: int, iterations: int, token_weight: Tensor, forced_init: Optional[Tensor] = None):
+    """k_medoids_fit kmedoids.py:40-85, weighted branch (token_weight given).  Returns (centres [B,K,D], cluster_idx [B,K],
+    assignment [B,P]).  The per-cluster loop of :74-79 is restated without the B*P*P clone: a row outside cluster k sums to
+    P*1e6, a row inside to sum_j dist_ij*w_i, argmin takes the first minimum (index 0 for an empty cluster)."""
+    B, N, C = x.shape
+    if forced_init is None:
+        cluster_idx = torch.sort(token_weight.squeeze(2), dim=1, descending=True, stable=True).indices[:, :cluster_num]
+    else:
+        cluster_idx = forced_init
+    cluster_idx = cluster_idx.clone()
+    dist = torch.cdist(x, x)
+    row_cost = torch.sum(dist * token_weight, dim=-1)                                   # [B,P]
+    masked = torch.sum(torch.full((N,), 1000000.0))
+    for _ in range(iterations):
+        center_matrix = torch.gather(dist, 2, cluster_idx[:, None, :].expand(B, N, cluster_num))
+        assignment = torch.argmin(center_matrix, dim=-1)
+        for k in range(cluster_num):
+            total = torch.where(assignment == k, row_cost, masked)
+            cluster_idx[:, k] = torch.argmin(total, dim=1)
+    center_matrix = torch.gather(dist, 2, cluster_idx[:, None, :].expand(B, N, cluster_num))
+    assignment = torch.argmin(center_matrix, dim=-1)
+    centers = torch.gather(x, 1, cluster_idx[:, :, None].expand(B, cluster_num, C))
+    return centers, cluster_idx, assignment
+
+
+def kmedoids_block_forward(x: Tensor, p: Dict[str, Tensor], i: int, cfg: VitConfig, precision: str = "fp32"):
+    """kmedoids.Block.forward :125-132: a plain block that also returns the softmax matrix [B,H,N,N]."""
+    from .vit import layer_norm, mlp, round_bf16
+    pre = f"blocks.{i}."
+    B, N, D = x.shape
+    H = cfg.num_heads
+    dh = D // H
+    xn = layer_norm(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"], cfg.ln_eps, precision)
+    qkv = _r(xn @ _r(p[pre + "attn.qkv.weight"], precision).t() + p[pre + "attn.qkv.bias"], precision)
+    q, k, v = qkv.reshape(B, N, 3, H, dh).permute(2, 0, 3, 1, 4).unbind(0)
+    s = (q @ k.transpose(-2, -1)) * (dh ** -0.5)
+    if precision == "bf16":
+        e = torch.exp(s - s.amax(dim=-1, keepdim=True))
+        attn = e / e.sum(dim=-1, keepdim=True)
+        o = (round_bf16(e) @ v) / e.sum(dim=-1, keepdim=True)
+    else:
+        attn = s.softmax(dim=-1)
+        o = attn @ v
+    o = _r(o.transpose(1, 2).reshape(B, N, D), precision)
+    x = x + _r(o @ _r(p[pre + "attn.proj.weight"], precision).t() + p[pre + "attn.proj.bias"], precision)
+    xn2 = layer_norm(x, p[pre + "norm2.weight"], p[pre + "norm2.bias"], cfg.ln_eps, precision)
+    x = x + mlp(xn2, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"], p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"],
+                precision)
+    return x, attn
+
+
+@torch.no_grad()
+def kmedoids_forward(params: Dict[str, Tensor], x: Tensor, cfg: VitConfig, precision: str = "fp32", return_viz: bool = False,
+                     iters: int = 3, forced: Optional[Dict[int, Tensor]] = None):
+    """KMedoidsVisionTransformer.forward kmedoids.py:219-272, eval mode, args.equal_weight False.  forced[blk] (tests only)
+    replaces the whole clustering result of that block by the given medoid ids [B,K]."""
+    p = params
+    tok = patch_embed(x, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], cfg.patch_size, precision)
+    h = embed_tokens(tok, p["cls_token"], p["pos_embed"])
+    counts = dpcknn_cluster_counts(cfg)
+    viz = {"Kept_Tokens": {}, "Assignment_Maps": {}, "Weights": {}, "Tokens": {}}
+    attn = None
+    for i in range(cfg.depth):
+        if i in counts:
+            w = kmedoids_token_weights(attn)
+            xs, centers, assign = kmedoids_fit(h[:, 1:], counts[i], iters, w)
+            if forced is not None:
+                centers = forced[i]
+                xs = torch.gather(h[:, 1:], 1, centers[:, :, None].expand(-1, -1, h.shape[-1]))
+            h = torch.cat([h[:, :1], xs], dim=1)
+            viz["Kept_Tokens"][i] = centers.numpy()
+            viz["Assignment_Maps"][i] = assign.numpy()
+            viz["Weights"][i] = w.squeeze(2)
+        h, attn = kmedoids_block_forward(h, p, i, cfg, precision)
+        viz["Tokens"][i] = h.shape[1]
+    logits = head(h, p["norm.weight"], p["norm.bias"], p["head.weight"], p["head.bias"], cfg.ln_eps, precision)
+    if return_viz:
+        viz["Final_Tokens"] = h
+        return logits, viz
+    return logits

@@ -151,6 +151,12 @@ GOLDEN_CASES = {
     "ats_small_kr05": dict(family="ats", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
                            keep_rate=[0.5], reduction_loc=[3, 6, 9], batch=3, wseed=135, xseed=136,
                            qkv_gain=4.0, factory="ats_small_patch16_224"),
+    # K-Medoids (models/kmedoids.py): weighted K-Medoids seeded by the previous block's attention column sums
+    "kmedoids_micro": dict(family="kmedoids", embed_dim=128, depth=4, num_heads=2, num_classes=16,
+                           keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=151, xseed=152, qkv_gain=6.0),
+    "kmedoids_small_kr07": dict(family="kmedoids", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
+                                keep_rate=[0.7], reduction_loc=[3, 6, 9], batch=2, wseed=153, xseed=154,
+                                qkv_gain=4.0, factory="kmedoids_small_patch16_224"),
     # Sinkhorn (models/sinkhorn.py): optimal-transport soft assignment to learned centres BEFORE the block
     "sinkhorn_micro": dict(family="sinkhorn", embed_dim=128, depth=4, num_heads=2, num_classes=16,
                            keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=141, xseed=142, qkv_gain=6.0),

@@ -44,11 +44,12 @@ from models.sit import SelfSlimmedVisionTransformer  # noqa: E402
 from models.dpcknn import DPCKNNVisionTransformer  # noqa: E402
 from models.ats import ATSVisionTransformer  # noqa: E402
 from models.sinkhorn import SinkhornVisionTransformer  # noqa: E402
+from models.kmedoids import KMedoidsVisionTransformer  # noqa: E402
 
 from tests._params import GOLDEN_CASES, make_params, make_stage_params, make_images, case_config  # noqa: E402
 
 CLASSES = {"topk": TopKVisionTransformer, "evit": EfficientVisionTransformer, "deit": DeitViz, "tome": ToMeVisionTransformer,
-           "dyvit": DynamicVisionTransformer, "sit": SelfSlimmedVisionTransformer, "dpcknn": DPCKNNVisionTransformer, "ats": ATSVisionTransformer, "sinkhorn": SinkhornVisionTransformer}
+           "dyvit": DynamicVisionTransformer, "sit": SelfSlimmedVisionTransformer, "dpcknn": DPCKNNVisionTransformer, "ats": ATSVisionTransformer, "sinkhorn": SinkhornVisionTransformer, "kmedoids": KMedoidsVisionTransformer}
 
 
 class TopkSpy:
@@ -173,6 +174,13 @@ def run_case(name, case):
             assert torch.unique(v).numel() == v.numel(), f"{name}: tied ranked values - pick another seed"
             srt = torch.sort(v, descending=True).values
             tome_gaps.append((srt[:-1] - srt[1:]).min().item())
+    if case["family"] == "kmedoids":
+        # spy.calls: one topk(token_weight, K) per stage -> the weights that seed the medoids (kmedoids.py:59)
+        blks = sorted(viz["Kept_Tokens"])
+        assert len(spy.calls) == len(blks)
+        for blk, (wts, _) in zip(blks, spy.calls):
+            rec[f"weights_{blk}"] = wts.squeeze(-1).numpy().astype(np.float32)
+        spy.calls = [(w.squeeze(-1), k) for w, k in spy.calls]
     if case["family"] == "ats":
         blks = sorted(viz["Kept_Tokens"])
         assert len(cspy.calls) == len(blks)

@@ -34,7 +34,7 @@ def test_registry_has_every_reference_name():
 
 def test_unbuilt_families_fail_loudly():
     with pytest.raises(NotImplementedError):
-        tra.create_model("kmedoids_small_patch16_224", args=_args(keep_rate=[0.7], reduction_loc=[3, 6, 9]))
+        tra.create_model("patchmerger_small_patch16_224", args=_args(keep_rate=[0.7], reduction_loc=[3, 6, 9]))
 
 
 @pytest.mark.parametrize("name,dims", [("topk_tiny_patch16_224", (192, 3)), ("evit_small_patch16_224", (384, 6)),
@@ -113,7 +113,7 @@ def test_argument_validation_without_gpu():
     p = ctypes.addressof(buf)
     p = (p + 255) // 256 * 256
     assert lib.tr_gemm_bf16(p, p, p, p, None, 0, 8, 8, 48, 0, None) == -1          # K % 64
-    assert lib.tr_attention_bf16(p, p, None, None, 1, 300, 1, None) == -1            # N > 224
+    assert lib.tr_attention_bf16(p, p, None, None, None, 1, 300, 1, None) == -1      # N > 224
     assert lib.tr_tome_match(p, 0, p, p, p, 1, 197, 6, 120, None) == -1              # r > (N-1)//2
     assert lib.tr_cls_topk(p, p, None, None, 1, 1, 10, 10, None) == -1               # K > P
     cfg = _lib.TrVitConfig()

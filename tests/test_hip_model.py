@@ -28,7 +28,7 @@ from tests._params import GOLDEN_CASES, case_config, case_params, make_images, m
 pytestmark = pytest.mark.gpu
 
 FAM = {"deit": "VisionTransformer", "topk": "TopKVisionTransformer", "evit": "EfficientVisionTransformer",
-       "tome": "ToMeVisionTransformer", "dyvit": "DynamicVisionTransformer", "sit": "SelfSlimmedVisionTransformer", "dpcknn": "DPCKNNVisionTransformer", "ats": "ATSVisionTransformer", "sinkhorn": "SinkhornVisionTransformer"}
+       "tome": "ToMeVisionTransformer", "dyvit": "DynamicVisionTransformer", "sit": "SelfSlimmedVisionTransformer", "dpcknn": "DPCKNNVisionTransformer", "ats": "ATSVisionTransformer", "sinkhorn": "SinkhornVisionTransformer", "kmedoids": "KMedoidsVisionTransformer"}
 
 
 def build_model(case):
@@ -93,7 +93,7 @@ def test_model_parity(golden_dir, name):
         return _tome_parity(name, case, g, model, params, cfg, x, logits, viz, info)
     if case["family"] in ("sit", "sinkhorn"):
         return _sit_parity(name, case, g, model, params, cfg, x, logits, viz, info)
-    if case["family"] == "dpcknn":
+    if case["family"] in ("dpcknn", "kmedoids"):
         return _dpcknn_parity(name, case, g, model, params, cfg, x, logits, viz, info, noise)
     if case["family"] == "ats":
         return _ats_parity(name, case, g, model, params, cfg, x, logits, viz, info)
@@ -201,8 +201,10 @@ def _dpcknn_parity(name, case, g, model, params, cfg, x, logits, viz, info, nois
         a = viz["Assignment_Maps"][blk]
         K = centers.shape[1]
         assert a.min() >= 0 and a.max() < K
-        # every centre is assigned to itself, every cluster is non-empty (dpcknn.py:95-98)
-        np.testing.assert_array_equal(np.take_along_axis(a, viz["Kept_Tokens"][blk], axis=1), np.broadcast_to(np.arange(K), (a.shape[0], K)))
+        if case["family"] == "dpcknn":
+            # every centre is assigned to itself, every cluster is non-empty (dpcknn.py:95-98)
+            np.testing.assert_array_equal(np.take_along_axis(a, viz["Kept_Tokens"][blk], axis=1),
+                                          np.broadcast_to(np.arange(K), (a.shape[0], K)))
     kept_keys = sorted((k for k in g.files if k.startswith("kept_")), key=lambda k: int(k.split("_")[1]))
     assert sorted(viz["Kept_Tokens"].keys()) == [int(k.split("_")[1]) for k in kept_keys]
     for blk, n in zip(g["token_count_blocks"], g["token_counts"]):

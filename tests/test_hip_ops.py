@@ -552,3 +552,44 @@ def test_weighted_merge(ops, B, N, K, D, ldl):
     want = torch.cat([x[:, :1].double(), torch.bmm(wt[:, 1:, :K].double().transpose(1, 2), src[:, 1:].double())], dim=1).float()
     got = ops.weighted_merge(wt.cuda(), x.cuda(), src.cuda(), K)
     torch.testing.assert_close(got.cpu(), want, atol=5e-5, rtol=2e-5)
+
+
+# ---------------------------------------------------------------------------------------- K-Medoids
+@pytest.mark.parametrize("B,N,H", [(2, 197, 6), (2, 138, 2), (1, 69, 3), (1, 40, 1), (1, 224, 2)])
+def test_attention_column_sums(ops, B, N, H):
+    """kmedoids.py:240: sum_h sum_q attn[b,h,q,:] from the per-wave partials of both attention kernels."""
+    rng = _rng(60 + N)
+    qkv = _bf(_randn(rng, B * N, 3 * H * 64, scale=1.5))
+    q, k, v = qkv.double().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    attn = ((q @ k.transpose(-2, -1)) * 0.125).softmax(-1)
+    want = attn.sum(dim=1).sum(dim=1).float()                                   # [B,N]
+    part = torch.full((B, H, 4, N), float("nan"), device="cuda")
+    out, _ = ops.attention(qkv.bfloat16().cuda(), B, N, H, colsum_part=part)
+    ref_out, _ = ops.attention(qkv.bfloat16().cuda(), B, N, H)
+    assert torch.equal(out, ref_out)                                            # the side output does not change the main one
+    torch.testing.assert_close(part.sum(dim=(1, 2)).cpu(), want, atol=2e-4, rtol=2e-5)
+    part32 = torch.full((B, H, 4, N), float("nan"), device="cuda")
+    ops.attention_f32(qkv.cuda(), B, N, H, colsum_part=part32)
+    torch.testing.assert_close(part32.sum(dim=(1, 2)).cpu(), want, atol=2e-5, rtol=2e-5)
+    np.testing.assert_allclose(want.sum(dim=1).numpy(), H * N, rtol=1e-5)       # every softmax row sums to 1
+
+
+@pytest.mark.parametrize("B,N,D,H,K,iters", [(3, 197, 384, 6, 137, 3), (2, 138, 128, 2, 96, 3), (2, 60, 64, 3, 9, 5), (1, 197, 768, 12, 98, 1)])
+def test_kmedoids(ops, B, N, D, H, K, iters):
+    rng = _rng(3000 + N + K)
+    x = _randn(rng, B, N, D)
+    part = torch.from_numpy(rng.random((B, H, 4, N)).astype(np.float32))
+    w = part.sum(dim=(1, 2))[:, 1:].unsqueeze(2)                                # same fixed summation order as the kernel
+    w = torch.zeros(B, N)
+    for h in range(H):
+        for wv in range(4):
+            w = w + part[:, h, wv]
+    w = w[:, 1:].unsqueeze(2)
+    _, centers_w, assign_w = oracle.kmedoids_fit(x[:, 1:], K, iters, w)
+    centers, assign = ops.kmedoids(x.cuda(), part.cuda(), K, iters)
+    c_eq = (centers.cpu().long() == centers_w).float().mean().item()
+    a_eq = (assign.cpu().long() == assign_w).float().mean().item()
+    print(f"\nkmedoids B={B} N={N} K={K}: medoid agreement {c_eq:.4f}, assignment agreement {a_eq:.4f}")
+    # identical unless a distance / cost near-tie (fp32 rounding of the matmul-form cdist) moves a decision
+    assert c_eq > 0.98 and a_eq > 0.98, (c_eq, a_eq)
+    assert int(centers.min()) >= 0 and int(centers.max()) < N - 1 and int(assign.min()) >= 0 and int(assign.max()) < K

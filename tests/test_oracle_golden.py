@@ -40,6 +40,8 @@ def test_model_matches_reference(golden_dir, name):
         return _check_dpcknn(case, g, x)
     if case["family"] == "ats":
         return _check_ats(case, g, x)
+    if case["family"] == "kmedoids":
+        return _check_kmedoids(case, g, x)
     logits, viz = oracle.vit_forward(params, x, cfg, return_viz=True)
     # integer outputs: bit-exact
     kept_keys = sorted(k for k in g.files if k.startswith("kept_"))
@@ -95,6 +97,22 @@ def _check_ats(case, g, x):
         assert v2["Kept_Tokens"][blk].shape[1] == counts[blk] - 1
         np.testing.assert_array_equal(v2["Kept_Tokens"][blk][:, :w], kt)
         assert (v2["Kept_Tokens"][blk][:, w:] == -1).all()
+
+
+def _check_kmedoids(case, g, x):
+    cfg, params = case_params(case)
+    logits, viz = oracle.kmedoids_forward(params, x, cfg, return_viz=True)
+    kept_keys = [k for k in g.files if k.startswith("kept_")]
+    assert len(kept_keys) == len(viz["Kept_Tokens"]) > 0
+    for k in kept_keys:                                   # medoid ids and assignments of every stage, bit-exact
+        blk = int(k.split("_")[1])
+        np.testing.assert_allclose(viz["Weights"][blk].numpy(), g[f"weights_{blk}"], atol=1e-5, rtol=1e-5)
+        np.testing.assert_array_equal(viz["Kept_Tokens"][blk], g[k])
+        np.testing.assert_array_equal(viz["Assignment_Maps"][blk], g[f"assign_{blk}"])
+    np.testing.assert_allclose(logits.numpy(), g["logits"], atol=FP_TOL, rtol=0)
+    np.testing.assert_allclose(viz["Final_Tokens"][:, :8].numpy(), g["final_tokens"], atol=1e-4, rtol=0)
+    for blk, n in zip(g["token_count_blocks"], g["token_counts"]):
+        assert viz["Tokens"][int(blk)] == int(n)
 
 
 def golden_noise(g):

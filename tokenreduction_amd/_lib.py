@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libtokenreduction_hip.so")
 TR_MAX_DEPTH = 32
 TR_EPI_BF16, TR_EPI_GELU_BF16, TR_EPI_RESID_F32, TR_EPI_F32, TR_EPI_PATCH_F32 = 0, 1, 2, 3, 4
 TR_FAMILY_DEIT, TR_FAMILY_TOPK, TR_FAMILY_EVIT, TR_FAMILY_TOME, TR_FAMILY_DYVIT, TR_FAMILY_SIT, \
-    TR_FAMILY_DPCKNN, TR_FAMILY_ATS, TR_FAMILY_SINKHORN = 0, 1, 2, 3, 4, 5, 6, 7, 8
+    TR_FAMILY_DPCKNN, TR_FAMILY_ATS, TR_FAMILY_SINKHORN, TR_FAMILY_KMEDOIDS = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
 TR_PREC_BF16, TR_PREC_FP32 = 0, 1
 
 _vp, _i, _f, _l, _sz = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t
@@ -49,14 +49,14 @@ SIGNATURES = {
     "tr_im2col_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tr_gemm_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tr_layernorm_f32": (_i, [_vp, _l, _vp, _l, _vp, _vp, _vp, _i, _i, _f, _vp]),
-    "tr_attention_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "tr_attention_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "tr_tome_match": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tr_tome_merge_layernorm": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "tr_gather_layernorm_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "tr_cls_pos_rows": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "tr_gemm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tr_layernorm_bf16": (_i, [_vp, _l, _vp, _l, _vp, _vp, _vp, _i, _i, _f, _vp]),
-    "tr_attention_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "tr_attention_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "tr_cls_topk": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tr_gather_layernorm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "tr_vit_workspace_bytes": (_sz, [C.POINTER(TrVitConfig), _i]),
@@ -69,6 +69,7 @@ SIGNATURES = {
     "tr_ats_sample": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tr_ats_gather": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tr_dpcknn_workspace_floats": (_sz, [_i, _i]),
+    "tr_kmedoids": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "tr_dpcknn_cluster": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tr_cluster_merge_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "tr_vit_forward": (_i, [C.POINTER(TrVitConfig), C.POINTER(TrVitWeights), _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp,

@@ -23,10 +23,25 @@ namespace {
 __device__ __forceinline__ int kswz(int key, int chunk) { return key * 128 + ((chunk ^ ((key >> 1) & 7)) << 4); }
 __device__ __forceinline__ int swap23(int k) { return (k & ~0xC) | ((k & 4) << 1) | ((k & 8) >> 1); }
 
-template <int NKB>
+// one step of the transpose-reduce over the 32 query lanes of a half-wave: the lane pair (xor BIT) splits the CNT live
+// values between them and adds the partner's copy, so 16 -> 8 -> 4 -> 2 -> 1 values per lane in a fixed summation order
+template <int CNT, int BIT>
+__device__ __forceinline__ void colsum_step(float* v, int ql) {
+  const bool hi = (ql & BIT) != 0;
+#pragma unroll
+  for (int i = 0; i < CNT / 2; ++i) {
+    const float send = hi ? v[i] : v[i + CNT / 2];
+    const float keep = hi ? v[i + CNT / 2] : v[i];
+    v[i] = keep + __shfl_xor(send, BIT, 64);
+  }
+}
+
+// COLSUM: also emit, per (image, head, wave), the column sums over this wave's queries of the softmax matrix -- the token
+// weights K-Medoids needs from the previous block's attention (kmedoids.py:240) -- without materialising B*H*N*N.
+template <int NKB, bool COLSUM>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
-                                                           float* __restrict__ cls_rows, const float* __restrict__ size, int N,
-                                                           int H) {
+                                                           float* __restrict__ cls_rows, const float* __restrict__ size,
+                                                           float* __restrict__ colsum_part, int N, int H) {
   constexpr int RS = NKB * 64 + 16;  // Vt row stride in bytes: odd multiple of 16 -> conflict-free b128 column reads
   __shared__ __attribute__((aligned(16))) unsigned char sK[NKB * 32 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char sVt[64 * RS];
@@ -66,6 +81,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
   const int ql = lane & 31, hh = lane >> 5;
   const int nqb = (N + 31) >> 5;
   const float c_exp = 0.125f * 1.44269504088896340736f;  // dh^-0.5 * log2(e), dh = 64
+  float colacc[NKB];
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb) colacc[kb] = 0.f;
 
   for (int qb = wave; qb < nqb; qb += 4) {
     const int q = qb * 32 + ql;
@@ -142,6 +160,20 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
           *reinterpret_cast<uint2*>(orow + db * 32 + 8 * g) = pk;
         }
     }
+    if (COLSUM) {
+      const float wq = q < N ? inv : 0.f;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = sacc[kb][r] * wq;
+        colsum_step<16, 1>(v, ql);
+        colsum_step<8, 2>(v, ql);
+        colsum_step<4, 4>(v, ql);
+        colsum_step<2, 8>(v, ql);
+        colacc[kb] += v[0] + __shfl_xor(v[0], 16, 64);
+      }
+    }
     if (cls_rows != nullptr && qb == 0 && ql == 0) {
       float* crow = cls_rows + ((size_t)b * H + h) * N;
 #pragma unroll
@@ -153,31 +185,45 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
         }
     }
   }
+  if (COLSUM && (ql & 16) == 0) {
+    // after the transpose-reduce, lane bits (b0,b1,b2,b3) of ql select register r = 8 b0 + 4 b1 + 2 b2 + b3
+    const int r = ((ql & 1) << 3) | ((ql & 2) << 1) | ((ql & 4) >> 1) | ((ql & 8) >> 3);
+    float* crow = colsum_part + (((size_t)b * H + h) * 4 + wave) * N;
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (key < N) crow[key] = colacc[kb];
+    }
+  }
 }
 
 template <int NKB>
-int launch_attention(const uint16_t* qkv, uint16_t* out, float* cls_rows, const float* size, int B, int N, int H, hipStream_t st) {
-  hipLaunchKernelGGL(attention_kernel<NKB>, dim3(B * H), dim3(256), 0, st, qkv, out, cls_rows, size, N, H);
+int launch_attention(const uint16_t* qkv, uint16_t* out, float* cls_rows, const float* size, float* colsum_part, int B, int N, int H,
+                     hipStream_t st) {
+  if (colsum_part)
+    hipLaunchKernelGGL((attention_kernel<NKB, true>), dim3(B * H), dim3(256), 0, st, qkv, out, cls_rows, size, colsum_part, N, H);
+  else
+    hipLaunchKernelGGL((attention_kernel<NKB, false>), dim3(B * H), dim3(256), 0, st, qkv, out, cls_rows, size, colsum_part, N, H);
   return 0;
 }
 
 }  // namespace
 
-extern "C" int tr_attention_bf16(const uint16_t* qkv, uint16_t* out, float* cls_rows, const float* size, int B, int N, int H,
-                                 tr_stream_t s) {
+extern "C" int tr_attention_bf16(const uint16_t* qkv, uint16_t* out, float* cls_rows, const float* size, float* colsum_part, int B,
+                                 int N, int H, tr_stream_t s) {
   TR_REQUIRE(qkv && out, TR_ERR_NULL, "tr_attention_bf16: null pointer");
   TR_REQUIRE(B > 0 && H > 0 && N >= 1, TR_ERR_SHAPE, "tr_attention_bf16: bad shape B=%d N=%d H=%d", B, N, H);
   TR_REQUIRE(N <= 224, TR_ERR_SHAPE, "tr_attention_bf16: N=%d > 224 not supported yet (register-resident score row)", N);
   TR_REQUIRE(tr_aligned16(qkv) && tr_aligned16(out), TR_ERR_ALIGN, "tr_attention_bf16: pointers must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(s);
   switch ((N + 31) / 32) {
-    case 1: launch_attention<1>(qkv, out, cls_rows, size, B, N, H, st); break;
-    case 2: launch_attention<2>(qkv, out, cls_rows, size, B, N, H, st); break;
-    case 3: launch_attention<3>(qkv, out, cls_rows, size, B, N, H, st); break;
-    case 4: launch_attention<4>(qkv, out, cls_rows, size, B, N, H, st); break;
-    case 5: launch_attention<5>(qkv, out, cls_rows, size, B, N, H, st); break;
-    case 6: launch_attention<6>(qkv, out, cls_rows, size, B, N, H, st); break;
-    default: launch_attention<7>(qkv, out, cls_rows, size, B, N, H, st); break;
+    case 1: launch_attention<1>(qkv, out, cls_rows, size, colsum_part, B, N, H, st); break;
+    case 2: launch_attention<2>(qkv, out, cls_rows, size, colsum_part, B, N, H, st); break;
+    case 3: launch_attention<3>(qkv, out, cls_rows, size, colsum_part, B, N, H, st); break;
+    case 4: launch_attention<4>(qkv, out, cls_rows, size, colsum_part, B, N, H, st); break;
+    case 5: launch_attention<5>(qkv, out, cls_rows, size, colsum_part, B, N, H, st); break;
+    case 6: launch_attention<6>(qkv, out, cls_rows, size, colsum_part, B, N, H, st); break;
+    default: launch_attention<7>(qkv, out, cls_rows, size, colsum_part, B, N, H, st); break;
   }
   TR_CHECK_LAUNCH("tr_attention_bf16");
   return TR_OK;

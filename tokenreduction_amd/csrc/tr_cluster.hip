@@ -299,6 +299,71 @@ __global__ __launch_bounds__(256) void cluster_merge_layernorm_kernel(const floa
   }
 }
 
+// ---- K-Medoids (models/kmedoids.py) ---------------------------------------------------------------------------------------
+// w[b][n] = sum_h sum_wave colsum_part[b][h][wave][n], fixed order; [B,N] layout (column 0 = CLS, ignored by the top-K)
+__global__ __launch_bounds__(256) void kmed_weight_kernel(const float* __restrict__ part, float* __restrict__ w, int B, int N, int H) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= B * N) return;
+  const int b = e / N, n = e - b * N;
+  float acc = 0.f;
+  for (int h = 0; h < H; ++h)
+    for (int wv = 0; wv < 4; ++wv) acc += part[(((size_t)b * H + h) * 4 + wv) * N + n];
+  w[e] = acc;
+}
+
+// one wave per row: t_i = sum_j dist[i][j] * w_i   (row sums of weighted_dist_matrix, kmedoids.py:65,77)
+__global__ __launch_bounds__(256) void kmed_rowcost_kernel(const float* __restrict__ dist, const float* __restrict__ w,
+                                                           float* __restrict__ t, int B, int P) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B * P) return;
+  const int b = row / P, i = row - b * P;
+  const float wi = w[(size_t)b * (P + 1) + 1 + i];
+  const float* dr = dist + (size_t)row * P;
+  float acc = 0.f;
+  for (int j = lane; j < P; j += 64) acc += dr[j] * wi;
+  acc = wave_sum(acc);
+  if (lane == 0) t[row] = acc;
+}
+
+__device__ __forceinline__ unsigned long long cost_key(float v, int i) {          // v >= 0: bit order == value order
+  return ((unsigned long long)__float_as_uint(v) << 32) | (unsigned int)i;
+}
+
+// one workgroup per image: iterate {assignment, medoid update}, final assignment
+__global__ __launch_bounds__(256) void kmed_iterate_kernel(const float* __restrict__ dist, const float* __restrict__ t,
+                                                           int32_t* __restrict__ centers, int32_t* __restrict__ assign, int P, int K,
+                                                           int iters) {
+  extern __shared__ unsigned long long s_best[];      // [K] packed (cost, index), then int s_c[K]
+  int* s_c = reinterpret_cast<int*>(s_best + K);
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* db = dist + (size_t)b * P * P;
+  const float* tb = t + (size_t)b * P;
+  for (int k = tid; k < K; k += 256) s_c[k] = centers[(size_t)b * K + k];
+  __syncthreads();
+  const float masked = (float)P * 1000000.0f;         // a row outside cluster k sums to P * 1e6 (kmedoids.py:76-77)
+  for (int it = 0; it <= iters; ++it) {
+    for (int k = tid; k < K; k += 256) s_best[k] = cost_key(masked, 0);
+    __syncthreads();
+    for (int p = tid; p < P; p += 256) {
+      const float* dr = db + (size_t)p * P;
+      float best = INFINITY;
+      int arg = 0;
+      for (int k = 0; k < K; ++k) {                   // argmin over the medoid columns, first minimum
+        const float d = dr[s_c[k]];
+        if (d < best) { best = d; arg = k; }
+      }
+      if (it == iters) assign[(size_t)b * P + p] = arg;
+      else atomicMin(&s_best[arg], cost_key(tb[p], p));       // smallest cost, ties -> smallest index; empty cluster -> index 0
+    }
+    __syncthreads();
+    if (it < iters)
+      for (int k = tid; k < K; k += 256) s_c[k] = (int)(s_best[k] & 0xffffffffull);
+    __syncthreads();
+  }
+  for (int k = tid; k < K; k += 256) centers[(size_t)b * K + k] = s_c[k];
+}
+
 }  // namespace
 
 extern "C" size_t tr_dpcknn_workspace_floats(int B, int N) {
@@ -358,5 +423,34 @@ extern "C" int tr_cluster_merge_layernorm(const float* x, const float* score_w, 
     hipLaunchKernelGGL(cluster_merge_layernorm_kernel<false>, dim3(B * rblocks), dim3(256), 0, st, x, score_w ? w_ws : nullptr,
                        idx_cluster, gamma, beta, x_out, y, N, K, D, eps);
   TR_CHECK_LAUNCH("tr_cluster_merge_layernorm");
+  return TR_OK;
+}
+
+extern "C" int tr_kmedoids(const float* x, const float* colsum_part, float* ws, int32_t* centers, int32_t* assign, int B, int N, int D,
+                           int H, int K, int iters, tr_stream_t s) {
+  TR_REQUIRE(x && colsum_part && ws && centers && assign, TR_ERR_NULL, "tr_kmedoids: null pointer");
+  const int P = N - 1;
+  TR_REQUIRE(B > 0 && H > 0 && P >= 2 && P <= 64 * PER_LANE && D > 0 && D % CK == 0, TR_ERR_SHAPE,
+             "tr_kmedoids: need 2 <= P <= %d and D %% %d == 0 (N=%d D=%d)", 64 * PER_LANE, CK, N, D);
+  TR_REQUIRE(K >= 1 && K <= P && iters >= 0, TR_ERR_SHAPE, "tr_kmedoids: bad K=%d / iters=%d for P=%d", K, iters, P);
+  TR_REQUIRE(tr_aligned16(x) && tr_aligned16(ws), TR_ERR_ALIGN, "tr_kmedoids: pointers must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(s);
+  float* dist = ws;
+  float* nrm = dist + (size_t)B * P * P;
+  float* t = nrm + (size_t)B * P;
+  float* wrow = t + (size_t)B * P;                              // [B,N]
+  const int rows = B * P, rb = (rows + 3) / 4;
+  hipLaunchKernelGGL(kmed_weight_kernel, dim3((B * N + 255) / 256), dim3(256), 0, st, colsum_part, wrow, B, N, H);
+  TR_CHECK_LAUNCH("tr_kmedoids");
+  // cluster_idx = topk(token_weight, K) (kmedoids.py:59); the scores output lands in t and is overwritten below
+  int rc = tr_cls_topk(wrow, centers, nullptr, t, B, 1, N, K, s);
+  if (rc != TR_OK) return rc;
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(rb), dim3(256), 0, st, x, nrm, B, N, D);
+  const int nt = (P + CT - 1) / CT;
+  if (P > 25) hipLaunchKernelGGL(dist_kernel<false>, dim3(nt * nt, B), dim3(256), 0, st, x, nrm, dist, N, D, 1.0f);   // torch.cdist(x, x)
+  else hipLaunchKernelGGL(dist_kernel<true>, dim3(nt * nt, B), dim3(256), 0, st, x, nrm, dist, N, D, 1.0f);
+  hipLaunchKernelGGL(kmed_rowcost_kernel, dim3(rb), dim3(256), 0, st, dist, wrow, t, B, P);
+  hipLaunchKernelGGL(kmed_iterate_kernel, dim3(B), dim3(256), (size_t)K * 12, st, dist, t, centers, assign, P, K, iters);
+  TR_CHECK_LAUNCH("tr_kmedoids");
   return TR_OK;
 }

@@ -75,8 +75,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 // One workgroup per (image, head); one wave per query row at a time.  K is kept TRANSPOSED in LDS (Kt[d][key]) so the lanes
 // of a wave (= keys) read consecutive addresses; V row-major (lane = d for the P.V product).
 __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                            float* __restrict__ cls_rows, const float* __restrict__ size, int N,
-                                                            int H) {
+                                                            float* __restrict__ cls_rows, const float* __restrict__ size,
+                                                            float* __restrict__ colsum_part, int N, int H) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int NP = (N + 63) & ~63;
   float* sKt = sm;                       // [64][NP]
@@ -97,6 +97,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
   }
   __syncthreads();
   const int nkc = NP >> 6;               // key chunks of 64 per lane
+  float colacc[4] = {0.f, 0.f, 0.f, 0.f}; // column sums of the softmax matrix over this wave's queries (kmedoids.py:240)
   for (int q = wave; q < N; q += 4) {
     sQ[wave * 64 + lane] = base[(size_t)q * ldq + qcol + lane];
     __builtin_amdgcn_wave_barrier();
@@ -127,7 +128,10 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
     const float inv = 1.0f / l;
 #pragma unroll
     for (int c = 0; c < 4; ++c)
-      if (c < nkc) sP[wave * NP + c * 64 + lane] = s[c] * inv;     // softmax row (attn = attn.softmax(-1))
+      if (c < nkc) {
+        sP[wave * NP + c * 64 + lane] = s[c] * inv;                // softmax row (attn = attn.softmax(-1))
+        colacc[c] += s[c] * inv;
+      }
     __builtin_amdgcn_wave_barrier();
     float o = 0.f;
     for (int key = 0; key < N; ++key) o = fmaf(sP[wave * NP + key], sV[key * 64 + lane], o);
@@ -140,6 +144,13 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
       }
     }
     __builtin_amdgcn_wave_barrier();
+  }
+  if (colsum_part != nullptr) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int key = c * 64 + lane;
+      if (c < nkc && key < N) colsum_part[(((size_t)b * H + h) * 4 + wave) * N + key] = colacc[c];
+    }
   }
 }
 
@@ -164,8 +175,8 @@ extern "C" int tr_gemm_f32(const float* A, const float* W, const float* bias, fl
   return TR_OK;
 }
 
-extern "C" int tr_attention_f32(const float* qkv, float* out, float* cls_rows, const float* size, int B, int N, int H,
-                                tr_stream_t s) {
+extern "C" int tr_attention_f32(const float* qkv, float* out, float* cls_rows, const float* size, float* colsum_part, int B, int N,
+                                int H, tr_stream_t s) {
   TR_REQUIRE(qkv && out, TR_ERR_NULL, "tr_attention_f32: null pointer");
   TR_REQUIRE(B > 0 && H > 0 && N >= 1 && N <= 256, TR_ERR_SHAPE, "tr_attention_f32: need 1 <= N <= 256 (N=%d)", N);
   const int NP = (N + 63) & ~63;
@@ -173,7 +184,7 @@ extern "C" int tr_attention_f32(const float* qkv, float* out, float* cls_rows, c
   hipStream_t st = static_cast<hipStream_t>(s);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_attention_f32: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-  hipLaunchKernelGGL(attention_f32_kernel, dim3(B * H), dim3(256), lds, st, qkv, out, cls_rows, size, N, H);
+  hipLaunchKernelGGL(attention_f32_kernel, dim3(B * H), dim3(256), lds, st, qkv, out, cls_rows, size, colsum_part, N, H);
   TR_CHECK_LAUNCH("tr_attention_f32");
   return TR_OK;
 }

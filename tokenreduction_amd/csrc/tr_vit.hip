@@ -40,7 +40,7 @@ bool make_plan(const tr_vit_config* c, int B, Plan* p) {
   if (c->patch <= 0 || c->img_size <= 0 || c->img_size % c->patch != 0) return false;
   if (c->depth <= 0 || c->depth > TR_MAX_DEPTH) return false;
   if (c->num_heads <= 0 || c->embed_dim != c->num_heads * 64) return false;
-  if (c->family < TR_FAMILY_DEIT || c->family > TR_FAMILY_SINKHORN) return false;
+  if (c->family < TR_FAMILY_DEIT || c->family > TR_FAMILY_KMEDOIDS) return false;
   const int g = c->img_size / c->patch;
   p->P = g * g;
   p->N0 = p->P + 1;
@@ -69,6 +69,8 @@ bool make_plan(const tr_vit_config* c, int B, Plan* p) {
   p->off_xcls = o;   o += align_up((size_t)B * p->D * es);
   p->off_cluster = o;
   if (c->family == TR_FAMILY_DPCKNN) o += align_up(tr_dpcknn_workspace_floats(B, p->N0) * 4 + (size_t)B * p->N0 * 4);
+  if (c->family == TR_FAMILY_KMEDOIDS)
+    o += align_up(tr_dpcknn_workspace_floats(B, p->N0) * 4) + align_up((size_t)B * p->H * 4 * p->N0 * 4);
   p->total = o;
   return true;
 }
@@ -90,9 +92,10 @@ inline int op_ln(bool f32, float* x, long ldx, const void* d, long ldd, const fl
   return f32 ? tr_layernorm_f32(x, ldx, static_cast<const float*>(d), ldd, g, b, static_cast<float*>(y), M, D, eps, s)
              : tr_layernorm_bf16(x, ldx, static_cast<const uint16_t*>(d), ldd, g, b, static_cast<uint16_t*>(y), M, D, eps, s);
 }
-inline int op_attn(bool f32, const void* qkv, void* out, float* cls_rows, const float* size, int B, int N, int H, tr_stream_t s) {
-  return f32 ? tr_attention_f32(static_cast<const float*>(qkv), static_cast<float*>(out), cls_rows, size, B, N, H, s)
-             : tr_attention_bf16(static_cast<const uint16_t*>(qkv), static_cast<uint16_t*>(out), cls_rows, size, B, N, H, s);
+inline int op_attn(bool f32, const void* qkv, void* out, float* cls_rows, const float* size, float* colsum, int B, int N, int H,
+                   tr_stream_t s) {
+  return f32 ? tr_attention_f32(static_cast<const float*>(qkv), static_cast<float*>(out), cls_rows, size, colsum, B, N, H, s)
+             : tr_attention_bf16(static_cast<const uint16_t*>(qkv), static_cast<uint16_t*>(out), cls_rows, size, colsum, B, N, H, s);
 }
 inline int op_gather(bool f32, const float* x, const void* d, const int32_t* idx, const int32_t* cidx, const float* scores,
                      const float* g, const float* b, float* x_out, void* y, int B, int N, int K, int D, float eps, tr_stream_t s) {
@@ -141,6 +144,9 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
   int32_t* idx_ws = reinterpret_cast<int32_t*>(ws + p.off_idx);
   int32_t* compl_ws = reinterpret_cast<int32_t*>(ws + p.off_compl);
   void* xcls = static_cast<void*>(ws + p.off_xcls);
+  float* colsum_part = cfg->family == TR_FAMILY_KMEDOIDS
+                           ? reinterpret_cast<float*>(ws + p.off_cluster + align_up(tr_dpcknn_workspace_floats(B, p.N0) * 4))
+                           : nullptr;
   float* size_cur = nullptr;                                            // ToMe token sizes: none until the first merge (tome.py:185)
   float* size_a = reinterpret_cast<float*>(ws + p.off_size0);
   float* size_b = reinterpret_cast<float*>(ws + p.off_size1);
@@ -173,6 +179,23 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
       if (noise_in) noise_in += (size_t)B * (N - 1);
       TR_TRY(tr_cluster_merge_layernorm(x, sw->w3, sw->b3, wtok, assign, bw->ln1_g, bw->ln1_b, x_alt, xn, f32 ? 1 : 0, B, N, Kc, D,
                                         cfg->ln_eps, s));
+      float* t = x; x = x_alt; x_alt = t;
+      N = Kc + 1;
+      have_xn = true;
+    }
+    if (cfg->family == TR_FAMILY_KMEDOIDS && cfg->keep[i] > 0) {
+      // a21: KMedoids (kmedoids.py:135-149) on x[:, 1:] BEFORE the block: the medoid tokens replace the patch tokens
+      const int Kc = cfg->keep[i], M = B * N;
+      TR_REQUIRE(i > 0, TR_ERR_CONFIG, "tr_vit_forward: K-Medoids at block 0 has no previous attention to weigh the tokens "
+                                       "(the reference fails there too: `attn` is unbound, kmedoids.py:240)");
+      TR_REQUIRE(Kc <= N - 1, TR_ERR_CONFIG, "tr_vit_forward: block %d asks for %d medoids of %d patch tokens", i, Kc, N - 1);
+      if (pending) TR_TRY(op_ln(f32, x, D, pending, D, bw->ln1_g, bw->ln1_b, xn, M, D, cfg->ln_eps, s));   // x += previous mlp output
+      pending = nullptr;
+      int32_t* centers = kept_idx ? kept_idx + (size_t)i * B * p.N0 : idx_ws;
+      int32_t* assign = compl_idx ? compl_idx + (size_t)i * B * p.N0 : compl_ws;
+      TR_TRY(tr_kmedoids(x, colsum_part, reinterpret_cast<float*>(ws + p.off_cluster), centers, assign, B, N, D, H, Kc,
+                         cfg->cluster_iters, s));
+      TR_TRY(op_gather(f32, x, nullptr, centers, nullptr, nullptr, bw->ln1_g, bw->ln1_b, x_alt, xn, B, N, Kc, D, cfg->ln_eps, s));
       float* t = x; x = x_alt; x_alt = t;
       N = Kc + 1;
       have_xn = true;
@@ -249,7 +272,10 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
     TR_TRY(op_gemm(f32, xn, bw->qkv_w, bw->qkv_b, qkv, nullptr, 0, M, 3 * D, D, TR_EPI_BF16, s));
     // ToMe: log(size) bias on the keys; ATS: key mask as a 1/0 "size" (log 0 = -inf -> exactly zero weight, like
     // masked_fill(-finfo.max) underflowing in the reference's softmax, ats.py:117-120)
-    TR_TRY(op_attn(f32, qkv, ao, (K > 0 || Ks > 0) ? cls_rows : nullptr, (tome || ats) ? size_cur : nullptr, B, N, H, s));
+    // K-Medoids: the NEXT block's clustering is seeded by the column sums of THIS block's attention (kmedoids.py:240)
+    const bool want_colsum = cfg->family == TR_FAMILY_KMEDOIDS && i + 1 < cfg->depth && cfg->keep[i + 1] > 0;
+    TR_TRY(op_attn(f32, qkv, ao, (K > 0 || Ks > 0) ? cls_rows : nullptr, (tome || ats) ? size_cur : nullptr,
+                   want_colsum ? colsum_part : nullptr, B, N, H, s));
     int Nn = N;
     if (Ks > 0) {
       // a16-a18: sample token ids on the CLS attention x |v|, keep those rows of x and of attn @ v

@@ -741,3 +741,55 @@ class SinkhornVisionTransformer(SelfSlimmedVisionTransformer):
         out = super()._viz_data(ws, B, tokens)
         out["Center_Feats"] = {}
         return out
+
+
+class KMedoids(nn.Module):
+    """kmedoids.py:135-149 (no parameters)."""
+
+    def __init__(self, num_clusters, iters, equal_weights=False):
+        super().__init__()
+        self.cluster_count, self.iters, self.equal_weights = num_clusters, iters, equal_weights
+
+
+class KMedoidsVisionTransformer(VisionTransformer):
+    """models/kmedoids.py:152-272: before each block in reduction_loc the patch tokens are clustered by weighted K-Medoids
+    (weights = column sums of the previous block's attention) and replaced by the medoid tokens themselves."""
+    _family = _lib.TR_FAMILY_KMEDOIDS
+
+    def __init__(self, *a, args=None, **kw):
+        super().__init__(*a, args=args, **kw)
+        self.num_patches = self.patch_embed.num_patches
+        self.cluster_loc = list(args.reduction_loc)
+        self.cluster_count = list(args.keep_rate)
+        self.sinkhorn_iters = self.cluster_iters = int(args.cluster_iters)      # cfg.cluster_iters carries it to the executor
+        self.equal_weight = bool(args.equal_weight)
+        if self.equal_weight:
+            raise NotImplementedError("kmedoids with --equal_weight seeds its medoids from numpy's global RNG (kmedoids.py:45-58); "
+                                      "only the attention-weighted branch is built")
+        if len(self.cluster_count) == 1:
+            self.cluster_count = [int(self.num_patches * (args.keep_rate[0] ** (idx + 1))) for idx in range(len(self.cluster_loc))]
+        assert len(self.cluster_count) == len(self.cluster_loc), \
+            f"Mismatch between the cluster location ({self.cluster_loc}) and cluster centers ({self.cluster_count})"
+        self.cluster_count = [int(c) for c in self.cluster_count]
+        if 0 in self.cluster_loc:
+            raise ValueError("kmedoids cannot reduce before block 0: there is no previous attention (kmedoids.py:240)")
+        self.cluster_layers = nn.ModuleList([KMedoids(c, self.cluster_iters, self.equal_weight) for c in self.cluster_count])
+        for c, loc in zip(self.cluster_count, self.cluster_loc):
+            self._keep[loc] = c
+
+    def get_new_module_names(self):
+        return ["cluster_layers"]
+
+    def get_reduction_count(self):
+        return self.cluster_loc
+
+    _stage_shapes = DPCKNNVisionTransformer._stage_shapes
+
+    def _viz_data(self, ws, B, tokens):
+        P1 = self.patch_embed.num_patches + 1
+        kept, assign = ws["kept"].cpu().numpy(), ws["compl"].cpu().numpy()
+        decisions, assignments = {}, {}
+        for blk, K, P in self._stage_shapes():
+            decisions[blk] = kept[blk * B * P1: blk * B * P1 + B * K].reshape(B, K).astype(np.int64)
+            assignments[blk] = assign[blk * B * P1: blk * B * P1 + B * P].reshape(B, P).astype(np.int64)
+        return {"Kept_Tokens": decisions, "Assignment_Maps": assignments, "Center_Feats": {}, "Features": {}}

@@ -79,13 +79,14 @@ def layernorm(x: torch.Tensor, gamma, beta, eps: float, rows: int = None, ldx: i
     return y
 
 
-def attention(qkv: torch.Tensor, B: int, N: int, H: int, want_cls: bool = False, size: torch.Tensor = None):
+def attention(qkv: torch.Tensor, B: int, N: int, H: int, want_cls: bool = False, size: torch.Tensor = None,
+              colsum_part: torch.Tensor = None):
     """softmax(q k^T / 8) v per (image, head) (topk.py:44-51).  qkv bf16 [B*N, 3*H*64] -> (out bf16 [B*N, H*64], cls_rows|None)."""
     out = torch.empty(B * N, H * 64, dtype=torch.bfloat16, device=qkv.device)
     cls_rows = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device) if want_cls else None
     _lib.check(_lib.load().tr_attention_bf16(_dev(qkv, torch.bfloat16, "qkv"), out.data_ptr(),
                                              None if cls_rows is None else cls_rows.data_ptr(), _opt(size, torch.float32, "size"),
-                                             B, N, H, _stream()),
+                                             _opt(colsum_part, torch.float32, "colsum_part"), B, N, H, _stream()),
                "tr_attention_bf16")
     return out, cls_rows
 
@@ -143,12 +144,13 @@ def layernorm_f32(x: torch.Tensor, gamma, beta, eps: float, delta: torch.Tensor 
     return y
 
 
-def attention_f32(qkv: torch.Tensor, B: int, N: int, H: int, want_cls: bool = False, size: torch.Tensor = None):
+def attention_f32(qkv: torch.Tensor, B: int, N: int, H: int, want_cls: bool = False, size: torch.Tensor = None,
+                  colsum_part: torch.Tensor = None):
     out = torch.empty(B * N, H * 64, dtype=torch.float32, device=qkv.device)
     cls_rows = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device) if want_cls else None
     _lib.check(_lib.load().tr_attention_f32(_dev(qkv, torch.float32, "qkv"), out.data_ptr(),
                                             None if cls_rows is None else cls_rows.data_ptr(), _opt(size, torch.float32, "size"),
-                                            B, N, H, _stream()), "tr_attention_f32")
+                                            _opt(colsum_part, torch.float32, "colsum_part"), B, N, H, _stream()), "tr_attention_f32")
     return out, cls_rows
 
 
@@ -303,3 +305,18 @@ def weighted_merge(wt: torch.Tensor, x: torch.Tensor, src: torch.Tensor, K: int)
                                              _dev(src, torch.float32, "src"), x_out.data_ptr(), B, N, K, D, _stream()),
                "tr_weighted_merge")
     return x_out
+
+
+# ---------------------------------------------------------------------------------------- K-Medoids (models/kmedoids.py)
+def kmedoids(x: torch.Tensor, colsum_part: torch.Tensor, K: int, iters: int):
+    """k_medoids_fit (kmedoids.py:40-85, weighted branch): x fp32 [B,N,D], colsum_part fp32 [B,H,4,N] (previous block's attention)
+    -> (centers int32 [B,K], assignment int32 [B,N-1])."""
+    B, N, D = x.shape
+    H = colsum_part.shape[1]
+    lib = _lib.load()
+    ws = torch.empty(lib.tr_dpcknn_workspace_floats(B, N), dtype=torch.float32, device=x.device)
+    centers = torch.empty(B, K, dtype=torch.int32, device=x.device)
+    assign = torch.empty(B, N - 1, dtype=torch.int32, device=x.device)
+    _lib.check(lib.tr_kmedoids(_dev(x, torch.float32, "x"), _dev(colsum_part, torch.float32, "colsum_part"), ws.data_ptr(),
+                               centers.data_ptr(), assign.data_ptr(), B, N, D, H, K, iters, _stream()), "tr_kmedoids")
+    return centers, assign

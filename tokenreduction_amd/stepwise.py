@@ -98,6 +98,7 @@ def forward_stepwise(model: VisionTransformer, x: torch.Tensor, trace: Optional[
     size = None        # ToMe token sizes [B, N] (None until the first merge)
     info["tome"] = {}
     info["soft"] = {}
+    colsum = None      # K-Medoids: per-wave column sums of the previous block's attention
     noise_parts = None
     if cfg.family == 6:       # DPC-KNN: the same density noise the executor would use (model.density_noise or fresh draws)
         model._noise_ptr(B, dev)
@@ -125,6 +126,21 @@ def forward_stepwise(model: VisionTransformer, x: torch.Tensor, trace: Optional[
             h3_, xn = tr.run("cluster_merge_layernorm_kernel", 0.0, 4.0 * M * D + 6.0 * B * (Kc + 1) * D,
                              lambda: ops.cluster_merge_layernorm(h.view(B, N, D), assign, Kc, f32(blk.norm1.weight),
                                                                  f32(blk.norm1.bias), eps, sw, sb))
+            N = Kc + 1
+            h, xn = h3_.view(B * N, D), xn.view(B * N, D)
+        if cfg.family == 9 and int(cfg.keep[i]) > 0:
+            # K-Medoids: medoids of the patch tokens replace them BEFORE the block (kmedoids.py:238-248)
+            Kc, M = int(cfg.keep[i]), B * N
+            if pending is not None:
+                tr.run("layernorm_kernel", 0.0, 12.0 * M * D,
+                       lambda: ops.layernorm(h, f32(blk.norm1.weight), f32(blk.norm1.bias), eps, delta=pending))
+                pending = None
+            centers, assign = tr.run("kmedoids", 2.0 * B * (N - 1) * (N - 1) * D, 8.0 * B * (N - 1) * (N - 1),
+                                     lambda: ops.kmedoids(h.view(B, N, D), colsum, Kc, model.cluster_iters))
+            info["kept"][i], info["compl"][i], info["scores"][i] = centers, assign, colsum.sum(dim=(1, 2))[:, 1:]
+            h3_, xn = tr.run("gather_layernorm_kernel", 0.0, 10.0 * B * (Kc + 1) * D,
+                             lambda: ops.gather_layernorm(h.view(B, N, D), centers, None, None, f32(blk.norm1.weight),
+                                                          f32(blk.norm1.bias), eps))
             N = Kc + 1
             h, xn = h3_.view(B * N, D), xn.view(B * N, D)
         if cfg.family == 8 and int(cfg.keep[i]) > 0:
@@ -197,8 +213,11 @@ def forward_stepwise(model: VisionTransformer, x: torch.Tensor, trace: Optional[
             xn = tr.run("layernorm_kernel", 0.0, (6.0 if pending is None else 12.0) * M * D,
                         lambda: ops.layernorm(h, f32(blk.norm1.weight), f32(blk.norm1.bias), eps, delta=pending))
         qkv = _gemm(tr, xn, bf(blk.attn.qkv.weight), f32(blk.attn.qkv.bias), ops.TR_EPI_BF16, tag="qkv")
+        colsum = None
+        if cfg.family == 9 and i + 1 < len(model.blocks) and int(cfg.keep[i + 1]) > 0:
+            colsum = torch.empty(B, H, 4, N, dtype=torch.float32, device=dev)      # feeds the NEXT block's K-Medoids
         ao, cls_rows = tr.run("attention_kernel", 4.0 * B * H * N * N * 64, 2.0 * M * 4 * D,
-                              lambda: ops.attention(qkv, B, N, H, want_cls=K > 0 or Ks > 0, size=size))
+                              lambda: ops.attention(qkv, B, N, H, want_cls=K > 0 or Ks > 0, size=size, colsum_part=colsum))
         tr.save(f"attn_out_{i}", ao)
         if Ks > 0:
             # ATS: sample ids on CLS attention x |v|, keep those rows of x and of attn @ v (ats.py:52-89,157)
