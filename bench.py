@@ -244,7 +244,13 @@ def main():
             for label, name, kr, loc in (("evit_small kr0.7 (configs[1])", "evit_small_patch16_224", [0.7], [3, 6, 9]),
                                          ("tome_small r16 every block (configs[2])", "tome_small_patch16_224",
                                           [196 - 16 * (i + 1) for i in range(12)], list(range(12))),
-                                         ("topk_small kr0.5 (north_star speed-up target)", MODEL, [0.5], [3, 6, 9])):
+                                         ("topk_small kr0.5 (north_star speed-up target)", MODEL, [0.5], [3, 6, 9]),
+                                         ("dyvit_small kr0.7 (eval path)", "dyvit_small_patch16_224", [0.7], [3, 6, 9]),
+                                         ("sit_small kr0.7", "sit_small_patch16_224", [0.7], [3, 6, 9]),
+                                         ("ats_small kr0.7 (static K padding)", "ats_small_patch16_224", [0.7], [3, 6, 9]),
+                                         ("dpcknn_small kr0.7", "dpcknn_small_patch16_224", [0.7], [3, 6, 9]),
+                                         ("sinkhorn_small kr0.7", "sinkhorn_small_patch16_224", [0.7], [3, 6, 9]),
+                                         ("kmedoids_small kr0.7", "kmedoids_small_patch16_224", [0.7], [3, 6, 9])):
                 m2 = build_model(name, kr, loc, dev)
                 for _ in range(3):
                     m2(x)
