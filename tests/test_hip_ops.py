@@ -593,3 +593,28 @@ def test_kmedoids(ops, B, N, D, H, K, iters):
     # identical unless a distance / cost near-tie (fp32 rounding of the matmul-form cdist) moves a decision
     assert c_eq > 0.98 and a_eq > 0.98, (c_eq, a_eq)
     assert int(centers.min()) >= 0 and int(centers.max()) < N - 1 and int(assign.min()) >= 0 and int(assign.max()) < K
+
+
+# ---------------------------------------------------------------------------------------- long sequences (384^2 inputs)
+@pytest.mark.parametrize("B,N,H", [(2, 577, 12), (1, 577, 3), (2, 225, 2), (1, 300, 1), (1, 608, 2)])
+def test_attention_long(ops, B, N, H):
+    """N > 224: chunked two-pass kernel.  Same contract as test_attention + CLS row, key bias/mask and column sums."""
+    rng = _rng(5000 + N + H)
+    qkv = _bf(_randn(rng, B * N, 3 * H * 64, scale=1.5))
+    size = torch.from_numpy(rng.integers(1, 5, size=(B, N)).astype(np.float32))
+    size[:, N - 7:] = 0                                                          # masked keys (ATS) through the same input
+    size[:, 0] = 1
+    q, k, v = qkv.double().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    for sz in (None, size):
+        logits = (q @ k.transpose(-2, -1)) * 0.125
+        if sz is not None:
+            logits = logits + sz.double().log()[:, None, None, :]
+        attn = logits.softmax(-1)
+        want = (attn @ v).transpose(1, 2).reshape(B * N, H * 64).float()
+        part = torch.full((B, H, 4, N), float("nan"), device="cuda")
+        got, cls = ops.attention(qkv.bfloat16().cuda(), B, N, H, want_cls=True, size=None if sz is None else sz.cuda(), colsum_part=part)
+        torch.testing.assert_close(got.float().cpu(), want, atol=3e-2, rtol=2e-2)
+        torch.testing.assert_close(cls.cpu(), attn[:, :, 0, :].float(), atol=2e-6, rtol=2e-3)
+        torch.testing.assert_close(part.sum(dim=(1, 2)).cpu(), attn.sum(dim=1).sum(dim=1).float(), atol=5e-4, rtol=2e-3)
+        got2, _ = ops.attention(qkv.bfloat16().cuda(), B, N, H, size=None if sz is None else sz.cuda())
+        assert torch.equal(got2, got)                                            # side outputs do not change the main one

@@ -1,4 +1,4 @@
-// Multi-head self-attention for short ViT sequences (N <= 224 tokens, head_dim 64) on gfx950 MFMA.
+// Multi-head self-attention for ViT sequences (N <= 224 tokens register-resident, N <= 608 chunked; head_dim 64) on gfx950 MFMA.
 //
 // Replaces  attn = softmax(q k^T * dh^-0.5); x = attn @ v   (topk.py:44-51 == evit.py:66-73 == deit_viz.py:43-51)
 // and emits the CLS query's softmax row per head (attn[:, :, 0, :], topk.py:59) as a side output, so the
@@ -197,6 +197,177 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
   }
 }
 
+// ---- long sequences (224 < N <= 608, i.e. 384^2 inputs: N = 577) -----------------------------------------------------------
+// Same MFMA scheme, but the score row no longer fits the register file, so the keys are walked in chunks of CH 32-key blocks,
+// twice: pass 1 finds every query's row maximum and normaliser (running max / rescaled sum), pass 2 recomputes the scores,
+// exponentiates against the final maximum and feeds P.V.  Probabilities are therefore final when they are produced, which
+// keeps the CLS-row and column-sum side outputs exact (no retro-active rescaling).  K and V^T of one (image, head) fill the LDS
+// (2 x 77 KB at N = 577): one workgroup per CU.
+constexpr int LCH = 4;   // key blocks per chunk: 64 score registers live
+
+template <bool COLSUM>
+__global__ __launch_bounds__(256, 1) void attention_long_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
+                                                                float* __restrict__ cls_rows, const float* __restrict__ size,
+                                                                float* __restrict__ colsum_part, int N, int H, int NKB) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int RS = NKB * 64 + 16;
+  unsigned char* sK = smem;                               // [NKB*32][128 B] swizzled
+  unsigned char* sVt = sK + (size_t)NKB * 32 * 128;       // [64][RS]
+  float* sLB = reinterpret_cast<float*>(sVt + (size_t)64 * RS);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int ldq = 3 * H * 64;
+  const uint16_t* base = qkv + (size_t)b * N * ldq;
+  const int qcol = h * 64, kcol = H * 64 + h * 64, vcol = 2 * H * 64 + h * 64;
+  for (int g = tid; g < NKB * 32 * 8; g += 256) {
+    const int key = g >> 3, c = g & 7;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (key < N) v = *reinterpret_cast<const uint4*>(base + (size_t)key * ldq + kcol + c * 8);
+    *reinterpret_cast<uint4*>(sK + kswz(key, c)) = v;
+  }
+  for (int u = wave; u < NKB * 4; u += 4) {
+    const int kb = u >> 2, c = 2 * (u & 3) + (lane >> 5);
+    const int kl = lane & 31, key = kb * 32 + kl;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (key < N) v = *reinterpret_cast<const uint4*>(base + (size_t)key * ldq + vcol + c * 8);
+    unsigned short* dst = reinterpret_cast<unsigned short*>(sVt + (size_t)(8 * c) * RS + (kb * 32 + swap23(kl)) * 2);
+    const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned int word = w[e >> 1];
+      dst[(e * RS) >> 1] = (unsigned short)((e & 1) ? (word >> 16) : (word & 0xffffu));
+    }
+  }
+  for (int key = tid; key < NKB * 32; key += 256)
+    sLB[key] = (size != nullptr && key < N) ? __builtin_amdgcn_logf(size[(size_t)b * N + key]) : 0.f;
+  __syncthreads();
+
+  const int ql = lane & 31, hh = lane >> 5;
+  const int nqb = (N + 31) >> 5;
+  const float c_exp = 0.125f * 1.44269504088896340736f;
+  const int r_own = ((ql & 1) << 3) | ((ql & 2) << 1) | ((ql & 4) >> 1) | ((ql & 8) >> 3);   // register this lane owns after the reduce
+  float* colrow = COLSUM ? colsum_part + (((size_t)b * H + h) * 4 + wave) * N : nullptr;
+  if (COLSUM && (ql & 16) == 0)                                     // zeroed by the lanes that accumulate below (same-thread ordering)
+    for (int kb = 0; kb < NKB; ++kb) {
+      const int key = kb * 32 + (r_own & 3) + 8 * (r_own >> 2) + 4 * hh;
+      if (key < N) colrow[key] = 0.f;
+    }
+
+  for (int qb = wave; qb < nqb; qb += 4) {
+    const int q = qb * 32 + ql;
+    const uint16_t* qrow = base + (size_t)min(q, N - 1) * ldq + qcol + 8 * hh;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qrow + 16 * s);
+
+    auto scores = [&](int kb0, f32x16* sacc) __attribute__((always_inline)) {
+#pragma unroll
+      for (int c = 0; c < LCH; ++c) {
+        const int kb = kb0 + c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[c][r] = 0.f;
+        if (kb < NKB) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + kswz(kb * 32 + ql, 2 * s + hh));
+            sacc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[c], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          sacc[c][r] = key < N ? sacc[c][r] * c_exp + sLB[min(key, NKB * 32 - 1)] : -INFINITY;
+        }
+      }
+    };
+
+    // ---- pass 1: row maximum and normaliser
+    float mx = -INFINITY, l = 0.f;
+    for (int kb0 = 0; kb0 < NKB; kb0 += LCH) {
+      f32x16 sacc[LCH];
+      scores(kb0, sacc);
+      float cm = mx;
+#pragma unroll
+      for (int c = 0; c < LCH; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cm = fmaxf(cm, sacc[c][r]);
+      cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+      float add = 0.f;
+#pragma unroll
+      for (int c = 0; c < LCH; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) add += __builtin_amdgcn_exp2f(sacc[c][r] - cm);
+      l = l * __builtin_amdgcn_exp2f(mx - cm) + add;     // mx = -inf on the first chunk: exp2(-inf) = 0
+      mx = cm;
+    }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    const float wq = q < N ? inv : 0.f;
+
+    // ---- pass 2: P = exp2(S - mx), O^T = Vt P^T
+    f32x16 o[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+    for (int kb0 = 0; kb0 < NKB; kb0 += LCH) {
+      f32x16 sacc[LCH];
+      scores(kb0, sacc);
+#pragma unroll
+      for (int c = 0; c < LCH; ++c) {
+        const int kb = kb0 + c;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[c][r] = __builtin_amdgcn_exp2f(sacc[c][r] - mx);
+        if (kb < NKB) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            bf16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = (__bf16)sacc[c][8 * s + j];
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+              const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sVt + (size_t)(db * 32 + ql) * RS + (kb * 32 + 16 * s + 8 * hh) * 2);
+              o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
+            }
+          }
+          if (cls_rows != nullptr && qb == 0 && ql == 0) {
+            float* crow = cls_rows + ((size_t)b * H + h) * N;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+              if (key < N) crow[key] = sacc[c][r] * inv;
+            }
+          }
+          if (COLSUM) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = sacc[c][r] * wq;
+            colsum_step<16, 1>(v, ql);
+            colsum_step<8, 2>(v, ql);
+            colsum_step<4, 4>(v, ql);
+            colsum_step<2, 8>(v, ql);
+            const float tot = v[0] + __shfl_xor(v[0], 16, 64);
+            const int key = kb * 32 + (r_own & 3) + 8 * (r_own >> 2) + 4 * hh;
+            if ((ql & 16) == 0 && key < N) colrow[key] += tot;       // one owner lane per key, query blocks in order: deterministic
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (q < N) {
+      uint16_t* orow = out + ((size_t)b * N + q) * (H * 64) + h * 64 + 4 * hh;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          uint2 pk;
+          pk.x = pack_bf16x2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
+          pk.y = pack_bf16x2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+          *reinterpret_cast<uint2*>(orow + db * 32 + 8 * g) = pk;
+        }
+    }
+  }
+}
+
 template <int NKB>
 int launch_attention(const uint16_t* qkv, uint16_t* out, float* cls_rows, const float* size, float* colsum_part, int B, int N, int H,
                      hipStream_t st) {
@@ -213,9 +384,23 @@ extern "C" int tr_attention_bf16(const uint16_t* qkv, uint16_t* out, float* cls_
                                  int N, int H, tr_stream_t s) {
   TR_REQUIRE(qkv && out, TR_ERR_NULL, "tr_attention_bf16: null pointer");
   TR_REQUIRE(B > 0 && H > 0 && N >= 1, TR_ERR_SHAPE, "tr_attention_bf16: bad shape B=%d N=%d H=%d", B, N, H);
-  TR_REQUIRE(N <= 224, TR_ERR_SHAPE, "tr_attention_bf16: N=%d > 224 not supported yet (register-resident score row)", N);
+  TR_REQUIRE(N <= 608, TR_ERR_SHAPE, "tr_attention_bf16: N=%d > 608 not supported (K and V^T of one head must fit the LDS)", N);
   TR_REQUIRE(tr_aligned16(qkv) && tr_aligned16(out), TR_ERR_ALIGN, "tr_attention_bf16: pointers must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(s);
+  if (N > 224) {
+    const int nkb = (N + 31) / 32;
+    const size_t lds = (size_t)nkb * 32 * 128 + (size_t)64 * (nkb * 64 + 16) + (size_t)nkb * 32 * 4;
+    const void* fn = colsum_part ? reinterpret_cast<const void*>(attention_long_kernel<true>)
+                                 : reinterpret_cast<const void*>(attention_long_kernel<false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_attention_bf16: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+    if (colsum_part)
+      hipLaunchKernelGGL(attention_long_kernel<true>, dim3(B * H), dim3(256), lds, st, qkv, out, cls_rows, size, colsum_part, N, H, nkb);
+    else
+      hipLaunchKernelGGL(attention_long_kernel<false>, dim3(B * H), dim3(256), lds, st, qkv, out, cls_rows, size, colsum_part, N, H, nkb);
+    TR_CHECK_LAUNCH("tr_attention_bf16");
+    return TR_OK;
+  }
   switch ((N + 31) / 32) {
     case 1: launch_attention<1>(qkv, out, cls_rows, size, colsum_part, B, N, H, st); break;
     case 2: launch_attention<2>(qkv, out, cls_rows, size, colsum_part, B, N, H, st); break;
