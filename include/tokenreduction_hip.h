@@ -119,7 +119,7 @@ int tr_gemm_f32(const float* A, const float* W, const float* bias, float* out, c
  *   (bf16, fp32 when lp_is_f32).
  * tr_sinkhorn: log_optimal_transport (sinkhorn.py:41-56) per image on scores fp32 [B,N,ldl] (row 0 = CLS ignored; columns
  *   0..K-1 = token . centre): wt (may alias scores) gets the transport plan token-major [B,N,ldl], soft (nullable) the same
- *   cluster-major [B,K,N-1] (Soft_Assignment_Maps).  K*(N-1) floats must fit LDS.
+ *   cluster-major [B,K,N-1] (Soft_Assignment_Maps).  K*(N-1) floats stay in LDS when they fit, else in the scores buffer.
  * tr_weighted_merge: x_out[b,1+k,:] = sum_p wt[b,1+p,k] * src[b,1+p,:]; x_out[b,0] = x[b,0]   (sinkhorn.py:83 with
  *   src = unit-norm tokens). */
 int tr_pool_broadcast(void* h, int is_f32, int B, int N, int C, float eps, tr_stream_t s);

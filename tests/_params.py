@@ -169,6 +169,16 @@ GOLDEN_CASES = {
     "sit_small_kr07": dict(family="sit", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
                            keep_rate=[0.7], reduction_loc=[3, 6, 9], batch=2, wseed=113, xseed=114,
                            qkv_gain=4.0, factory="sit_small_patch16_224"),
+    # 384x384 inputs (BASELINE configs[4] geometry, N = 577): chunked attention, Sinkhorn with K*P beyond the LDS, K-Medoids / ATS
+    # side outputs of the long kernel.  Top-K keeps int(ratio*196) tokens even here (196 is hard-coded, topk.py:56).
+    "topk_micro_384": dict(family="topk", embed_dim=128, depth=4, num_heads=2, num_classes=16, img_size=384,
+                           keep_rate=[0.5], reduction_loc=[1, 2, 3], batch=2, wseed=161, xseed=162, qkv_gain=6.0),
+    "sinkhorn_micro_384": dict(family="sinkhorn", embed_dim=128, depth=4, num_heads=2, num_classes=16, img_size=384,
+                               keep_rate=[0.25], reduction_loc=[1, 2, 3], batch=2, wseed=163, xseed=164, qkv_gain=6.0),
+    "kmedoids_micro_384": dict(family="kmedoids", embed_dim=128, depth=4, num_heads=2, num_classes=16, img_size=384,
+                               keep_rate=[0.25], reduction_loc=[1, 2, 3], batch=2, wseed=165, xseed=166, qkv_gain=6.0),
+    "ats_micro_384": dict(family="ats", embed_dim=128, depth=4, num_heads=2, num_classes=16, img_size=384,
+                          keep_rate=[0.25], reduction_loc=[1, 2, 3], batch=2, wseed=167, xseed=168, qkv_gain=6.0),
     "deit_small": dict(family="deit", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
                        keep_rate=[1.0], reduction_loc=[], batch=2, wseed=81, xseed=82,
                        qkv_gain=4.0, factory="deit_small_patch16_224_local"),
@@ -185,7 +195,7 @@ def case_params(case: dict):
 
 def case_config(case: dict):
     from oracle import VitConfig
-    return VitConfig(family=case["family"], embed_dim=case["embed_dim"], depth=case["depth"],
+    return VitConfig(family=case["family"], img_size=case.get("img_size", 224), embed_dim=case["embed_dim"], depth=case["depth"],
                      num_heads=case["num_heads"], num_classes=case["num_classes"],
                      keep_rate=list(case["keep_rate"]), reduction_loc=list(case["reduction_loc"]))
 

@@ -146,12 +146,13 @@ def build_reference(case):
             m = create_model(case["factory"], pretrained=False, num_classes=case["num_classes"], drop_rate=0.0,
                              drop_path_rate=0.0, drop_block_rate=None, img_size=224, args=args)
         else:
-            kw = dict(patch_size=16, embed_dim=case["embed_dim"], depth=case["depth"], num_heads=case["num_heads"],
+            kw = dict(img_size=case.get("img_size", 224), patch_size=16, embed_dim=case["embed_dim"], depth=case["depth"], num_heads=case["num_heads"],
                       mlp_ratio=4, qkv_bias=True, num_classes=case["num_classes"], args=args)
             m = CLASSES[case["family"]](**kw)
     m.viz_mode = True
     cfg = types.SimpleNamespace(embed_dim=case["embed_dim"], depth=case["depth"], num_heads=case["num_heads"],
-                                mlp_ratio=4, num_classes=case["num_classes"], img_size=224, patch_size=16, in_chans=3)
+                                mlp_ratio=4, num_classes=case["num_classes"], img_size=case.get("img_size", 224), patch_size=16,
+                                in_chans=3)
     params = make_params(cfg, case["wseed"], case.get("qkv_gain", 1.0))
     params.update(make_stage_params(case_config(case), case))
     missing, unexpected = m.load_state_dict(params, strict=True)
@@ -161,7 +162,7 @@ def build_reference(case):
 
 def run_case(name, case):
     m, _ = build_reference(case)
-    x = make_images(case["batch"], 224, case["xseed"])
+    x = make_images(case["batch"], case.get("img_size", 224), case["xseed"])
     torch.manual_seed(case["xseed"])
     with TopkSpy() as spy, ArgsortSpy() as aspy, RandSpy() as rspy, CdistSpy() as cspy, torch.no_grad():
         out = m(x)

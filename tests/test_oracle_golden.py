@@ -22,7 +22,7 @@ def test_model_matches_reference(golden_dir, name):
     g = _load(golden_dir, name)
     cfg = case_config(case)
     params = make_params(cfg, case["wseed"], case.get("qkv_gain", 1.0))
-    x = make_images(case["batch"], 224, case["xseed"])
+    x = make_images(case["batch"], case.get("img_size", 224), case["xseed"])
     if case["family"] == "tome":
         logits, viz = oracle.tome_forward(params, x, cfg, return_viz=True)
         akeys = sorted(k for k in g.files if k.startswith("assign_"))

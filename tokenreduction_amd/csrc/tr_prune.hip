@@ -243,6 +243,53 @@ __global__ __launch_bounds__(256) void sinkhorn_kernel(const float* __restrict__
   }
 }
 
+// Same iterations when K*P floats exceed the LDS (384^2 inputs: 144 x 576): Z stays in the token-major scores buffer
+// (L2/MALL resident, 332 KB per image); u-step = one thread per centre walking the tokens (lanes along k: coalesced),
+// v-step = one wave per token.
+__global__ __launch_bounds__(256) void sinkhorn_global_kernel(const float* __restrict__ scores, int ldl, float eps, int iters,
+                                                              float* __restrict__ wt, float* __restrict__ soft, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) float s_uv[];     // u[K], v[P]
+  const int P = N - 1;
+  float* s_u = s_uv;
+  float* s_v = s_uv + K;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x;
+  const float* sc = scores + ((size_t)b * N + 1) * ldl;
+  for (int p = tid; p < P; p += 256) s_v[p] = 0.f;
+  for (int k = tid; k < K; k += 256) s_u[k] = 0.f;
+  const float norm = -logf((float)K + (float)P);
+  __syncthreads();
+  for (int it = 0; it < iters; ++it) {
+    for (int k = tid; k < K; k += 256) {
+      float m = -INFINITY;
+      for (int p = 0; p < P; ++p) m = fmaxf(m, sc[(size_t)p * ldl + k] / eps + s_v[p]);
+      float t = 0.f;
+      for (int p = 0; p < P; ++p) t += expf(sc[(size_t)p * ldl + k] / eps + s_v[p] - m);
+      s_u[k] = norm - (m + logf(t));
+    }
+    __syncthreads();
+    for (int p = wave; p < P; p += 4) {
+      const float* zr = sc + (size_t)p * ldl;
+      float m = -INFINITY;
+      for (int k = lane; k < K; k += 64) m = fmaxf(m, zr[k] / eps + s_u[k]);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+      float t = 0.f;
+      for (int k = lane; k < K; k += 64) t += expf(zr[k] / eps + s_u[k] - m);
+      t = wave_sum(t);
+      if (lane == 0) s_v[p] = norm - (m + logf(t));
+    }
+    __syncthreads();
+  }
+  float* wb = wt + ((size_t)b * N + 1) * ldl;
+  for (int e = tid; e < K * P; e += 256) {
+    const int p = e / K, k = e - p * K;
+    const float w = expf(sc[(size_t)p * ldl + k] / eps + s_u[k] + s_v[p] - norm);   // read-then-write by the same thread: wt may alias scores
+    wb[(size_t)p * ldl + k] = w;
+    if (soft != nullptr) soft[((size_t)b * K + k) * P + p] = w;
+  }
+}
+
 }  // namespace
 
 extern "C" int tr_pool_broadcast(void* h, int is_f32, int B, int N, int C, float eps, tr_stream_t s) {
@@ -312,8 +359,13 @@ extern "C" int tr_sinkhorn(const float* scores, int ldl, float eps, int iters, f
   TR_REQUIRE(B > 0 && N >= 2 && K >= 1 && ldl >= K && iters >= 0 && eps > 0.f, TR_ERR_SHAPE,
              "tr_sinkhorn: bad arguments B=%d N=%d K=%d ldl=%d iters=%d eps=%g", B, N, K, ldl, iters, (double)eps);
   const size_t lds = ((size_t)K * (N - 1) + K + (N - 1)) * sizeof(float);
-  TR_REQUIRE(lds <= 158 * 1024, TR_ERR_SHAPE, "tr_sinkhorn: K*P = %d*%d floats do not fit LDS (%zu B > 158 KiB)", K, N - 1, lds);
   hipStream_t st = static_cast<hipStream_t>(s);
+  if (lds > 158 * 1024) {
+    hipLaunchKernelGGL(sinkhorn_global_kernel, dim3(B), dim3(256), (size_t)(K + N - 1) * sizeof(float), st, scores, ldl, eps, iters, wt,
+                       soft, N, K);
+    TR_CHECK_LAUNCH("tr_sinkhorn");
+    return TR_OK;
+  }
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sinkhorn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_sinkhorn: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
   hipLaunchKernelGGL(sinkhorn_kernel, dim3(B), dim3(256), lds, st, scores, ldl, eps, iters, wt, soft, N, K);
