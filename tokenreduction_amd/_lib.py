@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libtokenreduction_hip.so")
+# TOKENREDUCTION_HIP_LIB: load another build of the same library (kernel experiments, tools/attn_lab.py); same ABI required
+LIB_PATH = os.environ.get("TOKENREDUCTION_HIP_LIB") or os.path.join(_HERE, "csrc", "libtokenreduction_hip.so")
 
 TR_MAX_DEPTH = 32
 TR_EPI_BF16, TR_EPI_GELU_BF16, TR_EPI_RESID_F32, TR_EPI_F32, TR_EPI_PATCH_F32 = 0, 1, 2, 3, 4
