@@ -52,6 +52,14 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
   const int ldq = 3 * H * 64;
   const uint16_t* base = qkv + (size_t)b * N * ldq;
   const int qcol = h * 64, kcol = H * 64 + h * 64, vcol = 2 * H * 64 + h * 64;
+#ifdef TR_ATT_STAMPS   // diagnostic build (tools/attn_stamps.py): clock64 stamps of the first query block go to cls_rows
+  long long stamp[8];
+  int nst = 0;
+#define TR_STAMP() do { if (nst < 8) stamp[nst++] = clock64(); } while (0)
+  TR_STAMP();
+#else
+#define TR_STAMP() do { } while (0)
+#endif
 
   // ---- stage K (row-major, swizzled); keys >= N are zero rows
   for (int g = tid; g < NKB * 32 * 8; g += 256) {
@@ -77,6 +85,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
   for (int key = tid; key < NKB * 32; key += 256)
     sLB[key] = (size != nullptr && key < N) ? __builtin_amdgcn_logf(size[(size_t)b * N + key]) : 0.f;   // v_log_f32 = log2
   __syncthreads();
+  TR_STAMP();
 
   const int ql = lane & 31, hh = lane >> 5;
   const int nqb = (N + 31) >> 5;
@@ -91,6 +100,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
     bf16x8 qf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qrow + 16 * s);
+#ifdef TR_ATT_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    TR_STAMP();
 
     f32x16 sacc[NKB];
 #pragma unroll
@@ -104,6 +117,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
       }
       __builtin_amdgcn_sched_barrier(0);  // keep K-fragment reads per key block: bounds live registers
     }
+    TR_STAMP();
     // ---- softmax over keys (rows of S^T): registers of this lane + the other half-wave
     float mx = -INFINITY;
 #pragma unroll
@@ -129,6 +143,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
 
+    TR_STAMP();
     // ---- O^T = Vt P^T
     f32x16 o[2];
 #pragma unroll
@@ -148,6 +163,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
         __builtin_amdgcn_sched_barrier(0);
       }
 
+    TR_STAMP();
     if (q < N) {
       uint16_t* orow = out + ((size_t)b * N + q) * (H * 64) + h * 64 + 4 * hh;
 #pragma unroll
@@ -160,6 +176,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
           *reinterpret_cast<uint2*>(orow + db * 32 + 8 * g) = pk;
         }
     }
+    TR_STAMP();
     if (COLSUM) {
       const float wq = q < N ? inv : 0.f;
 #pragma unroll
@@ -174,6 +191,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
         colacc[kb] += v[0] + __shfl_xor(v[0], 16, 64);
       }
     }
+#ifndef TR_ATT_STAMPS
     if (cls_rows != nullptr && qb == 0 && ql == 0) {
       float* crow = cls_rows + ((size_t)b * H + h) * N;
 #pragma unroll
@@ -184,7 +202,14 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
           if (key < N) crow[key] = sacc[kb][r] * inv;
         }
     }
+#endif
   }
+#ifdef TR_ATT_STAMPS
+  if (lane == 0 && cls_rows != nullptr) {
+    long long* dbg = reinterpret_cast<long long*>(cls_rows) + ((size_t)blockIdx.x * 4 + wave) * 8;
+    for (int i = 0; i < 8; ++i) dbg[i] = i < nst ? stamp[i] - stamp[0] : -1;
+  }
+#endif
   if (COLSUM && (ql & 16) == 0) {
     // after the transpose-reduce, lane bits (b0,b1,b2,b3) of ql select register r = 8 b0 + 4 b1 + 2 b2 + b3
     const int r = ((ql & 1) << 3) | ((ql & 2) << 1) | ((ql & 4) >> 1) | ((ql & 8) >> 3);
