@@ -130,6 +130,10 @@ int tr_weighted_merge(const float* wt, int ldl, const float* x, const float* src
 int tr_dyvit_score(const void* h, int is_f32, const float* w, const float* bias, float* scores, int M, int C, tr_stream_t s);
 int tr_sit_merge(const float* logits, int ldl, float scale, const float* x, float* x_out, float* soft, int B, int N, int K,
                  int D, tr_stream_t s);
+/* tr_sit_merge with the summed rows taken from `src` fp32 [B,N,D] instead of x (PatchMerger sums the LayerNorm-ed tokens,
+ * patchmerger.py:36-39); the CLS row still comes from x. */
+int tr_softassign_merge(const float* logits, int ldl, float scale, const float* x, const float* src, float* x_out, float* soft,
+                        int B, int N, int K, int D, tr_stream_t s);
 /* ---- DPC-KNN (csrc/tr_cluster.hip) --------------------------------------------------------------------------------------
  * tr_dpcknn_cluster: cluster_dpc_knn dpcknn.py:44-100 (token_mask=None) on the patch rows of x fp32 [B,N,D] (row 0 = CLS,
  *   ignored): centers int32 [B,K] = topk(score, K) in descending-score order (index_down), idx_cluster int32 [B,N-1],
@@ -194,6 +198,7 @@ int tr_tome_merge_layernorm(const float* x, const void* delta, int f32_path, con
                               token bound of the block's output; padded rows are masked keys) */
 #define TR_FAMILY_SINKHORN 8 /* models/sinkhorn.py: optimal-transport soft assignment to learned centres BEFORE the block */
 #define TR_FAMILY_KMEDOIDS 9 /* models/kmedoids.py: weighted K-Medoids on the patch tokens BEFORE the block, medoids kept */
+#define TR_FAMILY_PATCHMERGER 10 /* models/patchmerger.py: K learned queries attend over the normalised tokens BEFORE the block */
 #define TR_FAMILY_DPCKNN 6 /* models/dpcknn.py: DPC-KNN clustering + weighted merge BEFORE the block; keep[blk] = clusters */
 #define TR_MAX_DEPTH 32
 #define TR_PREC_BF16 0   /* the product path: bf16 MFMA operands, fp32 accumulate / residual / statistics */
@@ -214,6 +219,8 @@ typedef struct {
  *     w2/b2 = out_conv.2 [D/4,D/2], w3/b3 = out_conv.4 [2,D/4] (fp32 in both precisions).
  *   SiT TokenSlimmingModule (sit.py:29-34): ln = weight.0 (eps 1e-5), w0/b0 = weight.1 [D/2,D], w1/b1 = weight.3 zero-padded
  *     to n_pad rows ([n_pad, D/2], n_pad = K rounded up to 8), scale = the module's scalar.
+ *   PatchMerger (patchmerger.py:32-33): ln = norm (eps 1e-5), w1 = queries zero-padded to n_pad rows [n_pad, D], b1 = zeros,
+ *     scale = 1 (embed_dim**-0.5 with scaled_attention).
  *   Sinkhorn (sinkhorn.py:62,73-76): w1 = F.normalize(v) zero-padded to n_pad rows [n_pad, D], b1 = zeros [n_pad].
  *   ATS (ats.py:48): w3 = sample_steps fp32 [n_pad], n_pad = their count (K-1).
  *   DPC-KNN CTM (dpcknn.py:150-151): w3/b3 = score.weight [1,D] / score.bias [1] (fp32); NULL = args.equal_weight. */

@@ -137,3 +137,39 @@ def sit_forward(params: Dict[str, Tensor], x: Tensor, cfg: VitConfig, precision:
         viz["Final_Tokens"] = h
         return logits, viz
     return logits
+
+
+# =========================================================================================== PatchMerger
+def patchmerger_merge(x_sp: Tensor, p: Dict[str, Tensor], j: int, precision: str = "fp32", scale: float = 1.0):
+    """PatchMerger.forward patchmerger.py:35-39: LayerNorm (eps 1e-5), similarity of K learned queries to every token, softmax
+    over the TOKENS, output = attention-weighted sum of the NORMALISED tokens.  Returns (x [B,K,D], attn [B,K,P])."""
+    pre = f"cluster_layers.{j}."
+    xn = torch.nn.functional.layer_norm(x_sp, (x_sp.shape[-1],), p[pre + "norm.weight"], p[pre + "norm.bias"], LN_EPS_DEFAULT)
+    sim = torch.matmul(_r(p[pre + "queries"], precision), _r(xn, precision).transpose(-1, -2)) * scale
+    attn = sim.softmax(dim=-1)
+    return torch.matmul(attn, xn), attn
+
+
+@torch.no_grad()
+def patchmerger_forward(params: Dict[str, Tensor], x: Tensor, cfg: VitConfig, precision: str = "fp32", return_viz: bool = False):
+    """PatchMergerVisionTransformer.forward patchmerger.py:98-150, eval mode (cluster counts as SiT, patchmerger.py:78-79)."""
+    p = params
+    tok = patch_embed(x, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], cfg.patch_size, precision)
+    h = embed_tokens(tok, p["cls_token"], p["pos_embed"])
+    counts = sit_cluster_counts(cfg)
+    viz = {"Assignment_Maps": {}, "Soft_Assignment_Maps": {}, "Tokens": {}}
+    j = 0
+    for i in range(cfg.depth):
+        if i in counts:
+            xs, w = patchmerger_merge(h[:, 1:], p, j, precision)
+            h = torch.cat([h[:, :1], xs], dim=1)
+            viz["Soft_Assignment_Maps"][i] = w.numpy()
+            viz["Assignment_Maps"][i] = torch.argmax(w, dim=-2).numpy()        # patchmerger.py:122
+            j += 1
+        h, _, _ = block_forward(h, p, i, cfg, None, precision)
+        viz["Tokens"][i] = h.shape[1]
+    logits = head(h, p["norm.weight"], p["norm.bias"], p["head.weight"], p["head.bias"], cfg.ln_eps, precision)
+    if return_viz:
+        viz["Final_Tokens"] = h
+        return logits, viz
+    return logits

@@ -70,6 +70,14 @@ def make_stage_params(cfg, case: dict):
         for j in range(n_stages):
             p[f"cluster_layers.{j}.score.weight"] = _normal(rng, (1, D), 0.05)
             p[f"cluster_layers.{j}.score.bias"] = _normal(rng, (1,), 0.02)
+    elif fam == "patchmerger":
+        from oracle.prune_before import sit_cluster_counts
+        counts = sit_cluster_counts(cfg)
+        for j, loc in enumerate(case["reduction_loc"]):
+            b = f"cluster_layers.{j}."
+            p[b + "norm.weight"] = 1.0 + _normal(rng, (D,), 0.1)
+            p[b + "norm.bias"] = _normal(rng, (D,), 0.05)
+            p[b + "queries"] = _normal(rng, (counts[loc], D), 0.15)
     elif fam == "sinkhorn":
         from oracle.cluster import dpcknn_cluster_counts
         counts = dpcknn_cluster_counts(cfg)
@@ -163,6 +171,12 @@ GOLDEN_CASES = {
     "sinkhorn_small_kr07": dict(family="sinkhorn", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
                                 keep_rate=[0.7], reduction_loc=[3, 6, 9], batch=2, wseed=143, xseed=144,
                                 qkv_gain=4.0, factory="sinkhorn_small_patch16_224"),
+    # PatchMerger (models/patchmerger.py): learned queries attend over the normalised tokens BEFORE the block
+    "patchmerger_micro": dict(family="patchmerger", embed_dim=128, depth=4, num_heads=2, num_classes=16,
+                              keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=171, xseed=172, qkv_gain=6.0),
+    "patchmerger_small_kr07": dict(family="patchmerger", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
+                                   keep_rate=[0.7], reduction_loc=[3, 6, 9], batch=2, wseed=173, xseed=174,
+                                   qkv_gain=4.0, factory="patchmerger_small_patch16_224"),
     # SiT (models/sit.py): soft assignment (softmax over tokens) BEFORE the block
     "sit_micro": dict(family="sit", embed_dim=128, depth=4, num_heads=2, num_classes=16,
                       keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=111, xseed=112, qkv_gain=6.0),

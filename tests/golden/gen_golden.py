@@ -45,11 +45,12 @@ from models.dpcknn import DPCKNNVisionTransformer  # noqa: E402
 from models.ats import ATSVisionTransformer  # noqa: E402
 from models.sinkhorn import SinkhornVisionTransformer  # noqa: E402
 from models.kmedoids import KMedoidsVisionTransformer  # noqa: E402
+from models.patchmerger import PatchMergerVisionTransformer  # noqa: E402
 
 from tests._params import GOLDEN_CASES, make_params, make_stage_params, make_images, case_config  # noqa: E402
 
 CLASSES = {"topk": TopKVisionTransformer, "evit": EfficientVisionTransformer, "deit": DeitViz, "tome": ToMeVisionTransformer,
-           "dyvit": DynamicVisionTransformer, "sit": SelfSlimmedVisionTransformer, "dpcknn": DPCKNNVisionTransformer, "ats": ATSVisionTransformer, "sinkhorn": SinkhornVisionTransformer, "kmedoids": KMedoidsVisionTransformer}
+           "dyvit": DynamicVisionTransformer, "sit": SelfSlimmedVisionTransformer, "dpcknn": DPCKNNVisionTransformer, "ats": ATSVisionTransformer, "sinkhorn": SinkhornVisionTransformer, "kmedoids": KMedoidsVisionTransformer, "patchmerger": PatchMergerVisionTransformer}
 
 
 class TopkSpy:

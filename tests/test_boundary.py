@@ -34,7 +34,7 @@ def test_registry_has_every_reference_name():
 
 def test_unbuilt_families_fail_loudly():
     with pytest.raises(NotImplementedError):
-        tra.create_model("patchmerger_small_patch16_224", args=_args(keep_rate=[0.7], reduction_loc=[3, 6, 9]))
+        tra.create_model("heuristic_small_patch16_224", args=_args(keep_rate=[0.7], reduction_loc=[3, 6, 9]))
 
 
 @pytest.mark.parametrize("name,dims", [("topk_tiny_patch16_224", (192, 3)), ("evit_small_patch16_224", (384, 6)),

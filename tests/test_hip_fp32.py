@@ -132,11 +132,11 @@ def test_model_fp32_matches_reference_golden(golden_dir, name):
     akeys = sorted((k for k in g.files if k.startswith("assign_")), key=lambda k: int(k.split("_")[1]))
     if case["family"] in ("dpcknn", "kmedoids"):
         akeys = []
-    if case["family"] in ("tome", "sit", "sinkhorn"):
+    if case["family"] in ("tome", "sit", "sinkhorn", "patchmerger"):
         assert sorted(viz["Assignment_Maps"].keys()) == [int(k.split("_")[1]) for k in akeys]
     for k in akeys:                                         # ToMe: every merge decision of every stage, bit-exact
         blk = int(k.split("_")[1])
-        if case["family"] in ("sit", "sinkhorn"):           # soft assignment to 1e-5 of its max; hard = argmax where no near-tie
+        if case["family"] in ("sit", "sinkhorn", "patchmerger"):   # soft assignment to 1e-5 of its max; hard = argmax where no near-tie
             soft = viz["Soft_Assignment_Maps"][blk]
             np.testing.assert_allclose(soft[:, :8], g[f"soft_{blk}"], atol=2e-6, rtol=1e-4)
             if float(g[f"soft_margin_{blk}"]) > 1e-5:

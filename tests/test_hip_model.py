@@ -28,7 +28,7 @@ from tests._params import GOLDEN_CASES, case_config, case_params, make_images, m
 pytestmark = pytest.mark.gpu
 
 FAM = {"deit": "VisionTransformer", "topk": "TopKVisionTransformer", "evit": "EfficientVisionTransformer",
-       "tome": "ToMeVisionTransformer", "dyvit": "DynamicVisionTransformer", "sit": "SelfSlimmedVisionTransformer", "dpcknn": "DPCKNNVisionTransformer", "ats": "ATSVisionTransformer", "sinkhorn": "SinkhornVisionTransformer", "kmedoids": "KMedoidsVisionTransformer"}
+       "tome": "ToMeVisionTransformer", "dyvit": "DynamicVisionTransformer", "sit": "SelfSlimmedVisionTransformer", "dpcknn": "DPCKNNVisionTransformer", "ats": "ATSVisionTransformer", "sinkhorn": "SinkhornVisionTransformer", "kmedoids": "KMedoidsVisionTransformer", "patchmerger": "PatchMergerVisionTransformer"}
 
 
 def build_model(case):
@@ -91,7 +91,7 @@ def test_model_parity(golden_dir, name):
 
     if case["family"] == "tome":
         return _tome_parity(name, case, g, model, params, cfg, x, logits, viz, info)
-    if case["family"] in ("sit", "sinkhorn"):
+    if case["family"] in ("sit", "sinkhorn", "patchmerger"):
         return _sit_parity(name, case, g, model, params, cfg, x, logits, viz, info)
     if case["family"] in ("dpcknn", "kmedoids"):
         return _dpcknn_parity(name, case, g, model, params, cfg, x, logits, viz, info, noise)
@@ -241,7 +241,7 @@ def _sit_parity(name, case, g, model, params, cfg, x, logits, viz, info):
         blk = int(k.split("_")[1])
         got = viz["Soft_Assignment_Maps"][blk]
         assert viz["Assignment_Maps"][blk].shape == g[k].shape and viz["Assignment_Maps"][blk].dtype == np.int64
-        if case["family"] == "sit":
+        if case["family"] in ("sit", "patchmerger"):
             np.testing.assert_allclose(got.sum(axis=2), 1.0, atol=1e-5)         # softmax over the token axis
         else:                                                                   # Sinkhorn plan: column marginals ~ (K+P)/(K+P) = 1
             K_, P_ = got.shape[1], got.shape[2]

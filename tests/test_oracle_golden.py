@@ -34,7 +34,7 @@ def test_model_matches_reference(golden_dir, name):
         for blk, n in zip(g["token_count_blocks"], g["token_counts"]):
             assert viz["Tokens"][int(blk)] == int(n)
         return
-    if case["family"] in ("dyvit", "sit", "sinkhorn"):
+    if case["family"] in ("dyvit", "sit", "sinkhorn", "patchmerger"):
         return _check_prune_before(case, g, x)
     if case["family"] == "dpcknn":
         return _check_dpcknn(case, g, x)

@@ -6,6 +6,7 @@ runs in hand-written HIP kernels behind the C ABI in include/tokenreduction_hip.
 from .registry import create_model, register_model, list_models, is_model  # noqa: F401
 from .models import (VisionTransformer, TopKVisionTransformer, EfficientVisionTransformer, ToMeVisionTransformer,  # noqa: F401
                      DynamicVisionTransformer, SelfSlimmedVisionTransformer, DPCKNNVisionTransformer,
-                     ATSVisionTransformer, SinkhornVisionTransformer, KMedoidsVisionTransformer)
+                     ATSVisionTransformer, SinkhornVisionTransformer, KMedoidsVisionTransformer,
+                     PatchMergerVisionTransformer)
 
 __version__ = "0.1.0"

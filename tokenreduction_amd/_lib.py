@@ -15,7 +15,8 @@ LIB_PATH = os.environ.get("TOKENREDUCTION_HIP_LIB") or os.path.join(_HERE, "csrc
 TR_MAX_DEPTH = 32
 TR_EPI_BF16, TR_EPI_GELU_BF16, TR_EPI_RESID_F32, TR_EPI_F32, TR_EPI_PATCH_F32 = 0, 1, 2, 3, 4
 TR_FAMILY_DEIT, TR_FAMILY_TOPK, TR_FAMILY_EVIT, TR_FAMILY_TOME, TR_FAMILY_DYVIT, TR_FAMILY_SIT, \
-    TR_FAMILY_DPCKNN, TR_FAMILY_ATS, TR_FAMILY_SINKHORN, TR_FAMILY_KMEDOIDS = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9
+    TR_FAMILY_DPCKNN, TR_FAMILY_ATS, TR_FAMILY_SINKHORN, TR_FAMILY_KMEDOIDS, \
+    TR_FAMILY_PATCHMERGER = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 TR_PREC_BF16, TR_PREC_FP32 = 0, 1
 
 _vp, _i, _f, _l, _sz = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t
@@ -64,6 +65,7 @@ SIGNATURES = {
     "tr_pool_broadcast": (_i, [_vp, _i, _i, _i, _i, _f, _vp]),
     "tr_dyvit_score": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "tr_sit_merge": (_i, [_vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "tr_softassign_merge": (_i, [_vp, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tr_rownorm": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "tr_sinkhorn": (_i, [_vp, _i, _f, _i, _vp, _vp, _i, _i, _i, _vp]),
     "tr_weighted_merge": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -315,12 +315,20 @@ extern "C" int tr_dyvit_score(const void* h, int is_f32, const float* w, const f
   return TR_OK;
 }
 
+extern "C" int tr_softassign_merge(const float* logits, int ldl, float scale, const float* x, const float* src, float* x_out,
+                                   float* soft, int B, int N, int K, int D, tr_stream_t s);
+
 extern "C" int tr_sit_merge(const float* logits, int ldl, float scale, const float* x, float* x_out, float* soft, int B, int N,
                             int K, int D, tr_stream_t s) {
-  TR_REQUIRE(logits && x && x_out, TR_ERR_NULL, "tr_sit_merge: null pointer");
+  return tr_softassign_merge(logits, ldl, scale, x, x, x_out, soft, B, N, K, D, s);
+}
+
+extern "C" int tr_softassign_merge(const float* logits, int ldl, float scale, const float* x, const float* src, float* x_out,
+                                   float* soft, int B, int N, int K, int D, tr_stream_t s) {
+  TR_REQUIRE(logits && x && src && x_out, TR_ERR_NULL, "tr_sit_merge: null pointer");
   TR_REQUIRE(B > 0 && N >= 2 && K >= 1 && D >= 1 && D <= 256 * SJ_MAX && ldl >= K, TR_ERR_SHAPE,
              "tr_sit_merge: bad shape B=%d N=%d K=%d D=%d ldl=%d (D <= %d)", B, N, K, D, ldl, 256 * SJ_MAX);
-  TR_REQUIRE(x_out != x, TR_ERR_SHAPE, "tr_sit_merge: needs a distinct x_out");
+  TR_REQUIRE(x_out != x && x_out != src, TR_ERR_SHAPE, "tr_sit_merge: needs a distinct x_out");
   const size_t lds = (size_t)(N - 1) * SKC * sizeof(float);
   TR_REQUIRE(lds <= 150 * 1024, TR_ERR_SHAPE, "tr_sit_merge: %d tokens need %zu B of LDS (max 150 KiB)", N - 1, lds);
   hipStream_t st = static_cast<hipStream_t>(s);
@@ -330,7 +338,7 @@ extern "C" int tr_sit_merge(const float* logits, int ldl, float scale, const flo
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sit_merge_kernel<J, true>),                                  \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
     TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_sit_merge: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));       \
-    hipLaunchKernelGGL((sit_merge_kernel<J, true>), grid, dim3(256), lds, st, logits, ldl, scale, x, x, x_out, soft, N, K, D);    \
+    hipLaunchKernelGGL((sit_merge_kernel<J, true>), grid, dim3(256), lds, st, logits, ldl, scale, x, src, x_out, soft, N, K, D);  \
   } while (0)
   switch ((D + 255) / 256) {
     case 1: TR_SIT_LAUNCH(1); break;

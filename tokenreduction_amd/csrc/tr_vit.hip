@@ -40,7 +40,7 @@ bool make_plan(const tr_vit_config* c, int B, Plan* p) {
   if (c->patch <= 0 || c->img_size <= 0 || c->img_size % c->patch != 0) return false;
   if (c->depth <= 0 || c->depth > TR_MAX_DEPTH) return false;
   if (c->num_heads <= 0 || c->embed_dim != c->num_heads * 64) return false;
-  if (c->family < TR_FAMILY_DEIT || c->family > TR_FAMILY_KMEDOIDS) return false;
+  if (c->family < TR_FAMILY_DEIT || c->family > TR_FAMILY_PATCHMERGER) return false;
   const int g = c->img_size / c->patch;
   p->P = g * g;
   p->N0 = p->P + 1;
@@ -199,6 +199,25 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
       float* t = x; x = x_alt; x_alt = t;
       N = Kc + 1;
       have_xn = true;
+    }
+    if (cfg->family == TR_FAMILY_PATCHMERGER && cfg->keep[i] > 0) {
+      // f4: PatchMerger.forward patchmerger.py:35-39 on x[:, 1:] BEFORE the block
+      const tr_stage_weights* sw = &w->stage[i];
+      const int Kc = cfg->keep[i], M = B * N;
+      TR_REQUIRE(Kc <= N - 1, TR_ERR_CONFIG, "tr_vit_forward: block %d asks for %d outputs of %d patch tokens", i, Kc, N - 1);
+      TR_REQUIRE(sw->ln_g && sw->ln_b && sw->w1 && sw->b1 && sw->n_pad >= Kc && sw->n_pad % 8 == 0 &&
+                     (size_t)sw->n_pad * 4 <= (size_t)p.Hd * (f32 ? 4 : 2),
+                 TR_ERR_CONFIG, "tr_vit_forward: block %d PatchMerger weights missing or n_pad=%d invalid for K=%d", i, sw->n_pad, Kc);
+      float* xh = static_cast<float*>(qkv);                       // LayerNorm-ed tokens, fp32 [M, D]
+      float* sc = static_cast<float*>(hbuf);                      // similarities [M, n_pad]
+      TR_TRY(op_ln(f32, x, D, pending, D, sw->ln_g, sw->ln_b, xn, M, D, 1e-5f, s));        // x += previous mlp output; GEMM operand
+      pending = nullptr;
+      TR_TRY(tr_layernorm_f32(x, D, nullptr, D, sw->ln_g, sw->ln_b, xh, M, D, 1e-5f, s));  // the rows that are summed
+      TR_TRY(op_gemm(f32, xn, sw->w1, sw->b1, sc, nullptr, 0, M, sw->n_pad, D, TR_EPI_F32, s));
+      TR_TRY(tr_softassign_merge(sc, sw->n_pad, sw->scale, x, xh, x_alt, soft_out, B, N, Kc, D, s));
+      if (soft_out) soft_out += (size_t)B * Kc * (N - 1);
+      float* t = x; x = x_alt; x_alt = t;
+      N = Kc + 1;
     }
     if (cfg->family == TR_FAMILY_SINKHORN && cfg->keep[i] > 0) {
       // a22: Sinkhorn.forward sinkhorn.py:66-86 on x[:, 1:] BEFORE the block

@@ -793,3 +793,52 @@ class KMedoidsVisionTransformer(VisionTransformer):
             decisions[blk] = kept[blk * B * P1: blk * B * P1 + B * K].reshape(B, K).astype(np.int64)
             assignments[blk] = assign[blk * B * P1: blk * B * P1 + B * P].reshape(B, P).astype(np.int64)
         return {"Kept_Tokens": decisions, "Assignment_Maps": assignments, "Center_Feats": {}, "Features": {}}
+
+
+class PatchMerger(nn.Module):
+    """Parameter holder (patchmerger.py:24-33)."""
+
+    def __init__(self, embed_dim, cluster_centers, scaled_attention=False):
+        super().__init__()
+        self.scale = embed_dim ** -0.5 if scaled_attention else 1.
+        self.norm = _ln_default(embed_dim)
+        self.queries = nn.Parameter(torch.randn(cluster_centers, embed_dim))
+
+
+class PatchMergerVisionTransformer(SelfSlimmedVisionTransformer):
+    """models/patchmerger.py:42-150: before each block in reduction_loc, K learned queries attend over the LayerNorm-ed patch
+    tokens (softmax over the tokens) and the outputs are the attention-weighted sums of the normalised tokens."""
+    _family = _lib.TR_FAMILY_PATCHMERGER
+
+    def __init__(self, *a, args=None, **kw):
+        VisionTransformer.__init__(self, *a, args=args, **kw)
+        self.cluster_loc = list(args.reduction_loc)
+        self.cluster_count = list(args.keep_rate)
+        P0 = self.patch_embed.num_patches
+        if len(self.cluster_count) == 1:
+            self.cluster_count = [int(P0 * (args.keep_rate[0] ** (idx + 1))) for idx in range(len(self.cluster_loc))]   # patchmerger.py:78-79
+        assert len(self.cluster_count) == len(self.cluster_loc), \
+            f"Mismatch between the cluster location ({self.cluster_loc}) and cluster centers ({self.cluster_count})"
+        self.cluster_count = [int(c) for c in self.cluster_count]
+        self.cluster_layers = nn.ModuleList([PatchMerger(self.embed_dim, c) for c in self.cluster_count])
+        for m in self.cluster_layers.modules():
+            _init_vit_weights(m)
+        for c, loc in zip(self.cluster_count, self.cluster_loc):
+            self._keep[loc] = c
+
+    def _pack_stages(self, W, w16, f32, keep_alive):
+        for j, loc in enumerate(self.cluster_loc):
+            m, st = self.cluster_layers[j], W.stage[loc]
+            K = self.cluster_count[j]
+            n_pad = (K + 7) // 8 * 8
+            w1 = torch.zeros(n_pad, self.embed_dim, dtype=torch.float32, device=m.queries.device)
+            w1[:K] = m.queries.detach()
+            st.ln_g, st.ln_b = f32(m.norm.weight), f32(m.norm.bias)
+            st.w1, st.b1 = w16(w1), f32(torch.zeros(n_pad, dtype=torch.float32, device=w1.device))
+            st.scale = float(m.scale)
+            st.n_pad = n_pad
+
+    def _viz_data(self, ws, B, tokens):
+        out = super()._viz_data(ws, B, tokens)
+        out["Center_Feats"] = {}
+        return out

@@ -143,6 +143,25 @@ def forward_stepwise(model: VisionTransformer, x: torch.Tensor, trace: Optional[
                                                           f32(blk.norm1.bias), eps))
             N = Kc + 1
             h, xn = h3_.view(B * N, D), xn.view(B * N, D)
+        if cfg.family == 10 and int(cfg.keep[i]) > 0:
+            # PatchMerger: K learned queries attend over the normalised tokens BEFORE the block (patchmerger.py:35-39)
+            Kc, M = int(cfg.keep[i]), B * N
+            j = model.cluster_loc.index(i)
+            m = model.cluster_layers[j]
+            y = tr.run("layernorm_kernel", 0.0, (6.0 if pending is None else 12.0) * M * D,
+                       lambda: ops.layernorm(h, f32(m.norm.weight), f32(m.norm.bias), 1e-5, delta=pending))
+            pending = None
+            xh = tr.run("layernorm_kernel", 0.0, 8.0 * M * D, lambda: ops.layernorm_f32(h, f32(m.norm.weight), f32(m.norm.bias), 1e-5))
+            n_pad = (Kc + 7) // 8 * 8
+            w1 = torch.zeros(n_pad, D, dtype=torch.float32, device=dev)
+            w1[:Kc] = m.queries.detach()
+            lg = _gemm(tr, y, bf(w1), torch.zeros(n_pad, dtype=torch.float32, device=dev), ops.TR_EPI_F32, tag="pm")
+            h3_, soft = tr.run("sit_merge_kernel", 2.0 * B * Kc * (N - 1) * D, 4.0 * B * (N + Kc) * D,
+                               lambda: ops.sit_merge(lg.view(B, N, n_pad), float(m.scale), h.view(B, N, D), Kc, want_soft=tr.keep,
+                                                     src=xh.view(B, N, D)))
+            info["soft"][i] = soft
+            N = Kc + 1
+            h = h3_.view(B * N, D)
         if cfg.family == 8 and int(cfg.keep[i]) > 0:
             # Sinkhorn: soft assignment to unit-norm centres BEFORE the block (sinkhorn.py:66-86)
             Kc, M = int(cfg.keep[i]), B * N
