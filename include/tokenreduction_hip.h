@@ -139,7 +139,9 @@ int tr_softassign_merge(const float* logits, int ldl, float scale, const float* 
  *   ignored): centers int32 [B,K] = topk(score, K) in descending-score order (index_down), idx_cluster int32 [B,N-1],
  *   scores fp32 [B,N-1] (distance-to-denser-token * density).  noise (nullable) fp32 [B,N-1]: the uniform [0,1) draws the
  *   reference adds * 1e-6 to the densities (dpcknn.py:71-72); NULL = none.  k = nearest neighbours (args.k_neighbors).
- *   ws: tr_dpcknn_workspace_floats(B,N) floats of scratch.
+ *   ws: tr_dpcknn_workspace_floats(B,N) floats of scratch.  fast_dist != 0 (also tr_kmedoids): the Gram product of the
+ *   distance matrix runs on MFMA with hi/lo-split bf16 operands (relative error ~2^-16) instead of fp32 VALU -- what the bf16
+ *   executor uses; 0 = the reference's fp32 arithmetic (validation executor).
  * tr_cluster_merge_layernorm: merge_tokens dpcknn.py:103-132 with token_weight = exp(x . score_w + score_b) (CTM, :155-157;
  *   score_w NULL = equal weights), then LayerNorm(gamma, beta, eps) of the merged tokens: x_out fp32 [B,K+1,D] (row 0 = CLS
  *   copied), y = LN(x_out) bf16 (fp32 when y_is_f32).  w_ws: [B,N-1] floats of scratch (token weights).
@@ -150,9 +152,9 @@ int tr_softassign_merge(const float* logits, int ldl, float scale, const float* 
  *   centers int32 [B,K] (cluster_idx), assign int32 [B,N-1].  ws: tr_dpcknn_workspace_floats(B,N) floats. */
 size_t tr_dpcknn_workspace_floats(int B, int N);
 int tr_kmedoids(const float* x, const float* colsum_part, float* ws, int32_t* centers, int32_t* assign, int B, int N, int D, int H,
-                int K, int iters, tr_stream_t s);
+                int K, int iters, int fast_dist, tr_stream_t s);
 int tr_dpcknn_cluster(const float* x, const float* noise, float* ws, int32_t* centers, int32_t* idx_cluster, float* scores,
-                      int B, int N, int D, int K, int k, tr_stream_t s);
+                      int B, int N, int D, int K, int k, int fast_dist, tr_stream_t s);
 int tr_cluster_merge_layernorm(const float* x, const float* score_w, const float* score_b, float* w_ws,
                                const int32_t* idx_cluster, const float* gamma, const float* beta, float* x_out, void* y,
                                int y_is_f32, int B, int N, int K, int D, float eps, tr_stream_t s);

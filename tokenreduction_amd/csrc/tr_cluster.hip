@@ -95,8 +95,108 @@ __global__ __launch_bounds__(256) void dist_kernel(const float* __restrict__ x, 
   }
 }
 
+// ---- fast-path distances: Gram product on MFMA with every fp32 operand split into bf16 hi + bf16 lo
+// (x.y ~= hi.hi' + hi.lo' + lo.hi': relative error ~2^-16, against 2^-9 for a plain bf16 product).  Used by the bf16
+// executor, whose token features already carry bf16-level noise from the GEMMs upstream; the fp32 validation executor keeps
+// the exact VALU kernel above.  128x128 tile per workgroup, 64x64 per wave, v_mfma_f32_16x16x32_bf16, D walked in 32-wide
+// slabs with the next slab's global loads in flight under the current slab's MFMAs.
+constexpr int GT = 256, GK = 32, GLD = 40;     // tile, slab depth, LDS row stride in bf16 (80 B: conflict-free 16-B fragment reads)
+
+__device__ __forceinline__ void split_store(const float4 v, unsigned short* hi, unsigned short* lo) {
+  const float f[4] = {v.x, v.y, v.z, v.w};
+  unsigned int h2[2], l2[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const unsigned int hp = pack_bf16x2(f[2 * q], f[2 * q + 1]);
+    const float r0 = f[2 * q] - __uint_as_float(hp << 16), r1 = f[2 * q + 1] - __uint_as_float(hp & 0xffff0000u);
+    h2[q] = hp;
+    l2[q] = pack_bf16x2(r0, r1);
+  }
+  *reinterpret_cast<uint2*>(hi) = make_uint2(h2[0], h2[1]);
+  *reinterpret_cast<uint2*>(lo) = make_uint2(l2[0], l2[1]);
+}
+
+// 512 threads = 4x2 waves of 64x64: a 256 x 128 tile per workgroup (two workgroups cover an image at 224^2 inputs, so a token
+// row is read ~1.5 times per launch instead of 4 times with 128 x 128 tiles -- the kernel is bound by those fp32 reads).
+constexpr int GTN = 128;
+__global__ __launch_bounds__(512) void dist_mfma_kernel(const float* __restrict__ x, const float* __restrict__ nrm,
+                                                        float* __restrict__ dist, int N, int D, float sqrt_d) {
+  __shared__ __attribute__((aligned(16))) unsigned short sAh[GT * GLD], sAl[GT * GLD], sBh[GTN * GLD], sBl[GTN * GLD];
+  const int P = N - 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int frow = lane & 15, fq = lane >> 4;
+  const int ntj = (P + GTN - 1) / GTN;
+  const int i0 = (blockIdx.x / ntj) * GT, j0 = (blockIdx.x % ntj) * GTN;
+  const int b = blockIdx.y;
+  const float* xb = x + ((size_t)b * N + 1) * D;
+  const int lr = tid >> 1, lc = (tid & 1) * 16;                      // A staging: row lr (0..255), 16 consecutive floats
+  const int br = tid >> 2, bc = (tid & 3) * 8;                       // B staging: row br (0..127), 8 consecutive floats
+  const float* ap = xb + (size_t)min(i0 + lr, P - 1) * D + lc;
+  const float* bp = xb + (size_t)min(j0 + br, P - 1) * D + bc;
+  float4 ra[4], rb[2];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) ra[q] = *reinterpret_cast<const float4*>(ap + 4 * q);
+#pragma unroll
+  for (int q = 0; q < 2; ++q) rb[q] = *reinterpret_cast<const float4*>(bp + 4 * q);
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool active = i0 + wm * 64 < P && j0 + wn * 64 < P;          // else this wave's 64x64 block lies outside the matrix
+  for (int k0 = 0; k0 < D; k0 += GK) {
+    __syncthreads();                                                 // previous slab's fragment reads are done
+#pragma unroll
+    for (int q = 0; q < 4; ++q) split_store(ra[q], sAh + lr * GLD + lc + 4 * q, sAl + lr * GLD + lc + 4 * q);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) split_store(rb[q], sBh + br * GLD + bc + 4 * q, sBl + br * GLD + bc + 4 * q);
+    if (k0 + GK < D) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) ra[q] = *reinterpret_cast<const float4*>(ap + k0 + GK + 4 * q);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) rb[q] = *reinterpret_cast<const float4*>(bp + k0 + GK + 4 * q);
+    }
+    __syncthreads();
+    if (!active) continue;
+    bf16x8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      ah[t] = *reinterpret_cast<const bf16x8*>(sAh + (wm * 64 + t * 16 + frow) * GLD + fq * 8);
+      al[t] = *reinterpret_cast<const bf16x8*>(sAl + (wm * 64 + t * 16 + frow) * GLD + fq * 8);
+      bh[t] = *reinterpret_cast<const bf16x8*>(sBh + (wn * 64 + t * 16 + frow) * GLD + fq * 8);
+      bl[t] = *reinterpret_cast<const bf16x8*>(sBl + (wn * 64 + t * 16 + frow) * GLD + fq * 8);
+    }
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        // small terms first, then the dominant one
+        acc[bb][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[bb], ah[a], acc[bb][a], 0, 0, 0);
+        acc[bb][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[bb], al[a], acc[bb][a], 0, 0, 0);
+        acc[bb][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[bb], ah[a], acc[bb][a], 0, 0, 0);
+      }
+  }
+  // acc[bb][a][e] = x_i . x_j with i = i0 + wm*64 + a*16 + frow, j = j0 + wn*64 + bb*16 + 4*fq + e
+  const float* nb = nrm + (size_t)b * P;
+  float* db = dist + (size_t)b * P * P;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int gi = i0 + wm * 64 + a * 16 + frow;
+    if (gi >= P) continue;
+    const float ni = nb[gi];
+#pragma unroll
+    for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int gj = j0 + wn * 64 + bb * 16 + 4 * fq + e;
+        if (gj < P) db[(size_t)gi * P + gj] = sqrtf(fmaxf((ni + nb[gj]) - 2.0f * acc[bb][a][e], 1e-30f)) / sqrt_d;
+      }
+  }
+}
+
 constexpr int KNN_MAX = 8;
-constexpr int PER_LANE = 16;      // P <= 1024
+constexpr int MAX_PER_LANE = 16;  // P <= 1024
 
 __device__ __forceinline__ void wave_min_pair(float& v, int& i) {
 #pragma unroll
@@ -107,14 +207,15 @@ __device__ __forceinline__ void wave_min_pair(float& v, int& i) {
   }
 }
 
-// one wave per row: density = exp(-mean(k smallest d^2)) + noise*1e-6; per-image max distance via atomicMax on the bits
+// one wave per row: density = exp(-mean(k smallest d^2)) + noise*1e-6; per-image max distance via atomicMax on the bits.
+// PER_LANE = row elements held per lane (4: P <= 256, the 224^2 case; 16: P <= 1024)
+template <int PER_LANE>
 __global__ __launch_bounds__(256) void density_kernel(const float* __restrict__ dist, const float* __restrict__ noise,
-                                                      float* __restrict__ density, int* __restrict__ dmax_bits, int B, int P,
+                                                      float* __restrict__ density, float* __restrict__ rowmax, int B, int P,
                                                       int k) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= B * P) return;
-  const int b = row / P;
   const float* dr = dist + (size_t)row * P;
   float v[PER_LANE];
   float mx = 0.f;
@@ -126,7 +227,7 @@ __global__ __launch_bounds__(256) void density_kernel(const float* __restrict__ 
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-  if (lane == 0) atomicMax(&dmax_bits[b], __float_as_int(mx));          // distances are >= 0: int order == float order
+  if (lane == 0) rowmax[row] = mx;                                       // reduced per image by parent_score_kernel (no atomics)
   float ss = 0.f;
   for (int t = 0; t < k; ++t) {                                          // ascending extraction = torch.topk(largest=False) order
     float best = INFINITY;
@@ -146,7 +247,7 @@ __global__ __launch_bounds__(256) void density_kernel(const float* __restrict__ 
 // one wave per row: distance to the nearest token of higher density (else the image's max distance); score = that * density,
 // written in [B,N] layout (column 0 = CLS slot, unused) for tr_cls_topk
 __global__ __launch_bounds__(256) void parent_score_kernel(const float* __restrict__ dist, const float* __restrict__ density,
-                                                           const int* __restrict__ dmax_bits, float* __restrict__ score_rows, int B,
+                                                           const float* __restrict__ rowmax, float* __restrict__ score_rows, int B,
                                                            int P) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -154,7 +255,10 @@ __global__ __launch_bounds__(256) void parent_score_kernel(const float* __restri
   const int b = row / P, i = row - b * P;
   const float* dr = dist + (size_t)row * P;
   const float* db = density + (size_t)b * P;
-  const float dmax = __int_as_float(dmax_bits[b]);
+  float dmax = 0.f;                                                      // dist_matrix.flatten(1).max(): max of the row maxima
+  for (int j = lane; j < P; j += 64) dmax = fmaxf(dmax, rowmax[(size_t)b * P + j]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o, 64));
   const float di = db[i];
   float mn = INFINITY;
   for (int j = lane; j < P; j += 64) mn = fminf(mn, db[j] > di ? dr[j] : dmax);
@@ -371,12 +475,26 @@ extern "C" size_t tr_dpcknn_workspace_floats(int B, int N) {
   return (size_t)B * P * P + (size_t)B * (3 * P + N) + 64 + (size_t)B;
 }
 
+static void launch_dist(bool fast, const float* x, const float* nrm, float* dist, int B, int N, int D, float sqrt_d, hipStream_t st) {
+  const int P = N - 1;
+  if (P <= 25) {                       // torch.cdist's exact form for tiny inputs
+    const int nt = (P + CT - 1) / CT;
+    hipLaunchKernelGGL(dist_kernel<true>, dim3(nt * nt, B), dim3(256), 0, st, x, nrm, dist, N, D, sqrt_d);
+  } else if (fast && D % GK == 0) {
+    const int nti = (P + GT - 1) / GT, ntj = (P + GTN - 1) / GTN;
+    hipLaunchKernelGGL(dist_mfma_kernel, dim3(nti * ntj, B), dim3(512), 0, st, x, nrm, dist, N, D, sqrt_d);
+  } else {
+    const int nt = (P + CT - 1) / CT;
+    hipLaunchKernelGGL(dist_kernel<false>, dim3(nt * nt, B), dim3(256), 0, st, x, nrm, dist, N, D, sqrt_d);
+  }
+}
+
 extern "C" int tr_dpcknn_cluster(const float* x, const float* noise, float* ws, int32_t* centers, int32_t* idx_cluster,
-                                 float* scores, int B, int N, int D, int K, int k, tr_stream_t s) {
+                                 float* scores, int B, int N, int D, int K, int k, int fast_dist, tr_stream_t s) {
   TR_REQUIRE(x && ws && centers && idx_cluster && scores, TR_ERR_NULL, "tr_dpcknn_cluster: null pointer");
   const int P = N - 1;
-  TR_REQUIRE(B > 0 && P >= 2 && P <= 64 * PER_LANE && D > 0 && D % CK == 0, TR_ERR_SHAPE,
-             "tr_dpcknn_cluster: need 2 <= P <= %d and D %% %d == 0 (N=%d D=%d)", 64 * PER_LANE, CK, N, D);
+  TR_REQUIRE(B > 0 && P >= 2 && P <= 64 * MAX_PER_LANE && D > 0 && D % CK == 0, TR_ERR_SHAPE,
+             "tr_dpcknn_cluster: need 2 <= P <= %d and D %% %d == 0 (N=%d D=%d)", 64 * MAX_PER_LANE, CK, N, D);
   TR_REQUIRE(K >= 1 && K <= P && k >= 1 && k <= KNN_MAX && k <= P, TR_ERR_SHAPE, "tr_dpcknn_cluster: bad K=%d / k=%d for P=%d", K, k, P);
   TR_REQUIRE(tr_aligned16(x) && tr_aligned16(ws), TR_ERR_ALIGN, "tr_dpcknn_cluster: pointers must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(s);
@@ -384,16 +502,13 @@ extern "C" int tr_dpcknn_cluster(const float* x, const float* noise, float* ws, 
   float* nrm = dist + (size_t)B * P * P;
   float* density = nrm + (size_t)B * P;
   float* score_rows = density + (size_t)B * P;                  // [B,N]
-  int* dmax = reinterpret_cast<int*>(score_rows + (size_t)B * N + 16);
-  hipError_t e = hipMemsetAsync(dmax, 0, sizeof(int) * B, st);
-  TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_dpcknn_cluster: memset failed: %s", hipGetErrorString(e));
+  float* rowmax = nrm;                                            // the norms are dead once the distances exist
   const int rows = B * P, rb = (rows + 3) / 4;
   hipLaunchKernelGGL(sqnorm_kernel, dim3(rb), dim3(256), 0, st, x, nrm, B, N, D);
-  const int nt = (P + CT - 1) / CT;
-  if (P > 25) hipLaunchKernelGGL(dist_kernel<false>, dim3(nt * nt, B), dim3(256), 0, st, x, nrm, dist, N, D, (float)sqrt((double)D));
-  else hipLaunchKernelGGL(dist_kernel<true>, dim3(nt * nt, B), dim3(256), 0, st, x, nrm, dist, N, D, (float)sqrt((double)D));
-  hipLaunchKernelGGL(density_kernel, dim3(rb), dim3(256), 0, st, dist, noise, density, dmax, B, P, k);
-  hipLaunchKernelGGL(parent_score_kernel, dim3(rb), dim3(256), 0, st, dist, density, dmax, score_rows, B, P);
+  launch_dist(fast_dist != 0, x, nrm, dist, B, N, D, (float)sqrt((double)D), st);
+  if (P <= 256) hipLaunchKernelGGL(density_kernel<4>, dim3(rb), dim3(256), 0, st, dist, noise, density, rowmax, B, P, k);
+  else hipLaunchKernelGGL(density_kernel<16>, dim3(rb), dim3(256), 0, st, dist, noise, density, rowmax, B, P, k);
+  hipLaunchKernelGGL(parent_score_kernel, dim3(rb), dim3(256), 0, st, dist, density, rowmax, score_rows, B, P);
   TR_CHECK_LAUNCH("tr_dpcknn_cluster");
   int rc = tr_cls_topk(score_rows, centers, nullptr, scores, B, 1, N, K, s);      // topk(score, K), sorted descending
   if (rc != TR_OK) return rc;
@@ -427,11 +542,11 @@ extern "C" int tr_cluster_merge_layernorm(const float* x, const float* score_w, 
 }
 
 extern "C" int tr_kmedoids(const float* x, const float* colsum_part, float* ws, int32_t* centers, int32_t* assign, int B, int N, int D,
-                           int H, int K, int iters, tr_stream_t s) {
+                           int H, int K, int iters, int fast_dist, tr_stream_t s) {
   TR_REQUIRE(x && colsum_part && ws && centers && assign, TR_ERR_NULL, "tr_kmedoids: null pointer");
   const int P = N - 1;
-  TR_REQUIRE(B > 0 && H > 0 && P >= 2 && P <= 64 * PER_LANE && D > 0 && D % CK == 0, TR_ERR_SHAPE,
-             "tr_kmedoids: need 2 <= P <= %d and D %% %d == 0 (N=%d D=%d)", 64 * PER_LANE, CK, N, D);
+  TR_REQUIRE(B > 0 && H > 0 && P >= 2 && P <= 64 * MAX_PER_LANE && D > 0 && D % CK == 0, TR_ERR_SHAPE,
+             "tr_kmedoids: need 2 <= P <= %d and D %% %d == 0 (N=%d D=%d)", 64 * MAX_PER_LANE, CK, N, D);
   TR_REQUIRE(K >= 1 && K <= P && iters >= 0, TR_ERR_SHAPE, "tr_kmedoids: bad K=%d / iters=%d for P=%d", K, iters, P);
   TR_REQUIRE(tr_aligned16(x) && tr_aligned16(ws), TR_ERR_ALIGN, "tr_kmedoids: pointers must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(s);
@@ -446,9 +561,7 @@ extern "C" int tr_kmedoids(const float* x, const float* colsum_part, float* ws, 
   int rc = tr_cls_topk(wrow, centers, nullptr, t, B, 1, N, K, s);
   if (rc != TR_OK) return rc;
   hipLaunchKernelGGL(sqnorm_kernel, dim3(rb), dim3(256), 0, st, x, nrm, B, N, D);
-  const int nt = (P + CT - 1) / CT;
-  if (P > 25) hipLaunchKernelGGL(dist_kernel<false>, dim3(nt * nt, B), dim3(256), 0, st, x, nrm, dist, N, D, 1.0f);   // torch.cdist(x, x)
-  else hipLaunchKernelGGL(dist_kernel<true>, dim3(nt * nt, B), dim3(256), 0, st, x, nrm, dist, N, D, 1.0f);
+  launch_dist(fast_dist != 0, x, nrm, dist, B, N, D, 1.0f, st);                               // torch.cdist(x, x)
   hipLaunchKernelGGL(kmed_rowcost_kernel, dim3(rb), dim3(256), 0, st, dist, wrow, t, B, P);
   hipLaunchKernelGGL(kmed_iterate_kernel, dim3(B), dim3(256), (size_t)K * 12, st, dist, t, centers, assign, P, K, iters);
   TR_CHECK_LAUNCH("tr_kmedoids");

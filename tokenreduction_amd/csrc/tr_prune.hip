@@ -185,9 +185,11 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
   }
 }
 
-// one workgroup per image; Z[k][p] = scores[p][k] / eps lives in LDS (K*P floats) through the iterations
-// (log_optimal_transport sinkhorn.py:41-56 over log_sinkhorn_iterations :25-38)
-__global__ __launch_bounds__(256) void sinkhorn_kernel(const float* __restrict__ scores, int ldl, float eps, int iters,
+// one workgroup (16 waves) per image; Z[k][p] = scores[p][k] / eps lives in LDS (K*P floats) through the iterations
+// (log_optimal_transport sinkhorn.py:41-56 over log_sinkhorn_iterations :25-38).  u-step: one wave per centre row;
+// v-step: four lanes per token column, combined with two shuffles.
+constexpr int SKT = 1024;
+__global__ __launch_bounds__(SKT) void sinkhorn_kernel(const float* __restrict__ scores, int ldl, float eps, int iters,
                                                        float* __restrict__ wt, float* __restrict__ soft, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) float s_z[];      // [K][P], then u[K], v[P]
   const int P = N - 1;
@@ -196,15 +198,16 @@ __global__ __launch_bounds__(256) void sinkhorn_kernel(const float* __restrict__
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x;
   const float* sc = scores + ((size_t)b * N + 1) * ldl;
-  for (int e = tid; e < K * P; e += 256) {
+  for (int e = tid; e < K * P; e += SKT) {
     const int p = e / K, k = e - p * K;                            // lanes along k: coalesced global reads
     s_z[k * P + p] = sc[(size_t)p * ldl + k] / eps;
   }
-  for (int p = tid; p < P; p += 256) s_v[p] = 0.f;
+  for (int p = tid; p < P; p += SKT) s_v[p] = 0.f;
+  for (int k = tid; k < K; k += SKT) s_u[k] = 0.f;
   const float norm = -logf((float)K + (float)P);                   // log_mu = log_nu = -log(m + n)
   __syncthreads();
   for (int it = 0; it < iters; ++it) {
-    for (int k = wave; k < K; k += 4) {                            // u = log_mu - logsumexp_p(Z + v)
+    for (int k = wave; k < K; k += SKT / 64) {                     // u = log_mu - logsumexp_p(Z + v)
       const float* zr = s_z + (size_t)k * P;
       float m = -INFINITY;
       for (int p = lane; p < P; p += 64) m = fmaxf(m, zr[p] + s_v[p]);
@@ -216,20 +219,26 @@ __global__ __launch_bounds__(256) void sinkhorn_kernel(const float* __restrict__
       if (lane == 0) s_u[k] = norm - (m + logf(t));
     }
     __syncthreads();
-    for (int p = tid; p < P; p += 256) {                           // v = log_nu - logsumexp_k(Z + u)
+    const int sub = tid & 3;
+    for (int p0 = 0; p0 < P; p0 += SKT / 4) {                      // v = log_nu - logsumexp_k(Z + u)
+      const int p = p0 + (tid >> 2);
+      const bool ok = p < P;
       float m = -INFINITY;
-      for (int k = 0; k < K; ++k) m = fmaxf(m, s_z[k * P + p] + s_u[k]);
+      if (ok)
+        for (int k = sub; k < K; k += 4) m = fmaxf(m, s_z[k * P + p] + s_u[k]);
+      m = fmaxf(m, __shfl_xor(m, 1, 64));
+      m = fmaxf(m, __shfl_xor(m, 2, 64));
       float t = 0.f;
-      for (int k = 0; k < K; ++k) t += expf(s_z[k * P + p] + s_u[k] - m);
-      s_v[p] = norm - (m + logf(t));
+      if (ok)
+        for (int k = sub; k < K; k += 4) t += expf(s_z[k * P + p] + s_u[k] - m);
+      t += __shfl_xor(t, 1, 64);
+      t += __shfl_xor(t, 2, 64);
+      if (ok && sub == 0) s_v[p] = norm - (m + logf(t));
     }
     __syncthreads();
   }
-  if (iters == 0)
-    for (int k = tid; k < K; k += 256) s_u[k] = 0.f;
-  __syncthreads();
   // W = exp(Z + u + v - norm): token-major copy for the merge, cluster-major copy for Soft_Assignment_Maps
-  for (int e = tid; e < K * P; e += 256) {
+  for (int e = tid; e < K * P; e += SKT) {
     const int k = e / P, p = e - k * P;
     const float w = expf(s_z[e] + s_u[k] + s_v[p] - norm);
     s_z[e] = w;
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(256) void sinkhorn_kernel(const float* __restrict__
   }
   __syncthreads();
   float* wb = wt + ((size_t)b * N + 1) * ldl;
-  for (int e = tid; e < K * P; e += 256) {
+  for (int e = tid; e < K * P; e += SKT) {
     const int p = e / K, k = e - p * K;
     wb[(size_t)p * ldl + k] = s_z[k * P + p];
   }
@@ -376,7 +385,7 @@ extern "C" int tr_sinkhorn(const float* scores, int ldl, float eps, int iters, f
   }
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sinkhorn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_sinkhorn: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-  hipLaunchKernelGGL(sinkhorn_kernel, dim3(B), dim3(256), lds, st, scores, ldl, eps, iters, wt, soft, N, K);
+  hipLaunchKernelGGL(sinkhorn_kernel, dim3(B), dim3(SKT), lds, st, scores, ldl, eps, iters, wt, soft, N, K);
   TR_CHECK_LAUNCH("tr_sinkhorn");
   return TR_OK;
 }

@@ -175,7 +175,7 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
       float* wtok = cws + tr_dpcknn_workspace_floats(B, p.N0);
       int32_t* centers = kept_idx ? kept_idx + (size_t)i * B * p.N0 : idx_ws;
       int32_t* assign = compl_idx ? compl_idx + (size_t)i * B * p.N0 : compl_ws;
-      TR_TRY(tr_dpcknn_cluster(x, noise_in, cws, centers, assign, scores, B, N, D, Kc, cfg->knn_k > 0 ? cfg->knn_k : 5, s));
+      TR_TRY(tr_dpcknn_cluster(x, noise_in, cws, centers, assign, scores, B, N, D, Kc, cfg->knn_k > 0 ? cfg->knn_k : 5, f32 ? 0 : 1, s));
       if (noise_in) noise_in += (size_t)B * (N - 1);
       TR_TRY(tr_cluster_merge_layernorm(x, sw->w3, sw->b3, wtok, assign, bw->ln1_g, bw->ln1_b, x_alt, xn, f32 ? 1 : 0, B, N, Kc, D,
                                         cfg->ln_eps, s));
@@ -194,7 +194,7 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
       int32_t* centers = kept_idx ? kept_idx + (size_t)i * B * p.N0 : idx_ws;
       int32_t* assign = compl_idx ? compl_idx + (size_t)i * B * p.N0 : compl_ws;
       TR_TRY(tr_kmedoids(x, colsum_part, reinterpret_cast<float*>(ws + p.off_cluster), centers, assign, B, N, D, H, Kc,
-                         cfg->cluster_iters, s));
+                         cfg->cluster_iters, f32 ? 0 : 1, s));
       TR_TRY(op_gather(f32, x, nullptr, centers, nullptr, nullptr, bw->ln1_g, bw->ln1_b, x_alt, xn, B, N, Kc, D, cfg->ln_eps, s));
       float* t = x; x = x_alt; x_alt = t;
       N = Kc + 1;

@@ -220,7 +220,7 @@ def sit_merge(logits: torch.Tensor, scale: float, x: torch.Tensor, K: int, want_
 
 
 # ---------------------------------------------------------------------------------------- DPC-KNN (models/dpcknn.py)
-def dpcknn_cluster(x: torch.Tensor, K: int, noise: torch.Tensor = None, k: int = 5):
+def dpcknn_cluster(x: torch.Tensor, K: int, noise: torch.Tensor = None, k: int = 5, fast_dist: bool = False):
     """cluster_dpc_knn (dpcknn.py:44-100) on the patch rows of x fp32 [B,N,D] ->
     (centers int32 [B,K] in descending-score order, idx_cluster int32 [B,N-1], scores fp32 [B,N-1])."""
     B, N, D = x.shape
@@ -230,7 +230,8 @@ def dpcknn_cluster(x: torch.Tensor, K: int, noise: torch.Tensor = None, k: int =
     idx_cluster = torch.empty(B, N - 1, dtype=torch.int32, device=x.device)
     scores = torch.empty(B, N - 1, dtype=torch.float32, device=x.device)
     _lib.check(lib.tr_dpcknn_cluster(_dev(x, torch.float32, "x"), _opt(noise, torch.float32, "noise"), ws.data_ptr(),
-                                     centers.data_ptr(), idx_cluster.data_ptr(), scores.data_ptr(), B, N, D, K, k, _stream()),
+                                     centers.data_ptr(), idx_cluster.data_ptr(), scores.data_ptr(), B, N, D, K, k, int(fast_dist),
+                                     _stream()),
                "tr_dpcknn_cluster")
     return centers, idx_cluster, scores
 
@@ -309,7 +310,7 @@ def weighted_merge(wt: torch.Tensor, x: torch.Tensor, src: torch.Tensor, K: int)
 
 
 # ---------------------------------------------------------------------------------------- K-Medoids (models/kmedoids.py)
-def kmedoids(x: torch.Tensor, colsum_part: torch.Tensor, K: int, iters: int):
+def kmedoids(x: torch.Tensor, colsum_part: torch.Tensor, K: int, iters: int, fast_dist: bool = False):
     """k_medoids_fit (kmedoids.py:40-85, weighted branch): x fp32 [B,N,D], colsum_part fp32 [B,H,4,N] (previous block's attention)
     -> (centers int32 [B,K], assignment int32 [B,N-1])."""
     B, N, D = x.shape
@@ -319,5 +320,5 @@ def kmedoids(x: torch.Tensor, colsum_part: torch.Tensor, K: int, iters: int):
     centers = torch.empty(B, K, dtype=torch.int32, device=x.device)
     assign = torch.empty(B, N - 1, dtype=torch.int32, device=x.device)
     _lib.check(lib.tr_kmedoids(_dev(x, torch.float32, "x"), _dev(colsum_part, torch.float32, "colsum_part"), ws.data_ptr(),
-                               centers.data_ptr(), assign.data_ptr(), B, N, D, H, K, iters, _stream()), "tr_kmedoids")
+                               centers.data_ptr(), assign.data_ptr(), B, N, D, H, K, iters, int(fast_dist), _stream()), "tr_kmedoids")
     return centers, assign

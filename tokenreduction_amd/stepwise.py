@@ -118,7 +118,7 @@ def forward_stepwise(model: VisionTransformer, x: torch.Tensor, trace: Optional[
                 pending = None
             noise = None if noise_parts is None else noise_parts[j]
             centers, assign, score = tr.run("dpcknn_cluster", 2.0 * B * (N - 1) * (N - 1) * D, 16.0 * B * (N - 1) * (N - 1),
-                                            lambda: ops.dpcknn_cluster(h.view(B, N, D), Kc, noise, model.k_neighbors))
+                                            lambda: ops.dpcknn_cluster(h.view(B, N, D), Kc, noise, model.k_neighbors, fast_dist=True))
             info["kept"][i], info["compl"][i], info["scores"][i] = centers, assign, score
             ctm = model.cluster_layers[j]
             sw = None if model.equal_weight else f32(ctm.score.weight)
@@ -136,7 +136,7 @@ def forward_stepwise(model: VisionTransformer, x: torch.Tensor, trace: Optional[
                        lambda: ops.layernorm(h, f32(blk.norm1.weight), f32(blk.norm1.bias), eps, delta=pending))
                 pending = None
             centers, assign = tr.run("kmedoids", 2.0 * B * (N - 1) * (N - 1) * D, 8.0 * B * (N - 1) * (N - 1),
-                                     lambda: ops.kmedoids(h.view(B, N, D), colsum, Kc, model.cluster_iters))
+                                     lambda: ops.kmedoids(h.view(B, N, D), colsum, Kc, model.cluster_iters, fast_dist=True))
             info["kept"][i], info["compl"][i], info["scores"][i] = centers, assign, colsum.sum(dim=(1, 2))[:, 1:]
             h3_, xn = tr.run("gather_layernorm_kernel", 0.0, 10.0 * B * (Kc + 1) * D,
                              lambda: ops.gather_layernorm(h.view(B, N, D), centers, None, None, f32(blk.norm1.weight),
