@@ -68,6 +68,10 @@ int tr_layernorm_bf16(float* x, long ldx, const uint16_t* delta, long ldd, const
 int tr_layernorm_f32(float* x, long ldx, const float* delta, long ldd, const float* gamma, const float* beta, float* y, int M,
                      int D, float eps, tr_stream_t s);                                                  /* fp32 validation path */
 
+/* out[i] = x[i] + delta[i] for n elements (delta nullable; bf16, fp32 when delta_is_f32): the residual stream after a block as
+ * the reference's viz_data["Features"] records it (topk.py:197) -- x itself absorbs the pending mlp output only in the next norm. */
+int tr_residual_snapshot(const float* x, const void* delta, int delta_is_f32, float* out, size_t n, tr_stream_t s);
+
 /* a3 (topk.py:44-51 == deit_viz.py:43-51): softmax(q k^T / sqrt(64)) v for every (image, head).
  * qkv bf16 [B*N, 3*H*64] (columns [q|k|v], head-major), out bf16 [B*N, H*64].
  * cls_rows (nullable) fp32 [B,H,N]: the CLS query's softmax row (attn[:, :, 0, :], topk.py:59) --
@@ -267,10 +271,11 @@ size_t tr_vit_workspace_bytes(const tr_vit_config* cfg, int B);
  * (Fusion_Assign, evit.py:229).  soft_out (nullable, SiT): fp32, the stages' soft assignments [B,K,P_in] back to back in
  * block order (Soft_Assignment_Maps, sit.py:124).  DPC-KNN: kept_idx gets the centres [B,K] (Kept_Tokens), compl_idx the
  * assignment [B,P_in] (Assignment_Maps), K-Medoids likewise (medoid ids, assignment); ATS: kept_idx gets ids [B,K] (CLS id 0 first, 1-based token ids, 0 padding); noise_in (nullable): fp32, the stages' density noise [B,P_in] back to back in block
- * order (dpcknn.py:71-72; NULL = no noise).  tokens_out (nullable, HOST pointer, int[depth]): token count after each block. */
+ * order (dpcknn.py:71-72; NULL = no noise).  features_out (nullable): fp32, the residual stream after EVERY block
+ * ([B,N_blk,D] back to back in block order; viz_data["Features"]).  tokens_out (nullable, HOST pointer, int[depth]): token count after each block. */
 int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits,
                    void* workspace, size_t workspace_bytes, int32_t* kept_idx, int32_t* compl_idx, float* soft_out,
-                   const float* noise_in, int* tokens_out, int B, tr_stream_t s);
+                   const float* noise_in, float* features_out, int* tokens_out, int B, tr_stream_t s);
 
 #ifdef __cplusplus
 }

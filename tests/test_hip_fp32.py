@@ -144,6 +144,13 @@ def test_model_fp32_matches_reference_golden(golden_dir, name):
             continue
         np.testing.assert_array_equal(viz["Assignment_Maps"][blk], g[k])
     kept_keys = kept_keys + akeys
+    # viz_data["Features"]: same blocks as the reference records, same shapes; values where the decisions are identical
+    assert sorted(viz["Features"].keys()) == [int(b) for b in g["token_count_blocks"]]
+    for blk, n in zip(g["token_count_blocks"], g["token_counts"]):
+        assert viz["Features"][int(blk)].shape == (case["batch"], int(n), case["embed_dim"])
+    if case["family"] not in ("dyvit",):
+        last = int(g["token_count_blocks"][-1])
+        np.testing.assert_allclose(viz["Features"][last][:, :8], g["final_tokens"], atol=2e-4, rtol=0)
     d = (logits.cpu() - torch.from_numpy(g["logits"])).abs().max().item()
     print(f"\n[{name}] fp32 path: max|logit - reference| = {d:.2e}; indices exact at blocks {[int(k.split('_')[1]) for k in kept_keys]}")
     assert d < 2e-4, d

@@ -366,3 +366,30 @@ def test_full_size_batch_properties():
     for blk, idx in info["kept"].items():
         sc = torch.gather(info["scores"][blk], 1, idx.long())
         assert (sc[:, :-1] >= sc[:, 1:]).all()          # sorted=True: descending score order
+
+
+def test_forward_is_graph_capturable():
+    """tr_vit_forward only enqueues kernels (no allocation, no sync, no host readback), so a forward can be captured in a
+    hipGraph and replayed: same logits bit for bit, also after the input buffer's contents change."""
+    case = GOLDEN_CASES["topk_micro"]
+    model, _, _ = build_model(case)
+    model.viz_mode = False
+    x = make_images(4, 224, 7).cuda()
+    ref = model(x).clone()                       # also warms the workspace / weight pack
+    static_x = x.clone()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        model(static_x)                          # warm-up on the capture stream
+    torch.cuda.current_stream().wait_stream(s)
+    with torch.cuda.graph(g):
+        out = model(static_x)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    x2 = make_images(4, 224, 8).cuda()
+    static_x.copy_(x2)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, model(x2))

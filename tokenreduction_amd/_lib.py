@@ -75,7 +75,8 @@ SIGNATURES = {
     "tr_kmedoids": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tr_dpcknn_cluster": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "tr_cluster_merge_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
-    "tr_vit_forward": (_i, [C.POINTER(TrVitConfig), C.POINTER(TrVitWeights), _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp,
+    "tr_residual_snapshot": (_i, [_vp, _vp, _i, _vp, _sz, _vp]),
+    "tr_vit_forward": (_i, [C.POINTER(TrVitConfig), C.POINTER(TrVitWeights), _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp,
                             C.POINTER(_i), _i, _vp]),
 }
 

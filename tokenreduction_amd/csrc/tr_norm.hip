@@ -257,6 +257,33 @@ static int gather_layernorm_impl(bool f32, const float* x, const void* delta, co
   return TR_OK;
 }
 
+// out = x + delta: the residual stream as the reference sees it after a block (x itself is only updated by the NEXT norm)
+template <bool F32>
+__global__ __launch_bounds__(256) void residual_snapshot_kernel(const float* __restrict__ x, const void* __restrict__ delta,
+                                                                float* __restrict__ out, size_t nchunks) {
+  const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= nchunks) return;
+  float4 v = *reinterpret_cast<const float4*>(x + 4 * c);
+  if (delta != nullptr) {
+    const float4 d = load_delta4<F32>(delta, 4 * c);
+    v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w;
+  }
+  *reinterpret_cast<float4*>(out + 4 * c) = v;
+}
+
+extern "C" int tr_residual_snapshot(const float* x, const void* delta, int delta_is_f32, float* out, size_t n, tr_stream_t s) {
+  TR_REQUIRE(x && out, TR_ERR_NULL, "tr_residual_snapshot: null pointer");
+  TR_REQUIRE(n > 0 && n % 4 == 0, TR_ERR_SHAPE, "tr_residual_snapshot: element count must be a positive multiple of 4");
+  TR_REQUIRE(tr_aligned16(x) && tr_aligned16(out) && ((uintptr_t)delta & 7u) == 0, TR_ERR_ALIGN, "tr_residual_snapshot: misaligned pointer");
+  hipStream_t st = static_cast<hipStream_t>(s);
+  const size_t nch = n / 4;
+  const unsigned nb = (unsigned)((nch + 255) / 256);
+  if (delta_is_f32) hipLaunchKernelGGL(residual_snapshot_kernel<true>, dim3(nb), dim3(256), 0, st, x, delta, out, nch);
+  else hipLaunchKernelGGL(residual_snapshot_kernel<false>, dim3(nb), dim3(256), 0, st, x, delta, out, nch);
+  TR_CHECK_LAUNCH("tr_residual_snapshot");
+  return TR_OK;
+}
+
 extern "C" int tr_gather_layernorm_bf16(const float* x, const uint16_t* delta, const int32_t* idx, const int32_t* compl_idx,
                                         const float* scores, const float* gamma, const float* beta, float* x_out, uint16_t* y, int B,
                                         int N, int K, int D, float eps, tr_stream_t s) {

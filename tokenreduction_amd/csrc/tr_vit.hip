@@ -121,7 +121,7 @@ extern "C" size_t tr_vit_workspace_bytes(const tr_vit_config* cfg, int B) {
 
 extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits, void* workspace,
                               size_t workspace_bytes, int32_t* kept_idx, int32_t* compl_idx, float* soft_out,
-                              const float* noise_in, int* tokens_out, int B, tr_stream_t s) {
+                              const float* noise_in, float* features_out, int* tokens_out, int B, tr_stream_t s) {
   Plan p;
   TR_REQUIRE(cfg && w && img && logits && workspace, TR_ERR_NULL, "tr_vit_forward: null pointer");
   TR_REQUIRE(make_plan(cfg, B, &p), TR_ERR_CONFIG,
@@ -344,6 +344,10 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
     TR_TRY(op_gemm(f32, xn, bw->fc1_w, bw->fc1_b, hbuf, nullptr, 0, M2, p.Hd, D, TR_EPI_GELU_BF16, s));
     TR_TRY(op_gemm(f32, hbuf, bw->fc2_w, bw->fc2_b, dbuf, nullptr, 0, M2, D, p.Hd, TR_EPI_BF16, s));
     pending = dbuf;
+    if (features_out) {      // viz_data["Features"][i] (topk.py:197): x + mlp output, which x itself only absorbs in the next norm
+      TR_TRY(tr_residual_snapshot(x, pending, f32 ? 1 : 0, features_out, (size_t)M2 * D, s));
+      features_out += (size_t)M2 * D;
+    }
     if (tokens_out) tokens_out[i] = N;
   }
   // a5: (x += last mlp output and) norm on the CLS rows only (LayerNorm is per-row), then the classifier

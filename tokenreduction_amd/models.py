@@ -258,22 +258,60 @@ class VisionTransformer(nn.Module):
         ws = self._workspace(B, x.device)
         if self.viz_mode and self._soft_elems(B) and ws.get("soft") is None:      # viz_mode switched on after the first call
             ws["soft"] = torch.empty(self._soft_elems(B), dtype=torch.float32, device=x.device)
+        if self.viz_mode and ws.get("feat") is None:
+            # viz_data["Features"]: the residual stream after every block (upper bound depth * B * N0 * D fp32)
+            n0 = self.patch_embed.num_patches + 1
+            ws["feat"] = torch.empty(self.depth * B * n0 * self.embed_dim, dtype=torch.float32, device=x.device)
         logits = torch.empty(B, self.num_classes, dtype=torch.float32, device=x.device)
         tokens = (C.c_int * self.depth)()
         with torch.cuda.device(x.device):
             rc = lib.tr_vit_forward(C.byref(cfg), C.byref(pk["W"]), x.data_ptr(), logits.data_ptr(), ws["buf"].data_ptr(),
                                     ws["nbytes"], ws["kept"].data_ptr(), ws["compl"].data_ptr(),
                                     None if ws.get("soft") is None else ws["soft"].data_ptr(), self._noise_ptr(B, x.device),
-                                    tokens, B,
+                                    ws["feat"].data_ptr() if self.viz_mode else None, tokens, B,
                                     torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "tr_vit_forward")
         self._last_tokens = list(tokens)
         if self.viz_mode:
-            return logits, self._viz_data(ws, B, list(tokens))
+            viz = self._viz_data(ws, B, list(tokens))
+            viz["Features"] = self._features(ws, B, list(tokens))
+            return logits, viz
         return logits
 
     def _viz_data(self, ws, B, tokens):
-        return {"Features": {}}
+        return {}
+
+    _features_every_block = True
+
+    def _feature_blocks(self, tokens):
+        """Blocks whose output the reference records in viz_data["Features"]: every block (deit_viz.py:199, sit.py:130), or --
+        families that reduce inside a block -- the blocks that reduced plus the last one (topk.py:195-200 and alike)."""
+        if self._features_every_block:
+            return list(range(self.depth))
+        n_in, out = self.patch_embed.num_patches + 1, {self.depth - 1}
+        for blk, n in enumerate(tokens):
+            k = self._keep[blk]
+            if self._family in (_lib.TR_FAMILY_TOPK, _lib.TR_FAMILY_EVIT):
+                reduced = k > 0 and k != n_in - 1                      # topk.py:57: left_tokens == N-1 returns idx None
+            elif self._family == _lib.TR_FAMILY_TOME:
+                reduced = min(k, (n_in - 1) // 2) > 0
+            else:
+                reduced = k > 0
+            if reduced:
+                out.add(blk)
+            n_in = n
+        return sorted(out)
+
+    def _features(self, ws, B, tokens):
+        D = self.embed_dim
+        want = set(self._feature_blocks(tokens))
+        feats, off = {}, 0
+        for blk in range(self.depth):
+            n = B * tokens[blk] * D
+            if blk in want:
+                feats[blk] = ws["feat"][off: off + n].reshape(B, tokens[blk], D).cpu().numpy()
+            off += n
+        return feats
 
     def _stage_indices(self, ws, B, tokens):
         """Per reduction block: (blk, N_in, K) from the static per-stage shapes."""
@@ -290,6 +328,8 @@ class VisionTransformer(nn.Module):
 
 class _TopKBase(VisionTransformer):
     """Shared ctor logic of topk.py:108-171 / evit.py:138-201."""
+
+    _features_every_block = False
 
     def __init__(self, *a, args=None, dyvit_distillation=False, **kw):
         super().__init__(*a, args=args, **kw)
@@ -361,6 +401,8 @@ class EfficientVisionTransformer(_TopKBase):
 class ToMeVisionTransformer(VisionTransformer):
     """models/tome.py:107-223: bipartite soft matching + size-weighted merge between attention and MLP, proportional attention."""
     _family = _lib.TR_FAMILY_TOME
+
+    _features_every_block = False
 
     def __init__(self, *a, args=None, **kw):
         super().__init__(*a, args=args, **kw)
@@ -435,6 +477,8 @@ class DynamicVisionTransformer(VisionTransformer):
     """models/dyvit.py:122-263, eval path: per pruning block, PredictorLG scores the patch tokens, the best int(P0*ratio) are
     gathered (argsort order) BEFORE the block runs.  Training (gumbel + policy softmax, dyvit.py:221-229) is not built."""
     _family = _lib.TR_FAMILY_DYVIT
+
+    _features_every_block = False
 
     def __init__(self, *a, args=None, dyvit_distillation=False, **kw):
         distilled = kw.pop("distilled", False)
@@ -647,6 +691,8 @@ class ATSVisionTransformer(VisionTransformer):
     ats.py:78); here it is the static bound K = sample_count, the surplus rows being masked keys (zero attention weight), which
     leaves every valid token and the logits unchanged.  Kept_Tokens is trimmed to the reference's batch-maximum width."""
     _family = _lib.TR_FAMILY_ATS
+
+    _features_every_block = False
 
     def __init__(self, *a, args=None, **kw):
         super().__init__(*a, args=args, **kw)
