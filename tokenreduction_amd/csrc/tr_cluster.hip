@@ -434,38 +434,44 @@ __device__ __forceinline__ unsigned long long cost_key(float v, int i) {        
   return ((unsigned long long)__float_as_uint(v) << 32) | (unsigned int)i;
 }
 
-// one workgroup per image: iterate {assignment, medoid update}, final assignment
-__global__ __launch_bounds__(256) void kmed_iterate_kernel(const float* __restrict__ dist, const float* __restrict__ t,
+// one workgroup (16 waves) per image: iterate {assignment, medoid update}, final assignment.  Assignment = one wave per token,
+// lanes across the K medoid columns of that token's distance row (gathered loads in parallel), wave arg-min with the
+// first-index tie rule of torch.argmin.
+constexpr int KMT = 1024;
+__global__ __launch_bounds__(KMT) void kmed_iterate_kernel(const float* __restrict__ dist, const float* __restrict__ t,
                                                            int32_t* __restrict__ centers, int32_t* __restrict__ assign, int P, int K,
                                                            int iters) {
   extern __shared__ unsigned long long s_best[];      // [K] packed (cost, index), then int s_c[K]
   int* s_c = reinterpret_cast<int*>(s_best + K);
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* db = dist + (size_t)b * P * P;
   const float* tb = t + (size_t)b * P;
-  for (int k = tid; k < K; k += 256) s_c[k] = centers[(size_t)b * K + k];
+  for (int k = tid; k < K; k += KMT) s_c[k] = centers[(size_t)b * K + k];
   __syncthreads();
   const float masked = (float)P * 1000000.0f;         // a row outside cluster k sums to P * 1e6 (kmedoids.py:76-77)
   for (int it = 0; it <= iters; ++it) {
-    for (int k = tid; k < K; k += 256) s_best[k] = cost_key(masked, 0);
+    for (int k = tid; k < K; k += KMT) s_best[k] = cost_key(masked, 0);
     __syncthreads();
-    for (int p = tid; p < P; p += 256) {
+    for (int p = wave; p < P; p += KMT / 64) {
       const float* dr = db + (size_t)p * P;
       float best = INFINITY;
-      int arg = 0;
-      for (int k = 0; k < K; ++k) {                   // argmin over the medoid columns, first minimum
+      int arg = 0x7fffffff;
+      for (int k = lane; k < K; k += 64) {            // ascending k per lane, strict <: the lane's first minimum
         const float d = dr[s_c[k]];
         if (d < best) { best = d; arg = k; }
       }
-      if (it == iters) assign[(size_t)b * P + p] = arg;
-      else atomicMin(&s_best[arg], cost_key(tb[p], p));       // smallest cost, ties -> smallest index; empty cluster -> index 0
+      wave_min_pair(best, arg);                       // smallest distance, ties -> smallest k (torch.argmin)
+      if (lane == 0) {
+        if (it == iters) assign[(size_t)b * P + p] = arg;
+        else atomicMin(&s_best[arg], cost_key(tb[p], p));     // smallest cost, ties -> smallest index; empty cluster -> index 0
+      }
     }
     __syncthreads();
     if (it < iters)
-      for (int k = tid; k < K; k += 256) s_c[k] = (int)(s_best[k] & 0xffffffffull);
+      for (int k = tid; k < K; k += KMT) s_c[k] = (int)(s_best[k] & 0xffffffffull);
     __syncthreads();
   }
-  for (int k = tid; k < K; k += 256) centers[(size_t)b * K + k] = s_c[k];
+  for (int k = tid; k < K; k += KMT) centers[(size_t)b * K + k] = s_c[k];
 }
 
 }  // namespace
@@ -563,7 +569,7 @@ extern "C" int tr_kmedoids(const float* x, const float* colsum_part, float* ws, 
   hipLaunchKernelGGL(sqnorm_kernel, dim3(rb), dim3(256), 0, st, x, nrm, B, N, D);
   launch_dist(fast_dist != 0, x, nrm, dist, B, N, D, 1.0f, st);                               // torch.cdist(x, x)
   hipLaunchKernelGGL(kmed_rowcost_kernel, dim3(rb), dim3(256), 0, st, dist, wrow, t, B, P);
-  hipLaunchKernelGGL(kmed_iterate_kernel, dim3(B), dim3(256), (size_t)K * 12, st, dist, t, centers, assign, P, K, iters);
+  hipLaunchKernelGGL(kmed_iterate_kernel, dim3(B), dim3(KMT), (size_t)K * 12, st, dist, t, centers, assign, P, K, iters);
   TR_CHECK_LAUNCH("tr_kmedoids");
   return TR_OK;
 }
