@@ -10,6 +10,7 @@
 // HBM: the [B,P,P] distance matrix is written once and read three times (density, parent distance, assignment) --
 // 4*P*P*4 B per image (0.6 MB at P=196), against 2*P*P*D flops of the Gram product.
 #include "tr_common.h"
+#include "tr_rowops.h"
 
 extern "C" int tr_cls_topk(const float* cls_rows, int32_t* idx, int32_t* compl_idx, float* scores, int B, int H, int N, int K,
                            tr_stream_t s);
@@ -307,7 +308,6 @@ __global__ __launch_bounds__(256) void token_weight_kernel(const float* __restri
   if (lane == 0) w[row] = expf(acc + bs[0]);
 }
 
-constexpr int LNC = 4;   // float4 chunks per lane -> D <= 1024
 
 // one wave per output row (row 0 = CLS copy, row 1+c = cluster c), fused with the following LayerNorm
 template <bool F32>
@@ -323,12 +323,12 @@ __global__ __launch_bounds__(256) void cluster_merge_layernorm_kernel(const floa
   if (r > K) return;
   const int P = N - 1, nchunks = D >> 2;
   const float* xb = x + (size_t)b * N * D;
-  float4 v[LNC];
+  float4 v[LN_MAX_CHUNKS];
 #pragma unroll
-  for (int c = 0; c < LNC; ++c) v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c = 0; c < LN_MAX_CHUNKS; ++c) v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (r == 0) {
 #pragma unroll
-    for (int c = 0; c < LNC; ++c)
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c)
       if (lane + 64 * c < nchunks) v[c] = *reinterpret_cast<const float4*>(xb + 4 * (lane + 64 * c));
   } else {
     const int cl = r - 1;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void cluster_merge_layernorm_kernel(const floa
         const float nw = (wb ? wb[p0 + q] : 1.0f) / aw;                      // norm_weight = token_weight / all_weight[idx]
         const float* xr = xb + (size_t)(1 + p0 + q) * D;
 #pragma unroll
-        for (int c = 0; c < LNC; ++c)
+        for (int c = 0; c < LN_MAX_CHUNKS; ++c)
           if (lane + 64 * c < nchunks) {
             const float4 a = *reinterpret_cast<const float4*>(xr + 4 * (lane + 64 * c));
             v[c].x += a.x * nw; v[c].y += a.y * nw; v[c].z += a.z * nw; v[c].w += a.w * nw;
@@ -367,40 +367,10 @@ __global__ __launch_bounds__(256) void cluster_merge_layernorm_kernel(const floa
   }
   const size_t orow = (size_t)b * (K + 1) + r;
 #pragma unroll
-  for (int c = 0; c < LNC; ++c)
+  for (int c = 0; c < LN_MAX_CHUNKS; ++c)
     if (lane + 64 * c < nchunks) *reinterpret_cast<float4*>(x_out + orow * D + 4 * (lane + 64 * c)) = v[c];
-  float s1 = 0.f;
-#pragma unroll
-  for (int c = 0; c < LNC; ++c)
-    if (lane + 64 * c < nchunks) s1 += (v[c].x + v[c].y) + (v[c].z + v[c].w);
-  const float mean = wave_sum(s1) / (float)D;
-  float q = 0.f;
-#pragma unroll
-  for (int c = 0; c < LNC; ++c)
-    if (lane + 64 * c < nchunks) {
-      const float a = v[c].x - mean, bb = v[c].y - mean, cc = v[c].z - mean, d = v[c].w - mean;
-      q += (a * a + bb * bb) + (cc * cc + d * d);
-    }
-  const float var = wave_sum(q) / (float)D + eps;
-  const float rstd = F32 ? 1.0f / sqrtf(var) : rsqrtf(var);
-#pragma unroll
-  for (int c = 0; c < LNC; ++c) {
-    const int ch = lane + 64 * c;
-    if (ch < nchunks) {
-      const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * ch);
-      const float4 be = *reinterpret_cast<const float4*>(beta + 4 * ch);
-      const float o0 = (v[c].x - mean) * rstd * g.x + be.x, o1 = (v[c].y - mean) * rstd * g.y + be.y;
-      const float o2 = (v[c].z - mean) * rstd * g.z + be.z, o3 = (v[c].w - mean) * rstd * g.w + be.w;
-      if (F32) {
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + orow * D + 4 * ch) = make_float4(o0, o1, o2, o3);
-      } else {
-        uint2 pk;
-        pk.x = pack_bf16x2(o0, o1);
-        pk.y = pack_bf16x2(o2, o3);
-        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(y) + orow * D + 4 * ch) = pk;
-      }
-    }
-  }
+  ln_row_store<F32>(v, nchunks, lane, D, eps, gamma, beta,
+                    F32 ? (void*)(reinterpret_cast<float*>(y) + orow * D) : (void*)(reinterpret_cast<uint16_t*>(y) + orow * D));
 }
 
 // ---- K-Medoids (models/kmedoids.py) ---------------------------------------------------------------------------------------
@@ -529,7 +499,7 @@ extern "C" int tr_cluster_merge_layernorm(const float* x, const float* score_w, 
   TR_REQUIRE(x && idx_cluster && gamma && beta && x_out && y, TR_ERR_NULL, "tr_cluster_merge_layernorm: null pointer");
   TR_REQUIRE((score_w == nullptr) == (score_b == nullptr) && (score_w == nullptr || w_ws != nullptr), TR_ERR_NULL,
              "tr_cluster_merge_layernorm: score weight, bias and the [B,P] weight scratch go together");
-  TR_REQUIRE(B > 0 && N >= 2 && K >= 1 && K <= N - 1 && D > 0 && D % 4 == 0 && D <= 256 * LNC, TR_ERR_SHAPE,
+  TR_REQUIRE(B > 0 && N >= 2 && K >= 1 && K <= N - 1 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAX_CHUNKS, TR_ERR_SHAPE,
              "tr_cluster_merge_layernorm: bad shape B=%d N=%d K=%d D=%d", B, N, K, D);
   TR_REQUIRE(x_out != x, TR_ERR_SHAPE, "tr_cluster_merge_layernorm: needs a distinct x_out");
   TR_REQUIRE(tr_aligned16(x) && tr_aligned16(x_out) && tr_aligned16(y) && tr_aligned16(gamma) && tr_aligned16(beta), TR_ERR_ALIGN,

@@ -1,0 +1,64 @@
+// Row helpers shared by the kernels that finish with a LayerNorm over a token row held in registers
+// (tr_norm.hip, tr_tome.hip, tr_cluster.hip): one wave per row, `LN_MAX_CHUNKS` float4 chunks per lane.
+#ifndef TR_ROWOPS_H
+#define TR_ROWOPS_H
+#include "tr_common.h"
+
+namespace {
+
+constexpr int LN_MAX_CHUNKS = 4;  // float4 chunks per lane -> D <= 1024
+
+// Normalise one row held as `nch` float4 chunks per lane; two-pass (mean, then centred variance) in registers.
+template <bool F32>
+__device__ __forceinline__ void ln_row_store(float4 (&v)[LN_MAX_CHUNKS], int nchunks, int lane, int D, float eps,
+                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                             void* __restrict__ yrow_) {
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+    if (lane + 64 * c < nchunks) s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+    if (lane + 64 * c < nchunks) {
+      const float a = v[c].x - mean, b = v[c].y - mean, cc = v[c].z - mean, d = v[c].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  const float rstd = F32 ? 1.0f / sqrtf(wave_sum(q) / (float)D + eps) : rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+  for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nchunks) {
+      const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * ch);
+      const float4 b = *reinterpret_cast<const float4*>(beta + 4 * ch);
+      const float o0 = (v[c].x - mean) * rstd * g.x + b.x, o1 = (v[c].y - mean) * rstd * g.y + b.y;
+      const float o2 = (v[c].z - mean) * rstd * g.z + b.z, o3 = (v[c].w - mean) * rstd * g.w + b.w;
+      if (F32) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(yrow_) + 4 * ch) = make_float4(o0, o1, o2, o3);
+      } else {
+        uint2 pk;
+        pk.x = pack_bf16x2(o0, o1);
+        pk.y = pack_bf16x2(o2, o3);
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(yrow_) + 4 * ch) = pk;
+      }
+    }
+  }
+}
+
+// 4 bf16 -> 4 fp32
+__device__ __forceinline__ float4 bf16x4_to_f32(uint2 u) {
+  return make_float4(bf16_bits_to_f32((unsigned short)(u.x & 0xffffu)), bf16_bits_to_f32((unsigned short)(u.x >> 16)),
+                     bf16_bits_to_f32((unsigned short)(u.y & 0xffffu)), bf16_bits_to_f32((unsigned short)(u.y >> 16)));
+}
+
+// pending-residual chunk: bf16 (fast path) or fp32 (validation path)
+template <bool F32>
+__device__ __forceinline__ float4 load_delta4(const void* base, size_t elem) {
+  if (F32) return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem);
+  return bf16x4_to_f32(*reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + elem));
+}
+
+
+}  // namespace
+#endif  // TR_ROWOPS_H

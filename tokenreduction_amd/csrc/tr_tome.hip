@@ -12,6 +12,7 @@
 // HBM traffic is the algorithmic minimum: match reads the K third of qkv once (2*N*H*64 B per image, bf16) and writes
 // 4*(na + r) B of indices; merge reads each input row once and writes each output row once.
 #include "tr_common.h"
+#include "tr_rowops.h"
 
 namespace {
 
@@ -184,16 +185,6 @@ __global__ __launch_bounds__(256) void tome_match_kernel(const void* __restrict_
   }
 }
 
-constexpr int LNC = 4;   // float4 chunks per lane -> D <= 1024
-
-template <bool F32>
-__device__ __forceinline__ float4 load_d4(const void* base, size_t elem) {
-  if (F32) return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem);
-  const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + elem);
-  return make_float4(bf16_bits_to_f32((unsigned short)(u.x & 0xffffu)), bf16_bits_to_f32((unsigned short)(u.x >> 16)),
-                     bf16_bits_to_f32((unsigned short)(u.y & 0xffffu)), bf16_bits_to_f32((unsigned short)(u.y >> 16)));
-}
-
 // one wave per OUTPUT row: [unmerged even tokens | all odd tokens]
 template <bool F32>
 __global__ __launch_bounds__(256) void tome_merge_layernorm_kernel(const float* __restrict__ x, const void* __restrict__ delta,
@@ -213,17 +204,17 @@ __global__ __launch_bounds__(256) void tome_merge_layernorm_kernel(const float* 
   const float* xb = x + (size_t)b * N * D;
   const size_t dbase = (size_t)b * N * D;
   const float* sb = size_in ? size_in + (size_t)b * N : nullptr;
-  float4 v[LNC];
+  float4 v[LN_MAX_CHUNKS];
   float sz;
   // (x + pending residual) * size of one input token, accumulated into v
   auto add_token = [&](int t, bool first) __attribute__((always_inline)) {
     const float s = sb ? sb[t] : 1.0f;
 #pragma unroll
-    for (int c = 0; c < LNC; ++c)
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c)
       if (lane + 64 * c < nchunks) {
         float4 a = *reinterpret_cast<const float4*>(xb + (size_t)t * D + 4 * (lane + 64 * c));
         if (delta) {
-          const float4 d = load_d4<F32>(delta, dbase + (size_t)t * D + 4 * (lane + 64 * c));
+          const float4 d = load_delta4<F32>(delta, dbase + (size_t)t * D + 4 * (lane + 64 * c));
           a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
         }
         if (first) v[c] = make_float4(a.x * s, a.y * s, a.z * s, a.w * s);
@@ -240,46 +231,16 @@ __global__ __launch_bounds__(256) void tome_merge_layernorm_kernel(const float* 
       if (dst_idx[(size_t)b * r + e] == j) add_token(2 * src_idx[(size_t)b * r + e], false);
   }
 #pragma unroll
-  for (int c = 0; c < LNC; ++c)
+  for (int c = 0; c < LN_MAX_CHUNKS; ++c)
     if (lane + 64 * c < nchunks) { v[c].x /= sz; v[c].y /= sz; v[c].z /= sz; v[c].w /= sz; }
   const size_t orow = (size_t)b * N_out + p;
   if (lane == 0) size_out[orow] = sz;
 #pragma unroll
-  for (int c = 0; c < LNC; ++c)
+  for (int c = 0; c < LN_MAX_CHUNKS; ++c)
     if (lane + 64 * c < nchunks) *reinterpret_cast<float4*>(x_out + orow * D + 4 * (lane + 64 * c)) = v[c];
-  // norm2 (same arithmetic as tr_norm.hip: two-pass statistics in registers)
-  float s1 = 0.f;
-#pragma unroll
-  for (int c = 0; c < LNC; ++c)
-    if (lane + 64 * c < nchunks) s1 += (v[c].x + v[c].y) + (v[c].z + v[c].w);
-  const float mean = wave_sum(s1) / (float)D;
-  float q = 0.f;
-#pragma unroll
-  for (int c = 0; c < LNC; ++c)
-    if (lane + 64 * c < nchunks) {
-      const float a = v[c].x - mean, bb = v[c].y - mean, cc = v[c].z - mean, d = v[c].w - mean;
-      q += (a * a + bb * bb) + (cc * cc + d * d);
-    }
-  const float var = wave_sum(q) / (float)D + eps;
-  const float rstd = F32 ? 1.0f / sqrtf(var) : rsqrtf(var);
-#pragma unroll
-  for (int c = 0; c < LNC; ++c) {
-    const int ch = lane + 64 * c;
-    if (ch < nchunks) {
-      const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * ch);
-      const float4 be = *reinterpret_cast<const float4*>(beta + 4 * ch);
-      const float o0 = (v[c].x - mean) * rstd * g.x + be.x, o1 = (v[c].y - mean) * rstd * g.y + be.y;
-      const float o2 = (v[c].z - mean) * rstd * g.z + be.z, o3 = (v[c].w - mean) * rstd * g.w + be.w;
-      if (F32) {
-        *reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + orow * D + 4 * ch) = make_float4(o0, o1, o2, o3);
-      } else {
-        uint2 pk;
-        pk.x = pack_bf16x2(o0, o1);
-        pk.y = pack_bf16x2(o2, o3);
-        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(y) + orow * D + 4 * ch) = pk;
-      }
-    }
-  }
+  // norm2
+  ln_row_store<F32>(v, nchunks, lane, D, eps, gamma, beta,
+                    F32 ? (void*)(reinterpret_cast<float*>(y) + orow * D) : (void*)(reinterpret_cast<uint16_t*>(y) + orow * D));
 }
 
 }  // namespace
@@ -301,7 +262,7 @@ extern "C" int tr_tome_merge_layernorm(const float* x, const void* delta, int f3
                                        const int32_t* src_idx, const int32_t* dst_idx, const float* gamma, const float* beta,
                                        float* x_out, float* size_out, void* y, int B, int N, int r, int D, float eps, tr_stream_t s) {
   TR_REQUIRE(x && unm_idx && src_idx && dst_idx && gamma && beta && x_out && size_out && y, TR_ERR_NULL, "tr_tome_merge_layernorm: null pointer");
-  TR_REQUIRE(B > 0 && N >= 3 && D > 0 && D % 4 == 0 && D <= 256 * LNC, TR_ERR_SHAPE, "tr_tome_merge_layernorm: bad shape B=%d N=%d D=%d", B, N, D);
+  TR_REQUIRE(B > 0 && N >= 3 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAX_CHUNKS, TR_ERR_SHAPE, "tr_tome_merge_layernorm: bad shape B=%d N=%d D=%d", B, N, D);
   TR_REQUIRE(r >= 1 && r <= (N - 1) / 2, TR_ERR_SHAPE, "tr_tome_merge_layernorm: r=%d out of range for N=%d", r, N);
   TR_REQUIRE(x_out != x, TR_ERR_SHAPE, "tr_tome_merge_layernorm: needs a distinct x_out");
   TR_REQUIRE(tr_aligned16(x) && tr_aligned16(delta) && tr_aligned16(x_out) && tr_aligned16(y) && tr_aligned16(gamma) && tr_aligned16(beta),
