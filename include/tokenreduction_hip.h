@@ -71,6 +71,8 @@ int tr_layernorm_f32(float* x, long ldx, const float* delta, long ldd, const flo
 /* out[i] = x[i] + delta[i] for n elements (delta nullable; bf16, fp32 when delta_is_f32): the residual stream after a block as
  * the reference's viz_data["Features"] records it (topk.py:197) -- x itself absorbs the pending mlp output only in the next norm. */
 int tr_residual_snapshot(const float* x, const void* delta, int delta_is_f32, float* out, size_t n, tr_stream_t s);
+/* dst fp32 [B,N] = src fp32 [N] in every row (the Heuristic family's per-block key mask, heuristic.py:247-258). */
+int tr_broadcast_rows(const float* src, float* dst, int B, int N, tr_stream_t s);
 
 /* a3 (topk.py:44-51 == deit_viz.py:43-51): softmax(q k^T / sqrt(64)) v for every (image, head).
  * qkv bf16 [B*N, 3*H*64] (columns [q|k|v], head-major), out bf16 [B*N, H*64].
@@ -205,6 +207,7 @@ int tr_tome_merge_layernorm(const float* x, const void* delta, int f32_path, con
 #define TR_FAMILY_SINKHORN 8 /* models/sinkhorn.py: optimal-transport soft assignment to learned centres BEFORE the block */
 #define TR_FAMILY_KMEDOIDS 9 /* models/kmedoids.py: weighted K-Medoids on the patch tokens BEFORE the block, medoids kept */
 #define TR_FAMILY_PATCHMERGER 10 /* models/patchmerger.py: K learned queries attend over the normalised tokens BEFORE the block */
+#define TR_FAMILY_HEURISTIC 11 /* models/heuristic.py: fixed spatial key/query masks from a block on; no token is removed */
 #define TR_FAMILY_DPCKNN 6 /* models/dpcknn.py: DPC-KNN clustering + weighted merge BEFORE the block; keep[blk] = clusters */
 #define TR_MAX_DEPTH 32
 #define TR_PREC_BF16 0   /* the product path: bf16 MFMA operands, fp32 accumulate / residual / statistics */
@@ -228,6 +231,8 @@ typedef struct {
  *   PatchMerger (patchmerger.py:32-33): ln = norm (eps 1e-5), w1 = queries zero-padded to n_pad rows [n_pad, D], b1 = zeros,
  *     scale = 1 (embed_dim**-0.5 with scaled_attention).
  *   Sinkhorn (sinkhorn.py:62,73-76): w1 = F.normalize(v) zero-padded to n_pad rows [n_pad, D], b1 = zeros [n_pad].
+ *   Heuristic (heuristic.py:247-258): w3 = the block's visibility mask fp32 [N] of 1/0 (CLS 1), n_pad = N; blocks without a
+ *     new mask leave w3 NULL and keep the previous one.
  *   ATS (ats.py:48): w3 = sample_steps fp32 [n_pad], n_pad = their count (K-1).
  *   DPC-KNN CTM (dpcknn.py:150-151): w3/b3 = score.weight [1,D] / score.bias [1] (fp32); NULL = args.equal_weight. */
 typedef struct {

@@ -30,10 +30,15 @@ from .cluster import (  # noqa: F401
 from .ats import (  # noqa: F401
     ats_sample_counts, ats_sample_steps, ats_scores, ats_cdf, ats_ids_from_cdf, ats_sample_ids, ats_block_forward, ats_forward,
 )
+from .heuristic import heuristic_masks, heuristic_forward  # noqa: F401
 
 
-def forward(params, x, cfg, precision="fp32", return_viz=False, forced=None, noise=None):
+def forward(params, x, cfg, precision="fp32", return_viz=False, forced=None, noise=None, extra=None):
     """Family dispatch used by the tests."""
+    if cfg.family == "heuristic":
+        assert forced is None
+        return heuristic_forward(params, x, cfg, extra["heuristic_pattern"], extra["not_contiguous"], extra.get("min_radius"),
+                                 precision, return_viz)
     if cfg.family == "patchmerger":
         assert forced is None
         return patchmerger_forward(params, x, cfg, precision, return_viz)

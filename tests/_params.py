@@ -177,6 +177,14 @@ GOLDEN_CASES = {
     "patchmerger_small_kr07": dict(family="patchmerger", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
                                    keep_rate=[0.7], reduction_loc=[3, 6, 9], batch=2, wseed=173, xseed=174,
                                    qkv_gain=4.0, factory="patchmerger_small_patch16_224"),
+    # Heuristic (models/heuristic.py): fixed spatial masks, no token removal
+    "heuristic_micro_l2": dict(family="heuristic", embed_dim=128, depth=4, num_heads=2, num_classes=16,
+                               keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=2, wseed=181, xseed=182, qkv_gain=6.0,
+                               heuristic_pattern="l2", not_contiguous=True),
+    "heuristic_small_linf": dict(family="heuristic", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
+                                 keep_rate=[0.7], reduction_loc=[3, 9], batch=2, wseed=183, xseed=184, qkv_gain=4.0,
+                                 factory="heuristic_small_patch16_224", heuristic_pattern="linf", not_contiguous=False,
+                                 min_radius=2.0),
     # SiT (models/sit.py): soft assignment (softmax over tokens) BEFORE the block
     "sit_micro": dict(family="sit", embed_dim=128, depth=4, num_heads=2, num_classes=16,
                       keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=111, xseed=112, qkv_gain=6.0),

@@ -46,11 +46,12 @@ from models.ats import ATSVisionTransformer  # noqa: E402
 from models.sinkhorn import SinkhornVisionTransformer  # noqa: E402
 from models.kmedoids import KMedoidsVisionTransformer  # noqa: E402
 from models.patchmerger import PatchMergerVisionTransformer  # noqa: E402
+from models.heuristic import HeuristicVisionTransformer  # noqa: E402
 
 from tests._params import GOLDEN_CASES, make_params, make_stage_params, make_images, case_config  # noqa: E402
 
 CLASSES = {"topk": TopKVisionTransformer, "evit": EfficientVisionTransformer, "deit": DeitViz, "tome": ToMeVisionTransformer,
-           "dyvit": DynamicVisionTransformer, "sit": SelfSlimmedVisionTransformer, "dpcknn": DPCKNNVisionTransformer, "ats": ATSVisionTransformer, "sinkhorn": SinkhornVisionTransformer, "kmedoids": KMedoidsVisionTransformer, "patchmerger": PatchMergerVisionTransformer}
+           "dyvit": DynamicVisionTransformer, "sit": SelfSlimmedVisionTransformer, "dpcknn": DPCKNNVisionTransformer, "ats": ATSVisionTransformer, "sinkhorn": SinkhornVisionTransformer, "kmedoids": KMedoidsVisionTransformer, "patchmerger": PatchMergerVisionTransformer, "heuristic": HeuristicVisionTransformer}
 
 
 class TopkSpy:
@@ -141,7 +142,9 @@ class RandSpy:
 def build_reference(case):
     args = types.SimpleNamespace(keep_rate=list(case["keep_rate"]), reduction_loc=list(case["reduction_loc"]),
                                  viz_mode=True, dyvit_distill=False, k_neighbors=5,
-                                 equal_weight=bool(case.get("equal_weight", False)), sinkhorn_eps=1.0, cluster_iters=3)
+                                 equal_weight=bool(case.get("equal_weight", False)), sinkhorn_eps=1.0, cluster_iters=3,
+                                 heuristic_pattern=case.get("heuristic_pattern", "l2"),
+                                 not_contiguous=bool(case.get("not_contiguous", False)), min_radius=case.get("min_radius"))
     with contextlib.redirect_stdout(io.StringIO()):
         if "factory" in case:
             m = create_model(case["factory"], pretrained=False, num_classes=case["num_classes"], drop_rate=0.0,
@@ -217,6 +220,8 @@ def run_case(name, case):
     rec["min_rel_gap_at_k"] = np.array(min(gaps) if gaps else np.inf, dtype=np.float64)
     for blk, idx in viz.get("Kept_Tokens", {}).items():
         rec[f"kept_{blk}"] = idx.astype(np.int64)
+    for blk, idx in viz.get("Kept_Tokens_Abs", {}).items():      # Heuristic: visible patch ids (identical for every image)
+        rec[f"keptabs_{blk}"] = idx.astype(np.int64)
     for blk, c in viz.get("Fusion_Assign", {}).items():
         rec[f"compl_{blk}"] = c.astype(np.int64)
     feats = viz.get("Features", {})

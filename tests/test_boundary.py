@@ -34,7 +34,7 @@ def test_registry_has_every_reference_name():
 
 def test_unbuilt_families_fail_loudly():
     with pytest.raises(NotImplementedError):
-        tra.create_model("heuristic_small_patch16_224", args=_args(keep_rate=[0.7], reduction_loc=[3, 6, 9]))
+        tra.create_model("dyvit_small_patch16_224_teacher", args=_args(keep_rate=[0.7], reduction_loc=[3, 6, 9]))
 
 
 @pytest.mark.parametrize("name,dims", [("topk_tiny_patch16_224", (192, 3)), ("evit_small_patch16_224", (384, 6)),
@@ -122,3 +122,37 @@ def test_argument_validation_without_gpu():
     cfg.embed_dim, cfg.depth, cfg.num_heads, cfg.mlp_hidden, cfg.num_classes = 384, 12, 6, 1536, 1000
     n = lib.tr_vit_workspace_bytes(ctypes.byref(cfg), 256)
     assert 0 < n < 2 ** 31
+
+
+def test_reference_finetune_ingest_snippet_runs_unchanged():
+    """train.py:343-369 (drop mismatching head, bicubic-resize the position embedding, load_state_dict(strict=False)) relies on
+    state_dict(), patch_embed.num_patches and pos_embed of the model object: it must run against this build's modules as is
+    (224 -> 384 fine-tuning)."""
+    src = tra.create_model("deit_small_patch16_224_local", pretrained=False, num_classes=1000, img_size=224)
+    checkpoint = {"model": {k: v.clone() for k, v in src.state_dict().items()}}
+    model = tra.create_model("topk_small_patch16_224", pretrained=False, num_classes=10, img_size=384,
+                             args=_args(keep_rate=[0.5], reduction_loc=[3, 6, 9]))
+    # ---- train.py:343-369, verbatim logic
+    checkpoint_model = checkpoint['model']
+    state_dict = model.state_dict()
+    for k in ['head.weight', 'head.bias', 'head_dist.weight', 'head_dist.bias']:
+        if k in checkpoint_model and checkpoint_model[k].shape != state_dict[k].shape:
+            del checkpoint_model[k]
+    pos_embed_checkpoint = checkpoint_model['pos_embed']
+    embedding_size = pos_embed_checkpoint.shape[-1]
+    num_patches = model.patch_embed.num_patches
+    num_extra_tokens = model.pos_embed.shape[-2] - num_patches
+    orig_size = int((pos_embed_checkpoint.shape[-2] - num_extra_tokens) ** 0.5)
+    new_size = int(num_patches ** 0.5)
+    extra_tokens = pos_embed_checkpoint[:, :num_extra_tokens]
+    pos_tokens = pos_embed_checkpoint[:, num_extra_tokens:]
+    pos_tokens = pos_tokens.reshape(-1, orig_size, orig_size, embedding_size).permute(0, 3, 1, 2)
+    pos_tokens = torch.nn.functional.interpolate(pos_tokens, size=(new_size, new_size), mode='bicubic', align_corners=False)
+    pos_tokens = pos_tokens.permute(0, 2, 3, 1).flatten(1, 2)
+    checkpoint_model['pos_embed'] = torch.cat((extra_tokens, pos_tokens), dim=1)
+    missing, unexpected = model.load_state_dict(checkpoint_model, strict=False)
+    # ----
+    assert (orig_size, new_size, num_extra_tokens) == (14, 24, 1)
+    assert sorted(missing) == ["head.bias", "head.weight"] and not unexpected
+    assert torch.equal(model.blocks[5].mlp.fc1.weight, src.blocks[5].mlp.fc1.weight)
+    assert model.pos_embed.shape == (1, 577, 384)

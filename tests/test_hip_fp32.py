@@ -100,6 +100,13 @@ def test_model_fp32_matches_reference_golden(golden_dir, name):
     assert sorted(viz.get("Kept_Tokens", {}).keys()) == [int(k.split("_")[1]) for k in kept_keys]
     if case["family"] == "ats":
         return _check_ats_fp32(name, case, g, logits, viz, kept_keys)
+    if case["family"] == "heuristic":
+        for k in (k for k in g.files if k.startswith("keptabs_")):
+            np.testing.assert_array_equal(viz["Kept_Tokens_Abs"][int(k.split("_")[1])], g[k])
+        d = (logits.cpu() - torch.from_numpy(g["logits"])).abs().max().item()
+        print(f"\n[{name}] fp32 path: masks exact, max|logit - reference| = {d:.2e}")
+        assert d < 2e-4, d
+        return
     for k in kept_keys:                                     # bit-exact token indices, every reduction stage, end to end
         blk = int(k.split("_")[1])
         if case["family"] == "kmedoids":

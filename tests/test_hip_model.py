@@ -28,14 +28,15 @@ from tests._params import GOLDEN_CASES, case_config, case_params, make_images, m
 pytestmark = pytest.mark.gpu
 
 FAM = {"deit": "VisionTransformer", "topk": "TopKVisionTransformer", "evit": "EfficientVisionTransformer",
-       "tome": "ToMeVisionTransformer", "dyvit": "DynamicVisionTransformer", "sit": "SelfSlimmedVisionTransformer", "dpcknn": "DPCKNNVisionTransformer", "ats": "ATSVisionTransformer", "sinkhorn": "SinkhornVisionTransformer", "kmedoids": "KMedoidsVisionTransformer", "patchmerger": "PatchMergerVisionTransformer"}
+       "tome": "ToMeVisionTransformer", "dyvit": "DynamicVisionTransformer", "sit": "SelfSlimmedVisionTransformer", "dpcknn": "DPCKNNVisionTransformer", "ats": "ATSVisionTransformer", "sinkhorn": "SinkhornVisionTransformer", "kmedoids": "KMedoidsVisionTransformer", "patchmerger": "PatchMergerVisionTransformer", "heuristic": "HeuristicVisionTransformer"}
 
 
 def build_model(case):
     import tokenreduction_amd as tra
     args = types.SimpleNamespace(keep_rate=list(case["keep_rate"]), reduction_loc=list(case["reduction_loc"]), viz_mode=True,
                                  dyvit_distill=False, k_neighbors=5, equal_weight=bool(case.get("equal_weight", False)),
-                                 sinkhorn_eps=1.0, cluster_iters=3)
+                                 sinkhorn_eps=1.0, cluster_iters=3, heuristic_pattern=case.get("heuristic_pattern", "l2"),
+                                 not_contiguous=bool(case.get("not_contiguous", False)), min_radius=case.get("min_radius"))
     if "factory" in case:
         m = tra.create_model(case["factory"].replace("_local", "_local_viz") if case["family"] == "deit" else case["factory"],
                              pretrained=False, num_classes=case["num_classes"], drop_rate=0.0,
@@ -91,6 +92,18 @@ def test_model_parity(golden_dir, name):
 
     if case["family"] == "tome":
         return _tome_parity(name, case, g, model, params, cfg, x, logits, viz, info)
+    if case["family"] == "heuristic":
+        keys = sorted((k for k in g.files if k.startswith("keptabs_")), key=lambda k: int(k.split("_")[1]))
+        assert sorted(viz["Kept_Tokens_Abs"].keys()) == [int(k.split("_")[1]) for k in keys]
+        for k in keys:                                                   # image-independent masks: bit-exact vs the reference
+            np.testing.assert_array_equal(viz["Kept_Tokens_Abs"][int(k.split("_")[1])], g[k])
+        lb = oracle.forward(params, x, cfg, precision="bf16", extra=case)
+        ref = torch.from_numpy(g["logits"])
+        rel_bf, rel_ref = ((logits - lb).norm() / lb.norm()).item(), ((logits - ref).norm() / ref.norm()).item()
+        print(f"\n[{name}] relative L2 of logits: vs oracle_bf16 {rel_bf:.3e}, vs reference fp32 {rel_ref:.3e}")
+        assert rel_bf < FORCED_TOL and rel_ref < 0.05, (rel_bf, rel_ref)   # no data-dependent decision anywhere
+        assert model._last_tokens == [197] * cfg.depth
+        return
     if case["family"] in ("sit", "sinkhorn", "patchmerger"):
         return _sit_parity(name, case, g, model, params, cfg, x, logits, viz, info)
     if case["family"] in ("dpcknn", "kmedoids"):

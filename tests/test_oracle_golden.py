@@ -42,6 +42,8 @@ def test_model_matches_reference(golden_dir, name):
         return _check_ats(case, g, x)
     if case["family"] == "kmedoids":
         return _check_kmedoids(case, g, x)
+    if case["family"] == "heuristic":
+        return _check_heuristic(case, g, x)
     logits, viz = oracle.vit_forward(params, x, cfg, return_viz=True)
     # integer outputs: bit-exact
     kept_keys = sorted(k for k in g.files if k.startswith("kept_"))
@@ -97,6 +99,17 @@ def _check_ats(case, g, x):
         assert v2["Kept_Tokens"][blk].shape[1] == counts[blk] - 1
         np.testing.assert_array_equal(v2["Kept_Tokens"][blk][:, :w], kt)
         assert (v2["Kept_Tokens"][blk][:, w:] == -1).all()
+
+
+def _check_heuristic(case, g, x):
+    cfg, params = case_params(case)
+    logits, viz = oracle.forward(params, x, cfg, return_viz=True, extra=case)
+    keys = [k for k in g.files if k.startswith("keptabs_")]
+    assert len(keys) == len(viz["Kept_Tokens_Abs"]) > 0
+    for k in keys:                                         # the visible-token sets of every block in the range, bit-exact
+        np.testing.assert_array_equal(viz["Kept_Tokens_Abs"][int(k.split("_")[1])], g[k])
+    np.testing.assert_allclose(logits.numpy(), g["logits"], atol=FP_TOL, rtol=0)
+    np.testing.assert_allclose(viz["Final_Tokens"][:, :1].numpy(), g["final_tokens"][:, :1], atol=1e-4, rtol=0)
 
 
 def _check_kmedoids(case, g, x):

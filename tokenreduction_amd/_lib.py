@@ -16,7 +16,7 @@ TR_MAX_DEPTH = 32
 TR_EPI_BF16, TR_EPI_GELU_BF16, TR_EPI_RESID_F32, TR_EPI_F32, TR_EPI_PATCH_F32 = 0, 1, 2, 3, 4
 TR_FAMILY_DEIT, TR_FAMILY_TOPK, TR_FAMILY_EVIT, TR_FAMILY_TOME, TR_FAMILY_DYVIT, TR_FAMILY_SIT, \
     TR_FAMILY_DPCKNN, TR_FAMILY_ATS, TR_FAMILY_SINKHORN, TR_FAMILY_KMEDOIDS, \
-    TR_FAMILY_PATCHMERGER = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+    TR_FAMILY_PATCHMERGER, TR_FAMILY_HEURISTIC = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 TR_PREC_BF16, TR_PREC_FP32 = 0, 1
 
 _vp, _i, _f, _l, _sz = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t
@@ -75,6 +75,7 @@ SIGNATURES = {
     "tr_kmedoids": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tr_dpcknn_cluster": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "tr_cluster_merge_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+    "tr_broadcast_rows": (_i, [_vp, _vp, _i, _i, _vp]),
     "tr_residual_snapshot": (_i, [_vp, _vp, _i, _vp, _sz, _vp]),
     "tr_vit_forward": (_i, [C.POINTER(TrVitConfig), C.POINTER(TrVitWeights), _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp,
                             C.POINTER(_i), _i, _vp]),

@@ -219,6 +219,20 @@ __global__ __launch_bounds__(256) void residual_snapshot_kernel(const float* __r
   *reinterpret_cast<float4*>(out + 4 * c) = v;
 }
 
+// dst[b][n] = src[n]: one per-block key mask for the whole batch (Heuristic family, heuristic.py:247-258)
+__global__ __launch_bounds__(256) void broadcast_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int N) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < B * N) dst[e] = src[e % N];
+}
+
+extern "C" int tr_broadcast_rows(const float* src, float* dst, int B, int N, tr_stream_t s) {
+  TR_REQUIRE(src && dst, TR_ERR_NULL, "tr_broadcast_rows: null pointer");
+  TR_REQUIRE(B > 0 && N > 0, TR_ERR_SHAPE, "tr_broadcast_rows: bad shape B=%d N=%d", B, N);
+  hipLaunchKernelGGL(broadcast_rows_kernel, dim3((B * N + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(s), src, dst, B, N);
+  TR_CHECK_LAUNCH("tr_broadcast_rows");
+  return TR_OK;
+}
+
 extern "C" int tr_residual_snapshot(const float* x, const void* delta, int delta_is_f32, float* out, size_t n, tr_stream_t s) {
   TR_REQUIRE(x && out, TR_ERR_NULL, "tr_residual_snapshot: null pointer");
   TR_REQUIRE(n > 0 && n % 4 == 0, TR_ERR_SHAPE, "tr_residual_snapshot: element count must be a positive multiple of 4");

@@ -40,7 +40,7 @@ bool make_plan(const tr_vit_config* c, int B, Plan* p) {
   if (c->patch <= 0 || c->img_size <= 0 || c->img_size % c->patch != 0) return false;
   if (c->depth <= 0 || c->depth > TR_MAX_DEPTH) return false;
   if (c->num_heads <= 0 || c->embed_dim != c->num_heads * 64) return false;
-  if (c->family < TR_FAMILY_DEIT || c->family > TR_FAMILY_PATCHMERGER) return false;
+  if (c->family < TR_FAMILY_DEIT || c->family > TR_FAMILY_HEURISTIC) return false;
   const int g = c->img_size / c->patch;
   p->P = g * g;
   p->N0 = p->P + 1;
@@ -200,6 +200,12 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
       N = Kc + 1;
       have_xn = true;
     }
+    if (cfg->family == TR_FAMILY_HEURISTIC && w->stage[i].w3 != nullptr) {
+      // f4: a new spatial mask takes effect at this block and stays until the next one (heuristic.py:247-258)
+      TR_REQUIRE(w->stage[i].n_pad == N, TR_ERR_CONFIG, "tr_vit_forward: block %d mask has %d entries for %d tokens", i, w->stage[i].n_pad, N);
+      TR_TRY(tr_broadcast_rows(w->stage[i].w3, size_a, B, N, s));
+      size_cur = size_a;
+    }
     if (cfg->family == TR_FAMILY_PATCHMERGER && cfg->keep[i] > 0) {
       // f4: PatchMerger.forward patchmerger.py:35-39 on x[:, 1:] BEFORE the block
       const tr_stage_weights* sw = &w->stage[i];
@@ -293,7 +299,8 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
     // masked_fill(-finfo.max) underflowing in the reference's softmax, ats.py:117-120)
     // K-Medoids: the NEXT block's clustering is seeded by the column sums of THIS block's attention (kmedoids.py:240)
     const bool want_colsum = cfg->family == TR_FAMILY_KMEDOIDS && i + 1 < cfg->depth && cfg->keep[i + 1] > 0;
-    TR_TRY(op_attn(f32, qkv, ao, (K > 0 || Ks > 0) ? cls_rows : nullptr, (tome || ats) ? size_cur : nullptr,
+    const bool masked = ats || cfg->family == TR_FAMILY_HEURISTIC;
+    TR_TRY(op_attn(f32, qkv, ao, (K > 0 || Ks > 0) ? cls_rows : nullptr, (tome || masked) ? size_cur : nullptr,
                    want_colsum ? colsum_part : nullptr, B, N, H, s));
     int Nn = N;
     if (Ks > 0) {

@@ -888,3 +888,101 @@ class PatchMergerVisionTransformer(SelfSlimmedVisionTransformer):
         out = super()._viz_data(ws, B, tokens)
         out["Center_Feats"] = {}
         return out
+
+
+class HeuristicVisionTransformer(VisionTransformer):
+    """models/heuristic.py:88-277: image-independent spatial pruning.  From every block in the reduction range on, the patch
+    tokens farther than that block's radius (L1 / L2 / Linf distance from the grid centre) are masked as attention keys; no
+    token is removed.  The radii are constructor-time geometry (prep_pattern / prep_pattern_stage_subset), computed on the
+    host exactly as the reference does.  (The reference also masks those tokens as QUERIES, which turns their rows into the
+    mean of V; here they attend like everyone else -- rows nothing ever reads: they stay masked as keys to the end.)"""
+    _family = _lib.TR_FAMILY_HEURISTIC
+    _features_every_block = False
+
+    def __init__(self, *a, args=None, **kw):
+        super().__init__(*a, args=args, **kw)
+        self.heuristic_pattern = args.heuristic_pattern
+        if args.not_contiguous:
+            self.reduction_loc = list(args.reduction_loc)
+            self.keep_rate = list(args.keep_rate)
+            if len(self.keep_rate) != 1:
+                raise ValueError("heuristic with --not_contiguous defines its token targets for a single keep_rate only "
+                                 "(heuristic.py:127-128)")
+            num_tokens = [int(self.patch_embed.num_patches * self.keep_rate[0] ** (idx + 1)) for idx in range(len(self.reduction_loc))]
+            self.distances, self.threshold, self.P = self.prep_pattern_stage_subset(num_tokens)
+        else:
+            self.min_radius = args.min_radius
+            self.start_stage = int(min(args.reduction_loc))
+            self.end_stage = int(max(args.reduction_loc))
+            self.reduction_loc = [idx for idx in range(self.start_stage, self.end_stage + 1)]
+            self.distances, self.threshold, self.P = self.prep_pattern()
+
+    def _distance_grid(self):
+        P = int(self.patch_embed.num_patches ** 0.5)
+        xs = torch.linspace(-P // 2, P // 2, steps=P)
+        ys = torch.linspace(-P // 2, P // 2, steps=P)
+        x, y = torch.meshgrid(xs, ys, indexing="ij")
+        pat = self.heuristic_pattern.lower()
+        if pat == "l1":
+            z = torch.abs(x) + torch.abs(y)
+        elif pat == "l2":
+            z = torch.sqrt(x * x + y * y)
+        elif pat == "linf":
+            z = torch.max(torch.abs(x), torch.abs(y))
+        else:
+            raise ValueError(f"heuristic_pattern {self.heuristic_pattern!r}: expected l1 | l2 | linf")
+        return z, P
+
+    def prep_pattern(self):
+        """heuristic.py:157-181: linear radius schedule over the contiguous reduction range."""
+        z, P = self._distance_grid()
+        if self.min_radius is None or self.min_radius <= 0:
+            self.min_radius = z[P // 2, P // 2]
+        steps = self.end_stage - self.start_stage + 3
+        threshold = torch.linspace(float(z[0, 0]), float(self.min_radius), steps)
+        threshold = torch.nn.functional.pad(threshold, (max(self.start_stage - 1, 0), 0), value=float(z[0, 0]))
+        threshold = torch.nn.functional.pad(threshold, (0, max(self.depth - self.end_stage - 1, 0)), value=float(threshold[-1]))
+        return z, threshold, P
+
+    def prep_pattern_stage_subset(self, num_tokens):
+        """heuristic.py:184-224: per stage, the radius whose visible-token count is closest to the target."""
+        z, P = self._distance_grid()
+        unique_distances = torch.unique(z)
+        within = [torch.sum(z <= u).item() for u in unique_distances]
+        closest_thresholds = []
+        for num_token in num_tokens:
+            closest, thr = np.inf, None
+            for idx, t in enumerate(within):
+                if np.abs(num_token - t) < closest:
+                    closest, thr = np.abs(num_token - t), unique_distances[idx].item()
+            closest_thresholds.append(thr)
+        closest_thresholds = [unique_distances[-1].item()] + closest_thresholds
+        threshold, counter = [], 0
+        for idx in range(self.depth):
+            if idx in self.reduction_loc:
+                counter += 1
+            threshold.append(torch.ones((P, P)) * closest_thresholds[counter])
+        return z, threshold, P
+
+    def get_reduction_count(self):
+        return self.reduction_loc
+
+    def _block_mask(self, idx):
+        return (self.distances <= self.threshold[idx]).reshape(self.P * self.P)
+
+    def _pack_stages(self, W, w16, f32, keep_alive):
+        dev = self.pos_embed.device
+        for idx in self.reduction_loc:
+            m = torch.cat([torch.ones(1), self._block_mask(idx).float()]).to(dev)
+            W.stage[idx].w3 = f32(m)
+            W.stage[idx].n_pad = m.numel()
+
+    def _feature_blocks(self, tokens):
+        return sorted(set(int(b) for b in self.reduction_loc) | {self.depth - 1})
+
+    def _viz_data(self, ws, B, tokens):
+        decisions = {}
+        for idx in self.reduction_loc:
+            ind = self._block_mask(idx).nonzero(as_tuple=True)[0]
+            decisions[idx] = ind.unsqueeze(0).expand(B, -1).numpy().astype(np.int64)
+        return {"Kept_Tokens_Abs": decisions}

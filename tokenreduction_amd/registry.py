@@ -6,7 +6,7 @@ callers train.py:322-331, validate.py:88-94):
 
 Same factory names and fixed dims as models_act.py (tiny 192/3, small 384/6, base 768/12; depth 12,
 mlp_ratio 4, qkv_bias, LayerNorm eps 1e-6).  Families on the hot path this round: deit_*_local,
-topk_*, evit_*, tome_*, dyvit_* (eval), sit_*, dpcknn_*, ats_*, sinkhorn_*, kmedoids_*, patchmerger_*.  The other families' names are registered too and raise NotImplementedError naming
+topk_*, evit_*, tome_*, dyvit_* (eval), sit_*, dpcknn_*, ats_*, sinkhorn_*, kmedoids_*, patchmerger_*, heuristic_*.  The other families' names are registered too and raise NotImplementedError naming
 the SURVEY.md section 8 row that will bring them, so a driver fails loudly instead of silently falling back.
 """
 from __future__ import annotations
@@ -17,7 +17,7 @@ from functools import partial
 import torch
 import torch.nn as nn
 
-from .models import (ATSVisionTransformer, KMedoidsVisionTransformer, PatchMergerVisionTransformer, SinkhornVisionTransformer, DPCKNNVisionTransformer, DynamicVisionTransformer, EfficientVisionTransformer, SelfSlimmedVisionTransformer, ToMeVisionTransformer,
+from .models import (ATSVisionTransformer, HeuristicVisionTransformer, KMedoidsVisionTransformer, PatchMergerVisionTransformer, SinkhornVisionTransformer, DPCKNNVisionTransformer, DynamicVisionTransformer, EfficientVisionTransformer, SelfSlimmedVisionTransformer, ToMeVisionTransformer,
                      TopKVisionTransformer, VisionTransformer)
 
 _model_entrypoints = {}
@@ -104,13 +104,10 @@ for _size in _DIMS:
                                (f"ats_{_size}_patch16_224", ATSVisionTransformer, False),
                                (f"sinkhorn_{_size}_patch16_224", SinkhornVisionTransformer, False),
                                (f"kmedoids_{_size}_patch16_224", KMedoidsVisionTransformer, False),
-                               (f"patchmerger_{_size}_patch16_224", PatchMergerVisionTransformer, False)):
+                               (f"patchmerger_{_size}_patch16_224", PatchMergerVisionTransformer, False),
+                               (f"heuristic_{_size}_patch16_224", HeuristicVisionTransformer, False)):
         _f = _make(_cls, _size, _name, _drop)
         _f.__name__ = _name
-        register_model(_f)
-    for _fam, _row in (("heuristic", "f4"),):
-        _f = _planned(_fam, _row)
-        _f.__name__ = f"{_fam}_{_size}_patch16_224"
         register_model(_f)
     _f = _planned("dyvit teacher", "a10-a11")
     _f.__name__ = f"dyvit_{_size}_patch16_224_teacher"

@@ -143,6 +143,10 @@ def forward_stepwise(model: VisionTransformer, x: torch.Tensor, trace: Optional[
                                                           f32(blk.norm1.bias), eps))
             N = Kc + 1
             h, xn = h3_.view(B * N, D), xn.view(B * N, D)
+        if cfg.family == 11 and i in model.reduction_loc:
+            # Heuristic: a new spatial key mask from this block on (heuristic.py:247-258)
+            m = torch.cat([torch.ones(1), model._block_mask(i).float()]).to(dev)
+            size = m.unsqueeze(0).expand(B, -1).contiguous()
         if cfg.family == 10 and int(cfg.keep[i]) > 0:
             # PatchMerger: K learned queries attend over the normalised tokens BEFORE the block (patchmerger.py:35-39)
             Kc, M = int(cfg.keep[i]), B * N
