@@ -32,9 +32,18 @@ def test_registry_has_every_reference_name():
         assert tra.is_model(n), n
 
 
-def test_unbuilt_families_fail_loudly():
-    with pytest.raises(NotImplementedError):
-        tra.create_model("dyvit_small_patch16_224_teacher", args=_args(keep_rate=[0.7], reduction_loc=[3, 6, 9]))
+def test_every_reference_factory_name_constructs():
+    """All 42 names of models_act.py:8-51 build a module of this package (construction is host-side; compute needs the GPU)."""
+    args = _args(keep_rate=[0.7], reduction_loc=[3, 6, 9], dyvit_distill=False, k_neighbors=5, equal_weight=False,
+                 cluster_iters=3, sinkhorn_eps=1.0, heuristic_pattern="l2", not_contiguous=False, min_radius=None)
+    for n in REFERENCE_NAMES:
+        if "_tiny_" not in n:          # one size is enough for the smoke; tiny = 5.7 M params keeps this fast
+            continue
+        m = tra.create_model(n, pretrained=False, num_classes=10, img_size=224, args=args)
+        assert isinstance(m, torch.nn.Module) and m.embed_dim == 192, n
+    with pytest.raises(NotImplementedError):      # the numpy-RNG branch of K-Medoids is refused loudly, not approximated
+        tra.create_model("kmedoids_tiny_patch16_224", args=_args(keep_rate=[0.7], reduction_loc=[3, 6, 9], equal_weight=True,
+                                                                cluster_iters=3))
 
 
 @pytest.mark.parametrize("name,dims", [("topk_tiny_patch16_224", (192, 3)), ("evit_small_patch16_224", (384, 6)),

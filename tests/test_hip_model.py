@@ -406,3 +406,21 @@ def test_forward_is_graph_capturable():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, model(x2))
+
+
+def test_dyvit_teacher_returns_logits_and_normed_tokens():
+    """VisionTransformerTeacher.forward dyvit.py:325-334: (head(norm(x)[:, 0]), norm(x)[:, 1:])."""
+    import tokenreduction_amd as tra
+    case = GOLDEN_CASES["deit_micro"]
+    cfg, params = case_params(case)
+    m = tra.VisionTransformerTeacher(patch_size=16, embed_dim=case["embed_dim"], depth=case["depth"], num_heads=case["num_heads"],
+                                     mlp_ratio=4, qkv_bias=True, num_classes=case["num_classes"])
+    m.load_state_dict(params, strict=True)
+    m = m.cuda().eval()
+    x = make_images(2, 224, 3)
+    logits, tokens = m(x.cuda())
+    lb, vb = oracle.vit_forward(params, x, cfg, precision="bf16", return_viz=True)
+    want = oracle.layer_norm(vb["Final_Tokens"], params["norm.weight"], params["norm.bias"], cfg.ln_eps)[:, 1:]
+    assert tokens.shape == want.shape == (2, 196, case["embed_dim"])
+    assert ((logits.cpu() - lb).norm() / lb.norm()).item() < FORCED_TOL
+    assert ((tokens.cpu() - want).norm() / want.norm()).item() < FORCED_TOL

@@ -7,6 +7,7 @@ from .registry import create_model, register_model, list_models, is_model  # noq
 from .models import (VisionTransformer, TopKVisionTransformer, EfficientVisionTransformer, ToMeVisionTransformer,  # noqa: F401
                      DynamicVisionTransformer, SelfSlimmedVisionTransformer, DPCKNNVisionTransformer,
                      ATSVisionTransformer, SinkhornVisionTransformer, KMedoidsVisionTransformer,
-                     PatchMergerVisionTransformer, HeuristicVisionTransformer)
+                     PatchMergerVisionTransformer, HeuristicVisionTransformer,
+                     VisionTransformerTeacher)
 
 __version__ = "0.1.0"

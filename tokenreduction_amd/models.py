@@ -258,7 +258,8 @@ class VisionTransformer(nn.Module):
         ws = self._workspace(B, x.device)
         if self.viz_mode and self._soft_elems(B) and ws.get("soft") is None:      # viz_mode switched on after the first call
             ws["soft"] = torch.empty(self._soft_elems(B), dtype=torch.float32, device=x.device)
-        if self.viz_mode and ws.get("feat") is None:
+        want_feat = self.viz_mode or getattr(self, "_always_features", False)
+        if want_feat and ws.get("feat") is None:
             # viz_data["Features"]: the residual stream after every block (upper bound depth * B * N0 * D fp32)
             n0 = self.patch_embed.num_patches + 1
             ws["feat"] = torch.empty(self.depth * B * n0 * self.embed_dim, dtype=torch.float32, device=x.device)
@@ -268,10 +269,11 @@ class VisionTransformer(nn.Module):
             rc = lib.tr_vit_forward(C.byref(cfg), C.byref(pk["W"]), x.data_ptr(), logits.data_ptr(), ws["buf"].data_ptr(),
                                     ws["nbytes"], ws["kept"].data_ptr(), ws["compl"].data_ptr(),
                                     None if ws.get("soft") is None else ws["soft"].data_ptr(), self._noise_ptr(B, x.device),
-                                    ws["feat"].data_ptr() if self.viz_mode else None, tokens, B,
+                                    ws["feat"].data_ptr() if want_feat else None, tokens, B,
                                     torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "tr_vit_forward")
         self._last_tokens = list(tokens)
+        self._last_ws = ws
         if self.viz_mode:
             viz = self._viz_data(ws, B, list(tokens))
             viz["Features"] = self._features(ws, B, list(tokens))
@@ -986,3 +988,23 @@ class HeuristicVisionTransformer(VisionTransformer):
             ind = self._block_mask(idx).nonzero(as_tuple=True)[0]
             decisions[idx] = ind.unsqueeze(0).expand(B, -1).numpy().astype(np.int64)
         return {"Kept_Tokens_Abs": decisions}
+
+
+class VisionTransformerTeacher(VisionTransformer):
+    """models/dyvit.py:267-334: the DyViT distillation teacher -- a plain DeiT whose forward returns
+    (head(norm(x)[:, 0]), norm(x)[:, 1:]): the logits and the final-norm patch-token features, always as a tuple."""
+    _always_features = True
+
+    def forward(self, x):
+        viz, self.viz_mode = self.viz_mode, False
+        try:
+            logits = super().forward(x)
+        finally:
+            self.viz_mode = viz
+        from . import ops
+        B, N, D = x.shape[0], self._last_tokens[-1], self.embed_dim
+        off = sum(B * n * D for n in self._last_tokens[:-1])
+        x_final = self._last_ws["feat"][off: off + B * N * D]                    # residual stream after the last block
+        feature = ops.layernorm_f32(x_final.view(B * N, D), self.norm.weight.detach().float().contiguous(),
+                                    self.norm.bias.detach().float().contiguous(), float(self.norm.eps)).view(B, N, D)
+        return logits, feature[:, 1:]

@@ -5,9 +5,9 @@ callers train.py:322-331, validate.py:88-94):
                  drop_block_rate=None, img_size=..., args=Namespace(keep_rate, reduction_loc, ...))
 
 Same factory names and fixed dims as models_act.py (tiny 192/3, small 384/6, base 768/12; depth 12,
-mlp_ratio 4, qkv_bias, LayerNorm eps 1e-6).  Families on the hot path this round: deit_*_local,
-topk_*, evit_*, tome_*, dyvit_* (eval), sit_*, dpcknn_*, ats_*, sinkhorn_*, kmedoids_*, patchmerger_*, heuristic_*.  The other families' names are registered too and raise NotImplementedError naming
-the SURVEY.md section 8 row that will bring them, so a driver fails loudly instead of silently falling back.
+mlp_ratio 4, qkv_bias, LayerNorm eps 1e-6): deit_*_local[_viz], topk_*, evit_*, tome_*, dyvit_* (eval) and
+dyvit_*_teacher, sit_*, dpcknn_*, ats_*, sinkhorn_*, kmedoids_*, patchmerger_*, heuristic_*.  Unsupported options
+(training mode, distillation token, K-Medoids' numpy-seeded equal_weight branch) raise instead of silently falling back.
 """
 from __future__ import annotations
 
@@ -17,7 +17,7 @@ from functools import partial
 import torch
 import torch.nn as nn
 
-from .models import (ATSVisionTransformer, HeuristicVisionTransformer, KMedoidsVisionTransformer, PatchMergerVisionTransformer, SinkhornVisionTransformer, DPCKNNVisionTransformer, DynamicVisionTransformer, EfficientVisionTransformer, SelfSlimmedVisionTransformer, ToMeVisionTransformer,
+from .models import (ATSVisionTransformer, HeuristicVisionTransformer, VisionTransformerTeacher, KMedoidsVisionTransformer, PatchMergerVisionTransformer, SinkhornVisionTransformer, DPCKNNVisionTransformer, DynamicVisionTransformer, EfficientVisionTransformer, SelfSlimmedVisionTransformer, ToMeVisionTransformer,
                      TopKVisionTransformer, VisionTransformer)
 
 _model_entrypoints = {}
@@ -85,13 +85,6 @@ def _make(cls, size, key_prefix, drop_args):
     return factory
 
 
-def _planned(family, row):
-    def factory(pretrained=False, **kwargs):
-        raise NotImplementedError(f"{family}: not built yet -- SURVEY.md section 8a rows {row} are scheduled after the "
-                                  f"Top-K/EViT path; no silent fallback exists")
-    return factory
-
-
 for _size in _DIMS:
     for _name, _cls, _drop in ((f"deit_{_size}_patch16_224_local", VisionTransformer, True),
                                (f"deit_{_size}_patch16_224_local_viz", VisionTransformer, False),
@@ -109,6 +102,6 @@ for _size in _DIMS:
         _f = _make(_cls, _size, _name, _drop)
         _f.__name__ = _name
         register_model(_f)
-    _f = _planned("dyvit teacher", "a10-a11")
+    _f = _make(VisionTransformerTeacher, _size, f"dyvit_{_size}_patch16_224_teacher", False)    # models_act.py:383-405
     _f.__name__ = f"dyvit_{_size}_patch16_224_teacher"
     register_model(_f)
