@@ -307,7 +307,8 @@ def test_attention_proportional(ops, B, N, H):
 
 
 @pytest.mark.parametrize("f32", [False, True])
-@pytest.mark.parametrize("B,N,H,r", [(3, 197, 6, 59), (2, 197, 2, 98), (2, 138, 3, 41), (2, 98, 6, 1), (1, 5, 1, 2), (2, 8, 2, 3)])
+@pytest.mark.parametrize("B,N,H,r", [(3, 197, 6, 59), (2, 197, 2, 98), (2, 138, 3, 41), (2, 98, 6, 1), (1, 5, 1, 2), (2, 8, 2, 3),
+                                     (2, 577, 12, 144)])
 def test_tome_match_bit_exact(ops, f32, B, N, H, r):
     """bipartite_soft_matching: integer outputs, bit-exact against the oracle on the device's own K (bf16-rounded for the
     bf16 path).  Random gaussians: score gaps are far above fp32 accumulation-order noise, checked below."""

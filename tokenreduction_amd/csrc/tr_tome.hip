@@ -16,7 +16,7 @@
 
 namespace {
 
-constexpr int TOME_MAX_N = 224;      // tokens incl. CLS (224^2 inputs: 197)
+constexpr int TOME_MAX_N = 600;      // tokens incl. CLS: 197 at 224^2 inputs, 577 at 384^2 (metric rows live in LDS: N*65 floats)
 constexpr int MST = 65;              // metric row stride in floats (odd: conflict-free column walks)
 
 // order-preserving map float -> uint32 (a < b  <=>  key(a) < key(b)), so (score, lowest j) maxima reduce with one ds_max_u64
@@ -30,7 +30,7 @@ template <bool F32>
 __global__ __launch_bounds__(256) void tome_match_kernel(const void* __restrict__ qkv, int32_t* __restrict__ unm_idx,
                                                          int32_t* __restrict__ src_idx, int32_t* __restrict__ dst_idx, int N, int H,
                                                          int r) {
-  __shared__ float s_m[TOME_MAX_N * MST];
+  extern __shared__ __attribute__((aligned(16))) float s_m[];      // [N][MST], dynamic: 50 KB at N = 197, 150 KB at N = 577
   __shared__ unsigned long long s_key[(TOME_MAX_N + 1) / 2];
   __shared__ int s_edge[(TOME_MAX_N + 1) / 2];
   __shared__ unsigned char s_unm[(TOME_MAX_N + 1) / 2];
@@ -252,8 +252,12 @@ extern "C" int tr_tome_match(const void* qkv, int qkv_is_f32, int32_t* unm_idx, 
   TR_REQUIRE(r >= 1 && r <= (N - 1) / 2, TR_ERR_SHAPE, "tr_tome_match: r=%d must be in [1, (N-1)/2] for N=%d (tome.py:253)", r, N);
   TR_REQUIRE(tr_aligned16(qkv), TR_ERR_ALIGN, "tr_tome_match: qkv must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(s);
-  if (qkv_is_f32) hipLaunchKernelGGL(tome_match_kernel<true>, dim3(B), dim3(256), 0, st, qkv, unm_idx, src_idx, dst_idx, N, H, r);
-  else hipLaunchKernelGGL(tome_match_kernel<false>, dim3(B), dim3(256), 0, st, qkv, unm_idx, src_idx, dst_idx, N, H, r);
+  const size_t lds = (size_t)N * MST * sizeof(float);
+  const void* fn = qkv_is_f32 ? reinterpret_cast<const void*>(tome_match_kernel<true>) : reinterpret_cast<const void*>(tome_match_kernel<false>);
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_tome_match: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+  if (qkv_is_f32) hipLaunchKernelGGL(tome_match_kernel<true>, dim3(B), dim3(256), lds, st, qkv, unm_idx, src_idx, dst_idx, N, H, r);
+  else hipLaunchKernelGGL(tome_match_kernel<false>, dim3(B), dim3(256), lds, st, qkv, unm_idx, src_idx, dst_idx, N, H, r);
   TR_CHECK_LAUNCH("tr_tome_match");
   return TR_OK;
 }
