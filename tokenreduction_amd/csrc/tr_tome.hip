@@ -26,8 +26,9 @@ __device__ __forceinline__ unsigned long long score_key(float v, int j) {
   return ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - (unsigned int)j);
 }
 
+constexpr int TMT = 1024;   // 16 waves per image: the kernel is a chain of short latency-bound phases, one workgroup per CU
 template <bool F32>
-__global__ __launch_bounds__(256) void tome_match_kernel(const void* __restrict__ qkv, int32_t* __restrict__ unm_idx,
+__global__ __launch_bounds__(TMT) void tome_match_kernel(const void* __restrict__ qkv, int32_t* __restrict__ unm_idx,
                                                          int32_t* __restrict__ src_idx, int32_t* __restrict__ dst_idx, int N, int H,
                                                          int r) {
   extern __shared__ __attribute__((aligned(16))) float s_m[];      // [N][MST], dynamic: 50 KB at N = 197, 150 KB at N = 577
@@ -40,7 +41,7 @@ __global__ __launch_bounds__(256) void tome_match_kernel(const void* __restrict_
   // metric = mean over heads of K (post-bias), then metric / metric.norm(dim=-1)  (tome.py:58, :255).  One 8-wide chunk of a
   // token per lane (16-B loads for bf16), head sum sequential in fp32 like a strided torch mean; the 8 lanes of a token
   // share the sum of squares through the wave.
-  for (int item = tid; item < N * 8; item += 256) {
+  for (int item = tid; item < N * 8; item += TMT) {
     const int n = item >> 3, c = item & 7;
     float m[8];
 #pragma unroll
@@ -84,13 +85,13 @@ __global__ __launch_bounds__(256) void tome_match_kernel(const void* __restrict_
 #pragma unroll
     for (int k = 0; k < 8; ++k) s_m[n * MST + c * 8 + k] = m[k] / nrm;
   }
-  for (int i = tid; i < na; i += 256) s_key[i] = score_key(-INFINITY, 0);    // row 0 (CLS) stays -inf: never merged (tome.py:259)
+  for (int i = tid; i < na; i += TMT) s_key[i] = score_key(-INFINITY, 0);    // row 0 (CLS) stays -inf: never merged (tome.py:259)
   __syncthreads();
   // scores[i][j] = a_i . b_j (a = even tokens, b = odd tokens) in 4x4 register tiles, rows/columns STRIDED over the tile grid
   // (i = ti + nti*ii, j = tj + ntj*jj) so the lanes of a wave read consecutive b rows (conflict-free, a rows broadcast);
   // row max/argmax (ties -> lowest j, torch's CPU max) through ds_max_u64 on an order-preserving (score, ~j) key
   const int nti = (na + 3) >> 2, ntj = (nb + 3) >> 2;
-  for (int t = tid; t < nti * ntj; t += 256) {
+  for (int t = tid; t < nti * ntj; t += TMT) {
     const int ti = t / ntj, tj = t - ti * ntj;
     const float* ap[4];
     const float* bp[4];
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(256) void tome_match_kernel(const void* __restrict_
   }
   __syncthreads();
   // descending rank of the row maxima (ties: lowest index first) = argsort(descending); keys order exactly like the floats
-  for (int i = tid; i < na; i += 256) {
+  for (int i = tid; i < na; i += TMT) {
     const unsigned int vi = (unsigned int)(s_key[i] >> 32);
     int rank = 0;
     for (int j = 0; j < na; ++j) {
@@ -171,13 +172,13 @@ __global__ __launch_bounds__(256) void tome_match_kernel(const void* __restrict_
     s_unm[i] = rank >= r;
   }
   __syncthreads();
-  for (int e = tid; e < r; e += 256) {
+  for (int e = tid; e < r; e += TMT) {
     const int i = s_edge[e];
     src_idx[(size_t)b * r + e] = i;
     dst_idx[(size_t)b * r + e] = (int)(0xffffffffu - (unsigned int)(s_key[i] & 0xffffffffull));
   }
   // unmerged tokens, ascending (tome.py:275-277: keeps the class token first)
-  for (int i = tid; i < na; i += 256) {
+  for (int i = tid; i < na; i += TMT) {
     if (!s_unm[i]) continue;
     int pos = 0;
     for (int j = 0; j < i; ++j) pos += s_unm[j];
@@ -256,8 +257,8 @@ extern "C" int tr_tome_match(const void* qkv, int qkv_is_f32, int32_t* unm_idx, 
   const void* fn = qkv_is_f32 ? reinterpret_cast<const void*>(tome_match_kernel<true>) : reinterpret_cast<const void*>(tome_match_kernel<false>);
   hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_tome_match: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-  if (qkv_is_f32) hipLaunchKernelGGL(tome_match_kernel<true>, dim3(B), dim3(256), lds, st, qkv, unm_idx, src_idx, dst_idx, N, H, r);
-  else hipLaunchKernelGGL(tome_match_kernel<false>, dim3(B), dim3(256), lds, st, qkv, unm_idx, src_idx, dst_idx, N, H, r);
+  if (qkv_is_f32) hipLaunchKernelGGL(tome_match_kernel<true>, dim3(B), dim3(TMT), lds, st, qkv, unm_idx, src_idx, dst_idx, N, H, r);
+  else hipLaunchKernelGGL(tome_match_kernel<false>, dim3(B), dim3(TMT), lds, st, qkv, unm_idx, src_idx, dst_idx, N, H, r);
   TR_CHECK_LAUNCH("tr_tome_match");
   return TR_OK;
 }
