@@ -140,6 +140,12 @@ int tr_sit_merge(const float* logits, int ldl, float scale, const float* x, floa
  * patchmerger.py:36-39); the CLS row still comes from x. */
 int tr_softassign_merge(const float* logits, int ldl, float scale, const float* x, const float* src, float* x_out, float* soft,
                         int B, int N, int K, int D, tr_stream_t s);
+/* Same result on MFMA (what the bf16 executor uses; K <= 192): apply_softmax != 0 first turns `logits` IN PLACE into the
+ * token-axis softmax of logits*scale (and writes `soft` if given), then x_out[b,1+k,:] = sum_p logits[b,1+p,k] * src[b,1+p,:]
+ * with both operands split into bf16 hi + lo (relative error ~2^-16).  apply_softmax == 0: `logits` already holds the
+ * weights (Sinkhorn's transport plan). */
+int tr_softassign_merge_fast(float* logits, int ldl, float scale, int apply_softmax, const float* x, const float* src, float* x_out,
+                             float* soft, int B, int N, int K, int D, tr_stream_t s);
 /* ---- DPC-KNN (csrc/tr_cluster.hip) --------------------------------------------------------------------------------------
  * tr_dpcknn_cluster: cluster_dpc_knn dpcknn.py:44-100 (token_mask=None) on the patch rows of x fp32 [B,N,D] (row 0 = CLS,
  *   ignored): centers int32 [B,K] = topk(score, K) in descending-score order (index_down), idx_cluster int32 [B,N-1],

@@ -623,3 +623,29 @@ def test_attention_long(ops, B, N, H):
         torch.testing.assert_close(part.sum(dim=(1, 2)).cpu(), attn.sum(dim=1).sum(dim=1).float(), atol=5e-4, rtol=2e-3)
         got2, _ = ops.attention(qkv.bfloat16().cuda(), B, N, H, size=None if sz is None else sz.cuda())
         assert torch.equal(got2, got)                                            # side outputs do not change the main one
+
+
+@pytest.mark.parametrize("softmax", [True, False])
+@pytest.mark.parametrize("B,N,K,D,ldl", [(3, 197, 137, 384, 144), (2, 138, 96, 128, 96), (2, 97, 67, 768, 72), (1, 9, 3, 64, 8),
+                                         (2, 197, 176, 192, 176), (1, 577, 144, 768, 144)])
+def test_softassign_merge_fast(ops, softmax, B, N, K, D, ldl):
+    """MFMA soft merge (SiT / PatchMerger / Sinkhorn in the bf16 executor): hi/lo-split bf16 operands, fp32 accumulation --
+    within 1e-4 of fp64, against 4e-3 for plain bf16 operands."""
+    rng = _rng(8000 + N + K)
+    x, src = _randn(rng, B, N, D), _randn(rng, B, N, D)
+    scale = 1.3
+    if softmax:
+        logits = _randn(rng, B, N, ldl, scale=2.0)
+        w = torch.softmax(logits[:, 1:, :K].double() * scale, dim=1)                # [B,P,K]
+    else:
+        logits = torch.from_numpy(rng.random((B, N, ldl)).astype(np.float32))
+        w = logits[:, 1:, :K].double()
+    want = torch.cat([x[:, :1].double(), torch.bmm(w.transpose(1, 2), src[:, 1:].double())], dim=1).float()
+    got, soft = ops.softassign_merge_fast(logits.clone().cuda(), scale, x.cuda(), K, apply_softmax=softmax, want_soft=True, src=src.cuda())
+    ref_scale = float(want[:, 1:].abs().max())
+    torch.testing.assert_close(got.cpu(), want, atol=1e-4 * ref_scale, rtol=1e-4)
+    assert torch.equal(got[:, 0].cpu(), x[:, 0])
+    if softmax:
+        torch.testing.assert_close(soft.cpu(), w.transpose(1, 2).float(), atol=1e-7, rtol=2e-5)
+    else:
+        assert soft is None

@@ -66,6 +66,7 @@ SIGNATURES = {
     "tr_dyvit_score": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "tr_sit_merge": (_i, [_vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tr_softassign_merge": (_i, [_vp, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "tr_softassign_merge_fast": (_i, [_vp, _i, _f, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tr_rownorm": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "tr_sinkhorn": (_i, [_vp, _i, _f, _i, _vp, _vp, _i, _i, _i, _vp]),
     "tr_weighted_merge": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -165,6 +165,131 @@ __global__ __launch_bounds__(256) void sit_merge_kernel(const float* __restrict_
   }
 }
 
+// ---- fast path of the soft merges (SiT, PatchMerger, Sinkhorn) for the bf16 executor --------------------------------------
+// softmax over the token axis, in place on the token-major logits (F.softmax(weight * scale, dim=1), sit.py:38).
+// grid (ceil(K/32), B): 32 output columns per workgroup (lanes along k: coalesced), 8 token groups reduced through LDS
+__global__ __launch_bounds__(256) void token_softmax_kernel(float* __restrict__ logits, int ldl, float scale, float* __restrict__ soft,
+                                                            int N, int K) {
+  __shared__ float s_red[8][32];
+  __shared__ float s_max[32], s_inv[32];
+  const int tid = threadIdx.x, kk = tid & 31, pg = tid >> 5;
+  const int b = blockIdx.y, k = blockIdx.x * 32 + kk;
+  const bool kval = k < K;
+  const int P = N - 1;
+  float* lg = logits + ((size_t)b * N + 1) * ldl + blockIdx.x * 32 + kk;
+  float mx = -INFINITY;
+  if (kval)
+    for (int p = pg; p < P; p += 8) mx = fmaxf(mx, lg[(size_t)p * ldl] * scale);
+  s_red[pg][kk] = mx;
+  __syncthreads();
+  if (tid < 32) {
+    float m = s_red[0][tid];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) m = fmaxf(m, s_red[g][tid]);
+    s_max[tid] = m;
+  }
+  __syncthreads();
+  const float m = s_max[kk];
+  float sum = 0.f;
+  if (kval)
+    for (int p = pg; p < P; p += 8) sum += expf(lg[(size_t)p * ldl] * scale - m);
+  __syncthreads();
+  s_red[pg][kk] = sum;
+  __syncthreads();
+  if (tid < 32) {
+    float t = s_red[0][tid];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) t += s_red[g][tid];
+    s_inv[tid] = 1.0f / t;
+  }
+  __syncthreads();
+  const float inv = s_inv[kk];
+  if (kval)
+    for (int p = pg; p < P; p += 8) {
+      const float w = expf(lg[(size_t)p * ldl] * scale - m) * inv;
+      lg[(size_t)p * ldl] = w;
+      if (soft != nullptr) soft[((size_t)b * K + k) * P + p] = w;
+    }
+}
+
+// out[b][1+k][:] = sum_p w[b][1+p][k] * src[b][1+p][:] on MFMA: both operands are split into bf16 hi + lo (3 products,
+// relative error ~2^-16) and transposed through LDS so the token axis is the contraction.  Workgroup = one image x 64
+// feature columns, wave = 16 columns x all K (<= 192) outputs; tokens walked in slabs of 32.
+constexpr int MK_MAX = 192, MLD = 40;    // LDS row stride in bf16 (80 B: conflict-free 16-B fragment reads)
+
+__device__ __forceinline__ void split2(float v, unsigned short& hi, unsigned short& lo) {
+  const unsigned int hp = pack_bf16x2(v, 0.f) & 0xffffu;
+  hi = (unsigned short)hp;
+  lo = (unsigned short)(pack_bf16x2(v - __uint_as_float(hp << 16), 0.f) & 0xffffu);
+}
+
+__global__ __launch_bounds__(256) void softmerge_mfma_kernel(const float* __restrict__ wt, int ldl, const float* __restrict__ x,
+                                                             const float* __restrict__ src, float* __restrict__ x_out, int N, int K,
+                                                             int D) {
+  __shared__ __attribute__((aligned(16))) unsigned short sSh[64 * MLD], sSl[64 * MLD], sWh[MK_MAX * MLD], sWl[MK_MAX * MLD];
+  const int P = N - 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frow = lane & 15, fq = lane >> 4;
+  const int b = blockIdx.y, d0 = blockIdx.x * 64;
+  const int nkf = (K + 15) >> 4, Kp = nkf * 16;
+  const float* sb = src + ((size_t)b * N + 1) * D;
+  const float* wb = wt + ((size_t)b * N + 1) * ldl;
+  f32x4 acc[MK_MAX / 16];
+#pragma unroll
+  for (int i = 0; i < MK_MAX / 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int sp = tid >> 3, sd = (tid & 7) * 8;                     // src staging: token sp of the slab, 8 feature columns
+  for (int p0 = 0; p0 < P; p0 += 32) {
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (p0 + sp < P && d0 + sd < D) {
+      s0 = *reinterpret_cast<const float4*>(sb + (size_t)(p0 + sp) * D + d0 + sd);
+      s1 = *reinterpret_cast<const float4*>(sb + (size_t)(p0 + sp) * D + d0 + sd + 4);
+    }
+    __syncthreads();                                               // previous slab's fragment reads are done
+    {
+      const float f[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) split2(f[e], sSh[(sd + e) * MLD + sp], sSl[(sd + e) * MLD + sp]);
+    }
+    for (int idx = tid; idx < 32 * (Kp >> 2); idx += 256) {        // weights: 4 consecutive centres of one token per thread
+      const int p = idx / (Kp >> 2), kq = (idx - p * (Kp >> 2)) * 4;
+      float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p0 + p < P && kq < ldl) w4 = *reinterpret_cast<const float4*>(wb + (size_t)(p0 + p) * ldl + kq);
+      const float f[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = (kq + e < K) ? f[e] : 0.f;
+        split2(v, sWh[(kq + e) * MLD + p], sWl[(kq + e) * MLD + p]);
+      }
+    }
+    __syncthreads();
+    const bf16x8 sh = *reinterpret_cast<const bf16x8*>(sSh + (wave * 16 + frow) * MLD + fq * 8);
+    const bf16x8 sl = *reinterpret_cast<const bf16x8*>(sSl + (wave * 16 + frow) * MLD + fq * 8);
+#pragma unroll
+    for (int kf = 0; kf < MK_MAX / 16; ++kf)
+      if (kf < nkf) {
+        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(sWh + (kf * 16 + frow) * MLD + fq * 8);
+        const bf16x8 wl = *reinterpret_cast<const bf16x8*>(sWl + (kf * 16 + frow) * MLD + fq * 8);
+        acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sl, wh, acc[kf], 0, 0, 0);
+        acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sh, wl, acc[kf], 0, 0, 0);
+        acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sh, wh, acc[kf], 0, 0, 0);
+      }
+  }
+  // acc[kf][e]: feature column d0 + wave*16 + 4*fq + e, centre kf*16 + frow
+  const int d = d0 + wave * 16 + 4 * fq;
+  if (d < D) {
+#pragma unroll
+    for (int kf = 0; kf < MK_MAX / 16; ++kf) {
+      const int k = kf * 16 + frow;
+      if (kf < nkf && k < K)
+        *reinterpret_cast<float4*>(x_out + ((size_t)b * (K + 1) + 1 + k) * D + d) =
+            make_float4(acc[kf][0], acc[kf][1], acc[kf][2], acc[kf][3]);
+    }
+  }
+  if (tid < 16 && d0 + 4 * tid < D)                                 // global (CLS) token
+    *reinterpret_cast<float4*>(x_out + (size_t)b * (K + 1) * D + d0 + 4 * tid) =
+        *reinterpret_cast<const float4*>(x + (size_t)b * N * D + d0 + 4 * tid);
+}
+
 // ---- Sinkhorn (models/sinkhorn.py) ------------------------------------------------------------------------------------
 // one wave per token row: xh = x / max(|x|_2, 1e-12)   (F.normalize, sinkhorn.py:70), fp32 copy + GEMM-operand copy
 template <bool F32>
@@ -416,5 +541,20 @@ extern "C" int tr_weighted_merge(const float* wt, int ldl, const float* x, const
   }
 #undef TR_WM_LAUNCH
   TR_CHECK_LAUNCH("tr_weighted_merge");
+  return TR_OK;
+}
+
+extern "C" int tr_softassign_merge_fast(float* logits, int ldl, float scale, int apply_softmax, const float* x, const float* src,
+                                        float* x_out, float* soft, int B, int N, int K, int D, tr_stream_t s) {
+  TR_REQUIRE(logits && x && src && x_out, TR_ERR_NULL, "tr_softassign_merge_fast: null pointer");
+  TR_REQUIRE(B > 0 && N >= 2 && K >= 1 && K <= MK_MAX && D >= 4 && D % 4 == 0 && ldl >= K && ldl % 4 == 0, TR_ERR_SHAPE,
+             "tr_softassign_merge_fast: bad shape B=%d N=%d K=%d (<= %d) D=%d ldl=%d", B, N, K, MK_MAX, D, ldl);
+  TR_REQUIRE(x_out != x && x_out != src, TR_ERR_SHAPE, "tr_softassign_merge_fast: needs a distinct x_out");
+  TR_REQUIRE(tr_aligned16(logits) && tr_aligned16(x) && tr_aligned16(src) && tr_aligned16(x_out), TR_ERR_ALIGN,
+             "tr_softassign_merge_fast: pointers must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(s);
+  if (apply_softmax) hipLaunchKernelGGL(token_softmax_kernel, dim3((K + 31) / 32, B), dim3(256), 0, st, logits, ldl, scale, soft, N, K);
+  hipLaunchKernelGGL(softmerge_mfma_kernel, dim3((D + 63) / 64, B), dim3(256), 0, st, logits, ldl, x, src, x_out, N, K, D);
+  TR_CHECK_LAUNCH("tr_softassign_merge_fast");
   return TR_OK;
 }

@@ -220,7 +220,10 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
       pending = nullptr;
       TR_TRY(tr_layernorm_f32(x, D, nullptr, D, sw->ln_g, sw->ln_b, xh, M, D, 1e-5f, s));  // the rows that are summed
       TR_TRY(op_gemm(f32, xn, sw->w1, sw->b1, sc, nullptr, 0, M, sw->n_pad, D, TR_EPI_F32, s));
-      TR_TRY(tr_softassign_merge(sc, sw->n_pad, sw->scale, x, xh, x_alt, soft_out, B, N, Kc, D, s));
+      if (!f32 && Kc <= 192)
+        TR_TRY(tr_softassign_merge_fast(sc, sw->n_pad, sw->scale, 1, x, xh, x_alt, soft_out, B, N, Kc, D, s));
+      else
+        TR_TRY(tr_softassign_merge(sc, sw->n_pad, sw->scale, x, xh, x_alt, soft_out, B, N, Kc, D, s));
       if (soft_out) soft_out += (size_t)B * Kc * (N - 1);
       float* t = x; x = x_alt; x_alt = t;
       N = Kc + 1;
@@ -241,7 +244,10 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
       TR_TRY(tr_sinkhorn(sc, sw->n_pad, cfg->sinkhorn_eps > 0.f ? cfg->sinkhorn_eps : 1.0f, cfg->cluster_iters, sc, soft_out, B, N,
                          Kc, s));
       if (soft_out) soft_out += (size_t)B * Kc * (N - 1);
-      TR_TRY(tr_weighted_merge(sc, sw->n_pad, x, xh, x_alt, B, N, Kc, D, s));
+      if (!f32 && Kc <= 192)
+        TR_TRY(tr_softassign_merge_fast(sc, sw->n_pad, 1.0f, 0, x, xh, x_alt, nullptr, B, N, Kc, D, s));
+      else
+        TR_TRY(tr_weighted_merge(sc, sw->n_pad, x, xh, x_alt, B, N, Kc, D, s));
       float* t = x; x = x_alt; x_alt = t;
       N = Kc + 1;
     }
@@ -274,7 +280,10 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
         TR_REQUIRE(D % 128 == 0 || f32, TR_ERR_CONFIG, "tr_vit_forward: SiT needs embed_dim %% 128 == 0 on the bf16 path (D=%d)", D);
         TR_TRY(op_gemm(f32, xn, sw->w0, sw->b0, ao, nullptr, 0, M, D / 2, D, TR_EPI_GELU_BF16, s));
         TR_TRY(op_gemm(f32, ao, sw->w1, sw->b1, hbuf, nullptr, 0, M, sw->n_pad, D / 2, TR_EPI_F32, s));
-        TR_TRY(tr_sit_merge(static_cast<const float*>(hbuf), sw->n_pad, sw->scale, x, x_alt, soft_out, B, N, Kc, D, s));
+        if (!f32 && Kc <= 192)
+          TR_TRY(tr_softassign_merge_fast(static_cast<float*>(hbuf), sw->n_pad, sw->scale, 1, x, x, x_alt, soft_out, B, N, Kc, D, s));
+        else
+          TR_TRY(tr_sit_merge(static_cast<const float*>(hbuf), sw->n_pad, sw->scale, x, x_alt, soft_out, B, N, Kc, D, s));
         if (soft_out) soft_out += (size_t)B * Kc * (N - 1);
       }
       float* t = x; x = x_alt; x_alt = t;

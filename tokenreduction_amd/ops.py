@@ -205,6 +205,21 @@ def dyvit_score(h: torch.Tensor, w: torch.Tensor, b: torch.Tensor):
     return scores
 
 
+def softassign_merge_fast(logits: torch.Tensor, scale: float, x: torch.Tensor, K: int, apply_softmax: bool = True,
+                          want_soft: bool = False, src: torch.Tensor = None):
+    """MFMA version of sit_merge / weighted_merge (bf16 executor; `logits` is overwritten by the weights when apply_softmax):
+    -> (x_out fp32 [B,K+1,D], soft fp32 [B,K,N-1] | None)."""
+    B, N, D = x.shape
+    ldl = logits.shape[-1]
+    x_out = torch.empty(B, K + 1, D, dtype=torch.float32, device=x.device)
+    soft = torch.empty(B, K, N - 1, dtype=torch.float32, device=x.device) if (want_soft and apply_softmax) else None
+    _lib.check(_lib.load().tr_softassign_merge_fast(_dev(logits, torch.float32, "logits"), ldl, float(scale), int(apply_softmax),
+                                                    _dev(x, torch.float32, "x"), _dev(x if src is None else src, torch.float32, "src"),
+                                                    x_out.data_ptr(), None if soft is None else soft.data_ptr(), B, N, K, D, _stream()),
+               "tr_softassign_merge_fast")
+    return x_out, soft
+
+
 def sit_merge(logits: torch.Tensor, scale: float, x: torch.Tensor, K: int, want_soft: bool = False, src: torch.Tensor = None):
     """TokenSlimmingModule tail (sit.py:38-39): logits fp32 [B,N,ldl] (first K columns), x fp32 [B,N,D] ->
     (x_out fp32 [B,K+1,D], soft fp32 [B,K,N-1] | None)."""

@@ -161,8 +161,10 @@ def forward_stepwise(model: VisionTransformer, x: torch.Tensor, trace: Optional[
             w1[:Kc] = m.queries.detach()
             lg = _gemm(tr, y, bf(w1), torch.zeros(n_pad, dtype=torch.float32, device=dev), ops.TR_EPI_F32, tag="pm")
             h3_, soft = tr.run("sit_merge_kernel", 2.0 * B * Kc * (N - 1) * D, 4.0 * B * (N + Kc) * D,
-                               lambda: ops.sit_merge(lg.view(B, N, n_pad), float(m.scale), h.view(B, N, D), Kc, want_soft=tr.keep,
-                                                     src=xh.view(B, N, D)))
+                               lambda: ops.softassign_merge_fast(lg.view(B, N, n_pad), float(m.scale), h.view(B, N, D), Kc, True, tr.keep,
+                                                                 src=xh.view(B, N, D))
+                               if Kc <= 192 else ops.sit_merge(lg.view(B, N, n_pad), float(m.scale), h.view(B, N, D), Kc,
+                                                               want_soft=tr.keep, src=xh.view(B, N, D)))
             info["soft"][i] = soft
             N = Kc + 1
             h = h3_.view(B * N, D)
@@ -183,7 +185,8 @@ def forward_stepwise(model: VisionTransformer, x: torch.Tensor, trace: Optional[
                               lambda: ops.sinkhorn(sc.view(B, N, n_pad), Kc, model.sinkhorn_eps, model.sinkhorn_iters, want_soft=tr.keep))
             info["soft"][i] = soft
             h3_ = tr.run("sit_merge_kernel", 2.0 * B * Kc * (N - 1) * D, 4.0 * B * (N + Kc) * D,
-                         lambda: ops.weighted_merge(wt, h.view(B, N, D), xh.view(B, N, D), Kc))
+                         lambda: ops.softassign_merge_fast(wt, 1.0, h.view(B, N, D), Kc, False, src=xh.view(B, N, D))[0]
+                         if Kc <= 192 else ops.weighted_merge(wt, h.view(B, N, D), xh.view(B, N, D), Kc))
             N = Kc + 1
             h = h3_.view(B * N, D)
         if cfg.family in (4, 5) and int(cfg.keep[i]) > 0:
@@ -222,7 +225,8 @@ def forward_stepwise(model: VisionTransformer, x: torch.Tensor, trace: Optional[
                 lg = _gemm(tr, h1, bf(w1), b1, ops.TR_EPI_F32, tag="s1")
                 scale = float(m.scale.detach().reshape(-1)[0])
                 h3_, soft = tr.run("sit_merge_kernel", 2.0 * B * Kc * (N - 1) * D, 4.0 * B * (N + Kc) * D,
-                                   lambda: ops.sit_merge(lg.view(B, N, n_pad), scale, h.view(B, N, D), Kc, want_soft=tr.keep))
+                                   lambda: ops.softassign_merge_fast(lg.view(B, N, n_pad), scale, h.view(B, N, D), Kc, True, tr.keep)
+                                   if Kc <= 192 else ops.sit_merge(lg.view(B, N, n_pad), scale, h.view(B, N, D), Kc, want_soft=tr.keep))
                 info["soft"][i] = soft
                 N = Kc + 1
                 h = h3_.view(B * N, D)
