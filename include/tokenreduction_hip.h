@@ -89,6 +89,12 @@ int tr_attention_bf16(const uint16_t* qkv, uint16_t* out, float* cls_rows, const
 /* fp32 validation path (N <= 256): same contract in the reference's arithmetic (expf softmax, fp32 everywhere). */
 int tr_attention_f32(const float* qkv, float* out, float* cls_rows, const float* size, float* colsum_part, int B, int N, int H,
                      tr_stream_t s);
+/* a11 (forward only): Policy_Attention.forward dyvit.py:53-67 with softmax_with_policy :39-51 -- the attention of DyViT's
+ * TRAINING forward, where pruned tokens stay in the sequence and are masked by policy fp32 [B,N] of 1/0:
+ *   attn = (exp(s - max_k s) * pol + eps/N) / (sum_k exp(s - max_k s) * pol + eps),  pol[q][k] = policy[k], 1 for k == q,
+ * eps = 1e-6.  N <= 224 (bf16) / 256 (fp32).  Not used by the eval executor; the training path is not built. */
+int tr_attention_policy_bf16(const uint16_t* qkv, uint16_t* out, const float* policy, int B, int N, int H, tr_stream_t s);
+int tr_attention_policy_f32(const float* qkv, float* out, const float* policy, int B, int N, int H, tr_stream_t s);
 
 /* a6 (topk.py:55-65 == evit.py:77-87) + a8 (evit.py:25-46 complement_idx):
  * scores[b,j] = mean_h cls_rows[b,h,1+j] (j < P = N-1); idx[b,:K] = indices of the K largest scores in

@@ -92,6 +92,19 @@ def dyvit_forward(params: Dict[str, Tensor], x: Tensor, cfg: VitConfig, precisio
     return logits
 
 
+def dyvit_softmax_with_policy(attn: Tensor, policy: Tensor, eps: float = 1e-6) -> Tensor:
+    """Policy_Attention.softmax_with_policy dyvit.py:39-51 (training forward): attn [B,H,N,N] scaled logits, policy [B,N,1]."""
+    B, N, _ = policy.size()
+    attn_policy = policy.reshape(B, 1, 1, N)
+    eye = torch.eye(N, dtype=attn_policy.dtype).view(1, 1, N, N)
+    attn_policy = attn_policy + (1.0 - attn_policy) * eye
+    max_att = torch.max(attn, dim=-1, keepdim=True)[0]
+    attn = attn - max_att
+    attn = attn.to(torch.float32).exp_() * attn_policy.to(torch.float32)
+    attn = (attn + eps / N) / (attn.sum(dim=-1, keepdim=True) + eps)
+    return attn.type_as(max_att)
+
+
 # =========================================================================================== SiT
 def sit_cluster_counts(cfg: VitConfig) -> Dict[int, int]:
     """sit.py:77-83: one keep_rate -> int(P0 * kr**(i+1)); several -> ABSOLUTE counts used verbatim."""

@@ -52,6 +52,8 @@ SIGNATURES = {
     "tr_gemm_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tr_layernorm_f32": (_i, [_vp, _l, _vp, _l, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "tr_attention_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "tr_attention_policy_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "tr_attention_policy_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "tr_tome_match": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tr_tome_merge_layernorm": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "tr_gather_layernorm_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),

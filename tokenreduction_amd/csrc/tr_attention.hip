@@ -38,7 +38,9 @@ __device__ __forceinline__ void colsum_step(float* v, int ql) {
 
 // COLSUM: also emit, per (image, head, wave), the column sums over this wave's queries of the softmax matrix -- the token
 // weights K-Medoids needs from the previous block's attention (kmedoids.py:240) -- without materialising B*H*N*N.
-template <int NKB, bool COLSUM>
+// POLICY: DyViT's training-time softmax_with_policy (dyvit.py:39-51): `size` then carries the keep policy [B,N] of 1/0 and
+//   attn = (exp(s - max) * pol + eps/N) / (sum_k exp(s - max) * pol + eps),  pol[q][k] = policy[k], 1 on the diagonal.
+template <int NKB, bool COLSUM, bool POLICY>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
                                                            float* __restrict__ cls_rows, const float* __restrict__ size,
                                                            float* __restrict__ colsum_part, int N, int H) {
@@ -83,7 +85,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
     }
   }
   for (int key = tid; key < NKB * 32; key += 256)
-    sLB[key] = (size != nullptr && key < N) ? __builtin_amdgcn_logf(size[(size_t)b * N + key]) : 0.f;   // v_log_f32 = log2
+    sLB[key] = POLICY ? (key < N ? size[(size_t)b * N + key] : 0.f)
+                      : ((size != nullptr && key < N) ? __builtin_amdgcn_logf(size[(size_t)b * N + key]) : 0.f);   // v_log_f32 = log2
   __syncthreads();
   TR_STAMP();
 
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
       for (int r = 0; r < 16; ++r) {
         const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
         // logits in the log2 domain: (q.k) * dh^-0.5 * log2(e) + log2(size[key])
-        sacc[kb][r] = sacc[kb][r] * c_exp + sLB[key];
+        sacc[kb][r] = POLICY ? sacc[kb][r] * c_exp : sacc[kb][r] * c_exp + sLB[key];
         if (kb == NKB - 1 && key >= N) sacc[kb][r] = -INFINITY;
         mx = fmaxf(mx, sacc[kb][r]);
       }
@@ -136,12 +139,26 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(sacc[kb][r] - mx);
+        float p = __builtin_amdgcn_exp2f(sacc[kb][r] - mx);
+        if (POLICY) {
+          const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          p *= (key == q) ? 1.0f : sLB[key];                     // attn_policy = policy + (1 - policy) * eye
+        }
         sacc[kb][r] = p;
         l += p;
       }
     l += __shfl_xor(l, 32, 64);
-    const float inv = 1.0f / l;
+    const float inv = POLICY ? 1.0f / (l + 1e-6f) : 1.0f / l;
+    if (POLICY) {                                                // (attn + eps/N) / (sum + eps); padded keys stay 0
+      const float add = 1e-6f / (float)N;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (kb < NKB - 1 || key < N) sacc[kb][r] += add;
+        }
+    }
 
     TR_STAMP();
     // ---- O^T = Vt P^T
@@ -395,11 +412,13 @@ __global__ __launch_bounds__(256, 1) void attention_long_kernel(const uint16_t* 
 
 template <int NKB>
 int launch_attention(const uint16_t* qkv, uint16_t* out, float* cls_rows, const float* size, float* colsum_part, int B, int N, int H,
-                     hipStream_t st) {
-  if (colsum_part)
-    hipLaunchKernelGGL((attention_kernel<NKB, true>), dim3(B * H), dim3(256), 0, st, qkv, out, cls_rows, size, colsum_part, N, H);
+                     hipStream_t st, bool policy = false) {
+  if (policy)
+    hipLaunchKernelGGL((attention_kernel<NKB, false, true>), dim3(B * H), dim3(256), 0, st, qkv, out, cls_rows, size, colsum_part, N, H);
+  else if (colsum_part)
+    hipLaunchKernelGGL((attention_kernel<NKB, true, false>), dim3(B * H), dim3(256), 0, st, qkv, out, cls_rows, size, colsum_part, N, H);
   else
-    hipLaunchKernelGGL((attention_kernel<NKB, false>), dim3(B * H), dim3(256), 0, st, qkv, out, cls_rows, size, colsum_part, N, H);
+    hipLaunchKernelGGL((attention_kernel<NKB, false, false>), dim3(B * H), dim3(256), 0, st, qkv, out, cls_rows, size, colsum_part, N, H);
   return 0;
 }
 
@@ -436,5 +455,25 @@ extern "C" int tr_attention_bf16(const uint16_t* qkv, uint16_t* out, float* cls_
     default: launch_attention<7>(qkv, out, cls_rows, size, colsum_part, B, N, H, st); break;
   }
   TR_CHECK_LAUNCH("tr_attention_bf16");
+  return TR_OK;
+}
+
+// a11: Policy_Attention.forward dyvit.py:53-67 with softmax_with_policy (:39-51) -- the attention of DyViT's TRAINING forward,
+// where tokens are masked by a keep policy instead of being removed.  Forward only (224^2 inputs).
+extern "C" int tr_attention_policy_bf16(const uint16_t* qkv, uint16_t* out, const float* policy, int B, int N, int H, tr_stream_t s) {
+  TR_REQUIRE(qkv && out && policy, TR_ERR_NULL, "tr_attention_policy_bf16: null pointer");
+  TR_REQUIRE(B > 0 && H > 0 && N >= 1 && N <= 224, TR_ERR_SHAPE, "tr_attention_policy_bf16: need 1 <= N <= 224 (N=%d)", N);
+  TR_REQUIRE(tr_aligned16(qkv) && tr_aligned16(out), TR_ERR_ALIGN, "tr_attention_policy_bf16: pointers must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(s);
+  switch ((N + 31) / 32) {
+    case 1: launch_attention<1>(qkv, out, nullptr, policy, nullptr, B, N, H, st, true); break;
+    case 2: launch_attention<2>(qkv, out, nullptr, policy, nullptr, B, N, H, st, true); break;
+    case 3: launch_attention<3>(qkv, out, nullptr, policy, nullptr, B, N, H, st, true); break;
+    case 4: launch_attention<4>(qkv, out, nullptr, policy, nullptr, B, N, H, st, true); break;
+    case 5: launch_attention<5>(qkv, out, nullptr, policy, nullptr, B, N, H, st, true); break;
+    case 6: launch_attention<6>(qkv, out, nullptr, policy, nullptr, B, N, H, st, true); break;
+    default: launch_attention<7>(qkv, out, nullptr, policy, nullptr, B, N, H, st, true); break;
+  }
+  TR_CHECK_LAUNCH("tr_attention_policy_bf16");
   return TR_OK;
 }

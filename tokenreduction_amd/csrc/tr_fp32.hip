@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 
 // One workgroup per (image, head); one wave per query row at a time.  K is kept TRANSPOSED in LDS (Kt[d][key]) so the lanes
 // of a wave (= keys) read consecutive addresses; V row-major (lane = d for the P.V product).
+template <bool POLICY>
 __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                             float* __restrict__ cls_rows, const float* __restrict__ size,
                                                             float* __restrict__ colsum_part, int N, int H) {
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
 #pragma unroll 16
         for (int d = 0; d < 64; ++d) acc = fmaf(sQ[wave * 64 + d], sKt[d * NP + key], acc);
         // (q @ k^T) * scale [+ size.log(), tome.py:48-49], scale = 64^-0.5
-        acc = key < N ? acc * 0.125f + (size ? logf(size[(size_t)b * N + key]) : 0.f) : -INFINITY;
+        acc = key < N ? acc * 0.125f + ((size && !POLICY) ? logf(size[(size_t)b * N + key]) : 0.f) : -INFINITY;
         s[c] = acc;
         mx = fmaxf(mx, acc);
       }
@@ -122,10 +123,19 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       s[c] = expf(s[c] - mx);           // exp(-inf) = 0 for padded keys / unused chunks
+      if (POLICY) {                     // softmax_with_policy dyvit.py:39-51: exp * (policy + (1 - policy) * eye)
+        const int key = c * 64 + lane;
+        if (c < nkc && key < N && key != q) s[c] *= size[(size_t)b * N + key];
+      }
       l += s[c];
     }
     l = wave_sum(l);
-    const float inv = 1.0f / l;
+    const float inv = POLICY ? 1.0f / (l + 1e-6f) : 1.0f / l;
+    if (POLICY) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < nkc && c * 64 + lane < N) s[c] += 1e-6f / (float)N;     // (attn + eps/N) / (sum + eps)
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c)
       if (c < nkc) {
@@ -182,9 +192,23 @@ extern "C" int tr_attention_f32(const float* qkv, float* out, float* cls_rows, c
   const int NP = (N + 63) & ~63;
   const size_t lds = (size_t)(64 * NP + NP * 64 + 4 * 64 + 4 * NP) * sizeof(float);
   hipStream_t st = static_cast<hipStream_t>(s);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_f32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_attention_f32: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-  hipLaunchKernelGGL(attention_f32_kernel, dim3(B * H), dim3(256), lds, st, qkv, out, cls_rows, size, colsum_part, N, H);
+  hipLaunchKernelGGL(attention_f32_kernel<false>, dim3(B * H), dim3(256), lds, st, qkv, out, cls_rows, size, colsum_part, N, H);
   TR_CHECK_LAUNCH("tr_attention_f32");
+  return TR_OK;
+}
+
+extern "C" int tr_attention_policy_f32(const float* qkv, float* out, const float* policy, int B, int N, int H, tr_stream_t s) {
+  TR_REQUIRE(qkv && out && policy, TR_ERR_NULL, "tr_attention_policy_f32: null pointer");
+  TR_REQUIRE(B > 0 && H > 0 && N >= 1 && N <= 256, TR_ERR_SHAPE, "tr_attention_policy_f32: need 1 <= N <= 256 (N=%d)", N);
+  const int NP = (N + 63) & ~63;
+  const size_t lds = (size_t)(64 * NP + NP * 64 + 4 * 64 + 4 * NP) * sizeof(float);
+  hipStream_t st = static_cast<hipStream_t>(s);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_f32_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_attention_policy_f32: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+  hipLaunchKernelGGL(attention_f32_kernel<true>, dim3(B * H), dim3(256), lds, st, qkv, out, static_cast<float*>(nullptr), policy,
+                     static_cast<float*>(nullptr), N, H);
+  TR_CHECK_LAUNCH("tr_attention_policy_f32");
   return TR_OK;
 }

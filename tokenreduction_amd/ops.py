@@ -337,3 +337,15 @@ def kmedoids(x: torch.Tensor, colsum_part: torch.Tensor, K: int, iters: int, fas
     _lib.check(lib.tr_kmedoids(_dev(x, torch.float32, "x"), _dev(colsum_part, torch.float32, "colsum_part"), ws.data_ptr(),
                                centers.data_ptr(), assign.data_ptr(), B, N, D, H, K, iters, int(fast_dist), _stream()), "tr_kmedoids")
     return centers, assign
+
+
+# ---------------------------------------------------------------------------------------- DyViT training attention (forward)
+def attention_policy(qkv: torch.Tensor, policy: torch.Tensor, B: int, N: int, H: int) -> torch.Tensor:
+    """Policy_Attention with softmax_with_policy (dyvit.py:39-67): qkv bf16|fp32 [B*N, 3*H*64], policy fp32 [B,N] of 1/0 ->
+    out [B*N, H*64] in qkv's dtype."""
+    out = torch.empty(B * N, H * 64, dtype=qkv.dtype, device=qkv.device)
+    lib = _lib.load()
+    fn = lib.tr_attention_policy_f32 if qkv.dtype == torch.float32 else lib.tr_attention_policy_bf16
+    _lib.check(fn(_dev(qkv, qkv.dtype, "qkv"), out.data_ptr(), _dev(policy, torch.float32, "policy"), B, N, H, _stream()),
+               "tr_attention_policy")
+    return out
