@@ -180,6 +180,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-extra", action="store_true", help="skip the roofline / cpu_baseline legs")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the RCCL process group even at world size 1 (exercises the N>1 code path on one GPU)")
     ap.add_argument("--selftest-gloo", action="store_true",
                     help="CPU-only check of the multi-process harness (gloo, no model): each rank's step sleeps 10 ms x (rank+1)")
     a = ap.parse_args()
@@ -189,9 +191,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dist = None
-    if world > 1:
+    if world > 1 or a.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     if a.selftest_gloo:
         if dist is not None:
             dist.init_process_group("gloo")
@@ -268,6 +273,11 @@ def main():
                 del m2
             rec["other_configs"] = others
             rec["cpu_baseline"] = cpu_baseline_leg(model)
+        try:        # RCCL writes its banner through C stdio: flush it first so the JSON line is the last thing on stdout
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
         print(json.dumps(rec), flush=True)
     if dist is not None:
         dist.destroy_process_group()
