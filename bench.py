@@ -32,13 +32,13 @@ PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md
 PEAK_HBM_GBPS = 8000.0
 
 
-def build_model(name=MODEL, keep_rate=KEEP_RATE, loc=REDUCTION_LOC, device="cuda"):
+def build_model(name=MODEL, keep_rate=KEEP_RATE, loc=REDUCTION_LOC, device="cuda", img_size=224):
     import tokenreduction_amd as tra
     torch.manual_seed(0)
     args = types.SimpleNamespace(keep_rate=list(keep_rate), reduction_loc=list(loc), dyvit_distill=False, k_neighbors=5,
                                  equal_weight=False, cluster_iters=3, sinkhorn_eps=1.0)
     m = tra.create_model(name, pretrained=False, num_classes=1000, drop_rate=0.0, drop_path_rate=0.0,
-                         drop_block_rate=None, img_size=224, args=args)
+                         drop_block_rate=None, img_size=img_size, args=args)
     with torch.no_grad():                       # "peaky" attention so the Top-K sees a realistic score spread
         for blk in m.blocks:
             blk.attn.qkv.weight.mul_(4.0)
@@ -271,6 +271,17 @@ def main():
                 others[label] = {"images_per_s": round(o_ips, 1), "speedup_vs_dense": round(o_ips / d_ips, 3),
                                  "tokens_per_block": m2._last_tokens}
                 del m2
+            # forward throughput of the DeiT-B configurations BASELINE names (configs[3] families at 224^2, configs[4] at 384^2);
+            # their DP fine-tuning / 8-GPU sweeps are not measured here
+            for label, name, kr, img, bsz in (("ats_base kr0.5 224^2 B=128 (configs[3] family, forward)", "ats_base_patch16_224", [0.5], 224, 128),
+                                              ("dpcknn_base kr0.5 224^2 B=128 (configs[3] family, forward)", "dpcknn_base_patch16_224", [0.5], 224, 128),
+                                              ("sinkhorn_base kr0.25 384^2 B=64 (configs[4] family)", "sinkhorn_base_patch16_224", [0.25], 384, 64),
+                                              ("kmedoids_base kr0.25 384^2 B=64 (configs[4] family)", "kmedoids_base_patch16_224", [0.25], 384, 64)):
+                m2 = build_model(name, kr, [3, 6, 9], dev, img_size=img)
+                xb = torch.randn(bsz, 3, img, img, generator=torch.Generator().manual_seed(7)).to(dev)
+                o_ips = quick_images_per_s(m2, xb)
+                others[label] = {"images_per_s": round(o_ips, 1), "tokens_per_block": m2._last_tokens}
+                del m2, xb
             rec["other_configs"] = others
             rec["cpu_baseline"] = cpu_baseline_leg(model)
         try:        # RCCL writes its banner through C stdio: flush it first so the JSON line is the last thing on stdout
