@@ -254,6 +254,9 @@ typedef struct {
   const void* w2; const float* b2;
   const float* w3; const float* b3;
   float scale; int n_pad;
+  int h_pad;                   /* DyViT / SiT: width of the D/2 hidden layer as packed (D/2 rounded up to 64 with zero weights, so
+                                  the bf16 GEMMs' K %% 64 holds for DeiT-T); 0 = D/2 */
+  int reserved_;
 } tr_stage_weights;
 
 typedef struct {

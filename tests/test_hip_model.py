@@ -424,3 +424,22 @@ def test_dyvit_teacher_returns_logits_and_normed_tokens():
     assert tokens.shape == want.shape == (2, 196, case["embed_dim"])
     assert ((logits.cpu() - lb).norm() / lb.norm()).item() < FORCED_TOL
     assert ((tokens.cpu() - want).norm() / want.norm()).item() < FORCED_TOL
+
+
+@pytest.mark.parametrize("family", ["dyvit", "sit"])
+def test_tiny_width_predictor_modules(family):
+    """DeiT-T (D = 192): the D/2 = 96-wide hidden layer of the DyViT predictor / SiT slimming MLP is packed zero-padded to 128 so
+    the bf16 GEMMs keep K %% 64; results must not notice."""
+    from tokenreduction_amd.stepwise import forward_stepwise
+    case = dict(family=family, embed_dim=192, depth=3, num_heads=3, num_classes=16, keep_rate=[0.6], reduction_loc=[1, 2],
+                batch=2, wseed=901, xseed=902, qkv_gain=6.0)
+    model, params, cfg = build_model(case)
+    x = make_images(2, 224, case["xseed"])
+    logits, viz = model(x.cuda())
+    l2, info = forward_stepwise(model, x.cuda())
+    assert torch.equal(l2.cpu(), logits.cpu())
+    forced = {blk: idx.cpu().long() for blk, idx in info["kept"].items()} if family == "dyvit" else None
+    want = oracle.forward(params, x, cfg, precision="bf16", forced=forced)
+    rel = ((logits.cpu() - want).norm() / want.norm()).item()
+    print(f"\n[{family} tiny-width] relative L2 vs oracle_bf16 (teacher-forced where there are decisions): {rel:.3e}")
+    assert rel < FORCED_TOL, rel

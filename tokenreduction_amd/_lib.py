@@ -28,7 +28,8 @@ class TrBlockWeights(C.Structure):
 
 
 class TrStageWeights(C.Structure):
-    _fields_ = [(n, _vp) for n in ("ln_g", "ln_b", "w0", "b0", "w1", "b1", "w2", "b2", "w3", "b3")] + [("scale", _f), ("n_pad", _i)]
+    _fields_ = [(n, _vp) for n in ("ln_g", "ln_b", "w0", "b0", "w1", "b1", "w2", "b2", "w3", "b3")] + [("scale", _f), ("n_pad", _i),
+                                                                                                          ("h_pad", _i), ("reserved_", _i)]
 
 
 class TrVitWeights(C.Structure):

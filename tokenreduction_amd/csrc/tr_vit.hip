@@ -263,11 +263,12 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
       if (cfg->family == TR_FAMILY_DYVIT) {
         // a10: PredictorLG (dyvit.py:113-119, policy == 1 in eval) -> score -> argsort(desc)[:K] -> batch_index_select
         TR_REQUIRE(sw->w2 && sw->b2 && sw->w3 && sw->b3, TR_ERR_NULL, "tr_vit_forward: block %d predictor weights missing", i);
-        TR_REQUIRE(D % 128 == 0 || f32, TR_ERR_CONFIG, "tr_vit_forward: DyViT predictor needs embed_dim %% 128 == 0 on the bf16 path (D=%d)", D);
+        const int Hh = sw->h_pad > 0 ? sw->h_pad : D / 2;            // hidden width as packed (zero-padded to 64 for DeiT-T)
+        TR_REQUIRE(Hh >= D / 2 && (Hh % 64 == 0 || f32), TR_ERR_CONFIG, "tr_vit_forward: DyViT predictor hidden width %d invalid (D=%d)", Hh, D);
         TR_TRY(op_gemm(f32, xn, sw->w0, sw->b0, ao, nullptr, 0, M, D, D, TR_EPI_GELU_BF16, s));
         TR_TRY(tr_pool_broadcast(ao, f32 ? 1 : 0, B, N, D, 1e-6f, s));
-        TR_TRY(op_gemm(f32, ao, sw->w1, sw->b1, qkv, nullptr, 0, M, D / 2, D, TR_EPI_GELU_BF16, s));
-        TR_TRY(op_gemm(f32, qkv, sw->w2, sw->b2, hbuf, nullptr, 0, M, D / 4, D / 2, TR_EPI_GELU_BF16, s));
+        TR_TRY(op_gemm(f32, ao, sw->w1, sw->b1, qkv, nullptr, 0, M, Hh, D, TR_EPI_GELU_BF16, s));
+        TR_TRY(op_gemm(f32, qkv, sw->w2, sw->b2, hbuf, nullptr, 0, M, D / 4, Hh, TR_EPI_GELU_BF16, s));
         TR_TRY(tr_dyvit_score(hbuf, f32 ? 1 : 0, sw->w3, sw->b3, cls_rows, M, D / 4, s));
         int32_t* idx_dst = kept_idx ? kept_idx + (size_t)i * B * p.N0 : idx_ws;
         TR_TRY(tr_cls_topk(cls_rows, idx_dst, nullptr, scores, B, 1, N, Kc, s));
@@ -277,9 +278,10 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
         // a23: TokenSlimmingModule (sit.py:36-40)
         TR_REQUIRE(sw->n_pad >= Kc && sw->n_pad % 8 == 0 && (size_t)sw->n_pad * 4 <= (size_t)p.Hd * (f32 ? 4 : 2), TR_ERR_CONFIG,
                    "tr_vit_forward: block %d SiT n_pad=%d invalid for K=%d", i, sw->n_pad, Kc);
-        TR_REQUIRE(D % 128 == 0 || f32, TR_ERR_CONFIG, "tr_vit_forward: SiT needs embed_dim %% 128 == 0 on the bf16 path (D=%d)", D);
-        TR_TRY(op_gemm(f32, xn, sw->w0, sw->b0, ao, nullptr, 0, M, D / 2, D, TR_EPI_GELU_BF16, s));
-        TR_TRY(op_gemm(f32, ao, sw->w1, sw->b1, hbuf, nullptr, 0, M, sw->n_pad, D / 2, TR_EPI_F32, s));
+        const int Hh = sw->h_pad > 0 ? sw->h_pad : D / 2;
+        TR_REQUIRE(Hh >= D / 2 && (Hh % 64 == 0 || f32), TR_ERR_CONFIG, "tr_vit_forward: SiT hidden width %d invalid (D=%d)", Hh, D);
+        TR_TRY(op_gemm(f32, xn, sw->w0, sw->b0, ao, nullptr, 0, M, Hh, D, TR_EPI_GELU_BF16, s));
+        TR_TRY(op_gemm(f32, ao, sw->w1, sw->b1, hbuf, nullptr, 0, M, sw->n_pad, Hh, TR_EPI_F32, s));
         if (!f32 && Kc <= 192)
           TR_TRY(tr_softassign_merge_fast(static_cast<float*>(hbuf), sw->n_pad, sw->scale, 1, x, x, x_alt, soft_out, B, N, Kc, D, s));
         else

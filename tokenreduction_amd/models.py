@@ -460,6 +460,25 @@ class ToMeVisionTransformer(VisionTransformer):
         return {"Assignment_Maps": maps, "Features": {}}
 
 
+def _pad_rows(w, rows):
+    """[r, c] -> [rows, c] with zero rows appended (detached fp32 copy)."""
+    out = torch.zeros(rows, w.shape[1], dtype=torch.float32, device=w.device)
+    out[:w.shape[0]] = w.detach()
+    return out
+
+
+def _pad_cols(w, cols):
+    out = torch.zeros(w.shape[0], cols, dtype=torch.float32, device=w.device)
+    out[:, :w.shape[1]] = w.detach()
+    return out
+
+
+def _pad_vec(b, n):
+    out = torch.zeros(n, dtype=torch.float32, device=b.device)
+    out[:b.shape[0]] = b.detach()
+    return out
+
+
 def _ln_default(dim):
     return nn.LayerNorm(dim)          # eps 1e-5: the reduction modules use nn.LayerNorm's default (dyvit.py:97, sit.py:30)
 
@@ -516,8 +535,10 @@ class DynamicVisionTransformer(VisionTransformer):
             sp, st = self.score_predictor[j], W.stage[loc]
             st.ln_g, st.ln_b = f32(sp.in_conv[0].weight), f32(sp.in_conv[0].bias)
             st.w0, st.b0 = w16(sp.in_conv[1].weight), f32(sp.in_conv[1].bias)
-            st.w1, st.b1 = w16(sp.out_conv[0].weight), f32(sp.out_conv[0].bias)
-            st.w2, st.b2 = w16(sp.out_conv[2].weight), f32(sp.out_conv[2].bias)
+            hh = (self.embed_dim // 2 + 63) // 64 * 64          # D/2 padded with zero weights: K %% 64 for the bf16 GEMM (DeiT-T: 96 -> 128)
+            st.w1, st.b1 = w16(_pad_rows(sp.out_conv[0].weight, hh)), f32(_pad_vec(sp.out_conv[0].bias, hh))
+            st.w2, st.b2 = w16(_pad_cols(sp.out_conv[2].weight, hh)), f32(sp.out_conv[2].bias)
+            st.h_pad = hh
             st.w3, st.b3 = f32(sp.out_conv[4].weight), f32(sp.out_conv[4].bias)
 
     def _viz_data(self, ws, B, tokens):
@@ -578,10 +599,12 @@ class SelfSlimmedVisionTransformer(VisionTransformer):
             b1 = torch.zeros(n_pad, dtype=torch.float32, device=w1.device)
             b1[:K] = m.weight[3].bias.detach()
             st.ln_g, st.ln_b = f32(m.weight[0].weight), f32(m.weight[0].bias)
-            st.w0, st.b0 = w16(m.weight[1].weight), f32(m.weight[1].bias)
-            st.w1, st.b1 = w16(w1), f32(b1)
+            hh = (m.weight[1].out_features + 63) // 64 * 64     # hidden width padded with zero weights (DeiT-T: 96 -> 128)
+            st.w0, st.b0 = w16(_pad_rows(m.weight[1].weight, hh)), f32(_pad_vec(m.weight[1].bias, hh))
+            st.w1, st.b1 = w16(_pad_cols(w1, hh)), f32(b1)
             st.scale = float(m.scale.detach().reshape(-1)[0])
             st.n_pad = n_pad
+            st.h_pad = hh
 
     def _stage_shapes(self):
         """[(blk, K, P_in)] per slimming stage."""

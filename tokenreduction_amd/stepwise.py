@@ -12,7 +12,7 @@ from typing import Callable, Dict, List, Optional
 import torch
 
 from . import ops
-from .models import VisionTransformer
+from .models import VisionTransformer, _pad_cols, _pad_rows, _pad_vec
 
 
 class Trace:
@@ -200,8 +200,10 @@ def forward_stepwise(model: VisionTransformer, x: torch.Tensor, trace: Optional[
                 pending = None
                 h1 = _gemm(tr, y, bf(sp.in_conv[1].weight), f32(sp.in_conv[1].bias), ops.TR_EPI_GELU_BF16, tag="p0")
                 tr.run("pool_broadcast_kernel", 0.0, 2.0 * M * D, lambda: ops.pool_broadcast(h1, B, N))
-                h2 = _gemm(tr, h1, bf(sp.out_conv[0].weight), f32(sp.out_conv[0].bias), ops.TR_EPI_GELU_BF16, tag="p1")
-                h3 = _gemm(tr, h2, bf(sp.out_conv[2].weight), f32(sp.out_conv[2].bias), ops.TR_EPI_GELU_BF16, tag="p2")
+                hh = (D // 2 + 63) // 64 * 64       # hidden width padded with zero weights, as models.py packs it
+                h2 = _gemm(tr, h1, bf(_pad_rows(sp.out_conv[0].weight, hh)), _pad_vec(sp.out_conv[0].bias, hh), ops.TR_EPI_GELU_BF16,
+                           tag="p1")
+                h3 = _gemm(tr, h2, bf(_pad_cols(sp.out_conv[2].weight, hh)), f32(sp.out_conv[2].bias), ops.TR_EPI_GELU_BF16, tag="p2")
                 sc = tr.run("dyvit_score_kernel", 0.0, 0.5 * M * D,
                             lambda: ops.dyvit_score(h3, f32(sp.out_conv[4].weight), f32(sp.out_conv[4].bias)))
                 idx, _, scores = tr.run("cls_topk_kernel", 0.0, 8.0 * M, lambda: ops.cls_topk(sc.view(B, 1, N), Kc))
@@ -216,10 +218,11 @@ def forward_stepwise(model: VisionTransformer, x: torch.Tensor, trace: Optional[
                 y = tr.run("layernorm_kernel", 0.0, (6.0 if pending is None else 12.0) * M * D,
                            lambda: ops.layernorm(h, f32(m.weight[0].weight), f32(m.weight[0].bias), 1e-5, delta=pending))
                 pending = None
-                h1 = _gemm(tr, y, bf(m.weight[1].weight), f32(m.weight[1].bias), ops.TR_EPI_GELU_BF16, tag="s0")
+                hh = (m.weight[1].out_features + 63) // 64 * 64
+                h1 = _gemm(tr, y, bf(_pad_rows(m.weight[1].weight, hh)), _pad_vec(m.weight[1].bias, hh), ops.TR_EPI_GELU_BF16, tag="s0")
                 n_pad = (Kc + 7) // 8 * 8
-                w1 = torch.zeros(n_pad, m.weight[3].in_features, dtype=torch.float32, device=dev)
-                w1[:Kc] = m.weight[3].weight.detach()
+                w1 = torch.zeros(n_pad, hh, dtype=torch.float32, device=dev)
+                w1[:Kc, :m.weight[3].in_features] = m.weight[3].weight.detach()
                 b1 = torch.zeros(n_pad, dtype=torch.float32, device=dev)
                 b1[:Kc] = m.weight[3].bias.detach()
                 lg = _gemm(tr, h1, bf(w1), b1, ops.TR_EPI_F32, tag="s1")
