@@ -669,3 +669,53 @@ def test_attention_with_policy(ops, B, N, H):
     ones = torch.ones(B, N)
     plain, _ = ops.attention_f32(qkv.cuda(), B, N, H)
     torch.testing.assert_close(ops.attention_policy(qkv.cuda(), ones.cuda(), B, N, H).cpu(), plain.cpu(), atol=1e-5, rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------- shape sweeps (edge sizes)
+def test_attention_every_sequence_length(ops):
+    """All token counts 2..224 in steps of 5 plus the block edges (31, 32, 33, 63, 64, 65, ...): masking of the padded keys,
+    partially filled query blocks, CLS row."""
+    rng = _rng(123)
+    H, B = 2, 2
+    ns = sorted(set(list(range(2, 225, 5)) + [31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 159, 160, 161, 191, 192, 193, 223, 224]))
+    worst = 0.0
+    for N in ns:
+        qkv = _bf(_randn(rng, B * N, 3 * H * 64, scale=1.2))
+        q, k, v = qkv.double().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+        attn = ((q @ k.transpose(-2, -1)) * 0.125).softmax(-1)
+        want = (attn @ v).transpose(1, 2).reshape(B * N, H * 64).float()
+        got, cls = ops.attention(qkv.bfloat16().cuda(), B, N, H, want_cls=True)
+        err = (got.float().cpu() - want).abs().max().item()
+        worst = max(worst, err)
+        assert err < 3e-2, (N, err)
+        torch.testing.assert_close(cls.cpu(), attn[:, :, 0, :].float(), atol=2e-6, rtol=2e-3)
+    print(f"attention N sweep ({len(ns)} lengths): worst abs error {worst:.2e}")
+
+
+def test_cls_topk_every_k(ops):
+    """K from 1 to P at P = 196 (and a small P): descending order, complement, bit-exact against the oracle."""
+    rng = _rng(321)
+    for N in (197, 9):
+        P = N - 1
+        rows = torch.from_numpy(rng.random((2, 3, N)).astype(np.float32))
+        scores = rows[:, :, 1:].sum(1) / 3
+        for K in sorted(set([1, 2, P // 2, P - 1, P] + list(range(1, P + 1, 13)))):
+            idx, compl, sc = ops.cls_topk(rows.cuda(), K, want_compl=True)
+            want = oracle.cls_topk_select(sc.cpu(), K)
+            np.testing.assert_array_equal(idx.cpu().numpy(), want.numpy())
+            np.testing.assert_array_equal(compl.cpu().numpy(), oracle.complement_idx(want, P).numpy())
+            torch.testing.assert_close(sc.cpu(), scores, atol=1e-7, rtol=1e-6)
+
+
+def test_tome_match_parity_sweep(ops):
+    """Odd/even token counts and r from 1 to the (N-1)//2 cap."""
+    rng = _rng(555)
+    for N in (3, 4, 5, 16, 17, 100, 101, 196, 197):
+        for r in sorted(set([1, (N - 1) // 4 or 1, (N - 1) // 2])):
+            qkv = _randn(rng, 2 * N, 3 * 2 * 64)
+            k = qkv.reshape(2, N, 3, 2, 64)[:, :, 1].permute(0, 2, 1, 3)
+            unm_w, src_w, dst_w = oracle.tome_match(k.mean(1), r)
+            unm, src, dst = ops.tome_match(qkv.cuda(), 2, N, 2, r)
+            np.testing.assert_array_equal(unm.cpu().numpy(), unm_w.numpy())
+            np.testing.assert_array_equal(src.cpu().numpy(), src_w.numpy())
+            np.testing.assert_array_equal(dst.cpu().numpy(), dst_w.numpy())
