@@ -283,6 +283,19 @@ def main():
                 others[label] = {"images_per_s": round(o_ips, 1), "tokens_per_block": m2._last_tokens}
                 del m2, xb
             rec["other_configs"] = others
+            # drift of the bf16 product path against the SAME executor in the reference's fp32 arithmetic (validation kernels):
+            # synthetic weights and inputs, so these are numerics indicators, not accuracy claims.  The dense model shows the
+            # arithmetic drift alone; with Top-K every flipped boundary token changes the token set of all later blocks.
+            def drift(m, xs):
+                lb = m(xs).float()
+                m.precision = "fp32"
+                lf = m(xs).float()
+                m.precision = "bf16"
+                return {"images": int(xs.shape[0]), "logit_rel_l2": round(((lb - lf).norm() / lf.norm()).item(), 5),
+                        "logit_max_abs": round((lb - lf).abs().max().item(), 5),
+                        "top1_agreement": round((lb.argmax(1) == lf.argmax(1)).float().mean().item(), 4)}
+            rec["drift_vs_fp32_path"] = {"dense_deit_s": drift(dense, x[:64]), "topk_kr0.7": drift(model, x[:64]),
+                                         "note": "random-init weights (qkv x4): near-flat, ill-conditioned logits"}
             rec["cpu_baseline"] = cpu_baseline_leg(model)
         try:        # RCCL writes its banner through C stdio: flush it first so the JSON line is the last thing on stdout
             import ctypes
