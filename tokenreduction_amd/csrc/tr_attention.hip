@@ -181,6 +181,9 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
       }
 
     TR_STAMP();
+#ifdef TR_ATT_NO_STORE
+    if (q == 0 && o[0][0] == 123.456f) out[0] = 1;
+#else
     if (q < N) {
       uint16_t* orow = out + ((size_t)b * N + q) * (H * 64) + h * 64 + 4 * hh;
 #pragma unroll
@@ -193,6 +196,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
           *reinterpret_cast<uint2*>(orow + db * 32 + 8 * g) = pk;
         }
     }
+#endif
     TR_STAMP();
     if (COLSUM) {
       const float wq = q < N ? inv : 0.f;
