@@ -165,3 +165,38 @@ def test_reference_finetune_ingest_snippet_runs_unchanged():
     assert sorted(missing) == ["head.bias", "head.weight"] and not unexpected
     assert torch.equal(model.blocks[5].mlp.fc1.weight, src.blocks[5].mlp.fc1.weight)
     assert model.pos_embed.shape == (1, 577, 384)
+
+
+@pytest.mark.parametrize("family", ["topk", "evit", "dyvit", "tome", "ats", "sit", "dpcknn", "sinkhorn", "kmedoids", "patchmerger"])
+def test_stage_schedules_match_the_oracle(family):
+    """The per-block token schedule every family derives from (keep_rate, reduction_loc) -- one rate (geometric) or an explicit
+    list (ratios for topk/evit/dyvit, ABSOLUTE counts for the others; tome.py:145-156, ats.py:204-205, dpcknn.py:214-215) --
+    must equal the oracle's, which is pinned on the reference."""
+    import oracle
+    from oracle import VitConfig
+    cases = [([0.7], [3, 6, 9]), ([0.5], [1, 5]), ([0.9], [0, 4, 8, 11])]
+    if family in ("topk", "evit", "dyvit"):
+        cases += [([0.8, 0.5, 0.3], [2, 5, 8])]
+    elif family == "ats":
+        cases += [([120, 60, 30], [2, 5, 8])]
+    else:
+        cases += [([150, 100, 40], [2, 5, 8])]
+    for kr, loc in cases:
+        if family == "kmedoids" and 0 in loc:
+            continue                                           # no previous attention at block 0 (kmedoids.py:240)
+        args = _args(keep_rate=list(kr), reduction_loc=list(loc), dyvit_distill=False, k_neighbors=5, equal_weight=False,
+                     cluster_iters=3, sinkhorn_eps=1.0)
+        m = tra.create_model(f"{family}_tiny_patch16_224", pretrained=False, num_classes=10, img_size=224, args=args)
+        cfg = VitConfig(family=family, embed_dim=192, depth=12, num_heads=3, keep_rate=list(kr), reduction_loc=list(loc))
+        if family in ("topk", "evit"):
+            want = oracle.stage_keep_counts(cfg)
+        elif family == "dyvit":
+            want = oracle.dyvit_keep_counts(cfg)
+        elif family == "tome":
+            want = oracle.tome_schedule(cfg)
+        elif family == "ats":
+            want = oracle.ats_sample_counts(cfg)
+        else:
+            want = oracle.sit_cluster_counts(cfg)              # sit / dpcknn / sinkhorn / kmedoids / patchmerger share the rule
+        got = {i: k for i, k in enumerate(m._keep) if k}
+        assert got == {int(k): int(v) for k, v in want.items() if v}, (family, kr, loc, got, want)
