@@ -600,6 +600,12 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
       continue;
     }
     // ---- epilogue (same LDS-staged full-line stores as gemm_bf16_persistent)
+#ifdef TR_ABLATE_NO_EPI
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(acc[i][j]), "v"(bv[i])); acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#else
     {
       unsigned char* stg = smem + P_NSTAGE * P_STAGE_BYTES + wave * 2048;
       const int m0 = (c_tile / nNt) * PBM, n0 = (c_tile % nNt) * PBN;
@@ -625,12 +631,16 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
           const u32x4 pk = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((rch ^ (row & 7)) << 4));
           const int m = m0 + wm * 64 + j * 16 + row;
           const int n = n0 + wn * 64 + rch * 8;
-          const bool ok = (m < M) && (n < N);
+          bool ok = (m < M) && (n < N);
+#ifdef TR_ABLATE_NO_STORE
+          ok = ok && (K == 0x7fffffff);
+#endif
           const unsigned off = ok ? (unsigned)(((size_t)m * N + n) * 2) : 0x80000000u;
           __builtin_amdgcn_raw_buffer_store_b128(pk, orsrc, off, 0, 0);
         }
       }
     }
+#endif
     c_kt = 0;
     c_tile += G;
   }

@@ -10,8 +10,8 @@ void tr_set_error(const char* fmt, ...) { (void)fmt; }
 int main(int argc, char** argv) {
   struct Shape { const char* name; int M, N, K, epi; };
   Shape shapes[] = {{"qkv  s1", 50432, 1152, 384, TR_EPI_BF16},   {"fc1  s1", 50432, 1536, 384, TR_EPI_GELU_BF16},
-                    {"proj s1", 50432, 384, 384, TR_EPI_RESID_F32}, {"fc2  s1", 50432, 384, 1536, TR_EPI_RESID_F32},
-                    {"qkv  s4", 17408, 1152, 384, TR_EPI_BF16},   {"fc2  s4", 17408, 384, 1536, TR_EPI_RESID_F32},
+                    {"proj s1", 50432, 384, 384, TR_EPI_BF16}, {"fc2  s1", 50432, 384, 1536, TR_EPI_BF16},
+                    {"qkv  s4", 17408, 1152, 384, TR_EPI_BF16},   {"fc2  s4", 17408, 384, 1536, TR_EPI_BF16},
                     {"big     ", 8192, 8192, 8192, TR_EPI_BF16}};
   for (auto& sh : shapes) {
     size_t na = (size_t)sh.M * sh.K, nw = (size_t)sh.N * sh.K, no = (size_t)sh.M * sh.N;
