@@ -1,0 +1,181 @@
+"""Host-side evaluation / pattern-dump harness: CPU checks against independent restatements of
+engine.py:118-151 and validate.py:199-229 written out longhand here, plus a world-size-2 gloo run of the metric reduction."""
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tokenreduction_amd import harness
+
+
+class _Stub(torch.nn.Module):
+    """A 'model' that returns pre-baked logits (and viz_data) keyed by the first pixel of each image."""
+
+    def __init__(self, logits, viz=None, locs=()):
+        super().__init__()
+        self.logits, self.viz, self.locs = logits, viz, list(locs)
+        self.viz_mode = viz is not None
+        self.w = torch.nn.Parameter(torch.zeros(1234))
+
+    def get_reduction_count(self):
+        return self.locs
+
+    def forward(self, x):
+        ids = x[:, 0, 0, 0].long()
+        out = self.logits[ids]
+        if self.viz_mode:
+            v = {k: {s: a[ids] for s, a in d.items()} for k, d in self.viz.items()}
+            return out, v
+        return out
+
+
+def _loader(n, bs):
+    imgs = torch.zeros(n, 3, 2, 2)
+    imgs[:, 0, 0, 0] = torch.arange(n).float()
+    g = torch.Generator().manual_seed(3)
+    tgt = torch.randint(0, 10, (n,), generator=g)
+    return [(imgs[i:i + bs], tgt[i:i + bs]) for i in range(0, n, bs)], tgt
+
+
+def test_accuracy_matches_definition():
+    g = torch.Generator().manual_seed(0)
+    out = torch.randn(37, 10, generator=g)
+    tgt = torch.randint(0, 10, (37,), generator=g)
+    a1, a5 = harness.accuracy(out, tgt, topk=(1, 5))
+    order = out.argsort(1, descending=True)
+    ref1 = sum(int(order[i, 0] == tgt[i]) for i in range(37)) * 100.0 / 37
+    ref5 = sum(int(tgt[i] in order[i, :5]) for i in range(37)) * 100.0 / 37
+    assert abs(a1.item() - ref1) < 1e-4 and abs(a5.item() - ref5) < 1e-4
+    # fewer classes than k: timm clamps k to the class count
+    a = harness.accuracy(out[:, :3], tgt.clamp(max=2), topk=(5,))[0]
+    assert abs(a.item() - 100.0) < 1e-4
+
+
+def test_evaluate_multiclass_weights_like_the_reference():
+    g = torch.Generator().manual_seed(1)
+    logits = torch.randn(11, 10, generator=g)
+    batches, tgt = _loader(11, 4)                      # ragged last batch (4, 4, 3)
+    got = harness.evaluate_multiclass(batches, _Stub(logits), "cpu")
+    losses, c1, c5 = [], 0, 0
+    for i in range(0, 11, 4):
+        o, t = logits[i:i + 4], tgt[i:i + 4]
+        losses.append(torch.nn.functional.cross_entropy(o, t).item())
+        order = o.argsort(1, descending=True)
+        c1 += sum(int(order[j, 0] == t[j]) for j in range(len(t)))
+        c5 += sum(int(t[j] in order[j, :5]) for j in range(len(t)))
+    assert abs(got["loss"] - sum(losses) / 3) < 1e-6          # per-batch means, weight 1 each (engine.py:140)
+    assert abs(got["acc1"] - 100.0 * c1 / 11) < 1e-4 and abs(got["acc5"] - 100.0 * c5 / 11) < 1e-4
+
+
+def _compose_longhand(name, locs, viz, i):
+    """validate.py:199-229 restated with explicit loops."""
+    kept_prev, out = None, {}
+    for s_idx, s in enumerate(locs):
+        cur = [int(v) for v in viz["Kept_Tokens"][s][i]]
+        if s_idx > 0:
+            if "evit" not in name:
+                cur = [v for v in cur if v >= 0]
+            cur = [kept_prev[v] for v in cur]
+        out[f"Stage-{s}"] = cur
+        kept_prev = cur
+    return out
+
+
+@pytest.mark.parametrize("name", ["topk_small_patch16_224", "ats_small_patch16_224", "evit_small_patch16_224"])
+def test_stage_records_compose_relative_indices(name):
+    g = torch.Generator().manual_seed(5)
+    B, P, locs = 3, 20, [3, 6, 9]
+    widths = [12, 8, 5]
+    viz = {"Kept_Tokens": {}}
+    n_prev = P
+    for s, w in zip(locs, widths):
+        rows = []
+        for _ in range(B):
+            r = torch.randperm(n_prev, generator=g)[:w]
+            if "ats" in name and s != locs[0]:
+                r[-2:] = -1                          # static-K padding of a stage that kept fewer tokens
+            rows.append(r)
+        viz["Kept_Tokens"][s] = torch.stack(rows)
+        n_prev = w - (2 if ("ats" in name and s != locs[0]) else 0)
+    if "evit" in name:
+        viz["Kept_Tokens"][locs[1]][0, 0] = widths[0] - 1      # evit keeps every index (never negative)
+    for i in range(B):
+        rec = harness.image_records(name, locs, viz, i)
+        want = _compose_longhand(name, locs, viz, i)
+        assert list(rec) == [f"Stage-{s}" for s in locs]
+        for k in want:
+            assert rec[k]["Kept_Token"].tolist() == want[k]
+            assert all(0 <= v < P for v in want[k])
+
+
+def test_stage_records_absolute_and_assignment_maps_pass_through():
+    viz = {"Kept_Tokens_Abs": {2: np.arange(12).reshape(2, 6), 5: np.arange(8).reshape(2, 4)},
+           "Assignment_Maps": {2: np.ones((2, 9), np.int64), 5: np.zeros((2, 6), np.int64)}}
+    rec = harness.image_records("heuristic_small_patch16_224", [2, 5], viz, 1)
+    assert rec["Stage-2"]["Kept_Token"].tolist() == list(range(6, 12))
+    assert rec["Stage-5"]["Kept_Token"].tolist() == list(range(4, 8))
+    assert rec["Stage-5"]["Assignment_Maps"].tolist() == [0] * 6
+
+
+def test_validate_writes_the_reference_json_layout(tmp_path):
+    g = torch.Generator().manual_seed(2)
+    n, locs = 6, [1, 2]
+    logits = torch.randn(n, 10, generator=g)
+    viz = {"Kept_Tokens": {1: torch.stack([torch.randperm(9, generator=g)[:5] for _ in range(n)]),
+                           2: torch.stack([torch.randperm(5, generator=g)[:3] for _ in range(n)])}}
+    batches, tgt = _loader(n, 4)
+    names = [f"img_{i}.JPEG" for i in range(n)]
+    model = _Stub(logits, viz, locs)
+    data = harness.validate(batches, model, "cpu", "topk_small_patch16_224", names, keep_rate=[0.5], reduction_loc=locs)
+    assert data["Model"] == "topk_small_patch16_224" and data["Ratio"] == [0.5] and data["Location"] == locs
+    assert data["Params"] == round(1234 / 1e6, 2)
+    for i, nm in enumerate(names):
+        rec = data[nm]
+        assert rec["Predictions"].tolist() == logits[i].argsort(descending=True)[:5].tolist()
+        assert int(rec["Target"]) == int(tgt[i])
+        assert rec["Stage-2"]["Kept_Token"].tolist() == viz["Kept_Tokens"][1][i][viz["Kept_Tokens"][2][i]].tolist()
+    f = tmp_path / "viz.json"
+    harness.write_viz(str(f), data)
+    back = json.loads(f.read_text())
+    assert back[names[0]]["Stage-1"]["Kept_Token"] == viz["Kept_Tokens"][1][0].tolist()
+    assert abs(back["Top1-Acc"] - data["Top1-Acc"]) < 1e-9
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _rank_eval(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(7)
+    logits = torch.randn(10, 10, generator=g)
+    batches, _ = _loader(10, 5)
+    # rank r evaluates batch r only; after the reduction both ranks report the whole-set numbers
+    got = harness.evaluate_multiclass([batches[rank]], _Stub(logits), "cpu")
+    q.put((rank, got))
+    torch.distributed.destroy_process_group()
+
+
+def test_metric_reduction_over_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_rank_eval, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = dict(q.get(timeout=120) for _ in range(2))
+    [p.join(60) for p in ps]
+    g = torch.Generator().manual_seed(7)
+    logits = torch.randn(10, 10, generator=g)
+    batches, _ = _loader(10, 5)
+    whole = harness.evaluate_multiclass(batches, _Stub(logits), "cpu")
+    for r in (0, 1):
+        for k in ("loss", "acc1", "acc5"):
+            assert abs(res[r][k] - whole[k]) < 1e-6, (r, k, res[r], whole)

@@ -165,3 +165,41 @@ def test_model_fp32_matches_reference_golden(golden_dir, name):
     model.precision = "bf16"
     l2, _ = model(x.cuda())
     assert torch.isfinite(l2).all()
+
+
+@pytest.mark.parametrize("name", ["topk_micro", "evit_micro", "topk_small_kr07", "tome_micro", "heuristic_micro_l2"])
+def test_validate_records_compose_to_the_reference_indices(golden_dir, name, tmp_path):
+    """validate.py:199-229 on the device model: the per-image `Stage-{loc}` records of
+    tokenreduction_amd.harness.validate(), composed from the fp32 path's relative indices, equal the composition of the index
+    arrays recorded from the reference; evaluate_multiclass() agrees with the top-1/top-5 of the reference's logits."""
+    from tokenreduction_amd import harness
+    case = GOLDEN_CASES[name]
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    model, _, _ = build_model(case)
+    model.precision = "fp32"
+    B = case["batch"]
+    x = make_images(B, case.get("img_size", 224), case["xseed"])
+    tgt = torch.from_numpy(g["logits"]).argsort(1, descending=True)[:, 1]           # the reference's runner-up class: top-1 0 %, top-5 100 %
+    names = [f"img{i}" for i in range(B)]
+    data = harness.validate([(x, tgt)], model, "cuda", case.get("factory", name), names, keep_rate=case["keep_rate"],
+                            reduction_loc=case["reduction_loc"])
+    locs = model.get_reduction_count()
+    for i, nm in enumerate(names):
+        rec = data[nm]
+        assert rec["Predictions"].tolist() == torch.from_numpy(g["logits"])[i].argsort(descending=True)[:5].tolist()
+        prev = None
+        for s_idx, s in enumerate(locs):
+            if case["family"] == "heuristic":
+                want = g[f"keptabs_{s}"][i]
+            elif case["family"] == "tome":
+                np.testing.assert_array_equal(rec[f"Stage-{s}"]["Assignment_Maps"], g[f"assign_{s}"][i])
+                continue
+            else:
+                want = g[f"kept_{s}"][i] if s_idx == 0 else prev[g[f"kept_{s}"][i]]
+            np.testing.assert_array_equal(rec[f"Stage-{s}"]["Kept_Token"], want)
+            prev = want
+    assert data["Top1-Acc"] == 0.0 and data["Top5-Acc"] == 100.0
+    harness.write_viz(str(tmp_path / "v.json"), data)
+    model.viz_mode = False
+    stats = harness.evaluate_multiclass([(x, tgt)], model, "cuda")
+    assert stats["acc1"] == 0.0 and stats["acc5"] == 100.0 and np.isfinite(stats["loss"])

@@ -10,4 +10,6 @@ from .models import (VisionTransformer, TopKVisionTransformer, EfficientVisionTr
                      PatchMergerVisionTransformer, HeuristicVisionTransformer,
                      VisionTransformerTeacher)
 
+from . import harness  # noqa: F401,E402  (evaluate_multiclass / validate / write_viz)
+
 __version__ = "0.1.0"

@@ -1,0 +1,163 @@
+"""Thin evaluation / pattern-dump harness around the models.
+
+Mirrors, for the forward (inference) path only:
+
+    engine.py:118-151     evaluate_multiclass()      -> evaluate_multiclass()
+    utils.py:20-75        SmoothedValue global_avg + synchronize_between_processes (sum of count/total over ranks)
+    timm.utils.accuracy   top-k accuracy in percent   -> accuracy()
+    validate.py:163-229   per-image `Stage-{loc}` records, relative -> absolute kept-token composition -> image_records()
+    validate.py:26-30, 278-287   NumpyArrayEncoder / write_viz -> write_viz()
+
+Host logic only: the model is any callable returning logits or `(logits, viz_data)`.  The fine-tune half of engine.py
+(backward, optimizer, EMA) is not built -- tokenreduction_amd has no training path.
+"""
+import json
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+
+def accuracy(output: torch.Tensor, target: torch.Tensor, topk: Sequence[int] = (1,)) -> List[torch.Tensor]:
+    """timm.utils.accuracy: percentage of rows whose target is among the k largest logits."""
+    maxk = min(max(topk), output.shape[1])
+    _, pred = output.topk(maxk, 1, True, True)
+    correct = pred.t().eq(target.reshape(1, -1).expand(maxk, -1))
+    return [correct[:min(k, maxk)].reshape(-1).float().sum(0) * 100.0 / target.shape[0] for k in topk]
+
+
+class _Meter:
+    """utils.py:20-75 reduced to what evaluate_* reads: global_avg = total / count, summed over ranks on synchronize."""
+
+    def __init__(self):
+        self.count, self.total = 0, 0.0
+
+    def update(self, value: float, n: int = 1):
+        self.count += n
+        self.total += value * n
+
+    def synchronize_between_processes(self, device=None):
+        if not (dist.is_available() and dist.is_initialized()):       # utils.py:40-41
+            return
+        dev = device if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([self.count, self.total], dtype=torch.float64, device=dev)
+        dist.barrier()
+        dist.all_reduce(t)
+        self.count, self.total = int(t[0].item()), float(t[1].item())
+
+    @property
+    def global_avg(self) -> float:
+        return self.total / self.count
+
+
+@torch.no_grad()
+def evaluate_multiclass(data_loader: Iterable, model, device) -> Dict[str, float]:
+    """engine.py:118-151.  `loss` averages the per-batch mean losses (meter weight 1 per batch, as the reference's
+    `metric_logger.update(loss=loss.item())` does); acc1/acc5 are weighted by batch size."""
+    meters = {"loss": _Meter(), "acc1": _Meter(), "acc5": _Meter()}
+    if hasattr(model, "eval"):
+        model.eval()
+    for images, target in data_loader:
+        images = images.to(device, non_blocking=True)
+        target = target.to(device, non_blocking=True)
+        output = model(images)
+        if isinstance(output, (tuple, list)):
+            output = output[0]
+        loss = F.cross_entropy(output.float(), target)
+        acc1, acc5 = accuracy(output, target, topk=(1, 5))
+        n = images.shape[0]
+        meters["loss"].update(loss.item())
+        meters["acc1"].update(acc1.item(), n=n)
+        meters["acc5"].update(acc5.item(), n=n)
+    for m in meters.values():
+        m.synchronize_between_processes(device)
+    return {k: m.global_avg for k, m in meters.items()}
+
+
+def _np(a):
+    return a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+
+
+def image_records(model_name: str, reduction_count: Sequence[int], viz_data: dict, i: int) -> Dict[str, dict]:
+    """The `Stage-{loc}` part of one image's record (validate.py:199-229).
+
+    `Kept_Tokens` of the first stage are patch indices of the input grid; later stages index into the PREVIOUS stage's kept
+    list, so they are composed into absolute indices here.  Padding entries (-1, the ATS static-K padding) are dropped before
+    the composition for every family but EViT (validate.py:213-214).  `Kept_Tokens_Abs` (heuristic patterns) and
+    `Assignment_Maps` (the merging families) are copied through; the reference switches the soft maps, centre features and
+    fusion assignment off (validate.py:178-180)."""
+    out: Dict[str, dict] = {}
+    prev: Optional[str] = None
+    for stage_idx, stage in enumerate(reduction_count):
+        name = f"Stage-{stage}"
+        rec: dict = {}
+        if "Kept_Tokens" in viz_data:
+            cur = _np(viz_data["Kept_Tokens"][stage][i])
+            if stage_idx == 0:
+                rec["Kept_Token"] = cur
+            else:
+                rel = cur
+                if "evit" not in model_name:
+                    rel = rel[rel >= 0]
+                rec["Kept_Token"] = out[prev]["Kept_Token"][rel]
+        if "Kept_Tokens_Abs" in viz_data:
+            rec["Kept_Token"] = _np(viz_data["Kept_Tokens_Abs"][stage][i])
+        if "Assignment_Maps" in viz_data:
+            rec["Assignment_Maps"] = _np(viz_data["Assignment_Maps"][stage][i])
+        out[name] = rec
+        prev = name
+    return out
+
+
+@torch.no_grad()
+def validate(data_loader: Iterable, model, device, model_name: str, image_names: Sequence[str], keep_rate=None,
+             reduction_loc=None) -> dict:
+    """validate.py:59-276 without dataset/checkpoint plumbing: runs the loader, returns the `*_viz_results.json` dictionary
+    (per image: top-5 `Predictions`, `Target`, the batch `Loss`, and -- with `model.viz_mode` -- the stage records)."""
+    data = {"Model": model_name, "Ratio": keep_rate, "Location": reduction_loc}
+    top1, top5 = _Meter(), _Meter()
+    viz_mode = bool(getattr(model, "viz_mode", False))
+    count = 0
+    for images, target in data_loader:
+        images = images.to(device, non_blocking=True)
+        target = target.to(device, non_blocking=True)
+        output = model(images)
+        viz_data = None
+        if viz_mode:
+            output, viz_data = output
+        loss = F.cross_entropy(output.float(), target)
+        acc1, acc5 = accuracy(output, target, topk=(1, 5))
+        _, pred = output.topk(min(5, output.shape[1]), 1, True, True)
+        n = images.shape[0]
+        top1.update(acc1.item(), n)
+        top5.update(acc5.item(), n)
+        for i in range(n):
+            rec = {"Predictions": _np(pred[i]), "Target": _np(target[i]), "Loss": loss.item()}
+            if viz_mode:
+                rec.update(image_records(model_name, model.get_reduction_count(), viz_data, i))
+            data[image_names[count + i]] = rec
+        count += n
+    data["Top1-Acc"] = round(top1.global_avg, 4)
+    data["Top5-Acc"] = round(top5.global_avg, 4)
+    if hasattr(model, "parameters"):
+        data["Params"] = round(sum(p.numel() for p in model.parameters()) / 1e6, 2)
+    return data
+
+
+class NumpyArrayEncoder(json.JSONEncoder):
+    """validate.py:26-30."""
+
+    def default(self, obj):
+        if isinstance(obj, np.ndarray):
+            return obj.tolist()
+        if isinstance(obj, np.generic):
+            return obj.item()
+        return json.JSONEncoder.default(self, obj)
+
+
+def write_viz(viz_file: str, viz_data: dict) -> None:
+    """validate.py:285-287."""
+    with open(viz_file, "w") as f:
+        json.dump(viz_data, f, cls=NumpyArrayEncoder, indent=4)
