@@ -10,6 +10,28 @@
 
 namespace {
 
+// The fp32 residual stream (and the bf16 delta) is read once and written once per LayerNorm and not touched again until the next
+// one, ~400 MB of GEMM/attention traffic later: nontemporal loads/stores keep it from displacing the lines the next kernel wants
+// (the normalised bf16 output, which the following GEMM reads at once, is stored with the default policy).  Measured with cold
+// caches at M = 50432, D = 384: 50.4 -> 40.9 us (tools/ln_lab.py); back to back on cache-resident rows it costs 7 %.
+#ifdef TR_LN_NO_NT
+#define LN_LOAD(p) (*(p))
+#define LN_STORE(v, p) (*(p) = (v))
+#else
+#define LN_LOAD(p) __builtin_nontemporal_load(p)
+#define LN_STORE(v, p) __builtin_nontemporal_store(v, p)
+#endif
+
+typedef __attribute__((ext_vector_type(4))) float ln_f4;
+__device__ __forceinline__ float4 ln_nt_load4(const float* p) {
+  const ln_f4 t = LN_LOAD(reinterpret_cast<const ln_f4*>(p));
+  return make_float4(t[0], t[1], t[2], t[3]);
+}
+__device__ __forceinline__ void ln_nt_store4(const float4& v, float* p) {
+  const ln_f4 t = {v.x, v.y, v.z, v.w};
+  LN_STORE(t, reinterpret_cast<ln_f4*>(p));
+}
+
 // x[row] (+= delta[row], written back) -> y[row] = LayerNorm(x[row]).  delta is the bf16 output of the preceding Linear
 // (attn.proj or mlp.fc2): the residual add `x = x + drop_path(...)` (topk.py:87 / :95) is folded into the norm that
 // reads x next, so the GEMMs never read-modify-write the fp32 stream.
@@ -25,18 +47,73 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, l
   float4 v[LN_MAX_CHUNKS];
 #pragma unroll
   for (int c = 0; c < LN_MAX_CHUNKS; ++c)
-    if (lane + 64 * c < nchunks) v[c] = *reinterpret_cast<const float4*>(xr + 4 * (lane + 64 * c));
+    if (lane + 64 * c < nchunks) v[c] = ln_nt_load4(xr + 4 * (lane + 64 * c));
   if (delta != nullptr) {
 #pragma unroll
     for (int c = 0; c < LN_MAX_CHUNKS; ++c)
       if (lane + 64 * c < nchunks) {
         const float4 d = load_delta4<F32>(delta, (size_t)row * ldd + 4 * (lane + 64 * c));
         v[c].x += d.x; v[c].y += d.y; v[c].z += d.z; v[c].w += d.w;
-        *reinterpret_cast<float4*>(xr + 4 * (lane + 64 * c)) = v[c];
+        ln_nt_store4(v[c], xr + 4 * (lane + 64 * c));
       }
   }
   ln_row_store<F32>(v, nchunks, lane, D, eps, gamma, beta,
                     F32 ? (void*)(reinterpret_cast<float*>(y) + (size_t)row * D) : (void*)(reinterpret_cast<uint16_t*>(y) + (size_t)row * D));
+}
+
+// D = 128 * CPL <= 512 (DeiT-S: 384): HALF a wave per row, CPL float4 chunks per lane -- every lane busy (the one-wave-per-row
+// kernel above leaves a quarter of the lanes idle at D = 384 and splits a row's 1.5 KiB into a full and a half request).
+// Same arithmetic as ln_row_store (two-pass statistics, sums over the row's 32 lanes by xor-shuffles 16..1).
+template <int CPL>
+__global__ __launch_bounds__(256) void layernorm_half_kernel(float* __restrict__ x, long ldx, const uint16_t* __restrict__ delta, long ldd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             uint16_t* __restrict__ y, int M, float eps) {
+  constexpr int D = 128 * CPL;
+  const int sub = threadIdx.x & 31;
+  const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (row >= M) return;
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  typedef __attribute__((ext_vector_type(2))) unsigned u2;
+  f4* xr = reinterpret_cast<f4*>(x + (size_t)row * ldx);
+  f4 v[CPL];
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) v[c] = LN_LOAD(xr + sub + 32 * c);
+  if (delta != nullptr) {
+    const u2* dr = reinterpret_cast<const u2*>(delta + (size_t)row * ldd);
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) {
+      const u2 d = LN_LOAD(dr + sub + 32 * c);
+      v[c][0] += __uint_as_float(d[0] << 16); v[c][1] += __uint_as_float(d[0] & 0xffff0000u);
+      v[c][2] += __uint_as_float(d[1] << 16); v[c][3] += __uint_as_float(d[1] & 0xffff0000u);
+      LN_STORE(v[c], xr + sub + 32 * c);
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const float a = v[c][0] - mean, b = v[c][1] - mean, cc = v[c][2] - mean, d = v[c][3] - mean;
+    q += (a * a + b * b) + (cc * cc + d * d);
+  }
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = rsqrtf(q / (float)D + eps);
+  u2* yr = reinterpret_cast<u2*>(y + (size_t)row * D);
+#pragma unroll
+  for (int c = 0; c < CPL; ++c) {
+    const int ch = sub + 32 * c;
+    const f4 g = *reinterpret_cast<const f4*>(gamma + 4 * ch);
+    const f4 b = *reinterpret_cast<const f4*>(beta + 4 * ch);
+    u2 pk;
+    pk[0] = pack_bf16x2((v[c][0] - mean) * rstd * g[0] + b[0], (v[c][1] - mean) * rstd * g[1] + b[1]);
+    pk[1] = pack_bf16x2((v[c][2] - mean) * rstd * g[2] + b[2], (v[c][3] - mean) * rstd * g[3] + b[3]);
+    yr[ch] = pk;
+  }
 }
 
 // grid: B * ceil(N_out/4) blocks; wave w of block handles output row r = 4*blk + w of image b.
@@ -87,7 +164,7 @@ __global__ __launch_bounds__(256) void gather_layernorm_kernel(const float* __re
 #pragma unroll
     for (int c = 0; c < LN_MAX_CHUNKS; ++c)
       if (lane + 64 * c < nchunks) {
-        v[c] = *reinterpret_cast<const float4*>(xr + 4 * (lane + 64 * c));
+        v[c] = ln_nt_load4(xr + 4 * (lane + 64 * c));
         if (has_d) {
           const float4 d = load_delta4<F32>(delta, dbase + (size_t)src * D + 4 * (lane + 64 * c));
           v[c].x += d.x; v[c].y += d.y; v[c].z += d.z; v[c].w += d.w;
@@ -99,7 +176,7 @@ __global__ __launch_bounds__(256) void gather_layernorm_kernel(const float* __re
     float* xo = x_out + orow * D;
 #pragma unroll
     for (int c = 0; c < LN_MAX_CHUNKS; ++c)
-      if (lane + 64 * c < nchunks) *reinterpret_cast<float4*>(xo + 4 * (lane + 64 * c)) = v[c];
+      if (lane + 64 * c < nchunks) ln_nt_store4(v[c], xo + 4 * (lane + 64 * c));
   }
   ln_row_store<F32>(v, nchunks, lane, D, eps, gamma, beta,
                     F32 ? (void*)(reinterpret_cast<float*>(y) + orow * D) : (void*)(reinterpret_cast<uint16_t*>(y) + orow * D));
@@ -157,6 +234,14 @@ static int layernorm_impl(bool f32, float* x, long ldx, const void* delta, long 
   TR_REQUIRE(tr_aligned16(x) && tr_aligned16(gamma) && tr_aligned16(beta) && tr_aligned16(y), TR_ERR_ALIGN,
              "tr_layernorm: pointers must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(s);
+#ifndef TR_LN_NO_HALF
+  if (!f32 && D == 384) {
+    hipLaunchKernelGGL(layernorm_half_kernel<3>, dim3((M + 7) / 8), dim3(256), 0, st, x, ldx, static_cast<const uint16_t*>(delta), ldd,
+                       gamma, beta, static_cast<uint16_t*>(y), M, eps);
+    TR_CHECK_LAUNCH("tr_layernorm");
+    return TR_OK;
+  }
+#endif
   if (f32) hipLaunchKernelGGL(layernorm_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, x, ldx, delta, ldd, gamma, beta, y, M, D, eps);
   else hipLaunchKernelGGL(layernorm_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, x, ldx, delta, ldd, gamma, beta, y, M, D, eps);
   TR_CHECK_LAUNCH("tr_layernorm");
