@@ -63,21 +63,39 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
 #define TR_STAMP() do { } while (0)
 #endif
 
-  // ---- stage K (row-major, swizzled); keys >= N are zero rows
-  for (int g = tid; g < NKB * 32 * 8; g += 256) {
+  // ---- stage K (row-major, swizzled) and V transposed; keys >= N are zero rows.  All 2 * NKB 16-byte loads of a thread are
+  // issued BEFORE the first LDS write: as rolled loops (load, wait, write, next) the 2 * NKB global round trips ran back to
+  // back and were 13.8 k of a workgroup's 33 k cycles at N = 197 (profiles/r01_attention_lab.md).  The registers are free here
+  // (nothing of the query loop is live yet).
+  uint4 kreg[NKB], vreg[NKB];
+#pragma unroll
+  for (int it = 0; it < NKB; ++it) {
+    const int g = tid + 256 * it;                       // NKB * 32 * 8 chunks = NKB per thread
     const int key = g >> 3, c = g & 7;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (key < N) v = *reinterpret_cast<const uint4*>(base + (size_t)key * ldq + kcol + c * 8);
-    *reinterpret_cast<uint4*>(sK + kswz(key, c)) = v;
+    kreg[it] = make_uint4(0u, 0u, 0u, 0u);
+    if (key < N) kreg[it] = *reinterpret_cast<const uint4*>(base + (size_t)key * ldq + kcol + c * 8);
   }
-  // ---- stage V transposed: lanes 0-31 take the 32 keys of a block for d-chunk c, lanes 32-63 chunk c+1
-  for (int u = wave; u < NKB * 4; u += 4) {
+  // V: lanes 0-31 take the 32 keys of a block for d-chunk c, lanes 32-63 chunk c+1
+#pragma unroll
+  for (int it = 0; it < NKB; ++it) {
+    const int u = wave + 4 * it;                        // NKB * 4 (block, chunk-pair) units = NKB per wave
     const int kb = u >> 2, c = 2 * (u & 3) + (lane >> 5);
-    const int kl = lane & 31, key = kb * 32 + kl;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (key < N) v = *reinterpret_cast<const uint4*>(base + (size_t)key * ldq + vcol + c * 8);
+    const int key = kb * 32 + (lane & 31);
+    vreg[it] = make_uint4(0u, 0u, 0u, 0u);
+    if (key < N) vreg[it] = *reinterpret_cast<const uint4*>(base + (size_t)key * ldq + vcol + c * 8);
+  }
+#pragma unroll
+  for (int it = 0; it < NKB; ++it) {
+    const int g = tid + 256 * it;
+    *reinterpret_cast<uint4*>(sK + kswz(g >> 3, g & 7)) = kreg[it];
+  }
+#pragma unroll
+  for (int it = 0; it < NKB; ++it) {
+    const int u = wave + 4 * it;
+    const int kb = u >> 2, c = 2 * (u & 3) + (lane >> 5);
+    const int kl = lane & 31;
     unsigned short* dst = reinterpret_cast<unsigned short*>(sVt + (8 * c) * RS + (kb * 32 + swap23(kl)) * 2);
-    const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+    const unsigned int w[4] = {vreg[it].x, vreg[it].y, vreg[it].z, vreg[it].w};
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const unsigned int word = w[e >> 1];

@@ -539,11 +539,22 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
   const int wm = wave >> 1, wn = wave & 1;
   const int frow = lane & 15, fq = lane >> 4;
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(outp, 0, (int)out_bytes, 0x00020000);
+  // The accumulators START at the bias of the tile's columns (instead of zero + a bias add in the epilogue: 64 VALU adds per lane
+  // and tile less, in the one phase where the matrix pipe idles); the next tile's bias is fetched under the last K-step.
+  auto load_bias = [&](f32x4 (&bv)[4], int tile) __attribute__((always_inline)) {
+    const int n0 = (tile % nNt) * PBN;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const f32x4*>(bias + min(n0 + wn * 64 + i * 16 + 4 * fq, N - 4));
+  };
   f32x4 acc[4][4];
+  {
+    f32x4 b0[4];
+    load_bias(b0, toff);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < 4; ++j) acc[i][j] = b0[i];
+  }
   bf16x8 wA[4], aA[4], wC[4], aC[4];
 #define READ_FRAGS(WF, AF, slot, ks)                                                                          \
   do {                                                                                                        \
@@ -572,12 +583,8 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
   for (int g = 0; g < S; ++g) {
     const bool tile_end = (c_kt == nk - 1);
     READ_FRAGS(wC, aC, c_slot, 1);
-    f32x4 bv[4];
-    if (tile_end) {
-      const int n0 = (c_tile % nNt) * PBN;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) bv[i] = *reinterpret_cast<const f32x4*>(bias + min(n0 + wn * 64 + i * 16 + 4 * fq, N - 4));
-    }
+    f32x4 bv[4];                           // bias of the NEXT tile (the tail workgroups reload their last tile's: unused)
+    if (tile_end) load_bias(bv, c_tile + G < T ? c_tile + G : c_tile);
     MFMA_GROUP(wA, aA, 0);
     MFMA_GROUP(wA, aA, 1);
     MFMA_GROUP(wA, aA, 2);
@@ -604,18 +611,25 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(acc[i][j]), "v"(bv[i])); acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      for (int i = 0; i < 4; ++i) { asm volatile("" ::"v"(acc[i][j])); acc[i][j] = bv[i]; }
 #else
     {
+      // Software-pipelined over the four 16-row slabs: slab j is staged (bf16 -> wave-private LDS) while slab j-1's read-back is
+      // still in flight, and stored after that.  LDS operations of one wave execute in order, so re-using the one 2-KiB stage
+      // is safe (the read-back of j-1 is queued before the writes of j), and only one LDS round trip per tile is exposed
+      // instead of four.
       unsigned char* stg = smem + P_NSTAGE * P_STAGE_BYTES + wave * 2048;
-      const int m0 = (c_tile / nNt) * PBM, n0 = (c_tile % nNt) * PBN;
       const int rrow = lane >> 3, rch = lane & 7;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      const int m_first = (c_tile / nNt) * PBM + wm * 64 + rrow;        // row of (slab 0, half 0); +8 per half-slab
+      const int n = (c_tile % nNt) * PBN + wn * 64 + rch * 8;
+      const unsigned off_first = ((unsigned)m_first * (unsigned)N + (unsigned)n) * 2u;      // < 2 GiB (launcher)
+      const unsigned off_step = 16u * (unsigned)N;                                          // 8 rows of bf16
+      const unsigned char* rd = stg + rrow * 128 + ((rch ^ rrow) << 4);                     // (row & 7) == rrow for both halves
+      auto stage = [&](int j) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          float v0 = acc[i][j][0] + bv[i][0], v1 = acc[i][j][1] + bv[i][1], v2 = acc[i][j][2] + bv[i][2], v3 = acc[i][j][3] + bv[i][3];
-          acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
+          acc[i][j] = bv[i];
           if (EPI == TR_EPI_GELU_BF16) {
             const f32x2 g01 = gelu2(f32x2{v0, v1}), g23 = gelu2(f32x2{v2, v3});
             v0 = g01[0]; v1 = g01[1]; v2 = g23[0]; v3 = g23[1];
@@ -625,20 +639,29 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
           pk[1] = pack_bf16x2(v2, v3);
           *reinterpret_cast<u32x2*>(stg + frow * 128 + (((2 * i + (fq >> 1)) ^ (frow & 7)) << 4) + (fq & 1) * 8) = pk;
         }
+      };
+      auto read_back = [&](u32x4 (&ln)[2]) __attribute__((always_inline)) {
+        ln[0] = *reinterpret_cast<const u32x4*>(rd);
+        ln[1] = *reinterpret_cast<const u32x4*>(rd + 1024);
+      };
+      auto store = [&](int j, const u32x4 (&ln)[2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
-          const int row = r * 8 + rrow;
-          const u32x4 pk = *reinterpret_cast<const u32x4*>(stg + row * 128 + ((rch ^ (row & 7)) << 4));
-          const int m = m0 + wm * 64 + j * 16 + row;
-          const int n = n0 + wn * 64 + rch * 8;
-          bool ok = (m < M) && (n < N);
+          bool ok = (m_first + 8 * (2 * j + r) < M) && (n < N);
 #ifdef TR_ABLATE_NO_STORE
           ok = ok && (K == 0x7fffffff);
 #endif
-          const unsigned off = ok ? (unsigned)(((size_t)m * N + n) * 2) : 0x80000000u;
-          __builtin_amdgcn_raw_buffer_store_b128(pk, orsrc, off, 0, 0);
+          // out-of-range lanes get an offset beyond num_records: the buffer bounds check drops their store
+          const unsigned off = ok ? off_first + (unsigned)(2 * j + r) * off_step : 0x80000000u;
+          __builtin_amdgcn_raw_buffer_store_b128(ln[r], orsrc, off, 0, 0);
         }
-      }
+      };
+      u32x4 lnA[2], lnB[2];
+      stage(0); read_back(lnA);
+      stage(1); store(0, lnA); read_back(lnB);
+      stage(2); store(1, lnB); read_back(lnA);
+      stage(3); store(2, lnA); read_back(lnB);
+      store(3, lnB);
     }
 #endif
     c_kt = 0;
