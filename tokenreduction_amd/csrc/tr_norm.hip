@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void layernorm_half_kernel(float* __restrict__
   }
 }
 
-// grid: B * ceil(N_out/4) blocks; wave w of block handles output row r = 4*blk + w of image b.
+// grid: B * (ceil(rows/4) [+ 1]) blocks; wave w of a gather block handles output row r = 4*blk + w of image b.
 template <bool F32>
 __global__ __launch_bounds__(256) void gather_layernorm_kernel(const float* __restrict__ x, const void* __restrict__ delta,
                                                                const int32_t* __restrict__ idx,
@@ -125,38 +125,86 @@ __global__ __launch_bounds__(256) void gather_layernorm_kernel(const float* __re
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                float* __restrict__ x_out, void* __restrict__ y, int N, int K,
                                                                int N_out, int D, float eps) {
-  const int lane = threadIdx.x & 63;
-  const int rblocks = (N_out + 3) >> 2;
-  const int b = blockIdx.x / rblocks;
-  const int r = (blockIdx.x % rblocks) * 4 + (threadIdx.x >> 6);
-  if (r >= N_out) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool fuse = compl_idx != nullptr;
+  const int grows = fuse ? N_out - 1 : N_out;          // rows that are plain gathers; EViT's fused token is row K+1 = grows
+  const int rblocks = (grows + 3) >> 2;
+  const int bpi = rblocks + (fuse ? 1 : 0);            // the fused token gets a block of its own (all four waves)
+  const int b = blockIdx.x / bpi;
+  const int lb = blockIdx.x % bpi;
+  const bool fused_block = fuse && lb == rblocks;
+  const int r = fused_block ? grows : lb * 4 + wave;
+  if (!fused_block && r >= grows) return;
   const int nchunks = D >> 2;
   const int P = N - 1;
   const float* xb = x + (size_t)b * N * D;
   const bool has_d = delta != nullptr;                 // pending residual (proj output), same row layout as x
   const size_t dbase = (size_t)b * N * D;
   float4 v[LN_MAX_CHUNKS];
-  if (idx != nullptr && r == K + 1) {
+  __shared__ float4 part[3][256];                      // partial sums of waves 1..3 of a fused block (D <= 1024)
+  if (fused_block) {
     // EViT fused token: sum over the NOT-kept tokens, weighted by their (un-normalised) CLS attention
 #pragma unroll
     for (int c = 0; c < LN_MAX_CHUNKS; ++c) v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int32_t* cb = compl_idx + (size_t)b * (P - K);
     const float* sb = scores + (size_t)b * P;
-    for (int j = 0; j < P - K; ++j) {
-      const int t = cb[j];
-      const float w = sb[t];
-      const float* xr = xb + (size_t)(1 + t) * D;
+    // The four waves take the complement tokens j = wave, wave+4, ...; lane l of a wave holds index and weight of its token
+    // 64*blk + l, the row loop reads them with v_readlane (wave-uniform) and fetches FOUR rows per step before accumulating.
+    // (As one wave walking all tokens, three dependent round trips per token, this row was the kernel's long pole: 81 us per
+    // launch against 27 us for the plain gather.)  Partials are combined in wave order: deterministic.
+    const int n_c = P - K;
+    const int n_w = (n_c - wave + 3) >> 2;                 // tokens of this wave
+    for (int i0 = 0; i0 < n_w; i0 += 64) {
+      int tl = 0;
+      float wl = 0.f;
+      if (i0 + lane < n_w) {
+        tl = cb[wave + 4 * (i0 + lane)];
+        wl = sb[tl];
+      }
+      const int cnt = min(64, n_w - i0);
+      for (int j = 0; j < cnt; j += 4) {
+        float4 a[4][LN_MAX_CHUNKS];
+        float w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int jj = min(j + u, cnt - 1);                 // past the end: a valid row with weight 0
+          const int t = __builtin_amdgcn_readlane(tl, jj);
+          w[u] = (j + u < cnt) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wl), jj)) : 0.f;
+          const float* xr = xb + (size_t)(1 + t) * D;
+#pragma unroll
+          for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+            if (lane + 64 * c < nchunks) {
+              a[u][c] = *reinterpret_cast<const float4*>(xr + 4 * (lane + 64 * c));
+              if (has_d) {
+                const float4 d = load_delta4<F32>(delta, dbase + (size_t)(1 + t) * D + 4 * (lane + 64 * c));
+                a[u][c].x += d.x; a[u][c].y += d.y; a[u][c].z += d.z; a[u][c].w += d.w;
+              }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+            if (lane + 64 * c < nchunks) {
+              v[c].x += a[u][c].x * w[u]; v[c].y += a[u][c].y * w[u]; v[c].z += a[u][c].z * w[u]; v[c].w += a[u][c].w * w[u];
+            }
+      }
+    }
+    if (wave > 0) {
+#pragma unroll
+      for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+        if (lane + 64 * c < nchunks) part[wave - 1][lane + 64 * c] = v[c];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
 #pragma unroll
       for (int c = 0; c < LN_MAX_CHUNKS; ++c)
         if (lane + 64 * c < nchunks) {
-          float4 a = *reinterpret_cast<const float4*>(xr + 4 * (lane + 64 * c));
-          if (has_d) {
-            const float4 d = load_delta4<F32>(delta, dbase + (size_t)(1 + t) * D + 4 * (lane + 64 * c));
-            a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
-          }
-          v[c].x += a.x * w; v[c].y += a.y * w; v[c].z += a.z * w; v[c].w += a.w * w;
+          const float4 q = part[p][lane + 64 * c];
+          v[c].x += q.x; v[c].y += q.y; v[c].z += q.z; v[c].w += q.w;
         }
-    }
   } else {
     int src = r;
     if (idx != nullptr && r > 0) src = 1 + idx[(size_t)b * K + (r - 1)];
@@ -278,7 +326,7 @@ static int gather_layernorm_impl(bool f32, const float* x, const void* delta, co
   TR_REQUIRE(tr_aligned16(x) && tr_aligned16(gamma) && tr_aligned16(beta) && tr_aligned16(y) && tr_aligned16(x_out) &&
                  tr_aligned16(delta),
              TR_ERR_ALIGN, "tr_gather_layernorm: pointers must be 16-byte aligned");
-  const int rblocks = (N_out + 3) / 4;
+  const int rblocks = compl_idx != nullptr ? (N_out - 1 + 3) / 4 + 1 : (N_out + 3) / 4;   // + one block per image for the fused token
   hipStream_t st = static_cast<hipStream_t>(s);
   if (f32)
     hipLaunchKernelGGL(gather_layernorm_kernel<true>, dim3(B * rblocks), dim3(256), 0, st, x, delta, idx, compl_idx, scores, gamma,
