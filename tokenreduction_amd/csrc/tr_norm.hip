@@ -10,28 +10,6 @@
 
 namespace {
 
-// The fp32 residual stream (and the bf16 delta) is read once and written once per LayerNorm and not touched again until the next
-// one, ~400 MB of GEMM/attention traffic later: nontemporal loads/stores keep it from displacing the lines the next kernel wants
-// (the normalised bf16 output, which the following GEMM reads at once, is stored with the default policy).  Measured with cold
-// caches at M = 50432, D = 384: 50.4 -> 40.9 us (tools/ln_lab.py); back to back on cache-resident rows it costs 7 %.
-#ifdef TR_LN_NO_NT
-#define LN_LOAD(p) (*(p))
-#define LN_STORE(v, p) (*(p) = (v))
-#else
-#define LN_LOAD(p) __builtin_nontemporal_load(p)
-#define LN_STORE(v, p) __builtin_nontemporal_store(v, p)
-#endif
-
-typedef __attribute__((ext_vector_type(4))) float ln_f4;
-__device__ __forceinline__ float4 ln_nt_load4(const float* p) {
-  const ln_f4 t = LN_LOAD(reinterpret_cast<const ln_f4*>(p));
-  return make_float4(t[0], t[1], t[2], t[3]);
-}
-__device__ __forceinline__ void ln_nt_store4(const float4& v, float* p) {
-  const ln_f4 t = {v.x, v.y, v.z, v.w};
-  LN_STORE(t, reinterpret_cast<ln_f4*>(p));
-}
-
 // x[row] (+= delta[row], written back) -> y[row] = LayerNorm(x[row]).  delta is the bf16 output of the preceding Linear
 // (attn.proj or mlp.fc2): the residual add `x = x + drop_path(...)` (topk.py:87 / :95) is folded into the norm that
 // reads x next, so the GEMMs never read-modify-write the fp32 stream.

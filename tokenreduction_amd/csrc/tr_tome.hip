@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void tome_merge_layernorm_kernel(const float* 
 #pragma unroll
     for (int c = 0; c < LN_MAX_CHUNKS; ++c)
       if (lane + 64 * c < nchunks) {
-        float4 a = *reinterpret_cast<const float4*>(xb + (size_t)t * D + 4 * (lane + 64 * c));
+        float4 a = ln_nt_load4(xb + (size_t)t * D + 4 * (lane + 64 * c));
         if (delta) {
           const float4 d = load_delta4<F32>(delta, dbase + (size_t)t * D + 4 * (lane + 64 * c));
           a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
@@ -228,8 +228,22 @@ __global__ __launch_bounds__(256) void tome_merge_layernorm_kernel(const float* 
   } else {
     const int j = p - n_unm;
     add_token(2 * j + 1, true);
-    for (int e = 0; e < r; ++e)                       // edge order = the order torch's CPU scatter_add applies the sources
-      if (dst_idx[(size_t)b * r + e] == j) add_token(2 * src_idx[(size_t)b * r + e], false);
+    // edge order = the order torch's CPU scatter_add applies the sources.  Lane l holds edge 64*blk + l; the edges that end in
+    // this dst token come out of one ballot, lowest edge first.  (A scalar loop over the r edges paid one dependent index load
+    // per edge: ~8 us per dst row at r = 16, the kernel's long pole.)
+    for (int e0 = 0; e0 < r; e0 += 64) {
+      int dl = -1, sl = 0;
+      if (e0 + lane < r) {
+        dl = dst_idx[(size_t)b * r + e0 + lane];
+        sl = src_idx[(size_t)b * r + e0 + lane];
+      }
+      unsigned long long m = __ballot(dl == j);
+      while (m) {
+        const int e = __builtin_ctzll(m);
+        m &= m - 1;
+        add_token(2 * __builtin_amdgcn_readlane(sl, e), false);
+      }
+    }
   }
 #pragma unroll
   for (int c = 0; c < LN_MAX_CHUNKS; ++c)
@@ -238,7 +252,7 @@ __global__ __launch_bounds__(256) void tome_merge_layernorm_kernel(const float* 
   if (lane == 0) size_out[orow] = sz;
 #pragma unroll
   for (int c = 0; c < LN_MAX_CHUNKS; ++c)
-    if (lane + 64 * c < nchunks) *reinterpret_cast<float4*>(x_out + orow * D + 4 * (lane + 64 * c)) = v[c];
+    if (lane + 64 * c < nchunks) ln_nt_store4(v[c], x_out + orow * D + 4 * (lane + 64 * c));
   // norm2
   ln_row_store<F32>(v, nchunks, lane, D, eps, gamma, beta,
                     F32 ? (void*)(reinterpret_cast<float*>(y) + orow * D) : (void*)(reinterpret_cast<uint16_t*>(y) + orow * D));
