@@ -284,23 +284,48 @@ __global__ __launch_bounds__(256, 1) void attention_long_kernel(const uint16_t* 
   const int ldq = 3 * H * 64;
   const uint16_t* base = qkv + (size_t)b * N * ldq;
   const int qcol = h * 64, kcol = H * 64 + h * 64, vcol = 2 * H * 64 + h * 64;
-  for (int g = tid; g < NKB * 32 * 8; g += 256) {
-    const int key = g >> 3, c = g & 7;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (key < N) v = *reinterpret_cast<const uint4*>(base + (size_t)key * ldq + kcol + c * 8);
-    *reinterpret_cast<uint4*>(sK + kswz(key, c)) = v;
-  }
-  for (int u = wave; u < NKB * 4; u += 4) {
-    const int kb = u >> 2, c = 2 * (u & 3) + (lane >> 5);
-    const int kl = lane & 31, key = kb * 32 + kl;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (key < N) v = *reinterpret_cast<const uint4*>(base + (size_t)key * ldq + vcol + c * 8);
-    unsigned short* dst = reinterpret_cast<unsigned short*>(sVt + (size_t)(8 * c) * RS + (kb * 32 + swap23(kl)) * 2);
-    const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+  // NKB is a run-time value here: the staging loops go in groups of EIGHT 16-byte loads per thread, all issued before the
+  // first LDS write of the group (as rolled load-wait-write loops they were 2 * NKB dependent global round trips, 38 at N = 577)
+  for (int it0 = 0; it0 < NKB; it0 += 8) {
+    uint4 kreg[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const unsigned int word = w[e >> 1];
-      dst[(e * RS) >> 1] = (unsigned short)((e & 1) ? (word >> 16) : (word & 0xffffu));
+    for (int u = 0; u < 8; ++u) {
+      const int g = tid + 256 * (it0 + u);
+      const int key = g >> 3, c = g & 7;
+      kreg[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (it0 + u < NKB && key < N) kreg[u] = *reinterpret_cast<const uint4*>(base + (size_t)key * ldq + kcol + c * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int g = tid + 256 * (it0 + u);
+      if (it0 + u < NKB) *reinterpret_cast<uint4*>(sK + kswz(g >> 3, g & 7)) = kreg[u];
+    }
+  }
+  // V transposed: lanes 0-31 take the 32 keys of a block for d-chunk c, lanes 32-63 chunk c+1
+  for (int it0 = 0; it0 < NKB; it0 += 8) {
+    uint4 vreg[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int un = wave + 4 * (it0 + u);
+      const int kb = un >> 2, c = 2 * (un & 3) + (lane >> 5);
+      const int key = kb * 32 + (lane & 31);
+      vreg[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (it0 + u < NKB && key < N) vreg[u] = *reinterpret_cast<const uint4*>(base + (size_t)key * ldq + vcol + c * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (it0 + u < NKB) {
+        const int un = wave + 4 * (it0 + u);
+        const int kb = un >> 2, c = 2 * (un & 3) + (lane >> 5);
+        const int kl = lane & 31;
+        unsigned short* dst = reinterpret_cast<unsigned short*>(sVt + (size_t)(8 * c) * RS + (kb * 32 + swap23(kl)) * 2);
+        const unsigned int w[4] = {vreg[u].x, vreg[u].y, vreg[u].z, vreg[u].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const unsigned int word = w[e >> 1];
+          dst[(e * RS) >> 1] = (unsigned short)((e & 1) ? (word >> 16) : (word & 0xffffu));
+        }
+      }
     }
   }
   for (int key = tid; key < NKB * 32; key += 256)
