@@ -603,14 +603,17 @@ def test_kmedoids(ops, fast, B, N, D, H, K, iters):
 # ---------------------------------------------------------------------------------------- long sequences (384^2 inputs)
 @pytest.mark.parametrize("B,N,H", [(2, 577, 12), (1, 577, 3), (2, 225, 2), (1, 300, 1), (1, 608, 2)])
 def test_attention_long(ops, B, N, H):
-    """N > 224: chunked two-pass kernel.  Same contract as test_attention + CLS row, key bias/mask and column sums."""
+    """N > 224: chunked two-pass kernel (with column sums) and online-softmax kernel (without).  Same contract as
+    test_attention + CLS row, key bias/mask and column sums."""
     rng = _rng(5000 + N + H)
     qkv = _bf(_randn(rng, B * N, 3 * H * 64, scale=1.5))
     size = torch.from_numpy(rng.integers(1, 5, size=(B, N)).astype(np.float32))
     size[:, N - 7:] = 0                                                          # masked keys (ATS) through the same input
     size[:, 0] = 1
     q, k, v = qkv.double().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
-    for sz in (None, size):
+    size_tail = size.clone()
+    size_tail[:, N // 2:] = 0                                                    # whole trailing key chunks masked (ATS padding)
+    for sz in (None, size, size_tail):
         logits = (q @ k.transpose(-2, -1)) * 0.125
         if sz is not None:
             logits = logits + sz.double().log()[:, None, None, :]
@@ -621,8 +624,14 @@ def test_attention_long(ops, B, N, H):
         torch.testing.assert_close(got.float().cpu(), want, atol=3e-2, rtol=2e-2)
         torch.testing.assert_close(cls.cpu(), attn[:, :, 0, :].float(), atol=2e-6, rtol=2e-3)
         torch.testing.assert_close(part.sum(dim=(1, 2)).cpu(), attn.sum(dim=1).sum(dim=1).float(), atol=5e-4, rtol=2e-3)
-        got2, _ = ops.attention(qkv.bfloat16().cuda(), B, N, H, size=None if sz is None else sz.cuda())
-        assert torch.equal(got2, got)                                            # side outputs do not change the main one
+        # without column sums the online-softmax kernel runs (key chunks of 128): same contract, its own rounding points
+        got2, cls2 = ops.attention(qkv.bfloat16().cuda(), B, N, H, want_cls=True, size=None if sz is None else sz.cuda())
+        torch.testing.assert_close(got2.float().cpu(), want, atol=3e-2, rtol=2e-2)
+        torch.testing.assert_close(cls2.cpu(), attn[:, :, 0, :].float(), atol=2e-6, rtol=2e-3)
+        got3, _ = ops.attention(qkv.bfloat16().cuda(), B, N, H, size=None if sz is None else sz.cuda())
+        assert torch.equal(got3, got2)                                           # the CLS side output does not change the main one
+        rel = ((got2.float() - got.float()).norm() / got.float().norm()).item()
+        assert rel < 4e-3, rel                                                   # two kernels, both within bf16 rounding of fp64
 
 
 @pytest.mark.parametrize("softmax", [True, False])
@@ -719,3 +728,18 @@ def test_tome_match_parity_sweep(ops):
             np.testing.assert_array_equal(unm.cpu().numpy(), unm_w.numpy())
             np.testing.assert_array_equal(src.cpu().numpy(), src_w.numpy())
             np.testing.assert_array_equal(dst.cpu().numpy(), dst_w.numpy())
+
+
+@pytest.mark.parametrize("B,N,H", [(1, 785, 2), (2, 1025, 1)])
+def test_attention_beyond_the_lds_limit(ops, B, N, H):
+    """Without column sums the online-softmax kernel has no sequence-length limit (448^2 and 512^2 inputs)."""
+    rng = _rng(5100 + N)
+    qkv = _bf(_randn(rng, B * N, 3 * H * 64, scale=1.5))
+    q, k, v = qkv.double().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    attn = ((q @ k.transpose(-2, -1)) * 0.125).softmax(-1)
+    want = (attn @ v).transpose(1, 2).reshape(B * N, H * 64).float()
+    got, cls = ops.attention(qkv.bfloat16().cuda(), B, N, H, want_cls=True)
+    torch.testing.assert_close(got.float().cpu(), want, atol=3e-2, rtol=2e-2)
+    torch.testing.assert_close(cls.cpu(), attn[:, :, 0, :].float(), atol=2e-6, rtol=2e-3)
+    with pytest.raises(Exception):
+        ops.attention(qkv.bfloat16().cuda(), B, N, H, colsum_part=torch.zeros(B, H, 4, N, device="cuda"))

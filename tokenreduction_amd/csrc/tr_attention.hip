@@ -1,4 +1,5 @@
-// Multi-head self-attention for ViT sequences (N <= 224 tokens register-resident, N <= 608 chunked; head_dim 64) on gfx950 MFMA.
+// Multi-head self-attention for ViT sequences (head_dim 64) on gfx950 MFMA: N <= 224 tokens register-resident; longer ones by an
+// online-softmax kernel over 128-key chunks (any N), or -- when column sums are wanted -- a two-pass kernel (N <= 608).
 //
 // Replaces  attn = softmax(q k^T * dh^-0.5); x = attn @ v   (topk.py:44-51 == evit.py:66-73 == deit_viz.py:43-51)
 // and emits the CLS query's softmax row per head (attn[:, :, 0, :], topk.py:59) as a side output, so the
@@ -17,6 +18,7 @@
 // Arithmetic: bf16 operands, fp32 accumulate/softmax; P is rounded to bf16 for P.V, the normaliser is the
 // fp32 sum of the un-rounded exponentials (same rounding points as oracle precision="bf16").
 #include "tr_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -457,6 +459,185 @@ __global__ __launch_bounds__(256, 1) void attention_long_kernel(const uint16_t* 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Long sequences (224 < N, the 384^2 inputs: N = 577) without column sums: keys go through the LDS in chunks of 128 with an
+// online softmax, one workgroup per (image, head, group of four 32-query blocks).  The register-resident formulation above
+// would need K and V^T of all 608 keys in LDS (152 KiB: one workgroup = one wave per SIMD per CU) and scores the keys twice;
+// here a workgroup holds 34 KiB, so three of them share a CU and overlap each other's staging.
+//   running maximum: kept as an INTEGER in the log2 domain (ceil of the largest logit seen), so the factor between two chunks'
+//   reference points is an exact power of two: rescaling O and l is exact in fp32, and the bf16 rounding of P commutes with it
+//   -- the result equals the two-pass formulation with the global ceil(max) as its reference point.
+//   The CLS row (query 0) is written as raw log2-domain logits chunk by chunk and normalised by the same two lanes at the end.
+constexpr int FKB = 4;                       // 32-key blocks per chunk
+constexpr int FRS = FKB * 64 + 16;           // V^T row stride in bytes
+#ifndef TR_FLASH_WGS
+#define TR_FLASH_WGS 3
+#endif
+__global__ __launch_bounds__(256, TR_FLASH_WGS) void attention_flash_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
+                                                                 float* __restrict__ cls_rows, const float* __restrict__ size, int N,
+                                                                 int H, int nqg) {
+  __shared__ __attribute__((aligned(16))) unsigned char sK[FKB * 32 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char sVt[64 * FRS];
+  __shared__ float sLB[FKB * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.x / nqg, qg = blockIdx.x - bh * nqg;
+  const int b = bh / H, h = bh - b * H;
+  const int ldq = 3 * H * 64;
+  const uint16_t* base = qkv + (size_t)b * N * ldq;
+  const int qcol = h * 64, kcol = H * 64 + h * 64, vcol = 2 * H * 64 + h * 64;
+  const int ql = lane & 31, hh = lane >> 5;
+  const int nqb = (N + 31) >> 5;
+  const int qb = qg * 4 + wave;                      // this wave's query block (may lie past the end: it still helps staging)
+  const int q = qb * 32 + ql;
+  const bool live = qb < nqb;
+  const float c_exp = 0.125f * 1.44269504088896340736f;
+
+  bf16x8 qf[4];
+  {
+    const uint16_t* qrow = base + (size_t)min(q, N - 1) * ldq + qcol + 8 * hh;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qrow + 16 * s);
+  }
+  f32x16 o[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+  float m = -INFINITY, l = 0.f;                      // m: integer-valued reference point; l: this lane's share of the row sum
+  float* crow = (cls_rows != nullptr && qb == 0 && ql == 0) ? cls_rows + ((size_t)b * H + h) * N : nullptr;
+
+  const int nch = (N + FKB * 32 - 1) / (FKB * 32);
+  for (int ch = 0; ch < nch; ++ch) {
+    const int key0 = ch * FKB * 32;
+    __syncthreads();                                 // the previous chunk's fragment reads are done
+    {
+      // stage the chunk: 4 K loads and 4 V loads per thread, all issued before the first LDS write
+      uint4 kreg[FKB], vreg[FKB];
+#pragma unroll
+      for (int it = 0; it < FKB; ++it) {
+        const int g = tid + 256 * it;
+        const int key = key0 + (g >> 3), c = g & 7;
+        kreg[it] = make_uint4(0u, 0u, 0u, 0u);
+        if (key < N) kreg[it] = *reinterpret_cast<const uint4*>(base + (size_t)key * ldq + kcol + c * 8);
+      }
+#pragma unroll
+      for (int it = 0; it < FKB; ++it) {
+        const int u = wave + 4 * it;
+        const int kb = u >> 2, c = 2 * (u & 3) + (lane >> 5);
+        const int key = key0 + kb * 32 + (lane & 31);
+        vreg[it] = make_uint4(0u, 0u, 0u, 0u);
+        if (key < N) vreg[it] = *reinterpret_cast<const uint4*>(base + (size_t)key * ldq + vcol + c * 8);
+      }
+      if (tid < FKB * 32) {
+        const int key = key0 + tid;
+        sLB[tid] = (size != nullptr && key < N) ? __builtin_amdgcn_logf(size[(size_t)b * N + key]) : 0.f;
+      }
+#pragma unroll
+      for (int it = 0; it < FKB; ++it) {
+        const int g = tid + 256 * it;
+        *reinterpret_cast<uint4*>(sK + kswz(g >> 3, g & 7)) = kreg[it];
+      }
+#pragma unroll
+      for (int it = 0; it < FKB; ++it) {
+        const int u = wave + 4 * it;
+        const int kb = u >> 2, c = 2 * (u & 3) + (lane >> 5);
+        unsigned short* dst = reinterpret_cast<unsigned short*>(sVt + (8 * c) * FRS + (kb * 32 + swap23(lane & 31)) * 2);
+        const unsigned int w[4] = {vreg[it].x, vreg[it].y, vreg[it].z, vreg[it].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const unsigned int word = w[e >> 1];
+          dst[(e * FRS) >> 1] = (unsigned short)((e & 1) ? (word >> 16) : (word & 0xffffu));
+        }
+      }
+    }
+    __syncthreads();
+    if (!live) continue;
+
+    f32x16 sacc[FKB];
+#pragma unroll
+    for (int kb = 0; kb < FKB; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + kswz(kb * 32 + ql, 2 * s + hh));
+        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kb], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < FKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        sacc[kb][r] = sacc[kb][r] * c_exp + sLB[kl];          // log2-domain logit (+ log2 size[key]: proportional attention)
+        if (key0 + kl >= N) sacc[kb][r] = -INFINITY;
+        mx = fmaxf(mx, sacc[kb][r]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (crow != nullptr) {
+#pragma unroll
+      for (int kb = 0; kb < FKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (key < N) crow[key] = sacc[kb][r];
+        }
+    }
+    // a chunk (or, with key masks, a prefix of chunks) may be masked entirely: the reference point stays at -inf until
+    // the first valid key, and a -inf reference is replaced by 0 in the exponents (all of them are exp2(-inf) = 0 then)
+    const float m_new = fmaxf(m, ceilf(mx));
+    const float alpha = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m - m_new);   // exact power of two
+    m = m_new;
+    const float m_ref = (m_new == -INFINITY) ? 0.f : m_new;
+    float lsum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < FKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(sacc[kb][r] - m_ref);
+        sacc[kb][r] = pv;
+        lsum += pv;
+      }
+    l = l * alpha + lsum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+#pragma unroll
+    for (int kb = 0; kb < FKB; ++kb)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (__bf16)sacc[kb][8 * s + j];
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sVt + (db * 32 + ql) * FRS + (kb * 32 + 16 * s + 8 * hh) * 2);
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[db], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+  }
+  if (!live) return;
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+  if (q < N) {
+    uint16_t* orow = out + ((size_t)b * N + q) * (H * 64) + h * 64 + 4 * hh;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        uint2 pk;
+        pk.x = pack_bf16x2(o[db][4 * g] * inv, o[db][4 * g + 1] * inv);
+        pk.y = pack_bf16x2(o[db][4 * g + 2] * inv, o[db][4 * g + 3] * inv);
+        *reinterpret_cast<uint2*>(orow + db * 32 + 8 * g) = pk;
+      }
+  }
+  if (crow != nullptr) {
+    // the two lanes that own query 0 wrote its logits (keys with ((key >> 2) & 1) == hh): same thread, same addresses
+    for (int key = 0; key < N; ++key)
+      if (((key >> 2) & 1) == hh) crow[key] = __builtin_amdgcn_exp2f(crow[key] - m) * inv;
+  }
+}
+
 template <int NKB>
 int launch_attention(const uint16_t* qkv, uint16_t* out, float* cls_rows, const float* size, float* colsum_part, int B, int N, int H,
                      hipStream_t st, bool policy = false) {
@@ -475,9 +656,20 @@ extern "C" int tr_attention_bf16(const uint16_t* qkv, uint16_t* out, float* cls_
                                  int N, int H, tr_stream_t s) {
   TR_REQUIRE(qkv && out, TR_ERR_NULL, "tr_attention_bf16: null pointer");
   TR_REQUIRE(B > 0 && H > 0 && N >= 1, TR_ERR_SHAPE, "tr_attention_bf16: bad shape B=%d N=%d H=%d", B, N, H);
-  TR_REQUIRE(N <= 608, TR_ERR_SHAPE, "tr_attention_bf16: N=%d > 608 not supported (K and V^T of one head must fit the LDS)", N);
+  TR_REQUIRE(N <= 608 || colsum_part == nullptr, TR_ERR_SHAPE,
+             "tr_attention_bf16: column sums need N <= 608 (N=%d: K and V^T of one head must fit the LDS)", N);
   TR_REQUIRE(tr_aligned16(qkv) && tr_aligned16(out), TR_ERR_ALIGN, "tr_attention_bf16: pointers must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(s);
+  static const int flash_min = [] {            // development switch: smallest N that takes the online-softmax kernel
+    const char* e = getenv("TR_ATT_FLASH_MIN");
+    return e ? atoi(e) : 225;
+  }();
+  if (N >= flash_min && colsum_part == nullptr) {
+    const int nqg = ((N + 31) / 32 + 3) / 4;
+    hipLaunchKernelGGL(attention_flash_kernel, dim3(B * H * nqg), dim3(256), 0, st, qkv, out, cls_rows, size, N, H, nqg);
+    TR_CHECK_LAUNCH("tr_attention_bf16");
+    return TR_OK;
+  }
   if (N > 224) {
     const int nkb = (N + 31) / 32;
     const size_t lds = (size_t)nkb * 32 * 128 + (size_t)64 * (nkb * 64 + 16) + (size_t)nkb * 32 * 4;

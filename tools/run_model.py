@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Run a few forwards of one registered model (for rocprofv3):  python3 tools/run_model.py tome_small_patch16_224 r16 [batch] [iters]
+"""Run a few forwards of one registered model (for rocprofv3):  python3 tools/run_model.py tome_small_patch16_224 r16 [batch] [iters] [img_size]
 keep spec: 'r16' (ToMe: 16 merged per block, every block) or a float keep_rate with reduction_loc 3,6,9."""
 import os
 import sys
@@ -12,13 +12,14 @@ from bench import build_model  # noqa: E402
 name, spec = sys.argv[1], sys.argv[2]
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+img = int(sys.argv[5]) if len(sys.argv) > 5 else 224
 if spec.startswith("r"):
     r = int(spec[1:])
     kr, loc = [196 - r * (i + 1) for i in range(12)], list(range(12))
 else:
     kr, loc = [float(spec)], [3, 6, 9]
-m = build_model(name, kr, loc, "cuda")
-x = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(1)).cuda()
+m = build_model(name, kr, loc, "cuda", img_size=img)
+x = torch.randn(B, 3, img, img, generator=torch.Generator().manual_seed(1)).cuda()
 for _ in range(3):
     m(x)
 torch.cuda.synchronize()
