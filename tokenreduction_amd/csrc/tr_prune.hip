@@ -238,29 +238,49 @@ __global__ __launch_bounds__(256) void softmerge_mfma_kernel(const float* __rest
 #pragma unroll
   for (int i = 0; i < MK_MAX / 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int sp = tid >> 3, sd = (tid & 7) * 8;                     // src staging: token sp of the slab, 8 feature columns
-  for (int p0 = 0; p0 < P; p0 += 32) {
-    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  // Register-staged prefetch: the loads of slab p0+32 (2 float4 of src, up to 6 float4 of weights per thread) are issued before
+  // the MFMAs of slab p0.  (The weights used to be fetched in a rolled load-wait-split loop: up to six dependent global round
+  // trips per slab, ~35 per workgroup -- the "latency-bound 70 us" of round 1's first profile.)
+  constexpr int WIT = 32 * (MK_MAX / 4) / 256;                     // 6: float4 weight loads per thread and slab, at most
+  const int kq4 = Kp >> 2;                                         // float4 groups per token
+  float4 s0, s1, w4[WIT];
+  auto load_slab = [&](int p0) __attribute__((always_inline)) {
+    s0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    s1 = s0;
     if (p0 + sp < P && d0 + sd < D) {
       s0 = *reinterpret_cast<const float4*>(sb + (size_t)(p0 + sp) * D + d0 + sd);
       s1 = *reinterpret_cast<const float4*>(sb + (size_t)(p0 + sp) * D + d0 + sd + 4);
     }
+#pragma unroll
+    for (int it = 0; it < WIT; ++it) {
+      const int idx = tid + 256 * it;
+      const int p = idx / kq4, kq = (idx - p * kq4) * 4;
+      w4[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < 32 * kq4 && p0 + p < P && kq < ldl) w4[it] = *reinterpret_cast<const float4*>(wb + (size_t)(p0 + p) * ldl + kq);
+    }
+  };
+  load_slab(0);
+  for (int p0 = 0; p0 < P; p0 += 32) {
     __syncthreads();                                               // previous slab's fragment reads are done
     {
       const float f[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
       for (int e = 0; e < 8; ++e) split2(f[e], sSh[(sd + e) * MLD + sp], sSl[(sd + e) * MLD + sp]);
     }
-    for (int idx = tid; idx < 32 * (Kp >> 2); idx += 256) {        // weights: 4 consecutive centres of one token per thread
-      const int p = idx / (Kp >> 2), kq = (idx - p * (Kp >> 2)) * 4;
-      float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p0 + p < P && kq < ldl) w4 = *reinterpret_cast<const float4*>(wb + (size_t)(p0 + p) * ldl + kq);
-      const float f[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float v = (kq + e < K) ? f[e] : 0.f;
-        split2(v, sWh[(kq + e) * MLD + p], sWl[(kq + e) * MLD + p]);
+    for (int it = 0; it < WIT; ++it) {                             // weights: 4 consecutive centres of one token per thread
+      const int idx = tid + 256 * it;
+      if (idx < 32 * kq4) {
+        const int p = idx / kq4, kq = (idx - p * kq4) * 4;
+        const float f[4] = {w4[it].x, w4[it].y, w4[it].z, w4[it].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float v = (kq + e < K) ? f[e] : 0.f;
+          split2(v, sWh[(kq + e) * MLD + p], sWl[(kq + e) * MLD + p]);
+        }
       }
     }
+    if (p0 + 32 < P) load_slab(p0 + 32);
     __syncthreads();
     const bf16x8 sh = *reinterpret_cast<const bf16x8*>(sSh + (wave * 16 + frow) * MLD + fq * 8);
     const bf16x8 sl = *reinterpret_cast<const bf16x8*>(sSl + (wave * 16 + frow) * MLD + fq * 8);
@@ -299,6 +319,36 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const float* xr = x + (size_t)row * D;
+  if ((D & 3) == 0 && D <= 1024) {
+    // the row stays in registers: one 16-byte load per lane and chunk, one pass (the scalar version below read it twice, 4 B per lane)
+    const int nch = D >> 2;
+    float4 v[4];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (lane + 64 * c < nch) {
+        v[c] = *reinterpret_cast<const float4*>(xr + 4 * (lane + 64 * c));
+        ss = fmaf(v[c].x, v[c].x, ss); ss = fmaf(v[c].y, v[c].y, ss); ss = fmaf(v[c].z, v[c].z, ss); ss = fmaf(v[c].w, v[c].w, ss);
+      }
+    ss = wave_sum(ss);
+    const float nrm = fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (lane + 64 * c < nch) {
+        const size_t e = (size_t)row * D + 4 * (lane + 64 * c);
+        const float4 o = make_float4(v[c].x / nrm, v[c].y / nrm, v[c].z / nrm, v[c].w / nrm);
+        *reinterpret_cast<float4*>(xh + e) = o;
+        if (F32) {
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(xh_lp) + e) = o;
+        } else {
+          uint2 pk;
+          pk.x = pack_bf16x2(o.x, o.y);
+          pk.y = pack_bf16x2(o.z, o.w);
+          *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(xh_lp) + e) = pk;
+        }
+      }
+    return;
+  }
   float ss = 0.f;
   for (int d = lane; d < D; d += 64) ss = fmaf(xr[d], xr[d], ss);
   ss = wave_sum(ss);
