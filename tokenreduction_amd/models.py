@@ -83,6 +83,7 @@ class VisionTransformer(nn.Module):
     """DeiT trunk, no reduction (deit_viz.py:75-212); also the base class of the reduction models."""
 
     _family = _lib.TR_FAMILY_DEIT
+    _blocks_last = False
 
     def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
                  num_heads=12, mlp_ratio=4., qkv_bias=True, representation_size=None, distilled=False,
@@ -117,6 +118,11 @@ class VisionTransformer(nn.Module):
         self.norm = norm_layer(embed_dim)
         self.pre_logits = nn.Identity()
         self.head = nn.Linear(embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+        # registration order = parameter order = the positional keys of an optimizer state_dict.  The reference's topk / evit / tome /
+        # dyvit / kmedoids classes delete the base class's `blocks` and build their own AFTER norm and head exist (topk.py:150-158):
+        # their parameters run patch_embed, norm, head, blocks; the other families keep timm's order (deit_viz.py:113-119)
+        if self._blocks_last:
+            self._modules["blocks"] = self._modules.pop("blocks")
         self.viz_mode = getattr(args, 'viz_mode', False)
         self._keep = [0] * depth
         self.precision = "bf16"      # "bf16" = the product path; "fp32" = validation path (reference arithmetic on the GPU)
@@ -330,6 +336,7 @@ class VisionTransformer(nn.Module):
 
 class _TopKBase(VisionTransformer):
     """Shared ctor logic of topk.py:108-171 / evit.py:138-201."""
+    _blocks_last = True
 
     _features_every_block = False
 
@@ -402,6 +409,7 @@ class EfficientVisionTransformer(_TopKBase):
 
 class ToMeVisionTransformer(VisionTransformer):
     """models/tome.py:107-223: bipartite soft matching + size-weighted merge between attention and MLP, proportional attention."""
+    _blocks_last = True
     _family = _lib.TR_FAMILY_TOME
 
     _features_every_block = False
@@ -497,6 +505,7 @@ class PredictorLG(nn.Module):
 class DynamicVisionTransformer(VisionTransformer):
     """models/dyvit.py:122-263, eval path: per pruning block, PredictorLG scores the patch tokens, the best int(P0*ratio) are
     gathered (argsort order) BEFORE the block runs.  Training (gumbel + policy softmax, dyvit.py:221-229) is not built."""
+    _blocks_last = True
     _family = _lib.TR_FAMILY_DYVIT
 
     _features_every_block = False
@@ -825,6 +834,7 @@ class KMedoids(nn.Module):
 class KMedoidsVisionTransformer(VisionTransformer):
     """models/kmedoids.py:152-272: before each block in reduction_loc the patch tokens are clustered by weighted K-Medoids
     (weights = column sums of the previous block's attention) and replaced by the medoid tokens themselves."""
+    _blocks_last = True
     _family = _lib.TR_FAMILY_KMEDOIDS
 
     def __init__(self, *a, args=None, **kw):
