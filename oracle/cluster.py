@@ -63,6 +63,9 @@ def dpcknn_cluster(x: Tensor, cluster_num: int, noise: Tensor, k: int = 5, force
     """cluster_dpc_knn dpcknn.py:44-100 (token_mask=None).  Returns (idx_cluster [B,P], index_down [B,K], score [B,P])."""
     dist = dpcknn_distances(x)
     _, _, score = dpcknn_scores(dist, noise, k)
+    if isinstance(forced_centers, (tuple, list)):          # tests only: centres AND assignment map taken from the device
+        centers, idx_cluster = forced_centers
+        return idx_cluster, centers, score
     centers = torch.sort(score, dim=-1, descending=True, stable=True).indices[:, :cluster_num] if forced_centers is None \
         else forced_centers
     return dpcknn_assign(dist, centers), centers, score

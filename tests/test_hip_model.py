@@ -223,6 +223,16 @@ def _dpcknn_parity(name, case, g, model, params, cfg, x, logits, viz, info, nois
     for blk, n in zip(g["token_count_blocks"], g["token_counts"]):
         assert model._last_tokens[int(blk)] == int(n)
     lb, vb = oracle.forward(params, x, cfg, precision="bf16", return_viz=True, noise=noise)
+    if case["family"] == "dpcknn":
+        # the token -> centre assignment is a discrete decision too (a token between two centres flips with bf16-level changes of
+        # the residual stream): given the device's centres the oracle's own nearest-centre map must agree almost everywhere at the
+        # first stage (same input up to rounding), and the logits are compared with centres AND assignment forced
+        _, vc = oracle.forward(params, x, cfg, precision="bf16", return_viz=True, forced=forced, noise=noise)
+        first = min(forced)
+        agree = float((vc["Assignment_Maps"][first] == viz["Assignment_Maps"][first]).mean())
+        print(f"   first-stage assignment agreement with the oracle given the device's centres: {agree:.4f}")
+        assert agree > 0.97, agree
+        forced = {blk: (c, torch.from_numpy(viz["Assignment_Maps"][blk]).long()) for blk, c in forced.items()}
     lf = oracle.forward(params, x, cfg, precision="bf16", forced=forced, noise=noise)
     ref = torch.from_numpy(g["logits"])
     rel_bf = ((logits - lb).norm() / lb.norm()).item()
@@ -230,7 +240,7 @@ def _dpcknn_parity(name, case, g, model, params, cfg, x, logits, viz, info, nois
     rel_forced = ((logits - lf).norm() / lf.norm()).item()
     ov_bf = [_overlap(viz["Kept_Tokens"][b], vb["Kept_Tokens"][b]) for b in sorted(vb["Kept_Tokens"])]
     ov_ref = [_overlap(viz["Kept_Tokens"][int(k.split("_")[1])], g[k]) for k in kept_keys]
-    print(f"\n[{name}] relative L2 of logits: vs oracle_bf16 {rel_bf:.3e}, vs reference fp32 {rel_ref:.3e}, teacher-forced centres "
+    print(f"\n[{name}] relative L2 of logits: vs oracle_bf16 {rel_bf:.3e}, vs reference fp32 {rel_ref:.3e}, teacher-forced decisions "
           f"{rel_forced:.3e}; centre-set overlap vs oracle_bf16 {ov_bf} vs reference {ov_ref}")
     assert rel_forced < FORCED_TOL, rel_forced
     # free-running: informational (see the DyViT note above); against the fp32 reference the 9-token end of a keep_rate 0.25

@@ -42,14 +42,14 @@ __device__ __forceinline__ void colsum_step(float* v, int ql) {
 // weights K-Medoids needs from the previous block's attention (kmedoids.py:240) -- without materialising B*H*N*N.
 // POLICY: DyViT's training-time softmax_with_policy (dyvit.py:39-51): `size` then carries the keep policy [B,N] of 1/0 and
 //   attn = (exp(s - max) * pol + eps/N) / (sum_k exp(s - max) * pol + eps),  pol[q][k] = policy[k], 1 on the diagonal.
-template <int NKB, bool COLSUM, bool POLICY>
+template <int NKB, bool COLSUM, bool POLICY, bool BIAS>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
                                                            float* __restrict__ cls_rows, const float* __restrict__ size,
                                                            float* __restrict__ colsum_part, int N, int H) {
   constexpr int RS = NKB * 64 + 16;  // Vt row stride in bytes: odd multiple of 16 -> conflict-free b128 column reads
   __shared__ __attribute__((aligned(16))) unsigned char sK[NKB * 32 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char sVt[64 * RS];
-  __shared__ float sLB[NKB * 32];   // log2(size[key]): ToMe's proportional attention (tome.py:48-49), 0 without sizes
+  __shared__ __attribute__((aligned(16))) float sLB[NKB * 32];   // log2(size[key]): ToMe's proportional attention (tome.py:48-49), 0 without sizes
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
@@ -143,6 +143,77 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
     TR_STAMP();
     // ---- softmax over keys (rows of S^T): registers of this lane + the other half-wave
     float mx = -INFINITY;
+    float l = 0.f;
+    if (!POLICY && !BIAS) {
+      // no key bias (DeiT / Top-K / EViT / DyViT ...): the maximum is taken on the raw scores and the scale folded into the
+      // exponent's fma, exp2(s * c - max * c), on register PAIRS (v_pk_fma_f32, v_pk_add_f32): 3 VALU instructions per element
+      // instead of 5 (scale, max3, sub, exp, add -> max3, half a pk_fma, exp, half a pk_add).  The softmax is the longer half
+      // of a query block (stamps: 4.1 k of 8 k cycles), so this is what the kernel's time follows.
+      typedef __attribute__((ext_vector_type(2))) float f32x2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = (NKB - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (key >= N) sacc[NKB - 1][r] = -INFINITY;
+      }
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float nm = -mx * c_exp;
+      f32x2 l2 = {0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          f32x2 t = {sacc[kb][r], sacc[kb][r + 1]};
+          t = t * c_exp + nm;
+          f32x2 pp;
+          pp[0] = __builtin_amdgcn_exp2f(t[0]);
+          pp[1] = __builtin_amdgcn_exp2f(t[1]);
+          sacc[kb][r] = pp[0];
+          sacc[kb][r + 1] = pp[1];
+          l2 += pp;
+        }
+      l = l2[0] + l2[1];
+    } else if (!POLICY) {
+      // key bias log2(size[key]) (ToMe's proportional attention, ATS / heuristic masks as log2 0 = -inf): same packed arithmetic,
+      // the bias comes from LDS four keys at a time (registers 4g..4g+3 of a block hold keys 8g + 4hh + 0..3)
+      typedef __attribute__((ext_vector_type(2))) float f32x2;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 b4 = *reinterpret_cast<const float4*>(&sLB[kb * 32 + 8 * g + 4 * hh]);
+          f32x2 t0 = {sacc[kb][4 * g], sacc[kb][4 * g + 1]}, t1 = {sacc[kb][4 * g + 2], sacc[kb][4 * g + 3]};
+          t0 = t0 * c_exp + f32x2{b4.x, b4.y};
+          t1 = t1 * c_exp + f32x2{b4.z, b4.w};
+          float e[4] = {t0[0], t0[1], t1[0], t1[1]};
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (kb == NKB - 1 && kb * 32 + 8 * g + 4 * hh + u >= N) e[u] = -INFINITY;
+            sacc[kb][4 * g + u] = e[u];
+            mx = fmaxf(mx, e[u]);
+          }
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float nm = (mx == -INFINITY) ? 0.f : -mx;         // every key masked: all weights exp2(-inf) = 0, as before
+      f32x2 l2 = {0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          f32x2 t = {sacc[kb][r], sacc[kb][r + 1]};
+          t = t + nm;
+          f32x2 pp;
+          pp[0] = __builtin_amdgcn_exp2f(t[0]);
+          pp[1] = __builtin_amdgcn_exp2f(t[1]);
+          sacc[kb][r] = pp[0];
+          sacc[kb][r + 1] = pp[1];
+          l2 += pp;
+        }
+      l = l2[0] + l2[1];
+    } else {
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -154,7 +225,6 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
         mx = fmaxf(mx, sacc[kb][r]);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    float l = 0.f;
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -167,6 +237,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
         sacc[kb][r] = p;
         l += p;
       }
+    }
     l += __shfl_xor(l, 32, 64);
     const float inv = POLICY ? 1.0f / (l + 1e-6f) : 1.0f / l;
     if (POLICY) {                                                // (attn + eps/N) / (sum + eps); padded keys stay 0
@@ -641,12 +712,17 @@ __global__ __launch_bounds__(256, TR_FLASH_WGS) void attention_flash_kernel(cons
 template <int NKB>
 int launch_attention(const uint16_t* qkv, uint16_t* out, float* cls_rows, const float* size, float* colsum_part, int B, int N, int H,
                      hipStream_t st, bool policy = false) {
+  // BIAS: the keys carry log2(size) / a mask (ToMe, ATS, heuristic masks); without it the softmax takes its packed fast path
   if (policy)
-    hipLaunchKernelGGL((attention_kernel<NKB, false, true>), dim3(B * H), dim3(256), 0, st, qkv, out, cls_rows, size, colsum_part, N, H);
+    hipLaunchKernelGGL((attention_kernel<NKB, false, true, true>), dim3(B * H), dim3(256), 0, st, qkv, out, cls_rows, size, colsum_part, N, H);
+  else if (colsum_part && size)
+    hipLaunchKernelGGL((attention_kernel<NKB, true, false, true>), dim3(B * H), dim3(256), 0, st, qkv, out, cls_rows, size, colsum_part, N, H);
   else if (colsum_part)
-    hipLaunchKernelGGL((attention_kernel<NKB, true, false>), dim3(B * H), dim3(256), 0, st, qkv, out, cls_rows, size, colsum_part, N, H);
+    hipLaunchKernelGGL((attention_kernel<NKB, true, false, false>), dim3(B * H), dim3(256), 0, st, qkv, out, cls_rows, size, colsum_part, N, H);
+  else if (size)
+    hipLaunchKernelGGL((attention_kernel<NKB, false, false, true>), dim3(B * H), dim3(256), 0, st, qkv, out, cls_rows, size, colsum_part, N, H);
   else
-    hipLaunchKernelGGL((attention_kernel<NKB, false, false>), dim3(B * H), dim3(256), 0, st, qkv, out, cls_rows, size, colsum_part, N, H);
+    hipLaunchKernelGGL((attention_kernel<NKB, false, false, false>), dim3(B * H), dim3(256), 0, st, qkv, out, cls_rows, size, colsum_part, N, H);
   return 0;
 }
 
