@@ -74,8 +74,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
   for (int it = 0; it < NKB; ++it) {
     const int g = tid + 256 * it;                       // NKB * 32 * 8 chunks = NKB per thread
     const int key = g >> 3, c = g & 7;
-    kreg[it] = make_uint4(0u, 0u, 0u, 0u);
-    if (key < N) kreg[it] = *reinterpret_cast<const uint4*>(base + (size_t)key * ldq + kcol + c * 8);
+    // branch-free (clamped row, zeroed below): a predicated load puts an exec-mask branch and, with it, a wait between the loads
+    kreg[it] = *reinterpret_cast<const uint4*>(base + (size_t)min(key, N - 1) * ldq + kcol + c * 8);
   }
   // V: lanes 0-31 take the 32 keys of a block for d-chunk c, lanes 32-63 chunk c+1
 #pragma unroll
@@ -83,12 +83,12 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
     const int u = wave + 4 * it;                        // NKB * 4 (block, chunk-pair) units = NKB per wave
     const int kb = u >> 2, c = 2 * (u & 3) + (lane >> 5);
     const int key = kb * 32 + (lane & 31);
-    vreg[it] = make_uint4(0u, 0u, 0u, 0u);
-    if (key < N) vreg[it] = *reinterpret_cast<const uint4*>(base + (size_t)key * ldq + vcol + c * 8);
+    vreg[it] = *reinterpret_cast<const uint4*>(base + (size_t)min(key, N - 1) * ldq + vcol + c * 8);
   }
 #pragma unroll
   for (int it = 0; it < NKB; ++it) {
     const int g = tid + 256 * it;
+    if ((g >> 3) >= N) kreg[it] = make_uint4(0u, 0u, 0u, 0u);
     *reinterpret_cast<uint4*>(sK + kswz(g >> 3, g & 7)) = kreg[it];
   }
 #pragma unroll
@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
     const int u = wave + 4 * it;
     const int kb = u >> 2, c = 2 * (u & 3) + (lane >> 5);
     const int kl = lane & 31;
+    if (kb * 32 + kl >= N) vreg[it] = make_uint4(0u, 0u, 0u, 0u);
     unsigned short* dst = reinterpret_cast<unsigned short*>(sVt + (8 * c) * RS + (kb * 32 + swap23(kl)) * 2);
     const unsigned int w[4] = {vreg[it].x, vreg[it].y, vreg[it].z, vreg[it].w};
 #pragma unroll
@@ -586,16 +587,14 @@ __global__ __launch_bounds__(256, TR_FLASH_WGS) void attention_flash_kernel(cons
       for (int it = 0; it < FKB; ++it) {
         const int g = tid + 256 * it;
         const int key = key0 + (g >> 3), c = g & 7;
-        kreg[it] = make_uint4(0u, 0u, 0u, 0u);
-        if (key < N) kreg[it] = *reinterpret_cast<const uint4*>(base + (size_t)key * ldq + kcol + c * 8);
+        kreg[it] = *reinterpret_cast<const uint4*>(base + (size_t)min(key, N - 1) * ldq + kcol + c * 8);   // branch-free; zeroed below
       }
 #pragma unroll
       for (int it = 0; it < FKB; ++it) {
         const int u = wave + 4 * it;
         const int kb = u >> 2, c = 2 * (u & 3) + (lane >> 5);
         const int key = key0 + kb * 32 + (lane & 31);
-        vreg[it] = make_uint4(0u, 0u, 0u, 0u);
-        if (key < N) vreg[it] = *reinterpret_cast<const uint4*>(base + (size_t)key * ldq + vcol + c * 8);
+        vreg[it] = *reinterpret_cast<const uint4*>(base + (size_t)min(key, N - 1) * ldq + vcol + c * 8);
       }
       if (tid < FKB * 32) {
         const int key = key0 + tid;
@@ -604,12 +603,14 @@ __global__ __launch_bounds__(256, TR_FLASH_WGS) void attention_flash_kernel(cons
 #pragma unroll
       for (int it = 0; it < FKB; ++it) {
         const int g = tid + 256 * it;
+        if (key0 + (g >> 3) >= N) kreg[it] = make_uint4(0u, 0u, 0u, 0u);
         *reinterpret_cast<uint4*>(sK + kswz(g >> 3, g & 7)) = kreg[it];
       }
 #pragma unroll
       for (int it = 0; it < FKB; ++it) {
         const int u = wave + 4 * it;
         const int kb = u >> 2, c = 2 * (u & 3) + (lane >> 5);
+        if (key0 + kb * 32 + (lane & 31) >= N) vreg[it] = make_uint4(0u, 0u, 0u, 0u);
         unsigned short* dst = reinterpret_cast<unsigned short*>(sVt + (8 * c) * FRS + (kb * 32 + swap23(lane & 31)) * 2);
         const unsigned int w[4] = {vreg[it].x, vreg[it].y, vreg[it].z, vreg[it].w};
 #pragma unroll
