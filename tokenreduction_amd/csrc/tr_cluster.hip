@@ -328,40 +328,44 @@ __global__ __launch_bounds__(256) void cluster_merge_layernorm_kernel(const floa
   for (int c = 0; c < LN_MAX_CHUNKS; ++c) v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (r == 0) {
 #pragma unroll
-    for (int c = 0; c < LN_MAX_CHUNKS; ++c)
-      if (lane + 64 * c < nchunks) v[c] = *reinterpret_cast<const float4*>(xb + 4 * (lane + 64 * c));
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) v[c] = *reinterpret_cast<const float4*>(xb + 4 * min(lane + 64 * c, nchunks - 1));
   } else {
     const int cl = r - 1;
     const int32_t* ic = idx_cluster + (size_t)b * P;
     const float* wb = w ? w + (size_t)b * P : nullptr;
     // all_weight = sum of member weights in token order + 1e-6 (index_add_ then + 1e-6, dpcknn.py:123-126)
+    // lane l holds cluster id and weight of token p0 + l; members come out of a ballot in token order and their weights by
+    // v_readlane, so the only dependent memory accesses left are the member rows themselves (fetched branch-free, whole row at once)
     float aw = 0.f;
     for (int p0 = 0; p0 < P; p0 += 64) {
       const int p = p0 + lane;
-      const bool m = p < P && ic[p] == cl;
-      unsigned long long mask = __ballot(m);
+      const bool in = p < P;
+      const int cid = in ? ic[p] : -1;
+      const float wl = in ? (wb ? wb[p] : 1.0f) : 0.f;
+      unsigned long long mask = __ballot(cid == cl);
       while (mask) {
         const int q = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
-        aw += wb ? wb[p0 + q] : 1.0f;
+        aw += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wl), q));
       }
     }
     aw += 1e-6f;
     for (int p0 = 0; p0 < P; p0 += 64) {
       const int p = p0 + lane;
-      const bool m = p < P && ic[p] == cl;
-      unsigned long long mask = __ballot(m);
+      const bool in = p < P;
+      const int cid = in ? ic[p] : -1;
+      const float wl = in ? (wb ? wb[p] : 1.0f) : 0.f;
+      unsigned long long mask = __ballot(cid == cl);
       while (mask) {
         const int q = __ffsll((long long)mask) - 1;
         mask &= mask - 1;
-        const float nw = (wb ? wb[p0 + q] : 1.0f) / aw;                      // norm_weight = token_weight / all_weight[idx]
+        const float nw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wl), q)) / aw;   // norm_weight = token_weight / all_weight[idx]
         const float* xr = xb + (size_t)(1 + p0 + q) * D;
+        float4 a[LN_MAX_CHUNKS];
 #pragma unroll
-        for (int c = 0; c < LN_MAX_CHUNKS; ++c)
-          if (lane + 64 * c < nchunks) {
-            const float4 a = *reinterpret_cast<const float4*>(xr + 4 * (lane + 64 * c));
-            v[c].x += a.x * nw; v[c].y += a.y * nw; v[c].z += a.z * nw; v[c].w += a.w * nw;
-          }
+        for (int c = 0; c < LN_MAX_CHUNKS; ++c) a[c] = *reinterpret_cast<const float4*>(xr + 4 * min(lane + 64 * c, nchunks - 1));
+#pragma unroll
+        for (int c = 0; c < LN_MAX_CHUNKS; ++c) { v[c].x += a[c].x * nw; v[c].y += a[c].y * nw; v[c].z += a[c].z * nw; v[c].w += a[c].w * nw; }
       }
     }
   }

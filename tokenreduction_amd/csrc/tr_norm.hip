@@ -25,13 +25,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, l
   float4 v[LN_MAX_CHUNKS];
 #pragma unroll
   for (int c = 0; c < LN_MAX_CHUNKS; ++c)
-    if (lane + 64 * c < nchunks) v[c] = ln_nt_load4(xr + 4 * (lane + 64 * c));
+    v[c] = ln_nt_load4(xr + 4 * min(lane + 64 * c, nchunks - 1));     // branch-free: all loads of the row go out in one batch
   if (delta != nullptr) {
+    float4 d[LN_MAX_CHUNKS];
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) d[c] = load_delta4<F32>(delta, (size_t)row * ldd + 4 * min(lane + 64 * c, nchunks - 1));
 #pragma unroll
     for (int c = 0; c < LN_MAX_CHUNKS; ++c)
       if (lane + 64 * c < nchunks) {
-        const float4 d = load_delta4<F32>(delta, (size_t)row * ldd + 4 * (lane + 64 * c));
-        v[c].x += d.x; v[c].y += d.y; v[c].z += d.z; v[c].w += d.w;
+        v[c].x += d[c].x; v[c].y += d[c].y; v[c].z += d[c].z; v[c].w += d[c].w;
         ln_nt_store4(v[c], xr + 4 * (lane + 64 * c));
       }
   }
@@ -150,14 +152,14 @@ __global__ __launch_bounds__(256) void gather_layernorm_kernel(const float* __re
           w[u] = (j + u < cnt) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wl), jj)) : 0.f;
           const float* xr = xb + (size_t)(1 + t) * D;
 #pragma unroll
-          for (int c = 0; c < LN_MAX_CHUNKS; ++c)
-            if (lane + 64 * c < nchunks) {
-              a[u][c] = *reinterpret_cast<const float4*>(xr + 4 * (lane + 64 * c));
-              if (has_d) {
-                const float4 d = load_delta4<F32>(delta, dbase + (size_t)(1 + t) * D + 4 * (lane + 64 * c));
-                a[u][c].x += d.x; a[u][c].y += d.y; a[u][c].z += d.z; a[u][c].w += d.w;
-              }
+          for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+            const int ch = min(lane + 64 * c, nchunks - 1);                  // branch-free: the step's loads go out in one batch
+            a[u][c] = *reinterpret_cast<const float4*>(xr + 4 * ch);
+            if (has_d) {
+              const float4 d = load_delta4<F32>(delta, dbase + (size_t)(1 + t) * D + 4 * ch);
+              a[u][c].x += d.x; a[u][c].y += d.y; a[u][c].z += d.z; a[u][c].w += d.w;
             }
+          }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -188,14 +190,14 @@ __global__ __launch_bounds__(256) void gather_layernorm_kernel(const float* __re
     if (idx != nullptr && r > 0) src = 1 + idx[(size_t)b * K + (r - 1)];
     const float* xr = xb + (size_t)src * D;
 #pragma unroll
-    for (int c = 0; c < LN_MAX_CHUNKS; ++c)
-      if (lane + 64 * c < nchunks) {
-        v[c] = ln_nt_load4(xr + 4 * (lane + 64 * c));
-        if (has_d) {
-          const float4 d = load_delta4<F32>(delta, dbase + (size_t)src * D + 4 * (lane + 64 * c));
-          v[c].x += d.x; v[c].y += d.y; v[c].z += d.z; v[c].w += d.w;
-        }
-      }
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) v[c] = ln_nt_load4(xr + 4 * min(lane + 64 * c, nchunks - 1));   // branch-free: one batch
+    if (has_d) {
+      float4 d[LN_MAX_CHUNKS];
+#pragma unroll
+      for (int c = 0; c < LN_MAX_CHUNKS; ++c) d[c] = load_delta4<F32>(delta, dbase + (size_t)src * D + 4 * min(lane + 64 * c, nchunks - 1));
+#pragma unroll
+      for (int c = 0; c < LN_MAX_CHUNKS; ++c) { v[c].x += d[c].x; v[c].y += d[c].y; v[c].z += d[c].z; v[c].w += d[c].w; }
+    }
   }
   const size_t orow = (size_t)b * N_out + r;
   if (x_out != nullptr) {

@@ -13,6 +13,15 @@ template <bool F32>
 __device__ __forceinline__ void ln_row_store(float4 (&v)[LN_MAX_CHUNKS], int nchunks, int lane, int D, float eps,
                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                              void* __restrict__ yrow_) {
+  // gamma / beta do not depend on the statistics: fetched first, branch-free (chunk index clamped), so they are in flight during
+  // the two reductions instead of costing one dependent round trip per chunk in the output loop
+  float4 gm[LN_MAX_CHUNKS], bt[LN_MAX_CHUNKS];
+#pragma unroll
+  for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+    const int ch = min(lane + 64 * c, nchunks - 1);
+    gm[c] = *reinterpret_cast<const float4*>(gamma + 4 * ch);
+    bt[c] = *reinterpret_cast<const float4*>(beta + 4 * ch);
+  }
   float s = 0.f;
 #pragma unroll
   for (int c = 0; c < LN_MAX_CHUNKS; ++c)
@@ -30,8 +39,7 @@ __device__ __forceinline__ void ln_row_store(float4 (&v)[LN_MAX_CHUNKS], int nch
   for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
     const int ch = lane + 64 * c;
     if (ch < nchunks) {
-      const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * ch);
-      const float4 b = *reinterpret_cast<const float4*>(beta + 4 * ch);
+      const float4 g = gm[c], b = bt[c];
       const float o0 = (v[c].x - mean) * rstd * g.x + b.x, o1 = (v[c].y - mean) * rstd * g.y + b.y;
       const float o2 = (v[c].z - mean) * rstd * g.z + b.z, o3 = (v[c].w - mean) * rstd * g.w + b.w;
       if (F32) {

@@ -210,17 +210,22 @@ __global__ __launch_bounds__(256) void tome_merge_layernorm_kernel(const float* 
   // (x + pending residual) * size of one input token, accumulated into v
   auto add_token = [&](int t, bool first) __attribute__((always_inline)) {
     const float s = sb ? sb[t] : 1.0f;
+    // branch-free loads (chunk index clamped; lanes past the row hold a harmless copy of its last chunk, never stored or summed)
+    float4 a[LN_MAX_CHUNKS];
 #pragma unroll
-    for (int c = 0; c < LN_MAX_CHUNKS; ++c)
-      if (lane + 64 * c < nchunks) {
-        float4 a = ln_nt_load4(xb + (size_t)t * D + 4 * (lane + 64 * c));
-        if (delta) {
-          const float4 d = load_delta4<F32>(delta, dbase + (size_t)t * D + 4 * (lane + 64 * c));
-          a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
-        }
-        if (first) v[c] = make_float4(a.x * s, a.y * s, a.z * s, a.w * s);
-        else { v[c].x += a.x * s; v[c].y += a.y * s; v[c].z += a.z * s; v[c].w += a.w * s; }
-      }
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) a[c] = ln_nt_load4(xb + (size_t)t * D + 4 * min(lane + 64 * c, nchunks - 1));
+    if (delta) {
+      float4 d[LN_MAX_CHUNKS];
+#pragma unroll
+      for (int c = 0; c < LN_MAX_CHUNKS; ++c) d[c] = load_delta4<F32>(delta, dbase + (size_t)t * D + 4 * min(lane + 64 * c, nchunks - 1));
+#pragma unroll
+      for (int c = 0; c < LN_MAX_CHUNKS; ++c) { a[c].x += d[c].x; a[c].y += d[c].y; a[c].z += d[c].z; a[c].w += d[c].w; }
+    }
+#pragma unroll
+    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+      if (first) v[c] = make_float4(a[c].x * s, a[c].y * s, a[c].z * s, a[c].w * s);
+      else { v[c].x += a[c].x * s; v[c].y += a[c].y * s; v[c].z += a[c].z * s; v[c].w += a[c].w * s; }
+    }
     if (first) sz = s; else sz += s;
   };
   if (p < n_unm) {
