@@ -28,7 +28,17 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x
   const int b = row / P, p = row - b * P;
   const float* xr = x + ((size_t)b * N + 1 + p) * D;
   float acc = 0.f;
-  for (int d = lane; d < D; d += 64) acc = fmaf(xr[d], xr[d], acc);
+  if ((D & 3) == 0 && D <= 1024) {                                       // 16-byte loads, the whole row in one batch
+    const int nch = D >> 2;
+    float4 v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const float4*>(xr + 4 * min(lane + 64 * c, nch - 1));
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (lane + 64 * c < nch) { acc = fmaf(v[c].x, v[c].x, acc); acc = fmaf(v[c].y, v[c].y, acc); acc = fmaf(v[c].z, v[c].z, acc); acc = fmaf(v[c].w, v[c].w, acc); }
+  } else {
+    for (int d = lane; d < D; d += 64) acc = fmaf(xr[d], xr[d], acc);
+  }
   acc = wave_sum(acc);
   if (lane == 0) nrm[row] = acc;
 }
@@ -221,10 +231,12 @@ __global__ __launch_bounds__(256) void density_kernel(const float* __restrict__ 
   float v[PER_LANE];
   float mx = 0.f;
 #pragma unroll
+  for (int c = 0; c < PER_LANE; ++c) v[c] = dr[min(c * 64 + lane, P - 1)];     // branch-free: the row's loads go out in one batch
+#pragma unroll
   for (int c = 0; c < PER_LANE; ++c) {
     const int j = c * 64 + lane;
-    v[c] = j < P ? dr[j] : INFINITY;
     if (j < P) mx = fmaxf(mx, v[c]);
+    else v[c] = INFINITY;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
@@ -247,6 +259,7 @@ __global__ __launch_bounds__(256) void density_kernel(const float* __restrict__ 
 
 // one wave per row: distance to the nearest token of higher density (else the image's max distance); score = that * density,
 // written in [B,N] layout (column 0 = CLS slot, unused) for tr_cls_topk
+template <int PER_LANE>
 __global__ __launch_bounds__(256) void parent_score_kernel(const float* __restrict__ dist, const float* __restrict__ density,
                                                            const float* __restrict__ rowmax, float* __restrict__ score_rows, int B,
                                                            int P) {
@@ -256,13 +269,24 @@ __global__ __launch_bounds__(256) void parent_score_kernel(const float* __restri
   const int b = row / P, i = row - b * P;
   const float* dr = dist + (size_t)row * P;
   const float* db = density + (size_t)b * P;
+  // all three row reads (row maxima, densities, distances) are issued branch-free before the first reduction
+  float rm[PER_LANE], dn[PER_LANE], dd[PER_LANE];
+#pragma unroll
+  for (int c = 0; c < PER_LANE; ++c) {
+    const int j = min(c * 64 + lane, P - 1);
+    rm[c] = rowmax[(size_t)b * P + j];
+    dn[c] = db[j];
+    dd[c] = dr[j];
+  }
+  const float di = db[i];
   float dmax = 0.f;                                                      // dist_matrix.flatten(1).max(): max of the row maxima
-  for (int j = lane; j < P; j += 64) dmax = fmaxf(dmax, rowmax[(size_t)b * P + j]);
+#pragma unroll
+  for (int c = 0; c < PER_LANE; ++c) dmax = fmaxf(dmax, rm[c]);             // clamped duplicates do not change a maximum
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o, 64));
-  const float di = db[i];
   float mn = INFINITY;
-  for (int j = lane; j < P; j += 64) mn = fminf(mn, db[j] > di ? dr[j] : dmax);
+#pragma unroll
+  for (int c = 0; c < PER_LANE; ++c) mn = fminf(mn, dn[c] > di ? dd[c] : dmax);   // nor a minimum
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o, 64));
   if (lane == 0) {
@@ -303,7 +327,21 @@ __global__ __launch_bounds__(256) void token_weight_kernel(const float* __restri
   const int b = row / P, p = row - b * P;
   const float* xr = x + ((size_t)b * N + 1 + p) * D;
   float acc = 0.f;
-  for (int d = lane; d < D; d += 64) acc = fmaf(xr[d], ws[d], acc);
+  if ((D & 3) == 0 && D <= 1024) {
+    const int nch = D >> 2;
+    float4 v[4], u[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int ch = min(lane + 64 * c, nch - 1);
+      v[c] = *reinterpret_cast<const float4*>(xr + 4 * ch);
+      u[c] = *reinterpret_cast<const float4*>(ws + 4 * ch);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (lane + 64 * c < nch) { acc = fmaf(v[c].x, u[c].x, acc); acc = fmaf(v[c].y, u[c].y, acc); acc = fmaf(v[c].z, u[c].z, acc); acc = fmaf(v[c].w, u[c].w, acc); }
+  } else {
+    for (int d = lane; d < D; d += 64) acc = fmaf(xr[d], ws[d], acc);
+  }
   acc = wave_sum(acc);
   if (lane == 0) w[row] = expf(acc + bs[0]);
 }
@@ -488,7 +526,8 @@ extern "C" int tr_dpcknn_cluster(const float* x, const float* noise, float* ws, 
   launch_dist(fast_dist != 0, x, nrm, dist, B, N, D, (float)sqrt((double)D), st);
   if (P <= 256) hipLaunchKernelGGL(density_kernel<4>, dim3(rb), dim3(256), 0, st, dist, noise, density, rowmax, B, P, k);
   else hipLaunchKernelGGL(density_kernel<16>, dim3(rb), dim3(256), 0, st, dist, noise, density, rowmax, B, P, k);
-  hipLaunchKernelGGL(parent_score_kernel, dim3(rb), dim3(256), 0, st, dist, density, rowmax, score_rows, B, P);
+  if (P <= 256) hipLaunchKernelGGL(parent_score_kernel<4>, dim3(rb), dim3(256), 0, st, dist, density, rowmax, score_rows, B, P);
+  else hipLaunchKernelGGL(parent_score_kernel<16>, dim3(rb), dim3(256), 0, st, dist, density, rowmax, score_rows, B, P);
   TR_CHECK_LAUNCH("tr_dpcknn_cluster");
   int rc = tr_cls_topk(score_rows, centers, nullptr, scores, B, 1, N, K, s);      // topk(score, K), sorted descending
   if (rc != TR_OK) return rc;
