@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256) void token_weight_kernel(const float* __restri
 
 
 // one wave per output row (row 0 = CLS copy, row 1+c = cluster c), fused with the following LayerNorm
-template <bool F32>
+template <bool F32, int NCH>
 __global__ __launch_bounds__(256) void cluster_merge_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                       const int32_t* __restrict__ idx_cluster,
                                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -361,12 +361,12 @@ __global__ __launch_bounds__(256) void cluster_merge_layernorm_kernel(const floa
   if (r > K) return;
   const int P = N - 1, nchunks = D >> 2;
   const float* xb = x + (size_t)b * N * D;
-  float4 v[LN_MAX_CHUNKS];
+  float4 v[NCH];
 #pragma unroll
-  for (int c = 0; c < LN_MAX_CHUNKS; ++c) v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c = 0; c < NCH; ++c) v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (r == 0) {
 #pragma unroll
-    for (int c = 0; c < LN_MAX_CHUNKS; ++c) v[c] = *reinterpret_cast<const float4*>(xb + 4 * min(lane + 64 * c, nchunks - 1));
+    for (int c = 0; c < NCH; ++c) v[c] = *reinterpret_cast<const float4*>(xb + 4 * min(lane + 64 * c, nchunks - 1));
   } else {
     const int cl = r - 1;
     const int32_t* ic = idx_cluster + (size_t)b * P;
@@ -399,19 +399,19 @@ __global__ __launch_bounds__(256) void cluster_merge_layernorm_kernel(const floa
         mask &= mask - 1;
         const float nw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wl), q)) / aw;   // norm_weight = token_weight / all_weight[idx]
         const float* xr = xb + (size_t)(1 + p0 + q) * D;
-        float4 a[LN_MAX_CHUNKS];
+        float4 a[NCH];
 #pragma unroll
-        for (int c = 0; c < LN_MAX_CHUNKS; ++c) a[c] = *reinterpret_cast<const float4*>(xr + 4 * min(lane + 64 * c, nchunks - 1));
+        for (int c = 0; c < NCH; ++c) a[c] = *reinterpret_cast<const float4*>(xr + 4 * min(lane + 64 * c, nchunks - 1));
 #pragma unroll
-        for (int c = 0; c < LN_MAX_CHUNKS; ++c) { v[c].x += a[c].x * nw; v[c].y += a[c].y * nw; v[c].z += a[c].z * nw; v[c].w += a[c].w * nw; }
+        for (int c = 0; c < NCH; ++c) { v[c].x += a[c].x * nw; v[c].y += a[c].y * nw; v[c].z += a[c].z * nw; v[c].w += a[c].w * nw; }
       }
     }
   }
   const size_t orow = (size_t)b * (K + 1) + r;
 #pragma unroll
-  for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+  for (int c = 0; c < NCH; ++c)
     if (lane + 64 * c < nchunks) *reinterpret_cast<float4*>(x_out + orow * D + 4 * (lane + 64 * c)) = v[c];
-  ln_row_store<F32>(v, nchunks, lane, D, eps, gamma, beta,
+  ln_row_store<F32, NCH>(v, nchunks, lane, D, eps, gamma, beta,
                     F32 ? (void*)(reinterpret_cast<float*>(y) + orow * D) : (void*)(reinterpret_cast<uint16_t*>(y) + orow * D));
 }
 
@@ -551,11 +551,11 @@ extern "C" int tr_cluster_merge_layernorm(const float* x, const float* score_w, 
   if (score_w) hipLaunchKernelGGL(token_weight_kernel, dim3((B * (N - 1) + 3) / 4), dim3(256), 0, st, x, score_w, score_b, w_ws, B, N, D);
   const int rblocks = (K + 1 + 3) / 4;
   if (y_is_f32)
-    hipLaunchKernelGGL(cluster_merge_layernorm_kernel<true>, dim3(B * rblocks), dim3(256), 0, st, x, score_w ? w_ws : nullptr,
-                       idx_cluster, gamma, beta, x_out, y, N, K, D, eps);
+    TR_DISPATCH_NCH(D, hipLaunchKernelGGL((cluster_merge_layernorm_kernel<true, NCH>), dim3(B * rblocks), dim3(256), 0, st, x,
+                                          score_w ? w_ws : nullptr, idx_cluster, gamma, beta, x_out, y, N, K, D, eps));
   else
-    hipLaunchKernelGGL(cluster_merge_layernorm_kernel<false>, dim3(B * rblocks), dim3(256), 0, st, x, score_w ? w_ws : nullptr,
-                       idx_cluster, gamma, beta, x_out, y, N, K, D, eps);
+    TR_DISPATCH_NCH(D, hipLaunchKernelGGL((cluster_merge_layernorm_kernel<false, NCH>), dim3(B * rblocks), dim3(256), 0, st, x,
+                                          score_w ? w_ws : nullptr, idx_cluster, gamma, beta, x_out, y, N, K, D, eps));
   TR_CHECK_LAUNCH("tr_cluster_merge_layernorm");
   return TR_OK;
 }

@@ -13,7 +13,7 @@ namespace {
 // x[row] (+= delta[row], written back) -> y[row] = LayerNorm(x[row]).  delta is the bf16 output of the preceding Linear
 // (attn.proj or mlp.fc2): the residual add `x = x + drop_path(...)` (topk.py:87 / :95) is folded into the norm that
 // reads x next, so the GEMMs never read-modify-write the fp32 stream.
-template <bool F32>
+template <bool F32, int NCH>
 __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, long ldx, const void* __restrict__ delta, long ldd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         void* __restrict__ y, int M, int D, float eps) {
@@ -22,22 +22,22 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, l
   if (row >= M) return;
   const int nchunks = D >> 2;
   float* xr = x + (size_t)row * ldx;
-  float4 v[LN_MAX_CHUNKS];
+  float4 v[NCH];
 #pragma unroll
-  for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+  for (int c = 0; c < NCH; ++c)
     v[c] = ln_nt_load4(xr + 4 * min(lane + 64 * c, nchunks - 1));     // branch-free: all loads of the row go out in one batch
   if (delta != nullptr) {
-    float4 d[LN_MAX_CHUNKS];
+    float4 d[NCH];
 #pragma unroll
-    for (int c = 0; c < LN_MAX_CHUNKS; ++c) d[c] = load_delta4<F32>(delta, (size_t)row * ldd + 4 * min(lane + 64 * c, nchunks - 1));
+    for (int c = 0; c < NCH; ++c) d[c] = load_delta4<F32>(delta, (size_t)row * ldd + 4 * min(lane + 64 * c, nchunks - 1));
 #pragma unroll
-    for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+    for (int c = 0; c < NCH; ++c)
       if (lane + 64 * c < nchunks) {
         v[c].x += d[c].x; v[c].y += d[c].y; v[c].z += d[c].z; v[c].w += d[c].w;
         ln_nt_store4(v[c], xr + 4 * (lane + 64 * c));
       }
   }
-  ln_row_store<F32>(v, nchunks, lane, D, eps, gamma, beta,
+  ln_row_store<F32, NCH>(v, nchunks, lane, D, eps, gamma, beta,
                     F32 ? (void*)(reinterpret_cast<float*>(y) + (size_t)row * D) : (void*)(reinterpret_cast<uint16_t*>(y) + (size_t)row * D));
 }
 
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void layernorm_half_kernel(float* __restrict__
 }
 
 // grid: B * (ceil(rows/4) [+ 1]) blocks; wave w of a gather block handles output row r = 4*blk + w of image b.
-template <bool F32>
+template <bool F32, int NCH>
 __global__ __launch_bounds__(256) void gather_layernorm_kernel(const float* __restrict__ x, const void* __restrict__ delta,
                                                                const int32_t* __restrict__ idx,
                                                                const int32_t* __restrict__ compl_idx,
@@ -120,12 +120,12 @@ __global__ __launch_bounds__(256) void gather_layernorm_kernel(const float* __re
   const float* xb = x + (size_t)b * N * D;
   const bool has_d = delta != nullptr;                 // pending residual (proj output), same row layout as x
   const size_t dbase = (size_t)b * N * D;
-  float4 v[LN_MAX_CHUNKS];
-  __shared__ float4 part[3][256];                      // partial sums of waves 1..3 of a fused block (D <= 1024)
+  float4 v[NCH];
+  __shared__ float4 part[3][64 * NCH];                 // partial sums of waves 1..3 of a fused block
   if (fused_block) {
     // EViT fused token: sum over the NOT-kept tokens, weighted by their (un-normalised) CLS attention
 #pragma unroll
-    for (int c = 0; c < LN_MAX_CHUNKS; ++c) v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < NCH; ++c) v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int32_t* cb = compl_idx + (size_t)b * (P - K);
     const float* sb = scores + (size_t)b * P;
     // The four waves take the complement tokens j = wave, wave+4, ...; lane l of a wave holds index and weight of its token
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void gather_layernorm_kernel(const float* __re
       }
       const int cnt = min(64, n_w - i0);
       for (int j = 0; j < cnt; j += 4) {
-        float4 a[4][LN_MAX_CHUNKS];
+        float4 a[4][NCH];
         float w[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void gather_layernorm_kernel(const float* __re
           w[u] = (j + u < cnt) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wl), jj)) : 0.f;
           const float* xr = xb + (size_t)(1 + t) * D;
 #pragma unroll
-          for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+          for (int c = 0; c < NCH; ++c) {
             const int ch = min(lane + 64 * c, nchunks - 1);                  // branch-free: the step's loads go out in one batch
             a[u][c] = *reinterpret_cast<const float4*>(xr + 4 * ch);
             if (has_d) {
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void gather_layernorm_kernel(const float* __re
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+          for (int c = 0; c < NCH; ++c)
             if (lane + 64 * c < nchunks) {
               v[c].x += a[u][c].x * w[u]; v[c].y += a[u][c].y * w[u]; v[c].z += a[u][c].z * w[u]; v[c].w += a[u][c].w * w[u];
             }
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void gather_layernorm_kernel(const float* __re
     }
     if (wave > 0) {
 #pragma unroll
-      for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+      for (int c = 0; c < NCH; ++c)
         if (lane + 64 * c < nchunks) part[wave - 1][lane + 64 * c] = v[c];
     }
     __syncthreads();
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void gather_layernorm_kernel(const float* __re
 #pragma unroll
     for (int p = 0; p < 3; ++p)
 #pragma unroll
-      for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+      for (int c = 0; c < NCH; ++c)
         if (lane + 64 * c < nchunks) {
           const float4 q = part[p][lane + 64 * c];
           v[c].x += q.x; v[c].y += q.y; v[c].z += q.z; v[c].w += q.w;
@@ -190,23 +190,23 @@ __global__ __launch_bounds__(256) void gather_layernorm_kernel(const float* __re
     if (idx != nullptr && r > 0) src = 1 + idx[(size_t)b * K + (r - 1)];
     const float* xr = xb + (size_t)src * D;
 #pragma unroll
-    for (int c = 0; c < LN_MAX_CHUNKS; ++c) v[c] = ln_nt_load4(xr + 4 * min(lane + 64 * c, nchunks - 1));   // branch-free: one batch
+    for (int c = 0; c < NCH; ++c) v[c] = ln_nt_load4(xr + 4 * min(lane + 64 * c, nchunks - 1));   // branch-free: one batch
     if (has_d) {
-      float4 d[LN_MAX_CHUNKS];
+      float4 d[NCH];
 #pragma unroll
-      for (int c = 0; c < LN_MAX_CHUNKS; ++c) d[c] = load_delta4<F32>(delta, dbase + (size_t)src * D + 4 * min(lane + 64 * c, nchunks - 1));
+      for (int c = 0; c < NCH; ++c) d[c] = load_delta4<F32>(delta, dbase + (size_t)src * D + 4 * min(lane + 64 * c, nchunks - 1));
 #pragma unroll
-      for (int c = 0; c < LN_MAX_CHUNKS; ++c) { v[c].x += d[c].x; v[c].y += d[c].y; v[c].z += d[c].z; v[c].w += d[c].w; }
+      for (int c = 0; c < NCH; ++c) { v[c].x += d[c].x; v[c].y += d[c].y; v[c].z += d[c].z; v[c].w += d[c].w; }
     }
   }
   const size_t orow = (size_t)b * N_out + r;
   if (x_out != nullptr) {
     float* xo = x_out + orow * D;
 #pragma unroll
-    for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+    for (int c = 0; c < NCH; ++c)
       if (lane + 64 * c < nchunks) ln_nt_store4(v[c], xo + 4 * (lane + 64 * c));
   }
-  ln_row_store<F32>(v, nchunks, lane, D, eps, gamma, beta,
+  ln_row_store<F32, NCH>(v, nchunks, lane, D, eps, gamma, beta,
                     F32 ? (void*)(reinterpret_cast<float*>(y) + orow * D) : (void*)(reinterpret_cast<uint16_t*>(y) + orow * D));
 }
 
@@ -270,8 +270,8 @@ static int layernorm_impl(bool f32, float* x, long ldx, const void* delta, long 
     return TR_OK;
   }
 #endif
-  if (f32) hipLaunchKernelGGL(layernorm_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, x, ldx, delta, ldd, gamma, beta, y, M, D, eps);
-  else hipLaunchKernelGGL(layernorm_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, x, ldx, delta, ldd, gamma, beta, y, M, D, eps);
+  if (f32) TR_DISPATCH_NCH(D, hipLaunchKernelGGL((layernorm_kernel<true, NCH>), dim3((M + 3) / 4), dim3(256), 0, st, x, ldx, delta, ldd, gamma, beta, y, M, D, eps));
+  else TR_DISPATCH_NCH(D, hipLaunchKernelGGL((layernorm_kernel<false, NCH>), dim3((M + 3) / 4), dim3(256), 0, st, x, ldx, delta, ldd, gamma, beta, y, M, D, eps));
   TR_CHECK_LAUNCH("tr_layernorm");
   return TR_OK;
 }
@@ -309,11 +309,11 @@ static int gather_layernorm_impl(bool f32, const float* x, const void* delta, co
   const int rblocks = compl_idx != nullptr ? (N_out - 1 + 3) / 4 + 1 : (N_out + 3) / 4;   // + one block per image for the fused token
   hipStream_t st = static_cast<hipStream_t>(s);
   if (f32)
-    hipLaunchKernelGGL(gather_layernorm_kernel<true>, dim3(B * rblocks), dim3(256), 0, st, x, delta, idx, compl_idx, scores, gamma,
-                       beta, x_out, y, N, K, N_out, D, eps);
+    TR_DISPATCH_NCH(D, hipLaunchKernelGGL((gather_layernorm_kernel<true, NCH>), dim3(B * rblocks), dim3(256), 0, st, x, delta, idx, compl_idx,
+                                          scores, gamma, beta, x_out, y, N, K, N_out, D, eps));
   else
-    hipLaunchKernelGGL(gather_layernorm_kernel<false>, dim3(B * rblocks), dim3(256), 0, st, x, delta, idx, compl_idx, scores, gamma,
-                       beta, x_out, y, N, K, N_out, D, eps);
+    TR_DISPATCH_NCH(D, hipLaunchKernelGGL((gather_layernorm_kernel<false, NCH>), dim3(B * rblocks), dim3(256), 0, st, x, delta, idx, compl_idx,
+                                          scores, gamma, beta, x_out, y, N, K, N_out, D, eps));
   TR_CHECK_LAUNCH("tr_gather_layernorm");
   return TR_OK;
 }

@@ -7,36 +7,48 @@
 namespace {
 
 constexpr int LN_MAX_CHUNKS = 4;  // float4 chunks per lane -> D <= 1024
+// launch KERNEL<..., NCH> with NCH = ceil(D / 256) in 1..4
+#define TR_DISPATCH_NCH(D_, ...)                        \
+  do {                                                  \
+    switch (((D_) + 255) / 256) {                       \
+      case 1: { constexpr int NCH = 1; __VA_ARGS__; } break; \
+      case 2: { constexpr int NCH = 2; __VA_ARGS__; } break; \
+      case 3: { constexpr int NCH = 3; __VA_ARGS__; } break; \
+      default: { constexpr int NCH = 4; __VA_ARGS__; } break; \
+    }                                                   \
+  } while (0)
 
 // Normalise one row held as `nch` float4 chunks per lane; two-pass (mean, then centred variance) in registers.
-template <bool F32>
-__device__ __forceinline__ void ln_row_store(float4 (&v)[LN_MAX_CHUNKS], int nchunks, int lane, int D, float eps,
+// NCH = 64-lane chunks the row actually spans (ceil(D / 256)): the callers instantiate per NCH so that no lane issues loads
+// for chunks the row does not have (the branch-free loads clamp the chunk index instead of predicating).
+template <bool F32, int NCH>
+__device__ __forceinline__ void ln_row_store(float4 (&v)[NCH], int nchunks, int lane, int D, float eps,
                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                              void* __restrict__ yrow_) {
   // gamma / beta do not depend on the statistics: fetched first, branch-free (chunk index clamped), so they are in flight during
   // the two reductions instead of costing one dependent round trip per chunk in the output loop
-  float4 gm[LN_MAX_CHUNKS], bt[LN_MAX_CHUNKS];
+  float4 gm[NCH], bt[NCH];
 #pragma unroll
-  for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+  for (int c = 0; c < NCH; ++c) {
     const int ch = min(lane + 64 * c, nchunks - 1);
     gm[c] = *reinterpret_cast<const float4*>(gamma + 4 * ch);
     bt[c] = *reinterpret_cast<const float4*>(beta + 4 * ch);
   }
   float s = 0.f;
 #pragma unroll
-  for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+  for (int c = 0; c < NCH; ++c)
     if (lane + 64 * c < nchunks) s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
   const float mean = wave_sum(s) / (float)D;
   float q = 0.f;
 #pragma unroll
-  for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+  for (int c = 0; c < NCH; ++c)
     if (lane + 64 * c < nchunks) {
       const float a = v[c].x - mean, b = v[c].y - mean, cc = v[c].z - mean, d = v[c].w - mean;
       q += (a * a + b * b) + (cc * cc + d * d);
     }
   const float rstd = F32 ? 1.0f / sqrtf(wave_sum(q) / (float)D + eps) : rsqrtf(wave_sum(q) / (float)D + eps);
 #pragma unroll
-  for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+  for (int c = 0; c < NCH; ++c) {
     const int ch = lane + 64 * c;
     if (ch < nchunks) {
       const float4 g = gm[c], b = bt[c];

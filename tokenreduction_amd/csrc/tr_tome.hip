@@ -187,7 +187,7 @@ __global__ __launch_bounds__(TMT) void tome_match_kernel(const void* __restrict_
 }
 
 // one wave per OUTPUT row: [unmerged even tokens | all odd tokens]
-template <bool F32>
+template <bool F32, int NCH>
 __global__ __launch_bounds__(256) void tome_merge_layernorm_kernel(const float* __restrict__ x, const void* __restrict__ delta,
                                                                    const float* __restrict__ size_in, const int32_t* __restrict__ unm_idx,
                                                                    const int32_t* __restrict__ src_idx, const int32_t* __restrict__ dst_idx,
@@ -205,24 +205,24 @@ __global__ __launch_bounds__(256) void tome_merge_layernorm_kernel(const float* 
   const float* xb = x + (size_t)b * N * D;
   const size_t dbase = (size_t)b * N * D;
   const float* sb = size_in ? size_in + (size_t)b * N : nullptr;
-  float4 v[LN_MAX_CHUNKS];
+  float4 v[NCH];
   float sz;
   // (x + pending residual) * size of one input token, accumulated into v
   auto add_token = [&](int t, bool first) __attribute__((always_inline)) {
     const float s = sb ? sb[t] : 1.0f;
     // branch-free loads (chunk index clamped; lanes past the row hold a harmless copy of its last chunk, never stored or summed)
-    float4 a[LN_MAX_CHUNKS];
+    float4 a[NCH];
 #pragma unroll
-    for (int c = 0; c < LN_MAX_CHUNKS; ++c) a[c] = ln_nt_load4(xb + (size_t)t * D + 4 * min(lane + 64 * c, nchunks - 1));
+    for (int c = 0; c < NCH; ++c) a[c] = ln_nt_load4(xb + (size_t)t * D + 4 * min(lane + 64 * c, nchunks - 1));
     if (delta) {
-      float4 d[LN_MAX_CHUNKS];
+      float4 d[NCH];
 #pragma unroll
-      for (int c = 0; c < LN_MAX_CHUNKS; ++c) d[c] = load_delta4<F32>(delta, dbase + (size_t)t * D + 4 * min(lane + 64 * c, nchunks - 1));
+      for (int c = 0; c < NCH; ++c) d[c] = load_delta4<F32>(delta, dbase + (size_t)t * D + 4 * min(lane + 64 * c, nchunks - 1));
 #pragma unroll
-      for (int c = 0; c < LN_MAX_CHUNKS; ++c) { a[c].x += d[c].x; a[c].y += d[c].y; a[c].z += d[c].z; a[c].w += d[c].w; }
+      for (int c = 0; c < NCH; ++c) { a[c].x += d[c].x; a[c].y += d[c].y; a[c].z += d[c].z; a[c].w += d[c].w; }
     }
 #pragma unroll
-    for (int c = 0; c < LN_MAX_CHUNKS; ++c) {
+    for (int c = 0; c < NCH; ++c) {
       if (first) v[c] = make_float4(a[c].x * s, a[c].y * s, a[c].z * s, a[c].w * s);
       else { v[c].x += a[c].x * s; v[c].y += a[c].y * s; v[c].z += a[c].z * s; v[c].w += a[c].w * s; }
     }
@@ -251,15 +251,15 @@ __global__ __launch_bounds__(256) void tome_merge_layernorm_kernel(const float* 
     }
   }
 #pragma unroll
-  for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+  for (int c = 0; c < NCH; ++c)
     if (lane + 64 * c < nchunks) { v[c].x /= sz; v[c].y /= sz; v[c].z /= sz; v[c].w /= sz; }
   const size_t orow = (size_t)b * N_out + p;
   if (lane == 0) size_out[orow] = sz;
 #pragma unroll
-  for (int c = 0; c < LN_MAX_CHUNKS; ++c)
+  for (int c = 0; c < NCH; ++c)
     if (lane + 64 * c < nchunks) ln_nt_store4(v[c], x_out + orow * D + 4 * (lane + 64 * c));
   // norm2
-  ln_row_store<F32>(v, nchunks, lane, D, eps, gamma, beta,
+  ln_row_store<F32, NCH>(v, nchunks, lane, D, eps, gamma, beta,
                     F32 ? (void*)(reinterpret_cast<float*>(y) + orow * D) : (void*)(reinterpret_cast<uint16_t*>(y) + orow * D));
 }
 
@@ -295,11 +295,11 @@ extern "C" int tr_tome_merge_layernorm(const float* x, const void* delta, int f3
   const int rblocks = (N_out + 3) / 4;
   hipStream_t st = static_cast<hipStream_t>(s);
   if (f32_path)
-    hipLaunchKernelGGL(tome_merge_layernorm_kernel<true>, dim3(B * rblocks), dim3(256), 0, st, x, delta, size_in, unm_idx, src_idx,
-                       dst_idx, gamma, beta, x_out, size_out, y, N, r, D, eps);
+    TR_DISPATCH_NCH(D, hipLaunchKernelGGL((tome_merge_layernorm_kernel<true, NCH>), dim3(B * rblocks), dim3(256), 0, st, x, delta, size_in,
+                                          unm_idx, src_idx, dst_idx, gamma, beta, x_out, size_out, y, N, r, D, eps));
   else
-    hipLaunchKernelGGL(tome_merge_layernorm_kernel<false>, dim3(B * rblocks), dim3(256), 0, st, x, delta, size_in, unm_idx, src_idx,
-                       dst_idx, gamma, beta, x_out, size_out, y, N, r, D, eps);
+    TR_DISPATCH_NCH(D, hipLaunchKernelGGL((tome_merge_layernorm_kernel<false, NCH>), dim3(B * rblocks), dim3(256), 0, st, x, delta, size_in,
+                                          unm_idx, src_idx, dst_idx, gamma, beta, x_out, size_out, y, N, r, D, eps));
   TR_CHECK_LAUNCH("tr_tome_merge_layernorm");
   return TR_OK;
 }
