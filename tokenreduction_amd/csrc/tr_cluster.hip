@@ -157,7 +157,7 @@ __global__ __launch_bounds__(512) void dist_mfma_kernel(const float* __restrict_
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const bool active = i0 + wm * 64 < P && j0 + wn * 64 < P;          // else this wave's 64x64 block lies outside the matrix
   for (int k0 = 0; k0 < D; k0 += GK) {
-    __syncthreads();                                                 // previous slab's fragment reads are done
+    lds_barrier();                                                   // previous slab's fragment reads are done (LDS only: the prefetch stays in flight)
 #pragma unroll
     for (int q = 0; q < 4; ++q) split_store(ra[q], sAh + lr * GLD + lc + 4 * q, sAl + lr * GLD + lc + 4 * q);
 #pragma unroll
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(512) void dist_mfma_kernel(const float* __restrict_
 #pragma unroll
       for (int q = 0; q < 2; ++q) rb[q] = *reinterpret_cast<const float4*>(bp + k0 + GK + 4 * q);
     }
-    __syncthreads();
+    lds_barrier();
     if (!active) continue;
     bf16x8 ah[4], al[4], bh[4], bl[4];
 #pragma unroll
@@ -191,17 +191,26 @@ __global__ __launch_bounds__(512) void dist_mfma_kernel(const float* __restrict_
   // acc[bb][a][e] = x_i . x_j with i = i0 + wm*64 + a*16 + frow, j = j0 + wn*64 + bb*16 + 4*fq + e
   const float* nb = nrm + (size_t)b * P;
   float* db = dist + (size_t)b * P * P;
+  // the 4 row norms and 16 column norms of this lane are fetched up front (clamped, branch-free) instead of one dependent load
+  // inside every output element
+  float ni4[4], nj[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) ni4[a] = nb[min(i0 + wm * 64 + a * 16 + frow, P - 1)];
+#pragma unroll
+  for (int bb = 0; bb < 4; ++bb)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) nj[bb][e] = nb[min(j0 + wn * 64 + bb * 16 + 4 * fq + e, P - 1)];
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const int gi = i0 + wm * 64 + a * 16 + frow;
     if (gi >= P) continue;
-    const float ni = nb[gi];
+    const float ni = ni4[a];
 #pragma unroll
     for (int bb = 0; bb < 4; ++bb)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int gj = j0 + wn * 64 + bb * 16 + 4 * fq + e;
-        if (gj < P) db[(size_t)gi * P + gj] = sqrtf(fmaxf((ni + nb[gj]) - 2.0f * acc[bb][a][e], 1e-30f)) / sqrt_d;
+        if (gj < P) db[(size_t)gi * P + gj] = sqrtf(fmaxf((ni + nj[bb][e]) - 2.0f * acc[bb][a][e], 1e-30f)) / sqrt_d;
       }
   }
 }

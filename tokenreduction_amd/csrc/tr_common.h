@@ -48,6 +48,15 @@ __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(unsigned int, v);
 }
 
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. it waits for every global load the
+// wave has in flight -- which turns a register-staged prefetch (loads of slab k+1 issued before the MFMAs of slab k) into a
+// load-wait-compute sequence.  Use between LDS producers and consumers when global loads should stay in flight across it.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void softmerge_mfma_kernel(const float* __rest
   };
   load_slab(0);
   for (int p0 = 0; p0 < P; p0 += 32) {
-    __syncthreads();                                               // previous slab's fragment reads are done
+    lds_barrier();                                                 // previous slab's fragment reads are done (LDS only)
     {
       const float f[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void softmerge_mfma_kernel(const float* __rest
       }
     }
     if (p0 + 32 < P) load_slab(p0 + 32);
-    __syncthreads();
+    lds_barrier();                                                 // the prefetch above stays in flight under the MFMAs
     const bf16x8 sh = *reinterpret_cast<const bf16x8*>(sSh + (wave * 16 + frow) * MLD + fq * 8);
     const bf16x8 sl = *reinterpret_cast<const bf16x8*>(sSl + (wave * 16 + frow) * MLD + fq * 8);
 #pragma unroll
