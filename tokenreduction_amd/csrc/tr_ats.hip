@@ -131,17 +131,36 @@ __global__ __launch_bounds__(256) void ats_gather_kernel(const float* __restrict
   if (row >= B * K) return;
   const int b = row / K;
   const size_t src = (size_t)b * N + ids[row];
+  // every load of the row pair goes out before the first store (rolled copy loops waited for each 16-byte chunk in turn);
+  // D <= 1024: at most 4 fp32 chunks and 2 (bf16) / 4 (fp32) chunks of the attention output per lane
   const float4* xs = reinterpret_cast<const float4*>(x + src * D);
   float4* xd = reinterpret_cast<float4*>(x_out + (size_t)row * D);
-  for (int c = lane; c < D / 4; c += 64) xd[c] = xs[c];
+  const int n4 = D / 4;
+  float4 xv[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) xv[c] = xs[min(lane + 64 * c, n4 - 1)];
   if (F32) {
     const float4* as = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(ao) + src * D);
     float4* ad = reinterpret_cast<float4*>(reinterpret_cast<float*>(ao_out) + (size_t)row * D);
-    for (int c = lane; c < D / 4; c += 64) ad[c] = as[c];
+    float4 av[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) av[c] = as[min(lane + 64 * c, n4 - 1)];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (lane + 64 * c < n4) { xd[lane + 64 * c] = xv[c]; ad[lane + 64 * c] = av[c]; }
   } else {
     const uint4* as = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(ao) + src * D);
     uint4* ad = reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(ao_out) + (size_t)row * D);
-    for (int c = lane; c < D / 8; c += 64) ad[c] = as[c];
+    const int n8 = D / 8;
+    uint4 av[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) av[c] = as[min(lane + 64 * c, n8 - 1)];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (lane + 64 * c < n4) xd[lane + 64 * c] = xv[c];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      if (lane + 64 * c < n8) ad[lane + 64 * c] = av[c];
   }
 }
 
@@ -169,7 +188,7 @@ extern "C" int tr_ats_sample(const float* cls_rows, const void* qkv, int qkv_is_
 extern "C" int tr_ats_gather(const float* x, const void* ao, int ao_is_f32, const int32_t* ids, float* x_out, void* ao_out, int B,
                              int N, int K, int D, tr_stream_t s) {
   TR_REQUIRE(x && ao && ids && x_out && ao_out, TR_ERR_NULL, "tr_ats_gather: null pointer");
-  TR_REQUIRE(B > 0 && N >= 1 && K >= 1 && D > 0 && D % 8 == 0, TR_ERR_SHAPE, "tr_ats_gather: bad shape B=%d N=%d K=%d D=%d", B, N, K, D);
+  TR_REQUIRE(B > 0 && N >= 1 && K >= 1 && D > 0 && D % 8 == 0 && D <= 1024, TR_ERR_SHAPE, "tr_ats_gather: bad shape B=%d N=%d K=%d D=%d (D %% 8 == 0, D <= 1024)", B, N, K, D);
   TR_REQUIRE(x_out != x && ao_out != ao, TR_ERR_SHAPE, "tr_ats_gather: needs distinct outputs");
   TR_REQUIRE(tr_aligned16(x) && tr_aligned16(ao) && tr_aligned16(x_out) && tr_aligned16(ao_out), TR_ERR_ALIGN,
              "tr_ats_gather: pointers must be 16-byte aligned");

@@ -325,9 +325,10 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const float* __restrict__ 
     float4 v[4];
     float ss = 0.f;
 #pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const float4*>(xr + 4 * min(lane + 64 * c, nch - 1));   // branch-free: one batch
+#pragma unroll
     for (int c = 0; c < 4; ++c)
       if (lane + 64 * c < nch) {
-        v[c] = *reinterpret_cast<const float4*>(xr + 4 * (lane + 64 * c));
         ss = fmaf(v[c].x, v[c].x, ss); ss = fmaf(v[c].y, v[c].y, ss); ss = fmaf(v[c].z, v[c].z, ss); ss = fmaf(v[c].w, v[c].w, ss);
       }
     ss = wave_sum(ss);
