@@ -47,6 +47,21 @@ __global__ __launch_bounds__(TMT) void tome_match_kernel(const void* __restrict_
 #pragma unroll
     for (int k = 0; k < 8; ++k) m[k] = 0.f;
     const size_t e0 = ((size_t)b * N + n) * ldq + H * 64 + c * 8;
+    if (!F32 && H <= 12) {
+      // all heads' chunks are requested before the first add (head index clamped: branch-free); summed in head order as before.
+      // As a rolled loop over H this was H dependent global round trips per item, half of the kernel's time at N = 197.
+      uint4 u[12];
+#pragma unroll
+      for (int h = 0; h < 12; ++h) u[h] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(qkv) + e0 + min(h, H - 1) * 64);
+#pragma unroll
+      for (int h = 0; h < 12; ++h)
+        if (h < H) {
+          m[0] += __uint_as_float(u[h].x << 16); m[1] += __uint_as_float(u[h].x & 0xffff0000u);
+          m[2] += __uint_as_float(u[h].y << 16); m[3] += __uint_as_float(u[h].y & 0xffff0000u);
+          m[4] += __uint_as_float(u[h].z << 16); m[5] += __uint_as_float(u[h].z & 0xffff0000u);
+          m[6] += __uint_as_float(u[h].w << 16); m[7] += __uint_as_float(u[h].w & 0xffff0000u);
+        }
+    } else
     for (int h = 0; h < H; ++h) {
       if (F32) {
         const float4 u0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(qkv) + e0 + h * 64);
