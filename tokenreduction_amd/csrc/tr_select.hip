@@ -28,7 +28,16 @@ __global__ __launch_bounds__(256) void cls_topk_kernel(const float* __restrict__
   (void)invH;
   for (int j = tid; j < P; j += 256) {
     float acc = 0.f;
-    for (int h = 0; h < H; ++h) acc += rows[(size_t)h * N + 1 + j];  // sequential over heads, like a strided torch sum
+    if (H <= 12) {                       // every head's value requested before the first add (a rolled loop waits for each in turn)
+      float v[12];
+#pragma unroll
+      for (int h = 0; h < 12; ++h) v[h] = rows[(size_t)min(h, H - 1) * N + 1 + j];
+#pragma unroll
+      for (int h = 0; h < 12; ++h)
+        if (h < H) acc += v[h];          // sequential over heads, like a strided torch sum
+    } else {
+      for (int h = 0; h < H; ++h) acc += rows[(size_t)h * N + 1 + j];
+    }
     const float sc = acc / (float)H;
     s_sc[j] = sc;
     if (scores) scores[(size_t)b * P + j] = sc;
