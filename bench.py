@@ -71,17 +71,26 @@ def model_flops_per_image(tokens_per_block, D=384, P=196, classes=1000, n0=197):
     return f
 
 
-def roofline_leg(model, x, reps=3):
+def roofline_leg(model, x, reps=5):
+    """Per-kernel HIP-event timing of instrumented forwards.  Each kernel's time is the MEDIAN over `reps` forwards of its summed
+    launch durations (one disturbed forward -- another tenant on the box, a clock dip -- must not skew a table measured once)."""
     from tokenreduction_amd.stepwise import Trace, forward_stepwise
-    agg = {}
+    per_rep = []
     tr = Trace(timing=True)
     forward_stepwise(model, x, tr)          # untimed pass: fills the trace's buffer cache
     for _ in range(reps):
         tr.launches = []
         forward_stepwise(model, x, tr)
+        rep = {}
         for l in tr.launches:
-            a = agg.setdefault(l["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            a = rep.setdefault(l["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
             a["ms"] += l["ms"]; a["flops"] += l["flops"]; a["bytes"] += l["bytes"]; a["launches"] += 1
+        per_rep.append(rep)
+    agg = {}
+    for k in per_rep[0]:
+        ms = sorted(r[k]["ms"] for r in per_rep)[reps // 2]
+        agg[k] = dict(ms=ms * reps, flops=per_rep[0][k]["flops"] * reps, bytes=per_rep[0][k]["bytes"] * reps,
+                      launches=per_rep[0][k]["launches"] * reps)
     total_ms = sum(a["ms"] for a in agg.values())
     table = {}
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
