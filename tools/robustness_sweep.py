@@ -5,7 +5,9 @@ from tests._params import make_params, make_images
 from oracle import VitConfig
 ok = True
 for (fam, cls, img, patch, chans, D, H, depth, B, kr, loc) in [
-    ("topk", "TopKVisionTransformer", 224, 32, 3, 128, 2, 3, 5, [0.6], [1]),
+    ("topk", "TopKVisionTransformer", 224, 16, 3, 128, 2, 3, 5, [0.6], [1]),      # keep = int(r * 196): the reference hard-codes 196 patches (topk.py:56)
+    ("topk", "TopKVisionTransformer", 224, 16, 3, 256, 4, 2, 3, [0.3], [0]),      # D = 256: one 64-lane chunk per LayerNorm row
+    ("evit", "EfficientVisionTransformer", 224, 16, 3, 1024, 16, 2, 2, [0.5], [1]),  # D = 1024: four chunks per row
     ("deit", "VisionTransformer", 224, 16, 1, 64, 1, 2, 1, [1.0], []),
     ("deit", "VisionTransformer", 96, 16, 3, 192, 3, 2, 77, [1.0], []),
     ("evit", "EfficientVisionTransformer", 160, 16, 3, 128, 2, 4, 3, [0.5], [0, 2]),
