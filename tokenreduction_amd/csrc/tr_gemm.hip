@@ -36,7 +36,7 @@ constexpr int BK = 64;
 constexpr int PBM = 256, PBN = 128;
 constexpr int P_STAGE_BYTES = (PBM + PBN) * 128;  // 48 KiB: A rows then W rows, 128 B (64 bf16) per row
 constexpr int P_NSTAGE = 3;
-constexpr int DMA_PER_STEP = 6;                   // LDS-DMA pieces per wave and K-step: 4 of A, 2 of W (documentation of the vmcnt immediates)
+// LDS-DMA pieces per wave and K-step in gemm_bf16_persistent: 4 of A, 2 of W = 6 (what its vmcnt immediates count)
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
