@@ -428,48 +428,107 @@ __global__ __launch_bounds__(SKT) void sinkhorn_kernel(const float* __restrict__
   }
 }
 
-// Same iterations when K*P floats exceed the LDS (384^2 inputs: 144 x 576): Z stays in the token-major scores buffer
-// (L2/MALL resident, 332 KB per image); u-step = one thread per centre walking the tokens (lanes along k: coalesced),
-// v-step = one wave per token.
-__global__ __launch_bounds__(256) void sinkhorn_global_kernel(const float* __restrict__ scores, int ldl, float eps, int iters,
+// Same iterations when K*P floats exceed the LDS (384^2 inputs: 144 x 576 = 332 KB): Z stays in the token-major scores buffer
+// (L2 / Infinity-Cache resident) and is re-read by every half-iteration, by all 16 waves of one workgroup per image:
+//   u-step  thread = (centre k, token segment): lanes along k (coalesced 256-byte rows), the 1024 threads split the tokens into
+//           1024 / ceil64(K) segments; two passes (max, then sum of exponentials) with the partials combined through LDS in
+//           segment order -- the same max-then-sum formulation as sinkhorn_kernel;
+//   v-step  one wave per token row, four rows in flight per wave, lanes along k.
+// All loads of a pass are issued in batches of eight (independent addresses).  The first version of this kernel ran 256 threads
+// per image with one thread walking all tokens of a centre: 1384 us at B = 64, K = 144, P = 576 -- a quarter of the 384^2 forward.
+constexpr int SGT = 1024;
+constexpr int SG_KMAX = 256;                 // centres handled per pass without looping (K <= 192 in every registered model)
+__global__ __launch_bounds__(SGT) void sinkhorn_global_kernel(const float* __restrict__ scores, int ldl, float eps, int iters,
                                                               float* __restrict__ wt, float* __restrict__ soft, int N, int K) {
-  extern __shared__ __attribute__((aligned(16))) float s_uv[];     // u[K], v[P]
+  extern __shared__ __attribute__((aligned(16))) float s_uv[];     // u[K], v[P], partials[nseg][KW]
   const int P = N - 1;
+  const int KW = (K + 63) & ~63;             // centre columns rounded up to whole waves
+  const int nseg = SGT / KW;                 // token segments of the u-step
   float* s_u = s_uv;
   float* s_v = s_uv + K;
+  float* s_part = s_v + P;                   // [nseg][KW]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x;
   const float* sc = scores + ((size_t)b * N + 1) * ldl;
-  for (int p = tid; p < P; p += 256) s_v[p] = 0.f;
-  for (int k = tid; k < K; k += 256) s_u[k] = 0.f;
+  const float inv_eps = 1.0f / eps;
+  for (int p = tid; p < P; p += SGT) s_v[p] = 0.f;
+  for (int k = tid; k < K; k += SGT) s_u[k] = 0.f;
   const float norm = -logf((float)K + (float)P);
+  const int kc = tid % KW, seg = tid / KW;   // u-step role (threads with seg >= nseg or kc >= K only help at the barriers)
+  const bool u_active = seg < nseg && kc < K;
+  const int seg_len = (P + nseg - 1) / nseg;
+  const int p_lo = min(seg * seg_len, P), p_hi = min(p_lo + seg_len, P);
   __syncthreads();
   for (int it = 0; it < iters; ++it) {
-    for (int k = tid; k < K; k += 256) {
-      float m = -INFINITY;
-      for (int p = 0; p < P; ++p) m = fmaxf(m, sc[(size_t)p * ldl + k] / eps + s_v[p]);
-      float t = 0.f;
-      for (int p = 0; p < P; ++p) t += expf(sc[(size_t)p * ldl + k] / eps + s_v[p] - m);
-      s_u[k] = norm - (m + logf(t));
+    // ---- u = log_mu - logsumexp_p(Z + v)
+    float m = -INFINITY;
+    if (u_active) {
+      for (int p0 = p_lo; p0 < p_hi; p0 += 8) {
+        float z[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) z[q] = sc[(size_t)min(p0 + q, p_hi - 1) * ldl + kc];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (p0 + q < p_hi) m = fmaxf(m, z[q] * inv_eps + s_v[p0 + q]);
+      }
+      s_part[seg * KW + kc] = m;
     }
     __syncthreads();
-    for (int p = wave; p < P; p += 4) {
-      const float* zr = sc + (size_t)p * ldl;
-      float m = -INFINITY;
-      for (int k = lane; k < K; k += 64) m = fmaxf(m, zr[k] / eps + s_u[k]);
+    float t = 0.f;
+    if (u_active) {
+      for (int sg = 0; sg < nseg; ++sg) m = fmaxf(m, s_part[sg * KW + kc]);
+      for (int p0 = p_lo; p0 < p_hi; p0 += 8) {
+        float z[8];
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-      float t = 0.f;
-      for (int k = lane; k < K; k += 64) t += expf(zr[k] / eps + s_u[k] - m);
-      t = wave_sum(t);
-      if (lane == 0) s_v[p] = norm - (m + logf(t));
+        for (int q = 0; q < 8; ++q) z[q] = sc[(size_t)min(p0 + q, p_hi - 1) * ldl + kc];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (p0 + q < p_hi) t += expf(z[q] * inv_eps + s_v[p0 + q] - m);
+      }
+    }
+    __syncthreads();                          // every thread has read the maxima: the partial buffer can take the sums
+    if (u_active) s_part[seg * KW + kc] = t;
+    __syncthreads();
+    if (u_active && seg == 0) {
+      float tt = 0.f;
+      for (int sg = 0; sg < nseg; ++sg) tt += s_part[sg * KW + kc];      // fixed order
+      s_u[kc] = norm - (m + logf(tt));
+    }
+    __syncthreads();
+    // ---- v = log_nu - logsumexp_k(Z + u): wave per token row, four rows per step
+    for (int p0 = wave * 4; p0 < P; p0 += (SGT / 64) * 4) {
+      float z[4][SG_KMAX / 64];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < SG_KMAX / 64; ++c) {
+          const int k = lane + 64 * c;
+          z[r][c] = sc[(size_t)min(p0 + r, P - 1) * ldl + min(k, K - 1)];
+        }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float mm = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < SG_KMAX / 64; ++c) {
+          const int k = lane + 64 * c;
+          z[r][c] = (k < K) ? z[r][c] * inv_eps + s_u[min(k, K - 1)] : -INFINITY;
+          mm = fmaxf(mm, z[r][c]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o, 64));
+        float ts = 0.f;
+#pragma unroll
+        for (int c = 0; c < SG_KMAX / 64; ++c) ts += expf(z[r][c] - mm);     // exp(-inf) = 0 for the padding lanes
+        ts = wave_sum(ts);
+        if (lane == 0 && p0 + r < P) s_v[p0 + r] = norm - (mm + logf(ts));
+      }
     }
     __syncthreads();
   }
   float* wb = wt + ((size_t)b * N + 1) * ldl;
-  for (int e = tid; e < K * P; e += 256) {
+  for (int e = tid; e < K * P; e += SGT) {
     const int p = e / K, k = e - p * K;
-    const float w = expf(sc[(size_t)p * ldl + k] / eps + s_u[k] + s_v[p] - norm);   // read-then-write by the same thread: wt may alias scores
+    const float w = expf(sc[(size_t)p * ldl + k] * inv_eps + s_u[k] + s_v[p] - norm);   // read-then-write by the same thread: wt may alias scores
     wb[(size_t)p * ldl + k] = w;
     if (soft != nullptr) soft[((size_t)b * K + k) * P + p] = w;
   }
@@ -554,8 +613,10 @@ extern "C" int tr_sinkhorn(const float* scores, int ldl, float eps, int iters, f
   const size_t lds = ((size_t)K * (N - 1) + K + (N - 1)) * sizeof(float);
   hipStream_t st = static_cast<hipStream_t>(s);
   if (lds > 158 * 1024) {
-    hipLaunchKernelGGL(sinkhorn_global_kernel, dim3(B), dim3(256), (size_t)(K + N - 1) * sizeof(float), st, scores, ldl, eps, iters, wt,
-                       soft, N, K);
+    TR_REQUIRE(K <= SG_KMAX, TR_ERR_SHAPE, "tr_sinkhorn: K=%d > %d centres with K*P beyond the LDS is not supported", K, SG_KMAX);
+    const int kw = (K + 63) & ~63;
+    const size_t lds_g = ((size_t)K + (N - 1) + (size_t)(SGT / kw) * kw) * sizeof(float);
+    hipLaunchKernelGGL(sinkhorn_global_kernel, dim3(B), dim3(SGT), lds_g, st, scores, ldl, eps, iters, wt, soft, N, K);
     TR_CHECK_LAUNCH("tr_sinkhorn");
     return TR_OK;
   }
