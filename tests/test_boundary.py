@@ -122,7 +122,7 @@ def test_argument_validation_without_gpu():
     p = ctypes.addressof(buf)
     p = (p + 255) // 256 * 256
     assert lib.tr_gemm_bf16(p, p, p, p, None, 0, 8, 8, 48, 0, None) == -1          # K % 64
-    assert lib.tr_attention_bf16(p, p, None, None, p, 1, 700, 1, None) == -1         # column sums: N > 608
+    assert lib.tr_attention_bf16(p, p, None, p, p, 1, 700, 1, None) == -1            # column sums WITH a key bias: N > 608
     assert lib.tr_tome_match(p, 0, p, p, p, 1, 197, 6, 120, None) == -1              # r > (N-1)//2
     assert lib.tr_cls_topk(p, p, None, None, 1, 1, 10, 10, None) == -1               # K > P
     cfg = _lib.TrVitConfig()

@@ -546,8 +546,8 @@ constexpr int FRS = FKB * 64 + 16;           // V^T row stride in bytes
 #define TR_FLASH_WGS 3
 #endif
 __global__ __launch_bounds__(256, TR_FLASH_WGS) void attention_flash_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
-                                                                 float* __restrict__ cls_rows, const float* __restrict__ size, int N,
-                                                                 int H, int nqg) {
+                                                                 float* __restrict__ cls_rows, const float* __restrict__ size,
+                                                                 float* __restrict__ stats, int N, int H, int nqg) {
   __shared__ __attribute__((aligned(16))) unsigned char sK[FKB * 32 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char sVt[64 * FRS];
   __shared__ float sLB[FKB * 32];
@@ -703,10 +703,105 @@ __global__ __launch_bounds__(256, TR_FLASH_WGS) void attention_flash_kernel(cons
         *reinterpret_cast<uint2*>(orow + db * 32 + 8 * g) = pk;
       }
   }
+  // per-query reference point and 1 / normaliser for attention_colsum_kernel: rows 0 and 1 of the [B,H,4,N] column-sum buffer
+  if (stats != nullptr && q < N && hh == 0) {
+    float* st = stats + ((size_t)b * H + h) * 4 * N;
+    st[q] = m;
+    st[N + q] = inv;
+  }
   if (crow != nullptr) {
     // the two lanes that own query 0 wrote its logits (keys with ((key >> 2) & 1) == hh): same thread, same addresses
     for (int key = 0; key < N; ++key)
       if (((key >> 2) & 1) == hh) crow[key] = __builtin_amdgcn_exp2f(crow[key] - m) * inv;
+  }
+}
+
+// Column sums of the softmax matrix for long sequences (K-Medoids at 384^2 inputs): second pass after attention_flash_kernel,
+// which leaves every query's reference point m and 1 / normaliser in rows 0 and 1 of the [B,H,4,N] partial buffer.  One workgroup
+// per (image, head, chunk of 128 keys) holds the K chunk in LDS and walks ALL query blocks: S^T = K Q^T again (half the FLOPs of
+// the attention itself), p = exp2(s * c - m_q) / l_q, summed over the queries of each wave by the same transpose-reduce as
+// attention_kernel<COLSUM>.  Waves 0,2 and 1,3 are combined (fixed order) into rows 2 and 3; the launcher zeroes rows 0 and 1
+// afterwards, so the consumer's sum over the four rows is unchanged.
+__global__ __launch_bounds__(256, 3) void attention_colsum_kernel(const uint16_t* __restrict__ qkv, float* __restrict__ part, int N,
+                                                                  int H, int nkc) {
+  __shared__ __attribute__((aligned(16))) unsigned char sK[FKB * 32 * 128];
+  __shared__ float sAcc[2][FKB * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.x / nkc, kc = blockIdx.x - bh * nkc;
+  const int b = bh / H, h = bh - b * H;
+  const int ldq = 3 * H * 64;
+  const uint16_t* base = qkv + (size_t)b * N * ldq;
+  const int qcol = h * 64, kcol = H * 64 + h * 64;
+  const int ql = lane & 31, hh = lane >> 5;
+  const int nqb = (N + 31) >> 5;
+  const int key0 = kc * FKB * 32;
+  const float c_exp = 0.125f * 1.44269504088896340736f;
+  float* pb = part + (size_t)bh * 4 * N;                 // rows 0,1: m and 1/l per query (read); rows 2,3: column sums (written)
+  {
+    uint4 kreg[FKB];
+#pragma unroll
+    for (int it = 0; it < FKB; ++it) {
+      const int g = tid + 256 * it;
+      kreg[it] = *reinterpret_cast<const uint4*>(base + (size_t)min(key0 + (g >> 3), N - 1) * ldq + kcol + (g & 7) * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < FKB; ++it) {
+      const int g = tid + 256 * it;
+      if (key0 + (g >> 3) >= N) kreg[it] = make_uint4(0u, 0u, 0u, 0u);
+      *reinterpret_cast<uint4*>(sK + kswz(g >> 3, g & 7)) = kreg[it];
+    }
+  }
+  __syncthreads();
+  float colacc[FKB];
+#pragma unroll
+  for (int kb = 0; kb < FKB; ++kb) colacc[kb] = 0.f;
+  for (int qb = wave; qb < nqb; qb += 4) {
+    const int q = qb * 32 + ql;
+    const int qc = min(q, N - 1);
+    const uint16_t* qrow = base + (size_t)qc * ldq + qcol + 8 * hh;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qrow + 16 * s);
+    const float mq = pb[qc];
+    const float wq = q < N ? pb[N + qc] : 0.f;
+#pragma unroll
+    for (int kb = 0; kb < FKB; ++kb) {
+      f32x16 sacc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + kswz(kb * 32 + ql, 2 * s + hh));
+        sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc, 0, 0, 0);
+      }
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = key0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        v[r] = key < N ? __builtin_amdgcn_exp2f(sacc[r] * c_exp - mq) * wq : 0.f;
+      }
+      colsum_step<16, 1>(v, ql);
+      colsum_step<8, 2>(v, ql);
+      colsum_step<4, 4>(v, ql);
+      colsum_step<2, 8>(v, ql);
+      colacc[kb] += v[0] + __shfl_xor(v[0], 16, 64);
+    }
+  }
+  // after the transpose-reduce, lane bits (b0,b1,b2,b3) of ql select register r = 8 b0 + 4 b1 + 2 b2 + b3
+  const int r = ((ql & 1) << 3) | ((ql & 2) << 1) | ((ql & 4) >> 1) | ((ql & 8) >> 3);
+  const int kl = (r & 3) + 8 * (r >> 2) + 4 * hh;
+  if (wave >= 2 && (ql & 16) == 0) {
+#pragma unroll
+    for (int kb = 0; kb < FKB; ++kb) sAcc[wave - 2][kb * 32 + kl] = colacc[kb];
+  }
+  __syncthreads();
+  if (wave < 2 && (ql & 16) == 0) {
+    float* crow = pb + (size_t)(2 + wave) * N;
+#pragma unroll
+    for (int kb = 0; kb < FKB; ++kb) {
+      const int key = key0 + kb * 32 + kl;
+      if (key < N) crow[key] = colacc[kb] + sAcc[wave][kb * 32 + kl];
+    }
   }
 }
 
@@ -733,17 +828,25 @@ extern "C" int tr_attention_bf16(const uint16_t* qkv, uint16_t* out, float* cls_
                                  int N, int H, tr_stream_t s) {
   TR_REQUIRE(qkv && out, TR_ERR_NULL, "tr_attention_bf16: null pointer");
   TR_REQUIRE(B > 0 && H > 0 && N >= 1, TR_ERR_SHAPE, "tr_attention_bf16: bad shape B=%d N=%d H=%d", B, N, H);
-  TR_REQUIRE(N <= 608 || colsum_part == nullptr, TR_ERR_SHAPE,
-             "tr_attention_bf16: column sums need N <= 608 (N=%d: K and V^T of one head must fit the LDS)", N);
+  TR_REQUIRE(N <= 608 || colsum_part == nullptr || size == nullptr, TR_ERR_SHAPE,
+             "tr_attention_bf16: column sums together with a key bias need N <= 608 (N=%d: K and V^T of one head must fit the LDS)", N);
   TR_REQUIRE(tr_aligned16(qkv) && tr_aligned16(out), TR_ERR_ALIGN, "tr_attention_bf16: pointers must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(s);
   static const int flash_min = [] {            // development switch: smallest N that takes the online-softmax kernel
     const char* e = getenv("TR_ATT_FLASH_MIN");
     return e ? atoi(e) : 225;
   }();
-  if (N >= flash_min && colsum_part == nullptr) {
+  if (N >= flash_min && (colsum_part == nullptr || size == nullptr)) {
     const int nqg = ((N + 31) / 32 + 3) / 4;
-    hipLaunchKernelGGL(attention_flash_kernel, dim3(B * H * nqg), dim3(256), 0, st, qkv, out, cls_rows, size, N, H, nqg);
+    hipLaunchKernelGGL(attention_flash_kernel, dim3(B * H * nqg), dim3(256), 0, st, qkv, out, cls_rows, size, colsum_part, N, H, nqg);
+    if (colsum_part != nullptr) {
+      // column sums by a second pass over the keys (rows 2,3 of every [4][N] block), then the per-query statistics the first pass
+      // left in rows 0,1 are cleared: the consumer adds all four rows
+      const int nkc = (N + FKB * 32 - 1) / (FKB * 32);
+      hipLaunchKernelGGL(attention_colsum_kernel, dim3(B * H * nkc), dim3(256), 0, st, qkv, colsum_part, N, H, nkc);
+      hipError_t e = hipMemset2DAsync(colsum_part, (size_t)4 * N * sizeof(float), 0, (size_t)2 * N * sizeof(float), (size_t)B * H, st);
+      TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_attention_bf16: clearing the statistics rows failed: %s", hipGetErrorString(e));
+    }
     TR_CHECK_LAUNCH("tr_attention_bf16");
     return TR_OK;
   }
