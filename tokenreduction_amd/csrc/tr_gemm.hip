@@ -508,8 +508,10 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
       const uint16_t* sW = real ? W : A;
 #pragma unroll
       for (int j = 0; j < 8; ++j) issue_piece(A, real ? o[j] : 0u, da + j * 1024);
+#ifndef TR_ABLATE_NO_W_DMA    // lab only: what would the K-loop do if the weight panel stayed in LDS (feed 32 KB instead of 48 KB per K-step)?
 #pragma unroll
       for (int j = 0; j < 4; ++j) issue_piece(sW, real ? o[8 + j] : 0u, dw + j * 1024);
+#endif
       if (real) {
         ++l_step;
         l_slot = (l_slot == P_NSTAGE - 1) ? 0 : l_slot + 1;
@@ -527,7 +529,11 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
     issue_group();      // group 0 -> slot 0
     issue_group();      // group 1 -> slot 1   (dummies if S < 2)
     for (int g = 0; g < S; ++g) {
+#ifdef TR_ABLATE_NO_W_DMA
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#else
       asm volatile("s_waitcnt vmcnt(12)" ::: "memory");    // group g landed (group g+1 -- real or dummy -- may still fly)
+#endif
       __builtin_amdgcn_s_barrier();                        // B_g: the MFMA waves are done reading slot (g-1)%3 == (g+2)%3
       if (g + 1 < S) issue_group();                        // group g+2 -> that slot (dummy pieces once nothing is left to load)
     }
