@@ -473,18 +473,53 @@ __global__ __launch_bounds__(KMT) void kmed_iterate_kernel(const float* __restri
   for (int it = 0; it <= iters; ++it) {
     for (int k = tid; k < K; k += KMT) s_best[k] = cost_key(masked, 0);
     __syncthreads();
-    for (int p = wave; p < P; p += KMT / 64) {
-      const float* dr = db + (size_t)p * P;
-      float best = INFINITY;
-      int arg = 0x7fffffff;
-      for (int k = lane; k < K; k += 64) {            // ascending k per lane, strict <: the lane's first minimum
-        const float d = dr[s_c[k]];
-        if (d < best) { best = d; arg = k; }
-      }
-      wave_min_pair(best, arg);                       // smallest distance, ties -> smallest k (torch.argmin)
-      if (lane == 0) {
-        if (it == iters) assign[(size_t)b * P + p] = arg;
-        else atomicMin(&s_best[arg], cost_key(tb[p], p));     // smallest cost, ties -> smallest index; empty cluster -> index 0
+    // four tokens per wave and step, all their gathered distances (up to 4 x 4 per lane) requested before the first compare:
+    // as a rolled loop over k every 64 medoids cost one dependent L2 round trip per token (3 x 12 tokens x 4 passes per wave)
+    const int kch = (K + 63) >> 6;
+    for (int p0 = wave * 4; p0 < P; p0 += (KMT / 64) * 4) {
+      if (kch <= 4) {
+        float d[4][4];
+        int ci[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ci[c] = s_c[min(lane + 64 * c, K - 1)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) d[q][c] = db[(size_t)min(p0 + q, P - 1) * P + ci[c]];
+        float cost[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cost[q] = tb[min(p0 + q, P - 1)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float best = INFINITY;
+          int arg = 0x7fffffff;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {               // ascending k per lane, strict <: the lane's first minimum
+            const int k = lane + 64 * c;
+            if (k < K && d[q][c] < best) { best = d[q][c]; arg = k; }
+          }
+          wave_min_pair(best, arg);                   // smallest distance, ties -> smallest k (torch.argmin)
+          if (lane == 0 && p0 + q < P) {
+            if (it == iters) assign[(size_t)b * P + p0 + q] = arg;
+            else atomicMin(&s_best[arg], cost_key(cost[q], p0 + q));   // smallest cost, ties -> smallest index; empty cluster -> index 0
+          }
+        }
+      } else {
+        for (int q = 0; q < 4 && p0 + q < P; ++q) {
+          const int p = p0 + q;
+          const float* dr = db + (size_t)p * P;
+          float best = INFINITY;
+          int arg = 0x7fffffff;
+          for (int k = lane; k < K; k += 64) {
+            const float dd = dr[s_c[k]];
+            if (dd < best) { best = dd; arg = k; }
+          }
+          wave_min_pair(best, arg);
+          if (lane == 0) {
+            if (it == iters) assign[(size_t)b * P + p] = arg;
+            else atomicMin(&s_best[arg], cost_key(tb[p], p));
+          }
+        }
       }
     }
     __syncthreads();
