@@ -315,9 +315,13 @@ __global__ __launch_bounds__(256) void assign_kernel(const float* __restrict__ d
   for (int p = tid; p < P; p += 256) {
     float best = INFINITY;
     int arg = 0;
-    for (int k = 0; k < K; ++k) {
-      const float d = db[(size_t)s_c[k] * P + p];
-      if (d < best) { best = d; arg = k; }
+    for (int k0 = 0; k0 < K; k0 += 8) {               // eight centre rows requested per step (independent addresses), compared in order
+      float d[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) d[u] = db[(size_t)s_c[min(k0 + u, K - 1)] * P + p];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k0 + u < K && d[u] < best) { best = d[u]; arg = k0 + u; }
     }
     idx_cluster[(size_t)b * P + p] = arg;
   }
