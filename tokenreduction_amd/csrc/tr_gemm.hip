@@ -643,12 +643,15 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
           u32x2 pk;
           pk[0] = pack_bf16x2(v0, v1);
           pk[1] = pack_bf16x2(v2, v3);
-          *reinterpret_cast<u32x2*>(stg + frow * 128 + (((2 * i + (fq >> 1)) ^ (frow & 7)) << 4) + (fq & 1) * 8) = pk;
+          // 16-byte chunk XOR row&7 spreads the rows over the banks; rows r and r+8 share a chunk, so they take OPPOSITE 8-byte
+          // halves of it (tools/lds_sim.py: 4 instead of 8 cycles per ds_write_b64) -- undone for free in read_back
+          *reinterpret_cast<u32x2*>(stg + frow * 128 + (((2 * i + (fq >> 1)) ^ (frow & 7)) << 4) + (((fq & 1) ^ (frow >> 3)) << 3)) = pk;
         }
       };
       auto read_back = [&](u32x4 (&ln)[2]) __attribute__((always_inline)) {
         ln[0] = *reinterpret_cast<const u32x4*>(rd);
-        ln[1] = *reinterpret_cast<const u32x4*>(rd + 1024);
+        const u32x4 t = *reinterpret_cast<const u32x4*>(rd + 1024);       // rows 8..15: halves swapped
+        ln[1] = u32x4{t[2], t[3], t[0], t[1]};
       };
       auto store = [&](int j, const u32x4 (&ln)[2]) __attribute__((always_inline)) {
 #pragma unroll
