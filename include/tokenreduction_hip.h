@@ -206,6 +206,53 @@ int tr_tome_merge_layernorm(const float* x, const void* delta, int f32_path, con
                             const int32_t* src_idx, const int32_t* dst_idx, const float* gamma, const float* beta, float* x_out,
                             float* size_out, void* y, int B, int N, int r, int D, float eps, tr_stream_t s);
 
+/* ---- backward kernels (csrc/tr_backward.hip, csrc/tr_attention_bwd.hip) -----------------------------------------------------
+ * The reference's training step is `loss.backward()` through the eager forward (engine.py:50-76, mp_scaler.py:10-11); these are
+ * the hand-written gradients of the ops above.  Reductions over tokens are two-stage with a fixed order (bitwise reproducible).
+ * `accumulate` != 0: the gradient is ADDED to the destination (gradient accumulation, engine.py:41), else it is overwritten.
+ * tr_wgrad_bf16: nn.Linear weight gradient dW[N,K] (+)= dY[M,N]^T X[M,K]; dY, X bf16 at row strides ldy, ldx (elements); yskip > 0:
+ *   dY row m is row m + m/yskip + 1 of its tensor (the patch rows of a [B, P+1, D] tensor, yskip = P: PatchEmbed's weight gradient).
+ *   ws: tr_wgrad_workspace_floats(M,N,K) floats (partials of the token splits).  N, K, ldy, ldx multiples of 8.
+ * tr_colsum_bf16: nn.Linear bias gradient db[N] (+)= sum_m dY[m,n]; ws: tr_colsum_workspace_floats(M,N) floats.
+ * tr_gelu_bf16 / tr_gelu_bwd_bf16: h = gelu(pre) with the SAME fit as TR_EPI_GELU_BF16 (the training forward stores fc1's
+ *   pre-activation, then applies this); dh := dh * gelu'(pre) in place (exact erf form).
+ * tr_layernorm_bwd: dy bf16 [M,D] (gradient wrt the LayerNorm output), x fp32 rows (the saved LayerNorm INPUT, row stride ldx),
+ *   g_in (nullable) fp32 rows: gradient already flowing in the residual stream at these rows; g_out = g_in + dLN -> fp32 rows
+ *   (stride ldgo) and gb_out (nullable) bf16 [rows, D].  d_gamma, d_beta fp32 [D].  idx != NULL: the rows are the gathered rows
+ *   [B, n_in] of a Top-K block (n_in = K+1, or K+2 with EViT's fused token); row r of image b is written to row
+ *   (r == 0 ? 0 : 1 + idx[b,r-1]) of [B, n_out, D] and the fused row to g_fused fp32 [B, D] (the caller zero-fills g_out/gb_out).
+ *   ws: tr_layernorm_bwd_workspace_floats(M, D) floats.
+ * tr_attention_bwd_bf16: d qkv from d out (see csrc/tr_attention_bwd.hip), N <= 224.
+ * tr_head_bwd: dxn bf16 [B,D] = dlogits W; dW (+)= dlogits^T xn; db (+)= colsum(dlogits)   (topk.py:203; W, xn bf16).
+ * tr_embed_bwd: d pos_embed [N,D] (+)= sum_b g[b,n,:], d cls_token [D] (+)= sum_b g[b,0,:]   (topk.py:183-186).
+ * tr_evit_fuse_bwd: evit.py:117-120: g_out[b,1+c,:] = scores[b,c] g_fused[b] (fp32 + bf16 copy) for the complement tokens c,
+ *   dscore[b,1+c] = <x[b,1+c] + delta[b,1+c], g_fused[b]>  (dscore fp32 [B,N], zero-filled by the caller).
+ * tr_tome_merge_bwd: merge_wavg (tome.py:309-323): g_out[b,i,:] = size_in[b,i] / size_out[b,o(i)] * g_merged[b,o(i),:];
+ *   inv_map int32 [B,N] scratch. */
+size_t tr_wgrad_workspace_floats(int M, int N, int K);
+int tr_wgrad_bf16(const uint16_t* dY, long ldy, int yskip, const uint16_t* X, long ldx, float* dW, int accumulate, float* ws,
+                  size_t ws_floats, int M, int N, int K, tr_stream_t s);
+size_t tr_colsum_workspace_floats(int M, int N);
+int tr_colsum_bf16(const uint16_t* dY, long ldy, int yskip, float* db, int accumulate, float* ws, size_t ws_floats, int M, int N,
+                   tr_stream_t s);
+int tr_gelu_bf16(const uint16_t* pre, uint16_t* h, size_t n, tr_stream_t s);
+int tr_gelu_bwd_bf16(const uint16_t* pre, uint16_t* dh, size_t n, tr_stream_t s);
+size_t tr_layernorm_bwd_workspace_floats(int M, int D);
+int tr_layernorm_bwd(const uint16_t* dy, const float* x, long ldx, const float* gamma, const float* g_in, long ldgi, float* g_out,
+                     long ldgo, uint16_t* gb_out, const int32_t* idx, int K, int n_in, int n_out, float* g_fused, float* dgamma,
+                     float* dbeta, int accumulate, float* ws, size_t ws_floats, int M, int D, float eps, tr_stream_t s);
+int tr_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, const float* size, const float* dcls, uint16_t* dqkv, int B,
+                          int N, int H, tr_stream_t s);
+int tr_head_bwd(const float* dlogits, const uint16_t* W, const uint16_t* xn, uint16_t* dxn, float* dW, float* db, int accumulate,
+                int B, int C, int D, tr_stream_t s);
+int tr_embed_bwd(const float* g, float* dpos, float* dcls, int accumulate, int B, int N, int D, tr_stream_t s);
+int tr_evit_fuse_bwd(const float* x, const uint16_t* delta, const int32_t* compl_idx, const float* scores, const float* g_fused,
+                     float* g_out, uint16_t* gb_out, float* dscore, int B, int N, int K, int D, tr_stream_t s);
+int tr_tome_merge_bwd(const float* g_merged, const float* size_in, const float* size_out, const int32_t* unm_idx,
+                      const int32_t* src_idx, const int32_t* dst_idx, int32_t* inv_map, float* g_out, uint16_t* gb_out, int B, int N,
+                      int r, int D, tr_stream_t s);
+int tr_f32_to_bf16(const float* src, uint16_t* dst, size_t n, tr_stream_t s);
+
 /* ---- whole-model executor: TopKVisionTransformer.forward topk.py:179-212,
  *      EfficientVisionTransformer.forward evit.py:209-244, deit_viz.VisionTransformer.forward :186-212 (eval) ---- */
 #define TR_FAMILY_DEIT 0

@@ -1,0 +1,256 @@
+"""GPU parity tests of the backward kernels (csrc/tr_backward.hip, csrc/tr_attention_bwd.hip) through the C ABI.
+
+The reference's backward is torch.autograd over its eager forward (engine.py:50-76), so the checker here is exactly that:
+torch.autograd in fp32 (on the GPU box's torch) over a plain PyTorch restatement of the op, fed the SAME bf16-rounded
+operands.  Tolerances: fp32 accumulations differ by summation order only (1e-4 relative to the result's scale); bf16 outputs
+add one rounding (2^-8 relative).  Gradients through bf16-rounded intermediates (attention: P and dS are rounded to bf16 for the
+MFMA products, exactly like P in the forward) are compared by relative L2 with the bound written in the test.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from tokenreduction_amd import ops as _ops
+    return _ops
+
+
+def _randn(seed, *shape, scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).cuda()
+
+
+def rel_l2(got, want):
+    got, want = got.double().cpu(), want.double().cpu()
+    return float((got - want).norm() / want.norm().clamp_min(1e-30))
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (100, 8, 8), (1000, 384, 1152), (50432, 1536, 384), (3000, 1000, 384), (777, 192, 576),
+                                   (1, 16, 24), (4096, 768, 3072)])
+def test_wgrad(ops, M, N, K):
+    dy = _randn(1, M, N, dtype=torch.bfloat16)
+    x = _randn(2, M, K, dtype=torch.bfloat16)
+    got = ops.wgrad(dy, x)
+    want = dy.float().t() @ x.float()
+    scale = float(want.abs().max())
+    assert float((got - want).abs().max()) <= 2e-4 * scale + 1e-6, f"max err {(got - want).abs().max():.3e} scale {scale:.3e}"
+    # accumulate: adds to the destination
+    acc = ops.wgrad(dy, x, out=got.clone(), accumulate=True)
+    assert float((acc - 2 * want).abs().max()) <= 4e-4 * scale + 1e-6
+    # deterministic: bitwise identical run to run
+    assert torch.equal(ops.wgrad(dy, x), got)
+
+
+def test_wgrad_exact_integers(ops):
+    """Small integers are exact in bf16 and fp32: any operand-layout mistake shows as a wrong integer."""
+    M, N, K = 200, 144, 136
+    g = torch.Generator().manual_seed(0)
+    dy = torch.randint(-3, 4, (M, N), generator=g).to(torch.bfloat16).cuda()
+    x = torch.randint(-3, 4, (M, K), generator=g).to(torch.bfloat16).cuda()
+    assert torch.equal(ops.wgrad(dy, x), dy.float().t() @ x.float())
+
+
+def test_wgrad_patch_rows(ops):
+    """yskip: dY rows are the patch rows of a [B, P+1, D] tensor (PatchEmbed weight gradient)."""
+    B, P, D, Kc = 5, 36, 128, 768
+    g = _randn(3, B, P + 1, D, dtype=torch.bfloat16)
+    cols = _randn(4, B * P, Kc, dtype=torch.bfloat16)
+    got = ops.wgrad(g.view(-1, D), cols, yskip=P, rows=B * P)
+    want = g[:, 1:].reshape(-1, D).float().t() @ cols.float()
+    assert float((got - want).abs().max()) <= 2e-4 * float(want.abs().max())
+    gotb = ops.colsum(g.view(-1, D), yskip=P, rows=B * P)
+    wantb = g[:, 1:].reshape(-1, D).float().sum(0)
+    assert float((gotb - wantb).abs().max()) <= 2e-4 * float(wantb.abs().max())
+
+
+@pytest.mark.parametrize("M,N", [(7, 8), (50432, 1536), (1000, 1000), (513, 384)])
+def test_colsum(ops, M, N):
+    dy = _randn(5, M, N, dtype=torch.bfloat16)
+    got = ops.colsum(dy)
+    want = dy.float().sum(0)
+    assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-5
+    assert torch.equal(ops.colsum(dy), got)
+
+
+def test_gelu_forward_matches_fused_epilogue_and_backward_matches_autograd(ops):
+    M, K, N = 300, 128, 256
+    a = _randn(6, M, K, dtype=torch.bfloat16)
+    w = _randn(7, N, K, scale=0.2, dtype=torch.bfloat16)
+    bias = _randn(8, N)
+    pre = ops.gemm(a, w, bias, ops.TR_EPI_BF16)
+    assert torch.equal(ops.gelu(pre), ops.gemm(a, w, bias, ops.TR_EPI_GELU_BF16)) or \
+        float((ops.gelu(pre).float() - ops.gemm(a, w, bias, ops.TR_EPI_GELU_BF16).float()).abs().max()) <= 2.0 ** -7 * 4
+    x = _randn(9, 1000, 64, scale=2.0, dtype=torch.bfloat16)
+    dh = _randn(10, 1000, 64, dtype=torch.bfloat16)
+    xf = x.float().requires_grad_(True)
+    torch.nn.functional.gelu(xf).backward(dh.float())
+    got = ops.gelu_bwd(x, dh.clone()).float()
+    assert float((got - xf.grad).abs().max()) <= 2.0 ** -8 * float(xf.grad.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("M,D", [(50, 384), (1001, 768), (4100, 192), (300, 128), (64, 1024)])
+def test_layernorm_bwd(ops, M, D):
+    x = _randn(11, M, D, scale=2.0) + 0.5
+    gamma = (_randn(12, D) * 0.3 + 1.0).contiguous()
+    dy = _randn(13, M, D, dtype=torch.bfloat16)
+    g_in = _randn(14, M, D)
+    eps = 1e-6
+    xf = x.clone().requires_grad_(True)
+    gf = gamma.clone().requires_grad_(True)
+    bf = torch.zeros(D, device="cuda", requires_grad=True)
+    torch.nn.functional.layer_norm(xf, (D,), gf, bf, eps).backward(dy.float())
+    g, gb, dgamma, dbeta = ops.layernorm_bwd(dy, x, gamma, eps, g_in=g_in)
+    want = g_in + xf.grad
+    assert float((g - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    assert float((gb.float() - want).abs().max()) <= 2.0 ** -8 * float(want.abs().max())
+    assert float((dgamma - gf.grad).abs().max()) <= 2e-4 * float(gf.grad.abs().max())
+    assert float((dbeta - bf.grad).abs().max()) <= 2e-4 * float(bf.grad.abs().max()) + 1e-5
+    g2, _, _, _ = ops.layernorm_bwd(dy, x, gamma, eps)          # no incoming gradient
+    assert float((g2 - xf.grad).abs().max()) <= 1e-4 * float(xf.grad.abs().max())
+
+
+@pytest.mark.parametrize("fused", [False, True])
+def test_layernorm_bwd_scatter(ops, fused):
+    """Backward of gather -> LayerNorm (topk.py:89-95): rows land at 1 + idx, dropped rows stay zero, EViT's fused row goes aside."""
+    B, N, K, D = 3, 50, 20, 384
+    n_in = K + 1 + (1 if fused else 0)
+    g0 = torch.Generator().manual_seed(1)
+    idx = torch.stack([torch.randperm(N - 1, generator=g0)[:K] for _ in range(B)]).to(torch.int32).cuda()
+    x = _randn(15, B * n_in, D)
+    gamma = (_randn(16, D) * 0.2 + 1.0).contiguous()
+    dy = _randn(17, B * n_in, D, dtype=torch.bfloat16)
+    g_in = _randn(18, B * n_in, D)
+    xf = x.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xf, (D,), gamma, None, 1e-6).backward(dy.float())
+    rows = (g_in + xf.grad).view(B, n_in, D)
+    want = torch.zeros(B, N, D, device="cuda")
+    want[:, 0] = rows[:, 0]
+    for b in range(B):
+        want[b, 1 + idx[b].long()] = rows[b, 1:K + 1]
+    out = ops.layernorm_bwd(dy, x, gamma, 1e-6, g_in=g_in, idx=idx, n_out=N, fused=fused)
+    g = out[0].view(B, N, D)
+    assert float((g - want).abs().max()) <= 1e-4 * float(want.abs().max())
+    assert float((out[1].float().view(B, N, D) - want).abs().max()) <= 2.0 ** -8 * float(want.abs().max())
+    if fused:
+        assert float((out[4] - rows[:, K + 1]).abs().max()) <= 1e-4 * float(want.abs().max())
+
+
+def _attn_ref(qkv, B, N, H, size=None):
+    q, k, v = qkv.view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q @ k.transpose(-1, -2)) * 0.125
+    if size is not None:
+        s = s + size.log()[:, None, None, :]
+    p = s.softmax(-1)
+    return (p @ v).transpose(1, 2).reshape(B * N, H * 64), p
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 197, 6), (3, 50, 3), (1, 224, 2), (2, 17, 1), (2, 139, 12), (1, 64, 1), (4, 98, 3)])
+@pytest.mark.parametrize("bias", [False, True])
+def test_attention_bwd(ops, B, N, H, bias):
+    qkv = _randn(20, B * N, 3 * H * 64, dtype=torch.bfloat16)
+    dout = _randn(21, B * N, H * 64, dtype=torch.bfloat16)
+    size = None
+    if bias:
+        size = (torch.rand(B, N, generator=torch.Generator().manual_seed(3)) * 3 + 1).floor().cuda()
+        size[:, -1] = 0.0 if N > 20 else 1.0          # a masked key (ATS / heuristic masks are log 0)
+    qf = qkv.float().requires_grad_(True)
+    out, _ = _attn_ref(qf, B, N, H, size)
+    out.backward(dout.float())
+    got = ops.attention_bwd(qkv, dout, B, N, H, size=size)
+    want = qf.grad.view(B * N, 3, H * 64)
+    gv = got.float().view(B * N, 3, H * 64)
+    for i, nm in enumerate("qkv"):
+        r = rel_l2(gv[:, i], want[:, i])
+        # P and dS pass through bf16 (2^-9 relative rounding each) before the three products; the result is rounded to bf16
+        assert r <= 1.2e-2, f"d{nm}: rel L2 {r:.3e}"
+
+
+def test_attention_bwd_cls_gradient(ops):
+    """EViT: extra gradient on the head-mean CLS attention row (evit.py:117-120)."""
+    B, N, H = 2, 139, 6
+    qkv = _randn(22, B * N, 3 * H * 64, dtype=torch.bfloat16)
+    dout = _randn(23, B * N, H * 64, scale=0.1, dtype=torch.bfloat16)
+    dcls = _randn(24, B, N)
+    dcls[:, 0] = 0
+    qf = qkv.float().requires_grad_(True)
+    out, p = _attn_ref(qf, B, N, H)
+    cls_attn = p[:, :, 0, :].mean(1)
+    ((out * dout.float()).sum() + (cls_attn * dcls).sum()).backward()
+    got = ops.attention_bwd(qkv, dout, B, N, H, dcls=dcls).float()
+    assert rel_l2(got, qf.grad) <= 1.2e-2
+
+
+def test_head_and_embed_bwd(ops):
+    B, Cc, D, N = 32, 1000, 384, 68
+    dl = _randn(25, B, Cc, scale=0.01)
+    w = _randn(26, Cc, D, scale=0.02, dtype=torch.bfloat16)
+    xn = _randn(27, B, D, dtype=torch.bfloat16)
+    dxn, dw, db = ops.head_bwd(dl, w, xn)
+    assert float((dxn.float() - dl @ w.float()).abs().max()) <= 2.0 ** -8 * float((dl @ w.float()).abs().max())
+    assert float((dw - dl.t() @ xn.float()).abs().max()) <= 1e-4 * float((dl.t() @ xn.float()).abs().max())
+    assert float((db - dl.sum(0)).abs().max()) <= 1e-5
+    g = _randn(28, B, N, D)
+    dpos, dcls = ops.embed_bwd(g)
+    assert float((dpos - g.sum(0)).abs().max()) <= 1e-4 * float(g.sum(0).abs().max())
+    assert float((dcls - g[:, 0].sum(0)).abs().max()) <= 1e-4 * float(g.sum(0).abs().max())
+
+
+def test_evit_fuse_bwd(ops):
+    B, N, K, D = 3, 60, 25, 384
+    P = N - 1
+    x = _randn(30, B, N, D)
+    delta = _randn(31, B, N, D, dtype=torch.bfloat16)
+    scores = torch.rand(B, P, generator=torch.Generator().manual_seed(5)).cuda()
+    g0 = torch.Generator().manual_seed(2)
+    perm = torch.stack([torch.randperm(P, generator=g0) for _ in range(B)])
+    compl = perm[:, K:].sort(dim=1).values.to(torch.int32).cuda()
+    g_fused = _randn(32, B, D)
+    xm = (x + delta.float()).requires_grad_(True)
+    sc = scores.clone().requires_grad_(True)
+    rows = torch.gather(xm[:, 1:], 1, compl.long()[..., None].expand(-1, -1, D))
+    wts = torch.gather(sc, 1, compl.long())
+    extra = (rows * wts[..., None]).sum(1)
+    (extra * g_fused).sum().backward()
+    g_out = torch.zeros(B, N, D, device="cuda")
+    gb_out = torch.zeros(B, N, D, dtype=torch.bfloat16, device="cuda")
+    dscore = ops.evit_fuse_bwd(x, delta, compl, scores, g_fused, g_out, gb_out)
+    assert float((g_out - xm.grad).abs().max()) <= 1e-5 * float(xm.grad.abs().max()) + 1e-7
+    assert float((dscore[:, 1:] - sc.grad).abs().max()) <= 1e-4 * float(sc.grad.abs().max())
+
+
+def test_tome_merge_bwd(ops):
+    B, N, r, D = 2, 51, 9, 384
+    na, nb = (N + 1) // 2, N // 2
+    g0 = torch.Generator().manual_seed(7)
+    x = _randn(33, B, N, D)
+    size_in = (torch.rand(B, N, generator=g0) * 3 + 1).floor().cuda()
+    unm, src, dst = [], [], []
+    for b in range(B):
+        perm = torch.randperm(na - 1, generator=g0) + 1           # A-tokens 1.. (0 = CLS stays unmerged)
+        src.append(perm[:r])
+        unm.append(torch.cat([torch.zeros(1, dtype=torch.long), perm[r:]]).sort().values)
+        dst.append(torch.randint(0, nb, (r,), generator=g0))
+    unm, src, dst = (torch.stack(t).to(torch.int32).cuda() for t in (unm, src, dst))
+    xf = x.clone().requires_grad_(True)
+    xs = xf * size_in[..., None]
+    a_x, b_x = xs[:, 0::2], xs[:, 1::2]
+    a_s, b_s = size_in[:, 0::2], size_in[:, 1::2]
+    outs, sizes = [], []
+    for b in range(B):
+        bx = b_x[b].index_add(0, dst[b].long(), a_x[b, src[b].long()])
+        bs = b_s[b].index_add(0, dst[b].long(), a_s[b, src[b].long()])
+        outs.append(torch.cat([a_x[b, unm[b].long()], bx]))
+        sizes.append(torch.cat([a_s[b, unm[b].long()], bs]))
+    size_out = torch.stack(sizes)
+    x_out = torch.stack(outs) / size_out[..., None]
+    gm = _randn(34, B, N - r, D)
+    (x_out * gm).sum().backward()
+    g, gb = ops.tome_merge_bwd(gm, size_in, size_out.contiguous(), unm, src, dst, N)
+    assert float((g - xf.grad).abs().max()) <= 1e-5 * float(xf.grad.abs().max())
+    assert float((gb.float() - xf.grad).abs().max()) <= 2.0 ** -8 * float(xf.grad.abs().max())

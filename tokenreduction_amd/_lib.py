@@ -81,6 +81,20 @@ SIGNATURES = {
     "tr_cluster_merge_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "tr_broadcast_rows": (_i, [_vp, _vp, _i, _i, _vp]),
     "tr_residual_snapshot": (_i, [_vp, _vp, _i, _vp, _sz, _vp]),
+    "tr_wgrad_workspace_floats": (_sz, [_i, _i, _i]),
+    "tr_wgrad_bf16": (_i, [_vp, _l, _i, _vp, _l, _vp, _i, _vp, _sz, _i, _i, _i, _vp]),
+    "tr_colsum_workspace_floats": (_sz, [_i, _i]),
+    "tr_colsum_bf16": (_i, [_vp, _l, _i, _vp, _i, _vp, _sz, _i, _i, _vp]),
+    "tr_gelu_bf16": (_i, [_vp, _vp, _sz, _vp]),
+    "tr_gelu_bwd_bf16": (_i, [_vp, _vp, _sz, _vp]),
+    "tr_layernorm_bwd_workspace_floats": (_sz, [_i, _i]),
+    "tr_layernorm_bwd": (_i, [_vp, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _i, _i, _f, _vp]),
+    "tr_attention_bwd_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "tr_head_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "tr_embed_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "tr_evit_fuse_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "tr_tome_merge_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "tr_f32_to_bf16": (_i, [_vp, _vp, _sz, _vp]),
     "tr_vit_forward": (_i, [C.POINTER(TrVitConfig), C.POINTER(TrVitWeights), _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp,
                             C.POINTER(_i), _i, _vp]),
 }

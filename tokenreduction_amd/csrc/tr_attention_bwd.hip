@@ -1,0 +1,313 @@
+// Backward of multi-head self-attention (head_dim 64, N <= 224 tokens) on gfx950 MFMA.
+//
+// Gradient of  attn = softmax(q k^T * dh^-0.5 [+ log size]); out = attn @ v   (topk.py:44-51, tome.py:41-58) with respect to
+// q, k, v, given d out -- what torch.autograd derives for the reference's eager ops -- plus EViT's extra path: the fused token
+// multiplies by cls_attn = attn[:, :, 0, 1:].mean(1) (evit.py:117-120), so d cls_attn / H is added to dP of query 0.
+//
+// Flash-style: nothing of the N x N matrix is kept by the forward; P is recomputed here from q, k (the whole score row of a
+// query fits the register file at N <= 224, so the row maximum and normaliser are recomputed exactly, no saved LSE).
+// One workgroup (4 waves, one per SIMD) per (image, head):
+//   K, V of all keys stay in LDS (row-major images, read by rows for S and dP and TRANSPOSED -- ds_read_b64_tr_b16 -- for dQ);
+//   queries go in blocks of 64 (wave w owns rows 16w .. 16w+15 of a block):
+//     S^T = K Q^T, dP^T = V dO^T       key on the accumulator ROW: a lane holds 4 consecutive keys of one query, so the
+//                                       softmax is lane-local + two shuffles, and P / dS go to LDS as 8-byte writes
+//     p = softmax, delta = sum_j p dp, ds = p (dp - delta) * dh^-0.5
+//     dQ^T = K^T dS^T                  (each wave on its own 16 queries; 8-byte stores of 4 consecutive d)
+//     dK^T += Q^T dS, dV^T += dO^T P   accumulated in registers over the query blocks, key tiles split over the waves
+// LDS images use one swizzle each that is conflict-free for both the 16-byte row reads and the transposed reads
+// (searched with tools/lds_sim.py): 128-B rows: chunk ^ (row bit1 << 1 | row bit3 << 2); 512-B rows (P, dS): chunk ^ f16(row).
+#include "tr_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+__device__ __forceinline__ bf16x8 lds_tr_pair(const unsigned char* p0, const unsigned char* p1) {
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p1));
+  const s16x8 c = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, c);
+}
+
+// [rows][64 bf16] image, 128-B rows
+__device__ __forceinline__ int qswz(int row, int ch) { return row * 128 + ((ch ^ ((((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2))) << 4); }
+// [64 rows][256 bf16] image, 512-B rows
+__device__ __forceinline__ int pswz(int row, int ch) { return row * 512 + ((ch ^ ((row & 15) ^ ((0 - (row & 1)) & 14))) << 4); }
+
+template <int NKB, bool BIAS>
+__global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dO,
+                                                               const float* __restrict__ size, const float* __restrict__ dcls,
+                                                               uint16_t* __restrict__ dqkv, int N, int H) {
+  constexpr int NP = NKB * 32;       // padded key count
+  constexpr int NT = NKB * 2;        // 16-key tiles
+  constexpr int KT_W = (NT + 3) / 4; // key tiles a wave accumulates dK / dV for
+  __shared__ __attribute__((aligned(16))) unsigned char sK[NP * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char sV[NP * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char sQ[64 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char sDO[64 * 128];
+  __shared__ __attribute__((aligned(16))) unsigned char sP[64 * 512];
+  __shared__ __attribute__((aligned(16))) unsigned char sDS[64 * 512];
+  __shared__ __attribute__((aligned(16))) float sLB[NP];     // log2(size[key]) (ToMe / key masks), 0 without sizes
+  __shared__ __attribute__((aligned(16))) float sDC[NP];     // d cls_attn[key] / H (EViT), 0 otherwise
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int ldq = 3 * H * 64, ldo = H * 64;
+  const uint16_t* base = qkv + (size_t)b * N * ldq;
+  const uint16_t* dobase = dO + (size_t)b * N * ldo + h * 64;
+  uint16_t* dbase = dqkv + (size_t)b * N * ldq;
+  const int qcol = h * 64, kcol = H * 64 + h * 64, vcol = 2 * H * 64 + h * 64;
+
+  // ---- stage K and V (keys >= N: zero rows); all loads first, then the LDS writes
+  {
+    uint4 kreg[NKB], vreg[NKB];
+#pragma unroll
+    for (int it = 0; it < NKB; ++it) {
+      const int c = tid + 256 * it, key = c >> 3, ch = c & 7;
+      kreg[it] = *reinterpret_cast<const uint4*>(base + (size_t)min(key, N - 1) * ldq + kcol + ch * 8);
+      vreg[it] = *reinterpret_cast<const uint4*>(base + (size_t)min(key, N - 1) * ldq + vcol + ch * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < NKB; ++it) {
+      const int c = tid + 256 * it, key = c >> 3, ch = c & 7;
+      if (key >= N) {
+        kreg[it] = make_uint4(0u, 0u, 0u, 0u);
+        vreg[it] = make_uint4(0u, 0u, 0u, 0u);
+      }
+      *reinterpret_cast<uint4*>(sK + qswz(key, ch)) = kreg[it];
+      *reinterpret_cast<uint4*>(sV + qswz(key, ch)) = vreg[it];
+    }
+    for (int key = tid; key < NP; key += 256) {
+      sLB[key] = (BIAS && key < N) ? __builtin_amdgcn_logf(size[(size_t)b * N + key]) : 0.f;     // v_log_f32 = log2
+      sDC[key] = (dcls != nullptr && key < N) ? dcls[(size_t)b * N + key] / (float)H : 0.f;
+    }
+  }
+
+  const int g = lane >> 4, li = lane & 15, q4 = li >> 2, p4 = li & 3;
+  const float c_exp = 0.125f * 1.44269504088896340736f;    // dh^-0.5 * log2(e)
+
+  f32x4 dk[KT_W][4], dv[KT_W][4];
+#pragma unroll
+  for (int t = 0; t < KT_W; ++t)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      dk[t][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dv[t][d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+  const int nqb = (N + 63) >> 6;
+  for (int qb = 0; qb < nqb; ++qb) {
+    // ---- stage this block's Q and dO rows (rows >= N: zero)
+    {
+      uint4 qreg[2], oreg[2];
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int c = tid + 256 * it, r = c >> 3, ch = c & 7;
+        const int i = qb * 64 + r;
+        qreg[it] = *reinterpret_cast<const uint4*>(base + (size_t)min(i, N - 1) * ldq + qcol + ch * 8);
+        oreg[it] = *reinterpret_cast<const uint4*>(dobase + (size_t)min(i, N - 1) * ldo + ch * 8);
+      }
+      __syncthreads();                // every wave is done with the previous block's Q, dO, P, dS images
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int c = tid + 256 * it, r = c >> 3, ch = c & 7;
+        if (qb * 64 + r >= N) {
+          qreg[it] = make_uint4(0u, 0u, 0u, 0u);
+          oreg[it] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        *reinterpret_cast<uint4*>(sQ + qswz(r, ch)) = qreg[it];
+        *reinterpret_cast<uint4*>(sDO + qswz(r, ch)) = oreg[it];
+      }
+      __syncthreads();
+    }
+
+    // ---- phase 1: this wave's 16 queries (rows 16*wave + li of the block) against all keys
+    const int il = 16 * wave + li;                      // query row inside the block (this lane's accumulator column)
+    const int iq = qb * 64 + il;                        // global query index
+    bf16x8 qf[2], of[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[ks] = *reinterpret_cast<const bf16x8*>(sQ + qswz(il, 4 * ks + g));
+      of[ks] = *reinterpret_cast<const bf16x8*>(sDO + qswz(il, 4 * ks + g));
+    }
+    f32x4 sacc[NT], dpacc[NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      sacc[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      dpacc[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 kf = *reinterpret_cast<const bf16x8*>(sK + qswz(16 * jt + li, 4 * ks + g));
+        const bf16x8 vf = *reinterpret_cast<const bf16x8*>(sV + qswz(16 * jt + li, 4 * ks + g));
+        sacc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], sacc[jt], 0, 0, 0);     // S^T[key 4g+r][query li]
+        dpacc[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, of[ks], dpacc[jt], 0, 0, 0);   // dP^T
+      }
+    }
+    // softmax over the keys of query li: registers (jt, r) of this lane and the lanes li + 16, 32, 48
+    float mx = -INFINITY;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      const float4 lb = *reinterpret_cast<const float4*>(&sLB[16 * jt + 4 * g]);
+      const float lbv[4] = {lb.x, lb.y, lb.z, lb.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float t = sacc[jt][r] * c_exp + lbv[r];
+        if (16 * jt + 4 * g + r >= N) t = -INFINITY;
+        sacc[jt][r] = t;
+        mx = fmaxf(mx, t);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (mx == -INFINITY) mx = 0.f;                      // every key masked: all weights 0 (as the forward)
+    float l = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pe = __builtin_amdgcn_exp2f(sacc[jt][r] - mx);
+        sacc[jt][r] = pe;
+        l += pe;
+      }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    float dl = 0.f;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      const float4 dc = *reinterpret_cast<const float4*>(&sDC[16 * jt + 4 * g]);
+      const float dcv[4] = {dc.x, dc.y, dc.z, dc.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float pn = sacc[jt][r] * inv;
+        sacc[jt][r] = pn;
+        if (iq == 0) dpacc[jt][r] += dcv[r];             // EViT: d cls_attn reaches the CLS query's row (key 0 carries 0)
+        dl += pn * dpacc[jt][r];
+      }
+    }
+    dl += __shfl_xor(dl, 16, 64);
+    dl += __shfl_xor(dl, 32, 64);
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      uint2 pp, ds;
+      const float d0 = sacc[jt][0] * (dpacc[jt][0] - dl) * 0.125f, d1 = sacc[jt][1] * (dpacc[jt][1] - dl) * 0.125f;
+      const float d2 = sacc[jt][2] * (dpacc[jt][2] - dl) * 0.125f, d3 = sacc[jt][3] * (dpacc[jt][3] - dl) * 0.125f;
+      pp.x = pack_bf16x2(sacc[jt][0], sacc[jt][1]);
+      pp.y = pack_bf16x2(sacc[jt][2], sacc[jt][3]);
+      ds.x = pack_bf16x2(d0, d1);
+      ds.y = pack_bf16x2(d2, d3);
+      const int off = pswz(il, 2 * jt + (g >> 1)) + 8 * (g & 1);     // keys 16jt + 4g .. +3 of row il
+      *reinterpret_cast<uint2*>(sP + off) = pp;
+      *reinterpret_cast<uint2*>(sDS + off) = ds;
+    }
+    // ---- dQ^T[d][query] = sum_key K[key][d] dS[query][key]: own rows only (LDS operations of one wave are ordered)
+    {
+      f32x4 dq[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) dq[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NKB; ++ks) {
+        const bf16x8 dsf = *reinterpret_cast<const bf16x8*>(sDS + pswz(il, 4 * ks + g));          // B[k = key][col = query]
+        const int r0 = 32 * ks + 8 * g + q4;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const int ch = 2 * d + (p4 >> 1);
+          const bf16x8 ktf = lds_tr_pair(sK + qswz(r0, ch) + 8 * (p4 & 1), sK + qswz(r0 + 4, ch) + 8 * (p4 & 1));   // A[row = d][k = key]
+          dq[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf, dsf, dq[d], 0, 0, 0);
+        }
+      }
+      if (iq < N) {
+        uint16_t* qrow = dbase + (size_t)iq * ldq + qcol + 4 * g;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          uint2 pk;
+          pk.x = pack_bf16x2(dq[d][0], dq[d][1]);
+          pk.y = pack_bf16x2(dq[d][2], dq[d][3]);
+          *reinterpret_cast<uint2*>(qrow + 16 * d) = pk;
+        }
+      }
+    }
+    __syncthreads();                  // P and dS rows of all four waves are in LDS
+    // ---- phase 2: dK^T[d][key] += sum_query Q[query][d] dS[query][key], dV^T[d][key] += sum_query dO[query][d] P[query][key]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int r0 = 32 * ks + 8 * g + q4;
+      bf16x8 qt[4], ot[4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int ch = 2 * d + (p4 >> 1);
+        qt[d] = lds_tr_pair(sQ + qswz(r0, ch) + 8 * (p4 & 1), sQ + qswz(r0 + 4, ch) + 8 * (p4 & 1));       // A[row = d][k = query]
+        ot[d] = lds_tr_pair(sDO + qswz(r0, ch) + 8 * (p4 & 1), sDO + qswz(r0 + 4, ch) + 8 * (p4 & 1));
+      }
+#pragma unroll
+      for (int t = 0; t < KT_W; ++t) {
+        const int jt = wave + 4 * t;
+        if (jt < NT) {                  // wave-uniform
+          const int ch = 2 * jt + (p4 >> 1);
+          const bf16x8 dsf = lds_tr_pair(sDS + pswz(r0, ch) + 8 * (p4 & 1), sDS + pswz(r0 + 4, ch) + 8 * (p4 & 1));   // B[k = query][col = key]
+          const bf16x8 pf = lds_tr_pair(sP + pswz(r0, ch) + 8 * (p4 & 1), sP + pswz(r0 + 4, ch) + 8 * (p4 & 1));
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            dk[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt[d], dsf, dk[t][d], 0, 0, 0);
+            dv[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ot[d], pf, dv[t][d], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // ---- dK, dV rows: accumulator (t, d): rows d-index 16d + 4g + r, column key 16*(wave + 4t) + li
+#pragma unroll
+  for (int t = 0; t < KT_W; ++t) {
+    const int key = 16 * (wave + 4 * t) + li;
+    if (wave + 4 * t < NT && key < N) {
+      uint16_t* krow = dbase + (size_t)key * ldq + kcol + 4 * g;
+      uint16_t* vrow = dbase + (size_t)key * ldq + vcol + 4 * g;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        uint2 pk;
+        pk.x = pack_bf16x2(dk[t][d][0], dk[t][d][1]);
+        pk.y = pack_bf16x2(dk[t][d][2], dk[t][d][3]);
+        *reinterpret_cast<uint2*>(krow + 16 * d) = pk;
+        pk.x = pack_bf16x2(dv[t][d][0], dv[t][d][1]);
+        pk.y = pack_bf16x2(dv[t][d][2], dv[t][d][3]);
+        *reinterpret_cast<uint2*>(vrow + 16 * d) = pk;
+      }
+    }
+  }
+}
+
+template <int NKB>
+int launch_bwd(const uint16_t* qkv, const uint16_t* dO, const float* size, const float* dcls, uint16_t* dqkv, int B, int N, int H,
+               hipStream_t st) {
+  if (size != nullptr)
+    hipLaunchKernelGGL((attention_bwd_kernel<NKB, true>), dim3(B * H), dim3(256), 0, st, qkv, dO, size, dcls, dqkv, N, H);
+  else
+    hipLaunchKernelGGL((attention_bwd_kernel<NKB, false>), dim3(B * H), dim3(256), 0, st, qkv, dO, size, dcls, dqkv, N, H);
+  return 0;
+}
+
+}  // namespace
+
+// d qkv [B*N, 3*H*64] (bf16) from d out [B*N, H*64] (bf16) and the forward's qkv.  size (nullable) fp32 [B,N]: the key bias the
+// forward used (log size, or a 1/0 key mask).  dcls (nullable) fp32 [B,N]: gradient wrt the head-MEAN of the CLS query's softmax
+// row (evit.py:117-120; entry 0 = the CLS key must be 0) -- added / H to every head's dP row 0.  N <= 224.
+extern "C" int tr_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, const float* size, const float* dcls, uint16_t* dqkv,
+                                     int B, int N, int H, tr_stream_t s) {
+  TR_REQUIRE(qkv && dout && dqkv, TR_ERR_NULL, "tr_attention_bwd_bf16: null pointer");
+  TR_REQUIRE(B > 0 && H > 0 && N >= 1, TR_ERR_SHAPE, "tr_attention_bwd_bf16: bad shape B=%d N=%d H=%d", B, N, H);
+  TR_REQUIRE(N <= 224, TR_ERR_SHAPE, "tr_attention_bwd_bf16: N=%d > 224 (training at 384^2 inputs is not built)", N);
+  TR_REQUIRE(tr_aligned16(qkv) && tr_aligned16(dout) && tr_aligned16(dqkv), TR_ERR_ALIGN, "tr_attention_bwd_bf16: pointers must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(s);
+  switch ((N + 31) / 32) {
+    case 1: launch_bwd<1>(qkv, dout, size, dcls, dqkv, B, N, H, st); break;
+    case 2: launch_bwd<2>(qkv, dout, size, dcls, dqkv, B, N, H, st); break;
+    case 3: launch_bwd<3>(qkv, dout, size, dcls, dqkv, B, N, H, st); break;
+    case 4: launch_bwd<4>(qkv, dout, size, dcls, dqkv, B, N, H, st); break;
+    case 5: launch_bwd<5>(qkv, dout, size, dcls, dqkv, B, N, H, st); break;
+    case 6: launch_bwd<6>(qkv, dout, size, dcls, dqkv, B, N, H, st); break;
+    default: launch_bwd<7>(qkv, dout, size, dcls, dqkv, B, N, H, st); break;
+  }
+  TR_CHECK_LAUNCH("tr_attention_bwd_bf16");
+  return TR_OK;
+}

@@ -1,0 +1,661 @@
+// Backward kernels of the DeiT block for gfx950 (the training half of the hot path: engine.py:50-76 fwd -> loss -> backward).
+//
+// The reference's backward is whatever torch.autograd derives from the eager forward (topk.py:83-99, timm Mlp, nn.LayerNorm,
+// nn.Linear); these kernels are the hand-written gradients of the SAME forward the HIP executor runs:
+//   tr_wgrad_bf16        dW[N,K] (+)= dY[M,N]^T X[M,K]        (nn.Linear weight gradient; MFMA, both operands read TRANSPOSED
+//                                                              from row-major LDS images with ds_read_b64_tr_b16, split over M)
+//   tr_colsum_bf16       db[N]  (+)= sum_m dY[m,n]             (nn.Linear bias gradient)
+//   tr_gelu_bf16 / tr_gelu_bwd_bf16                            (timm Mlp act: the training forward keeps the pre-activation)
+//   tr_layernorm_bwd     g (+)= dLN(dy; x, gamma), d_gamma, d_beta, bf16 copy of g for the next GEMMs; optional row scatter
+//                        (the backward of the Top-K gather topk.py:89-93 and of EViT's fused token evit.py:111-123)
+//   tr_head_bwd          classifier nn.Linear on the CLS rows (topk.py:203)
+//   tr_embed_bwd         d pos_embed / d cls_token (topk.py:183-186)
+//   tr_evit_fuse_bwd     gradient of extra = sum_j x[compl_j] * cls_attn[compl_j] (evit.py:117-120) wrt x rows and wrt cls_attn
+//   tr_tome_merge_bwd    gradient of merge_wavg (tome.py:309-323) wrt x
+// dgrad (dX = dY W) reuses tr_gemm_bf16 on a transposed copy of W.  All reductions over tokens are two-stage with fixed
+// summation order (per-workgroup partials + one reduce kernel): results are bitwise reproducible run to run, no float atomics.
+#include "tr_common.h"
+#include "tr_rowops.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+// two transposed 4x16 block reads -> one 16x16x32 MFMA operand (8 bf16: k = 8*(lane>>4) + e, row/col = lane&15); cdna guide T10
+__device__ __forceinline__ bf16x8 lds_tr_pair(const unsigned char* p0, const unsigned char* p1) {
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p1));
+  const s16x8 c = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, c);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient.  Output tile 128 (dW rows = dY columns) x 128 (dW columns = X columns); the token dimension is walked in
+// slabs of 64 rows and split over blockIdx.y.  LDS image of a slab: [64 tokens][128 columns] bf16 = 256-B rows, 16-byte chunk
+// index XOR ((row&3)<<2 | (row>>2)&3) -- conflict-free for the transposed reads (cdna guide T10, image (b)).
+constexpr int WB = 128, WM = 64;
+__device__ __forceinline__ int wswz(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const uint16_t* __restrict__ Y, long ldy, int yskip,
+                                                       const uint16_t* __restrict__ X, long ldx, float* __restrict__ part, int M,
+                                                       int N, int K, int nNt, int sps) {
+  __shared__ __attribute__((aligned(16))) unsigned char sm[2][2][WM * 256];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int n0 = (blockIdx.x % nNt) * WB, k0 = (blockIdx.x / nNt) * WB;
+  const int nslab = (M + WM - 1) / WM;
+  const int s_begin = blockIdx.y * sps, s_end = min(nslab, s_begin + sps);
+
+  int srow[4], sch[4];
+  size_t ycol[4], xcol[4];
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int c = tid + 256 * it;
+    srow[it] = c >> 4;
+    sch[it] = c & 15;
+    ycol[it] = (size_t)min(n0 + sch[it] * 8, N - 8);     // out-of-range columns: clamped (their outputs are never stored)
+    xcol[it] = (size_t)min(k0 + sch[it] * 8, K - 8);
+  }
+  uint4 yreg[4], xreg[4];
+  auto load_slab = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int m = s * WM + srow[it];
+      const int mc = min(m, M - 1);
+      const size_t my = yskip > 0 ? (size_t)mc + (size_t)(mc / yskip) + 1 : (size_t)mc;   // patch rows of a [B, P+1, D] tensor
+      yreg[it] = *reinterpret_cast<const uint4*>(Y + my * ldy + ycol[it]);
+      xreg[it] = *reinterpret_cast<const uint4*>(X + (size_t)mc * ldx + xcol[it]);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+      if (s * WM + srow[it] >= M) {          // rows past the end contribute zero
+        yreg[it] = make_uint4(0u, 0u, 0u, 0u);
+        xreg[it] = make_uint4(0u, 0u, 0u, 0u);
+      }
+  };
+  auto write_slab = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      *reinterpret_cast<uint4*>(&sm[buf][0][wswz(srow[it], sch[it])]) = yreg[it];
+      *reinterpret_cast<uint4*>(&sm[buf][1][wswz(srow[it], sch[it])]) = xreg[it];
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  if (s_begin < s_end) {
+    load_slab(s_begin);
+    write_slab(0);
+  }
+  __syncthreads();
+  for (int s = s_begin; s < s_end; ++s) {
+    const int buf = (s - s_begin) & 1;
+    if (s + 1 < s_end) load_slab(s + 1);           // global loads of the next slab fly under this slab's MFMAs
+    const unsigned char* sy = &sm[buf][0][0];
+    const unsigned char* sx = &sm[buf][1][0];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int r0 = 32 * ks + 8 * g + q;          // this lane's row of the first 4-row block; the second is 4 rows on
+      bf16x8 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ch = (wn * 64 + i * 16) / 8 + (p >> 1);
+        af[i] = lds_tr_pair(sy + wswz(r0, ch) + 8 * (p & 1), sy + wswz(r0 + 4, ch) + 8 * (p & 1));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ch = (wk * 64 + j * 16) / 8 + (p >> 1);
+        bf[j] = lds_tr_pair(sx + wswz(r0, ch) + 8 * (p & 1), sx + wswz(r0 + 4, ch) + 8 * (p & 1));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (s + 1 < s_end) write_slab(buf ^ 1);
+    __syncthreads();
+  }
+  // partial of this token range: part[split][n][k]; accumulator element r of tile (i,j) = row n 4g+r, column k lane&15
+  float* po = part + (size_t)blockIdx.y * N * K;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + wk * 64 + j * 16 + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 64 + i * 16 + 4 * g + r;
+        if (n < N && k < K) po[(size_t)n * K + k] = acc[i][j][r];
+      }
+    }
+}
+
+// dst[e] = (accumulate ? dst[e] : 0) + sum_s part[s][e]   (fixed order: deterministic)
+__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ part, int S, size_t count, float* __restrict__ dst,
+                                                             int accumulate) {
+  const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e >= count) return;
+  if (e + 4 <= count) {
+    float4 a = accumulate ? *reinterpret_cast<const float4*>(dst + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < S; ++s) {
+      const float4 v = *reinterpret_cast<const float4*>(part + (size_t)s * count + e);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *reinterpret_cast<float4*>(dst + e) = a;
+  } else {
+    for (size_t i = e; i < count; ++i) {
+      float a = accumulate ? dst[i] : 0.f;
+      for (int s = 0; s < S; ++s) a += part[(size_t)s * count + i];
+      dst[i] = a;
+    }
+  }
+}
+
+// column sums of a bf16 matrix: grid (ceil(N/512), S); thread = 2 adjacent columns; part[s][n]
+__global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* __restrict__ Y, long ldy, int yskip, float* __restrict__ part, int M,
+                                                     int N, int rows_per_split) {
+  const int n = blockIdx.x * 512 + threadIdx.x * 2;
+  if (n >= N) return;
+  const int r0 = blockIdx.y * rows_per_split, r1 = min(M, r0 + rows_per_split);
+  float a0 = 0.f, a1 = 0.f;
+  int m = r0;
+  for (; m + 4 <= r1; m += 4) {
+    unsigned int u[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const size_t my = yskip > 0 ? (size_t)(m + t) + (size_t)((m + t) / yskip) + 1 : (size_t)(m + t);
+      u[t] = *reinterpret_cast<const unsigned int*>(Y + my * ldy + n);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      a0 += __uint_as_float(u[t] << 16);
+      a1 += __uint_as_float(u[t] & 0xffff0000u);
+    }
+  }
+  for (; m < r1; ++m) {
+    const size_t my = yskip > 0 ? (size_t)m + (size_t)(m / yskip) + 1 : (size_t)m;
+    const unsigned int u = *reinterpret_cast<const unsigned int*>(Y + my * ldy + n);
+    a0 += __uint_as_float(u << 16);
+    a1 += __uint_as_float(u & 0xffff0000u);
+  }
+  float* po = part + (size_t)blockIdx.y * N + n;
+  po[0] = a0;
+  po[1] = a1;
+}
+
+// ---- GELU: the training forward keeps fc1's pre-activation (bf16) and applies the SAME fit the fused eval epilogue uses
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const uint16_t* __restrict__ pre, uint16_t* __restrict__ h, size_t nchunks) {
+  const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= nchunks) return;
+  const uint4 u = *reinterpret_cast<const uint4*>(pre + 8 * c);
+  const unsigned int w[4] = {u.x, u.y, u.z, u.w};
+  unsigned int o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x2 v = gelu2(f32x2{__uint_as_float(w[i] << 16), __uint_as_float(w[i] & 0xffff0000u)});
+    o[i] = pack_bf16x2(v[0], v[1]);
+  }
+  *reinterpret_cast<uint4*>(h + 8 * c) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// d/dx [x Phi(x)] = Phi(x) + x phi(x)  (exact erf form, nn.GELU)
+__device__ __forceinline__ float gelu_grad(float x) {
+  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const uint16_t* __restrict__ pre, uint16_t* __restrict__ dh, size_t nchunks) {
+  const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= nchunks) return;
+  const uint4 u = *reinterpret_cast<const uint4*>(pre + 8 * c);
+  const uint4 d = *reinterpret_cast<const uint4*>(dh + 8 * c);
+  const unsigned int w[4] = {u.x, u.y, u.z, u.w}, dd[4] = {d.x, d.y, d.z, d.w};
+  unsigned int o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float x0 = __uint_as_float(w[i] << 16), x1 = __uint_as_float(w[i] & 0xffff0000u);
+    const float g0 = __uint_as_float(dd[i] << 16), g1 = __uint_as_float(dd[i] & 0xffff0000u);
+    o[i] = pack_bf16x2(g0 * gelu_grad(x0), g1 * gelu_grad(x1));
+  }
+  *reinterpret_cast<uint4*>(dh + 8 * c) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// LayerNorm backward, one wave per row (rows strided over the grid), fused with the residual stream's gradient:
+//   xhat = (x - mean) * rstd;  dyg = dy * gamma;  dx = rstd * (dyg - mean(dyg) - xhat * mean(dyg * xhat))
+//   g_new[row] = g_in[row] + dx   -> g_out (fp32) and gb_out (bf16: the dY operand of the next dgrad / wgrad GEMMs)
+//   d_gamma += dy * xhat, d_beta += dy   (per-workgroup partials part[2][wg][D], reduced in a second kernel)
+// Row scatter (idx != NULL): the LayerNorm ran on gathered rows [B, K+1(+1)] (topk.py:89-95); row r of image b goes to row
+// (r == 0 ? 0 : 1 + idx[b,r-1]) of the [B, n_out] gradient, and EViT's fused row r == K+1 to g_fused[b] (fp32 [B, D]).
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const uint16_t* __restrict__ dy, const float* __restrict__ x, long ldx,
+                                                     const float* __restrict__ gamma, const float* __restrict__ g_in, long ldgi,
+                                                     float* __restrict__ g_out, long ldgo, uint16_t* __restrict__ gb_out,
+                                                     const int32_t* __restrict__ idx, int K, int n_in, int n_out,
+                                                     float* __restrict__ g_fused, float* __restrict__ part, int M, int D, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunks = D >> 2;
+  float4 gm[NCH], ag[NCH], ab[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    gm[c] = *reinterpret_cast<const float4*>(gamma + 4 * min(lane + 64 * c, nchunks - 1));
+    ag[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    ab[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    float4 v[NCH], d[NCH], gi[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = min(lane + 64 * c, nchunks - 1);
+      v[c] = ln_nt_load4(x + (size_t)row * ldx + 4 * ch);
+      d[c] = bf16x4_to_f32(*reinterpret_cast<const uint2*>(dy + (size_t)row * D + 4 * ch));
+      gi[c] = g_in != nullptr ? ln_nt_load4(g_in + (size_t)row * ldgi + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      if (lane + 64 * c < nchunks) s += (v[c].x + v[c].y) + (v[c].z + v[c].w);
+    const float mean = wave_sum(s) / (float)D;
+    float qv = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      if (lane + 64 * c < nchunks) {
+        v[c].x -= mean; v[c].y -= mean; v[c].z -= mean; v[c].w -= mean;
+        qv += (v[c].x * v[c].x + v[c].y * v[c].y) + (v[c].z * v[c].z + v[c].w * v[c].w);
+      }
+    const float rstd = rsqrtf(wave_sum(qv) / (float)D + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      if (lane + 64 * c < nchunks) {
+        v[c].x *= rstd; v[c].y *= rstd; v[c].z *= rstd; v[c].w *= rstd;                       // xhat
+        ag[c].x += d[c].x * v[c].x; ag[c].y += d[c].y * v[c].y; ag[c].z += d[c].z * v[c].z; ag[c].w += d[c].w * v[c].w;
+        ab[c].x += d[c].x; ab[c].y += d[c].y; ab[c].z += d[c].z; ab[c].w += d[c].w;
+        d[c].x *= gm[c].x; d[c].y *= gm[c].y; d[c].z *= gm[c].z; d[c].w *= gm[c].w;           // dy * gamma
+        s1 += (d[c].x + d[c].y) + (d[c].z + d[c].w);
+        s2 += (d[c].x * v[c].x + d[c].y * v[c].y) + (d[c].z * v[c].z + d[c].w * v[c].w);
+      }
+    const float m1 = wave_sum(s1) / (float)D, m2 = wave_sum(s2) / (float)D;
+    // destination row
+    size_t orow = (size_t)row;
+    bool fused = false;
+    if (idx != nullptr) {
+      const int b = row / n_in, r = row - b * n_in;
+      if (r == K + 1) fused = true;
+      else orow = (size_t)b * n_out + (r == 0 ? 0 : 1 + idx[(size_t)b * K + (r - 1)]);
+    }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunks) {
+        float4 o;
+        o.x = gi[c].x + rstd * (d[c].x - m1 - v[c].x * m2);
+        o.y = gi[c].y + rstd * (d[c].y - m1 - v[c].y * m2);
+        o.z = gi[c].z + rstd * (d[c].z - m1 - v[c].z * m2);
+        o.w = gi[c].w + rstd * (d[c].w - m1 - v[c].w * m2);
+        if (fused) {
+          *reinterpret_cast<float4*>(g_fused + (size_t)(row / n_in) * D + 4 * ch) = o;
+        } else {
+          ln_nt_store4(o, g_out + orow * ldgo + 4 * ch);
+          if (gb_out != nullptr) {
+            uint2 pk;
+            pk.x = pack_bf16x2(o.x, o.y);
+            pk.y = pack_bf16x2(o.z, o.w);
+            *reinterpret_cast<uint2*>(gb_out + orow * D + 4 * ch) = pk;
+          }
+        }
+      }
+    }
+  }
+  // per-workgroup partial of d_gamma / d_beta: waves combined in wave order
+  __shared__ float4 red[3][2][64 * NCH];
+  if (wave > 0) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      red[wave - 1][0][lane + 64 * c] = ag[c];
+      red[wave - 1][1][lane + 64 * c] = ab[c];
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunks) {
+        float4 a = ag[c], b = ab[c];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          const float4 a2 = red[w][0][ch], b2 = red[w][1][ch];
+          a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
+          b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+        }
+        *reinterpret_cast<float4*>(part + (size_t)blockIdx.x * D + 4 * ch) = a;                          // part[0][wg][D]
+        *reinterpret_cast<float4*>(part + ((size_t)gridDim.x + blockIdx.x) * D + 4 * ch) = b;            // part[1][wg][D]
+      }
+    }
+  }
+}
+
+// ---- classifier (topk.py:203) backward on the CLS rows: tiny (B x C x D), fp32 accumulate, one output element per thread
+__global__ __launch_bounds__(256) void head_dx_kernel(const float* __restrict__ dlogits, const uint16_t* __restrict__ W, uint16_t* __restrict__ dxn,
+                                                      int B, int C, int D) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= B * D) return;
+  const int b = t / D, d = t - b * D;
+  float a = 0.f;
+  for (int c = 0; c < C; ++c) a += dlogits[(size_t)b * C + c] * bf16_bits_to_f32(W[(size_t)c * D + d]);
+  dxn[t] = (uint16_t)(pack_bf16x2(a, 0.f) & 0xffffu);
+}
+__global__ __launch_bounds__(256) void head_dw_kernel(const float* __restrict__ dlogits, const uint16_t* __restrict__ xn, float* __restrict__ dW,
+                                                      float* __restrict__ db, int B, int C, int D, int accumulate) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= C * (D + 1)) return;
+  const int c = t / (D + 1), d = t - c * (D + 1);
+  float a = 0.f;
+  if (d < D) {
+    for (int b = 0; b < B; ++b) a += dlogits[(size_t)b * C + c] * bf16_bits_to_f32(xn[(size_t)b * D + d]);
+    float* o = dW + (size_t)c * D + d;
+    *o = accumulate ? *o + a : a;
+  } else {
+    for (int b = 0; b < B; ++b) a += dlogits[(size_t)b * C + c];
+    db[c] = accumulate ? db[c] + a : a;
+  }
+}
+
+// ---- d pos_embed[n][:] = sum_b g[b][n][:], d cls_token = sum_b g[b][0][:]   (topk.py:183-186)
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ g, float* __restrict__ dpos, float* __restrict__ dcls, int B,
+                                                        int N, int D, int accumulate) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int nch = N * (D >> 2);
+  if (t >= nch) return;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b = 0; b < B; ++b) {
+    const float4 v = *reinterpret_cast<const float4*>(g + (size_t)b * N * D + 4 * (size_t)t);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  float4* o = reinterpret_cast<float4*>(dpos + 4 * (size_t)t);
+  float4 r = a;
+  if (accumulate) { const float4 p = *o; r.x += p.x; r.y += p.y; r.z += p.z; r.w += p.w; }
+  *o = r;
+  if (t < (D >> 2)) {
+    float4* oc = reinterpret_cast<float4*>(dcls + 4 * (size_t)t);
+    float4 rc = a;
+    if (accumulate) { const float4 p = *oc; rc.x += p.x; rc.y += p.y; rc.z += p.z; rc.w += p.w; }
+    *oc = rc;
+  }
+}
+
+// ---- EViT fused token backward (evit.py:117-120): extra = sum_j xm[1+c_j] * s[c_j], xm = x + delta (post-attention stream).
+// One workgroup per image; wave w takes complement tokens w, w+4, ...:
+//   g_out[b, 1+c_j, :] = s[c_j] * g_fused[b]   (fp32 + bf16 copy; these rows get no other gradient: the token is dropped)
+//   dscore[b, 1+c_j]   = <xm[1+c_j], g_fused[b]>   (d cls_attn, head-mean -> the attention backward divides by H)
+template <int NCH>
+__global__ __launch_bounds__(256) void evit_fuse_bwd_kernel(const float* __restrict__ x, const uint16_t* __restrict__ delta,
+                                                            const int32_t* __restrict__ compl_idx, const float* __restrict__ scores,
+                                                            const float* __restrict__ g_fused, float* __restrict__ g_out,
+                                                            uint16_t* __restrict__ gb_out, float* __restrict__ dscore, int N, int K, int D) {
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunks = D >> 2, P = N - 1, nc = P - K;
+  float4 gf[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) gf[c] = *reinterpret_cast<const float4*>(g_fused + (size_t)b * D + 4 * min(lane + 64 * c, nchunks - 1));
+  for (int j = wave; j < nc; j += 4) {
+    const int t = compl_idx[(size_t)b * nc + j];
+    const float sc = scores[(size_t)b * P + t];
+    const size_t rbase = ((size_t)b * N + 1 + t) * D;
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunks) {
+        float4 xv = *reinterpret_cast<const float4*>(x + rbase + 4 * ch);
+        if (delta != nullptr) {
+          const float4 dv = bf16x4_to_f32(*reinterpret_cast<const uint2*>(delta + rbase + 4 * ch));
+          xv.x += dv.x; xv.y += dv.y; xv.z += dv.z; xv.w += dv.w;
+        }
+        dot += (xv.x * gf[c].x + xv.y * gf[c].y) + (xv.z * gf[c].z + xv.w * gf[c].w);
+        const float4 o = make_float4(sc * gf[c].x, sc * gf[c].y, sc * gf[c].z, sc * gf[c].w);
+        *reinterpret_cast<float4*>(g_out + rbase + 4 * ch) = o;
+        uint2 pk;
+        pk.x = pack_bf16x2(o.x, o.y);
+        pk.y = pack_bf16x2(o.z, o.w);
+        *reinterpret_cast<uint2*>(gb_out + rbase + 4 * ch) = pk;
+      }
+    }
+    dot = wave_sum(dot);
+    if (lane == 0) dscore[(size_t)b * N + 1 + t] = dot;
+  }
+}
+
+// ---- ToMe merge_wavg backward (tome.py:309-323): x_out[o] = sum_{i in o} x[i] size[i] / size_out[o]
+//   g_in[b, i, :] = size_in[b,i] / size_out[b,o(i)] * g_out_rows[b, o(i), :]        (sizes carry no gradient)
+// One wave per INPUT row; o(i): unmerged A-token -> its rank in unm_idx; B-token (odd position) -> (na - r) + (i >> 1);
+// merged A-token (src) -> the slot of its dst B-token.  inv_map[b][i] is built by the first kernel.
+__global__ __launch_bounds__(256) void tome_invmap_kernel(const int32_t* __restrict__ unm_idx, const int32_t* __restrict__ src_idx,
+                                                          const int32_t* __restrict__ dst_idx, int32_t* __restrict__ inv_map, int N, int r) {
+  const int b = blockIdx.x;
+  const int na = (N + 1) >> 1, nb = N >> 1, nu = na - r;
+  int32_t* im = inv_map + (size_t)b * N;
+  for (int t = threadIdx.x; t < nu; t += 256) im[2 * unm_idx[(size_t)b * nu + t]] = t;
+  for (int t = threadIdx.x; t < nb; t += 256) im[2 * t + 1] = nu + t;
+  for (int t = threadIdx.x; t < r; t += 256) im[2 * src_idx[(size_t)b * r + t]] = nu + dst_idx[(size_t)b * r + t];
+}
+template <int NCH>
+__global__ __launch_bounds__(256) void tome_merge_bwd_kernel(const float* __restrict__ g_merged, const float* __restrict__ size_in,
+                                                             const float* __restrict__ size_out, const int32_t* __restrict__ inv_map,
+                                                             float* __restrict__ g_out, uint16_t* __restrict__ gb_out, int N, int N_out,
+                                                             int D, int M) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int b = row / N, i = row - b * N;
+  const int o = inv_map[(size_t)b * N + i];
+  const float w = (size_in != nullptr ? size_in[(size_t)b * N + i] : 1.0f) / size_out[(size_t)b * N_out + o];
+  const int nchunks = D >> 2;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nchunks) {
+      const float4 v = *reinterpret_cast<const float4*>(g_merged + ((size_t)b * N_out + o) * D + 4 * ch);
+      const float4 ov = make_float4(w * v.x, w * v.y, w * v.z, w * v.w);
+      *reinterpret_cast<float4*>(g_out + (size_t)row * D + 4 * ch) = ov;
+      uint2 pk;
+      pk.x = pack_bf16x2(ov.x, ov.y);
+      pk.y = pack_bf16x2(ov.z, ov.w);
+      *reinterpret_cast<uint2*>(gb_out + (size_t)row * D + 4 * ch) = pk;
+    }
+  }
+}
+
+// fp32 rows -> bf16 rows (the initial gradient of the residual stream as a GEMM operand)
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t nchunks) {
+  const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= nchunks) return;
+  const float4 v = *reinterpret_cast<const float4*>(src + 4 * c);
+  uint2 pk;
+  pk.x = pack_bf16x2(v.x, v.y);
+  pk.y = pack_bf16x2(v.z, v.w);
+  *reinterpret_cast<uint2*>(dst + 4 * c) = pk;
+}
+
+inline int reduce_partials(const float* part, int S, size_t count, float* dst, int accumulate, hipStream_t st) {
+  const unsigned nb = (unsigned)((count / 4 + 1 + 255) / 256);
+  hipLaunchKernelGGL(partial_reduce_kernel, dim3(nb), dim3(256), 0, st, part, S, count, dst, accumulate);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" size_t tr_wgrad_workspace_floats(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int tiles = ((N + WB - 1) / WB) * ((K + WB - 1) / WB);
+  const int nslab = (M + WM - 1) / WM;
+  int S = 1024 / tiles;
+  if (S < 1) S = 1;
+  if (S > nslab) S = nslab;
+  return (size_t)S * N * K;
+}
+
+extern "C" int tr_wgrad_bf16(const uint16_t* dY, long ldy, int yskip, const uint16_t* X, long ldx, float* dW, int accumulate, float* ws,
+                             size_t ws_floats, int M, int N, int K, tr_stream_t s) {
+  TR_REQUIRE(dY && X && dW && ws, TR_ERR_NULL, "tr_wgrad_bf16: null pointer");
+  TR_REQUIRE(M > 0 && N >= 8 && K >= 8 && N % 8 == 0 && K % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0 && ldy >= N && ldx >= K && yskip >= 0,
+             TR_ERR_SHAPE, "tr_wgrad_bf16: need N,K,ldy,ldx multiples of 8 (M=%d N=%d K=%d ldy=%ld ldx=%ld)", M, N, K, ldy, ldx);
+  TR_REQUIRE(tr_aligned16(dY) && tr_aligned16(X) && tr_aligned16(dW) && tr_aligned16(ws), TR_ERR_ALIGN, "tr_wgrad_bf16: pointers must be 16-byte aligned");
+  const int nNt = (N + WB - 1) / WB, nKt = (K + WB - 1) / WB, tiles = nNt * nKt;
+  const int nslab = (M + WM - 1) / WM;
+  int S = 1024 / tiles;
+  if (S < 1) S = 1;
+  if (S > nslab) S = nslab;
+  const size_t fit = ws_floats / ((size_t)N * K);
+  TR_REQUIRE(fit >= 1, TR_ERR_SHAPE, "tr_wgrad_bf16: workspace of %zu floats cannot hold one %d x %d partial", ws_floats, N, K);
+  if ((size_t)S > fit) S = (int)fit;
+  const int sps = (nslab + S - 1) / S;
+  S = (nslab + sps - 1) / sps;                 // every split owns at least one slab
+  hipStream_t st = static_cast<hipStream_t>(s);
+  hipLaunchKernelGGL(wgrad_kernel, dim3(tiles, S), dim3(256), 0, st, dY, ldy, yskip, X, ldx, ws, M, N, K, nNt, sps);
+  TR_CHECK_LAUNCH("tr_wgrad_bf16");
+  reduce_partials(ws, S, (size_t)N * K, dW, accumulate, st);
+  TR_CHECK_LAUNCH("tr_wgrad_bf16 (reduce)");
+  return TR_OK;
+}
+
+extern "C" size_t tr_colsum_workspace_floats(int M, int N) {
+  if (M <= 0 || N <= 0) return 0;
+  int S = (M + 127) / 128;
+  if (S > 256) S = 256;
+  return (size_t)S * N;
+}
+
+extern "C" int tr_colsum_bf16(const uint16_t* dY, long ldy, int yskip, float* db, int accumulate, float* ws, size_t ws_floats, int M,
+                              int N, tr_stream_t s) {
+  TR_REQUIRE(dY && db && ws, TR_ERR_NULL, "tr_colsum_bf16: null pointer");
+  TR_REQUIRE(M > 0 && N > 0 && N % 2 == 0 && ldy % 2 == 0 && ldy >= N && yskip >= 0, TR_ERR_SHAPE, "tr_colsum_bf16: need even N and ldy (M=%d N=%d)", M, N);
+  int S = (M + 127) / 128;
+  if (S > 256) S = 256;
+  if ((size_t)S * N > ws_floats) S = (int)(ws_floats / N);
+  TR_REQUIRE(S >= 1, TR_ERR_SHAPE, "tr_colsum_bf16: workspace too small");
+  const int rps = (M + S - 1) / S;
+  S = (M + rps - 1) / rps;
+  hipStream_t st = static_cast<hipStream_t>(s);
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 511) / 512, S), dim3(256), 0, st, dY, ldy, yskip, ws, M, N, rps);
+  TR_CHECK_LAUNCH("tr_colsum_bf16");
+  reduce_partials(ws, S, (size_t)N, db, accumulate, st);
+  TR_CHECK_LAUNCH("tr_colsum_bf16 (reduce)");
+  return TR_OK;
+}
+
+extern "C" int tr_gelu_bf16(const uint16_t* pre, uint16_t* h, size_t n, tr_stream_t s) {
+  TR_REQUIRE(pre && h, TR_ERR_NULL, "tr_gelu_bf16: null pointer");
+  TR_REQUIRE(n > 0 && n % 8 == 0, TR_ERR_SHAPE, "tr_gelu_bf16: element count must be a positive multiple of 8");
+  TR_REQUIRE(tr_aligned16(pre) && tr_aligned16(h), TR_ERR_ALIGN, "tr_gelu_bf16: pointers must be 16-byte aligned");
+  const size_t nch = n / 8;
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((nch + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(s), pre, h, nch);
+  TR_CHECK_LAUNCH("tr_gelu_bf16");
+  return TR_OK;
+}
+
+extern "C" int tr_gelu_bwd_bf16(const uint16_t* pre, uint16_t* dh, size_t n, tr_stream_t s) {
+  TR_REQUIRE(pre && dh, TR_ERR_NULL, "tr_gelu_bwd_bf16: null pointer");
+  TR_REQUIRE(n > 0 && n % 8 == 0, TR_ERR_SHAPE, "tr_gelu_bwd_bf16: element count must be a positive multiple of 8");
+  TR_REQUIRE(tr_aligned16(pre) && tr_aligned16(dh), TR_ERR_ALIGN, "tr_gelu_bwd_bf16: pointers must be 16-byte aligned");
+  const size_t nch = n / 8;
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((nch + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(s), pre, dh, nch);
+  TR_CHECK_LAUNCH("tr_gelu_bwd_bf16");
+  return TR_OK;
+}
+
+static inline int ln_bwd_grid(int M) {
+  int g = (M + 3) / 4;
+  return g > 1024 ? 1024 : g;
+}
+
+extern "C" size_t tr_layernorm_bwd_workspace_floats(int M, int D) { return (size_t)ln_bwd_grid(M) * 2 * D; }
+
+extern "C" int tr_layernorm_bwd(const uint16_t* dy, const float* x, long ldx, const float* gamma, const float* g_in, long ldgi,
+                                float* g_out, long ldgo, uint16_t* gb_out, const int32_t* idx, int K, int n_in, int n_out,
+                                float* g_fused, float* dgamma, float* dbeta, int accumulate, float* ws, size_t ws_floats, int M, int D,
+                                float eps, tr_stream_t s) {
+  TR_REQUIRE(dy && x && gamma && g_out && dgamma && dbeta && ws, TR_ERR_NULL, "tr_layernorm_bwd: null pointer");
+  TR_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAX_CHUNKS && ldx % 4 == 0 && ldgo % 4 == 0 && (g_in == nullptr || ldgi % 4 == 0),
+             TR_ERR_SHAPE, "tr_layernorm_bwd: need D %% 4 == 0, D <= 1024, strides %% 4 == 0 (M=%d D=%d)", M, D);
+  if (idx != nullptr)
+    TR_REQUIRE(K >= 1 && n_in >= K + 1 && n_in <= K + 2 && n_out >= K + 1 && M % n_in == 0 && (n_in == K + 1 || g_fused != nullptr) && ldgo == D,
+               TR_ERR_SHAPE, "tr_layernorm_bwd: scatter needs n_in in {K+1, K+2}, M %% n_in == 0 (K=%d n_in=%d n_out=%d M=%d)", K, n_in, n_out, M);
+  const int grid = ln_bwd_grid(M);
+  TR_REQUIRE(ws_floats >= (size_t)grid * 2 * D, TR_ERR_SHAPE, "tr_layernorm_bwd: workspace too small (%zu < %zu floats)", ws_floats, (size_t)grid * 2 * D);
+  TR_REQUIRE(tr_aligned16(dy) && tr_aligned16(x) && tr_aligned16(gamma) && tr_aligned16(g_in) && tr_aligned16(g_out) && tr_aligned16(gb_out) &&
+                 tr_aligned16(ws) && tr_aligned16(g_fused),
+             TR_ERR_ALIGN, "tr_layernorm_bwd: pointers must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(s);
+  TR_DISPATCH_NCH(D, hipLaunchKernelGGL((ln_bwd_kernel<NCH>), dim3(grid), dim3(256), 0, st, dy, x, ldx, gamma, g_in, ldgi, g_out, ldgo, gb_out, idx,
+                                        K, n_in, n_out, g_fused, ws, M, D, eps));
+  TR_CHECK_LAUNCH("tr_layernorm_bwd");
+  reduce_partials(ws, grid, (size_t)D, dgamma, accumulate, st);
+  reduce_partials(ws + (size_t)grid * D, grid, (size_t)D, dbeta, accumulate, st);
+  TR_CHECK_LAUNCH("tr_layernorm_bwd (reduce)");
+  return TR_OK;
+}
+
+extern "C" int tr_head_bwd(const float* dlogits, const uint16_t* W, const uint16_t* xn, uint16_t* dxn, float* dW, float* db,
+                           int accumulate, int B, int C, int D, tr_stream_t s) {
+  TR_REQUIRE(dlogits && W && xn && dxn && dW && db, TR_ERR_NULL, "tr_head_bwd: null pointer");
+  TR_REQUIRE(B > 0 && C > 0 && D > 0, TR_ERR_SHAPE, "tr_head_bwd: bad shape B=%d C=%d D=%d", B, C, D);
+  hipStream_t st = static_cast<hipStream_t>(s);
+  hipLaunchKernelGGL(head_dx_kernel, dim3((B * D + 255) / 256), dim3(256), 0, st, dlogits, W, dxn, B, C, D);
+  hipLaunchKernelGGL(head_dw_kernel, dim3((C * (D + 1) + 255) / 256), dim3(256), 0, st, dlogits, xn, dW, db, B, C, D, accumulate);
+  TR_CHECK_LAUNCH("tr_head_bwd");
+  return TR_OK;
+}
+
+extern "C" int tr_embed_bwd(const float* g, float* dpos, float* dcls, int accumulate, int B, int N, int D, tr_stream_t s) {
+  TR_REQUIRE(g && dpos && dcls, TR_ERR_NULL, "tr_embed_bwd: null pointer");
+  TR_REQUIRE(B > 0 && N > 0 && D > 0 && D % 4 == 0, TR_ERR_SHAPE, "tr_embed_bwd: bad shape B=%d N=%d D=%d", B, N, D);
+  TR_REQUIRE(tr_aligned16(g) && tr_aligned16(dpos) && tr_aligned16(dcls), TR_ERR_ALIGN, "tr_embed_bwd: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((N * (D / 4) + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(s), g, dpos, dcls, B, N, D, accumulate);
+  TR_CHECK_LAUNCH("tr_embed_bwd");
+  return TR_OK;
+}
+
+extern "C" int tr_evit_fuse_bwd(const float* x, const uint16_t* delta, const int32_t* compl_idx, const float* scores, const float* g_fused,
+                                float* g_out, uint16_t* gb_out, float* dscore, int B, int N, int K, int D, tr_stream_t s) {
+  TR_REQUIRE(x && compl_idx && scores && g_fused && g_out && gb_out && dscore, TR_ERR_NULL, "tr_evit_fuse_bwd: null pointer");
+  TR_REQUIRE(B > 0 && N > 1 && K >= 1 && K < N - 1 && D % 4 == 0 && D <= 256 * LN_MAX_CHUNKS, TR_ERR_SHAPE,
+             "tr_evit_fuse_bwd: bad shape B=%d N=%d K=%d D=%d", B, N, K, D);
+  hipStream_t st = static_cast<hipStream_t>(s);
+  TR_DISPATCH_NCH(D, hipLaunchKernelGGL((evit_fuse_bwd_kernel<NCH>), dim3(B), dim3(256), 0, st, x, delta, compl_idx, scores, g_fused, g_out, gb_out,
+                                        dscore, N, K, D));
+  TR_CHECK_LAUNCH("tr_evit_fuse_bwd");
+  return TR_OK;
+}
+
+extern "C" int tr_tome_merge_bwd(const float* g_merged, const float* size_in, const float* size_out, const int32_t* unm_idx,
+                                 const int32_t* src_idx, const int32_t* dst_idx, int32_t* inv_map, float* g_out, uint16_t* gb_out, int B,
+                                 int N, int r, int D, tr_stream_t s) {
+  TR_REQUIRE(g_merged && size_out && unm_idx && src_idx && dst_idx && inv_map && g_out && gb_out, TR_ERR_NULL, "tr_tome_merge_bwd: null pointer");
+  TR_REQUIRE(B > 0 && N >= 3 && r >= 1 && r <= (N - 1) / 2 && D % 4 == 0 && D <= 256 * LN_MAX_CHUNKS, TR_ERR_SHAPE,
+             "tr_tome_merge_bwd: bad shape B=%d N=%d r=%d D=%d", B, N, r, D);
+  hipStream_t st = static_cast<hipStream_t>(s);
+  hipLaunchKernelGGL(tome_invmap_kernel, dim3(B), dim3(256), 0, st, unm_idx, src_idx, dst_idx, inv_map, N, r);
+  const int M = B * N;
+  TR_DISPATCH_NCH(D, hipLaunchKernelGGL((tome_merge_bwd_kernel<NCH>), dim3((M + 3) / 4), dim3(256), 0, st, g_merged, size_in, size_out, inv_map, g_out,
+                                        gb_out, N, N - r, D, M));
+  TR_CHECK_LAUNCH("tr_tome_merge_bwd");
+  return TR_OK;
+}
+
+extern "C" int tr_f32_to_bf16(const float* src, uint16_t* dst, size_t n, tr_stream_t s) {
+  TR_REQUIRE(src && dst, TR_ERR_NULL, "tr_f32_to_bf16: null pointer");
+  TR_REQUIRE(n > 0 && n % 4 == 0, TR_ERR_SHAPE, "tr_f32_to_bf16: element count must be a positive multiple of 4");
+  const size_t nch = n / 4;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((nch + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(s), src, dst, nch);
+  TR_CHECK_LAUNCH("tr_f32_to_bf16");
+  return TR_OK;
+}

@@ -349,3 +349,135 @@ def attention_policy(qkv: torch.Tensor, policy: torch.Tensor, B: int, N: int, H:
     _lib.check(fn(_dev(qkv, qkv.dtype, "qkv"), out.data_ptr(), _dev(policy, torch.float32, "policy"), B, N, H, _stream()),
                "tr_attention_policy")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# backward kernels (csrc/tr_backward.hip, csrc/tr_attention_bwd.hip): gradients of the ops above
+def _ws(n_floats: int, dev) -> torch.Tensor:
+    return torch.empty(max(int(n_floats), 4), dtype=torch.float32, device=dev)
+
+
+def wgrad(dy: torch.Tensor, x: torch.Tensor, out: torch.Tensor = None, accumulate: bool = False, yskip: int = 0,
+          rows: int = None) -> torch.Tensor:
+    """nn.Linear weight gradient dW[N,K] (+)= dy[M,N]^T x[M,K] (bf16 operands, fp32 result)."""
+    M = rows if rows is not None else x.shape[0]
+    N, K = dy.shape[-1], x.shape[-1]
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(N, K, dtype=torch.float32, device=x.device)
+    nws = lib.tr_wgrad_workspace_floats(M, N, K)
+    ws = _ws(nws, x.device)
+    _lib.check(lib.tr_wgrad_bf16(_dev(dy, torch.bfloat16, "dy"), N, yskip, _dev(x, torch.bfloat16, "x"), K, _dev(out, torch.float32, "out"),
+                                 int(accumulate), ws.data_ptr(), ws.numel(), M, N, K, _stream()), "tr_wgrad_bf16")
+    return out
+
+
+def colsum(dy: torch.Tensor, out: torch.Tensor = None, accumulate: bool = False, yskip: int = 0, rows: int = None) -> torch.Tensor:
+    """nn.Linear bias gradient db[N] (+)= sum_m dy[m,n]."""
+    N = dy.shape[-1]
+    M = rows if rows is not None else dy.numel() // N
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(N, dtype=torch.float32, device=dy.device)
+    ws = _ws(lib.tr_colsum_workspace_floats(M, N), dy.device)
+    _lib.check(lib.tr_colsum_bf16(_dev(dy, torch.bfloat16, "dy"), N, yskip, _dev(out, torch.float32, "out"), int(accumulate),
+                                  ws.data_ptr(), ws.numel(), M, N, _stream()), "tr_colsum_bf16")
+    return out
+
+
+def gelu(pre: torch.Tensor) -> torch.Tensor:
+    h = torch.empty_like(pre)
+    _lib.check(_lib.load().tr_gelu_bf16(_dev(pre, torch.bfloat16, "pre"), h.data_ptr(), pre.numel(), _stream()), "tr_gelu_bf16")
+    return h
+
+
+def gelu_bwd(pre: torch.Tensor, dh: torch.Tensor) -> torch.Tensor:
+    """dh := dh * gelu'(pre) in place."""
+    _lib.check(_lib.load().tr_gelu_bwd_bf16(_dev(pre, torch.bfloat16, "pre"), _dev(dh, torch.bfloat16, "dh"), pre.numel(), _stream()),
+               "tr_gelu_bwd_bf16")
+    return dh
+
+
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, eps: float, g_in: torch.Tensor = None, idx: torch.Tensor = None,
+                  n_out: int = None, fused: bool = False):
+    """LayerNorm backward fused with the residual gradient.  dy bf16 [M,D], x fp32 [M,D] (LayerNorm input), g_in fp32 [M,D]|None.
+    Plain: returns (g fp32 [M,D], gb bf16 [M,D], dgamma, dbeta).  With idx int32 [B,K] (Top-K gather backward): rows are
+    [B, K+1(+1 fused)], results scattered into zero-filled [B, n_out, D]; also returns g_fused [B,D] when fused."""
+    M, D = dy.shape
+    lib = _lib.load()
+    dgamma = torch.empty(D, dtype=torch.float32, device=dy.device)
+    dbeta = torch.empty(D, dtype=torch.float32, device=dy.device)
+    ws = _ws(lib.tr_layernorm_bwd_workspace_floats(M, D), dy.device)
+    g_fused = None
+    if idx is None:
+        g = torch.empty(M, D, dtype=torch.float32, device=dy.device)
+        gb = torch.empty(M, D, dtype=torch.bfloat16, device=dy.device)
+        K = n_in = no = 0
+    else:
+        B, K = idx.shape
+        n_in = K + 1 + (1 if fused else 0)
+        no = n_out
+        g = torch.zeros(B * n_out, D, dtype=torch.float32, device=dy.device)
+        gb = torch.zeros(B * n_out, D, dtype=torch.bfloat16, device=dy.device)
+        if fused:
+            g_fused = torch.empty(B, D, dtype=torch.float32, device=dy.device)
+    _lib.check(lib.tr_layernorm_bwd(_dev(dy, torch.bfloat16, "dy"), _dev(x, torch.float32, "x"), D, _dev(gamma, torch.float32, "gamma"),
+                                    _opt(g_in, torch.float32, "g_in"), D, g.data_ptr(), D, gb.data_ptr(), _opt(idx, torch.int32, "idx"), K, n_in,
+                                    no, None if g_fused is None else g_fused.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), 0,
+                                    ws.data_ptr(), ws.numel(), M, D, eps, _stream()), "tr_layernorm_bwd")
+    if idx is not None and fused:
+        return g, gb, dgamma, dbeta, g_fused
+    return g, gb, dgamma, dbeta
+
+
+def attention_bwd(qkv: torch.Tensor, dout: torch.Tensor, B: int, N: int, H: int, size: torch.Tensor = None, dcls: torch.Tensor = None):
+    """d qkv (bf16 [B*N, 3*H*64]) of softmax(q k^T / 8 [+ log size]) v given d out (bf16 [B*N, H*64])."""
+    dqkv = torch.empty_like(qkv)
+    _lib.check(_lib.load().tr_attention_bwd_bf16(_dev(qkv, torch.bfloat16, "qkv"), _dev(dout, torch.bfloat16, "dout"),
+                                                 _opt(size, torch.float32, "size"), _opt(dcls, torch.float32, "dcls"), dqkv.data_ptr(), B, N,
+                                                 H, _stream()), "tr_attention_bwd_bf16")
+    return dqkv
+
+
+def head_bwd(dlogits: torch.Tensor, w: torch.Tensor, xn: torch.Tensor):
+    B, Cc = dlogits.shape
+    D = w.shape[1]
+    dxn = torch.empty(B, D, dtype=torch.bfloat16, device=w.device)
+    dw = torch.empty(Cc, D, dtype=torch.float32, device=w.device)
+    db = torch.empty(Cc, dtype=torch.float32, device=w.device)
+    _lib.check(_lib.load().tr_head_bwd(_dev(dlogits, torch.float32, "dlogits"), _dev(w, torch.bfloat16, "w"), _dev(xn, torch.bfloat16, "xn"),
+                                       dxn.data_ptr(), dw.data_ptr(), db.data_ptr(), 0, B, Cc, D, _stream()), "tr_head_bwd")
+    return dxn, dw, db
+
+
+def embed_bwd(g: torch.Tensor):
+    B, N, D = g.shape
+    dpos = torch.empty(N, D, dtype=torch.float32, device=g.device)
+    dcls = torch.empty(D, dtype=torch.float32, device=g.device)
+    _lib.check(_lib.load().tr_embed_bwd(_dev(g, torch.float32, "g"), dpos.data_ptr(), dcls.data_ptr(), 0, B, N, D, _stream()), "tr_embed_bwd")
+    return dpos, dcls
+
+
+def evit_fuse_bwd(x, delta, compl, scores, g_fused, g_out, gb_out):
+    """In place on g_out / gb_out ([B,N,D]); returns dscore fp32 [B,N] (gradient wrt the head-mean CLS attention, entry 1+token)."""
+    B, N, D = x.shape
+    K = N - 1 - compl.shape[1]
+    dscore = torch.zeros(B, N, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().tr_evit_fuse_bwd(_dev(x, torch.float32, "x"), _opt(delta, torch.bfloat16, "delta"), _dev(compl, torch.int32, "compl"),
+                                            _dev(scores, torch.float32, "scores"), _dev(g_fused, torch.float32, "g_fused"),
+                                            _dev(g_out, torch.float32, "g_out"), _dev(gb_out, torch.bfloat16, "gb_out"), dscore.data_ptr(),
+                                            B, N, K, D, _stream()), "tr_evit_fuse_bwd")
+    return dscore
+
+
+def tome_merge_bwd(g_merged, size_in, size_out, unm, src, dst, N: int):
+    B, N_out, D = g_merged.shape
+    r = N - N_out
+    g = torch.empty(B, N, D, dtype=torch.float32, device=g_merged.device)
+    gb = torch.empty(B, N, D, dtype=torch.bfloat16, device=g_merged.device)
+    inv = torch.empty(B, N, dtype=torch.int32, device=g_merged.device)
+    _lib.check(_lib.load().tr_tome_merge_bwd(_dev(g_merged, torch.float32, "g_merged"), _opt(size_in, torch.float32, "size_in"),
+                                             _dev(size_out, torch.float32, "size_out"), _dev(unm, torch.int32, "unm"), _dev(src, torch.int32, "src"),
+                                             _dev(dst, torch.int32, "dst"), inv.data_ptr(), g.data_ptr(), gb.data_ptr(), B, N, r, D, _stream()),
+               "tr_tome_merge_bwd")
+    return g, gb
