@@ -67,6 +67,10 @@ int tr_layernorm_bf16(float* x, long ldx, const uint16_t* delta, long ldd, const
                       int M, int D, float eps, tr_stream_t s);
 int tr_layernorm_f32(float* x, long ldx, const float* delta, long ldd, const float* gamma, const float* beta, float* y, int M,
                      int D, float eps, tr_stream_t s);                                                  /* fp32 validation path */
+/* Same, out of place: x_out[row] = x[row] + delta[row] (rows at stride ldxo; x_out == x is the in-place form above).  The training
+ * forward uses it so that the input of every norm survives for the backward pass. */
+int tr_layernorm_bf16_to(const float* x, long ldx, float* x_out, long ldxo, const uint16_t* delta, long ldd, const float* gamma,
+                         const float* beta, uint16_t* y, int M, int D, float eps, tr_stream_t s);
 
 /* out[i] = x[i] + delta[i] for n elements (delta nullable; bf16, fp32 when delta_is_f32): the residual stream after a block as
  * the reference's viz_data["Features"] records it (topk.py:197) -- x itself absorbs the pending mlp output only in the next norm. */
@@ -343,6 +347,27 @@ size_t tr_vit_workspace_bytes(const tr_vit_config* cfg, int B);
 int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits,
                    void* workspace, size_t workspace_bytes, int32_t* kept_idx, int32_t* compl_idx, float* soft_out,
                    const float* noise_in, float* features_out, int* tokens_out, int B, tr_stream_t s);
+
+/* ---- training: forward that keeps its activations + backward executor (csrc/tr_vit.hip, csrc/tr_train.hip) ----------------------
+ * engine.py:50-76: `output = model(samples)` in train mode, `loss.backward()`.  Families: DeiT, Top-K, EViT, ToMe (bf16, N <= 224).
+ * tr_vit_forward_train: as tr_vit_forward, and every activation the backward needs is written to `tape` (tr_vit_tape_bytes(cfg, B)
+ *   bytes, caller-owned; 0 = family / precision without a training path).  Dropout / DropPath rates are 0 (the caller applies none).
+ * tr_vit_backward: dlogits fp32 [B,classes] -> parameter gradients.  `w` = the forward's weights; `wt` = same struct with the block
+ *   matrices TRANSPOSED (bf16: qkv_w [D,3D], proj_w [D,D], fc1_w [D,Hd], fc2_w [Hd,D]); `grads` = same struct, every pointer an
+ *   fp32 buffer of the parameter's shape (written; added to when accumulate != 0).  workspace: tr_vit_backward_workspace_bytes.
+ *   block_events (nullable): hipEvent_t[depth+1] recorded on the stream as each block's gradients (index = block; depth = embedding,
+ *   last) are enqueued -- the hook for overlapping the data-parallel gradient reduction (train.py:405-407) with the backward. */
+size_t tr_vit_tape_bytes(const tr_vit_config* cfg, int B);
+int tr_vit_forward_train(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits, void* workspace,
+                         size_t workspace_bytes, void* tape, size_t tape_bytes, const float* noise_in, int* tokens_out, int B,
+                         tr_stream_t s);
+/* Byte offsets of block blk's tape slots (x0,x1,xn1,qkv,ao,dattn,x2,xn2,pre,h,idx,idx2,scores,size) followed by its token counts
+ * (entering, in attention, in the MLP) and its reduction count: lets a host read the decisions of a training forward. */
+int tr_vit_tape_layout(const tr_vit_config* cfg, int B, int blk, size_t* out18);
+size_t tr_vit_backward_workspace_bytes(const tr_vit_config* cfg, int B);
+int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w, const tr_vit_weights* wt, const tr_vit_weights* grads,
+                    const float* dlogits, const void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes, int accumulate,
+                    void** block_events, int B, tr_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -367,7 +367,11 @@ def tome_block_forward(x: Tensor, size: Optional[Tensor], p: Dict[str, Tensor], 
     assign = None
     r = tome_block_r(r, x.shape[1])
     if r > 0:
-        unm, src, dst = tome_match(metric, r) if forced is None else forced
+        if forced is None:
+            with torch.no_grad():                      # tome.py:258: the matching runs under no_grad; only merge_wavg is differentiable
+                unm, src, dst = tome_match(metric.detach(), r)
+        else:
+            unm, src, dst = forced
         assert src.shape == (x.shape[0], r)
         assign = tome_assignment(unm, src, dst, x.shape[1])
         x, size = tome_merge(x, size, unm, src, dst)

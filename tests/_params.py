@@ -207,6 +207,37 @@ GOLDEN_CASES = {
 }
 
 
+# Gradient fixtures (tests/golden/grad_<case>.npz): the reference's own `loss.backward()` (engine.py:60-76 with a plain
+# cross-entropy criterion) in train mode on the golden case's weights / images, labels from grad_labels().  Too large to store
+# whole (22 M values at DeiT-S), so per parameter: the L2 norm and <= 512 evenly strided entries (grad_sample_index).
+GRAD_CASES = ["deit_micro", "topk_micro", "evit_micro", "tome_micro", "topk_small_kr07", "evit_small_kr07", "tome_small_r16"]
+
+
+def grad_labels(case: dict):
+    rng = np.random.default_rng(case["xseed"] + 7)
+    return torch.from_numpy(rng.integers(0, case["num_classes"], size=(case["batch"],)).astype(np.int64))
+
+
+def grad_sample_index(numel: int):
+    return np.unique(np.linspace(0, numel - 1, min(numel, 512)).astype(np.int64))
+
+
+def oracle_param_grads(case: dict, forced=None, precision: str = "fp32", noise=None):
+    """Parameter gradients of cross-entropy(oracle logits, grad_labels) by torch.autograd over the oracle's functional forward
+    (the reference's backward IS torch.autograd over its eager forward, engine.py:60-76).  Returns (loss, logits, {name: grad})."""
+    import oracle
+    cfg, params = case_params(case)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    x = make_images(case["batch"], case.get("img_size", 224), case["xseed"])
+    fns = {"tome": oracle.tome_forward, "deit": oracle.vit_forward, "topk": oracle.vit_forward, "evit": oracle.vit_forward}
+    fn = fns[case["family"]].__wrapped__          # the undecorated function: the public one runs under torch.no_grad()
+    with torch.enable_grad():
+        logits = fn(leaves, x, cfg, precision, False, forced)
+        loss = torch.nn.functional.cross_entropy(logits, grad_labels(case))
+        loss.backward()
+    return loss.item(), logits.detach(), {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
+
+
 def case_params(case: dict):
     """(cfg, params) of a golden case: trunk + the family's stage modules."""
     cfg = case_config(case)

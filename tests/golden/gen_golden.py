@@ -48,7 +48,8 @@ from models.kmedoids import KMedoidsVisionTransformer  # noqa: E402
 from models.patchmerger import PatchMergerVisionTransformer  # noqa: E402
 from models.heuristic import HeuristicVisionTransformer  # noqa: E402
 
-from tests._params import GOLDEN_CASES, make_params, make_stage_params, make_images, case_config  # noqa: E402
+from tests._params import (GOLDEN_CASES, GRAD_CASES, make_params, make_stage_params, make_images, case_config,  # noqa: E402
+                            grad_labels, grad_sample_index)
 
 CLASSES = {"topk": TopKVisionTransformer, "evit": EfficientVisionTransformer, "deit": DeitViz, "tome": ToMeVisionTransformer,
            "dyvit": DynamicVisionTransformer, "sit": SelfSlimmedVisionTransformer, "dpcknn": DPCKNNVisionTransformer, "ats": ATSVisionTransformer, "sinkhorn": SinkhornVisionTransformer, "kmedoids": KMedoidsVisionTransformer, "patchmerger": PatchMergerVisionTransformer, "heuristic": HeuristicVisionTransformer}
@@ -278,8 +279,44 @@ def run_ops():
     print("ops: ", {k: v.shape for k, v in rec.items() if k.endswith(("out", "idx", "compl"))})
 
 
+def run_grad_case(name, case):
+    """Train-mode forward + cross-entropy + loss.backward() of the REFERENCE model: the gradient pin of the training path."""
+    m, _ = build_reference(case)
+    m.train()
+    m.viz_mode = False
+    x = make_images(case["batch"], case.get("img_size", 224), case["xseed"])
+    labels = grad_labels(case)
+    torch.manual_seed(case["xseed"])
+    with RandSpy() as rspy:
+        out = m(x)
+    logits = out[0] if isinstance(out, (tuple, list)) else out
+    loss = torch.nn.functional.cross_entropy(logits, labels)
+    loss.backward()
+    rec = {"logits": logits.detach().numpy(), "loss": np.array(loss.item(), dtype=np.float64), "labels": labels.numpy()}
+    for n, r in enumerate(rspy.calls):
+        rec[f"rand_{n}"] = r.numpy().astype(np.float32)
+    names = []
+    for pname, p in m.named_parameters():
+        g = p.grad if p.grad is not None else torch.zeros_like(p)
+        flat = g.detach().reshape(-1)
+        rec["norm:" + pname] = np.array(flat.double().norm().item(), dtype=np.float64)
+        rec["sample:" + pname] = flat[torch.from_numpy(grad_sample_index(flat.numel()))].numpy().astype(np.float32)
+        names.append(pname)
+    rec["param_names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, f"grad_{name}.npz"), **rec)
+    print(f"grad_{name}: loss {loss.item():.5f}  {len(names)} parameters, |g| total "
+          f"{sum(float(rec['norm:' + n]) ** 2 for n in names) ** 0.5:.4e}")
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
+    for name in GRAD_CASES:
+        if only and ("grad_" + name) not in only and "grads" not in only:
+            continue
+        if not only or ("grad_" + name) in only or "grads" in only:
+            run_grad_case(name, GOLDEN_CASES[name])
+    if only and all(o == "grads" or o.startswith("grad_") for o in only):
+        sys.exit(0)
     for name, case in GOLDEN_CASES.items():
         if only and name not in only:
             continue

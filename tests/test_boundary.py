@@ -80,12 +80,16 @@ def test_create_model_drops_none_kwargs():
     assert m.num_classes == 5
 
 
-def test_no_cpu_path_and_no_training_path():
+def test_no_cpu_path_in_eval_or_train_mode():
     m = tra.create_model("topk_tiny_patch16_224", args=_args(keep_rate=[0.7], reduction_loc=[3, 6, 9]))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="no CPU path"):
         m.train()(torch.zeros(1, 3, 224, 224))
     with pytest.raises(RuntimeError, match="no CPU path"):
         m.eval()(torch.zeros(1, 3, 224, 224))
+    # the reference's default --drop-path 0.1 (train.py:48) has no HIP path yet: loud, not silently ignored
+    m = tra.create_model("topk_tiny_patch16_224", drop_path_rate=0.1, args=_args(keep_rate=[0.7], reduction_loc=[3, 6, 9]))
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        m.train()(torch.zeros(1, 3, 224, 224))
 
 
 def test_pretrained_offline_fails_loudly(tmp_path, monkeypatch):

@@ -95,6 +95,13 @@ SIGNATURES = {
     "tr_evit_fuse_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tr_tome_merge_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tr_f32_to_bf16": (_i, [_vp, _vp, _sz, _vp]),
+    "tr_layernorm_bf16_to": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "tr_vit_tape_bytes": (_sz, [C.POINTER(TrVitConfig), _i]),
+    "tr_vit_forward_train": (_i, [C.POINTER(TrVitConfig), C.POINTER(TrVitWeights), _vp, _vp, _vp, _sz, _vp, _sz, _vp, C.POINTER(_i), _i, _vp]),
+    "tr_vit_tape_layout": (_i, [C.POINTER(TrVitConfig), _i, _i, C.POINTER(_sz)]),
+    "tr_vit_backward_workspace_bytes": (_sz, [C.POINTER(TrVitConfig), _i]),
+    "tr_vit_backward": (_i, [C.POINTER(TrVitConfig), C.POINTER(TrVitWeights), C.POINTER(TrVitWeights), C.POINTER(TrVitWeights), _vp, _vp, _sz,
+                             _vp, _sz, _i, C.POINTER(_vp), _i, _vp]),
     "tr_vit_forward": (_i, [C.POINTER(TrVitConfig), C.POINTER(TrVitWeights), _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp,
                             C.POINTER(_i), _i, _vp]),
 }

@@ -14,18 +14,24 @@ namespace {
 // (attn.proj or mlp.fc2): the residual add `x = x + drop_path(...)` (topk.py:87 / :95) is folded into the norm that
 // reads x next, so the GEMMs never read-modify-write the fp32 stream.
 template <bool F32, int NCH>
-__global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, long ldx, const void* __restrict__ delta, long ldd,
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x, long ldx, float* x_out, long ldxo, const void* __restrict__ delta, long ldd,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         void* __restrict__ y, int M, int D, float eps) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int nchunks = D >> 2;
-  float* xr = x + (size_t)row * ldx;
+  const float* xr = x + (size_t)row * ldx;
+  float* xo = x_out + (size_t)row * ldxo;            // == xr in the eval executor; a fresh tape slot in the training forward
   float4 v[NCH];
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
     v[c] = ln_nt_load4(xr + 4 * min(lane + 64 * c, nchunks - 1));     // branch-free: all loads of the row go out in one batch
+  if (delta == nullptr && xo != xr) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      if (lane + 64 * c < nchunks) ln_nt_store4(v[c], xo + 4 * (lane + 64 * c));
+  }
   if (delta != nullptr) {
     float4 d[NCH];
 #pragma unroll
@@ -34,7 +40,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, l
     for (int c = 0; c < NCH; ++c)
       if (lane + 64 * c < nchunks) {
         v[c].x += d[c].x; v[c].y += d[c].y; v[c].z += d[c].z; v[c].w += d[c].w;
-        ln_nt_store4(v[c], xr + 4 * (lane + 64 * c));
+        ln_nt_store4(v[c], xo + 4 * (lane + 64 * c));
       }
   }
   ln_row_store<F32, NCH>(v, nchunks, lane, D, eps, gamma, beta,
@@ -45,7 +51,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(float* __restrict__ x, l
 // kernel above leaves a quarter of the lanes idle at D = 384 and splits a row's 1.5 KiB into a full and a half request).
 // Same arithmetic as ln_row_store (two-pass statistics, sums over the row's 32 lanes by xor-shuffles 16..1).
 template <int CPL>
-__global__ __launch_bounds__(256) void layernorm_half_kernel(float* __restrict__ x, long ldx, const uint16_t* __restrict__ delta, long ldd,
+__global__ __launch_bounds__(256) void layernorm_half_kernel(const float* x, long ldx, float* x_out, long ldxo, const uint16_t* __restrict__ delta, long ldd,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              uint16_t* __restrict__ y, int M, float eps) {
   constexpr int D = 128 * CPL;
@@ -54,10 +60,15 @@ __global__ __launch_bounds__(256) void layernorm_half_kernel(float* __restrict__
   if (row >= M) return;
   typedef __attribute__((ext_vector_type(4))) float f4;
   typedef __attribute__((ext_vector_type(2))) unsigned u2;
-  f4* xr = reinterpret_cast<f4*>(x + (size_t)row * ldx);
+  const f4* xr = reinterpret_cast<const f4*>(x + (size_t)row * ldx);
+  f4* xo = reinterpret_cast<f4*>(x_out + (size_t)row * ldxo);
   f4 v[CPL];
 #pragma unroll
   for (int c = 0; c < CPL; ++c) v[c] = LN_LOAD(xr + sub + 32 * c);
+  if (delta == nullptr && xo != xr) {
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) LN_STORE(v[c], xo + sub + 32 * c);
+  }
   if (delta != nullptr) {
     const u2* dr = reinterpret_cast<const u2*>(delta + (size_t)row * ldd);
 #pragma unroll
@@ -65,7 +76,7 @@ __global__ __launch_bounds__(256) void layernorm_half_kernel(float* __restrict__
       const u2 d = LN_LOAD(dr + sub + 32 * c);
       v[c][0] += __uint_as_float(d[0] << 16); v[c][1] += __uint_as_float(d[0] & 0xffff0000u);
       v[c][2] += __uint_as_float(d[1] << 16); v[c][3] += __uint_as_float(d[1] & 0xffff0000u);
-      LN_STORE(v[c], xr + sub + 32 * c);
+      LN_STORE(v[c], xo + sub + 32 * c);
     }
   }
   float s = 0.f;
@@ -253,9 +264,10 @@ __global__ __launch_bounds__(256) void cls_pos_kernel(const float* __restrict__ 
 
 }  // namespace
 
-static int layernorm_impl(bool f32, float* x, long ldx, const void* delta, long ldd, const float* gamma, const float* beta, void* y,
-                          int M, int D, float eps, tr_stream_t s) {
-  TR_REQUIRE(x && gamma && beta && y, TR_ERR_NULL, "tr_layernorm: null pointer");
+static int layernorm_impl(bool f32, const float* x, long ldx, float* x_out, long ldxo, const void* delta, long ldd, const float* gamma,
+                          const float* beta, void* y, int M, int D, float eps, tr_stream_t s) {
+  TR_REQUIRE(x && x_out && gamma && beta && y, TR_ERR_NULL, "tr_layernorm: null pointer");
+  TR_REQUIRE(ldxo % 4 == 0 && ldxo >= D && tr_aligned16(x_out), TR_ERR_SHAPE, "tr_layernorm: bad x_out stride %ld", ldxo);
   TR_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAX_CHUNKS && ldx % 4 == 0 && ldx >= D, TR_ERR_SHAPE,
              "tr_layernorm: need D %% 4 == 0, D <= 1024, ldx %% 4 == 0 (M=%d D=%d ldx=%ld)", M, D, ldx);
   if (delta) TR_REQUIRE(ldd % 4 == 0 && ldd >= D && ((uintptr_t)delta & 7u) == 0, TR_ERR_SHAPE, "tr_layernorm: bad delta stride %ld", ldd);
@@ -264,25 +276,29 @@ static int layernorm_impl(bool f32, float* x, long ldx, const void* delta, long 
   hipStream_t st = static_cast<hipStream_t>(s);
 #ifndef TR_LN_NO_HALF
   if (!f32 && D == 384) {
-    hipLaunchKernelGGL(layernorm_half_kernel<3>, dim3((M + 7) / 8), dim3(256), 0, st, x, ldx, static_cast<const uint16_t*>(delta), ldd,
+    hipLaunchKernelGGL(layernorm_half_kernel<3>, dim3((M + 7) / 8), dim3(256), 0, st, x, ldx, x_out, ldxo, static_cast<const uint16_t*>(delta), ldd,
                        gamma, beta, static_cast<uint16_t*>(y), M, eps);
     TR_CHECK_LAUNCH("tr_layernorm");
     return TR_OK;
   }
 #endif
-  if (f32) TR_DISPATCH_NCH(D, hipLaunchKernelGGL((layernorm_kernel<true, NCH>), dim3((M + 3) / 4), dim3(256), 0, st, x, ldx, delta, ldd, gamma, beta, y, M, D, eps));
-  else TR_DISPATCH_NCH(D, hipLaunchKernelGGL((layernorm_kernel<false, NCH>), dim3((M + 3) / 4), dim3(256), 0, st, x, ldx, delta, ldd, gamma, beta, y, M, D, eps));
+  if (f32) TR_DISPATCH_NCH(D, hipLaunchKernelGGL((layernorm_kernel<true, NCH>), dim3((M + 3) / 4), dim3(256), 0, st, x, ldx, x_out, ldxo, delta, ldd, gamma, beta, y, M, D, eps));
+  else TR_DISPATCH_NCH(D, hipLaunchKernelGGL((layernorm_kernel<false, NCH>), dim3((M + 3) / 4), dim3(256), 0, st, x, ldx, x_out, ldxo, delta, ldd, gamma, beta, y, M, D, eps));
   TR_CHECK_LAUNCH("tr_layernorm");
   return TR_OK;
 }
 
 extern "C" int tr_layernorm_bf16(float* x, long ldx, const uint16_t* delta, long ldd, const float* gamma, const float* beta,
                                  uint16_t* y, int M, int D, float eps, tr_stream_t s) {
-  return layernorm_impl(false, x, ldx, delta, ldd, gamma, beta, y, M, D, eps, s);
+  return layernorm_impl(false, x, ldx, x, ldx, delta, ldd, gamma, beta, y, M, D, eps, s);
+}
+extern "C" int tr_layernorm_bf16_to(const float* x, long ldx, float* x_out, long ldxo, const uint16_t* delta, long ldd, const float* gamma,
+                                    const float* beta, uint16_t* y, int M, int D, float eps, tr_stream_t s) {
+  return layernorm_impl(false, x, ldx, x_out, ldxo, delta, ldd, gamma, beta, y, M, D, eps, s);
 }
 extern "C" int tr_layernorm_f32(float* x, long ldx, const float* delta, long ldd, const float* gamma, const float* beta, float* y,
                                 int M, int D, float eps, tr_stream_t s) {
-  return layernorm_impl(true, x, ldx, delta, ldd, gamma, beta, y, M, D, eps, s);
+  return layernorm_impl(true, x, ldx, x, ldx, delta, ldd, gamma, beta, y, M, D, eps, s);
 }
 
 static int gather_layernorm_impl(bool f32, const float* x, const void* delta, const int32_t* idx, const int32_t* compl_idx,

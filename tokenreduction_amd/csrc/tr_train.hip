@@ -1,0 +1,208 @@
+// Backward executor: enqueues the gradient pass of a training forward (tr_vit_forward_train) on the caller's stream.
+//
+// The reference's training step is `output = model(samples); loss = criterion(...); loss.backward()` (engine.py:50-76) with
+// torch.autograd deriving the backward of the eager ops; under DistributedDataParallel (train.py:405-407) the parameter
+// gradients are all-reduced in buckets while the backward is still running.  Here the backward is one fixed launch sequence over
+// the tape the forward left (tr_plan.h): block by block in reverse, for each nn.Linear a weight-gradient GEMM (tr_wgrad_bf16), a
+// bias column sum and a data-gradient GEMM (tr_gemm_bf16 on the transposed weight), the attention / LayerNorm / GELU backward
+// kernels, and the backward of the block's token reduction (Top-K scatter topk.py:89-93, EViT fused token evit.py:111-123, ToMe
+// merge tome.py:309-323).  After each block's parameter gradients are enqueued an optional event is recorded, so the caller can
+// start that bucket's RCCL reduce on a second stream while the rest of the backward runs (the DDP overlap).
+// Host-side only: no allocation, no synchronisation -- capturable in a hipGraph.
+#include "tr_common.h"
+#include "tr_plan.h"
+
+using trplan::align_up;
+
+namespace {
+
+struct BwdPlan {
+  size_t g0, g1, gb0, gb1, dxn, dqkv, dao, dh, zeros, wsf, dscore, gfused, invmap, dxcls, total;
+  size_t wsf_floats;
+};
+
+bool make_bwd_plan(const tr_vit_config* c, int B, const trplan::TokenPlan& t, BwdPlan* p) {
+  const size_t D = c->embed_dim, Hd = c->mlp_hidden, T = (size_t)B * t.N0;
+  const size_t kcols = (size_t)c->in_chans * c->patch * c->patch;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += align_up(bytes); return at; };
+  p->g0 = take(T * D * 4);
+  p->g1 = take(T * D * 4);
+  p->gb0 = take(T * D * 2);
+  p->gb1 = take(T * D * 2);
+  p->dxn = take(T * D * 2);
+  p->dqkv = take(T * 3 * D * 2);
+  p->dao = take(T * D * 2);
+  p->dh = take(T * Hd * 2);
+  size_t zmax = 3 * D > Hd ? 3 * D : Hd;
+  if (kcols > zmax) zmax = kcols;
+  p->zeros = take(zmax * 4);
+  // scratch of the two-stage reductions: the largest request of any call below
+  size_t f = tr_wgrad_workspace_floats((int)T, (int)(3 * D), (int)D);
+  auto upd = [&](size_t v) { if (v > f) f = v; };
+  upd(tr_wgrad_workspace_floats((int)T, (int)Hd, (int)D));
+  upd(tr_wgrad_workspace_floats((int)T, (int)D, (int)Hd));
+  upd(tr_wgrad_workspace_floats((int)T, (int)D, (int)D));
+  upd(tr_wgrad_workspace_floats(B * t.P, (int)D, (int)kcols));
+  upd(tr_colsum_workspace_floats((int)T, (int)(3 * D)));
+  upd(tr_colsum_workspace_floats((int)T, (int)Hd));
+  upd(tr_layernorm_bwd_workspace_floats((int)T, (int)D));
+  p->wsf_floats = f;
+  p->wsf = take(f * 4);
+  p->dscore = take(T * 4);
+  p->gfused = take((size_t)B * D * 4);
+  p->invmap = take(T * 4);
+  p->dxcls = take((size_t)B * D * 2);
+  p->total = o;
+  return true;
+}
+
+#define TR_TRY(call)                \
+  do {                              \
+    int rc__ = (call);              \
+    if (rc__ != TR_OK) return rc__; \
+  } while (0)
+
+inline float* F(const void* p) { return const_cast<float*>(static_cast<const float*>(p)); }
+inline const uint16_t* U(const void* p) { return static_cast<const uint16_t*>(p); }
+
+}  // namespace
+
+extern "C" size_t tr_vit_backward_workspace_bytes(const tr_vit_config* cfg, int B) {
+  trplan::TokenPlan t;
+  BwdPlan p;
+  if (!cfg || B <= 0 || !trplan::trainable_family(cfg->family) || !trplan::make_token_plan(cfg, &t) || !make_bwd_plan(cfg, B, t, &p)) return 0;
+  return p.total;
+}
+
+// wt: the weight MATRICES transposed (bf16): blocks[i].qkv_w = qkv.weight^T [D,3D], proj_w = proj.weight^T [D,D], fc1_w = fc1.weight^T
+//     [D,Hd], fc2_w = fc2.weight^T [Hd,D]; other fields unused.  w: the forward's weights (head_w and the LayerNorm gammas are read).
+// grads: same layout as tr_vit_weights, every pointer an fp32 gradient buffer of the parameter's shape (matrices included).
+// accumulate != 0: gradients are added to the buffers (engine.py:41 grad accumulation), else overwritten.
+// block_events (nullable): hipEvent_t[depth + 1]; event i is recorded once block i's parameter gradients are enqueued, event
+// `depth` after the embedding gradients (the last ones).  The head / final norm gradients precede event depth-1.
+extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w, const tr_vit_weights* wt, const tr_vit_weights* grads,
+                               const float* dlogits, const void* tape_, size_t tape_bytes, void* workspace, size_t workspace_bytes,
+                               int accumulate, void** block_events, int B, tr_stream_t s) {
+  TR_REQUIRE(cfg && w && wt && grads && dlogits && tape_ && workspace, TR_ERR_NULL, "tr_vit_backward: null pointer");
+  TR_REQUIRE(cfg->precision == TR_PREC_BF16 && trplan::trainable_family(cfg->family), TR_ERR_CONFIG,
+             "tr_vit_backward: family %d / precision %d has no training path", cfg->family, cfg->precision);
+  trplan::TokenPlan t;
+  trplan::TapePlan tp;
+  BwdPlan bp;
+  TR_REQUIRE(trplan::make_token_plan(cfg, &t) && trplan::make_tape_plan(cfg, B, t, &tp) && make_bwd_plan(cfg, B, t, &bp), TR_ERR_CONFIG,
+             "tr_vit_backward: invalid config");
+  TR_REQUIRE(tape_bytes >= tp.total && workspace_bytes >= bp.total, TR_ERR_SHAPE, "tr_vit_backward: tape (%zu < %zu) or workspace (%zu < %zu) too small",
+             tape_bytes, tp.total, workspace_bytes, bp.total);
+  TR_REQUIRE(tr_aligned16(tape_) && tr_aligned16(workspace), TR_ERR_ALIGN, "tr_vit_backward: tape / workspace must be 16-byte aligned");
+  const char* tape = static_cast<const char*>(tape_);
+  char* ws = static_cast<char*>(workspace);
+  hipStream_t st = static_cast<hipStream_t>(s);
+  const int D = cfg->embed_dim, H = cfg->num_heads, Hd = cfg->mlp_hidden, C = cfg->num_classes;
+  const int kcols = cfg->in_chans * cfg->patch * cfg->patch;
+  float* g = reinterpret_cast<float*>(ws + bp.g0);
+  float* g_alt = reinterpret_cast<float*>(ws + bp.g1);
+  uint16_t* gb = reinterpret_cast<uint16_t*>(ws + bp.gb0);
+  uint16_t* gb_alt = reinterpret_cast<uint16_t*>(ws + bp.gb1);
+  uint16_t* dxn = reinterpret_cast<uint16_t*>(ws + bp.dxn);
+  uint16_t* dqkv = reinterpret_cast<uint16_t*>(ws + bp.dqkv);
+  uint16_t* dao = reinterpret_cast<uint16_t*>(ws + bp.dao);
+  uint16_t* dh = reinterpret_cast<uint16_t*>(ws + bp.dh);
+  float* zeros = reinterpret_cast<float*>(ws + bp.zeros);
+  float* wsf = reinterpret_cast<float*>(ws + bp.wsf);
+  float* dscore = reinterpret_cast<float*>(ws + bp.dscore);
+  float* gfused = reinterpret_cast<float*>(ws + bp.gfused);
+  int32_t* invmap = reinterpret_cast<int32_t*>(ws + bp.invmap);
+  uint16_t* dxcls = reinterpret_cast<uint16_t*>(ws + bp.dxcls);
+  const size_t wsn = bp.wsf_floats;
+  const int acc = accumulate ? 1 : 0;
+
+  size_t zmax = (size_t)(3 * D > Hd ? 3 * D : Hd);
+  if ((size_t)kcols > zmax) zmax = kcols;
+  TR_REQUIRE(hipMemsetAsync(zeros, 0, zmax * 4, st) == hipSuccess, TR_ERR_LAUNCH, "tr_vit_backward: memset failed");
+
+  // ---- classifier + final norm (topk.py:201-203): gradient enters the CLS rows of the last block's output stream
+  const int Nl = t.n_mlp[cfg->depth - 1];
+  TR_TRY(tr_head_bwd(dlogits, U(w->head_w), U(tape + tp.xcls), dxcls, F(grads->head_w), F(grads->head_b), acc, B, C, D, s));
+  TR_REQUIRE(hipMemsetAsync(g, 0, (size_t)B * Nl * D * 4, st) == hipSuccess, TR_ERR_LAUNCH, "tr_vit_backward: memset failed");
+  TR_TRY(tr_layernorm_bwd(dxcls, reinterpret_cast<const float*>(tape + tp.xfinal), D, w->norm_g, nullptr, 0, g, (long)Nl * D, nullptr, nullptr, 0, 0,
+                          0, nullptr, F(grads->norm_g), F(grads->norm_b), acc, wsf, wsn, B, D, cfg->ln_eps, s));
+  TR_TRY(tr_f32_to_bf16(g, gb, (size_t)B * Nl * D, s));
+
+  for (int i = cfg->depth - 1; i >= 0; --i) {
+    const trplan::BlockTape& bt = tp.blk[i];
+    const tr_block_weights* bw = &w->blocks[i];
+    const tr_block_weights* bwt = &wt->blocks[i];
+    const tr_block_weights* bg = &grads->blocks[i];
+    const int Na = t.n_att[i], Nm = t.n_mlp[i];
+    const int M2 = B * Nm, M1 = B * Na;
+    // ---- mlp: x2 -> norm2 -> fc1 -> gelu -> fc2 -> (+ residual)
+    TR_TRY(tr_wgrad_bf16(gb, D, 0, U(tape + bt.h), Hd, F(bg->fc2_w), acc, wsf, wsn, M2, D, Hd, s));
+    TR_TRY(tr_colsum_bf16(gb, D, 0, F(bg->fc2_b), acc, wsf, wsn, M2, D, s));
+    TR_TRY(tr_gemm_bf16(gb, U(bwt->fc2_w), zeros, dh, nullptr, 0, M2, Hd, D, TR_EPI_BF16, s));
+    TR_TRY(tr_gelu_bwd_bf16(U(tape + bt.pre), dh, (size_t)M2 * Hd, s));
+    TR_TRY(tr_wgrad_bf16(dh, Hd, 0, U(tape + bt.xn2), D, F(bg->fc1_w), acc, wsf, wsn, M2, Hd, D, s));
+    TR_TRY(tr_colsum_bf16(dh, Hd, 0, F(bg->fc1_b), acc, wsf, wsn, M2, Hd, s));
+    TR_TRY(tr_gemm_bf16(dh, U(bwt->fc1_w), zeros, dxn, nullptr, 0, M2, D, Hd, TR_EPI_BF16, s));
+    // ---- norm2 (+ the block's in-block token reduction)
+    const float* x2 = reinterpret_cast<const float*>(tape + bt.x2);
+    const float* x1 = reinterpret_cast<const float*>(tape + bt.x1);
+    const float* dcls = nullptr;
+    const int K = t.kk[i];
+    if ((cfg->family == TR_FAMILY_TOPK || cfg->family == TR_FAMILY_EVIT) && K > 0) {
+      const bool fuse = cfg->family == TR_FAMILY_EVIT;
+      const int32_t* idx = reinterpret_cast<const int32_t*>(tape + bt.idx);
+      TR_REQUIRE(hipMemsetAsync(g_alt, 0, (size_t)M1 * D * 4, st) == hipSuccess && hipMemsetAsync(gb_alt, 0, (size_t)M1 * D * 2, st) == hipSuccess,
+                 TR_ERR_LAUNCH, "tr_vit_backward: memset failed");
+      TR_TRY(tr_layernorm_bwd(dxn, x2, D, bw->ln2_g, g, D, g_alt, D, gb_alt, idx, K, Nm, Na, fuse ? gfused : nullptr, F(bg->ln2_g), F(bg->ln2_b),
+                              acc, wsf, wsn, M2, D, cfg->ln_eps, s));
+      if (fuse) {
+        TR_REQUIRE(hipMemsetAsync(dscore, 0, (size_t)M1 * 4, st) == hipSuccess, TR_ERR_LAUNCH, "tr_vit_backward: memset failed");
+        TR_TRY(tr_evit_fuse_bwd(x1, U(tape + bt.dattn), reinterpret_cast<const int32_t*>(tape + bt.idx2),
+                                reinterpret_cast<const float*>(tape + bt.scores), gfused, g_alt, gb_alt, dscore, B, Na, K, D, s));
+        dcls = dscore;
+      }
+      float* tg = g; g = g_alt; g_alt = tg;
+      uint16_t* tb = gb; gb = gb_alt; gb_alt = tb;
+    } else if (cfg->family == TR_FAMILY_TOME && K > 0) {
+      TR_TRY(tr_layernorm_bwd(dxn, x2, D, bw->ln2_g, g, D, g, D, nullptr, nullptr, 0, 0, 0, nullptr, F(bg->ln2_g), F(bg->ln2_b), acc, wsf, wsn, M2, D,
+                              cfg->ln_eps, s));
+      const int na = (Na + 1) / 2;
+      const int32_t* unm = reinterpret_cast<const int32_t*>(tape + bt.idx);
+      const int32_t* src = unm + (size_t)B * (na - K);
+      const int32_t* dst = src + (size_t)B * K;
+      const float* size_in = nullptr;                       // sizes entering this block's merge: after the previous merging block
+      for (int j = i - 1; j >= 0; --j)
+        if (t.kk[j] > 0) { size_in = reinterpret_cast<const float*>(tape + tp.blk[j].size); break; }
+      TR_TRY(tr_tome_merge_bwd(g, size_in, reinterpret_cast<const float*>(tape + bt.size), unm, src, dst, invmap, g_alt, gb_alt, B, Na, K, D, s));
+      float* tg = g; g = g_alt; g_alt = tg;
+      uint16_t* tb = gb; gb = gb_alt; gb_alt = tb;
+    } else {
+      TR_TRY(tr_layernorm_bwd(dxn, x2, D, bw->ln2_g, g, D, g, D, gb, nullptr, 0, 0, 0, nullptr, F(bg->ln2_g), F(bg->ln2_b), acc, wsf, wsn, M2, D,
+                              cfg->ln_eps, s));
+    }
+    // ---- attention: x1 -> norm1 -> qkv -> softmax(q k^T) v -> proj -> (+ residual)
+    TR_TRY(tr_wgrad_bf16(gb, D, 0, U(tape + bt.ao), D, F(bg->proj_w), acc, wsf, wsn, M1, D, D, s));
+    TR_TRY(tr_colsum_bf16(gb, D, 0, F(bg->proj_b), acc, wsf, wsn, M1, D, s));
+    TR_TRY(tr_gemm_bf16(gb, U(bwt->proj_w), zeros, dao, nullptr, 0, M1, D, D, TR_EPI_BF16, s));
+    const float* size_att = nullptr;                        // ToMe: log(size) bias of this block's keys (tome.py:48-49)
+    if (cfg->family == TR_FAMILY_TOME)
+      for (int j = i - 1; j >= 0; --j)
+        if (t.kk[j] > 0) { size_att = reinterpret_cast<const float*>(tape + tp.blk[j].size); break; }
+    TR_TRY(tr_attention_bwd_bf16(U(tape + bt.qkv), dao, size_att, dcls, dqkv, B, Na, H, s));
+    TR_TRY(tr_wgrad_bf16(dqkv, 3 * D, 0, U(tape + bt.xn1), D, F(bg->qkv_w), acc, wsf, wsn, M1, 3 * D, D, s));
+    TR_TRY(tr_colsum_bf16(dqkv, 3 * D, 0, F(bg->qkv_b), acc, wsf, wsn, M1, 3 * D, s));
+    TR_TRY(tr_gemm_bf16(dqkv, U(bwt->qkv_w), zeros, dxn, nullptr, 0, M1, D, 3 * D, TR_EPI_BF16, s));
+    TR_TRY(tr_layernorm_bwd(dxn, x1, D, bw->ln1_g, g, D, g, D, gb, nullptr, 0, 0, 0, nullptr, F(bg->ln1_g), F(bg->ln1_b), acc, wsf, wsn, M1, D,
+                            cfg->ln_eps, s));
+    if (block_events && block_events[i])
+      TR_REQUIRE(hipEventRecord(static_cast<hipEvent_t>(block_events[i]), st) == hipSuccess, TR_ERR_LAUNCH, "tr_vit_backward: event record failed");
+  }
+  // ---- embedding (topk.py:181-186): g is d x0 [B, N0, D]
+  TR_TRY(tr_embed_bwd(g, F(grads->pos_embed), F(grads->cls_token), acc, B, t.N0, D, s));
+  TR_TRY(tr_wgrad_bf16(gb, D, t.P, U(tape + tp.cols), kcols, F(grads->patch_w), acc, wsf, wsn, B * t.P, D, kcols, s));
+  TR_TRY(tr_colsum_bf16(gb, D, t.P, F(grads->patch_b), acc, wsf, wsn, B * t.P, D, s));
+  if (block_events && block_events[cfg->depth])
+    TR_REQUIRE(hipEventRecord(static_cast<hipEvent_t>(block_events[cfg->depth]), st) == hipSuccess, TR_ERR_LAUNCH, "tr_vit_backward: event record failed");
+  return TR_OK;
+}

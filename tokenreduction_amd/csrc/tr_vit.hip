@@ -11,6 +11,7 @@
 #include <stdarg.h>
 #include <string.h>
 #include "tr_common.h"
+#include "tr_plan.h"
 
 static thread_local char g_err[512] = "";
 
@@ -26,7 +27,7 @@ extern "C" int tr_version(void) { return 100; }
 
 namespace {
 
-inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+using trplan::align_up;
 
 struct Plan {
   int P, N0, D, H, Hd, C, kcols;
@@ -119,10 +120,15 @@ extern "C" size_t tr_vit_workspace_bytes(const tr_vit_config* cfg, int B) {
     if (rc__ != TR_OK) return rc__; \
   } while (0)
 
-extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits, void* workspace,
-                              size_t workspace_bytes, int32_t* kept_idx, int32_t* compl_idx, float* soft_out,
-                              const float* noise_in, float* features_out, int* tokens_out, int B, tr_stream_t s) {
+// tape != nullptr: TRAINING forward -- every activation the backward pass needs goes to its own slot of the tape (tr_plan.h)
+// instead of the shared scratch, the residual stream is written out of place (the inputs of norm1 / norm2 of every block stay),
+// fc1 keeps its pre-activation (GELU as a separate kernel), and the decisions (kept ids, sizes) are kept per block.
+static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits, void* workspace,
+                            size_t workspace_bytes, int32_t* kept_idx, int32_t* compl_idx, float* soft_out,
+                            const float* noise_in, float* features_out, int* tokens_out, int B, tr_stream_t s, char* tape,
+                            const trplan::TapePlan* tp) {
   Plan p;
+  const bool train = tape != nullptr;
   TR_REQUIRE(cfg && w && img && logits && workspace, TR_ERR_NULL, "tr_vit_forward: null pointer");
   TR_REQUIRE(make_plan(cfg, B, &p), TR_ERR_CONFIG,
              "tr_vit_forward: invalid config (need embed_dim == 64*heads, dims %% 64 == 0, classes %% 4 == 0, depth <= %d)",
@@ -138,7 +144,8 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
   void* ao = static_cast<void*>(ws + p.off_ao);
   void* hbuf = static_cast<void*>(ws + p.off_h);
   void* dbuf = static_cast<void*>(ws + p.off_d);   // bf16 output of proj / fc2, added to x by the NEXT norm
-  void* cols = static_cast<void*>(ws + p.off_cols);
+  void* const dbuf_shared = dbuf;
+  void* cols = train ? static_cast<void*>(tape + tp->cols) : static_cast<void*>(ws + p.off_cols);
   float* cls_rows = reinterpret_cast<float*>(ws + p.off_cls);
   float* scores = reinterpret_cast<float*>(ws + p.off_scores);
   int32_t* idx_ws = reinterpret_cast<int32_t*>(ws + p.off_idx);
@@ -303,8 +310,19 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
       r = cfg->keep[i] < (N - 1) / 2 ? cfg->keep[i] : (N - 1) / 2;
     }
     const int M = B * N;
+    if (train) {          // this block's tape slots replace the shared scratch
+      const trplan::BlockTape& bt = tp->blk[i];
+      xn = tape + bt.xn1; qkv = tape + bt.qkv; ao = tape + bt.ao; hbuf = tape + bt.h;
+      dbuf = (cfg->family == TR_FAMILY_EVIT && K > 0) ? static_cast<void*>(tape + bt.dattn) : dbuf_shared;
+      x_alt = reinterpret_cast<float*>(tape + bt.x2);
+    }
     // x (+= previous mlp output); attn(norm1(x)) -> dbuf   [x + dbuf is the reference's post-attention x, topk.py:87]
-    if (!have_xn) TR_TRY(op_ln(f32, x, D, pending, D, bw->ln1_g, bw->ln1_b, xn, M, D, cfg->ln_eps, s));
+    if (train && !have_xn) {
+      float* x1 = reinterpret_cast<float*>(tape + tp->blk[i].x1);
+      TR_TRY(tr_layernorm_bf16_to(x, D, x1, D, static_cast<const uint16_t*>(pending), D, bw->ln1_g, bw->ln1_b, static_cast<uint16_t*>(xn), M, D,
+                                  cfg->ln_eps, s));
+      x = x1;
+    } else if (!have_xn) TR_TRY(op_ln(f32, x, D, pending, D, bw->ln1_g, bw->ln1_b, xn, M, D, cfg->ln_eps, s));
     TR_TRY(op_gemm(f32, xn, bw->qkv_w, bw->qkv_b, qkv, nullptr, 0, M, 3 * D, D, TR_EPI_BF16, s));
     // ToMe: log(size) bias on the keys; ATS: key mask as a 1/0 "size" (log 0 = -inf -> exactly zero weight, like
     // masked_fill(-finfo.max) underflowing in the reference's softmax, ats.py:117-120)
@@ -335,31 +353,54 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
       const bool fuse = cfg->family == TR_FAMILY_EVIT;
       int32_t* idx_dst = kept_idx ? kept_idx + (size_t)i * B * p.N0 : idx_ws;
       int32_t* compl_dst = fuse ? (compl_idx ? compl_idx + (size_t)i * B * p.N0 : compl_ws) : nullptr;
-      TR_TRY(tr_cls_topk(cls_rows, idx_dst, compl_dst, scores, B, H, N, K, s));
-      TR_TRY(op_gather(f32, x, dbuf, idx_dst, compl_dst, scores, bw->ln2_g, bw->ln2_b, x_alt, xn, B, N, K, D, cfg->ln_eps, s));
+      float* sc_dst = scores;
+      if (train) {
+        idx_dst = reinterpret_cast<int32_t*>(tape + tp->blk[i].idx);
+        if (fuse) compl_dst = reinterpret_cast<int32_t*>(tape + tp->blk[i].idx2);
+        sc_dst = reinterpret_cast<float*>(tape + tp->blk[i].scores);
+        xn = tape + tp->blk[i].xn2;
+      }
+      TR_TRY(tr_cls_topk(cls_rows, idx_dst, compl_dst, sc_dst, B, H, N, K, s));
+      TR_TRY(op_gather(f32, x, dbuf, idx_dst, compl_dst, sc_dst, bw->ln2_g, bw->ln2_b, x_alt, xn, B, N, K, D, cfg->ln_eps, s));
       float* t = x; x = x_alt; x_alt = t;
       Nn = K + 1 + (fuse ? 1 : 0);
     } else if (r > 0) {
       // ToMe: bipartite matching on mean-over-heads K, then residual add + size-weighted merge + norm2 in one pass
       const int na = (N + 1) / 2;
       int32_t* slab = kept_idx ? kept_idx + (size_t)i * B * p.N0 : idx_ws;
+      if (train) {
+        slab = reinterpret_cast<int32_t*>(tape + tp->blk[i].idx);
+        xn = tape + tp->blk[i].xn2;
+      }
       int32_t* unm = slab;
       int32_t* src = slab + (size_t)B * (na - r);
       int32_t* dst = src + (size_t)B * r;
-      float* size_next = (size_cur == size_a) ? size_b : size_a;
+      float* size_next = train ? reinterpret_cast<float*>(tape + tp->blk[i].size) : ((size_cur == size_a) ? size_b : size_a);
       TR_TRY(tr_tome_match(qkv, f32 ? 1 : 0, unm, src, dst, B, N, H, r, s));
       TR_TRY(tr_tome_merge_layernorm(x, dbuf, f32 ? 1 : 0, size_cur, unm, src, dst, bw->ln2_g, bw->ln2_b, x_alt, size_next, xn, B, N, r,
                                      D, cfg->ln_eps, s));
       float* t = x; x = x_alt; x_alt = t;
       size_cur = size_next;
       Nn = N - r;
+    } else if (train) {
+      xn = tape + tp->blk[i].xn2;
+      TR_TRY(tr_layernorm_bf16_to(x, D, x_alt, D, static_cast<const uint16_t*>(dbuf), D, bw->ln2_g, bw->ln2_b, static_cast<uint16_t*>(xn), B * Nn, D,
+                                  cfg->ln_eps, s));
+      x = x_alt;
     } else {
       TR_TRY(op_ln(f32, x, D, dbuf, D, bw->ln2_g, bw->ln2_b, xn, B * Nn, D, cfg->ln_eps, s));
     }
     N = Nn;
     const int M2 = B * N;
     // mlp(norm2(x)) -> dbuf, added to x by the next block's norm1 (or the final norm)
-    TR_TRY(op_gemm(f32, xn, bw->fc1_w, bw->fc1_b, hbuf, nullptr, 0, M2, p.Hd, D, TR_EPI_GELU_BF16, s));
+    if (train) {
+      void* pre = tape + tp->blk[i].pre;
+      TR_TRY(op_gemm(f32, xn, bw->fc1_w, bw->fc1_b, pre, nullptr, 0, M2, p.Hd, D, TR_EPI_BF16, s));
+      TR_TRY(tr_gelu_bf16(static_cast<const uint16_t*>(pre), static_cast<uint16_t*>(hbuf), (size_t)M2 * p.Hd, s));
+    } else {
+      TR_TRY(op_gemm(f32, xn, bw->fc1_w, bw->fc1_b, hbuf, nullptr, 0, M2, p.Hd, D, TR_EPI_GELU_BF16, s));
+    }
+    dbuf = dbuf_shared;
     TR_TRY(op_gemm(f32, hbuf, bw->fc2_w, bw->fc2_b, dbuf, nullptr, 0, M2, D, p.Hd, TR_EPI_BF16, s));
     pending = dbuf;
     if (features_out) {      // viz_data["Features"][i] (topk.py:197): x + mlp output, which x itself only absorbs in the next norm
@@ -369,7 +410,62 @@ extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w,
     if (tokens_out) tokens_out[i] = N;
   }
   // a5: (x += last mlp output and) norm on the CLS rows only (LayerNorm is per-row), then the classifier
-  TR_TRY(op_ln(f32, x, (long)N * D, pending, (long)N * D, w->norm_g, w->norm_b, xcls, B, D, cfg->ln_eps, s));
+  if (train) {
+    xcls = tape + tp->xcls;
+    TR_TRY(tr_layernorm_bf16_to(x, (long)N * D, reinterpret_cast<float*>(tape + tp->xfinal), D, static_cast<const uint16_t*>(pending), (long)N * D,
+                                w->norm_g, w->norm_b, static_cast<uint16_t*>(xcls), B, D, cfg->ln_eps, s));
+  } else {
+    TR_TRY(op_ln(f32, x, (long)N * D, pending, (long)N * D, w->norm_g, w->norm_b, xcls, B, D, cfg->ln_eps, s));
+  }
   TR_TRY(op_gemm(f32, xcls, w->head_w, w->head_b, logits, nullptr, 0, B, p.C, D, TR_EPI_F32, s));
   return TR_OK;
+}
+
+extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits, void* workspace,
+                              size_t workspace_bytes, int32_t* kept_idx, int32_t* compl_idx, float* soft_out,
+                              const float* noise_in, float* features_out, int* tokens_out, int B, tr_stream_t s) {
+  return vit_forward_impl(cfg, w, img, logits, workspace, workspace_bytes, kept_idx, compl_idx, soft_out, noise_in, features_out, tokens_out,
+                          B, s, nullptr, nullptr);
+}
+
+extern "C" size_t tr_vit_tape_bytes(const tr_vit_config* cfg, int B) {
+  Plan p;
+  trplan::TokenPlan t;
+  trplan::TapePlan tp;
+  if (!make_plan(cfg, B, &p) || cfg->precision != TR_PREC_BF16 || !trplan::trainable_family(cfg->family)) return 0;
+  if (!trplan::make_token_plan(cfg, &t) || !trplan::make_tape_plan(cfg, B, t, &tp)) return 0;
+  return tp.total;
+}
+
+// offsets (bytes) of block blk's tape slots, in BlockTape order: x0,x1,xn1,qkv,ao,dattn,x2,xn2,pre,h,idx,idx2,scores,size + token
+// counts n_pre,n_att,n_mlp,kk: lets a host read the decisions (kept ids, sizes) a training forward left on the tape
+extern "C" int tr_vit_tape_layout(const tr_vit_config* cfg, int B, int blk, size_t* out18) {
+  Plan p;
+  trplan::TokenPlan t;
+  trplan::TapePlan tp;
+  TR_REQUIRE(cfg && out18, TR_ERR_NULL, "tr_vit_tape_layout: null pointer");
+  TR_REQUIRE(make_plan(cfg, B, &p) && trplan::make_token_plan(cfg, &t) && trplan::make_tape_plan(cfg, B, t, &tp) && blk >= 0 && blk < cfg->depth,
+             TR_ERR_CONFIG, "tr_vit_tape_layout: invalid config or block");
+  const trplan::BlockTape& b = tp.blk[blk];
+  const size_t v[18] = {b.x0, b.x1, b.xn1, b.qkv, b.ao, b.dattn, b.x2, b.xn2, b.pre, b.h, b.idx, b.idx2, b.scores, b.size,
+                        (size_t)t.n_pre[blk], (size_t)t.n_att[blk], (size_t)t.n_mlp[blk], (size_t)t.kk[blk]};
+  for (int i = 0; i < 18; ++i) out18[i] = v[i];
+  return TR_OK;
+}
+
+extern "C" int tr_vit_forward_train(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits, void* workspace,
+                                    size_t workspace_bytes, void* tape, size_t tape_bytes, const float* noise_in, int* tokens_out, int B,
+                                    tr_stream_t s) {
+  TR_REQUIRE(cfg && tape, TR_ERR_NULL, "tr_vit_forward_train: null pointer");
+  TR_REQUIRE(cfg->precision == TR_PREC_BF16, TR_ERR_CONFIG, "tr_vit_forward_train: the training path is bf16 only");
+  TR_REQUIRE(trplan::trainable_family(cfg->family), TR_ERR_CONFIG, "tr_vit_forward_train: family %d has no training path yet", cfg->family);
+  trplan::TokenPlan t;
+  trplan::TapePlan tp;
+  TR_REQUIRE(trplan::make_token_plan(cfg, &t) && trplan::make_tape_plan(cfg, B, t, &tp), TR_ERR_CONFIG, "tr_vit_forward_train: invalid config");
+  TR_REQUIRE(tape_bytes >= tp.total, TR_ERR_SHAPE, "tr_vit_forward_train: tape too small (%zu < %zu)", tape_bytes, tp.total);
+  TR_REQUIRE(tr_aligned16(tape), TR_ERR_ALIGN, "tr_vit_forward_train: tape must be 16-byte aligned");
+  for (int i = 0; i < cfg->depth; ++i)
+    TR_REQUIRE(t.n_att[i] <= 224, TR_ERR_SHAPE, "tr_vit_forward_train: %d tokens in block %d; the attention backward holds N <= 224", t.n_att[i], i);
+  return vit_forward_impl(cfg, w, img, logits, workspace, workspace_bytes, nullptr, nullptr, nullptr, noise_in, nullptr, tokens_out, B, s,
+                          static_cast<char*>(tape), &tp);
 }

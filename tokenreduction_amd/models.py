@@ -10,8 +10,9 @@ so a `train.py` / `validate.py`-style driver can swap `timm.models.create_model`
 load_state_dict / state_dict / optimizers see the reference's key names); `forward` never calls
 them: it hands the image batch to the gfx950 executor (csrc/tr_vit.hip) through the C ABI.
 
-There is no CPU path: forward() on a CPU tensor raises.  Training (autograd through the HIP
-kernels) is not built yet and raises NotImplementedError.
+There is no CPU path: forward() on a CPU tensor raises.  In train mode forward() runs the training executor
+(activations kept on a tape) and `loss.backward()` runs the HIP backward executor (training.py); families
+without a backward yet raise NotImplementedError there.
 """
 from __future__ import annotations
 
@@ -247,11 +248,25 @@ class VisionTransformer(nn.Module):
             self._ws = {B: ws}   # keep one batch size resident
         return ws
 
+    # ---- training state (flat gradient buffer, tape, workspaces): training.py -----------------------
+    def _train_state(self):
+        st = getattr(self, "_tstate", None)
+        if st is None or st.flat.device != self.pos_embed.device or len(st.order) != len(list(self.parameters())):
+            from . import training
+            st = self._tstate = training.TrainState(self)
+        return st
+
+    def _grad_events(self, st):
+        """hipEvent_t[depth+1] for tr_vit_backward when a gradient reducer wants to overlap with the backward, else None."""
+        reducer = getattr(self, "_grad_reducer", None)
+        return None if reducer is None else reducer.events_array(self, st)
+
     # ---- forward ------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor):
         if self.training:
-            raise NotImplementedError("training through the HIP kernels is not built yet (inference/eval path only); "
-                                      "call model.eval()")
+            # engine.py:50-51 `output = model(samples)` in train mode: logits with the HIP backward behind them (training.py)
+            from . import training
+            return training.train_forward(self, x)
         if not x.is_cuda:
             raise RuntimeError(f"input is on {x.device}: tokenreduction_amd has no CPU path (HIP kernels only)")
         lib = _lib.load()

@@ -1,0 +1,246 @@
+"""Training-mode forward/backward of the models through the HIP executors (csrc/tr_vit.hip, csrc/tr_train.hip).
+
+The reference trains with `output = model(samples); loss = criterion(...); loss.backward()` (engine.py:50-76) and wraps the
+model in DistributedDataParallel (train.py:405-407).  Here `model.train(); model(x)` runs `tr_vit_forward_train` (the forward
+that keeps its activations on a tape) and returns logits that carry an autograd node; `loss.backward()` hands d logits to
+`tr_vit_backward`, which writes every parameter gradient into ONE flat fp32 buffer.  `p.grad` of every parameter is a view
+into that buffer, laid out in the order the backward finishes them (head, norm, blocks depth-1..0, embedding), so a
+data-parallel reducer can all-reduce contiguous slices in place while the rest of the backward is still running
+(dp.GradientAllReducer) -- no flatten/unflatten copies.
+
+PyTorch is plumbing: memory, the stream, the autograd hook and the loss.  No arithmetic of the model happens in torch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Tuple
+
+import torch
+
+from . import _lib
+
+
+def _align4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+def backward_order(model) -> List[Tuple[str, torch.nn.Parameter]]:
+    """(name, parameter) in the order the backward pass finishes their gradients; buckets are contiguous runs of this list."""
+    named = dict(model.named_parameters())
+    order, seen = [], set()
+
+    def take(prefix):
+        for n in named:
+            if (n == prefix or n.startswith(prefix + ".")) and n not in seen:
+                seen.add(n)
+                order.append((n, named[n]))
+
+    take("head")
+    take("norm")
+    for i in reversed(range(model.depth)):
+        take(f"blocks.{i}")
+    for n in list(named):            # family modules (score predictors, cluster layers): finished before the embedding
+        if n not in seen and not n.startswith(("pos_embed", "cls_token", "patch_embed")):
+            take(n)
+    take("pos_embed")
+    take("cls_token")
+    take("patch_embed")
+    return order
+
+
+class TrainState:
+    """Per-model training state: flat gradient buffer + views, transposed weights, tape and workspaces (one batch size)."""
+
+    def __init__(self, model):
+        dev = model.pos_embed.device
+        self.order = backward_order(model)
+        self.offsets, off = {}, 0
+        for n, p in self.order:
+            self.offsets[n] = off
+            off += _align4(p.numel())
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.views = {n: self.flat[o: o + p.numel()].view_as(p) for (n, p), o in zip(self.order, self.offsets.values())}
+        # bucket boundaries: [head+norm+last block] ... per block ... [block 0 + embedding]; event index that completes each
+        self.block_slices = self._block_slices(model)
+        self.B = None
+        self.tape = self.bws = None
+        self.key = None
+        self.events = None
+
+    def _block_slices(self, model):
+        """[(event_index, start, stop)] over the flat buffer: the slice event `e` of tr_vit_backward completes."""
+        names = [n for n, _ in self.order]
+        ends = {}
+        for n, p in self.order:
+            if n.startswith("blocks."):
+                e = int(n.split(".")[1])
+            elif n.startswith(("head", "norm")):
+                e = model.depth - 1                     # finished before the last block's event
+            else:
+                e = model.depth                          # embedding + family modules: the final event
+            ends[e] = self.offsets[n] + _align4(p.numel())
+        out, start = [], 0
+        for e in sorted(ends, key=lambda k: ends[k]):
+            out.append((e, start, ends[e]))
+            start = ends[e]
+        del names
+        return out
+
+    def grads_struct(self, model):
+        """tr_vit_weights-shaped struct whose pointers are the gradient views."""
+        G = _lib.TrVitWeights()
+        v = self.views
+
+        def ptr(name):
+            return v[name].data_ptr()
+
+        G.patch_w, G.patch_b = ptr("patch_embed.proj.weight"), ptr("patch_embed.proj.bias")
+        G.cls_token, G.pos_embed = ptr("cls_token"), ptr("pos_embed")
+        G.norm_g, G.norm_b = ptr("norm.weight"), ptr("norm.bias")
+        G.head_w, G.head_b = ptr("head.weight"), ptr("head.bias")
+        for i in range(model.depth):
+            b, pre = G.blocks[i], f"blocks.{i}."
+            b.ln1_g, b.ln1_b = ptr(pre + "norm1.weight"), ptr(pre + "norm1.bias")
+            b.qkv_w, b.qkv_b = ptr(pre + "attn.qkv.weight"), ptr(pre + "attn.qkv.bias")
+            b.proj_w, b.proj_b = ptr(pre + "attn.proj.weight"), ptr(pre + "attn.proj.bias")
+            b.ln2_g, b.ln2_b = ptr(pre + "norm2.weight"), ptr(pre + "norm2.bias")
+            b.fc1_w, b.fc1_b = ptr(pre + "mlp.fc1.weight"), ptr(pre + "mlp.fc1.bias")
+            b.fc2_w, b.fc2_b = ptr(pre + "mlp.fc2.weight"), ptr(pre + "mlp.fc2.bias")
+        return G
+
+    def transposed(self, model, pk):
+        """bf16 transposed copies of the block matrices (the dgrad GEMM operands), re-made when the parameters change."""
+        if self.key == pk["key"]:
+            return self.wt
+        WT = _lib.TrVitWeights()
+        keep = []
+
+        def t16(w):
+            c = w.detach().t().to(torch.bfloat16).contiguous()
+            keep.append(c)
+            return c.data_ptr()
+
+        for i, blk in enumerate(model.blocks):
+            b = WT.blocks[i]
+            b.qkv_w, b.proj_w = t16(blk.attn.qkv.weight), t16(blk.attn.proj.weight)
+            b.fc1_w, b.fc2_w = t16(blk.mlp.fc1.weight), t16(blk.mlp.fc2.weight)
+        self.wt, self.wt_keep, self.key = WT, keep, pk["key"]
+        return WT
+
+    def buffers(self, model, pk, B, dev):
+        if self.B != B:
+            lib = _lib.load()
+            nt = lib.tr_vit_tape_bytes(C.byref(pk["cfg"]), B)
+            nb = lib.tr_vit_backward_workspace_bytes(C.byref(pk["cfg"]), B)
+            if nt == 0 or nb == 0:
+                raise NotImplementedError(
+                    f"{type(model).__name__}: this family / configuration has no training path in the HIP executor "
+                    "(built: DeiT, Top-K, EViT, ToMe at 224x224, bf16); call model.eval() for inference")
+            self.tape = torch.empty(nt, dtype=torch.uint8, device=dev)
+            self.bws = torch.empty(nb, dtype=torch.uint8, device=dev)
+            self.B = B
+        return self.tape, self.bws
+
+
+TAPE_FIELDS = ("x0", "x1", "xn1", "qkv", "ao", "dattn", "x2", "xn2", "pre", "h", "idx", "idx2", "scores", "size",
+               "n_pre", "n_att", "n_mlp", "kk")
+
+
+def tape_layout(model, blk: int) -> dict:
+    """Offsets / token counts of block `blk` on the tape of the last training forward."""
+    st = model._train_state()
+    out = (C.c_size_t * 18)()
+    _lib.check(_lib.load().tr_vit_tape_layout(C.byref(model._packed["cfg"]), st.B, blk, out), "tr_vit_tape_layout")
+    return dict(zip(TAPE_FIELDS, (int(v) for v in out)))
+
+
+def train_decisions(model) -> dict:
+    """{blk: decision tensors} of the last training forward, read back from the tape (int64 on the host side):
+    Top-K / EViT: idx [B,K]; ToMe: (unm [B,na-r], src [B,r], dst [B,r])."""
+    st = model._train_state()
+    B, out = st.B, {}
+    for blk in range(model.depth):
+        lay = tape_layout(model, blk)
+        k = lay["kk"]
+        if k <= 0:
+            continue
+        raw = st.tape[lay["idx"]: lay["idx"] + 4 * B * lay["n_att"]].view(torch.int32)
+        if model._family in (_lib.TR_FAMILY_TOPK, _lib.TR_FAMILY_EVIT):
+            out[blk] = raw[: B * k].view(B, k).long()
+        elif model._family == _lib.TR_FAMILY_TOME:
+            na = (lay["n_att"] + 1) // 2
+            out[blk] = (raw[: B * (na - k)].view(B, na - k).long(), raw[B * (na - k): B * na].view(B, k).long(),
+                        raw[B * na: B * (na + k)].view(B, k).long())
+    return out
+
+
+class _VitTrainFn(torch.autograd.Function):
+    """logits = model(x) with the backward wired to tr_vit_backward.  `anchor` only makes autograd call backward."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, model):
+        lib = _lib.load()
+        pk = model._pack()
+        cfg = pk["cfg"]
+        B = x.shape[0]
+        st = model._train_state()
+        tape, bws = st.buffers(model, pk, B, x.device)
+        ws = model._workspace(B, x.device)
+        logits = torch.empty(B, model.num_classes, dtype=torch.float32, device=x.device)
+        tokens = (C.c_int * model.depth)()
+        with torch.cuda.device(x.device):
+            rc = lib.tr_vit_forward_train(C.byref(cfg), C.byref(pk["W"]), x.data_ptr(), logits.data_ptr(), ws["buf"].data_ptr(), ws["nbytes"],
+                                          tape.data_ptr(), tape.numel(), model._noise_ptr(B, x.device), tokens, B,
+                                          torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "tr_vit_forward_train")
+        model._last_tokens = list(tokens)
+        ctx.model, ctx.B, ctx.pk = model, B, pk
+        ctx.keep = x
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model, B, pk = ctx.model, ctx.B, ctx.pk
+        lib = _lib.load()
+        st = model._train_state()
+        dl = dlogits.detach().to(torch.float32).contiguous()
+        # gradient views: zero the slices of parameters that hold no gradient yet (zero_grad(set_to_none=True) is torch's
+        # default), keep accumulating into the others (engine.py:41-84: gradient accumulation over micro-steps)
+        fresh = [n for n, p in st.order if p.grad is None or p.grad.data_ptr() != st.views[n].data_ptr()]
+        if len(fresh) == len(st.order):
+            st.flat.zero_()
+        else:
+            for n in fresh:
+                st.views[n].zero_()
+        G = st.grads_struct(model)
+        WT = st.transposed(model, pk)
+        events = model._grad_events(st)
+        with torch.cuda.device(dl.device):
+            rc = lib.tr_vit_backward(C.byref(pk["cfg"]), C.byref(pk["W"]), C.byref(WT), C.byref(G), dl.data_ptr(), st.tape.data_ptr(),
+                                     st.tape.numel(), st.bws.data_ptr(), st.bws.numel(), 1, events, B,
+                                     torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "tr_vit_backward")
+        for n, p in st.order:
+            if not p.requires_grad:
+                continue
+            if p.grad is None:
+                p.grad = st.views[n]
+            elif p.grad.data_ptr() != st.views[n].data_ptr():
+                p.grad.add_(st.views[n])
+        reducer = getattr(model, "_grad_reducer", None)
+        if reducer is not None:
+            reducer.on_backward(st)
+        return None, None, None
+
+
+def train_forward(model, x: torch.Tensor) -> torch.Tensor:
+    if not x.is_cuda:
+        raise RuntimeError(f"input is on {x.device}: tokenreduction_amd has no CPU path (HIP kernels only)")
+    if model.precision != "bf16":
+        raise NotImplementedError("the training path is bf16 (fp32 accumulate); set model.precision = 'bf16'")
+    if model.drop_rate or model.attn_drop_rate or model.drop_path_rate:
+        raise NotImplementedError("dropout / DropPath in the HIP training path are not built: construct the model with "
+                                  "drop_rate=0, drop_path_rate=0 (train.py --drop 0 --drop-path 0)")
+    x = x.detach().to(torch.float32).contiguous()
+    anchor = torch.empty(0, dtype=torch.float32, device=x.device, requires_grad=True)
+    return _VitTrainFn.apply(anchor, x, model)
