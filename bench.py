@@ -148,6 +148,36 @@ def cpu_baseline_leg(model, budget_s=12.0):
                 sample=f"{n} forward passes of batch {bs} (same model/config, fp32 torch-CPU oracle), {el:.1f} s")
 
 
+def finetune_leg(name, keep_rate, loc, batch, device, dist, steps=8, warmup=3, img_size=224):
+    """fwd + loss + bwd + AdamW step through the HIP training path (engine.py:50-91 without the data loader): images/s over all
+    ranks.  Under torch.distributed the gradients are averaged by tokenreduction_amd.dp.FlatGradReducer (RCCL reduce-scatter +
+    all-gather per bucket, overlapped with the backward)."""
+    model = build_model(name, keep_rate, loc, device, img_size).train()
+    rank = dist.get_rank() if dist is not None else 0
+    world = dist.get_world_size() if dist is not None else 1
+    x = torch.randn(batch, 3, img_size, img_size, generator=torch.Generator().manual_seed(200 + rank)).to(device)
+    y = torch.randint(0, 1000, (batch,), generator=torch.Generator().manual_seed(300 + rank)).to(device)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05, fused=True)
+    if dist is not None:
+        from tokenreduction_amd.dp import FlatGradReducer
+        red = FlatGradReducer().attach(model)
+        red.broadcast_parameters(model)
+    last = [None]
+
+    def step():
+        loss = torch.nn.functional.cross_entropy(model(x), y)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        last[0] = loss
+
+    el = timed_steps(step, steps, warmup, dist, torch.cuda.synchronize, device)
+    assert torch.isfinite(last[0]).item()
+    return {"images_per_s": round(world * batch * steps / el, 1), "ms_per_step": round(1e3 * el / steps, 3), "batch_per_gpu": batch,
+            "n_gpus": world, "steps": steps, "warmup": warmup, "optimizer": "AdamW(fused)", "loss_last": round(last[0].item(), 4),
+            "tokens_per_block": model._last_tokens}
+
+
 def timed_steps(step, steps, warmup, dist, sync, device):
     """W untimed + K timed steps bracketed by barrier + device sync on both sides; returns MAX-over-ranks seconds."""
     for _ in range(warmup):
@@ -236,6 +266,11 @@ def main():
     el = timed_steps(step, a.steps, a.warmup, dist, torch.cuda.synchronize, dev)
     assert torch.isfinite(out[0]).all()
 
+    # fine-tune leg (all ranks take part: it contains the gradient collectives).  Extra key, outside the headline's timed region.
+    finetune = None
+    if not a.no_extra:
+        finetune = {"topk_small kr0.7 B=256/GPU (configs[1] model, fwd+bwd+AdamW)":
+                    finetune_leg(MODEL, KEEP_RATE, REDUCTION_LOC, BATCH, dev, dist)}
     if rank == 0:
         ips = world * BATCH * a.steps / el
         tokens = model._last_tokens
@@ -251,7 +286,14 @@ def main():
             "model_tflops": round(ips * gflop / 1e3, 1),
             "model_mfma_frac": round(ips * gflop / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
         }
+        if finetune is not None:
+            rec["finetune"] = finetune
         if world == 1 and not a.no_extra:
+            for label, name, kr, loc, bsz in (("deit_small dense B=256 (fwd+bwd+AdamW)", "deit_small_patch16_224_local", [1.0], [], 256),
+                                              ("evit_small kr0.7 B=256 (fwd+bwd+AdamW)", "evit_small_patch16_224", [0.7], [3, 6, 9], 256),
+                                              ("tome_small r16 B=256 (fwd+bwd+AdamW)", "tome_small_patch16_224",
+                                               [196 - 16 * (i + 1) for i in range(12)], list(range(12)), 256)):
+                rec["finetune"][label] = finetune_leg(name, kr, loc, bsz, dev, None, steps=5, warmup=2)
             roof, table, step_ms = roofline_leg(model, x)
             roof["traffic"] = pmc_traffic(roof["kernel"])
             rec["roofline"] = roof

@@ -227,7 +227,8 @@ int tr_tome_merge_layernorm(const float* x, const void* delta, int f32_path, con
  *   (r == 0 ? 0 : 1 + idx[b,r-1]) of [B, n_out, D] and the fused row to g_fused fp32 [B, D] (the caller zero-fills g_out/gb_out).
  *   ws: tr_layernorm_bwd_workspace_floats(M, D) floats.
  * tr_attention_bwd_bf16: d qkv from d out (see csrc/tr_attention_bwd.hip), N <= 224.
- * tr_head_bwd: dxn bf16 [B,D] = dlogits W; dW (+)= dlogits^T xn; db (+)= colsum(dlogits)   (topk.py:203; W, xn bf16).
+ * tr_head_bwd: dxn bf16 [B,D] = dlogits W; dW (+)= dlogits^T xn; db (+)= colsum(dlogits)   (topk.py:203; W, xn bf16); the weight and
+ *   bias gradients run through tr_wgrad_bf16 / tr_colsum_bf16 on dl16, a bf16 copy of dlogits ([B,C] scratch); ws as tr_wgrad_bf16.
  * tr_embed_bwd: d pos_embed [N,D] (+)= sum_b g[b,n,:], d cls_token [D] (+)= sum_b g[b,0,:]   (topk.py:183-186).
  * tr_evit_fuse_bwd: evit.py:117-120: g_out[b,1+c,:] = scores[b,c] g_fused[b] (fp32 + bf16 copy) for the complement tokens c,
  *   dscore[b,1+c] = <x[b,1+c] + delta[b,1+c], g_fused[b]>  (dscore fp32 [B,N], zero-filled by the caller).
@@ -248,7 +249,7 @@ int tr_layernorm_bwd(const uint16_t* dy, const float* x, long ldx, const float* 
 int tr_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, const float* size, const float* dcls, uint16_t* dqkv, int B,
                           int N, int H, tr_stream_t s);
 int tr_head_bwd(const float* dlogits, const uint16_t* W, const uint16_t* xn, uint16_t* dxn, float* dW, float* db, int accumulate,
-                int B, int C, int D, tr_stream_t s);
+                uint16_t* dl16, float* ws, size_t ws_floats, int B, int C, int D, tr_stream_t s);
 int tr_embed_bwd(const float* g, float* dpos, float* dcls, int accumulate, int B, int N, int D, tr_stream_t s);
 int tr_evit_fuse_bwd(const float* x, const uint16_t* delta, const int32_t* compl_idx, const float* scores, const float* g_fused,
                      float* g_out, uint16_t* gb_out, float* dscore, int B, int N, int K, int D, tr_stream_t s);
@@ -355,8 +356,10 @@ int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w, const floa
  * tr_vit_backward: dlogits fp32 [B,classes] -> parameter gradients.  `w` = the forward's weights; `wt` = same struct with the block
  *   matrices TRANSPOSED (bf16: qkv_w [D,3D], proj_w [D,D], fc1_w [D,Hd], fc2_w [Hd,D]); `grads` = same struct, every pointer an
  *   fp32 buffer of the parameter's shape (written; added to when accumulate != 0).  workspace: tr_vit_backward_workspace_bytes.
- *   block_events (nullable): hipEvent_t[depth+1] recorded on the stream as each block's gradients (index = block; depth = embedding,
- *   last) are enqueued -- the hook for overlapping the data-parallel gradient reduction (train.py:405-407) with the backward. */
+ *   [blk_hi .. blk_lo]: the blocks this call walks, in reverse; blk_hi == depth-1 runs the classifier + final norm first, blk_lo == 0
+ *   the embedding gradients last; a whole pass is (depth-1, 0) or consecutive ranges in descending order (the stream's gradient
+ *   stays in the workspace in between) -- the hook for overlapping the data-parallel gradient reduction (train.py:405-407) with
+ *   the backward: reduce one range's gradients on a second stream while the next range runs. */
 size_t tr_vit_tape_bytes(const tr_vit_config* cfg, int B);
 int tr_vit_forward_train(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits, void* workspace,
                          size_t workspace_bytes, void* tape, size_t tape_bytes, const float* noise_in, int* tokens_out, int B,
@@ -367,7 +370,7 @@ int tr_vit_tape_layout(const tr_vit_config* cfg, int B, int blk, size_t* out18);
 size_t tr_vit_backward_workspace_bytes(const tr_vit_config* cfg, int B);
 int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w, const tr_vit_weights* wt, const tr_vit_weights* grads,
                     const float* dlogits, const void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes, int accumulate,
-                    void** block_events, int B, tr_stream_t s);
+                    int blk_hi, int blk_lo, int B, tr_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -1,4 +1,10 @@
-"""Row a24: bucketed gradient mean over a data-parallel group, exercised on CPU with gloo, world_size 2."""
+"""Row a24: bucketed in-place gradient mean over a data-parallel group, exercised on CPU with gloo, world_size 2.
+
+The HIP backward cannot run here, so each rank fills the model's flat gradient buffer (training.TrainState: the real layout,
+the real bucket plan) with the gradients torch.autograd gives over the oracle on the rank's own shard of images -- the same
+values `loss.backward()` produces on the GPU up to bf16 rounding (tests/test_hip_train.py) -- and the reducer must turn them
+into the mean over the ranks, bucket by bucket, in place.
+"""
 import os
 import subprocess
 import sys
@@ -7,40 +13,50 @@ import textwrap
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = textwrap.dedent("""
-    import os, sys
+    import os, sys, types
     sys.path.insert(0, %r)
     import torch, torch.distributed as dist
-    from tokenreduction_amd.dp import GradientAllReducer
+    import tokenreduction_amd as tra
+    from tokenreduction_amd import training
+    from tokenreduction_amd.dp import FlatGradReducer
+    from tests._params import GOLDEN_CASES, case_params, oracle_param_grads
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    torch.manual_seed(0)                                   # identical replicas
-    model = torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.GELU(), torch.nn.Linear(64, 64), torch.nn.GELU(),
-                                torch.nn.Linear(64, 10))
-    unused = torch.nn.Parameter(torch.ones(7))             # a parameter no loss touches
-    params = list(model.parameters()) + [unused]
-    red = GradientAllReducer(params, bucket_bytes=8 * 1024).attach()
-    assert len(red.buckets) >= 3, len(red.buckets)         # several buckets, reverse parameter order
-    assert red.buckets[0][0] is unused and red.buckets[-1][-1] is params[0]
-    for step in range(2):
-        g = torch.Generator().manual_seed(100 + 10 * step + rank)          # every rank its own shard
-        x, y = torch.randn(16, 32, generator=g), torch.randint(0, 10, (16,), generator=g)
-        for p in params:
-            p.grad = None
-        red.start()
-        torch.nn.functional.cross_entropy(model(x), y).backward()
-        red.finish()
-        # expected: mean over ranks of the per-rank gradients, recomputed locally from both shards
-        want = [torch.zeros_like(p) for p in params]
-        for r in range(world):
-            g = torch.Generator().manual_seed(100 + 10 * step + r)
-            xr, yr = torch.randn(16, 32, generator=g), torch.randint(0, 10, (16,), generator=g)
-            grads = torch.autograd.grad(torch.nn.functional.cross_entropy(model(xr), yr), list(model.parameters()))
-            for w, gr in zip(want, grads):
-                w += gr / world
-        for p, w in zip(params, want):
-            assert torch.allclose(p.grad, w, atol=1e-6), (step, (p.grad - w).abs().max())
+    case = dict(GOLDEN_CASES["topk_micro"])
+    args = types.SimpleNamespace(keep_rate=case["keep_rate"], reduction_loc=case["reduction_loc"])
+    model = tra.TopKVisionTransformer(img_size=224, patch_size=16, embed_dim=128, depth=4, num_heads=2, mlp_ratio=4, qkv_bias=True,
+                                      num_classes=16, args=args)
+    cfg, params = case_params(case)
+    model.load_state_dict(params)
+    st = training.TrainState(model)                        # flat buffer in backward order, p.grad views
+    red = FlatGradReducer(bucket_bytes=256 * 1024).attach(model)
+    red.broadcast_parameters(model)
+    plan = red.plan(st.block_slices, model.depth)
+    assert len(plan) >= 3, plan                            # several buckets
+    assert plan[0][0] == model.depth - 1 and plan[-1][1] == 0 and plan[0][2] == 0 and plan[-1][3] == st.flat.numel()
+    assert all(a[3] == b[2] and a[1] == b[0] + 1 for a, b in zip(plan, plan[1:])), plan      # contiguous slices, consecutive ranges
+    assert all((b[3] - b[2]) %% 64 == 0 for b in plan)
+
+    def local_grads(r):
+        c = dict(case, xseed=case["xseed"] + 100 * r)      # every rank its own shard of images / labels
+        return oracle_param_grads(c)[2]
+
+    mine = local_grads(rank)
+    for n, p in st.order:
+        st.views[n].copy_(mine[n])
+        p.grad = st.views[n]
+    for hi, lo, start, stop in plan:                       # what training._VitTrainFn.backward does after each block range
+        red.reduce_slice(st.flat, start, stop)
+    red.finish(st.flat)
+    want = {n: sum(local_grads(r)[n] for r in range(world)) / world for n, _ in st.order}
+    for n, p in model.named_parameters():
+        assert torch.allclose(p.grad, want[n], rtol=1e-6, atol=1e-8), (n, (p.grad - want[n]).abs().max())
+    # no_sync: nothing is reduced (gradient accumulation micro-steps)
+    with red.no_sync():
+        assert red.sync is False
+    assert red.sync is True
     if rank == 0:
-        print("dp ok", len(red.buckets), "buckets")
+        print("dp ok", len(plan), "buckets")
     dist.destroy_process_group()
 """) % ROOT
 
@@ -48,8 +64,8 @@ WORKER = textwrap.dedent("""
 def test_bucketed_gradient_mean_gloo_world2(tmp_path):
     script = tmp_path / "dp_worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29617", str(script)], capture_output=True, text=True, env=env, timeout=240)
+                          "--master-port", "29617", str(script)], capture_output=True, text=True, env=env, timeout=400)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert "dp ok" in out.stdout

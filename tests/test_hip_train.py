@@ -144,3 +144,38 @@ def test_unsupported_family_raises_in_train_mode():
     x = make_images(case["batch"], 224, case["xseed"]).cuda()
     with pytest.raises(NotImplementedError, match="no training path"):
         model.train()(x)
+
+
+def test_gradient_reducer_on_rccl_world1():
+    """The data-parallel path on RCCL with one rank (the GPU box has one GPU): the backward runs in per-bucket block ranges, each
+    bucket is reduce-scattered + all-gathered in place on the side stream; with world size 1 the mean is the identity, so the
+    gradients must equal the plain single-call backward bit for bit."""
+    import torch.distributed as dist
+    from tokenreduction_amd.dp import FlatGradReducer
+    case = GOLDEN_CASES["evit_micro"]
+    model, *_ = _train_step(case)
+    want = {n: p.grad.clone() for n, p in model.named_parameters()}
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29571")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        red = FlatGradReducer(bucket_bytes=512 * 1024).attach(model)
+        assert red.algorithm == "rs_ag"
+        red.broadcast_parameters(model)
+        x = make_images(case["batch"], 224, case["xseed"]).cuda()
+        for rep in range(2):
+            model.zero_grad(set_to_none=True)
+            torch.nn.functional.cross_entropy(model(x), grad_labels(case).cuda()).backward()
+            torch.cuda.synchronize()
+            assert len(red.launched) >= 3 and red.launched[-1][1] == model._train_state().flat.numel()
+            for n, p in model.named_parameters():
+                assert torch.equal(p.grad, want[n]), (rep, n)
+        with red.no_sync():                                   # accumulation micro-step: no collective, gradients add up
+            red.launched = []
+            torch.nn.functional.cross_entropy(model(x), grad_labels(case).cuda()).backward()
+            assert red.launched == []
+        for n, p in model.named_parameters():
+            assert torch.allclose(p.grad, 2 * want[n], rtol=1e-5, atol=1e-7), n
+    finally:
+        model._grad_reducer = None
+        dist.destroy_process_group()

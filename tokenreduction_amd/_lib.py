@@ -90,7 +90,7 @@ SIGNATURES = {
     "tr_layernorm_bwd_workspace_floats": (_sz, [_i, _i]),
     "tr_layernorm_bwd": (_i, [_vp, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _i, _i, _f, _vp]),
     "tr_attention_bwd_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
-    "tr_head_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "tr_head_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _i, _i, _i, _vp]),
     "tr_embed_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tr_evit_fuse_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tr_tome_merge_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
@@ -101,7 +101,7 @@ SIGNATURES = {
     "tr_vit_tape_layout": (_i, [C.POINTER(TrVitConfig), _i, _i, C.POINTER(_sz)]),
     "tr_vit_backward_workspace_bytes": (_sz, [C.POINTER(TrVitConfig), _i]),
     "tr_vit_backward": (_i, [C.POINTER(TrVitConfig), C.POINTER(TrVitWeights), C.POINTER(TrVitWeights), C.POINTER(TrVitWeights), _vp, _vp, _sz,
-                             _vp, _sz, _i, C.POINTER(_vp), _i, _vp]),
+                             _vp, _sz, _i, _i, _i, _i, _vp]),
     "tr_vit_forward": (_i, [C.POINTER(TrVitConfig), C.POINTER(TrVitWeights), _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp,
                             C.POINTER(_i), _i, _vp]),
 }

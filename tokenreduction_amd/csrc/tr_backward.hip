@@ -136,24 +136,56 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const uint16_t* __restric
     }
 }
 
-// dst[e] = (accumulate ? dst[e] : 0) + sum_s part[s][e]   (fixed order: deterministic)
+// dst[e] = (accumulate ? dst[e] : 0) + sum_s part[s][e].  Block = 64 float4 chunks x 4 partial-lanes: lane y sums partials
+// y, y+4, ... (independent loads, 4 in flight), the four lane sums are combined in lane order -- a fixed order, so the result is
+// bitwise reproducible.  (One thread per chunk walking all S partials was a chain of up to 1024 dependent round trips: 53 % of a
+// training step in the first profile.)
 __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ part, int S, size_t count, float* __restrict__ dst,
                                                              int accumulate) {
-  const size_t e = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  if (e >= count) return;
-  if (e + 4 <= count) {
-    float4 a = accumulate ? *reinterpret_cast<const float4*>(dst + e) : make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int s = 0; s < S; ++s) {
+  __shared__ float4 red[3][64];
+  const int cx = threadIdx.x & 63, y = threadIdx.x >> 6;
+  const size_t e = ((size_t)blockIdx.x * 64 + cx) * 4;
+  const bool full = e + 4 <= count, any = e < count;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (full) {
+    int s = y;
+    for (; s + 12 < S; s += 16) {
+      const float4 v0 = *reinterpret_cast<const float4*>(part + (size_t)s * count + e);
+      const float4 v1 = *reinterpret_cast<const float4*>(part + (size_t)(s + 4) * count + e);
+      const float4 v2 = *reinterpret_cast<const float4*>(part + (size_t)(s + 8) * count + e);
+      const float4 v3 = *reinterpret_cast<const float4*>(part + (size_t)(s + 12) * count + e);
+      a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
+      a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; s < S; s += 4) {
       const float4 v = *reinterpret_cast<const float4*>(part + (size_t)s * count + e);
       a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
     }
+  } else if (any) {
+    float t[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = y; s < S; s += 4)
+      for (int i = 0; i < 4; ++i)
+        if (e + i < count) t[i] += part[(size_t)s * count + e + i];
+    a = make_float4(t[0], t[1], t[2], t[3]);
+  }
+  if (y > 0) red[y - 1][cx] = a;
+  __syncthreads();
+  if (y > 0 || !any) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    const float4 v = red[w][cx];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  if (full) {
+    if (accumulate) {
+      const float4 d = *reinterpret_cast<const float4*>(dst + e);
+      a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+    }
     *reinterpret_cast<float4*>(dst + e) = a;
   } else {
-    for (size_t i = e; i < count; ++i) {
-      float a = accumulate ? dst[i] : 0.f;
-      for (int s = 0; s < S; ++s) a += part[(size_t)s * count + i];
-      dst[i] = a;
-    }
+    const float t[4] = {a.x, a.y, a.z, a.w};
+    for (int i = 0; i < 4; ++i)
+      if (e + i < count) dst[e + i] = (accumulate ? dst[e + i] : 0.f) + t[i];
   }
 }
 
@@ -343,41 +375,50 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const uint16_t* __restrict_
   }
 }
 
-// ---- classifier (topk.py:203) backward on the CLS rows: tiny (B x C x D), fp32 accumulate, one output element per thread
+// ---- classifier (topk.py:203) backward on the CLS rows.  dxn[b][d] = sum_c dlogits[b][c] W[c][d]: grid (B, D/64), block = 64 d x 4
+// class-partitions combined through LDS in partition order (C = 1000 is not a multiple of the MFMA GEMM's K step; the product is
+// tiny: B x C x D).  The weight gradient goes through tr_wgrad_bf16 / tr_colsum_bf16 on a bf16 copy of dlogits.
 __global__ __launch_bounds__(256) void head_dx_kernel(const float* __restrict__ dlogits, const uint16_t* __restrict__ W, uint16_t* __restrict__ dxn,
                                                       int B, int C, int D) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= B * D) return;
-  const int b = t / D, d = t - b * D;
-  float a = 0.f;
-  for (int c = 0; c < C; ++c) a += dlogits[(size_t)b * C + c] * bf16_bits_to_f32(W[(size_t)c * D + d]);
-  dxn[t] = (uint16_t)(pack_bf16x2(a, 0.f) & 0xffffu);
-}
-__global__ __launch_bounds__(256) void head_dw_kernel(const float* __restrict__ dlogits, const uint16_t* __restrict__ xn, float* __restrict__ dW,
-                                                      float* __restrict__ db, int B, int C, int D, int accumulate) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= C * (D + 1)) return;
-  const int c = t / (D + 1), d = t - c * (D + 1);
-  float a = 0.f;
-  if (d < D) {
-    for (int b = 0; b < B; ++b) a += dlogits[(size_t)b * C + c] * bf16_bits_to_f32(xn[(size_t)b * D + d]);
-    float* o = dW + (size_t)c * D + d;
-    *o = accumulate ? *o + a : a;
-  } else {
-    for (int b = 0; b < B; ++b) a += dlogits[(size_t)b * C + c];
-    db[c] = accumulate ? db[c] + a : a;
+  __shared__ float red[3][64];
+  const int b = blockIdx.x, dl = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int d = min(blockIdx.y * 64 + dl, D - 1);
+  float a0 = 0.f, a1 = 0.f;
+  int c = part;
+  for (; c + 4 < C; c += 8) {
+    a0 += dlogits[(size_t)b * C + c] * bf16_bits_to_f32(W[(size_t)c * D + d]);
+    a1 += dlogits[(size_t)b * C + c + 4] * bf16_bits_to_f32(W[(size_t)(c + 4) * D + d]);
   }
+  for (; c < C; c += 4) a0 += dlogits[(size_t)b * C + c] * bf16_bits_to_f32(W[(size_t)c * D + d]);
+  float a = a0 + a1;
+  if (part > 0) red[part - 1][dl] = a;
+  __syncthreads();
+  if (part > 0 || blockIdx.y * 64 + dl >= D) return;
+  a += red[0][dl];
+  a += red[1][dl];
+  a += red[2][dl];
+  dxn[(size_t)b * D + d] = (uint16_t)(pack_bf16x2(a, 0.f) & 0xffffu);
 }
 
-// ---- d pos_embed[n][:] = sum_b g[b][n][:], d cls_token = sum_b g[b][0][:]   (topk.py:183-186)
+// ---- d pos_embed[n][:] = sum_b g[b][n][:], d cls_token = sum_b g[b][0][:]   (topk.py:183-186); block = 64 chunks x 4 batch lanes
 __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ g, float* __restrict__ dpos, float* __restrict__ dcls, int B,
                                                         int N, int D, int accumulate) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float4 red[3][64];
+  const int cx = threadIdx.x & 63, y = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + cx;
   const int nch = N * (D >> 2);
-  if (t >= nch) return;
+  const int tc = min(t, nch - 1);
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int b = 0; b < B; ++b) {
-    const float4 v = *reinterpret_cast<const float4*>(g + (size_t)b * N * D + 4 * (size_t)t);
+  for (int b = y; b < B; b += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(g + (size_t)b * N * D + 4 * (size_t)tc);
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  if (y > 0) red[y - 1][cx] = a;
+  __syncthreads();
+  if (y > 0 || t >= nch) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    const float4 v = red[w][cx];
     a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
   }
   float4* o = reinterpret_cast<float4*>(dpos + 4 * (size_t)t);
@@ -486,7 +527,7 @@ __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restric
 }
 
 inline int reduce_partials(const float* part, int S, size_t count, float* dst, int accumulate, hipStream_t st) {
-  const unsigned nb = (unsigned)((count / 4 + 1 + 255) / 256);
+  const unsigned nb = (unsigned)(((count + 3) / 4 + 63) / 64);
   hipLaunchKernelGGL(partial_reduce_kernel, dim3(nb), dim3(256), 0, st, part, S, count, dst, accumulate);
   return 0;
 }
@@ -574,7 +615,7 @@ extern "C" int tr_gelu_bwd_bf16(const uint16_t* pre, uint16_t* dh, size_t n, tr_
 
 static inline int ln_bwd_grid(int M) {
   int g = (M + 3) / 4;
-  return g > 1024 ? 1024 : g;
+  return g > 512 ? 512 : g;
 }
 
 extern "C" size_t tr_layernorm_bwd_workspace_floats(int M, int D) { return (size_t)ln_bwd_grid(M) * 2 * D; }
@@ -604,22 +645,26 @@ extern "C" int tr_layernorm_bwd(const uint16_t* dy, const float* x, long ldx, co
   return TR_OK;
 }
 
+// dl16: bf16 scratch [B, C]; ws: tr_wgrad_workspace_floats(B, C, D) floats
 extern "C" int tr_head_bwd(const float* dlogits, const uint16_t* W, const uint16_t* xn, uint16_t* dxn, float* dW, float* db,
-                           int accumulate, int B, int C, int D, tr_stream_t s) {
-  TR_REQUIRE(dlogits && W && xn && dxn && dW && db, TR_ERR_NULL, "tr_head_bwd: null pointer");
-  TR_REQUIRE(B > 0 && C > 0 && D > 0, TR_ERR_SHAPE, "tr_head_bwd: bad shape B=%d C=%d D=%d", B, C, D);
+                           int accumulate, uint16_t* dl16, float* ws, size_t ws_floats, int B, int C, int D, tr_stream_t s) {
+  TR_REQUIRE(dlogits && W && xn && dxn && dW && db && dl16 && ws, TR_ERR_NULL, "tr_head_bwd: null pointer");
+  TR_REQUIRE(B > 0 && C > 0 && D > 0 && C % 8 == 0 && D % 8 == 0, TR_ERR_SHAPE, "tr_head_bwd: need classes, D multiples of 8 (B=%d C=%d D=%d)", B, C, D);
   hipStream_t st = static_cast<hipStream_t>(s);
-  hipLaunchKernelGGL(head_dx_kernel, dim3((B * D + 255) / 256), dim3(256), 0, st, dlogits, W, dxn, B, C, D);
-  hipLaunchKernelGGL(head_dw_kernel, dim3((C * (D + 1) + 255) / 256), dim3(256), 0, st, dlogits, xn, dW, db, B, C, D, accumulate);
+  hipLaunchKernelGGL(head_dx_kernel, dim3(B, (D + 63) / 64), dim3(256), 0, st, dlogits, W, dxn, B, C, D);
   TR_CHECK_LAUNCH("tr_head_bwd");
-  return TR_OK;
+  int rc = tr_f32_to_bf16(dlogits, dl16, (size_t)B * C, s);
+  if (rc != TR_OK) return rc;
+  rc = tr_wgrad_bf16(dl16, C, 0, xn, D, dW, accumulate, ws, ws_floats, B, C, D, s);
+  if (rc != TR_OK) return rc;
+  return tr_colsum_bf16(dl16, C, 0, db, accumulate, ws, ws_floats, B, C, s);
 }
 
 extern "C" int tr_embed_bwd(const float* g, float* dpos, float* dcls, int accumulate, int B, int N, int D, tr_stream_t s) {
   TR_REQUIRE(g && dpos && dcls, TR_ERR_NULL, "tr_embed_bwd: null pointer");
   TR_REQUIRE(B > 0 && N > 0 && D > 0 && D % 4 == 0, TR_ERR_SHAPE, "tr_embed_bwd: bad shape B=%d N=%d D=%d", B, N, D);
   TR_REQUIRE(tr_aligned16(g) && tr_aligned16(dpos) && tr_aligned16(dcls), TR_ERR_ALIGN, "tr_embed_bwd: pointers must be 16-byte aligned");
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3((N * (D / 4) + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(s), g, dpos, dcls, B, N, D, accumulate);
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3((N * (D / 4) + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(s), g, dpos, dcls, B, N, D, accumulate);
   TR_CHECK_LAUNCH("tr_embed_bwd");
   return TR_OK;
 }

@@ -6,8 +6,8 @@
 // the tape the forward left (tr_plan.h): block by block in reverse, for each nn.Linear a weight-gradient GEMM (tr_wgrad_bf16), a
 // bias column sum and a data-gradient GEMM (tr_gemm_bf16 on the transposed weight), the attention / LayerNorm / GELU backward
 // kernels, and the backward of the block's token reduction (Top-K scatter topk.py:89-93, EViT fused token evit.py:111-123, ToMe
-// merge tome.py:309-323).  After each block's parameter gradients are enqueued an optional event is recorded, so the caller can
-// start that bucket's RCCL reduce on a second stream while the rest of the backward runs (the DDP overlap).
+// merge tome.py:309-323).  A call may cover a RANGE of blocks [blk_hi .. blk_lo]: the caller walks the model in a few ranges and,
+// after each, starts that range's gradient bucket on RCCL from a second stream while the next range runs (the DDP overlap).
 // Host-side only: no allocation, no synchronisation -- capturable in a hipGraph.
 #include "tr_common.h"
 #include "tr_plan.h"
@@ -17,7 +17,7 @@ using trplan::align_up;
 namespace {
 
 struct BwdPlan {
-  size_t g0, g1, gb0, gb1, dxn, dqkv, dao, dh, zeros, wsf, dscore, gfused, invmap, dxcls, total;
+  size_t g0, g1, gb0, gb1, dxn, dqkv, dao, dh, zeros, wsf, dscore, gfused, invmap, dxcls, dl16, total;
   size_t wsf_floats;
 };
 
@@ -47,12 +47,14 @@ bool make_bwd_plan(const tr_vit_config* c, int B, const trplan::TokenPlan& t, Bw
   upd(tr_colsum_workspace_floats((int)T, (int)(3 * D)));
   upd(tr_colsum_workspace_floats((int)T, (int)Hd));
   upd(tr_layernorm_bwd_workspace_floats((int)T, (int)D));
+  upd(tr_wgrad_workspace_floats(B, c->num_classes, (int)D));
   p->wsf_floats = f;
   p->wsf = take(f * 4);
   p->dscore = take(T * 4);
   p->gfused = take((size_t)B * D * 4);
   p->invmap = take(T * 4);
   p->dxcls = take((size_t)B * D * 2);
+  p->dl16 = take((size_t)B * c->num_classes * 2);
   p->total = o;
   return true;
 }
@@ -79,11 +81,12 @@ extern "C" size_t tr_vit_backward_workspace_bytes(const tr_vit_config* cfg, int 
 //     [D,Hd], fc2_w = fc2.weight^T [Hd,D]; other fields unused.  w: the forward's weights (head_w and the LayerNorm gammas are read).
 // grads: same layout as tr_vit_weights, every pointer an fp32 gradient buffer of the parameter's shape (matrices included).
 // accumulate != 0: gradients are added to the buffers (engine.py:41 grad accumulation), else overwritten.
-// block_events (nullable): hipEvent_t[depth + 1]; event i is recorded once block i's parameter gradients are enqueued, event
-// `depth` after the embedding gradients (the last ones).  The head / final norm gradients precede event depth-1.
+// [blk_hi .. blk_lo] (blk_hi >= blk_lo): the blocks this call walks, in reverse.  blk_hi == depth-1 also runs the classifier and
+// the final norm first; blk_lo == 0 also runs the embedding gradients last.  The gradient of the residual stream stays in the
+// workspace between calls, so a backward pass is the calls (depth-1 .. a), (a-1 .. b), ..., (c .. 0) in this order.
 extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w, const tr_vit_weights* wt, const tr_vit_weights* grads,
                                const float* dlogits, const void* tape_, size_t tape_bytes, void* workspace, size_t workspace_bytes,
-                               int accumulate, void** block_events, int B, tr_stream_t s) {
+                               int accumulate, int blk_hi, int blk_lo, int B, tr_stream_t s) {
   TR_REQUIRE(cfg && w && wt && grads && dlogits && tape_ && workspace, TR_ERR_NULL, "tr_vit_backward: null pointer");
   TR_REQUIRE(cfg->precision == TR_PREC_BF16 && trplan::trainable_family(cfg->family), TR_ERR_CONFIG,
              "tr_vit_backward: family %d / precision %d has no training path", cfg->family, cfg->precision);
@@ -95,6 +98,7 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
   TR_REQUIRE(tape_bytes >= tp.total && workspace_bytes >= bp.total, TR_ERR_SHAPE, "tr_vit_backward: tape (%zu < %zu) or workspace (%zu < %zu) too small",
              tape_bytes, tp.total, workspace_bytes, bp.total);
   TR_REQUIRE(tr_aligned16(tape_) && tr_aligned16(workspace), TR_ERR_ALIGN, "tr_vit_backward: tape / workspace must be 16-byte aligned");
+  TR_REQUIRE(blk_lo >= 0 && blk_hi >= blk_lo && blk_hi < cfg->depth, TR_ERR_CONFIG, "tr_vit_backward: bad block range [%d .. %d]", blk_hi, blk_lo);
   const char* tape = static_cast<const char*>(tape_);
   char* ws = static_cast<char*>(workspace);
   hipStream_t st = static_cast<hipStream_t>(s);
@@ -117,19 +121,27 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
   const size_t wsn = bp.wsf_floats;
   const int acc = accumulate ? 1 : 0;
 
-  size_t zmax = (size_t)(3 * D > Hd ? 3 * D : Hd);
-  if ((size_t)kcols > zmax) zmax = kcols;
-  TR_REQUIRE(hipMemsetAsync(zeros, 0, zmax * 4, st) == hipSuccess, TR_ERR_LAUNCH, "tr_vit_backward: memset failed");
+  // which of the two stream-gradient buffers is current at block blk_hi: they swap at every block that reduces tokens
+  for (int j = cfg->depth - 1; j > blk_hi; --j)
+    if ((cfg->family == TR_FAMILY_TOPK || cfg->family == TR_FAMILY_EVIT || cfg->family == TR_FAMILY_TOME) && t.kk[j] > 0) {
+      float* tg = g; g = g_alt; g_alt = tg;
+      uint16_t* tb = gb; gb = gb_alt; gb_alt = tb;
+    }
+  if (blk_hi == cfg->depth - 1) {
+    size_t zmax = (size_t)(3 * D > Hd ? 3 * D : Hd);
+    if ((size_t)kcols > zmax) zmax = kcols;
+    TR_REQUIRE(hipMemsetAsync(zeros, 0, zmax * 4, st) == hipSuccess, TR_ERR_LAUNCH, "tr_vit_backward: memset failed");
+    // ---- classifier + final norm (topk.py:201-203): gradient enters the CLS rows of the last block's output stream
+    const int Nl = t.n_mlp[cfg->depth - 1];
+    TR_TRY(tr_head_bwd(dlogits, U(w->head_w), U(tape + tp.xcls), dxcls, F(grads->head_w), F(grads->head_b), acc,
+                       reinterpret_cast<uint16_t*>(ws + bp.dl16), wsf, wsn, B, C, D, s));
+    TR_REQUIRE(hipMemsetAsync(g, 0, (size_t)B * Nl * D * 4, st) == hipSuccess, TR_ERR_LAUNCH, "tr_vit_backward: memset failed");
+    TR_TRY(tr_layernorm_bwd(dxcls, reinterpret_cast<const float*>(tape + tp.xfinal), D, w->norm_g, nullptr, 0, g, (long)Nl * D, nullptr, nullptr, 0, 0,
+                            0, nullptr, F(grads->norm_g), F(grads->norm_b), acc, wsf, wsn, B, D, cfg->ln_eps, s));
+    TR_TRY(tr_f32_to_bf16(g, gb, (size_t)B * Nl * D, s));
+  }
 
-  // ---- classifier + final norm (topk.py:201-203): gradient enters the CLS rows of the last block's output stream
-  const int Nl = t.n_mlp[cfg->depth - 1];
-  TR_TRY(tr_head_bwd(dlogits, U(w->head_w), U(tape + tp.xcls), dxcls, F(grads->head_w), F(grads->head_b), acc, B, C, D, s));
-  TR_REQUIRE(hipMemsetAsync(g, 0, (size_t)B * Nl * D * 4, st) == hipSuccess, TR_ERR_LAUNCH, "tr_vit_backward: memset failed");
-  TR_TRY(tr_layernorm_bwd(dxcls, reinterpret_cast<const float*>(tape + tp.xfinal), D, w->norm_g, nullptr, 0, g, (long)Nl * D, nullptr, nullptr, 0, 0,
-                          0, nullptr, F(grads->norm_g), F(grads->norm_b), acc, wsf, wsn, B, D, cfg->ln_eps, s));
-  TR_TRY(tr_f32_to_bf16(g, gb, (size_t)B * Nl * D, s));
-
-  for (int i = cfg->depth - 1; i >= 0; --i) {
+  for (int i = blk_hi; i >= blk_lo; --i) {
     const trplan::BlockTape& bt = tp.blk[i];
     const tr_block_weights* bw = &w->blocks[i];
     const tr_block_weights* bwt = &wt->blocks[i];
@@ -195,14 +207,11 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
     TR_TRY(tr_gemm_bf16(dqkv, U(bwt->qkv_w), zeros, dxn, nullptr, 0, M1, D, 3 * D, TR_EPI_BF16, s));
     TR_TRY(tr_layernorm_bwd(dxn, x1, D, bw->ln1_g, g, D, g, D, gb, nullptr, 0, 0, 0, nullptr, F(bg->ln1_g), F(bg->ln1_b), acc, wsf, wsn, M1, D,
                             cfg->ln_eps, s));
-    if (block_events && block_events[i])
-      TR_REQUIRE(hipEventRecord(static_cast<hipEvent_t>(block_events[i]), st) == hipSuccess, TR_ERR_LAUNCH, "tr_vit_backward: event record failed");
   }
+  if (blk_lo > 0) return TR_OK;
   // ---- embedding (topk.py:181-186): g is d x0 [B, N0, D]
   TR_TRY(tr_embed_bwd(g, F(grads->pos_embed), F(grads->cls_token), acc, B, t.N0, D, s));
   TR_TRY(tr_wgrad_bf16(gb, D, t.P, U(tape + tp.cols), kcols, F(grads->patch_w), acc, wsf, wsn, B * t.P, D, kcols, s));
   TR_TRY(tr_colsum_bf16(gb, D, t.P, F(grads->patch_b), acc, wsf, wsn, B * t.P, D, s));
-  if (block_events && block_events[cfg->depth])
-    TR_REQUIRE(hipEventRecord(static_cast<hipEvent_t>(block_events[cfg->depth]), st) == hipSuccess, TR_ERR_LAUNCH, "tr_vit_backward: event record failed");
   return TR_OK;
 }

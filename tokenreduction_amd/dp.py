@@ -1,131 +1,124 @@
 """Data-parallel gradient reduction.
 
-The reference wraps the model in `torch.nn.parallel.DistributedDataParallel` (train.py:406): fp32 gradients are averaged over
-the ranks in ~25 MB buckets while the backward pass is still running.  This module is the MI355X-side equivalent for a
-one-process-per-GPU job on RCCL (`torch.distributed`, backend "nccl" on ROCm; "gloo" in the CPU tests):
+The reference wraps the model in `torch.nn.parallel.DistributedDataParallel` (train.py:405-407): fp32 gradients are averaged over
+the ranks in ~25 MB buckets while the backward pass is still running, on every micro-step (engine.py:41-84 uses no `no_sync`).
+This is the MI355X-side equivalent for a one-process-per-GPU job on RCCL (`torch.distributed`, backend "nccl" on ROCm; "gloo" in
+the CPU tests), built on what the HIP backward executor provides (training.py):
 
-* buckets are filled in REVERSE parameter order (the order gradients become ready in a backward pass) and launched as soon as
-  their last gradient has been accumulated (`register_post_accumulate_grad_hook`), on a side stream when the gradients live on
-  the GPU, so the collective overlaps the rest of the backward;
-* xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce is bound by ONE link, so buckets are larger than
-  NCCL-on-NVSwitch habits (default 64 MiB: ~0.45 ms of wire time per bucket at 8 GPUs, against ~20 us of launch latency) and the
-  payload can be sent as bf16 (`comm_dtype`) to halve the bytes -- the mean is still accumulated into the fp32 `.grad`;
-* `finish()` waits for the outstanding collectives, divides by the world size and scatters the flat buckets back.
-
-It is plumbing, not compute: the backward kernels that would feed it are not built yet, so it is exercised
-by the world_size-2 gloo test in tests/test_dp.py only.
+* every parameter gradient lives in ONE flat fp32 buffer, in the order the backward finishes them, so a bucket is a contiguous
+  slice [start, stop) of that buffer: the collective runs IN PLACE on the slice -- no flatten / unflatten copies;
+* the backward runs in block ranges (tr_vit_backward blk_hi..blk_lo); after each range an event is recorded and that range's
+  bucket is reduced on a side stream while the next range's kernels run (the DDP overlap);
+* xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce is bound by ONE link, so the mean is taken as
+  reduce-scatter + all-gather (RCCL drives all links for these with its direct algorithms) and buckets are larger than
+  NCCL-on-NVSwitch habits (default 64 MiB; DeiT-B's 346 MB of gradients -> 6 buckets);
+* `no_sync()` skips the reduction for gradient-accumulation micro-steps (the reference reduces on every micro-step; same result,
+  1/accum of the traffic).
 """
 from __future__ import annotations
 
-from typing import Iterable, List, Optional
+import contextlib
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
 
 
-class GradientAllReducer:
-    def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 64 << 20, process_group=None,
-                 comm_dtype: Optional[torch.dtype] = None):
-        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
-        if not self.params:
-            raise ValueError("no trainable parameters")
-        self.group = process_group
-        self.comm_dtype = comm_dtype
-        self.world = dist.get_world_size(process_group)
-        # buckets in reverse parameter order, closed when they reach bucket_bytes (a parameter is never split)
-        self.buckets: List[List[torch.nn.Parameter]] = [[]]
-        size = 0
-        for p in reversed(self.params):
-            nbytes = p.numel() * (torch.finfo(comm_dtype).bits // 8 if comm_dtype else p.element_size())
-            if self.buckets[-1] and size + nbytes > bucket_bytes:
-                self.buckets.append([])
-                size = 0
-            self.buckets[-1].append(p)
-            size += nbytes
-        self._bucket_of = {id(p): b for b, ps in enumerate(self.buckets) for p in ps}
-        self._pending = [0] * len(self.buckets)
-        self._flat: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
-        self._work = [None] * len(self.buckets)
-        self._hooks = []
-        self._stream = None
-        self._armed = False
+class FlatGradReducer:
+    """Bucketed in-place mean of a flat gradient buffer over the ranks of `process_group`."""
 
-    # ---- lifecycle ------------------------------------------------------------------------------------------------------
-    def attach(self):
-        """Install the per-parameter hooks (once); call `start()` before every backward pass."""
-        if self._hooks:
-            return self
-        for p in self.params:
-            self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+    def __init__(self, process_group=None, bucket_bytes: int = 64 << 20, comm_dtype: Optional[torch.dtype] = None,
+                 algorithm: str = "auto"):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self.bucket_bytes = int(bucket_bytes)
+        self.comm_dtype = comm_dtype
+        backend = dist.get_backend(process_group)
+        if algorithm == "auto":
+            algorithm = "rs_ag" if backend == "nccl" else "all_reduce"      # gloo has no reduce_scatter
+        if algorithm not in ("rs_ag", "all_reduce"):
+            raise ValueError("algorithm must be 'auto', 'rs_ag' or 'all_reduce'")
+        self.algorithm = algorithm
+        self.avg_op = dist.ReduceOp.AVG if backend == "nccl" else None       # gloo: SUM then divide
+        self.sync = True
+        self._stream = None
+        self._stage = None
+        self.launched: List[Tuple[int, int]] = []          # (start, stop) of the buckets of the last backward, in launch order
+
+    # ---- model wiring ---------------------------------------------------------------------------------------------------
+    def attach(self, model):
+        """Make `loss.backward()` of this model reduce its gradients (training._VitTrainFn.backward consults the reducer)."""
+        model._grad_reducer = self
         return self
 
-    def detach(self):
-        for h in self._hooks:
-            h.remove()
-        self._hooks = []
+    def broadcast_parameters(self, model, src: int = 0):
+        """DDP's construction-time broadcast: every rank starts from rank `src`'s parameters and buffers."""
+        for t in list(model.parameters()) + list(model.buffers()):
+            dist.broadcast(t.data, src=src, group=self.group)
 
-    def start(self):
-        self._pending = [len(ps) for ps in self.buckets]
-        self._work = [None] * len(self.buckets)
-        self._armed = True
+    @contextlib.contextmanager
+    def no_sync(self):
+        old, self.sync = self.sync, False
+        try:
+            yield
+        finally:
+            self.sync = old
 
-    def _on_grad(self, p: torch.nn.Parameter):
-        if not self._armed:
-            return
-        b = self._bucket_of[id(p)]
-        self._pending[b] -= 1
-        if self._pending[b] == 0:
-            self._launch(b)
+    # ---- bucketing ------------------------------------------------------------------------------------------------------
+    def plan(self, block_slices, depth: int):
+        """block_slices: [(event_block, start, stop)] contiguous slices of the flat buffer in backward order (training.TrainState).
+        Returns [(blk_hi, blk_lo, start, stop)]: block ranges of tr_vit_backward and the bucket each completes."""
+        out, cur_hi, cur_start, cur_stop = [], None, None, None
+        for e, start, stop in block_slices:
+            blk = min(e, depth - 1) if e < depth else 0            # the final slice (embedding + family modules) ends with block 0
+            if cur_hi is None:
+                cur_hi, cur_start = depth - 1, start
+            cur_stop = stop
+            if e < depth and (cur_stop - cur_start) * 4 >= self.bucket_bytes and blk > 0:
+                out.append((cur_hi, blk, cur_start, cur_stop))
+                cur_hi, cur_start = blk - 1, stop
+        if cur_hi is not None and cur_start < cur_stop:
+            out.append((cur_hi, 0, cur_start, cur_stop))
+        return out
 
-    def _launch(self, b: int):
-        ps = self.buckets[b]
-        dev = ps[0].grad.device
-        dtype = self.comm_dtype or ps[0].grad.dtype
-        n = sum(p.numel() for p in ps)
-        flat = self._flat[b]
-        if flat is None or flat.numel() != n or flat.dtype != dtype or flat.device != dev:
-            flat = self._flat[b] = torch.empty(n, dtype=dtype, device=dev)
-        if dev.type == "cuda":
+    # ---- the collective -------------------------------------------------------------------------------------------------
+    def reduce_slice(self, flat: torch.Tensor, start: int, stop: int):
+        """Mean over the ranks of flat[start:stop], in place, on the side stream (GPU) / synchronously (CPU)."""
+        sl = flat[start:stop]
+        self.launched.append((start, stop))
+        if flat.is_cuda:
+            dev = flat.device
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=dev)
-            self._stream.wait_stream(torch.cuda.current_stream(dev))       # the gradients of this bucket are complete
-            ctx = torch.cuda.stream(self._stream)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))               # the range's gradient kernels are enqueued before this point
+            self._stream.wait_event(ev)
+            with torch.cuda.stream(self._stream):
+                self._collective(sl)
         else:
-            ctx = _NullCtx()
-        with ctx:
-            off = 0
-            for p in ps:
-                flat[off: off + p.numel()].copy_(p.grad.reshape(-1))
-                off += p.numel()
-            self._work[b] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._collective(sl)
 
-    def finish(self):
-        """Wait for every bucket, write the mean back into `.grad`.  Buckets whose gradients never all arrived (unused
-        parameters) are reduced here with zeros in the gaps, so every rank issues the same collectives."""
-        if not self._armed:
-            raise RuntimeError("finish() without start()")
-        for b, ps in enumerate(self.buckets):
-            if self._work[b] is None:
-                for p in ps:
-                    if p.grad is None:
-                        p.grad = torch.zeros_like(p)
-                self._launch(b)
-        for b, ps in enumerate(self.buckets):
-            self._work[b].wait()
-            flat = self._flat[b]
-            dev = flat.device
-            if dev.type == "cuda":
-                torch.cuda.current_stream(dev).wait_stream(self._stream)
-            off = 0
-            for p in ps:
-                p.grad.copy_(flat[off: off + p.numel()].reshape(p.shape).to(p.grad.dtype) / self.world)
-                off += p.numel()
-        self._armed = False
+    def _collective(self, sl: torch.Tensor):
+        n = sl.numel()
+        buf = sl
+        if self.comm_dtype is not None and self.comm_dtype != sl.dtype:            # e.g. bf16 payload: half the bytes on the links
+            if self._stage is None or self._stage.numel() < n or self._stage.device != sl.device:
+                self._stage = torch.empty(n, dtype=self.comm_dtype, device=sl.device)
+            buf = self._stage[:n]
+            buf.copy_(sl)
+        op = self.avg_op if self.avg_op is not None else dist.ReduceOp.SUM
+        if self.algorithm == "rs_ag" and n % self.world == 0:
+            shard = buf[dist.get_rank(self.group) * (n // self.world): (dist.get_rank(self.group) + 1) * (n // self.world)]
+            dist.reduce_scatter_tensor(shard, buf, op=op, group=self.group)        # in place: the shard is this rank's part of buf
+            dist.all_gather_into_tensor(buf, shard, group=self.group)
+        else:
+            dist.all_reduce(buf, op=op, group=self.group)
+        if self.avg_op is None:
+            buf.div_(self.world)
+        if buf is not sl:
+            sl.copy_(buf)
 
-
-class _NullCtx:
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc):
-        return False
+    def finish(self, flat: torch.Tensor):
+        """Order the caller's stream after the outstanding bucket reductions (no host wait)."""
+        if flat.is_cuda and self._stream is not None:
+            torch.cuda.current_stream(flat.device).wait_stream(self._stream)

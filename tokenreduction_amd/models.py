@@ -256,11 +256,6 @@ class VisionTransformer(nn.Module):
             st = self._tstate = training.TrainState(self)
         return st
 
-    def _grad_events(self, st):
-        """hipEvent_t[depth+1] for tr_vit_backward when a gradient reducer wants to overlap with the backward, else None."""
-        reducer = getattr(self, "_grad_reducer", None)
-        return None if reducer is None else reducer.events_array(self, st)
-
     # ---- forward ------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor):
         if self.training:

@@ -445,8 +445,12 @@ def head_bwd(dlogits: torch.Tensor, w: torch.Tensor, xn: torch.Tensor):
     dxn = torch.empty(B, D, dtype=torch.bfloat16, device=w.device)
     dw = torch.empty(Cc, D, dtype=torch.float32, device=w.device)
     db = torch.empty(Cc, dtype=torch.float32, device=w.device)
-    _lib.check(_lib.load().tr_head_bwd(_dev(dlogits, torch.float32, "dlogits"), _dev(w, torch.bfloat16, "w"), _dev(xn, torch.bfloat16, "xn"),
-                                       dxn.data_ptr(), dw.data_ptr(), db.data_ptr(), 0, B, Cc, D, _stream()), "tr_head_bwd")
+    lib = _lib.load()
+    dl16 = torch.empty(B, Cc, dtype=torch.bfloat16, device=w.device)
+    ws = _ws(lib.tr_wgrad_workspace_floats(B, Cc, D), w.device)
+    _lib.check(lib.tr_head_bwd(_dev(dlogits, torch.float32, "dlogits"), _dev(w, torch.bfloat16, "w"), _dev(xn, torch.bfloat16, "xn"),
+                               dxn.data_ptr(), dw.data_ptr(), db.data_ptr(), 0, dl16.data_ptr(), ws.data_ptr(), ws.numel(), B, Cc, D, _stream()),
+               "tr_head_bwd")
     return dxn, dw, db
 
 

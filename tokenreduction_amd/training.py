@@ -21,7 +21,9 @@ from . import _lib
 
 
 def _align4(n: int) -> int:
-    return (n + 3) // 4 * 4
+    """Slot size of a parameter in the flat gradient buffer: 64 floats (256 B), so every bucket boundary is 16-byte aligned and
+    divisible by the world size (reduce-scatter shards)."""
+    return (n + 63) // 64 * 64
 
 
 def backward_order(model) -> List[Tuple[str, torch.nn.Parameter]]:
@@ -214,12 +216,23 @@ class _VitTrainFn(torch.autograd.Function):
                 st.views[n].zero_()
         G = st.grads_struct(model)
         WT = st.transposed(model, pk)
-        events = model._grad_events(st)
+        reducer = getattr(model, "_grad_reducer", None)
+        reduce_now = reducer is not None and reducer.sync
+        # one call for the whole model, or -- under a gradient reducer -- one call per bucket's block range, each followed by
+        # that bucket's in-place reduction on the reducer's stream while the next range runs
+        ranges = reducer.plan(st.block_slices, model.depth) if reduce_now else [(model.depth - 1, 0, 0, st.flat.numel())]
+        if reduce_now:
+            reducer.launched = []
+        stream = torch.cuda.current_stream().cuda_stream
         with torch.cuda.device(dl.device):
-            rc = lib.tr_vit_backward(C.byref(pk["cfg"]), C.byref(pk["W"]), C.byref(WT), C.byref(G), dl.data_ptr(), st.tape.data_ptr(),
-                                     st.tape.numel(), st.bws.data_ptr(), st.bws.numel(), 1, events, B,
-                                     torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, "tr_vit_backward")
+            for hi, lo, start, stop in ranges:
+                rc = lib.tr_vit_backward(C.byref(pk["cfg"]), C.byref(pk["W"]), C.byref(WT), C.byref(G), dl.data_ptr(), st.tape.data_ptr(),
+                                         st.tape.numel(), st.bws.data_ptr(), st.bws.numel(), 1, hi, lo, B, stream)
+                _lib.check(rc, "tr_vit_backward")
+                if reduce_now:
+                    reducer.reduce_slice(st.flat, start, stop)
+        if reduce_now:
+            reducer.finish(st.flat)
         for n, p in st.order:
             if not p.requires_grad:
                 continue
@@ -227,9 +240,6 @@ class _VitTrainFn(torch.autograd.Function):
                 p.grad = st.views[n]
             elif p.grad.data_ptr() != st.views[n].data_ptr():
                 p.grad.add_(st.views[n])
-        reducer = getattr(model, "_grad_reducer", None)
-        if reducer is not None:
-            reducer.on_backward(st)
         return None, None, None
 
 
