@@ -175,6 +175,11 @@ int tr_softassign_merge_fast(float* logits, int ldl, float scale, int apply_soft
 size_t tr_dpcknn_workspace_floats(int B, int N);
 int tr_kmedoids(const float* x, const float* colsum_part, float* ws, int32_t* centers, int32_t* assign, int B, int N, int D, int H,
                 int K, int iters, int fast_dist, tr_stream_t s);
+/* k_medoids_fit with token_weight = None (args.equal_weight, kmedoids.py:43-58): the first medoid is init_idx for every image -- the
+ * reference draws it with np.random.choice on the host, so it is an input --, the others by the farthest-point rule of :47-56,
+ * then the same iterations with unit weights. */
+int tr_kmedoids_equal(const float* x, int init_idx, float* ws, int32_t* centers, int32_t* assign, int B, int N, int D, int K, int iters,
+                      int fast_dist, tr_stream_t s);
 int tr_dpcknn_cluster(const float* x, const float* noise, float* ws, int32_t* centers, int32_t* idx_cluster, float* scores,
                       int B, int N, int D, int K, int k, int fast_dist, tr_stream_t s);
 int tr_cluster_merge_layernorm(const float* x, const float* score_w, const float* score_b, float* w_ws,
@@ -257,6 +262,14 @@ int tr_tome_merge_bwd(const float* g_merged, const float* size_in, const float* 
                       const int32_t* src_idx, const int32_t* dst_idx, int32_t* inv_map, float* g_out, uint16_t* gb_out, int B, int N,
                       int r, int D, tr_stream_t s);
 int tr_f32_to_bf16(const float* src, uint16_t* dst, size_t n, tr_stream_t s);
+/* DPC-KNN CTM backward (merge_tokens dpcknn.py:103-132 + the score Linear, CTM.forward :155-157): see csrc/tr_backward.hip.
+ * ws: (B+1)*(D+4) floats.  tr_ats_scatter: backward of ATS's row sampling (ats.py:86,157): valid sampled rows t go back to row
+ * ids[b,t] of the zero-filled full tensors (g fp32 [B,Ks,D] -> [B,N,D]; d(attn @ v) bf16 likewise). */
+int tr_cluster_merge_bwd(const float* g_in, const float* x0, const float* x1, const float* wtok, const int32_t* assign,
+                         const float* score_w, float* g_out, uint16_t* gb_out, float* d_sw, float* d_sb, int accumulate, float* ws,
+                         size_t ws_floats, int B, int N, int K, int D, tr_stream_t s);
+int tr_ats_scatter(const float* g, const uint16_t* dao_s, const int32_t* ids, float* g_full, uint16_t* dao_full, int B, int N, int Ks,
+                   int D, tr_stream_t s);
 
 /* ---- whole-model executor: TopKVisionTransformer.forward topk.py:179-212,
  *      EfficientVisionTransformer.forward evit.py:209-244, deit_viz.VisionTransformer.forward :186-212 (eval) ---- */
@@ -331,6 +344,8 @@ typedef struct {
   int knn_k;                  /* DPC-KNN: neighbours of the local density (args.k_neighbors, train.py:221 default 5) */
   int cluster_iters;          /* Sinkhorn / K-Medoids iterations (args.cluster_iters, train.py:232 default 3) */
   float sinkhorn_eps;         /* Sinkhorn temperature (args.sinkhorn_eps, train.py:229 default 1.0) */
+  int kmed_init[TR_MAX_DEPTH];/* K-Medoids args.equal_weight: per block, 1 + the first medoid id (the host's np.random.choice draw,
+                                 kmedoids.py:45); 0 = the attention-weighted branch */
 } tr_vit_config;
 
 /* Bytes of workspace tr_vit_forward needs for batch B (0 on invalid config). */

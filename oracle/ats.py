@@ -92,7 +92,8 @@ def ats_block_forward(x: Tensor, mask: Tensor, p: Dict[str, Tensor], i: int, cfg
         attn = dots.softmax(dim=-1)
     ids = cdf = None
     if sample_count:
-        cdf = ats_cdf(ats_scores(attn[:, :, 0, :], v), mask)
+        with torch.no_grad():      # the sampled ids are integers (argmin, ats.py:74): nothing of this reaches a gradient
+            cdf = ats_cdf(ats_scores(attn[:, :, 0, :].detach(), v.detach()), mask)
         if forced_ids is None:
             ids, mask = ats_ids_from_cdf(cdf, ats_sample_steps(sample_count), sample_count if static_pad else None)
         else:

@@ -94,7 +94,8 @@ def dpcknn_ctm(x_sp: Tensor, p: Dict[str, Tensor], j: int, cluster_num: int, noi
     token_weight = None
     if key in p:                                                                         # not equal_weight
         token_weight = (x_sp @ p[key].t() + p[f"cluster_layers.{j}.score.bias"]).exp()
-    idx_cluster, centers, score = dpcknn_cluster(x_sp, cluster_num, noise, k, forced_centers)
+    with torch.no_grad():                                  # dpcknn.py:56: the clustering runs under no_grad
+        idx_cluster, centers, score = dpcknn_cluster(x_sp.detach(), cluster_num, noise, k, forced_centers)
     return dpcknn_merge(x_sp, idx_cluster, cluster_num, token_weight), centers, idx_cluster, score
 
 

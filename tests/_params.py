@@ -201,6 +201,18 @@ GOLDEN_CASES = {
                                keep_rate=[0.25], reduction_loc=[1, 2, 3], batch=2, wseed=165, xseed=166, qkv_gain=6.0),
     "ats_micro_384": dict(family="ats", embed_dim=128, depth=4, num_heads=2, num_classes=16, img_size=384,
                           keep_rate=[0.25], reduction_loc=[1, 2, 3], batch=2, wseed=167, xseed=168, qkv_gain=6.0),
+    # BASELINE.json configs[3] families at DeiT-B width (D = 768, H = 12): ATS + DPC-KNN keep_rate 0.5.  qkv gain 2 gives the
+    # attention logits the same spread (std ~1.2-2.5) as gain 4 does at DeiT-S width: q.k/8 scales with D
+    "dpcknn_base_kr05": dict(family="dpcknn", embed_dim=768, depth=12, num_heads=12, num_classes=1000,
+                             keep_rate=[0.5], reduction_loc=[3, 6, 9], batch=2, wseed=201, xseed=202,
+                             qkv_gain=2.0, factory="dpcknn_base_patch16_224"),
+    "ats_base_kr05": dict(family="ats", embed_dim=768, depth=12, num_heads=12, num_classes=1000,
+                          keep_rate=[0.5], reduction_loc=[3, 6, 9], batch=2, wseed=203, xseed=204,
+                          qkv_gain=2.0, factory="ats_base_patch16_224"),
+    # dense DeiT-B: the trunk alone at D = 768 / H = 12 / depth 12 (no discrete decision anywhere)
+    "deit_base": dict(family="deit", embed_dim=768, depth=12, num_heads=12, num_classes=1000,
+                      keep_rate=[1.0], reduction_loc=[], batch=2, wseed=205, xseed=206,
+                      qkv_gain=2.0, factory="deit_base_patch16_224_local"),
     "deit_small": dict(family="deit", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
                        keep_rate=[1.0], reduction_loc=[], batch=2, wseed=81, xseed=82,
                        qkv_gain=4.0, factory="deit_small_patch16_224_local"),
@@ -210,7 +222,8 @@ GOLDEN_CASES = {
 # Gradient fixtures (tests/golden/grad_<case>.npz): the reference's own `loss.backward()` (engine.py:60-76 with a plain
 # cross-entropy criterion) in train mode on the golden case's weights / images, labels from grad_labels().  Too large to store
 # whole (22 M values at DeiT-S), so per parameter: the L2 norm and <= 512 evenly strided entries (grad_sample_index).
-GRAD_CASES = ["deit_micro", "topk_micro", "evit_micro", "tome_micro", "topk_small_kr07", "evit_small_kr07", "tome_small_r16"]
+GRAD_CASES = ["deit_micro", "topk_micro", "evit_micro", "tome_micro", "dpcknn_micro", "dpcknn_micro_equal", "ats_micro", "topk_small_kr07",
+              "evit_small_kr07", "tome_small_r16", "deit_base", "dpcknn_base_kr05", "ats_base_kr05"]
 
 
 def grad_labels(case: dict):
@@ -224,15 +237,22 @@ def grad_sample_index(numel: int):
 
 def oracle_param_grads(case: dict, forced=None, precision: str = "fp32", noise=None):
     """Parameter gradients of cross-entropy(oracle logits, grad_labels) by torch.autograd over the oracle's functional forward
-    (the reference's backward IS torch.autograd over its eager forward, engine.py:60-76).  Returns (loss, logits, {name: grad})."""
+    (the reference's backward IS torch.autograd over its eager forward, engine.py:60-76).  Returns (loss, logits, {name: grad}).
+    noise: DPC-KNN's density draws {blk: [B,P_in]} (the reference's torch.rand calls, recorded with the fixture)."""
     import oracle
     cfg, params = case_params(case)
     leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     x = make_images(case["batch"], case.get("img_size", 224), case["xseed"])
-    fns = {"tome": oracle.tome_forward, "deit": oracle.vit_forward, "topk": oracle.vit_forward, "evit": oracle.vit_forward}
-    fn = fns[case["family"]].__wrapped__          # the undecorated function: the public one runs under torch.no_grad()
-    with torch.enable_grad():
-        logits = fn(leaves, x, cfg, precision, False, forced)
+    fam = case["family"]
+    with torch.enable_grad():          # the undecorated functions: the public ones run under torch.no_grad()
+        if fam == "tome":
+            logits = oracle.tome_forward.__wrapped__(leaves, x, cfg, precision, False, forced)
+        elif fam == "dpcknn":
+            logits = oracle.dpcknn_forward.__wrapped__(leaves, x, cfg, noise, precision, False, forced)
+        elif fam == "ats":
+            logits = oracle.ats_forward.__wrapped__(leaves, x, cfg, precision, False, False, forced)
+        else:
+            logits = oracle.vit_forward.__wrapped__(leaves, x, cfg, precision, False, forced)
         loss = torch.nn.functional.cross_entropy(logits, grad_labels(case))
         loss.backward()
     return loss.item(), logits.detach(), {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}

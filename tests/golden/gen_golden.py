@@ -287,14 +287,28 @@ def run_grad_case(name, case):
     x = make_images(case["batch"], case.get("img_size", 224), case["xseed"])
     labels = grad_labels(case)
     torch.manual_seed(case["xseed"])
-    with RandSpy() as rspy:
-        out = m(x)
+    ats_ids = []
+    import models.ats as ref_ats
+    orig_ats = ref_ats.AdaptiveTokenSampling.forward
+
+    def ats_spy(self, xv, attn, mask):                    # records the sampled ids (ats.py:84): the ATS decision of each stage
+        out_ = orig_ats(self, xv, attn, mask)
+        ats_ids.append(out_[2].detach().clone())
+        return out_
+    ref_ats.AdaptiveTokenSampling.forward = ats_spy
+    try:
+        with RandSpy() as rspy:
+            out = m(x)
+    finally:
+        ref_ats.AdaptiveTokenSampling.forward = orig_ats
     logits = out[0] if isinstance(out, (tuple, list)) else out
     loss = torch.nn.functional.cross_entropy(logits, labels)
     loss.backward()
     rec = {"logits": logits.detach().numpy(), "loss": np.array(loss.item(), dtype=np.float64), "labels": labels.numpy()}
     for n, r in enumerate(rspy.calls):
         rec[f"rand_{n}"] = r.numpy().astype(np.float32)
+    for n, t in enumerate(ats_ids):
+        rec[f"atsids_{n}"] = t.numpy().astype(np.int64)
     names = []
     for pname, p in m.named_parameters():
         g = p.grad if p.grad is not None else torch.zeros_like(p)

@@ -179,3 +179,79 @@ def test_metric_reduction_over_two_ranks():
     for r in (0, 1):
         for k in ("loss", "acc1", "acc5"):
             assert abs(res[r][k] - whole[k]) < 1e-6, (r, k, res[r], whole)
+
+
+# ------------------------------------------------------------------------------------------------ train_one_epoch (engine.py:14-114)
+class _TinyNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(0)
+        self.body = torch.nn.Linear(12, 8)
+        self.head = torch.nn.Linear(8, 4)
+
+    def forward(self, x):
+        return self.head(torch.tanh(self.body(x.flatten(1))))
+
+
+def _train_loader(n, bs):
+    g = torch.Generator().manual_seed(5)
+    xs, ys = torch.randn(n, 3, 2, 2, generator=g), torch.randint(0, 4, (n,), generator=g)
+    return [(xs[i: i + bs], ys[i: i + bs]) for i in range(0, n, bs)]
+
+
+class _Sched:
+    def __init__(self):
+        self.calls = []
+
+    def step_update(self, num_updates):
+        self.calls.append(num_updates)
+
+
+def test_train_one_epoch_accumulates_like_the_reference_loop():
+    """Longhand engine.py:33-91 on a tiny torch model vs harness.train_one_epoch: same parameters afterwards, the optimizer steps
+    every `grad_accum_steps` batches and at the end of the loader, frozen groups run at lr 0, EMA / scheduler tick per step."""
+    crit = harness.plain_criterion(torch.nn.functional.cross_entropy)
+    loader = _train_loader(28, 4)                  # 7 batches, accumulation 3 -> optimizer steps after batches 3, 6 and 7
+    net_a, net_b = _TinyNet(), _TinyNet()
+
+    def groups(net):
+        return [{"params": list(net.body.parameters()), "lr": 0.05, "fix_step": 2}, {"params": list(net.head.parameters()), "lr": 0.1, "fix_step": 0}]
+    opt_a = torch.optim.SGD(groups(net_a), lr=0.1)
+    opt_b = torch.optim.SGD(groups(net_b), lr=0.1)
+    sched = _Sched()
+    ema = harness.ModelEma(net_a, decay=0.5)
+    stats, total = harness.train_one_epoch(net_a, crit, loader, opt_a, "cpu", epoch=1, lr_scheduler=sched, max_norm=0.5, model_ema=ema,
+                                           grad_accum_steps=3, num_steps_epoch=10)
+    # longhand
+    ema_ref = {k: v.clone() for k, v in net_b.state_dict().items()}
+    losses, steps = [], 10
+    for i, (x, y) in enumerate(loader, start=1):
+        for g in opt_b.param_groups:
+            if 1 < g["fix_step"]:
+                g["lr"] = 0
+        opt_step = (i % 3 == 0) or i == len(loader)
+        loss = torch.nn.functional.cross_entropy(net_b(x), y) / 3
+        losses.append(loss.item())
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(net_b.parameters(), 0.5)
+        if opt_step:
+            opt_b.step()
+            opt_b.zero_grad()
+            steps += 1
+            for k, v in net_b.state_dict().items():
+                ema_ref[k] = 0.5 * ema_ref[k] + 0.5 * v
+    assert total == steps == 13 and sched.calls == [11, 12, 13]
+    assert abs(stats["loss"] - float(np.mean(losses))) < 1e-6 and stats["lr-0"] == 0 and stats["lr-1"] == 0.1
+    for (n, pa), pb in zip(net_a.named_parameters(), net_b.parameters()):
+        assert torch.allclose(pa, pb, atol=1e-7), n
+    assert torch.equal(net_a.body.weight, _TinyNet().body.weight)          # the frozen group did not move
+    for k, v in ema.module.state_dict().items():
+        assert torch.allclose(v, ema_ref[k], atol=1e-6), k
+
+
+def test_train_one_epoch_stops_on_a_non_finite_loss():
+    net = _TinyNet()
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    crit = harness.plain_criterion(lambda out, y: out.sum() * float("nan"))
+    with pytest.raises(FloatingPointError):
+        harness.train_one_epoch(net, crit, _train_loader(8, 4), opt, "cpu", epoch=0)

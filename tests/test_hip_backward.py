@@ -255,3 +255,52 @@ def test_tome_merge_bwd(ops):
     g, gb = ops.tome_merge_bwd(gm, size_in, size_out.contiguous(), unm, src, dst, N)
     assert float((g - xf.grad).abs().max()) <= 1e-5 * float(xf.grad.abs().max())
     assert float((gb.float() - xf.grad).abs().max()) <= 2.0 ** -8 * float(xf.grad.abs().max())
+
+
+@pytest.mark.parametrize("weighted", [True, False])
+@pytest.mark.parametrize("D", [128, 768])
+def test_cluster_merge_bwd(ops, weighted, D):
+    """DPC-KNN CTM (merge_tokens dpcknn.py:103-132 + score Linear): backward vs torch.autograd of the same expression."""
+    B, N, K = 3, 99, 49
+    P = N - 1
+    x0 = _randn(40, B, N, D)
+    sw = _randn(41, D, scale=0.05) if weighted else None
+    sb = _randn(42, 1, scale=0.02) if weighted else None
+    g0 = torch.Generator().manual_seed(9)
+    assign = torch.stack([torch.cat([torch.arange(K), torch.randint(0, K, (P - K,), generator=g0)])[torch.randperm(P, generator=g0)]
+                          for _ in range(B)]).to(torch.int32).cuda()
+    xf = x0.clone().requires_grad_(True)
+    swf = sw.clone().requires_grad_(True) if weighted else None
+    sbf = sb.clone().requires_grad_(True) if weighted else None
+    xs = xf[:, 1:]
+    w = (xs @ swf + sbf).exp() if weighted else torch.ones(B, P, device="cuda")
+    onehot = torch.nn.functional.one_hot(assign.long(), K).float()            # [B,P,K]
+    W = torch.einsum("bpk,bp->bk", onehot, w) + 1e-6
+    merged = torch.einsum("bpk,bp,bpd->bkd", onehot, w, xs) / W[..., None]
+    x1 = torch.cat([xf[:, :1], merged], dim=1)
+    g_in = _randn(43, B, K + 1, D)
+    (x1 * g_in).sum().backward()
+    g, gb, dsw, dsb = ops.cluster_merge_bwd(g_in, x0, x1.detach().contiguous(), w.detach().contiguous() if weighted else None, assign, sw)
+    assert float((g - xf.grad).abs().max()) <= 2e-4 * float(xf.grad.abs().max()), float((g - xf.grad).abs().max())
+    assert float((gb.float() - xf.grad).abs().max()) <= 2.0 ** -8 * float(xf.grad.abs().max()) + 2e-4 * float(xf.grad.abs().max())
+    if weighted:
+        assert float((dsw - swf.grad).abs().max()) <= 2e-4 * float(swf.grad.abs().max())
+        # d sb = sum_i dlog_i cancels within every cluster (sum_i w_i (x_i - x_c) = x_c * 1e-6): what is left is rounding residue of
+        # terms of magnitude |dlog_i|, so the bound is relative to those, not to the (near-zero) result
+        assert float((dsb - sbf.grad).abs().max()) <= 1e-3 * float(swf.grad.abs().max())
+
+
+def test_ats_scatter(ops):
+    B, N, Ks, D = 2, 50, 12, 384
+    g = _randn(44, B, Ks, D)
+    dao = _randn(45, B, Ks, D, dtype=torch.bfloat16)
+    ids = torch.tensor([[0, 3, 7, 8, 20, 21, 30, 41, 49, 0, 0, 0], [0, 1, 2, 5, 9, 10, 11, 12, 13, 14, 15, 48]], dtype=torch.int32).cuda()
+    gf, df = ops.ats_scatter(g, dao, ids, N)
+    want = torch.zeros(B, N, D, device="cuda")
+    wantd = torch.zeros(B, N, D, device="cuda")
+    for b in range(B):
+        for t in range(Ks):
+            if t == 0 or ids[b, t] != 0:
+                want[b, ids[b, t]] = g[b, t]
+                wantd[b, ids[b, t]] = dao[b, t].float()
+    assert torch.equal(gf, want) and torch.equal(df.float(), wantd)

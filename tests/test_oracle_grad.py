@@ -14,22 +14,44 @@ import torch
 
 from tests._params import GOLDEN_CASES, GRAD_CASES, grad_sample_index, oracle_param_grads
 
-CPU_CASES = [n for n in GRAD_CASES if GOLDEN_CASES[n]["embed_dim"] <= 128] + ["topk_small_kr07"]
+CPU_CASES = [n for n in GRAD_CASES if GOLDEN_CASES[n]["embed_dim"] <= 128] + ["topk_small_kr07", "dpcknn_base_kr05", "ats_base_kr05"]
+
+
+def fixture_inputs(case, g):
+    """(forced, noise) the oracle needs to follow the reference's run: DPC-KNN's recorded torch.rand draws; ATS's sampled ids (its
+    argmin over a matmul-form cdist is chaotic at the 1e-4 level even CPU vs CPU -- DESIGN.md section 0 -- so the ids the
+    reference sampled are forced; everything differentiable is downstream of them)."""
+    from oracle import ats_sample_counts, dpcknn_cluster_counts
+    from tests._params import case_config
+    cfg = case_config(case)
+    forced = noise = None
+    if case["family"] == "dpcknn":
+        noise = {blk: torch.from_numpy(g[f"rand_{n}"]) for n, blk in enumerate(sorted(dpcknn_cluster_counts(cfg)))}
+    if case["family"] == "ats":
+        forced = {blk: torch.from_numpy(g[f"atsids_{n}"]) for n, blk in enumerate(sorted(b for b, c in ats_sample_counts(cfg).items() if c))}
+    return forced, noise
 
 
 @pytest.mark.parametrize("name", CPU_CASES)
 def test_oracle_gradients_match_the_reference(golden_dir, name):
     g = np.load(os.path.join(golden_dir, f"grad_{name}.npz"))
-    loss, logits, grads = oracle_param_grads(GOLDEN_CASES[name])
+    forced, noise = fixture_inputs(GOLDEN_CASES[name], g)
+    loss, logits, grads = oracle_param_grads(GOLDEN_CASES[name], forced=forced, noise=noise)
     assert abs(loss - float(g["loss"])) <= 1e-5 * max(1.0, abs(float(g["loss"])))
-    np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=0, atol=3e-5)
+    # DeiT-B width (D = 768, depth 12, qkv gain 4): fp32 summation-order noise between nn.Linear's addmm and the oracle's matmul is
+    # amplified to ~2e-4 on logits of magnitude ~2 (measured 2.2e-4 / 1.3e-4); the micro and DeiT-S cases stay below 3e-5
+    wide = GOLDEN_CASES[name]["embed_dim"] >= 768
+    np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=0, atol=5e-4 if wide else 3e-5)
+    rel = 3e-3 if wide else 1e-4
     names = [str(n) for n in g["param_names"]]
     assert set(names) == set(grads)
+    total = sum(float(g["norm:" + n]) ** 2 for n in names) ** 0.5
     for n in names:
         flat = grads[n].reshape(-1)
         ref_norm = float(g["norm:" + n])
         got_norm = float(flat.double().norm())
-        assert abs(got_norm - ref_norm) <= 1e-4 * ref_norm + 1e-9, (n, got_norm, ref_norm)
+        # parameters whose true gradient is zero (the key bias: softmax is shift invariant) hold rounding residue only
+        assert abs(got_norm - ref_norm) <= rel * ref_norm + 1e-7 * total, (n, got_norm, ref_norm)
         smp = flat[torch.from_numpy(grad_sample_index(flat.numel()))].numpy()
         err = np.abs(smp - g["sample:" + n]).max()
-        assert err <= 1e-4 * ref_norm / np.sqrt(max(1, flat.numel())) * 30 + 1e-9, (n, err, ref_norm)
+        assert err <= (rel * ref_norm + 1e-7 * total) / np.sqrt(max(1, flat.numel())) * 30 + 1e-9, (n, err, ref_norm)

@@ -41,7 +41,8 @@ class TrVitWeights(C.Structure):
 class TrVitConfig(C.Structure):
     _fields_ = [("family", _i), ("img_size", _i), ("patch", _i), ("in_chans", _i), ("embed_dim", _i),
                 ("depth", _i), ("num_heads", _i), ("mlp_hidden", _i), ("num_classes", _i), ("ln_eps", _f),
-                ("keep", _i * TR_MAX_DEPTH), ("precision", _i), ("knn_k", _i), ("cluster_iters", _i), ("sinkhorn_eps", _f)]
+                ("keep", _i * TR_MAX_DEPTH), ("precision", _i), ("knn_k", _i), ("cluster_iters", _i), ("sinkhorn_eps", _f),
+                ("kmed_init", _i * TR_MAX_DEPTH)]
 
 
 # every symbol include/tokenreduction_hip.h declares: name -> (restype, argtypes)
@@ -77,6 +78,7 @@ SIGNATURES = {
     "tr_ats_gather": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tr_dpcknn_workspace_floats": (_sz, [_i, _i]),
     "tr_kmedoids": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "tr_kmedoids_equal": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "tr_dpcknn_cluster": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "tr_cluster_merge_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "tr_broadcast_rows": (_i, [_vp, _vp, _i, _i, _vp]),
@@ -95,6 +97,8 @@ SIGNATURES = {
     "tr_evit_fuse_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tr_tome_merge_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tr_f32_to_bf16": (_i, [_vp, _vp, _sz, _vp]),
+    "tr_cluster_merge_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _i, _i, _i, _i, _vp]),
+    "tr_ats_scatter": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tr_layernorm_bf16_to": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "tr_vit_tape_bytes": (_sz, [C.POINTER(TrVitConfig), _i]),
     "tr_vit_forward_train": (_i, [C.POINTER(TrVitConfig), C.POINTER(TrVitWeights), _vp, _vp, _vp, _sz, _vp, _sz, _vp, C.POINTER(_i), _i, _vp]),

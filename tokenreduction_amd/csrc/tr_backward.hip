@@ -515,6 +515,141 @@ __global__ __launch_bounds__(256) void tome_merge_bwd_kernel(const float* __rest
   }
 }
 
+// ---- DPC-KNN CTM backward (merge_tokens dpcknn.py:103-132 with token_weight = exp(score(x)), CTM.forward :155-157):
+//   x_c = sum_{i in c} x_i w_i / W_c,  W_c = sum_{i in c} w_i + 1e-6,  w_i = exp(x_i . sw + sb)   (w_i = 1 with equal_weight)
+//   d x_i = (w_i / W_c) g_c + dlog_i sw,   dlog_i = w_i <g_c, x_i - x_c> / W_c,   d sw = sum_i dlog_i x_i,   d sb = sum_i dlog_i
+// (the clustering itself runs under no_grad, dpcknn.py:56).  One workgroup per image: thread c sums its cluster's weights in
+// token order (fixed order), then one wave per token; the image's d sw / d sb partial goes to part[b][D+4].
+template <int NCH>
+__global__ __launch_bounds__(256) void cluster_merge_bwd_kernel(const float* __restrict__ g_in, const float* __restrict__ x0,
+                                                                const float* __restrict__ x1, const float* __restrict__ wtok,
+                                                                const int32_t* __restrict__ assign, const float* __restrict__ sw,
+                                                                float* __restrict__ g_out, uint16_t* __restrict__ gb_out,
+                                                                float* __restrict__ part, int N, int K, int D) {
+  __shared__ float sW[256];
+  __shared__ float4 red[3][64 * NCH];
+  __shared__ float redb[4];
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int P = N - 1, nchunks = D >> 2;
+  const bool weighted = sw != nullptr;
+  const int32_t* as = assign + (size_t)b * P;
+  for (int c = threadIdx.x; c < K; c += 256) {
+    float a = 0.f;
+    for (int i = 0; i < P; ++i)
+      if (as[i] == c) a += weighted ? wtok[(size_t)b * P + i] : 1.0f;
+    sW[c] = a + 1e-6f;
+  }
+  __syncthreads();
+  float4 swv[NCH], acc[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    swv[c] = weighted ? *reinterpret_cast<const float4*>(sw + 4 * min(lane + 64 * c, nchunks - 1)) : make_float4(0.f, 0.f, 0.f, 0.f);
+    acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float accb = 0.f;
+  if (wave == 0) {      // CLS row passes through
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunks) {
+        const float4 v = *reinterpret_cast<const float4*>(g_in + (size_t)b * (K + 1) * D + 4 * ch);
+        *reinterpret_cast<float4*>(g_out + (size_t)b * N * D + 4 * ch) = v;
+        uint2 pk;
+        pk.x = pack_bf16x2(v.x, v.y);
+        pk.y = pack_bf16x2(v.z, v.w);
+        *reinterpret_cast<uint2*>(gb_out + (size_t)b * N * D + 4 * ch) = pk;
+      }
+    }
+  }
+  for (int i = wave; i < P; i += 4) {
+    const int c = as[i];
+    const float wi = weighted ? wtok[(size_t)b * P + i] : 1.0f;
+    const float iw = 1.0f / sW[c];
+    const float* gr = g_in + ((size_t)b * (K + 1) + 1 + c) * D;
+    const float* xi = x0 + ((size_t)b * N + 1 + i) * D;
+    const float* xc = x1 + ((size_t)b * (K + 1) + 1 + c) * D;
+    float4 gv[NCH], xv[NCH];
+    float dot = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc) {
+      const int ch = min(lane + 64 * cc, nchunks - 1);
+      gv[cc] = *reinterpret_cast<const float4*>(gr + 4 * ch);
+      xv[cc] = *reinterpret_cast<const float4*>(xi + 4 * ch);
+      const float4 cv = *reinterpret_cast<const float4*>(xc + 4 * ch);
+      if (lane + 64 * cc < nchunks)
+        dot += (gv[cc].x * (xv[cc].x - cv.x) + gv[cc].y * (xv[cc].y - cv.y)) + (gv[cc].z * (xv[cc].z - cv.z) + gv[cc].w * (xv[cc].w - cv.w));
+    }
+    const float dlog = weighted ? wave_sum(dot) * iw * wi : 0.f;
+    const float sc = wi * iw;
+    accb += dlog;
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc) {
+      const int ch = lane + 64 * cc;
+      if (ch < nchunks) {
+        const float4 o = make_float4(sc * gv[cc].x + dlog * swv[cc].x, sc * gv[cc].y + dlog * swv[cc].y, sc * gv[cc].z + dlog * swv[cc].z,
+                                     sc * gv[cc].w + dlog * swv[cc].w);
+        acc[cc].x += dlog * xv[cc].x; acc[cc].y += dlog * xv[cc].y; acc[cc].z += dlog * xv[cc].z; acc[cc].w += dlog * xv[cc].w;
+        *reinterpret_cast<float4*>(g_out + ((size_t)b * N + 1 + i) * D + 4 * ch) = o;
+        uint2 pk;
+        pk.x = pack_bf16x2(o.x, o.y);
+        pk.y = pack_bf16x2(o.z, o.w);
+        *reinterpret_cast<uint2*>(gb_out + ((size_t)b * N + 1 + i) * D + 4 * ch) = pk;
+      }
+    }
+  }
+  if (!weighted) return;
+  if (wave > 0) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) red[wave - 1][lane + 64 * c] = acc[c];
+  }
+  if (lane == 0) redb[wave] = accb;
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int ch = lane + 64 * c;
+      if (ch < nchunks) {
+        float4 a = acc[c];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          const float4 v = red[w][ch];
+          a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        *reinterpret_cast<float4*>(part + (size_t)b * (D + 4) + 4 * ch) = a;
+      }
+    }
+    if (lane == 0) {
+      float4 bs = make_float4((redb[0] + redb[1]) + (redb[2] + redb[3]), 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(part + (size_t)b * (D + 4) + D) = bs;
+    }
+  }
+}
+
+// ---- ATS backward of the row sampling (ats.py:86,157): row t of the sampled tensors came from row ids[b,t] of the full ones.
+// Valid rows (t == 0: CLS, or id != 0) are scattered -- ids are unique there --; padded rows replicate the CLS row in the forward
+// but nothing downstream reads them (masked keys), so their gradient is zero and they are skipped.  The caller zero-fills the outputs.
+template <int NCH>
+__global__ __launch_bounds__(256) void ats_scatter_kernel(const float* __restrict__ g, const uint16_t* __restrict__ dao_s,
+                                                          const int32_t* __restrict__ ids, float* __restrict__ g_full,
+                                                          uint16_t* __restrict__ dao_full, int N, int Ks, int D, int M) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int b = row / Ks, t = row - b * Ks;
+  const int id = ids[row];
+  if (t > 0 && id == 0) return;
+  const int nchunks = D >> 2;
+  const size_t orow = (size_t)b * N + id;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int ch = lane + 64 * c;
+    if (ch < nchunks) {
+      *reinterpret_cast<float4*>(g_full + orow * D + 4 * ch) = *reinterpret_cast<const float4*>(g + (size_t)row * D + 4 * ch);
+      *reinterpret_cast<uint2*>(dao_full + orow * D + 4 * ch) = *reinterpret_cast<const uint2*>(dao_s + (size_t)row * D + 4 * ch);
+    }
+  }
+}
+
 // fp32 rows -> bf16 rows (the initial gradient of the residual stream as a GEMM operand)
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t nchunks) {
   const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -702,5 +837,43 @@ extern "C" int tr_f32_to_bf16(const float* src, uint16_t* dst, size_t n, tr_stre
   const size_t nch = n / 4;
   hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((nch + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(s), src, dst, nch);
   TR_CHECK_LAUNCH("tr_f32_to_bf16");
+  return TR_OK;
+}
+
+// DPC-KNN CTM backward.  g_in fp32 [B,K+1,D] (gradient wrt the merged stream, CLS row first), x0 fp32 [B,N,D] (stream before the
+// merge), x1 fp32 [B,K+1,D] (merged stream), wtok fp32 [B,N-1] (token weights of the forward; ignored when score_w == NULL =
+// equal_weight), assign int32 [B,N-1].  g_out fp32 / gb_out bf16 [B,N,D].  d_sw [D], d_sb [1] (+)=.  ws: B*(D+4) floats.
+extern "C" int tr_cluster_merge_bwd(const float* g_in, const float* x0, const float* x1, const float* wtok, const int32_t* assign,
+                                    const float* score_w, float* g_out, uint16_t* gb_out, float* d_sw, float* d_sb, int accumulate,
+                                    float* ws, size_t ws_floats, int B, int N, int K, int D, tr_stream_t s) {
+  TR_REQUIRE(g_in && x0 && x1 && assign && g_out && gb_out && ws, TR_ERR_NULL, "tr_cluster_merge_bwd: null pointer");
+  TR_REQUIRE(score_w == nullptr || (wtok && d_sw && d_sb), TR_ERR_NULL, "tr_cluster_merge_bwd: weighted merge needs wtok, d_sw, d_sb");
+  TR_REQUIRE(B > 0 && N > 1 && K >= 1 && K <= 256 && K <= N - 1 && D % 4 == 0 && D <= 256 * LN_MAX_CHUNKS, TR_ERR_SHAPE,
+             "tr_cluster_merge_bwd: bad shape B=%d N=%d K=%d D=%d (K <= 256)", B, N, K, D);
+  TR_REQUIRE(ws_floats >= (size_t)B * (D + 4), TR_ERR_SHAPE, "tr_cluster_merge_bwd: workspace too small");
+  hipStream_t st = static_cast<hipStream_t>(s);
+  TR_DISPATCH_NCH(D, hipLaunchKernelGGL((cluster_merge_bwd_kernel<NCH>), dim3(B), dim3(256), 0, st, g_in, x0, x1, wtok, assign, score_w, g_out, gb_out,
+                                        ws, N, K, D));
+  TR_CHECK_LAUNCH("tr_cluster_merge_bwd");
+  if (score_w != nullptr) {
+    // partial rows are [d_sw (D) | d_sb, 0, 0, 0]: reduce them as one vector of D+4 into a scratch tail, then split
+    float* tail = ws + (size_t)B * (D + 4);
+    TR_REQUIRE(ws_floats >= (size_t)(B + 1) * (D + 4), TR_ERR_SHAPE, "tr_cluster_merge_bwd: workspace too small");
+    reduce_partials(ws, B, (size_t)D + 4, tail, 0, st);
+    reduce_partials(tail, 1, (size_t)D, d_sw, accumulate, st);
+    reduce_partials(tail + D, 1, (size_t)1, d_sb, accumulate, st);
+    TR_CHECK_LAUNCH("tr_cluster_merge_bwd (reduce)");
+  }
+  return TR_OK;
+}
+
+extern "C" int tr_ats_scatter(const float* g, const uint16_t* dao_s, const int32_t* ids, float* g_full, uint16_t* dao_full, int B, int N,
+                              int Ks, int D, tr_stream_t s) {
+  TR_REQUIRE(g && dao_s && ids && g_full && dao_full, TR_ERR_NULL, "tr_ats_scatter: null pointer");
+  TR_REQUIRE(B > 0 && N > 1 && Ks >= 1 && Ks <= N && D % 4 == 0 && D <= 256 * LN_MAX_CHUNKS, TR_ERR_SHAPE, "tr_ats_scatter: bad shape");
+  const int M = B * Ks;
+  hipStream_t st = static_cast<hipStream_t>(s);
+  TR_DISPATCH_NCH(D, hipLaunchKernelGGL((ats_scatter_kernel<NCH>), dim3((M + 3) / 4), dim3(256), 0, st, g, dao_s, ids, g_full, dao_full, N, Ks, D, M));
+  TR_CHECK_LAUNCH("tr_ats_scatter");
   return TR_OK;
 }

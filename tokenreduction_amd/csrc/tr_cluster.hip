@@ -496,7 +496,7 @@ __global__ __launch_bounds__(KMT) void kmed_iterate_kernel(const float* __restri
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           float best = INFINITY;
-          int arg = 0x7fffffff;
+          int arg = 0;                                  // all-NaN row: index 0, like torch.argmin (never an out-of-range LDS slot)
 #pragma unroll
           for (int c = 0; c < 4; ++c) {               // ascending k per lane, strict <: the lane's first minimum
             const int k = lane + 64 * c;
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(KMT) void kmed_iterate_kernel(const float* __restri
           const int p = p0 + q;
           const float* dr = db + (size_t)p * P;
           float best = INFINITY;
-          int arg = 0x7fffffff;
+          int arg = 0;                                  // all-NaN row: index 0, like torch.argmin (never an out-of-range LDS slot)
           for (int k = lane; k < K; k += 64) {
             const float dd = dr[s_c[k]];
             if (dd < best) { best = dd; arg = k; }
@@ -605,6 +605,85 @@ extern "C" int tr_cluster_merge_layernorm(const float* x, const float* score_w, 
     TR_DISPATCH_NCH(D, hipLaunchKernelGGL((cluster_merge_layernorm_kernel<false, NCH>), dim3(B * rblocks), dim3(256), 0, st, x,
                                           score_w ? w_ws : nullptr, idx_cluster, gamma, beta, x_out, y, N, K, D, eps));
   TR_CHECK_LAUNCH("tr_cluster_merge_layernorm");
+  return TR_OK;
+}
+
+// equal_weight branch of k_medoids_fit (kmedoids.py:43-58): the first medoid is one random token id shared by the whole batch
+// (np.random.choice on the host: an INPUT here), then K-1 times the token with the largest "max distance to the chosen medoids"
+// joins (rows of already chosen tokens are zeroed, kmedoids.py:52-54; torch.max -> first index on ties).  One workgroup per image
+// over the [P,P] distance matrix; s_max[i] is kept incrementally (a new medoid only adds one column to the max).
+__global__ __launch_bounds__(256) void kmed_init_equal_kernel(const float* __restrict__ dist, int32_t* __restrict__ centers, int P, int K,
+                                                              int init) {
+  __shared__ float s_max[64 * MAX_PER_LANE];
+  __shared__ unsigned char s_ch[64 * MAX_PER_LANE];
+  __shared__ unsigned long long s_red[4];
+  __shared__ int s_new;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* db = dist + (size_t)b * P * P;
+  int32_t* cb = centers + (size_t)b * K;
+  if (tid == 0) cb[0] = init;
+  for (int i = tid; i < P; i += 256) {
+    s_ch[i] = i == init;
+    s_max[i] = i == init ? 0.f : db[(size_t)i * P + init];
+  }
+  for (int k = 1; k < K; ++k) {
+    __syncthreads();
+    unsigned long long best = 0ull;
+    for (int i = tid; i < P; i += 256) {
+      const unsigned long long key = ((unsigned long long)__float_as_uint(fmaxf(s_max[i], 0.f)) << 32) | (unsigned int)(0xffffffffu - (unsigned int)i);
+      best = key > best ? key : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned long long other = __shfl_xor(best, o, 64);
+      best = other > best ? other : best;
+    }
+    if (lane == 0) s_red[wave] = best;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned long long m = s_red[0];
+      for (int w = 1; w < 4; ++w) m = s_red[w] > m ? s_red[w] : m;
+      const int nw = (int)(0xffffffffu - (unsigned int)(m & 0xffffffffull));
+      s_new = nw;
+      cb[k] = nw;
+    }
+    __syncthreads();
+    const int nw = s_new;
+    for (int i = tid; i < P; i += 256) {
+      if (i == nw) { s_ch[i] = 1; s_max[i] = 0.f; }
+      else if (!s_ch[i]) s_max[i] = fmaxf(s_max[i], db[(size_t)i * P + nw]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, float v, size_t n) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+// k_medoids_fit with token_weight = None (args.equal_weight, kmedoids.py:43-58): init_idx = the host's np.random.choice draw.
+extern "C" int tr_kmedoids_equal(const float* x, int init_idx, float* ws, int32_t* centers, int32_t* assign, int B, int N, int D, int K,
+                                 int iters, int fast_dist, tr_stream_t s) {
+  TR_REQUIRE(x && ws && centers && assign, TR_ERR_NULL, "tr_kmedoids_equal: null pointer");
+  const int P = N - 1;
+  TR_REQUIRE(B > 0 && P >= 2 && P <= 64 * MAX_PER_LANE && D > 0 && D % CK == 0, TR_ERR_SHAPE,
+             "tr_kmedoids_equal: need 2 <= P <= %d and D %% %d == 0 (N=%d D=%d)", 64 * MAX_PER_LANE, CK, N, D);
+  TR_REQUIRE(K >= 1 && K <= P && iters >= 0 && init_idx >= 0 && init_idx < P, TR_ERR_SHAPE, "tr_kmedoids_equal: bad K=%d / iters=%d / init=%d for P=%d",
+             K, iters, init_idx, P);
+  TR_REQUIRE(tr_aligned16(x) && tr_aligned16(ws), TR_ERR_ALIGN, "tr_kmedoids_equal: pointers must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(s);
+  float* dist = ws;
+  float* nrm = dist + (size_t)B * P * P;
+  float* t = nrm + (size_t)B * P;
+  float* wrow = t + (size_t)B * P;                              // [B,N] of ones
+  const int rows = B * P, rb = (rows + 3) / 4;
+  hipLaunchKernelGGL(fill_kernel, dim3((B * N + 255) / 256), dim3(256), 0, st, wrow, 1.0f, (size_t)B * N);
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(rb), dim3(256), 0, st, x, nrm, B, N, D);
+  launch_dist(fast_dist != 0, x, nrm, dist, B, N, D, 1.0f, st);
+  hipLaunchKernelGGL(kmed_init_equal_kernel, dim3(B), dim3(256), 0, st, dist, centers, P, K, init_idx);
+  hipLaunchKernelGGL(kmed_rowcost_kernel, dim3(rb), dim3(256), 0, st, dist, wrow, t, B, P);
+  hipLaunchKernelGGL(kmed_iterate_kernel, dim3(B), dim3(KMT), (size_t)K * 12, st, dist, t, centers, assign, P, K, iters);
+  TR_CHECK_LAUNCH("tr_kmedoids_equal");
   return TR_OK;
 }
 

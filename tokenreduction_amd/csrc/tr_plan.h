@@ -10,7 +10,8 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 
 // families whose training path (saved activations + backward) is built
 inline bool trainable_family(int family) {
-  return family == TR_FAMILY_DEIT || family == TR_FAMILY_TOPK || family == TR_FAMILY_EVIT || family == TR_FAMILY_TOME;
+  return family == TR_FAMILY_DEIT || family == TR_FAMILY_TOPK || family == TR_FAMILY_EVIT || family == TR_FAMILY_TOME ||
+         family == TR_FAMILY_DPCKNN || family == TR_FAMILY_ATS;
 }
 
 // tokens (incl. CLS) entering block i, inside its attention, and inside its MLP: the rules of tr_vit_forward
@@ -63,11 +64,12 @@ inline bool make_token_plan(const tr_vit_config* c, TokenPlan* t) {
 
 // ---- the tape: activations a training forward keeps for the backward pass, one slot set per block
 struct BlockTape {
-  size_t x0;      // fp32 [B, n_pre, D]   stream entering a pre-block reducer, pending residual added (pre-block families only)
+  size_t x0;      // fp32 [B, n_pre, D]   stream entering a pre-block reducer, pending residual added (DPC-KNN);
+                  //                      ATS sampling blocks: the sampled rows of the stream [B, n_mlp, D] (x before the attention residual)
   size_t x1;      // fp32 [B, n_att, D]   input of norm1
   size_t xn1;     // bf16 [B, n_att, D]   norm1 output (qkv's operand)
   size_t qkv;     // bf16 [B, n_att, 3D]
-  size_t ao;      // bf16 [B, n_att, D]   attention output (proj's operand; ATS: the sampled rows [B, n_mlp, D])
+  size_t ao;      // bf16 [B, n_att, D]   attention output = proj's operand (ATS sampling blocks: only the sampled rows [B, n_mlp, D])
   size_t dattn;   // bf16 [B, n_att, D]   proj output (EViT reduction blocks: the fused token reads x + this at the dropped rows)
   size_t x2;      // fp32 [B, n_mlp, D]   input of norm2
   size_t xn2;     // bf16 [B, n_mlp, D]
@@ -100,7 +102,7 @@ inline bool make_tape_plan(const tr_vit_config* c, int B, const TokenPlan& t, Ta
   for (int i = 0; i < c->depth; ++i) {
     BlockTape& b = p->blk[i];
     const size_t Tp = (size_t)B * t.n_pre[i], Ta = (size_t)B * t.n_att[i], Tm = (size_t)B * t.n_mlp[i];
-    b.x0 = (pre && t.kk[i] > 0) ? take(Tp * D * 4) : 0;
+    b.x0 = (pre && t.kk[i] > 0) ? take(Tp * D * 4) : ((c->family == TR_FAMILY_ATS && t.kk[i] > 0) ? take(Tm * D * 4) : 0);
     b.x1 = take(Ta * D * 4);
     b.xn1 = take(Ta * D * 2);
     b.qkv = take(Ta * 3 * D * 2);

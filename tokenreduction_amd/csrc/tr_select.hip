@@ -5,7 +5,9 @@
 //   compl[b,:]  = sorted(set(range(P)) - set(idx))          evit.py:25-46 complement_idx  (ascending)
 //
 // Integer work, bit-exact by construction: every token computes its RANK by counting
-// (#scores greater, ties broken by lower index first) over the P<=1024 scores held in LDS, and writes itself
+// (#scores greater, ties broken by lower index first) over the P<=1024 scores held in LDS -- as order-preserving integer keys, with
+// NaN ranked LARGEST like torch.topk does, so the ranks are a permutation of 0..P-1 for ANY input (a NaN score used to compare
+// false against everything: several tokens got rank 0 and other idx slots stayed unwritten) -- and writes itself
 // to idx[rank] when rank < K.  That yields the sorted order directly, is deterministic, and needs no sort
 // network; P^2 = 38k compares per image at P=196 is noise next to the block's GEMMs.  HBM traffic is the
 // algorithmic minimum: 4*H*N bytes of CLS rows in, 4*K (+4*(P-K) +4*P) bytes out per image.
@@ -18,7 +20,7 @@ constexpr int MAX_P = 1024;
 __global__ __launch_bounds__(256) void cls_topk_kernel(const float* __restrict__ cls_rows, int32_t* __restrict__ idx,
                                                        int32_t* __restrict__ compl_idx, float* __restrict__ scores, int H, int N,
                                                        int K) {
-  __shared__ float s_sc[MAX_P];
+  __shared__ unsigned int s_sc[MAX_P];       // order keys: key(a) < key(b) <=> a < b; -0 == +0; NaN above +inf
   __shared__ unsigned char s_drop[MAX_P];
   const int b = blockIdx.x;
   const int P = N - 1;
@@ -39,15 +41,17 @@ __global__ __launch_bounds__(256) void cls_topk_kernel(const float* __restrict__
       for (int h = 0; h < H; ++h) acc += rows[(size_t)h * N + 1 + j];
     }
     const float sc = acc / (float)H;
-    s_sc[j] = sc;
+    unsigned int u = __float_as_uint(sc + 0.0f);                     // -0 -> +0
+    u = (sc != sc) ? 0xffffffffu : (u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u));
+    s_sc[j] = u;
     if (scores) scores[(size_t)b * P + j] = sc;
   }
   __syncthreads();
   for (int i = tid; i < P; i += 256) {
-    const float si = s_sc[i];
+    const unsigned int si = s_sc[i];
     int rank = 0;
     for (int j = 0; j < P; ++j) {
-      const float sj = s_sc[j];
+      const unsigned int sj = s_sc[j];
       rank += (sj > si) || (sj == si && j < i);
     }
     if (rank < K) idx[(size_t)b * K + rank] = i;

@@ -48,6 +48,7 @@ bool make_bwd_plan(const tr_vit_config* c, int B, const trplan::TokenPlan& t, Bw
   upd(tr_colsum_workspace_floats((int)T, (int)Hd));
   upd(tr_layernorm_bwd_workspace_floats((int)T, (int)D));
   upd(tr_wgrad_workspace_floats(B, c->num_classes, (int)D));
+  upd((size_t)(B + 1) * (D + 4));
   p->wsf_floats = f;
   p->wsf = take(f * 4);
   p->dscore = take(T * 4);
@@ -123,7 +124,7 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
 
   // which of the two stream-gradient buffers is current at block blk_hi: they swap at every block that reduces tokens
   for (int j = cfg->depth - 1; j > blk_hi; --j)
-    if ((cfg->family == TR_FAMILY_TOPK || cfg->family == TR_FAMILY_EVIT || cfg->family == TR_FAMILY_TOME) && t.kk[j] > 0) {
+    if (t.kk[j] > 0) {          // every token-reducing block of the built families swaps once
       float* tg = g; g = g_alt; g_alt = tg;
       uint16_t* tb = gb; gb = gb_alt; gb_alt = tb;
     }
@@ -194,11 +195,23 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
                               cfg->ln_eps, s));
     }
     // ---- attention: x1 -> norm1 -> qkv -> softmax(q k^T) v -> proj -> (+ residual)
-    TR_TRY(tr_wgrad_bf16(gb, D, 0, U(tape + bt.ao), D, F(bg->proj_w), acc, wsf, wsn, M1, D, D, s));
-    TR_TRY(tr_colsum_bf16(gb, D, 0, F(bg->proj_b), acc, wsf, wsn, M1, D, s));
-    TR_TRY(tr_gemm_bf16(gb, U(bwt->proj_w), zeros, dao, nullptr, 0, M1, D, D, TR_EPI_BF16, s));
-    const float* size_att = nullptr;                        // ToMe: log(size) bias of this block's keys (tome.py:48-49)
-    if (cfg->family == TR_FAMILY_TOME)
+    const bool ats_sampled = cfg->family == TR_FAMILY_ATS && K > 0;
+    const int Mp = ats_sampled ? M2 : M1;                   // rows that went through proj (ATS: only the sampled ones, ats.py:86,129)
+    TR_TRY(tr_wgrad_bf16(gb, D, 0, U(tape + bt.ao), D, F(bg->proj_w), acc, wsf, wsn, Mp, D, D, s));
+    TR_TRY(tr_colsum_bf16(gb, D, 0, F(bg->proj_b), acc, wsf, wsn, Mp, D, s));
+    if (ats_sampled) {
+      // d(attn @ v) of the sampled rows and the stream's gradient go back to the rows they were sampled from (ats.py:86,157)
+      TR_TRY(tr_gemm_bf16(gb, U(bwt->proj_w), zeros, dxn, nullptr, 0, Mp, D, D, TR_EPI_BF16, s));
+      TR_REQUIRE(hipMemsetAsync(g_alt, 0, (size_t)M1 * D * 4, st) == hipSuccess && hipMemsetAsync(dao, 0, (size_t)M1 * D * 2, st) == hipSuccess,
+                 TR_ERR_LAUNCH, "tr_vit_backward: memset failed");
+      TR_TRY(tr_ats_scatter(g, dxn, reinterpret_cast<const int32_t*>(tape + bt.idx), g_alt, dao, B, Na, Nm, D, s));
+      float* tg = g; g = g_alt; g_alt = tg;
+      uint16_t* tb = gb; gb = gb_alt; gb_alt = tb;           // gb is rewritten by norm1's backward below
+    } else {
+      TR_TRY(tr_gemm_bf16(gb, U(bwt->proj_w), zeros, dao, nullptr, 0, M1, D, D, TR_EPI_BF16, s));
+    }
+    const float* size_att = nullptr;       // ToMe: log(size) bias of this block's keys (tome.py:48-49); ATS: the key mask (ats.py:117-120)
+    if (cfg->family == TR_FAMILY_TOME || cfg->family == TR_FAMILY_ATS)
       for (int j = i - 1; j >= 0; --j)
         if (t.kk[j] > 0) { size_att = reinterpret_cast<const float*>(tape + tp.blk[j].size); break; }
     TR_TRY(tr_attention_bwd_bf16(U(tape + bt.qkv), dao, size_att, dcls, dqkv, B, Na, H, s));
@@ -207,6 +220,16 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
     TR_TRY(tr_gemm_bf16(dqkv, U(bwt->qkv_w), zeros, dxn, nullptr, 0, M1, D, 3 * D, TR_EPI_BF16, s));
     TR_TRY(tr_layernorm_bwd(dxn, x1, D, bw->ln1_g, g, D, g, D, gb, nullptr, 0, 0, 0, nullptr, F(bg->ln1_g), F(bg->ln1_b), acc, wsf, wsn, M1, D,
                             cfg->ln_eps, s));
+    if (cfg->family == TR_FAMILY_DPCKNN && K > 0) {
+      // CTM before the block (dpcknn.py:257-260): gradient of the merged tokens -> the tokens they were merged from + the score Linear
+      const tr_stage_weights* sw = &w->stage[i];
+      const tr_stage_weights* sg = &grads->stage[i];
+      TR_TRY(tr_cluster_merge_bwd(g, reinterpret_cast<const float*>(tape + bt.x0), x1, reinterpret_cast<const float*>(tape + bt.scores),
+                                  reinterpret_cast<const int32_t*>(tape + bt.idx2), sw->w3, g_alt, gb_alt, F(sg->w3), F(sg->b3), acc, wsf, wsn, B,
+                                  t.n_pre[i], K, D, s));
+      float* tg = g; g = g_alt; g_alt = tg;
+      uint16_t* tb = gb; gb = gb_alt; gb_alt = tb;
+    }
   }
   if (blk_lo > 0) return TR_OK;
   // ---- embedding (topk.py:181-186): g is d x0 [B, N0, D]

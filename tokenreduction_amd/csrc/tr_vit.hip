@@ -140,8 +140,10 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
   float* x = reinterpret_cast<float*>(ws + p.off_x0);
   float* x_alt = reinterpret_cast<float*>(ws + p.off_x1);
   void* xn = static_cast<void*>(ws + p.off_xn);
+  void* const xn_shared = xn;
   void* qkv = static_cast<void*>(ws + p.off_qkv);
   void* ao = static_cast<void*>(ws + p.off_ao);
+  void* const ao_shared = ao;
   void* hbuf = static_cast<void*>(ws + p.off_h);
   void* dbuf = static_cast<void*>(ws + p.off_d);   // bf16 output of proj / fc2, added to x by the NEXT norm
   void* const dbuf_shared = dbuf;
@@ -176,12 +178,25 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       const tr_stage_weights* sw = &w->stage[i];
       const int Kc = cfg->keep[i], M = B * N;
       TR_REQUIRE(Kc <= N - 1, TR_ERR_CONFIG, "tr_vit_forward: block %d asks for %d clusters of %d patch tokens", i, Kc, N - 1);
-      if (pending) TR_TRY(op_ln(f32, x, D, pending, D, bw->ln1_g, bw->ln1_b, xn, M, D, cfg->ln_eps, s));   // x += previous mlp output
+      if (train) {          // the stream entering the merge stays on the tape (out of place), norm1's input / output go to their slots
+        float* x0 = reinterpret_cast<float*>(tape + tp->blk[i].x0);
+        // (the norm output of this pass is not used -- it goes to the shared scratch, NOT to xn, which still names the previous
+        // block's norm2 slot on the tape)
+        TR_TRY(tr_layernorm_bf16_to(x, D, x0, D, static_cast<const uint16_t*>(pending), D, bw->ln1_g, bw->ln1_b, static_cast<uint16_t*>(xn_shared), M,
+                                    D, cfg->ln_eps, s));
+        x = x0;
+        x_alt = reinterpret_cast<float*>(tape + tp->blk[i].x1);
+        xn = tape + tp->blk[i].xn1;
+      } else if (pending) TR_TRY(op_ln(f32, x, D, pending, D, bw->ln1_g, bw->ln1_b, xn, M, D, cfg->ln_eps, s));   // x += previous mlp output
       pending = nullptr;
       float* cws = reinterpret_cast<float*>(ws + p.off_cluster);
-      float* wtok = cws + tr_dpcknn_workspace_floats(B, p.N0);
+      float* wtok = train ? reinterpret_cast<float*>(tape + tp->blk[i].scores) : cws + tr_dpcknn_workspace_floats(B, p.N0);
       int32_t* centers = kept_idx ? kept_idx + (size_t)i * B * p.N0 : idx_ws;
       int32_t* assign = compl_idx ? compl_idx + (size_t)i * B * p.N0 : compl_ws;
+      if (train) {
+        centers = reinterpret_cast<int32_t*>(tape + tp->blk[i].idx);
+        assign = reinterpret_cast<int32_t*>(tape + tp->blk[i].idx2);
+      }
       TR_TRY(tr_dpcknn_cluster(x, noise_in, cws, centers, assign, scores, B, N, D, Kc, cfg->knn_k > 0 ? cfg->knn_k : 5, f32 ? 0 : 1, s));
       if (noise_in) noise_in += (size_t)B * (N - 1);
       TR_TRY(tr_cluster_merge_layernorm(x, sw->w3, sw->b3, wtok, assign, bw->ln1_g, bw->ln1_b, x_alt, xn, f32 ? 1 : 0, B, N, Kc, D,
@@ -195,13 +210,18 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       const int Kc = cfg->keep[i], M = B * N;
       TR_REQUIRE(i > 0, TR_ERR_CONFIG, "tr_vit_forward: K-Medoids at block 0 has no previous attention to weigh the tokens "
                                        "(the reference fails there too: `attn` is unbound, kmedoids.py:240)");
+      const int kinit = cfg->kmed_init[i];             // > 0: args.equal_weight, first medoid id + 1
       TR_REQUIRE(Kc <= N - 1, TR_ERR_CONFIG, "tr_vit_forward: block %d asks for %d medoids of %d patch tokens", i, Kc, N - 1);
       if (pending) TR_TRY(op_ln(f32, x, D, pending, D, bw->ln1_g, bw->ln1_b, xn, M, D, cfg->ln_eps, s));   // x += previous mlp output
       pending = nullptr;
       int32_t* centers = kept_idx ? kept_idx + (size_t)i * B * p.N0 : idx_ws;
       int32_t* assign = compl_idx ? compl_idx + (size_t)i * B * p.N0 : compl_ws;
-      TR_TRY(tr_kmedoids(x, colsum_part, reinterpret_cast<float*>(ws + p.off_cluster), centers, assign, B, N, D, H, Kc,
-                         cfg->cluster_iters, f32 ? 0 : 1, s));
+      if (kinit > 0)
+        TR_TRY(tr_kmedoids_equal(x, kinit - 1, reinterpret_cast<float*>(ws + p.off_cluster), centers, assign, B, N, D, Kc, cfg->cluster_iters,
+                                 f32 ? 0 : 1, s));
+      else
+        TR_TRY(tr_kmedoids(x, colsum_part, reinterpret_cast<float*>(ws + p.off_cluster), centers, assign, B, N, D, H, Kc,
+                           cfg->cluster_iters, f32 ? 0 : 1, s));
       TR_TRY(op_gather(f32, x, nullptr, centers, nullptr, nullptr, bw->ln1_g, bw->ln1_b, x_alt, xn, B, N, Kc, D, cfg->ln_eps, s));
       float* t = x; x = x_alt; x_alt = t;
       N = Kc + 1;
@@ -312,7 +332,8 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
     const int M = B * N;
     if (train) {          // this block's tape slots replace the shared scratch
       const trplan::BlockTape& bt = tp->blk[i];
-      xn = tape + bt.xn1; qkv = tape + bt.qkv; ao = tape + bt.ao; hbuf = tape + bt.h;
+      xn = tape + bt.xn1; qkv = tape + bt.qkv; hbuf = tape + bt.h;
+      ao = (ats && Ks > 0) ? ao_shared : static_cast<void*>(tape + bt.ao);      // ATS keeps only the sampled rows of attn @ v
       dbuf = (cfg->family == TR_FAMILY_EVIT && K > 0) ? static_cast<void*>(tape + bt.dattn) : dbuf_shared;
       x_alt = reinterpret_cast<float*>(tape + bt.x2);
     }
@@ -339,9 +360,20 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       TR_REQUIRE(sw->w3 && sw->n_pad >= 1, TR_ERR_NULL, "tr_vit_forward: block %d has no ATS sample grid (tr_vit_weights.stage)", i);
       int32_t* ids = kept_idx ? kept_idx + (size_t)i * B * p.N0 : idx_ws;
       float* mask_next = (size_cur == size_a) ? size_b : size_a;
+      if (train) {
+        ids = reinterpret_cast<int32_t*>(tape + tp->blk[i].idx);
+        mask_next = reinterpret_cast<float*>(tape + tp->blk[i].size);
+      }
       TR_TRY(tr_ats_sample(cls_rows, qkv, f32 ? 1 : 0, size_cur, sw->w3, sw->n_pad, ids, mask_next, nullptr, B, N, H, Ks, s));
-      TR_TRY(tr_ats_gather(x, ao, f32 ? 1 : 0, ids, x_alt, xn, B, N, Ks, D, s));
-      float* t = x; x = x_alt; x_alt = t;
+      if (train) {          // sampled rows of the stream -> x0 slot, of attn @ v -> ao slot (proj's operand); norm1's input stays in x1
+        float* xg = reinterpret_cast<float*>(tape + tp->blk[i].x0);
+        xn = tape + tp->blk[i].ao;
+        TR_TRY(tr_ats_gather(x, ao, 0, ids, xg, xn, B, N, Ks, D, s));
+        x = xg;
+      } else {
+        TR_TRY(tr_ats_gather(x, ao, f32 ? 1 : 0, ids, x_alt, xn, B, N, Ks, D, s));
+        float* t = x; x = x_alt; x_alt = t;
+      }
       size_cur = mask_next;
       Nn = Ks;
       TR_TRY(op_gemm(f32, xn, bw->proj_w, bw->proj_b, dbuf, nullptr, 0, B * Nn, D, D, TR_EPI_BF16, s));

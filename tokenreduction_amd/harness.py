@@ -8,9 +8,15 @@ Mirrors, for the forward (inference) path only:
     validate.py:163-229   per-image `Stage-{loc}` records, relative -> absolute kept-token composition -> image_records()
     validate.py:26-30, 278-287   NumpyArrayEncoder / write_viz -> write_viz()
 
-Host logic only: the model is any callable returning logits or `(logits, viz_data)`.  The fine-tune half of engine.py
-(backward, optimizer, EMA) is not built -- tokenreduction_amd has no training path.
+    engine.py:14-114      train_one_epoch()          -> train_one_epoch()  (grad accumulation, clipping, EMA, frozen groups, step-wise LR)
+    timm ModelEmaV2       (train.py:399, engine.py:88) -> ModelEma
+
+Host logic only: the model is any callable returning logits or `(logits, viz_data)`; in train mode `loss.backward()` runs the HIP
+backward executor (training.py) and the optimizer is a stock torch optimizer over the models' fp32 master parameters.
 """
+import contextlib
+import copy
+import math
 import json
 from typing import Dict, Iterable, List, Optional, Sequence
 
@@ -74,6 +80,104 @@ def evaluate_multiclass(data_loader: Iterable, model, device) -> Dict[str, float
     for m in meters.values():
         m.synchronize_between_processes(device)
     return {k: m.global_avg for k, m in meters.items()}
+
+
+class ModelEma:
+    """timm 0.4.12 ModelEmaV2 (train.py:399-402, engine.py:88-89): a deep copy of the model in eval mode whose parameters and
+    buffers follow ema = decay * ema + (1 - decay) * model after every optimizer step."""
+
+    def __init__(self, model, decay: float = 0.9999, device=None):
+        packed, model._packed = getattr(model, "_packed", None), None          # ctypes structs / workspaces are not copied
+        tstate = model.__dict__.pop("_tstate", None)
+        reducer = model.__dict__.pop("_grad_reducer", None)
+        try:
+            self.module = copy.deepcopy(model)
+        finally:
+            model._packed = packed
+            if tstate is not None:
+                model._tstate = tstate
+            if reducer is not None:
+                model._grad_reducer = reducer
+        self.module.eval()
+        self.decay = decay
+        self.device = device
+        if device is not None:
+            self.module.to(device=device)
+
+    @torch.no_grad()
+    def update(self, model):
+        ema_v, model_v = list(self.module.state_dict().values()), list(model.state_dict().values())
+        fl_e = [e for e, m in zip(ema_v, model_v) if e.is_floating_point()]
+        fl_m = [m.to(e.device) for e, m in zip(ema_v, model_v) if e.is_floating_point()]
+        torch._foreach_lerp_(fl_e, fl_m, 1.0 - self.decay)                       # e + (1 - decay) * (m - e)
+        for e, m in zip(ema_v, model_v):
+            if not e.is_floating_point():
+                e.copy_(m)
+        for p in self.module.parameters():                                        # the packed bf16 copies follow the new values
+            p._version                                                            # (in-place lerp_ already bumped every version)
+
+
+def train_one_epoch(model, criterion, data_loader: Iterable, optimizer, device, epoch: int, lr_scheduler=None, max_norm: float = 0,
+                    model_ema=None, mixup_fn=None, grad_accum_steps: int = 1, num_steps_epoch: int = 1000, reducer=None,
+                    reduce_every_micro_step: bool = False):
+    """engine.py:14-114 without the logging: frozen parameter groups (`fix_step`, :35-37), gradient accumulation with the
+    optimizer stepping every `grad_accum_steps` batches or at the end of the loader (:41, :76-91), loss / grad_accum_steps
+    (:62-63), finite-loss check (:65-67), gradient clipping by total norm (:71-75 `dispatch_clip_grad(mode="norm")`), EMA update
+    and step-wise LR schedule after each optimizer step (:88-89, :108-111).  `criterion(samples, output, targets, model)` as the
+    reference's loss wrappers are called (:60).  `reducer` (dp.FlatGradReducer): the reference's DDP all-reduces on every
+    micro-step (no `no_sync`); here the accumulation micro-steps skip the collective unless `reduce_every_micro_step`.
+    Returns ({"loss": mean over the epoch and over ranks, "lr-i": ...}, total_step) like engine.py:113-114."""
+    model.train(True)
+    meter = _Meter()
+    total_step = epoch * num_steps_epoch
+    n_batches = len(data_loader) if hasattr(data_loader, "__len__") else None
+    epoch_step = 0
+    for samples, targets in data_loader:
+        for g in optimizer.param_groups:                       # engine.py:35-37
+            if epoch < g.get("fix_step", 0):
+                g["lr"] = 0
+        epoch_step += 1
+        opt_step = (epoch_step % grad_accum_steps == 0) or (n_batches is not None and epoch_step == n_batches)
+        samples = samples.to(device, non_blocking=True)
+        targets = targets.to(device, non_blocking=True)
+        if mixup_fn is not None:
+            samples, targets = mixup_fn(samples, targets)
+        skip_sync = reducer is not None and not opt_step and not reduce_every_micro_step
+        with (reducer.no_sync() if skip_sync else contextlib.nullcontext()):
+            output = model(samples)
+            loss = criterion(samples, output, targets, model)
+            loss_value = loss.item() / grad_accum_steps
+            loss = loss / grad_accum_steps
+            if not math.isfinite(loss_value):
+                raise FloatingPointError(f"Loss is {loss_value}, stopping training")      # engine.py:65-67
+            loss.backward()
+        if max_norm is not None and max_norm > 0.0:
+            torch.nn.utils.clip_grad_norm_(list(model.parameters()), max_norm)
+        if opt_step:
+            optimizer.step()
+            optimizer.zero_grad()
+            if model_ema is not None:
+                model_ema.update(model)
+            total_step += 1
+        if samples.is_cuda:
+            torch.cuda.synchronize()                           # engine.py:93
+        meter.update(loss_value)
+        if lr_scheduler is not None and opt_step:
+            lr_scheduler.step_update(num_updates=total_step)
+    meter.synchronize_between_processes(device)
+    stats = {"loss": meter.global_avg}
+    for i, g in enumerate(optimizer.param_groups):
+        stats[f"lr-{i}"] = g["lr"]
+    return stats, total_step
+
+
+def plain_criterion(fn):
+    """Adapter: a `fn(output, targets)` loss called the way engine.py:60 calls its loss wrappers."""
+    def wrapped(samples, output, targets, model):
+        if isinstance(output, (tuple, list)):
+            output = output[0]
+        return fn(output.float(), targets)
+    return wrapped
 
 
 def _np(a):

@@ -127,6 +127,7 @@ class VisionTransformer(nn.Module):
         self.viz_mode = getattr(args, 'viz_mode', False)
         self._keep = [0] * depth
         self.precision = "bf16"      # "bf16" = the product path; "fp32" = validation path (reference arithmetic on the GPU)
+        self.use_graph = True        # eval forward replays a captured hipGraph (False: plain launches)
         self._packed = None
         self._ws = {}
         nn.init.trunc_normal_(self.pos_embed, std=.02)
@@ -227,6 +228,9 @@ class VisionTransformer(nn.Module):
         """Device pointer of the per-stage random inputs (DPC-KNN density noise), None for deterministic families."""
         return None
 
+    def _grad_stage_ptrs(self, G, ptr):
+        """Families with learned reduction modules point G.stage[blk] (tr_stage_weights layout) at their gradient views."""
+
     def _soft_elems(self, B):
         """fp32 elements of the soft-assignment output (SiT), 0 for families without one."""
         return 0
@@ -279,15 +283,41 @@ class VisionTransformer(nn.Module):
             # viz_data["Features"]: the residual stream after every block (upper bound depth * B * N0 * D fp32)
             n0 = self.patch_embed.num_patches + 1
             ws["feat"] = torch.empty(self.depth * B * n0 * self.embed_dim, dtype=torch.float32, device=x.device)
-        logits = torch.empty(B, self.num_classes, dtype=torch.float32, device=x.device)
-        tokens = (C.c_int * self.depth)()
-        with torch.cuda.device(x.device):
-            rc = lib.tr_vit_forward(C.byref(cfg), C.byref(pk["W"]), x.data_ptr(), logits.data_ptr(), ws["buf"].data_ptr(),
+        noise_ptr = self._noise_ptr(B, x.device)
+
+        def launch(out):
+            tokens = (C.c_int * self.depth)()
+            rc = lib.tr_vit_forward(C.byref(cfg), C.byref(pk["W"]), x.data_ptr(), out.data_ptr(), ws["buf"].data_ptr(),
                                     ws["nbytes"], ws["kept"].data_ptr(), ws["compl"].data_ptr(),
-                                    None if ws.get("soft") is None else ws["soft"].data_ptr(), self._noise_ptr(B, x.device),
+                                    None if ws.get("soft") is None else ws["soft"].data_ptr(), noise_ptr,
                                     ws["feat"].data_ptr() if want_feat else None, tokens, B,
                                     torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, "tr_vit_forward")
+            _lib.check(rc, "tr_vit_forward")
+            return list(tokens)
+
+        with torch.cuda.device(x.device):
+            if self.use_graph and not torch.cuda.is_current_stream_capturing():
+                # The forward is a fixed sequence of ~90-130 dependent launches with no host decision in between: replay it as one
+                # hipGraph (captured once per batch size / input buffer / output set; the workspace and every output are static
+                # buffers).  Re-packing the weights or a new batch size drops the workspace and its graphs with it.
+                key = (x.data_ptr(), bool(want_feat), ws.get("soft") is not None, noise_ptr)
+                graphs = ws.setdefault("graphs", {})
+                ent = graphs.get(key)
+                if ent is None:
+                    out = torch.empty(B, self.num_classes, dtype=torch.float32, device=x.device)
+                    launch(out)                                       # eager once: first-touch of the workspace, lazy module load
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        toks = launch(out)
+                    if len(graphs) >= 8:
+                        graphs.pop(next(iter(graphs)))
+                    ent = graphs[key] = (g, out, toks)
+                g, out, toks = ent
+                g.replay()
+                logits, tokens = out.clone(), toks
+            else:
+                logits = torch.empty(B, self.num_classes, dtype=torch.float32, device=x.device)
+                tokens = launch(logits)
         self._last_tokens = list(tokens)
         self._last_ws = ws
         if self.viz_mode:
@@ -703,6 +733,12 @@ class DPCKNNVisionTransformer(VisionTransformer):
             st = W.stage[loc]
             st.w3, st.b3 = f32(self.cluster_layers[j].score.weight), f32(self.cluster_layers[j].score.bias)
 
+    def _grad_stage_ptrs(self, G, ptr):
+        if self.equal_weight:
+            return
+        for j, loc in enumerate(self.cluster_loc):
+            G.stage[loc].w3, G.stage[loc].b3 = ptr(f"cluster_layers.{j}.score.weight"), ptr(f"cluster_layers.{j}.score.bias")
+
     def _stage_shapes(self):
         out, p_in = [], self.patch_embed.num_patches
         for K, loc in sorted(zip(self.cluster_count, self.cluster_loc), key=lambda t: t[1]):
@@ -712,11 +748,14 @@ class DPCKNNVisionTransformer(VisionTransformer):
 
     def _noise_ptr(self, B, dev):
         shapes = self._stage_shapes()
+        n = sum(B * P for _, _, P in shapes)
+        if self._noise_buf is None or self._noise_buf.numel() != n or self._noise_buf.device != dev:
+            self._noise_buf = torch.empty(n, dtype=torch.float32, device=dev)      # static: a captured forward reads this address
         if self.density_noise is not None:
             parts = [self.density_noise[blk].to(device=dev, dtype=torch.float32).reshape(B, P) for blk, _, P in shapes]
-            self._noise_buf = torch.cat([t.reshape(-1) for t in parts]).contiguous()
+            self._noise_buf.copy_(torch.cat([t.reshape(-1) for t in parts]))
         else:
-            self._noise_buf = torch.rand(sum(B * P for _, _, P in shapes), dtype=torch.float32, device=dev)
+            self._noise_buf.uniform_()                                               # torch.rand: [0, 1)
         return self._noise_buf.data_ptr()
 
     def _viz_data(self, ws, B, tokens):

@@ -485,3 +485,29 @@ def tome_merge_bwd(g_merged, size_in, size_out, unm, src, dst, N: int):
                                              _dev(dst, torch.int32, "dst"), inv.data_ptr(), g.data_ptr(), gb.data_ptr(), B, N, r, D, _stream()),
                "tr_tome_merge_bwd")
     return g, gb
+
+
+def cluster_merge_bwd(g_in, x0, x1, wtok, assign, score_w):
+    """DPC-KNN CTM backward.  Returns (g fp32 [B,N,D], gb bf16, d_sw [D]|None, d_sb [1]|None)."""
+    B, N, D = x0.shape
+    K = x1.shape[1] - 1
+    lib = _lib.load()
+    g = torch.empty(B, N, D, dtype=torch.float32, device=x0.device)
+    gb = torch.empty(B, N, D, dtype=torch.bfloat16, device=x0.device)
+    dsw = torch.empty(D, dtype=torch.float32, device=x0.device) if score_w is not None else None
+    dsb = torch.empty(1, dtype=torch.float32, device=x0.device) if score_w is not None else None
+    ws = _ws((B + 1) * (D + 4), x0.device)
+    _lib.check(lib.tr_cluster_merge_bwd(_dev(g_in, torch.float32, "g_in"), _dev(x0, torch.float32, "x0"), _dev(x1, torch.float32, "x1"),
+                                        _opt(wtok, torch.float32, "wtok"), _dev(assign, torch.int32, "assign"), _opt(score_w, torch.float32, "score_w"),
+                                        g.data_ptr(), gb.data_ptr(), None if dsw is None else dsw.data_ptr(), None if dsb is None else dsb.data_ptr(),
+                                        0, ws.data_ptr(), ws.numel(), B, N, K, D, _stream()), "tr_cluster_merge_bwd")
+    return g, gb, dsw, dsb
+
+
+def ats_scatter(g, dao_s, ids, N: int):
+    B, Ks, D = g.shape
+    g_full = torch.zeros(B, N, D, dtype=torch.float32, device=g.device)
+    dao_full = torch.zeros(B, N, D, dtype=torch.bfloat16, device=g.device)
+    _lib.check(_lib.load().tr_ats_scatter(_dev(g, torch.float32, "g"), _dev(dao_s, torch.bfloat16, "dao_s"), _dev(ids, torch.int32, "ids"),
+                                          g_full.data_ptr(), dao_full.data_ptr(), B, N, Ks, D, _stream()), "tr_ats_scatter")
+    return g_full, dao_full

@@ -108,6 +108,7 @@ class TrainState:
             b.ln2_g, b.ln2_b = ptr(pre + "norm2.weight"), ptr(pre + "norm2.bias")
             b.fc1_w, b.fc1_b = ptr(pre + "mlp.fc1.weight"), ptr(pre + "mlp.fc1.bias")
             b.fc2_w, b.fc2_b = ptr(pre + "mlp.fc2.weight"), ptr(pre + "mlp.fc2.bias")
+        model._grad_stage_ptrs(G, ptr)
         return G
 
     def transposed(self, model, pk):
@@ -137,7 +138,7 @@ class TrainState:
             if nt == 0 or nb == 0:
                 raise NotImplementedError(
                     f"{type(model).__name__}: this family / configuration has no training path in the HIP executor "
-                    "(built: DeiT, Top-K, EViT, ToMe at 224x224, bf16); call model.eval() for inference")
+                    "(built: DeiT, Top-K, EViT, ToMe, DPC-KNN, ATS at 224x224, bf16); call model.eval() for inference")
             self.tape = torch.empty(nt, dtype=torch.uint8, device=dev)
             self.bws = torch.empty(nb, dtype=torch.uint8, device=dev)
             self.B = B
@@ -158,7 +159,7 @@ def tape_layout(model, blk: int) -> dict:
 
 def train_decisions(model) -> dict:
     """{blk: decision tensors} of the last training forward, read back from the tape (int64 on the host side):
-    Top-K / EViT: idx [B,K]; ToMe: (unm [B,na-r], src [B,r], dst [B,r])."""
+    Top-K / EViT: idx [B,K]; ToMe: (unm [B,na-r], src [B,r], dst [B,r]); DPC-KNN: (centres [B,K], assignment [B,P_in]); ATS: ids."""
     st = model._train_state()
     B, out = st.B, {}
     for blk in range(model.depth):
@@ -173,6 +174,12 @@ def train_decisions(model) -> dict:
             na = (lay["n_att"] + 1) // 2
             out[blk] = (raw[: B * (na - k)].view(B, na - k).long(), raw[B * (na - k): B * na].view(B, k).long(),
                         raw[B * na: B * (na + k)].view(B, k).long())
+        elif model._family == _lib.TR_FAMILY_DPCKNN:          # (centres [B,K], assignment [B,P_in])
+            p_in = lay["n_pre"] - 1
+            raw2 = st.tape[lay["idx2"]: lay["idx2"] + 4 * B * p_in].view(torch.int32)
+            out[blk] = (raw[: B * k].view(B, k).long(), raw2.view(B, p_in).long())
+        elif model._family == _lib.TR_FAMILY_ATS:             # ids [B,Ks]: CLS id 0 first, 1-based token ids, 0 padding
+            out[blk] = raw[: B * k].view(B, k).long()
     return out
 
 
