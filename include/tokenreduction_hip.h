@@ -90,7 +90,8 @@ int tr_broadcast_rows(const float* src, float* dst, int B, int N, tr_stream_t s)
  * N <= 224 in this round (whole score row in registers); larger N returns TR_ERR_SHAPE. */
 int tr_attention_bf16(const uint16_t* qkv, uint16_t* out, float* cls_rows, const float* size, float* colsum_part, int B, int N,
                       int H, tr_stream_t s);
-/* fp32 validation path (N <= 256): same contract in the reference's arithmetic (expf softmax, fp32 everywhere). */
+/* fp32 validation path (N <= 640; K/V of a head in LDS up to N = 256, read from L2 beyond): same contract in the reference's
+ * arithmetic (expf softmax, fp32 everywhere). */
 int tr_attention_f32(const float* qkv, float* out, float* cls_rows, const float* size, float* colsum_part, int B, int N, int H,
                      tr_stream_t s);
 /* a11 (forward only): Policy_Attention.forward dyvit.py:53-67 with softmax_with_policy :39-51 -- the attention of DyViT's

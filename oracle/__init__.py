@@ -43,7 +43,7 @@ def forward(params, x, cfg, precision="fp32", return_viz=False, forced=None, noi
         assert forced is None
         return patchmerger_forward(params, x, cfg, precision, return_viz)
     if cfg.family == "kmedoids":
-        return kmedoids_forward(params, x, cfg, precision, return_viz, forced=forced)
+        return kmedoids_forward(params, x, cfg, precision, return_viz, forced=forced, equal_first=(extra or {}).get("equal_first"))
     if cfg.family == "sinkhorn":
         assert forced is None
         return sinkhorn_forward(params, x, cfg, precision, return_viz)

@@ -192,6 +192,21 @@ def kmedoids_token_weights(attn: Tensor) -> Tensor:
     return torch.sum(torch.sum(attn, dim=1), dim=1)[:, 1:].unsqueeze(2)
 
 
+def kmedoids_init_equal(x: Tensor, cluster_num: int, first: int) -> Tensor:
+    """k_medoids_fit kmedoids.py:43-56, token_weight None (args.equal_weight): `first` is the reference's
+    np.random.choice(np.arange(N), 1) draw, shared by the whole batch; then cluster_num-1 times the token whose LARGEST distance
+    to the medoids chosen so far is largest joins (rows of chosen tokens are zeroed first; torch.max -> first index)."""
+    B, N, C = x.shape
+    cluster_idx = torch.full((B, 1), int(first), dtype=torch.long)
+    for k in range(1, cluster_num):
+        centers = torch.gather(x, 1, cluster_idx[:, :, None].expand(B, k, C))
+        inter = torch.cdist(x, centers)
+        inter.scatter_(1, cluster_idx[:, :, None].expand(B, k, k), 0.0)           # inter[b, cluster_idx[b, j], :] = 0
+        new = inter.max(dim=-1).values.max(dim=-1).indices
+        cluster_idx = torch.cat([cluster_idx, new.reshape(B, 1)], dim=-1)
+    return cluster_idx
+
+
 def kmedoids_fit(x: Tensor, cluster_num: int, iterations: int, token_weight: Tensor, forced_init: Optional[Tensor] = None):
     """k_medoids_fit kmedoids.py:40-85, weighted branch (token_weight given).  Returns (centres [B,K,D], cluster_idx [B,K],
     assignment [B,P]).  The per-cluster loop of :74-79 is restated without the B*P*P clone: a row outside cluster k sums to
@@ -199,6 +214,9 @@ def kmedoids_fit(x: Tensor, cluster_num: int, iterations: int, token_weight: Ten
     B, N, C = x.shape
     if forced_init is None:
         cluster_idx = torch.sort(token_weight.squeeze(2), dim=1, descending=True, stable=True).indices[:, :cluster_num]
+    elif isinstance(forced_init, int):                    # equal_weight branch: the host's first-medoid draw, unit weights
+        cluster_idx = kmedoids_init_equal(x, cluster_num, forced_init)
+        token_weight = x.new_ones(B, N, 1)
     else:
         cluster_idx = forced_init
     cluster_idx = cluster_idx.clone()
@@ -245,7 +263,7 @@ def kmedoids_block_forward(x: Tensor, p: Dict[str, Tensor], i: int, cfg: VitConf
 
 @torch.no_grad()
 def kmedoids_forward(params: Dict[str, Tensor], x: Tensor, cfg: VitConfig, precision: str = "fp32", return_viz: bool = False,
-                     iters: int = 3, forced: Optional[Dict[int, Tensor]] = None):
+                     iters: int = 3, forced: Optional[Dict[int, Tensor]] = None, equal_first: Optional[Dict[int, int]] = None):
     """KMedoidsVisionTransformer.forward kmedoids.py:219-272, eval mode, args.equal_weight False.  forced[blk] (tests only)
     replaces the whole clustering result of that block by the given medoid ids [B,K]."""
     p = params
@@ -257,7 +275,8 @@ def kmedoids_forward(params: Dict[str, Tensor], x: Tensor, cfg: VitConfig, preci
     for i in range(cfg.depth):
         if i in counts:
             w = kmedoids_token_weights(attn)
-            xs, centers, assign = kmedoids_fit(h[:, 1:], counts[i], iters, w)
+            # equal_first[blk] (args.equal_weight): the reference's np.random.choice draw for that stage
+            xs, centers, assign = kmedoids_fit(h[:, 1:], counts[i], iters, w, None if equal_first is None else int(equal_first[i]))
             if forced is not None:
                 centers = forced[i]
                 xs = torch.gather(h[:, 1:], 1, centers[:, :, None].expand(-1, -1, h.shape[-1]))

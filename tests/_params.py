@@ -165,6 +165,9 @@ GOLDEN_CASES = {
     "kmedoids_small_kr07": dict(family="kmedoids", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
                                 keep_rate=[0.7], reduction_loc=[3, 6, 9], batch=2, wseed=153, xseed=154,
                                 qkv_gain=4.0, factory="kmedoids_small_patch16_224"),
+    # args.equal_weight (kmedoids.py:43-58): first medoid from numpy's global RNG (seeded with xseed by the generator), farthest-point init
+    "kmedoids_micro_equal": dict(family="kmedoids", embed_dim=128, depth=4, num_heads=2, num_classes=16, equal_weight=True,
+                                 keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=155, xseed=156, qkv_gain=6.0),
     # Sinkhorn (models/sinkhorn.py): optimal-transport soft assignment to learned centres BEFORE the block
     "sinkhorn_micro": dict(family="sinkhorn", embed_dim=128, depth=4, num_heads=2, num_classes=16,
                            keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=141, xseed=142, qkv_gain=6.0),

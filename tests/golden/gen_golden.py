@@ -169,8 +169,20 @@ def run_case(name, case):
     m, _ = build_reference(case)
     x = make_images(case["batch"], case.get("img_size", 224), case["xseed"])
     torch.manual_seed(case["xseed"])
-    with TopkSpy() as spy, ArgsortSpy() as aspy, RandSpy() as rspy, CdistSpy() as cspy, torch.no_grad():
-        out = m(x)
+    np.random.seed(case["xseed"])              # K-Medoids equal_weight draws its first medoid from numpy's global generator
+    first_draws = []
+    orig_choice = np.random.choice
+
+    def choice_spy(*a, **kw):
+        r = orig_choice(*a, **kw)
+        first_draws.append(int(np.asarray(r).reshape(-1)[0]))
+        return r
+    np.random.choice = choice_spy
+    try:
+        with TopkSpy() as spy, ArgsortSpy() as aspy, RandSpy() as rspy, CdistSpy() as cspy, torch.no_grad():
+            out = m(x)
+    finally:
+        np.random.choice = orig_choice
     logits, viz = out if isinstance(out, tuple) else (out, {})
     rec = {"logits": logits.numpy()}
     tome_gaps = []
@@ -180,7 +192,10 @@ def run_case(name, case):
             assert torch.unique(v).numel() == v.numel(), f"{name}: tied ranked values - pick another seed"
             srt = torch.sort(v, descending=True).values
             tome_gaps.append((srt[:-1] - srt[1:]).min().item())
-    if case["family"] == "kmedoids":
+    if case["family"] == "kmedoids" and case.get("equal_weight"):
+        rec["first_medoid"] = np.array(first_draws, dtype=np.int64)       # the np.random.choice draws, one per stage
+        spy.calls = []
+    elif case["family"] == "kmedoids":
         # spy.calls: one topk(token_weight, K) per stage -> the weights that seed the medoids (kmedoids.py:59)
         blks = sorted(viz["Kept_Tokens"])
         assert len(spy.calls) == len(blks)

@@ -41,9 +41,9 @@ def test_every_reference_factory_name_constructs():
             continue
         m = tra.create_model(n, pretrained=False, num_classes=10, img_size=224, args=args)
         assert isinstance(m, torch.nn.Module) and m.embed_dim == 192, n
-    with pytest.raises(NotImplementedError):      # the numpy-RNG branch of K-Medoids is refused loudly, not approximated
-        tra.create_model("kmedoids_tiny_patch16_224", args=_args(keep_rate=[0.7], reduction_loc=[3, 6, 9], equal_weight=True,
-                                                                cluster_iters=3))
+    m = tra.create_model("kmedoids_tiny_patch16_224", args=_args(keep_rate=[0.7], reduction_loc=[3, 6, 9], equal_weight=True,
+                                                                cluster_iters=3))       # the numpy-RNG branch (kmedoids.py:43-58)
+    assert m.equal_weight
 
 
 @pytest.mark.parametrize("name,dims", [("topk_tiny_patch16_224", (192, 3)), ("evit_small_patch16_224", (384, 6)),

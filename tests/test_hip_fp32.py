@@ -39,7 +39,7 @@ def test_gemm_f32(ops, M, N, K, epi):
     torch.testing.assert_close(out.cpu(), ref.float(), atol=2e-5, rtol=2e-5)
 
 
-@pytest.mark.parametrize("B,N,H", [(2, 197, 6), (2, 138, 2), (1, 69, 3), (1, 7, 1), (1, 256, 1)])
+@pytest.mark.parametrize("B,N,H", [(2, 197, 6), (2, 138, 2), (1, 69, 3), (1, 7, 1), (1, 256, 1), (2, 577, 2), (1, 257, 1), (1, 640, 1)])
 def test_attention_f32(ops, B, N, H):
     qkv = _randn(N + H, B * N, 3 * H * 64, scale=1.5)
     q, k, v = qkv.double().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
@@ -80,14 +80,14 @@ def _check_ats_fp32(name, case, g, logits, viz, kept_keys):
     if all(same):
         assert d < 2e-4, d
     else:
-        assert d < 0.2, d
+        # one moved sample changes the token set of every later block; at N = 577 (143 grid points on 576 cdf entries) more grid
+        # points sit on a rounding plateau than at N = 197: measured 2.5e-1 there against <= 1e-1 at 224^2
+        assert d < (0.5 if case.get("img_size", 224) > 224 else 0.2), d
 
 
 @pytest.mark.parametrize("name", list(GOLDEN_CASES))
 def test_model_fp32_matches_reference_golden(golden_dir, name):
     case = GOLDEN_CASES[name]
-    if case.get("img_size", 224) > 224:
-        pytest.skip("the fp32 validation attention holds K^T and V of a head in LDS as fp32: N <= 256 (224^2 inputs)")
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     model, _, _ = build_model(case)
     model.precision = "fp32"
@@ -95,6 +95,7 @@ def test_model_fp32_matches_reference_golden(golden_dir, name):
     if noise:
         model.density_noise = noise                         # DPC-KNN: the reference's own torch.rand draws
     x = make_images(case["batch"], case.get("img_size", 224), case["xseed"])
+    np.random.seed(case["xseed"])          # K-Medoids equal_weight: the reference's numpy stream
     logits, viz = model(x.cuda())
     kept_keys = sorted(k for k in g.files if k.startswith("kept_"))
     assert sorted(viz.get("Kept_Tokens", {}).keys()) == [int(k.split("_")[1]) for k in kept_keys]

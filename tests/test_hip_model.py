@@ -75,6 +75,7 @@ def test_model_parity(golden_dir, name):
     noise = {int(k.split("_")[1]): torch.from_numpy(g[k]) for k in g.files if k.startswith("noise_")}
     if noise:
         model.density_noise = noise                      # DPC-KNN: the reference's own torch.rand draws (dpcknn.py:71-72)
+    np.random.seed(case["xseed"])          # K-Medoids equal_weight draws its first medoids from numpy's global generator, like the reference
     out = model(x.cuda())
     logits, viz = out
     logits = logits.cpu()
@@ -222,7 +223,11 @@ def _dpcknn_parity(name, case, g, model, params, cfg, x, logits, viz, info, nois
     assert sorted(viz["Kept_Tokens"].keys()) == [int(k.split("_")[1]) for k in kept_keys]
     for blk, n in zip(g["token_count_blocks"], g["token_counts"]):
         assert model._last_tokens[int(blk)] == int(n)
-    lb, vb = oracle.forward(params, x, cfg, precision="bf16", return_viz=True, noise=noise)
+    extra = None
+    if case["family"] == "kmedoids" and case.get("equal_weight"):
+        extra = {"equal_first": dict(zip(sorted(oracle.dpcknn_cluster_counts(cfg)), g["first_medoid"].tolist()))}
+        assert list(model._kmed_draws) == g["first_medoid"].tolist()          # same numpy stream as the reference run
+    lb, vb = oracle.forward(params, x, cfg, precision="bf16", return_viz=True, noise=noise, extra=extra)
     if case["family"] == "dpcknn":
         # the token -> centre assignment is a discrete decision too (a token between two centres flips with bf16-level changes of
         # the residual stream): given the device's centres the oracle's own nearest-centre map must agree almost everywhere at the
@@ -233,7 +238,7 @@ def _dpcknn_parity(name, case, g, model, params, cfg, x, logits, viz, info, nois
         print(f"   first-stage assignment agreement with the oracle given the device's centres: {agree:.4f}")
         assert agree > 0.97, agree
         forced = {blk: (c, torch.from_numpy(viz["Assignment_Maps"][blk]).long()) for blk, c in forced.items()}
-    lf = oracle.forward(params, x, cfg, precision="bf16", forced=forced, noise=noise)
+    lf = oracle.forward(params, x, cfg, precision="bf16", forced=forced, noise=noise, extra=extra)
     ref = torch.from_numpy(g["logits"])
     rel_bf = ((logits - lb).norm() / lb.norm()).item()
     rel_ref = ((logits - ref).norm() / ref.norm()).item()

@@ -164,6 +164,83 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float* __restr
   }
 }
 
+// Long sequences (256 < N <= 640: the 384^2 inputs, N = 577): K^T and V of a head no longer fit the LDS as fp32 (2 x 164 KB), so
+// the same wave-per-query scheme reads K rows and V rows straight from global memory (they stay in L2: 2 x 148 KB per head).
+// Only the softmax row lives in LDS.  Same arithmetic and summation order as attention_f32_kernel.
+constexpr int F32_LONG_CHUNKS = 10;
+__global__ __launch_bounds__(256) void attention_f32_long_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                 float* __restrict__ cls_rows, const float* __restrict__ size,
+                                                                 float* __restrict__ colsum_part, int N, int H) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int NP = (N + 63) & ~63;
+  float* sQ = sm;                        // [4 waves][64]
+  float* sP = sQ + 4 * 64;               // [4 waves][NP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int ldq = 3 * H * 64;
+  const float* base = qkv + (size_t)b * N * ldq;
+  const int qcol = h * 64, kcol = H * 64 + h * 64, vcol = 2 * H * 64 + h * 64;
+  const int nkc = NP >> 6;
+  float colacc[F32_LONG_CHUNKS];
+#pragma unroll
+  for (int c = 0; c < F32_LONG_CHUNKS; ++c) colacc[c] = 0.f;
+  for (int q = wave; q < N; q += 4) {
+    sQ[wave * 64 + lane] = base[(size_t)q * ldq + qcol + lane];
+    __builtin_amdgcn_wave_barrier();
+    float s[F32_LONG_CHUNKS];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < F32_LONG_CHUNKS; ++c) {
+      s[c] = -INFINITY;
+      if (c < nkc) {
+        const int key = c * 64 + lane;
+        const float* krow = base + (size_t)min(key, N - 1) * ldq + kcol;
+        float acc = 0.f;
+#pragma unroll 16
+        for (int d = 0; d < 64; ++d) acc = fmaf(sQ[wave * 64 + d], krow[d], acc);
+        acc = key < N ? acc * 0.125f + (size ? logf(size[(size_t)b * N + key]) : 0.f) : -INFINITY;
+        s[c] = acc;
+        mx = fmaxf(mx, acc);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int c = 0; c < F32_LONG_CHUNKS; ++c) {
+      s[c] = expf(s[c] - mx);
+      l += s[c];
+    }
+    l = wave_sum(l);
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int c = 0; c < F32_LONG_CHUNKS; ++c)
+      if (c < nkc) {
+        sP[wave * NP + c * 64 + lane] = s[c] * inv;
+        colacc[c] += s[c] * inv;
+      }
+    __builtin_amdgcn_wave_barrier();
+    float o = 0.f;
+    for (int key = 0; key < N; ++key) o = fmaf(sP[wave * NP + key], base[(size_t)key * ldq + vcol + lane], o);
+    out[((size_t)b * N + q) * (H * 64) + h * 64 + lane] = o;
+    if (cls_rows != nullptr && q == 0) {
+#pragma unroll
+      for (int c = 0; c < F32_LONG_CHUNKS; ++c) {
+        const int key = c * 64 + lane;
+        if (c < nkc && key < N) cls_rows[((size_t)b * H + h) * N + key] = s[c] * inv;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (colsum_part != nullptr) {
+#pragma unroll
+    for (int c = 0; c < F32_LONG_CHUNKS; ++c) {
+      const int key = c * 64 + lane;
+      if (c < nkc && key < N) colsum_part[(((size_t)b * H + h) * 4 + wave) * N + key] = colacc[c];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int tr_gemm_f32(const float* A, const float* W, const float* bias, float* out, const float* aux, int aux_i, int M,
@@ -188,10 +265,16 @@ extern "C" int tr_gemm_f32(const float* A, const float* W, const float* bias, fl
 extern "C" int tr_attention_f32(const float* qkv, float* out, float* cls_rows, const float* size, float* colsum_part, int B, int N,
                                 int H, tr_stream_t s) {
   TR_REQUIRE(qkv && out, TR_ERR_NULL, "tr_attention_f32: null pointer");
-  TR_REQUIRE(B > 0 && H > 0 && N >= 1 && N <= 256, TR_ERR_SHAPE, "tr_attention_f32: need 1 <= N <= 256 (N=%d)", N);
+  TR_REQUIRE(B > 0 && H > 0 && N >= 1 && N <= 64 * F32_LONG_CHUNKS, TR_ERR_SHAPE, "tr_attention_f32: need 1 <= N <= %d (N=%d)", 64 * F32_LONG_CHUNKS, N);
   const int NP = (N + 63) & ~63;
-  const size_t lds = (size_t)(64 * NP + NP * 64 + 4 * 64 + 4 * NP) * sizeof(float);
   hipStream_t st = static_cast<hipStream_t>(s);
+  if (N > 256) {
+    const size_t lds_long = (size_t)(4 * 64 + 4 * NP) * sizeof(float);
+    hipLaunchKernelGGL(attention_f32_long_kernel, dim3(B * H), dim3(256), lds_long, st, qkv, out, cls_rows, size, colsum_part, N, H);
+    TR_CHECK_LAUNCH("tr_attention_f32");
+    return TR_OK;
+  }
+  const size_t lds = (size_t)(64 * NP + NP * 64 + 4 * 64 + 4 * NP) * sizeof(float);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_f32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_attention_f32: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
   hipLaunchKernelGGL(attention_f32_kernel<false>, dim3(B * H), dim3(256), lds, st, qkv, out, cls_rows, size, colsum_part, N, H);

@@ -231,6 +231,9 @@ class VisionTransformer(nn.Module):
     def _grad_stage_ptrs(self, G, ptr):
         """Families with learned reduction modules point G.stage[blk] (tr_stage_weights layout) at their gradient views."""
 
+    def _per_forward_config(self, cfg):
+        """Host-side random draws of a forward that the executor takes as inputs (K-Medoids equal_weight)."""
+
     def _soft_elems(self, B):
         """fp32 elements of the soft-assignment output (SiT), 0 for families without one."""
         return 0
@@ -284,6 +287,8 @@ class VisionTransformer(nn.Module):
             n0 = self.patch_embed.num_patches + 1
             ws["feat"] = torch.empty(self.depth * B * n0 * self.embed_dim, dtype=torch.float32, device=x.device)
         noise_ptr = self._noise_ptr(B, x.device)
+        self._kmed_draws = None
+        self._per_forward_config(cfg)
 
         def launch(out):
             tokens = (C.c_int * self.depth)()
@@ -300,7 +305,7 @@ class VisionTransformer(nn.Module):
                 # The forward is a fixed sequence of ~90-130 dependent launches with no host decision in between: replay it as one
                 # hipGraph (captured once per batch size / input buffer / output set; the workspace and every output are static
                 # buffers).  Re-packing the weights or a new batch size drops the workspace and its graphs with it.
-                key = (x.data_ptr(), bool(want_feat), ws.get("soft") is not None, noise_ptr)
+                key = (x.data_ptr(), bool(want_feat), ws.get("soft") is not None, noise_ptr, self._kmed_draws)
                 graphs = ws.setdefault("graphs", {})
                 ent = graphs.get(key)
                 if ent is None:
@@ -893,9 +898,6 @@ class KMedoidsVisionTransformer(VisionTransformer):
         self.cluster_count = list(args.keep_rate)
         self.sinkhorn_iters = self.cluster_iters = int(args.cluster_iters)      # cfg.cluster_iters carries it to the executor
         self.equal_weight = bool(args.equal_weight)
-        if self.equal_weight:
-            raise NotImplementedError("kmedoids with --equal_weight seeds its medoids from numpy's global RNG (kmedoids.py:45-58); "
-                                      "only the attention-weighted branch is built")
         if len(self.cluster_count) == 1:
             self.cluster_count = [int(self.num_patches * (args.keep_rate[0] ** (idx + 1))) for idx in range(len(self.cluster_loc))]
         assert len(self.cluster_count) == len(self.cluster_loc), \
@@ -906,6 +908,24 @@ class KMedoidsVisionTransformer(VisionTransformer):
         self.cluster_layers = nn.ModuleList([KMedoids(c, self.cluster_iters, self.equal_weight) for c in self.cluster_count])
         for c, loc in zip(self.cluster_count, self.cluster_loc):
             self._keep[loc] = c
+
+    def _per_forward_config(self, cfg):
+        """args.equal_weight (kmedoids.py:43-47): every k_medoids_fit call draws its first medoid with
+        `np.random.choice(np.arange(N), 1)` from numpy's GLOBAL generator -- drawn here, stage by stage in forward order, so a
+        seeded run consumes the stream exactly like the reference; the executor takes the ids as inputs (and a captured graph is
+        keyed on them through the noise key below)."""
+        if not self.equal_weight:
+            return
+        p_in, draws = self.num_patches, []
+        for K, loc in sorted(zip(self.cluster_count, self.cluster_loc), key=lambda t: t[1]):
+            first = int(np.random.choice(np.arange(p_in), 1)[0])
+            cfg.kmed_init[loc] = first + 1
+            draws.append(first)
+            p_in = K
+        self._kmed_draws = tuple(draws)
+
+    def _noise_ptr(self, B, dev):
+        return None
 
     def get_new_module_names(self):
         return ["cluster_layers"]

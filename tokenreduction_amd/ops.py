@@ -339,6 +339,18 @@ def kmedoids(x: torch.Tensor, colsum_part: torch.Tensor, K: int, iters: int, fas
     return centers, assign
 
 
+def kmedoids_equal(x: torch.Tensor, first: int, K: int, iters: int, fast_dist: bool = False):
+    """k_medoids_fit with token_weight None (args.equal_weight, kmedoids.py:43-58): `first` = the np.random.choice draw."""
+    B, N, D = x.shape
+    lib = _lib.load()
+    ws = torch.empty(lib.tr_dpcknn_workspace_floats(B, N), dtype=torch.float32, device=x.device)
+    centers = torch.empty(B, K, dtype=torch.int32, device=x.device)
+    assign = torch.empty(B, N - 1, dtype=torch.int32, device=x.device)
+    _lib.check(lib.tr_kmedoids_equal(_dev(x, torch.float32, "x"), int(first), ws.data_ptr(), centers.data_ptr(), assign.data_ptr(), B, N, D, K,
+                                     iters, int(fast_dist), _stream()), "tr_kmedoids_equal")
+    return centers, assign
+
+
 # ---------------------------------------------------------------------------------------- DyViT training attention (forward)
 def attention_policy(qkv: torch.Tensor, policy: torch.Tensor, B: int, N: int, H: int) -> torch.Tensor:
     """Policy_Attention with softmax_with_policy (dyvit.py:39-67): qkv bf16|fp32 [B*N, 3*H*64], policy fp32 [B,N] of 1/0 ->

@@ -135,9 +135,15 @@ def forward_stepwise(model: VisionTransformer, x: torch.Tensor, trace: Optional[
                 tr.run("layernorm_kernel", 0.0, 12.0 * M * D,
                        lambda: ops.layernorm(h, f32(blk.norm1.weight), f32(blk.norm1.bias), eps, delta=pending))
                 pending = None
-            centers, assign = tr.run("kmedoids", 2.0 * B * (N - 1) * (N - 1) * D, 8.0 * B * (N - 1) * (N - 1),
-                                     lambda: ops.kmedoids(h.view(B, N, D), colsum, Kc, model.cluster_iters, fast_dist=True))
-            info["kept"][i], info["compl"][i], info["scores"][i] = centers, assign, colsum.sum(dim=(1, 2))[:, 1:]
+            if getattr(model, "equal_weight", False):          # the first-medoid draws of the model's last forward (same stage order)
+                first = model._kmed_draws[sorted(model.cluster_loc).index(i)]
+                centers, assign = tr.run("kmedoids", 2.0 * B * (N - 1) * (N - 1) * D, 8.0 * B * (N - 1) * (N - 1),
+                                         lambda: ops.kmedoids_equal(h.view(B, N, D), first, Kc, model.cluster_iters, fast_dist=True))
+                info["kept"][i], info["compl"][i], info["scores"][i] = centers, assign, None
+            else:
+                centers, assign = tr.run("kmedoids", 2.0 * B * (N - 1) * (N - 1) * D, 8.0 * B * (N - 1) * (N - 1),
+                                         lambda: ops.kmedoids(h.view(B, N, D), colsum, Kc, model.cluster_iters, fast_dist=True))
+                info["kept"][i], info["compl"][i], info["scores"][i] = centers, assign, colsum.sum(dim=(1, 2))[:, 1:]
             h3_, xn = tr.run("gather_layernorm_kernel", 0.0, 10.0 * B * (Kc + 1) * D,
                              lambda: ops.gather_layernorm(h.view(B, N, D), centers, None, None, f32(blk.norm1.weight),
                                                           f32(blk.norm1.bias), eps))
