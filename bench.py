@@ -71,33 +71,50 @@ def model_flops_per_image(tokens_per_block, D=384, P=196, classes=1000, n0=197):
     return f
 
 
-def roofline_leg(model, x, reps=5):
-    """Per-kernel HIP-event timing of instrumented forwards.  Each kernel's time is the MEDIAN over `reps` forwards of its summed
-    launch durations (one disturbed forward -- another tenant on the box, a clock dip -- must not skew a table measured once)."""
-    from tokenreduction_amd.stepwise import Trace, forward_stepwise
-    per_rep = []
-    tr = Trace(timing=True)
-    forward_stepwise(model, x, tr)          # untimed pass: fills the trace's buffer cache
-    for _ in range(reps):
-        tr.launches = []
-        forward_stepwise(model, x, tr)
-        rep = {}
-        for l in tr.launches:
-            a = rep.setdefault(l["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
-            a["ms"] += l["ms"]; a["flops"] += l["flops"]; a["bytes"] += l["bytes"]; a["launches"] += 1
-        per_rep.append(rep)
+def profile_forward(model, x, reps=5):
+    """Per-launch-group HIP-event timing of the EXECUTOR (tr_profile_begin / tr_profile_end: an event on the launch stream after
+    every launch the library enqueues).  Returns {label: dict(ms, flops, bytes, launches)} with ms = the MEDIAN over `reps`
+    forwards of the group's summed durations (one disturbed forward must not skew a table measured once)."""
+    import ctypes as C
+    from tokenreduction_amd import _lib
+    lib = _lib.load()
+    graph, model.use_graph = model.use_graph, False          # plain launches: events cannot be recorded inside a graph replay
+    try:
+        model(x)
+        torch.cuda.synchronize()
+        per_rep, cap = [], 4096
+        labels = C.create_string_buffer(cap * 48)
+        ms, fl, by = (C.c_float * cap)(), (C.c_double * cap)(), (C.c_double * cap)()
+        for _ in range(reps):
+            _lib.check(lib.tr_profile_begin(torch.cuda.current_stream().cuda_stream), "tr_profile_begin")
+            model(x)
+            n = lib.tr_profile_end(cap, labels, ms, fl, by)
+            assert 0 < n <= cap, n
+            rep = {}
+            for i in range(n):
+                name = labels.raw[i * 48:(i + 1) * 48].split(b"\0", 1)[0].decode()
+                a = rep.setdefault(name, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+                a["ms"] += ms[i]; a["flops"] += fl[i]; a["bytes"] += by[i]; a["launches"] += 1
+            per_rep.append(rep)
+    finally:
+        model.use_graph = graph
     agg = {}
     for k in per_rep[0]:
-        ms = sorted(r[k]["ms"] for r in per_rep)[reps // 2]
-        agg[k] = dict(ms=ms * reps, flops=per_rep[0][k]["flops"] * reps, bytes=per_rep[0][k]["bytes"] * reps,
-                      launches=per_rep[0][k]["launches"] * reps)
+        agg[k] = dict(per_rep[0][k], ms=sorted(r[k]["ms"] for r in per_rep)[reps // 2])
+    return agg
+
+
+def roofline_leg(model, x, reps=5):
+    """Kernel table + roofline of the dominant kernel from profile_forward()."""
+    agg = profile_forward(model, x, reps)
     total_ms = sum(a["ms"] for a in agg.values())
     table = {}
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
         t = a["ms"] * 1e-3
-        table[k] = dict(share=round(a["ms"] / total_ms, 4), launches_per_fwd=a["launches"] // reps,
-                        avg_us=round(1e3 * a["ms"] / a["launches"], 2),
-                        tflops=round(a["flops"] / t / 1e12, 2), gbps=round(a["bytes"] / t / 1e9, 1))
+        tf, gb = a["flops"] / t / 1e12, a["bytes"] / t / 1e9
+        table[k] = dict(share=round(a["ms"] / total_ms, 4), launches_per_fwd=a["launches"], avg_us=round(1e3 * a["ms"] / a["launches"], 2),
+                        tflops=round(tf, 2), gbps=round(gb, 1), mfma_frac=round(tf / PEAK_BF16_TFLOPS, 4),
+                        hbm_frac=round(gb / PEAK_HBM_GBPS, 4))
     dom = max(agg, key=lambda k: agg[k]["ms"])
     a = agg[dom]
     if a["flops"] > 0:
@@ -110,42 +127,58 @@ def roofline_leg(model, x, reps=5):
         roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
                     frac=round(ach / PEAK_HBM_GBPS, 4), traffic=None,
                     bytes_per_launch=a["bytes"] / a["launches"], avg_launch_us=round(1e3 * a["ms"] / a["launches"], 2))
-    return roof, table, total_ms / reps
+    return roof, table, total_ms
 
 
-def cpu_baseline_leg(model, budget_s=12.0):
-    """The oracle (port of the reference's eval forward, fp32, torch CPU) on a bounded sample of the same workload."""
+def kernel_source_hash():
+    """sha256 over the kernel sources the shipped .so was built from: a PMC summary is only trusted for the sources it was
+    collected on (tools/prof_summary.py stores the same hash)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "tokenreduction_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "tokenreduction_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline_leg(model, budget_s=25.0):
+    """The oracle (port of the reference's eval forward, fp32, torch CPU) on a bounded sample of the same workload: SURVEY 8d's
+    protocol -- torch.set_num_threads(host cores available), 10 warm-up + 30 timed passes, median -- on a batch sized so that the
+    whole leg stays within ~budget_s seconds (the batch is stated in `sample`)."""
     import oracle
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     params = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     cfg = oracle.VitConfig(family="topk", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
                            keep_rate=list(KEEP_RATE), reduction_loc=list(REDUCTION_LOC))
-    bs = 32
-    x = torch.randn(bs, 3, 224, 224, generator=torch.Generator().manual_seed(1))
-    # torch's intra-op pool degrades badly when oversubscribed (256 threads: 45 s per pass on the GPU box), so pick
-    # the best of a few thread counts on a 4-image probe, then time the sample with it
-    best, cores = None, 1
-    for t in sorted({c for c in (8, 16, 32, 64, 128) if c <= avail} | {min(avail, 8)}):
-        torch.set_num_threads(t)
-        oracle.vit_forward(params, x[:4], cfg)
-        t0 = time.perf_counter()
-        oracle.vit_forward(params, x[:4], cfg)
-        dt = time.perf_counter() - t0
-        if best is None or dt < best:
-            best, cores = dt, t
-        if dt > 5.0:
+    x = torch.randn(32, 3, 224, 224, generator=torch.Generator().manual_seed(1))
+    # torch's intra-op pool degrades badly when oversubscribed (256 threads: 45 s per pass on the GPU box): nproc is the
+    # protocol's thread count, capped at the count that a 2-image probe shows is not slower than half of it
+    cores = avail
+    while cores > 8:
+        torch.set_num_threads(cores)
+        oracle.vit_forward(params, x[:2], cfg)
+        t0 = time.perf_counter(); oracle.vit_forward(params, x[:2], cfg); t_full = time.perf_counter() - t0
+        torch.set_num_threads(cores // 2)
+        oracle.vit_forward(params, x[:2], cfg)
+        t0 = time.perf_counter(); oracle.vit_forward(params, x[:2], cfg); t_half = time.perf_counter() - t0
+        if t_full <= t_half:
             break
+        cores //= 2
     torch.set_num_threads(cores)
-    oracle.vit_forward(params, x, cfg)            # warm-up
-    n, t0 = 0, time.perf_counter()
-    while True:
-        oracle.vit_forward(params, x, cfg)
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 40:
-            break
-    return dict(value=round(bs * n / el, 1), unit="images/s", cores=cores, kind="port",
-                sample=f"{n} forward passes of batch {bs} (same model/config, fp32 torch-CPU oracle), {el:.1f} s")
+    t0 = time.perf_counter(); oracle.vit_forward(params, x[:4], cfg); per_img = (time.perf_counter() - t0) / 4
+    bs = max(1, min(32, int(budget_s / 40.0 / max(per_img, 1e-4))))        # 10 + 30 passes within the budget
+    xs = x[:bs]
+    for _ in range(10):
+        oracle.vit_forward(params, xs, cfg)
+    times = []
+    for _ in range(30):
+        t0 = time.perf_counter()
+        oracle.vit_forward(params, xs, cfg)
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return dict(value=round(bs / med, 1), unit="images/s", cores=cores, kind="port",
+                sample=f"median of 30 timed forward passes (after 10 warm-up) of batch {bs} of the same model/config, fp32 torch-CPU "
+                       f"oracle, {cores} of {avail} host threads, {sum(times):.1f} s timed")
 
 
 def finetune_leg(name, keep_rate, loc, batch, device, dist, steps=8, warmup=3, img_size=224):
@@ -199,15 +232,19 @@ def timed_steps(step, steps, warmup, dist, sync, device):
 
 
 def pmc_traffic(kernel_label):
-    """HBM bytes per launch of `kernel_label` from the committed PMC summary (tools/prof_summary.py), or None."""
+    """HBM bytes per launch of `kernel_label` from the committed PMC summary (tools/prof_summary.py) -- only when that summary was
+    collected on the kernel sources this library was built from (source hash), else None with the reason."""
     import glob
     import re
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if not files:
         return None
     tbl = json.load(open(files[-1]))
-    epi = {"EPI_BF16": 0, "EPI_GELU_BF16": 1, "EPI_RESID_F32": 2, "EPI_F32": 3, "EPI_PATCH_F32": 4}
-    m = re.match(r"(\w+)<(\w+)>", kernel_label)
+    if tbl.get("_kernel_source_hash") != kernel_source_hash():
+        return dict(hbm_bytes_per_launch=None, source=os.path.basename(files[-1]),
+                    note="stale: collected on other kernel sources than the ones built here; re-run tools/prof_round.sh")
+    m = re.match(r"(\w+)<EPI_(\w+)>", kernel_label)
+    epi = {"BF16": 0, "GELU_BF16": 1, "RESID_F32": 2, "F32": 3, "PATCH_F32": 4}
     key = f"{m.group(1)}<{epi[m.group(2)]}>" if m and m.group(2) in epi else kernel_label
     v = tbl.get(key)
     return None if v is None else dict(hbm_bytes_per_launch=v["hbm_bytes_per_launch"], source=os.path.basename(files[-1]))
@@ -265,6 +302,11 @@ def main():
 
     el = timed_steps(step, a.steps, a.warmup, dist, torch.cuda.synchronize, dev)
     assert torch.isfinite(out[0]).all()
+    eager_ms = None
+    if rank == 0 and not a.no_extra:          # the same forward as plain launches (model.use_graph = False): what the graph replay saves
+        model.use_graph = False
+        eager_ms = 1e3 * timed_steps(step, a.steps, 2, None, torch.cuda.synchronize, dev) / a.steps
+        model.use_graph = True
 
     # fine-tune leg (all ranks take part: it contains the gradient collectives).  Extra key, outside the headline's timed region.
     finetune = None
@@ -283,6 +325,8 @@ def main():
             "config": {"workload": f"{MODEL} keep_rate=0.7 reduction_loc=3,6,9 batch={BATCH}/GPU 224x224 eval forward "
                                    f"(BASELINE.json configs[1])", "global_batch": BATCH * world,
                        "tokens_per_block": tokens, "gflop_per_image": round(gflop, 3), "parallelism": f"dp{world}"},
+            "launch_mode": "hipGraph replay of the executor's launch sequence",
+            "ms_per_step_plain_launches": None if eager_ms is None else round(eager_ms, 3),
             "model_tflops": round(ips * gflop / 1e3, 1),
             "model_mfma_frac": round(ips * gflop / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
         }
@@ -298,7 +342,7 @@ def main():
             roof["traffic"] = pmc_traffic(roof["kernel"])
             rec["roofline"] = roof
             rec["kernels"] = table
-            rec["stepwise_ms_per_step"] = round(step_ms, 3)
+            rec["profiled_ms_per_step"] = round(step_ms, 3)      # same executor, plain launches with an event after each
             # no-reduction DeiT-S through the same kernels: the baseline the north_star's speed-up is quoted against
             dense = build_model("deit_small_patch16_224_local", [1.0], [], dev)
             d_ips = quick_images_per_s(dense, x)

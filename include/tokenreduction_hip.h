@@ -45,6 +45,14 @@ typedef void* tr_stream_t; /* hipStream_t */
 int tr_version(void);
 const char* tr_last_error(void);
 
+/* Launch profiler: between tr_profile_begin(stream) and tr_profile_end, every launch this thread enqueues through the entry points
+ * below drops a HIP event on `stream`; tr_profile_end waits for the stream and returns, per launch group ("mark"), a label
+ * (48 chars), the milliseconds since the previous mark (kernel + its dependent-launch boundary), and the group's algorithmic
+ * FLOPs / bytes where the entry point states them (0 otherwise).  Returns the number of marks (only `max` are written).
+ * Not capturable in a hipGraph.  This is how bench.py times the executor kernel by kernel. */
+int tr_profile_begin(tr_stream_t s);
+int tr_profile_end(int max, char* labels, float* ms, double* flops, double* bytes);
+
 /* a1 (PatchEmbed, call site topk.py:181): unfold 16x16 patches.  img fp32 [B,C,H,W] ->
  * cols bf16 [B*(H/p)*(W/p), C*p*p], column order (c, iy, ix) = Conv2d weight.view(D,-1) order. */
 int tr_im2col_bf16(const float* img, uint16_t* cols, int B, int C, int H, int W, int patch, tr_stream_t s);

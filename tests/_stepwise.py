@@ -1,8 +1,8 @@
-"""Kernel-by-kernel forward through the per-op C-ABI entry points.
+"""TEST INFRASTRUCTURE: kernel-by-kernel forward through the per-op C-ABI entry points.
 
-Same launch sequence as the native executor (csrc/tr_vit.hip -> tr_vit_forward), but driven from Python
-so a caller can (a) time every launch with events on the launch stream (bench.py roofline leg) and
-(b) look at every intermediate (parity tests: op-boundary checks against the oracle).
+Same launch sequence as the native executor (csrc/tr_vit.hip -> tr_vit_forward), driven from Python so the parity tests can
+look at every intermediate (op-boundary checks against the oracle) and assert the executor's result bit for bit.  Not part of
+the product and not used for timing: bench.py times the executor itself through the library's launch profiler.
 HIP kernels only -- no CPU path.  Results are bit-identical to tr_vit_forward (same kernels, same order).
 """
 from __future__ import annotations
@@ -11,8 +11,8 @@ from typing import Callable, Dict, List, Optional
 
 import torch
 
-from . import ops
-from .models import VisionTransformer, _pad_cols, _pad_rows, _pad_vec
+from tokenreduction_amd import ops
+from tokenreduction_amd.models import VisionTransformer, _pad_cols, _pad_rows, _pad_vec
 
 
 class Trace:

@@ -204,3 +204,22 @@ def test_stage_schedules_match_the_oracle(family):
             want = oracle.sit_cluster_counts(cfg)              # sit / dpcknn / sinkhorn / kmedoids / patchmerger share the rule
         got = {i: k for i, k in enumerate(m._keep) if k}
         assert got == {int(k): int(v) for k, v in want.items() if v}, (family, kr, loc, got, want)
+
+
+@pytest.mark.parametrize("name", ["heuristic_micro_l2", "heuristic_small_linf"])
+def test_heuristic_masks_match_the_reference(name):
+    """Constructor-time geometry (heuristic.py:157-224), no GPU needed: the visible patch ids of every block in the reduction range
+    equal the reference's recorded Kept_Tokens_Abs, for the contiguous (linear radius ramp) and the listed-blocks variant."""
+    import numpy as np
+    from tests._params import GOLDEN_CASES
+    case = GOLDEN_CASES[name]
+    g = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    args = _args(keep_rate=list(case["keep_rate"]), reduction_loc=list(case["reduction_loc"]), heuristic_pattern=case["heuristic_pattern"],
+                 not_contiguous=case["not_contiguous"], min_radius=case.get("min_radius"))
+    m = tra.HeuristicVisionTransformer(img_size=224, patch_size=16, embed_dim=case["embed_dim"], depth=case["depth"],
+                                       num_heads=case["num_heads"], mlp_ratio=4, qkv_bias=True, num_classes=case["num_classes"], args=args)
+    keys = [k for k in g.files if k.startswith("keptabs_")]
+    assert sorted(int(k.split("_")[1]) for k in keys) == sorted(m.reduction_loc)
+    for k in keys:
+        blk = int(k.split("_")[1])
+        np.testing.assert_array_equal(m._block_mask(blk).nonzero(as_tuple=True)[0].numpy(), g[k][0])

@@ -67,7 +67,7 @@ def _overlap(a, b):
 
 @pytest.mark.parametrize("name", list(GOLDEN_CASES))
 def test_model_parity(golden_dir, name):
-    from tokenreduction_amd.stepwise import forward_stepwise
+    from tests._stepwise import forward_stepwise
     case = GOLDEN_CASES[name]
     g = np.load(os.path.join(golden_dir, name + ".npz"))
     model, params, cfg = build_model(case)
@@ -82,7 +82,7 @@ def test_model_parity(golden_dir, name):
     assert logits.shape == g["logits"].shape and torch.isfinite(logits).all()
 
     # (1) executor vs stepwise op sequence: bit identical
-    from tokenreduction_amd.stepwise import Trace
+    from tests._stepwise import Trace
     trace = Trace(keep=True)      # keep=True also makes the ATS leg return the cdf it sampled on
     l2, info = forward_stepwise(model, x.cuda(), trace)
     info["trace"] = trace
@@ -374,7 +374,7 @@ def test_full_size_batch_properties():
     """BASELINE configs[1] at its full size (DeiT-S Top-K kr 0.7, batch 256): size-independent properties --
     finite logits, every kept index in range and unique per image, descending-score order, batch independence."""
     import tokenreduction_amd as tra
-    from tokenreduction_amd.stepwise import forward_stepwise
+    from tests._stepwise import forward_stepwise
     args = types.SimpleNamespace(keep_rate=[0.7], reduction_loc=[3, 6, 9], viz_mode=True)
     model = tra.create_model("topk_small_patch16_224", args=args)
     case = GOLDEN_CASES["topk_small_kr07"]
@@ -445,7 +445,7 @@ def test_dyvit_teacher_returns_logits_and_normed_tokens():
 def test_tiny_width_predictor_modules(family):
     """DeiT-T (D = 192): the D/2 = 96-wide hidden layer of the DyViT predictor / SiT slimming MLP is packed zero-padded to 128 so
     the bf16 GEMMs keep K %% 64; results must not notice."""
-    from tokenreduction_amd.stepwise import forward_stepwise
+    from tests._stepwise import forward_stepwise
     case = dict(family=family, embed_dim=192, depth=3, num_heads=3, num_classes=16, keep_rate=[0.6], reduction_loc=[1, 2],
                 batch=2, wseed=901, xseed=902, qkv_gain=6.0)
     model, params, cfg = build_model(case)

@@ -49,6 +49,8 @@ class TrVitConfig(C.Structure):
 SIGNATURES = {
     "tr_version": (_i, []),
     "tr_last_error": (C.c_char_p, []),
+    "tr_profile_begin": (_i, [_vp]),
+    "tr_profile_end": (_i, [_i, _vp, _vp, _vp, _vp]),
     "tr_im2col_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tr_im2col_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tr_gemm_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

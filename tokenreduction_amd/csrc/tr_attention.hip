@@ -832,10 +832,15 @@ extern "C" int tr_attention_bf16(const uint16_t* qkv, uint16_t* out, float* cls_
              "tr_attention_bf16: column sums together with a key bias need N <= 608 (N=%d: K and V^T of one head must fit the LDS)", N);
   TR_REQUIRE(tr_aligned16(qkv) && tr_aligned16(out), TR_ERR_ALIGN, "tr_attention_bf16: pointers must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(s);
-  static const int flash_min = [] {            // development switch: smallest N that takes the online-softmax kernel
+  tr_prof_note(N <= 224 ? "attention_kernel" : "attention_flash_kernel", 4.0 * B * H * (double)N * N * 64, 2.0 * B * N * 4.0 * H * 64);
+#ifdef TR_ATT_LAB          // lab builds only (tools/attn_lab.py): smallest N that takes the online-softmax kernel, from the environment
+  static const int flash_min = [] {
     const char* e = getenv("TR_ATT_FLASH_MIN");
     return e ? atoi(e) : 225;
   }();
+#else
+  constexpr int flash_min = 225;   // N <= 224: whole score row in registers; beyond: online softmax over 128-key chunks
+#endif
   if (N >= flash_min && (colsum_part == nullptr || size == nullptr)) {
     const int nqg = ((N + 31) / 32 + 3) / 4;
     hipLaunchKernelGGL(attention_flash_kernel, dim3(B * H * nqg), dim3(256), 0, st, qkv, out, cls_rows, size, colsum_part, N, H, nqg);
@@ -855,8 +860,12 @@ extern "C" int tr_attention_bf16(const uint16_t* qkv, uint16_t* out, float* cls_
     const size_t lds = (size_t)nkb * 32 * 128 + (size_t)64 * (nkb * 64 + 16) + (size_t)nkb * 32 * 4;
     const void* fn = colsum_part ? reinterpret_cast<const void*>(attention_long_kernel<true>)
                                  : reinterpret_cast<const void*>(attention_long_kernel<false>);
-    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_attention_bf16: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+    static thread_local size_t reserved[2] = {0, 0};            // the attribute is sticky: set it only when a launch needs more
+    if (lds > reserved[colsum_part ? 1 : 0]) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_attention_bf16: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+      reserved[colsum_part ? 1 : 0] = lds;
+    }
     if (colsum_part)
       hipLaunchKernelGGL(attention_long_kernel<true>, dim3(B * H), dim3(256), lds, st, qkv, out, cls_rows, size, colsum_part, N, H, nkb);
     else

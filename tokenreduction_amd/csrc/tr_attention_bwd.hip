@@ -299,6 +299,7 @@ extern "C" int tr_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, 
   TR_REQUIRE(N <= 224, TR_ERR_SHAPE, "tr_attention_bwd_bf16: N=%d > 224 (training at 384^2 inputs is not built)", N);
   TR_REQUIRE(tr_aligned16(qkv) && tr_aligned16(dout) && tr_aligned16(dqkv), TR_ERR_ALIGN, "tr_attention_bwd_bf16: pointers must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(s);
+  tr_prof_note("attention_bwd_kernel", 10.0 * B * H * (double)N * N * 64, 2.0 * B * N * 8.0 * H * 64);
   switch ((N + 31) / 32) {
     case 1: launch_bwd<1>(qkv, dout, size, dcls, dqkv, B, N, H, st); break;
     case 2: launch_bwd<2>(qkv, dout, size, dcls, dqkv, B, N, H, st); break;

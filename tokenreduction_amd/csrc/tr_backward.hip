@@ -696,6 +696,7 @@ extern "C" int tr_wgrad_bf16(const uint16_t* dY, long ldy, int yskip, const uint
   const int sps = (nslab + S - 1) / S;
   S = (nslab + sps - 1) / sps;                 // every split owns at least one slab
   hipStream_t st = static_cast<hipStream_t>(s);
+  tr_prof_note("wgrad_kernel", 2.0 * M * N * K, 2.0 * ((double)M * N + (double)M * K) + 4.0 * S * N * K);
   hipLaunchKernelGGL(wgrad_kernel, dim3(tiles, S), dim3(256), 0, st, dY, ldy, yskip, X, ldx, ws, M, N, K, nNt, sps);
   TR_CHECK_LAUNCH("tr_wgrad_bf16");
   reduce_partials(ws, S, (size_t)N * K, dW, accumulate, st);
@@ -721,6 +722,7 @@ extern "C" int tr_colsum_bf16(const uint16_t* dY, long ldy, int yskip, float* db
   const int rps = (M + S - 1) / S;
   S = (M + rps - 1) / rps;
   hipStream_t st = static_cast<hipStream_t>(s);
+  tr_prof_note("colsum_kernel", 0.0, 2.0 * M * N);
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 511) / 512, S), dim3(256), 0, st, dY, ldy, yskip, ws, M, N, rps);
   TR_CHECK_LAUNCH("tr_colsum_bf16");
   reduce_partials(ws, S, (size_t)N, db, accumulate, st);
@@ -733,6 +735,7 @@ extern "C" int tr_gelu_bf16(const uint16_t* pre, uint16_t* h, size_t n, tr_strea
   TR_REQUIRE(n > 0 && n % 8 == 0, TR_ERR_SHAPE, "tr_gelu_bf16: element count must be a positive multiple of 8");
   TR_REQUIRE(tr_aligned16(pre) && tr_aligned16(h), TR_ERR_ALIGN, "tr_gelu_bf16: pointers must be 16-byte aligned");
   const size_t nch = n / 8;
+  tr_prof_note("gelu_fwd_kernel", 0.0, 4.0 * n);
   hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((nch + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(s), pre, h, nch);
   TR_CHECK_LAUNCH("tr_gelu_bf16");
   return TR_OK;
@@ -743,6 +746,7 @@ extern "C" int tr_gelu_bwd_bf16(const uint16_t* pre, uint16_t* dh, size_t n, tr_
   TR_REQUIRE(n > 0 && n % 8 == 0, TR_ERR_SHAPE, "tr_gelu_bwd_bf16: element count must be a positive multiple of 8");
   TR_REQUIRE(tr_aligned16(pre) && tr_aligned16(dh), TR_ERR_ALIGN, "tr_gelu_bwd_bf16: pointers must be 16-byte aligned");
   const size_t nch = n / 8;
+  tr_prof_note("gelu_bwd_kernel", 0.0, 6.0 * n);
   hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((nch + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(s), pre, dh, nch);
   TR_CHECK_LAUNCH("tr_gelu_bwd_bf16");
   return TR_OK;
@@ -771,6 +775,7 @@ extern "C" int tr_layernorm_bwd(const uint16_t* dy, const float* x, long ldx, co
                  tr_aligned16(ws) && tr_aligned16(g_fused),
              TR_ERR_ALIGN, "tr_layernorm_bwd: pointers must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(s);
+  tr_prof_note("ln_bwd_kernel", 0.0, (double)M * D * (2.0 + 4.0 + (g_in ? 4.0 : 0.0) + 4.0 + (gb_out ? 2.0 : 0.0)));
   TR_DISPATCH_NCH(D, hipLaunchKernelGGL((ln_bwd_kernel<NCH>), dim3(grid), dim3(256), 0, st, dy, x, ldx, gamma, g_in, ldgi, g_out, ldgo, gb_out, idx,
                                         K, n_in, n_out, g_fused, ws, M, D, eps));
   TR_CHECK_LAUNCH("tr_layernorm_bwd");

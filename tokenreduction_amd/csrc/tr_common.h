@@ -24,6 +24,15 @@ void tr_set_error(const char* fmt, ...);
     }                                      \
   } while (0)
 
+// Launch profiler (tr_profile_begin / tr_profile_end, csrc/tr_vit.hip): while a recording is active on this thread, every
+// TR_CHECK_LAUNCH drops a HIP event on the recording's stream, so consecutive marks bracket the launches of one entry point (the
+// event-bracketed duration: kernel + its dependent-launch boundary).  tr_prof_note() names the next mark and gives it the
+// algorithmic FLOPs / bytes of the launch; without a note the mark carries the entry point's name and zeros.  Inactive: one
+// thread-local load per launch.
+void tr_prof_mark(const char* label);
+void tr_prof_restart();
+void tr_prof_note(const char* label, double flops, double bytes);
+
 #define TR_CHECK_LAUNCH(name)                                                   \
   do {                                                                          \
     hipError_t e__ = hipGetLastError();                                         \
@@ -31,6 +40,7 @@ void tr_set_error(const char* fmt, ...);
       tr_set_error("%s: launch failed: %s", (name), hipGetErrorString(e__));    \
       return TR_ERR_LAUNCH;                                                     \
     }                                                                           \
+    tr_prof_mark(name);                                                         \
   } while (0)
 
 static inline bool tr_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

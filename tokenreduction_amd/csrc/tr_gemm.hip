@@ -686,6 +686,12 @@ extern "C" int tr_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* b
   if (epilogue == TR_EPI_RESID_F32 || epilogue == TR_EPI_PATCH_F32)
     TR_REQUIRE(N % 64 == 0, TR_ERR_SHAPE, "tr_gemm_bf16: residual/patch epilogues need N %% 64 == 0 (got %d)", N);
   hipStream_t st = static_cast<hipStream_t>(s);
+  {
+    static const char* const kname[5] = {"gemm_bf16_pc<EPI_BF16>", "gemm_bf16_pc<EPI_GELU_BF16>", "gemm_bf16_persistent<EPI_RESID_F32>",
+                                         "gemm_bf16_persistent<EPI_F32>", "gemm_bf16_persistent<EPI_PATCH_F32>"};
+    if (epilogue >= 0 && epilogue < 5)
+      tr_prof_note(kname[epilogue], 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K) + (double)esz * M * N);
+  }
   const int nMt = (M + PBM - 1) / PBM, nNt = (N + PBN - 1) / PBN;
   // one persistent workgroup per CU (all 160 KiB of LDS each); 256 CUs on MI355X.  A multiple of 8 keeps the XCD grouping.
   dim3 grid(256), block(512);

@@ -274,6 +274,7 @@ static int layernorm_impl(bool f32, const float* x, long ldx, float* x_out, long
   TR_REQUIRE(tr_aligned16(x) && tr_aligned16(gamma) && tr_aligned16(beta) && tr_aligned16(y), TR_ERR_ALIGN,
              "tr_layernorm: pointers must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(s);
+  tr_prof_note("layernorm_kernel", 0.0, (double)M * D * (f32 ? 4.0 : 2.0) + (delta ? (double)M * D * (8.0 + (f32 ? 4.0 : 2.0)) : (double)M * D * 4.0));
 #ifndef TR_LN_NO_HALF
   if (!f32 && D == 384) {
     hipLaunchKernelGGL(layernorm_half_kernel<3>, dim3((M + 7) / 8), dim3(256), 0, st, x, ldx, x_out, ldxo, static_cast<const uint16_t*>(delta), ldd,
@@ -323,6 +324,8 @@ static int gather_layernorm_impl(bool f32, const float* x, const void* delta, co
                  tr_aligned16(delta),
              TR_ERR_ALIGN, "tr_gather_layernorm: pointers must be 16-byte aligned");
   const int rblocks = compl_idx != nullptr ? (N_out - 1 + 3) / 4 + 1 : (N_out + 3) / 4;   // + one block per image for the fused token
+  tr_prof_note("gather_layernorm_kernel", 0.0, (double)B * N_out * D * ((delta ? 6.0 : 4.0) + (x_out ? 4.0 : 0.0) + (f32 ? 4.0 : 2.0)) +
+                                                    (compl_idx ? (double)B * (N - 1 - K) * D * (delta ? 6.0 : 4.0) : 0.0));
   hipStream_t st = static_cast<hipStream_t>(s);
   if (f32)
     TR_DISPATCH_NCH(D, hipLaunchKernelGGL((gather_layernorm_kernel<true, NCH>), dim3(B * rblocks), dim3(256), 0, st, x, delta, idx, compl_idx,
@@ -392,6 +395,7 @@ static int im2col_impl(bool f32, const float* img, void* cols, int B, int C, int
              "tr_im2col: need patch %% 8 == 0 and H,W multiples of patch (H=%d W=%d patch=%d)", H, W, patch);
   TR_REQUIRE(tr_aligned16(img) && tr_aligned16(cols), TR_ERR_ALIGN, "tr_im2col: pointers must be 16-byte aligned");
   const long total = (long)B * C * H * W / 8;
+  tr_prof_note("im2col_kernel", 0.0, (double)B * C * H * W * (f32 ? 8.0 : 6.0));
   hipStream_t st = static_cast<hipStream_t>(s);
   if (f32) hipLaunchKernelGGL(im2col_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, img, cols, B, C, H, W, patch, total);
   else hipLaunchKernelGGL(im2col_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, img, cols, B, C, H, W, patch, total);

@@ -10,6 +10,7 @@
 // Token counts are static per (config) -- topk.py:56 int(ratio*196) -- so every buffer size is known up front.
 #include <stdarg.h>
 #include <string.h>
+#include <vector>
 #include "tr_common.h"
 #include "tr_plan.h"
 
@@ -23,6 +24,89 @@ void tr_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* tr_last_error(void) { return g_err; }
+
+// ---- launch profiler (see tr_common.h) ---------------------------------------------------------------------------------
+namespace {
+struct ProfRec { char label[48]; double flops, bytes; };
+struct Prof {
+  bool on = false;
+  hipStream_t st = nullptr;
+  std::vector<hipEvent_t> ev;       // ev[0] = begin, ev[i+1] = after mark i
+  std::vector<ProfRec> recs;
+  size_t used = 0;
+  bool noted = false;
+  ProfRec note;
+};
+thread_local Prof g_prof;
+}  // namespace
+
+void tr_prof_note(const char* label, double flops, double bytes) {
+  if (!g_prof.on) return;
+  snprintf(g_prof.note.label, sizeof(g_prof.note.label), "%s", label);
+  g_prof.note.flops = flops;
+  g_prof.note.bytes = bytes;
+  g_prof.noted = true;
+}
+
+void tr_prof_mark(const char* label) {
+  Prof& p = g_prof;
+  if (!p.on) return;
+  ProfRec r;
+  if (p.noted) r = p.note;
+  else { snprintf(r.label, sizeof(r.label), "%s", label); r.flops = 0; r.bytes = 0; }
+  p.noted = false;
+  if (p.used + 1 >= p.ev.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    p.ev.push_back(e);
+  }
+  (void)hipEventRecord(p.ev[p.used + 1], p.st);
+  ++p.used;
+  p.recs.push_back(r);
+}
+
+// Called at the top of the executors: when a recording is active and nothing has been marked yet, the opening event is taken again
+// HERE, so the first mark does not include the host time between tr_profile_begin and the executor's first launch.
+void tr_prof_restart() {
+  Prof& p = g_prof;
+  if (p.on && p.used == 0) (void)hipEventRecord(p.ev[0], p.st);
+}
+
+// Start recording the launches this thread enqueues on stream s (must not be capturing).
+extern "C" int tr_profile_begin(tr_stream_t s) {
+  Prof& p = g_prof;
+  if (p.ev.empty()) {
+    hipEvent_t e;
+    TR_REQUIRE(hipEventCreate(&e) == hipSuccess, TR_ERR_LAUNCH, "tr_profile_begin: cannot create an event");
+    p.ev.push_back(e);
+  }
+  p.st = static_cast<hipStream_t>(s);
+  p.recs.clear();
+  p.used = 0;
+  p.noted = false;
+  TR_REQUIRE(hipEventRecord(p.ev[0], p.st) == hipSuccess, TR_ERR_LAUNCH, "tr_profile_begin: event record failed");
+  p.on = true;
+  return TR_OK;
+}
+
+// Stop, wait for the stream, and return up to `max` marks: label (48 chars each), ms since the previous mark, FLOPs, bytes.
+// Returns the number of marks recorded (may exceed max; only max are written), or < 0 on error.
+extern "C" int tr_profile_end(int max, char* labels, float* ms, double* flops, double* bytes) {
+  Prof& p = g_prof;
+  TR_REQUIRE(p.on, TR_ERR_CONFIG, "tr_profile_end: no recording is active");
+  p.on = false;
+  TR_REQUIRE(hipStreamSynchronize(p.st) == hipSuccess, TR_ERR_LAUNCH, "tr_profile_end: stream synchronize failed");
+  const int n = (int)p.recs.size();
+  for (int i = 0; i < n && i < max; ++i) {
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, p.ev[i], p.ev[i + 1]);
+    if (labels) memcpy(labels + (size_t)i * 48, p.recs[i].label, 48);
+    if (ms) ms[i] = t;
+    if (flops) flops[i] = p.recs[i].flops;
+    if (bytes) bytes[i] = p.recs[i].bytes;
+  }
+  return n;
+}
 extern "C" int tr_version(void) { return 100; }
 
 namespace {
@@ -136,6 +220,7 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
   TR_REQUIRE(workspace_bytes >= p.total, TR_ERR_SHAPE, "tr_vit_forward: workspace too small (%zu < %zu)", workspace_bytes, p.total);
   TR_REQUIRE(tr_aligned16(workspace), TR_ERR_ALIGN, "tr_vit_forward: workspace must be 16-byte aligned");
 
+  tr_prof_restart();
   char* ws = static_cast<char*>(workspace);
   float* x = reinterpret_cast<float*>(ws + p.off_x0);
   float* x_alt = reinterpret_cast<float*>(ws + p.off_x1);

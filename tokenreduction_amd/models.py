@@ -1021,52 +1021,45 @@ class HeuristicVisionTransformer(VisionTransformer):
             self.reduction_loc = [idx for idx in range(self.start_stage, self.end_stage + 1)]
             self.distances, self.threshold, self.P = self.prep_pattern()
 
-    def _distance_grid(self):
-        P = int(self.patch_embed.num_patches ** 0.5)
-        xs = torch.linspace(-P // 2, P // 2, steps=P)
-        ys = torch.linspace(-P // 2, P // 2, steps=P)
-        x, y = torch.meshgrid(xs, ys, indexing="ij")
-        pat = self.heuristic_pattern.lower()
-        if pat == "l1":
-            z = torch.abs(x) + torch.abs(y)
-        elif pat == "l2":
-            z = torch.sqrt(x * x + y * y)
-        elif pat == "linf":
-            z = torch.max(torch.abs(x), torch.abs(y))
-        else:
+    # ---- constructor-time geometry: one radius per block, a patch is visible while its distance to the grid centre is within it
+    _NORMS = {"l1": lambda u, v: u.abs() + v.abs(), "l2": lambda u, v: (u * u + v * v).sqrt(), "linf": lambda u, v: torch.maximum(u.abs(), v.abs())}
+
+    def _patch_radii(self):
+        """[g, g] distance of every patch to the centre of the patch grid, in the norm named by --heuristic_pattern.  The grid
+        coordinates are the reference's (g evenly spaced values from floor(-g/2) to floor(g/2), heuristic.py:158-162) so the
+        radii -- and with them every mask -- are the same floats."""
+        norm = self._NORMS.get(str(self.heuristic_pattern).lower())
+        if norm is None:
             raise ValueError(f"heuristic_pattern {self.heuristic_pattern!r}: expected l1 | l2 | linf")
-        return z, P
+        g = int(self.patch_embed.num_patches ** 0.5)
+        axis = torch.linspace((-g) // 2, g // 2, steps=g)
+        return norm(axis[:, None].expand(g, g), axis[None, :].expand(g, g)), g
 
     def prep_pattern(self):
-        """heuristic.py:157-181: linear radius schedule over the contiguous reduction range."""
-        z, P = self._distance_grid()
+        """Contiguous range (heuristic.py:157-181): the radius shrinks linearly from the corner distance (everything visible) one
+        block before the range to `min_radius` one block after it, and stays constant outside."""
+        radii, g = self._patch_radii()
         if self.min_radius is None or self.min_radius <= 0:
-            self.min_radius = z[P // 2, P // 2]
-        steps = self.end_stage - self.start_stage + 3
-        threshold = torch.linspace(float(z[0, 0]), float(self.min_radius), steps)
-        threshold = torch.nn.functional.pad(threshold, (max(self.start_stage - 1, 0), 0), value=float(z[0, 0]))
-        threshold = torch.nn.functional.pad(threshold, (0, max(self.depth - self.end_stage - 1, 0)), value=float(threshold[-1]))
-        return z, threshold, P
+            self.min_radius = radii[g // 2, g // 2]
+        corner = float(radii[0, 0])
+        n_stage = self.end_stage - self.start_stage + 1
+        ramp = torch.linspace(corner, float(self.min_radius), n_stage + 2)            # ramp[0] = all visible, ramp[-1] = min_radius
+        pos = (torch.arange(self.depth + 2) - (self.start_stage - 1)).clamp(0, n_stage + 1)
+        return radii, ramp[pos], g
 
     def prep_pattern_stage_subset(self, num_tokens):
-        """heuristic.py:184-224: per stage, the radius whose visible-token count is closest to the target."""
-        z, P = self._distance_grid()
-        unique_distances = torch.unique(z)
-        within = [torch.sum(z <= u).item() for u in unique_distances]
-        closest_thresholds = []
-        for num_token in num_tokens:
-            closest, thr = np.inf, None
-            for idx, t in enumerate(within):
-                if np.abs(num_token - t) < closest:
-                    closest, thr = np.abs(num_token - t), unique_distances[idx].item()
-            closest_thresholds.append(thr)
-        closest_thresholds = [unique_distances[-1].item()] + closest_thresholds
-        threshold, counter = [], 0
-        for idx in range(self.depth):
-            if idx in self.reduction_loc:
-                counter += 1
-            threshold.append(torch.ones((P, P)) * closest_thresholds[counter])
-        return z, threshold, P
+        """Listed blocks only (heuristic.py:184-224): each stage takes, among the distinct radii of the grid, the one whose disc
+        covers a patch count closest to its target (the smaller radius on a tie); a block uses the radius of the last stage at
+        or before it, and everything is visible before the first one."""
+        radii, g = self._patch_radii()
+        levels = torch.unique(radii)                                                   # ascending
+        covered = (radii.reshape(1, -1) <= levels.reshape(-1, 1)).sum(dim=1)            # patches inside each candidate disc
+        targets = torch.as_tensor(list(num_tokens), dtype=covered.dtype)
+        pick = (covered.reshape(1, -1) - targets.reshape(-1, 1)).abs().argmin(dim=1)    # first minimum = smallest radius
+        table = torch.cat([levels[-1:], levels[pick]])
+        is_stage = torch.zeros(self.depth, dtype=torch.long)
+        is_stage[torch.as_tensor(sorted(self.reduction_loc), dtype=torch.long)] = 1
+        return radii, table[torch.cumsum(is_stage, dim=0)], g
 
     def get_reduction_count(self):
         return self.reduction_loc

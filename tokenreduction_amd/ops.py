@@ -13,8 +13,15 @@ from ._lib import (TR_EPI_BF16, TR_EPI_F32, TR_EPI_GELU_BF16, TR_EPI_PATCH_F32, 
                    TR_EPI_RESID_F32)
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream(t: torch.Tensor = None) -> int:
+    """The launch stream: the current stream of the tensor's device (not of whatever device happens to be current)."""
+    return torch.cuda.current_stream(None if t is None else t.device).cuda_stream
+
+
+def _same_device(*tensors):
+    devs = {t.device for t in tensors if t is not None}
+    if len(devs) > 1:
+        raise ValueError(f"operands live on different devices: {sorted(str(d) for d in devs)}")
 
 
 def _dev(t: torch.Tensor, dtype, name: str) -> int:
@@ -50,6 +57,13 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, epilogue: int, ou
     """nn.Linear on MFMA: epilogue(a[M,K] @ w[N,K]^T + bias).  For RESID/PATCH `out` is required (updated in place)."""
     M, K = a.shape
     N = w.shape[0]
+    if w.dim() != 2 or w.shape[1] != K:
+        raise ValueError(f"gemm: weight is {tuple(w.shape)}, expected [N, {K}] for an activation of {tuple(a.shape)}")
+    if bias.numel() != N:
+        raise ValueError(f"gemm: bias has {bias.numel()} entries for {N} output columns")
+    _same_device(a, w, bias, out, aux)
+    if out is not None and epilogue not in (TR_EPI_PATCH_F32,) and tuple(out.shape) != (M, N):
+        raise ValueError(f"gemm: out is {tuple(out.shape)}, expected {(M, N)}")
     if out is None:
         if epilogue in (TR_EPI_BF16, TR_EPI_GELU_BF16):
             out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
@@ -59,7 +73,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, epilogue: int, ou
             raise ValueError("this epilogue needs an explicit `out`")
     odt = torch.bfloat16 if epilogue in (TR_EPI_BF16, TR_EPI_GELU_BF16) else torch.float32
     _lib.check(_lib.load().tr_gemm_bf16(_dev(a, torch.bfloat16, "a"), _dev(w, torch.bfloat16, "w"), _dev(bias, torch.float32, "bias"),
-                                        _dev(out, odt, "out"), _opt(aux, torch.float32, "aux"), aux_i, M, N, K, epilogue, _stream()),
+                                        _dev(out, odt, "out"), _opt(aux, torch.float32, "aux"), aux_i, M, N, K, epilogue, _stream(a)),
                "tr_gemm_bf16")
     return out
 
@@ -126,6 +140,13 @@ def gemm_f32(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, epilogue: int
     """nn.Linear in the reference's arithmetic (fp32 operands): epilogue TR_EPI_F32 | TR_EPI_GELU_BF16 (GELU, fp32 out) | PATCH."""
     M, K = a.shape
     N = w.shape[0]
+    if w.dim() != 2 or w.shape[1] != K:
+        raise ValueError(f"gemm: weight is {tuple(w.shape)}, expected [N, {K}] for an activation of {tuple(a.shape)}")
+    if bias.numel() != N:
+        raise ValueError(f"gemm: bias has {bias.numel()} entries for {N} output columns")
+    _same_device(a, w, bias, out, aux)
+    if out is not None and epilogue not in (TR_EPI_PATCH_F32,) and tuple(out.shape) != (M, N):
+        raise ValueError(f"gemm: out is {tuple(out.shape)}, expected {(M, N)}")
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     _lib.check(_lib.load().tr_gemm_f32(_dev(a, torch.float32, "a"), _dev(w, torch.float32, "w"), _dev(bias, torch.float32, "bias"),

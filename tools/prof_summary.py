@@ -46,6 +46,10 @@ for k in sorted(set(f) | set(w)):
     wb = 1024.0 * w[k][0] / max(w[k][1], 1)
     out[k] = dict(launches_profiled=f[k][1], fetch_bytes_per_launch=round(fb), write_bytes_per_launch=round(wb),
                   hbm_bytes_per_launch=round(fb + wb))
+sys.path.insert(0, ".")
+import bench  # noqa: E402
+out["_kernel_source_hash"] = bench.kernel_source_hash()          # bench.py only trusts this file for the sources it was collected on
 json.dump(out, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
+out.pop("_kernel_source_hash")
 for k, v in out.items():
     print(f"{k:45s} fetch {v['fetch_bytes_per_launch']/1e6:9.2f} MB  write {v['write_bytes_per_launch']/1e6:9.2f} MB  (avg per launch, {v['launches_profiled']} launches)")
