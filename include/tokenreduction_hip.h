@@ -105,7 +105,7 @@ int tr_attention_f32(const float* qkv, float* out, float* cls_rows, const float*
 /* a11 (forward only): Policy_Attention.forward dyvit.py:53-67 with softmax_with_policy :39-51 -- the attention of DyViT's
  * TRAINING forward, where pruned tokens stay in the sequence and are masked by policy fp32 [B,N] of 1/0:
  *   attn = (exp(s - max_k s) * pol + eps/N) / (sum_k exp(s - max_k s) * pol + eps),  pol[q][k] = policy[k], 1 for k == q,
- * eps = 1e-6.  N <= 224 (bf16) / 256 (fp32).  Not used by the eval executor; the training path is not built. */
+ * eps = 1e-6.  N <= 224 (bf16) / 256 (fp32).  Used by the DyViT training executor (backward: tr_attention_policy_bwd_bf16). */
 int tr_attention_policy_bf16(const uint16_t* qkv, uint16_t* out, const float* policy, int B, int N, int H, tr_stream_t s);
 int tr_attention_policy_f32(const float* qkv, float* out, const float* policy, int B, int N, int H, tr_stream_t s);
 
@@ -271,6 +271,23 @@ int tr_tome_merge_bwd(const float* g_merged, const float* size_in, const float* 
                       const int32_t* src_idx, const int32_t* dst_idx, int32_t* inv_map, float* g_out, uint16_t* gb_out, int B, int N,
                       int r, int D, tr_stream_t s);
 int tr_f32_to_bf16(const float* src, uint16_t* dst, size_t n, tr_stream_t s);
+int tr_reduce_partials_f32(const float* part, int S, size_t count, float* dst, int accumulate, tr_stream_t s);   /* dst (+)= sum_s part[s] */
+/* ---- DyViT training pieces (csrc/tr_dyvit_train.hip, csrc/tr_attention_bwd.hip): see the file headers.  policy / prev / outputs are
+ * fp32 [B,N] with entry 0 = the CLS token (always 1); gumbel fp32 [B,N-1,2]. */
+int tr_pool_policy(uint16_t* h, const float* policy, int B, int N, int C, float eps, tr_stream_t s);
+int tr_pool_policy_bwd(const uint16_t* dcat, const uint16_t* pre0, const uint16_t* cat, const float* policy, uint16_t* dh, float* dpolicy,
+                       int B, int N, int C, tr_stream_t s);
+int tr_dyvit_decide(const uint16_t* h2, int ldh, const float* w, const float* bias, const float* gumbel, const float* prev,
+                    float* policy_out, float* ysoft0, float* sm0, float* hard0, int B, int N, int C, tr_stream_t s);
+size_t tr_dyvit_decide_bwd_workspace_floats(int B, int N, int C);
+int tr_dyvit_decide_bwd(const float* dkeep, const float* prev, const float* hard0, const float* ysoft0, const float* sm0,
+                        const uint16_t* h2, int ldh, const float* w, uint16_t* dh2, float* dprev, float* dw, float* db, int accumulate,
+                        float* ws, size_t ws_floats, int B, int N, int C, tr_stream_t s);
+int tr_attention_policy_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, const float* policy, uint16_t* dqkv, float* dpol_part, int B,
+                                 int N, int H, tr_stream_t s);
+int tr_head_sum(const float* part, float* dst, int B, int H, int N, tr_stream_t s);
+int tr_fill_f32(float* p, float v, size_t n, tr_stream_t s);
+int tr_add_patch_rows(float* dst, const float* src, int B, int N, tr_stream_t s);
 /* DPC-KNN CTM backward (merge_tokens dpcknn.py:103-132 + the score Linear, CTM.forward :155-157): see csrc/tr_backward.hip.
  * ws: (B+1)*(D+4) floats.  tr_ats_scatter: backward of ATS's row sampling (ats.py:86,157): valid sampled rows t go back to row
  * ids[b,t] of the zero-filled full tensors (g fp32 [B,Ks,D] -> [B,N,D]; d(attn @ v) bf16 likewise). */
@@ -374,7 +391,11 @@ int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w, const floa
                    const float* noise_in, float* features_out, int* tokens_out, int B, tr_stream_t s);
 
 /* ---- training: forward that keeps its activations + backward executor (csrc/tr_vit.hip, csrc/tr_train.hip) ----------------------
- * engine.py:50-76: `output = model(samples)` in train mode, `loss.backward()`.  Families: DeiT, Top-K, EViT, ToMe (bf16, N <= 224).
+ * engine.py:50-76: `output = model(samples)` in train mode, `loss.backward()`.  Families: DeiT, Top-K, EViT, ToMe, DPC-KNN, ATS, DyViT
+ * (bf16, N <= 224).  DyViT (dyvit.py:221-229): noise_in = the Gumbel noise of every stage, fp32 [B,P,2] back to back (torch's
+ * -log(Exp(1)) draws); the stages' policies stay on the tape (tr_vit_tape_layout); features_out (nullable) fp32 [B,N0,D]: the final
+ * norm of every row (the distillation features, dyvit.py:252-258); tr_vit_backward takes dpred fp32 [stages,B,P] (gradient wrt each
+ * stage's out_pred_prob) and dfeat fp32 [B,N0,D] (gradient wrt features_out), both nullable.
  * tr_vit_forward_train: as tr_vit_forward, and every activation the backward needs is written to `tape` (tr_vit_tape_bytes(cfg, B)
  *   bytes, caller-owned; 0 = family / precision without a training path).  Dropout / DropPath rates are 0 (the caller applies none).
  * tr_vit_backward: dlogits fp32 [B,classes] -> parameter gradients.  `w` = the forward's weights; `wt` = same struct with the block
@@ -386,15 +407,15 @@ int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w, const floa
  *   the backward: reduce one range's gradients on a second stream while the next range runs. */
 size_t tr_vit_tape_bytes(const tr_vit_config* cfg, int B);
 int tr_vit_forward_train(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits, void* workspace,
-                         size_t workspace_bytes, void* tape, size_t tape_bytes, const float* noise_in, int* tokens_out, int B,
-                         tr_stream_t s);
+                         size_t workspace_bytes, void* tape, size_t tape_bytes, const float* noise_in, float* features_out,
+                         int* tokens_out, int B, tr_stream_t s);
 /* Byte offsets of block blk's tape slots (x0,x1,xn1,qkv,ao,dattn,x2,xn2,pre,h,idx,idx2,scores,size) followed by its token counts
  * (entering, in attention, in the MLP) and its reduction count: lets a host read the decisions of a training forward. */
 int tr_vit_tape_layout(const tr_vit_config* cfg, int B, int blk, size_t* out18);
 size_t tr_vit_backward_workspace_bytes(const tr_vit_config* cfg, int B);
 int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w, const tr_vit_weights* wt, const tr_vit_weights* grads,
-                    const float* dlogits, const void* tape, size_t tape_bytes, void* workspace, size_t workspace_bytes, int accumulate,
-                    int blk_hi, int blk_lo, int B, tr_stream_t s);
+                    const float* dlogits, const float* dpred, const float* dfeat, const void* tape, size_t tape_bytes, void* workspace,
+                    size_t workspace_bytes, int accumulate, int blk_hi, int blk_lo, int B, tr_stream_t s);
 
 #ifdef __cplusplus
 }

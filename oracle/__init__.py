@@ -21,7 +21,8 @@ from .vit import (  # noqa: F401
     tome_schedule, tome_block_r, tome_attention, tome_match, tome_merge, tome_assignment, tome_block_forward, tome_forward,
 )
 from .prune_before import (  # noqa: F401
-    dyvit_keep_counts, dyvit_predictor_scores, dyvit_select, dyvit_forward, dyvit_softmax_with_policy, sit_cluster_counts, sit_slim, sit_forward, patchmerger_merge, patchmerger_forward,
+    dyvit_keep_counts, dyvit_predictor_scores, dyvit_select, dyvit_forward, dyvit_softmax_with_policy, dyvit_train_forward,
+    dyvit_predictor_logprob, dyvit_policy_block, sit_cluster_counts, sit_slim, sit_forward, patchmerger_merge, patchmerger_forward,
 )
 from .cluster import (  # noqa: F401
     dpcknn_cluster_counts, dpcknn_distances, dpcknn_scores, dpcknn_assign, dpcknn_cluster, dpcknn_merge, dpcknn_ctm,

@@ -105,6 +105,72 @@ def dyvit_softmax_with_policy(attn: Tensor, policy: Tensor, eps: float = 1e-6) -
     return attn.type_as(max_att)
 
 
+def dyvit_predictor_logprob(x_sp: Tensor, policy: Tensor, p: Dict[str, Tensor], j: int, precision: str = "fp32", eps: float = 1e-6) -> Tensor:
+    """PredictorLG.forward dyvit.py:113-119 with a real policy [B,P,1] (training): log_softmax over the two classes, [B,P,2]."""
+    pre = f"score_predictor.{j}."
+    h = layer_norm(x_sp, p[pre + "in_conv.0.weight"], p[pre + "in_conv.0.bias"], LN_EPS_DEFAULT, precision)
+    h = _r(gelu_erf(_r(h @ _r(p[pre + "in_conv.1.weight"], precision).t() + p[pre + "in_conv.1.bias"], precision)), precision)
+    C = h.shape[-1]
+    local_x = h[:, :, :C // 2]
+    global_x = _r((h[:, :, C // 2:] * policy).sum(dim=1, keepdim=True) / torch.sum(policy, dim=1, keepdim=True) + eps, precision)
+    h = torch.cat([local_x, global_x.expand(-1, h.shape[1], -1)], dim=-1)
+    h = _r(gelu_erf(_r(h @ _r(p[pre + "out_conv.0.weight"], precision).t() + p[pre + "out_conv.0.bias"], precision)), precision)
+    h = _r(gelu_erf(_r(h @ _r(p[pre + "out_conv.2.weight"], precision).t() + p[pre + "out_conv.2.bias"], precision)), precision)
+    return torch.log_softmax(h @ p[pre + "out_conv.4.weight"].t() + p[pre + "out_conv.4.bias"], dim=-1)
+
+
+def dyvit_policy_block(x: Tensor, policy: Tensor, p: Dict[str, Tensor], i: int, cfg: VitConfig, precision: str = "fp32") -> Tensor:
+    """Block_DyVIT.forward dyvit.py:85-88 over Policy_Attention.forward :53-67 (policy [B,N,1])."""
+    pre = f"blocks.{i}."
+    B, N, D = x.shape
+    H = cfg.num_heads
+    xn = layer_norm(x, p[pre + "norm1.weight"], p[pre + "norm1.bias"], cfg.ln_eps, precision)
+    qkv = _r(xn @ _r(p[pre + "attn.qkv.weight"], precision).t() + p[pre + "attn.qkv.bias"], precision)
+    q, k, v = qkv.reshape(B, N, 3, H, D // H).permute(2, 0, 3, 1, 4).unbind(0)
+    attn = dyvit_softmax_with_policy((q @ k.transpose(-2, -1)) * ((D // H) ** -0.5), policy)
+    o = _r((_r(attn, precision) @ v).transpose(1, 2).reshape(B, N, D), precision)
+    x = x + _r(o @ _r(p[pre + "attn.proj.weight"], precision).t() + p[pre + "attn.proj.bias"], precision)
+    xn2 = layer_norm(x, p[pre + "norm2.weight"], p[pre + "norm2.bias"], cfg.ln_eps, precision)
+    from .vit import mlp
+    return x + mlp(xn2, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"], p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"], precision)
+
+
+def dyvit_train_forward(params: Dict[str, Tensor], x: Tensor, cfg: VitConfig, gumbels: Dict[int, Tensor], precision: str = "fp32",
+                        forced_hard: Optional[Dict[int, Tensor]] = None):
+    """DynamicVisionTransformer.forward dyvit.py:203-261 in TRAINING mode: nothing is pruned; at each stage the predictor's
+    log-probabilities go through F.gumbel_softmax(hard=True) (torch/nn/functional.py: y_soft = softmax(logits + gumbels);
+    y_hard = one_hot(argmax); ret = y_hard - y_soft.detach() + y_soft) with the Gumbel noise `gumbels[stage]` [B,P,2] given (the
+    reference draws it), the first class times prev_decision is the keep decision, [1, decision] the policy of this and every later
+    block.  forced_hard[stage] [B,P] (tests): take this one-hot value instead of the argmax (the straight-through gradient stays).
+    Returns (logits, features [B,P,D], prev_decision [B,P,1], out_pred_prob list of [B,P]).  Differentiable (not under no_grad)."""
+    p = params
+    tok = patch_embed(x, p["patch_embed.proj.weight"], p["patch_embed.proj.bias"], cfg.patch_size, precision)
+    h = embed_tokens(tok, p["cls_token"], p["pos_embed"])
+    B, P = h.shape[0], cfg.num_patches
+    stages = sorted(dyvit_keep_counts(cfg))
+    prev = torch.ones(B, P, 1)
+    policy = torch.ones(B, P + 1, 1)
+    out_pred = []
+    for i in range(cfg.depth):
+        if i in stages:
+            j = stages.index(i)
+            score = dyvit_predictor_logprob(h[:, 1:], prev, p, j, precision)
+            y_soft = torch.softmax(score + gumbels[j], dim=-1)
+            if forced_hard is None:
+                hard0 = (torch.argmax(y_soft, dim=-1) == 0).to(y_soft.dtype)
+            else:
+                hard0 = forced_hard[j].to(y_soft.dtype)
+            y0 = (hard0 - y_soft[..., 0].detach() + y_soft[..., 0]).unsqueeze(-1)          # straight-through
+            keep = y0 * prev
+            out_pred.append(keep.reshape(B, P))
+            policy = torch.cat([torch.ones(B, 1, 1), keep], dim=1)
+            prev = keep
+        h = dyvit_policy_block(h, policy, p, i, cfg, precision)
+    hn = layer_norm(h, p["norm.weight"], p["norm.bias"], cfg.ln_eps)
+    logits = _r(hn[:, 0], precision) @ _r(p["head.weight"], precision).t() + p["head.bias"]
+    return logits, hn[:, 1:], prev.detach(), out_pred
+
+
 # =========================================================================================== SiT
 def sit_cluster_counts(cfg: VitConfig) -> Dict[int, int]:
     """sit.py:77-83: one keep_rate -> int(P0 * kr**(i+1)); several -> ABSOLUTE counts used verbatim."""

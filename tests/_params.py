@@ -142,6 +142,12 @@ GOLDEN_CASES = {
     "dyvit_small_kr07": dict(family="dyvit", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
                              keep_rate=[0.7], reduction_loc=[3, 6, 9], batch=2, wseed=103, xseed=104,
                              qkv_gain=4.0, factory="dyvit_small_patch16_224"),
+    # DyViT TRAINING (dyvit.py:221-229, 257-261) with the distillation outputs: gradient fixtures only (grad_<name>.npz)
+    "dyvit_micro_train": dict(family="dyvit", embed_dim=128, depth=4, num_heads=2, num_classes=16, dyvit_distill=True, train_only=True,
+                              keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=105, xseed=106, qkv_gain=6.0),
+    "dyvit_small_train": dict(family="dyvit", embed_dim=384, depth=12, num_heads=6, num_classes=1000, dyvit_distill=True, train_only=True,
+                              keep_rate=[0.7], reduction_loc=[3, 6, 9], batch=2, wseed=107, xseed=108,
+                              qkv_gain=4.0, factory="dyvit_small_patch16_224"),
     # DPC-KNN (models/dpcknn.py): density-peak clustering + weighted merge BEFORE the block (noise recorded in the fixture)
     "dpcknn_micro": dict(family="dpcknn", embed_dim=128, depth=4, num_heads=2, num_classes=16,
                          keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=121, xseed=122, qkv_gain=6.0),
@@ -226,7 +232,32 @@ GOLDEN_CASES = {
 # cross-entropy criterion) in train mode on the golden case's weights / images, labels from grad_labels().  Too large to store
 # whole (22 M values at DeiT-S), so per parameter: the L2 norm and <= 512 evenly strided entries (grad_sample_index).
 GRAD_CASES = ["deit_micro", "topk_micro", "evit_micro", "tome_micro", "dpcknn_micro", "dpcknn_micro_equal", "ats_micro", "topk_small_kr07",
-              "evit_small_kr07", "tome_small_r16", "deit_base", "dpcknn_base_kr05", "ats_base_kr05"]
+              "evit_small_kr07", "tome_small_r16", "deit_base", "dpcknn_base_kr05", "ats_base_kr05", "dyvit_micro_train", "dyvit_small_train"]
+
+
+def dyvit_token_ratio(case: dict):
+    r = list(case["keep_rate"])
+    return [r[0] ** (i + 1) for i in range(len(case["reduction_loc"]))] if len(r) == 1 else r
+
+
+def dyvit_train_loss(outputs, labels, case: dict):
+    """The loss of the DyViT gradient fixtures: cross-entropy + 2 x the keep-ratio loss of losses.py:113-118 + 0.5 x a token MSE
+    against seeded pseudo-teacher tokens on the kept positions (the shape of losses.py:134-151 with mse_token) -- so that all
+    four training outputs (logits, features, prev_decision mask, out_pred_prob) carry gradient."""
+    pred, token_pred, mask, out_pred = outputs
+    loss = torch.nn.functional.cross_entropy(pred, labels)
+    ratio = dyvit_token_ratio(case)
+    pl = 0.0
+    for i, score in enumerate(out_pred):
+        pl = pl + ((score.mean(1) - ratio[i]) ** 2).mean()
+    loss = loss + 2.0 * pl / len(out_pred)
+    B, N, C = token_pred.shape
+    rng = np.random.default_rng(case["xseed"] + 11)
+    target = torch.from_numpy(rng.standard_normal((B, N, C)).astype(np.float32)).to(token_pred.device)
+    keep = (mask.reshape(B * N) > 0.5)
+    if keep.any():
+        loss = loss + 0.5 * torch.pow(token_pred.reshape(B * N, C)[keep] - target.reshape(B * N, C)[keep], 2).mean()
+    return loss
 
 
 def grad_labels(case: dict):
@@ -248,6 +279,11 @@ def oracle_param_grads(case: dict, forced=None, precision: str = "fp32", noise=N
     x = make_images(case["batch"], case.get("img_size", 224), case["xseed"])
     fam = case["family"]
     with torch.enable_grad():          # the undecorated functions: the public ones run under torch.no_grad()
+        if fam == "dyvit":             # training forward: noise = {stage: gumbel [B,P,2]}, forced = {stage: hard decision [B,P]}
+            outs = oracle.dyvit_train_forward(leaves, x, cfg, noise, precision, forced)
+            loss = dyvit_train_loss(outs, grad_labels(case), case)
+            loss.backward()
+            return loss.item(), outs[0].detach(), {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
         if fam == "tome":
             logits = oracle.tome_forward.__wrapped__(leaves, x, cfg, precision, False, forced)
         elif fam == "dpcknn":

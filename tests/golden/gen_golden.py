@@ -49,7 +49,7 @@ from models.patchmerger import PatchMergerVisionTransformer  # noqa: E402
 from models.heuristic import HeuristicVisionTransformer  # noqa: E402
 
 from tests._params import (GOLDEN_CASES, GRAD_CASES, make_params, make_stage_params, make_images, case_config,  # noqa: E402
-                            grad_labels, grad_sample_index)
+                            grad_labels, grad_sample_index, dyvit_train_loss)
 
 CLASSES = {"topk": TopKVisionTransformer, "evit": EfficientVisionTransformer, "deit": DeitViz, "tome": ToMeVisionTransformer,
            "dyvit": DynamicVisionTransformer, "sit": SelfSlimmedVisionTransformer, "dpcknn": DPCKNNVisionTransformer, "ats": ATSVisionTransformer, "sinkhorn": SinkhornVisionTransformer, "kmedoids": KMedoidsVisionTransformer, "patchmerger": PatchMergerVisionTransformer, "heuristic": HeuristicVisionTransformer}
@@ -142,7 +142,7 @@ class RandSpy:
 
 def build_reference(case):
     args = types.SimpleNamespace(keep_rate=list(case["keep_rate"]), reduction_loc=list(case["reduction_loc"]),
-                                 viz_mode=True, dyvit_distill=False, k_neighbors=5,
+                                 viz_mode=True, dyvit_distill=bool(case.get("dyvit_distill", False)), k_neighbors=5,
                                  equal_weight=bool(case.get("equal_weight", False)), sinkhorn_eps=1.0, cluster_iters=3,
                                  heuristic_pattern=case.get("heuristic_pattern", "l2"),
                                  not_contiguous=bool(case.get("not_contiguous", False)), min_radius=case.get("min_radius"))
@@ -153,6 +153,8 @@ def build_reference(case):
         else:
             kw = dict(img_size=case.get("img_size", 224), patch_size=16, embed_dim=case["embed_dim"], depth=case["depth"], num_heads=case["num_heads"],
                       mlp_ratio=4, qkv_bias=True, num_classes=case["num_classes"], args=args)
+            if case.get("dyvit_distill"):
+                kw["dyvit_distillation"] = True
             m = CLASSES[case["family"]](**kw)
     m.viz_mode = True
     cfg = types.SimpleNamespace(embed_dim=case["embed_dim"], depth=case["depth"], num_heads=case["num_heads"],
@@ -311,19 +313,41 @@ def run_grad_case(name, case):
         ats_ids.append(out_[2].detach().clone())
         return out_
     ref_ats.AdaptiveTokenSampling.forward = ats_spy
+    gumbels = []
+    orig_gs = torch.nn.functional.gumbel_softmax
+
+    def gs_spy(logits, tau=1, hard=False, eps=1e-10, dim=-1):       # torch/nn/functional.py gumbel_softmax, with the noise recorded
+        g_ = -torch.empty_like(logits, memory_format=torch.legacy_contiguous_format).exponential_().log()
+        gumbels.append(g_.clone())
+        y_soft = ((logits + g_) / tau).softmax(dim)
+        if not hard:
+            return y_soft
+        index = y_soft.max(dim, keepdim=True)[1]
+        y_hard = torch.zeros_like(logits, memory_format=torch.legacy_contiguous_format).scatter_(dim, index, 1.0)
+        return y_hard - y_soft.detach() + y_soft
+    torch.nn.functional.gumbel_softmax = gs_spy
     try:
         with RandSpy() as rspy:
             out = m(x)
     finally:
         ref_ats.AdaptiveTokenSampling.forward = orig_ats
+        torch.nn.functional.gumbel_softmax = orig_gs
     logits = out[0] if isinstance(out, (tuple, list)) else out
-    loss = torch.nn.functional.cross_entropy(logits, labels)
+    if case["family"] == "dyvit":
+        loss = dyvit_train_loss(out, labels, case)
+    else:
+        loss = torch.nn.functional.cross_entropy(logits, labels)
     loss.backward()
     rec = {"logits": logits.detach().numpy(), "loss": np.array(loss.item(), dtype=np.float64), "labels": labels.numpy()}
     for n, r in enumerate(rspy.calls):
         rec[f"rand_{n}"] = r.numpy().astype(np.float32)
     for n, t in enumerate(ats_ids):
         rec[f"atsids_{n}"] = t.numpy().astype(np.int64)
+    for n, t in enumerate(gumbels):
+        rec[f"gumbel_{n}"] = t.numpy().astype(np.float32)
+    if case["family"] == "dyvit":
+        for n, t in enumerate(out[3]):
+            rec[f"pred_{n}"] = t.detach().numpy().astype(np.float32)      # the hard keep decisions of each stage [B,P]
     names = []
     for pname, p in m.named_parameters():
         g = p.grad if p.grad is not None else torch.zeros_like(p)
@@ -347,7 +371,7 @@ if __name__ == "__main__":
     if only and all(o == "grads" or o.startswith("grad_") for o in only):
         sys.exit(0)
     for name, case in GOLDEN_CASES.items():
-        if only and name not in only:
+        if (only and name not in only) or case.get("train_only"):
             continue
         run_case(name, case)
     if not only or "ops" in only:

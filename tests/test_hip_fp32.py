@@ -85,7 +85,7 @@ def _check_ats_fp32(name, case, g, logits, viz, kept_keys):
         assert d < (0.5 if case.get("img_size", 224) > 224 else 0.2), d
 
 
-@pytest.mark.parametrize("name", list(GOLDEN_CASES))
+@pytest.mark.parametrize("name", [n for n, c in GOLDEN_CASES.items() if not c.get("train_only")])
 def test_model_fp32_matches_reference_golden(golden_dir, name):
     case = GOLDEN_CASES[name]
     g = np.load(os.path.join(golden_dir, name + ".npz"))

@@ -34,7 +34,7 @@ FAM = {"deit": "VisionTransformer", "topk": "TopKVisionTransformer", "evit": "Ef
 def build_model(case):
     import tokenreduction_amd as tra
     args = types.SimpleNamespace(keep_rate=list(case["keep_rate"]), reduction_loc=list(case["reduction_loc"]), viz_mode=True,
-                                 dyvit_distill=False, k_neighbors=5, equal_weight=bool(case.get("equal_weight", False)),
+                                 dyvit_distill=bool(case.get("dyvit_distill", False)), k_neighbors=5, equal_weight=bool(case.get("equal_weight", False)),
                                  sinkhorn_eps=1.0, cluster_iters=3, heuristic_pattern=case.get("heuristic_pattern", "l2"),
                                  not_contiguous=bool(case.get("not_contiguous", False)), min_radius=case.get("min_radius"))
     if "factory" in case:
@@ -43,6 +43,9 @@ def build_model(case):
                              drop_path_rate=0.0, drop_block_rate=None, img_size=224, args=args)
     else:
         cls = getattr(tra, FAM[case["family"]])
+        if case.get("dyvit_distill"):
+            from functools import partial
+            cls = partial(cls, dyvit_distillation=True)
         m = cls(img_size=case.get("img_size", 224), patch_size=16, embed_dim=case["embed_dim"], depth=case["depth"], num_heads=case["num_heads"], mlp_ratio=4,
                 qkv_bias=True, num_classes=case["num_classes"], args=args)
     cfg, params = case_params(case)
@@ -65,7 +68,7 @@ def _overlap(a, b):
     return float(np.mean([len(set(x.tolist()) & set(y.tolist())) / len(x) for x, y in zip(a, b)]))
 
 
-@pytest.mark.parametrize("name", list(GOLDEN_CASES))
+@pytest.mark.parametrize("name", [n for n, c in GOLDEN_CASES.items() if not c.get("train_only")])
 def test_model_parity(golden_dir, name):
     from tests._stepwise import forward_stepwise
     case = GOLDEN_CASES[name]

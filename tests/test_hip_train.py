@@ -38,6 +38,10 @@ def _need_gpu():
 
 def _noise(case, golden_dir):
     """DPC-KNN: the reference's recorded density draws {blk: [B,P_in]} (gradient fixture), else None."""
+    if case["family"] == "dyvit":
+        name = [n for n, c in GOLDEN_CASES.items() if c is case][0]
+        g = np.load(os.path.join(golden_dir, f"grad_{name}.npz"))
+        return {n: torch.from_numpy(g[f"gumbel_{n}"]) for n in range(len(case["reduction_loc"]))}
     if case["family"] != "dpcknn":
         return None
     import oracle
@@ -52,11 +56,19 @@ def _train_step(case, noise=None):
     model, params, cfg = build_model(case)
     model.viz_mode = False
     model.train()
-    if noise is not None:
+    if noise is not None and case["family"] == "dyvit":
+        model.gumbel_noise = noise                          # the reference's Gumbel draws, stage by stage
+    elif noise is not None:
         model.density_noise = noise
     x = make_images(case["batch"], case.get("img_size", 224), case["xseed"]).cuda()
-    logits = model(x)
-    loss = torch.nn.functional.cross_entropy(logits, grad_labels(case).cuda())
+    out = model(x)
+    if case["family"] == "dyvit":
+        from tests._params import dyvit_train_loss
+        logits = out[0]
+        loss = dyvit_train_loss(out, grad_labels(case).cuda(), case)
+    else:
+        logits = out
+        loss = torch.nn.functional.cross_entropy(logits, grad_labels(case).cuda())
     loss.backward()
     return model, logits.detach().cpu(), loss.item(), training.train_decisions(model)
 
@@ -71,6 +83,8 @@ def test_gradients_match_the_oracle_on_the_device_decisions(golden_dir, name):
     noise = _noise(case, golden_dir)
     model, logits, loss, decisions = _train_step(case, noise)
     forced = {blk: (tuple(t.cpu() for t in d) if isinstance(d, tuple) else d.cpu()) for blk, d in decisions.items()}
+    if case["family"] == "dyvit":          # the oracle indexes DyViT's stages 0..S-1
+        forced = {j: forced[blk] for j, blk in enumerate(sorted(forced))}
     o_loss, o_logits, o_grads = oracle_param_grads(case, forced=forced or None, precision="bf16", noise=noise)
     rl = _rel(logits, o_logits)
     print(f"\n[{name}] loss {loss:.5f} (oracle {o_loss:.5f}); logits rel L2 {rl:.3e}")
@@ -198,3 +212,29 @@ def test_gradient_reducer_on_rccl_world1():
     finally:
         model._grad_reducer = None
         dist.destroy_process_group()
+
+
+def test_dyvit_train_return_contract():
+    """dyvit.py:257-261: training returns (logits, out_pred_prob) or, with the DyViT distillation scheme, (logits, features [B,P,D],
+    prev_decision.detach() [B,P,1], out_pred_prob: one [B,P] 0/1 tensor per stage, non-increasing: a dropped token stays dropped)."""
+    from tests._params import dyvit_train_loss
+    for distill in (False, True):
+        case = dict(GOLDEN_CASES["dyvit_micro_train"], dyvit_distill=distill)
+        model, params, cfg = build_model(case)
+        model.viz_mode = False
+        x = make_images(case["batch"], 224, case["xseed"]).cuda()
+        out = model.train()(x)
+        B, P, D = case["batch"], 196, case["embed_dim"]
+        assert isinstance(out, tuple) and len(out) == (4 if distill else 2)
+        preds = out[-1]
+        assert len(preds) == 3 and all(p.shape == (B, P) and set(p.unique().tolist()) <= {0.0, 1.0} for p in preds)
+        assert all(bool((b <= a).all()) for a, b in zip(preds, preds[1:]))
+        assert out[0].shape == (B, case["num_classes"]) and out[0].requires_grad
+        if distill:
+            assert out[1].shape == (B, P, D) and out[2].shape == (B, P, 1) and not out[2].requires_grad
+            assert torch.equal(out[2].squeeze(-1), preds[-1].detach())
+            dyvit_train_loss(out, grad_labels(case).cuda(), case).backward()
+            assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+        # eval mode still prunes for real (dyvit.py:230-238)
+        le = model.eval()(x)
+        assert le.shape == (B, case["num_classes"]) and model._last_tokens[-1] == int(196 * 0.7 ** 3) + 1

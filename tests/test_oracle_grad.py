@@ -14,7 +14,7 @@ import torch
 
 from tests._params import GOLDEN_CASES, GRAD_CASES, grad_sample_index, oracle_param_grads
 
-CPU_CASES = [n for n in GRAD_CASES if GOLDEN_CASES[n]["embed_dim"] <= 128] + ["topk_small_kr07", "dpcknn_base_kr05", "ats_base_kr05"]
+CPU_CASES = [n for n in GRAD_CASES if GOLDEN_CASES[n]["embed_dim"] <= 128] + ["topk_small_kr07", "dpcknn_base_kr05", "ats_base_kr05", "dyvit_small_train"]
 
 
 def fixture_inputs(case, g):
@@ -29,6 +29,8 @@ def fixture_inputs(case, g):
         noise = {blk: torch.from_numpy(g[f"rand_{n}"]) for n, blk in enumerate(sorted(dpcknn_cluster_counts(cfg)))}
     if case["family"] == "ats":
         forced = {blk: torch.from_numpy(g[f"atsids_{n}"]) for n, blk in enumerate(sorted(b for b, c in ats_sample_counts(cfg).items() if c))}
+    if case["family"] == "dyvit":      # the Gumbel noise the reference drew, stage by stage (F.gumbel_softmax, dyvit.py:224)
+        noise = {n: torch.from_numpy(g[f"gumbel_{n}"]) for n in range(len(case["reduction_loc"]))}
     return forced, noise
 
 

@@ -35,10 +35,15 @@ __device__ __forceinline__ int qswz(int row, int ch) { return row * 128 + ((ch ^
 // [64 rows][256 bf16] image, 512-B rows
 __device__ __forceinline__ int pswz(int row, int ch) { return row * 512 + ((ch ^ ((row & 15) ^ ((0 - (row & 1)) & 14))) << 4); }
 
-template <int NKB, bool BIAS>
+// POLICY (DyViT training, Policy_Attention.softmax_with_policy dyvit.py:39-51): `size` carries the keep policy [B,N] of 1/0,
+//   e = exp(s - max), a = e * pi (pi[q][k] = policy[k], 1 on the diagonal), p = (a + eps/N) / (sum a + eps), eps = 1e-6;
+//   with w = dp - sum_k p_k dp_k:  ds = w * a / (sum a + eps),  d policy[k] += w * e / (sum a + eps) over all queries q != k and all
+//   heads (the straight-through Gumbel sample upstream makes the policy differentiable, dyvit.py:223-224).  The per-key sums are
+//   LDS float atomics (order varies run to run at the 1e-7 level), written per (image, head) to dpol_part [B,H,N].
+template <int NKB, bool BIAS, bool POLICY>
 __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dO,
                                                                const float* __restrict__ size, const float* __restrict__ dcls,
-                                                               uint16_t* __restrict__ dqkv, int N, int H) {
+                                                               uint16_t* __restrict__ dqkv, float* __restrict__ dpol_part, int N, int H) {
   constexpr int NP = NKB * 32;       // padded key count
   constexpr int NT = NKB * 2;        // 16-key tiles
   constexpr int KT_W = (NT + 3) / 4; // key tiles a wave accumulates dK / dV for
@@ -49,7 +54,7 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const uint16_t* _
   __shared__ __attribute__((aligned(16))) unsigned char sP[64 * 512];
   __shared__ __attribute__((aligned(16))) unsigned char sDS[64 * 512];
   __shared__ __attribute__((aligned(16))) float sLB[NP];     // log2(size[key]) (ToMe / key masks), 0 without sizes
-  __shared__ __attribute__((aligned(16))) float sDC[NP];     // d cls_attn[key] / H (EViT), 0 otherwise
+  __shared__ __attribute__((aligned(16))) float sDC[NP];     // d cls_attn[key] / H (EViT), 0 otherwise; POLICY: the d policy[key] sums
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
@@ -79,8 +84,13 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const uint16_t* _
       *reinterpret_cast<uint4*>(sV + qswz(key, ch)) = vreg[it];
     }
     for (int key = tid; key < NP; key += 256) {
-      sLB[key] = (BIAS && key < N) ? __builtin_amdgcn_logf(size[(size_t)b * N + key]) : 0.f;     // v_log_f32 = log2
-      sDC[key] = (dcls != nullptr && key < N) ? dcls[(size_t)b * N + key] / (float)H : 0.f;
+      if (POLICY) {
+        sLB[key] = key < N ? size[(size_t)b * N + key] : 0.f;
+        sDC[key] = 0.f;
+      } else {
+        sLB[key] = (BIAS && key < N) ? __builtin_amdgcn_logf(size[(size_t)b * N + key]) : 0.f;     // v_log_f32 = log2
+        sDC[key] = (dcls != nullptr && key < N) ? dcls[(size_t)b * N + key] / (float)H : 0.f;
+      }
     }
   }
 
@@ -152,7 +162,7 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const uint16_t* _
       const float lbv[4] = {lb.x, lb.y, lb.z, lb.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float t = sacc[jt][r] * c_exp + lbv[r];
+        float t = POLICY ? sacc[jt][r] * c_exp : sacc[jt][r] * c_exp + lbv[r];
         if (16 * jt + 4 * g + r >= N) t = -INFINITY;
         sacc[jt][r] = t;
         mx = fmaxf(mx, t);
@@ -163,26 +173,39 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const uint16_t* _
     if (mx == -INFINITY) mx = 0.f;                      // every key masked: all weights 0 (as the forward)
     float l = 0.f;
 #pragma unroll
-    for (int jt = 0; jt < NT; ++jt)
+    for (int jt = 0; jt < NT; ++jt) {
+      const float4 lb = *reinterpret_cast<const float4*>(&sLB[16 * jt + 4 * g]);
+      const float lbv[4] = {lb.x, lb.y, lb.z, lb.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float pe = __builtin_amdgcn_exp2f(sacc[jt][r] - mx);
-        sacc[jt][r] = pe;
-        l += pe;
+        sacc[jt][r] = pe;                                 // POLICY: e (the policy is applied below, e itself is needed for d policy)
+        l += POLICY ? pe * ((16 * jt + 4 * g + r == iq) ? 1.0f : lbv[r]) : pe;
       }
+    }
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
-    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    const float inv = POLICY ? 1.0f / (l + 1e-6f) : (l > 0.f ? 1.0f / l : 0.f);
+    const float padd = POLICY ? 1e-6f / (float)N : 0.f;
     float dl = 0.f;
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) {
       const float4 dc = *reinterpret_cast<const float4*>(&sDC[16 * jt + 4 * g]);
       const float dcv[4] = {dc.x, dc.y, dc.z, dc.w};
+      const float4 lb = *reinterpret_cast<const float4*>(&sLB[16 * jt + 4 * g]);
+      const float lbv[4] = {lb.x, lb.y, lb.z, lb.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float pn = sacc[jt][r] * inv;
-        sacc[jt][r] = pn;
-        if (iq == 0) dpacc[jt][r] += dcv[r];             // EViT: d cls_attn reaches the CLS query's row (key 0 carries 0)
+        const int key = 16 * jt + 4 * g + r;
+        float pn;
+        if (POLICY) {
+          const float pi = key == iq ? 1.0f : lbv[r];
+          pn = key < N ? (sacc[jt][r] * pi + padd) * inv : 0.f;
+        } else {
+          pn = sacc[jt][r] * inv;
+          sacc[jt][r] = pn;
+          if (iq == 0) dpacc[jt][r] += dcv[r];           // EViT: d cls_attn reaches the CLS query's row (key 0 carries 0)
+        }
         dl += pn * dpacc[jt][r];
       }
     }
@@ -190,13 +213,29 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const uint16_t* _
     dl += __shfl_xor(dl, 32, 64);
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) {
+      const float4 lb = *reinterpret_cast<const float4*>(&sLB[16 * jt + 4 * g]);
+      const float lbv[4] = {lb.x, lb.y, lb.z, lb.w};
+      float pv[4], dsv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = 16 * jt + 4 * g + r;
+        const float w = dpacc[jt][r] - dl;
+        if (POLICY) {
+          const float pi = key == iq ? 1.0f : lbv[r];
+          const float en = sacc[jt][r] * inv;             // e / (sum a + eps)
+          pv[r] = key < N ? en * pi + padd * inv : 0.f;
+          dsv[r] = w * en * pi * 0.125f;
+          if (key != iq && key < N && iq < N) atomicAdd(&sDC[key], w * en);
+        } else {
+          pv[r] = sacc[jt][r];
+          dsv[r] = sacc[jt][r] * w * 0.125f;
+        }
+      }
       uint2 pp, ds;
-      const float d0 = sacc[jt][0] * (dpacc[jt][0] - dl) * 0.125f, d1 = sacc[jt][1] * (dpacc[jt][1] - dl) * 0.125f;
-      const float d2 = sacc[jt][2] * (dpacc[jt][2] - dl) * 0.125f, d3 = sacc[jt][3] * (dpacc[jt][3] - dl) * 0.125f;
-      pp.x = pack_bf16x2(sacc[jt][0], sacc[jt][1]);
-      pp.y = pack_bf16x2(sacc[jt][2], sacc[jt][3]);
-      ds.x = pack_bf16x2(d0, d1);
-      ds.y = pack_bf16x2(d2, d3);
+      pp.x = pack_bf16x2(pv[0], pv[1]);
+      pp.y = pack_bf16x2(pv[2], pv[3]);
+      ds.x = pack_bf16x2(dsv[0], dsv[1]);
+      ds.y = pack_bf16x2(dsv[2], dsv[3]);
       const int off = pswz(il, 2 * jt + (g >> 1)) + 8 * (g & 1);     // keys 16jt + 4g .. +3 of row il
       *reinterpret_cast<uint2*>(sP + off) = pp;
       *reinterpret_cast<uint2*>(sDS + off) = ds;
@@ -256,6 +295,10 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const uint16_t* _
       }
     }
   }
+  if (POLICY) {
+    __syncthreads();
+    for (int key = tid; key < N; key += 256) dpol_part[((size_t)b * H + h) * N + key] = sDC[key];
+  }
   // ---- dK, dV rows: accumulator (t, d): rows d-index 16d + 4g + r, column key 16*(wave + 4t) + li
 #pragma unroll
   for (int t = 0; t < KT_W; ++t) {
@@ -278,13 +321,28 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const uint16_t* _
 }
 
 template <int NKB>
-int launch_bwd(const uint16_t* qkv, const uint16_t* dO, const float* size, const float* dcls, uint16_t* dqkv, int B, int N, int H,
-               hipStream_t st) {
-  if (size != nullptr)
-    hipLaunchKernelGGL((attention_bwd_kernel<NKB, true>), dim3(B * H), dim3(256), 0, st, qkv, dO, size, dcls, dqkv, N, H);
+int launch_bwd(const uint16_t* qkv, const uint16_t* dO, const float* size, const float* dcls, uint16_t* dqkv, float* dpol_part, int B, int N,
+               int H, hipStream_t st) {
+  if (dpol_part != nullptr)
+    hipLaunchKernelGGL((attention_bwd_kernel<NKB, false, true>), dim3(B * H), dim3(256), 0, st, qkv, dO, size, dcls, dqkv, dpol_part, N, H);
+  else if (size != nullptr)
+    hipLaunchKernelGGL((attention_bwd_kernel<NKB, true, false>), dim3(B * H), dim3(256), 0, st, qkv, dO, size, dcls, dqkv, dpol_part, N, H);
   else
-    hipLaunchKernelGGL((attention_bwd_kernel<NKB, false>), dim3(B * H), dim3(256), 0, st, qkv, dO, size, dcls, dqkv, N, H);
+    hipLaunchKernelGGL((attention_bwd_kernel<NKB, false, false>), dim3(B * H), dim3(256), 0, st, qkv, dO, size, dcls, dqkv, dpol_part, N, H);
   return 0;
+}
+
+int dispatch_bwd(const uint16_t* qkv, const uint16_t* dO, const float* size, const float* dcls, uint16_t* dqkv, float* dpol_part, int B, int N,
+                 int H, hipStream_t st) {
+  switch ((N + 31) / 32) {
+    case 1: return launch_bwd<1>(qkv, dO, size, dcls, dqkv, dpol_part, B, N, H, st);
+    case 2: return launch_bwd<2>(qkv, dO, size, dcls, dqkv, dpol_part, B, N, H, st);
+    case 3: return launch_bwd<3>(qkv, dO, size, dcls, dqkv, dpol_part, B, N, H, st);
+    case 4: return launch_bwd<4>(qkv, dO, size, dcls, dqkv, dpol_part, B, N, H, st);
+    case 5: return launch_bwd<5>(qkv, dO, size, dcls, dqkv, dpol_part, B, N, H, st);
+    case 6: return launch_bwd<6>(qkv, dO, size, dcls, dqkv, dpol_part, B, N, H, st);
+    default: return launch_bwd<7>(qkv, dO, size, dcls, dqkv, dpol_part, B, N, H, st);
+  }
 }
 
 }  // namespace
@@ -300,15 +358,21 @@ extern "C" int tr_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, 
   TR_REQUIRE(tr_aligned16(qkv) && tr_aligned16(dout) && tr_aligned16(dqkv), TR_ERR_ALIGN, "tr_attention_bwd_bf16: pointers must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(s);
   tr_prof_note("attention_bwd_kernel", 10.0 * B * H * (double)N * N * 64, 2.0 * B * N * 8.0 * H * 64);
-  switch ((N + 31) / 32) {
-    case 1: launch_bwd<1>(qkv, dout, size, dcls, dqkv, B, N, H, st); break;
-    case 2: launch_bwd<2>(qkv, dout, size, dcls, dqkv, B, N, H, st); break;
-    case 3: launch_bwd<3>(qkv, dout, size, dcls, dqkv, B, N, H, st); break;
-    case 4: launch_bwd<4>(qkv, dout, size, dcls, dqkv, B, N, H, st); break;
-    case 5: launch_bwd<5>(qkv, dout, size, dcls, dqkv, B, N, H, st); break;
-    case 6: launch_bwd<6>(qkv, dout, size, dcls, dqkv, B, N, H, st); break;
-    default: launch_bwd<7>(qkv, dout, size, dcls, dqkv, B, N, H, st); break;
-  }
+  dispatch_bwd(qkv, dout, size, dcls, dqkv, nullptr, B, N, H, st);
   TR_CHECK_LAUNCH("tr_attention_bwd_bf16");
+  return TR_OK;
+}
+
+// DyViT training: backward of tr_attention_policy_bf16.  policy fp32 [B,N] of 1/0 (the forward's); dpol_part fp32 [B,H,N]: per head,
+// the gradient wrt policy[key] summed over the queries (sum the heads with tr_head_sum).
+extern "C" int tr_attention_policy_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, const float* policy, uint16_t* dqkv, float* dpol_part,
+                                            int B, int N, int H, tr_stream_t s) {
+  TR_REQUIRE(qkv && dout && policy && dqkv && dpol_part, TR_ERR_NULL, "tr_attention_policy_bwd_bf16: null pointer");
+  TR_REQUIRE(B > 0 && H > 0 && N >= 1 && N <= 224, TR_ERR_SHAPE, "tr_attention_policy_bwd_bf16: need 1 <= N <= 224 (N=%d)", N);
+  TR_REQUIRE(tr_aligned16(qkv) && tr_aligned16(dout) && tr_aligned16(dqkv), TR_ERR_ALIGN, "tr_attention_policy_bwd_bf16: pointers must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(s);
+  tr_prof_note("attention_bwd_kernel<policy>", 10.0 * B * H * (double)N * N * 64, 2.0 * B * N * 8.0 * H * 64);
+  dispatch_bwd(qkv, dout, policy, nullptr, dqkv, dpol_part, B, N, H, st);
+  TR_CHECK_LAUNCH("tr_attention_policy_bwd_bf16");
   return TR_OK;
 }

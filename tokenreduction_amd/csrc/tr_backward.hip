@@ -882,3 +882,11 @@ extern "C" int tr_ats_scatter(const float* g, const uint16_t* dao_s, const int32
   TR_CHECK_LAUNCH("tr_ats_scatter");
   return TR_OK;
 }
+
+// dst[e] = (accumulate ? dst[e] : 0) + sum_{s < S} part[s][e]: the deterministic second stage of the two-stage reductions
+extern "C" int tr_reduce_partials_f32(const float* part, int S, size_t count, float* dst, int accumulate, tr_stream_t s) {
+  TR_REQUIRE(part && dst && S >= 1 && count >= 1, TR_ERR_NULL, "tr_reduce_partials_f32: bad arguments");
+  reduce_partials(part, S, count, dst, accumulate, static_cast<hipStream_t>(s));
+  TR_CHECK_LAUNCH("tr_reduce_partials_f32");
+  return TR_OK;
+}

@@ -11,7 +11,7 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 // families whose training path (saved activations + backward) is built
 inline bool trainable_family(int family) {
   return family == TR_FAMILY_DEIT || family == TR_FAMILY_TOPK || family == TR_FAMILY_EVIT || family == TR_FAMILY_TOME ||
-         family == TR_FAMILY_DPCKNN || family == TR_FAMILY_ATS;
+         family == TR_FAMILY_DPCKNN || family == TR_FAMILY_ATS || family == TR_FAMILY_DYVIT;
 }
 
 // tokens (incl. CLS) entering block i, inside its attention, and inside its MLP: the rules of tr_vit_forward
@@ -31,7 +31,12 @@ inline bool make_token_plan(const tr_vit_config* c, TokenPlan* t) {
     t->kk[i] = 0;
     const int f = c->family;
     const bool pre = f == TR_FAMILY_DPCKNN || f == TR_FAMILY_KMEDOIDS || f == TR_FAMILY_PATCHMERGER || f == TR_FAMILY_SINKHORN ||
-                     f == TR_FAMILY_DYVIT || f == TR_FAMILY_SIT;
+                     f == TR_FAMILY_SIT;
+    if (f == TR_FAMILY_DYVIT && c->keep[i] > 0) {
+      // DyViT TRAINS without removing tokens (dyvit.py:223-229: policy masks instead); kk marks the predictor stages
+      if (c->keep[i] > N - 1) return false;
+      t->kk[i] = c->keep[i];
+    }
     if (pre && c->keep[i] > 0) {
       if (c->keep[i] > N - 1) return false;
       t->kk[i] = c->keep[i];
@@ -79,7 +84,19 @@ struct BlockTape {
   size_t idx2;    // int32 [B, N0]        complement ids / cluster assignment
   size_t scores;  // fp32 [B, N0]         Top-K scores (EViT fuse weights) / DPC-KNN token weights
   size_t size;    // fp32 [B, N0]         ToMe token sizes AFTER this block's merge / ATS key mask after this block
-  size_t xa;      // fp32 [B, n_att, D]   ATS: full-row post-attention stream is not needed; reserved (0 bytes) for other families
+  size_t xa;      // reserved
+  // DyViT predictor stage (blocks with kk > 0, family DYVIT): the PredictorLG activations of dyvit.py:113-119 over all B*N rows
+  size_t pu;      // bf16 [B*N, D]    in_conv.0 (LayerNorm) output
+  size_t ppre0;   // bf16 [B*N, D]    in_conv.1 pre-activation
+  size_t pcat;    // bf16 [B*N, D]    [local | policy-weighted global mean]: out_conv.0's operand
+  size_t ppre1;   // bf16 [B*N, Hh]   out_conv.0 pre-activation      ph1: its GELU
+  size_t ph1;
+  size_t ppre2;   // bf16 [B*N, Q]    out_conv.2 pre-activation (Q = D/4 padded to 64)      ph2: its GELU
+  size_t ph2;
+  size_t pol;     // fp32 [B, N]      the stage's policy = [1, hard_keep]  (entry 0 = CLS)
+  size_t ysoft;   // fp32 [B, N]      softmax(score + gumbel)[..., 0];  sm: softmax(z)[..., 0];  hard: the one-hot's first entry
+  size_t sm;
+  size_t hard;
 };
 
 struct TapePlan {
@@ -87,6 +104,8 @@ struct TapePlan {
   size_t cols;     // bf16 [B*P, C*p*p]  im2col of the images (PatchEmbed's weight-gradient operand)
   size_t xfinal;   // fp32 [B, D]        CLS rows entering the final norm
   size_t xcls;     // bf16 [B, D]        final norm output (the classifier's operand)
+  size_t ones;     // fp32 [B, N0]       DyViT: the all-ones policy of the blocks before the first predictor stage
+  size_t xfin_all; // fp32 [B, N0, D]    DyViT: the whole stream entering the final norm (the distillation features need every row)
   size_t total;
 };
 
@@ -99,11 +118,16 @@ inline bool make_tape_plan(const tr_vit_config* c, int B, const TokenPlan& t, Ta
   p->xfinal = take((size_t)B * D * 4);
   p->xcls = take((size_t)B * D * 2);
   const bool pre = c->family == TR_FAMILY_DPCKNN || c->family == TR_FAMILY_KMEDOIDS;
+  const bool dyvit = c->family == TR_FAMILY_DYVIT;
+  p->ones = dyvit ? take((size_t)B * t.N0 * 4) : 0;
+  p->xfin_all = dyvit ? take((size_t)B * t.N0 * D * 4) : 0;
+  const size_t Hh = (D / 2 + 63) / 64 * 64, Q = (D / 4 + 63) / 64 * 64;
   for (int i = 0; i < c->depth; ++i) {
     BlockTape& b = p->blk[i];
     const size_t Tp = (size_t)B * t.n_pre[i], Ta = (size_t)B * t.n_att[i], Tm = (size_t)B * t.n_mlp[i];
     b.x0 = (pre && t.kk[i] > 0) ? take(Tp * D * 4) : ((c->family == TR_FAMILY_ATS && t.kk[i] > 0) ? take(Tm * D * 4) : 0);
     b.x1 = take(Ta * D * 4);
+    if (dyvit && t.kk[i] > 0) b.x0 = b.x1;       // the predictor reads the stream norm1 reads: one slot (norm1 runs in place on it)
     b.xn1 = take(Ta * D * 2);
     b.qkv = take(Ta * 3 * D * 2);
     b.ao = take(Ta * D * 2);
@@ -117,6 +141,13 @@ inline bool make_tape_plan(const tr_vit_config* c, int B, const TokenPlan& t, Ta
     b.scores = take((size_t)B * t.N0 * 4);
     b.size = take((size_t)B * t.N0 * 4);
     b.xa = 0;
+    b.pu = b.ppre0 = b.pcat = b.ppre1 = b.ph1 = b.ppre2 = b.ph2 = b.pol = b.ysoft = b.sm = b.hard = 0;
+    if (dyvit && t.kk[i] > 0) {
+      b.pu = take(Ta * D * 2); b.ppre0 = take(Ta * D * 2); b.pcat = take(Ta * D * 2);
+      b.ppre1 = take(Ta * Hh * 2); b.ph1 = take(Ta * Hh * 2);
+      b.ppre2 = take(Ta * Q * 2); b.ph2 = take(Ta * Q * 2);
+      b.pol = take(Ta * 4); b.ysoft = take(Ta * 4); b.sm = take(Ta * 4); b.hard = take(Ta * 4);
+    }
   }
   p->total = o;
   return true;

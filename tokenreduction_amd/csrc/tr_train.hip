@@ -17,7 +17,7 @@ using trplan::align_up;
 namespace {
 
 struct BwdPlan {
-  size_t g0, g1, gb0, gb1, dxn, dqkv, dao, dh, zeros, wsf, dscore, gfused, invmap, dxcls, dl16, total;
+  size_t g0, g1, gb0, gb1, dxn, dqkv, dao, dh, zeros, wsf, dscore, gfused, invmap, dxcls, dl16, dpol, dprev, dpolpart, total;
   size_t wsf_floats;
 };
 
@@ -49,6 +49,8 @@ bool make_bwd_plan(const tr_vit_config* c, int B, const trplan::TokenPlan& t, Bw
   upd(tr_layernorm_bwd_workspace_floats((int)T, (int)D));
   upd(tr_wgrad_workspace_floats(B, c->num_classes, (int)D));
   upd((size_t)(B + 1) * (D + 4));
+  upd(tr_dyvit_decide_bwd_workspace_floats(B, t.N0, (int)(D / 4)));
+  upd(tr_wgrad_workspace_floats((int)T, (int)(D / 2), (int)D));
   p->wsf_floats = f;
   p->wsf = take(f * 4);
   p->dscore = take(T * 4);
@@ -56,6 +58,9 @@ bool make_bwd_plan(const tr_vit_config* c, int B, const trplan::TokenPlan& t, Bw
   p->invmap = take(T * 4);
   p->dxcls = take((size_t)B * D * 2);
   p->dl16 = take((size_t)B * c->num_classes * 2);
+  p->dpol = take(T * 4);
+  p->dprev = take(T * 4);
+  p->dpolpart = take(T * c->num_heads * 4);
   p->total = o;
   return true;
 }
@@ -83,11 +88,13 @@ extern "C" size_t tr_vit_backward_workspace_bytes(const tr_vit_config* cfg, int 
 // grads: same layout as tr_vit_weights, every pointer an fp32 gradient buffer of the parameter's shape (matrices included).
 // accumulate != 0: gradients are added to the buffers (engine.py:41 grad accumulation), else overwritten.
 // [blk_hi .. blk_lo] (blk_hi >= blk_lo): the blocks this call walks, in reverse.  blk_hi == depth-1 also runs the classifier and
-// the final norm first; blk_lo == 0 also runs the embedding gradients last.  The gradient of the residual stream stays in the
+// the final norm first; blk_lo == 0 also runs the embedding gradients last.
+// DyViT only: dpred (nullable) fp32 [stages, B, P]: gradient wrt each stage's out_pred_prob (the ratio loss, losses.py:113-118), stages in
+// block order; dfeat (nullable) fp32 [B, N0, D]: gradient wrt the final-norm token features (distillation, losses.py:134-156; row 0 = 0).  The gradient of the residual stream stays in the
 // workspace between calls, so a backward pass is the calls (depth-1 .. a), (a-1 .. b), ..., (c .. 0) in this order.
 extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w, const tr_vit_weights* wt, const tr_vit_weights* grads,
-                               const float* dlogits, const void* tape_, size_t tape_bytes, void* workspace, size_t workspace_bytes,
-                               int accumulate, int blk_hi, int blk_lo, int B, tr_stream_t s) {
+                               const float* dlogits, const float* dpred, const float* dfeat, const void* tape_, size_t tape_bytes,
+                               void* workspace, size_t workspace_bytes, int accumulate, int blk_hi, int blk_lo, int B, tr_stream_t s) {
   TR_REQUIRE(cfg && w && wt && grads && dlogits && tape_ && workspace, TR_ERR_NULL, "tr_vit_backward: null pointer");
   TR_REQUIRE(cfg->precision == TR_PREC_BF16 && trplan::trainable_family(cfg->family), TR_ERR_CONFIG,
              "tr_vit_backward: family %d / precision %d has no training path", cfg->family, cfg->precision);
@@ -124,7 +131,7 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
 
   // which of the two stream-gradient buffers is current at block blk_hi: they swap at every block that reduces tokens
   for (int j = cfg->depth - 1; j > blk_hi; --j)
-    if (t.kk[j] > 0) {          // every token-reducing block of the built families swaps once
+    if (t.kk[j] > 0 && cfg->family != TR_FAMILY_DYVIT) {          // every token-reducing block of the built families swaps once
       float* tg = g; g = g_alt; g_alt = tg;
       uint16_t* tb = gb; gb = gb_alt; gb_alt = tb;
     }
@@ -139,7 +146,16 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
     TR_REQUIRE(hipMemsetAsync(g, 0, (size_t)B * Nl * D * 4, st) == hipSuccess, TR_ERR_LAUNCH, "tr_vit_backward: memset failed");
     TR_TRY(tr_layernorm_bwd(dxcls, reinterpret_cast<const float*>(tape + tp.xfinal), D, w->norm_g, nullptr, 0, g, (long)Nl * D, nullptr, nullptr, 0, 0,
                             0, nullptr, F(grads->norm_g), F(grads->norm_b), acc, wsf, wsn, B, D, cfg->ln_eps, s));
+    if (dfeat != nullptr) {
+      // distillation: gradient wrt the final norm of every row (dyvit.py:252): a second pass of the norm's backward over all rows
+      TR_REQUIRE(cfg->family == TR_FAMILY_DYVIT, TR_ERR_CONFIG, "tr_vit_backward: dfeat is DyViT's distillation gradient");
+      TR_TRY(tr_f32_to_bf16(dfeat, dxn, (size_t)B * Nl * D, s));
+      TR_TRY(tr_layernorm_bwd(dxn, reinterpret_cast<const float*>(tape + tp.xfin_all), D, w->norm_g, g, D, g, D, nullptr, nullptr, 0, 0, 0, nullptr,
+                              F(grads->norm_g), F(grads->norm_b), 1, wsf, wsn, B * Nl, D, cfg->ln_eps, s));
+    }
     TR_TRY(tr_f32_to_bf16(g, gb, (size_t)B * Nl * D, s));
+    if (cfg->family == TR_FAMILY_DYVIT)
+      TR_REQUIRE(hipMemsetAsync(ws + bp.dpol, 0, (size_t)B * t.N0 * 4, st) == hipSuccess, TR_ERR_LAUNCH, "tr_vit_backward: memset failed");
   }
 
   for (int i = blk_hi; i >= blk_lo; --i) {
@@ -214,12 +230,62 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
     if (cfg->family == TR_FAMILY_TOME || cfg->family == TR_FAMILY_ATS)
       for (int j = i - 1; j >= 0; --j)
         if (t.kk[j] > 0) { size_att = reinterpret_cast<const float*>(tape + tp.blk[j].size); break; }
-    TR_TRY(tr_attention_bwd_bf16(U(tape + bt.qkv), dao, size_att, dcls, dqkv, B, Na, H, s));
+    if (cfg->family == TR_FAMILY_DYVIT) {
+      // the policy this block attended under: the last predictor stage at or before it, all ones before the first
+      const float* pol = reinterpret_cast<const float*>(tape + tp.ones);
+      for (int j = i; j >= 0; --j)
+        if (t.kk[j] > 0) { pol = reinterpret_cast<const float*>(tape + tp.blk[j].pol); break; }
+      float* dpart = reinterpret_cast<float*>(ws + bp.dpolpart);
+      TR_TRY(tr_attention_policy_bwd_bf16(U(tape + bt.qkv), dao, pol, dqkv, dpart, B, Na, H, s));
+      TR_TRY(tr_head_sum(dpart, reinterpret_cast<float*>(ws + bp.dpol), B, H, Na, s));
+    } else {
+      TR_TRY(tr_attention_bwd_bf16(U(tape + bt.qkv), dao, size_att, dcls, dqkv, B, Na, H, s));
+    }
     TR_TRY(tr_wgrad_bf16(dqkv, 3 * D, 0, U(tape + bt.xn1), D, F(bg->qkv_w), acc, wsf, wsn, M1, 3 * D, D, s));
     TR_TRY(tr_colsum_bf16(dqkv, 3 * D, 0, F(bg->qkv_b), acc, wsf, wsn, M1, 3 * D, s));
     TR_TRY(tr_gemm_bf16(dqkv, U(bwt->qkv_w), zeros, dxn, nullptr, 0, M1, D, 3 * D, TR_EPI_BF16, s));
     TR_TRY(tr_layernorm_bwd(dxn, x1, D, bw->ln1_g, g, D, g, D, gb, nullptr, 0, 0, 0, nullptr, F(bg->ln1_g), F(bg->ln1_b), acc, wsf, wsn, M1, D,
                             cfg->ln_eps, s));
+    if (cfg->family == TR_FAMILY_DYVIT && K > 0) {
+      // PredictorLG + Gumbel straight-through of this stage (dyvit.py:221-224), backwards.  d keep = the policy gradient collected
+      // from the blocks that attended under this stage's policy (+ the later stage's d prev_decision) + d out_pred_prob
+      const tr_stage_weights* sw = &w->stage[i];
+      const tr_stage_weights* swt = &wt->stage[i];
+      const tr_stage_weights* sg = &grads->stage[i];
+      const int Hh = D / 2, Q = (D / 4 + 63) / 64 * 64, Cq = D / 4;
+      float* dpol = reinterpret_cast<float*>(ws + bp.dpol);
+      float* dprev = reinterpret_cast<float*>(ws + bp.dprev);
+      int stage = 0;
+      for (int j = 0; j < i; ++j) stage += t.kk[j] > 0 ? 1 : 0;
+      if (dpred != nullptr) TR_TRY(tr_add_patch_rows(dpol, dpred + (size_t)stage * B * t.P, B, Na, s));
+      const float* prev = reinterpret_cast<const float*>(tape + tp.ones);       // prev_decision entering this stage, [B,N] layout
+      for (int j = i - 1; j >= 0; --j)
+        if (t.kk[j] > 0) { prev = reinterpret_cast<const float*>(tape + tp.blk[j].pol); break; }
+      TR_REQUIRE(hipMemsetAsync(dprev, 0, (size_t)M1 * 4, st) == hipSuccess, TR_ERR_LAUNCH, "tr_vit_backward: memset failed");
+      uint16_t* d2 = dqkv;                    // scratch: [M1, Q] then reused
+      TR_TRY(tr_dyvit_decide_bwd(dpol, prev, reinterpret_cast<const float*>(tape + bt.hard), reinterpret_cast<const float*>(tape + bt.ysoft),
+                                 reinterpret_cast<const float*>(tape + bt.sm), U(tape + bt.ph2), Q, sw->w3, d2, dprev, F(sg->w3), F(sg->b3), acc, wsf,
+                                 wsn, B, Na, Cq, s));
+      TR_TRY(tr_gelu_bwd_bf16(U(tape + bt.ppre2), d2, (size_t)M1 * Q, s));
+      TR_TRY(tr_wgrad_bf16(d2, Q, 0, U(tape + bt.ph1), Hh, F(sg->w2), acc, wsf, wsn, M1, Cq, Hh, s));
+      TR_TRY(tr_colsum_bf16(d2, Q, 0, F(sg->b2), acc, wsf, wsn, M1, Cq, s));
+      uint16_t* d1 = dao;                     // [M1, Hh]
+      TR_TRY(tr_gemm_bf16(d2, U(swt->w2), zeros, d1, nullptr, 0, M1, Hh, Q, TR_EPI_BF16, s));
+      TR_TRY(tr_gelu_bwd_bf16(U(tape + bt.ppre1), d1, (size_t)M1 * Hh, s));
+      TR_TRY(tr_wgrad_bf16(d1, Hh, 0, U(tape + bt.pcat), D, F(sg->w1), acc, wsf, wsn, M1, Hh, D, s));
+      TR_TRY(tr_colsum_bf16(d1, Hh, 0, F(sg->b1), acc, wsf, wsn, M1, Hh, s));
+      TR_TRY(tr_gemm_bf16(d1, U(swt->w1), zeros, dxn, nullptr, 0, M1, D, Hh, TR_EPI_BF16, s));          // d [local | global]
+      uint16_t* d0 = dh;                      // [M1, D]
+      TR_TRY(tr_pool_policy_bwd(dxn, U(tape + bt.ppre0), U(tape + bt.pcat), prev, d0, dprev, B, Na, D, s));
+      TR_TRY(tr_gelu_bwd_bf16(U(tape + bt.ppre0), d0, (size_t)M1 * D, s));
+      TR_TRY(tr_wgrad_bf16(d0, D, 0, U(tape + bt.pu), D, F(sg->w0), acc, wsf, wsn, M1, D, D, s));
+      TR_TRY(tr_colsum_bf16(d0, D, 0, F(sg->b0), acc, wsf, wsn, M1, D, s));
+      TR_TRY(tr_gemm_bf16(d0, U(swt->w0), zeros, dxn, nullptr, 0, M1, D, D, TR_EPI_BF16, s));
+      TR_TRY(tr_layernorm_bwd(dxn, reinterpret_cast<const float*>(tape + bt.x0), D, sw->ln_g, g, D, g, D, gb, nullptr, 0, 0, 0, nullptr, F(sg->ln_g),
+                              F(sg->ln_b), acc, wsf, wsn, M1, D, 1e-5f, s));
+      // what is left of the policy gradient belongs to the previous stage's decision
+      TR_REQUIRE(hipMemcpyAsync(dpol, dprev, (size_t)M1 * 4, hipMemcpyDeviceToDevice, st) == hipSuccess, TR_ERR_LAUNCH, "tr_vit_backward: copy failed");
+    }
     if (cfg->family == TR_FAMILY_DPCKNN && K > 0) {
       // CTM before the block (dpcknn.py:257-260): gradient of the merged tokens -> the tokens they were merged from + the score Linear
       const tr_stage_weights* sw = &w->stage[i];

@@ -254,6 +254,12 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
 
   int N = p.N0;
   const void* pending = nullptr;   // residual not yet added to x (the previous block's fc2 output)
+  const float* policy_cur = nullptr;      // DyViT training: the keep policy every block attends under (all ones before the first stage)
+  if (train && cfg->family == TR_FAMILY_DYVIT) {
+    float* ones = reinterpret_cast<float*>(tape + tp->ones);
+    TR_TRY(tr_fill_f32(ones, 1.0f, (size_t)B * p.N0, s));
+    policy_cur = ones;
+  }
   for (int i = 0; i < cfg->depth; ++i) {
     const tr_block_weights* bw = &w->blocks[i];
     const bool tome = cfg->family == TR_FAMILY_TOME;
@@ -363,7 +369,42 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       float* t = x; x = x_alt; x_alt = t;
       N = Kc + 1;
     }
-    if ((cfg->family == TR_FAMILY_DYVIT || cfg->family == TR_FAMILY_SIT) && cfg->keep[i] > 0) {
+    if (train && cfg->family == TR_FAMILY_DYVIT && cfg->keep[i] > 0) {
+      // a11 / f4: DyViT TRAINING (dyvit.py:221-229): PredictorLG on the patch tokens under the previous decision, a straight-through
+      // Gumbel-softmax sample becomes this stage's policy; no token is removed.  Every activation goes to the stage's tape slots.
+      const tr_stage_weights* sw = &w->stage[i];
+      const trplan::BlockTape& bt = tp->blk[i];
+      const int M = B * N, Hh = sw->h_pad > 0 ? sw->h_pad : D / 2, Q = (D / 4 + 63) / 64 * 64;
+      TR_REQUIRE(sw->ln_g && sw->ln_b && sw->w0 && sw->b0 && sw->w1 && sw->b1 && sw->w2 && sw->b2 && sw->w3 && sw->b3, TR_ERR_NULL,
+                 "tr_vit_forward_train: block %d predictor weights missing", i);
+      TR_REQUIRE(Hh == D / 2 && sw->reserved_ == Q, TR_ERR_CONFIG,
+                 "tr_vit_forward_train: the DyViT training path needs D/2 %% 64 == 0 (DeiT-S / DeiT-B) and out_conv.2 packed to %d rows (got %d)", Q,
+                 sw->reserved_);
+      TR_REQUIRE(noise_in != nullptr, TR_ERR_NULL, "tr_vit_forward_train: DyViT needs the Gumbel noise of every stage (noise_in)");
+      float* x0 = reinterpret_cast<float*>(tape + bt.x0);
+      uint16_t* pu = reinterpret_cast<uint16_t*>(tape + bt.pu);
+      uint16_t* ppre0 = reinterpret_cast<uint16_t*>(tape + bt.ppre0);
+      uint16_t* pcat = reinterpret_cast<uint16_t*>(tape + bt.pcat);
+      uint16_t* ppre1 = reinterpret_cast<uint16_t*>(tape + bt.ppre1);
+      uint16_t* ph1 = reinterpret_cast<uint16_t*>(tape + bt.ph1);
+      uint16_t* ppre2 = reinterpret_cast<uint16_t*>(tape + bt.ppre2);
+      uint16_t* ph2 = reinterpret_cast<uint16_t*>(tape + bt.ph2);
+      float* pol = reinterpret_cast<float*>(tape + bt.pol);
+      TR_TRY(tr_layernorm_bf16_to(x, D, x0, D, static_cast<const uint16_t*>(pending), D, sw->ln_g, sw->ln_b, pu, M, D, 1e-5f, s));
+      pending = nullptr;
+      x = x0;
+      TR_TRY(tr_gemm_bf16(pu, static_cast<const uint16_t*>(sw->w0), sw->b0, ppre0, nullptr, 0, M, D, D, TR_EPI_BF16, s));
+      TR_TRY(tr_gelu_bf16(ppre0, pcat, (size_t)M * D, s));
+      TR_TRY(tr_pool_policy(pcat, policy_cur, B, N, D, 1e-6f, s));
+      TR_TRY(tr_gemm_bf16(pcat, static_cast<const uint16_t*>(sw->w1), sw->b1, ppre1, nullptr, 0, M, Hh, D, TR_EPI_BF16, s));
+      TR_TRY(tr_gelu_bf16(ppre1, ph1, (size_t)M * Hh, s));
+      TR_TRY(tr_gemm_bf16(ph1, static_cast<const uint16_t*>(sw->w2), sw->b2, ppre2, nullptr, 0, M, Q, Hh, TR_EPI_BF16, s));
+      TR_TRY(tr_gelu_bf16(ppre2, ph2, (size_t)M * Q, s));
+      TR_TRY(tr_dyvit_decide(ph2, Q, sw->w3, sw->b3, noise_in, policy_cur, pol, reinterpret_cast<float*>(tape + bt.ysoft),
+                             reinterpret_cast<float*>(tape + bt.sm), reinterpret_cast<float*>(tape + bt.hard), B, N, D / 4, s));
+      noise_in += (size_t)B * (N - 1) * 2;
+      policy_cur = pol;
+    } else if ((cfg->family == TR_FAMILY_DYVIT || cfg->family == TR_FAMILY_SIT) && cfg->keep[i] > 0) {
       const tr_stage_weights* sw = &w->stage[i];
       const int Kc = cfg->keep[i], M = B * N;
       TR_REQUIRE(Kc <= N - 1, TR_ERR_CONFIG, "tr_vit_forward: block %d asks for %d of %d patch tokens", i, Kc, N - 1);
@@ -435,8 +476,11 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
     // K-Medoids: the NEXT block's clustering is seeded by the column sums of THIS block's attention (kmedoids.py:240)
     const bool want_colsum = cfg->family == TR_FAMILY_KMEDOIDS && i + 1 < cfg->depth && cfg->keep[i + 1] > 0;
     const bool masked = ats || cfg->family == TR_FAMILY_HEURISTIC;
-    TR_TRY(op_attn(f32, qkv, ao, (K > 0 || Ks > 0) ? cls_rows : nullptr, (tome || masked) ? size_cur : nullptr,
-                   want_colsum ? colsum_part : nullptr, B, N, H, s));
+    if (policy_cur != nullptr)       // DyViT training: softmax_with_policy in every block (dyvit.py:245-246)
+      TR_TRY(tr_attention_policy_bf16(static_cast<const uint16_t*>(qkv), static_cast<uint16_t*>(ao), policy_cur, B, N, H, s));
+    else
+      TR_TRY(op_attn(f32, qkv, ao, (K > 0 || Ks > 0) ? cls_rows : nullptr, (tome || masked) ? size_cur : nullptr,
+                     want_colsum ? colsum_part : nullptr, B, N, H, s));
     int Nn = N;
     if (Ks > 0) {
       // a16-a18: sample token ids on the CLS attention x |v|, keep those rows of x and of attn @ v
@@ -520,13 +564,22 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
     dbuf = dbuf_shared;
     TR_TRY(op_gemm(f32, hbuf, bw->fc2_w, bw->fc2_b, dbuf, nullptr, 0, M2, D, p.Hd, TR_EPI_BF16, s));
     pending = dbuf;
-    if (features_out) {      // viz_data["Features"][i] (topk.py:197): x + mlp output, which x itself only absorbs in the next norm
+    if (features_out && !train) {      // viz_data["Features"][i] (topk.py:197): x + mlp output, which x itself only absorbs in the next norm
       TR_TRY(tr_residual_snapshot(x, pending, f32 ? 1 : 0, features_out, (size_t)M2 * D, s));
       features_out += (size_t)M2 * D;
     }
     if (tokens_out) tokens_out[i] = N;
   }
   // a5: (x += last mlp output and) norm on the CLS rows only (LayerNorm is per-row), then the classifier
+  if (train && features_out != nullptr) {
+    // DyViT distillation (dyvit.py:252-258): the final norm of EVERY row is an output; the whole stream stays for its backward
+    float* xfa = reinterpret_cast<float*>(tape + tp->xfin_all);
+    TR_TRY(tr_layernorm_bf16_to(x, D, xfa, D, static_cast<const uint16_t*>(pending), D, w->norm_g, w->norm_b, static_cast<uint16_t*>(xn_shared),
+                                B * N, D, cfg->ln_eps, s));
+    TR_TRY(tr_layernorm_f32(xfa, D, nullptr, D, w->norm_g, w->norm_b, features_out, B * N, D, cfg->ln_eps, s));
+    x = xfa;
+    pending = nullptr;
+  }
   if (train) {
     xcls = tape + tp->xcls;
     TR_TRY(tr_layernorm_bf16_to(x, (long)N * D, reinterpret_cast<float*>(tape + tp->xfinal), D, static_cast<const uint16_t*>(pending), (long)N * D,
@@ -564,15 +617,17 @@ extern "C" int tr_vit_tape_layout(const tr_vit_config* cfg, int B, int blk, size
   TR_REQUIRE(make_plan(cfg, B, &p) && trplan::make_token_plan(cfg, &t) && trplan::make_tape_plan(cfg, B, t, &tp) && blk >= 0 && blk < cfg->depth,
              TR_ERR_CONFIG, "tr_vit_tape_layout: invalid config or block");
   const trplan::BlockTape& b = tp.blk[blk];
-  const size_t v[18] = {b.x0, b.x1, b.xn1, b.qkv, b.ao, b.dattn, b.x2, b.xn2, b.pre, b.h, b.idx, b.idx2, b.scores, b.size,
+  const bool dy = cfg->family == TR_FAMILY_DYVIT;       // DyViT: the stage's one-hot decisions / policy [B,N] sit in the "scores" / "size" places
+  const size_t v[18] = {b.x0, b.x1, b.xn1, b.qkv, b.ao, b.dattn, b.x2, b.xn2, b.pre, b.h, b.idx, b.idx2, dy ? b.hard : b.scores,
+                        dy ? b.pol : b.size,
                         (size_t)t.n_pre[blk], (size_t)t.n_att[blk], (size_t)t.n_mlp[blk], (size_t)t.kk[blk]};
   for (int i = 0; i < 18; ++i) out18[i] = v[i];
   return TR_OK;
 }
 
 extern "C" int tr_vit_forward_train(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits, void* workspace,
-                                    size_t workspace_bytes, void* tape, size_t tape_bytes, const float* noise_in, int* tokens_out, int B,
-                                    tr_stream_t s) {
+                                    size_t workspace_bytes, void* tape, size_t tape_bytes, const float* noise_in, float* features_out,
+                                    int* tokens_out, int B, tr_stream_t s) {
   TR_REQUIRE(cfg && tape, TR_ERR_NULL, "tr_vit_forward_train: null pointer");
   TR_REQUIRE(cfg->precision == TR_PREC_BF16, TR_ERR_CONFIG, "tr_vit_forward_train: the training path is bf16 only");
   TR_REQUIRE(trplan::trainable_family(cfg->family), TR_ERR_CONFIG, "tr_vit_forward_train: family %d has no training path yet", cfg->family);
@@ -583,6 +638,7 @@ extern "C" int tr_vit_forward_train(const tr_vit_config* cfg, const tr_vit_weigh
   TR_REQUIRE(tr_aligned16(tape), TR_ERR_ALIGN, "tr_vit_forward_train: tape must be 16-byte aligned");
   for (int i = 0; i < cfg->depth; ++i)
     TR_REQUIRE(t.n_att[i] <= 224, TR_ERR_SHAPE, "tr_vit_forward_train: %d tokens in block %d; the attention backward holds N <= 224", t.n_att[i], i);
-  return vit_forward_impl(cfg, w, img, logits, workspace, workspace_bytes, nullptr, nullptr, nullptr, noise_in, nullptr, tokens_out, B, s,
+  TR_REQUIRE(features_out == nullptr || cfg->family == TR_FAMILY_DYVIT, TR_ERR_CONFIG, "tr_vit_forward_train: features_out is DyViT's distillation output");
+  return vit_forward_impl(cfg, w, img, logits, workspace, workspace_bytes, nullptr, nullptr, nullptr, noise_in, features_out, tokens_out, B, s,
                           static_cast<char*>(tape), &tp);
 }

@@ -234,6 +234,9 @@ class VisionTransformer(nn.Module):
     def _per_forward_config(self, cfg):
         """Host-side random draws of a forward that the executor takes as inputs (K-Medoids equal_weight)."""
 
+    def _transposed_stage_weights(self, WT, t16):
+        """Families whose reduction modules have a backward: transposed bf16 copies of their matrices (dgrad operands)."""
+
     def _soft_elems(self, B):
         """fp32 elements of the soft-assignment output (SiT), 0 for families without one."""
         return 0
@@ -548,8 +551,10 @@ class PredictorLG(nn.Module):
 
 
 class DynamicVisionTransformer(VisionTransformer):
-    """models/dyvit.py:122-263, eval path: per pruning block, PredictorLG scores the patch tokens, the best int(P0*ratio) are
-    gathered (argsort order) BEFORE the block runs.  Training (gumbel + policy softmax, dyvit.py:221-229) is not built."""
+    """models/dyvit.py:122-263.  Eval: per pruning block, PredictorLG scores the patch tokens, the best int(P0*ratio) are gathered
+    (argsort order) BEFORE the block runs.  Training (dyvit.py:221-229): no token is removed; a straight-through Gumbel-softmax
+    sample of the scores becomes the keep policy every later block attends under, and forward returns
+    (logits, out_pred_prob) or, with dyvit_distillation, (logits, features, prev_decision, out_pred_prob) (dyvit.py:257-261)."""
     _blocks_last = True
     _family = _lib.TR_FAMILY_DYVIT
 
@@ -581,6 +586,37 @@ class DynamicVisionTransformer(VisionTransformer):
     def get_new_module_names(self):
         return ["score_predictor"]
 
+    # ---- training (dyvit.py:221-229, 257-261) ------------------------------------------------------------------
+    gumbel_noise = None      # tests: {stage: tensor [B,P,2]} = the reference's -log(Exp(1)) draws; None = drawn on the device
+
+    def _gumbel_ptr(self, B, dev):
+        P, n_st = self.num_patches, len(self.pruning_loc)
+        buf = getattr(self, "_gumbel_buf", None)
+        if buf is None or buf.numel() != n_st * B * P * 2 or buf.device != dev:
+            buf = self._gumbel_buf = torch.empty(n_st * B * P * 2, dtype=torch.float32, device=dev)
+        if self.gumbel_noise is not None:
+            buf.copy_(torch.cat([self.gumbel_noise[j].to(device=dev, dtype=torch.float32).reshape(-1) for j in range(n_st)]))
+        else:
+            buf.exponential_().log_().neg_()          # F.gumbel_softmax: -empty_like(logits).exponential_().log()
+        return buf.data_ptr()
+
+    def _grad_stage_ptrs(self, G, ptr):
+        for j, loc in enumerate(self.pruning_loc):
+            g, pre = G.stage[loc], f"score_predictor.{j}."
+            g.ln_g, g.ln_b = ptr(pre + "in_conv.0.weight"), ptr(pre + "in_conv.0.bias")
+            g.w0, g.b0 = ptr(pre + "in_conv.1.weight"), ptr(pre + "in_conv.1.bias")
+            g.w1, g.b1 = ptr(pre + "out_conv.0.weight"), ptr(pre + "out_conv.0.bias")
+            g.w2, g.b2 = ptr(pre + "out_conv.2.weight"), ptr(pre + "out_conv.2.bias")
+            g.w3, g.b3 = ptr(pre + "out_conv.4.weight"), ptr(pre + "out_conv.4.bias")
+
+    def _transposed_stage_weights(self, WT, t16):
+        qq = (self.embed_dim // 4 + 63) // 64 * 64
+        for j, loc in enumerate(self.pruning_loc):
+            sp, st = self.score_predictor[j], WT.stage[loc]
+            st.w0 = t16(sp.in_conv[1].weight)                               # [D, D]^T
+            st.w1 = t16(sp.out_conv[0].weight)                              # [D/2, D]^T -> [D, D/2]
+            st.w2 = t16(_pad_rows(sp.out_conv[2].weight, qq))               # [Q, D/2]^T -> [D/2, Q]
+
     def get_reduction_count(self):
         return self.pruning_loc
 
@@ -591,8 +627,10 @@ class DynamicVisionTransformer(VisionTransformer):
             st.w0, st.b0 = w16(sp.in_conv[1].weight), f32(sp.in_conv[1].bias)
             hh = (self.embed_dim // 2 + 63) // 64 * 64          # D/2 padded with zero weights: K %% 64 for the bf16 GEMM (DeiT-T: 96 -> 128)
             st.w1, st.b1 = w16(_pad_rows(sp.out_conv[0].weight, hh)), f32(_pad_vec(sp.out_conv[0].bias, hh))
-            st.w2, st.b2 = w16(_pad_cols(sp.out_conv[2].weight, hh)), f32(sp.out_conv[2].bias)
+            qq = (self.embed_dim // 4 + 63) // 64 * 64          # D/4 rows padded likewise: the training path's GEMMs reduce over them
+            st.w2, st.b2 = w16(_pad_rows(_pad_cols(sp.out_conv[2].weight, hh), qq)), f32(_pad_vec(sp.out_conv[2].bias, qq))
             st.h_pad = hh
+            st.reserved_ = qq
             st.w3, st.b3 = f32(sp.out_conv[4].weight), f32(sp.out_conv[4].bias)
 
     def _viz_data(self, ws, B, tokens):

@@ -127,6 +127,7 @@ class TrainState:
             b = WT.blocks[i]
             b.qkv_w, b.proj_w = t16(blk.attn.qkv.weight), t16(blk.attn.proj.weight)
             b.fc1_w, b.fc2_w = t16(blk.mlp.fc1.weight), t16(blk.mlp.fc2.weight)
+        model._transposed_stage_weights(WT, t16)
         self.wt, self.wt_keep, self.key = WT, keep, pk["key"]
         return WT
 
@@ -138,7 +139,7 @@ class TrainState:
             if nt == 0 or nb == 0:
                 raise NotImplementedError(
                     f"{type(model).__name__}: this family / configuration has no training path in the HIP executor "
-                    "(built: DeiT, Top-K, EViT, ToMe, DPC-KNN, ATS at 224x224, bf16); call model.eval() for inference")
+                    "(built: DeiT, Top-K, EViT, ToMe, DPC-KNN, ATS, DyViT at 224x224, bf16); call model.eval() for inference")
             self.tape = torch.empty(nt, dtype=torch.uint8, device=dev)
             self.bws = torch.empty(nb, dtype=torch.uint8, device=dev)
             self.B = B
@@ -180,11 +181,16 @@ def train_decisions(model) -> dict:
             out[blk] = (raw[: B * k].view(B, k).long(), raw2.view(B, p_in).long())
         elif model._family == _lib.TR_FAMILY_ATS:             # ids [B,Ks]: CLS id 0 first, 1-based token ids, 0 padding
             out[blk] = raw[: B * k].view(B, k).long()
+        elif model._family == _lib.TR_FAMILY_DYVIT:           # the Gumbel one-hot's first entry per patch token [B,P] (before * prev_decision)
+            n = lay["n_att"]
+            out[blk] = st.tape[lay["scores"]: lay["scores"] + 4 * B * n].view(torch.float32).view(B, n)[:, 1:].clone()
     return out
 
 
 class _VitTrainFn(torch.autograd.Function):
-    """logits = model(x) with the backward wired to tr_vit_backward.  `anchor` only makes autograd call backward."""
+    """logits (+ DyViT's extra outputs) = model(x) with the backward wired to tr_vit_backward.  `anchor` only makes autograd call
+    backward.  Outputs: (logits,) or for DyViT (logits, pred_0 .. pred_{S-1} [, features]): pred_j = the stage's hard keep decision
+    [B,P] (straight-through differentiable, dyvit.py:223-225), features = the final norm of the patch tokens [B,P,D]."""
 
     @staticmethod
     def forward(ctx, anchor, x, model):
@@ -197,22 +203,48 @@ class _VitTrainFn(torch.autograd.Function):
         ws = model._workspace(B, x.device)
         logits = torch.empty(B, model.num_classes, dtype=torch.float32, device=x.device)
         tokens = (C.c_int * model.depth)()
+        dyvit = model._family == _lib.TR_FAMILY_DYVIT
+        distill = dyvit and bool(getattr(model, "dyvit_distillation", False))
+        feats = torch.empty(B, model.patch_embed.num_patches + 1, model.embed_dim, dtype=torch.float32, device=x.device) if distill else None
+        noise = model._gumbel_ptr(B, x.device) if dyvit else model._noise_ptr(B, x.device)
         with torch.cuda.device(x.device):
             rc = lib.tr_vit_forward_train(C.byref(cfg), C.byref(pk["W"]), x.data_ptr(), logits.data_ptr(), ws["buf"].data_ptr(), ws["nbytes"],
-                                          tape.data_ptr(), tape.numel(), model._noise_ptr(B, x.device), tokens, B,
+                                          tape.data_ptr(), tape.numel(), noise, None if feats is None else feats.data_ptr(), tokens, B,
                                           torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "tr_vit_forward_train")
         model._last_tokens = list(tokens)
         ctx.model, ctx.B, ctx.pk = model, B, pk
         ctx.keep = x
-        return logits
+        ctx.n_pred, ctx.distill = 0, distill
+        if not dyvit:
+            return logits
+        preds = []
+        for blk in sorted(model.pruning_loc):
+            lay = tape_layout(model, blk)
+            n = lay["n_att"]
+            pol = tape[lay["size"]: lay["size"] + 4 * B * n].view(torch.float32).view(B, n)
+            preds.append(pol[:, 1:].clone())
+        ctx.n_pred = len(preds)
+        outs = [logits] + preds + ([feats[:, 1:].clone()] if distill else [])
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, dlogits):
+    def backward(ctx, dlogits, *dextra):
         model, B, pk = ctx.model, ctx.B, ctx.pk
         lib = _lib.load()
         st = model._train_state()
+        dev = st.flat.device
+        if dlogits is None:
+            dlogits = torch.zeros(B, model.num_classes, dtype=torch.float32, device=dev)
         dl = dlogits.detach().to(torch.float32).contiguous()
+        dpred = dfeat = None
+        if ctx.n_pred:
+            P = model.patch_embed.num_patches
+            gp = [torch.zeros(B, P, dtype=torch.float32, device=dev) if g is None else g.detach().to(torch.float32) for g in dextra[:ctx.n_pred]]
+            dpred = torch.stack(gp).contiguous()                              # [stages, B, P]
+            if ctx.distill and dextra[ctx.n_pred] is not None:
+                dfeat = torch.zeros(B, P + 1, model.embed_dim, dtype=torch.float32, device=dev)
+                dfeat[:, 1:] = dextra[ctx.n_pred].detach()
         # gradient views: zero the slices of parameters that hold no gradient yet (zero_grad(set_to_none=True) is torch's
         # default), keep accumulating into the others (engine.py:41-84: gradient accumulation over micro-steps)
         fresh = [n for n, p in st.order if p.grad is None or p.grad.data_ptr() != st.views[n].data_ptr()]
@@ -233,8 +265,9 @@ class _VitTrainFn(torch.autograd.Function):
         stream = torch.cuda.current_stream().cuda_stream
         with torch.cuda.device(dl.device):
             for hi, lo, start, stop in ranges:
-                rc = lib.tr_vit_backward(C.byref(pk["cfg"]), C.byref(pk["W"]), C.byref(WT), C.byref(G), dl.data_ptr(), st.tape.data_ptr(),
-                                         st.tape.numel(), st.bws.data_ptr(), st.bws.numel(), 1, hi, lo, B, stream)
+                rc = lib.tr_vit_backward(C.byref(pk["cfg"]), C.byref(pk["W"]), C.byref(WT), C.byref(G), dl.data_ptr(),
+                                         None if dpred is None else dpred.data_ptr(), None if dfeat is None else dfeat.data_ptr(),
+                                         st.tape.data_ptr(), st.tape.numel(), st.bws.data_ptr(), st.bws.numel(), 1, hi, lo, B, stream)
                 _lib.check(rc, "tr_vit_backward")
                 if reduce_now:
                     reducer.reduce_slice(st.flat, start, stop)
@@ -260,4 +293,12 @@ def train_forward(model, x: torch.Tensor) -> torch.Tensor:
                                   "drop_rate=0, drop_path_rate=0 (train.py --drop 0 --drop-path 0)")
     x = x.detach().to(torch.float32).contiguous()
     anchor = torch.empty(0, dtype=torch.float32, device=x.device, requires_grad=True)
-    return _VitTrainFn.apply(anchor, x, model)
+    out = _VitTrainFn.apply(anchor, x, model)
+    if model._family != _lib.TR_FAMILY_DYVIT:
+        return out
+    # dyvit.py:257-261: (x, features, prev_decision.detach(), out_pred_prob) with the DyViT distillation scheme, else (x, out_pred_prob)
+    n_st = len(model.pruning_loc)
+    logits, preds = out[0], list(out[1: 1 + n_st])
+    if getattr(model, "dyvit_distillation", False):
+        return logits, out[1 + n_st], preds[-1].detach().unsqueeze(-1), preds
+    return logits, preds
