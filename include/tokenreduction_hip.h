@@ -251,6 +251,10 @@ int tr_tome_merge_layernorm(const float* x, const void* delta, int f32_path, con
 size_t tr_wgrad_workspace_floats(int M, int N, int K);
 int tr_wgrad_bf16(const uint16_t* dY, long ldy, int yskip, const uint16_t* X, long ldx, float* dW, int accumulate, float* ws,
                   size_t ws_floats, int M, int N, int K, tr_stream_t s);
+/* Both parameter gradients of an nn.Linear in one pass over dY (the bias sums come out of the weight-gradient kernel's staging
+ * registers) and one reduce launch; ws as tr_wgrad_bf16. */
+int tr_linear_bwd_params(const uint16_t* dY, long ldy, int yskip, const uint16_t* X, long ldx, float* dW, float* db, int accumulate,
+                         float* ws, size_t ws_floats, int M, int N, int K, tr_stream_t s);
 size_t tr_colsum_workspace_floats(int M, int N);
 int tr_colsum_bf16(const uint16_t* dY, long ldy, int yskip, float* db, int accumulate, float* ws, size_t ws_floats, int M, int N,
                    tr_stream_t s);
@@ -260,6 +264,9 @@ size_t tr_layernorm_bwd_workspace_floats(int M, int D);
 int tr_layernorm_bwd(const uint16_t* dy, const float* x, long ldx, const float* gamma, const float* g_in, long ldgi, float* g_out,
                      long ldgo, uint16_t* gb_out, const int32_t* idx, int K, int n_in, int n_out, float* g_fused, float* dgamma,
                      float* dbeta, int accumulate, float* ws, size_t ws_floats, int M, int D, float eps, tr_stream_t s);
+int tr_layernorm_bwd_scatter_add(const uint16_t* dy, const float* x, const float* gamma, const float* g_in, float* g_out,
+                                 const int32_t* idx, int K, int n_out, float* dgamma, float* dbeta, int accumulate, float* ws,
+                                 size_t ws_floats, int M, int D, float eps, tr_stream_t s);   /* repeated ids: rows are added (atomics) */
 int tr_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, const float* size, const float* dcls, uint16_t* dqkv, int B,
                           int N, int H, tr_stream_t s);
 int tr_head_bwd(const float* dlogits, const uint16_t* W, const uint16_t* xn, uint16_t* dxn, float* dW, float* db, int accumulate,

@@ -232,7 +232,7 @@ GOLDEN_CASES = {
 # cross-entropy criterion) in train mode on the golden case's weights / images, labels from grad_labels().  Too large to store
 # whole (22 M values at DeiT-S), so per parameter: the L2 norm and <= 512 evenly strided entries (grad_sample_index).
 GRAD_CASES = ["deit_micro", "topk_micro", "evit_micro", "tome_micro", "dpcknn_micro", "dpcknn_micro_equal", "ats_micro", "topk_small_kr07",
-              "evit_small_kr07", "tome_small_r16", "deit_base", "dpcknn_base_kr05", "ats_base_kr05", "dyvit_micro_train", "dyvit_small_train"]
+              "evit_small_kr07", "tome_small_r16", "deit_base", "dpcknn_base_kr05", "ats_base_kr05", "dyvit_micro_train", "dyvit_small_train", "kmedoids_micro", "heuristic_micro_l2"]
 
 
 def dyvit_token_ratio(case: dict):
@@ -284,7 +284,12 @@ def oracle_param_grads(case: dict, forced=None, precision: str = "fp32", noise=N
             loss = dyvit_train_loss(outs, grad_labels(case), case)
             loss.backward()
             return loss.item(), outs[0].detach(), {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}
-        if fam == "tome":
+        if fam == "kmedoids":
+            logits = oracle.kmedoids_forward.__wrapped__(leaves, x, cfg, precision, False, 3, forced)
+        elif fam == "heuristic":
+            logits = oracle.heuristic_forward.__wrapped__(leaves, x, cfg, case["heuristic_pattern"], case["not_contiguous"], case.get("min_radius"),
+                                                          precision, False)
+        elif fam == "tome":
             logits = oracle.tome_forward.__wrapped__(leaves, x, cfg, precision, False, forced)
         elif fam == "dpcknn":
             logits = oracle.dpcknn_forward.__wrapped__(leaves, x, cfg, noise, precision, False, forced)

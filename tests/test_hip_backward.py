@@ -47,6 +47,21 @@ def test_wgrad(ops, M, N, K):
     assert torch.equal(ops.wgrad(dy, x), got)
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 128, 128), (1000, 384, 1152), (50432, 1536, 384), (777, 96, 192), (3000, 1000, 384)])
+def test_linear_bwd_params(ops, M, N, K):
+    """Fused weight + bias gradient == the separate kernels, bit for bit (same partial sums in the same order for dW; the bias sums
+    are a different, also fixed, order -> compared with the torch value)."""
+    dy = _randn(50, M, N, dtype=torch.bfloat16)
+    x = _randn(51, M, K, dtype=torch.bfloat16)
+    dw, db = ops.linear_bwd_params(dy, x)
+    assert torch.equal(dw, ops.wgrad(dy, x))
+    want = dy.float().sum(0)
+    assert float((db - want).abs().max()) <= 1e-4 * float(want.abs().max()) + 1e-5
+    dw2, db2 = ops.linear_bwd_params(dy, x, accumulate=True, dw=dw.clone(), db=db.clone())
+    assert torch.allclose(dw2, 2 * dw, rtol=1e-6) and torch.allclose(db2, 2 * db, rtol=1e-6)
+    assert torch.equal(ops.linear_bwd_params(dy, x)[1], db)
+
+
 def test_wgrad_exact_integers(ops):
     """Small integers are exact in bf16 and fp32: any operand-layout mistake shows as a wrong integer."""
     M, N, K = 200, 144, 136

@@ -87,12 +87,14 @@ SIGNATURES = {
     "tr_residual_snapshot": (_i, [_vp, _vp, _i, _vp, _sz, _vp]),
     "tr_wgrad_workspace_floats": (_sz, [_i, _i, _i]),
     "tr_wgrad_bf16": (_i, [_vp, _l, _i, _vp, _l, _vp, _i, _vp, _sz, _i, _i, _i, _vp]),
+    "tr_linear_bwd_params": (_i, [_vp, _l, _i, _vp, _l, _vp, _vp, _i, _vp, _sz, _i, _i, _i, _vp]),
     "tr_colsum_workspace_floats": (_sz, [_i, _i]),
     "tr_colsum_bf16": (_i, [_vp, _l, _i, _vp, _i, _vp, _sz, _i, _i, _vp]),
     "tr_gelu_bf16": (_i, [_vp, _vp, _sz, _vp]),
     "tr_gelu_bwd_bf16": (_i, [_vp, _vp, _sz, _vp]),
     "tr_layernorm_bwd_workspace_floats": (_sz, [_i, _i]),
     "tr_layernorm_bwd": (_i, [_vp, _vp, _l, _vp, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _i, _i, _f, _vp]),
+    "tr_layernorm_bwd_scatter_add": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _sz, _i, _i, _f, _vp]),
     "tr_attention_bwd_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "tr_head_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _sz, _i, _i, _i, _vp]),
     "tr_embed_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -37,9 +37,13 @@ __device__ __forceinline__ bf16x8 lds_tr_pair(const unsigned char* p0, const uns
 constexpr int WB = 128, WM = 64;
 __device__ __forceinline__ int wswz(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
+// BIAS: the workgroups of the first column tile (k0 == 0) also sum their 128 dY columns over their token range -- the bias gradient
+// db[n] = sum_m dY[m][n] -- from the registers the slab passes through anyway (bpart[split][N]; a separate column-sum kernel re-read
+// dY: 1.0 of a 14 ms training step).
+template <bool BIAS>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const uint16_t* __restrict__ Y, long ldy, int yskip,
-                                                       const uint16_t* __restrict__ X, long ldx, float* __restrict__ part, int M,
-                                                       int N, int K, int nNt, int sps) {
+                                                       const uint16_t* __restrict__ X, long ldx, float* __restrict__ part,
+                                                       float* __restrict__ bpart, int M, int N, int K, int nNt, int sps) {
   __shared__ __attribute__((aligned(16))) unsigned char sm[2][2][WM * 256];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wk = wave & 1;
@@ -74,11 +78,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const uint16_t* __restric
         xreg[it] = make_uint4(0u, 0u, 0u, 0u);
       }
   };
+  const bool do_bias = BIAS && k0 == 0;
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // this thread's 8 columns (chunk tid & 15), its 4 rows of every slab
   auto write_slab = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       *reinterpret_cast<uint4*>(&sm[buf][0][wswz(srow[it], sch[it])]) = yreg[it];
       *reinterpret_cast<uint4*>(&sm[buf][1][wswz(srow[it], sch[it])]) = xreg[it];
+    }
+    if (do_bias) {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const unsigned int w[4] = {yreg[it].x, yreg[it].y, yreg[it].z, yreg[it].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          bsum[2 * e] += __uint_as_float(w[e] << 16);
+          bsum[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u);
+        }
+      }
     }
   };
 
@@ -120,6 +137,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const uint16_t* __restric
     }
     if (s + 1 < s_end) write_slab(buf ^ 1);
     __syncthreads();
+  }
+  if (do_bias) {
+    // 16 threads (tid >> 4) hold partial sums of the same 8 columns: combined through LDS in thread order (fixed order)
+    float* sb = reinterpret_cast<float*>(&sm[0][0][0]);           // [16][128]; the slab buffers are free after the loop's last barrier
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sb[(tid >> 4) * 128 + (tid & 15) * 8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < 128) {
+      float a = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a += sb[r * 128 + tid];
+      if (n0 + tid < N) bpart[(size_t)blockIdx.y * N + n0 + tid] = a;
+    }
   }
   // partial of this token range: part[split][n][k]; accumulator element r of tile (i,j) = row n 4g+r, column k lane&15
   float* po = part + (size_t)blockIdx.y * N * K;
@@ -187,6 +217,50 @@ __global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __rest
     for (int i = 0; i < 4; ++i)
       if (e + i < count) dst[e + i] = (accumulate ? dst[e + i] : 0.f) + t[i];
   }
+}
+
+// the same for TWO results in one launch (a Linear's weight and bias gradient, a LayerNorm's d_gamma and d_beta): blocks
+// 0 .. nb0-1 reduce (part0, count0, dst0), the others (part1, count1, dst1); counts are multiples of 4
+__global__ __launch_bounds__(256) void partial_reduce2_kernel(const float* __restrict__ part0, size_t count0, float* __restrict__ dst0,
+                                                              const float* __restrict__ part1, size_t count1, float* __restrict__ dst1,
+                                                              int S, int nb0, int accumulate) {
+  __shared__ float4 red[3][64];
+  const bool second = (int)blockIdx.x >= nb0;
+  const float* part = second ? part1 : part0;
+  const size_t count = second ? count1 : count0;
+  float* dst = second ? dst1 : dst0;
+  const int cx = threadIdx.x & 63, y = threadIdx.x >> 6;
+  const size_t e = ((size_t)(second ? blockIdx.x - nb0 : blockIdx.x) * 64 + cx) * 4;
+  const bool ok = e + 4 <= count;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) {
+    int s = y;
+    for (; s + 12 < S; s += 16) {
+      const float4 v0 = *reinterpret_cast<const float4*>(part + (size_t)s * count + e);
+      const float4 v1 = *reinterpret_cast<const float4*>(part + (size_t)(s + 4) * count + e);
+      const float4 v2 = *reinterpret_cast<const float4*>(part + (size_t)(s + 8) * count + e);
+      const float4 v3 = *reinterpret_cast<const float4*>(part + (size_t)(s + 12) * count + e);
+      a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
+      a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; s < S; s += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(part + (size_t)s * count + e);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  }
+  if (y > 0) red[y - 1][cx] = a;
+  __syncthreads();
+  if (y > 0 || !ok) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    const float4 v = red[w][cx];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  if (accumulate) {
+    const float4 d = *reinterpret_cast<const float4*>(dst + e);
+    a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+  }
+  *reinterpret_cast<float4*>(dst + e) = a;
 }
 
 // column sums of a bf16 matrix: grid (ceil(N/512), S); thread = 2 adjacent columns; part[s][n]
@@ -266,7 +340,9 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const uint16_t* __restric
 //   d_gamma += dy * xhat, d_beta += dy   (per-workgroup partials part[2][wg][D], reduced in a second kernel)
 // Row scatter (idx != NULL): the LayerNorm ran on gathered rows [B, K+1(+1)] (topk.py:89-95); row r of image b goes to row
 // (r == 0 ? 0 : 1 + idx[b,r-1]) of the [B, n_out] gradient, and EViT's fused row r == K+1 to g_fused[b] (fp32 [B, D]).
-template <int NCH>
+// ADD (K-Medoids: the gathered ids may repeat -- an empty cluster's medoid is token 0, kmedoids.py:74-79): the scattered rows are
+// ADDED to the zero-filled destination with float atomics and no bf16 copy is written (the caller converts afterwards).
+template <int NCH, bool ADD>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const uint16_t* __restrict__ dy, const float* __restrict__ x, long ldx,
                                                      const float* __restrict__ gamma, const float* __restrict__ g_in, long ldgi,
                                                      float* __restrict__ g_out, long ldgo, uint16_t* __restrict__ gb_out,
@@ -334,6 +410,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const uint16_t* __restrict_
         o.w = gi[c].w + rstd * (d[c].w - m1 - v[c].w * m2);
         if (fused) {
           *reinterpret_cast<float4*>(g_fused + (size_t)(row / n_in) * D + 4 * ch) = o;
+        } else if (ADD) {
+          float* gp = g_out + orow * ldgo + 4 * ch;
+          atomicAdd(gp, o.x); atomicAdd(gp + 1, o.y); atomicAdd(gp + 2, o.z); atomicAdd(gp + 3, o.w);
         } else {
           ln_nt_store4(o, g_out + orow * ldgo + 4 * ch);
           if (gb_out != nullptr) {
@@ -667,6 +746,11 @@ inline int reduce_partials(const float* part, int S, size_t count, float* dst, i
   return 0;
 }
 
+inline void reduce_partials2(const float* p0, size_t c0, float* d0, const float* p1, size_t c1, float* d1, int S, int accumulate, hipStream_t st) {
+  const int nb0 = (int)((c0 / 4 + 63) / 64), nb1 = (int)((c1 / 4 + 63) / 64);
+  hipLaunchKernelGGL(partial_reduce2_kernel, dim3(nb0 + nb1), dim3(256), 0, st, p0, c0, d0, p1, c1, d1, S, nb0, accumulate);
+}
+
 }  // namespace
 
 extern "C" size_t tr_wgrad_workspace_floats(int M, int N, int K) {
@@ -676,7 +760,7 @@ extern "C" size_t tr_wgrad_workspace_floats(int M, int N, int K) {
   int S = 1024 / tiles;
   if (S < 1) S = 1;
   if (S > nslab) S = nslab;
-  return (size_t)S * N * K;
+  return (size_t)S * N * K + (size_t)S * N;         // weight partials, then the bias partials of tr_linear_bwd_params
 }
 
 extern "C" int tr_wgrad_bf16(const uint16_t* dY, long ldy, int yskip, const uint16_t* X, long ldx, float* dW, int accumulate, float* ws,
@@ -697,10 +781,40 @@ extern "C" int tr_wgrad_bf16(const uint16_t* dY, long ldy, int yskip, const uint
   S = (nslab + sps - 1) / sps;                 // every split owns at least one slab
   hipStream_t st = static_cast<hipStream_t>(s);
   tr_prof_note("wgrad_kernel", 2.0 * M * N * K, 2.0 * ((double)M * N + (double)M * K) + 4.0 * S * N * K);
-  hipLaunchKernelGGL(wgrad_kernel, dim3(tiles, S), dim3(256), 0, st, dY, ldy, yskip, X, ldx, ws, M, N, K, nNt, sps);
+  hipLaunchKernelGGL(wgrad_kernel<false>, dim3(tiles, S), dim3(256), 0, st, dY, ldy, yskip, X, ldx, ws, static_cast<float*>(nullptr), M, N, K, nNt, sps);
   TR_CHECK_LAUNCH("tr_wgrad_bf16");
   reduce_partials(ws, S, (size_t)N * K, dW, accumulate, st);
   TR_CHECK_LAUNCH("tr_wgrad_bf16 (reduce)");
+  return TR_OK;
+}
+
+// nn.Linear parameter gradients in one pass over dY: dW[N,K] (+)= dY^T X and db[N] (+)= column sums of dY (tr_wgrad_bf16 +
+// tr_colsum_bf16 fused: the bias sums come out of the weight-gradient kernel's staging registers), one reduce launch for both.
+extern "C" int tr_linear_bwd_params(const uint16_t* dY, long ldy, int yskip, const uint16_t* X, long ldx, float* dW, float* db, int accumulate,
+                                    float* ws, size_t ws_floats, int M, int N, int K, tr_stream_t s) {
+  TR_REQUIRE(dY && X && dW && db && ws, TR_ERR_NULL, "tr_linear_bwd_params: null pointer");
+  TR_REQUIRE(M > 0 && N >= 8 && K >= 8 && N % 8 == 0 && K % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0 && ldy >= N && ldx >= K && yskip >= 0,
+             TR_ERR_SHAPE, "tr_linear_bwd_params: need N,K,ldy,ldx multiples of 8 (M=%d N=%d K=%d ldy=%ld ldx=%ld)", M, N, K, ldy, ldx);
+  TR_REQUIRE(tr_aligned16(dY) && tr_aligned16(X) && tr_aligned16(dW) && tr_aligned16(db) && tr_aligned16(ws), TR_ERR_ALIGN,
+             "tr_linear_bwd_params: pointers must be 16-byte aligned");
+  const int nNt = (N + WB - 1) / WB, nKt = (K + WB - 1) / WB, tiles = nNt * nKt;
+  const int nslab = (M + WM - 1) / WM;
+  int S = 1024 / tiles;
+  if (S < 1) S = 1;
+  if (S > nslab) S = nslab;
+  const size_t per = (size_t)N * K + (size_t)N;
+  const size_t fit = ws_floats / per;
+  TR_REQUIRE(fit >= 1, TR_ERR_SHAPE, "tr_linear_bwd_params: workspace of %zu floats cannot hold one partial", ws_floats);
+  if ((size_t)S > fit) S = (int)fit;
+  const int sps = (nslab + S - 1) / S;
+  S = (nslab + sps - 1) / sps;
+  float* bpart = ws + (size_t)S * N * K;
+  hipStream_t st = static_cast<hipStream_t>(s);
+  tr_prof_note("wgrad_kernel", 2.0 * M * N * K, 2.0 * ((double)M * N + (double)M * K) + 4.0 * S * N * K);
+  hipLaunchKernelGGL(wgrad_kernel<true>, dim3(tiles, S), dim3(256), 0, st, dY, ldy, yskip, X, ldx, ws, bpart, M, N, K, nNt, sps);
+  TR_CHECK_LAUNCH("tr_linear_bwd_params");
+  reduce_partials2(ws, (size_t)N * K, dW, bpart, (size_t)N, db, S, accumulate, st);
+  TR_CHECK_LAUNCH("tr_linear_bwd_params (reduce)");
   return TR_OK;
 }
 
@@ -759,10 +873,10 @@ static inline int ln_bwd_grid(int M) {
 
 extern "C" size_t tr_layernorm_bwd_workspace_floats(int M, int D) { return (size_t)ln_bwd_grid(M) * 2 * D; }
 
-extern "C" int tr_layernorm_bwd(const uint16_t* dy, const float* x, long ldx, const float* gamma, const float* g_in, long ldgi,
-                                float* g_out, long ldgo, uint16_t* gb_out, const int32_t* idx, int K, int n_in, int n_out,
-                                float* g_fused, float* dgamma, float* dbeta, int accumulate, float* ws, size_t ws_floats, int M, int D,
-                                float eps, tr_stream_t s) {
+static int layernorm_bwd_impl(const uint16_t* dy, const float* x, long ldx, const float* gamma, const float* g_in, long ldgi,
+                              float* g_out, long ldgo, uint16_t* gb_out, const int32_t* idx, int K, int n_in, int n_out,
+                              float* g_fused, float* dgamma, float* dbeta, int accumulate, float* ws, size_t ws_floats, int M, int D,
+                              float eps, bool scatter_add, tr_stream_t s) {
   TR_REQUIRE(dy && x && gamma && g_out && dgamma && dbeta && ws, TR_ERR_NULL, "tr_layernorm_bwd: null pointer");
   TR_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAX_CHUNKS && ldx % 4 == 0 && ldgo % 4 == 0 && (g_in == nullptr || ldgi % 4 == 0),
              TR_ERR_SHAPE, "tr_layernorm_bwd: need D %% 4 == 0, D <= 1024, strides %% 4 == 0 (M=%d D=%d)", M, D);
@@ -776,13 +890,34 @@ extern "C" int tr_layernorm_bwd(const uint16_t* dy, const float* x, long ldx, co
              TR_ERR_ALIGN, "tr_layernorm_bwd: pointers must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(s);
   tr_prof_note("ln_bwd_kernel", 0.0, (double)M * D * (2.0 + 4.0 + (g_in ? 4.0 : 0.0) + 4.0 + (gb_out ? 2.0 : 0.0)));
-  TR_DISPATCH_NCH(D, hipLaunchKernelGGL((ln_bwd_kernel<NCH>), dim3(grid), dim3(256), 0, st, dy, x, ldx, gamma, g_in, ldgi, g_out, ldgo, gb_out, idx,
-                                        K, n_in, n_out, g_fused, ws, M, D, eps));
+  if (scatter_add)
+    TR_DISPATCH_NCH(D, hipLaunchKernelGGL((ln_bwd_kernel<NCH, true>), dim3(grid), dim3(256), 0, st, dy, x, ldx, gamma, g_in, ldgi, g_out, ldgo,
+                                          static_cast<uint16_t*>(nullptr), idx, K, n_in, n_out, g_fused, ws, M, D, eps));
+  else
+    TR_DISPATCH_NCH(D, hipLaunchKernelGGL((ln_bwd_kernel<NCH, false>), dim3(grid), dim3(256), 0, st, dy, x, ldx, gamma, g_in, ldgi, g_out, ldgo, gb_out,
+                                          idx, K, n_in, n_out, g_fused, ws, M, D, eps));
   TR_CHECK_LAUNCH("tr_layernorm_bwd");
-  reduce_partials(ws, grid, (size_t)D, dgamma, accumulate, st);
-  reduce_partials(ws + (size_t)grid * D, grid, (size_t)D, dbeta, accumulate, st);
+  reduce_partials2(ws, (size_t)D, dgamma, ws + (size_t)grid * D, (size_t)D, dbeta, grid, accumulate, st);
   TR_CHECK_LAUNCH("tr_layernorm_bwd (reduce)");
   return TR_OK;
+}
+
+extern "C" int tr_layernorm_bwd(const uint16_t* dy, const float* x, long ldx, const float* gamma, const float* g_in, long ldgi,
+                                float* g_out, long ldgo, uint16_t* gb_out, const int32_t* idx, int K, int n_in, int n_out,
+                                float* g_fused, float* dgamma, float* dbeta, int accumulate, float* ws, size_t ws_floats, int M, int D,
+                                float eps, tr_stream_t s) {
+  return layernorm_bwd_impl(dy, x, ldx, gamma, g_in, ldgi, g_out, ldgo, gb_out, idx, K, n_in, n_out, g_fused, dgamma, dbeta, accumulate, ws,
+                            ws_floats, M, D, eps, false, s);
+}
+
+// As tr_layernorm_bwd with idx, for gathers whose ids may REPEAT (K-Medoids' medoid rows): rows are ADDED into the zero-filled g_out
+// (float atomics); no bf16 copy is written.
+extern "C" int tr_layernorm_bwd_scatter_add(const uint16_t* dy, const float* x, const float* gamma, const float* g_in, float* g_out,
+                                            const int32_t* idx, int K, int n_out, float* dgamma, float* dbeta, int accumulate, float* ws,
+                                            size_t ws_floats, int M, int D, float eps, tr_stream_t s) {
+  TR_REQUIRE(idx != nullptr, TR_ERR_NULL, "tr_layernorm_bwd_scatter_add: idx is required");
+  return layernorm_bwd_impl(dy, x, D, gamma, g_in, D, g_out, D, nullptr, idx, K, K + 1, n_out, nullptr, dgamma, dbeta, accumulate, ws, ws_floats,
+                            M, D, eps, true, s);
 }
 
 // dl16: bf16 scratch [B, C]; ws: tr_wgrad_workspace_floats(B, C, D) floats

@@ -11,7 +11,8 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 // families whose training path (saved activations + backward) is built
 inline bool trainable_family(int family) {
   return family == TR_FAMILY_DEIT || family == TR_FAMILY_TOPK || family == TR_FAMILY_EVIT || family == TR_FAMILY_TOME ||
-         family == TR_FAMILY_DPCKNN || family == TR_FAMILY_ATS || family == TR_FAMILY_DYVIT;
+         family == TR_FAMILY_DPCKNN || family == TR_FAMILY_ATS || family == TR_FAMILY_DYVIT || family == TR_FAMILY_KMEDOIDS ||
+         family == TR_FAMILY_HEURISTIC;
 }
 
 // tokens (incl. CLS) entering block i, inside its attention, and inside its MLP: the rules of tr_vit_forward

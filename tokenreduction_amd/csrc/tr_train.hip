@@ -3,8 +3,8 @@
 // The reference's training step is `output = model(samples); loss = criterion(...); loss.backward()` (engine.py:50-76) with
 // torch.autograd deriving the backward of the eager ops; under DistributedDataParallel (train.py:405-407) the parameter
 // gradients are all-reduced in buckets while the backward is still running.  Here the backward is one fixed launch sequence over
-// the tape the forward left (tr_plan.h): block by block in reverse, for each nn.Linear a weight-gradient GEMM (tr_wgrad_bf16), a
-// bias column sum and a data-gradient GEMM (tr_gemm_bf16 on the transposed weight), the attention / LayerNorm / GELU backward
+// the tape the forward left (tr_plan.h): block by block in reverse, for each nn.Linear a weight-gradient GEMM that also sums the bias
+// gradient (tr_linear_bwd_params) and a data-gradient GEMM (tr_gemm_bf16 on the transposed weight), the attention / LayerNorm / GELU backward
 // kernels, and the backward of the block's token reduction (Top-K scatter topk.py:89-93, EViT fused token evit.py:111-123, ToMe
 // merge tome.py:309-323).  A call may cover a RANGE of blocks [blk_hi .. blk_lo]: the caller walks the model in a few ranges and,
 // after each, starts that range's gradient bucket on RCCL from a second stream while the next range runs (the DDP overlap).
@@ -166,12 +166,10 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
     const int Na = t.n_att[i], Nm = t.n_mlp[i];
     const int M2 = B * Nm, M1 = B * Na;
     // ---- mlp: x2 -> norm2 -> fc1 -> gelu -> fc2 -> (+ residual)
-    TR_TRY(tr_wgrad_bf16(gb, D, 0, U(tape + bt.h), Hd, F(bg->fc2_w), acc, wsf, wsn, M2, D, Hd, s));
-    TR_TRY(tr_colsum_bf16(gb, D, 0, F(bg->fc2_b), acc, wsf, wsn, M2, D, s));
+    TR_TRY(tr_linear_bwd_params(gb, D, 0, U(tape + bt.h), Hd, F(bg->fc2_w), F(bg->fc2_b), acc, wsf, wsn, M2, D, Hd, s));
     TR_TRY(tr_gemm_bf16(gb, U(bwt->fc2_w), zeros, dh, nullptr, 0, M2, Hd, D, TR_EPI_BF16, s));
     TR_TRY(tr_gelu_bwd_bf16(U(tape + bt.pre), dh, (size_t)M2 * Hd, s));
-    TR_TRY(tr_wgrad_bf16(dh, Hd, 0, U(tape + bt.xn2), D, F(bg->fc1_w), acc, wsf, wsn, M2, Hd, D, s));
-    TR_TRY(tr_colsum_bf16(dh, Hd, 0, F(bg->fc1_b), acc, wsf, wsn, M2, Hd, s));
+    TR_TRY(tr_linear_bwd_params(dh, Hd, 0, U(tape + bt.xn2), D, F(bg->fc1_w), F(bg->fc1_b), acc, wsf, wsn, M2, Hd, D, s));
     TR_TRY(tr_gemm_bf16(dh, U(bwt->fc1_w), zeros, dxn, nullptr, 0, M2, D, Hd, TR_EPI_BF16, s));
     // ---- norm2 (+ the block's in-block token reduction)
     const float* x2 = reinterpret_cast<const float*>(tape + bt.x2);
@@ -213,8 +211,7 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
     // ---- attention: x1 -> norm1 -> qkv -> softmax(q k^T) v -> proj -> (+ residual)
     const bool ats_sampled = cfg->family == TR_FAMILY_ATS && K > 0;
     const int Mp = ats_sampled ? M2 : M1;                   // rows that went through proj (ATS: only the sampled ones, ats.py:86,129)
-    TR_TRY(tr_wgrad_bf16(gb, D, 0, U(tape + bt.ao), D, F(bg->proj_w), acc, wsf, wsn, Mp, D, D, s));
-    TR_TRY(tr_colsum_bf16(gb, D, 0, F(bg->proj_b), acc, wsf, wsn, Mp, D, s));
+    TR_TRY(tr_linear_bwd_params(gb, D, 0, U(tape + bt.ao), D, F(bg->proj_w), F(bg->proj_b), acc, wsf, wsn, Mp, D, D, s));
     if (ats_sampled) {
       // d(attn @ v) of the sampled rows and the stream's gradient go back to the rows they were sampled from (ats.py:86,157)
       TR_TRY(tr_gemm_bf16(gb, U(bwt->proj_w), zeros, dxn, nullptr, 0, Mp, D, D, TR_EPI_BF16, s));
@@ -230,6 +227,9 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
     if (cfg->family == TR_FAMILY_TOME || cfg->family == TR_FAMILY_ATS)
       for (int j = i - 1; j >= 0; --j)
         if (t.kk[j] > 0) { size_att = reinterpret_cast<const float*>(tape + tp.blk[j].size); break; }
+    if (cfg->family == TR_FAMILY_HEURISTIC)          // the spatial key mask in force at this block: the last one set at or before it
+      for (int j = i; j >= 0; --j)
+        if (w->stage[j].w3 != nullptr) { size_att = reinterpret_cast<const float*>(tape + tp.blk[j].size); break; }
     if (cfg->family == TR_FAMILY_DYVIT) {
       // the policy this block attended under: the last predictor stage at or before it, all ones before the first
       const float* pol = reinterpret_cast<const float*>(tape + tp.ones);
@@ -241,11 +241,21 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
     } else {
       TR_TRY(tr_attention_bwd_bf16(U(tape + bt.qkv), dao, size_att, dcls, dqkv, B, Na, H, s));
     }
-    TR_TRY(tr_wgrad_bf16(dqkv, 3 * D, 0, U(tape + bt.xn1), D, F(bg->qkv_w), acc, wsf, wsn, M1, 3 * D, D, s));
-    TR_TRY(tr_colsum_bf16(dqkv, 3 * D, 0, F(bg->qkv_b), acc, wsf, wsn, M1, 3 * D, s));
+    TR_TRY(tr_linear_bwd_params(dqkv, 3 * D, 0, U(tape + bt.xn1), D, F(bg->qkv_w), F(bg->qkv_b), acc, wsf, wsn, M1, 3 * D, D, s));
     TR_TRY(tr_gemm_bf16(dqkv, U(bwt->qkv_w), zeros, dxn, nullptr, 0, M1, D, 3 * D, TR_EPI_BF16, s));
-    TR_TRY(tr_layernorm_bwd(dxn, x1, D, bw->ln1_g, g, D, g, D, gb, nullptr, 0, 0, 0, nullptr, F(bg->ln1_g), F(bg->ln1_b), acc, wsf, wsn, M1, D,
-                            cfg->ln_eps, s));
+    if (cfg->family == TR_FAMILY_KMEDOIDS && K > 0) {
+      // norm1 ran on the gathered medoid rows (kmedoids.py:243-248): its backward scatter-ADDS into the pre-reduction stream's gradient
+      const size_t nfull = (size_t)B * t.n_pre[i] * D;
+      TR_REQUIRE(hipMemsetAsync(g_alt, 0, nfull * 4, st) == hipSuccess, TR_ERR_LAUNCH, "tr_vit_backward: memset failed");
+      TR_TRY(tr_layernorm_bwd_scatter_add(dxn, x1, bw->ln1_g, g, g_alt, reinterpret_cast<const int32_t*>(tape + bt.idx), K, t.n_pre[i], F(bg->ln1_g),
+                                          F(bg->ln1_b), acc, wsf, wsn, M1, D, cfg->ln_eps, s));
+      TR_TRY(tr_f32_to_bf16(g_alt, gb_alt, nfull, s));
+      float* tg = g; g = g_alt; g_alt = tg;
+      uint16_t* tb = gb; gb = gb_alt; gb_alt = tb;
+    } else {
+      TR_TRY(tr_layernorm_bwd(dxn, x1, D, bw->ln1_g, g, D, g, D, gb, nullptr, 0, 0, 0, nullptr, F(bg->ln1_g), F(bg->ln1_b), acc, wsf, wsn, M1, D,
+                              cfg->ln_eps, s));
+    }
     if (cfg->family == TR_FAMILY_DYVIT && K > 0) {
       // PredictorLG + Gumbel straight-through of this stage (dyvit.py:221-224), backwards.  d keep = the policy gradient collected
       // from the blocks that attended under this stage's policy (+ the later stage's d prev_decision) + d out_pred_prob
@@ -267,19 +277,16 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
                                  reinterpret_cast<const float*>(tape + bt.sm), U(tape + bt.ph2), Q, sw->w3, d2, dprev, F(sg->w3), F(sg->b3), acc, wsf,
                                  wsn, B, Na, Cq, s));
       TR_TRY(tr_gelu_bwd_bf16(U(tape + bt.ppre2), d2, (size_t)M1 * Q, s));
-      TR_TRY(tr_wgrad_bf16(d2, Q, 0, U(tape + bt.ph1), Hh, F(sg->w2), acc, wsf, wsn, M1, Cq, Hh, s));
-      TR_TRY(tr_colsum_bf16(d2, Q, 0, F(sg->b2), acc, wsf, wsn, M1, Cq, s));
+      TR_TRY(tr_linear_bwd_params(d2, Q, 0, U(tape + bt.ph1), Hh, F(sg->w2), F(sg->b2), acc, wsf, wsn, M1, Cq, Hh, s));
       uint16_t* d1 = dao;                     // [M1, Hh]
       TR_TRY(tr_gemm_bf16(d2, U(swt->w2), zeros, d1, nullptr, 0, M1, Hh, Q, TR_EPI_BF16, s));
       TR_TRY(tr_gelu_bwd_bf16(U(tape + bt.ppre1), d1, (size_t)M1 * Hh, s));
-      TR_TRY(tr_wgrad_bf16(d1, Hh, 0, U(tape + bt.pcat), D, F(sg->w1), acc, wsf, wsn, M1, Hh, D, s));
-      TR_TRY(tr_colsum_bf16(d1, Hh, 0, F(sg->b1), acc, wsf, wsn, M1, Hh, s));
+      TR_TRY(tr_linear_bwd_params(d1, Hh, 0, U(tape + bt.pcat), D, F(sg->w1), F(sg->b1), acc, wsf, wsn, M1, Hh, D, s));
       TR_TRY(tr_gemm_bf16(d1, U(swt->w1), zeros, dxn, nullptr, 0, M1, D, Hh, TR_EPI_BF16, s));          // d [local | global]
       uint16_t* d0 = dh;                      // [M1, D]
       TR_TRY(tr_pool_policy_bwd(dxn, U(tape + bt.ppre0), U(tape + bt.pcat), prev, d0, dprev, B, Na, D, s));
       TR_TRY(tr_gelu_bwd_bf16(U(tape + bt.ppre0), d0, (size_t)M1 * D, s));
-      TR_TRY(tr_wgrad_bf16(d0, D, 0, U(tape + bt.pu), D, F(sg->w0), acc, wsf, wsn, M1, D, D, s));
-      TR_TRY(tr_colsum_bf16(d0, D, 0, F(sg->b0), acc, wsf, wsn, M1, D, s));
+      TR_TRY(tr_linear_bwd_params(d0, D, 0, U(tape + bt.pu), D, F(sg->w0), F(sg->b0), acc, wsf, wsn, M1, D, D, s));
       TR_TRY(tr_gemm_bf16(d0, U(swt->w0), zeros, dxn, nullptr, 0, M1, D, D, TR_EPI_BF16, s));
       TR_TRY(tr_layernorm_bwd(dxn, reinterpret_cast<const float*>(tape + bt.x0), D, sw->ln_g, g, D, g, D, gb, nullptr, 0, 0, 0, nullptr, F(sg->ln_g),
                               F(sg->ln_b), acc, wsf, wsn, M1, D, 1e-5f, s));
@@ -300,7 +307,6 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
   if (blk_lo > 0) return TR_OK;
   // ---- embedding (topk.py:181-186): g is d x0 [B, N0, D]
   TR_TRY(tr_embed_bwd(g, F(grads->pos_embed), F(grads->cls_token), acc, B, t.N0, D, s));
-  TR_TRY(tr_wgrad_bf16(gb, D, t.P, U(tape + tp.cols), kcols, F(grads->patch_w), acc, wsf, wsn, B * t.P, D, kcols, s));
-  TR_TRY(tr_colsum_bf16(gb, D, t.P, F(grads->patch_b), acc, wsf, wsn, B * t.P, D, s));
+  TR_TRY(tr_linear_bwd_params(gb, D, t.P, U(tape + tp.cols), kcols, F(grads->patch_w), F(grads->patch_b), acc, wsf, wsn, B * t.P, D, kcols, s));
   return TR_OK;
 }

@@ -303,10 +303,19 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
                                        "(the reference fails there too: `attn` is unbound, kmedoids.py:240)");
       const int kinit = cfg->kmed_init[i];             // > 0: args.equal_weight, first medoid id + 1
       TR_REQUIRE(Kc <= N - 1, TR_ERR_CONFIG, "tr_vit_forward: block %d asks for %d medoids of %d patch tokens", i, Kc, N - 1);
-      if (pending) TR_TRY(op_ln(f32, x, D, pending, D, bw->ln1_g, bw->ln1_b, xn, M, D, cfg->ln_eps, s));   // x += previous mlp output
-      pending = nullptr;
       int32_t* centers = kept_idx ? kept_idx + (size_t)i * B * p.N0 : idx_ws;
       int32_t* assign = compl_idx ? compl_idx + (size_t)i * B * p.N0 : compl_ws;
+      if (train) {          // as for DPC-KNN: the stream entering the reduction stays on the tape, the medoid rows become norm1's input slot
+        float* x0 = reinterpret_cast<float*>(tape + tp->blk[i].x0);
+        TR_TRY(tr_layernorm_bf16_to(x, D, x0, D, static_cast<const uint16_t*>(pending), D, bw->ln1_g, bw->ln1_b, static_cast<uint16_t*>(xn_shared), M,
+                                    D, cfg->ln_eps, s));
+        x = x0;
+        x_alt = reinterpret_cast<float*>(tape + tp->blk[i].x1);
+        xn = tape + tp->blk[i].xn1;
+        centers = reinterpret_cast<int32_t*>(tape + tp->blk[i].idx);
+        assign = reinterpret_cast<int32_t*>(tape + tp->blk[i].idx2);
+      } else if (pending) TR_TRY(op_ln(f32, x, D, pending, D, bw->ln1_g, bw->ln1_b, xn, M, D, cfg->ln_eps, s));   // x += previous mlp output
+      pending = nullptr;
       if (kinit > 0)
         TR_TRY(tr_kmedoids_equal(x, kinit - 1, reinterpret_cast<float*>(ws + p.off_cluster), centers, assign, B, N, D, Kc, cfg->cluster_iters,
                                  f32 ? 0 : 1, s));
@@ -321,8 +330,9 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
     if (cfg->family == TR_FAMILY_HEURISTIC && w->stage[i].w3 != nullptr) {
       // f4: a new spatial mask takes effect at this block and stays until the next one (heuristic.py:247-258)
       TR_REQUIRE(w->stage[i].n_pad == N, TR_ERR_CONFIG, "tr_vit_forward: block %d mask has %d entries for %d tokens", i, w->stage[i].n_pad, N);
-      TR_TRY(tr_broadcast_rows(w->stage[i].w3, size_a, B, N, s));
-      size_cur = size_a;
+      float* mask_dst = train ? reinterpret_cast<float*>(tape + tp->blk[i].size) : size_a;      // training keeps every block's mask
+      TR_TRY(tr_broadcast_rows(w->stage[i].w3, mask_dst, B, N, s));
+      size_cur = mask_dst;
     }
     if (cfg->family == TR_FAMILY_PATCHMERGER && cfg->keep[i] > 0) {
       // f4: PatchMerger.forward patchmerger.py:35-39 on x[:, 1:] BEFORE the block

@@ -405,6 +405,19 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, out: torch.Tensor = None, accumulat
     return out
 
 
+def linear_bwd_params(dy: torch.Tensor, x: torch.Tensor, accumulate: bool = False, dw: torch.Tensor = None, db: torch.Tensor = None):
+    """Weight and bias gradient of an nn.Linear in one pass (tr_linear_bwd_params): (dW fp32 [N,K], db fp32 [N])."""
+    M, N, K = x.shape[0], dy.shape[-1], x.shape[-1]
+    lib = _lib.load()
+    dw = torch.empty(N, K, dtype=torch.float32, device=x.device) if dw is None else dw
+    db = torch.empty(N, dtype=torch.float32, device=x.device) if db is None else db
+    ws = _ws(lib.tr_wgrad_workspace_floats(M, N, K), x.device)
+    _lib.check(lib.tr_linear_bwd_params(_dev(dy, torch.bfloat16, "dy"), N, 0, _dev(x, torch.bfloat16, "x"), K, _dev(dw, torch.float32, "dw"),
+                                        _dev(db, torch.float32, "db"), int(accumulate), ws.data_ptr(), ws.numel(), M, N, K, _stream()),
+               "tr_linear_bwd_params")
+    return dw, db
+
+
 def colsum(dy: torch.Tensor, out: torch.Tensor = None, accumulate: bool = False, yskip: int = 0, rows: int = None) -> torch.Tensor:
     """nn.Linear bias gradient db[N] (+)= sum_m dy[m,n]."""
     N = dy.shape[-1]

@@ -139,7 +139,7 @@ class TrainState:
             if nt == 0 or nb == 0:
                 raise NotImplementedError(
                     f"{type(model).__name__}: this family / configuration has no training path in the HIP executor "
-                    "(built: DeiT, Top-K, EViT, ToMe, DPC-KNN, ATS, DyViT at 224x224, bf16); call model.eval() for inference")
+                    "(built: DeiT, Top-K, EViT, ToMe, DPC-KNN, ATS, DyViT, K-Medoids, Heuristic at 224x224, bf16); call model.eval() for inference")
             self.tape = torch.empty(nt, dtype=torch.uint8, device=dev)
             self.bws = torch.empty(nb, dtype=torch.uint8, device=dev)
             self.B = B
@@ -179,6 +179,8 @@ def train_decisions(model) -> dict:
             p_in = lay["n_pre"] - 1
             raw2 = st.tape[lay["idx2"]: lay["idx2"] + 4 * B * p_in].view(torch.int32)
             out[blk] = (raw[: B * k].view(B, k).long(), raw2.view(B, p_in).long())
+        elif model._family == _lib.TR_FAMILY_KMEDOIDS:        # medoid ids [B,K]
+            out[blk] = raw[: B * k].view(B, k).long()
         elif model._family == _lib.TR_FAMILY_ATS:             # ids [B,Ks]: CLS id 0 first, 1-based token ids, 0 padding
             out[blk] = raw[: B * k].view(B, k).long()
         elif model._family == _lib.TR_FAMILY_DYVIT:           # the Gumbel one-hot's first entry per patch token [B,P] (before * prev_decision)
