@@ -278,6 +278,7 @@ int tr_tome_merge_bwd(const float* g_merged, const float* size_in, const float* 
                       const int32_t* src_idx, const int32_t* dst_idx, int32_t* inv_map, float* g_out, uint16_t* gb_out, int B, int N,
                       int r, int D, tr_stream_t s);
 int tr_f32_to_bf16(const float* src, uint16_t* dst, size_t n, tr_stream_t s);
+int tr_rowscale_bf16(const uint16_t* src, uint16_t* dst, const float* scale, int B, int rows, int D, tr_stream_t s);   /* dst[b,r,:] = src[b,r,:] * scale[b] */
 int tr_reduce_partials_f32(const float* part, int S, size_t count, float* dst, int accumulate, tr_stream_t s);   /* dst (+)= sum_s part[s] */
 /* ---- DyViT training pieces (csrc/tr_dyvit_train.hip, csrc/tr_attention_bwd.hip): see the file headers.  policy / prev / outputs are
  * fp32 [B,N] with entry 0 = the CLS token (always 1); gumbel fp32 [B,N-1,2]. */
@@ -404,7 +405,9 @@ int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w, const floa
  * norm of every row (the distillation features, dyvit.py:252-258); tr_vit_backward takes dpred fp32 [stages,B,P] (gradient wrt each
  * stage's out_pred_prob) and dfeat fp32 [B,N0,D] (gradient wrt features_out), both nullable.
  * tr_vit_forward_train: as tr_vit_forward, and every activation the backward needs is written to `tape` (tr_vit_tape_bytes(cfg, B)
- *   bytes, caller-owned; 0 = family / precision without a training path).  Dropout / DropPath rates are 0 (the caller applies none).
+ *   bytes, caller-owned; 0 = family / precision without a training path).  drop_scale (nullable, both calls get the same): DropPath
+ *   (timm 0.4.12 drop_path, topk.py:78,87,95) as fp32 [2*depth, B]: entry [2i][b] / [2i+1][b] = the scale (0 or 1/keep_prob) of
+ *   image b's attention / MLP branch in block i -- the random draw is the caller's.  Dropout (drop_rate) is not built.
  * tr_vit_backward: dlogits fp32 [B,classes] -> parameter gradients.  `w` = the forward's weights; `wt` = same struct with the block
  *   matrices TRANSPOSED (bf16: qkv_w [D,3D], proj_w [D,D], fc1_w [D,Hd], fc2_w [Hd,D]); `grads` = same struct, every pointer an
  *   fp32 buffer of the parameter's shape (written; added to when accumulate != 0).  workspace: tr_vit_backward_workspace_bytes.
@@ -415,14 +418,15 @@ int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w, const floa
 size_t tr_vit_tape_bytes(const tr_vit_config* cfg, int B);
 int tr_vit_forward_train(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits, void* workspace,
                          size_t workspace_bytes, void* tape, size_t tape_bytes, const float* noise_in, float* features_out,
-                         int* tokens_out, int B, tr_stream_t s);
+                         const float* drop_scale, int* tokens_out, int B, tr_stream_t s);
 /* Byte offsets of block blk's tape slots (x0,x1,xn1,qkv,ao,dattn,x2,xn2,pre,h,idx,idx2,scores,size) followed by its token counts
  * (entering, in attention, in the MLP) and its reduction count: lets a host read the decisions of a training forward. */
 int tr_vit_tape_layout(const tr_vit_config* cfg, int B, int blk, size_t* out18);
 size_t tr_vit_backward_workspace_bytes(const tr_vit_config* cfg, int B);
 int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w, const tr_vit_weights* wt, const tr_vit_weights* grads,
-                    const float* dlogits, const float* dpred, const float* dfeat, const void* tape, size_t tape_bytes, void* workspace,
-                    size_t workspace_bytes, int accumulate, int blk_hi, int blk_lo, int B, tr_stream_t s);
+                    const float* dlogits, const float* dpred, const float* dfeat, const float* drop_scale, const void* tape,
+                    size_t tape_bytes, void* workspace, size_t workspace_bytes, int accumulate, int blk_hi, int blk_lo, int B,
+                    tr_stream_t s);
 
 #ifdef __cplusplus
 }

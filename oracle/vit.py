@@ -196,7 +196,7 @@ def evit_fuse(x: Tensor, idx: Tensor, scores: Tensor) -> Tuple[Tensor, Tensor]:
 
 # --------------------------------------------------------------------------- block / model
 def block_forward(x: Tensor, p: Dict[str, Tensor], i: int, cfg: VitConfig, keep: Optional[int],
-                  precision: str = "fp32", forced_idx: Optional[Tensor] = None):
+                  precision: str = "fp32", forced_idx: Optional[Tensor] = None, drop: Optional[Tensor] = None):
     """Block_TopK.forward topk.py:83-99 / Block_EVIT.forward evit.py:105-129 /
     deit_viz.Block.forward :69-72 (keep=None).  Returns (x, idx|None, compl|None).
 
@@ -207,7 +207,8 @@ def block_forward(x: Tensor, p: Dict[str, Tensor], i: int, cfg: VitConfig, keep:
     a, cls_rows = attention(xn, p[pre + "attn.qkv.weight"], p[pre + "attn.qkv.bias"],
                             p[pre + "attn.proj.weight"], p[pre + "attn.proj.bias"],
                             cfg.num_heads, precision)
-    x = x + a
+    # drop [2,B] (training only): timm DropPath's per-image scale (0 or 1/keep_prob) of the attention / MLP branch, topk.py:87,95
+    x = x + (a if drop is None else _r(a * drop[0][:, None, None], precision))
     idx = compl = None
     N = x.shape[1]
     # topk.py:55-58: keep_rate<1 and left_tokens != N-1, else the block is a plain block
@@ -221,14 +222,14 @@ def block_forward(x: Tensor, p: Dict[str, Tensor], i: int, cfg: VitConfig, keep:
         else:
             x = gather_compact(x, idx)
     xn2 = layer_norm(x, p[pre + "norm2.weight"], p[pre + "norm2.bias"], cfg.ln_eps, precision)
-    x = x + mlp(xn2, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"],
-                p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"], precision)
+    m = mlp(xn2, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"], p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"], precision)
+    x = x + (m if drop is None else _r(m * drop[1][:, None, None], precision))
     return x, idx, compl
 
 
 @torch.no_grad()
 def vit_forward(params: Dict[str, Tensor], x: Tensor, cfg: VitConfig, precision: str = "fp32",
-                return_viz: bool = False, forced: Optional[Dict[int, Tensor]] = None):
+                return_viz: bool = False, forced: Optional[Dict[int, Tensor]] = None, drop: Optional[Tensor] = None):
     """TopKVisionTransformer.forward topk.py:179-212 / EfficientVisionTransformer.forward
     evit.py:209-244 / deit_viz.VisionTransformer.forward :186-212 (eval mode).
 
@@ -243,7 +244,8 @@ def vit_forward(params: Dict[str, Tensor], x: Tensor, cfg: VitConfig, precision:
     keeps = stage_keep_counts(cfg) if cfg.family in ("topk", "evit") else {}
     viz = {"Kept_Tokens": {}, "Fusion_Assign": {}, "Tokens": {}}
     for i in range(cfg.depth):
-        h, idx, compl = block_forward(h, p, i, cfg, keeps.get(i), precision, None if forced is None else forced.get(i))
+        h, idx, compl = block_forward(h, p, i, cfg, keeps.get(i), precision, None if forced is None else forced.get(i),
+                                      None if drop is None else drop[2 * i: 2 * i + 2])           # drop [2*depth, B]: DropPath scales
         viz["Tokens"][i] = h.shape[1]
         if idx is not None:
             if cfg.family == "evit":

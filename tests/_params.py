@@ -142,6 +142,9 @@ GOLDEN_CASES = {
     "dyvit_small_kr07": dict(family="dyvit", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
                              keep_rate=[0.7], reduction_loc=[3, 6, 9], batch=2, wseed=103, xseed=104,
                              qkv_gain=4.0, factory="dyvit_small_patch16_224"),
+    # DropPath in training (timm drop_path, topk.py:78,87,95; train.py's default --drop-path 0.1): gradient fixture only
+    "topk_micro_droppath": dict(family="topk", embed_dim=128, depth=4, num_heads=2, num_classes=16, drop_path=0.3, train_only=True,
+                                keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=6, wseed=13, xseed=14, qkv_gain=6.0),
     # DyViT TRAINING (dyvit.py:221-229, 257-261) with the distillation outputs: gradient fixtures only (grad_<name>.npz)
     "dyvit_micro_train": dict(family="dyvit", embed_dim=128, depth=4, num_heads=2, num_classes=16, dyvit_distill=True, train_only=True,
                               keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=105, xseed=106, qkv_gain=6.0),
@@ -232,7 +235,7 @@ GOLDEN_CASES = {
 # cross-entropy criterion) in train mode on the golden case's weights / images, labels from grad_labels().  Too large to store
 # whole (22 M values at DeiT-S), so per parameter: the L2 norm and <= 512 evenly strided entries (grad_sample_index).
 GRAD_CASES = ["deit_micro", "topk_micro", "evit_micro", "tome_micro", "dpcknn_micro", "dpcknn_micro_equal", "ats_micro", "topk_small_kr07",
-              "evit_small_kr07", "tome_small_r16", "deit_base", "dpcknn_base_kr05", "ats_base_kr05", "dyvit_micro_train", "dyvit_small_train", "kmedoids_micro", "heuristic_micro_l2"]
+              "evit_small_kr07", "tome_small_r16", "deit_base", "dpcknn_base_kr05", "ats_base_kr05", "dyvit_micro_train", "dyvit_small_train", "kmedoids_micro", "heuristic_micro_l2", "topk_micro_droppath"]
 
 
 def dyvit_token_ratio(case: dict):
@@ -269,6 +272,23 @@ def grad_sample_index(numel: int):
     return np.unique(np.linspace(0, numel - 1, min(numel, 512)).astype(np.int64))
 
 
+def drop_path_draws(case: dict, rand_calls):
+    """[2*depth, B] uniform draws for tokenreduction_amd's DropPath from the reference's recorded torch.rand calls: block 0 has
+    drop probability 0 (an nn.Identity: no draw, topk.py:78,157), every later block draws twice (attention branch, MLP branch)."""
+    B, depth = case["batch"], case["depth"]
+    assert len(rand_calls) == 2 * (depth - 1), len(rand_calls)
+    u = torch.zeros(2 * depth, B)
+    for n, r in enumerate(rand_calls):
+        u[2 + n] = torch.as_tensor(r).reshape(B)
+    return u
+
+
+def drop_path_scale(case: dict, draws):
+    dpr = torch.linspace(0, case["drop_path"], case["depth"])
+    keep = (1.0 - dpr).repeat_interleave(2).unsqueeze(1)
+    return (keep + draws).floor() / keep
+
+
 def oracle_param_grads(case: dict, forced=None, precision: str = "fp32", noise=None):
     """Parameter gradients of cross-entropy(oracle logits, grad_labels) by torch.autograd over the oracle's functional forward
     (the reference's backward IS torch.autograd over its eager forward, engine.py:60-76).  Returns (loss, logits, {name: grad}).
@@ -296,7 +316,8 @@ def oracle_param_grads(case: dict, forced=None, precision: str = "fp32", noise=N
         elif fam == "ats":
             logits = oracle.ats_forward.__wrapped__(leaves, x, cfg, precision, False, False, forced)
         else:
-            logits = oracle.vit_forward.__wrapped__(leaves, x, cfg, precision, False, forced)
+            drop = drop_path_scale(case, noise) if case.get("drop_path") else None       # noise = the [2*depth, B] uniform draws
+            logits = oracle.vit_forward.__wrapped__(leaves, x, cfg, precision, False, forced, drop)
         loss = torch.nn.functional.cross_entropy(logits, grad_labels(case))
         loss.backward()
     return loss.item(), logits.detach(), {k: (v.grad if v.grad is not None else torch.zeros_like(v)) for k, v in leaves.items()}

@@ -42,6 +42,11 @@ def _noise(case, golden_dir):
         name = [n for n, c in GOLDEN_CASES.items() if c is case][0]
         g = np.load(os.path.join(golden_dir, f"grad_{name}.npz"))
         return {n: torch.from_numpy(g[f"gumbel_{n}"]) for n in range(len(case["reduction_loc"]))}
+    if case.get("drop_path"):
+        from tests._params import drop_path_draws
+        name = [n for n, c in GOLDEN_CASES.items() if c is case][0]
+        g = np.load(os.path.join(golden_dir, f"grad_{name}.npz"))
+        return drop_path_draws(case, [g[k] for k in sorted((k for k in g.files if k.startswith("rand_")), key=lambda k: int(k.split("_")[1]))])
     if case["family"] != "dpcknn":
         return None
     import oracle
@@ -56,7 +61,9 @@ def _train_step(case, noise=None):
     model, params, cfg = build_model(case)
     model.viz_mode = False
     model.train()
-    if noise is not None and case["family"] == "dyvit":
+    if noise is not None and case.get("drop_path"):
+        model.drop_path_draws = noise                       # the reference's DropPath draws [2*depth, B]
+    elif noise is not None and case["family"] == "dyvit":
         model.gumbel_noise = noise                          # the reference's Gumbel draws, stage by stage
     elif noise is not None:
         model.density_noise = noise

@@ -29,6 +29,9 @@ def fixture_inputs(case, g):
         noise = {blk: torch.from_numpy(g[f"rand_{n}"]) for n, blk in enumerate(sorted(dpcknn_cluster_counts(cfg)))}
     if case["family"] == "ats":
         forced = {blk: torch.from_numpy(g[f"atsids_{n}"]) for n, blk in enumerate(sorted(b for b, c in ats_sample_counts(cfg).items() if c))}
+    if case.get("drop_path"):          # the reference's DropPath draws (torch.rand per branch and image), replayed
+        from tests._params import drop_path_draws
+        noise = drop_path_draws(case, [g[k] for k in sorted((k for k in g.files if k.startswith("rand_")), key=lambda k: int(k.split("_")[1]))])
     if case["family"] == "dyvit":      # the Gumbel noise the reference drew, stage by stage (F.gumbel_softmax, dyvit.py:224)
         noise = {n: torch.from_numpy(g[f"gumbel_{n}"]) for n in range(len(case["reduction_loc"]))}
     return forced, noise

@@ -729,6 +729,22 @@ __global__ __launch_bounds__(256) void ats_scatter_kernel(const float* __restric
   }
 }
 
+// DropPath (timm 0.4.12: x.div(keep_prob) * floor(keep_prob + rand), one draw per image; call sites topk.py:87,95): dst[b, r, :] =
+// src[b, r, :] * scale[b] for bf16 rows; scale[b] is 0 or 1/keep_prob.  Applied to a branch's output before the residual add, and to
+// the stream's gradient before it enters that branch's backward.  One 16-byte chunk per thread.
+__global__ __launch_bounds__(256) void rowscale_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, const float* __restrict__ scale,
+                                                       size_t nchunks, size_t chunks_per_image) {
+  const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= nchunks) return;
+  const float sc = scale[c / chunks_per_image];
+  const uint4 u = *reinterpret_cast<const uint4*>(src + 8 * c);
+  const unsigned int w[4] = {u.x, u.y, u.z, u.w};
+  unsigned int o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = pack_bf16x2(__uint_as_float(w[i] << 16) * sc, __uint_as_float(w[i] & 0xffff0000u) * sc);
+  *reinterpret_cast<uint4*>(dst + 8 * c) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
 // fp32 rows -> bf16 rows (the initial gradient of the residual stream as a GEMM operand)
 __global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t nchunks) {
   const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -1023,5 +1039,15 @@ extern "C" int tr_reduce_partials_f32(const float* part, int S, size_t count, fl
   TR_REQUIRE(part && dst && S >= 1 && count >= 1, TR_ERR_NULL, "tr_reduce_partials_f32: bad arguments");
   reduce_partials(part, S, count, dst, accumulate, static_cast<hipStream_t>(s));
   TR_CHECK_LAUNCH("tr_reduce_partials_f32");
+  return TR_OK;
+}
+
+// dst[b, r, :] = src[b, r, :] * scale[b]: bf16 [B, rows, D] (dst may be src).  DropPath's per-image scaling (see the kernel).
+extern "C" int tr_rowscale_bf16(const uint16_t* src, uint16_t* dst, const float* scale, int B, int rows, int D, tr_stream_t s) {
+  TR_REQUIRE(src && dst && scale, TR_ERR_NULL, "tr_rowscale_bf16: null pointer");
+  TR_REQUIRE(B > 0 && rows > 0 && D > 0 && D % 8 == 0, TR_ERR_SHAPE, "tr_rowscale_bf16: bad shape B=%d rows=%d D=%d", B, rows, D);
+  const size_t cpi = (size_t)rows * D / 8, n = cpi * B;
+  hipLaunchKernelGGL(rowscale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(s), src, dst, scale, n, cpi);
+  TR_CHECK_LAUNCH("tr_rowscale_bf16");
   return TR_OK;
 }

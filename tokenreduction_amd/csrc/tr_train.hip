@@ -93,8 +93,9 @@ extern "C" size_t tr_vit_backward_workspace_bytes(const tr_vit_config* cfg, int 
 // block order; dfeat (nullable) fp32 [B, N0, D]: gradient wrt the final-norm token features (distillation, losses.py:134-156; row 0 = 0).  The gradient of the residual stream stays in the
 // workspace between calls, so a backward pass is the calls (depth-1 .. a), (a-1 .. b), ..., (c .. 0) in this order.
 extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w, const tr_vit_weights* wt, const tr_vit_weights* grads,
-                               const float* dlogits, const float* dpred, const float* dfeat, const void* tape_, size_t tape_bytes,
-                               void* workspace, size_t workspace_bytes, int accumulate, int blk_hi, int blk_lo, int B, tr_stream_t s) {
+                               const float* dlogits, const float* dpred, const float* dfeat, const float* drop_scale, const void* tape_,
+                               size_t tape_bytes, void* workspace, size_t workspace_bytes, int accumulate, int blk_hi, int blk_lo, int B,
+                               tr_stream_t s) {
   TR_REQUIRE(cfg && w && wt && grads && dlogits && tape_ && workspace, TR_ERR_NULL, "tr_vit_backward: null pointer");
   TR_REQUIRE(cfg->precision == TR_PREC_BF16 && trplan::trainable_family(cfg->family), TR_ERR_CONFIG,
              "tr_vit_backward: family %d / precision %d has no training path", cfg->family, cfg->precision);
@@ -166,8 +167,13 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
     const int Na = t.n_att[i], Nm = t.n_mlp[i];
     const int M2 = B * Nm, M1 = B * Na;
     // ---- mlp: x2 -> norm2 -> fc1 -> gelu -> fc2 -> (+ residual)
-    TR_TRY(tr_linear_bwd_params(gb, D, 0, U(tape + bt.h), Hd, F(bg->fc2_w), F(bg->fc2_b), acc, wsf, wsn, M2, D, Hd, s));
-    TR_TRY(tr_gemm_bf16(gb, U(bwt->fc2_w), zeros, dh, nullptr, 0, M2, Hd, D, TR_EPI_BF16, s));
+    const uint16_t* gy = gb;          // the branch's dY: the stream gradient, times the branch's DropPath scale when there is one
+    if (drop_scale != nullptr) {
+      TR_TRY(tr_rowscale_bf16(gb, dao, drop_scale + (size_t)(2 * i + 1) * B, B, Nm, D, s));
+      gy = dao;
+    }
+    TR_TRY(tr_linear_bwd_params(gy, D, 0, U(tape + bt.h), Hd, F(bg->fc2_w), F(bg->fc2_b), acc, wsf, wsn, M2, D, Hd, s));
+    TR_TRY(tr_gemm_bf16(gy, U(bwt->fc2_w), zeros, dh, nullptr, 0, M2, Hd, D, TR_EPI_BF16, s));
     TR_TRY(tr_gelu_bwd_bf16(U(tape + bt.pre), dh, (size_t)M2 * Hd, s));
     TR_TRY(tr_linear_bwd_params(dh, Hd, 0, U(tape + bt.xn2), D, F(bg->fc1_w), F(bg->fc1_b), acc, wsf, wsn, M2, Hd, D, s));
     TR_TRY(tr_gemm_bf16(dh, U(bwt->fc1_w), zeros, dxn, nullptr, 0, M2, D, Hd, TR_EPI_BF16, s));
@@ -211,17 +217,22 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
     // ---- attention: x1 -> norm1 -> qkv -> softmax(q k^T) v -> proj -> (+ residual)
     const bool ats_sampled = cfg->family == TR_FAMILY_ATS && K > 0;
     const int Mp = ats_sampled ? M2 : M1;                   // rows that went through proj (ATS: only the sampled ones, ats.py:86,129)
-    TR_TRY(tr_linear_bwd_params(gb, D, 0, U(tape + bt.ao), D, F(bg->proj_w), F(bg->proj_b), acc, wsf, wsn, Mp, D, D, s));
+    gy = gb;
+    if (drop_scale != nullptr) {
+      TR_TRY(tr_rowscale_bf16(gb, dh, drop_scale + (size_t)(2 * i) * B, B, Mp / B, D, s));
+      gy = dh;
+    }
+    TR_TRY(tr_linear_bwd_params(gy, D, 0, U(tape + bt.ao), D, F(bg->proj_w), F(bg->proj_b), acc, wsf, wsn, Mp, D, D, s));
     if (ats_sampled) {
       // d(attn @ v) of the sampled rows and the stream's gradient go back to the rows they were sampled from (ats.py:86,157)
-      TR_TRY(tr_gemm_bf16(gb, U(bwt->proj_w), zeros, dxn, nullptr, 0, Mp, D, D, TR_EPI_BF16, s));
+      TR_TRY(tr_gemm_bf16(gy, U(bwt->proj_w), zeros, dxn, nullptr, 0, Mp, D, D, TR_EPI_BF16, s));
       TR_REQUIRE(hipMemsetAsync(g_alt, 0, (size_t)M1 * D * 4, st) == hipSuccess && hipMemsetAsync(dao, 0, (size_t)M1 * D * 2, st) == hipSuccess,
                  TR_ERR_LAUNCH, "tr_vit_backward: memset failed");
       TR_TRY(tr_ats_scatter(g, dxn, reinterpret_cast<const int32_t*>(tape + bt.idx), g_alt, dao, B, Na, Nm, D, s));
       float* tg = g; g = g_alt; g_alt = tg;
       uint16_t* tb = gb; gb = gb_alt; gb_alt = tb;           // gb is rewritten by norm1's backward below
     } else {
-      TR_TRY(tr_gemm_bf16(gb, U(bwt->proj_w), zeros, dao, nullptr, 0, M1, D, D, TR_EPI_BF16, s));
+      TR_TRY(tr_gemm_bf16(gy, U(bwt->proj_w), zeros, dao, nullptr, 0, M1, D, D, TR_EPI_BF16, s));
     }
     const float* size_att = nullptr;       // ToMe: log(size) bias of this block's keys (tome.py:48-49); ATS: the key mask (ats.py:117-120)
     if (cfg->family == TR_FAMILY_TOME || cfg->family == TR_FAMILY_ATS)

@@ -210,7 +210,7 @@ extern "C" size_t tr_vit_workspace_bytes(const tr_vit_config* cfg, int B) {
 static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits, void* workspace,
                             size_t workspace_bytes, int32_t* kept_idx, int32_t* compl_idx, float* soft_out,
                             const float* noise_in, float* features_out, int* tokens_out, int B, tr_stream_t s, char* tape,
-                            const trplan::TapePlan* tp) {
+                            const trplan::TapePlan* tp, const float* drop_scale = nullptr) {
   Plan p;
   const bool train = tape != nullptr;
   TR_REQUIRE(cfg && w && img && logits && workspace, TR_ERR_NULL, "tr_vit_forward: null pointer");
@@ -519,6 +519,8 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
     } else {
       TR_TRY(op_gemm(f32, ao, bw->proj_w, bw->proj_b, dbuf, nullptr, 0, M, D, D, TR_EPI_BF16, s));
     }
+    if (drop_scale != nullptr)      // DropPath on the attention branch (topk.py:87): this block's per-image scale, first of its two draws
+      TR_TRY(tr_rowscale_bf16(static_cast<const uint16_t*>(dbuf), static_cast<uint16_t*>(dbuf), drop_scale + (size_t)(2 * i) * B, B, Nn, D, s));
     if (K > 0) {
       // Top-K on the CLS attention, then residual add + gather/compact (+ EViT fused token) + norm2 in one pass
       const bool fuse = cfg->family == TR_FAMILY_EVIT;
@@ -573,6 +575,8 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
     }
     dbuf = dbuf_shared;
     TR_TRY(op_gemm(f32, hbuf, bw->fc2_w, bw->fc2_b, dbuf, nullptr, 0, M2, D, p.Hd, TR_EPI_BF16, s));
+    if (drop_scale != nullptr)      // DropPath on the MLP branch (topk.py:95)
+      TR_TRY(tr_rowscale_bf16(static_cast<const uint16_t*>(dbuf), static_cast<uint16_t*>(dbuf), drop_scale + (size_t)(2 * i + 1) * B, B, N, D, s));
     pending = dbuf;
     if (features_out && !train) {      // viz_data["Features"][i] (topk.py:197): x + mlp output, which x itself only absorbs in the next norm
       TR_TRY(tr_residual_snapshot(x, pending, f32 ? 1 : 0, features_out, (size_t)M2 * D, s));
@@ -637,7 +641,7 @@ extern "C" int tr_vit_tape_layout(const tr_vit_config* cfg, int B, int blk, size
 
 extern "C" int tr_vit_forward_train(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits, void* workspace,
                                     size_t workspace_bytes, void* tape, size_t tape_bytes, const float* noise_in, float* features_out,
-                                    int* tokens_out, int B, tr_stream_t s) {
+                                    const float* drop_scale, int* tokens_out, int B, tr_stream_t s) {
   TR_REQUIRE(cfg && tape, TR_ERR_NULL, "tr_vit_forward_train: null pointer");
   TR_REQUIRE(cfg->precision == TR_PREC_BF16, TR_ERR_CONFIG, "tr_vit_forward_train: the training path is bf16 only");
   TR_REQUIRE(trplan::trainable_family(cfg->family), TR_ERR_CONFIG, "tr_vit_forward_train: family %d has no training path yet", cfg->family);
@@ -650,5 +654,5 @@ extern "C" int tr_vit_forward_train(const tr_vit_config* cfg, const tr_vit_weigh
     TR_REQUIRE(t.n_att[i] <= 224, TR_ERR_SHAPE, "tr_vit_forward_train: %d tokens in block %d; the attention backward holds N <= 224", t.n_att[i], i);
   TR_REQUIRE(features_out == nullptr || cfg->family == TR_FAMILY_DYVIT, TR_ERR_CONFIG, "tr_vit_forward_train: features_out is DyViT's distillation output");
   return vit_forward_impl(cfg, w, img, logits, workspace, workspace_bytes, nullptr, nullptr, nullptr, noise_in, features_out, tokens_out, B, s,
-                          static_cast<char*>(tape), &tp);
+                          static_cast<char*>(tape), &tp, drop_scale);
 }

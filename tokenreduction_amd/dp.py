@@ -43,6 +43,7 @@ class FlatGradReducer:
         self.sync = True
         self._stream = None
         self._stage = None
+        self._shard = None
         self.launched: List[Tuple[int, int]] = []          # (start, stop) of the buckets of the last backward, in launch order
 
     # ---- model wiring ---------------------------------------------------------------------------------------------------
@@ -108,8 +109,12 @@ class FlatGradReducer:
             buf.copy_(sl)
         op = self.avg_op if self.avg_op is not None else dist.ReduceOp.SUM
         if self.algorithm == "rs_ag" and n % self.world == 0:
-            shard = buf[dist.get_rank(self.group) * (n // self.world): (dist.get_rank(self.group) + 1) * (n // self.world)]
-            dist.reduce_scatter_tensor(shard, buf, op=op, group=self.group)        # in place: the shard is this rank's part of buf
+            # the reduced shard lands in a small staging buffer (1/world of the bucket), the all-gather writes the bucket in place
+            m = n // self.world
+            if self._shard is None or self._shard.numel() < m or self._shard.dtype != buf.dtype or self._shard.device != buf.device:
+                self._shard = torch.empty(m, dtype=buf.dtype, device=buf.device)
+            shard = self._shard[:m]
+            dist.reduce_scatter_tensor(shard, buf, op=op, group=self.group)
             dist.all_gather_into_tensor(buf, shard, group=self.group)
         else:
             dist.all_reduce(buf, op=op, group=self.group)

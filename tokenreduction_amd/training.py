@@ -189,6 +189,22 @@ def train_decisions(model) -> dict:
     return out
 
 
+def drop_path_scales(model, B: int, dev):
+    """DropPath (timm 0.4.12 drop_path, call sites topk.py:78,87,95): block i drops a branch of an image with probability
+    dpr[i] = linspace(0, drop_path_rate, depth)[i] (topk.py:157) and scales the survivors by 1/keep_prob; two independent draws per
+    block (attention branch, MLP branch).  Returns fp32 [2*depth, B] of scales, or None when drop_path_rate == 0.
+    `model.drop_path_draws` (tests): the uniform draws [2*depth, B] to use instead of torch.rand (the reference's, replayed)."""
+    if not model.drop_path_rate:
+        return None
+    dpr = torch.linspace(0, model.drop_path_rate, model.depth)
+    keep = (1.0 - dpr).repeat_interleave(2).to(dev).unsqueeze(1)                      # [2*depth, 1]
+    draws = getattr(model, "drop_path_draws", None)
+    u = torch.rand(2 * model.depth, B, device=dev) if draws is None else draws.to(device=dev, dtype=torch.float32).reshape(2 * model.depth, B)
+    scale = (keep + u).floor() / keep                                                   # x.div(keep) * floor(keep + rand)
+    scale[keep.squeeze(1) >= 1.0] = 1.0                                                 # drop_prob 0 (block 0): DropPath is the identity
+    return scale.contiguous()
+
+
 class _VitTrainFn(torch.autograd.Function):
     """logits (+ DyViT's extra outputs) = model(x) with the backward wired to tr_vit_backward.  `anchor` only makes autograd call
     backward.  Outputs: (logits,) or for DyViT (logits, pred_0 .. pred_{S-1} [, features]): pred_j = the stage's hard keep decision
@@ -209,10 +225,11 @@ class _VitTrainFn(torch.autograd.Function):
         distill = dyvit and bool(getattr(model, "dyvit_distillation", False))
         feats = torch.empty(B, model.patch_embed.num_patches + 1, model.embed_dim, dtype=torch.float32, device=x.device) if distill else None
         noise = model._gumbel_ptr(B, x.device) if dyvit else model._noise_ptr(B, x.device)
+        ctx.drop = drop_path_scales(model, B, x.device)
         with torch.cuda.device(x.device):
             rc = lib.tr_vit_forward_train(C.byref(cfg), C.byref(pk["W"]), x.data_ptr(), logits.data_ptr(), ws["buf"].data_ptr(), ws["nbytes"],
-                                          tape.data_ptr(), tape.numel(), noise, None if feats is None else feats.data_ptr(), tokens, B,
-                                          torch.cuda.current_stream().cuda_stream)
+                                          tape.data_ptr(), tape.numel(), noise, None if feats is None else feats.data_ptr(),
+                                          None if ctx.drop is None else ctx.drop.data_ptr(), tokens, B, torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "tr_vit_forward_train")
         model._last_tokens = list(tokens)
         ctx.model, ctx.B, ctx.pk = model, B, pk
@@ -269,7 +286,7 @@ class _VitTrainFn(torch.autograd.Function):
             for hi, lo, start, stop in ranges:
                 rc = lib.tr_vit_backward(C.byref(pk["cfg"]), C.byref(pk["W"]), C.byref(WT), C.byref(G), dl.data_ptr(),
                                          None if dpred is None else dpred.data_ptr(), None if dfeat is None else dfeat.data_ptr(),
-                                         st.tape.data_ptr(), st.tape.numel(), st.bws.data_ptr(), st.bws.numel(), 1, hi, lo, B, stream)
+                                         None if ctx.drop is None else ctx.drop.data_ptr(), st.tape.data_ptr(), st.tape.numel(), st.bws.data_ptr(), st.bws.numel(), 1, hi, lo, B, stream)
                 _lib.check(rc, "tr_vit_backward")
                 if reduce_now:
                     reducer.reduce_slice(st.flat, start, stop)
@@ -290,9 +307,9 @@ def train_forward(model, x: torch.Tensor) -> torch.Tensor:
         raise RuntimeError(f"input is on {x.device}: tokenreduction_amd has no CPU path (HIP kernels only)")
     if model.precision != "bf16":
         raise NotImplementedError("the training path is bf16 (fp32 accumulate); set model.precision = 'bf16'")
-    if model.drop_rate or model.attn_drop_rate or model.drop_path_rate:
-        raise NotImplementedError("dropout / DropPath in the HIP training path are not built: construct the model with "
-                                  "drop_rate=0, drop_path_rate=0 (train.py --drop 0 --drop-path 0)")
+    if model.drop_rate or model.attn_drop_rate:
+        raise NotImplementedError("dropout (drop_rate / attn_drop_rate) in the HIP training path is not built: construct the model with "
+                                  "drop_rate=0 (train.py's default --drop 0.0); DropPath (--drop-path) is supported")
     x = x.detach().to(torch.float32).contiguous()
     anchor = torch.empty(0, dtype=torch.float32, device=x.device, requires_grad=True)
     out = _VitTrainFn.apply(anchor, x, model)
