@@ -312,7 +312,12 @@ def main():
     finetune = None
     if not a.no_extra:
         finetune = {"topk_small kr0.7 B=256/GPU (configs[1] model, fwd+bwd+AdamW)":
-                    finetune_leg(MODEL, KEEP_RATE, REDUCTION_LOC, BATCH, dev, dist)}
+                    finetune_leg(MODEL, KEEP_RATE, REDUCTION_LOC, BATCH, dev, dist),
+                    # BASELINE.json configs[3]: DeiT-B ATS / DPC-KNN keep_rate 0.5, DP fine-tune at 128 images per GPU (1024 on 8 GPUs)
+                    "ats_base kr0.5 B=128/GPU (configs[3], fwd+bwd+AdamW)":
+                    finetune_leg("ats_base_patch16_224", [0.5], [3, 6, 9], 128, dev, dist, steps=6, warmup=2),
+                    "dpcknn_base kr0.5 B=128/GPU (configs[3], fwd+bwd+AdamW)":
+                    finetune_leg("dpcknn_base_patch16_224", [0.5], [3, 6, 9], 128, dev, dist, steps=6, warmup=2)}
     if rank == 0:
         ips = world * BATCH * a.steps / el
         tokens = model._last_tokens
