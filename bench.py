@@ -387,15 +387,27 @@ def main():
             # synthetic weights and inputs, so these are numerics indicators, not accuracy claims.  The dense model shows the
             # arithmetic drift alone; with Top-K every flipped boundary token changes the token set of all later blocks.
             def drift(m, xs):
-                lb = m(xs).float()
+                out = {"images": int(xs.shape[0])}
                 m.precision = "fp32"
                 lf = m(xs).float()
+                for prec in ("bf16", "bf16x3"):
+                    m.precision = prec
+                    lb = m(xs).float()
+                    out[prec] = {"logit_rel_l2": float(f"{((lb - lf).norm() / lf.norm()).item():.3e}"),
+                                 "logit_max_abs": float(f"{(lb - lf).abs().max().item():.3e}"),
+                                 "top1_agreement": round((lb.argmax(1) == lf.argmax(1)).float().mean().item(), 4)}
                 m.precision = "bf16"
-                return {"images": int(xs.shape[0]), "logit_rel_l2": round(((lb - lf).norm() / lf.norm()).item(), 5),
-                        "logit_max_abs": round((lb - lf).abs().max().item(), 5),
-                        "top1_agreement": round((lb.argmax(1) == lf.argmax(1)).float().mean().item(), 4)}
+                return out
             rec["drift_vs_fp32_path"] = {"dense_deit_s": drift(dense, x[:64]), "topk_kr0.7": drift(model, x[:64]),
                                          "note": "random-init weights (qkv x4): near-flat, ill-conditioned logits"}
+            # precision="bf16x3": the fp32 executor with Linears + attention as split-bf16 (hi/lo) products on the matrix cores -- the
+            # mode that meets north_star's 1e-3-abs logit tolerance against the reference's golden vectors (tests/test_hip_split.py)
+            model.precision = "bf16x3"
+            x3_ips = quick_images_per_s(model, x, iters=3, reps=2)
+            model.precision = "bf16"
+            rec["bf16x3_mode"] = {"images_per_s": round(x3_ips, 1), "ms_per_step": round(BATCH / x3_ips * 1e3, 3),
+                                  "vs_bf16_product_path": round(x3_ips / ips, 3),
+                                  "note": "same config as `value`; 3 MFMAs per product, fp32 activations, fp32 twins for every non-GEMM op"}
             rec["cpu_baseline"] = cpu_baseline_leg(model)
         try:        # RCCL writes its banner through C stdio: flush it first so the JSON line is the last thing on stdout
             import ctypes

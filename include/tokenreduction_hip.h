@@ -102,6 +102,10 @@ int tr_attention_bf16(const uint16_t* qkv, uint16_t* out, float* cls_rows, const
  * arithmetic (expf softmax, fp32 everywhere). */
 int tr_attention_f32(const float* qkv, float* out, float* cls_rows, const float* size, float* colsum_part, int B, int N, int H,
                      tr_stream_t s);
+/* TR_PREC_BF16X3: same contract, q k^T and P v as split-bf16 products on the matrix cores (fp32 softmax, whole row in registers);
+ * N <= 224 on MFMA, longer sequences are forwarded to tr_attention_f32. */
+int tr_attention_split(const float* qkv, float* out, float* cls_rows, const float* size, float* colsum_part, int B, int N, int H,
+                       tr_stream_t s);
 /* a11 (forward only): Policy_Attention.forward dyvit.py:53-67 with softmax_with_policy :39-51 -- the attention of DyViT's
  * TRAINING forward, where pruned tokens stay in the sequence and are masked by policy fp32 [B,N] of 1/0:
  *   attn = (exp(s - max_k s) * pol + eps/N) / (sum_k exp(s - max_k s) * pol + eps),  pol[q][k] = policy[k], 1 for k == q,
@@ -132,6 +136,11 @@ int tr_gather_layernorm_f32(const float* x, const float* delta, const int32_t* i
  * epilogue: TR_EPI_F32 (bias), TR_EPI_GELU_BF16 (bias + exact-erf GELU, fp32 out), TR_EPI_PATCH_F32. */
 int tr_gemm_f32(const float* A, const float* W, const float* bias, float* out, const float* aux, int aux_i, int M, int N, int K,
                 int epilogue, tr_stream_t s);
+/* TR_PREC_BF16X3: the same Linear (same operands, epilogues and fp32 output) on the matrix cores -- every fp32 operand is split
+ * into hi = bf16(v), lo = bf16(v - hi) and a product is taken as hi*hi + hi*lo + lo*hi in the fp32 MFMA accumulator (~2^-17
+ * relative per product).  K % 32 == 0 and N % 4 == 0 run on MFMA; other shapes are forwarded to tr_gemm_f32. */
+int tr_gemm_split(const float* A, const float* W, const float* bias, float* out, const float* aux, int aux_i, int M, int N, int K,
+                  int epilogue, tr_stream_t s);
 
 /* ---- reducers that run before a block (csrc/tr_prune.hip) ------------------------------------------------------------
  * tr_pool_broadcast: PredictorLG.forward dyvit.py:115-118 with policy == 1 (eval): h [B,N,C] (bf16, or fp32 when is_f32), in
@@ -278,6 +287,28 @@ int tr_tome_merge_bwd(const float* g_merged, const float* size_in, const float* 
                       const int32_t* src_idx, const int32_t* dst_idx, int32_t* inv_map, float* g_out, uint16_t* gb_out, int B, int N,
                       int r, int D, tr_stream_t s);
 int tr_f32_to_bf16(const float* src, uint16_t* dst, size_t n, tr_stream_t s);
+/* ---- backward of the soft-assignment reducers (csrc/tr_soft_bwd.hip): SiT sit.py:36-40, PatchMerger patchmerger.py:35-39, Sinkhorn
+ * sinkhorn.py:41-86.  Forward: out[b,1+k,:] = sum_p wt[b,1+p,k] * src[b,1+p,:] (tr_softassign_merge*), wt token-major fp32 [B,N,ldl], row 0
+ * of an image (CLS) unused.  With g = d out fp32 [B,K+1,D]:
+ * tr_soft_dweights: dwt[b,1+p,k] = <g[b,1+k,:], src[b,1+p,:]>  (fp32 [B,N,ldl], CLS rows untouched)
+ * tr_soft_dsrc:     dsrc[b,1+p,:] = sum_k wt[b,1+p,k] g[b,1+k,:]  (fp32 [B,N,D], CLS rows untouched)
+ * tr_token_softmax_bwd: wt = softmax over the tokens of logits*scale: ds[b,1+p,k] = scale * wt (dwt - sum_p' wt dwt) as bf16 at row stride
+ *   ldo (CLS rows zero; columns K..ldo-1 untouched: zero them once), the next GEMMs' operand; dscale (nullable, fp32[1]) (+)= d/d scale
+ *   (SiT's learnable temperature, sit.py:34) -- needs the raw logits and tr_token_softmax_bwd_workspace_floats(B,K) floats.
+ * tr_sinkhorn_bwd: log_optimal_transport backwards: scores = the raw token.centre products, dplan = d of the transport plan (both fp32
+ *   [B,N,ldl]); the iterations are recomputed in LDS (K*(N-1) floats must fit: 224x224 inputs); ds bf16 as above.
+ * tr_rownorm_bwd: F.normalize backwards: dx = (d xh - xh <xh, d xh>) / |x| with d xh = da (fp32) + db (bf16, nullable).
+ * tr_add_into_bf16: y := bf16(a + y). */
+int tr_soft_dweights(const float* g, const float* src, float* dwt, int ldl, int B, int N, int K, int D, tr_stream_t s);
+int tr_soft_dsrc(const float* g, const float* wt, int ldl, float* dsrc, int B, int N, int K, int D, tr_stream_t s);
+size_t tr_token_softmax_bwd_workspace_floats(int B, int K);
+int tr_token_softmax_bwd(const float* wt, const float* dwt, const float* logits, int ldl, float scale, uint16_t* ds, int ldo, float* dscale,
+                         int accumulate, float* ws, size_t ws_floats, int B, int N, int K, tr_stream_t s);
+int tr_sinkhorn_bwd(const float* scores, const float* dplan, int ldl, float eps, int iters, uint16_t* ds, int ldo, int B, int N, int K,
+                    tr_stream_t s);
+int tr_rownorm_bwd(const float* x, const float* da, const uint16_t* db, float* dx, int M, int D, tr_stream_t s);
+int tr_add_into_bf16(const float* a, uint16_t* y, size_t n, tr_stream_t s);
+
 int tr_rowscale_bf16(const uint16_t* src, uint16_t* dst, const float* scale, int B, int rows, int D, tr_stream_t s);   /* dst[b,r,:] = src[b,r,:] * scale[b] */
 int tr_reduce_partials_f32(const float* part, int S, size_t count, float* dst, int accumulate, tr_stream_t s);   /* dst (+)= sum_s part[s] */
 /* ---- DyViT training pieces (csrc/tr_dyvit_train.hip, csrc/tr_attention_bwd.hip): see the file headers.  policy / prev / outputs are
@@ -323,8 +354,9 @@ int tr_ats_scatter(const float* g, const uint16_t* dao_s, const int32_t* ids, fl
 #define TR_MAX_DEPTH 32
 #define TR_PREC_BF16 0   /* the product path: bf16 MFMA operands, fp32 accumulate / residual / statistics */
 #define TR_PREC_FP32 1   /* validation path: the reference's own arithmetic on the GPU (bit-exact indices vs its golden vectors) */
+#define TR_PREC_BF16X3 2 /* the fp32 executor with Linears + attention as split-bf16 (hi/lo) products on the matrix cores */
 
-/* Weight MATRICES are bf16 (uint16_t bits) when cfg.precision == TR_PREC_BF16 and fp32 when TR_PREC_FP32; vectors are fp32. */
+/* Weight MATRICES are bf16 (uint16_t bits) when cfg.precision == TR_PREC_BF16 and fp32 otherwise; vectors are fp32. */
 typedef struct {
   const float* ln1_g; const float* ln1_b;
   const void* qkv_w; const float* qkv_b;     /* [3D,D], [3D] */

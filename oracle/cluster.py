@@ -153,7 +153,9 @@ def sinkhorn_layer(x_sp: Tensor, centers: Tensor, eps: float, iters: int, precis
     """Sinkhorn.forward sinkhorn.py:66-86: unit-norm tokens against unit-norm centres, Sinkhorn-normalised soft assignment,
     output = assignment-weighted sum of the NORMALISED tokens.  Returns (x [B,K,D], soft [B,K,P])."""
     xh = F.normalize(x_sp, p=2, dim=-1)
-    w = F.normalize(centers, p=2, dim=-1)
+    # sinkhorn.py:72-76 re-normalises self.v IN PLACE under no_grad and then uses the parameter itself: the value is the unit
+    # vector, the gradient reaches v without the normalisation's Jacobian
+    w = centers + (F.normalize(centers.detach(), p=2, dim=-1) - centers.detach())
     scores = torch.bmm(_r(xh, precision), _r(w, precision)[None].expand(x_sp.shape[0], -1, -1).transpose(1, 2))
     weights = sinkhorn_transport(scores.transpose(1, 2), eps, iters).transpose(1, 2)
     out = torch.bmm(xh.transpose(1, 2), weights).transpose(1, 2)
@@ -174,7 +176,7 @@ def sinkhorn_forward(params: Dict[str, Tensor], x: Tensor, cfg: VitConfig, preci
         if i in counts:
             xs, soft = sinkhorn_layer(h[:, 1:], p[f"cluster_layers.{j}.v"], eps, iters, precision)
             h = torch.cat([h[:, :1], xs], dim=1)
-            viz["Soft_Assignment_Maps"][i] = soft.numpy()
+            viz["Soft_Assignment_Maps"][i] = soft.detach().numpy()
             viz["Assignment_Maps"][i] = torch.argmax(soft, dim=-2).numpy()            # sinkhorn.py:173
             j += 1
         h, _, _ = block_forward(h, p, i, cfg, None, precision)

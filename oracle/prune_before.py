@@ -206,7 +206,7 @@ def sit_forward(params: Dict[str, Tensor], x: Tensor, cfg: VitConfig, precision:
         if i in counts:
             xs, w = sit_slim(h[:, 1:], p, j, precision)
             h = torch.cat([h[:, :1], xs], dim=1)
-            viz["Soft_Assignment_Maps"][i] = w.numpy()
+            viz["Soft_Assignment_Maps"][i] = w.detach().numpy()
             viz["Assignment_Maps"][i] = torch.argmax(w, dim=-2).numpy()        # sit.py:122
             j += 1
         h, _, _ = block_forward(h, p, i, cfg, None, precision)
@@ -242,7 +242,7 @@ def patchmerger_forward(params: Dict[str, Tensor], x: Tensor, cfg: VitConfig, pr
         if i in counts:
             xs, w = patchmerger_merge(h[:, 1:], p, j, precision)
             h = torch.cat([h[:, :1], xs], dim=1)
-            viz["Soft_Assignment_Maps"][i] = w.numpy()
+            viz["Soft_Assignment_Maps"][i] = w.detach().numpy()
             viz["Assignment_Maps"][i] = torch.argmax(w, dim=-2).numpy()        # patchmerger.py:122
             j += 1
         h, _, _ = block_forward(h, p, i, cfg, None, precision)

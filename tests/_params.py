@@ -235,7 +235,8 @@ GOLDEN_CASES = {
 # cross-entropy criterion) in train mode on the golden case's weights / images, labels from grad_labels().  Too large to store
 # whole (22 M values at DeiT-S), so per parameter: the L2 norm and <= 512 evenly strided entries (grad_sample_index).
 GRAD_CASES = ["deit_micro", "topk_micro", "evit_micro", "tome_micro", "dpcknn_micro", "dpcknn_micro_equal", "ats_micro", "topk_small_kr07",
-              "evit_small_kr07", "tome_small_r16", "deit_base", "dpcknn_base_kr05", "ats_base_kr05", "dyvit_micro_train", "dyvit_small_train", "kmedoids_micro", "heuristic_micro_l2", "topk_micro_droppath"]
+              "evit_small_kr07", "tome_small_r16", "deit_base", "dpcknn_base_kr05", "ats_base_kr05", "dyvit_micro_train", "dyvit_small_train", "kmedoids_micro", "heuristic_micro_l2", "topk_micro_droppath",
+              "sit_micro", "patchmerger_micro", "sinkhorn_micro", "sit_small_kr07", "patchmerger_small_kr07", "sinkhorn_small_kr07"]
 
 
 def dyvit_token_ratio(case: dict):
@@ -315,6 +316,12 @@ def oracle_param_grads(case: dict, forced=None, precision: str = "fp32", noise=N
             logits = oracle.dpcknn_forward.__wrapped__(leaves, x, cfg, noise, precision, False, forced)
         elif fam == "ats":
             logits = oracle.ats_forward.__wrapped__(leaves, x, cfg, precision, False, False, forced)
+        elif fam == "sit":
+            logits = oracle.sit_forward.__wrapped__(leaves, x, cfg, precision, False)
+        elif fam == "patchmerger":
+            logits = oracle.patchmerger_forward.__wrapped__(leaves, x, cfg, precision, False)
+        elif fam == "sinkhorn":
+            logits = oracle.sinkhorn_forward.__wrapped__(leaves, x, cfg, precision, False)
         else:
             drop = drop_path_scale(case, noise) if case.get("drop_path") else None       # noise = the [2*depth, B] uniform draws
             logits = oracle.vit_forward.__wrapped__(leaves, x, cfg, precision, False, forced, drop)

@@ -319,3 +319,75 @@ def test_ats_scatter(ops):
                 want[b, ids[b, t]] = g[b, t]
                 wantd[b, ids[b, t]] = dao[b, t].float()
     assert torch.equal(gf, want) and torch.equal(df.float(), wantd)
+
+
+# ------------------------------------------------------------------------------------------ soft-assignment reducers (tr_soft_bwd.hip)
+def _soft_case(seed, B, N, K, D):
+    rng = np.random.default_rng(seed)
+    ld = (K + 7) // 8 * 8
+    src = torch.from_numpy(rng.standard_normal((B, N, D)).astype(np.float32))
+    logits = torch.zeros(B, N, ld)
+    logits[:, :, :K] = torch.from_numpy(rng.standard_normal((B, N, K)).astype(np.float32))
+    g = torch.from_numpy(rng.standard_normal((B, K + 1, D)).astype(np.float32)) * 0.1
+    return src, logits, g, ld
+
+
+@pytest.mark.parametrize("B,N,K,D", [(2, 197, 137, 128), (3, 138, 96, 384), (1, 20, 5, 64)])
+def test_soft_merge_and_token_softmax_bwd(ops, B, N, K, D):
+    """SiT / PatchMerger: out_k = sum_p softmax_p(scale * logits[p,k]) src[p] against float64 autograd, d scale included."""
+    src, logits, g, ld = _soft_case(3, B, N, K, D)
+    scale = 0.7
+    s64 = src.double().requires_grad_(True)
+    l64 = logits[:, 1:, :K].double().requires_grad_(True)
+    sc = torch.tensor(scale, dtype=torch.float64, requires_grad=True)
+    w = torch.softmax(l64 * sc, dim=1)                                   # over the tokens
+    out = torch.einsum("bpk,bpd->bkd", w, s64[:, 1:])
+    out.backward(g[:, 1:].double())
+    wt = torch.zeros(B, N, ld)
+    wt[:, 1:, :K] = w.detach().float()
+    dwt, dsrc = ops.soft_merge_bwd(g.cuda(), wt.cuda(), src.cuda())
+    want_dw = torch.einsum("bkd,bpd->bpk", g[:, 1:].double(), src[:, 1:].double())
+    torch.testing.assert_close(dwt[:, 1:, :K].cpu().double(), want_dw, atol=1e-4, rtol=1e-4)
+    assert float(dwt[:, 0].abs().max()) == 0.0
+    torch.testing.assert_close(dsrc[:, 1:].cpu().double(), s64.grad[:, 1:], atol=1e-5, rtol=1e-4)
+    assert float(dsrc[:, 0].abs().max()) == 0.0
+    ds, dscale = ops.token_softmax_bwd(wt.cuda(), dwt, logits.cuda(), scale, K, want_dscale=True)
+    got = ds[:, 1:, :K].float().cpu().double()
+    rel = float((got - l64.grad).norm() / l64.grad.norm())
+    assert rel < 4e-3, rel                                               # bf16 output
+    assert float(ds[:, 0].float().abs().max()) == 0.0 and float(ds[:, :, K:].float().abs().max()) == 0.0
+    assert abs(float(dscale) - float(sc.grad)) <= 1e-4 * max(1.0, abs(float(sc.grad))), (float(dscale), float(sc.grad))
+
+
+@pytest.mark.parametrize("B,N,K,iters,eps", [(2, 197, 137, 3, 1.0), (2, 138, 96, 3, 0.5), (1, 30, 7, 5, 1.0)])
+def test_sinkhorn_bwd(ops, B, N, K, iters, eps):
+    """log_optimal_transport backwards against autograd through the oracle's restatement of sinkhorn.py:25-56 (float64)."""
+    import oracle
+    rng = np.random.default_rng(11)
+    ld = (K + 7) // 8 * 8
+    scores = torch.zeros(B, N, ld)
+    scores[:, :, :K] = torch.from_numpy((rng.standard_normal((B, N, K)) * 0.3).astype(np.float32))
+    dplan = torch.zeros(B, N, ld)
+    dplan[:, 1:, :K] = torch.from_numpy(rng.standard_normal((B, N - 1, K)).astype(np.float32))
+    s64 = scores[:, 1:, :K].double().requires_grad_(True)
+    plan = oracle.sinkhorn_transport(s64.transpose(1, 2), eps, iters).transpose(1, 2)          # [B,P,K]
+    plan.backward(dplan[:, 1:, :K].double())
+    ds = ops.sinkhorn_bwd(scores.cuda(), dplan.cuda(), K, eps, iters)
+    got = ds[:, 1:, :K].float().cpu().double()
+    rel = float((got - s64.grad).norm() / s64.grad.norm())
+    assert rel < 4e-3, rel
+    assert float(ds[:, 0].float().abs().max()) == 0.0
+
+
+def test_rownorm_bwd_and_add_into_bf16(ops):
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.standard_normal((77, 384)).astype(np.float32)) * 3
+    da = torch.from_numpy(rng.standard_normal((77, 384)).astype(np.float32))
+    db = torch.from_numpy(rng.standard_normal((77, 384)).astype(np.float32)).bfloat16()
+    x64 = x.double().requires_grad_(True)
+    torch.nn.functional.normalize(x64, p=2, dim=-1).backward(da.double() + db.double())
+    dx = ops.rownorm_bwd(x.cuda(), da.cuda(), db.cuda())
+    torch.testing.assert_close(dx.cpu().double(), x64.grad, atol=1e-6, rtol=1e-4)
+    y = db.clone().cuda()
+    ops.add_into_bf16(da.cuda(), y)
+    assert torch.equal(y.cpu(), (da + db.float()).bfloat16())

@@ -17,7 +17,7 @@ TR_EPI_BF16, TR_EPI_GELU_BF16, TR_EPI_RESID_F32, TR_EPI_F32, TR_EPI_PATCH_F32 = 
 TR_FAMILY_DEIT, TR_FAMILY_TOPK, TR_FAMILY_EVIT, TR_FAMILY_TOME, TR_FAMILY_DYVIT, TR_FAMILY_SIT, \
     TR_FAMILY_DPCKNN, TR_FAMILY_ATS, TR_FAMILY_SINKHORN, TR_FAMILY_KMEDOIDS, \
     TR_FAMILY_PATCHMERGER, TR_FAMILY_HEURISTIC = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
-TR_PREC_BF16, TR_PREC_FP32 = 0, 1
+TR_PREC_BF16, TR_PREC_FP32, TR_PREC_BF16X3 = 0, 1, 2
 
 _vp, _i, _f, _l, _sz = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t
 
@@ -54,8 +54,17 @@ SIGNATURES = {
     "tr_im2col_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tr_im2col_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tr_gemm_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "tr_soft_dweights": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "tr_soft_dsrc": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "tr_token_softmax_bwd_workspace_floats": (_sz, [_i, _i]),
+    "tr_token_softmax_bwd": (_i, [_vp, _vp, _vp, _i, _f, _vp, _i, _vp, _i, _vp, _sz, _i, _i, _i, _vp]),
+    "tr_sinkhorn_bwd": (_i, [_vp, _vp, _i, _f, _i, _vp, _i, _i, _i, _i, _vp]),
+    "tr_rownorm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "tr_add_into_bf16": (_i, [_vp, _vp, _sz, _vp]),
+    "tr_gemm_split": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tr_layernorm_f32": (_i, [_vp, _l, _vp, _l, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "tr_attention_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "tr_attention_split": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "tr_attention_policy_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "tr_attention_policy_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "tr_tome_match": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -12,8 +12,11 @@ inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
 inline bool trainable_family(int family) {
   return family == TR_FAMILY_DEIT || family == TR_FAMILY_TOPK || family == TR_FAMILY_EVIT || family == TR_FAMILY_TOME ||
          family == TR_FAMILY_DPCKNN || family == TR_FAMILY_ATS || family == TR_FAMILY_DYVIT || family == TR_FAMILY_KMEDOIDS ||
-         family == TR_FAMILY_HEURISTIC;
+         family == TR_FAMILY_HEURISTIC || family == TR_FAMILY_SIT || family == TR_FAMILY_PATCHMERGER || family == TR_FAMILY_SINKHORN;
 }
+inline bool soft_family(int family) { return family == TR_FAMILY_SIT || family == TR_FAMILY_PATCHMERGER || family == TR_FAMILY_SINKHORN; }
+inline int soft_ld(int K) { return (K + 7) / 8 * 8; }          // row stride of the token-major weight matrices (= tr_stage_weights.n_pad)
+inline int soft_ld64(int K) { return (K + 63) / 64 * 64; }     // row stride of their bf16 gradient (a GEMM contraction dimension)
 
 // tokens (incl. CLS) entering block i, inside its attention, and inside its MLP: the rules of tr_vit_forward
 struct TokenPlan {
@@ -98,6 +101,11 @@ struct BlockTape {
   size_t ysoft;   // fp32 [B, N]      softmax(score + gumbel)[..., 0];  sm: softmax(z)[..., 0];  hard: the one-hot's first entry
   size_t sm;
   size_t hard;
+  // soft-assignment stage (blocks with kk > 0, families SIT / PATCHMERGER / SINKHORN), rows = B * n_pre; x0 holds the stream
+  // entering the stage, pu the GEMM operand (LayerNorm / unit-norm rows, bf16), ppre0 / pcat SiT's hidden layer [rows, D/2]
+  size_t sxh;     // fp32 [rows, D]         the rows that are summed when they are not x0: LayerNorm (PatchMerger), unit norm (Sinkhorn)
+  size_t slog;    // fp32 [rows, soft_ld]   raw logits / scores
+  size_t swt;     // fp32 [rows, soft_ld]   token-axis softmax / transport plan
 };
 
 struct TapePlan {
@@ -118,7 +126,8 @@ inline bool make_tape_plan(const tr_vit_config* c, int B, const TokenPlan& t, Ta
   p->cols = take((size_t)B * t.P * kcols * 2);
   p->xfinal = take((size_t)B * D * 4);
   p->xcls = take((size_t)B * D * 2);
-  const bool pre = c->family == TR_FAMILY_DPCKNN || c->family == TR_FAMILY_KMEDOIDS;
+  const bool soft = soft_family(c->family);
+  const bool pre = c->family == TR_FAMILY_DPCKNN || c->family == TR_FAMILY_KMEDOIDS || soft;
   const bool dyvit = c->family == TR_FAMILY_DYVIT;
   p->ones = dyvit ? take((size_t)B * t.N0 * 4) : 0;
   p->xfin_all = dyvit ? take((size_t)B * t.N0 * D * 4) : 0;
@@ -148,6 +157,15 @@ inline bool make_tape_plan(const tr_vit_config* c, int B, const TokenPlan& t, Ta
       b.ppre1 = take(Ta * Hh * 2); b.ph1 = take(Ta * Hh * 2);
       b.ppre2 = take(Ta * Q * 2); b.ph2 = take(Ta * Q * 2);
       b.pol = take(Ta * 4); b.ysoft = take(Ta * 4); b.sm = take(Ta * 4); b.hard = take(Ta * 4);
+    }
+    b.sxh = b.slog = b.swt = 0;
+    if (soft && t.kk[i] > 0) {
+      const size_t ld = soft_ld(t.kk[i]);
+      b.pu = take(Tp * D * 2);
+      if (c->family == TR_FAMILY_SIT) { b.ppre0 = take(Tp * (D / 2) * 2); b.pcat = take(Tp * (D / 2) * 2); }
+      else b.sxh = take(Tp * D * 4);
+      b.slog = take(Tp * ld * 4);
+      b.swt = take(Tp * ld * 4);
     }
   }
   p->total = o;

@@ -17,7 +17,7 @@ using trplan::align_up;
 namespace {
 
 struct BwdPlan {
-  size_t g0, g1, gb0, gb1, dxn, dqkv, dao, dh, zeros, wsf, dscore, gfused, invmap, dxcls, dl16, dpol, dprev, dpolpart, total;
+  size_t g0, g1, gb0, gb1, dxn, dqkv, dao, dh, zeros, wsf, dscore, gfused, invmap, dxcls, dl16, dpol, dprev, dpolpart, soft_dp, soft_ds, soft_s, total;
   size_t wsf_floats;
 };
 
@@ -51,6 +51,13 @@ bool make_bwd_plan(const tr_vit_config* c, int B, const trplan::TokenPlan& t, Bw
   upd((size_t)(B + 1) * (D + 4));
   upd(tr_dyvit_decide_bwd_workspace_floats(B, t.N0, (int)(D / 4)));
   upd(tr_wgrad_workspace_floats((int)T, (int)(D / 2), (int)D));
+  int soft_k = 0;                    // soft-assignment families: the widest stage
+  if (trplan::soft_family(c->family))
+    for (int i = 0; i < c->depth; ++i) soft_k = t.kk[i] > soft_k ? t.kk[i] : soft_k;
+  if (soft_k > 0) {
+    upd(tr_wgrad_workspace_floats((int)T, trplan::soft_ld(soft_k), (int)D));
+    upd(tr_token_softmax_bwd_workspace_floats(B, soft_k));
+  }
   p->wsf_floats = f;
   p->wsf = take(f * 4);
   p->dscore = take(T * 4);
@@ -61,6 +68,12 @@ bool make_bwd_plan(const tr_vit_config* c, int B, const trplan::TokenPlan& t, Bw
   p->dpol = take(T * 4);
   p->dprev = take(T * 4);
   p->dpolpart = take(T * c->num_heads * 4);
+  p->soft_dp = p->soft_ds = p->soft_s = 0;
+  if (soft_k > 0) {
+    p->soft_dp = take(T * trplan::soft_ld(soft_k) * 4);
+    p->soft_ds = take(T * trplan::soft_ld64(soft_k) * 2);
+    p->soft_s = take(T * D * 4);
+  }
   p->total = o;
   return true;
 }
@@ -303,6 +316,59 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
                               F(sg->ln_b), acc, wsf, wsn, M1, D, 1e-5f, s));
       // what is left of the policy gradient belongs to the previous stage's decision
       TR_REQUIRE(hipMemcpyAsync(dpol, dprev, (size_t)M1 * 4, hipMemcpyDeviceToDevice, st) == hipSuccess, TR_ERR_LAUNCH, "tr_vit_backward: copy failed");
+    }
+    if (trplan::soft_family(cfg->family) && K > 0) {
+      // soft-assignment stage before the block (sit.py:36-40, patchmerger.py:35-39, sinkhorn.py:66-86): g = d of the merged stream
+      // [B, K+1, D] -> the stream entering the stage [B, n_pre, D] + the stage's parameters (tr_soft_bwd.hip)
+      const tr_stage_weights* sw = &w->stage[i];
+      const tr_stage_weights* swt = &wt->stage[i];
+      const tr_stage_weights* sg = &grads->stage[i];
+      const int Np = t.n_pre[i], Mp = B * Np, ld = trplan::soft_ld(K), ld64 = trplan::soft_ld64(K);
+      const bool sit = cfg->family == TR_FAMILY_SIT, sink = cfg->family == TR_FAMILY_SINKHORN;
+      const float* x0 = reinterpret_cast<const float*>(tape + bt.x0);
+      const float* wts = reinterpret_cast<const float*>(tape + bt.swt);
+      const float* slog = reinterpret_cast<const float*>(tape + bt.slog);
+      const float* src = sit ? x0 : reinterpret_cast<const float*>(tape + bt.sxh);
+      float* dwt = reinterpret_cast<float*>(ws + bp.soft_dp);
+      uint16_t* ds = reinterpret_cast<uint16_t*>(ws + bp.soft_ds);
+      float* dsrc = sit ? g_alt : reinterpret_cast<float*>(ws + bp.soft_s);       // SiT sums the stream's own rows: d src IS a stream gradient
+      TR_REQUIRE(hipMemsetAsync(ds, 0, (size_t)Mp * ld64 * 2, st) == hipSuccess && hipMemsetAsync(dsrc, 0, (size_t)Mp * D * 4, st) == hipSuccess,
+                 TR_ERR_LAUNCH, "tr_vit_backward: memset failed");
+      TR_TRY(tr_soft_dweights(g, src, dwt, ld, B, Np, K, D, s));
+      TR_TRY(tr_soft_dsrc(g, wts, ld, dsrc, B, Np, K, D, s));
+      if (sink)
+        TR_TRY(tr_sinkhorn_bwd(slog, dwt, ld, cfg->sinkhorn_eps > 0.f ? cfg->sinkhorn_eps : 1.0f, cfg->cluster_iters, ds, ld64, B, Np, K, s));
+      else
+        TR_TRY(tr_token_softmax_bwd(wts, dwt, slog, ld, sw->scale, ds, ld64, sit ? F(sg->b2) : nullptr, acc, wsf, wsn, B, Np, K, s));
+      if (sit) {
+        const int Hh = D / 2;
+        uint16_t* d1 = dh;                    // [Mp, Hh]
+        TR_TRY(tr_linear_bwd_params(ds, ld64, 0, U(tape + bt.pcat), Hh, F(sg->w1), F(sg->b1), acc, wsf, wsn, Mp, ld, Hh, s));
+        TR_TRY(tr_gemm_bf16(ds, U(swt->w1), zeros, d1, nullptr, 0, Mp, Hh, ld64, TR_EPI_BF16, s));
+        TR_TRY(tr_gelu_bwd_bf16(U(tape + bt.ppre0), d1, (size_t)Mp * Hh, s));
+        TR_TRY(tr_linear_bwd_params(d1, Hh, 0, U(tape + bt.pu), D, F(sg->w0), F(sg->b0), acc, wsf, wsn, Mp, Hh, D, s));
+        TR_TRY(tr_gemm_bf16(d1, U(swt->w0), zeros, dxn, nullptr, 0, Mp, D, Hh, TR_EPI_BF16, s));
+      } else {
+        // the similarity / score product: d queries (d centres) and d of its token operand
+        TR_TRY(tr_wgrad_bf16(ds, ld64, 0, U(tape + bt.pu), D, F(sg->w1), acc, wsf, wsn, Mp, ld, D, s));
+        TR_TRY(tr_gemm_bf16(ds, U(swt->w1), zeros, dxn, nullptr, 0, Mp, D, ld64, TR_EPI_BF16, s));
+      }
+      // the CLS row passes the stage untouched
+      if (!sit) TR_REQUIRE(hipMemsetAsync(g_alt, 0, (size_t)Mp * D * 4, st) == hipSuccess, TR_ERR_LAUNCH, "tr_vit_backward: memset failed");
+      if (sink) {
+        TR_TRY(tr_rownorm_bwd(x0, dsrc, dxn, g_alt, Mp, D, s));                  // d unit-norm rows = merge part + score-product part
+        TR_REQUIRE(hipMemcpy2DAsync(g_alt, (size_t)Np * D * 4, g, (size_t)(K + 1) * D * 4, (size_t)D * 4, B, hipMemcpyDeviceToDevice, st) == hipSuccess,
+                   TR_ERR_LAUNCH, "tr_vit_backward: copy failed");
+        TR_TRY(tr_f32_to_bf16(g_alt, gb_alt, (size_t)Mp * D, s));
+      } else {
+        TR_REQUIRE(hipMemcpy2DAsync(g_alt, (size_t)Np * D * 4, g, (size_t)(K + 1) * D * 4, (size_t)D * 4, B, hipMemcpyDeviceToDevice, st) == hipSuccess,
+                   TR_ERR_LAUNCH, "tr_vit_backward: copy failed");
+        if (!sit) TR_TRY(tr_add_into_bf16(dsrc, dxn, (size_t)Mp * D, s));        // PatchMerger sums the LayerNorm output: both uses meet here
+        TR_TRY(tr_layernorm_bwd(dxn, x0, D, sw->ln_g, g_alt, D, g_alt, D, gb_alt, nullptr, 0, 0, 0, nullptr, F(sg->ln_g), F(sg->ln_b), acc, wsf,
+                                wsn, Mp, D, 1e-5f, s));
+      }
+      float* tg = g; g = g_alt; g_alt = tg;
+      uint16_t* tb = gb; gb = gb_alt; gb_alt = tb;
     }
     if (cfg->family == TR_FAMILY_DPCKNN && K > 0) {
       // CTM before the block (dpcknn.py:257-260): gradient of the merged tokens -> the tokens they were merged from + the score Linear

@@ -120,8 +120,8 @@ struct Plan {
 
 bool make_plan(const tr_vit_config* c, int B, Plan* p) {
   if (!c || B <= 0) return false;
-  if (c->precision != TR_PREC_BF16 && c->precision != TR_PREC_FP32) return false;
-  const size_t es = c->precision == TR_PREC_FP32 ? 4 : 2;   // activation element size
+  if (c->precision != TR_PREC_BF16 && c->precision != TR_PREC_FP32 && c->precision != TR_PREC_BF16X3) return false;
+  const size_t es = c->precision != TR_PREC_BF16 ? 4 : 2;   // activation element size
   if (c->patch <= 0 || c->img_size <= 0 || c->img_size % c->patch != 0) return false;
   if (c->depth <= 0 || c->depth > TR_MAX_DEPTH) return false;
   if (c->num_heads <= 0 || c->embed_dim != c->num_heads * 64) return false;
@@ -160,15 +160,20 @@ bool make_plan(const tr_vit_config* c, int B, Plan* p) {
   return true;
 }
 
-// ---- precision dispatch: the executor is one launch sequence; TR_PREC_FP32 swaps every op for its fp32 validation twin
+// ---- precision dispatch: the executor is one launch sequence; TR_PREC_FP32 swaps every op for its fp32 validation twin;
+// TR_PREC_BF16X3 is that fp32 executor with the Linears and the attention on the matrix cores as split-bf16 products (tr_split.hip)
 inline int op_im2col(bool f32, const float* img, void* cols, int B, int C, int H, int W, int patch, tr_stream_t s) {
   return f32 ? tr_im2col_f32(img, static_cast<float*>(cols), B, C, H, W, patch, s)
              : tr_im2col_bf16(img, static_cast<uint16_t*>(cols), B, C, H, W, patch, s);
 }
-inline int op_gemm(bool f32, const void* A, const void* W, const float* bias, void* out, const float* aux, int aux_i, int M, int N,
+inline int op_gemm(int prec, const void* A, const void* W, const float* bias, void* out, const float* aux, int aux_i, int M, int N,
                    int K, int epi, tr_stream_t s) {
-  if (!f32) return tr_gemm_bf16(static_cast<const uint16_t*>(A), static_cast<const uint16_t*>(W), bias, out, aux, aux_i, M, N, K, epi, s);
+  if (prec == TR_PREC_BF16)
+    return tr_gemm_bf16(static_cast<const uint16_t*>(A), static_cast<const uint16_t*>(W), bias, out, aux, aux_i, M, N, K, epi, s);
   const int e32 = (epi == TR_EPI_BF16) ? TR_EPI_F32 : epi;      // "store bf16" becomes "store fp32"; GELU / PATCH / F32 keep their meaning
+  if (prec == TR_PREC_BF16X3)
+    return tr_gemm_split(static_cast<const float*>(A), static_cast<const float*>(W), bias, static_cast<float*>(out), aux, aux_i, M, N, K,
+                         e32, s);
   return tr_gemm_f32(static_cast<const float*>(A), static_cast<const float*>(W), bias, static_cast<float*>(out), aux, aux_i, M, N, K,
                      e32, s);
 }
@@ -177,9 +182,11 @@ inline int op_ln(bool f32, float* x, long ldx, const void* d, long ldd, const fl
   return f32 ? tr_layernorm_f32(x, ldx, static_cast<const float*>(d), ldd, g, b, static_cast<float*>(y), M, D, eps, s)
              : tr_layernorm_bf16(x, ldx, static_cast<const uint16_t*>(d), ldd, g, b, static_cast<uint16_t*>(y), M, D, eps, s);
 }
-inline int op_attn(bool f32, const void* qkv, void* out, float* cls_rows, const float* size, float* colsum, int B, int N, int H,
+inline int op_attn(int prec, const void* qkv, void* out, float* cls_rows, const float* size, float* colsum, int B, int N, int H,
                    tr_stream_t s) {
-  return f32 ? tr_attention_f32(static_cast<const float*>(qkv), static_cast<float*>(out), cls_rows, size, colsum, B, N, H, s)
+  if (prec == TR_PREC_BF16X3)
+    return tr_attention_split(static_cast<const float*>(qkv), static_cast<float*>(out), cls_rows, size, colsum, B, N, H, s);
+  return prec == TR_PREC_FP32 ? tr_attention_f32(static_cast<const float*>(qkv), static_cast<float*>(out), cls_rows, size, colsum, B, N, H, s)
              : tr_attention_bf16(static_cast<const uint16_t*>(qkv), static_cast<uint16_t*>(out), cls_rows, size, colsum, B, N, H, s);
 }
 inline int op_gather(bool f32, const float* x, const void* d, const int32_t* idx, const int32_t* cidx, const float* scores,
@@ -246,10 +253,11 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
   float* size_b = reinterpret_cast<float*>(ws + p.off_size1);
 
   const int D = p.D, H = p.H;
-  const bool f32 = cfg->precision == TR_PREC_FP32;
+  const int prec = cfg->precision;
+  const bool f32 = prec != TR_PREC_BF16;            // fp32 activations (TR_PREC_FP32 and TR_PREC_BF16X3)
   // a1 + a2: patch embedding, CLS token, position embedding
   TR_TRY(op_im2col(f32, img, cols, B, cfg->in_chans, cfg->img_size, cfg->img_size, cfg->patch, s));
-  TR_TRY(op_gemm(f32, cols, w->patch_w, w->patch_b, x, w->pos_embed, p.P, B * p.P, D, p.kcols, TR_EPI_PATCH_F32, s));
+  TR_TRY(op_gemm(prec, cols, w->patch_w, w->patch_b, x, w->pos_embed, p.P, B * p.P, D, p.kcols, TR_EPI_PATCH_F32, s));
   TR_TRY(tr_cls_pos_rows(w->cls_token, w->pos_embed, x, B, p.N0, D, s));
 
   int N = p.N0;
@@ -342,12 +350,33 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       TR_REQUIRE(sw->ln_g && sw->ln_b && sw->w1 && sw->b1 && sw->n_pad >= Kc && sw->n_pad % 8 == 0 &&
                      (size_t)sw->n_pad * 4 <= (size_t)p.Hd * (f32 ? 4 : 2),
                  TR_ERR_CONFIG, "tr_vit_forward: block %d PatchMerger weights missing or n_pad=%d invalid for K=%d", i, sw->n_pad, Kc);
+      if (train) {
+        // every operand of the stage's backward stays on the tape; the merged stream is written to norm1's input slot
+        const trplan::BlockTape& bt = tp->blk[i];
+        TR_REQUIRE(sw->n_pad == trplan::soft_ld(Kc) && Kc <= 192, TR_ERR_CONFIG, "tr_vit_forward_train: block %d PatchMerger n_pad=%d K=%d", i, sw->n_pad, Kc);
+        float* x0 = reinterpret_cast<float*>(tape + bt.x0);
+        float* xh = reinterpret_cast<float*>(tape + bt.sxh);
+        float* slog = reinterpret_cast<float*>(tape + bt.slog);
+        float* swt = reinterpret_cast<float*>(tape + bt.swt);
+        uint16_t* pu = reinterpret_cast<uint16_t*>(tape + bt.pu);
+        float* x1 = reinterpret_cast<float*>(tape + bt.x1);
+        TR_TRY(tr_layernorm_bf16_to(x, D, x0, D, static_cast<const uint16_t*>(pending), D, sw->ln_g, sw->ln_b, pu, M, D, 1e-5f, s));
+        pending = nullptr;
+        TR_TRY(tr_layernorm_f32(x0, D, nullptr, D, sw->ln_g, sw->ln_b, xh, M, D, 1e-5f, s));
+        TR_TRY(tr_gemm_bf16(pu, static_cast<const uint16_t*>(sw->w1), sw->b1, slog, nullptr, 0, M, sw->n_pad, D, TR_EPI_F32, s));
+        TR_REQUIRE(hipMemcpyAsync(swt, slog, (size_t)M * sw->n_pad * 4, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(s)) == hipSuccess,
+                   TR_ERR_LAUNCH, "tr_vit_forward_train: copy failed");
+        TR_TRY(tr_softassign_merge_fast(swt, sw->n_pad, sw->scale, 1, x0, xh, x1, soft_out, B, N, Kc, D, s));
+        if (soft_out) soft_out += (size_t)B * Kc * (N - 1);
+        x = x1;
+        N = Kc + 1;
+      } else {
       float* xh = static_cast<float*>(qkv);                       // LayerNorm-ed tokens, fp32 [M, D]
       float* sc = static_cast<float*>(hbuf);                      // similarities [M, n_pad]
       TR_TRY(op_ln(f32, x, D, pending, D, sw->ln_g, sw->ln_b, xn, M, D, 1e-5f, s));        // x += previous mlp output; GEMM operand
       pending = nullptr;
       TR_TRY(tr_layernorm_f32(x, D, nullptr, D, sw->ln_g, sw->ln_b, xh, M, D, 1e-5f, s));  // the rows that are summed
-      TR_TRY(op_gemm(f32, xn, sw->w1, sw->b1, sc, nullptr, 0, M, sw->n_pad, D, TR_EPI_F32, s));
+      TR_TRY(op_gemm(prec, xn, sw->w1, sw->b1, sc, nullptr, 0, M, sw->n_pad, D, TR_EPI_F32, s));
       if (!f32 && Kc <= 192)
         TR_TRY(tr_softassign_merge_fast(sc, sw->n_pad, sw->scale, 1, x, xh, x_alt, soft_out, B, N, Kc, D, s));
       else
@@ -355,6 +384,7 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       if (soft_out) soft_out += (size_t)B * Kc * (N - 1);
       float* t = x; x = x_alt; x_alt = t;
       N = Kc + 1;
+      }
     }
     if (cfg->family == TR_FAMILY_SINKHORN && cfg->keep[i] > 0) {
       // a22: Sinkhorn.forward sinkhorn.py:66-86 on x[:, 1:] BEFORE the block
@@ -363,12 +393,33 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       TR_REQUIRE(Kc <= N - 1, TR_ERR_CONFIG, "tr_vit_forward: block %d asks for %d clusters of %d patch tokens", i, Kc, N - 1);
       TR_REQUIRE(sw->w1 && sw->b1 && sw->n_pad >= Kc && sw->n_pad % 8 == 0 && (size_t)sw->n_pad * 4 <= (size_t)p.Hd * (f32 ? 4 : 2),
                  TR_ERR_CONFIG, "tr_vit_forward: block %d Sinkhorn centres missing or n_pad=%d invalid for K=%d", i, sw->n_pad, Kc);
+      if (train) {
+        const trplan::BlockTape& bt = tp->blk[i];
+        TR_REQUIRE(sw->n_pad == trplan::soft_ld(Kc) && Kc <= 192, TR_ERR_CONFIG, "tr_vit_forward_train: block %d Sinkhorn n_pad=%d K=%d", i, sw->n_pad, Kc);
+        float* x0 = reinterpret_cast<float*>(tape + bt.x0);
+        float* xh = reinterpret_cast<float*>(tape + bt.sxh);
+        float* slog = reinterpret_cast<float*>(tape + bt.slog);
+        float* swt = reinterpret_cast<float*>(tape + bt.swt);
+        uint16_t* pu = reinterpret_cast<uint16_t*>(tape + bt.pu);
+        float* x1 = reinterpret_cast<float*>(tape + bt.x1);
+        // x0 = x + pending (the norm output of this pass is not used: shared scratch)
+        TR_TRY(tr_layernorm_bf16_to(x, D, x0, D, static_cast<const uint16_t*>(pending), D, bw->ln1_g, bw->ln1_b, static_cast<uint16_t*>(xn_shared), M, D,
+                                    cfg->ln_eps, s));
+        pending = nullptr;
+        TR_TRY(tr_rownorm(x0, xh, pu, 0, M, D, s));
+        TR_TRY(tr_gemm_bf16(pu, static_cast<const uint16_t*>(sw->w1), sw->b1, slog, nullptr, 0, M, sw->n_pad, D, TR_EPI_F32, s));
+        TR_TRY(tr_sinkhorn(slog, sw->n_pad, cfg->sinkhorn_eps > 0.f ? cfg->sinkhorn_eps : 1.0f, cfg->cluster_iters, swt, soft_out, B, N, Kc, s));
+        if (soft_out) soft_out += (size_t)B * Kc * (N - 1);
+        TR_TRY(tr_softassign_merge_fast(swt, sw->n_pad, 1.0f, 0, x0, xh, x1, nullptr, B, N, Kc, D, s));
+        x = x1;
+        N = Kc + 1;
+      } else {
       if (pending) TR_TRY(op_ln(f32, x, D, pending, D, bw->ln1_g, bw->ln1_b, xn, M, D, cfg->ln_eps, s));   // x += previous mlp output
       pending = nullptr;
       float* xh = static_cast<float*>(qkv);                       // unit-norm tokens, fp32 [M, D] (the qkv slab is free here)
       float* sc = static_cast<float*>(hbuf);                      // scores, then the transport plan in place [M, n_pad]
       TR_TRY(tr_rownorm(x, xh, xn, f32 ? 1 : 0, M, D, s));
-      TR_TRY(op_gemm(f32, xn, sw->w1, sw->b1, sc, nullptr, 0, M, sw->n_pad, D, TR_EPI_F32, s));
+      TR_TRY(op_gemm(prec, xn, sw->w1, sw->b1, sc, nullptr, 0, M, sw->n_pad, D, TR_EPI_F32, s));
       TR_TRY(tr_sinkhorn(sc, sw->n_pad, cfg->sinkhorn_eps > 0.f ? cfg->sinkhorn_eps : 1.0f, cfg->cluster_iters, sc, soft_out, B, N,
                          Kc, s));
       if (soft_out) soft_out += (size_t)B * Kc * (N - 1);
@@ -378,6 +429,7 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
         TR_TRY(tr_weighted_merge(sc, sw->n_pad, x, xh, x_alt, B, N, Kc, D, s));
       float* t = x; x = x_alt; x_alt = t;
       N = Kc + 1;
+      }
     }
     if (train && cfg->family == TR_FAMILY_DYVIT && cfg->keep[i] > 0) {
       // a11 / f4: DyViT TRAINING (dyvit.py:221-229): PredictorLG on the patch tokens under the previous decision, a straight-through
@@ -414,6 +466,34 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
                              reinterpret_cast<float*>(tape + bt.sm), reinterpret_cast<float*>(tape + bt.hard), B, N, D / 4, s));
       noise_in += (size_t)B * (N - 1) * 2;
       policy_cur = pol;
+    } else if (train && cfg->family == TR_FAMILY_SIT && cfg->keep[i] > 0) {
+      // a23 TRAINING: TokenSlimmingModule (sit.py:36-40) with every activation on the tape
+      const tr_stage_weights* sw = &w->stage[i];
+      const trplan::BlockTape& bt = tp->blk[i];
+      const int Kc = cfg->keep[i], M = B * N, Hh = D / 2;
+      TR_REQUIRE(Kc <= N - 1 && Kc <= 192, TR_ERR_CONFIG, "tr_vit_forward_train: block %d asks for %d of %d patch tokens (<= 192)", i, Kc, N - 1);
+      TR_REQUIRE(sw->ln_g && sw->ln_b && sw->w0 && sw->b0 && sw->w1 && sw->b1, TR_ERR_NULL, "tr_vit_forward_train: block %d SiT weights missing", i);
+      TR_REQUIRE(sw->n_pad == trplan::soft_ld(Kc) && Hh % 64 == 0 && (sw->h_pad == 0 || sw->h_pad == Hh), TR_ERR_CONFIG,
+                 "tr_vit_forward_train: the SiT training path needs D/2 %% 64 == 0 and n_pad == %d (got h_pad=%d n_pad=%d)", trplan::soft_ld(Kc),
+                 sw->h_pad, sw->n_pad);
+      float* x0 = reinterpret_cast<float*>(tape + bt.x0);
+      float* slog = reinterpret_cast<float*>(tape + bt.slog);
+      float* swt = reinterpret_cast<float*>(tape + bt.swt);
+      uint16_t* pu = reinterpret_cast<uint16_t*>(tape + bt.pu);
+      uint16_t* ppre0 = reinterpret_cast<uint16_t*>(tape + bt.ppre0);
+      uint16_t* ph0 = reinterpret_cast<uint16_t*>(tape + bt.pcat);
+      float* x1 = reinterpret_cast<float*>(tape + bt.x1);
+      TR_TRY(tr_layernorm_bf16_to(x, D, x0, D, static_cast<const uint16_t*>(pending), D, sw->ln_g, sw->ln_b, pu, M, D, 1e-5f, s));
+      pending = nullptr;
+      TR_TRY(tr_gemm_bf16(pu, static_cast<const uint16_t*>(sw->w0), sw->b0, ppre0, nullptr, 0, M, Hh, D, TR_EPI_BF16, s));
+      TR_TRY(tr_gelu_bf16(ppre0, ph0, (size_t)M * Hh, s));
+      TR_TRY(tr_gemm_bf16(ph0, static_cast<const uint16_t*>(sw->w1), sw->b1, slog, nullptr, 0, M, sw->n_pad, Hh, TR_EPI_F32, s));
+      TR_REQUIRE(hipMemcpyAsync(swt, slog, (size_t)M * sw->n_pad * 4, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(s)) == hipSuccess,
+                 TR_ERR_LAUNCH, "tr_vit_forward_train: copy failed");
+      TR_TRY(tr_softassign_merge_fast(swt, sw->n_pad, sw->scale, 1, x0, x0, x1, soft_out, B, N, Kc, D, s));
+      if (soft_out) soft_out += (size_t)B * Kc * (N - 1);
+      x = x1;
+      N = Kc + 1;
     } else if ((cfg->family == TR_FAMILY_DYVIT || cfg->family == TR_FAMILY_SIT) && cfg->keep[i] > 0) {
       const tr_stage_weights* sw = &w->stage[i];
       const int Kc = cfg->keep[i], M = B * N;
@@ -428,10 +508,10 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
         TR_REQUIRE(sw->w2 && sw->b2 && sw->w3 && sw->b3, TR_ERR_NULL, "tr_vit_forward: block %d predictor weights missing", i);
         const int Hh = sw->h_pad > 0 ? sw->h_pad : D / 2;            // hidden width as packed (zero-padded to 64 for DeiT-T)
         TR_REQUIRE(Hh >= D / 2 && (Hh % 64 == 0 || f32), TR_ERR_CONFIG, "tr_vit_forward: DyViT predictor hidden width %d invalid (D=%d)", Hh, D);
-        TR_TRY(op_gemm(f32, xn, sw->w0, sw->b0, ao, nullptr, 0, M, D, D, TR_EPI_GELU_BF16, s));
+        TR_TRY(op_gemm(prec, xn, sw->w0, sw->b0, ao, nullptr, 0, M, D, D, TR_EPI_GELU_BF16, s));
         TR_TRY(tr_pool_broadcast(ao, f32 ? 1 : 0, B, N, D, 1e-6f, s));
-        TR_TRY(op_gemm(f32, ao, sw->w1, sw->b1, qkv, nullptr, 0, M, Hh, D, TR_EPI_GELU_BF16, s));
-        TR_TRY(op_gemm(f32, qkv, sw->w2, sw->b2, hbuf, nullptr, 0, M, D / 4, Hh, TR_EPI_GELU_BF16, s));
+        TR_TRY(op_gemm(prec, ao, sw->w1, sw->b1, qkv, nullptr, 0, M, Hh, D, TR_EPI_GELU_BF16, s));
+        TR_TRY(op_gemm(prec, qkv, sw->w2, sw->b2, hbuf, nullptr, 0, M, D / 4, Hh, TR_EPI_GELU_BF16, s));
         TR_TRY(tr_dyvit_score(hbuf, f32 ? 1 : 0, sw->w3, sw->b3, cls_rows, M, D / 4, s));
         int32_t* idx_dst = kept_idx ? kept_idx + (size_t)i * B * p.N0 : idx_ws;
         TR_TRY(tr_cls_topk(cls_rows, idx_dst, nullptr, scores, B, 1, N, Kc, s));
@@ -443,8 +523,8 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
                    "tr_vit_forward: block %d SiT n_pad=%d invalid for K=%d", i, sw->n_pad, Kc);
         const int Hh = sw->h_pad > 0 ? sw->h_pad : D / 2;
         TR_REQUIRE(Hh >= D / 2 && (Hh % 64 == 0 || f32), TR_ERR_CONFIG, "tr_vit_forward: SiT hidden width %d invalid (D=%d)", Hh, D);
-        TR_TRY(op_gemm(f32, xn, sw->w0, sw->b0, ao, nullptr, 0, M, Hh, D, TR_EPI_GELU_BF16, s));
-        TR_TRY(op_gemm(f32, ao, sw->w1, sw->b1, hbuf, nullptr, 0, M, sw->n_pad, Hh, TR_EPI_F32, s));
+        TR_TRY(op_gemm(prec, xn, sw->w0, sw->b0, ao, nullptr, 0, M, Hh, D, TR_EPI_GELU_BF16, s));
+        TR_TRY(op_gemm(prec, ao, sw->w1, sw->b1, hbuf, nullptr, 0, M, sw->n_pad, Hh, TR_EPI_F32, s));
         if (!f32 && Kc <= 192)
           TR_TRY(tr_softassign_merge_fast(static_cast<float*>(hbuf), sw->n_pad, sw->scale, 1, x, x, x_alt, soft_out, B, N, Kc, D, s));
         else
@@ -480,7 +560,7 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
                                   cfg->ln_eps, s));
       x = x1;
     } else if (!have_xn) TR_TRY(op_ln(f32, x, D, pending, D, bw->ln1_g, bw->ln1_b, xn, M, D, cfg->ln_eps, s));
-    TR_TRY(op_gemm(f32, xn, bw->qkv_w, bw->qkv_b, qkv, nullptr, 0, M, 3 * D, D, TR_EPI_BF16, s));
+    TR_TRY(op_gemm(prec, xn, bw->qkv_w, bw->qkv_b, qkv, nullptr, 0, M, 3 * D, D, TR_EPI_BF16, s));
     // ToMe: log(size) bias on the keys; ATS: key mask as a 1/0 "size" (log 0 = -inf -> exactly zero weight, like
     // masked_fill(-finfo.max) underflowing in the reference's softmax, ats.py:117-120)
     // K-Medoids: the NEXT block's clustering is seeded by the column sums of THIS block's attention (kmedoids.py:240)
@@ -489,7 +569,7 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
     if (policy_cur != nullptr)       // DyViT training: softmax_with_policy in every block (dyvit.py:245-246)
       TR_TRY(tr_attention_policy_bf16(static_cast<const uint16_t*>(qkv), static_cast<uint16_t*>(ao), policy_cur, B, N, H, s));
     else
-      TR_TRY(op_attn(f32, qkv, ao, (K > 0 || Ks > 0) ? cls_rows : nullptr, (tome || masked) ? size_cur : nullptr,
+      TR_TRY(op_attn(prec, qkv, ao, (K > 0 || Ks > 0) ? cls_rows : nullptr, (tome || masked) ? size_cur : nullptr,
                      want_colsum ? colsum_part : nullptr, B, N, H, s));
     int Nn = N;
     if (Ks > 0) {
@@ -515,9 +595,9 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       }
       size_cur = mask_next;
       Nn = Ks;
-      TR_TRY(op_gemm(f32, xn, bw->proj_w, bw->proj_b, dbuf, nullptr, 0, B * Nn, D, D, TR_EPI_BF16, s));
+      TR_TRY(op_gemm(prec, xn, bw->proj_w, bw->proj_b, dbuf, nullptr, 0, B * Nn, D, D, TR_EPI_BF16, s));
     } else {
-      TR_TRY(op_gemm(f32, ao, bw->proj_w, bw->proj_b, dbuf, nullptr, 0, M, D, D, TR_EPI_BF16, s));
+      TR_TRY(op_gemm(prec, ao, bw->proj_w, bw->proj_b, dbuf, nullptr, 0, M, D, D, TR_EPI_BF16, s));
     }
     if (drop_scale != nullptr)      // DropPath on the attention branch (topk.py:87): this block's per-image scale, first of its two draws
       TR_TRY(tr_rowscale_bf16(static_cast<const uint16_t*>(dbuf), static_cast<uint16_t*>(dbuf), drop_scale + (size_t)(2 * i) * B, B, Nn, D, s));
@@ -568,13 +648,13 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
     // mlp(norm2(x)) -> dbuf, added to x by the next block's norm1 (or the final norm)
     if (train) {
       void* pre = tape + tp->blk[i].pre;
-      TR_TRY(op_gemm(f32, xn, bw->fc1_w, bw->fc1_b, pre, nullptr, 0, M2, p.Hd, D, TR_EPI_BF16, s));
+      TR_TRY(op_gemm(prec, xn, bw->fc1_w, bw->fc1_b, pre, nullptr, 0, M2, p.Hd, D, TR_EPI_BF16, s));
       TR_TRY(tr_gelu_bf16(static_cast<const uint16_t*>(pre), static_cast<uint16_t*>(hbuf), (size_t)M2 * p.Hd, s));
     } else {
-      TR_TRY(op_gemm(f32, xn, bw->fc1_w, bw->fc1_b, hbuf, nullptr, 0, M2, p.Hd, D, TR_EPI_GELU_BF16, s));
+      TR_TRY(op_gemm(prec, xn, bw->fc1_w, bw->fc1_b, hbuf, nullptr, 0, M2, p.Hd, D, TR_EPI_GELU_BF16, s));
     }
     dbuf = dbuf_shared;
-    TR_TRY(op_gemm(f32, hbuf, bw->fc2_w, bw->fc2_b, dbuf, nullptr, 0, M2, D, p.Hd, TR_EPI_BF16, s));
+    TR_TRY(op_gemm(prec, hbuf, bw->fc2_w, bw->fc2_b, dbuf, nullptr, 0, M2, D, p.Hd, TR_EPI_BF16, s));
     if (drop_scale != nullptr)      // DropPath on the MLP branch (topk.py:95)
       TR_TRY(tr_rowscale_bf16(static_cast<const uint16_t*>(dbuf), static_cast<uint16_t*>(dbuf), drop_scale + (size_t)(2 * i + 1) * B, B, N, D, s));
     pending = dbuf;
@@ -601,7 +681,7 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
   } else {
     TR_TRY(op_ln(f32, x, (long)N * D, pending, (long)N * D, w->norm_g, w->norm_b, xcls, B, D, cfg->ln_eps, s));
   }
-  TR_TRY(op_gemm(f32, xcls, w->head_w, w->head_b, logits, nullptr, 0, B, p.C, D, TR_EPI_F32, s));
+  TR_TRY(op_gemm(prec, xcls, w->head_w, w->head_b, logits, nullptr, 0, B, p.C, D, TR_EPI_F32, s));
   return TR_OK;
 }
 
@@ -617,6 +697,7 @@ extern "C" size_t tr_vit_tape_bytes(const tr_vit_config* cfg, int B) {
   trplan::TokenPlan t;
   trplan::TapePlan tp;
   if (!make_plan(cfg, B, &p) || cfg->precision != TR_PREC_BF16 || !trplan::trainable_family(cfg->family)) return 0;
+  if (p.N0 > 224) return 0;                 // the attention backward holds K / V of a head in LDS (N <= 224): 224 x 224 inputs
   if (!trplan::make_token_plan(cfg, &t) || !trplan::make_tape_plan(cfg, B, t, &tp)) return 0;
   return tp.total;
 }

@@ -126,7 +126,9 @@ class VisionTransformer(nn.Module):
             self._modules["blocks"] = self._modules.pop("blocks")
         self.viz_mode = getattr(args, 'viz_mode', False)
         self._keep = [0] * depth
-        self.precision = "bf16"      # "bf16" = the product path; "fp32" = validation path (reference arithmetic on the GPU)
+        # "bf16" = the product path; "fp32" = validation path (reference arithmetic on the GPU, VALU); "bf16x3" = the fp32 executor
+        # with its Linears and attention on the matrix cores as split-bf16 products (3 MFMAs per product, ~1e-5 relative per Linear)
+        self.precision = "bf16"
         self.use_graph = True        # eval forward replays a captured hipGraph (False: plain launches)
         self._packed = None
         self._ws = {}
@@ -162,8 +164,9 @@ class VisionTransformer(nn.Module):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def _pack(self):
-        if self.precision not in ("bf16", "fp32"):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
+        if self.precision not in ("bf16", "fp32", "bf16x3"):
+            raise ValueError("precision must be 'bf16', 'bf16x3' or 'fp32'")
+        self._pre_pack()
         key = (self.precision,) + self._param_key()
         if self._packed is not None and self._packed["key"] == key:
             return self._packed
@@ -174,7 +177,7 @@ class VisionTransformer(nn.Module):
             raise NotImplementedError("num_classes == 0 (headless) is not supported by the executor")
         keep_alive = []
 
-        wdt = torch.float32 if self.precision == "fp32" else torch.bfloat16
+        wdt = torch.bfloat16 if self.precision == "bf16" else torch.float32
 
         def w16(t):      # weight matrix in the executor's operand type
             c = t.detach().to(wdt).contiguous()
@@ -211,7 +214,7 @@ class VisionTransformer(nn.Module):
         cfg.mlp_hidden = self.blocks[0].mlp.fc1.out_features
         cfg.num_classes = self.num_classes
         cfg.ln_eps = float(self.norm.eps)
-        cfg.precision = _lib.TR_PREC_FP32 if self.precision == "fp32" else _lib.TR_PREC_BF16
+        cfg.precision = {"bf16": _lib.TR_PREC_BF16, "fp32": _lib.TR_PREC_FP32, "bf16x3": _lib.TR_PREC_BF16X3}[self.precision]
         cfg.knn_k = int(getattr(self, "k_neighbors", 0))
         cfg.cluster_iters = int(getattr(self, "sinkhorn_iters", 0))
         cfg.sinkhorn_eps = float(getattr(self, "sinkhorn_eps", 0.0))
@@ -230,6 +233,13 @@ class VisionTransformer(nn.Module):
 
     def _grad_stage_ptrs(self, G, ptr):
         """Families with learned reduction modules point G.stage[blk] (tr_stage_weights layout) at their gradient views."""
+
+    def _grad_slot_numel(self, name, p):
+        """fp32 elements reserved for parameter `name` in the flat gradient buffer (>= p.numel(): matrices whose rows the kernels pad)."""
+        return p.numel()
+
+    def _pre_pack(self):
+        """Parameter maintenance the reference does inside forward() (Sinkhorn re-normalises its centres in place)."""
 
     def _per_forward_config(self, cfg):
         """Host-side random draws of a forward that the executor takes as inputs (K-Medoids equal_weight)."""
@@ -698,6 +708,32 @@ class SelfSlimmedVisionTransformer(VisionTransformer):
             st.n_pad = n_pad
             st.h_pad = hh
 
+    def _soft_pad(self, K):
+        return (K + 7) // 8 * 8, (K + 63) // 64 * 64
+
+    def _grad_slot_numel(self, name, p):
+        # the last Linear's rows are padded to a multiple of 8 by the weight-gradient kernel (rows >= K receive zeros)
+        for j, K in enumerate(self.cluster_count):
+            if name == f"cluster_layers.{j}.weight.3.weight":
+                return self._soft_pad(K)[0] * p.shape[1]
+            if name == f"cluster_layers.{j}.weight.3.bias":
+                return self._soft_pad(K)[0]
+        return p.numel()
+
+    def _grad_stage_ptrs(self, G, ptr):
+        for j, loc in enumerate(self.cluster_loc):
+            g, pre = G.stage[loc], f"cluster_layers.{j}."
+            g.ln_g, g.ln_b = ptr(pre + "weight.0.weight"), ptr(pre + "weight.0.bias")
+            g.w0, g.b0 = ptr(pre + "weight.1.weight"), ptr(pre + "weight.1.bias")
+            g.w1, g.b1 = ptr(pre + "weight.3.weight"), ptr(pre + "weight.3.bias")
+            g.b2 = ptr(pre + "scale")                                    # d scale (sit.py:34), fp32[1]
+
+    def _transposed_stage_weights(self, WT, t16):
+        for j, loc in enumerate(self.cluster_loc):
+            m, st = self.cluster_layers[j], WT.stage[loc]
+            st.w0 = t16(m.weight[1].weight)                                           # [D/2, D]^T
+            st.w1 = t16(_pad_rows(m.weight[3].weight, self._soft_pad(self.cluster_count[j])[1]))   # [K -> ld64, D/2]^T
+
     def _stage_shapes(self):
         """[(blk, K, P_in)] per slimming stage."""
         out, p_in = [], self.patch_embed.num_patches
@@ -899,6 +935,27 @@ class SinkhornVisionTransformer(SelfSlimmedVisionTransformer):
         for c, loc in zip(self.cluster_count, self.cluster_loc):
             self._keep[loc] = c
 
+    def _pre_pack(self):
+        if self.training:                       # sinkhorn.py:72-76: the centres are re-normalised IN PLACE (no grad) at every forward
+            with torch.no_grad():
+                for m in self.cluster_layers:
+                    m.v.copy_(torch.nn.functional.normalize(m.v, p=2, dim=-1))
+
+    def _grad_slot_numel(self, name, p):
+        for j, K in enumerate(self.cluster_count):
+            if name == f"cluster_layers.{j}.v":
+                return self._soft_pad(K)[0] * p.shape[1]
+        return p.numel()
+
+    def _grad_stage_ptrs(self, G, ptr):
+        for j, loc in enumerate(self.cluster_loc):
+            G.stage[loc].w1 = ptr(f"cluster_layers.{j}.v")               # the gradient reaches v as if it were the unit vector (sinkhorn.py:76-77)
+
+    def _transposed_stage_weights(self, WT, t16):
+        for j, loc in enumerate(self.cluster_loc):
+            v = torch.nn.functional.normalize(self.cluster_layers[j].v.detach().float(), p=2, dim=-1)
+            WT.stage[loc].w1 = t16(_pad_rows(v, self._soft_pad(self.cluster_count[j])[1]))
+
     def _pack_stages(self, W, w16, f32, keep_alive):
         for j, loc in enumerate(self.cluster_loc):
             v, st = self.cluster_layers[j].v.detach(), W.stage[loc]
@@ -1013,6 +1070,22 @@ class PatchMergerVisionTransformer(SelfSlimmedVisionTransformer):
             _init_vit_weights(m)
         for c, loc in zip(self.cluster_count, self.cluster_loc):
             self._keep[loc] = c
+
+    def _grad_slot_numel(self, name, p):
+        for j, K in enumerate(self.cluster_count):
+            if name == f"cluster_layers.{j}.queries":
+                return self._soft_pad(K)[0] * p.shape[1]
+        return p.numel()
+
+    def _grad_stage_ptrs(self, G, ptr):
+        for j, loc in enumerate(self.cluster_loc):
+            g, pre = G.stage[loc], f"cluster_layers.{j}."
+            g.ln_g, g.ln_b = ptr(pre + "norm.weight"), ptr(pre + "norm.bias")
+            g.w1 = ptr(pre + "queries")
+
+    def _transposed_stage_weights(self, WT, t16):
+        for j, loc in enumerate(self.cluster_loc):
+            WT.stage[loc].w1 = t16(_pad_rows(self.cluster_layers[j].queries, self._soft_pad(self.cluster_count[j])[1]))
 
     def _pack_stages(self, W, w16, f32, keep_alive):
         for j, loc in enumerate(self.cluster_loc):

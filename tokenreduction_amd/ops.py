@@ -136,8 +136,9 @@ def gather_layernorm(x: torch.Tensor, idx, compl, scores, gamma, beta, eps: floa
 
 # ---------------------------------------------------------------------------------------- fp32 validation path
 def gemm_f32(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, epilogue: int = TR_EPI_F32, out: torch.Tensor = None,
-             aux: torch.Tensor = None, aux_i: int = 0) -> torch.Tensor:
-    """nn.Linear in the reference's arithmetic (fp32 operands): epilogue TR_EPI_F32 | TR_EPI_GELU_BF16 (GELU, fp32 out) | PATCH."""
+             aux: torch.Tensor = None, aux_i: int = 0, split: bool = False) -> torch.Tensor:
+    """nn.Linear in the reference's arithmetic (fp32 operands): epilogue TR_EPI_F32 | TR_EPI_GELU_BF16 (GELU, fp32 out) | PATCH.
+    split=True: the same Linear as split-bf16 (hi/lo) products on the matrix cores (TR_PREC_BF16X3)."""
     M, K = a.shape
     N = w.shape[0]
     if w.dim() != 2 or w.shape[1] != K:
@@ -149,9 +150,10 @@ def gemm_f32(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, epilogue: int
         raise ValueError(f"gemm: out is {tuple(out.shape)}, expected {(M, N)}")
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=a.device)
-    _lib.check(_lib.load().tr_gemm_f32(_dev(a, torch.float32, "a"), _dev(w, torch.float32, "w"), _dev(bias, torch.float32, "bias"),
-                                       _dev(out, torch.float32, "out"), _opt(aux, torch.float32, "aux"), aux_i, M, N, K, epilogue,
-                                       _stream()), "tr_gemm_f32")
+    fn = _lib.load().tr_gemm_split if split else _lib.load().tr_gemm_f32
+    _lib.check(fn(_dev(a, torch.float32, "a"), _dev(w, torch.float32, "w"), _dev(bias, torch.float32, "bias"),
+                  _dev(out, torch.float32, "out"), _opt(aux, torch.float32, "aux"), aux_i, M, N, K, epilogue, _stream()),
+               "tr_gemm_split" if split else "tr_gemm_f32")
     return out
 
 
@@ -166,12 +168,13 @@ def layernorm_f32(x: torch.Tensor, gamma, beta, eps: float, delta: torch.Tensor 
 
 
 def attention_f32(qkv: torch.Tensor, B: int, N: int, H: int, want_cls: bool = False, size: torch.Tensor = None,
-                  colsum_part: torch.Tensor = None):
+                  colsum_part: torch.Tensor = None, split: bool = False):
     out = torch.empty(B * N, H * 64, dtype=torch.float32, device=qkv.device)
     cls_rows = torch.empty(B, H, N, dtype=torch.float32, device=qkv.device) if want_cls else None
-    _lib.check(_lib.load().tr_attention_f32(_dev(qkv, torch.float32, "qkv"), out.data_ptr(),
-                                            None if cls_rows is None else cls_rows.data_ptr(), _opt(size, torch.float32, "size"),
-                                            _opt(colsum_part, torch.float32, "colsum_part"), B, N, H, _stream()), "tr_attention_f32")
+    fn = _lib.load().tr_attention_split if split else _lib.load().tr_attention_f32
+    _lib.check(fn(_dev(qkv, torch.float32, "qkv"), out.data_ptr(), None if cls_rows is None else cls_rows.data_ptr(),
+                  _opt(size, torch.float32, "size"), _opt(colsum_part, torch.float32, "colsum_part"), B, N, H, _stream()),
+               "tr_attention_split" if split else "tr_attention_f32")
     return out, cls_rows
 
 
@@ -557,3 +560,54 @@ def ats_scatter(g, dao_s, ids, N: int):
     _lib.check(_lib.load().tr_ats_scatter(_dev(g, torch.float32, "g"), _dev(dao_s, torch.bfloat16, "dao_s"), _dev(ids, torch.int32, "ids"),
                                           g_full.data_ptr(), dao_full.data_ptr(), B, N, Ks, D, _stream()), "tr_ats_scatter")
     return g_full, dao_full
+
+
+# ---------------------------------------------------------------------------------------- soft-assignment reducers, backward (csrc/tr_soft_bwd.hip)
+def soft_merge_bwd(g: torch.Tensor, wt: torch.Tensor, src: torch.Tensor):
+    """out[b,1+k] = sum_p wt[b,1+p,k] src[b,1+p] backwards: g fp32 [B,K+1,D], wt fp32 [B,N,ldl], src fp32 [B,N,D] ->
+    (dwt fp32 [B,N,ldl] (CLS rows / columns >= K zero), dsrc fp32 [B,N,D] (CLS rows zero))."""
+    B, N, D = src.shape
+    K, ldl = g.shape[1] - 1, wt.shape[2]
+    lib = _lib.load()
+    dwt = torch.zeros(B, N, ldl, dtype=torch.float32, device=src.device)
+    dsrc = torch.zeros(B, N, D, dtype=torch.float32, device=src.device)
+    _lib.check(lib.tr_soft_dweights(_dev(g, torch.float32, "g"), _dev(src, torch.float32, "src"), dwt.data_ptr(), ldl, B, N, K, D, _stream()),
+               "tr_soft_dweights")
+    _lib.check(lib.tr_soft_dsrc(_dev(g, torch.float32, "g"), _dev(wt, torch.float32, "wt"), ldl, dsrc.data_ptr(), B, N, K, D, _stream()), "tr_soft_dsrc")
+    return dwt, dsrc
+
+
+def token_softmax_bwd(wt: torch.Tensor, dwt: torch.Tensor, logits: torch.Tensor, scale: float, K: int, want_dscale: bool = False):
+    """-> (ds bf16 [B,N,ld64], dscale fp32[1] | None)."""
+    B, N, ldl = wt.shape
+    ldo = (K + 63) // 64 * 64
+    lib = _lib.load()
+    ds = torch.zeros(B, N, ldo, dtype=torch.bfloat16, device=wt.device)
+    dscale = torch.zeros(1, dtype=torch.float32, device=wt.device) if want_dscale else None
+    ws = _ws(lib.tr_token_softmax_bwd_workspace_floats(B, K), wt.device)
+    _lib.check(lib.tr_token_softmax_bwd(_dev(wt, torch.float32, "wt"), _dev(dwt, torch.float32, "dwt"), _dev(logits, torch.float32, "logits"), ldl,
+                                        float(scale), ds.data_ptr(), ldo, None if dscale is None else dscale.data_ptr(), 0, ws.data_ptr(), ws.numel(),
+                                        B, N, K, _stream()), "tr_token_softmax_bwd")
+    return ds, dscale
+
+
+def sinkhorn_bwd(scores: torch.Tensor, dplan: torch.Tensor, K: int, eps: float, iters: int) -> torch.Tensor:
+    B, N, ldl = scores.shape
+    ldo = (K + 63) // 64 * 64
+    ds = torch.zeros(B, N, ldo, dtype=torch.bfloat16, device=scores.device)
+    _lib.check(_lib.load().tr_sinkhorn_bwd(_dev(scores, torch.float32, "scores"), _dev(dplan, torch.float32, "dplan"), ldl, float(eps), iters,
+                                           ds.data_ptr(), ldo, B, N, K, _stream()), "tr_sinkhorn_bwd")
+    return ds
+
+
+def rownorm_bwd(x: torch.Tensor, da: torch.Tensor, db: torch.Tensor = None) -> torch.Tensor:
+    M, D = x.shape
+    dx = torch.empty(M, D, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().tr_rownorm_bwd(_dev(x, torch.float32, "x"), _dev(da, torch.float32, "da"), _opt(db, torch.bfloat16, "db"), dx.data_ptr(), M, D,
+                                          _stream()), "tr_rownorm_bwd")
+    return dx
+
+
+def add_into_bf16(a: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    _lib.check(_lib.load().tr_add_into_bf16(_dev(a, torch.float32, "a"), _dev(y, torch.bfloat16, "y"), a.numel(), _stream()), "tr_add_into_bf16")
+    return y

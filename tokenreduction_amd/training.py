@@ -59,7 +59,7 @@ class TrainState:
         self.offsets, off = {}, 0
         for n, p in self.order:
             self.offsets[n] = off
-            off += _align4(p.numel())
+            off += _align4(model._grad_slot_numel(n, p))
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
         self.views = {n: self.flat[o: o + p.numel()].view_as(p) for (n, p), o in zip(self.order, self.offsets.values())}
         # bucket boundaries: [head+norm+last block] ... per block ... [block 0 + embedding]; event index that completes each
@@ -80,7 +80,7 @@ class TrainState:
                 e = model.depth - 1                     # finished before the last block's event
             else:
                 e = model.depth                          # embedding + family modules: the final event
-            ends[e] = self.offsets[n] + _align4(p.numel())
+            ends[e] = self.offsets[n] + _align4(model._grad_slot_numel(n, p))
         out, start = [], 0
         for e in sorted(ends, key=lambda k: ends[k]):
             out.append((e, start, ends[e]))
@@ -138,8 +138,8 @@ class TrainState:
             nb = lib.tr_vit_backward_workspace_bytes(C.byref(pk["cfg"]), B)
             if nt == 0 or nb == 0:
                 raise NotImplementedError(
-                    f"{type(model).__name__}: this family / configuration has no training path in the HIP executor "
-                    "(built: DeiT, Top-K, EViT, ToMe, DPC-KNN, ATS, DyViT, K-Medoids, Heuristic at 224x224, bf16); call model.eval() for inference")
+                    f"{type(model).__name__}: this configuration has no training path in the HIP executor (built: every family at "
+                    "224x224, i.e. <= 224 tokens, bf16); call model.eval() for inference")
             self.tape = torch.empty(nt, dtype=torch.uint8, device=dev)
             self.bws = torch.empty(nb, dtype=torch.uint8, device=dev)
             self.B = B
