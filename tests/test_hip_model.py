@@ -461,3 +461,23 @@ def test_tiny_width_predictor_modules(family):
     rel = ((logits.cpu() - want).norm() / want.norm()).item()
     print(f"\n[{family} tiny-width] relative L2 vs oracle_bf16 (teacher-forced where there are decisions): {rel:.3e}")
     assert rel < FORCED_TOL, rel
+
+
+@pytest.mark.parametrize("name", ["topk_micro", "evit_micro", "dpcknn_micro", "kmedoids_micro", "dyvit_micro", "tome_micro", "ats_micro"])
+def test_non_finite_input_gives_nan_logits_and_no_fault(name):
+    """A NaN pixel makes every score of that image NaN.  The reference returns NaN logits for it (torch.topk / argsort order NaN as
+    the largest value and still return valid indices); the decision kernels here must likewise stay inside their index ranges -- the
+    index slabs feed gathers -- and leave the other images of the batch untouched."""
+    case = GOLDEN_CASES[name]
+    model, _, _ = build_model(case)
+    x = make_images(case["batch"], 224, case["xseed"])
+    clean, _ = model(x.cuda())
+    bad = x.clone()
+    bad[1, 0, 5, 7] = float("nan")
+    logits, viz = model(bad.cuda())
+    torch.cuda.synchronize()
+    assert torch.isnan(logits[1]).all()
+    assert torch.equal(logits[0], clean[0]) and torch.equal(logits[2:], clean[2:])
+    for blk, kept in viz.get("Kept_Tokens", {}).items():
+        kept = np.asarray(kept)
+        assert kept.min() >= -1 and kept.max() <= 196, (blk, kept.min(), kept.max())      # -1: EViT's fused-token / padding marker
