@@ -448,9 +448,22 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
   const int G = gridDim.x, bid = blockIdx.x;
   const int T = nMt * nNt;
   const int toff = (bid & 7) * (G >> 3) + (bid >> 3);
-  if (toff >= T) return;
-  const int my_tiles = (T - toff + G - 1) / G;
-  const int S = my_tiles * nk;
+  // Tail round.  T tiles on G workgroups = F full rounds + R = T - F*G tiles that would occupy R workgroups for a whole tile time
+  // while G - R idle (591 tiles of the N = 384 GEMMs at B = 256: 2.31 rounds paid as 3).  When R <= G/2 the tail tiles are cut into
+  // two 128-row HALF tiles, one per workgroup (2R <= G): same ring, same barrier protocol, the loaders fetch 128 instead of 256
+  // activation rows (8 instead of 12 pieces per wave and K-step) and only the MFMA waves of rows 0..127 (wm < 2, one per SIMD) work.
+#ifdef TR_ABLATE_NO_W_DMA
+  const bool split = false;
+#else
+  const int F = T / G, R = T - F * G;
+  const bool split = R > 0 && 2 * R <= G;
+#endif
+  const int my_full = split ? T / G : (toff < T ? (T - toff + G - 1) / G : 0);
+  const bool has_half = split && toff < 2 * (T - (T / G) * G);
+  const int units = my_full + (has_half ? 1 : 0);
+  if (units == 0) return;
+  const int half_tile = (T / G) * G + (toff >> 1), half_sel = toff & 1;
+  const int S_full = my_full * nk, S = units * nk;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
   if (wave >= 8) {
@@ -460,13 +473,16 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
     // LDS position (row, chunk pc) must hold LOGICAL chunk pc ^ ((row>>1)&7); rows lw*64 + 8j + l3 and lw*32 + 8j + l3:
     // (row>>1)&7 = (4j + (l3>>1)) & 7 for both (lw*64, lw*32 are multiples of 16)
     unsigned o[12];
-    int l_tile = toff, l_kt = 0, l_slot = 0, l_step = 0;
-    auto set_tile = [&](int tile) __attribute__((always_inline)) {
-      const int tm0 = (tile / nNt) * PBM, tn0 = (tile % nNt) * PBN;
+    int l_unit = 0, l_kt = 0, l_slot = 0, l_step = 0;
+    auto set_unit = [&](int u) __attribute__((always_inline)) {
+      const bool half = u >= my_full;
+      const int tile = half ? half_tile : toff + u * G;
+      const int tm0 = (tile / nNt) * PBM + (half ? 128 * half_sel : 0), tn0 = (tile % nNt) * PBN;
+      const int rpw = half ? 32 : 64;       // activation rows per loader wave
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int c = (pc ^ ((4 * j + (l3 >> 1)) & 7)) * 8;
-        o[j] = ((unsigned)min(tm0 + lw * 64 + 8 * j + l3, M - 1) * K + c) * 2u;
+        o[j] = ((unsigned)min(tm0 + lw * rpw + 8 * j + l3, M - 1) * K + c) * 2u;     // j >= 4 unused by a half tile
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -476,11 +492,16 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
     };
     auto issue_group = [&]() __attribute__((always_inline)) {
       const bool real = l_step < S;
-      const unsigned da = lds0 + l_slot * P_STAGE_BYTES + lw * 8192;
+      const bool hmode = has_half && l_step >= S_full;     // the half tile is a workgroup's LAST unit; the dummy groups behind it keep its size
+      const unsigned da = lds0 + l_slot * P_STAGE_BYTES + lw * (hmode ? 4096 : 8192);
       const unsigned dw = lds0 + l_slot * P_STAGE_BYTES + PBM * 128 + lw * 4096;
       const uint16_t* sW = real ? W : A;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) issue_piece(A, real ? o[j] : 0u, da + j * 1024);
+      for (int j = 0; j < 4; ++j) issue_piece(A, real ? o[j] : 0u, da + j * 1024);
+      if (!hmode) {
+#pragma unroll
+        for (int j = 4; j < 8; ++j) issue_piece(A, real ? o[j] : 0u, da + j * 1024);
+      }
 #ifndef TR_ABLATE_NO_W_DMA    // lab only: what would the K-loop do if the weight panel stayed in LDS (feed 32 KB instead of 48 KB per K-step)?
 #pragma unroll
       for (int j = 0; j < 4; ++j) issue_piece(sW, real ? o[8 + j] : 0u, dw + j * 1024);
@@ -490,22 +511,24 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
         l_slot = (l_slot == P_NSTAGE - 1) ? 0 : l_slot + 1;
         if (++l_kt == nk) {
           l_kt = 0;
-          l_tile += G;
-          if (l_step < S) set_tile(l_tile);
+          ++l_unit;
+          if (l_step < S) set_unit(l_unit);
         } else {
 #pragma unroll
           for (int j = 0; j < 12; ++j) o[j] += 2 * BK;
         }
       }
     };
-    set_tile(l_tile);
+    set_unit(0);
     issue_group();      // group 0 -> slot 0
     issue_group();      // group 1 -> slot 1   (dummies if S < 2)
     for (int g = 0; g < S; ++g) {
+      // group g landed; group g+1 -- real or dummy, 12 pieces or a half tile's 8 -- may still fly
 #ifdef TR_ABLATE_NO_W_DMA
       asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
 #else
-      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");    // group g landed (group g+1 -- real or dummy -- may still fly)
+      if (has_half && g + 1 >= S_full) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
 #endif
       __builtin_amdgcn_s_barrier();                        // B_g: the MFMA waves are done reading slot (g-1)%3 == (g+2)%3
       if (g + 1 < S) issue_group();                        // group g+2 -> that slot (dummy pieces once nothing is left to load)
@@ -528,7 +551,7 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
   f32x4 acc[4][4];
   {
     f32x4 b0[4];
-    load_bias(b0, toff);
+    load_bias(b0, my_full > 0 ? toff : half_tile);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -552,24 +575,35 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
       acc[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(WF[i_], AF[j_], acc[i_][j_], 0, 0, 0)
 #endif
 
-  int c_tile = toff, c_kt = 0, c_slot = 0;
+  int c_tile = my_full > 0 ? toff : half_tile, c_kt = 0, c_slot = 0;
+  int gs = 0;                                // K-steps done, over all units of this workgroup
 #ifdef TR_DIAG_CLOCK
   const unsigned long long ck0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
 #endif
   __builtin_amdgcn_s_barrier();            // B_0
   asm volatile("" ::: "memory");
-  READ_FRAGS(wA, aA, 0, 0);
-  for (int g = 0; g < S; ++g) {
+  // One K-step (+ the epilogue after a tile's last one).  HALF: the unit is this workgroup's 128-row half tile (its last unit).
+  // The loop is instantiated twice (full tiles, then the half tile) so that the full-tile path keeps its register allocation.
+  auto k_step = [&](const bool HALF) __attribute__((always_inline)) {
+    // the half-tile copy of the loop recomputes the lane id (2 instructions) instead of keeping lane-derived values alive across the
+    // full-tile loop (the allocator spilled one of them to scratch otherwise)
+    const int lane_h = HALF ? (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) : lane;
+    const int frow = lane_h & 15, fq = lane_h >> 4;
     const bool tile_end = (c_kt == nk - 1);
     READ_FRAGS(wC, aC, c_slot, 1);
     f32x4 bv[4];                           // bias of the NEXT tile (the tail workgroups reload their last tile's: unused)
-    if (tile_end) load_bias(bv, c_tile + G < T ? c_tile + G : c_tile);
+    int n_tile = c_tile;
+    if (tile_end) {
+      if (!HALF) n_tile = (gs + 1 < S_full) ? c_tile + G : (has_half ? half_tile : c_tile);
+      asm volatile("" : "+s"(n_tile));      // keeps the address arithmetic of the bias loads HERE (hoisted, it cost 8 VGPRs for a whole K-step)
+      load_bias(bv, n_tile);
+    }
     MFMA_GROUP(wA, aA, 0);
     MFMA_GROUP(wA, aA, 1);
     MFMA_GROUP(wA, aA, 2);
     MFMA_GROUP(wA, aA, 3);
     const int next_slot = (c_slot == P_NSTAGE - 1) ? 0 : c_slot + 1;
-    if (g + 1 < S) {
+    if (gs + 1 < S) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own reads of slot g%3 are done: the loaders may refill it after B_{g+2}
       __builtin_amdgcn_s_barrier();                        // B_{g+1}: group g+1 has landed
       asm volatile("" ::: "memory");
@@ -581,9 +615,10 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
     MFMA_GROUP(wC, aC, 2);
     MFMA_GROUP(wC, aC, 3);
     c_slot = next_slot;
+    ++gs;
     if (!tile_end) {
       ++c_kt;
-      continue;
+      return;
     }
     // ---- epilogue (same LDS-staged full-line stores as gemm_bf16_persistent)
 #ifdef TR_ABLATE_NO_EPI
@@ -598,8 +633,8 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
       // is safe (the read-back of j-1 is queued before the writes of j), and only one LDS round trip per tile is exposed
       // instead of four.
       unsigned char* stg = smem + P_NSTAGE * P_STAGE_BYTES + wave * 2048;
-      const int rrow = lane >> 3, rch = lane & 7;
-      const int m_first = (c_tile / nNt) * PBM + wm * 64 + rrow;        // row of (slab 0, half 0); +8 per half-slab
+      const int rrow = lane_h >> 3, rch = lane_h & 7;
+      const int m_first = (c_tile / nNt) * PBM + (HALF ? 128 * half_sel : 0) + wm * 64 + rrow;   // row of (slab 0, half 0); +8 per half-slab
       const int n = (c_tile % nNt) * PBN + wn * 64 + rch * 8;
       const unsigned off_first = ((unsigned)m_first * (unsigned)N + (unsigned)n) * 2u;      // < 2 GiB (launcher)
       const unsigned off_step = 16u * (unsigned)N;                                          // 8 rows of bf16
@@ -647,7 +682,20 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
     }
 #endif
     c_kt = 0;
-    c_tile += G;
+    c_tile = n_tile;
+  };
+  READ_FRAGS(wA, aA, 0, 0);
+  for (int g = 0; g < S_full; ++g) k_step(false);
+  if (has_half) {
+    if (wm < 2) {
+      for (int g = 0; g < nk; ++g) k_step(true);
+    } else {
+      // rows 128..255 do not exist in a half tile: these waves only keep the barrier count (one per K-step, none after the last)
+      for (int g = 0; g < nk; ++g) {
+        if (gs + 1 < S) __builtin_amdgcn_s_barrier();
+        ++gs;
+      }
+    }
   }
 #ifdef TR_DIAG_CLOCK
   if (bid == 8 && tid == 0) {   // diagnostic build only: shader clock = d(memtime) / d(memrealtime) * 100 MHz (lab allocates 4 B/elem)
