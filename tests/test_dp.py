@@ -29,7 +29,8 @@ WORKER = textwrap.dedent("""
     cfg, params = case_params(case)
     model.load_state_dict(params)
     st = training.TrainState(model)                        # flat buffer in backward order, p.grad views
-    red = FlatGradReducer(bucket_bytes=256 * 1024).attach(model)
+    red = FlatGradReducer(bucket_bytes=256 * 1024, algorithm=os.environ["TR_DP_ALGO"]).attach(model)
+    assert red.algorithm == os.environ["TR_DP_ALGO"]
     red.broadcast_parameters(model)
     plan = red.plan(st.block_slices, model.depth)
     assert len(plan) >= 3, plan                            # several buckets
@@ -61,11 +62,17 @@ WORKER = textwrap.dedent("""
 """) % ROOT
 
 
-def test_bucketed_gradient_mean_gloo_world2(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("world,algo", [(2, "all_reduce"), (2, "rs_ag"), (4, "rs_ag")])
+def test_bucketed_gradient_mean_gloo(tmp_path, world, algo):
+    """rs_ag = the RCCL path (reduce-scatter into a shard + all-gather in place; this torch's gloo implements both collectives, so
+    the shard arithmetic is exercised at world sizes 2 and 4 on CPU); all_reduce = the fallback for buckets the world size does not divide."""
     script = tmp_path / "dp_worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29617", str(script)], capture_output=True, text=True, env=env, timeout=400)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", TR_DP_ALGO=algo)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                          "--master-port", str(29617 + world + (7 if algo == "rs_ag" else 0)), str(script)], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert "dp ok" in out.stdout

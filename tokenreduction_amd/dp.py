@@ -35,7 +35,7 @@ class FlatGradReducer:
         self.comm_dtype = comm_dtype
         backend = dist.get_backend(process_group)
         if algorithm == "auto":
-            algorithm = "rs_ag" if backend == "nccl" else "all_reduce"      # gloo has no reduce_scatter
+            algorithm = "rs_ag" if backend == "nccl" else "all_reduce"      # xGMI: reduce-scatter + all-gather drive every link; CPU/gloo: one all-reduce
         if algorithm not in ("rs_ag", "all_reduce"):
             raise ValueError("algorithm must be 'auto', 'rs_ag' or 'all_reduce'")
         self.algorithm = algorithm
