@@ -221,6 +221,13 @@ GOLDEN_CASES = {
     "ats_base_kr05": dict(family="ats", embed_dim=768, depth=12, num_heads=12, num_classes=1000,
                           keep_rate=[0.5], reduction_loc=[3, 6, 9], batch=2, wseed=203, xseed=204,
                           qkv_gain=2.0, factory="ats_base_patch16_224"),
+    # BASELINE.json configs[4] at full size: DeiT-B at 384 x 384 (577 tokens), Sinkhorn / K-Medoids keep_rate 0.25
+    "sinkhorn_base_384_kr025": dict(family="sinkhorn", embed_dim=768, depth=12, num_heads=12, num_classes=1000, img_size=384,
+                                    keep_rate=[0.25], reduction_loc=[3, 6, 9], batch=2, wseed=207, xseed=208,
+                                    qkv_gain=2.0, factory="sinkhorn_base_patch16_224"),
+    "kmedoids_base_384_kr025": dict(family="kmedoids", embed_dim=768, depth=12, num_heads=12, num_classes=1000, img_size=384,
+                                    keep_rate=[0.25], reduction_loc=[3, 6, 9], batch=2, wseed=209, xseed=210,
+                                    qkv_gain=2.0, factory="kmedoids_base_patch16_224"),
     # dense DeiT-B: the trunk alone at D = 768 / H = 12 / depth 12 (no discrete decision anywhere)
     "deit_base": dict(family="deit", embed_dim=768, depth=12, num_heads=12, num_classes=1000,
                       keep_rate=[1.0], reduction_loc=[], batch=2, wseed=205, xseed=206,

@@ -149,7 +149,7 @@ def build_reference(case):
     with contextlib.redirect_stdout(io.StringIO()):
         if "factory" in case:
             m = create_model(case["factory"], pretrained=False, num_classes=case["num_classes"], drop_rate=0.0,
-                             drop_path_rate=float(case.get("drop_path", 0.0)), drop_block_rate=None, img_size=224, args=args)
+                             drop_path_rate=float(case.get("drop_path", 0.0)), drop_block_rate=None, img_size=case.get("img_size", 224), args=args)
         else:
             kw = dict(img_size=case.get("img_size", 224), patch_size=16, embed_dim=case["embed_dim"], depth=case["depth"], num_heads=case["num_heads"],
                       mlp_ratio=4, qkv_bias=True, num_classes=case["num_classes"], args=args)

@@ -40,7 +40,7 @@ def build_model(case):
     if "factory" in case:
         m = tra.create_model(case["factory"].replace("_local", "_local_viz") if case["family"] == "deit" else case["factory"],
                              pretrained=False, num_classes=case["num_classes"], drop_rate=0.0,
-                             drop_path_rate=0.0, drop_block_rate=None, img_size=224, args=args)
+                             drop_path_rate=0.0, drop_block_rate=None, img_size=case.get("img_size", 224), args=args)
     else:
         cls = getattr(tra, FAM[case["family"]])
         if case.get("dyvit_distill"):

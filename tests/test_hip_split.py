@@ -125,7 +125,7 @@ def _decisions_match(case, g, viz):
     return same
 
 
-@pytest.mark.parametrize("name", [n for n, c in GOLDEN_CASES.items() if not c.get("train_only") and c.get("img_size", 224) == 224])
+@pytest.mark.parametrize("name", [n for n, c in GOLDEN_CASES.items() if not c.get("train_only")])      # 384 x 384: split GEMMs, VALU attention
 def test_model_bf16x3_free_running_against_reference_golden(golden_dir, name):
     case = GOLDEN_CASES[name]
     g = np.load(os.path.join(golden_dir, name + ".npz"))
