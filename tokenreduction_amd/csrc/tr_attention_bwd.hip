@@ -107,18 +107,23 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const uint16_t* _
     }
 
   const int nqb = (N + 63) >> 6;
+  // Q and dO rows of a query block travel global -> registers -> LDS.  The loads of block qb + 1 are issued right after block qb's
+  // registers have been written to LDS, so they fly under block qb's phases (the barriers inside a block wait for LDS only).
+  uint4 qreg[2], oreg[2];
+  auto load_block = [&](int qb) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int c = tid + 256 * it, r = c >> 3, ch = c & 7;
+      const int i = qb * 64 + r;
+      qreg[it] = *reinterpret_cast<const uint4*>(base + (size_t)min(i, N - 1) * ldq + qcol + ch * 8);
+      oreg[it] = *reinterpret_cast<const uint4*>(dobase + (size_t)min(i, N - 1) * ldo + ch * 8);
+    }
+  };
+  load_block(0);
   for (int qb = 0; qb < nqb; ++qb) {
     // ---- stage this block's Q and dO rows (rows >= N: zero)
     {
-      uint4 qreg[2], oreg[2];
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        const int c = tid + 256 * it, r = c >> 3, ch = c & 7;
-        const int i = qb * 64 + r;
-        qreg[it] = *reinterpret_cast<const uint4*>(base + (size_t)min(i, N - 1) * ldq + qcol + ch * 8);
-        oreg[it] = *reinterpret_cast<const uint4*>(dobase + (size_t)min(i, N - 1) * ldo + ch * 8);
-      }
-      __syncthreads();                // every wave is done with the previous block's Q, dO, P, dS images
+      __syncthreads();                // every wave is done with the previous block's Q, dO, P, dS images (and the loads have landed)
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int c = tid + 256 * it, r = c >> 3, ch = c & 7;
@@ -129,7 +134,8 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const uint16_t* _
         *reinterpret_cast<uint4*>(sQ + qswz(r, ch)) = qreg[it];
         *reinterpret_cast<uint4*>(sDO + qswz(r, ch)) = oreg[it];
       }
-      __syncthreads();
+      if (qb + 1 < nqb) load_block(qb + 1);
+      lds_barrier();
     }
 
     // ---- phase 1: this wave's 16 queries (rows 16*wave + li of the block) against all keys
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const uint16_t* _
         }
       }
     }
-    __syncthreads();                  // P and dS rows of all four waves are in LDS
+    lds_barrier();                    // P and dS rows of all four waves are in LDS (LDS-only wait: the next block's loads stay in flight)
     // ---- phase 2: dK^T[d][key] += sum_query Q[query][d] dS[query][key], dV^T[d][key] += sum_query dO[query][d] P[query][key]
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
