@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <atomic>
 #include "../../include/tokenreduction_hip.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -41,6 +42,19 @@ void tr_prof_note(const char* label, double flops, double bytes);
       return TR_ERR_LAUNCH;                                                     \
     }                                                                           \
     tr_prof_mark(name);                                                         \
+  } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is sticky per kernel: raise it only when a launch needs more than any earlier one did
+// (otherwise a host-side driver call per launch).  One cache per expansion site: use one site per kernel instantiation.
+#define TR_RESERVE_LDS(fn_ptr, bytes, what)                                                                                     \
+  do {                                                                                                                          \
+    static std::atomic<size_t> have__{0};                                                                                       \
+    const size_t want__ = (bytes);                                                                                              \
+    if (want__ > have__.load(std::memory_order_relaxed)) {                                                                      \
+      hipError_t e__ = hipFuncSetAttribute((fn_ptr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want__);                  \
+      TR_REQUIRE(e__ == hipSuccess, TR_ERR_LAUNCH, "%s: cannot reserve %zu B of LDS: %s", (what), want__, hipGetErrorString(e__)); \
+      have__.store(want__, std::memory_order_relaxed);                                                                          \
+    }                                                                                                                           \
   } while (0)
 
 static inline bool tr_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -275,8 +275,7 @@ extern "C" int tr_attention_f32(const float* qkv, float* out, float* cls_rows, c
     return TR_OK;
   }
   const size_t lds = (size_t)(64 * NP + NP * 64 + 4 * 64 + 4 * NP) * sizeof(float);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_f32_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_attention_f32: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+  TR_RESERVE_LDS(reinterpret_cast<const void*>(attention_f32_kernel<false>), lds, "tr_attention_f32");
   hipLaunchKernelGGL(attention_f32_kernel<false>, dim3(B * H), dim3(256), lds, st, qkv, out, cls_rows, size, colsum_part, N, H);
   TR_CHECK_LAUNCH("tr_attention_f32");
   return TR_OK;
@@ -288,8 +287,7 @@ extern "C" int tr_attention_policy_f32(const float* qkv, float* out, const float
   const int NP = (N + 63) & ~63;
   const size_t lds = (size_t)(64 * NP + NP * 64 + 4 * 64 + 4 * NP) * sizeof(float);
   hipStream_t st = static_cast<hipStream_t>(s);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_f32_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_attention_policy_f32: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+  TR_RESERVE_LDS(reinterpret_cast<const void*>(attention_f32_kernel<true>), lds, "tr_attention_policy_f32");
   hipLaunchKernelGGL(attention_f32_kernel<true>, dim3(B * H), dim3(256), lds, st, qkv, out, static_cast<float*>(nullptr), policy,
                      static_cast<float*>(nullptr), N, H);
   TR_CHECK_LAUNCH("tr_attention_policy_f32");

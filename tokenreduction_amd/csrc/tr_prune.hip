@@ -579,9 +579,7 @@ extern "C" int tr_softassign_merge(const float* logits, int ldl, float scale, co
   const dim3 grid((K + SKC - 1) / SKC, B);
 #define TR_SIT_LAUNCH(J)                                                                                                          \
   do {                                                                                                                            \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sit_merge_kernel<J, true>),                                  \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
-    TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_sit_merge: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));       \
+    TR_RESERVE_LDS(reinterpret_cast<const void*>(sit_merge_kernel<J, true>), lds, "tr_sit_merge");                                \
     hipLaunchKernelGGL((sit_merge_kernel<J, true>), grid, dim3(256), lds, st, logits, ldl, scale, x, src, x_out, soft, N, K, D);  \
   } while (0)
   switch ((D + 255) / 256) {
@@ -620,8 +618,7 @@ extern "C" int tr_sinkhorn(const float* scores, int ldl, float eps, int iters, f
     TR_CHECK_LAUNCH("tr_sinkhorn");
     return TR_OK;
   }
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sinkhorn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_sinkhorn: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+  TR_RESERVE_LDS(reinterpret_cast<const void*>(sinkhorn_kernel), lds, "tr_sinkhorn");
   hipLaunchKernelGGL(sinkhorn_kernel, dim3(B), dim3(SKT), lds, st, scores, ldl, eps, iters, wt, soft, N, K);
   TR_CHECK_LAUNCH("tr_sinkhorn");
   return TR_OK;
@@ -639,9 +636,7 @@ extern "C" int tr_weighted_merge(const float* wt, int ldl, const float* x, const
   const dim3 grid((K + SKC - 1) / SKC, B);
 #define TR_WM_LAUNCH(J)                                                                                                           \
   do {                                                                                                                            \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sit_merge_kernel<J, false>),                                 \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
-    TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_weighted_merge: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));  \
+    TR_RESERVE_LDS(reinterpret_cast<const void*>(sit_merge_kernel<J, false>), lds, "tr_weighted_merge");                          \
     hipLaunchKernelGGL((sit_merge_kernel<J, false>), grid, dim3(256), lds, st, wt, ldl, 1.0f, x, src, x_out,                      \
                        static_cast<float*>(nullptr), N, K, D);                                                                    \
   } while (0)

@@ -351,8 +351,7 @@ extern "C" int tr_sinkhorn_bwd(const float* scores, const float* dplan, int ldl,
   const size_t lds = sinkhorn_bwd_lds(N, K, iters);
   TR_REQUIRE(lds <= 160 * 1024, TR_ERR_SHAPE, "tr_sinkhorn_bwd: K=%d x P=%d needs %zu B of LDS (the training path holds the score matrix of an image "
              "in LDS: 224x224 inputs)", K, N - 1, lds);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sinkhorn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_sinkhorn_bwd: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+  TR_RESERVE_LDS(reinterpret_cast<const void*>(sinkhorn_bwd_kernel), lds, "tr_sinkhorn_bwd");
   hipLaunchKernelGGL(sinkhorn_bwd_kernel, dim3(B), dim3(SB_T), lds, static_cast<hipStream_t>(s), scores, dplan, ldl, eps, iters, ds, ldo, N, K);
   TR_CHECK_LAUNCH("tr_sinkhorn_bwd");
   return TR_OK;

@@ -301,13 +301,7 @@ int launch_attention_split_(const float* qkv, float* out, float* cls_rows, const
                            hipStream_t st) {
   constexpr int NP = NT * 16;
   const size_t lds = (size_t)2 * NP * A_KROW + (size_t)2 * 64 * (NP * 2 + 8) + (size_t)NP * 4;
-  static bool reserved = false;
-  if (!reserved) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_split_kernel<NT, COLSUM>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_attention_split: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-    reserved = true;
-  }
+  TR_RESERVE_LDS(reinterpret_cast<const void*>(attention_split_kernel<NT, COLSUM>), lds, "tr_attention_split");
   hipLaunchKernelGGL((attention_split_kernel<NT, COLSUM>), dim3(B * H), dim3(256), lds, st, qkv, out, cls_rows, size, colsum_part, N, H);
   return TR_OK;
 }

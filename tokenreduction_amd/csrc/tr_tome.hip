@@ -288,11 +288,13 @@ extern "C" int tr_tome_match(const void* qkv, int qkv_is_f32, int32_t* unm_idx, 
   TR_REQUIRE(tr_aligned16(qkv), TR_ERR_ALIGN, "tr_tome_match: qkv must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(s);
   const size_t lds = (size_t)N * MST * sizeof(float);
-  const void* fn = qkv_is_f32 ? reinterpret_cast<const void*>(tome_match_kernel<true>) : reinterpret_cast<const void*>(tome_match_kernel<false>);
-  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_tome_match: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-  if (qkv_is_f32) hipLaunchKernelGGL(tome_match_kernel<true>, dim3(B), dim3(TMT), lds, st, qkv, unm_idx, src_idx, dst_idx, N, H, r);
-  else hipLaunchKernelGGL(tome_match_kernel<false>, dim3(B), dim3(TMT), lds, st, qkv, unm_idx, src_idx, dst_idx, N, H, r);
+  if (qkv_is_f32) {
+    TR_RESERVE_LDS(reinterpret_cast<const void*>(tome_match_kernel<true>), lds, "tr_tome_match");
+    hipLaunchKernelGGL(tome_match_kernel<true>, dim3(B), dim3(TMT), lds, st, qkv, unm_idx, src_idx, dst_idx, N, H, r);
+  } else {
+    TR_RESERVE_LDS(reinterpret_cast<const void*>(tome_match_kernel<false>), lds, "tr_tome_match");
+    hipLaunchKernelGGL(tome_match_kernel<false>, dim3(B), dim3(TMT), lds, st, qkv, unm_idx, src_idx, dst_idx, N, H, r);
+  }
   TR_CHECK_LAUNCH("tr_tome_match");
   return TR_OK;
 }
