@@ -223,3 +223,29 @@ def test_heuristic_masks_match_the_reference(name):
     for k in keys:
         blk = int(k.split("_")[1])
         np.testing.assert_array_equal(m._block_mask(blk).nonzero(as_tuple=True)[0].numpy(), g[k][0])
+
+
+def test_header_is_plain_c_and_the_integration_example_compiles(tmp_path):
+    """The C ABI header must be usable from a C host: compile the documented snippet with gcc -std=c11."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "host.c"
+    src.write_text('''
+#include <stdio.h>
+#include "tokenreduction_hip.h"
+int run(const float* d_images_f32, float* d_logits_f32, void* d_workspace, int B, tr_stream_t stream, const tr_vit_weights* w) {
+  tr_vit_config cfg = { .family = TR_FAMILY_TOPK, .img_size = 224, .patch = 16, .in_chans = 3, .embed_dim = 384, .depth = 12,
+                        .num_heads = 6, .mlp_hidden = 1536, .num_classes = 1000, .ln_eps = 1e-6f, .precision = TR_PREC_BF16 };
+  cfg.keep[3] = 137; cfg.keep[6] = 96; cfg.keep[9] = 67;
+  size_t ws_bytes = tr_vit_workspace_bytes(&cfg, B);
+  int rc = tr_vit_forward(&cfg, w, d_images_f32, d_logits_f32, d_workspace, ws_bytes, NULL, NULL, NULL, NULL, NULL, NULL, B, stream);
+  if (rc != TR_OK) fprintf(stderr, "%s\\n", tr_last_error());
+  return rc;
+}
+''')
+    out = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-c", str(src), "-I", os.path.join(root, "include"), "-o", str(tmp_path / "host.o")],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
