@@ -185,6 +185,8 @@ def finetune_leg(name, keep_rate, loc, batch, device, dist, steps=8, warmup=3, i
     """fwd + loss + bwd + AdamW step through the HIP training path (engine.py:50-91 without the data loader): images/s over all
     ranks.  Under torch.distributed the gradients are averaged by tokenreduction_amd.dp.FlatGradReducer (RCCL reduce-scatter +
     all-gather per bucket, overlapped with the backward)."""
+    steps = int(os.environ.get("TR_BENCH_FINETUNE_STEPS", steps))           # test rigs shorten the legs
+    warmup = min(warmup, steps)
     model = build_model(name, keep_rate, loc, device, img_size).train()
     rank = dist.get_rank() if dist is not None else 0
     world = dist.get_world_size() if dist is not None else 1
@@ -307,12 +309,18 @@ def main():
         if dist is not None:
             dist.destroy_process_group()
         return
+    # TR_BENCH_SHARE_GPU=1 (test rigs with ONE GPU): all ranks use cuda:0 and the collectives go through gloo (RCCL refuses two ranks
+    # on one device) -- exercises the N > 1 code path end to end; the numbers it prints mean nothing.
+    share = os.environ.get("TR_BENCH_SHARE_GPU") == "1"
     if dist is not None:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(0 if share else local_rank)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    dev = torch.device("cuda", local_rank if (world > 1 and not share) else 0)
 
     # data-parallel inference: every rank owns its own shard of images (one batch of 256), weights replicated, no collective
     # on the data path

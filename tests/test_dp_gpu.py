@@ -1,0 +1,89 @@
+"""Row a24 / e2 on the GPU: two data-parallel ranks SHARING the box's one MI355X (RCCL refuses two ranks on one device, so the
+collectives go through gloo, which reduces HIP tensors too).  Everything else is the production path: each rank runs the HIP
+training forward / backward on its own shard of images, the backward is walked in block ranges, every finished bucket is
+reduce-scattered + all-gathered on the side stream while the next range runs, and the result must be the mean of the two ranks'
+single-process gradients."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r)
+    import torch, torch.distributed as dist
+    from tokenreduction_amd.dp import FlatGradReducer
+    from tests._params import GOLDEN_CASES, grad_labels, make_images
+    from tests.test_hip_model import build_model
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    name = os.environ["TR_DP_CASE"]
+    case = GOLDEN_CASES[name]
+    model, _, _ = build_model(case)
+    model.viz_mode = False
+    model.train()
+
+    def shard(r):
+        x = make_images(case["batch"], 224, case["xseed"] + 100 * r).cuda()
+        y = grad_labels(dict(case, xseed=case["xseed"] + 100 * r)).cuda()
+        return x, y
+
+    def backward(x, y):
+        model.zero_grad(set_to_none=True)
+        torch.nn.functional.cross_entropy(model(x), y).backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.clone() for n, p in model.named_parameters()}
+
+    local = [backward(*shard(r)) for r in range(world)]           # every rank computes both shards' gradients on its own (no reducer)
+    want = {n: sum(g[n] for g in local) / world for n in local[0]}
+    red = FlatGradReducer(bucket_bytes=256 * 1024, algorithm=os.environ["TR_DP_ALGO"]).attach(model)
+    red.broadcast_parameters(model)
+    for rep in range(2):
+        got = backward(*shard(rank))                              # this rank's shard, reduced in buckets during the backward
+        assert len(red.launched) >= 3, red.launched
+        for n in want:
+            assert torch.allclose(got[n], want[n], rtol=1e-5, atol=1e-7), (rep, n, float((got[n] - want[n]).abs().max()))
+    if rank == 0:
+        print("dp gpu ok", name, len(red.launched), "buckets")
+    dist.destroy_process_group()
+""") % ROOT
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case,algo", [("topk_micro", "rs_ag"), ("dpcknn_micro", "rs_ag"), ("evit_micro", "all_reduce")])
+def test_two_ranks_average_their_hip_gradients(tmp_path, case, algo):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    script = tmp_path / "dp_gpu_worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", TR_DP_CASE=case, TR_DP_ALGO=algo)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29641", str(script)], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "dp gpu ok" in out.stdout
+
+
+@pytest.mark.gpu
+def test_bench_runs_its_two_rank_path_on_one_gpu(tmp_path):
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per process) with both ranks on the box's one GPU
+    (TR_BENCH_SHARE_GPU=1: gloo collectives): the headline line and all three data-parallel fine-tune legs must come out."""
+    import json
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", TR_BENCH_SHARE_GPU="1", TR_BENCH_FINETUNE_STEPS="2")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29643", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-1500:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2" and rec["scaling"] == "weak" and rec["value"] > 0
+    assert len(rec["finetune"]) == 3 and all("error" not in v and v["n_gpus"] == 2 for v in rec["finetune"].values()), rec["finetune"]
