@@ -382,7 +382,12 @@ def main():
                                                [196 - 16 * (i + 1) for i in range(12)], list(range(12)), 256)):
                 rec["finetune"][label] = finetune_leg(name, kr, loc, bsz, dev, None, steps=5, warmup=2)
             roof, table, step_ms = roofline_leg(model, x)
-            roof["traffic"] = pmc_traffic(roof["kernel"])
+            # `traffic`: HBM bytes per launch of the dominant kernel as a plain number (or null), from the PMC passes committed with the
+            # profile of these very kernel sources (source hash); where it came from / why it is null goes to `traffic_source`
+            t = pmc_traffic(roof["kernel"])
+            roof["traffic"] = None if t is None else t.get("hbm_bytes_per_launch")
+            roof["traffic_unit"] = "B/launch"
+            roof["traffic_source"] = None if t is None else (t.get("source") + ("" if t.get("note") is None else ": " + t["note"]))
             rec["roofline"] = roof
             rec["kernels"] = table
             rec["profiled_ms_per_step"] = round(step_ms, 3)      # same executor, plain launches with an event after each
