@@ -79,6 +79,32 @@ def test_gemm(ops, M, N, K, epi):
         torch.testing.assert_close(out.cpu(), ref.float(), atol=2e-4, rtol=1e-5)
 
 
+@pytest.mark.parametrize("M,N,K,why", [
+    (30000, 384, 384, "354 tiles = 1 round + 98: tail as 196 half tiles; the last M tile has 48 rows, so one half tile has NO valid row"),
+    (50432, 384, 1536, "591 tiles: 2 rounds + 79 tail tiles split (fc2 of the headline config)"),
+    (24832, 1152, 384, "873 tiles: 3 rounds + 105 split (qkv at 97 tokens)"),
+    (12000, 384, 384, "141 tiles < 256 and > 128: ONE round of full tiles, nothing split"),
+    (9000, 256, 128, "72 tiles <= 128: every tile runs as two half tiles"),
+    (129, 136, 64, "2 tiles, both ragged: second half tile of rows 128..255 holds one valid row, columns 128..135 ragged"),
+])
+@pytest.mark.parametrize("epi", ["bf16", "gelu"])
+def test_gemm_half_tile_tail_round(ops, M, N, K, why, epi):
+    """gemm_bf16_pc cuts the tail round into 128-row half tiles when at most half the workgroups would get a tile (tr_gemm.hip): every
+    row of the output against the float64 Linear on the bf16-rounded operands, for tile counts on both sides of every scheduling case."""
+    rng = np.random.default_rng(M + N)
+    a, w, b = _randn(rng, M, K).bfloat16(), _randn(rng, N, K, scale=0.05).bfloat16(), _randn(rng, N, scale=0.1)
+    out = ops.gemm(a.cuda(), w.cuda(), b.cuda(), ops.TR_EPI_GELU_BF16 if epi == "gelu" else ops.TR_EPI_BF16)
+    rows = torch.cat([torch.arange(0, min(M, 300)), torch.arange(max(0, M - 700), M), torch.arange(0, M, 997)]).unique()
+    ref = a[rows].double() @ w.double().t() + b.double()
+    if epi == "gelu":
+        ref = oracle.gelu_erf(ref)
+    torch.testing.assert_close(out[rows.cuda()].cpu().double(), ref, atol=2e-2, rtol=1.2e-2)
+    # and nothing outside the [M, N] output was touched / left unwritten: a second call on a poisoned buffer gives the same bits
+    out2 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ops.gemm(a.cuda(), w.cuda(), b.cuda(), ops.TR_EPI_GELU_BF16 if epi == "gelu" else ops.TR_EPI_BF16, out=out2)
+    assert torch.equal(out, out2) and not torch.isnan(out2.float()).any()
+
+
 def test_gemm_operand_roles_not_transposed(ops):
     """A = I-like probe with an ASYMMETRIC weight: catches a swapped row/col map in the accumulator write."""
     M = N = K = 128
