@@ -278,6 +278,12 @@ int tr_layernorm_bwd_scatter_add(const uint16_t* dy, const float* x, const float
                                  size_t ws_floats, int M, int D, float eps, tr_stream_t s);   /* repeated ids: rows are added (atomics) */
 int tr_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, const float* size, const float* dcls, uint16_t* dqkv, int B,
                           int N, int H, tr_stream_t s);
+/* The same gradient for ANY sequence length (the training executor uses it beyond 224 tokens: 384 x 384 inputs): keys in blocks of 64,
+ * three launches per call -- per-query statistics (log-sum-exp and delta = sum_k p dP by online softmax), dQ per query block, dK / dV
+ * per key block -- 9 N x N x 64 products per head instead of 5, no float atomics.  ws: tr_attention_bwd_long_workspace_floats floats. */
+size_t tr_attention_bwd_long_workspace_floats(int B, int N, int H);
+int tr_attention_bwd_long_bf16(const uint16_t* qkv, const uint16_t* dout, const float* size, const float* dcls, uint16_t* dqkv, float* ws,
+                               size_t ws_floats, int B, int N, int H, tr_stream_t s);
 int tr_head_bwd(const float* dlogits, const uint16_t* W, const uint16_t* xn, uint16_t* dxn, float* dW, float* db, int accumulate,
                 uint16_t* dl16, float* ws, size_t ws_floats, int B, int C, int D, tr_stream_t s);
 int tr_embed_bwd(const float* g, float* dpos, float* dcls, int accumulate, int B, int N, int D, tr_stream_t s);

@@ -201,6 +201,33 @@ def test_attention_bwd_cls_gradient(ops):
     assert rel_l2(got, qf.grad) <= 1.2e-2
 
 
+@pytest.mark.parametrize("B,N,H", [(2, 577, 3), (1, 290, 2), (2, 197, 6), (1, 65, 1), (3, 64, 2), (1, 640, 1), (2, 17, 1)])
+@pytest.mark.parametrize("bias", [False, True])
+def test_attention_bwd_long(ops, B, N, H, bias):
+    """The key-blocked backward (any N; the executor's choice beyond 224 tokens) against torch.autograd, masked keys and the EViT
+    d cls_attn path included; at N <= 224 also against the register-resident kernel it replaces there."""
+    qkv = _randn(30, B * N, 3 * H * 64, dtype=torch.bfloat16)
+    dout = _randn(31, B * N, H * 64, dtype=torch.bfloat16)
+    dcls = _randn(32, B, N, scale=0.5)
+    dcls[:, 0] = 0
+    size = None
+    if bias:
+        size = (torch.rand(B, N, generator=torch.Generator().manual_seed(3)) * 3 + 1).floor().cuda()
+        size[:, -1] = 0.0 if N > 20 else 1.0
+    qf = qkv.float().requires_grad_(True)
+    out, p = _attn_ref(qf, B, N, H, size)
+    ((out * dout.float()).sum() + (p[:, :, 0, :].mean(1) * dcls).sum()).backward()
+    got = ops.attention_bwd_long(qkv, dout, B, N, H, size=size, dcls=dcls)
+    want = qf.grad.view(B * N, 3, H * 64)
+    gv = got.float().view(B * N, 3, H * 64)
+    for i, nm in enumerate("qkv"):
+        r = rel_l2(gv[:, i], want[:, i])
+        assert r <= 1.2e-2, f"d{nm}: rel L2 {r:.3e}"
+    if N <= 224:
+        short = ops.attention_bwd(qkv, dout, B, N, H, size=size, dcls=dcls)
+        assert rel_l2(got.float(), short.float()) <= 8e-3          # two roundings of P / dS apart
+
+
 def test_head_and_embed_bwd(ops):
     B, Cc, D, N = 32, 1000, 384, 68
     dl = _randn(25, B, Cc, scale=0.01)

@@ -54,6 +54,8 @@ SIGNATURES = {
     "tr_im2col_bf16": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tr_im2col_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tr_gemm_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "tr_attention_bwd_long_workspace_floats": (_sz, [_i, _i, _i]),
+    "tr_attention_bwd_long_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
     "tr_soft_dweights": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tr_soft_dsrc": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "tr_token_softmax_bwd_workspace_floats": (_sz, [_i, _i]),

@@ -17,7 +17,7 @@ using trplan::align_up;
 namespace {
 
 struct BwdPlan {
-  size_t g0, g1, gb0, gb1, dxn, dqkv, dao, dh, zeros, wsf, dscore, gfused, invmap, dxcls, dl16, dpol, dprev, dpolpart, soft_dp, soft_ds, soft_s, total;
+  size_t g0, g1, gb0, gb1, dxn, dqkv, dao, dh, zeros, wsf, dscore, gfused, invmap, dxcls, dl16, dpol, dprev, dpolpart, soft_dp, soft_ds, soft_s, attn_stats, total;
   size_t wsf_floats;
 };
 
@@ -68,6 +68,7 @@ bool make_bwd_plan(const tr_vit_config* c, int B, const trplan::TokenPlan& t, Bw
   p->dpol = take(T * 4);
   p->dprev = take(T * 4);
   p->dpolpart = take(T * c->num_heads * 4);
+  p->attn_stats = t.N0 > 224 ? take(tr_attention_bwd_long_workspace_floats(B, t.N0, c->num_heads) * 4) : 0;
   p->soft_dp = p->soft_ds = p->soft_s = 0;
   if (soft_k > 0) {
     p->soft_dp = take(T * trplan::soft_ld(soft_k) * 4);
@@ -262,6 +263,9 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
       float* dpart = reinterpret_cast<float*>(ws + bp.dpolpart);
       TR_TRY(tr_attention_policy_bwd_bf16(U(tape + bt.qkv), dao, pol, dqkv, dpart, B, Na, H, s));
       TR_TRY(tr_head_sum(dpart, reinterpret_cast<float*>(ws + bp.dpol), B, H, Na, s));
+    } else if (Na > 224) {       // 384 x 384 inputs: key-blocked kernels (tr_attention_bwd_long.hip)
+      TR_TRY(tr_attention_bwd_long_bf16(U(tape + bt.qkv), dao, size_att, dcls, dqkv, reinterpret_cast<float*>(ws + bp.attn_stats),
+                                        tr_attention_bwd_long_workspace_floats(B, t.N0, H), B, Na, H, s));
     } else {
       TR_TRY(tr_attention_bwd_bf16(U(tape + bt.qkv), dao, size_att, dcls, dqkv, B, Na, H, s));
     }

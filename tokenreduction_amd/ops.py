@@ -611,3 +611,14 @@ def rownorm_bwd(x: torch.Tensor, da: torch.Tensor, db: torch.Tensor = None) -> t
 def add_into_bf16(a: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     _lib.check(_lib.load().tr_add_into_bf16(_dev(a, torch.float32, "a"), _dev(y, torch.bfloat16, "y"), a.numel(), _stream()), "tr_add_into_bf16")
     return y
+
+
+def attention_bwd_long(qkv: torch.Tensor, dout: torch.Tensor, B: int, N: int, H: int, size: torch.Tensor = None, dcls: torch.Tensor = None):
+    """tr_attention_bwd_bf16's gradient for any sequence length (key-blocked kernels; what the training executor runs beyond 224 tokens)."""
+    lib = _lib.load()
+    dqkv = torch.empty_like(qkv)
+    ws = _ws(lib.tr_attention_bwd_long_workspace_floats(B, N, H), qkv.device)
+    _lib.check(lib.tr_attention_bwd_long_bf16(_dev(qkv, torch.bfloat16, "qkv"), _dev(dout, torch.bfloat16, "dout"), _opt(size, torch.float32, "size"),
+                                              _opt(dcls, torch.float32, "dcls"), dqkv.data_ptr(), ws.data_ptr(), ws.numel(), B, N, H, _stream()),
+               "tr_attention_bwd_long_bf16")
+    return dqkv
