@@ -132,6 +132,12 @@ int tr_gather_layernorm_f32(const float* x, const float* delta, const int32_t* i
                             const float* gamma, const float* beta, float* x_out, float* y, int B, int N, int K, int D,
                             float eps, tr_stream_t s);                                                  /* fp32 validation path */
 
+/* The training forward's Linear + GELU (timm Mlp fc1, the DyViT / SiT predictor layers): pre bf16 [M,N] = A W^T + bias stays for the
+ * backward, h bf16 [M,N] = gelu(pre) on the ROUNDED pre-activation -- bitwise tr_gemm_bf16(TR_EPI_BF16) followed by tr_gelu_bf16, in
+ * one launch.  K % 64 == 0, N % 8 == 0. */
+int tr_gemm_gelu_keep_bf16(const uint16_t* A, const uint16_t* W, const float* bias, uint16_t* pre, uint16_t* h, int M, int N, int K,
+                           tr_stream_t s);
+
 /* fp32 validation path of the Linear layers: A fp32 [M,K], W fp32 [N,K], out fp32; K % 16 == 0.
  * epilogue: TR_EPI_F32 (bias), TR_EPI_GELU_BF16 (bias + exact-erf GELU, fp32 out), TR_EPI_PATCH_F32. */
 int tr_gemm_f32(const float* A, const float* W, const float* bias, float* out, const float* aux, int aux_i, int M, int N, int K,

@@ -418,3 +418,16 @@ def test_rownorm_bwd_and_add_into_bf16(ops):
     y = db.clone().cuda()
     ops.add_into_bf16(da.cuda(), y)
     assert torch.equal(y.cpu(), (da + db.float()).bfloat16())
+
+
+@pytest.mark.parametrize("M,N,K", [(50432, 1536, 384), (300, 1536, 384), (30000, 384, 384), (777, 192, 576), (5, 16, 128)])
+def test_gemm_gelu_keep_is_bitwise_the_two_launch_path(ops, M, N, K):
+    """fc1 of the training forward in one launch: the pre-activation and its GELU must be bit for bit what tr_gemm_bf16(TR_EPI_BF16)
+    followed by tr_gelu_bf16 produce (the backward differentiates the stored pre-activation)."""
+    a = _randn(40, M, K, dtype=torch.bfloat16)
+    w = _randn(41, N, K, scale=0.05, dtype=torch.bfloat16)
+    b = _randn(42, N, scale=0.1)
+    pre, h = ops.gemm_gelu_keep(a, w, b)
+    pre2 = ops.gemm(a, w, b, ops.TR_EPI_BF16)
+    assert torch.equal(pre, pre2)
+    assert torch.equal(h, ops.gelu(pre2))

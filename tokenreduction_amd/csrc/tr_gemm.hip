@@ -36,6 +36,7 @@ constexpr int BK = 64;
 constexpr int PBM = 256, PBN = 128;
 constexpr int P_STAGE_BYTES = (PBM + PBN) * 128;  // 48 KiB: A rows then W rows, 128 B (64 bf16) per row
 constexpr int P_NSTAGE = 3;
+constexpr int EPI_GELU_KEEP = 16;     // internal: TR_EPI_GELU_BF16 plus the pre-activation as a second bf16 output (tr_gemm_gelu_keep_bf16)
 // LDS-DMA pieces per wave and K-step in gemm_bf16_persistent: 4 of A, 2 of W = 6 (what its vmcnt immediates count)
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -438,9 +439,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persistent(const uint16_t* _
 // after it the loaders refill that slot with group g+2 and the MFMA waves read slot g%3.
 template <int EPI>
 __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
-                                                       const float* __restrict__ bias, uint16_t* __restrict__ outp, int M, int N,
-                                                       int K, int nMt, int nNt, unsigned out_bytes) {
-  static_assert(EPI == TR_EPI_BF16 || EPI == TR_EPI_GELU_BF16, "bf16-output epilogues only");
+                                                       const float* __restrict__ bias, uint16_t* __restrict__ outp,
+                                                       uint16_t* __restrict__ outp2, int M, int N, int K, int nMt, int nNt,
+                                                       unsigned out_bytes) {
+  // EPI_GELU_KEEP (training forward of fc1): outp2 receives the pre-activation, outp its GELU -- one pass instead of a GEMM that
+  // writes the pre-activation and an elementwise kernel that re-reads it (0.37 ms of a 12.5 ms DeiT-S step)
+  static_assert(EPI == TR_EPI_BF16 || EPI == TR_EPI_GELU_BF16 || EPI == EPI_GELU_KEEP, "bf16-output epilogues only");
   __shared__ __attribute__((aligned(16))) unsigned char smem[P_NSTAGE * P_STAGE_BYTES + 8 * 2048];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -541,6 +545,7 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
   const int wm = wave >> 1, wn = wave & 1;
   const int frow = lane & 15, fq = lane >> 4;
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(outp, 0, (int)out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t orsrc2 = __builtin_amdgcn_make_buffer_rsrc(EPI == EPI_GELU_KEEP ? outp2 : outp, 0, (int)out_bytes, 0x00020000);
   // The accumulators START at the bias of the tile's columns (instead of zero + a bias add in the epilogue: 64 VALU adds per lane
   // and tile less, in the one phase where the matrix pipe idles); the next tile's bias is fetched under the last K-step.
   auto load_bias = [&](f32x4 (&bv)[4], int tile) __attribute__((always_inline)) {
@@ -639,12 +644,18 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
       const unsigned off_first = ((unsigned)m_first * (unsigned)N + (unsigned)n) * 2u;      // < 2 GiB (launcher)
       const unsigned off_step = 16u * (unsigned)N;                                          // 8 rows of bf16
       const unsigned char* rd = stg + rrow * 128 + ((rch ^ rrow) << 4);                     // (row & 7) == rrow for both halves
-      auto stage = [&](int j) __attribute__((always_inline)) {
+      // PRE: stage the pre-activation itself and leave the accumulators alone (EPI_GELU_KEEP's first pass over a slab)
+      auto stage_ = [&](int j, const bool PRE) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float v0 = acc[i][j][0], v1 = acc[i][j][1], v2 = acc[i][j][2], v3 = acc[i][j][3];
-          acc[i][j] = bv[i];
-          if (EPI == TR_EPI_GELU_BF16) {
+          if (!PRE) acc[i][j] = bv[i];
+          if (!PRE && (EPI == TR_EPI_GELU_BF16 || EPI == EPI_GELU_KEEP)) {
+            if (EPI == EPI_GELU_KEEP) {        // GELU of the ROUNDED pre-activation: what the backward differentiates (tr_gelu_bwd_bf16 reads it)
+              const unsigned r01 = pack_bf16x2(v0, v1), r23 = pack_bf16x2(v2, v3);
+              v0 = __builtin_bit_cast(float, r01 << 16); v1 = __builtin_bit_cast(float, r01 & 0xffff0000u);
+              v2 = __builtin_bit_cast(float, r23 << 16); v3 = __builtin_bit_cast(float, r23 & 0xffff0000u);
+            }
             const f32x2 g01 = gelu2(f32x2{v0, v1}), g23 = gelu2(f32x2{v2, v3});
             v0 = g01[0]; v1 = g01[1]; v2 = g23[0]; v3 = g23[1];
           }
@@ -656,12 +667,13 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
           *reinterpret_cast<u32x2*>(stg + frow * 128 + (((2 * i + (fq >> 1)) ^ (frow & 7)) << 4) + (((fq & 1) ^ (frow >> 3)) << 3)) = pk;
         }
       };
+      auto stage = [&](int j) __attribute__((always_inline)) { stage_(j, false); };
       auto read_back = [&](u32x4 (&ln)[2]) __attribute__((always_inline)) {
         ln[0] = *reinterpret_cast<const u32x4*>(rd);
         const u32x4 t = *reinterpret_cast<const u32x4*>(rd + 1024);       // rows 8..15: halves swapped
         ln[1] = u32x4{t[2], t[3], t[0], t[1]};
       };
-      auto store = [&](int j, const u32x4 (&ln)[2]) __attribute__((always_inline)) {
+      auto store_ = [&](int j, const u32x4 (&ln)[2], const bool SECOND) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 2; ++r) {
           bool ok = (m_first + 8 * (2 * j + r) < M) && (n < N);
@@ -670,15 +682,28 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
 #endif
           // out-of-range lanes get an offset beyond num_records: the buffer bounds check drops their store
           const unsigned off = ok ? off_first + (unsigned)(2 * j + r) * off_step : 0x80000000u;
-          __builtin_amdgcn_raw_buffer_store_b128(ln[r], orsrc, off, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(ln[r], SECOND ? orsrc2 : orsrc, off, 0, 0);
         }
       };
+      auto store = [&](int j, const u32x4 (&ln)[2]) __attribute__((always_inline)) { store_(j, ln, false); };
       u32x4 lnA[2], lnB[2];
-      stage(0); read_back(lnA);
-      stage(1); store(0, lnA); read_back(lnB);
-      stage(2); store(1, lnB); read_back(lnA);
-      stage(3); store(2, lnA); read_back(lnB);
-      store(3, lnB);
+      if (EPI == EPI_GELU_KEEP) {
+        // every slab passes the stage twice: pre-activation (to outp2), then its GELU (to outp); same one-ahead pipelining
+        stage_(0, true); read_back(lnA);
+        stage_(0, false); store_(0, lnA, true); read_back(lnB);
+#pragma unroll
+        for (int j = 1; j < 4; ++j) {
+          stage_(j, true); store_(j - 1, lnB, false); read_back(lnA);
+          stage_(j, false); store_(j, lnA, true); read_back(lnB);
+        }
+        store_(3, lnB, false);
+      } else {
+        stage(0); read_back(lnA);
+        stage(1); store(0, lnA); read_back(lnB);
+        stage(2); store(1, lnB); read_back(lnA);
+        stage(3); store(2, lnA); read_back(lnB);
+        store(3, lnB);
+      }
     }
 #endif
     c_kt = 0;
@@ -746,11 +771,11 @@ extern "C" int tr_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* b
   if (epilogue == TR_EPI_BF16 || epilogue == TR_EPI_GELU_BF16) {
     // the per-block GEMMs: 8 MFMA waves + 4 loader waves
     if (epilogue == TR_EPI_BF16)
-      hipLaunchKernelGGL(gemm_bf16_pc<TR_EPI_BF16>, grid, dim3(768), 0, st, A, W, bias, static_cast<uint16_t*>(out), M, N, K, nMt, nNt,
-                         (unsigned)out_bytes);
+      hipLaunchKernelGGL(gemm_bf16_pc<TR_EPI_BF16>, grid, dim3(768), 0, st, A, W, bias, static_cast<uint16_t*>(out),
+                         static_cast<uint16_t*>(nullptr), M, N, K, nMt, nNt, (unsigned)out_bytes);
     else
-      hipLaunchKernelGGL(gemm_bf16_pc<TR_EPI_GELU_BF16>, grid, dim3(768), 0, st, A, W, bias, static_cast<uint16_t*>(out), M, N, K, nMt,
-                         nNt, (unsigned)out_bytes);
+      hipLaunchKernelGGL(gemm_bf16_pc<TR_EPI_GELU_BF16>, grid, dim3(768), 0, st, A, W, bias, static_cast<uint16_t*>(out),
+                         static_cast<uint16_t*>(nullptr), M, N, K, nMt, nNt, (unsigned)out_bytes);
     TR_CHECK_LAUNCH("tr_gemm_bf16");
     return TR_OK;
   }
@@ -767,5 +792,26 @@ extern "C" int tr_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* b
   }
 #undef TR_LAUNCH
   TR_CHECK_LAUNCH("tr_gemm_bf16");
+  return TR_OK;
+}
+
+// fc1 of the TRAINING forward (timm Mlp): pre bf16 [M,N] = A W^T + bias (what the backward differentiates), h bf16 [M,N] = gelu(pre)
+// with the fit of TR_EPI_GELU_BF16 applied to the ROUNDED pre-activation -- bitwise what tr_gemm_bf16(TR_EPI_BF16) followed by
+// tr_gelu_bf16 produces, in one launch.
+extern "C" int tr_gemm_gelu_keep_bf16(const uint16_t* A, const uint16_t* W, const float* bias, uint16_t* pre, uint16_t* h, int M, int N, int K,
+                                      tr_stream_t s) {
+  TR_REQUIRE(A && W && bias && pre && h, TR_ERR_NULL, "tr_gemm_gelu_keep_bf16: null pointer");
+  TR_REQUIRE(M > 0 && N > 0 && K > 0 && K % BK == 0 && N % 8 == 0, TR_ERR_SHAPE, "tr_gemm_gelu_keep_bf16: need K %% %d == 0, N %% 8 == 0 (M=%d N=%d K=%d)", BK,
+             M, N, K);
+  TR_REQUIRE(tr_aligned16(A) && tr_aligned16(W) && tr_aligned16(bias) && tr_aligned16(pre) && tr_aligned16(h), TR_ERR_ALIGN,
+             "tr_gemm_gelu_keep_bf16: pointers must be 16-byte aligned");
+  const size_t out_bytes = (size_t)M * N * 2;
+  TR_REQUIRE(out_bytes < ((size_t)1 << 31) && (size_t)M * K * 2 < ((size_t)1 << 32) && (size_t)N * K * 2 < ((size_t)1 << 32), TR_ERR_SHAPE,
+             "tr_gemm_gelu_keep_bf16: operands / outputs beyond the 32-bit offset range");
+  tr_prof_note("gemm_bf16_pc<EPI_GELU_KEEP>", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K) + 4.0 * M * N);
+  const int nMt = (M + PBM - 1) / PBM, nNt = (N + PBN - 1) / PBN;
+  hipLaunchKernelGGL(gemm_bf16_pc<EPI_GELU_KEEP>, dim3(256), dim3(768), 0, static_cast<hipStream_t>(s), A, W, bias, h, pre, M, N, K, nMt, nNt,
+                     (unsigned)out_bytes);
+  TR_CHECK_LAUNCH("tr_gemm_gelu_keep_bf16");
   return TR_OK;
 }

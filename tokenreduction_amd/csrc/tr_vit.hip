@@ -455,13 +455,10 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       TR_TRY(tr_layernorm_bf16_to(x, D, x0, D, static_cast<const uint16_t*>(pending), D, sw->ln_g, sw->ln_b, pu, M, D, 1e-5f, s));
       pending = nullptr;
       x = x0;
-      TR_TRY(tr_gemm_bf16(pu, static_cast<const uint16_t*>(sw->w0), sw->b0, ppre0, nullptr, 0, M, D, D, TR_EPI_BF16, s));
-      TR_TRY(tr_gelu_bf16(ppre0, pcat, (size_t)M * D, s));
+      TR_TRY(tr_gemm_gelu_keep_bf16(pu, static_cast<const uint16_t*>(sw->w0), sw->b0, ppre0, pcat, M, D, D, s));
       TR_TRY(tr_pool_policy(pcat, policy_cur, B, N, D, 1e-6f, s));
-      TR_TRY(tr_gemm_bf16(pcat, static_cast<const uint16_t*>(sw->w1), sw->b1, ppre1, nullptr, 0, M, Hh, D, TR_EPI_BF16, s));
-      TR_TRY(tr_gelu_bf16(ppre1, ph1, (size_t)M * Hh, s));
-      TR_TRY(tr_gemm_bf16(ph1, static_cast<const uint16_t*>(sw->w2), sw->b2, ppre2, nullptr, 0, M, Q, Hh, TR_EPI_BF16, s));
-      TR_TRY(tr_gelu_bf16(ppre2, ph2, (size_t)M * Q, s));
+      TR_TRY(tr_gemm_gelu_keep_bf16(pcat, static_cast<const uint16_t*>(sw->w1), sw->b1, ppre1, ph1, M, Hh, D, s));
+      TR_TRY(tr_gemm_gelu_keep_bf16(ph1, static_cast<const uint16_t*>(sw->w2), sw->b2, ppre2, ph2, M, Q, Hh, s));
       TR_TRY(tr_dyvit_decide(ph2, Q, sw->w3, sw->b3, noise_in, policy_cur, pol, reinterpret_cast<float*>(tape + bt.ysoft),
                              reinterpret_cast<float*>(tape + bt.sm), reinterpret_cast<float*>(tape + bt.hard), B, N, D / 4, s));
       noise_in += (size_t)B * (N - 1) * 2;
@@ -485,8 +482,7 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       float* x1 = reinterpret_cast<float*>(tape + bt.x1);
       TR_TRY(tr_layernorm_bf16_to(x, D, x0, D, static_cast<const uint16_t*>(pending), D, sw->ln_g, sw->ln_b, pu, M, D, 1e-5f, s));
       pending = nullptr;
-      TR_TRY(tr_gemm_bf16(pu, static_cast<const uint16_t*>(sw->w0), sw->b0, ppre0, nullptr, 0, M, Hh, D, TR_EPI_BF16, s));
-      TR_TRY(tr_gelu_bf16(ppre0, ph0, (size_t)M * Hh, s));
+      TR_TRY(tr_gemm_gelu_keep_bf16(pu, static_cast<const uint16_t*>(sw->w0), sw->b0, ppre0, ph0, M, Hh, D, s));
       TR_TRY(tr_gemm_bf16(ph0, static_cast<const uint16_t*>(sw->w1), sw->b1, slog, nullptr, 0, M, sw->n_pad, Hh, TR_EPI_F32, s));
       TR_REQUIRE(hipMemcpyAsync(swt, slog, (size_t)M * sw->n_pad * 4, hipMemcpyDeviceToDevice, static_cast<hipStream_t>(s)) == hipSuccess,
                  TR_ERR_LAUNCH, "tr_vit_forward_train: copy failed");
@@ -648,8 +644,8 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
     // mlp(norm2(x)) -> dbuf, added to x by the next block's norm1 (or the final norm)
     if (train) {
       void* pre = tape + tp->blk[i].pre;
-      TR_TRY(op_gemm(prec, xn, bw->fc1_w, bw->fc1_b, pre, nullptr, 0, M2, p.Hd, D, TR_EPI_BF16, s));
-      TR_TRY(tr_gelu_bf16(static_cast<const uint16_t*>(pre), static_cast<uint16_t*>(hbuf), (size_t)M2 * p.Hd, s));
+      TR_TRY(tr_gemm_gelu_keep_bf16(static_cast<const uint16_t*>(xn), static_cast<const uint16_t*>(bw->fc1_w), bw->fc1_b, static_cast<uint16_t*>(pre),
+                                    static_cast<uint16_t*>(hbuf), M2, p.Hd, D, s));
     } else {
       TR_TRY(op_gemm(prec, xn, bw->fc1_w, bw->fc1_b, hbuf, nullptr, 0, M2, p.Hd, D, TR_EPI_GELU_BF16, s));
     }

@@ -622,3 +622,17 @@ def attention_bwd_long(qkv: torch.Tensor, dout: torch.Tensor, B: int, N: int, H:
                                               _opt(dcls, torch.float32, "dcls"), dqkv.data_ptr(), ws.data_ptr(), ws.numel(), B, N, H, _stream()),
                "tr_attention_bwd_long_bf16")
     return dqkv
+
+
+def gemm_gelu_keep(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor):
+    """Training forward of Linear + GELU in one launch: (pre bf16 [M,N], h = gelu(pre) bf16 [M,N])."""
+    M, K = a.shape
+    N = w.shape[0]
+    if w.dim() != 2 or w.shape[1] != K or bias.numel() != N:
+        raise ValueError(f"gemm_gelu_keep: a {tuple(a.shape)}, w {tuple(w.shape)}, bias {tuple(bias.shape)} do not form a Linear")
+    _same_device(a, w, bias)
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    h = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    _lib.check(_lib.load().tr_gemm_gelu_keep_bf16(_dev(a, torch.bfloat16, "a"), _dev(w, torch.bfloat16, "w"), _dev(bias, torch.float32, "bias"),
+                                                  pre.data_ptr(), h.data_ptr(), M, N, K, _stream(a)), "tr_gemm_gelu_keep_bf16")
+    return pre, h
