@@ -244,7 +244,7 @@ GOLDEN_CASES = {
 GRAD_CASES = ["deit_micro", "topk_micro", "evit_micro", "tome_micro", "dpcknn_micro", "dpcknn_micro_equal", "ats_micro", "topk_small_kr07",
               "evit_small_kr07", "tome_small_r16", "deit_base", "dpcknn_base_kr05", "ats_base_kr05", "dyvit_micro_train", "dyvit_small_train", "kmedoids_micro", "heuristic_micro_l2", "topk_micro_droppath",
               "sit_micro", "patchmerger_micro", "sinkhorn_micro", "sit_small_kr07", "patchmerger_small_kr07", "sinkhorn_small_kr07",
-              "topk_micro_384", "kmedoids_micro_384", "ats_micro_384"]
+              "topk_micro_384", "kmedoids_micro_384", "ats_micro_384", "sinkhorn_micro_384"]
 
 
 def dyvit_token_ratio(case: dict):

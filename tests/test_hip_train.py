@@ -180,8 +180,8 @@ def test_eval_and_train_logits_agree():
 
 def test_unsupported_configuration_raises_in_train_mode():
     """What the training path does not cover raises up front, never a fallback: DyViT at 384 x 384 (its policy attention holds a whole
-    score row in registers: <= 224 tokens) and Sinkhorn at 384 x 384 (its backward holds an image's K x P score matrix in LDS)."""
-    for name in ("dyvit_micro_train", "sinkhorn_micro_384"):
+    score row in registers: <= 224 tokens)."""
+    for name in ("dyvit_micro_train",):
         case = dict(GOLDEN_CASES[name], img_size=384)
         model, params, cfg = build_model(case)
         x = make_images(case["batch"], 384, case["xseed"]).cuda()

@@ -179,12 +179,15 @@ __global__ __launch_bounds__(256) void rownorm_bwd_kernel(const float* __restric
 // Z0 lives in LDS ([K][PP], K*PP floats), the u_t / v_t / du_t / dv_t vectors too; the iterations are recomputed, not saved.
 constexpr int SB_T = 1024, SB_MAXIT = 8;
 
+// ZLDS = false: K x P does not fit the LDS (384 x 384 inputs: 144 x 576) -- Z0 is then re-read from the scores in global memory (an
+// image's matrix, 330 KB, stays in L2 over the 2 T + 3 passes); only the vectors live in LDS.
+template <bool ZLDS>
 __global__ __launch_bounds__(SB_T) void sinkhorn_bwd_kernel(const float* __restrict__ scores, const float* __restrict__ dplan, int ldl,
                                                             float eps, int iters, uint16_t* __restrict__ ds, int ldo, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int P = N - 1, PP = P | 1;                // odd row stride: column walks hit distinct banks
-  float* z = sm;                                   // [K][PP]
-  float* u = z + (size_t)K * PP;                   // [iters+1][K]   u_0 = 0
+  float* z = sm;                                   // [K][PP]  (ZLDS only)
+  float* u = z + (ZLDS ? (size_t)K * PP : 0);      // [iters+1][K]   u_0 = 0
   float* v = u + (size_t)(iters + 1) * K;          // [iters+1][P]   v_0 = 0
   float* du = v + (size_t)(iters + 1) * P;         // [K]   current du_t
   float* dv = du + K;                              // [P]   current dv_t
@@ -196,30 +199,32 @@ __global__ __launch_bounds__(SB_T) void sinkhorn_bwd_kernel(const float* __restr
   const float inv_eps = 1.0f / eps;
   const float* sc = scores + ((size_t)b * N + 1) * ldl;
   const float* dp = dplan + ((size_t)b * N + 1) * ldl;
-  for (int e = tid; e < K * P; e += SB_T) {
-    const int p = e / K, k = e - p * K;            // global reads along k (contiguous)
-    z[(size_t)k * PP + p] = sc[(size_t)p * ldl + k] * inv_eps;
-  }
+  if (ZLDS)
+    for (int e = tid; e < K * P; e += SB_T) {
+      const int p = e / K, k = e - p * K;          // global reads along k (contiguous)
+      z[(size_t)k * PP + p] = sc[(size_t)p * ldl + k] * inv_eps;
+    }
+#define Z_(k, p) (ZLDS ? z[(size_t)(k) * PP + (p)] : sc[(size_t)(p) * ldl + (k)] * inv_eps)
   for (int e = tid; e < K; e += SB_T) u[e] = 0.f;
   for (int e = tid; e < P; e += SB_T) v[e] = 0.f;
   __syncthreads();
   for (int t = 1; t <= iters; ++t) {
     for (int k = wave; k < K; k += nw) {           // u_t[k] = norm - LSE_p(z[k,p] + v_{t-1}[p]): one wave per row
       float mx = -INFINITY;
-      for (int p = lane; p < P; p += 64) mx = fmaxf(mx, z[(size_t)k * PP + p] + v[(t - 1) * P + p]);
+      for (int p = lane; p < P; p += 64) mx = fmaxf(mx, Z_(k, p) + v[(t - 1) * P + p]);
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
       float s = 0.f;
-      for (int p = lane; p < P; p += 64) s += expf(z[(size_t)k * PP + p] + v[(t - 1) * P + p] - mx);
+      for (int p = lane; p < P; p += 64) s += expf(Z_(k, p) + v[(t - 1) * P + p] - mx);
       s = wave_sum(s);
       if (lane == 0) u[t * K + k] = norm - (mx + logf(s));
     }
     __syncthreads();
     for (int p = tid; p < P; p += SB_T) {          // v_t[p] = norm - LSE_k(z[k,p] + u_t[k]): one thread per column
       float mx = -INFINITY;
-      for (int k = 0; k < K; ++k) mx = fmaxf(mx, z[(size_t)k * PP + p] + u[t * K + k]);
+      for (int k = 0; k < K; ++k) mx = fmaxf(mx, Z_(k, p) + u[t * K + k]);
       float s = 0.f;
-      for (int k = 0; k < K; ++k) s += expf(z[(size_t)k * PP + p] + u[t * K + k] - mx);
+      for (int k = 0; k < K; ++k) s += expf(Z_(k, p) + u[t * K + k] - mx);
       v[t * P + p] = norm - (mx + logf(s));
     }
     __syncthreads();
@@ -228,13 +233,13 @@ __global__ __launch_bounds__(SB_T) void sinkhorn_bwd_kernel(const float* __restr
   for (int k = wave; k < K; k += nw) {
     float s = 0.f;
     for (int p = lane; p < P; p += 64)
-      s += dp[(size_t)p * ldl + k] * expf(z[(size_t)k * PP + p] + u[iters * K + k] + v[iters * P + p] - norm);
+      s += dp[(size_t)p * ldl + k] * expf(Z_(k, p) + u[iters * K + k] + v[iters * P + p] - norm);
     s = wave_sum(s);
     if (lane == 0) du[k] = s;
   }
   for (int p = tid; p < P; p += SB_T) {
     float s = 0.f;
-    for (int k = 0; k < K; ++k) s += dp[(size_t)p * ldl + k] * expf(z[(size_t)k * PP + p] + u[iters * K + k] + v[iters * P + p] - norm);
+    for (int k = 0; k < K; ++k) s += dp[(size_t)p * ldl + k] * expf(Z_(k, p) + u[iters * K + k] + v[iters * P + p] - norm);
     dv[p] = s;
   }
   __syncthreads();
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(SB_T) void sinkhorn_bwd_kernel(const float* __restr
     // du_t[k] -= sum_p dv_t[p] A_t[k,p]
     for (int k = wave; k < K; k += nw) {
       float s = 0.f;
-      for (int p = lane; p < P; p += 64) s += dv[p] * expf(z[(size_t)k * PP + p] + u[t * K + k] + v[t * P + p] - norm);
+      for (int p = lane; p < P; p += 64) s += dv[p] * expf(Z_(k, p) + u[t * K + k] + v[t * P + p] - norm);
       s = wave_sum(s);
       if (lane == 0) {
         const float d = du[k] - s;
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(SB_T) void sinkhorn_bwd_kernel(const float* __restr
     // dv_{t-1}[p] = - sum_k du_t[k] B_t[k,p];  u_{t-1} receives nothing else (u_t does not depend on u_{t-1})
     for (int p = tid; p < P; p += SB_T) {
       float s = 0.f;
-      for (int k = 0; k < K; ++k) s += du[k] * expf(z[(size_t)k * PP + p] + u[t * K + k] + v[(t - 1) * P + p] - norm);
+      for (int k = 0; k < K; ++k) s += du[k] * expf(Z_(k, p) + u[t * K + k] + v[(t - 1) * P + p] - norm);
       dv[p] = -s;
     }
     __syncthreads();
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(SB_T) void sinkhorn_bwd_kernel(const float* __restr
   uint16_t* o = ds + ((size_t)b * N + 1) * ldo;
   for (int e = tid; e < K * P; e += SB_T) {
     const int p = e / K, k = e - p * K;
-    const float zz = z[(size_t)k * PP + p];
+    const float zz = Z_(k, p);
     float g = dp[(size_t)p * ldl + k] * expf(zz + u[iters * K + k] + v[iters * P + p] - norm);
     for (int t = 1; t <= iters; ++t) {
       const float base = zz + u[t * K + k] - norm;
@@ -275,11 +280,12 @@ __global__ __launch_bounds__(SB_T) void sinkhorn_bwd_kernel(const float* __restr
     o[(size_t)p * ldo + k] = (uint16_t)(pack_bf16x2(g * inv_eps, 0.f) & 0xffffu);
   }
   for (int k = tid; k < K; k += SB_T) ds[(size_t)b * N * ldo + k] = 0;
+#undef Z_
 }
 
-inline size_t sinkhorn_bwd_lds(int N, int K, int iters) {
+inline size_t sinkhorn_bwd_lds(int N, int K, int iters, bool zlds) {
   const size_t P = N - 1, PP = P | 1;
-  return ((size_t)K * PP + (size_t)2 * (iters + 1) * (K + P) + K + P) * sizeof(float);
+  return ((zlds ? (size_t)K * PP : 0) + (size_t)2 * (iters + 1) * (K + P) + K + P) * sizeof(float);
 }
 
 }  // namespace
@@ -348,11 +354,17 @@ extern "C" int tr_sinkhorn_bwd(const float* scores, const float* dplan, int ldl,
   TR_REQUIRE(scores && dplan && ds, TR_ERR_NULL, "tr_sinkhorn_bwd: null pointer");
   TR_REQUIRE(B > 0 && N >= 2 && K >= 1 && ldl >= K && ldo >= K && iters >= 1 && iters <= SB_MAXIT && eps > 0.f, TR_ERR_SHAPE,
              "tr_sinkhorn_bwd: bad shape / iters (1..%d)", SB_MAXIT);
-  const size_t lds = sinkhorn_bwd_lds(N, K, iters);
-  TR_REQUIRE(lds <= 160 * 1024, TR_ERR_SHAPE, "tr_sinkhorn_bwd: K=%d x P=%d needs %zu B of LDS (the training path holds the score matrix of an image "
-             "in LDS: 224x224 inputs)", K, N - 1, lds);
-  TR_RESERVE_LDS(reinterpret_cast<const void*>(sinkhorn_bwd_kernel), lds, "tr_sinkhorn_bwd");
-  hipLaunchKernelGGL(sinkhorn_bwd_kernel, dim3(B), dim3(SB_T), lds, static_cast<hipStream_t>(s), scores, dplan, ldl, eps, iters, ds, ldo, N, K);
+  const bool zlds = sinkhorn_bwd_lds(N, K, iters, true) <= 160 * 1024;      // else the score matrix is re-read from global memory (L2)
+  const size_t lds = sinkhorn_bwd_lds(N, K, iters, zlds);
+  TR_REQUIRE(lds <= 160 * 1024, TR_ERR_SHAPE, "tr_sinkhorn_bwd: K=%d, P=%d, %d iterations need %zu B of LDS for the scaling vectors alone", K, N - 1,
+             iters, lds);
+  if (zlds) {
+    TR_RESERVE_LDS(reinterpret_cast<const void*>(sinkhorn_bwd_kernel<true>), lds, "tr_sinkhorn_bwd");
+    hipLaunchKernelGGL(sinkhorn_bwd_kernel<true>, dim3(B), dim3(SB_T), lds, static_cast<hipStream_t>(s), scores, dplan, ldl, eps, iters, ds, ldo, N, K);
+  } else {
+    TR_RESERVE_LDS(reinterpret_cast<const void*>(sinkhorn_bwd_kernel<false>), lds, "tr_sinkhorn_bwd");
+    hipLaunchKernelGGL(sinkhorn_bwd_kernel<false>, dim3(B), dim3(SB_T), lds, static_cast<hipStream_t>(s), scores, dplan, ldl, eps, iters, ds, ldo, N, K);
+  }
   TR_CHECK_LAUNCH("tr_sinkhorn_bwd");
   return TR_OK;
 }

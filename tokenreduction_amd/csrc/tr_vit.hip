@@ -694,17 +694,8 @@ extern "C" size_t tr_vit_tape_bytes(const tr_vit_config* cfg, int B) {
   trplan::TapePlan tp;
   if (!make_plan(cfg, B, &p) || cfg->precision != TR_PREC_BF16 || !trplan::trainable_family(cfg->family)) return 0;
   // beyond 224 tokens (384 x 384 inputs) the attention backward runs key-blocked (tr_attention_bwd_long.hip); what does NOT scale:
-  // DyViT's policy attention (N <= 224) and Sinkhorn's backward, which holds an image's K x P score matrix in LDS
+  // DyViT's policy attention (N <= 224)
   if (p.N0 > 640 || (p.N0 > 224 && cfg->family == TR_FAMILY_DYVIT)) return 0;
-  if (cfg->family == TR_FAMILY_SINKHORN) {
-    int Nn = p.N0;
-    for (int i = 0; i < cfg->depth; ++i)
-      if (cfg->keep[i] > 0) {
-        const size_t K = cfg->keep[i], P = Nn - 1, it = cfg->cluster_iters > 0 ? cfg->cluster_iters : 3;
-        if ((K * (P | 1) + (2 * (it + 1) + 1) * (K + P)) * 4 > 160 * 1024) return 0;
-        Nn = cfg->keep[i] + 1;
-      }
-  }
   if (!trplan::make_token_plan(cfg, &t) || !trplan::make_tape_plan(cfg, B, t, &tp)) return 0;
   return tp.total;
 }
