@@ -769,13 +769,27 @@ inline void reduce_partials2(const float* p0, size_t c0, float* d0, const float*
 
 }  // namespace
 
-extern "C" size_t tr_wgrad_workspace_floats(int M, int N, int K) {
-  if (M <= 0 || N <= 0 || K <= 0) return 0;
+// Token splits of a weight-gradient launch.  512 workgroups (2 per CU) are resident at a time, so tiles x S should fill whole rounds of
+// 512; but every split writes an N x K fp32 partial that the reduce re-reads (DeiT-S: 37 splits of qkv's 1152 x 384 = 65 MB each way), so
+// more rounds than necessary cost more than they balance.  Cost model (fitted on tools/lab/wgrad_target_ab.py: DeiT-S shapes prefer ONE
+// round, the large DeiT-B matrices two): time ~ flops / (round efficiency x 500 TFLOP/s) + 8 S N K bytes / 4 TB/s.
+static int wgrad_splits(int M, int N, int K) {
   const int tiles = ((N + WB - 1) / WB) * ((K + WB - 1) / WB);
   const int nslab = (M + WM - 1) / WM;
-  int S = 1024 / tiles;
-  if (S < 1) S = 1;
-  if (S > nslab) S = nslab;
+  int best = 1;
+  double best_t = 1e30;
+  for (int S = 1; S <= nslab && tiles * S <= 2048; ++S) {
+    const int wg = tiles * S;
+    const double eff = (double)wg / (double)(((wg + 511) / 512) * 512);
+    const double t = 2.0 * M * N * K / (eff * 500e12) + 8.0 * S * N * K / 4e12;
+    if (t < best_t) { best_t = t; best = S; }
+  }
+  return best;
+}
+
+extern "C" size_t tr_wgrad_workspace_floats(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  const int S = wgrad_splits(M, N, K);
   return (size_t)S * N * K + (size_t)S * N;         // weight partials, then the bias partials of tr_linear_bwd_params
 }
 
@@ -787,9 +801,7 @@ extern "C" int tr_wgrad_bf16(const uint16_t* dY, long ldy, int yskip, const uint
   TR_REQUIRE(tr_aligned16(dY) && tr_aligned16(X) && tr_aligned16(dW) && tr_aligned16(ws), TR_ERR_ALIGN, "tr_wgrad_bf16: pointers must be 16-byte aligned");
   const int nNt = (N + WB - 1) / WB, nKt = (K + WB - 1) / WB, tiles = nNt * nKt;
   const int nslab = (M + WM - 1) / WM;
-  int S = 1024 / tiles;
-  if (S < 1) S = 1;
-  if (S > nslab) S = nslab;
+  int S = wgrad_splits(M, N, K);
   const size_t fit = ws_floats / ((size_t)N * K);
   TR_REQUIRE(fit >= 1, TR_ERR_SHAPE, "tr_wgrad_bf16: workspace of %zu floats cannot hold one %d x %d partial", ws_floats, N, K);
   if ((size_t)S > fit) S = (int)fit;
@@ -815,9 +827,7 @@ extern "C" int tr_linear_bwd_params(const uint16_t* dY, long ldy, int yskip, con
              "tr_linear_bwd_params: pointers must be 16-byte aligned");
   const int nNt = (N + WB - 1) / WB, nKt = (K + WB - 1) / WB, tiles = nNt * nKt;
   const int nslab = (M + WM - 1) / WM;
-  int S = 1024 / tiles;
-  if (S < 1) S = 1;
-  if (S > nslab) S = nslab;
+  int S = wgrad_splits(M, N, K);
   const size_t per = (size_t)N * K + (size_t)N;
   const size_t fit = ws_floats / per;
   TR_REQUIRE(fit >= 1, TR_ERR_SHAPE, "tr_linear_bwd_params: workspace of %zu floats cannot hold one partial", ws_floats);
