@@ -248,3 +248,39 @@ def test_dyvit_train_return_contract():
         # eval mode still prunes for real (dyvit.py:230-238)
         le = model.eval()(x)
         assert le.shape == (B, case["num_classes"]) and model._last_tokens[-1] == int(196 * 0.7 ** 3) + 1
+
+
+@pytest.mark.parametrize("name", ["topk_micro", "dpcknn_micro", "sit_micro"])
+def test_train_one_epoch_drives_the_hip_model(name):
+    """engine.py:14-114 through harness.train_one_epoch on the real thing: gradient accumulation over two micro-steps (the second one
+    ADDS into the flat buffer), norm clipping, EMA, a frozen parameter group, and the loss goes down over two epochs of one repeated
+    batch; every p.grad is still a view into the flat gradient buffer afterwards."""
+    from tokenreduction_amd import finetune, harness
+    case = GOLDEN_CASES[name]
+    model, params, cfg = build_model(case)
+    model.viz_mode = False
+    x = make_images(4 * case["batch"], 224, case["xseed"])
+    y = torch.cat([grad_labels(dict(case, xseed=case["xseed"] + i)) for i in range(4)])
+    loader = [(x[i * case["batch"]:(i + 1) * case["batch"]], y[i * case["batch"]:(i + 1) * case["batch"]]) for i in range(4)]
+    groups = finetune.get_parameter_groups(model, 2e-3, 0.05, 1.0, 0)
+    opt = torch.optim.AdamW(groups, lr=2e-3)
+    ema = harness.ModelEma(model, 0.9)
+    crit = harness.plain_criterion(torch.nn.functional.cross_entropy)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    losses = []
+    for epoch in range(3):
+        stats, total = harness.train_one_epoch(model, crit, loader, opt, "cuda", epoch, max_norm=5.0, model_ema=ema, grad_accum_steps=2,
+                                               num_steps_epoch=2)
+        assert np.isfinite(stats["loss"])
+        losses.append(stats["loss"])
+    assert total == 2 * 2 + 2                 # epoch * num_steps_epoch + optimizer steps of the last epoch (engine.py:113)
+    assert losses[-1] < losses[0], losses
+    moved = [n for n, p in model.named_parameters() if not torch.equal(p.detach(), before[n])]
+    assert len(moved) >= len(before) - 2, set(before) - set(moved)          # (the key bias may stay: its gradient is zero)
+    st = model._train_state()
+    lo, hi = st.flat.data_ptr(), st.flat.data_ptr() + st.flat.numel() * 4
+    torch.nn.functional.cross_entropy(model(loader[0][0].cuda()), loader[0][1].cuda()).backward()
+    assert all(lo <= p.grad.data_ptr() < hi for p in model.parameters())
+    # the EMA copy follows the parameters without being them
+    ema_p = dict(ema.module.named_parameters())
+    assert any(not torch.equal(ema_p[n].detach(), p.detach()) for n, p in model.named_parameters())
