@@ -32,7 +32,7 @@ PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md
 PEAK_HBM_GBPS = 8000.0
 
 
-def build_model(name=MODEL, keep_rate=KEEP_RATE, loc=REDUCTION_LOC, device="cuda", img_size=224):
+def build_model(name=MODEL, keep_rate=KEEP_RATE, loc=REDUCTION_LOC, device="cuda", img_size=224, qkv_gain=4.0):
     import tokenreduction_amd as tra
     torch.manual_seed(0)
     args = types.SimpleNamespace(keep_rate=list(keep_rate), reduction_loc=list(loc), dyvit_distill=False, k_neighbors=5,
@@ -41,7 +41,7 @@ def build_model(name=MODEL, keep_rate=KEEP_RATE, loc=REDUCTION_LOC, device="cuda
                          drop_block_rate=None, img_size=img_size, args=args)
     with torch.no_grad():                       # "peaky" attention so the Top-K sees a realistic score spread
         for blk in m.blocks:
-            blk.attn.qkv.weight.mul_(4.0)
+            blk.attn.qkv.weight.mul_(qkv_gain)
     return m.to(device).eval()
 
 
@@ -443,6 +443,12 @@ def main():
                 return out
             rec["drift_vs_fp32_path"] = {"dense_deit_s": drift(dense, x[:64]), "topk_kr0.7": drift(model, x[:64]),
                                          "note": "random-init weights (qkv x4): near-flat, ill-conditioned logits"}
+            # the same with the plain initialisation (trunc_normal(0.02), no qkv gain): near-uniform attention, i.e. what random
+            # weights give without the conditioning stress -- SURVEY 8d's well-conditioned counterpart of the "peaky" variant
+            plain_dense = build_model("deit_small_patch16_224_local", [1.0], [], dev, qkv_gain=1.0)
+            plain_topk = build_model(qkv_gain=1.0, device=dev)
+            rec["drift_vs_fp32_path"]["plain_init"] = {"dense_deit_s": drift(plain_dense, x[:64]), "topk_kr0.7": drift(plain_topk, x[:64])}
+            del plain_dense, plain_topk
             # precision="bf16x3": the fp32 executor with Linears + attention as split-bf16 (hi/lo) products on the matrix cores -- the
             # mode that meets north_star's 1e-3-abs logit tolerance against the reference's golden vectors (tests/test_hip_split.py)
             model.precision = "bf16x3"
