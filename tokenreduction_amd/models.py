@@ -1198,15 +1198,19 @@ class HeuristicVisionTransformer(VisionTransformer):
 
 class VisionTransformerTeacher(VisionTransformer):
     """models/dyvit.py:267-334: the DyViT distillation teacher -- a plain DeiT whose forward returns
-    (head(norm(x)[:, 0]), norm(x)[:, 1:]): the logits and the final-norm patch-token features, always as a tuple."""
+    (head(norm(x)[:, 0]), norm(x)[:, 1:]): the logits and the final-norm patch-token features, always as a tuple.  The teacher is
+    only ever run under `torch.no_grad()` (losses.py:122-123), so its forward is the inference executor whatever `self.training` says;
+    its outputs carry no gradient."""
     _always_features = True
 
     def forward(self, x):
         viz, self.viz_mode = self.viz_mode, False
+        was_training, self.training = self.training, False          # the module flag only: the teacher has no train-mode behaviour
         try:
             logits = super().forward(x)
         finally:
             self.viz_mode = viz
+            self.training = was_training
         from . import ops
         B, N, D = x.shape[0], self._last_tokens[-1], self.embed_dim
         off = sum(B * n * D for n in self._last_tokens[:-1])
