@@ -249,3 +249,34 @@ int run(const float* d_images_f32, float* d_logits_f32, void* d_workspace, int B
     out = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-c", str(src), "-I", os.path.join(root, "include"), "-o", str(tmp_path / "host.o")],
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
+
+
+def test_heuristic_masks_match_the_oracle_for_every_range():
+    """HeuristicVisionTransformer's constructor-time geometry (CPU code of the product) against the oracle's restatement of
+    heuristic.py:157-224 (itself pinned on the reference): every pattern, depth, reduction range -- including ranges that start at
+    block 0, where the reference's radius ramp has no block before the range -- min_radius, and the non-contiguous stage subsets."""
+    import itertools
+    import types
+    import torch
+    import tokenreduction_amd as tra
+    from oracle.heuristic import heuristic_masks
+    from tests._params import case_config
+    checked = 0
+    for pattern, depth in itertools.product(("l1", "l2", "linf"), (2, 5, 12)):
+        ranges = [(s, e) for s in range(depth) for e in range(s, depth)]
+        if depth == 12:
+            ranges = [(0, 0), (0, 11), (0, 5), (1, 1), (1, 9), (3, 9), (10, 11), (11, 11)]
+        for (start, end), mr, nc in itertools.product(ranges, (None, 2.0), (False, True)):
+            loc = sorted({start, end}) if not nc else sorted({start, (start + end) // 2, end})
+            for kr in ([0.7], [0.3]):
+                case = dict(family="heuristic", embed_dim=64, depth=depth, num_heads=1, num_classes=8, keep_rate=kr, reduction_loc=loc, batch=1,
+                            wseed=1, xseed=2)
+                args = types.SimpleNamespace(keep_rate=kr, reduction_loc=loc, heuristic_pattern=pattern, not_contiguous=nc, min_radius=mr)
+                m = tra.HeuristicVisionTransformer(img_size=224, patch_size=16, embed_dim=64, depth=depth, num_heads=1, mlp_ratio=1, qkv_bias=True,
+                                                   num_classes=8, args=args)
+                want = heuristic_masks(case_config(case), pattern, nc, mr)
+                assert sorted(want) == sorted(int(b) for b in m.reduction_loc), (pattern, depth, loc, nc)
+                for b, mask in want.items():
+                    assert torch.equal(mask, m._block_mask(b)), (pattern, depth, loc, nc, mr, kr, b)
+                    checked += 1
+    assert checked > 1000

@@ -297,3 +297,28 @@ def test_every_factory_name_takes_a_training_step():
                          cwd=root)
     assert out.returncode == 0 and out.stdout.strip().endswith("ALL OK"), out.stdout[-3000:] + out.stderr[-2000:]
     assert out.stdout.count(" ok ") >= 40
+
+
+@pytest.mark.parametrize("classes", [555, 81, 10, 1])
+def test_any_number_of_classes_trains_and_evaluates(classes):
+    """train.py:334 `model.reset_classifier(args.num_classes)`: NABirds has 555 classes, NUS-WIDE 81.  The kernels see the classifier padded to a
+    multiple of 8 rows; logits, loss and gradients must be those of the unpadded head (against torch on the CLS features)."""
+    case = GOLDEN_CASES["topk_micro"]
+    model, params, cfg = build_model(case)
+    model.viz_mode = False
+    torch.manual_seed(0)
+    model.reset_classifier(classes)
+    x = make_images(case["batch"], 224, case["xseed"]).cuda()
+    y = torch.randint(0, classes, (case["batch"],)).cuda()
+    model.eval()
+    le = model(x)
+    assert le.shape == (case["batch"], classes)
+    model.train()
+    lt = model(x)
+    assert lt.shape == (case["batch"], classes) and _rel(lt.detach().cpu(), le.cpu()) < 1e-1      # eval / train kernels differ by roundings only
+    torch.nn.functional.cross_entropy(lt, y).backward()
+    assert model.head.weight.grad.shape == (classes, case["embed_dim"]) and model.head.bias.grad.shape == (classes,)
+    # d bias of cross-entropy = mean over the batch of (softmax - onehot): independent of everything upstream
+    want_db = (torch.softmax(lt.detach().float(), -1) - torch.nn.functional.one_hot(y, classes).float()).mean(0)
+    torch.testing.assert_close(model.head.bias.grad, want_db, atol=2e-3, rtol=2e-2)
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())

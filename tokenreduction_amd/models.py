@@ -152,6 +152,13 @@ class VisionTransformer(nn.Module):
         dev = self.pos_embed.device
         self.head = (nn.Linear(self.embed_dim, num_classes) if num_classes > 0 else nn.Identity()).to(dev)
         self._packed = None
+        self._tstate = None          # the flat gradient buffer is laid out for the old head
+
+    @property
+    def _classes_padded(self):
+        """The classifier as the kernels see it: rows padded with zeros to a multiple of 8 (any --num_classes works: NABirds 555,
+        NUS-WIDE 81, train.py:334); the padded logits columns are cut off again before anything is returned."""
+        return (self.num_classes + 7) // 8 * 8
 
     def get_new_module_names(self):
         return []
@@ -196,7 +203,9 @@ class VisionTransformer(nn.Module):
         W.cls_token = f32(self.cls_token.reshape(-1))
         W.pos_embed = f32(self.pos_embed.reshape(-1, D))
         W.norm_g, W.norm_b = f32(self.norm.weight), f32(self.norm.bias)
-        W.head_w, W.head_b = w16(self.head.weight), f32(self.head.bias)
+        cpad = self._classes_padded
+        W.head_w = w16(self.head.weight if cpad == self.num_classes else _pad_rows(self.head.weight, cpad))
+        W.head_b = f32(self.head.bias if cpad == self.num_classes else _pad_vec(self.head.bias, cpad))
         for i, blk in enumerate(self.blocks):
             b = W.blocks[i]
             b.ln1_g, b.ln1_b = f32(blk.norm1.weight), f32(blk.norm1.bias)
@@ -212,7 +221,7 @@ class VisionTransformer(nn.Module):
         cfg.in_chans = self.patch_embed.proj.in_channels
         cfg.embed_dim, cfg.depth, cfg.num_heads = D, self.depth, self.num_heads
         cfg.mlp_hidden = self.blocks[0].mlp.fc1.out_features
-        cfg.num_classes = self.num_classes
+        cfg.num_classes = self._classes_padded
         cfg.ln_eps = float(self.norm.eps)
         cfg.precision = {"bf16": _lib.TR_PREC_BF16, "fp32": _lib.TR_PREC_FP32, "bf16x3": _lib.TR_PREC_BF16X3}[self.precision]
         cfg.knn_k = int(getattr(self, "k_neighbors", 0))
@@ -236,6 +245,10 @@ class VisionTransformer(nn.Module):
 
     def _grad_slot_numel(self, name, p):
         """fp32 elements reserved for parameter `name` in the flat gradient buffer (>= p.numel(): matrices whose rows the kernels pad)."""
+        if name == "head.weight":
+            return self._classes_padded * p.shape[1]
+        if name == "head.bias":
+            return self._classes_padded
         return p.numel()
 
     def _pre_pack(self):
@@ -322,7 +335,7 @@ class VisionTransformer(nn.Module):
                 graphs = ws.setdefault("graphs", {})
                 ent = graphs.get(key)
                 if ent is None:
-                    out = torch.empty(B, self.num_classes, dtype=torch.float32, device=x.device)
+                    out = torch.empty(B, self._classes_padded, dtype=torch.float32, device=x.device)
                     launch(out)                                       # eager once: first-touch of the workspace, lazy module load
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
@@ -332,10 +345,12 @@ class VisionTransformer(nn.Module):
                     ent = graphs[key] = (g, out, toks)
                 g, out, toks = ent
                 g.replay()
-                logits, tokens = out.clone(), toks
+                logits, tokens = out[:, :self.num_classes].clone(), toks
             else:
-                logits = torch.empty(B, self.num_classes, dtype=torch.float32, device=x.device)
+                logits = torch.empty(B, self._classes_padded, dtype=torch.float32, device=x.device)
                 tokens = launch(logits)
+                if self._classes_padded != self.num_classes:
+                    logits = logits[:, :self.num_classes].contiguous()
         self._last_tokens = list(tokens)
         self._last_ws = ws
         if self.viz_mode:
@@ -718,7 +733,7 @@ class SelfSlimmedVisionTransformer(VisionTransformer):
                 return self._soft_pad(K)[0] * p.shape[1]
             if name == f"cluster_layers.{j}.weight.3.bias":
                 return self._soft_pad(K)[0]
-        return p.numel()
+        return super()._grad_slot_numel(name, p)
 
     def _grad_stage_ptrs(self, G, ptr):
         for j, loc in enumerate(self.cluster_loc):
@@ -945,7 +960,7 @@ class SinkhornVisionTransformer(SelfSlimmedVisionTransformer):
         for j, K in enumerate(self.cluster_count):
             if name == f"cluster_layers.{j}.v":
                 return self._soft_pad(K)[0] * p.shape[1]
-        return p.numel()
+        return VisionTransformer._grad_slot_numel(self, name, p)
 
     def _grad_stage_ptrs(self, G, ptr):
         for j, loc in enumerate(self.cluster_loc):
@@ -1075,7 +1090,7 @@ class PatchMergerVisionTransformer(SelfSlimmedVisionTransformer):
         for j, K in enumerate(self.cluster_count):
             if name == f"cluster_layers.{j}.queries":
                 return self._soft_pad(K)[0] * p.shape[1]
-        return p.numel()
+        return VisionTransformer._grad_slot_numel(self, name, p)
 
     def _grad_stage_ptrs(self, G, ptr):
         for j, loc in enumerate(self.cluster_loc):
@@ -1155,7 +1170,9 @@ class HeuristicVisionTransformer(VisionTransformer):
         corner = float(radii[0, 0])
         n_stage = self.end_stage - self.start_stage + 1
         ramp = torch.linspace(corner, float(self.min_radius), n_stage + 2)            # ramp[0] = all visible, ramp[-1] = min_radius
-        pos = (torch.arange(self.depth + 2) - (self.start_stage - 1)).clamp(0, n_stage + 1)
+        # the ramp starts one block BEFORE the range -- except for a range that starts at block 0, where the reference's left padding is
+        # empty (F.pad(..., max(start_stage - 1, 0)), heuristic.py:178) and block 0 itself still sees everything
+        pos = (torch.arange(self.depth + 2) - max(self.start_stage - 1, 0)).clamp(0, n_stage + 1)
         return radii, ramp[pos], g
 
     def prep_pattern_stage_subset(self, num_tokens):

@@ -219,7 +219,7 @@ class _VitTrainFn(torch.autograd.Function):
         st = model._train_state()
         tape, bws = st.buffers(model, pk, B, x.device)
         ws = model._workspace(B, x.device)
-        logits = torch.empty(B, model.num_classes, dtype=torch.float32, device=x.device)
+        logits = torch.empty(B, model._classes_padded, dtype=torch.float32, device=x.device)
         tokens = (C.c_int * model.depth)()
         dyvit = model._family == _lib.TR_FAMILY_DYVIT
         distill = dyvit and bool(getattr(model, "dyvit_distillation", False))
@@ -235,6 +235,8 @@ class _VitTrainFn(torch.autograd.Function):
         ctx.model, ctx.B, ctx.pk = model, B, pk
         ctx.keep = x
         ctx.n_pred, ctx.distill = 0, distill
+        if model._classes_padded != model.num_classes:          # the padded classifier columns never leave the executor
+            logits = logits[:, :model.num_classes].contiguous()
         if not dyvit:
             return logits
         preds = []
@@ -256,6 +258,10 @@ class _VitTrainFn(torch.autograd.Function):
         if dlogits is None:
             dlogits = torch.zeros(B, model.num_classes, dtype=torch.float32, device=dev)
         dl = dlogits.detach().to(torch.float32).contiguous()
+        if model._classes_padded != model.num_classes:          # zero gradient on the padded classifier columns
+            dlp = torch.zeros(B, model._classes_padded, dtype=torch.float32, device=dev)
+            dlp[:, :model.num_classes] = dl
+            dl = dlp
         dpred = dfeat = None
         if ctx.n_pred:
             P = model.patch_embed.num_patches

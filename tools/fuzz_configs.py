@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Seeded sweep over odd configurations of every family (reduction at block 0 / the last block, one or many stages, extreme keep rates,
+batch 1 / odd batches, D = 128 / 192 / 256, several depths): eval logits against the CPU oracle with the HIP rounding points
+(teacher-forced where the family has discrete decisions is NOT attempted here: loose 0.5 relative-L2 bound, this is a crash / NaN /
+shape hunt), then one training step with finite loss and gradients.   python tools/fuzz_configs.py [n_configs] [seed]"""
+import os
+import sys
+import types
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import oracle  # noqa: E402
+import tokenreduction_amd as tra  # noqa: E402
+from tests._params import case_config, case_params, make_images  # noqa: E402
+from tests.test_hip_model import FAM  # noqa: E402
+
+n_cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+families = ["topk", "evit", "tome", "dyvit", "sit", "ats", "dpcknn", "sinkhorn", "kmedoids", "patchmerger", "heuristic", "deit"]
+bad = 0
+for it in range(n_cfg):
+    fam = families[it % len(families)]
+    D = int(rng.choice([128, 256])) if fam in ("dyvit", "sit") else int(rng.choice([128, 192, 256]))
+    depth = int(rng.integers(2, 6))
+    nloc = int(rng.integers(1, depth + 1))
+    loc = sorted(rng.choice(np.arange(1 if fam == "kmedoids" else 0, depth), size=min(nloc, depth - (1 if fam == "kmedoids" else 0)), replace=False).tolist())
+    kr = [float(rng.choice([0.3, 0.5, 0.7, 0.9]))]
+    if fam in ("sit", "patchmerger", "sinkhorn", "dpcknn", "kmedoids", "ats") and 196 * kr[0] ** len(loc) < 4:
+        kr = [0.7]                                                           # geometric schedules: keep at least a few clusters at the last stage
+    if fam == "tome":                                                        # ToMe: absolute token counts after each listed block, non-increasing
+        r = int(rng.choice([4, 16, 40]))
+        kr = [max(2, 196 - r * (j + 1)) for j in range(len(loc))]
+    if fam == "deit":
+        loc, kr = [], [1.0]
+    B = int(rng.choice([1, 2, 3, 5, 8]))
+    case = dict(family=fam, embed_dim=D, depth=depth, num_heads=D // 64, num_classes=12, keep_rate=kr, reduction_loc=loc, batch=B,
+                wseed=1000 + it, xseed=2000 + it, qkv_gain=3.0, heuristic_pattern="l2", not_contiguous=bool(it % 2), min_radius=None)
+    tag = f"{fam:11s} D{D} depth{depth} loc{loc} kr{kr} B{B}"
+    try:
+        args = types.SimpleNamespace(keep_rate=list(kr), reduction_loc=list(loc), viz_mode=True, dyvit_distill=False, k_neighbors=5, equal_weight=False,
+                                     sinkhorn_eps=1.0, cluster_iters=3, heuristic_pattern="l2", not_contiguous=case["not_contiguous"], min_radius=None)
+        m = getattr(tra, FAM[fam])(img_size=224, patch_size=16, embed_dim=D, depth=depth, num_heads=D // 64, mlp_ratio=4, qkv_bias=True,
+                                   num_classes=12, args=args)
+        cfg, params = case_params(case)
+        m.load_state_dict(params, strict=True)
+        m = m.cuda().eval()
+        x = make_images(B, 224, case["xseed"])
+        noise = None
+        if fam == "dpcknn":                     # the density noise is an input on both sides: zeros
+            noise = {blk: torch.zeros(B, P) for blk, _, P in m._stage_shapes()}
+            m.density_noise = noise
+        out = m(x.cuda())
+        logits = (out[0] if isinstance(out, tuple) else out).cpu()
+        extra = dict(heuristic_pattern="l2", not_contiguous=case["not_contiguous"], min_radius=None)
+        want = oracle.forward(params, x, cfg, precision="bf16", extra=extra, noise=noise)
+        want = want[0] if isinstance(want, tuple) else want
+        rel = float((logits - want).norm() / want.norm())
+        ok = bool(torch.isfinite(logits).all()) and rel < 0.5
+        msg = f"eval rel {rel:.2e} tokens {m._last_tokens}"
+        try:
+            m.train()
+            m.viz_mode = False
+            o = m(x.cuda())
+            lg = o[0] if isinstance(o, tuple) else o
+            loss = torch.nn.functional.cross_entropy(lg, torch.randint(0, 12, (B,)).cuda())
+            if isinstance(o, tuple) and isinstance(o[-1], (list, tuple)):
+                loss = loss + sum(((s_.mean(1) - 0.5) ** 2).mean() for s_ in o[-1])
+            loss.backward()
+            torch.cuda.synchronize()
+            gok = all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+            ok &= bool(torch.isfinite(loss)) and gok
+            msg += f"; train loss {loss.item():.3f} grads {'finite' if gok else 'BAD'}"
+        except NotImplementedError as e:
+            msg += f"; train raises: {str(e)[:60]}"
+        print(f"{tag}: {'ok ' if ok else 'BAD'} {msg}")
+        bad += not ok
+    except Exception as e:   # noqa: BLE001
+        bad += 1
+        print(f"{tag}: FAILED {type(e).__name__}: {str(e)[:200]}")
+print("ALL OK" if not bad else f"{bad} FAILED")
