@@ -29,7 +29,7 @@ from .cluster import (  # noqa: F401
     dpcknn_forward, kmedoids_token_weights, kmedoids_fit, kmedoids_block_forward, kmedoids_forward, sinkhorn_log_iterations, sinkhorn_transport, sinkhorn_layer, sinkhorn_forward,
 )
 from .ats import (  # noqa: F401
-    ats_sample_counts, ats_sample_steps, ats_scores, ats_cdf, ats_ids_from_cdf, ats_sample_ids, ats_block_forward, ats_forward,
+    ats_sample_counts, ats_token_bounds, ats_sample_steps, ats_scores, ats_cdf, ats_ids_from_cdf, ats_sample_ids, ats_block_forward, ats_forward,
 )
 from .heuristic import heuristic_masks, heuristic_forward  # noqa: F401
 

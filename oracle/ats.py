@@ -32,6 +32,13 @@ def ats_sample_counts(cfg: VitConfig) -> Dict[int, int]:
     return {int(l): int(c) for c, l in zip(counts, loc)}
 
 
+def ats_token_bounds(cfg: VitConfig) -> Dict[int, int]:
+    """Most tokens (CLS included) a sampling block can keep: one per grid point + the CLS token.  The grid of ats.py:48 is a float
+    `torch.arange` with an exclusive end; for 42 of the sample counts up to 197 (7, 12, 14, 19, 27, ..., 126, ...) rounding lets the
+    end point in and the grid has K points instead of K - 1, so the bound is K + 1 there (the reference's dynamic shapes do not care)."""
+    return {blk: int(ats_sample_steps(c).numel()) + 1 for blk, c in ats_sample_counts(cfg).items() if c}
+
+
 def ats_sample_steps(sample_count: int) -> Tensor:
     """ats.py:48 verbatim: K-1 points of the inverse-CDF grid."""
     return torch.arange(1 / (2 * sample_count), (2 * sample_count - 1) / (2 * sample_count), 2 / (2 * sample_count))
@@ -95,7 +102,8 @@ def ats_block_forward(x: Tensor, mask: Tensor, p: Dict[str, Tensor], i: int, cfg
         with torch.no_grad():      # the sampled ids are integers (argmin, ats.py:74): nothing of this reaches a gradient
             cdf = ats_cdf(ats_scores(attn[:, :, 0, :].detach(), v.detach()), mask)
         if forced_ids is None:
-            ids, mask = ats_ids_from_cdf(cdf, ats_sample_steps(sample_count), sample_count if static_pad else None)
+            steps = ats_sample_steps(sample_count)
+            ids, mask = ats_ids_from_cdf(cdf, steps, int(steps.numel()) + 1 if static_pad else None)
         else:
             ids, mask = forced_ids, F.pad(forced_ids[:, 1:] != 0, (1, 0), value=True)
         gi = ids[:, None, :, None].expand(B, H, ids.shape[1], N)

@@ -199,7 +199,7 @@ def test_stage_schedules_match_the_oracle(family):
         elif family == "tome":
             want = oracle.tome_schedule(cfg)
         elif family == "ats":
-            want = oracle.ats_sample_counts(cfg)
+            want = oracle.ats_token_bounds(cfg)
         else:
             want = oracle.sit_cluster_counts(cfg)              # sit / dpcknn / sinkhorn / kmedoids / patchmerger share the rule
         got = {i: k for i, k in enumerate(m._keep) if k}

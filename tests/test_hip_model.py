@@ -481,3 +481,33 @@ def test_non_finite_input_gives_nan_logits_and_no_fault(name):
     for blk, kept in viz.get("Kept_Tokens", {}).items():
         kept = np.asarray(kept)
         assert kept.min() >= -1 and kept.max() <= 196, (blk, kept.min(), kept.max())      # -1: EViT's fused-token / padding marker
+
+
+@pytest.mark.parametrize("kr,loc", [([0.8], [1, 2]), ([0.5], [0, 1, 2, 3, 4])])
+def test_ats_sample_counts_whose_grid_has_k_points(kr, loc):
+    """ats.py:48 builds the inverse-CDF grid with a float arange; for sample counts such as 126 (keep_rate 0.8, second stage) or 7 rounding
+    lets the end point in: K grid points, up to K + 1 kept tokens.  The static bound must follow the grid (it used to raise)."""
+    case = dict(family="ats", embed_dim=128, depth=max(loc) + 1, num_heads=2, num_classes=16, keep_rate=kr, reduction_loc=loc, batch=3,
+                wseed=41, xseed=42, qkv_gain=4.0)
+    cfg = case_config(case)
+    counts, bounds = oracle.ats_sample_counts(cfg), oracle.ats_token_bounds(cfg)
+    assert any(bounds[b] == counts[b] + 1 for b in counts), (counts, bounds)         # the case this test is about
+    model, params, _ = build_model(case)
+    model.precision = "fp32"
+    x = make_images(3, 224, 42)
+    logits, viz = model(x.cuda())
+    assert [t for i, t in enumerate(model._last_tokens) if i in bounds] == [bounds[b] for b in sorted(bounds)]
+    want, oviz = oracle.forward(params, x, cfg, precision="fp32", return_viz=True)
+    for b in sorted(bounds):
+        kept = viz["Kept_Tokens"][b]
+        assert kept.shape[1] <= bounds[b] - 1 and kept.max() <= 195
+    blk0 = sorted(bounds)[0]
+    same = viz["Kept_Tokens"][blk0].shape == oviz["Kept_Tokens"][blk0].shape and (viz["Kept_Tokens"][blk0] == oviz["Kept_Tokens"][blk0]).all()
+    d = (logits.cpu() - want).abs().max().item()
+    print(f"\\nATS kr {kr} loc {loc}: bounds {bounds}; first-stage ids identical to the oracle: {bool(same)}; max|logit - oracle_fp32| = {d:.2e}")
+    assert d < (2e-4 if same and len(loc) == 1 else 0.5)
+    model.precision = "bf16"
+    model.train()
+    model.viz_mode = False
+    torch.nn.functional.cross_entropy(model(x.cuda()), torch.randint(0, 16, (3,)).cuda()).backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())

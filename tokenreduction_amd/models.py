@@ -886,7 +886,9 @@ class ATSVisionTransformer(VisionTransformer):
             if idx in self.sample_loc:
                 self.sample_count[idx] = int(sample_count[cnt])
                 cnt += 1
-        self._keep = list(self.sample_count)
+        # static token bound of a sampling block: one token per grid point + CLS.  The grid (ats.py:48) is a float arange with an
+        # exclusive end; for 42 sample counts up to 197 (7, 12, 14, ..., 126, ...) rounding admits the end point: K points, bound K + 1
+        self._keep = [int(self.sample_steps(k).numel()) + 1 if k else 0 for k in self.sample_count]
 
     def get_reduction_count(self):
         return self.sample_loc
@@ -900,8 +902,6 @@ class ATSVisionTransformer(VisionTransformer):
         for blk, K in enumerate(self.sample_count):
             if K:
                 steps = self.sample_steps(K).to(self.pos_embed.device)
-                if steps.numel() > K - 1:
-                    raise ValueError(f"sample_count {K}: the grid has {steps.numel()} points, more than K-1")
                 W.stage[blk].w3 = f32(steps)
                 W.stage[blk].n_pad = steps.numel()
 
@@ -909,7 +909,7 @@ class ATSVisionTransformer(VisionTransformer):
         P1 = self.patch_embed.num_patches + 1
         kept = ws["kept"].cpu().numpy()
         decisions = {}
-        for blk, K in enumerate(self.sample_count):
+        for blk, K in enumerate(self._keep):
             if K:
                 ids = kept[blk * B * P1: blk * B * P1 + B * K].reshape(B, K).astype(np.int64)
                 width = int((ids[:, 1:] != 0).sum(axis=1).max())                      # pad_sequence to the batch maximum, ats.py:78

@@ -30,7 +30,7 @@ for it in range(n_cfg):
         kr = [0.7]                                                           # geometric schedules: keep at least a few clusters at the last stage
     if fam == "tome":                                                        # ToMe: absolute token counts after each listed block, non-increasing
         r = int(rng.choice([4, 16, 40]))
-        kr = [max(2, 196 - r * (j + 1)) for j in range(len(loc))]
+        kr = [max(2, 196 - r * (j + 1)) for j in range(len(loc))] if len(loc) > 1 else [0.7]      # one value = a ratio (tome.py:145-156)
     if fam == "deit":
         loc, kr = [], [1.0]
     B = int(rng.choice([1, 2, 3, 5, 8]))
@@ -58,6 +58,17 @@ for it in range(n_cfg):
         rel = float((logits - want).norm() / want.norm())
         ok = bool(torch.isfinite(logits).all()) and rel < 0.5
         msg = f"eval rel {rel:.2e} tokens {m._last_tokens}"
+        if fam in ("deit", "topk", "evit", "tome", "sit", "patchmerger", "sinkhorn", "heuristic", "dyvit"):
+            # split-bf16 precision against the fp32 oracle: decisions are the reference's up to score near-ties, logits to ~1e-4
+            m.precision = "bf16x3"
+            o3 = m(x.cuda())
+            l3 = (o3[0] if isinstance(o3, tuple) else o3).cpu()
+            w32 = oracle.forward(params, x, cfg, precision="fp32", extra=extra, noise=noise)
+            w32 = w32[0] if isinstance(w32, tuple) else w32
+            d3 = float((l3 - w32).abs().max())
+            m.precision = "bf16"
+            msg += f"; bf16x3 max|d| {d3:.1e}"
+            ok &= d3 < 5e-2            # (a flipped near-tie decision moves the logits by more than arithmetic does; 5e-2 flags real bugs only)
         try:
             m.train()
             m.viz_mode = False
