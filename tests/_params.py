@@ -213,6 +213,16 @@ GOLDEN_CASES = {
                                keep_rate=[0.25], reduction_loc=[1, 2, 3], batch=2, wseed=165, xseed=166, qkv_gain=6.0),
     "ats_micro_384": dict(family="ats", embed_dim=128, depth=4, num_heads=2, num_classes=16, img_size=384,
                           keep_rate=[0.25], reduction_loc=[1, 2, 3], batch=2, wseed=167, xseed=168, qkv_gain=6.0),
+    # 384x384 with keep_rate 0.9: 518 / 466 / 419 clusters (Sinkhorn's whole-image kernel beyond 256 centres, DPC-KNN's merge backward
+    # beyond 256 clusters) and soft assignments wider than the 192 columns the fused merge holds in registers (SiT, PatchMerger)
+    "sinkhorn_micro_384_kr09": dict(family="sinkhorn", embed_dim=128, depth=4, num_heads=2, num_classes=16, img_size=384,
+                                    keep_rate=[0.9], reduction_loc=[1, 2, 3], batch=2, wseed=171, xseed=172, qkv_gain=6.0),
+    "dpcknn_micro_384_kr09": dict(family="dpcknn", embed_dim=128, depth=4, num_heads=2, num_classes=16, img_size=384,
+                                  keep_rate=[0.9], reduction_loc=[1, 2, 3], batch=2, wseed=173, xseed=174, qkv_gain=6.0),
+    "sit_micro_384_kr07": dict(family="sit", embed_dim=128, depth=4, num_heads=2, num_classes=16, img_size=384,
+                               keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=2, wseed=175, xseed=176, qkv_gain=6.0),
+    "patchmerger_micro_384_kr07": dict(family="patchmerger", embed_dim=128, depth=4, num_heads=2, num_classes=16, img_size=384,
+                                       keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=2, wseed=177, xseed=178, qkv_gain=6.0),
     # BASELINE.json configs[3] families at DeiT-B width (D = 768, H = 12): ATS + DPC-KNN keep_rate 0.5.  qkv gain 2 gives the
     # attention logits the same spread (std ~1.2-2.5) as gain 4 does at DeiT-S width: q.k/8 scales with D
     "dpcknn_base_kr05": dict(family="dpcknn", embed_dim=768, depth=12, num_heads=12, num_classes=1000,
@@ -244,7 +254,8 @@ GOLDEN_CASES = {
 GRAD_CASES = ["deit_micro", "topk_micro", "evit_micro", "tome_micro", "dpcknn_micro", "dpcknn_micro_equal", "ats_micro", "topk_small_kr07",
               "evit_small_kr07", "tome_small_r16", "deit_base", "dpcknn_base_kr05", "ats_base_kr05", "dyvit_micro_train", "dyvit_small_train", "kmedoids_micro", "heuristic_micro_l2", "topk_micro_droppath",
               "sit_micro", "patchmerger_micro", "sinkhorn_micro", "sit_small_kr07", "patchmerger_small_kr07", "sinkhorn_small_kr07",
-              "topk_micro_384", "kmedoids_micro_384", "ats_micro_384", "sinkhorn_micro_384"]
+              "topk_micro_384", "kmedoids_micro_384", "ats_micro_384", "sinkhorn_micro_384",
+              "sinkhorn_micro_384_kr09", "dpcknn_micro_384_kr09", "sit_micro_384_kr07", "patchmerger_micro_384_kr07"]
 
 
 def dyvit_token_ratio(case: dict):

@@ -108,7 +108,8 @@ def test_model_fp32_matches_reference_golden(golden_dir, name):
         print(f"\n[{name}] fp32 path: masks exact, max|logit - reference| = {d:.2e}")
         assert d < 2e-4, d
         return
-    for k in kept_keys:                                     # bit-exact token indices, every reduction stage, end to end
+    dpc_permuted = False
+    for k in sorted(kept_keys, key=lambda k: int(k.split("_")[1])):      # bit-exact token indices, every reduction stage, end to end
         blk = int(k.split("_")[1])
         if case["family"] == "kmedoids":
             same = bool((viz["Kept_Tokens"][blk] == g[k]).all())
@@ -121,8 +122,12 @@ def test_model_fp32_matches_reference_golden(golden_dir, name):
         if case["family"] == "dpcknn":
             # centres = top-K of (distance to the nearest denser token) * density: the reference's own scores decide, up to
             # fp32 noise of the distance matrix (matmul-form cdist: ~1e-6 relative); then assignments given the centres
-            assert_valid_ranking(viz["Kept_Tokens"][blk], g[f"scores_{blk}"], tol=1e-5 * float(np.abs(g[f"scores_{blk}"]).max()))
+            # (an exact tie that swaps two centres permutes the token rows of every later stage: the reference's positional scores
+            # then no longer describe this run's rows, so stages after the first difference are held by the logits alone)
+            if not dpc_permuted:
+                assert_valid_ranking(viz["Kept_Tokens"][blk], g[f"scores_{blk}"], tol=1e-5 * float(np.abs(g[f"scores_{blk}"]).max()))
             same = (viz["Kept_Tokens"][blk] == g[k]).all()
+            dpc_permuted = dpc_permuted or not same
             print(f"   dpcknn block {blk}: centres identical to the reference: {bool(same)}; assignment agreement "
                   f"{(viz['Assignment_Maps'][blk] == g[f'assign_{blk}']).mean():.4f}")
             if same:

@@ -605,7 +605,7 @@ __global__ __launch_bounds__(256) void cluster_merge_bwd_kernel(const float* __r
                                                                 const int32_t* __restrict__ assign, const float* __restrict__ sw,
                                                                 float* __restrict__ g_out, uint16_t* __restrict__ gb_out,
                                                                 float* __restrict__ part, int N, int K, int D) {
-  __shared__ float sW[256];
+  __shared__ float sW[640];          // summed token weight of every cluster (K <= 640: 384 x 384 inputs at keep_rate 0.9 have 518)
   __shared__ float4 red[3][64 * NCH];
   __shared__ float redb[4];
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1014,8 +1014,8 @@ extern "C" int tr_cluster_merge_bwd(const float* g_in, const float* x0, const fl
                                     float* ws, size_t ws_floats, int B, int N, int K, int D, tr_stream_t s) {
   TR_REQUIRE(g_in && x0 && x1 && assign && g_out && gb_out && ws, TR_ERR_NULL, "tr_cluster_merge_bwd: null pointer");
   TR_REQUIRE(score_w == nullptr || (wtok && d_sw && d_sb), TR_ERR_NULL, "tr_cluster_merge_bwd: weighted merge needs wtok, d_sw, d_sb");
-  TR_REQUIRE(B > 0 && N > 1 && K >= 1 && K <= 256 && K <= N - 1 && D % 4 == 0 && D <= 256 * LN_MAX_CHUNKS, TR_ERR_SHAPE,
-             "tr_cluster_merge_bwd: bad shape B=%d N=%d K=%d D=%d (K <= 256)", B, N, K, D);
+  TR_REQUIRE(B > 0 && N > 1 && K >= 1 && K <= 640 && K <= N - 1 && D % 4 == 0 && D <= 256 * LN_MAX_CHUNKS, TR_ERR_SHAPE,
+             "tr_cluster_merge_bwd: bad shape B=%d N=%d K=%d D=%d (K <= 640)", B, N, K, D);
   TR_REQUIRE(ws_floats >= (size_t)B * (D + 4), TR_ERR_SHAPE, "tr_cluster_merge_bwd: workspace too small");
   hipStream_t st = static_cast<hipStream_t>(s);
   TR_DISPATCH_NCH(D, hipLaunchKernelGGL((cluster_merge_bwd_kernel<NCH>), dim3(B), dim3(256), 0, st, g_in, x0, x1, wtok, assign, score_w, g_out, gb_out,

@@ -437,7 +437,9 @@ __global__ __launch_bounds__(SKT) void sinkhorn_kernel(const float* __restrict__
 // All loads of a pass are issued in batches of eight (independent addresses).  The first version of this kernel ran 256 threads
 // per image with one thread walking all tokens of a centre: 1384 us at B = 64, K = 144, P = 576 -- a quarter of the 384^2 forward.
 constexpr int SGT = 1024;
-constexpr int SG_KMAX = 256;                 // centres handled per pass without looping (K <= 192 in every registered model)
+constexpr int SG_KMAX = 640;                 // centres the wide instantiation holds per token row (K = 518 at 384 x 384, keep_rate 0.9)
+// KC: 64-centre groups a lane holds of one token row in the v-step (4: K <= 256, every registered model; 10: K <= 640)
+template <int KC>
 __global__ __launch_bounds__(SGT) void sinkhorn_global_kernel(const float* __restrict__ scores, int ldl, float eps, int iters,
                                                               float* __restrict__ wt, float* __restrict__ soft, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) float s_uv[];     // u[K], v[P], partials[nseg][KW]
@@ -497,11 +499,11 @@ __global__ __launch_bounds__(SGT) void sinkhorn_global_kernel(const float* __res
     __syncthreads();
     // ---- v = log_nu - logsumexp_k(Z + u): wave per token row, four rows per step
     for (int p0 = wave * 4; p0 < P; p0 += (SGT / 64) * 4) {
-      float z[4][SG_KMAX / 64];
+      float z[4][KC];
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int c = 0; c < SG_KMAX / 64; ++c) {
+        for (int c = 0; c < KC; ++c) {
           const int k = lane + 64 * c;
           z[r][c] = sc[(size_t)min(p0 + r, P - 1) * ldl + min(k, K - 1)];
         }
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(SGT) void sinkhorn_global_kernel(const float* __res
       for (int r = 0; r < 4; ++r) {
         float mm = -INFINITY;
 #pragma unroll
-        for (int c = 0; c < SG_KMAX / 64; ++c) {
+        for (int c = 0; c < KC; ++c) {
           const int k = lane + 64 * c;
           z[r][c] = (k < K) ? z[r][c] * inv_eps + s_u[min(k, K - 1)] : -INFINITY;
           mm = fmaxf(mm, z[r][c]);
@@ -518,7 +520,7 @@ __global__ __launch_bounds__(SGT) void sinkhorn_global_kernel(const float* __res
         for (int o = 32; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o, 64));
         float ts = 0.f;
 #pragma unroll
-        for (int c = 0; c < SG_KMAX / 64; ++c) ts += expf(z[r][c] - mm);     // exp(-inf) = 0 for the padding lanes
+        for (int c = 0; c < KC; ++c) ts += expf(z[r][c] - mm);     // exp(-inf) = 0 for the padding lanes
         ts = wave_sum(ts);
         if (lane == 0 && p0 + r < P) s_v[p0 + r] = norm - (mm + logf(ts));
       }
@@ -614,7 +616,8 @@ extern "C" int tr_sinkhorn(const float* scores, int ldl, float eps, int iters, f
     TR_REQUIRE(K <= SG_KMAX, TR_ERR_SHAPE, "tr_sinkhorn: K=%d > %d centres with K*P beyond the LDS is not supported", K, SG_KMAX);
     const int kw = (K + 63) & ~63;
     const size_t lds_g = ((size_t)K + (N - 1) + (size_t)(SGT / kw) * kw) * sizeof(float);
-    hipLaunchKernelGGL(sinkhorn_global_kernel, dim3(B), dim3(SGT), lds_g, st, scores, ldl, eps, iters, wt, soft, N, K);
+    if (K <= 256) hipLaunchKernelGGL(sinkhorn_global_kernel<4>, dim3(B), dim3(SGT), lds_g, st, scores, ldl, eps, iters, wt, soft, N, K);
+    else hipLaunchKernelGGL(sinkhorn_global_kernel<SG_KMAX / 64>, dim3(B), dim3(SGT), lds_g, st, scores, ldl, eps, iters, wt, soft, N, K);
     TR_CHECK_LAUNCH("tr_sinkhorn");
     return TR_OK;
   }
@@ -654,13 +657,17 @@ extern "C" int tr_weighted_merge(const float* wt, int ldl, const float* x, const
 extern "C" int tr_softassign_merge_fast(float* logits, int ldl, float scale, int apply_softmax, const float* x, const float* src,
                                         float* x_out, float* soft, int B, int N, int K, int D, tr_stream_t s) {
   TR_REQUIRE(logits && x && src && x_out, TR_ERR_NULL, "tr_softassign_merge_fast: null pointer");
-  TR_REQUIRE(B > 0 && N >= 2 && K >= 1 && K <= MK_MAX && D >= 4 && D % 4 == 0 && ldl >= K && ldl % 4 == 0, TR_ERR_SHAPE,
-             "tr_softassign_merge_fast: bad shape B=%d N=%d K=%d (<= %d) D=%d ldl=%d", B, N, K, MK_MAX, D, ldl);
+  TR_REQUIRE(B > 0 && N >= 2 && K >= 1 && D >= 4 && D % 4 == 0 && ldl >= K && ldl % 4 == 0, TR_ERR_SHAPE,
+             "tr_softassign_merge_fast: bad shape B=%d N=%d K=%d D=%d ldl=%d", B, N, K, D, ldl);
   TR_REQUIRE(x_out != x && x_out != src, TR_ERR_SHAPE, "tr_softassign_merge_fast: needs a distinct x_out");
   TR_REQUIRE(tr_aligned16(logits) && tr_aligned16(x) && tr_aligned16(src) && tr_aligned16(x_out), TR_ERR_ALIGN,
              "tr_softassign_merge_fast: pointers must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(s);
   if (apply_softmax) hipLaunchKernelGGL(token_softmax_kernel, dim3((K + 31) / 32, B), dim3(256), 0, st, logits, ldl, scale, soft, N, K);
+  if (K > MK_MAX) {          // more outputs than the MFMA kernel's accumulators hold (384 x 384 inputs at high keep rates): the VALU merge
+    TR_CHECK_LAUNCH("tr_softassign_merge_fast");
+    return tr_weighted_merge(logits, ldl, x, src, x_out, B, N, K, D, s);
+  }
   hipLaunchKernelGGL(softmerge_mfma_kernel, dim3((D + 63) / 64, B), dim3(256), 0, st, logits, ldl, x, src, x_out, N, K, D);
   TR_CHECK_LAUNCH("tr_softassign_merge_fast");
   return TR_OK;

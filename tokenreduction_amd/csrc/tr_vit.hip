@@ -115,7 +115,7 @@ using trplan::align_up;
 
 struct Plan {
   int P, N0, D, H, Hd, C, kcols;
-  size_t off_x0, off_x1, off_xn, off_qkv, off_ao, off_h, off_d, off_cols, off_cls, off_scores, off_idx, off_compl, off_xcls, off_size0, off_size1, off_cluster, total;
+  size_t off_x0, off_x1, off_xn, off_qkv, off_ao, off_h, off_d, off_cols, off_cls, off_scores, off_idx, off_compl, off_xcls, off_size0, off_size1, off_cluster, off_soft, total;
 };
 
 bool make_plan(const tr_vit_config* c, int B, Plan* p) {
@@ -156,6 +156,13 @@ bool make_plan(const tr_vit_config* c, int B, Plan* p) {
   if (c->family == TR_FAMILY_DPCKNN) o += align_up(tr_dpcknn_workspace_floats(B, p->N0) * 4 + (size_t)B * p->N0 * 4);
   if (c->family == TR_FAMILY_KMEDOIDS)
     o += align_up(tr_dpcknn_workspace_floats(B, p->N0) * 4) + align_up((size_t)B * p->H * 4 * p->N0 * 4);
+  // soft-assignment families: token-major logits / scores / transport plan of a stage, fp32 [B*N0, soft_ld(K)]
+  p->off_soft = o;
+  if (trplan::soft_family(c->family)) {
+    int kmax = 0;
+    for (int i = 0; i < c->depth; ++i) kmax = c->keep[i] > kmax ? c->keep[i] : kmax;
+    o += align_up(T * (size_t)trplan::soft_ld(kmax) * 4);
+  }
   p->total = o;
   return true;
 }
@@ -348,12 +355,12 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       const int Kc = cfg->keep[i], M = B * N;
       TR_REQUIRE(Kc <= N - 1, TR_ERR_CONFIG, "tr_vit_forward: block %d asks for %d outputs of %d patch tokens", i, Kc, N - 1);
       TR_REQUIRE(sw->ln_g && sw->ln_b && sw->w1 && sw->b1 && sw->n_pad >= Kc && sw->n_pad % 8 == 0 &&
-                     (size_t)sw->n_pad * 4 <= (size_t)p.Hd * (f32 ? 4 : 2),
+                     sw->n_pad == trplan::soft_ld(Kc),
                  TR_ERR_CONFIG, "tr_vit_forward: block %d PatchMerger weights missing or n_pad=%d invalid for K=%d", i, sw->n_pad, Kc);
       if (train) {
         // every operand of the stage's backward stays on the tape; the merged stream is written to norm1's input slot
         const trplan::BlockTape& bt = tp->blk[i];
-        TR_REQUIRE(sw->n_pad == trplan::soft_ld(Kc) && Kc <= 192, TR_ERR_CONFIG, "tr_vit_forward_train: block %d PatchMerger n_pad=%d K=%d", i, sw->n_pad, Kc);
+        TR_REQUIRE(sw->n_pad == trplan::soft_ld(Kc), TR_ERR_CONFIG, "tr_vit_forward_train: block %d PatchMerger n_pad=%d K=%d", i, sw->n_pad, Kc);
         float* x0 = reinterpret_cast<float*>(tape + bt.x0);
         float* xh = reinterpret_cast<float*>(tape + bt.sxh);
         float* slog = reinterpret_cast<float*>(tape + bt.slog);
@@ -372,7 +379,7 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
         N = Kc + 1;
       } else {
       float* xh = static_cast<float*>(qkv);                       // LayerNorm-ed tokens, fp32 [M, D]
-      float* sc = static_cast<float*>(hbuf);                      // similarities [M, n_pad]
+      float* sc = reinterpret_cast<float*>(ws + p.off_soft);      // similarities [M, n_pad]
       TR_TRY(op_ln(f32, x, D, pending, D, sw->ln_g, sw->ln_b, xn, M, D, 1e-5f, s));        // x += previous mlp output; GEMM operand
       pending = nullptr;
       TR_TRY(tr_layernorm_f32(x, D, nullptr, D, sw->ln_g, sw->ln_b, xh, M, D, 1e-5f, s));  // the rows that are summed
@@ -391,11 +398,11 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       const tr_stage_weights* sw = &w->stage[i];
       const int Kc = cfg->keep[i], M = B * N;
       TR_REQUIRE(Kc <= N - 1, TR_ERR_CONFIG, "tr_vit_forward: block %d asks for %d clusters of %d patch tokens", i, Kc, N - 1);
-      TR_REQUIRE(sw->w1 && sw->b1 && sw->n_pad >= Kc && sw->n_pad % 8 == 0 && (size_t)sw->n_pad * 4 <= (size_t)p.Hd * (f32 ? 4 : 2),
+      TR_REQUIRE(sw->w1 && sw->b1 && sw->n_pad >= Kc && sw->n_pad % 8 == 0 && sw->n_pad == trplan::soft_ld(Kc),
                  TR_ERR_CONFIG, "tr_vit_forward: block %d Sinkhorn centres missing or n_pad=%d invalid for K=%d", i, sw->n_pad, Kc);
       if (train) {
         const trplan::BlockTape& bt = tp->blk[i];
-        TR_REQUIRE(sw->n_pad == trplan::soft_ld(Kc) && Kc <= 192, TR_ERR_CONFIG, "tr_vit_forward_train: block %d Sinkhorn n_pad=%d K=%d", i, sw->n_pad, Kc);
+        TR_REQUIRE(sw->n_pad == trplan::soft_ld(Kc), TR_ERR_CONFIG, "tr_vit_forward_train: block %d Sinkhorn n_pad=%d K=%d", i, sw->n_pad, Kc);
         float* x0 = reinterpret_cast<float*>(tape + bt.x0);
         float* xh = reinterpret_cast<float*>(tape + bt.sxh);
         float* slog = reinterpret_cast<float*>(tape + bt.slog);
@@ -417,7 +424,7 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       if (pending) TR_TRY(op_ln(f32, x, D, pending, D, bw->ln1_g, bw->ln1_b, xn, M, D, cfg->ln_eps, s));   // x += previous mlp output
       pending = nullptr;
       float* xh = static_cast<float*>(qkv);                       // unit-norm tokens, fp32 [M, D] (the qkv slab is free here)
-      float* sc = static_cast<float*>(hbuf);                      // scores, then the transport plan in place [M, n_pad]
+      float* sc = reinterpret_cast<float*>(ws + p.off_soft);      // scores, then the transport plan in place [M, n_pad]
       TR_TRY(tr_rownorm(x, xh, xn, f32 ? 1 : 0, M, D, s));
       TR_TRY(op_gemm(prec, xn, sw->w1, sw->b1, sc, nullptr, 0, M, sw->n_pad, D, TR_EPI_F32, s));
       TR_TRY(tr_sinkhorn(sc, sw->n_pad, cfg->sinkhorn_eps > 0.f ? cfg->sinkhorn_eps : 1.0f, cfg->cluster_iters, sc, soft_out, B, N,
@@ -468,7 +475,7 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       const tr_stage_weights* sw = &w->stage[i];
       const trplan::BlockTape& bt = tp->blk[i];
       const int Kc = cfg->keep[i], M = B * N, Hh = D / 2;
-      TR_REQUIRE(Kc <= N - 1 && Kc <= 192, TR_ERR_CONFIG, "tr_vit_forward_train: block %d asks for %d of %d patch tokens (<= 192)", i, Kc, N - 1);
+      TR_REQUIRE(Kc <= N - 1, TR_ERR_CONFIG, "tr_vit_forward_train: block %d asks for %d of %d patch tokens", i, Kc, N - 1);
       TR_REQUIRE(sw->ln_g && sw->ln_b && sw->w0 && sw->b0 && sw->w1 && sw->b1, TR_ERR_NULL, "tr_vit_forward_train: block %d SiT weights missing", i);
       TR_REQUIRE(sw->n_pad == trplan::soft_ld(Kc) && Hh % 64 == 0 && (sw->h_pad == 0 || sw->h_pad == Hh), TR_ERR_CONFIG,
                  "tr_vit_forward_train: the SiT training path needs D/2 %% 64 == 0 and n_pad == %d (got h_pad=%d n_pad=%d)", trplan::soft_ld(Kc),
@@ -515,16 +522,17 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
         have_xn = true;
       } else {
         // a23: TokenSlimmingModule (sit.py:36-40)
-        TR_REQUIRE(sw->n_pad >= Kc && sw->n_pad % 8 == 0 && (size_t)sw->n_pad * 4 <= (size_t)p.Hd * (f32 ? 4 : 2), TR_ERR_CONFIG,
+        TR_REQUIRE(sw->n_pad >= Kc && sw->n_pad % 8 == 0 && sw->n_pad == trplan::soft_ld(Kc), TR_ERR_CONFIG,
                    "tr_vit_forward: block %d SiT n_pad=%d invalid for K=%d", i, sw->n_pad, Kc);
         const int Hh = sw->h_pad > 0 ? sw->h_pad : D / 2;
         TR_REQUIRE(Hh >= D / 2 && (Hh % 64 == 0 || f32), TR_ERR_CONFIG, "tr_vit_forward: SiT hidden width %d invalid (D=%d)", Hh, D);
         TR_TRY(op_gemm(prec, xn, sw->w0, sw->b0, ao, nullptr, 0, M, Hh, D, TR_EPI_GELU_BF16, s));
-        TR_TRY(op_gemm(prec, ao, sw->w1, sw->b1, hbuf, nullptr, 0, M, sw->n_pad, Hh, TR_EPI_F32, s));
+        float* sc = reinterpret_cast<float*>(ws + p.off_soft);    // logits [M, n_pad]
+        TR_TRY(op_gemm(prec, ao, sw->w1, sw->b1, sc, nullptr, 0, M, sw->n_pad, Hh, TR_EPI_F32, s));
         if (!f32 && Kc <= 192)
-          TR_TRY(tr_softassign_merge_fast(static_cast<float*>(hbuf), sw->n_pad, sw->scale, 1, x, x, x_alt, soft_out, B, N, Kc, D, s));
+          TR_TRY(tr_softassign_merge_fast(sc, sw->n_pad, sw->scale, 1, x, x, x_alt, soft_out, B, N, Kc, D, s));
         else
-          TR_TRY(tr_sit_merge(static_cast<const float*>(hbuf), sw->n_pad, sw->scale, x, x_alt, soft_out, B, N, Kc, D, s));
+          TR_TRY(tr_sit_merge(sc, sw->n_pad, sw->scale, x, x_alt, soft_out, B, N, Kc, D, s));
         if (soft_out) soft_out += (size_t)B * Kc * (N - 1);
       }
       float* t = x; x = x_alt; x_alt = t;

@@ -34,25 +34,35 @@ for it in range(n_cfg):
     if fam == "deit":
         loc, kr = [], [1.0]
     B = int(rng.choice([1, 2, 3, 5, 8]))
-    case = dict(family=fam, embed_dim=D, depth=depth, num_heads=D // 64, num_classes=12, keep_rate=kr, reduction_loc=loc, batch=B,
-                wseed=1000 + it, xseed=2000 + it, qkv_gain=3.0, heuristic_pattern="l2", not_contiguous=bool(it % 2), min_radius=None)
-    tag = f"{fam:11s} D{D} depth{depth} loc{loc} kr{kr} B{B}"
+    img = 384 if (it % 7 == 6 and fam not in ("dyvit",)) else 224                 # a few 384 x 384 configurations (577 tokens)
+    pattern = str(rng.choice(["l1", "l2", "linf"]))
+    equal = bool(rng.integers(0, 2)) and fam in ("dpcknn", "kmedoids")
+    min_radius = float(rng.choice([0.0, 2.0, 4.0])) or None
+    if fam in ("topk", "evit", "dyvit") and len(loc) > 1 and it % 3 == 0:           # explicit per-stage ratios instead of one geometric rate
+        kr = sorted((float(v) for v in rng.choice([0.9, 0.8, 0.6, 0.5, 0.4, 0.3], size=len(loc), replace=False)), reverse=True)
+    case = dict(family=fam, embed_dim=D, depth=depth, num_heads=D // 64, num_classes=12, keep_rate=kr, reduction_loc=loc, batch=B, img_size=img,
+                wseed=1000 + it, xseed=2000 + it, qkv_gain=3.0, heuristic_pattern=pattern, not_contiguous=bool(it % 2), min_radius=min_radius,
+                equal_weight=equal)
+    tag = f"{fam:11s} D{D} depth{depth} loc{loc} kr{kr} B{B} img{img}" + (f" {pattern} nc{int(case['not_contiguous'])} mr{min_radius}" if fam == "heuristic" else "") + (" equal" if equal else "")
     try:
-        args = types.SimpleNamespace(keep_rate=list(kr), reduction_loc=list(loc), viz_mode=True, dyvit_distill=False, k_neighbors=5, equal_weight=False,
-                                     sinkhorn_eps=1.0, cluster_iters=3, heuristic_pattern="l2", not_contiguous=case["not_contiguous"], min_radius=None)
-        m = getattr(tra, FAM[fam])(img_size=224, patch_size=16, embed_dim=D, depth=depth, num_heads=D // 64, mlp_ratio=4, qkv_bias=True,
+        args = types.SimpleNamespace(keep_rate=list(kr), reduction_loc=list(loc), viz_mode=True, dyvit_distill=False, k_neighbors=5, equal_weight=equal,
+                                     sinkhorn_eps=1.0, cluster_iters=3, heuristic_pattern=pattern, not_contiguous=case["not_contiguous"], min_radius=min_radius)
+        m = getattr(tra, FAM[fam])(img_size=img, patch_size=16, embed_dim=D, depth=depth, num_heads=D // 64, mlp_ratio=4, qkv_bias=True,
                                    num_classes=12, args=args)
         cfg, params = case_params(case)
         m.load_state_dict(params, strict=True)
         m = m.cuda().eval()
-        x = make_images(B, 224, case["xseed"])
+        x = make_images(B, img, case["xseed"])
+        np.random.seed(case["xseed"])          # K-Medoids equal_weight: numpy's global stream picks the first medoid on both sides
         noise = None
         if fam == "dpcknn":                     # the density noise is an input on both sides: zeros
             noise = {blk: torch.zeros(B, P) for blk, _, P in m._stage_shapes()}
             m.density_noise = noise
         out = m(x.cuda())
         logits = (out[0] if isinstance(out, tuple) else out).cpu()
-        extra = dict(heuristic_pattern="l2", not_contiguous=case["not_contiguous"], min_radius=None)
+        extra = dict(heuristic_pattern=pattern, not_contiguous=case["not_contiguous"], min_radius=min_radius)
+        if equal and fam == "kmedoids":
+            extra["equal_first"] = dict(zip(sorted(int(b) for b in m.cluster_loc), m._kmed_draws))
         want = oracle.forward(params, x, cfg, precision="bf16", extra=extra, noise=noise)
         want = want[0] if isinstance(want, tuple) else want
         rel = float((logits - want).norm() / want.norm())
