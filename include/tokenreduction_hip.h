@@ -138,6 +138,11 @@ int tr_gather_layernorm_f32(const float* x, const float* delta, const int32_t* i
 int tr_gemm_gelu_keep_bf16(const uint16_t* A, const uint16_t* W, const float* bias, uint16_t* pre, uint16_t* h, int M, int N, int K,
                            tr_stream_t s);
 
+/* Backward of Linear -> GELU's second half (timm Mlp fc2 -> act, the DyViT / SiT predictor layers): out bf16 [M,N] =
+ * bf16(A W^T) * gelu'(pre) (a data gradient: no bias), pre bf16 [M,N] the pre-activation tr_gemm_gelu_keep_bf16 kept (engine.py:76 loss.backward() through
+ * timm Mlp) -- bitwise tr_gemm_bf16(TR_EPI_BF16) followed by tr_gelu_bwd_bf16, in one launch.  K % 64 == 0, N % 8 == 0. */
+int tr_gemm_dgelu_bf16(const uint16_t* A, const uint16_t* W, const uint16_t* pre, uint16_t* out, int M, int N, int K, tr_stream_t s);
+
 /* fp32 validation path of the Linear layers: A fp32 [M,K], W fp32 [N,K], out fp32; K % 16 == 0.
  * epilogue: TR_EPI_F32 (bias), TR_EPI_GELU_BF16 (bias + exact-erf GELU, fp32 out), TR_EPI_PATCH_F32. */
 int tr_gemm_f32(const float* A, const float* W, const float* bias, float* out, const float* aux, int aux_i, int M, int N, int K,

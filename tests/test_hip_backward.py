@@ -431,3 +431,16 @@ def test_gemm_gelu_keep_is_bitwise_the_two_launch_path(ops, M, N, K):
     pre2 = ops.gemm(a, w, b, ops.TR_EPI_BF16)
     assert torch.equal(pre, pre2)
     assert torch.equal(h, ops.gelu(pre2))
+
+
+@pytest.mark.parametrize("M,N,K", [(50432, 1536, 384), (300, 1536, 384), (25216, 3072, 768), (777, 192, 576), (5, 16, 128)])
+def test_gemm_dgelu_is_bitwise_the_two_launch_path(ops, M, N, K):
+    """fc2's data gradient with the GELU backward folded into the epilogue: bit for bit tr_gemm_bf16(TR_EPI_BF16) followed by
+    tr_gelu_bwd_bf16 (both multiply the ROUNDED data gradient by the same derivative), full tiles, half-tile tails and ragged edges."""
+    a = _randn(50, M, K, dtype=torch.bfloat16)
+    w = _randn(51, N, K, scale=0.05, dtype=torch.bfloat16)
+    b = torch.zeros(N, device="cuda")
+    pre = _randn(52, M, N, scale=1.5, dtype=torch.bfloat16)
+    got = ops.gemm_dgelu(a, w, pre)
+    want = ops.gelu_bwd(pre, ops.gemm(a, w, b, ops.TR_EPI_BF16))
+    assert torch.equal(got, want)

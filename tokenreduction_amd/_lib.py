@@ -64,6 +64,7 @@ SIGNATURES = {
     "tr_rownorm_bwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "tr_add_into_bf16": (_i, [_vp, _vp, _sz, _vp]),
     "tr_gemm_gelu_keep_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "tr_gemm_dgelu_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "tr_gemm_split": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tr_layernorm_f32": (_i, [_vp, _l, _vp, _l, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "tr_attention_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -310,13 +310,7 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const uint16_t* __restric
   *reinterpret_cast<uint4*>(h + 8 * c) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 
-// d/dx [x Phi(x)] = Phi(x) + x phi(x)  (exact erf form, nn.GELU)
-__device__ __forceinline__ float gelu_grad(float x) {
-  const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
-}
-
+// dh *= gelu'(pre): the derivative of the fit the forward applied (gelu2_grad, tr_common.h)
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const uint16_t* __restrict__ pre, uint16_t* __restrict__ dh, size_t nchunks) {
   const size_t c = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= nchunks) return;
@@ -324,12 +318,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const uint16_t* __restric
   const uint4 d = *reinterpret_cast<const uint4*>(dh + 8 * c);
   const unsigned int w[4] = {u.x, u.y, u.z, u.w}, dd[4] = {d.x, d.y, d.z, d.w};
   unsigned int o[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float x0 = __uint_as_float(w[i] << 16), x1 = __uint_as_float(w[i] & 0xffff0000u);
-    const float g0 = __uint_as_float(dd[i] << 16), g1 = __uint_as_float(dd[i] & 0xffff0000u);
-    o[i] = pack_bf16x2(g0 * gelu_grad(x0), g1 * gelu_grad(x1));
-  }
+  dgelu_line(dd, w, o);
   *reinterpret_cast<uint4*>(dh + 8 * c) = make_uint4(o[0], o[1], o[2], o[3]);
 }
 

@@ -114,6 +114,43 @@ __device__ __forceinline__ f32x2 gelu2(f32x2 x) {
   return x * r;
 }
 
+// d/dx [x Phi(x)] = Phi(x) + x phi(x) = 1/2 + o(x), o odd (the exact-erf derivative nn.GELU differentiates): o(x) ~= x P(t) with
+// t = 2 x^2 / c^2 - 1 on |x| <= c = 4.5, x clamped beyond (o(4.5) is within 7e-5 of its limit 1/2); P of degree 9 in the monomial basis of
+// t in [-1, 1], where fp32 Horner has no cancellation (tools/fit_gelu_grad.py).  |gelu2_grad - exact| <= 6e-5 absolute everywhere: 60x below
+// the bf16 resolution of the gradient it multiplies.  No transcendental: 13 packed ops per PAIR of elements (the first version, the derivative
+// of the forward's sigmoid fit, needed exp2 + rcp per element, quarter rate -- the fused epilogue of tr_gemm_dgelu_bf16 is VALU-bound).
+__device__ __forceinline__ f32x2 gelu2_grad(f32x2 x) {
+  constexpr float C = 4.5f;
+  constexpr float P0 = 1.594457889e-01f, P1 = -8.990845048e-02f, P2 = 8.617554151e-02f, P3 = -9.554615128e-02f, P4 = 1.051488888e-01f,
+                  P5 = -8.720398095e-02f, P6 = 4.744845022e-02f, P7 = -4.606752329e-02f, P8 = 5.617017796e-02f, P9 = -2.454702451e-02f;
+  f32x2 xc;
+  xc[0] = __builtin_amdgcn_fmed3f(x[0], -C, C);
+  xc[1] = __builtin_amdgcn_fmed3f(x[1], -C, C);
+  const f32x2 t = (xc * xc) * (2.0f / (C * C)) - 1.0f;
+  f32x2 p = t * P9 + P8;
+  p = p * t + P7;
+  p = p * t + P6;
+  p = p * t + P5;
+  p = p * t + P4;
+  p = p * t + P3;
+  p = p * t + P2;
+  p = p * t + P1;
+  p = p * t + P0;
+  return p * xc + 0.5f;
+}
+
+// eight bf16 gradients times gelu'(eight bf16 pre-activations), rounded back to bf16: one 16-byte line of tr_gelu_bwd_bf16 and of the
+// fused data-gradient epilogue (tr_gemm_dgelu_bf16) -- the two are bitwise the same by construction
+__device__ __forceinline__ void dgelu_line(const unsigned int (&dh)[4], const unsigned int (&pre)[4], unsigned int (&out)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const f32x2 x = {__builtin_bit_cast(float, pre[i] << 16), __builtin_bit_cast(float, pre[i] & 0xffff0000u)};
+    const f32x2 g = {__builtin_bit_cast(float, dh[i] << 16), __builtin_bit_cast(float, dh[i] & 0xffff0000u)};
+    const f32x2 d = g * gelu2_grad(x);
+    out[i] = pack_bf16x2(d[0], d[1]);
+  }
+}
+
 // XCD-aware bijective remap of a linear block id (cdna guide T1): blocks b and b+8 share an XCD/L2, so give
 // each XCD a CONTIGUOUS chunk of the logical tile order.  Speed only, never correctness.
 __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {

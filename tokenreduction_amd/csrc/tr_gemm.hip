@@ -36,6 +36,7 @@ constexpr int BK = 64;
 constexpr int PBM = 256, PBN = 128;
 constexpr int P_STAGE_BYTES = (PBM + PBN) * 128;  // 48 KiB: A rows then W rows, 128 B (64 bf16) per row
 constexpr int P_NSTAGE = 3;
+constexpr int EPI_DGELU = 17;         // internal: bf16 output times gelu'(outp2[same element]) -- fc2's data gradient with the GELU backward folded in (tr_gemm_dgelu_bf16)
 constexpr int EPI_GELU_KEEP = 16;     // internal: TR_EPI_GELU_BF16 plus the pre-activation as a second bf16 output (tr_gemm_gelu_keep_bf16)
 // LDS-DMA pieces per wave and K-step in gemm_bf16_persistent: 4 of A, 2 of W = 6 (what its vmcnt immediates count)
 
@@ -444,7 +445,9 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
                                                        unsigned out_bytes) {
   // EPI_GELU_KEEP (training forward of fc1): outp2 receives the pre-activation, outp its GELU -- one pass instead of a GEMM that
   // writes the pre-activation and an elementwise kernel that re-reads it (0.37 ms of a 12.5 ms DeiT-S step)
-  static_assert(EPI == TR_EPI_BF16 || EPI == TR_EPI_GELU_BF16 || EPI == EPI_GELU_KEEP, "bf16-output epilogues only");
+  // EPI_DGELU (backward of fc2 -> GELU): outp2 is READ -- the kept pre-activation, laid out like the output; every finished 16-byte output
+  // line is multiplied by gelu'(pre) before it is stored, instead of an elementwise pass over [M, hidden] afterwards
+  static_assert(EPI == TR_EPI_BF16 || EPI == TR_EPI_GELU_BF16 || EPI == EPI_GELU_KEEP || EPI == EPI_DGELU, "bf16-output epilogues only");
   __shared__ __attribute__((aligned(16))) unsigned char smem[P_NSTAGE * P_STAGE_BYTES + 8 * 2048];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -545,7 +548,7 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
   const int wm = wave >> 1, wn = wave & 1;
   const int frow = lane & 15, fq = lane >> 4;
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(outp, 0, (int)out_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t orsrc2 = __builtin_amdgcn_make_buffer_rsrc(EPI == EPI_GELU_KEEP ? outp2 : outp, 0, (int)out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t orsrc2 = __builtin_amdgcn_make_buffer_rsrc(EPI == EPI_GELU_KEEP || EPI == EPI_DGELU ? outp2 : outp, 0, (int)out_bytes, 0x00020000);
   // The accumulators START at the bias of the tile's columns (instead of zero + a bias add in the epilogue: 64 VALU adds per lane
   // and tile less, in the one phase where the matrix pipe idles); the next tile's bias is fetched under the last K-step.
   auto load_bias = [&](f32x4 (&bv)[4], int tile) __attribute__((always_inline)) {
@@ -556,7 +559,12 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
   f32x4 acc[4][4];
   {
     f32x4 b0[4];
-    load_bias(b0, my_full > 0 ? toff : half_tile);
+    if (EPI == EPI_DGELU) {                 // a data gradient has no bias
+#pragma unroll
+      for (int i = 0; i < 4; ++i) b0[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      load_bias(b0, my_full > 0 ? toff : half_tile);
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -597,11 +605,27 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
     const bool tile_end = (c_kt == nk - 1);
     READ_FRAGS(wC, aC, c_slot, 1);
     f32x4 bv[4];                           // bias of the NEXT tile (the tail workgroups reload their last tile's: unused)
+    u32x4 pr[8];                           // EPI_DGELU: pre-activation lines of THIS tile
     int n_tile = c_tile;
     if (tile_end) {
       if (!HALF) n_tile = (gs + 1 < S_full) ? c_tile + G : (has_half ? half_tile : c_tile);
       asm volatile("" : "+s"(n_tile));      // keeps the address arithmetic of the bias loads HERE (hoisted, it cost 8 VGPRs for a whole K-step)
-      load_bias(bv, n_tile);
+      if (EPI == EPI_DGELU) {
+        // no bias: its registers (and 16 more) hold THIS tile's eight pre-activation lines per lane instead, requested a whole K-step
+        // before the epilogue multiplies them in -- issued from inside the epilogue, every slab waited out the full memory latency
+        const int m0 = (c_tile / nNt) * PBM + (HALF ? 128 * half_sel : 0) + wm * 64 + (lane_h >> 3);
+        const int n0 = (c_tile % nNt) * PBN + wn * 64 + (lane_h & 7) * 8;
+        const unsigned o0 = ((unsigned)m0 * (unsigned)N + (unsigned)n0) * 2u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {       // slabs 0 and 1 now (the bias registers); slabs 2 and 3 once the last MFMAs have freed their fragments
+          const bool ok = (m0 + 8 * q < M) && (n0 < N);
+          pr[q] = __builtin_amdgcn_raw_buffer_load_b128(orsrc2, ok ? o0 + (unsigned)q * 16u * (unsigned)N : 0x80000000u, 0, 0);   // out of range: zeros
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+        load_bias(bv, n_tile);
+      }
     }
     MFMA_GROUP(wA, aA, 0);
     MFMA_GROUP(wA, aA, 1);
@@ -687,7 +711,28 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
       };
       auto store = [&](int j, const u32x4 (&ln)[2]) __attribute__((always_inline)) { store_(j, ln, false); };
       u32x4 lnA[2], lnB[2];
-      if (EPI == EPI_GELU_KEEP) {
+      if (EPI == EPI_DGELU) {
+        auto scale = [&](u32x4 (&ln)[2], int j) __attribute__((always_inline)) {
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const unsigned int d[4] = {ln[r][0], ln[r][1], ln[r][2], ln[r][3]};
+            const unsigned int x[4] = {pr[2 * j + r][0], pr[2 * j + r][1], pr[2 * j + r][2], pr[2 * j + r][3]};
+            unsigned int o[4];
+            dgelu_line(d, x, o);
+            ln[r] = u32x4{o[0], o[1], o[2], o[3]};
+          }
+        };
+#pragma unroll
+        for (int q = 4; q < 8; ++q) {
+          const bool ok = (m_first + 8 * q < M) && (n < N);
+          pr[q] = __builtin_amdgcn_raw_buffer_load_b128(orsrc2, ok ? off_first + (unsigned)q * off_step : 0x80000000u, 0, 0);
+        }
+        stage(0); read_back(lnA);
+        stage(1); scale(lnA, 0); store(0, lnA); read_back(lnB);
+        stage(2); scale(lnB, 1); store(1, lnB); read_back(lnA);
+        stage(3); scale(lnA, 2); store(2, lnA); read_back(lnB);
+        scale(lnB, 3); store(3, lnB);
+      } else if (EPI == EPI_GELU_KEEP) {
         // every slab passes the stage twice: pre-activation (to outp2), then its GELU (to outp); same one-ahead pipelining
         stage_(0, true); read_back(lnA);
         stage_(0, false); store_(0, lnA, true); read_back(lnB);
@@ -792,6 +837,26 @@ extern "C" int tr_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* b
   }
 #undef TR_LAUNCH
   TR_CHECK_LAUNCH("tr_gemm_bf16");
+  return TR_OK;
+}
+
+// Backward of fc2 -> GELU (timm Mlp): out bf16 [M,N] = bf16(A W^T) * gelu'(pre), pre bf16 [M,N] the pre-activation the training forward
+// kept -- bitwise what tr_gemm_bf16(TR_EPI_BF16, zero bias) followed by tr_gelu_bwd_bf16 produces, in one launch.
+extern "C" int tr_gemm_dgelu_bf16(const uint16_t* A, const uint16_t* W, const uint16_t* pre, uint16_t* out, int M, int N, int K, tr_stream_t s) {
+  TR_REQUIRE(A && W && pre && out, TR_ERR_NULL, "tr_gemm_dgelu_bf16: null pointer");
+  TR_REQUIRE(M > 0 && N > 0 && K > 0 && K % BK == 0 && N % 8 == 0, TR_ERR_SHAPE, "tr_gemm_dgelu_bf16: need K %% %d == 0, N %% 8 == 0 (M=%d N=%d K=%d)", BK, M, N,
+             K);
+  TR_REQUIRE(tr_aligned16(A) && tr_aligned16(W) && tr_aligned16(pre) && tr_aligned16(out), TR_ERR_ALIGN,
+             "tr_gemm_dgelu_bf16: pointers must be 16-byte aligned");
+  const size_t out_bytes = (size_t)M * N * 2;
+  TR_REQUIRE(out_bytes < ((size_t)1 << 31) && (size_t)M * K * 2 < ((size_t)1 << 32) && (size_t)N * K * 2 < ((size_t)1 << 32), TR_ERR_SHAPE,
+             "tr_gemm_dgelu_bf16: operands / outputs beyond the 32-bit offset range");
+  tr_prof_note("gemm_bf16_pc<EPI_DGELU>", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K) + 4.0 * M * N);
+  const int nMt = (M + PBM - 1) / PBM, nNt = (N + PBN - 1) / PBN;
+  hipLaunchKernelGGL(gemm_bf16_pc<EPI_DGELU>, dim3(256), dim3(768), 0, static_cast<hipStream_t>(s), A, W, static_cast<const float*>(nullptr), out,
+                     const_cast<uint16_t*>(pre), M, N, K,
+                     nMt, nNt, (unsigned)out_bytes);
+  TR_CHECK_LAUNCH("tr_gemm_dgelu_bf16");
   return TR_OK;
 }
 

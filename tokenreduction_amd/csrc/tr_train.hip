@@ -187,8 +187,7 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
       gy = dao;
     }
     TR_TRY(tr_linear_bwd_params(gy, D, 0, U(tape + bt.h), Hd, F(bg->fc2_w), F(bg->fc2_b), acc, wsf, wsn, M2, D, Hd, s));
-    TR_TRY(tr_gemm_bf16(gy, U(bwt->fc2_w), zeros, dh, nullptr, 0, M2, Hd, D, TR_EPI_BF16, s));
-    TR_TRY(tr_gelu_bwd_bf16(U(tape + bt.pre), dh, (size_t)M2 * Hd, s));
+    TR_TRY(tr_gemm_dgelu_bf16(gy, U(bwt->fc2_w), U(tape + bt.pre), dh, M2, Hd, D, s));          // d fc2 input, times gelu'(pre): d pre
     TR_TRY(tr_linear_bwd_params(dh, Hd, 0, U(tape + bt.xn2), D, F(bg->fc1_w), F(bg->fc1_b), acc, wsf, wsn, M2, Hd, D, s));
     TR_TRY(tr_gemm_bf16(dh, U(bwt->fc1_w), zeros, dxn, nullptr, 0, M2, D, Hd, TR_EPI_BF16, s));
     // ---- norm2 (+ the block's in-block token reduction)
@@ -307,8 +306,7 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
       TR_TRY(tr_gelu_bwd_bf16(U(tape + bt.ppre2), d2, (size_t)M1 * Q, s));
       TR_TRY(tr_linear_bwd_params(d2, Q, 0, U(tape + bt.ph1), Hh, F(sg->w2), F(sg->b2), acc, wsf, wsn, M1, Cq, Hh, s));
       uint16_t* d1 = dao;                     // [M1, Hh]
-      TR_TRY(tr_gemm_bf16(d2, U(swt->w2), zeros, d1, nullptr, 0, M1, Hh, Q, TR_EPI_BF16, s));
-      TR_TRY(tr_gelu_bwd_bf16(U(tape + bt.ppre1), d1, (size_t)M1 * Hh, s));
+      TR_TRY(tr_gemm_dgelu_bf16(d2, U(swt->w2), U(tape + bt.ppre1), d1, M1, Hh, Q, s));
       TR_TRY(tr_linear_bwd_params(d1, Hh, 0, U(tape + bt.pcat), D, F(sg->w1), F(sg->b1), acc, wsf, wsn, M1, Hh, D, s));
       TR_TRY(tr_gemm_bf16(d1, U(swt->w1), zeros, dxn, nullptr, 0, M1, D, Hh, TR_EPI_BF16, s));          // d [local | global]
       uint16_t* d0 = dh;                      // [M1, D]
@@ -348,8 +346,7 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
         const int Hh = D / 2;
         uint16_t* d1 = dh;                    // [Mp, Hh]
         TR_TRY(tr_linear_bwd_params(ds, ld64, 0, U(tape + bt.pcat), Hh, F(sg->w1), F(sg->b1), acc, wsf, wsn, Mp, ld, Hh, s));
-        TR_TRY(tr_gemm_bf16(ds, U(swt->w1), zeros, d1, nullptr, 0, Mp, Hh, ld64, TR_EPI_BF16, s));
-        TR_TRY(tr_gelu_bwd_bf16(U(tape + bt.ppre0), d1, (size_t)Mp * Hh, s));
+        TR_TRY(tr_gemm_dgelu_bf16(ds, U(swt->w1), U(tape + bt.ppre0), d1, Mp, Hh, ld64, s));
         TR_TRY(tr_linear_bwd_params(d1, Hh, 0, U(tape + bt.pu), D, F(sg->w0), F(sg->b0), acc, wsf, wsn, Mp, Hh, D, s));
         TR_TRY(tr_gemm_bf16(d1, U(swt->w0), zeros, dxn, nullptr, 0, Mp, D, Hh, TR_EPI_BF16, s));
       } else {

@@ -636,3 +636,16 @@ def gemm_gelu_keep(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor):
     _lib.check(_lib.load().tr_gemm_gelu_keep_bf16(_dev(a, torch.bfloat16, "a"), _dev(w, torch.bfloat16, "w"), _dev(bias, torch.float32, "bias"),
                                                   pre.data_ptr(), h.data_ptr(), M, N, K, _stream(a)), "tr_gemm_gelu_keep_bf16")
     return pre, h
+
+
+def gemm_dgelu(a: torch.Tensor, w: torch.Tensor, pre: torch.Tensor) -> torch.Tensor:
+    """Data gradient of a Linear with the GELU backward of the layer below folded in: bf16(a w^T) * gelu'(pre), bf16 [M,N]."""
+    M, K = a.shape
+    N = w.shape[0]
+    if w.dim() != 2 or w.shape[1] != K or tuple(pre.shape) != (M, N):
+        raise ValueError(f"gemm_dgelu: a {tuple(a.shape)}, w {tuple(w.shape)}, pre {tuple(pre.shape)} do not fit")
+    _same_device(a, w, pre)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    _lib.check(_lib.load().tr_gemm_dgelu_bf16(_dev(a, torch.bfloat16, "a"), _dev(w, torch.bfloat16, "w"), _dev(pre, torch.bfloat16, "pre"),
+                                              out.data_ptr(), M, N, K, _stream(a)), "tr_gemm_dgelu_bf16")
+    return out

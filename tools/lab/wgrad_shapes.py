@@ -23,4 +23,16 @@ for label, M, shapes in (("DeiT-S B=256 N=197", 256 * 197, ((1152, 384), (384, 3
         e1.record()
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / 20
-        print(f"{label}: dW[{N:4d},{K:4d}] M={M:6d}: {us:7.1f} us  {2.0 * M * N * K / us / 1e6:6.1f} TFLOP/s")
+        # the vendor library on the same product (bf16 out, no bias sums): comparison only
+        dwl = torch.empty(N, K, device=dev, dtype=torch.bfloat16)
+        for _ in range(3):
+            torch.mm(dy.t(), x, out=dwl)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(20):
+            torch.mm(dy.t(), x, out=dwl)
+        e1.record()
+        torch.cuda.synchronize()
+        usl = e0.elapsed_time(e1) * 1e3 / 20
+        print(f"{label}: dW[{N:4d},{K:4d}] M={M:6d}: {us:7.1f} us  {2.0 * M * N * K / us / 1e6:6.1f} TFLOP/s | library mm(dy.T, x) {usl:7.1f} us "
+              f"{2.0 * M * N * K / usl / 1e6:6.1f} TFLOP/s")
