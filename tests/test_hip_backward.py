@@ -71,6 +71,27 @@ def test_wgrad_exact_integers(ops):
     assert torch.equal(ops.wgrad(dy, x), dy.float().t() @ x.float())
 
 
+@pytest.mark.parametrize("M,N,K", [(200, 192, 384), (64, 384, 192), (65, 192, 192), (1000, 576, 192), (12608, 1152, 384), (50432, 384, 1536)])
+def test_wgrad_exact_integers_producer_consumer_kernel(ops, M, N, K):
+    """N and K multiples of 192 take the LDS-DMA weight-gradient kernel (tr_wgrad_pc.hip): exact integers through its swizzled images and
+    transposed reads, ragged last slabs (rows past M must contribute zero), one slab, many units per workgroup; bias sums from the
+    all-ones MFMA exact as well."""
+    g = torch.Generator().manual_seed(M + N)
+    dy = torch.randint(-2, 3, (M, N), generator=g).to(torch.bfloat16).cuda()
+    x = torch.randint(-2, 3, (M, K), generator=g).to(torch.bfloat16).cuda()
+    want = dy.float().t() @ x.float()
+    assert torch.equal(ops.wgrad(dy, x), want)
+    dw, db = ops.linear_bwd_params(dy, x)
+    assert torch.equal(dw, want)
+    assert torch.equal(db, dy.float().sum(0))
+    # strided operands (column slices of wider tensors, as the executor passes them)
+    wide_y = torch.randint(-2, 3, (M, N + 64), generator=g).to(torch.bfloat16).cuda()
+    wide_x = torch.randint(-2, 3, (M, K + 192), generator=g).to(torch.bfloat16).cuda()
+    dw2, db2 = ops.linear_bwd_params(wide_y[:, :N], wide_x[:, 192:])
+    assert torch.equal(dw2, wide_y[:, :N].float().t() @ wide_x[:, 192:].float())
+    assert torch.equal(db2, wide_y[:, :N].float().sum(0))
+
+
 def test_wgrad_patch_rows(ops):
     """yskip: dY rows are the patch rows of a [B, P+1, D] tensor (PatchEmbed weight gradient)."""
     B, P, D, Kc = 5, 36, 128, 768

@@ -776,9 +776,15 @@ static int wgrad_splits(int M, int N, int K) {
   return best;
 }
 
+// tr_wgrad_pc.hip: the producer/consumer weight-gradient kernel (192 x 192 tiles, LDS-DMA ring) for shapes whose N and K are multiples of 192
+bool tr_wgrad_pc_fits(int M, int N, int K, long ldy, long ldx, int yskip);
+int tr_wgrad_pc_splits(int M, int N, int K);
+int tr_wgrad_pc_launch(const uint16_t* dY, long ldy, const uint16_t* X, long ldx, float* part, float* bpart, int M, int N, int K, int S_max, hipStream_t st);
+
 extern "C" size_t tr_wgrad_workspace_floats(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
-  const int S = wgrad_splits(M, N, K);
+  int S = wgrad_splits(M, N, K);
+  if (tr_wgrad_pc_fits(M, N, K, 8, 8, 0)) S = max(S, tr_wgrad_pc_splits(M, N, K));
   return (size_t)S * N * K + (size_t)S * N;         // weight partials, then the bias partials of tr_linear_bwd_params
 }
 
@@ -797,8 +803,13 @@ extern "C" int tr_wgrad_bf16(const uint16_t* dY, long ldy, int yskip, const uint
   const int sps = (nslab + S - 1) / S;
   S = (nslab + sps - 1) / sps;                 // every split owns at least one slab
   hipStream_t st = static_cast<hipStream_t>(s);
-  tr_prof_note("wgrad_kernel", 2.0 * M * N * K, 2.0 * ((double)M * N + (double)M * K) + 4.0 * S * N * K);
-  hipLaunchKernelGGL(wgrad_kernel<false>, dim3(tiles, S), dim3(256), 0, st, dY, ldy, yskip, X, ldx, ws, static_cast<float*>(nullptr), M, N, K, nNt, sps);
+  if (tr_wgrad_pc_fits(M, N, K, ldy, ldx, yskip)) {
+    tr_prof_note("wgrad_pc_kernel", 2.0 * M * N * K, 2.0 * ((double)M * N + (double)M * K) + 4.0 * S * N * K);
+    S = tr_wgrad_pc_launch(dY, ldy, X, ldx, ws, nullptr, M, N, K, (int)min(fit, (size_t)1 << 20), st);
+  } else {
+    tr_prof_note("wgrad_kernel", 2.0 * M * N * K, 2.0 * ((double)M * N + (double)M * K) + 4.0 * S * N * K);
+    hipLaunchKernelGGL(wgrad_kernel<false>, dim3(tiles, S), dim3(256), 0, st, dY, ldy, yskip, X, ldx, ws, static_cast<float*>(nullptr), M, N, K, nNt, sps);
+  }
   TR_CHECK_LAUNCH("tr_wgrad_bf16");
   reduce_partials(ws, S, (size_t)N * K, dW, accumulate, st);
   TR_CHECK_LAUNCH("tr_wgrad_bf16 (reduce)");
@@ -825,8 +836,16 @@ extern "C" int tr_linear_bwd_params(const uint16_t* dY, long ldy, int yskip, con
   S = (nslab + sps - 1) / sps;
   float* bpart = ws + (size_t)S * N * K;
   hipStream_t st = static_cast<hipStream_t>(s);
-  tr_prof_note("wgrad_kernel", 2.0 * M * N * K, 2.0 * ((double)M * N + (double)M * K) + 4.0 * S * N * K);
-  hipLaunchKernelGGL(wgrad_kernel<true>, dim3(tiles, S), dim3(256), 0, st, dY, ldy, yskip, X, ldx, ws, bpart, M, N, K, nNt, sps);
+  if (tr_wgrad_pc_fits(M, N, K, ldy, ldx, yskip)) {
+    // the bias partials sit behind the weight partials of the LARGEST split count the workspace admits (the launch may pick fewer)
+    const int S_max = (int)min(fit, (size_t)1 << 20);
+    bpart = ws + (size_t)S_max * N * K;
+    tr_prof_note("wgrad_pc_kernel", 2.0 * M * N * K, 2.0 * ((double)M * N + (double)M * K) + 4.0 * S * N * K);
+    S = tr_wgrad_pc_launch(dY, ldy, X, ldx, ws, bpart, M, N, K, S_max, st);
+  } else {
+    tr_prof_note("wgrad_kernel", 2.0 * M * N * K, 2.0 * ((double)M * N + (double)M * K) + 4.0 * S * N * K);
+    hipLaunchKernelGGL(wgrad_kernel<true>, dim3(tiles, S), dim3(256), 0, st, dY, ldy, yskip, X, ldx, ws, bpart, M, N, K, nNt, sps);
+  }
   TR_CHECK_LAUNCH("tr_linear_bwd_params");
   reduce_partials2(ws, (size_t)N * K, dW, bpart, (size_t)N, db, S, accumulate, st);
   TR_CHECK_LAUNCH("tr_linear_bwd_params (reduce)");

@@ -449,6 +449,10 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
   // line is multiplied by gelu'(pre) before it is stored, instead of an elementwise pass over [M, hidden] afterwards
   static_assert(EPI == TR_EPI_BF16 || EPI == TR_EPI_GELU_BF16 || EPI == EPI_GELU_KEEP || EPI == EPI_DGELU, "bf16-output epilogues only");
   __shared__ __attribute__((aligned(16))) unsigned char smem[P_NSTAGE * P_STAGE_BYTES + 8 * 2048];
+#ifdef TR_LAB_STAGGER   // lab only: every other workgroup of an XCD starts late, so that the epilogues (all of a tile's HBM traffic) of one half of the chip fall into the K-loops of the other
+  if ((blockIdx.x >> 3) & 1)
+    for (int i = 0; i < TR_LAB_STAGGER; ++i) __builtin_amdgcn_s_sleep(64);
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nk = K / BK;

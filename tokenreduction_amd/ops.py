@@ -415,7 +415,13 @@ def linear_bwd_params(dy: torch.Tensor, x: torch.Tensor, accumulate: bool = Fals
     dw = torch.empty(N, K, dtype=torch.float32, device=x.device) if dw is None else dw
     db = torch.empty(N, dtype=torch.float32, device=x.device) if db is None else db
     ws = _ws(lib.tr_wgrad_workspace_floats(M, N, K), x.device)
-    _lib.check(lib.tr_linear_bwd_params(_dev(dy, torch.bfloat16, "dy"), N, 0, _dev(x, torch.bfloat16, "x"), K, _dev(dw, torch.float32, "dw"),
+
+    def rows(t, name):      # 2-D operands may be column slices of a wider tensor (unit column stride, any row stride): the C ABI takes ldy / ldx
+        if t.dim() == 2 and t.stride(1) == 1 and t.is_cuda and t.dtype == torch.bfloat16:
+            return t.data_ptr(), t.stride(0)
+        return _dev(t, torch.bfloat16, name), t.shape[-1]
+    (py, ldy), (px, ldx) = rows(dy, "dy"), rows(x, "x")
+    _lib.check(lib.tr_linear_bwd_params(py, ldy, 0, px, ldx, _dev(dw, torch.float32, "dw"),
                                         _dev(db, torch.float32, "db"), int(accumulate), ws.data_ptr(), ws.numel(), M, N, K, _stream()),
                "tr_linear_bwd_params")
     return dw, db
