@@ -275,6 +275,14 @@ int tr_wgrad_bf16(const uint16_t* dY, long ldy, int yskip, const uint16_t* X, lo
  * registers) and one reduce launch; ws as tr_wgrad_bf16. */
 int tr_linear_bwd_params(const uint16_t* dY, long ldy, int yskip, const uint16_t* X, long ldx, float* dW, float* db, int accumulate,
                          float* ws, size_t ws_floats, int M, int N, int K, tr_stream_t s);
+
+/* Parameter gradients of TWO Linear layers at once -- one weight-gradient launch and one reduce launch for both (the backward executor
+ * pairs fc2 + fc1 and proj + qkv of a block; engine.py:76).  Each layer as in tr_linear_bwd_params with yskip = 0; results identical to
+ * two separate calls up to the (fixed, reproducible) summation order over token ranges. */
+size_t tr_linear_bwd_params2_workspace_floats(int M0, int N0, int K0, int M1, int N1, int K1);
+int tr_linear_bwd_params2(const uint16_t* dY0, long ldy0, const uint16_t* X0, long ldx0, float* dW0, float* db0, int M0, int N0, int K0,
+                          const uint16_t* dY1, long ldy1, const uint16_t* X1, long ldx1, float* dW1, float* db1, int M1, int N1, int K1,
+                          int accumulate, float* ws, size_t ws_floats, tr_stream_t s);
 size_t tr_colsum_workspace_floats(int M, int N);
 int tr_colsum_bf16(const uint16_t* dY, long ldy, int yskip, float* db, int accumulate, float* ws, size_t ws_floats, int M, int N,
                    tr_stream_t s);

@@ -465,3 +465,28 @@ def test_gemm_dgelu_is_bitwise_the_two_launch_path(ops, M, N, K):
     got = ops.gemm_dgelu(a, w, pre)
     want = ops.gelu_bwd(pre, ops.gemm(a, w, b, ops.TR_EPI_BF16))
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("shapes", [((50432, 384, 1536), (50432, 1536, 384)), ((24832, 384, 384), (35328, 1152, 384)), ((200, 192, 192), (70, 576, 192)),
+                                    ((12608, 768, 3072), (12608, 3072, 768)), ((300, 128, 256), (300, 384, 192))])
+def test_linear_bwd_params2_pairs_two_layers_in_one_launch(ops, shapes):
+    """Two Linear layers' parameter gradients from one weight-gradient launch: exact on small integers (every unit -> problem -> tile -> token
+    range mapping), different M per layer, accumulate, run-to-run bitwise; a pair the 192-tile kernel does not take falls back to two calls."""
+    (M0, N0, K0), (M1, N1, K1) = shapes
+    g = torch.Generator().manual_seed(M0 + N1)
+    mk = lambda m, n: torch.randint(-2, 3, (m, n), generator=g).to(torch.bfloat16).cuda()
+    dy0, x0, dy1, x1 = mk(M0, N0), mk(M0, K0), mk(M1, N1), mk(M1, K1)
+    (dw0, db0), (dw1, db1) = ops.linear_bwd_params2(dy0, x0, dy1, x1)
+    assert torch.equal(dw0, dy0.float().t() @ x0.float()) and torch.equal(db0, dy0.float().sum(0))
+    assert torch.equal(dw1, dy1.float().t() @ x1.float()) and torch.equal(db1, dy1.float().sum(0))
+    outs = (dw0.clone(), db0.clone(), dw1.clone(), db1.clone())
+    ops.linear_bwd_params2(dy0, x0, dy1, x1, accumulate=True, outs=outs)
+    assert torch.equal(outs[0], 2 * dw0) and torch.equal(outs[3], 2 * db1)
+    # random data: within fp32 summation-order noise of the separate calls, and bitwise reproducible
+    dy0, x0, dy1, x1 = (_randn(60 + i, *t.shape, dtype=torch.bfloat16) for i, t in enumerate((dy0, x0, dy1, x1)))
+    (a0, b0), (a1, b1) = ops.linear_bwd_params2(dy0, x0, dy1, x1)
+    (c0, d0), (c1, d1) = ops.linear_bwd_params(dy0, x0), ops.linear_bwd_params(dy1, x1)
+    for got, want in ((a0, c0), (b0, d0), (a1, c1), (b1, d1)):
+        assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()) + 1e-6
+    again = ops.linear_bwd_params2(dy0, x0, dy1, x1)
+    assert torch.equal(again[0][0], a0) and torch.equal(again[1][0], a1) and torch.equal(again[1][1], b1)

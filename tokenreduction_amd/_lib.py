@@ -101,6 +101,8 @@ SIGNATURES = {
     "tr_wgrad_workspace_floats": (_sz, [_i, _i, _i]),
     "tr_wgrad_bf16": (_i, [_vp, _l, _i, _vp, _l, _vp, _i, _vp, _sz, _i, _i, _i, _vp]),
     "tr_linear_bwd_params": (_i, [_vp, _l, _i, _vp, _l, _vp, _vp, _i, _vp, _sz, _i, _i, _i, _vp]),
+    "tr_linear_bwd_params2_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "tr_linear_bwd_params2": (_i, [_vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "tr_colsum_workspace_floats": (_sz, [_i, _i]),
     "tr_colsum_bf16": (_i, [_vp, _l, _i, _vp, _i, _vp, _sz, _i, _i, _vp]),
     "tr_gelu_bf16": (_i, [_vp, _vp, _sz, _vp]),

@@ -263,6 +263,66 @@ __global__ __launch_bounds__(256) void partial_reduce2_kernel(const float* __res
   *reinterpret_cast<float4*>(dst + e) = a;
 }
 
+// the same for up to FOUR results with their own partial counts (the weight and bias gradients of two Linear layers whose weight
+// gradients ran as one launch): block ranges [0, nb0), [nb0, nb0 + nb1), ...; counts are multiples of 4
+struct RSeg {
+  const float* part;
+  float* dst;
+  size_t count;
+  int S, nb;
+};
+struct RSegs {
+  RSeg s[4];
+};
+__global__ __launch_bounds__(256) void partial_reduce4_kernel(const RSegs segs, int accumulate) {
+  __shared__ float4 red[3][64];
+  int b = blockIdx.x;
+  const int i0 = b >= segs.s[0].nb ? 1 : 0;
+  b -= i0 ? segs.s[0].nb : 0;
+  const int i1 = (i0 && b >= segs.s[1].nb) ? 1 : 0;
+  b -= i1 ? segs.s[1].nb : 0;
+  const int i2 = (i1 && b >= segs.s[2].nb) ? 1 : 0;
+  b -= i2 ? segs.s[2].nb : 0;
+#define RS(f) (i2 ? segs.s[3].f : i1 ? segs.s[2].f : i0 ? segs.s[1].f : segs.s[0].f)
+  const float* part = RS(part);
+  float* dst = RS(dst);
+  const size_t count = RS(count);
+  const int S = RS(S);
+#undef RS
+  const int cx = threadIdx.x & 63, y = threadIdx.x >> 6;
+  const size_t e = ((size_t)b * 64 + cx) * 4;
+  const bool ok = e + 4 <= count;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) {
+    int s = y;
+    for (; s + 12 < S; s += 16) {
+      const float4 v0 = *reinterpret_cast<const float4*>(part + (size_t)s * count + e);
+      const float4 v1 = *reinterpret_cast<const float4*>(part + (size_t)(s + 4) * count + e);
+      const float4 v2 = *reinterpret_cast<const float4*>(part + (size_t)(s + 8) * count + e);
+      const float4 v3 = *reinterpret_cast<const float4*>(part + (size_t)(s + 12) * count + e);
+      a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
+      a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; s < S; s += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(part + (size_t)s * count + e);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  }
+  if (y > 0) red[y - 1][cx] = a;
+  __syncthreads();
+  if (y > 0 || !ok) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+    const float4 v = red[w][cx];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  if (accumulate) {
+    const float4 d = *reinterpret_cast<const float4*>(dst + e);
+    a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+  }
+  *reinterpret_cast<float4*>(dst + e) = a;
+}
+
 // column sums of a bf16 matrix: grid (ceil(N/512), S); thread = 2 adjacent columns; part[s][n]
 __global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* __restrict__ Y, long ldy, int yskip, float* __restrict__ part, int M,
                                                      int N, int rows_per_split) {
@@ -849,6 +909,68 @@ extern "C" int tr_linear_bwd_params(const uint16_t* dY, long ldy, int yskip, con
   TR_CHECK_LAUNCH("tr_linear_bwd_params");
   reduce_partials2(ws, (size_t)N * K, dW, bpart, (size_t)N, db, S, accumulate, st);
   TR_CHECK_LAUNCH("tr_linear_bwd_params (reduce)");
+  return TR_OK;
+}
+
+void tr_wgrad_pc_splits2(int M0, int N0, int K0, int M1, int N1, int K1, int* S0, int* S1);
+void tr_wgrad_pc_launch2(const uint16_t* dY0, long ldy0, const uint16_t* X0, long ldx0, int M0, int N0, int K0, const uint16_t* dY1, long ldy1,
+                         const uint16_t* X1, long ldx1, int M1, int N1, int K1, float* ws, int* S0, int* S1, float** part, float** bpart,
+                         hipStream_t st);
+
+// Parameter gradients of TWO Linear layers in one weight-gradient launch and one reduce launch (the executor pairs fc2 + fc1 and
+// proj + qkv of a block: both dY exist at that point of the backward).  Each layer as in tr_linear_bwd_params (yskip = 0).  Pairs the
+// producer/consumer kernel does not take (N or K not a multiple of 192, a workspace too small) run as two tr_linear_bwd_params calls.
+extern "C" size_t tr_linear_bwd_params2_workspace_floats(int M0, int N0, int K0, int M1, int N1, int K1) {
+  const size_t single = max(tr_wgrad_workspace_floats(M0, N0, K0), tr_wgrad_workspace_floats(M1, N1, K1));
+  if (M0 <= 0 || M1 <= 0 || !tr_wgrad_pc_fits(M0, N0, K0, 8, 8, 0) || !tr_wgrad_pc_fits(M1, N1, K1, 8, 8, 0)) return single;
+  int S0, S1;
+  tr_wgrad_pc_splits2(M0, N0, K0, M1, N1, K1, &S0, &S1);
+  return max(single, (size_t)S0 * ((size_t)N0 * K0 + N0) + (size_t)S1 * ((size_t)N1 * K1 + N1));
+}
+
+extern "C" int tr_linear_bwd_params2(const uint16_t* dY0, long ldy0, const uint16_t* X0, long ldx0, float* dW0, float* db0, int M0, int N0, int K0,
+                                     const uint16_t* dY1, long ldy1, const uint16_t* X1, long ldx1, float* dW1, float* db1, int M1, int N1, int K1,
+                                     int accumulate, float* ws, size_t ws_floats, tr_stream_t s) {
+  TR_REQUIRE(dY0 && X0 && dW0 && db0 && dY1 && X1 && dW1 && db1 && ws, TR_ERR_NULL, "tr_linear_bwd_params2: null pointer");
+  bool paired = M0 > 0 && M1 > 0 && N0 > 0 && N1 > 0 && K0 > 0 && K1 > 0 && tr_wgrad_pc_fits(M0, N0, K0, ldy0, ldx0, 0) &&
+                tr_wgrad_pc_fits(M1, N1, K1, ldy1, ldx1, 0) && ldy0 >= N0 && ldx0 >= K0 && ldy1 >= N1 && ldx1 >= K1;
+  if (paired) {
+    int S0, S1;
+    tr_wgrad_pc_splits2(M0, N0, K0, M1, N1, K1, &S0, &S1);
+    paired = (size_t)S0 * ((size_t)N0 * K0 + N0) + (size_t)S1 * ((size_t)N1 * K1 + N1) <= ws_floats;
+  }
+  if (!paired) {
+    const int rc = tr_linear_bwd_params(dY0, ldy0, 0, X0, ldx0, dW0, db0, accumulate, ws, ws_floats, M0, N0, K0, s);
+    if (rc != TR_OK) return rc;
+    return tr_linear_bwd_params(dY1, ldy1, 0, X1, ldx1, dW1, db1, accumulate, ws, ws_floats, M1, N1, K1, s);
+  }
+  TR_REQUIRE(tr_aligned16(dY0) && tr_aligned16(X0) && tr_aligned16(dW0) && tr_aligned16(db0) && tr_aligned16(dY1) && tr_aligned16(X1) &&
+                 tr_aligned16(dW1) && tr_aligned16(db1) && tr_aligned16(ws),
+             TR_ERR_ALIGN, "tr_linear_bwd_params2: pointers must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(s);
+  int S0, S1;
+  float* part[2];
+  float* bpart[2];
+  tr_prof_note("wgrad_pc_kernel", 2.0 * M0 * N0 * K0 + 2.0 * M1 * N1 * K1,
+               2.0 * ((double)M0 * N0 + (double)M0 * K0 + (double)M1 * N1 + (double)M1 * K1));
+  tr_wgrad_pc_launch2(dY0, ldy0, X0, ldx0, M0, N0, K0, dY1, ldy1, X1, ldx1, M1, N1, K1, ws, &S0, &S1, part, bpart, st);
+  TR_CHECK_LAUNCH("tr_linear_bwd_params2");
+  RSegs segs;
+  const size_t counts[4] = {(size_t)N0 * K0, (size_t)N1 * K1, (size_t)N0, (size_t)N1};
+  const float* parts[4] = {part[0], part[1], bpart[0], bpart[1]};
+  float* dsts[4] = {dW0, dW1, db0, db1};
+  const int Ss[4] = {S0, S1, S0, S1};
+  int nb = 0;
+  for (int i = 0; i < 4; ++i) {
+    segs.s[i].part = parts[i];
+    segs.s[i].dst = dsts[i];
+    segs.s[i].count = counts[i];
+    segs.s[i].S = Ss[i];
+    segs.s[i].nb = (int)((counts[i] / 4 + 63) / 64);
+    nb += segs.s[i].nb;
+  }
+  hipLaunchKernelGGL(partial_reduce4_kernel, dim3(nb), dim3(256), 0, st, segs, accumulate);
+  TR_CHECK_LAUNCH("tr_linear_bwd_params2 (reduce)");
   return TR_OK;
 }
 

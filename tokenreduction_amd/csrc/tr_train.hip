@@ -58,6 +58,12 @@ bool make_bwd_plan(const tr_vit_config* c, int B, const trplan::TokenPlan& t, Bw
     upd(tr_wgrad_workspace_floats((int)T, trplan::soft_ld(soft_k), (int)D));
     upd(tr_token_softmax_bwd_workspace_floats(B, soft_k));
   }
+  for (int i = 0; i < c->depth; ++i) {          // the paired weight-gradient launches of every block, at the block's own token counts
+    const int M1 = B * t.n_att[i], M2 = B * t.n_mlp[i];
+    const int Mp = (c->family == TR_FAMILY_ATS && t.kk[i] > 0) ? M2 : M1;
+    upd(tr_linear_bwd_params2_workspace_floats(M2, (int)D, (int)Hd, M2, (int)Hd, (int)D));
+    upd(tr_linear_bwd_params2_workspace_floats(Mp, (int)D, (int)D, M1, (int)(3 * D), (int)D));
+  }
   p->wsf_floats = f;
   p->wsf = take(f * 4);
   p->dscore = take(T * 4);
@@ -186,9 +192,10 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
       TR_TRY(tr_rowscale_bf16(gb, dao, drop_scale + (size_t)(2 * i + 1) * B, B, Nm, D, s));
       gy = dao;
     }
-    TR_TRY(tr_linear_bwd_params(gy, D, 0, U(tape + bt.h), Hd, F(bg->fc2_w), F(bg->fc2_b), acc, wsf, wsn, M2, D, Hd, s));
     TR_TRY(tr_gemm_dgelu_bf16(gy, U(bwt->fc2_w), U(tape + bt.pre), dh, M2, Hd, D, s));          // d fc2 input, times gelu'(pre): d pre
-    TR_TRY(tr_linear_bwd_params(dh, Hd, 0, U(tape + bt.xn2), D, F(bg->fc1_w), F(bg->fc1_b), acc, wsf, wsn, M2, Hd, D, s));
+    // fc2's and fc1's parameter gradients in one launch: both dY (gy, dh) exist now, and nothing below reads the results
+    TR_TRY(tr_linear_bwd_params2(gy, D, U(tape + bt.h), Hd, F(bg->fc2_w), F(bg->fc2_b), M2, D, Hd, dh, Hd, U(tape + bt.xn2), D, F(bg->fc1_w),
+                                 F(bg->fc1_b), M2, Hd, D, acc, wsf, wsn, s));
     TR_TRY(tr_gemm_bf16(dh, U(bwt->fc1_w), zeros, dxn, nullptr, 0, M2, D, Hd, TR_EPI_BF16, s));
     // ---- norm2 (+ the block's in-block token reduction)
     const float* x2 = reinterpret_cast<const float*>(tape + bt.x2);
@@ -235,7 +242,7 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
       TR_TRY(tr_rowscale_bf16(gb, dh, drop_scale + (size_t)(2 * i) * B, B, Mp / B, D, s));
       gy = dh;
     }
-    TR_TRY(tr_linear_bwd_params(gy, D, 0, U(tape + bt.ao), D, F(bg->proj_w), F(bg->proj_b), acc, wsf, wsn, Mp, D, D, s));
+    const uint16_t* gy_proj = gy;           // proj's dY: stays valid until norm1's backward rewrites gb (ATS: the swapped-out buffer)
     if (ats_sampled) {
       // d(attn @ v) of the sampled rows and the stream's gradient go back to the rows they were sampled from (ats.py:86,157)
       TR_TRY(tr_gemm_bf16(gy, U(bwt->proj_w), zeros, dxn, nullptr, 0, Mp, D, D, TR_EPI_BF16, s));
@@ -268,7 +275,9 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
     } else {
       TR_TRY(tr_attention_bwd_bf16(U(tape + bt.qkv), dao, size_att, dcls, dqkv, B, Na, H, s));
     }
-    TR_TRY(tr_linear_bwd_params(dqkv, 3 * D, 0, U(tape + bt.xn1), D, F(bg->qkv_w), F(bg->qkv_b), acc, wsf, wsn, M1, 3 * D, D, s));
+    // proj's and qkv's parameter gradients in one launch (dY: the branch gradient kept above, and dqkv)
+    TR_TRY(tr_linear_bwd_params2(gy_proj, D, U(tape + bt.ao), D, F(bg->proj_w), F(bg->proj_b), Mp, D, D, dqkv, 3 * D, U(tape + bt.xn1), D,
+                                 F(bg->qkv_w), F(bg->qkv_b), M1, 3 * D, D, acc, wsf, wsn, s));
     TR_TRY(tr_gemm_bf16(dqkv, U(bwt->qkv_w), zeros, dxn, nullptr, 0, M1, D, 3 * D, TR_EPI_BF16, s));
     if (cfg->family == TR_FAMILY_KMEDOIDS && K > 0) {
       // norm1 ran on the gathered medoid rows (kmedoids.py:243-248): its backward scatter-ADDS into the pre-reduction stream's gradient

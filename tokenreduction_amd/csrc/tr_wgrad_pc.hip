@@ -48,23 +48,39 @@ __device__ __forceinline__ void dma_piece(const unsigned char* src, unsigned lds
       : "memory", "m0");
 }
 
-// units: u = split * tiles + tile (split-major: the workgroups of one round share their dY / X slabs in L2), tile = nt * nKt + kt
+// One launch serves up to TWO Linear layers (fc2 + fc1, proj + qkv of a block: their dY are alive together in the backward): the units
+// of both share the 256 workgroups, so each matrix is cut into half as many token ranges -- every launch writes (and the reduce re-reads)
+// 256 x 192 x 192 fp32 partials = 38 MB whatever the matrices are, and that traffic is now paid once per pair.
+struct QProblem {
+  const uint16_t* Y;      // dY [M, ldy]
+  const uint16_t* X;      // X  [M, ldx]
+  float* part;            // [S][N][K]
+  float* bpart;           // [S][N] or nullptr
+  long ldy, ldx;
+  int M, N, K, nKt, tiles, S, sps, u0;      // u0: first unit of this problem; units u0 + split * tiles + tile (split-major: the workgroups of
+};                                          // one round share their dY / X slabs in L2), tile = nt * nKt + kt
+struct QGroup {
+  QProblem p[2];
+  int n, U;
+};
+#define QSEL(pi, f) ((pi) ? grp.p[1].f : grp.p[0].f)      // field-wise selects: indexing the kernel argument dynamically would copy it to scratch
+
 template <bool BIAS>
-__global__ __launch_bounds__(768, 3) void wgrad_pc_kernel(const uint16_t* __restrict__ Y, long ldy, const uint16_t* __restrict__ X, long ldx,
-                                                          float* __restrict__ part, float* __restrict__ bpart, int M, int N, int K, int nKt,
-                                                          int tiles, int S, int sps) {
+__global__ __launch_bounds__(768, 3) void wgrad_pc_kernel(const QGroup grp) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[Q_NSTAGE * Q_STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int G = gridDim.x, bid = blockIdx.x;
-  const int U = tiles * S;
+  const int U = grp.U;
   const int toff = (bid & 7) * (G >> 3) + (bid >> 3);
   const int units = toff < U ? (U - toff + G - 1) / G : 0;
   if (units == 0) return;
-  const int nslab = (M + QM - 1) / QM;
   auto unit_slabs = [&](int u) __attribute__((always_inline)) {
-    const int split = (toff + u * G) / tiles;
-    return min(sps, nslab - split * sps);
+    const int uu = toff + u * G;
+    const int pi = (grp.n > 1 && uu >= grp.p[1].u0) ? 1 : 0;
+    const int split = (uu - QSEL(pi, u0)) / QSEL(pi, tiles);
+    const int sps = QSEL(pi, sps);
+    return min(sps, (QSEL(pi, M) + QM - 1) / QM - split * sps);
   };
   int total = 0;
   for (int u = 0; u < units; ++u) total += unit_slabs(u);
@@ -75,13 +91,24 @@ __global__ __launch_bounds__(768, 3) void wgrad_pc_kernel(const uint16_t* __rest
     const int lw = wave - 8;
     const int prow = lane >> 3, pc = lane & 7;
     int l_unit = 0, l_kt = 0, l_nk = unit_slabs(0), l_slot = 0, l_step = 0;
-    int n0 = 0, k0 = 0, slab0 = 0;
+    int n0 = 0, k0 = 0, slab0 = 0, M = 0;
+    const uint16_t* Y = nullptr;
+    const uint16_t* X = nullptr;
+    long ldy = 0, ldx = 0;
     auto set_unit = [&](int u) __attribute__((always_inline)) {
       const int uu = toff + u * G;
-      const int split = uu / tiles, tile = uu - split * tiles;
+      const int pi = (grp.n > 1 && uu >= grp.p[1].u0) ? 1 : 0;
+      const int tiles = QSEL(pi, tiles), nKt = QSEL(pi, nKt);
+      const int local = uu - QSEL(pi, u0);
+      const int split = local / tiles, tile = local - split * tiles;
       n0 = (tile / nKt) * QT;
       k0 = (tile % nKt) * QT;
-      slab0 = split * sps;
+      slab0 = split * QSEL(pi, sps);
+      M = QSEL(pi, M);
+      Y = QSEL(pi, Y);
+      X = QSEL(pi, X);
+      ldy = QSEL(pi, ldy);
+      ldx = QSEL(pi, ldx);
     };
     const unsigned char* zline = reinterpret_cast<const unsigned char*>(g_zero_line);
     auto issue_group = [&]() __attribute__((always_inline)) {
@@ -180,8 +207,11 @@ __global__ __launch_bounds__(768, 3) void wgrad_pc_kernel(const uint16_t* __rest
   Q_READ(a0, b0, 0, 0);
   while (gs < total) {
     const int uu = toff + c_unit * G;
-    const int split = uu / tiles, tile = uu - split * tiles;
-    const bool do_bias = BIAS && wn == 0 && (tile % nKt) == 0;
+    const int pi = (grp.n > 1 && uu >= grp.p[1].u0) ? 1 : 0;
+    const int tiles = QSEL(pi, tiles), nKt = QSEL(pi, nKt);
+    const int local = uu - QSEL(pi, u0);
+    const int split = local / tiles, tile = local - split * tiles;
+    const bool do_bias = BIAS && wn == 0 && (tile % nKt) == 0 && QSEL(pi, bpart) != nullptr;
     Q_READ(a1, b1, c_slot, 1);
     Q_MFMA(a0, b0);
     if (do_bias) {
@@ -207,7 +237,9 @@ __global__ __launch_bounds__(768, 3) void wgrad_pc_kernel(const uint16_t* __rest
     // ---- the unit's partial: part[split][n][k]; accumulator element r of tile (i, j) = dW row 4 g4 + r, column lane & 15
     {
       const int n0 = (tile / nKt) * QT + wm * 48, k0 = (tile % nKt) * QT + wn * 96;
-      float* po = part + (size_t)split * N * K;
+      const int N = QSEL(pi, N), K = QSEL(pi, K);
+      float* po = QSEL(pi, part) + (size_t)split * N * K;
+      float* bpart = QSEL(pi, bpart);
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -236,6 +268,48 @@ __global__ __launch_bounds__(768, 3) void wgrad_pc_kernel(const uint16_t* __rest
 #undef Q_MFMA
 }
 
+#undef QSEL
+
+// Token ranges per problem for a group: every unit walks at most `sps` slabs; pick the sps whose modelled time is least --
+// rounds of 256 units x (sps slabs at ~900 TFLOP/s per chip + fill and partial store) + partial traffic (written, then re-read by the reduce).
+void plan_group(QGroup* g) {
+  int max_slab = 0;
+  for (int i = 0; i < g->n; ++i) max_slab = max(max_slab, (g->p[i].M + QM - 1) / QM);
+  double best_t = 1e30;
+  int best = max_slab;
+  for (int sps = 1; sps <= max_slab; ++sps) {
+    long U = 0;
+    double traffic = 0.0;
+    for (int i = 0; i < g->n; ++i) {
+      const int nslab = (g->p[i].M + QM - 1) / QM;
+      const int S = (nslab + sps - 1) / sps;
+      U += (long)g->p[i].tiles * S;
+      traffic += 8.0 * S * g->p[i].N * g->p[i].K;
+    }
+    if (U > 2048) continue;
+    const double rounds = (double)((U + 255) / 256);
+    const double t = rounds * (sps * 1.34e-6 + 3.0e-6) + traffic / 4e12;
+    if (t < best_t) { best_t = t; best = sps; }
+  }
+  int u0 = 0;
+  for (int i = 0; i < g->n; ++i) {
+    QProblem& q = g->p[i];
+    const int nslab = (q.M + QM - 1) / QM;
+    const int sps = min(best, nslab);
+    q.S = (nslab + sps - 1) / sps;
+    q.sps = (nslab + q.S - 1) / q.S;            // even ranges; every split owns at least one slab
+    q.S = (nslab + q.sps - 1) / q.sps;
+    q.u0 = u0;
+    u0 += q.tiles * q.S;
+  }
+  g->U = u0;
+}
+
+void fill_problem(QProblem* q, const uint16_t* dY, long ldy, const uint16_t* X, long ldx, int M, int N, int K) {
+  q->Y = dY; q->X = X; q->part = nullptr; q->bpart = nullptr; q->ldy = ldy; q->ldx = ldx;
+  q->M = M; q->N = N; q->K = K; q->nKt = K / QT; q->tiles = (N / QT) * (K / QT); q->S = q->sps = q->u0 = 0;
+}
+
 }  // namespace
 
 // Shapes the producer/consumer kernel takes (everything else stays on wgrad_kernel): both dimensions multiples of 192, plain row layout.
@@ -243,33 +317,66 @@ bool tr_wgrad_pc_fits(int M, int N, int K, long ldy, long ldx, int yskip) {
   return yskip == 0 && N % QT == 0 && K % QT == 0 && ldy % 8 == 0 && ldx % 8 == 0 && M >= QM;
 }
 
-// Token splits: units = tiles x S on 256 persistent workgroups; same cost model as wgrad_splits (tr_backward.hip), one workgroup per CU.
+// Split count a single problem would get (workspace sizing: part[S][N][K] + bpart[S][N]).
 int tr_wgrad_pc_splits(int M, int N, int K) {
-  const int tiles = (N / QT) * (K / QT);
-  const int nslab = (M + QM - 1) / QM;
-  int best = 1;
-  double best_t = 1e30;
-  for (int S = 1; S <= nslab && tiles * S <= 1024; ++S) {
-    const int u = tiles * S;
-    const double eff = (double)u / (double)(((u + 255) / 256) * 256);
-    const double t = 2.0 * M * N * K / (eff * 900e12) + 8.0 * S * N * K / 4e12;
-    if (t < best_t) { best_t = t; best = S; }
-  }
-  return best;
+  QGroup g;
+  g.n = 1;
+  fill_problem(&g.p[0], nullptr, N, nullptr, K, M, N, K);
+  plan_group(&g);
+  return g.p[0].S;
 }
 
-// Launch; returns the number of splits written (part[S][N][K], bpart[S][N] when bpart != nullptr).  S_max: what the workspace holds.
+// Split counts of a pair launched together.
+void tr_wgrad_pc_splits2(int M0, int N0, int K0, int M1, int N1, int K1, int* S0, int* S1) {
+  QGroup g;
+  g.n = 2;
+  fill_problem(&g.p[0], nullptr, N0, nullptr, K0, M0, N0, K0);
+  fill_problem(&g.p[1], nullptr, N1, nullptr, K1, M1, N1, K1);
+  plan_group(&g);
+  *S0 = g.p[0].S;
+  *S1 = g.p[1].S;
+}
+
+// Launch of one problem; returns the number of splits written (part[S][N][K], bpart[S][N] when bpart != nullptr).  S_max: what the
+// workspace holds.
 int tr_wgrad_pc_launch(const uint16_t* dY, long ldy, const uint16_t* X, long ldx, float* part, float* bpart, int M, int N, int K, int S_max,
                        hipStream_t st) {
-  const int nKt = K / QT, tiles = (N / QT) * nKt;
-  const int nslab = (M + QM - 1) / QM;
-  int S = tr_wgrad_pc_splits(M, N, K);
-  if (S > S_max) S = S_max;
-  const int sps = (nslab + S - 1) / S;
-  S = (nslab + sps - 1) / sps;                 // every split owns at least one slab
-  if (bpart != nullptr)
-    hipLaunchKernelGGL(wgrad_pc_kernel<true>, dim3(256), dim3(768), 0, st, dY, ldy, X, ldx, part, bpart, M, N, K, nKt, tiles, S, sps);
-  else
-    hipLaunchKernelGGL(wgrad_pc_kernel<false>, dim3(256), dim3(768), 0, st, dY, ldy, X, ldx, part, bpart, M, N, K, nKt, tiles, S, sps);
-  return S;
+  QGroup g;
+  g.n = 1;
+  fill_problem(&g.p[0], dY, ldy, X, ldx, M, N, K);
+  plan_group(&g);
+  QProblem& q = g.p[0];
+  if (q.S > S_max) {
+    const int nslab = (M + QM - 1) / QM;
+    q.sps = (nslab + S_max - 1) / S_max;
+    q.S = (nslab + q.sps - 1) / q.sps;
+    g.U = q.tiles * q.S;
+  }
+  q.part = part;
+  q.bpart = bpart;
+  g.p[1] = g.p[0];
+  if (bpart != nullptr) hipLaunchKernelGGL(wgrad_pc_kernel<true>, dim3(256), dim3(768), 0, st, g);
+  else hipLaunchKernelGGL(wgrad_pc_kernel<false>, dim3(256), dim3(768), 0, st, g);
+  return q.S;
+}
+
+// Launch of a pair (weight + bias partials of both); ws must hold S0 (N0 K0 + N0) + S1 (N1 K1 + N1) floats for the split counts of
+// tr_wgrad_pc_splits2.  Layout: part0, part1, bpart0, bpart1.
+void tr_wgrad_pc_launch2(const uint16_t* dY0, long ldy0, const uint16_t* X0, long ldx0, int M0, int N0, int K0, const uint16_t* dY1, long ldy1,
+                         const uint16_t* X1, long ldx1, int M1, int N1, int K1, float* ws, int* S0, int* S1, float** part, float** bpart,
+                         hipStream_t st) {
+  QGroup g;
+  g.n = 2;
+  fill_problem(&g.p[0], dY0, ldy0, X0, ldx0, M0, N0, K0);
+  fill_problem(&g.p[1], dY1, ldy1, X1, ldx1, M1, N1, K1);
+  plan_group(&g);
+  g.p[0].part = ws;
+  g.p[1].part = g.p[0].part + (size_t)g.p[0].S * N0 * K0;
+  g.p[0].bpart = g.p[1].part + (size_t)g.p[1].S * N1 * K1;
+  g.p[1].bpart = g.p[0].bpart + (size_t)g.p[0].S * N0;
+  hipLaunchKernelGGL(wgrad_pc_kernel<true>, dim3(256), dim3(768), 0, st, g);
+  *S0 = g.p[0].S;
+  *S1 = g.p[1].S;
+  part[0] = g.p[0].part; part[1] = g.p[1].part;
+  bpart[0] = g.p[0].bpart; bpart[1] = g.p[1].bpart;
 }

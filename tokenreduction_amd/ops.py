@@ -655,3 +655,20 @@ def gemm_dgelu(a: torch.Tensor, w: torch.Tensor, pre: torch.Tensor) -> torch.Ten
     _lib.check(_lib.load().tr_gemm_dgelu_bf16(_dev(a, torch.bfloat16, "a"), _dev(w, torch.bfloat16, "w"), _dev(pre, torch.bfloat16, "pre"),
                                               out.data_ptr(), M, N, K, _stream(a)), "tr_gemm_dgelu_bf16")
     return out
+
+
+def linear_bwd_params2(dy0: torch.Tensor, x0: torch.Tensor, dy1: torch.Tensor, x1: torch.Tensor, accumulate: bool = False, outs=None):
+    """Weight and bias gradients of TWO Linear layers in one weight-gradient launch + one reduce (tr_linear_bwd_params2):
+    ((dW0, db0), (dW1, db1)).  outs: the four destination tensors when accumulating."""
+    lib = _lib.load()
+    (M0, N0), K0 = dy0.shape, x0.shape[-1]
+    (M1, N1), K1 = dy1.shape, x1.shape[-1]
+    dev = x0.device
+    if outs is None:
+        outs = (torch.empty(N0, K0, device=dev), torch.empty(N0, device=dev), torch.empty(N1, K1, device=dev), torch.empty(N1, device=dev))
+    ws = _ws(lib.tr_linear_bwd_params2_workspace_floats(M0, N0, K0, M1, N1, K1), dev)
+    _lib.check(lib.tr_linear_bwd_params2(_dev(dy0, torch.bfloat16, "dy0"), N0, _dev(x0, torch.bfloat16, "x0"), K0, _dev(outs[0], torch.float32, "dw0"),
+                                         _dev(outs[1], torch.float32, "db0"), M0, N0, K0, _dev(dy1, torch.bfloat16, "dy1"), N1,
+                                         _dev(x1, torch.bfloat16, "x1"), K1, _dev(outs[2], torch.float32, "dw1"), _dev(outs[3], torch.float32, "db1"),
+                                         M1, N1, K1, int(accumulate), ws.data_ptr(), ws.numel(), _stream()), "tr_linear_bwd_params2")
+    return (outs[0], outs[1]), (outs[2], outs[3])
