@@ -279,6 +279,16 @@ int tr_linear_bwd_params(const uint16_t* dY, long ldy, int yskip, const uint16_t
 /* Parameter gradients of TWO Linear layers at once -- one weight-gradient launch and one reduce launch for both (the backward executor
  * pairs fc2 + fc1 and proj + qkv of a block; engine.py:76).  Each layer as in tr_linear_bwd_params with yskip = 0; results identical to
  * two separate calls up to the (fixed, reproducible) summation order over token ranges. */
+/* ... and of up to FOUR (what the backward executor does with fc2, fc1, proj and qkv of a block when nothing rewrites their dY in between):
+ * layer i: dW_i [N,K] (+)= dY_i[M, ldy]^T X_i[M, ldx], db_i [N] (+)= column sums of dY_i. */
+typedef struct tr_linear_grad {
+  const uint16_t* dY; long ldy;
+  const uint16_t* X;  long ldx;
+  float* dW; float* db;
+  int M, N, K;
+} tr_linear_grad;
+size_t tr_linear_bwd_group_workspace_floats(const tr_linear_grad* layers, int n);      /* only M, N, K of each layer are read */
+int tr_linear_bwd_group(const tr_linear_grad* layers, int n, int accumulate, float* ws, size_t ws_floats, tr_stream_t s);
 size_t tr_linear_bwd_params2_workspace_floats(int M0, int N0, int K0, int M1, int N1, int K1);
 int tr_linear_bwd_params2(const uint16_t* dY0, long ldy0, const uint16_t* X0, long ldx0, float* dW0, float* db0, int M0, int N0, int K0,
                           const uint16_t* dY1, long ldy1, const uint16_t* X1, long ldx1, float* dW1, float* db1, int M1, int N1, int K1,

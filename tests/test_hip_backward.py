@@ -490,3 +490,32 @@ def test_linear_bwd_params2_pairs_two_layers_in_one_launch(ops, shapes):
         assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()) + 1e-6
     again = ops.linear_bwd_params2(dy0, x0, dy1, x1)
     assert torch.equal(again[0][0], a0) and torch.equal(again[1][0], a1) and torch.equal(again[1][1], b1)
+
+
+@pytest.mark.parametrize("shapes", [[(50432, 384, 1536), (50432, 1536, 384), (50432, 384, 384), (50432, 1152, 384)],
+                                    [(24832, 384, 1536), (24832, 1536, 384), (35328, 384, 384), (35328, 1152, 384)],
+                                    [(200, 192, 192), (70, 576, 192), (64, 192, 384)],
+                                    [(12672, 768, 3072), (12672, 3072, 768), (12672, 768, 768), (25216, 2304, 768)],
+                                    [(300, 128, 256), (300, 384, 192), (300, 192, 192)]])
+def test_linear_bwd_group_up_to_four_layers_in_one_launch(ops, shapes):
+    """The block's four parameter-gradient products from one weight-gradient launch: exact on small integers (unit -> layer -> tile -> token
+    range), layers with different token counts, three layers, a group with a layer the 192-tile kernel does not take (separate calls),
+    accumulate, run-to-run bitwise."""
+    g = torch.Generator().manual_seed(shapes[0][0] + len(shapes))
+    mk = lambda m, n: torch.randint(-2, 3, (m, n), generator=g).to(torch.bfloat16).cuda()
+    layers = [(mk(M, N), mk(M, K)) for M, N, K in shapes]
+    outs = ops.linear_bwd_group(layers)
+    for (dy, x), (dw, db) in zip(layers, outs):
+        assert torch.equal(dw, dy.float().t() @ x.float()) and torch.equal(db, dy.float().sum(0))
+    acc = [(dw.clone(), db.clone()) for dw, db in outs]
+    ops.linear_bwd_group(layers, accumulate=True, outs=acc)
+    for (dw, db), (aw, ab) in zip(outs, acc):
+        assert torch.equal(aw, 2 * dw) and torch.equal(ab, 2 * db)
+    layers = [(_randn(70 + 2 * i, *dy.shape, dtype=torch.bfloat16), _randn(71 + 2 * i, *x.shape, dtype=torch.bfloat16)) for i, (dy, x) in enumerate(layers)]
+    a = ops.linear_bwd_group(layers)
+    for (dy, x), (dw, db) in zip(layers, a):
+        cw, cb = ops.linear_bwd_params(dy, x)
+        assert float((dw - cw).abs().max()) <= 1e-5 * float(cw.abs().max()) + 1e-6
+        assert float((db - cb).abs().max()) <= 1e-5 * float(cb.abs().max()) + 1e-6
+    b = ops.linear_bwd_group(layers)
+    assert all(torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) for x, y in zip(a, b))

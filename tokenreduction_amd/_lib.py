@@ -45,6 +45,10 @@ class TrVitConfig(C.Structure):
                 ("kmed_init", _i * TR_MAX_DEPTH)]
 
 
+class TrLinearGrad(C.Structure):     # tr_linear_grad: one layer of tr_linear_bwd_group
+    _fields_ = [("dY", _vp), ("ldy", _l), ("X", _vp), ("ldx", _l), ("dW", _vp), ("db", _vp), ("M", _i), ("N", _i), ("K", _i)]
+
+
 # every symbol include/tokenreduction_hip.h declares: name -> (restype, argtypes)
 SIGNATURES = {
     "tr_version": (_i, []),
@@ -101,6 +105,8 @@ SIGNATURES = {
     "tr_wgrad_workspace_floats": (_sz, [_i, _i, _i]),
     "tr_wgrad_bf16": (_i, [_vp, _l, _i, _vp, _l, _vp, _i, _vp, _sz, _i, _i, _i, _vp]),
     "tr_linear_bwd_params": (_i, [_vp, _l, _i, _vp, _l, _vp, _vp, _i, _vp, _sz, _i, _i, _i, _vp]),
+    "tr_linear_bwd_group_workspace_floats": (_sz, [_vp, _i]),
+    "tr_linear_bwd_group": (_i, [_vp, _i, _i, _vp, _sz, _vp]),
     "tr_linear_bwd_params2_workspace_floats": (_sz, [_i, _i, _i, _i, _i, _i]),
     "tr_linear_bwd_params2": (_i, [_vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _vp, _l, _vp, _l, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "tr_colsum_workspace_floats": (_sz, [_i, _i]),

@@ -263,8 +263,8 @@ __global__ __launch_bounds__(256) void partial_reduce2_kernel(const float* __res
   *reinterpret_cast<float4*>(dst + e) = a;
 }
 
-// the same for up to FOUR results with their own partial counts (the weight and bias gradients of two Linear layers whose weight
-// gradients ran as one launch): block ranges [0, nb0), [nb0, nb0 + nb1), ...; counts are multiples of 4
+// the same for up to EIGHT results with their own partial counts (the weight and bias gradients of up to four Linear layers whose weight
+// gradients ran as one launch): block ranges [0, nb0), [nb0, nb0 + nb1), ...; counts are multiples of 4; unused segments have nb = 0
 struct RSeg {
   const float* part;
   float* dst;
@@ -272,18 +272,24 @@ struct RSeg {
   int S, nb;
 };
 struct RSegs {
-  RSeg s[4];
+  RSeg s[8];
 };
-__global__ __launch_bounds__(256) void partial_reduce4_kernel(const RSegs segs, int accumulate) {
+template <typename T>
+__device__ __forceinline__ T rsel8(int i, T a, T b, T c, T d, T e, T f, T g, T h) {      // by value (see qsel4 in tr_wgrad_pc.hip)
+  return i >= 4 ? (i >= 6 ? (i == 7 ? h : g) : (i == 5 ? f : e)) : (i >= 2 ? (i == 3 ? d : c) : (i ? b : a));
+}
+__global__ __launch_bounds__(256) void partial_reduce8_kernel(const RSegs segs, int accumulate) {
   __shared__ float4 red[3][64];
-  int b = blockIdx.x;
-  const int i0 = b >= segs.s[0].nb ? 1 : 0;
-  b -= i0 ? segs.s[0].nb : 0;
-  const int i1 = (i0 && b >= segs.s[1].nb) ? 1 : 0;
-  b -= i1 ? segs.s[1].nb : 0;
-  const int i2 = (i1 && b >= segs.s[2].nb) ? 1 : 0;
-  b -= i2 ? segs.s[2].nb : 0;
-#define RS(f) (i2 ? segs.s[3].f : i1 ? segs.s[2].f : i0 ? segs.s[1].f : segs.s[0].f)
+  int b = blockIdx.x, seg = 0;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int nb = segs.s[i].nb;
+    if (seg == i && b >= nb) {
+      b -= nb;
+      seg = i + 1;
+    }
+  }
+#define RS(f) rsel8(seg, segs.s[0].f, segs.s[1].f, segs.s[2].f, segs.s[3].f, segs.s[4].f, segs.s[5].f, segs.s[6].f, segs.s[7].f)
   const float* part = RS(part);
   float* dst = RS(dst);
   const size_t count = RS(count);
@@ -912,66 +918,105 @@ extern "C" int tr_linear_bwd_params(const uint16_t* dY, long ldy, int yskip, con
   return TR_OK;
 }
 
-void tr_wgrad_pc_splits2(int M0, int N0, int K0, int M1, int N1, int K1, int* S0, int* S1);
-void tr_wgrad_pc_launch2(const uint16_t* dY0, long ldy0, const uint16_t* X0, long ldx0, int M0, int N0, int K0, const uint16_t* dY1, long ldy1,
-                         const uint16_t* X1, long ldx1, int M1, int N1, int K1, float* ws, int* S0, int* S1, float** part, float** bpart,
-                         hipStream_t st);
+void tr_wgrad_pc_group_splits(const int (*mnk)[3], int n, int* S);
+void tr_wgrad_pc_group_launch(const uint16_t* const* dY, const long* ldy, const uint16_t* const* X, const long* ldx, const int (*mnk)[3], int n,
+                              float* ws, int* S, float** part, float** bpart, hipStream_t st);
 
-// Parameter gradients of TWO Linear layers in one weight-gradient launch and one reduce launch (the executor pairs fc2 + fc1 and
-// proj + qkv of a block: both dY exist at that point of the backward).  Each layer as in tr_linear_bwd_params (yskip = 0).  Pairs the
-// producer/consumer kernel does not take (N or K not a multiple of 192, a workspace too small) run as two tr_linear_bwd_params calls.
+// Parameter gradients of up to FOUR Linear layers in one weight-gradient launch and one reduce launch (the executor hands over fc2, fc1,
+// proj and qkv of a block together, or pairs of them).  Each layer as in tr_linear_bwd_params (yskip = 0).  Groups the producer/consumer
+// kernel does not take (an N or K that is not a multiple of 192, a workspace too small) run as separate tr_linear_bwd_params calls.
+static bool group_fits(const tr_linear_grad* L, int n) {
+  for (int i = 0; i < n; ++i)
+    if (L[i].M <= 0 || L[i].N <= 0 || L[i].K <= 0 || !tr_wgrad_pc_fits(L[i].M, L[i].N, L[i].K, L[i].ldy, L[i].ldx, 0) || L[i].ldy < L[i].N ||
+        L[i].ldx < L[i].K)
+      return false;
+  return true;
+}
+
+static size_t group_floats(const tr_linear_grad* L, int n, int* S) {
+  int mnk[4][3];
+  for (int i = 0; i < n; ++i) { mnk[i][0] = L[i].M; mnk[i][1] = L[i].N; mnk[i][2] = L[i].K; }
+  tr_wgrad_pc_group_splits(mnk, n, S);
+  size_t f = 0;
+  for (int i = 0; i < n; ++i) f += (size_t)S[i] * ((size_t)L[i].N * L[i].K + L[i].N);
+  return f;
+}
+
+extern "C" size_t tr_linear_bwd_group_workspace_floats(const tr_linear_grad* layers, int n) {
+  if (!layers || n < 1 || n > 4) return 0;
+  size_t single = 0;
+  for (int i = 0; i < n; ++i) single = max(single, tr_wgrad_workspace_floats(layers[i].M, layers[i].N, layers[i].K));
+  tr_linear_grad plain[4];
+  for (int i = 0; i < n; ++i) { plain[i] = layers[i]; plain[i].ldy = layers[i].N; plain[i].ldx = layers[i].K; }
+  if (!group_fits(plain, n)) return single;
+  int S[4];
+  return max(single, group_floats(plain, n, S));
+}
+
+extern "C" int tr_linear_bwd_group(const tr_linear_grad* layers, int n, int accumulate, float* ws, size_t ws_floats, tr_stream_t s) {
+  TR_REQUIRE(layers && ws && n >= 1 && n <= 4, TR_ERR_NULL, "tr_linear_bwd_group: need 1..4 layers and a workspace");
+  for (int i = 0; i < n; ++i)
+    TR_REQUIRE(layers[i].dY && layers[i].X && layers[i].dW && layers[i].db, TR_ERR_NULL, "tr_linear_bwd_group: null pointer in layer %d", i);
+  int S[4];
+  bool grouped = n > 1 && group_fits(layers, n);
+  if (grouped) grouped = group_floats(layers, n, S) <= ws_floats;
+  if (!grouped) {
+    for (int i = 0; i < n; ++i) {
+      const tr_linear_grad& L = layers[i];
+      const int rc = tr_linear_bwd_params(L.dY, L.ldy, 0, L.X, L.ldx, L.dW, L.db, accumulate, ws, ws_floats, L.M, L.N, L.K, s);
+      if (rc != TR_OK) return rc;
+    }
+    return TR_OK;
+  }
+  const uint16_t* dY[4];
+  const uint16_t* X[4];
+  long ldy[4], ldx[4];
+  int mnk[4][3];
+  double flops = 0.0, bytes = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const tr_linear_grad& L = layers[i];
+    TR_REQUIRE(tr_aligned16(L.dY) && tr_aligned16(L.X) && tr_aligned16(L.dW) && tr_aligned16(L.db), TR_ERR_ALIGN,
+               "tr_linear_bwd_group: pointers of layer %d must be 16-byte aligned", i);
+    dY[i] = L.dY; X[i] = L.X; ldy[i] = L.ldy; ldx[i] = L.ldx;
+    mnk[i][0] = L.M; mnk[i][1] = L.N; mnk[i][2] = L.K;
+    flops += 2.0 * L.M * L.N * L.K;
+    bytes += 2.0 * ((double)L.M * L.N + (double)L.M * L.K);
+  }
+  TR_REQUIRE(tr_aligned16(ws), TR_ERR_ALIGN, "tr_linear_bwd_group: workspace must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(s);
+  float* part[4];
+  float* bpart[4];
+  tr_prof_note("wgrad_pc_kernel", flops, bytes);
+  tr_wgrad_pc_group_launch(dY, ldy, X, ldx, mnk, n, ws, S, part, bpart, st);
+  TR_CHECK_LAUNCH("tr_linear_bwd_group");
+  RSegs segs;
+  int nb = 0;
+  for (int i = 0; i < 8; ++i) {
+    const int l = i & 3, bias = i >> 2;        // segments: dW of layers 0..3, then db of layers 0..3
+    RSeg& g = segs.s[i];
+    if (l >= n) { g.part = nullptr; g.dst = nullptr; g.count = 0; g.S = 0; g.nb = 0; continue; }
+    g.part = bias ? bpart[l] : part[l];
+    g.dst = bias ? layers[l].db : layers[l].dW;
+    g.count = bias ? (size_t)layers[l].N : (size_t)layers[l].N * layers[l].K;
+    g.S = S[l];
+    g.nb = (int)((g.count / 4 + 63) / 64);
+    nb += g.nb;
+  }
+  hipLaunchKernelGGL(partial_reduce8_kernel, dim3(nb), dim3(256), 0, st, segs, accumulate);
+  TR_CHECK_LAUNCH("tr_linear_bwd_group (reduce)");
+  return TR_OK;
+}
+
 extern "C" size_t tr_linear_bwd_params2_workspace_floats(int M0, int N0, int K0, int M1, int N1, int K1) {
-  const size_t single = max(tr_wgrad_workspace_floats(M0, N0, K0), tr_wgrad_workspace_floats(M1, N1, K1));
-  if (M0 <= 0 || M1 <= 0 || !tr_wgrad_pc_fits(M0, N0, K0, 8, 8, 0) || !tr_wgrad_pc_fits(M1, N1, K1, 8, 8, 0)) return single;
-  int S0, S1;
-  tr_wgrad_pc_splits2(M0, N0, K0, M1, N1, K1, &S0, &S1);
-  return max(single, (size_t)S0 * ((size_t)N0 * K0 + N0) + (size_t)S1 * ((size_t)N1 * K1 + N1));
+  const tr_linear_grad L[2] = {{nullptr, N0, nullptr, K0, nullptr, nullptr, M0, N0, K0}, {nullptr, N1, nullptr, K1, nullptr, nullptr, M1, N1, K1}};
+  return tr_linear_bwd_group_workspace_floats(L, 2);
 }
 
 extern "C" int tr_linear_bwd_params2(const uint16_t* dY0, long ldy0, const uint16_t* X0, long ldx0, float* dW0, float* db0, int M0, int N0, int K0,
                                      const uint16_t* dY1, long ldy1, const uint16_t* X1, long ldx1, float* dW1, float* db1, int M1, int N1, int K1,
                                      int accumulate, float* ws, size_t ws_floats, tr_stream_t s) {
-  TR_REQUIRE(dY0 && X0 && dW0 && db0 && dY1 && X1 && dW1 && db1 && ws, TR_ERR_NULL, "tr_linear_bwd_params2: null pointer");
-  bool paired = M0 > 0 && M1 > 0 && N0 > 0 && N1 > 0 && K0 > 0 && K1 > 0 && tr_wgrad_pc_fits(M0, N0, K0, ldy0, ldx0, 0) &&
-                tr_wgrad_pc_fits(M1, N1, K1, ldy1, ldx1, 0) && ldy0 >= N0 && ldx0 >= K0 && ldy1 >= N1 && ldx1 >= K1;
-  if (paired) {
-    int S0, S1;
-    tr_wgrad_pc_splits2(M0, N0, K0, M1, N1, K1, &S0, &S1);
-    paired = (size_t)S0 * ((size_t)N0 * K0 + N0) + (size_t)S1 * ((size_t)N1 * K1 + N1) <= ws_floats;
-  }
-  if (!paired) {
-    const int rc = tr_linear_bwd_params(dY0, ldy0, 0, X0, ldx0, dW0, db0, accumulate, ws, ws_floats, M0, N0, K0, s);
-    if (rc != TR_OK) return rc;
-    return tr_linear_bwd_params(dY1, ldy1, 0, X1, ldx1, dW1, db1, accumulate, ws, ws_floats, M1, N1, K1, s);
-  }
-  TR_REQUIRE(tr_aligned16(dY0) && tr_aligned16(X0) && tr_aligned16(dW0) && tr_aligned16(db0) && tr_aligned16(dY1) && tr_aligned16(X1) &&
-                 tr_aligned16(dW1) && tr_aligned16(db1) && tr_aligned16(ws),
-             TR_ERR_ALIGN, "tr_linear_bwd_params2: pointers must be 16-byte aligned");
-  hipStream_t st = static_cast<hipStream_t>(s);
-  int S0, S1;
-  float* part[2];
-  float* bpart[2];
-  tr_prof_note("wgrad_pc_kernel", 2.0 * M0 * N0 * K0 + 2.0 * M1 * N1 * K1,
-               2.0 * ((double)M0 * N0 + (double)M0 * K0 + (double)M1 * N1 + (double)M1 * K1));
-  tr_wgrad_pc_launch2(dY0, ldy0, X0, ldx0, M0, N0, K0, dY1, ldy1, X1, ldx1, M1, N1, K1, ws, &S0, &S1, part, bpart, st);
-  TR_CHECK_LAUNCH("tr_linear_bwd_params2");
-  RSegs segs;
-  const size_t counts[4] = {(size_t)N0 * K0, (size_t)N1 * K1, (size_t)N0, (size_t)N1};
-  const float* parts[4] = {part[0], part[1], bpart[0], bpart[1]};
-  float* dsts[4] = {dW0, dW1, db0, db1};
-  const int Ss[4] = {S0, S1, S0, S1};
-  int nb = 0;
-  for (int i = 0; i < 4; ++i) {
-    segs.s[i].part = parts[i];
-    segs.s[i].dst = dsts[i];
-    segs.s[i].count = counts[i];
-    segs.s[i].S = Ss[i];
-    segs.s[i].nb = (int)((counts[i] / 4 + 63) / 64);
-    nb += segs.s[i].nb;
-  }
-  hipLaunchKernelGGL(partial_reduce4_kernel, dim3(nb), dim3(256), 0, st, segs, accumulate);
-  TR_CHECK_LAUNCH("tr_linear_bwd_params2 (reduce)");
-  return TR_OK;
+  const tr_linear_grad L[2] = {{dY0, ldy0, X0, ldx0, dW0, db0, M0, N0, K0}, {dY1, ldy1, X1, ldx1, dW1, db1, M1, N1, K1}};
+  return tr_linear_bwd_group(L, 2, accumulate, ws, ws_floats, s);
 }
 
 extern "C" size_t tr_colsum_workspace_floats(int M, int N) {

@@ -17,7 +17,7 @@ using trplan::align_up;
 namespace {
 
 struct BwdPlan {
-  size_t g0, g1, gb0, gb1, dxn, dqkv, dao, dh, zeros, wsf, dscore, gfused, invmap, dxcls, dl16, dpol, dprev, dpolpart, soft_dp, soft_ds, soft_s, attn_stats, total;
+  size_t g0, g1, gb0, gb1, gb2, dxn, dqkv, dao, dh, zeros, wsf, dscore, gfused, invmap, dxcls, dl16, dpol, dprev, dpolpart, soft_dp, soft_ds, soft_s, attn_stats, total;
   size_t wsf_floats;
 };
 
@@ -30,6 +30,7 @@ bool make_bwd_plan(const tr_vit_config* c, int B, const trplan::TokenPlan& t, Bw
   p->g1 = take(T * D * 4);
   p->gb0 = take(T * D * 2);
   p->gb1 = take(T * D * 2);
+  p->gb2 = take(T * D * 2);          // spare: keeps fc2's dY alive past norm2's backward (the block's four weight gradients run as one launch)
   p->dxn = take(T * D * 2);
   p->dqkv = take(T * 3 * D * 2);
   p->dao = take(T * D * 2);
@@ -63,6 +64,11 @@ bool make_bwd_plan(const tr_vit_config* c, int B, const trplan::TokenPlan& t, Bw
     const int Mp = (c->family == TR_FAMILY_ATS && t.kk[i] > 0) ? M2 : M1;
     upd(tr_linear_bwd_params2_workspace_floats(M2, (int)D, (int)Hd, M2, (int)Hd, (int)D));
     upd(tr_linear_bwd_params2_workspace_floats(Mp, (int)D, (int)D, M1, (int)(3 * D), (int)D));
+    const tr_linear_grad four[4] = {{nullptr, (long)D, nullptr, (long)Hd, nullptr, nullptr, M2, (int)D, (int)Hd},
+                                    {nullptr, (long)Hd, nullptr, (long)D, nullptr, nullptr, M2, (int)Hd, (int)D},
+                                    {nullptr, (long)D, nullptr, (long)D, nullptr, nullptr, Mp, (int)D, (int)D},
+                                    {nullptr, (long)(3 * D), nullptr, (long)D, nullptr, nullptr, M1, (int)(3 * D), (int)D}};
+    upd(tr_linear_bwd_group_workspace_floats(four, 4));
   }
   p->wsf_floats = f;
   p->wsf = take(f * 4);
@@ -150,12 +156,24 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
   const size_t wsn = bp.wsf_floats;
   const int acc = accumulate ? 1 : 0;
 
-  // which of the two stream-gradient buffers is current at block blk_hi: they swap at every block that reduces tokens
-  for (int j = cfg->depth - 1; j > blk_hi; --j)
+  uint16_t* gb_spare = reinterpret_cast<uint16_t*>(ws + bp.gb2);
+  // The four parameter-gradient products of a block (fc2, fc1, proj, qkv) run as ONE launch after the attention backward, when all four dY
+  // exist -- provided nothing has rewritten fc2's dY (the bf16 stream gradient gb) by then: norm2's backward writes its bf16 output into the
+  // spare buffer instead and the two trade places.  With DropPath the scaled dY copies live in scratch that is reused: pairs then.
+  const bool four = drop_scale == nullptr;
+  auto plain_ln2 = [&](int j) {      // blocks whose norm2 backward writes gb in place (no gather / merge between norm2 and the stream)
+    const bool gathers = (cfg->family == TR_FAMILY_TOPK || cfg->family == TR_FAMILY_EVIT || cfg->family == TR_FAMILY_TOME) && t.kk[j] > 0;
+    return !gathers;
+  };
+  // which stream-gradient buffers are current at block blk_hi: replay the pointer moves of the blocks above (per block: the spare rotation
+  // of norm2's backward first, then the swap of a token-reducing block)
+  for (int j = cfg->depth - 1; j > blk_hi; --j) {
+    if (four && plain_ln2(j)) { uint16_t* tb = gb; gb = gb_spare; gb_spare = tb; }
     if (t.kk[j] > 0 && cfg->family != TR_FAMILY_DYVIT) {          // every token-reducing block of the built families swaps once
       float* tg = g; g = g_alt; g_alt = tg;
       uint16_t* tb = gb; gb = gb_alt; gb_alt = tb;
     }
+  }
   if (blk_hi == cfg->depth - 1) {
     size_t zmax = (size_t)(3 * D > Hd ? 3 * D : Hd);
     if ((size_t)kcols > zmax) zmax = kcols;
@@ -193,9 +211,11 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
       gy = dao;
     }
     TR_TRY(tr_gemm_dgelu_bf16(gy, U(bwt->fc2_w), U(tape + bt.pre), dh, M2, Hd, D, s));          // d fc2 input, times gelu'(pre): d pre
-    // fc2's and fc1's parameter gradients in one launch: both dY (gy, dh) exist now, and nothing below reads the results
-    TR_TRY(tr_linear_bwd_params2(gy, D, U(tape + bt.h), Hd, F(bg->fc2_w), F(bg->fc2_b), M2, D, Hd, dh, Hd, U(tape + bt.xn2), D, F(bg->fc1_w),
-                                 F(bg->fc1_b), M2, Hd, D, acc, wsf, wsn, s));
+    // fc2's and fc1's parameter gradients: both dY (gy, dh) exist now; launched here as a pair, or with proj's and qkv's further down
+    tr_linear_grad LG[4];
+    LG[0] = {gy, (long)D, U(tape + bt.h), (long)Hd, F(bg->fc2_w), F(bg->fc2_b), M2, D, Hd};
+    LG[1] = {dh, (long)Hd, U(tape + bt.xn2), (long)D, F(bg->fc1_w), F(bg->fc1_b), M2, Hd, D};
+    if (!four) TR_TRY(tr_linear_bwd_group(LG, 2, acc, wsf, wsn, s));
     TR_TRY(tr_gemm_bf16(dh, U(bwt->fc1_w), zeros, dxn, nullptr, 0, M2, D, Hd, TR_EPI_BF16, s));
     // ---- norm2 (+ the block's in-block token reduction)
     const float* x2 = reinterpret_cast<const float*>(tape + bt.x2);
@@ -231,8 +251,9 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
       float* tg = g; g = g_alt; g_alt = tg;
       uint16_t* tb = gb; gb = gb_alt; gb_alt = tb;
     } else {
-      TR_TRY(tr_layernorm_bwd(dxn, x2, D, bw->ln2_g, g, D, g, D, gb, nullptr, 0, 0, 0, nullptr, F(bg->ln2_g), F(bg->ln2_b), acc, wsf, wsn, M2, D,
-                              cfg->ln_eps, s));
+      TR_TRY(tr_layernorm_bwd(dxn, x2, D, bw->ln2_g, g, D, g, D, four ? gb_spare : gb, nullptr, 0, 0, 0, nullptr, F(bg->ln2_g), F(bg->ln2_b), acc, wsf,
+                              wsn, M2, D, cfg->ln_eps, s));
+      if (four) { uint16_t* tb = gb; gb = gb_spare; gb_spare = tb; }       // gb_spare: fc2's dY, until this block's weight-gradient launch
     }
     // ---- attention: x1 -> norm1 -> qkv -> softmax(q k^T) v -> proj -> (+ residual)
     const bool ats_sampled = cfg->family == TR_FAMILY_ATS && K > 0;
@@ -275,9 +296,11 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
     } else {
       TR_TRY(tr_attention_bwd_bf16(U(tape + bt.qkv), dao, size_att, dcls, dqkv, B, Na, H, s));
     }
-    // proj's and qkv's parameter gradients in one launch (dY: the branch gradient kept above, and dqkv)
-    TR_TRY(tr_linear_bwd_params2(gy_proj, D, U(tape + bt.ao), D, F(bg->proj_w), F(bg->proj_b), Mp, D, D, dqkv, 3 * D, U(tape + bt.xn1), D,
-                                 F(bg->qkv_w), F(bg->qkv_b), M1, 3 * D, D, acc, wsf, wsn, s));
+    // the block's parameter gradients (dY: the branch gradients kept above, dh and dqkv): one launch for all four, or the second pair
+    LG[2] = {gy_proj, (long)D, U(tape + bt.ao), (long)D, F(bg->proj_w), F(bg->proj_b), Mp, D, D};
+    LG[3] = {dqkv, (long)(3 * D), U(tape + bt.xn1), (long)D, F(bg->qkv_w), F(bg->qkv_b), M1, 3 * D, D};
+    if (four) TR_TRY(tr_linear_bwd_group(LG, 4, acc, wsf, wsn, s));
+    else TR_TRY(tr_linear_bwd_group(LG + 2, 2, acc, wsf, wsn, s));
     TR_TRY(tr_gemm_bf16(dqkv, U(bwt->qkv_w), zeros, dxn, nullptr, 0, M1, D, 3 * D, TR_EPI_BF16, s));
     if (cfg->family == TR_FAMILY_KMEDOIDS && K > 0) {
       // norm1 ran on the gathered medoid rows (kmedoids.py:243-248): its backward scatter-ADDS into the pre-reduction stream's gradient

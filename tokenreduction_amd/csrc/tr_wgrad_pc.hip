@@ -48,9 +48,9 @@ __device__ __forceinline__ void dma_piece(const unsigned char* src, unsigned lds
       : "memory", "m0");
 }
 
-// One launch serves up to TWO Linear layers (fc2 + fc1, proj + qkv of a block: their dY are alive together in the backward): the units
-// of both share the 256 workgroups, so each matrix is cut into half as many token ranges -- every launch writes (and the reduce re-reads)
-// 256 x 192 x 192 fp32 partials = 38 MB whatever the matrices are, and that traffic is now paid once per pair.
+// One launch serves up to FOUR Linear layers (the executor hands over fc2, fc1, proj and qkv of a block together): their units share the
+// 256 workgroups, so each matrix is cut into a quarter as many token ranges -- every launch writes (and the reduce re-reads)
+// 256 x 192 x 192 fp32 partials = 38 MB whatever the matrices are, and that traffic is now paid once per block instead of four times.
 struct QProblem {
   const uint16_t* Y;      // dY [M, ldy]
   const uint16_t* X;      // X  [M, ldx]
@@ -60,24 +60,31 @@ struct QProblem {
   int M, N, K, nKt, tiles, S, sps, u0;      // u0: first unit of this problem; units u0 + split * tiles + tile (split-major: the workgroups of
 };                                          // one round share their dY / X slabs in L2), tile = nt * nKt + kt
 struct QGroup {
-  QProblem p[2];
+  QProblem p[4];          // unused entries: u0 = INT_MAX
   int n, U;
 };
-#define QSEL(pi, f) ((pi) ? grp.p[1].f : grp.p[0].f)      // field-wise selects: indexing the kernel argument dynamically would copy it to scratch
+// field-wise selects: indexing the kernel argument dynamically would copy it to scratch
+// (a conditional expression on two struct fields is an LVALUE in C++: the compiler selected between addresses and, to be able to, kept a
+// 360-byte private copy of the arguments in scratch.  qsel4 takes the four candidates BY VALUE -- four static scalar loads and selects.)
+template <typename T>
+__device__ __forceinline__ T qsel4(int pi, T a, T b, T c, T d) {
+  return pi >= 2 ? (pi == 3 ? d : c) : (pi ? b : a);
+}
+#define QSEL(pi, f) qsel4(pi, q0.f, q1.f, q2.f, q3.f)
+#define QPROB(uu) (((uu) >= q1.u0 ? 1 : 0) + ((uu) >= q2.u0 ? 1 : 0) + ((uu) >= q3.u0 ? 1 : 0))
 
 template <bool BIAS>
-__global__ __launch_bounds__(768, 3) void wgrad_pc_kernel(const QGroup grp) {
+__global__ __launch_bounds__(768, 3) void wgrad_pc_kernel(const QProblem q0, const QProblem q1, const QProblem q2, const QProblem q3, const int U) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[Q_NSTAGE * Q_STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int G = gridDim.x, bid = blockIdx.x;
-  const int U = grp.U;
   const int toff = (bid & 7) * (G >> 3) + (bid >> 3);
   const int units = toff < U ? (U - toff + G - 1) / G : 0;
   if (units == 0) return;
   auto unit_slabs = [&](int u) __attribute__((always_inline)) {
     const int uu = toff + u * G;
-    const int pi = (grp.n > 1 && uu >= grp.p[1].u0) ? 1 : 0;
+    const int pi = __builtin_amdgcn_readfirstlane(QPROB(uu));
     const int split = (uu - QSEL(pi, u0)) / QSEL(pi, tiles);
     const int sps = QSEL(pi, sps);
     return min(sps, (QSEL(pi, M) + QM - 1) / QM - split * sps);
@@ -97,7 +104,7 @@ __global__ __launch_bounds__(768, 3) void wgrad_pc_kernel(const QGroup grp) {
     long ldy = 0, ldx = 0;
     auto set_unit = [&](int u) __attribute__((always_inline)) {
       const int uu = toff + u * G;
-      const int pi = (grp.n > 1 && uu >= grp.p[1].u0) ? 1 : 0;
+      const int pi = __builtin_amdgcn_readfirstlane(QPROB(uu));
       const int tiles = QSEL(pi, tiles), nKt = QSEL(pi, nKt);
       const int local = uu - QSEL(pi, u0);
       const int split = local / tiles, tile = local - split * tiles;
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(768, 3) void wgrad_pc_kernel(const QGroup grp) {
     const unsigned char* zline = reinterpret_cast<const unsigned char*>(g_zero_line);
     auto issue_group = [&]() __attribute__((always_inline)) {
       const bool real = l_step < total;
-      const unsigned dst = lds0 + l_slot * Q_STAGE + lw * 2048;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + l_slot * Q_STAGE + lw * 2048);
       const int tok0 = (slab0 + l_kt) * QM + lw * 16 + prow;
 #pragma unroll
       for (int jj = 0; jj < 2; ++jj) {
@@ -205,13 +212,22 @@ __global__ __launch_bounds__(768, 3) void wgrad_pc_kernel(const QGroup grp) {
   __builtin_amdgcn_s_barrier();            // B_0
   asm volatile("" ::: "memory");
   Q_READ(a0, b0, 0, 0);
-  while (gs < total) {
-    const int uu = toff + c_unit * G;
-    const int pi = (grp.n > 1 && uu >= grp.p[1].u0) ? 1 : 0;
+  // the current unit, decoded once per unit (two integer divisions and a dozen selects: per K-step they cost a quarter of the kernel)
+  int pi = 0, split = 0, tn = 0, tk = 0;
+  bool do_bias = false;
+  auto decode_unit = [&](int u) __attribute__((always_inline)) {
+    const int uu = toff + u * G;
+    pi = __builtin_amdgcn_readfirstlane(QPROB(uu));
     const int tiles = QSEL(pi, tiles), nKt = QSEL(pi, nKt);
     const int local = uu - QSEL(pi, u0);
-    const int split = local / tiles, tile = local - split * tiles;
-    const bool do_bias = BIAS && wn == 0 && (tile % nKt) == 0 && QSEL(pi, bpart) != nullptr;
+    split = local / tiles;
+    const int tile = local - split * tiles;
+    tn = tile / nKt;
+    tk = tile - tn * nKt;
+    do_bias = BIAS && wn == 0 && tk == 0 && QSEL(pi, bpart) != nullptr;
+  };
+  decode_unit(0);
+  while (gs < total) {
     Q_READ(a1, b1, c_slot, 1);
     Q_MFMA(a0, b0);
     if (do_bias) {
@@ -236,7 +252,7 @@ __global__ __launch_bounds__(768, 3) void wgrad_pc_kernel(const QGroup grp) {
     if (++c_kt < c_nk) continue;
     // ---- the unit's partial: part[split][n][k]; accumulator element r of tile (i, j) = dW row 4 g4 + r, column lane & 15
     {
-      const int n0 = (tile / nKt) * QT + wm * 48, k0 = (tile % nKt) * QT + wn * 96;
+      const int n0 = tn * QT + wm * 48, k0 = tk * QT + wn * 96;
       const int N = QSEL(pi, N), K = QSEL(pi, K);
       float* po = QSEL(pi, part) + (size_t)split * N * K;
       float* bpart = QSEL(pi, bpart);
@@ -262,13 +278,17 @@ __global__ __launch_bounds__(768, 3) void wgrad_pc_kernel(const QGroup grp) {
     }
     c_kt = 0;
     ++c_unit;
-    if (gs < total) c_nk = unit_slabs(c_unit);
+    if (gs < total) {
+      c_nk = unit_slabs(c_unit);
+      decode_unit(c_unit);
+    }
   }
 #undef Q_READ
 #undef Q_MFMA
 }
 
 #undef QSEL
+#undef QPROB
 
 // Token ranges per problem for a group: every unit walks at most `sps` slabs; pick the sps whose modelled time is least --
 // rounds of 256 units x (sps slabs at ~900 TFLOP/s per chip + fill and partial store) + partial traffic (written, then re-read by the reduce).
@@ -326,15 +346,20 @@ int tr_wgrad_pc_splits(int M, int N, int K) {
   return g.p[0].S;
 }
 
-// Split counts of a pair launched together.
-void tr_wgrad_pc_splits2(int M0, int N0, int K0, int M1, int N1, int K1, int* S0, int* S1) {
+// Split counts of n <= 4 problems launched together; mnk[i] = {M, N, K}.
+void tr_wgrad_pc_group_splits(const int (*mnk)[3], int n, int* S) {
   QGroup g;
-  g.n = 2;
-  fill_problem(&g.p[0], nullptr, N0, nullptr, K0, M0, N0, K0);
-  fill_problem(&g.p[1], nullptr, N1, nullptr, K1, M1, N1, K1);
+  g.n = n;
+  for (int i = 0; i < n; ++i) fill_problem(&g.p[i], nullptr, mnk[i][1], nullptr, mnk[i][2], mnk[i][0], mnk[i][1], mnk[i][2]);
   plan_group(&g);
-  *S0 = g.p[0].S;
-  *S1 = g.p[1].S;
+  for (int i = 0; i < n; ++i) S[i] = g.p[i].S;
+}
+
+static void pad_group(QGroup* g) {
+  for (int i = g->n; i < 4; ++i) {
+    g->p[i] = g->p[0];
+    g->p[i].u0 = 0x7fffffff;
+  }
 }
 
 // Launch of one problem; returns the number of splits written (part[S][N][K], bpart[S][N] when bpart != nullptr).  S_max: what the
@@ -354,29 +379,34 @@ int tr_wgrad_pc_launch(const uint16_t* dY, long ldy, const uint16_t* X, long ldx
   }
   q.part = part;
   q.bpart = bpart;
-  g.p[1] = g.p[0];
-  if (bpart != nullptr) hipLaunchKernelGGL(wgrad_pc_kernel<true>, dim3(256), dim3(768), 0, st, g);
-  else hipLaunchKernelGGL(wgrad_pc_kernel<false>, dim3(256), dim3(768), 0, st, g);
+  pad_group(&g);
+  if (bpart != nullptr) hipLaunchKernelGGL(wgrad_pc_kernel<true>, dim3(256), dim3(768), 0, st, g.p[0], g.p[1], g.p[2], g.p[3], g.U);
+  else hipLaunchKernelGGL(wgrad_pc_kernel<false>, dim3(256), dim3(768), 0, st, g.p[0], g.p[1], g.p[2], g.p[3], g.U);
   return q.S;
 }
 
-// Launch of a pair (weight + bias partials of both); ws must hold S0 (N0 K0 + N0) + S1 (N1 K1 + N1) floats for the split counts of
-// tr_wgrad_pc_splits2.  Layout: part0, part1, bpart0, bpart1.
-void tr_wgrad_pc_launch2(const uint16_t* dY0, long ldy0, const uint16_t* X0, long ldx0, int M0, int N0, int K0, const uint16_t* dY1, long ldy1,
-                         const uint16_t* X1, long ldx1, int M1, int N1, int K1, float* ws, int* S0, int* S1, float** part, float** bpart,
-                         hipStream_t st) {
+// Launch of n <= 4 problems (weight + bias partials of all); ws must hold sum_i S_i (N_i K_i + N_i) floats for the split counts of
+// tr_wgrad_pc_group_splits.  Layout: part_0 .. part_{n-1}, bpart_0 .. bpart_{n-1}.
+void tr_wgrad_pc_group_launch(const uint16_t* const* dY, const long* ldy, const uint16_t* const* X, const long* ldx, const int (*mnk)[3], int n,
+                              float* ws, int* S, float** part, float** bpart, hipStream_t st) {
   QGroup g;
-  g.n = 2;
-  fill_problem(&g.p[0], dY0, ldy0, X0, ldx0, M0, N0, K0);
-  fill_problem(&g.p[1], dY1, ldy1, X1, ldx1, M1, N1, K1);
+  g.n = n;
+  for (int i = 0; i < n; ++i) fill_problem(&g.p[i], dY[i], ldy[i], X[i], ldx[i], mnk[i][0], mnk[i][1], mnk[i][2]);
   plan_group(&g);
-  g.p[0].part = ws;
-  g.p[1].part = g.p[0].part + (size_t)g.p[0].S * N0 * K0;
-  g.p[0].bpart = g.p[1].part + (size_t)g.p[1].S * N1 * K1;
-  g.p[1].bpart = g.p[0].bpart + (size_t)g.p[0].S * N0;
-  hipLaunchKernelGGL(wgrad_pc_kernel<true>, dim3(256), dim3(768), 0, st, g);
-  *S0 = g.p[0].S;
-  *S1 = g.p[1].S;
-  part[0] = g.p[0].part; part[1] = g.p[1].part;
-  bpart[0] = g.p[0].bpart; bpart[1] = g.p[1].bpart;
+  float* at = ws;
+  for (int i = 0; i < n; ++i) {
+    g.p[i].part = at;
+    at += (size_t)g.p[i].S * g.p[i].N * g.p[i].K;
+  }
+  for (int i = 0; i < n; ++i) {
+    g.p[i].bpart = at;
+    at += (size_t)g.p[i].S * g.p[i].N;
+  }
+  for (int i = 0; i < n; ++i) {
+    S[i] = g.p[i].S;
+    part[i] = g.p[i].part;
+    bpart[i] = g.p[i].bpart;
+  }
+  pad_group(&g);
+  hipLaunchKernelGGL(wgrad_pc_kernel<true>, dim3(256), dim3(768), 0, st, g.p[0], g.p[1], g.p[2], g.p[3], g.U);
 }

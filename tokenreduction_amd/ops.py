@@ -672,3 +672,26 @@ def linear_bwd_params2(dy0: torch.Tensor, x0: torch.Tensor, dy1: torch.Tensor, x
                                          _dev(x1, torch.bfloat16, "x1"), K1, _dev(outs[2], torch.float32, "dw1"), _dev(outs[3], torch.float32, "db1"),
                                          M1, N1, K1, int(accumulate), ws.data_ptr(), ws.numel(), _stream()), "tr_linear_bwd_params2")
     return (outs[0], outs[1]), (outs[2], outs[3])
+
+
+def linear_bwd_group(layers, accumulate: bool = False, outs=None):
+    """Weight and bias gradients of up to four Linear layers in ONE weight-gradient launch + one reduce (tr_linear_bwd_group).
+    layers: [(dy bf16 [M_i, N_i], x bf16 [M_i, K_i]), ...]; returns [(dW_i fp32 [N_i, K_i], db_i fp32 [N_i]), ...]; outs: the same list
+    of destination tensors when accumulating."""
+    import ctypes
+    lib = _lib.load()
+    n = len(layers)
+    if not 1 <= n <= 4:
+        raise ValueError("linear_bwd_group: 1..4 layers")
+    dev = layers[0][0].device
+    if outs is None:
+        outs = [(torch.empty(dy.shape[1], x.shape[1], device=dev), torch.empty(dy.shape[1], device=dev)) for dy, x in layers]
+    arr = (_lib.TrLinearGrad * n)()
+    for i, ((dy, x), (dw, db)) in enumerate(zip(layers, outs)):
+        if dy.shape[0] != x.shape[0] or tuple(dw.shape) != (dy.shape[1], x.shape[1]) or db.numel() != dy.shape[1]:
+            raise ValueError(f"linear_bwd_group: layer {i}: dy {tuple(dy.shape)}, x {tuple(x.shape)}, dw {tuple(dw.shape)}, db {tuple(db.shape)} do not fit")
+        arr[i] = _lib.TrLinearGrad(_dev(dy, torch.bfloat16, "dy"), dy.shape[1], _dev(x, torch.bfloat16, "x"), x.shape[1], _dev(dw, torch.float32, "dw"),
+                                   _dev(db, torch.float32, "db"), dy.shape[0], dy.shape[1], x.shape[1])
+    ws = _ws(lib.tr_linear_bwd_group_workspace_floats(ctypes.cast(arr, ctypes.c_void_p), n), dev)
+    _lib.check(lib.tr_linear_bwd_group(ctypes.cast(arr, ctypes.c_void_p), n, int(accumulate), ws.data_ptr(), ws.numel(), _stream()), "tr_linear_bwd_group")
+    return outs
