@@ -263,6 +263,52 @@ __global__ __launch_bounds__(256) void partial_reduce2_kernel(const float* __res
   *reinterpret_cast<float4*>(dst + e) = a;
 }
 
+// TALL variant of the two-result reduce: few elements (a LayerNorm's d_gamma / d_beta: D each), many partials (one per workgroup of the
+// producing kernel: 512).  Block = 16 float4 chunks x 16 partial-lanes: lane y sums partials y, y + 16, ... four loads in flight, the
+// sixteen lane sums are added in lane order (fixed).  With the 64 x 4 layout above the same job was 4 workgroups walking 128 partials each
+// in 32 dependent round trips: 13 us, 26 times per training step.
+__global__ __launch_bounds__(256) void partial_reduce2_tall_kernel(const float* __restrict__ part0, size_t count0, float* __restrict__ dst0,
+                                                                   const float* __restrict__ part1, size_t count1, float* __restrict__ dst1,
+                                                                   int S, int nb0, int accumulate) {
+  __shared__ float4 red[15][16];
+  const bool second = (int)blockIdx.x >= nb0;
+  const float* part = second ? part1 : part0;
+  const size_t count = second ? count1 : count0;
+  float* dst = second ? dst1 : dst0;
+  const int cx = threadIdx.x & 15, y = threadIdx.x >> 4;
+  const size_t e = ((size_t)(second ? blockIdx.x - nb0 : blockIdx.x) * 16 + cx) * 4;
+  const bool ok = e + 4 <= count;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) {
+    int s = y;
+    for (; s + 48 < S; s += 64) {
+      const float4 v0 = *reinterpret_cast<const float4*>(part + (size_t)s * count + e);
+      const float4 v1 = *reinterpret_cast<const float4*>(part + (size_t)(s + 16) * count + e);
+      const float4 v2 = *reinterpret_cast<const float4*>(part + (size_t)(s + 32) * count + e);
+      const float4 v3 = *reinterpret_cast<const float4*>(part + (size_t)(s + 48) * count + e);
+      a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
+      a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; s < S; s += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(part + (size_t)s * count + e);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  }
+  if (y > 0) red[y - 1][cx] = a;
+  __syncthreads();
+  if (y > 0 || !ok) return;
+#pragma unroll
+  for (int w = 0; w < 15; ++w) {
+    const float4 v = red[w][cx];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  if (accumulate) {
+    const float4 d = *reinterpret_cast<const float4*>(dst + e);
+    a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+  }
+  *reinterpret_cast<float4*>(dst + e) = a;
+}
+
 // the same for up to EIGHT results with their own partial counts (the weight and bias gradients of up to four Linear layers whose weight
 // gradients ran as one launch): block ranges [0, nb0), [nb0, nb0 + nb1), ...; counts are multiples of 4; unused segments have nb = 0
 struct RSeg {
@@ -818,6 +864,11 @@ inline int reduce_partials(const float* part, int S, size_t count, float* dst, i
 }
 
 inline void reduce_partials2(const float* p0, size_t c0, float* d0, const float* p1, size_t c1, float* d1, int S, int accumulate, hipStream_t st) {
+  if (S >= 64 && c0 <= 4096 && c1 <= 4096) {        // many partials of short vectors: spread the partials over the lanes
+    const int nb0 = (int)((c0 / 4 + 15) / 16), nb1 = (int)((c1 / 4 + 15) / 16);
+    hipLaunchKernelGGL(partial_reduce2_tall_kernel, dim3(nb0 + nb1), dim3(256), 0, st, p0, c0, d0, p1, c1, d1, S, nb0, accumulate);
+    return;
+  }
   const int nb0 = (int)((c0 / 4 + 63) / 64), nb1 = (int)((c1 / 4 + 63) / 64);
   hipLaunchKernelGGL(partial_reduce2_kernel, dim3(nb0 + nb1), dim3(256), 0, st, p0, c0, d0, p1, c1, d1, S, nb0, accumulate);
 }
