@@ -363,7 +363,7 @@ int tr_head_sum(const float* part, float* dst, int B, int H, int N, tr_stream_t 
 int tr_fill_f32(float* p, float v, size_t n, tr_stream_t s);
 int tr_add_patch_rows(float* dst, const float* src, int B, int N, tr_stream_t s);
 /* DPC-KNN CTM backward (merge_tokens dpcknn.py:103-132 + the score Linear, CTM.forward :155-157): see csrc/tr_backward.hip.
- * ws: (B+1)*(D+4) floats.  tr_ats_scatter: backward of ATS's row sampling (ats.py:86,157): valid sampled rows t go back to row
+ * ws: at least (B+1)*(D+4) floats; with (8B+1)*(D+4) eight workgroups share an image.  tr_ats_scatter: backward of ATS's row sampling (ats.py:86,157): valid sampled rows t go back to row
  * ids[b,t] of the zero-filled full tensors (g fp32 [B,Ks,D] -> [B,N,D]; d(attn @ v) bf16 likewise). */
 int tr_cluster_merge_bwd(const float* g_in, const float* x0, const float* x1, const float* wtok, const int32_t* assign,
                          const float* score_w, float* g_out, uint16_t* gb_out, float* d_sw, float* d_sb, int accumulate, float* ws,

@@ -706,6 +706,8 @@ __global__ __launch_bounds__(256) void cluster_merge_bwd_kernel(const float* __r
                                                                 const int32_t* __restrict__ assign, const float* __restrict__ sw,
                                                                 float* __restrict__ g_out, uint16_t* __restrict__ gb_out,
                                                                 float* __restrict__ part, int N, int K, int D) {
+  // grid (B, SPLIT): the SPLIT workgroups of an image take its tokens round robin (one per image left half of the CUs idle at B = 128 and
+  // walked 49 dependent row gathers per wave: 112 us at DeiT-B); each recomputes the cluster weights, each writes its own d sw / d sb partial
   __shared__ float sW[640];          // summed token weight of every cluster (K <= 640: 384 x 384 inputs at keep_rate 0.9 have 518)
   __shared__ float4 red[3][64 * NCH];
   __shared__ float redb[4];
@@ -713,10 +715,26 @@ __global__ __launch_bounds__(256) void cluster_merge_bwd_kernel(const float* __r
   const int P = N - 1, nchunks = D >> 2;
   const bool weighted = sw != nullptr;
   const int32_t* as = assign + (size_t)b * P;
+  // cluster weights, summed in token order (fixed): assignments and token weights staged in LDS first when they fit (every built input
+  // size: P <= 576) -- walking them in global memory, one dependent branch per token, was half of this kernel once the tokens were split
+  __shared__ int sA[640];
+  __shared__ float sT[640];
+  const bool staged = P <= 640;
+  if (staged) {
+    for (int i = threadIdx.x; i < P; i += 256) {
+      sA[i] = as[i];
+      sT[i] = weighted ? wtok[(size_t)b * P + i] : 1.0f;
+    }
+    __syncthreads();
+  }
   for (int c = threadIdx.x; c < K; c += 256) {
     float a = 0.f;
-    for (int i = 0; i < P; ++i)
-      if (as[i] == c) a += weighted ? wtok[(size_t)b * P + i] : 1.0f;
+    if (staged) {
+      for (int i = 0; i < P; ++i) a += sA[i] == c ? sT[i] : 0.f;
+    } else {
+      for (int i = 0; i < P; ++i)
+        if (as[i] == c) a += weighted ? wtok[(size_t)b * P + i] : 1.0f;
+    }
     sW[c] = a + 1e-6f;
   }
   __syncthreads();
@@ -727,7 +745,7 @@ __global__ __launch_bounds__(256) void cluster_merge_bwd_kernel(const float* __r
     acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   float accb = 0.f;
-  if (wave == 0) {      // CLS row passes through
+  if (wave == 0 && blockIdx.y == 0) {      // CLS row passes through
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int ch = lane + 64 * c;
@@ -741,7 +759,7 @@ __global__ __launch_bounds__(256) void cluster_merge_bwd_kernel(const float* __r
       }
     }
   }
-  for (int i = wave; i < P; i += 4) {
+  for (int i = blockIdx.y * 4 + wave; i < P; i += 4 * gridDim.y) {
     const int c = as[i];
     const float wi = weighted ? wtok[(size_t)b * P + i] : 1.0f;
     const float iw = 1.0f / sW[c];
@@ -795,12 +813,12 @@ __global__ __launch_bounds__(256) void cluster_merge_bwd_kernel(const float* __r
           const float4 v = red[w][ch];
           a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
-        *reinterpret_cast<float4*>(part + (size_t)b * (D + 4) + 4 * ch) = a;
+        *reinterpret_cast<float4*>(part + ((size_t)b * gridDim.y + blockIdx.y) * (D + 4) + 4 * ch) = a;
       }
     }
     if (lane == 0) {
       float4 bs = make_float4((redb[0] + redb[1]) + (redb[2] + redb[3]), 0.f, 0.f, 0.f);
-      *reinterpret_cast<float4*>(part + (size_t)b * (D + 4) + D) = bs;
+      *reinterpret_cast<float4*>(part + ((size_t)b * gridDim.y + blockIdx.y) * (D + 4) + D) = bs;
     }
   }
 }
@@ -1244,14 +1262,17 @@ extern "C" int tr_cluster_merge_bwd(const float* g_in, const float* x0, const fl
              "tr_cluster_merge_bwd: bad shape B=%d N=%d K=%d D=%d (K <= 640)", B, N, K, D);
   TR_REQUIRE(ws_floats >= (size_t)B * (D + 4), TR_ERR_SHAPE, "tr_cluster_merge_bwd: workspace too small");
   hipStream_t st = static_cast<hipStream_t>(s);
-  TR_DISPATCH_NCH(D, hipLaunchKernelGGL((cluster_merge_bwd_kernel<NCH>), dim3(B), dim3(256), 0, st, g_in, x0, x1, wtok, assign, score_w, g_out, gb_out,
-                                        ws, N, K, D));
+  // workgroups per image: as many as the workspace holds partials for (8 with (8 B + 1)(D + 4) floats), while B x split stays near the chip
+  int split = 8;
+  while (split > 1 && (ws_floats < ((size_t)B * split + 1) * (D + 4) || B * split > 2048)) split >>= 1;
+  TR_DISPATCH_NCH(D, hipLaunchKernelGGL((cluster_merge_bwd_kernel<NCH>), dim3(B, split), dim3(256), 0, st, g_in, x0, x1, wtok, assign, score_w, g_out,
+                                        gb_out, ws, N, K, D));
   TR_CHECK_LAUNCH("tr_cluster_merge_bwd");
   if (score_w != nullptr) {
     // partial rows are [d_sw (D) | d_sb, 0, 0, 0]: reduce them as one vector of D+4 into a scratch tail, then split
-    float* tail = ws + (size_t)B * (D + 4);
-    TR_REQUIRE(ws_floats >= (size_t)(B + 1) * (D + 4), TR_ERR_SHAPE, "tr_cluster_merge_bwd: workspace too small");
-    reduce_partials(ws, B, (size_t)D + 4, tail, 0, st);
+    float* tail = ws + (size_t)B * split * (D + 4);
+    TR_REQUIRE(ws_floats >= ((size_t)B * split + 1) * (D + 4), TR_ERR_SHAPE, "tr_cluster_merge_bwd: workspace too small");
+    reduce_partials(ws, B * split, (size_t)D + 4, tail, 0, st);
     reduce_partials(tail, 1, (size_t)D, d_sw, accumulate, st);
     reduce_partials(tail + D, 1, (size_t)1, d_sb, accumulate, st);
     TR_CHECK_LAUNCH("tr_cluster_merge_bwd (reduce)");

@@ -49,7 +49,7 @@ bool make_bwd_plan(const tr_vit_config* c, int B, const trplan::TokenPlan& t, Bw
   upd(tr_colsum_workspace_floats((int)T, (int)Hd));
   upd(tr_layernorm_bwd_workspace_floats((int)T, (int)D));
   upd(tr_wgrad_workspace_floats(B, c->num_classes, (int)D));
-  upd((size_t)(B + 1) * (D + 4));
+  upd((size_t)(8 * B + 1) * (D + 4));          // tr_cluster_merge_bwd: eight workgroups per image
   upd(tr_dyvit_decide_bwd_workspace_floats(B, t.N0, (int)(D / 4)));
   upd(tr_wgrad_workspace_floats((int)T, (int)(D / 2), (int)D));
   int soft_k = 0;                    // soft-assignment families: the widest stage

@@ -551,7 +551,7 @@ def cluster_merge_bwd(g_in, x0, x1, wtok, assign, score_w):
     gb = torch.empty(B, N, D, dtype=torch.bfloat16, device=x0.device)
     dsw = torch.empty(D, dtype=torch.float32, device=x0.device) if score_w is not None else None
     dsb = torch.empty(1, dtype=torch.float32, device=x0.device) if score_w is not None else None
-    ws = _ws((B + 1) * (D + 4), x0.device)
+    ws = _ws((8 * B + 1) * (D + 4), x0.device)
     _lib.check(lib.tr_cluster_merge_bwd(_dev(g_in, torch.float32, "g_in"), _dev(x0, torch.float32, "x0"), _dev(x1, torch.float32, "x1"),
                                         _opt(wtok, torch.float32, "wtok"), _dev(assign, torch.int32, "assign"), _opt(score_w, torch.float32, "score_w"),
                                         g.data_ptr(), gb.data_ptr(), None if dsw is None else dsw.data_ptr(), None if dsb is None else dsb.data_ptr(),
