@@ -36,7 +36,8 @@ def build_model(name=MODEL, keep_rate=KEEP_RATE, loc=REDUCTION_LOC, device="cuda
     import tokenreduction_amd as tra
     torch.manual_seed(0)
     args = types.SimpleNamespace(keep_rate=list(keep_rate), reduction_loc=list(loc), dyvit_distill=False, k_neighbors=5,
-                                 equal_weight=False, cluster_iters=3, sinkhorn_eps=1.0)
+                                 equal_weight=False, cluster_iters=3, sinkhorn_eps=1.0, heuristic_pattern="l2", not_contiguous=False,
+                                 min_radius=None)
     m = tra.create_model(name, pretrained=False, num_classes=1000, drop_rate=0.0, drop_path_rate=0.0,
                          drop_block_rate=None, img_size=img_size, args=args)
     with torch.no_grad():                       # "peaky" attention so the Top-K sees a realistic score spread

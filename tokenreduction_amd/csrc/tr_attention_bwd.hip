@@ -39,7 +39,7 @@ __device__ __forceinline__ int pswz(int row, int ch) { return row * 512 + ((ch ^
 //   e = exp(s - max), a = e * pi (pi[q][k] = policy[k], 1 on the diagonal), p = (a + eps/N) / (sum a + eps), eps = 1e-6;
 //   with w = dp - sum_k p_k dp_k:  ds = w * a / (sum a + eps),  d policy[k] += w * e / (sum a + eps) over all queries q != k and all
 //   heads (the straight-through Gumbel sample upstream makes the policy differentiable, dyvit.py:223-224).  The per-key sums are
-//   LDS float atomics (order varies run to run at the 1e-7 level), written per (image, head) to dpol_part [B,H,N].
+//   accumulated in registers and combined in a fixed order, written per (image, head) to dpol_part [B,H,N].
 template <int NKB, bool BIAS, bool POLICY>
 __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dO,
                                                                const float* __restrict__ size, const float* __restrict__ dcls,
@@ -54,7 +54,11 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const uint16_t* _
   __shared__ __attribute__((aligned(16))) unsigned char sP[64 * 512];
   __shared__ __attribute__((aligned(16))) unsigned char sDS[64 * 512];
   __shared__ __attribute__((aligned(16))) float sLB[NP];     // log2(size[key]) (ToMe / key masks), 0 without sizes
-  __shared__ __attribute__((aligned(16))) float sDC[NP];     // d cls_attn[key] / H (EViT), 0 otherwise; POLICY: the d policy[key] sums
+  __shared__ __attribute__((aligned(16))) float sDC[NP];     // d cls_attn[key] / H (EViT), 0 otherwise
+  // POLICY: d policy[key], one row per wave (its 16 query columns of every block, reduced over the lanes before they are added: a single
+  // lane owns each entry, so plain read-modify-write in a fixed order).  As LDS float atomics straight from every lane -- sixteen lanes of
+  // a quarter wave on one address, N^2 atomics per head -- this sum made the policy variant 3x the plain kernel (601 vs 196 us at N = 197).
+  __shared__ float sPol[POLICY ? 4 * NP : 1];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
@@ -87,6 +91,7 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const uint16_t* _
       if (POLICY) {
         sLB[key] = key < N ? size[(size_t)b * N + key] : 0.f;
         sDC[key] = 0.f;
+        sPol[key] = sPol[NP + key] = sPol[2 * NP + key] = sPol[3 * NP + key] = 0.f;
       } else {
         sLB[key] = (BIAS && key < N) ? __builtin_amdgcn_logf(size[(size_t)b * N + key]) : 0.f;     // v_log_f32 = log2
         sDC[key] = (dcls != nullptr && key < N) ? dcls[(size_t)b * N + key] / (float)H : 0.f;
@@ -231,7 +236,9 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const uint16_t* _
           const float en = sacc[jt][r] * inv;             // e / (sum a + eps)
           pv[r] = key < N ? en * pi + padd * inv : 0.f;
           dsv[r] = w * en * pi * 0.125f;
-          if (key != iq && key < N && iq < N) atomicAdd(&sDC[key], w * en);
+          float dp = (key != iq && key < N && iq < N) ? w * en : 0.f;       // summed over this wave's 16 query columns (lanes li)
+          dp = row16_sum(dp);
+          if (li == 0) sPol[wave * NP + key] += dp;
         } else {
           pv[r] = sacc[jt][r];
           dsv[r] = sacc[jt][r] * w * 0.125f;
@@ -302,8 +309,10 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const uint16_t* _
     }
   }
   if (POLICY) {
+    // the four waves' rows, added in wave order
     __syncthreads();
-    for (int key = tid; key < N; key += 256) dpol_part[((size_t)b * H + h) * N + key] = sDC[key];
+    for (int key = tid; key < N; key += 256)
+      dpol_part[((size_t)b * H + h) * N + key] = (sPol[key] + sPol[NP + key]) + (sPol[2 * NP + key] + sPol[3 * NP + key]);
   }
   // ---- dK, dV rows: accumulator (t, d): rows d-index 16d + 4g + r, column key 16*(wave + 4t) + li
 #pragma unroll

@@ -87,6 +87,16 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// sum over the 16 lanes of a DPP row (lanes with equal lane >> 4), result in every lane: quad butterfly, half-row mirror, row mirror --
+// four full-rate v_add_f32_dpp (a __shfl_xor is a ds_bpermute on gfx9: LDS pipe, and that pipe feeds the MFMA operands)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));    // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));    // row_mirror
+  return v;
+}
+
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
 // GELU(x) = x * Phi(x) (the exact-erf form nn.GELU() computes) with Phi(x) ~= sigmoid(a1 x + a3 x^3 + a5 x^5), a minimax fit

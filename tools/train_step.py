@@ -24,7 +24,8 @@ for i in range(steps + 2):
     if i == 2:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-    loss = torch.nn.functional.cross_entropy(model(x), y)
+    out = model(x)
+    loss = torch.nn.functional.cross_entropy(out[0] if isinstance(out, tuple) else out, y)      # DyViT returns its train tuple (dyvit.py:257-261)
     opt.zero_grad(set_to_none=True)
     loss.backward()
     opt.step()
