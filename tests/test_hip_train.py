@@ -189,14 +189,21 @@ def test_unsupported_configuration_raises_in_train_mode():
             model.train()(x)
 
 
-def test_gradient_reducer_on_rccl_world1():
+@pytest.mark.parametrize("name", ["evit_micro", "ats_micro", "tome_micro", "kmedoids_micro", "sit_micro", "dpcknn_micro", "deit_micro"])
+def test_gradient_reducer_on_rccl_world1(name):
     """The data-parallel path on RCCL with one rank (the GPU box has one GPU): the backward runs in per-bucket block ranges, each
     bucket is reduce-scattered + all-gathered in place on the side stream; with world size 1 the mean is the identity, so the
-    gradients must equal the plain single-call backward bit for bit."""
+    gradients must equal the plain single-call backward bit for bit -- for every way a block moves the stream-gradient buffers
+    (gather / merge swaps, the spare rotation of norm2's backward, ATS's scatter, K-Medoids' scatter-add, none): a range call has to
+    find the buffers where the previous range left them."""
     import torch.distributed as dist
     from tokenreduction_amd.dp import FlatGradReducer
-    case = GOLDEN_CASES["evit_micro"]
-    model, *_ = _train_step(case)
+    case = GOLDEN_CASES[name]
+    noise = None
+    if case["family"] == "dpcknn":          # the density noise is drawn per forward unless given: the same (zero) draws for every forward here
+        probe, *_ = build_model(case)
+        noise = {blk: torch.zeros(case["batch"], P) for blk, _, P in probe._stage_shapes()}
+    model, *_ = _train_step(case, noise)
     want = {n: p.grad.clone() for n, p in model.named_parameters()}
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29571")
