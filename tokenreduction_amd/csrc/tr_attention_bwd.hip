@@ -55,10 +55,11 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const uint16_t* _
   __shared__ __attribute__((aligned(16))) unsigned char sDS[64 * 512];
   __shared__ __attribute__((aligned(16))) float sLB[NP];     // log2(size[key]) (ToMe / key masks), 0 without sizes
   __shared__ __attribute__((aligned(16))) float sDC[NP];     // d cls_attn[key] / H (EViT), 0 otherwise
-  // POLICY: d policy[key], one row per wave (its 16 query columns of every block, reduced over the lanes before they are added: a single
-  // lane owns each entry, so plain read-modify-write in a fixed order).  As LDS float atomics straight from every lane -- sixteen lanes of
-  // a quarter wave on one address, N^2 atomics per head -- this sum made the policy variant 3x the plain kernel (601 vs 196 us at N = 197).
-  __shared__ float sPol[POLICY ? 4 * NP : 1];
+  // POLICY: d policy[key], one row per (query block, wave): the wave's 16 query columns are reduced over the lanes (DPP) and stored by one
+  // lane; the rows are added at the end in a fixed order.  As LDS float atomics straight from every lane -- sixteen lanes of a quarter wave
+  // on one address, N^2 atomics per head -- this sum made the policy variant 3x the plain kernel (601 vs 196 us at N = 197); as a
+  // read-modify-write per entry it still waited out 56 LDS round trips per block (346 us).
+  __shared__ __attribute__((aligned(16))) float sPol[POLICY ? 16 * NP : 1];      // [query block (<= 4)][wave][key]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
@@ -91,7 +92,6 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const uint16_t* _
       if (POLICY) {
         sLB[key] = key < N ? size[(size_t)b * N + key] : 0.f;
         sDC[key] = 0.f;
-        sPol[key] = sPol[NP + key] = sPol[2 * NP + key] = sPol[3 * NP + key] = 0.f;
       } else {
         sLB[key] = (BIAS && key < N) ? __builtin_amdgcn_logf(size[(size_t)b * N + key]) : 0.f;     // v_log_f32 = log2
         sDC[key] = (dcls != nullptr && key < N) ? dcls[(size_t)b * N + key] / (float)H : 0.f;
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const uint16_t* _
     for (int jt = 0; jt < NT; ++jt) {
       const float4 lb = *reinterpret_cast<const float4*>(&sLB[16 * jt + 4 * g]);
       const float lbv[4] = {lb.x, lb.y, lb.z, lb.w};
-      float pv[4], dsv[4];
+      float pv[4], dsv[4], dpv[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = 16 * jt + 4 * g + r;
@@ -236,14 +236,14 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const uint16_t* _
           const float en = sacc[jt][r] * inv;             // e / (sum a + eps)
           pv[r] = key < N ? en * pi + padd * inv : 0.f;
           dsv[r] = w * en * pi * 0.125f;
-          float dp = (key != iq && key < N && iq < N) ? w * en : 0.f;       // summed over this wave's 16 query columns (lanes li)
-          dp = row16_sum(dp);
-          if (li == 0) sPol[wave * NP + key] += dp;
+          dpv[r] = row16_sum((key != iq && key < N && iq < N) ? w * en : 0.f);      // summed over this wave's 16 query columns (lanes li)
         } else {
           pv[r] = sacc[jt][r];
           dsv[r] = sacc[jt][r] * w * 0.125f;
         }
       }
+      if (POLICY && li == 0)       // this (query block, wave)'s own row: a plain 16-byte store, nothing to wait for
+        *reinterpret_cast<float4*>(&sPol[(qb * 4 + wave) * NP + 16 * jt + 4 * g]) = make_float4(dpv[0], dpv[1], dpv[2], dpv[3]);
       uint2 pp, ds;
       pp.x = pack_bf16x2(pv[0], pv[1]);
       pp.y = pack_bf16x2(pv[2], pv[3]);
@@ -309,10 +309,13 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(const uint16_t* _
     }
   }
   if (POLICY) {
-    // the four waves' rows, added in wave order
+    // the rows of every (query block, wave), added in that order
     __syncthreads();
-    for (int key = tid; key < N; key += 256)
-      dpol_part[((size_t)b * H + h) * N + key] = (sPol[key] + sPol[NP + key]) + (sPol[2 * NP + key] + sPol[3 * NP + key]);
+    for (int key = tid; key < N; key += 256) {
+      float a = 0.f;
+      for (int rw = 0; rw < 4 * nqb; ++rw) a += sPol[rw * NP + key];
+      dpol_part[((size_t)b * H + h) * N + key] = a;
+    }
   }
   // ---- dK, dV rows: accumulator (t, d): rows d-index 16d + 4g + r, column key 16*(wave + 4t) + li
 #pragma unroll
