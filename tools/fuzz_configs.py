@@ -92,6 +92,24 @@ for it in range(n_cfg):
             gok = all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in m.parameters())
             ok &= bool(torch.isfinite(loss)) and gok
             msg += f"; train loss {loss.item():.3f} grads {'finite' if gok else 'BAD'}"
+            # gradients against torch.autograd over the oracle's forward on the device's own decisions (what tests/test_hip_train.py does
+            # for the fixed cases): every parameter, whole-model relative L2.  Not for Sinkhorn (it re-normalises a parameter in place per
+            # training forward) and DyViT (needs the recorded Gumbel draws).
+            if fam in ("deit", "topk", "evit", "tome", "ats", "dpcknn", "sit", "patchmerger", "heuristic") or (fam == "kmedoids" and not equal):
+                from tokenreduction_amd import training
+                from tests._params import grad_labels, oracle_param_grads
+                m.zero_grad(set_to_none=True)
+                lg2 = m(x.cuda())
+                torch.nn.functional.cross_entropy(lg2, grad_labels(case).cuda()).backward()
+                dec = training.train_decisions(m)
+                forced = {blk: (tuple(t.cpu() for t in d) if isinstance(d, tuple) else d.cpu()) for blk, d in dec.items()}
+                _, _, og = oracle_param_grads(case, forced=forced or None, precision="bf16", noise=noise)
+                names = [n for n, _ in m.named_parameters()]
+                got = torch.cat([p.grad.reshape(-1).cpu().double() for _, p in m.named_parameters()])
+                want_g = torch.cat([og[n].reshape(-1).double() for n in names])
+                grel = float((got - want_g).norm() / want_g.norm().clamp_min(1e-30))
+                msg += f"; grad rel L2 vs oracle {grel:.2e}"
+                ok &= grel < 3e-2
         except NotImplementedError as e:
             msg += f"; train raises: {str(e)[:60]}"
         print(f"{tag}: {'ok ' if ok else 'BAD'} {msg}")
