@@ -280,3 +280,17 @@ def test_heuristic_masks_match_the_oracle_for_every_range():
                     assert torch.equal(mask, m._block_mask(b)), (pattern, depth, loc, nc, mr, kr, b)
                     checked += 1
     assert checked > 1000
+
+
+@pytest.mark.parametrize("name,kr,loc", [("evit_small_patch16_224", [0.3], [0, 1, 2, 3, 4]), ("topk_small_patch16_224", [0.004], [3]),
+                                         ("dyvit_small_patch16_224", [0.3], [1, 2, 3, 4, 5]), ("dpcknn_small_patch16_224", [0.3], [1, 2, 3, 4, 5]),
+                                         ("sit_small_patch16_224", [0.004], [3])])
+def test_schedules_that_keep_no_token_raise(name, kr, loc):
+    """int(0.3**5 * 196) = 0: the reference would carry on with the CLS token alone (a k = 0 topk is legal in torch); here 0 marks "no
+    reduction at this block", so such a schedule must raise at construction instead of silently skipping the stage."""
+    import types
+    import tokenreduction_amd as tra
+    args = types.SimpleNamespace(keep_rate=list(kr), reduction_loc=list(loc), dyvit_distill=False, k_neighbors=5, equal_weight=False, cluster_iters=3,
+                                 sinkhorn_eps=1.0)
+    with pytest.raises(ValueError, match="keeps 0 tokens"):
+        tra.create_model(name, pretrained=False, num_classes=10, args=args)

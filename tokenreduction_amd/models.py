@@ -137,6 +137,15 @@ class VisionTransformer(nn.Module):
         self.apply(_init_vit_weights)
 
     # ---- reference helper surface -------------------------------------------------------------
+    def _set_keep(self, loc, k, rule):
+        """Token / cluster count of the reduction at block `loc`.  0 is this package's "no reduction here" marker, so a schedule that
+        rounds down to zero tokens (int(0.3**5 * 196) = 0: the reference would go on with the CLS token alone) raises instead of being
+        skipped silently."""
+        k = int(k)
+        if k < 1:
+            raise ValueError(f"block {loc}: {rule} keeps {k} tokens -- schedules that leave no patch token / cluster are not built")
+        self._keep[loc] = k
+
     def _init_weights(self, m):
         _init_vit_weights(m)
 
@@ -428,7 +437,10 @@ class _TopKBase(VisionTransformer):
         for r, loc in zip(token_ratio, pruning_loc):
             assert 0 < r <= 1, "keep_rate must > 0 and <= 1, got {0}".format(r)   # topk.py:39
             self.blocks[loc].attn.keep_rate = r
-            self._keep[loc] = int(r * 196) if r < 1 else 0     # topk.py:56 (196 hard-coded)
+            if r < 1:
+                self._set_keep(loc, int(r * 196), f"int({r:.4g} * 196) (topk.py:56, 196 hard-coded)")
+            else:
+                self._keep[loc] = 0
         self._check_static_shapes()
 
     def _check_static_shapes(self):
@@ -602,7 +614,7 @@ class DynamicVisionTransformer(VisionTransformer):
         for m in self.score_predictor.modules():
             _init_vit_weights(m)
         for ratio, loc in zip(token_ratio, pruning_loc):
-            self._keep[loc] = int(self.num_patches * ratio)                                               # dyvit.py:232
+            self._set_keep(loc, int(self.num_patches * ratio), f"int({self.num_patches} * {ratio:.4g}) (dyvit.py:232)")
         self.deit_distillation = False
         self.dyvit_distillation = dyvit_distillation
         self.pruning_loc = pruning_loc
@@ -698,7 +710,7 @@ class SelfSlimmedVisionTransformer(VisionTransformer):
         for m in self.cluster_layers.modules():
             _init_vit_weights(m)
         for c, loc in zip(self.cluster_count, self.cluster_loc):
-            self._keep[loc] = c
+            self._set_keep(loc, c, "the cluster schedule")
 
     def get_new_module_names(self):
         return ["cluster_layers"]
@@ -810,7 +822,7 @@ class DPCKNNVisionTransformer(VisionTransformer):
         for m in self.cluster_layers.modules():
             _init_vit_weights(m)
         for c, loc in zip(self.cluster_count, self.cluster_loc):
-            self._keep[loc] = c
+            self._set_keep(loc, c, "the cluster schedule")
         self.density_noise = None
         self._noise_buf = None
 
@@ -885,6 +897,8 @@ class ATSVisionTransformer(VisionTransformer):
         for idx in range(self.depth):
             if idx in self.sample_loc:
                 self.sample_count[idx] = int(sample_count[cnt])
+                if self.sample_count[idx] < 1:
+                    raise ValueError(f"block {idx}: the sampling schedule keeps {self.sample_count[idx]} tokens -- schedules that leave no patch token are not built")
                 cnt += 1
         # static token bound of a sampling block: one token per grid point + CLS.  The grid (ats.py:48) is a float arange with an
         # exclusive end; for 42 sample counts up to 197 (7, 12, 14, ..., 126, ...) rounding admits the end point: K points, bound K + 1
@@ -948,7 +962,7 @@ class SinkhornVisionTransformer(SelfSlimmedVisionTransformer):
         self.cluster_layers = nn.ModuleList([Sinkhorn(self.embed_dim, c, self.sinkhorn_eps, self.sinkhorn_iters)
                                              for c in self.cluster_count])
         for c, loc in zip(self.cluster_count, self.cluster_loc):
-            self._keep[loc] = c
+            self._set_keep(loc, c, "the cluster schedule")
 
     def _pre_pack(self):
         if self.training:                       # sinkhorn.py:72-76: the centres are re-normalised IN PLACE (no grad) at every forward
@@ -1017,7 +1031,7 @@ class KMedoidsVisionTransformer(VisionTransformer):
             raise ValueError("kmedoids cannot reduce before block 0: there is no previous attention (kmedoids.py:240)")
         self.cluster_layers = nn.ModuleList([KMedoids(c, self.cluster_iters, self.equal_weight) for c in self.cluster_count])
         for c, loc in zip(self.cluster_count, self.cluster_loc):
-            self._keep[loc] = c
+            self._set_keep(loc, c, "the cluster schedule")
 
     def _per_forward_config(self, cfg):
         """args.equal_weight (kmedoids.py:43-47): every k_medoids_fit call draws its first medoid with
@@ -1084,7 +1098,7 @@ class PatchMergerVisionTransformer(SelfSlimmedVisionTransformer):
         for m in self.cluster_layers.modules():
             _init_vit_weights(m)
         for c, loc in zip(self.cluster_count, self.cluster_loc):
-            self._keep[loc] = c
+            self._set_keep(loc, c, "the cluster schedule")
 
     def _grad_slot_numel(self, name, p):
         for j, K in enumerate(self.cluster_count):

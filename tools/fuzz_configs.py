@@ -26,7 +26,7 @@ for it in range(n_cfg):
     nloc = int(rng.integers(1, depth + 1))
     loc = sorted(rng.choice(np.arange(1 if fam == "kmedoids" else 0, depth), size=min(nloc, depth - (1 if fam == "kmedoids" else 0)), replace=False).tolist())
     kr = [float(rng.choice([0.3, 0.5, 0.7, 0.9]))]
-    if fam in ("sit", "patchmerger", "sinkhorn", "dpcknn", "kmedoids", "ats") and 196 * kr[0] ** len(loc) < 4:
+    if fam in ("sit", "patchmerger", "sinkhorn", "dpcknn", "kmedoids", "ats", "topk", "evit", "dyvit") and 196 * kr[0] ** len(loc) < 4:
         kr = [0.7]                                                           # geometric schedules: keep at least a few clusters at the last stage
     if fam == "tome":                                                        # ToMe: absolute token counts after each listed block, non-increasing
         r = int(rng.choice([4, 16, 40]))
