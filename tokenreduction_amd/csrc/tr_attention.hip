@@ -335,6 +335,279 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const uint16_t* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// N <= 224, round 3: the same whole-row-in-registers softmax on 16-QUERY blocks (v_mfma_f32_16x16x32_bf16), three workgroups per CU.
+//
+// Why (profiles/r02_final_pmc_sq.json): attention_kernel above keeps 32 queries x 224 keys = 112 score registers per
+// lane, so two waves per SIMD is all the register file takes, two workgroups per CU is all the LDS takes (K + V^T = 58 KB), and a
+// wave spends its 2 x 8 k cycles per workgroup in order: matrix pipe busy 15 %, HBM at 3.1 TB/s -- bound by neither.  Here:
+//   * S^T block = 16 keys x 16 queries: a lane holds 4 consecutive keys of ONE query per block, 56 registers for 224 keys, so three
+//     waves per SIMD fit (168 VGPRs) and the waves of three workgroups in different phases overlap MFMA, softmax VALU and staging;
+//   * LDS rows are allocated for ceil(N/16)*16 keys (208 at N = 197): K + V = 52 KB -> three workgroups per CU;
+//   * V is staged ROW-major like K (one 16-byte LDS write per 16 bytes loaded; the transposing scatter above took 8 two-byte writes)
+//     and read transposed by ds_read_b64_tr_b16.  V image: 16-byte chunk c of key row r sits at chunk c ^ 4 (r>>1 & 1) with its two
+//     8-byte halves swapped when (r>>2 & 1): conflict-free for the transposed reads (tools/lds_sim.py);
+//   * the P.V operand rows are PERMUTED through the transposed read's four independently addressed column pieces, so that a lane's
+//     output registers of a d-block pair are 8 consecutive head dimensions: 16-byte output stores.
+// Layouts (cdna guide section 3, 16x16x32): S^T[kb] = K_kb Q^T: lane (q = lane & 15, g = lane >> 4), register r = key kb*16 + 4g + r.
+// P^T as the B operand of O^T += V^T P^T over the key pair (2t, 2t+1): k index 8g + j <-> key 32t + 16 (j>>2) + 4g + (j&3), the same
+// keys the two transposed reads of V deliver.  O^T[db] register r <-> head dimension 32 (db>>1) + 8g + 4 (db&1) + r.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+__device__ __forceinline__ bf16x8 lds_tr_pair16(const unsigned char* p0, const unsigned char* p1) {
+  const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0));
+  const s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p1));
+  const s16x8_t c = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, c);
+}
+
+// reductions over the four lanes (lane >> 4 = 0..3) that share a query: two VALU half / row swaps instead of two LDS round trips
+// (v_permlane32_swap: lanes 32..63 of the first operand <-> lanes 0..31 of the second; v_permlane16_swap: odd 16-lane rows of the
+// first <-> even rows of the second; with both operands the same value, the two results are the value of the two partners)
+__device__ __forceinline__ float quad_rows_max(float v) {
+  // (the elements of the builtin's result are copied to scalars first: __builtin_bit_cast applied to `a[1]` directly read element 0
+  // -- hipcc 7.2 -- and the reduction silently lost the partner's value)
+  const auto a = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  const unsigned a0 = a[0], a1 = a[1];
+  v = fmaxf(__builtin_bit_cast(float, a0), __builtin_bit_cast(float, a1));
+  const auto c = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  const unsigned c0 = c[0], c1 = c[1];
+  return fmaxf(__builtin_bit_cast(float, c0), __builtin_bit_cast(float, c1));
+}
+__device__ __forceinline__ float quad_rows_sum(float v) {
+  const auto a = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  const unsigned a0 = a[0], a1 = a[1];
+  v = __builtin_bit_cast(float, a0) + __builtin_bit_cast(float, a1);
+  const auto c = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  const unsigned c0 = c[0], c1 = c[1];
+  return __builtin_bit_cast(float, c0) + __builtin_bit_cast(float, c1);
+}
+#ifndef TR_ATT16_WAVES
+#define TR_ATT16_WAVES 4
+#endif
+#ifndef TR_ATT16_SB
+#define TR_ATT16_SB 3
+#endif
+constexpr int A16_NW = TR_ATT16_WAVES, A16_NT = 64 * A16_NW;     // waves / threads per workgroup
+template <int NP, bool COLSUM, bool POLICY, bool BIAS>
+__global__ __launch_bounds__(A16_NT, (COLSUM || POLICY) ? 2 : 3) void attention16_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
+                                                             float* __restrict__ cls_rows, const float* __restrict__ size,
+                                                             float* __restrict__ colsum_part, int N, int H) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+  constexpr int NKB = 2 * NP;                       // 16-key blocks
+  const int R = ((N + 15) >> 4) << 4;               // key rows held in LDS
+  unsigned char* sK = smem16;
+  unsigned char* sV = sK + R * 128;
+  float* sLB = reinterpret_cast<float*>(sV + R * 128);     // POLICY: keep policy; BIAS: log2(size[key]) (ToMe / key masks)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int ldq = 3 * H * 64;
+  const uint16_t* base = qkv + (size_t)b * N * ldq;
+  const int qcol = h * 64, kcol = H * 64 + h * 64, vcol = 2 * H * 64 + h * 64;
+  const int nqb = (N + 15) >> 4;
+
+  // ---- stage K and V (all loads issued before the first LDS write); the first query block's fragments are requested alongside
+  constexpr int NIT = (NP * 256 + A16_NT - 1) / A16_NT;     // 16-byte chunks per thread and matrix
+  uint4 kreg[NIT], vreg[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = tid + A16_NT * it, key = c >> 3, ch = c & 7;
+    kreg[it] = *reinterpret_cast<const uint4*>(base + (size_t)min(key, N - 1) * ldq + kcol + ch * 8);
+    vreg[it] = *reinterpret_cast<const uint4*>(base + (size_t)min(key, N - 1) * ldq + vcol + ch * 8);
+  }
+  bf16x8 qf[2];
+  {
+    const uint16_t* qrow = base + (size_t)min(wave * 16 + li, N - 1) * ldq + qcol + 8 * g;
+    qf[0] = *reinterpret_cast<const bf16x8*>(qrow);
+    qf[1] = *reinterpret_cast<const bf16x8*>(qrow + 32);
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int c = tid + A16_NT * it, key = c >> 3, ch = c & 7;
+    if (key < R) {
+      uint4 k4 = kreg[it], v4 = vreg[it];
+      if (key >= N) { k4 = make_uint4(0u, 0u, 0u, 0u); v4 = make_uint4(0u, 0u, 0u, 0u); }
+      *reinterpret_cast<uint4*>(sK + kswz(key, ch)) = k4;
+      if ((key >> 2) & 1) v4 = make_uint4(v4.z, v4.w, v4.x, v4.y);
+      *reinterpret_cast<uint4*>(sV + key * 128 + ((ch ^ (((key >> 1) & 1) << 2)) << 4)) = v4;
+    }
+  }
+  if (POLICY || BIAS) {
+    for (int key = tid; key < R; key += A16_NT)
+      sLB[key] = POLICY ? (key < N ? size[(size_t)b * N + key] : 0.f)
+                        : ((size != nullptr && key < N) ? __builtin_amdgcn_logf(size[(size_t)b * N + key]) : 0.f);   // v_log_f32 = log2
+  }
+  __syncthreads();
+
+  const float c_exp = 0.125f * 1.44269504088896340736f;  // dh^-0.5 * log2(e), dh = 64
+  const bool last_empty = R < NKB * 16;                   // the last pair's second 16-key block lies wholly past the keys
+  // K fragment of block kb, k-step s: row kb*16 + li, logical chunk 4s + g; (row >> 1) & 7 = (li >> 1) & 7 for every kb
+  const unsigned char* kbase = sK + li * 128;
+  const int kx0 = ((g ^ ((li >> 1) & 7)) << 4), kx1 = (((4 + g) ^ ((li >> 1) & 7)) << 4);
+  // transposed V reads: lane 4q'+p' of a 16-lane group addresses key row 32t + 4g + q' (+16), piece p' of the d-block's four
+  const int q4 = li >> 2, p4 = li & 3;
+  const unsigned char* vb[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) {
+    const int c = 4 * (db >> 1) + p4, hb = db & 1;
+    vb[db] = sV + (4 * g + q4) * 128 + ((c ^ (((q4 >> 1) & 1) << 2)) << 4) + ((hb ^ (g & 1)) << 3);
+  }
+  float colacc[4] = {0.f, 0.f, 0.f, 0.f};                // COLSUM: lane li owns key block li
+
+  for (int qb = wave; qb < nqb; qb += A16_NW) {
+    const int q = qb * 16 + li;
+    // ---- S^T = K Q^T
+    f32x4 sacc[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+      sacc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (kb < NKB - 1 || !last_empty) {
+        const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kbase + kb * 2048 + kx0);
+        const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kbase + kb * 2048 + kx1);
+        sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k0, qf[0], sacc[kb], 0, 0, 0);
+        sacc[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k1, qf[1], sacc[kb], 0, 0, 0);
+      }
+      if ((kb & TR_ATT16_SB) == TR_ATT16_SB) __builtin_amdgcn_sched_barrier(0);      // K-fragment reads stay with their group of key blocks: bounds the live registers
+    }
+    // the next block's query fragments fly under this block's softmax and P.V
+    {
+      const int qn = qb + A16_NW < nqb ? qb + A16_NW : qb;
+      const uint16_t* qrow = base + (size_t)min(qn * 16 + li, N - 1) * ldq + qcol + 8 * g;
+      qf[0] = *reinterpret_cast<const bf16x8*>(qrow);
+      qf[1] = *reinterpret_cast<const bf16x8*>(qrow + 32);
+    }
+    // ---- softmax over keys: this lane's registers, then the four lanes (g = 0..3) that share the query
+    float mx = -INFINITY, l = 0.f;
+    if (!POLICY && !BIAS) {
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (kb >= NKB - 2 && kb * 16 + 4 * g + r >= N) sacc[kb][r] = -INFINITY;
+          mx = fmaxf(mx, sacc[kb][r]);
+        }
+      mx = quad_rows_max(mx);
+      const float nm = -mx * c_exp;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(sacc[kb][r] * c_exp + nm);
+          sacc[kb][r] = pv;
+          l += pv;
+        }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!POLICY && (kb < NKB - 1 || !last_empty)) b4 = *reinterpret_cast<const float4*>(&sLB[kb * 16 + 4 * g]);
+        const float bb[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // logits in the log2 domain: (q.k) * dh^-0.5 * log2(e) [+ log2(size[key])]
+          sacc[kb][r] = sacc[kb][r] * c_exp + bb[r];
+          if (kb >= NKB - 2 && kb * 16 + 4 * g + r >= N) sacc[kb][r] = -INFINITY;
+          mx = fmaxf(mx, sacc[kb][r]);
+        }
+      }
+      mx = quad_rows_max(mx);
+      const float nm = (mx == -INFINITY) ? 0.f : -mx;          // every key masked: all weights exp2(-inf) = 0
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        float4 p4v = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (POLICY && (kb < NKB - 1 || !last_empty)) p4v = *reinterpret_cast<const float4*>(&sLB[kb * 16 + 4 * g]);
+        const float pw[4] = {p4v.x, p4v.y, p4v.z, p4v.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float pv = __builtin_amdgcn_exp2f(sacc[kb][r] + nm);
+          if (POLICY) pv *= (kb * 16 + 4 * g + r == q) ? 1.0f : pw[r];      // attn_policy = policy + (1 - policy) * eye
+          sacc[kb][r] = pv;
+          l += pv;
+        }
+      }
+    }
+    l = quad_rows_sum(l);
+    const float inv = POLICY ? 1.0f / (l + 1e-6f) : 1.0f / l;
+    if (POLICY) {                                                // (attn + eps/N) / (sum + eps); padded keys stay 0
+      const float add = 1e-6f / (float)N;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (kb < NKB - 2 || kb * 16 + 4 * g + r < N) sacc[kb][r] += add;
+    }
+
+    // ---- O^T = V^T P^T
+    f32x4 o[4];
+#pragma unroll
+    for (int db = 0; db < 4; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NP; ++t) {
+      bf16x8 pf;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        pf[j] = (__bf16)sacc[2 * t][j];
+        pf[4 + j] = (__bf16)sacc[2 * t + 1][j];
+      }
+      const bool half = (t == NP - 1) && last_empty;        // rows R.. are not in LDS: re-read the first block's rows (their P is 0)
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const unsigned char* p0 = vb[db] + t * 4096;
+        const bf16x8 vf = lds_tr_pair16(p0, half ? p0 : p0 + 2048);
+        o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[db], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (q < N) {
+      uint16_t* orow = out + ((size_t)b * N + q) * (H * 64) + h * 64 + 8 * g;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        uint4 pk;
+        pk.x = pack_bf16x2(o[2 * u][0] * inv, o[2 * u][1] * inv);
+        pk.y = pack_bf16x2(o[2 * u][2] * inv, o[2 * u][3] * inv);
+        pk.z = pack_bf16x2(o[2 * u + 1][0] * inv, o[2 * u + 1][1] * inv);
+        pk.w = pack_bf16x2(o[2 * u + 1][2] * inv, o[2 * u + 1][3] * inv);
+        *reinterpret_cast<uint4*>(orow + 32 * u) = pk;
+      }
+    }
+    if (COLSUM) {
+      const float wq = q < N ? inv : 0.f;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sres = row16_sum(sacc[kb][r] * wq);      // over the 16 queries of the block (the DPP row = equal g)
+          if (li == kb) colacc[r] += sres;
+        }
+    }
+    if (cls_rows != nullptr && qb == 0 && li == 0) {
+      float* crow = cls_rows + ((size_t)b * H + h) * N;
+#pragma unroll
+      for (int kb = 0; kb < NKB; ++kb) {
+        const int key = kb * 16 + 4 * g;
+        if (kb < NKB - 2 || key + 3 < N) {       // rows of N floats are only 4-byte aligned: four scalar stores, one branch
+#pragma unroll
+          for (int r = 0; r < 4; ++r) crow[key + r] = sacc[kb][r] * inv;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (key + r < N) crow[key + r] = sacc[kb][r] * inv;
+        }
+      }
+    }
+  }
+  if (COLSUM && li < NKB) {
+    float* crow = colsum_part + (((size_t)b * H + h) * 4 + wave) * N;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = li * 16 + 4 * g + r;
+      if (key < N) crow[key] = colacc[r];
+    }
+  }
+}
+
 // ---- long sequences (224 < N <= 608, i.e. 384^2 inputs: N = 577) -----------------------------------------------------------
 // Same MFMA scheme, but the score row no longer fits the register file, so the keys are walked in chunks of CH 32-key blocks,
 // twice: pass 1 finds every query's row maximum and normaliser (running max / rescaled sum), pass 2 recomputes the scores,
@@ -805,6 +1078,24 @@ __global__ __launch_bounds__(256, 3) void attention_colsum_kernel(const uint16_t
   }
 }
 
+template <int NP>
+int launch_attention16(const uint16_t* qkv, uint16_t* out, float* cls_rows, const float* size, float* colsum_part, int B, int N, int H,
+                       hipStream_t st, bool policy = false) {
+  const int R = ((N + 15) >> 4) << 4;
+  const size_t lds = (size_t)R * 256 + ((policy || size) ? (size_t)R * 4 : 0);
+  if (policy)
+    hipLaunchKernelGGL((attention16_kernel<NP, false, true, false>), dim3(B * H), dim3(A16_NT), lds, st, qkv, out, cls_rows, size, colsum_part, N, H);
+  else if (colsum_part && size)
+    hipLaunchKernelGGL((attention16_kernel<NP, true, false, true>), dim3(B * H), dim3(A16_NT), lds, st, qkv, out, cls_rows, size, colsum_part, N, H);
+  else if (colsum_part)
+    hipLaunchKernelGGL((attention16_kernel<NP, true, false, false>), dim3(B * H), dim3(A16_NT), lds, st, qkv, out, cls_rows, size, colsum_part, N, H);
+  else if (size)
+    hipLaunchKernelGGL((attention16_kernel<NP, false, false, true>), dim3(B * H), dim3(A16_NT), lds, st, qkv, out, cls_rows, size, colsum_part, N, H);
+  else
+    hipLaunchKernelGGL((attention16_kernel<NP, false, false, false>), dim3(B * H), dim3(A16_NT), lds, st, qkv, out, cls_rows, size, colsum_part, N, H);
+  return 0;
+}
+
 template <int NKB>
 int launch_attention(const uint16_t* qkv, uint16_t* out, float* cls_rows, const float* size, float* colsum_part, int B, int N, int H,
                      hipStream_t st, bool policy = false) {
@@ -870,6 +1161,20 @@ extern "C" int tr_attention_bf16(const uint16_t* qkv, uint16_t* out, float* cls_
       hipLaunchKernelGGL(attention_long_kernel<true>, dim3(B * H), dim3(256), lds, st, qkv, out, cls_rows, size, colsum_part, N, H, nkb);
     else
       hipLaunchKernelGGL(attention_long_kernel<false>, dim3(B * H), dim3(256), lds, st, qkv, out, cls_rows, size, colsum_part, N, H, nkb);
+    TR_CHECK_LAUNCH("tr_attention_bf16");
+    return TR_OK;
+  }
+  static const bool use_old = [] { const char* e = getenv("TR_ATT_OLD"); return e && atoi(e) != 0; }();   // lab: the 32-query kernel
+  if (!use_old) {
+    switch ((N + 31) / 32) {
+      case 1: launch_attention16<1>(qkv, out, cls_rows, size, colsum_part, B, N, H, st); break;
+      case 2: launch_attention16<2>(qkv, out, cls_rows, size, colsum_part, B, N, H, st); break;
+      case 3: launch_attention16<3>(qkv, out, cls_rows, size, colsum_part, B, N, H, st); break;
+      case 4: launch_attention16<4>(qkv, out, cls_rows, size, colsum_part, B, N, H, st); break;
+      case 5: launch_attention16<5>(qkv, out, cls_rows, size, colsum_part, B, N, H, st); break;
+      case 6: launch_attention16<6>(qkv, out, cls_rows, size, colsum_part, B, N, H, st); break;
+      default: launch_attention16<7>(qkv, out, cls_rows, size, colsum_part, B, N, H, st); break;
+    }
     TR_CHECK_LAUNCH("tr_attention_bf16");
     return TR_OK;
   }
