@@ -294,3 +294,29 @@ def test_schedules_that_keep_no_token_raise(name, kr, loc):
                                  sinkhorn_eps=1.0)
     with pytest.raises(ValueError, match="keeps 0 tokens"):
         tra.create_model(name, pretrained=False, num_classes=10, args=args)
+
+
+def test_deepcopy_leaves_the_executor_caches_behind():
+    """copy.deepcopy(model) (timm's ModelEmaV2, torch.optim.swa_utils) copies parameters, buffers and configuration, never the executor's
+    state: workspaces hold captured graphs that cannot be copied, and a copied workspace would not match the copy's own packed weights."""
+    import copy
+    import types
+    import tokenreduction_amd as tra
+
+    class NoCopy:
+        def __deepcopy__(self, memo):
+            raise TypeError("cannot be deep-copied (stands in for torch.cuda.CUDAGraph)")
+
+    args = types.SimpleNamespace(keep_rate=[0.7], reduction_loc=[1, 2], viz_mode=False)
+    m = tra.TopKVisionTransformer(patch_size=16, embed_dim=128, depth=4, num_heads=2, mlp_ratio=4, qkv_bias=True, num_classes=8, args=args)
+    m._ws = {2: {"graphs": {0: NoCopy()}}}
+    m._packed = {"key": 1, "keep_alive": [NoCopy()]}
+    m._last_ws = m._ws[2]
+    m._tstate = NoCopy()
+    m._noise_buf = NoCopy()
+    twin = copy.deepcopy(m)
+    assert twin._ws == {} and twin._packed is None and twin._tstate is None and twin._last_ws is None and twin._noise_buf is None
+    assert twin._keep == m._keep and twin.precision == m.precision and twin.pruning_loc == m.pruning_loc
+    for (n, a), (_, b) in zip(m.state_dict().items(), twin.state_dict().items()):
+        assert torch.equal(a, b) and a.data_ptr() != b.data_ptr(), n
+    assert isinstance(m._ws[2]["graphs"][0], NoCopy)      # the original is untouched

@@ -29,8 +29,11 @@ WORKER = textwrap.dedent("""
     cfg, params = case_params(case)
     model.load_state_dict(params)
     st = training.TrainState(model)                        # flat buffer in backward order, p.grad views
-    red = FlatGradReducer(bucket_bytes=256 * 1024, algorithm=os.environ["TR_DP_ALGO"]).attach(model)
+    comm = {"": None, "bf16": torch.bfloat16}[os.environ.get("TR_DP_COMM", "")]
+    red = FlatGradReducer(bucket_bytes=256 * 1024, algorithm=os.environ["TR_DP_ALGO"], comm_dtype=comm).attach(model)
     assert red.algorithm == os.environ["TR_DP_ALGO"]
+    # the default bucket size: a sixth of the gradient bytes clamped to [8, 64] MiB -- this micro model is one bucket, DeiT-S is six
+    assert len(FlatGradReducer().plan(st.block_slices, model.depth)) == 1
     red.broadcast_parameters(model)
     plan = red.plan(st.block_slices, model.depth)
     assert len(plan) >= 3, plan                            # several buckets
@@ -51,7 +54,14 @@ WORKER = textwrap.dedent("""
     red.finish(st.flat)
     want = {n: sum(local_grads(r)[n] for r in range(world)) / world for n, _ in st.order}
     for n, p in model.named_parameters():
-        assert torch.allclose(p.grad, want[n], rtol=1e-6, atol=1e-8), (n, (p.grad - want[n]).abs().max())
+        if comm is None:
+            assert torch.allclose(p.grad, want[n], rtol=1e-6, atol=1e-8), (n, (p.grad - want[n]).abs().max())
+        else:
+            # bf16 payload: every rank's slice is rounded to bf16 (2^-9 relative), summed in bf16 by the collective and divided:
+            # per element within 2^-7 of the largest contribution
+            scale = torch.stack([local_grads(r)[n].abs() for r in range(world)]).max(0).values
+            assert ((p.grad - want[n]).abs() <= scale * 2.0 ** -7 + 1e-12).all(), (n, ((p.grad - want[n]).abs() / (scale + 1e-30)).max())
+            assert not torch.equal(p.grad, want[n]) or want[n].abs().max() == 0
     # no_sync: nothing is reduced (gradient accumulation micro-steps)
     with red.no_sync():
         assert red.sync is False
@@ -65,14 +75,14 @@ WORKER = textwrap.dedent("""
 import pytest
 
 
-@pytest.mark.parametrize("world,algo", [(2, "all_reduce"), (2, "rs_ag"), (4, "rs_ag")])
-def test_bucketed_gradient_mean_gloo(tmp_path, world, algo):
+@pytest.mark.parametrize("world,algo,comm", [(2, "all_reduce", ""), (2, "rs_ag", ""), (4, "rs_ag", ""), (2, "rs_ag", "bf16")])
+def test_bucketed_gradient_mean_gloo(tmp_path, world, algo, comm):
     """rs_ag = the RCCL path (reduce-scatter into a shard + all-gather in place; this torch's gloo implements both collectives, so
     the shard arithmetic is exercised at world sizes 2 and 4 on CPU); all_reduce = the fallback for buckets the world size does not divide."""
     script = tmp_path / "dp_worker.py"
     script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", TR_DP_ALGO=algo)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", TR_DP_ALGO=algo, TR_DP_COMM=comm)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-                          "--master-port", str(29617 + world + (7 if algo == "rs_ag" else 0)), str(script)], capture_output=True, text=True, env=env, timeout=600)
+                          "--master-port", str(29617 + world + (7 if algo == "rs_ag" else 0) + (13 if comm else 0)), str(script)], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert "dp ok" in out.stdout

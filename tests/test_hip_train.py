@@ -147,6 +147,48 @@ def test_grad_accumulation_and_zero_grad():
         assert torch.equal(p.grad, g1[n]), n
 
 
+def test_backward_of_an_overwritten_tape_raises():
+    """The tape belongs to the model, not to the autograd node: after a second train-mode forward the first one's activations are
+    gone, and its backward must say so instead of writing gradients of the wrong forward (round-2 advisor finding)."""
+    case = GOLDEN_CASES["topk_micro"]
+    model, *_ = _train_step(case)
+    model.zero_grad(set_to_none=True)
+    x = make_images(case["batch"], 224, case["xseed"]).cuda()
+    y = grad_labels(case).cuda()
+    first = torch.nn.functional.cross_entropy(model(x), y)
+    second = torch.nn.functional.cross_entropy(model(x + 0.5), y)
+    with pytest.raises(RuntimeError, match="overwritten"):
+        first.backward()
+    second.backward()                                    # the latest forward's backward is the valid one
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+    # an eval / no-grad forward in between does not touch the tape
+    third = torch.nn.functional.cross_entropy(model(x), y)
+    with torch.no_grad():
+        model.eval()(x)
+    model.train()
+    third.backward()
+
+
+def test_ema_copy_after_a_captured_eval_forward():
+    """harness.ModelEma deep-copies the model; a model that has run an eval forward owns captured hipGraphs and a GPU workspace, which
+    must not be (and cannot be) copied: the copy starts with empty executor caches and builds its own (round-2 advisor finding)."""
+    import copy
+    from tokenreduction_amd import harness
+    case = GOLDEN_CASES["topk_micro"]
+    model, params, cfg = build_model(case)
+    model.viz_mode = False
+    x = make_images(case["batch"], 224, case["xseed"]).cuda()
+    want = model.eval()(x).clone()
+    model.train()(x).sum().backward()                    # ... and a tape + flat gradient buffer
+    assert model._ws and model._packed is not None and model._tstate is not None
+    ema = harness.ModelEma(model, 0.99)
+    assert ema.module._ws == {} and ema.module._packed is None and ema.module._tstate is None
+    assert model._ws and model._packed is not None       # the original keeps its caches
+    assert torch.equal(ema.module(x), want)              # same weights, its own workspace and graph
+    twin = copy.deepcopy(model)
+    assert twin._packed is None and all(a.data_ptr() != b.data_ptr() for a, b in zip(twin.parameters(), model.parameters()))
+
+
 def test_optimizer_step_reduces_the_loss():
     """A few AdamW steps on one batch through the whole HIP training path: the loss falls (weights are re-packed each step)."""
     case = GOLDEN_CASES["evit_micro"]

@@ -1158,14 +1158,8 @@ extern "C" int tr_attention_bf16(const uint16_t* qkv, uint16_t* out, float* cls_
   if (N > 224) {
     const int nkb = (N + 31) / 32;
     const size_t lds = (size_t)nkb * 32 * 128 + (size_t)64 * (nkb * 64 + 16) + (size_t)nkb * 32 * 4;
-    const void* fn = colsum_part ? reinterpret_cast<const void*>(attention_long_kernel<true>)
-                                 : reinterpret_cast<const void*>(attention_long_kernel<false>);
-    static thread_local size_t reserved[2] = {0, 0};            // the attribute is sticky: set it only when a launch needs more
-    if (lds > reserved[colsum_part ? 1 : 0]) {
-      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_attention_bf16: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-      reserved[colsum_part ? 1 : 0] = lds;
-    }
+    if (colsum_part) TR_RESERVE_LDS(reinterpret_cast<const void*>(attention_long_kernel<true>), lds, "tr_attention_bf16");
+    else TR_RESERVE_LDS(reinterpret_cast<const void*>(attention_long_kernel<false>), lds, "tr_attention_bf16");
     if (colsum_part)
       hipLaunchKernelGGL(attention_long_kernel<true>, dim3(B * H), dim3(256), lds, st, qkv, out, cls_rows, size, colsum_part, N, H, nkb);
     else

@@ -44,16 +44,20 @@ void tr_prof_note(const char* label, double flops, double bytes);
     tr_prof_mark(name);                                                         \
   } while (0)
 
-// hipFuncAttributeMaxDynamicSharedMemorySize is sticky per kernel: raise it only when a launch needs more than any earlier one did
-// (otherwise a host-side driver call per launch).  One cache per expansion site: use one site per kernel instantiation.
+// hipFuncAttributeMaxDynamicSharedMemorySize is sticky per kernel AND per device: raise it only when a launch needs more than any earlier one
+// on the current device did (otherwise a host-side driver call per launch).  One cache per expansion site: use one site per kernel
+// instantiation.  (A single process-wide cache left the second GPU of a one-process multi-GPU program at the default 64 KB limit.)
 #define TR_RESERVE_LDS(fn_ptr, bytes, what)                                                                                     \
   do {                                                                                                                          \
-    static std::atomic<size_t> have__{0};                                                                                       \
+    static std::atomic<size_t> have__[64];                                                                                      \
+    int dev__ = 0;                                                                                                              \
+    (void)hipGetDevice(&dev__);                                                                                                 \
+    std::atomic<size_t>& slot__ = have__[(unsigned)dev__ & 63u];                                                                \
     const size_t want__ = (bytes);                                                                                              \
-    if (want__ > have__.load(std::memory_order_relaxed)) {                                                                      \
+    if (want__ > slot__.load(std::memory_order_relaxed)) {                                                                      \
       hipError_t e__ = hipFuncSetAttribute((fn_ptr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)want__);                  \
       TR_REQUIRE(e__ == hipSuccess, TR_ERR_LAUNCH, "%s: cannot reserve %zu B of LDS: %s", (what), want__, hipGetErrorString(e__)); \
-      have__.store(want__, std::memory_order_relaxed);                                                                          \
+      slot__.store(want__, std::memory_order_relaxed);                                                                          \
     }                                                                                                                           \
   } while (0)
 

@@ -11,7 +11,9 @@ the CPU tests), built on what the HIP backward executor provides (training.py):
   bucket is reduced on a side stream while the next range's kernels run (the DDP overlap);
 * xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring all-reduce is bound by ONE link, so the mean is taken as
   reduce-scatter + all-gather (RCCL drives all links for these with its direct algorithms) and buckets are larger than
-  NCCL-on-NVSwitch habits (default 64 MiB; DeiT-B's 346 MB of gradients -> 6 buckets);
+  NCCL-on-NVSwitch habits: by default a sixth of the model's gradient bytes, clamped to [8, 64] MiB and cut at block boundaries
+  (DeiT-B's 346 MB of gradients -> 6 buckets of ~58 MB, DeiT-S's 88 MB -> 6 of ~15 MB: every model overlaps all but the last bucket's
+  collective with the remaining backward ranges);
 * `no_sync()` skips the reduction for gradient-accumulation micro-steps (the reference reduces on every micro-step; same result,
   1/accum of the traffic).
 """
@@ -27,11 +29,16 @@ import torch.distributed as dist
 class FlatGradReducer:
     """Bucketed in-place mean of a flat gradient buffer over the ranks of `process_group`."""
 
-    def __init__(self, process_group=None, bucket_bytes: int = 64 << 20, comm_dtype: Optional[torch.dtype] = None,
+    TARGET_BUCKETS, MIN_BUCKET, MAX_BUCKET = 6, 8 << 20, 64 << 20
+
+    def __init__(self, process_group=None, bucket_bytes: Optional[int] = None, comm_dtype: Optional[torch.dtype] = None,
                  algorithm: str = "auto"):
+        """bucket_bytes None: chosen per model in plan() -- total gradient bytes / TARGET_BUCKETS, clamped to [MIN_BUCKET, MAX_BUCKET].
+        comm_dtype (e.g. torch.bfloat16): the payload on the links is a copy of the slice in that type (half the bytes for bf16); the
+        mean is then rounded to it once per rank pair -- relative error <= 2^-8 per element for bf16 (tests/test_dp.py)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group)
-        self.bucket_bytes = int(bucket_bytes)
+        self.bucket_bytes = None if bucket_bytes is None else int(bucket_bytes)
         self.comm_dtype = comm_dtype
         backend = dist.get_backend(process_group)
         if algorithm == "auto":
@@ -70,12 +77,16 @@ class FlatGradReducer:
         """block_slices: [(event_block, start, stop)] contiguous slices of the flat buffer in backward order (training.TrainState).
         Returns [(blk_hi, blk_lo, start, stop)]: block ranges of tr_vit_backward and the bucket each completes."""
         out, cur_hi, cur_start, cur_stop = [], None, None, None
+        bucket_bytes = self.bucket_bytes
+        if bucket_bytes is None:
+            total = 4 * max(stop for _, _, stop in block_slices)
+            bucket_bytes = min(self.MAX_BUCKET, max(self.MIN_BUCKET, total // self.TARGET_BUCKETS))
         for e, start, stop in block_slices:
             blk = min(e, depth - 1) if e < depth else 0            # the final slice (embedding + family modules) ends with block 0
             if cur_hi is None:
                 cur_hi, cur_start = depth - 1, start
             cur_stop = stop
-            if e < depth and (cur_stop - cur_start) * 4 >= self.bucket_bytes and blk > 0:
+            if e < depth and (cur_stop - cur_start) * 4 >= bucket_bytes and blk > 0:
                 out.append((cur_hi, blk, cur_start, cur_stop))
                 cur_hi, cur_start = blk - 1, stop
         if cur_hi is not None and cur_start < cur_stop:

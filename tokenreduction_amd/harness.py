@@ -87,17 +87,7 @@ class ModelEma:
     buffers follow ema = decay * ema + (1 - decay) * model after every optimizer step."""
 
     def __init__(self, model, decay: float = 0.9999, device=None):
-        packed, model._packed = getattr(model, "_packed", None), None          # ctypes structs / workspaces are not copied
-        tstate = model.__dict__.pop("_tstate", None)
-        reducer = model.__dict__.pop("_grad_reducer", None)
-        try:
-            self.module = copy.deepcopy(model)
-        finally:
-            model._packed = packed
-            if tstate is not None:
-                model._tstate = tstate
-            if reducer is not None:
-                model._grad_reducer = reducer
+        self.module = copy.deepcopy(model)          # VisionTransformer.__deepcopy__ leaves every executor cache behind (workspaces, graphs, tape)
         self.module.eval()
         self.decay = decay
         self.device = device

@@ -16,6 +16,7 @@ without a backward yet raise NotImplementedError there.
 """
 from __future__ import annotations
 
+import copy
 import ctypes as C
 from functools import partial
 from typing import List, Optional
@@ -135,6 +136,23 @@ class VisionTransformer(nn.Module):
         nn.init.trunc_normal_(self.pos_embed, std=.02)
         nn.init.trunc_normal_(self.cls_token, std=.02)
         self.apply(_init_vit_weights)
+
+    # ---- copies -----------------------------------------------------------------------------------
+    # executor caches (ctypes structs, GPU workspaces with captured hipGraphs, the tape / flat gradient buffer, noise buffers): state of
+    # THIS object's executor, rebuilt on demand.  A copy (copy.deepcopy: ModelEma, torch's swa_utils) starts without them: captured
+    # torch.cuda.CUDAGraph objects cannot be deep-copied at all, and a copied workspace would not belong to the copy's own packed weights.
+    _EXECUTOR_CACHES = {"_packed": None, "_ws": None, "_last_ws": None, "_tstate": None, "_grad_reducer": None, "_noise_buf": None,
+                        "_gumbel_buf": None, "_kmed_draws": None}
+
+    def __deepcopy__(self, memo):
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k in self._EXECUTOR_CACHES:
+                new.__dict__[k] = {} if k == "_ws" else None
+            else:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
 
     # ---- reference helper surface -------------------------------------------------------------
     def _set_keep(self, loc, k, rule):

@@ -214,6 +214,12 @@ def _attention_setup(ctx, inputs, output):
 def _attention_backward(ctx, dout, dcls):
     qkv, size = ctx.saved_tensors
     B, N, H = ctx.dims
+    if dcls is not None and bool(dcls.ne(0).any()):
+        # the second output (the CLS query's softmax rows, per head) is a side output for selection scores.  The native backward takes the
+        # gradient of their head MEAN only (tr_attention_bwd_bf16's `dcls`, what EViT's fused token needs: the model executor wires it);
+        # a per-head gradient has no kernel -- refuse instead of returning a gradient that silently lacks this path
+        raise NotImplementedError("tokenreduction_amd::attention: a gradient reached the `cls` output; only `out` is differentiable "
+                                  "through this op (EViT's cls_attn gradient is handled inside the model's training executor)")
     return torch.ops.tokenreduction_amd.attention_bwd(qkv, dout.contiguous(), B, N, H, size), None, None, None, None, None
 
 

@@ -6,7 +6,7 @@ that keeps its activations on a tape) and returns logits that carry an autograd 
 `tr_vit_backward`, which writes every parameter gradient into ONE flat fp32 buffer.  `p.grad` of every parameter is a view
 into that buffer, laid out in the order the backward finishes them (head, norm, blocks depth-1..0, embedding), so a
 data-parallel reducer can all-reduce contiguous slices in place while the rest of the backward is still running
-(dp.GradientAllReducer) -- no flatten/unflatten copies.
+(dp.FlatGradReducer) -- no flatten/unflatten copies.
 
 PyTorch is plumbing: memory, the stream, the autograd hook and the loss.  No arithmetic of the model happens in torch.
 """
@@ -68,6 +68,7 @@ class TrainState:
         self.tape = self.bws = None
         self.key = None
         self.events = None
+        self.gen = 0                 # counts training forwards: the tape belongs to the LAST one (see _VitTrainFn.backward)
 
     def _block_slices(self, model):
         """[(event_index, start, stop)] over the flat buffer: the slice event `e` of tr_vit_backward completes."""
@@ -218,6 +219,8 @@ class _VitTrainFn(torch.autograd.Function):
         B = x.shape[0]
         st = model._train_state()
         tape, bws = st.buffers(model, pk, B, x.device)
+        st.gen += 1
+        ctx.gen = st.gen
         ws = model._workspace(B, x.device)
         logits = torch.empty(B, model._classes_padded, dtype=torch.float32, device=x.device)
         tokens = (C.c_int * model.depth)()
@@ -254,6 +257,14 @@ class _VitTrainFn(torch.autograd.Function):
         model, B, pk = ctx.model, ctx.B, ctx.pk
         lib = _lib.load()
         st = model._train_state()
+        if ctx.gen != st.gen:
+            # the tape, the Gumbel / DPC-KNN noise and the workspace belong to the model, not to the autograd node: a later train-mode
+            # forward has overwritten the activations and decisions this backward would read
+            raise RuntimeError(
+                f"{type(model).__name__}: backward() of training forward #{ctx.gen}, but forward #{st.gen} has run since and overwritten "
+                "the activation tape (one tape per model).  Call loss.backward() before the next model(x) in train mode; for several "
+                "forwards per step (two views, accumulated losses) run forward + backward per view and let the gradients accumulate, or "
+                "use model.eval() / torch.no_grad() for the forwards that need no gradient.")
         dev = st.flat.device
         if dlogits is None:
             dlogits = torch.zeros(B, model.num_classes, dtype=torch.float32, device=dev)
