@@ -151,6 +151,13 @@ GOLDEN_CASES = {
     "dyvit_small_train": dict(family="dyvit", embed_dim=384, depth=12, num_heads=6, num_classes=1000, dyvit_distill=True, train_only=True,
                               keep_rate=[0.7], reduction_loc=[3, 6, 9], batch=2, wseed=107, xseed=108,
                               qkv_gain=4.0, factory="dyvit_small_patch16_224"),
+    # DeiT-T width (D = 192, 3 heads: the *_tiny_* factory names): D/2 = 96 is not a multiple of the GEMMs' 64-deep K-step, so the
+    # predictor / slimming-module hidden layers run zero-padded to 128 -- in eval since round 2, through the tape and the backward
+    # since round 3 (models_act.py:280, :1375)
+    "dyvit_tiny_train": dict(family="dyvit", embed_dim=192, depth=4, num_heads=3, num_classes=16, dyvit_distill=True, train_only=True,
+                             keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=115, xseed=116, qkv_gain=5.0),
+    "sit_tiny": dict(family="sit", embed_dim=192, depth=4, num_heads=3, num_classes=16,
+                     keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=117, xseed=118, qkv_gain=5.0),
     # DPC-KNN (models/dpcknn.py): density-peak clustering + weighted merge BEFORE the block (noise recorded in the fixture)
     "dpcknn_micro": dict(family="dpcknn", embed_dim=128, depth=4, num_heads=2, num_classes=16,
                          keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=121, xseed=122, qkv_gain=6.0),
@@ -255,7 +262,8 @@ GRAD_CASES = ["deit_micro", "topk_micro", "evit_micro", "tome_micro", "dpcknn_mi
               "evit_small_kr07", "tome_small_r16", "deit_base", "dpcknn_base_kr05", "ats_base_kr05", "dyvit_micro_train", "dyvit_small_train", "kmedoids_micro", "heuristic_micro_l2", "topk_micro_droppath",
               "sit_micro", "patchmerger_micro", "sinkhorn_micro", "sit_small_kr07", "patchmerger_small_kr07", "sinkhorn_small_kr07",
               "topk_micro_384", "kmedoids_micro_384", "ats_micro_384", "sinkhorn_micro_384",
-              "sinkhorn_micro_384_kr09", "dpcknn_micro_384_kr09", "sit_micro_384_kr07", "patchmerger_micro_384_kr07"]
+              "sinkhorn_micro_384_kr09", "dpcknn_micro_384_kr09", "sit_micro_384_kr07", "patchmerger_micro_384_kr07",
+              "dyvit_tiny_train", "sit_tiny"]
 
 
 def dyvit_token_ratio(case: dict):

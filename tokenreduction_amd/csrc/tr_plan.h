@@ -162,7 +162,7 @@ inline bool make_tape_plan(const tr_vit_config* c, int B, const TokenPlan& t, Ta
     if (soft && t.kk[i] > 0) {
       const size_t ld = soft_ld(t.kk[i]);
       b.pu = take(Tp * D * 2);
-      if (c->family == TR_FAMILY_SIT) { b.ppre0 = take(Tp * (D / 2) * 2); b.pcat = take(Tp * (D / 2) * 2); }
+      if (c->family == TR_FAMILY_SIT) { b.ppre0 = take(Tp * Hh * 2); b.pcat = take(Tp * Hh * 2); }     // hidden layer as packed (D/2 padded to 64)
       else b.sxh = take(Tp * D * 4);
       b.slog = take(Tp * ld * 4);
       b.swt = take(Tp * ld * 4);

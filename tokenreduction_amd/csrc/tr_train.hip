@@ -321,7 +321,9 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
       const tr_stage_weights* sw = &w->stage[i];
       const tr_stage_weights* swt = &wt->stage[i];
       const tr_stage_weights* sg = &grads->stage[i];
-      const int Hh = D / 2, Q = (D / 4 + 63) / 64 * 64, Cq = D / 4;
+      // Hr: the predictor's real hidden width (the shapes of the parameter gradients); Hh: as packed and as laid out on the tape
+      // (DeiT-T: 96 -> 128 with zero weights: the padded columns of every activation and gradient are zero)
+      const int Hr = D / 2, Hh = (D / 2 + 63) / 64 * 64, Q = (D / 4 + 63) / 64 * 64, Cq = D / 4;
       float* dpol = reinterpret_cast<float*>(ws + bp.dpol);
       float* dprev = reinterpret_cast<float*>(ws + bp.dprev);
       int stage = 0;
@@ -336,10 +338,10 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
                                  reinterpret_cast<const float*>(tape + bt.sm), U(tape + bt.ph2), Q, sw->w3, d2, dprev, F(sg->w3), F(sg->b3), acc, wsf,
                                  wsn, B, Na, Cq, s));
       TR_TRY(tr_gelu_bwd_bf16(U(tape + bt.ppre2), d2, (size_t)M1 * Q, s));
-      TR_TRY(tr_linear_bwd_params(d2, Q, 0, U(tape + bt.ph1), Hh, F(sg->w2), F(sg->b2), acc, wsf, wsn, M1, Cq, Hh, s));
+      TR_TRY(tr_linear_bwd_params(d2, Q, 0, U(tape + bt.ph1), Hh, F(sg->w2), F(sg->b2), acc, wsf, wsn, M1, Cq, Hr, s));
       uint16_t* d1 = dao;                     // [M1, Hh]
       TR_TRY(tr_gemm_dgelu_bf16(d2, U(swt->w2), U(tape + bt.ppre1), d1, M1, Hh, Q, s));
-      TR_TRY(tr_linear_bwd_params(d1, Hh, 0, U(tape + bt.pcat), D, F(sg->w1), F(sg->b1), acc, wsf, wsn, M1, Hh, D, s));
+      TR_TRY(tr_linear_bwd_params(d1, Hh, 0, U(tape + bt.pcat), D, F(sg->w1), F(sg->b1), acc, wsf, wsn, M1, Hr, D, s));
       TR_TRY(tr_gemm_bf16(d1, U(swt->w1), zeros, dxn, nullptr, 0, M1, D, Hh, TR_EPI_BF16, s));          // d [local | global]
       uint16_t* d0 = dh;                      // [M1, D]
       TR_TRY(tr_pool_policy_bwd(dxn, U(tape + bt.ppre0), U(tape + bt.pcat), prev, d0, dprev, B, Na, D, s));
@@ -375,11 +377,11 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
       else
         TR_TRY(tr_token_softmax_bwd(wts, dwt, slog, ld, sw->scale, ds, ld64, sit ? F(sg->b2) : nullptr, acc, wsf, wsn, B, Np, K, s));
       if (sit) {
-        const int Hh = D / 2;
+        const int Hr = D / 2, Hh = (D / 2 + 63) / 64 * 64;     // real / packed hidden width (DeiT-T: 96 / 128)
         uint16_t* d1 = dh;                    // [Mp, Hh]
-        TR_TRY(tr_linear_bwd_params(ds, ld64, 0, U(tape + bt.pcat), Hh, F(sg->w1), F(sg->b1), acc, wsf, wsn, Mp, ld, Hh, s));
+        TR_TRY(tr_linear_bwd_params(ds, ld64, 0, U(tape + bt.pcat), Hh, F(sg->w1), F(sg->b1), acc, wsf, wsn, Mp, ld, Hr, s));
         TR_TRY(tr_gemm_dgelu_bf16(ds, U(swt->w1), U(tape + bt.ppre0), d1, Mp, Hh, ld64, s));
-        TR_TRY(tr_linear_bwd_params(d1, Hh, 0, U(tape + bt.pu), D, F(sg->w0), F(sg->b0), acc, wsf, wsn, Mp, Hh, D, s));
+        TR_TRY(tr_linear_bwd_params(d1, Hh, 0, U(tape + bt.pu), D, F(sg->w0), F(sg->b0), acc, wsf, wsn, Mp, Hr, D, s));
         TR_TRY(tr_gemm_bf16(d1, U(swt->w0), zeros, dxn, nullptr, 0, Mp, D, Hh, TR_EPI_BF16, s));
       } else {
         // the similarity / score product: d queries (d centres) and d of its token operand

@@ -446,9 +446,11 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       const int M = B * N, Hh = sw->h_pad > 0 ? sw->h_pad : D / 2, Q = (D / 4 + 63) / 64 * 64;
       TR_REQUIRE(sw->ln_g && sw->ln_b && sw->w0 && sw->b0 && sw->w1 && sw->b1 && sw->w2 && sw->b2 && sw->w3 && sw->b3, TR_ERR_NULL,
                  "tr_vit_forward_train: block %d predictor weights missing", i);
-      TR_REQUIRE(Hh == D / 2 && sw->reserved_ == Q, TR_ERR_CONFIG,
-                 "tr_vit_forward_train: the DyViT training path needs D/2 %% 64 == 0 (DeiT-S / DeiT-B) and out_conv.2 packed to %d rows (got %d)", Q,
-                 sw->reserved_);
+      // Hh: the D/2 hidden layer as packed -- zero-padded to a multiple of 64 (DeiT-T: 96 -> 128; zero weight rows / columns and zero
+      // bias: the padded activations are gelu(0) = 0 and carry no gradient), like the D/4 layer is padded to Q rows
+      TR_REQUIRE(Hh >= D / 2 && Hh % 64 == 0 && Hh == (D / 2 + 63) / 64 * 64 && sw->reserved_ == Q, TR_ERR_CONFIG,
+                 "tr_vit_forward_train: the DyViT predictor must be packed with its hidden layers padded to %d / %d columns (got h_pad=%d, %d)",
+                 (D / 2 + 63) / 64 * 64, Q, sw->h_pad, sw->reserved_);
       TR_REQUIRE(noise_in != nullptr, TR_ERR_NULL, "tr_vit_forward_train: DyViT needs the Gumbel noise of every stage (noise_in)");
       float* x0 = reinterpret_cast<float*>(tape + bt.x0);
       uint16_t* pu = reinterpret_cast<uint16_t*>(tape + bt.pu);
@@ -474,12 +476,12 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       // a23 TRAINING: TokenSlimmingModule (sit.py:36-40) with every activation on the tape
       const tr_stage_weights* sw = &w->stage[i];
       const trplan::BlockTape& bt = tp->blk[i];
-      const int Kc = cfg->keep[i], M = B * N, Hh = D / 2;
+      const int Kc = cfg->keep[i], M = B * N, Hh = (D / 2 + 63) / 64 * 64;     // hidden width as packed (DeiT-T: 96 -> 128, zero padded)
       TR_REQUIRE(Kc <= N - 1, TR_ERR_CONFIG, "tr_vit_forward_train: block %d asks for %d of %d patch tokens", i, Kc, N - 1);
       TR_REQUIRE(sw->ln_g && sw->ln_b && sw->w0 && sw->b0 && sw->w1 && sw->b1, TR_ERR_NULL, "tr_vit_forward_train: block %d SiT weights missing", i);
-      TR_REQUIRE(sw->n_pad == trplan::soft_ld(Kc) && Hh % 64 == 0 && (sw->h_pad == 0 || sw->h_pad == Hh), TR_ERR_CONFIG,
-                 "tr_vit_forward_train: the SiT training path needs D/2 %% 64 == 0 and n_pad == %d (got h_pad=%d n_pad=%d)", trplan::soft_ld(Kc),
-                 sw->h_pad, sw->n_pad);
+      TR_REQUIRE(sw->n_pad == trplan::soft_ld(Kc) && (sw->h_pad == Hh || (sw->h_pad == 0 && Hh == D / 2)), TR_ERR_CONFIG,
+                 "tr_vit_forward_train: the SiT module must be packed with its hidden layer padded to %d columns and n_pad == %d (got h_pad=%d n_pad=%d)",
+                 Hh, trplan::soft_ld(Kc), sw->h_pad, sw->n_pad);
       float* x0 = reinterpret_cast<float*>(tape + bt.x0);
       float* slog = reinterpret_cast<float*>(tape + bt.slog);
       float* swt = reinterpret_cast<float*>(tape + bt.swt);

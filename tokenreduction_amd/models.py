@@ -665,12 +665,12 @@ class DynamicVisionTransformer(VisionTransformer):
             g.w3, g.b3 = ptr(pre + "out_conv.4.weight"), ptr(pre + "out_conv.4.bias")
 
     def _transposed_stage_weights(self, WT, t16):
-        qq = (self.embed_dim // 4 + 63) // 64 * 64
+        hh, qq = (self.embed_dim // 2 + 63) // 64 * 64, (self.embed_dim // 4 + 63) // 64 * 64      # hidden widths as packed (_pack_stages)
         for j, loc in enumerate(self.pruning_loc):
             sp, st = self.score_predictor[j], WT.stage[loc]
-            st.w0 = t16(sp.in_conv[1].weight)                               # [D, D]^T
-            st.w1 = t16(sp.out_conv[0].weight)                              # [D/2, D]^T -> [D, D/2]
-            st.w2 = t16(_pad_rows(sp.out_conv[2].weight, qq))               # [Q, D/2]^T -> [D/2, Q]
+            st.w0 = t16(sp.in_conv[1].weight)                                              # [D, D]^T
+            st.w1 = t16(_pad_rows(sp.out_conv[0].weight, hh))                              # [Hh, D]^T -> [D, Hh]
+            st.w2 = t16(_pad_rows(_pad_cols(sp.out_conv[2].weight, hh), qq))               # [Q, Hh]^T -> [Hh, Q]
 
     def get_reduction_count(self):
         return self.pruning_loc
@@ -776,8 +776,9 @@ class SelfSlimmedVisionTransformer(VisionTransformer):
     def _transposed_stage_weights(self, WT, t16):
         for j, loc in enumerate(self.cluster_loc):
             m, st = self.cluster_layers[j], WT.stage[loc]
-            st.w0 = t16(m.weight[1].weight)                                           # [D/2, D]^T
-            st.w1 = t16(_pad_rows(m.weight[3].weight, self._soft_pad(self.cluster_count[j])[1]))   # [K -> ld64, D/2]^T
+            hh = (m.weight[1].out_features + 63) // 64 * 64                           # hidden width as packed (DeiT-T: 96 -> 128)
+            st.w0 = t16(_pad_rows(m.weight[1].weight, hh))                            # [Hh, D]^T
+            st.w1 = t16(_pad_rows(_pad_cols(m.weight[3].weight, hh), self._soft_pad(self.cluster_count[j])[1]))   # [K -> ld64, Hh]^T
 
     def _stage_shapes(self):
         """[(blk, K, P_in)] per slimming stage."""

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One training step (forward, cross-entropy, backward) of every registered factory name on the GPU (B=4, random weights): finite loss,
-a finite gradient for every parameter, nothing raised except the documented limits (DyViT / SiT at DeiT-T width: D/2 % 64 != 0)."""
+a finite gradient for every parameter, nothing raised (no whitelist: since round 3 DyViT / SiT train at DeiT-T width too, their 96-wide
+hidden layers zero-padded to 128 through the tape and the backward)."""
 import os
 import sys
 import types
@@ -34,12 +35,7 @@ for name in tra.list_models():
         ok = bool(torch.isfinite(loss)) and not missing
         print(f"{name:36s} {'ok ' if ok else 'BAD'} loss {loss.item():.4f} tokens {m._last_tokens} {missing[:3]}")
         bad += not ok
-    except NotImplementedError as e:
-        expected = "tiny" in name and ("dyvit" in name or "sit" in name)
-        print(f"{name:36s} {'raises (documented limit)' if expected else 'RAISES'}: {str(e)[:110]}")
-        bad += not expected
     except Exception as e:   # noqa: BLE001
-        expected = "tiny" in name and ("dyvit" in name or "sit" in name)
-        print(f"{name:36s} {'raises (documented limit)' if expected else 'FAILED'} {type(e).__name__}: {str(e)[:150]}")
-        bad += not expected
+        print(f"{name:36s} FAILED {type(e).__name__}: {str(e)[:150]}")
+        bad += 1
 print("ALL OK" if not bad else f"{bad} FAILED")
