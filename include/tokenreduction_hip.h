@@ -474,7 +474,7 @@ int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w, const floa
  * tr_vit_forward_train: as tr_vit_forward, and every activation the backward needs is written to `tape` (tr_vit_tape_bytes(cfg, B)
  *   bytes, caller-owned; 0 = family / precision without a training path).  drop_scale (nullable, both calls get the same): DropPath
  *   (timm 0.4.12 drop_path, topk.py:78,87,95) as fp32 [2*depth, B]: entry [2i][b] / [2i+1][b] = the scale (0 or 1/keep_prob) of
- *   image b's attention / MLP branch in block i -- the random draw is the caller's.  Dropout (drop_rate) is not built.
+ *   image b's attention / MLP branch in block i -- the random draw is the caller's.  Dropout: see below.
  * tr_vit_backward: dlogits fp32 [B,classes] -> parameter gradients.  `w` = the forward's weights; `wt` = same struct with the block
  *   matrices TRANSPOSED (bf16: qkv_w [D,3D], proj_w [D,D], fc1_w [D,Hd], fc2_w [Hd,D]); `grads` = same struct, every pointer an
  *   fp32 buffer of the parameter's shape (written; added to when accumulate != 0).  workspace: tr_vit_backward_workspace_bytes.
@@ -485,7 +485,15 @@ int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w, const floa
 size_t tr_vit_tape_bytes(const tr_vit_config* cfg, int B);
 int tr_vit_forward_train(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits, void* workspace,
                          size_t workspace_bytes, void* tape, size_t tape_bytes, const float* noise_in, float* features_out,
-                         const float* drop_scale, int* tokens_out, int B, tr_stream_t s);
+                         const float* drop_scale, int* tokens_out, int B, tr_stream_t s, const uint8_t* dropout_keep, float drop_rate);
+/* Dropout (timm's drop_rate, train.py:46 --drop: pos_drop topk.py:186, proj_drop :53, the Mlp's two nn.Dropout): dropout_keep (nullable
+ * = drop_rate 0; both calls get the same) is the caller's keep mask, 1 byte per element (non-zero = keep), tr_vit_dropout_mask_bytes()
+ * bytes in the order the forward consumes them -- the embedded tokens [B,N0,D], then per block proj's output rows, the Mlp's hidden
+ * layer and its output: the order in which the reference module draws them.  Survivors are scaled by 1 / (1 - drop_rate).
+ * (attn_drop_rate -- dropout on the attention probabilities, topk.py:49 -- is not built; the reference's CLI cannot set it either.) */
+size_t tr_vit_dropout_mask_bytes(const tr_vit_config* cfg, int B);
+int tr_dropout_bf16(const uint16_t* src, uint16_t* dst, const uint8_t* keep, float mul, size_t n, tr_stream_t s);
+int tr_dropout_f32(const float* src, float* dst, const uint8_t* keep, float mul, size_t n, tr_stream_t s);
 /* Byte offsets of block blk's tape slots (x0,x1,xn1,qkv,ao,dattn,x2,xn2,pre,h,idx,idx2,scores,size) followed by its token counts
  * (entering, in attention, in the MLP) and its reduction count: lets a host read the decisions of a training forward. */
 int tr_vit_tape_layout(const tr_vit_config* cfg, int B, int blk, size_t* out18);
@@ -493,7 +501,7 @@ size_t tr_vit_backward_workspace_bytes(const tr_vit_config* cfg, int B);
 int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w, const tr_vit_weights* wt, const tr_vit_weights* grads,
                     const float* dlogits, const float* dpred, const float* dfeat, const float* drop_scale, const void* tape,
                     size_t tape_bytes, void* workspace, size_t workspace_bytes, int accumulate, int blk_hi, int blk_lo, int B,
-                    tr_stream_t s);
+                    tr_stream_t s, const uint8_t* dropout_keep, float drop_rate);
 
 #ifdef __cplusplus
 }

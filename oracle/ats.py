@@ -17,7 +17,7 @@ import torch
 import torch.nn.functional as F
 from torch.nn.utils.rnn import pad_sequence
 
-from .vit import VitConfig, _r, embed_tokens, head, layer_norm, mlp, patch_embed, round_bf16
+from .vit import dropout_site, VitConfig, _r, embed_tokens, head, layer_norm, mlp, patch_embed, round_bf16
 
 Tensor = torch.Tensor
 
@@ -118,7 +118,7 @@ def ats_block_forward(x: Tensor, mask: Tensor, p: Dict[str, Tensor], i: int, cfg
         o = (round_bf16(e) @ v) / e.sum(dim=-1, keepdim=True) if precision == "bf16" else attn @ v
     n_out = o.shape[2]
     o = _r(o.transpose(1, 2).reshape(B, n_out, D), precision)
-    x = x + _r(o @ _r(p[pre + "attn.proj.weight"], precision).t() + p[pre + "attn.proj.bias"], precision)
+    x = x + dropout_site(_r(o @ _r(p[pre + "attn.proj.weight"], precision).t() + p[pre + "attn.proj.bias"], precision), precision)
     xn2 = layer_norm(x, p[pre + "norm2.weight"], p[pre + "norm2.bias"], cfg.ln_eps, precision)
     x = x + mlp(xn2, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"], p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"],
                 precision)

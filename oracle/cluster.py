@@ -18,7 +18,7 @@ import torch
 
 import torch.nn.functional as F
 
-from .vit import VitConfig, _r, block_forward, embed_tokens, head, patch_embed
+from .vit import dropout_site, VitConfig, _r, block_forward, embed_tokens, head, patch_embed
 
 Tensor = torch.Tensor
 
@@ -256,7 +256,7 @@ def kmedoids_block_forward(x: Tensor, p: Dict[str, Tensor], i: int, cfg: VitConf
         attn = s.softmax(dim=-1)
         o = attn @ v
     o = _r(o.transpose(1, 2).reshape(B, N, D), precision)
-    x = x + _r(o @ _r(p[pre + "attn.proj.weight"], precision).t() + p[pre + "attn.proj.bias"], precision)
+    x = x + dropout_site(_r(o @ _r(p[pre + "attn.proj.weight"], precision).t() + p[pre + "attn.proj.bias"], precision), precision)
     xn2 = layer_norm(x, p[pre + "norm2.weight"], p[pre + "norm2.bias"], cfg.ln_eps, precision)
     x = x + mlp(xn2, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"], p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"],
                 precision)

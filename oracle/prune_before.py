@@ -22,7 +22,7 @@ from typing import Dict, Optional
 
 import torch
 
-from .vit import VitConfig, _r, block_forward, embed_tokens, gelu_erf, head, layer_norm, patch_embed, round_bf16
+from .vit import dropout_site, VitConfig, _r, block_forward, embed_tokens, gelu_erf, head, layer_norm, patch_embed, round_bf16
 
 Tensor = torch.Tensor
 LN_EPS_DEFAULT = 1e-5          # nn.LayerNorm(embed_dim) without eps: dyvit.py:97, sit.py:30
@@ -129,7 +129,7 @@ def dyvit_policy_block(x: Tensor, policy: Tensor, p: Dict[str, Tensor], i: int, 
     q, k, v = qkv.reshape(B, N, 3, H, D // H).permute(2, 0, 3, 1, 4).unbind(0)
     attn = dyvit_softmax_with_policy((q @ k.transpose(-2, -1)) * ((D // H) ** -0.5), policy)
     o = _r((_r(attn, precision) @ v).transpose(1, 2).reshape(B, N, D), precision)
-    x = x + _r(o @ _r(p[pre + "attn.proj.weight"], precision).t() + p[pre + "attn.proj.bias"], precision)
+    x = x + dropout_site(_r(o @ _r(p[pre + "attn.proj.weight"], precision).t() + p[pre + "attn.proj.bias"], precision), precision)
     xn2 = layer_norm(x, p[pre + "norm2.weight"], p[pre + "norm2.bias"], cfg.ln_eps, precision)
     from .vit import mlp
     return x + mlp(xn2, p[pre + "mlp.fc1.weight"], p[pre + "mlp.fc1.bias"], p[pre + "mlp.fc2.weight"], p[pre + "mlp.fc2.bias"], precision)

@@ -91,10 +91,42 @@ def patch_embed(x: Tensor, w: Tensor, b: Tensor, patch: int, precision: str = "f
     return _r(cols, precision) @ _r(wm, precision).t() + b
 
 
+# Training-mode nn.Dropout (timm's drop_rate: pos_drop topk.py:186, proj_drop :53, the Mlp's two nn.Dropout) REPLAYED with recorded keep
+# masks: inside `with dropout_replay(masks, p):` every dropout site of the trunk takes the next mask (in the reference module's call
+# order) and scales the survivors by 1 / (1 - p), like F.dropout.  Outside the context the sites are the identity (eval).
+_DROPOUT = None
+
+
+class dropout_replay:
+    def __init__(self, masks, p: float):
+        self.masks, self.p = list(masks), float(p)
+
+    def __enter__(self):
+        global _DROPOUT
+        _DROPOUT = (iter(self.masks), self.p, self)
+        self.used = 0
+        return self
+
+    def __exit__(self, *exc):
+        global _DROPOUT
+        _DROPOUT = None
+        if exc[0] is None and self.used != len(self.masks):
+            raise AssertionError(f"dropout_replay: {self.used} of {len(self.masks)} recorded masks consumed")
+
+
+def dropout_site(x: Tensor, precision: str = "fp32") -> Tensor:
+    if _DROPOUT is None:
+        return x
+    it, p, ctx = _DROPOUT
+    m = torch.as_tensor(next(it)).to(x.dtype).reshape(x.shape)
+    ctx.used += 1
+    return _r(x * m * (1.0 / (1.0 - p)), precision)
+
+
 def embed_tokens(tok: Tensor, cls_token: Tensor, pos_embed: Tensor) -> Tensor:
-    """topk.py:183-186: cat(cls.expand, x) + pos_embed; pos_drop is identity in eval."""
+    """topk.py:183-186: cat(cls.expand, x) + pos_embed; pos_drop is identity in eval (training: dropout_replay)."""
     B = tok.shape[0]
-    return torch.cat((cls_token.expand(B, -1, -1), tok), dim=1) + pos_embed
+    return dropout_site(torch.cat((cls_token.expand(B, -1, -1), tok), dim=1) + pos_embed)
 
 
 def layer_norm(x: Tensor, w: Tensor, b: Tensor, eps: float, precision: str = "fp32") -> Tensor:
@@ -134,13 +166,13 @@ def attention(xn: Tensor, qkv_w: Tensor, qkv_b: Tensor, proj_w: Tensor, proj_b: 
         o = attn @ v
     o = _r(o.transpose(1, 2).reshape(B, N, D), precision)
     out = _r(o @ _r(proj_w, precision).t() + proj_b, precision)   # bf16 mode: the Linear output is stored in bf16
-    return out, attn[:, :, 0, :]
+    return dropout_site(out, precision), attn[:, :, 0, :]
 
 
 def mlp(xn: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor, precision: str = "fp32") -> Tensor:
     """timm Mlp: fc1 -> GELU(erf) -> fc2 (dropouts are identity in eval)."""
-    h = _r(gelu_erf(xn @ _r(w1, precision).t() + b1), precision)
-    return _r(h @ _r(w2, precision).t() + b2, precision)
+    h = dropout_site(_r(gelu_erf(xn @ _r(w1, precision).t() + b1), precision), precision)
+    return dropout_site(_r(h @ _r(w2, precision).t() + b2, precision), precision)
 
 
 def head(x: Tensor, norm_w: Tensor, norm_b: Tensor, head_w: Tensor, head_b: Tensor,
@@ -302,7 +334,7 @@ def tome_attention(xn: Tensor, qkv_w: Tensor, qkv_b: Tensor, proj_w: Tensor, pro
     else:
         o = s.softmax(dim=-1) @ v
     o = _r(o.transpose(1, 2).reshape(B, N, D), precision)
-    out = _r(o @ _r(proj_w, precision).t() + proj_b, precision)
+    out = dropout_site(_r(o @ _r(proj_w, precision).t() + proj_b, precision), precision)
     return out, k.mean(1)
 
 

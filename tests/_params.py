@@ -145,6 +145,14 @@ GOLDEN_CASES = {
     # DropPath in training (timm drop_path, topk.py:78,87,95; train.py's default --drop-path 0.1): gradient fixture only
     "topk_micro_droppath": dict(family="topk", embed_dim=128, depth=4, num_heads=2, num_classes=16, drop_path=0.3, train_only=True,
                                 keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=6, wseed=13, xseed=14, qkv_gain=6.0),
+    # Dropout in training (timm's drop_rate, train.py:46 --drop: pos_drop topk.py:186, proj_drop :53, the Mlp's two nn.Dropout), the
+    # first one together with DropPath.  Gradient fixtures only; the reference's keep masks are recorded with them (bit-packed) and
+    # replayed by the oracle and by the HIP executor.  (Not ATS: its reference masks have the data-dependent batch-max row count,
+    # ats.py:77-78, the executor's the static bound -- ATS with dropout is covered by the every-family smoke test only.)
+    "topk_micro_dropout": dict(family="topk", embed_dim=128, depth=4, num_heads=2, num_classes=16, drop_rate=0.1, drop_path=0.2, train_only=True,
+                               keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=4, wseed=15, xseed=16, qkv_gain=6.0),
+    "evit_micro_dropout": dict(family="evit", embed_dim=128, depth=4, num_heads=2, num_classes=16, drop_rate=0.15, train_only=True,
+                               keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=17, xseed=18, qkv_gain=6.0),
     # DyViT TRAINING (dyvit.py:221-229, 257-261) with the distillation outputs: gradient fixtures only (grad_<name>.npz)
     "dyvit_micro_train": dict(family="dyvit", embed_dim=128, depth=4, num_heads=2, num_classes=16, dyvit_distill=True, train_only=True,
                               keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=105, xseed=106, qkv_gain=6.0),
@@ -263,7 +271,7 @@ GRAD_CASES = ["deit_micro", "topk_micro", "evit_micro", "tome_micro", "dpcknn_mi
               "sit_micro", "patchmerger_micro", "sinkhorn_micro", "sit_small_kr07", "patchmerger_small_kr07", "sinkhorn_small_kr07",
               "topk_micro_384", "kmedoids_micro_384", "ats_micro_384", "sinkhorn_micro_384",
               "sinkhorn_micro_384_kr09", "dpcknn_micro_384_kr09", "sit_micro_384_kr07", "patchmerger_micro_384_kr07",
-              "dyvit_tiny_train", "sit_tiny"]
+              "dyvit_tiny_train", "sit_tiny", "topk_micro_dropout", "evit_micro_dropout"]
 
 
 def dyvit_token_ratio(case: dict):
@@ -317,7 +325,29 @@ def drop_path_scale(case: dict, draws):
     return (keep + draws).floor() / keep
 
 
-def oracle_param_grads(case: dict, forced=None, precision: str = "fp32", noise=None):
+def dropout_masks(g):
+    """The reference's nn.Dropout keep masks of a gradient fixture, in call order: list of uint8 arrays (flat), or None."""
+    if "dropkeep" not in g.files:
+        return None
+    sizes = [int(v) for v in g["dropkeep_sizes"]]
+    bits = np.unpackbits(g["dropkeep"])[: sum(sizes)]
+    out, o = [], 0
+    for n in sizes:
+        out.append(bits[o: o + n].copy())
+        o += n
+    return out
+
+
+def oracle_param_grads(case: dict, forced=None, precision: str = "fp32", noise=None, dropout=None):
+    """dropout: the recorded keep masks (dropout_masks) of a case with drop_rate."""
+    if dropout is not None:
+        import oracle.vit as ovit
+        with ovit.dropout_replay([torch.from_numpy(m) for m in dropout], case["drop_rate"]):
+            return _oracle_param_grads(case, forced, precision, noise)
+    return _oracle_param_grads(case, forced, precision, noise)
+
+
+def _oracle_param_grads(case: dict, forced=None, precision: str = "fp32", noise=None):
     """Parameter gradients of cross-entropy(oracle logits, grad_labels) by torch.autograd over the oracle's functional forward
     (the reference's backward IS torch.autograd over its eager forward, engine.py:60-76).  Returns (loss, logits, {name: grad}).
     noise: DPC-KNN's density draws {blk: [B,P_in]} (the reference's torch.rand calls, recorded with the fixture)."""

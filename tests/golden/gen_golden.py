@@ -157,6 +157,8 @@ def build_reference(case):
                 kw["dyvit_distillation"] = True
             if case.get("drop_path"):
                 kw["drop_path_rate"] = float(case["drop_path"])
+            if case.get("drop_rate"):
+                kw["drop_rate"] = float(case["drop_rate"])
             m = CLASSES[case["family"]](**kw)
     m.viz_mode = True
     cfg = types.SimpleNamespace(embed_dim=case["embed_dim"], depth=case["depth"], num_heads=case["num_heads"],
@@ -328,12 +330,23 @@ def run_grad_case(name, case):
         y_hard = torch.zeros_like(logits, memory_format=torch.legacy_contiguous_format).scatter_(dim, index, 1.0)
         return y_hard - y_soft.detach() + y_soft
     torch.nn.functional.gumbel_softmax = gs_spy
+    keeps = []
+    orig_drop = torch.nn.functional.dropout
+
+    def drop_spy(inp, p=0.5, training=True, inplace=False):     # nn.Dropout -> F.dropout with the keep mask drawn here and recorded
+        if not training or p == 0.0:
+            return inp
+        keep = torch.rand_like(inp) >= p                          # (rand_like, not torch.rand: RandSpy's DropPath record stays clean)
+        keeps.append(keep.reshape(-1).to(torch.uint8))
+        return inp * keep.to(inp.dtype) * (1.0 / (1.0 - p))
+    torch.nn.functional.dropout = drop_spy
     try:
         with RandSpy() as rspy:
             out = m(x)
     finally:
         ref_ats.AdaptiveTokenSampling.forward = orig_ats
         torch.nn.functional.gumbel_softmax = orig_gs
+        torch.nn.functional.dropout = orig_drop
     logits = out[0] if isinstance(out, (tuple, list)) else out
     if case["family"] == "dyvit":
         loss = dyvit_train_loss(out, labels, case)
@@ -347,6 +360,9 @@ def run_grad_case(name, case):
         rec[f"atsids_{n}"] = t.numpy().astype(np.int64)
     for n, t in enumerate(gumbels):
         rec[f"gumbel_{n}"] = t.numpy().astype(np.float32)
+    if keeps:
+        rec["dropkeep"] = np.packbits(torch.cat(keeps).numpy())
+        rec["dropkeep_sizes"] = np.array([k.numel() for k in keeps], dtype=np.int64)
     if case["family"] == "dyvit":
         for n, t in enumerate(out[3]):
             rec[f"pred_{n}"] = t.detach().numpy().astype(np.float32)      # the hard keep decisions of each stage [B,P]

@@ -47,7 +47,8 @@ def build_model(case):
             from functools import partial
             cls = partial(cls, dyvit_distillation=True)
         m = cls(img_size=case.get("img_size", 224), patch_size=16, embed_dim=case["embed_dim"], depth=case["depth"], num_heads=case["num_heads"], mlp_ratio=4,
-                qkv_bias=True, num_classes=case["num_classes"], drop_path_rate=float(case.get("drop_path", 0.0)), args=args)
+                qkv_bias=True, num_classes=case["num_classes"], drop_path_rate=float(case.get("drop_path", 0.0)),
+                drop_rate=float(case.get("drop_rate", 0.0)), args=args)
     cfg, params = case_params(case)
     m.load_state_dict(params, strict=True)
     m.viz_mode = True

@@ -56,11 +56,22 @@ def _noise(case, golden_dir):
     return {blk: torch.from_numpy(g[f"rand_{n}"]) for n, blk in enumerate(sorted(oracle.dpcknn_cluster_counts(case_config(case))))}
 
 
-def _train_step(case, noise=None):
+def _dropout(case, golden_dir):
+    """The reference's recorded nn.Dropout keep masks of a drop_rate case (gradient fixture), else None."""
+    if not case.get("drop_rate"):
+        return None
+    from tests._params import dropout_masks
+    name = [n for n, c in GOLDEN_CASES.items() if c is case][0]
+    return dropout_masks(np.load(os.path.join(golden_dir, f"grad_{name}.npz")))
+
+
+def _train_step(case, noise=None, dropout=None):
     from tokenreduction_amd import training
     model, params, cfg = build_model(case)
     model.viz_mode = False
     model.train()
+    if dropout is not None:
+        model.dropout_draws = dropout                       # the reference's keep masks, in its module call order
     if noise is not None and case.get("drop_path"):
         model.drop_path_draws = noise                       # the reference's DropPath draws [2*depth, B]
     elif noise is not None and case["family"] == "dyvit":
@@ -88,11 +99,12 @@ def _rel(a, b):
 def test_gradients_match_the_oracle_on_the_device_decisions(golden_dir, name):
     case = GOLDEN_CASES[name]
     noise = _noise(case, golden_dir)
-    model, logits, loss, decisions = _train_step(case, noise)
+    dropout = _dropout(case, golden_dir)
+    model, logits, loss, decisions = _train_step(case, noise, dropout)
     forced = {blk: (tuple(t.cpu() for t in d) if isinstance(d, tuple) else d.cpu()) for blk, d in decisions.items()}
     if case["family"] == "dyvit":          # the oracle indexes DyViT's stages 0..S-1
         forced = {j: forced[blk] for j, blk in enumerate(sorted(forced))}
-    o_loss, o_logits, o_grads = oracle_param_grads(case, forced=forced or None, precision="bf16", noise=noise)
+    o_loss, o_logits, o_grads = oracle_param_grads(case, forced=forced or None, precision="bf16", noise=noise, dropout=dropout)
     rl = _rel(logits, o_logits)
     print(f"\n[{name}] loss {loss:.5f} (oracle {o_loss:.5f}); logits rel L2 {rl:.3e}")
     assert rl < 3e-2
@@ -218,6 +230,32 @@ def test_eval_and_train_logits_agree():
     # same kernels except GELU as a separate pass on the bf16 pre-activation (one extra rounding of fc1's output, which can
     # also move a token across a Top-K boundary): measured 1.2e-2
     assert _rel(lt.cpu(), le.cpu()) < 3e-2
+
+
+def test_dropout_draws_its_own_masks_and_every_family_takes_it():
+    """Without recorded masks the keep mask is a fresh Bernoulli(1 - p) draw on the device: two steps differ, every gradient is finite,
+    eval ignores drop_rate; DyViT's policy-attention blocks go through the same dropout sites; attn_drop_rate still refuses."""
+    for name in ("topk_micro", "tome_micro", "ats_micro", "dyvit_micro_train", "sit_micro"):
+        case = dict(GOLDEN_CASES[name], drop_rate=0.2)
+        model, params, cfg = build_model(case)
+        model.viz_mode = False
+        x = make_images(case["batch"], 224, case["xseed"]).cuda()
+        y = grad_labels(case).cuda()
+        want_eval = model.eval()(x).clone()
+        model.train()
+        losses = []
+        for _ in range(2):
+            model.zero_grad(set_to_none=True)
+            out = model(x)
+            loss = torch.nn.functional.cross_entropy(out[0] if isinstance(out, tuple) else out, y)
+            loss.backward()
+            losses.append(loss.item())
+            assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in model.named_parameters() if "score_predictor" not in n), name
+        assert losses[0] != losses[1], (name, losses)                 # different masks
+        assert torch.equal(model.eval()(x), want_eval), name          # dropout is a training-time thing
+    model.attn_drop_rate = 0.1
+    with pytest.raises(NotImplementedError, match="attn_drop_rate"):
+        model.train()(x)
 
 
 def test_unsupported_configuration_raises_in_train_mode():

@@ -41,7 +41,8 @@ def fixture_inputs(case, g):
 def test_oracle_gradients_match_the_reference(golden_dir, name):
     g = np.load(os.path.join(golden_dir, f"grad_{name}.npz"))
     forced, noise = fixture_inputs(GOLDEN_CASES[name], g)
-    loss, logits, grads = oracle_param_grads(GOLDEN_CASES[name], forced=forced, noise=noise)
+    from tests._params import dropout_masks
+    loss, logits, grads = oracle_param_grads(GOLDEN_CASES[name], forced=forced, noise=noise, dropout=dropout_masks(g))
     assert abs(loss - float(g["loss"])) <= 1e-5 * max(1.0, abs(float(g["loss"])))
     # DeiT-B width (D = 768, depth 12, qkv gain 4): fp32 summation-order noise between nn.Linear's addmm and the oracle's matmul is
     # amplified to ~2e-4 on logits of magnitude ~2 (measured 2.2e-4 / 1.3e-4); the micro and DeiT-S cases stay below 3e-5

@@ -126,11 +126,15 @@ SIGNATURES = {
     "tr_ats_scatter": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tr_layernorm_bf16_to": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "tr_vit_tape_bytes": (_sz, [C.POINTER(TrVitConfig), _i]),
-    "tr_vit_forward_train": (_i, [C.POINTER(TrVitConfig), C.POINTER(TrVitWeights), _vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, C.POINTER(_i), _i, _vp]),
+    "tr_vit_forward_train": (_i, [C.POINTER(TrVitConfig), C.POINTER(TrVitWeights), _vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, C.POINTER(_i), _i, _vp,
+                                  _vp, _f]),
+    "tr_vit_dropout_mask_bytes": (_sz, [C.POINTER(TrVitConfig), _i]),
+    "tr_dropout_bf16": (_i, [_vp, _vp, _vp, _f, _sz, _vp]),
+    "tr_dropout_f32": (_i, [_vp, _vp, _vp, _f, _sz, _vp]),
     "tr_vit_tape_layout": (_i, [C.POINTER(TrVitConfig), _i, _i, C.POINTER(_sz)]),
     "tr_vit_backward_workspace_bytes": (_sz, [C.POINTER(TrVitConfig), _i]),
     "tr_vit_backward": (_i, [C.POINTER(TrVitConfig), C.POINTER(TrVitWeights), C.POINTER(TrVitWeights), C.POINTER(TrVitWeights), _vp, _vp, _vp,
-                             _vp, _vp, _sz, _vp, _sz, _i, _i, _i, _i, _vp]),
+                             _vp, _vp, _sz, _vp, _sz, _i, _i, _i, _i, _vp, _vp, _f]),
     "tr_rowscale_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "tr_reduce_partials_f32": (_i, [_vp, _i, _sz, _vp, _i, _vp]),
     "tr_pool_policy": (_i, [_vp, _vp, _i, _i, _i, _f, _vp]),

@@ -1299,6 +1299,34 @@ extern "C" int tr_reduce_partials_f32(const float* part, int S, size_t count, fl
   return TR_OK;
 }
 
+// nn.Dropout with the caller's keep mask (1 byte per element, non-zero = keep): dst = keep ? src * mul : 0, mul = 1 / (1 - p).  Eight
+// elements per thread: 16 bytes of bf16 (or 2 x 16 of fp32) and 8 mask bytes.  The product is rounded to bf16 once.
+__global__ __launch_bounds__(256) void dropout_bf16_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, const uint8_t* __restrict__ keep,
+                                                           float mul, size_t n8) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const uint4 v = reinterpret_cast<const uint4*>(src)[i];
+  const uint2 k = reinterpret_cast<const uint2*>(keep)[i];
+  const unsigned w[4] = {v.x, v.y, v.z, v.w};
+  const unsigned long long kb = ((unsigned long long)k.y << 32) | k.x;
+  unsigned o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float lo = ((kb >> (16 * j)) & 0xffull) ? __builtin_bit_cast(float, w[j] << 16) * mul : 0.f;
+    const float hi = ((kb >> (16 * j + 8)) & 0xffull) ? __builtin_bit_cast(float, w[j] & 0xffff0000u) * mul : 0.f;
+    o[j] = pack_bf16x2(lo, hi);
+  }
+  reinterpret_cast<uint4*>(dst)[i] = make_uint4(o[0], o[1], o[2], o[3]);
+}
+__global__ __launch_bounds__(256) void dropout_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, const uint8_t* __restrict__ keep, float mul,
+                                                          size_t n4) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4 v = reinterpret_cast<const float4*>(src)[i];
+  const unsigned k = reinterpret_cast<const unsigned*>(keep)[i];
+  reinterpret_cast<float4*>(dst)[i] = make_float4((k & 0xffu) ? v.x * mul : 0.f, (k & 0xff00u) ? v.y * mul : 0.f, (k & 0xff0000u) ? v.z * mul : 0.f,
+                                                  (k & 0xff000000u) ? v.w * mul : 0.f);
+}
 // dst[b, r, :] = src[b, r, :] * scale[b]: bf16 [B, rows, D] (dst may be src).  DropPath's per-image scaling (see the kernel).
 extern "C" int tr_rowscale_bf16(const uint16_t* src, uint16_t* dst, const float* scale, int B, int rows, int D, tr_stream_t s) {
   TR_REQUIRE(src && dst && scale, TR_ERR_NULL, "tr_rowscale_bf16: null pointer");
@@ -1306,5 +1334,26 @@ extern "C" int tr_rowscale_bf16(const uint16_t* src, uint16_t* dst, const float*
   const size_t cpi = (size_t)rows * D / 8, n = cpi * B;
   hipLaunchKernelGGL(rowscale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(s), src, dst, scale, n, cpi);
   TR_CHECK_LAUNCH("tr_rowscale_bf16");
+  return TR_OK;
+}
+
+// Dropout of the training path (timm's drop_rate: pos_drop, proj_drop, the Mlp's two nn.Dropout -- topk.py:186, :53) with the CALLER's
+// keep mask, forward and backward alike: dst = keep ? src * mul : 0 (dst may be src).  n elements, n % 8 == 0 (bf16) / n % 4 == 0 (fp32).
+extern "C" int tr_dropout_bf16(const uint16_t* src, uint16_t* dst, const uint8_t* keep, float mul, size_t n, tr_stream_t s) {
+  TR_REQUIRE(src && dst && keep, TR_ERR_NULL, "tr_dropout_bf16: null pointer");
+  TR_REQUIRE(n > 0 && n % 8 == 0, TR_ERR_SHAPE, "tr_dropout_bf16: element count must be a positive multiple of 8 (got %zu)", n);
+  TR_REQUIRE(tr_aligned16(src) && tr_aligned16(dst) && (reinterpret_cast<uintptr_t>(keep) & 7u) == 0, TR_ERR_ALIGN,
+             "tr_dropout_bf16: data must be 16-byte, the mask 8-byte aligned");
+  hipLaunchKernelGGL(dropout_bf16_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(s), src, dst, keep, mul, n / 8);
+  TR_CHECK_LAUNCH("tr_dropout_bf16");
+  return TR_OK;
+}
+extern "C" int tr_dropout_f32(const float* src, float* dst, const uint8_t* keep, float mul, size_t n, tr_stream_t s) {
+  TR_REQUIRE(src && dst && keep, TR_ERR_NULL, "tr_dropout_f32: null pointer");
+  TR_REQUIRE(n > 0 && n % 4 == 0, TR_ERR_SHAPE, "tr_dropout_f32: element count must be a positive multiple of 4 (got %zu)", n);
+  TR_REQUIRE(tr_aligned16(src) && tr_aligned16(dst) && (reinterpret_cast<uintptr_t>(keep) & 3u) == 0, TR_ERR_ALIGN,
+             "tr_dropout_f32: data must be 16-byte, the mask 4-byte aligned");
+  hipLaunchKernelGGL(dropout_f32_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(s), src, dst, keep, mul, n / 4);
+  TR_CHECK_LAUNCH("tr_dropout_f32");
   return TR_OK;
 }

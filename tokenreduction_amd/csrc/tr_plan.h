@@ -25,6 +25,11 @@ struct TokenPlan {
   int N0, P;
 };
 
+// rows of block i that go through attn.proj: the attended tokens, except ATS after a sampling stage, where only the sampled rows do (ats.py:86,129)
+inline size_t proj_rows(const tr_vit_config* c, const TokenPlan& t, int i) {
+  return (size_t)((c->family == TR_FAMILY_ATS && t.kk[i] > 0) ? t.n_mlp[i] : t.n_att[i]);
+}
+
 inline bool make_token_plan(const tr_vit_config* c, TokenPlan* t) {
   const int g = c->img_size / c->patch;
   t->P = g * g;

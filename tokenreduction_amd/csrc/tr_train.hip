@@ -121,8 +121,11 @@ extern "C" size_t tr_vit_backward_workspace_bytes(const tr_vit_config* cfg, int 
 extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w, const tr_vit_weights* wt, const tr_vit_weights* grads,
                                const float* dlogits, const float* dpred, const float* dfeat, const float* drop_scale, const void* tape_,
                                size_t tape_bytes, void* workspace, size_t workspace_bytes, int accumulate, int blk_hi, int blk_lo, int B,
-                               tr_stream_t s) {
+                               tr_stream_t s, const uint8_t* dropout_keep, float drop_rate) {
   TR_REQUIRE(cfg && w && wt && grads && dlogits && tape_ && workspace, TR_ERR_NULL, "tr_vit_backward: null pointer");
+  TR_REQUIRE((dropout_keep == nullptr) == (drop_rate == 0.f) && drop_rate >= 0.f && drop_rate < 1.f, TR_ERR_CONFIG,
+             "tr_vit_backward: dropout needs the forward's keep mask AND its drop_rate (got mask %p, rate %g)", (const void*)dropout_keep, (double)drop_rate);
+  const float drop_mul = dropout_keep != nullptr ? 1.0f / (1.0f - drop_rate) : 1.0f;
   TR_REQUIRE(cfg->precision == TR_PREC_BF16 && trplan::trainable_family(cfg->family), TR_ERR_CONFIG,
              "tr_vit_backward: family %d / precision %d has no training path", cfg->family, cfg->precision);
   trplan::TokenPlan t;
@@ -160,7 +163,7 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
   // The four parameter-gradient products of a block (fc2, fc1, proj, qkv) run as ONE launch after the attention backward, when all four dY
   // exist -- provided nothing has rewritten fc2's dY (the bf16 stream gradient gb) by then: norm2's backward writes its bf16 output into the
   // spare buffer instead and the two trade places.  With DropPath the scaled dY copies live in scratch that is reused: pairs then.
-  const bool four = drop_scale == nullptr;
+  const bool four = drop_scale == nullptr && dropout_keep == nullptr;    // the branches' dY are the stream gradient itself (no scaled / masked copies)
   auto plain_ln2 = [&](int j) {      // blocks whose norm2 backward writes gb in place (no gather / merge between norm2 and the stream)
     const bool gathers = (cfg->family == TR_FAMILY_TOPK || cfg->family == TR_FAMILY_EVIT || cfg->family == TR_FAMILY_TOME) && t.kk[j] > 0;
     return !gathers;
@@ -197,6 +200,10 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
       TR_REQUIRE(hipMemsetAsync(ws + bp.dpol, 0, (size_t)B * t.N0 * 4, st) == hipSuccess, TR_ERR_LAUNCH, "tr_vit_backward: memset failed");
   }
 
+  // dropout keep masks: the forward consumed them in order (tr_vit_dropout_mask_bytes): [pos | block 0: proj, hidden, fc2 | block 1: ...]
+  size_t drop_off[TR_MAX_DEPTH + 1];
+  drop_off[0] = (size_t)B * t.N0 * D;
+  for (int i = 0; i < cfg->depth; ++i) drop_off[i + 1] = drop_off[i] + (size_t)B * (trplan::proj_rows(cfg, t, i) * D + (size_t)t.n_mlp[i] * (Hd + D));
   for (int i = blk_hi; i >= blk_lo; --i) {
     const trplan::BlockTape& bt = tp.blk[i];
     const tr_block_weights* bw = &w->blocks[i];
@@ -210,7 +217,16 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
       TR_TRY(tr_rowscale_bf16(gb, dao, drop_scale + (size_t)(2 * i + 1) * B, B, Nm, D, s));
       gy = dao;
     }
+    const uint8_t* keep_proj = dropout_keep ? dropout_keep + drop_off[i] : nullptr;                                  // [B*n_proj, D]
+    const uint8_t* keep_h = dropout_keep ? keep_proj + (size_t)B * trplan::proj_rows(cfg, t, i) * D : nullptr;        // [M2, Hd]
+    const uint8_t* keep_fc2 = dropout_keep ? keep_h + (size_t)M2 * Hd : nullptr;                                      // [M2, D]
+    if (dropout_keep != nullptr) {    // the Mlp's second dropout (after fc2): the same mask on fc2's dY
+      TR_TRY(tr_dropout_bf16(gy, dao, keep_fc2, drop_mul, (size_t)M2 * D, s));
+      gy = dao;
+    }
     TR_TRY(tr_gemm_dgelu_bf16(gy, U(bwt->fc2_w), U(tape + bt.pre), dh, M2, Hd, D, s));          // d fc2 input, times gelu'(pre): d pre
+    if (dropout_keep != nullptr)      // ... and the first one (after the activation): d pre = (dY W) * keep/(1-p) * gelu'(pre), the factors commute
+      TR_TRY(tr_dropout_bf16(dh, dh, keep_h, drop_mul, (size_t)M2 * Hd, s));
     // fc2's and fc1's parameter gradients: both dY (gy, dh) exist now; launched here as a pair, or with proj's and qkv's further down
     tr_linear_grad LG[4];
     LG[0] = {gy, (long)D, U(tape + bt.h), (long)Hd, F(bg->fc2_w), F(bg->fc2_b), M2, D, Hd};
@@ -261,6 +277,10 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
     gy = gb;
     if (drop_scale != nullptr) {
       TR_TRY(tr_rowscale_bf16(gb, dh, drop_scale + (size_t)(2 * i) * B, B, Mp / B, D, s));
+      gy = dh;
+    }
+    if (dropout_keep != nullptr) {    // proj_drop (topk.py:53): the same mask on proj's dY
+      TR_TRY(tr_dropout_bf16(gy, dh, keep_proj, drop_mul, (size_t)Mp * D, s));
       gy = dh;
     }
     const uint16_t* gy_proj = gy;           // proj's dY: stays valid until norm1's backward rewrites gb (ATS: the swapped-out buffer)
@@ -418,6 +438,10 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
   }
   if (blk_lo > 0) return TR_OK;
   // ---- embedding (topk.py:181-186): g is d x0 [B, N0, D]
+  if (dropout_keep != nullptr) {      // pos_drop (topk.py:186): on the stream gradient and on its bf16 copy (the patch projection's dY)
+    TR_TRY(tr_dropout_f32(g, g, dropout_keep, drop_mul, (size_t)B * t.N0 * D, s));
+    TR_TRY(tr_dropout_bf16(gb, gb, dropout_keep, drop_mul, (size_t)B * t.N0 * D, s));
+  }
   TR_TRY(tr_embed_bwd(g, F(grads->pos_embed), F(grads->cls_token), acc, B, t.N0, D, s));
   TR_TRY(tr_linear_bwd_params(gb, D, t.P, U(tape + tp.cols), kcols, F(grads->patch_w), F(grads->patch_b), acc, wsf, wsn, B * t.P, D, kcols, s));
   return TR_OK;

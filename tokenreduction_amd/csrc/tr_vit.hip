@@ -224,7 +224,7 @@ extern "C" size_t tr_vit_workspace_bytes(const tr_vit_config* cfg, int B) {
 static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits, void* workspace,
                             size_t workspace_bytes, int32_t* kept_idx, int32_t* compl_idx, float* soft_out,
                             const float* noise_in, float* features_out, int* tokens_out, int B, tr_stream_t s, char* tape,
-                            const trplan::TapePlan* tp, const float* drop_scale = nullptr) {
+                            const trplan::TapePlan* tp, const float* drop_scale = nullptr, const uint8_t* drop_keep = nullptr, float drop_rate = 0.f) {
   Plan p;
   const bool train = tape != nullptr;
   TR_REQUIRE(cfg && w && img && logits && workspace, TR_ERR_NULL, "tr_vit_forward: null pointer");
@@ -266,6 +266,13 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
   TR_TRY(op_im2col(f32, img, cols, B, cfg->in_chans, cfg->img_size, cfg->img_size, cfg->patch, s));
   TR_TRY(op_gemm(prec, cols, w->patch_w, w->patch_b, x, w->pos_embed, p.P, B * p.P, D, p.kcols, TR_EPI_PATCH_F32, s));
   TR_TRY(tr_cls_pos_rows(w->cls_token, w->pos_embed, x, B, p.N0, D, s));
+  // Dropout (timm's drop_rate: pos_drop topk.py:186, proj_drop :53, the Mlp's two nn.Dropout): training only.  The caller draws the keep
+  // masks (1 byte per element, in forward order: tr_vit_dropout_mask_bytes); survivors are scaled by 1 / (1 - p) like nn.Dropout.
+  const float drop_mul = drop_keep != nullptr ? 1.0f / (1.0f - drop_rate) : 1.0f;
+  if (drop_keep != nullptr) {
+    TR_TRY(tr_dropout_f32(x, x, drop_keep, drop_mul, (size_t)B * p.N0 * D, s));
+    drop_keep += (size_t)B * p.N0 * D;
+  }
 
   int N = p.N0;
   const void* pending = nullptr;   // residual not yet added to x (the previous block's fc2 output)
@@ -605,6 +612,10 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
     } else {
       TR_TRY(op_gemm(prec, ao, bw->proj_w, bw->proj_b, dbuf, nullptr, 0, M, D, D, TR_EPI_BF16, s));
     }
+    if (drop_keep != nullptr) {      // proj_drop (topk.py:53), inside the attention module: before the branch's DropPath
+      TR_TRY(tr_dropout_bf16(static_cast<const uint16_t*>(dbuf), static_cast<uint16_t*>(dbuf), drop_keep, drop_mul, (size_t)B * Nn * D, s));
+      drop_keep += (size_t)B * Nn * D;
+    }
     if (drop_scale != nullptr)      // DropPath on the attention branch (topk.py:87): this block's per-image scale, first of its two draws
       TR_TRY(tr_rowscale_bf16(static_cast<const uint16_t*>(dbuf), static_cast<uint16_t*>(dbuf), drop_scale + (size_t)(2 * i) * B, B, Nn, D, s));
     if (K > 0) {
@@ -659,8 +670,16 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
     } else {
       TR_TRY(op_gemm(prec, xn, bw->fc1_w, bw->fc1_b, hbuf, nullptr, 0, M2, p.Hd, D, TR_EPI_GELU_BF16, s));
     }
+    if (drop_keep != nullptr) {      // timm Mlp: drop after the activation ...
+      TR_TRY(tr_dropout_bf16(static_cast<const uint16_t*>(hbuf), static_cast<uint16_t*>(hbuf), drop_keep, drop_mul, (size_t)M2 * p.Hd, s));
+      drop_keep += (size_t)M2 * p.Hd;
+    }
     dbuf = dbuf_shared;
     TR_TRY(op_gemm(prec, hbuf, bw->fc2_w, bw->fc2_b, dbuf, nullptr, 0, M2, D, p.Hd, TR_EPI_BF16, s));
+    if (drop_keep != nullptr) {      // ... and after fc2
+      TR_TRY(tr_dropout_bf16(static_cast<const uint16_t*>(dbuf), static_cast<uint16_t*>(dbuf), drop_keep, drop_mul, (size_t)M2 * D, s));
+      drop_keep += (size_t)M2 * D;
+    }
     if (drop_scale != nullptr)      // DropPath on the MLP branch (topk.py:95)
       TR_TRY(tr_rowscale_bf16(static_cast<const uint16_t*>(dbuf), static_cast<uint16_t*>(dbuf), drop_scale + (size_t)(2 * i + 1) * B, B, N, D, s));
     pending = dbuf;
@@ -730,8 +749,10 @@ extern "C" int tr_vit_tape_layout(const tr_vit_config* cfg, int B, int blk, size
 
 extern "C" int tr_vit_forward_train(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits, void* workspace,
                                     size_t workspace_bytes, void* tape, size_t tape_bytes, const float* noise_in, float* features_out,
-                                    const float* drop_scale, int* tokens_out, int B, tr_stream_t s) {
+                                    const float* drop_scale, int* tokens_out, int B, tr_stream_t s, const uint8_t* dropout_keep, float drop_rate) {
   TR_REQUIRE(cfg && tape, TR_ERR_NULL, "tr_vit_forward_train: null pointer");
+  TR_REQUIRE((dropout_keep == nullptr) == (drop_rate == 0.f) && drop_rate >= 0.f && drop_rate < 1.f, TR_ERR_CONFIG,
+             "tr_vit_forward_train: dropout needs a keep mask AND 0 < drop_rate < 1 (got mask %p, rate %g)", (const void*)dropout_keep, (double)drop_rate);
   TR_REQUIRE(cfg->precision == TR_PREC_BF16, TR_ERR_CONFIG, "tr_vit_forward_train: the training path is bf16 only");
   TR_REQUIRE(trplan::trainable_family(cfg->family), TR_ERR_CONFIG, "tr_vit_forward_train: family %d has no training path yet", cfg->family);
   trplan::TokenPlan t;
@@ -744,5 +765,17 @@ extern "C" int tr_vit_forward_train(const tr_vit_config* cfg, const tr_vit_weigh
                "tr_vit_forward_train: %d tokens in block %d (the training path holds 640, DyViT's policy attention 224)", t.n_att[i], i);
   TR_REQUIRE(features_out == nullptr || cfg->family == TR_FAMILY_DYVIT, TR_ERR_CONFIG, "tr_vit_forward_train: features_out is DyViT's distillation output");
   return vit_forward_impl(cfg, w, img, logits, workspace, workspace_bytes, nullptr, nullptr, nullptr, noise_in, features_out, tokens_out, B, s,
-                          static_cast<char*>(tape), &tp, drop_scale);
+                          static_cast<char*>(tape), &tp, drop_scale, dropout_keep, drop_rate);
+}
+
+// Bytes of the dropout keep mask of one training forward (1 byte per element, 1 = keep), in the order the forward consumes it:
+// the embedded tokens [B,N0,D] (pos_drop), then per block proj's output rows [B*n_proj,D], the Mlp's hidden layer [B*n_mlp,Hd] and its
+// output [B*n_mlp,D] -- the order in which the reference module draws them (topk.py:186, :53, timm Mlp).  0 = no training path.
+extern "C" size_t tr_vit_dropout_mask_bytes(const tr_vit_config* cfg, int B) {
+  trplan::TokenPlan t;
+  if (cfg == nullptr || B <= 0 || !trplan::make_token_plan(cfg, &t)) return 0;
+  const size_t D = (size_t)cfg->embed_dim, Hd = (size_t)cfg->mlp_hidden;
+  size_t n = (size_t)B * t.N0 * D;
+  for (int i = 0; i < cfg->depth; ++i) n += (size_t)B * (trplan::proj_rows(cfg, t, i) * D + (size_t)t.n_mlp[i] * (Hd + D));
+  return n;
 }

@@ -206,6 +206,26 @@ def drop_path_scales(model, B: int, dev):
     return scale.contiguous()
 
 
+def dropout_keep_mask(model, pk, B: int, dev):
+    """Dropout (timm's drop_rate; train.py:46 --drop): the keep mask of one training forward, uint8 (1 = keep), one byte per element in
+    the order the executor consumes it -- the embedded tokens [B,N0,D] (pos_drop, topk.py:186), then per block proj's output rows
+    (proj_drop, :53), the Mlp's hidden layer and its output (timm Mlp's two nn.Dropout): the order in which the reference module draws.
+    Returns None when drop_rate == 0.  `model.dropout_draws` (tests): the reference's recorded keep masks, in call order, used instead
+    of a fresh Bernoulli(1 - p) draw on the device."""
+    if not model.drop_rate:
+        return None
+    n = int(_lib.load().tr_vit_dropout_mask_bytes(C.byref(pk["cfg"]), B))
+    if n == 0:
+        raise NotImplementedError(f"{type(model).__name__}: no training path for this configuration")
+    draws = getattr(model, "dropout_draws", None)
+    if draws is not None:
+        keep = torch.cat([torch.as_tensor(d).reshape(-1).to(torch.uint8) for d in draws]).to(dev)
+        if keep.numel() != n:
+            raise ValueError(f"dropout_draws hold {keep.numel()} elements, this forward consumes {n}")
+        return keep.contiguous()
+    return torch.empty(n, dtype=torch.uint8, device=dev).bernoulli_(1.0 - float(model.drop_rate))
+
+
 class _VitTrainFn(torch.autograd.Function):
     """logits (+ DyViT's extra outputs) = model(x) with the backward wired to tr_vit_backward.  `anchor` only makes autograd call
     backward.  Outputs: (logits,) or for DyViT (logits, pred_0 .. pred_{S-1} [, features]): pred_j = the stage's hard keep decision
@@ -229,10 +249,12 @@ class _VitTrainFn(torch.autograd.Function):
         feats = torch.empty(B, model.patch_embed.num_patches + 1, model.embed_dim, dtype=torch.float32, device=x.device) if distill else None
         noise = model._gumbel_ptr(B, x.device) if dyvit else model._noise_ptr(B, x.device)
         ctx.drop = drop_path_scales(model, B, x.device)
+        ctx.keep_mask = dropout_keep_mask(model, pk, B, x.device)
         with torch.cuda.device(x.device):
             rc = lib.tr_vit_forward_train(C.byref(cfg), C.byref(pk["W"]), x.data_ptr(), logits.data_ptr(), ws["buf"].data_ptr(), ws["nbytes"],
                                           tape.data_ptr(), tape.numel(), noise, None if feats is None else feats.data_ptr(),
-                                          None if ctx.drop is None else ctx.drop.data_ptr(), tokens, B, torch.cuda.current_stream().cuda_stream)
+                                          None if ctx.drop is None else ctx.drop.data_ptr(), tokens, B, torch.cuda.current_stream().cuda_stream,
+                                          None if ctx.keep_mask is None else ctx.keep_mask.data_ptr(), float(model.drop_rate or 0.0))
         _lib.check(rc, "tr_vit_forward_train")
         model._last_tokens = list(tokens)
         ctx.model, ctx.B, ctx.pk = model, B, pk
@@ -303,7 +325,8 @@ class _VitTrainFn(torch.autograd.Function):
             for hi, lo, start, stop in ranges:
                 rc = lib.tr_vit_backward(C.byref(pk["cfg"]), C.byref(pk["W"]), C.byref(WT), C.byref(G), dl.data_ptr(),
                                          None if dpred is None else dpred.data_ptr(), None if dfeat is None else dfeat.data_ptr(),
-                                         None if ctx.drop is None else ctx.drop.data_ptr(), st.tape.data_ptr(), st.tape.numel(), st.bws.data_ptr(), st.bws.numel(), 1, hi, lo, B, stream)
+                                         None if ctx.drop is None else ctx.drop.data_ptr(), st.tape.data_ptr(), st.tape.numel(), st.bws.data_ptr(), st.bws.numel(), 1, hi, lo, B, stream,
+                                         None if ctx.keep_mask is None else ctx.keep_mask.data_ptr(), float(model.drop_rate or 0.0))
                 _lib.check(rc, "tr_vit_backward")
                 if reduce_now:
                     reducer.reduce_slice(st.flat, start, stop)
@@ -324,9 +347,10 @@ def train_forward(model, x: torch.Tensor) -> torch.Tensor:
         raise RuntimeError(f"input is on {x.device}: tokenreduction_amd has no CPU path (HIP kernels only)")
     if model.precision != "bf16":
         raise NotImplementedError("the training path is bf16 (fp32 accumulate); set model.precision = 'bf16'")
-    if model.drop_rate or model.attn_drop_rate:
-        raise NotImplementedError("dropout (drop_rate / attn_drop_rate) in the HIP training path is not built: construct the model with "
-                                  "drop_rate=0 (train.py's default --drop 0.0); DropPath (--drop-path) is supported")
+    if model.attn_drop_rate:
+        raise NotImplementedError("attn_drop_rate (dropout on the attention probabilities, topk.py:49) is not built in the HIP training path; "
+                                  "the reference's command line cannot set it either (train.py:46 exposes --drop only, which IS supported, "
+                                  "as is --drop-path)")
     x = x.detach().to(torch.float32).contiguous()
     anchor = torch.empty(0, dtype=torch.float32, device=x.device, requires_grad=True)
     out = _VitTrainFn.apply(anchor, x, model)
