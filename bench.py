@@ -107,7 +107,11 @@ def profile_forward(model, x, reps=5):
 
 def roofline_leg(model, x, reps=5):
     """Kernel table + roofline of the dominant kernel from profile_forward()."""
-    agg = profile_forward(model, x, reps)
+    roof, table, total_ms = roofline_from(profile_forward(model, x, reps), full=True)
+    return roof, table, total_ms
+
+
+def roofline_from(agg, full=False):
     total_ms = sum(a["ms"] for a in agg.values())
     table = {}
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
@@ -128,6 +132,10 @@ def roofline_leg(model, x, reps=5):
         roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
                     frac=round(ach / PEAK_HBM_GBPS, 4), traffic=None,
                     bytes_per_launch=a["bytes"] / a["launches"], avg_launch_us=round(1e3 * a["ms"] / a["launches"], 2))
+    roof["share_of_step"] = round(a["ms"] / total_ms, 4)
+    roof["traffic_source"] = "not collected for this config (PMC passes cover the headline config)"
+    if not full:
+        return dict(roof, profiled_ms_per_step=round(total_ms, 3))
     return roof, table, total_ms
 
 
@@ -180,6 +188,90 @@ def cpu_baseline_leg(model, budget_s=25.0):
     return dict(value=round(bs / med, 1), unit="images/s", cores=cores, kind="port",
                 sample=f"median of 30 timed forward passes (after 10 warm-up) of batch {bs} of the same model/config, fp32 torch-CPU "
                        f"oracle, {cores} of {avail} host threads, {sum(times):.1f} s timed")
+
+
+def oracle_forward(family, params, x, cfg, grad=False):
+    """The oracle's forward of `family` (the CPU restatement of the reference, test infrastructure: used here as the cpu_baseline only).
+    grad=True: the undecorated function under autograd (the public ones run under torch.no_grad())."""
+    import oracle
+    fn = {"topk": oracle.vit_forward, "tome": oracle.tome_forward, "ats": oracle.ats_forward, "dpcknn": oracle.dpcknn_forward,
+          "sinkhorn": oracle.sinkhorn_forward, "kmedoids": oracle.kmedoids_forward}[family]
+    f = fn.__wrapped__ if grad else fn
+    if family == "dpcknn":       # the density tie-break noise (dpcknn.py:71-72) is an input of the oracle: one torch.rand draw per stage
+        noise, prev = {}, cfg.num_patches
+        for blk, cnt in sorted(oracle.dpcknn_cluster_counts(cfg).items()):
+            noise[blk] = torch.rand(x.shape[0], prev, generator=torch.Generator().manual_seed(blk))
+            prev = cnt
+        return f(params, x, cfg, noise)
+    return f(params, x, cfg)
+
+
+def cpu_config_leg(model, family, keep_rate, loc, img_size, train, budget_s=10.0):
+    """cpu_baseline of one more BASELINE config: the oracle on a bounded sample (a few images, `budget_s` seconds of CPU work) of the same
+    model / config on this box's host cores; train=True: forward + cross-entropy + backward by torch.autograd over the oracle (the
+    reference's training step without the optimizer, engine.py:60-76)."""
+    import oracle
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(avail, 16)                      # what the headline leg's probe settles on (torch's pool collapses when oversubscribed)
+    torch.set_num_threads(cores)
+    params = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    cfg = oracle.VitConfig(family=family, img_size=img_size, embed_dim=model.embed_dim, depth=model.depth, num_heads=model.num_heads,
+                           num_classes=1000, keep_rate=list(keep_rate), reduction_loc=list(loc))
+    x = torch.randn(2, 3, img_size, img_size, generator=torch.Generator().manual_seed(1))
+    y = torch.tensor([1, 2])
+
+    def once():
+        if not train:
+            return oracle_forward(family, params, x, cfg)
+        leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        with torch.enable_grad():
+            loss = torch.nn.functional.cross_entropy(oracle_forward(family, leaves, x, cfg, grad=True), y)
+            loss.backward()
+        return loss
+    once()
+    times, t_start = [], time.perf_counter()
+    while len(times) < 3 or (time.perf_counter() - t_start < budget_s and len(times) < 30):
+        t0 = time.perf_counter()
+        once()
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    return dict(value=round(2 / med, 2), unit="images/s", cores=cores, kind="port",
+                sample=f"median of {len(times)} passes of batch 2 ({'forward + cross-entropy + backward (torch.autograd)' if train else 'eval forward'}), "
+                       f"fp32 torch-CPU oracle, {cores} of {avail} host threads, {sum(times):.1f} s timed")
+
+
+def train_roofline_leg(name, keep_rate, loc, batch, device, reps=3):
+    """Kernel table + roofline of the dominant kernel of one TRAINING step (forward with tape + backward; the optimizer's torch kernels are
+    not in the table) from the library's launch profiler."""
+    import ctypes as C
+    from tokenreduction_amd import _lib
+    lib = _lib.load()
+    model = build_model(name, keep_rate, loc, device).train()
+    x = torch.randn(batch, 3, 224, 224, generator=torch.Generator().manual_seed(200)).to(device)
+    y = torch.randint(0, 1000, (batch,), generator=torch.Generator().manual_seed(300)).to(device)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        torch.nn.functional.cross_entropy(model(x), y).backward()
+    step()
+    torch.cuda.synchronize()
+    cap = 8192
+    labels = C.create_string_buffer(cap * 48)
+    ms, fl, by = (C.c_float * cap)(), (C.c_double * cap)(), (C.c_double * cap)()
+    per_rep = []
+    for _ in range(reps):
+        _lib.check(lib.tr_profile_begin(torch.cuda.current_stream().cuda_stream), "tr_profile_begin")
+        step()
+        n = lib.tr_profile_end(cap, labels, ms, fl, by)
+        assert 0 < n <= cap, n
+        rep = {}
+        for i in range(n):
+            nm = labels.raw[i * 48:(i + 1) * 48].split(b"\0", 1)[0].decode()
+            a = rep.setdefault(nm, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            a["ms"] += ms[i]; a["flops"] += fl[i]; a["bytes"] += by[i]; a["launches"] += 1
+        per_rep.append(rep)
+    agg = {k: dict(per_rep[0][k], ms=sorted(r[k]["ms"] for r in per_rep)[reps // 2]) for k in per_rep[0]}
+    return roofline_from(agg), model
 
 
 def finetune_leg(name, keep_rate, loc, batch, device, dist, steps=8, warmup=3, img_size=224):
@@ -461,6 +553,37 @@ def main():
                                   "vs_bf16_product_path": round(x3_ips / ips, 3),
                                   "note": "same config as `value`; 3 MFMAs per product, fp32 activations, fp32 twins for every non-GEMM op"}
             rec["cpu_baseline"] = cpu_baseline_leg(model)
+            # SURVEY 8d asks the same three numbers (images/s, fraction of the dominant kernel's roofline, CPU baseline) for every BASELINE
+            # config, not only the headline: configs[2] ToMe r16 (eval), configs[3] DeiT-B ATS / DPC-KNN kr 0.5 (the per-GPU shape of the DP
+            # fine-tune: a training step at 128 images), configs[4] DeiT-B Sinkhorn / K-Medoids kr 0.25 at 384^2 (eval)
+            per = {}
+            tome_kr = [196 - 16 * (i + 1) for i in range(12)]
+            for label, name, fam, kr, loc, img, bsz in (
+                    ("configs[2] tome_small r16 eval B=256", "tome_small_patch16_224", "tome", tome_kr, list(range(12)), 224, 256),
+                    ("configs[4] sinkhorn_base kr0.25 384^2 eval B=64", "sinkhorn_base_patch16_224", "sinkhorn", [0.25], [3, 6, 9], 384, 64),
+                    ("configs[4] kmedoids_base kr0.25 384^2 eval B=64", "kmedoids_base_patch16_224", "kmedoids", [0.25], [3, 6, 9], 384, 64)):
+                m2 = build_model(name, kr, loc, dev, img_size=img)
+                xb = torch.randn(bsz, 3, img, img, generator=torch.Generator().manual_seed(7)).to(dev)
+                entry = {"images_per_s": round(quick_images_per_s(m2, xb), 1), "tokens_per_block": m2._last_tokens,
+                         "roofline": roofline_from(profile_forward(m2, xb, 3)),
+                         "cpu_baseline": cpu_config_leg(m2, fam, kr, loc, img, train=False)}
+                if img == 384:       # configs[4]: "DP inference throughput sweep" -- the per-GPU batch sweep (8 GPUs: x 8, no collective)
+                    sweep = {}
+                    for b2 in (32, 64, 128, 256):
+                        xs = torch.randn(b2, 3, img, img, generator=torch.Generator().manual_seed(8)).to(dev)
+                        sweep[str(b2)] = round(quick_images_per_s(m2, xs, iters=5, reps=2), 1)
+                        del xs
+                    entry["images_per_s_by_batch"] = sweep
+                per[label] = entry
+                del m2, xb
+            for label, name, fam, kr in (("configs[3] ats_base kr0.5 train step B=128", "ats_base_patch16_224", "ats", [0.5]),
+                                         ("configs[3] dpcknn_base kr0.5 train step B=128", "dpcknn_base_patch16_224", "dpcknn", [0.5])):
+                roof, m3 = train_roofline_leg(name, kr, [3, 6, 9], 128, dev)
+                ft = rec["finetune"].get(next(k for k in rec["finetune"] if k.startswith(name.split("_patch")[0])), {})
+                per[label] = {"images_per_s": ft.get("images_per_s"), "ms_per_step": ft.get("ms_per_step"), "roofline": roof,
+                              "cpu_baseline": cpu_config_leg(m3, fam, kr, [3, 6, 9], 224, train=True)}
+                del m3
+            rec["per_config"] = per
         try:        # RCCL writes its banner through C stdio: flush it first so the JSON line is the last thing on stdout
             import ctypes
             ctypes.CDLL(None).fflush(None)

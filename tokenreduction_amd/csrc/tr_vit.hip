@@ -12,6 +12,7 @@
 #include <string.h>
 #include <vector>
 #include "tr_common.h"
+#include <mutex>
 #include "tr_plan.h"
 
 static thread_local char g_err[512] = "";
@@ -29,32 +30,38 @@ extern "C" const char* tr_last_error(void) { return g_err; }
 namespace {
 struct ProfRec { char label[48]; double flops, bytes; };
 struct Prof {
-  bool on = false;
+  std::atomic<bool> on{false};
   hipStream_t st = nullptr;
   std::vector<hipEvent_t> ev;       // ev[0] = begin, ev[i+1] = after mark i
   std::vector<ProfRec> recs;
   size_t used = 0;
-  bool noted = false;
-  ProfRec note;
 };
-thread_local Prof g_prof;
+// ONE recording per process, whatever thread launches: a training step's forward runs on the caller's thread, its backward on the
+// autograd engine's device thread, and a recording started by the caller must see both (round 3: per-thread state recorded a third of
+// the step).  The launches of a recording are sequential on one stream; the mutex only keeps the vectors consistent.
+Prof g_prof;
+std::mutex g_prof_mu;
+thread_local ProfRec t_note;        // the pending note -> mark pair of this thread's current launch
+thread_local bool t_noted = false;
 }  // namespace
 
 void tr_prof_note(const char* label, double flops, double bytes) {
-  if (!g_prof.on) return;
-  snprintf(g_prof.note.label, sizeof(g_prof.note.label), "%s", label);
-  g_prof.note.flops = flops;
-  g_prof.note.bytes = bytes;
-  g_prof.noted = true;
+  if (!g_prof.on.load(std::memory_order_relaxed)) return;
+  snprintf(t_note.label, sizeof(t_note.label), "%s", label);
+  t_note.flops = flops;
+  t_note.bytes = bytes;
+  t_noted = true;
 }
 
 void tr_prof_mark(const char* label) {
   Prof& p = g_prof;
-  if (!p.on) return;
+  if (!p.on.load(std::memory_order_relaxed)) return;
   ProfRec r;
-  if (p.noted) r = p.note;
+  if (t_noted) r = t_note;
   else { snprintf(r.label, sizeof(r.label), "%s", label); r.flops = 0; r.bytes = 0; }
-  p.noted = false;
+  t_noted = false;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (!p.on.load(std::memory_order_relaxed)) return;
   if (p.used + 1 >= p.ev.size()) {
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
@@ -69,12 +76,15 @@ void tr_prof_mark(const char* label) {
 // HERE, so the first mark does not include the host time between tr_profile_begin and the executor's first launch.
 void tr_prof_restart() {
   Prof& p = g_prof;
-  if (p.on && p.used == 0) (void)hipEventRecord(p.ev[0], p.st);
+  if (!p.on.load(std::memory_order_relaxed)) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (p.on.load(std::memory_order_relaxed) && p.used == 0) (void)hipEventRecord(p.ev[0], p.st);
 }
 
-// Start recording the launches this thread enqueues on stream s (must not be capturing).
+// Start recording the launches the process enqueues on stream s through this library (must not be capturing).
 extern "C" int tr_profile_begin(tr_stream_t s) {
   Prof& p = g_prof;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   if (p.ev.empty()) {
     hipEvent_t e;
     TR_REQUIRE(hipEventCreate(&e) == hipSuccess, TR_ERR_LAUNCH, "tr_profile_begin: cannot create an event");
@@ -83,9 +93,9 @@ extern "C" int tr_profile_begin(tr_stream_t s) {
   p.st = static_cast<hipStream_t>(s);
   p.recs.clear();
   p.used = 0;
-  p.noted = false;
+  t_noted = false;
   TR_REQUIRE(hipEventRecord(p.ev[0], p.st) == hipSuccess, TR_ERR_LAUNCH, "tr_profile_begin: event record failed");
-  p.on = true;
+  p.on.store(true);
   return TR_OK;
 }
 
@@ -93,8 +103,9 @@ extern "C" int tr_profile_begin(tr_stream_t s) {
 // Returns the number of marks recorded (may exceed max; only max are written), or < 0 on error.
 extern "C" int tr_profile_end(int max, char* labels, float* ms, double* flops, double* bytes) {
   Prof& p = g_prof;
-  TR_REQUIRE(p.on, TR_ERR_CONFIG, "tr_profile_end: no recording is active");
-  p.on = false;
+  TR_REQUIRE(p.on.load(), TR_ERR_CONFIG, "tr_profile_end: no recording is active");
+  p.on.store(false);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   TR_REQUIRE(hipStreamSynchronize(p.st) == hipSuccess, TR_ERR_LAUNCH, "tr_profile_end: stream synchronize failed");
   const int n = (int)p.recs.size();
   for (int i = 0; i < n && i < max; ++i) {
