@@ -492,6 +492,12 @@ int tr_vit_forward_train(const tr_vit_config* cfg, const tr_vit_weights* w, cons
  * layer and its output: the order in which the reference module draws them.  Survivors are scaled by 1 / (1 - drop_rate).
  * (attn_drop_rate -- dropout on the attention probabilities, topk.py:49 -- is not built; the reference's CLI cannot set it either.) */
 size_t tr_vit_dropout_mask_bytes(const tr_vit_config* cfg, int B);
+/* fp32 master parameters -> the bf16 operand copies of the GEMMs, every matrix of a model in ONE launch (an optimizer step changes them
+ * all: engine.py:76-91).  Item i: src fp32 [rows, cols] contiguous -> dst bf16 [rows, cols] (nullable) and dst_t bf16 [cols, rows]
+ * (nullable: the transposed copy the data-gradient GEMMs read).  items / first are DEVICE arrays; first[i] = tiles before item i with
+ * ceil(rows/64) * ceil(cols/64) tiles per item, total_tiles = first[n_items]. */
+typedef struct tr_cast_item { const void* src; void* dst; void* dst_t; int rows, cols; } tr_cast_item;
+int tr_cast_pack_bf16(const tr_cast_item* items, const int* first, int n_items, int total_tiles, tr_stream_t s);
 int tr_dropout_bf16(const uint16_t* src, uint16_t* dst, const uint8_t* keep, float mul, size_t n, tr_stream_t s);
 int tr_dropout_f32(const float* src, float* dst, const uint8_t* keep, float mul, size_t n, tr_stream_t s);
 /* Byte offsets of block blk's tape slots (x0,x1,xn1,qkv,ao,dattn,x2,xn2,pre,h,idx,idx2,scores,size) followed by its token counts

@@ -409,3 +409,43 @@ def test_any_number_of_classes_trains_and_evaluates(classes):
     want_db = (torch.softmax(lt.detach().float(), -1) - torch.nn.functional.one_hot(y, classes).float()).mean(0)
     torch.testing.assert_close(model.head.bias.grad, want_db, atol=2e-3, rtol=2e-2)
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())
+
+
+def test_fused_optimizer_steps_reach_the_executor():
+    """torch's fused optimizers update parameters without bumping `_version`; the executor's operand copies must follow anyway (round 3:
+    they did not -- AdamW(fused=True) trained on the initial bf16 matrices).  Fused and unfused AdamW from the same start must walk the
+    same loss curve, the eval logits must move with the parameters, and workspaces / captured graphs survive the in-place repack."""
+    case = GOLDEN_CASES["topk_micro"]
+    x = make_images(case["batch"], 224, case["xseed"]).cuda()
+    y = grad_labels(case).cuda()
+    curves, finals = {}, {}
+    for fused in (False, True):
+        model, params, cfg = build_model(case)
+        model.viz_mode = False
+        e0 = model.eval()(x).clone()
+        model.train()
+        opt = torch.optim.AdamW(model.parameters(), lr=2e-3, weight_decay=0.05, fused=fused)
+        losses, ws_id = [], None
+        for it in range(5):
+            loss = torch.nn.functional.cross_entropy(model(x), y)
+            if it == 0:           # (the first training forward adds the transposed copies: one reallocation)
+                ws_id = id(next(iter(model._ws.values())))
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        curves[fused] = losses
+        e1 = model.eval()(x).clone()
+        finals[fused] = e1
+        assert not torch.equal(e0, e1), "eval logits did not move with the optimizer steps"
+        assert id(next(iter(model._ws.values()))) == ws_id, "the workspace (and its captured graph) was thrown away by a repack"
+        # the packed copies ARE the parameters, rounded
+        pk = model._pack()
+        w = model.blocks[1].mlp.fc1.weight.detach()
+        slot = [t for (i, kind), t in model._pack_slots.items() if kind == "w" and t.shape == w.shape]
+        assert any(torch.equal(t, w.to(torch.bfloat16)) for t in slot)
+        tq = pk["tblocks"][1][2]
+        assert torch.equal(tq, w.t().to(torch.bfloat16).contiguous())
+    print("\nunfused", [round(v, 4) for v in curves[False]], "\nfused  ", [round(v, 4) for v in curves[True]])
+    assert curves[True][-1] < curves[True][0] - 0.5
+    assert all(abs(a - b) < 5e-2 * max(1.0, abs(a)) for a, b in zip(curves[False], curves[True])), curves

@@ -129,6 +129,7 @@ SIGNATURES = {
     "tr_vit_forward_train": (_i, [C.POINTER(TrVitConfig), C.POINTER(TrVitWeights), _vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, C.POINTER(_i), _i, _vp,
                                   _vp, _f]),
     "tr_vit_dropout_mask_bytes": (_sz, [C.POINTER(TrVitConfig), _i]),
+    "tr_cast_pack_bf16": (_i, [_vp, _vp, _i, _i, _vp]),
     "tr_dropout_bf16": (_i, [_vp, _vp, _vp, _f, _sz, _vp]),
     "tr_dropout_f32": (_i, [_vp, _vp, _vp, _f, _sz, _vp]),
     "tr_vit_tape_layout": (_i, [C.POINTER(TrVitConfig), _i, _i, C.POINTER(_sz)]),

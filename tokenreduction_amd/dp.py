@@ -63,6 +63,8 @@ class FlatGradReducer:
         """DDP's construction-time broadcast: every rank starts from rank `src`'s parameters and buffers."""
         for t in list(model.parameters()) + list(model.buffers()):
             dist.broadcast(t.data, src=src, group=self.group)
+        if hasattr(model, "weights_changed"):
+            model.weights_changed()              # writes through .data do not bump the version counters the executor's pack cache reads
 
     @contextlib.contextmanager
     def no_sync(self):

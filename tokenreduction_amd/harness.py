@@ -103,8 +103,7 @@ class ModelEma:
         for e, m in zip(ema_v, model_v):
             if not e.is_floating_point():
                 e.copy_(m)
-        for p in self.module.parameters():                                        # the packed bf16 copies follow the new values
-            p._version                                                            # (in-place lerp_ already bumped every version)
+        self.module.weights_changed()                                             # the packed bf16 copies follow the new values
 
 
 def train_one_epoch(model, criterion, data_loader: Iterable, optimizer, device, epoch: int, lr_scheduler=None, max_norm: float = 0,

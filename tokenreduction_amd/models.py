@@ -142,13 +142,15 @@ class VisionTransformer(nn.Module):
     # THIS object's executor, rebuilt on demand.  A copy (copy.deepcopy: ModelEma, torch's swa_utils) starts without them: captured
     # torch.cuda.CUDAGraph objects cannot be deep-copied at all, and a copied workspace would not belong to the copy's own packed weights.
     _EXECUTOR_CACHES = {"_packed": None, "_ws": None, "_last_ws": None, "_tstate": None, "_grad_reducer": None, "_noise_buf": None,
-                        "_gumbel_buf": None, "_kmed_draws": None}
+                        "_gumbel_buf": None, "_kmed_draws": None, "_pack_slots": None, "_pack_table": None}
 
     def __deepcopy__(self, memo):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
             if k in self._EXECUTOR_CACHES:
+                if k in ("_pack_slots", "_pack_table"):
+                    continue
                 new.__dict__[k] = {} if k == "_ws" else None
             else:
                 new.__dict__[k] = copy.deepcopy(v, memo)
@@ -197,12 +199,25 @@ class VisionTransformer(nn.Module):
     def _param_key(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
-    def _pack(self):
+    def weights_changed(self):
+        """Tell the executor that parameter VALUES changed behind autograd's version counters.  Automatic after every backward pass (an
+        optimizer step follows: torch's fused optimizers -- AdamW(fused=True) -- update the parameters without bumping `_version`, which
+        round 2's packing cache keyed on: the bf16 operand copies went stale and training silently ran on the initial matrices).  Call it
+        yourself after writing into `p.data` through an API that does not bump versions."""
+        self._weights_dirty = True
+
+    def _pack(self, need_transposed=False):
+        """bf16 (or fp32) operand copies of every parameter the executor reads + the C structs.  The copies live in PERSISTENT buffers:
+        a repack after an optimizer step rewrites them in place -- one fused launch for all matrices (tr_cast_pack_bf16), transposed
+        copies for the data-gradient GEMMs included once training asked for them -- so addresses, workspaces and captured graphs survive."""
         if self.precision not in ("bf16", "fp32", "bf16x3"):
             raise ValueError("precision must be 'bf16', 'bf16x3' or 'fp32'")
         self._pre_pack()
-        key = (self.precision,) + self._param_key()
-        if self._packed is not None and self._packed["key"] == key:
+        if need_transposed:
+            self._want_transposed = True
+        want_t = bool(getattr(self, "_want_transposed", False)) and self.precision == "bf16"
+        key = (self.precision, want_t) + self._param_key()
+        if self._packed is not None and self._packed["key"] == key and not getattr(self, "_weights_dirty", False):
             return self._packed
         dev = self.pos_embed.device
         if dev.type != "cuda":
@@ -210,19 +225,57 @@ class VisionTransformer(nn.Module):
         if not isinstance(self.head, nn.Linear):
             raise NotImplementedError("num_classes == 0 (headless) is not supported by the executor")
         keep_alive = []
-
         wdt = torch.bfloat16 if self.precision == "bf16" else torch.float32
+        slots = self.__dict__.setdefault("_pack_slots", {})          # persistent operand buffers: {(call index, kind): tensor}
+        own = {p_.untyped_storage().data_ptr() for p_ in self.parameters()}      # storages that ARE parameters: always current, never copied
 
-        def w16(t):      # weight matrix in the executor's operand type
-            c = t.detach().to(wdt).contiguous()
-            keep_alive.append(c)
+        def live(t):
+            return t.dtype == torch.float32 and t.is_contiguous() and t.device == dev and t.untyped_storage().data_ptr() in own
+
+        state = {"i": 0, "moved": False}
+        fused = []                                                     # (fp32 source, bf16 slot, transposed bf16 slot or None)
+
+        def slot(kind, shape, dtype):
+            k = (state["i"], kind)
+            t = slots.get(k)
+            if t is None or t.shape != torch.Size(shape) or t.dtype != dtype or t.device != dev:
+                t = slots[k] = torch.zeros(shape, dtype=dtype, device=dev)
+                state["moved"] = True
+            return t
+
+        def w16(t, transposed=False):      # weight matrix in the executor's operand type; transposed=True: also its [cols, rows] copy
+            state["i"] += 1
+            t = t.detach()
+            if wdt == torch.float32:
+                if live(t):
+                    keep_alive.append(t)
+                    return t.data_ptr()           # the parameter's own storage: always current
+                c = slot("w", t.shape, torch.float32)
+                c.copy_(t)
+                return c.data_ptr()
+            c = slot("w", t.shape, torch.bfloat16)
+            ct = slot("t", (t.shape[1], t.shape[0]), torch.bfloat16) if (transposed and want_t) else None
+            if t.dim() == 2 and live(t) and t.numel() >= 4096:
+                fused.append((t, c, ct))
+            else:
+                c.copy_(t)
+                if ct is not None:
+                    ct.copy_(t.t())
+            if ct is not None:
+                tslots[state["i"]] = ct
             return c.data_ptr()
 
         def f32(t):
-            c = t.detach().to(torch.float32).contiguous()
-            keep_alive.append(c)
+            state["i"] += 1
+            t = t.detach()
+            if live(t):
+                keep_alive.append(t)
+                return t.data_ptr()               # the parameter's own storage: always current
+            c = slot("f", t.shape, torch.float32)
+            c.copy_(t)
             return c.data_ptr()
 
+        tslots = {}
         W = _lib.TrVitWeights()
         D = self.embed_dim
         W.patch_w = w16(self.patch_embed.proj.weight.reshape(D, -1))
@@ -233,15 +286,23 @@ class VisionTransformer(nn.Module):
         cpad = self._classes_padded
         W.head_w = w16(self.head.weight if cpad == self.num_classes else _pad_rows(self.head.weight, cpad))
         W.head_b = f32(self.head.bias if cpad == self.num_classes else _pad_vec(self.head.bias, cpad))
+        tblocks = []
         for i, blk in enumerate(self.blocks):
             b = W.blocks[i]
             b.ln1_g, b.ln1_b = f32(blk.norm1.weight), f32(blk.norm1.bias)
-            b.qkv_w, b.qkv_b = w16(blk.attn.qkv.weight), f32(blk.attn.qkv.bias)
-            b.proj_w, b.proj_b = w16(blk.attn.proj.weight), f32(blk.attn.proj.bias)
+            b.qkv_w, b.qkv_b = w16(blk.attn.qkv.weight, True), f32(blk.attn.qkv.bias)
+            tq = tslots.get(state["i"] - 1)
+            b.proj_w, b.proj_b = w16(blk.attn.proj.weight, True), f32(blk.attn.proj.bias)
+            tp_ = tslots.get(state["i"] - 1)
             b.ln2_g, b.ln2_b = f32(blk.norm2.weight), f32(blk.norm2.bias)
-            b.fc1_w, b.fc1_b = w16(blk.mlp.fc1.weight), f32(blk.mlp.fc1.bias)
-            b.fc2_w, b.fc2_b = w16(blk.mlp.fc2.weight), f32(blk.mlp.fc2.bias)
+            b.fc1_w, b.fc1_b = w16(blk.mlp.fc1.weight, True), f32(blk.mlp.fc1.bias)
+            t1 = tslots.get(state["i"] - 1)
+            b.fc2_w, b.fc2_b = w16(blk.mlp.fc2.weight, True), f32(blk.mlp.fc2.bias)
+            t2 = tslots.get(state["i"] - 1)
+            tblocks.append((tq, tp_, t1, t2))
         self._pack_stages(W, w16, f32, keep_alive)
+        if fused:
+            self._run_fused_pack(fused, dev, state["moved"])
         cfg = _lib.TrVitConfig()
         cfg.family = self._family
         cfg.img_size, cfg.patch = self.patch_embed.img_size[0], self.patch_embed.patch_size[0]
@@ -256,9 +317,32 @@ class VisionTransformer(nn.Module):
         cfg.sinkhorn_eps = float(getattr(self, "sinkhorn_eps", 0.0))
         for i in range(self.depth):
             cfg.keep[i] = int(self._keep[i])
-        self._packed = dict(key=key, W=W, cfg=cfg, keep_alive=keep_alive)
-        self._ws = {}
+        old = self._packed
+        gen = 1 if old is None else old.get("gen", 0) + 1
+        self._packed = dict(key=key, W=W, cfg=cfg, keep_alive=keep_alive, gen=gen, tblocks=tblocks if want_t else None)
+        self._weights_dirty = False
+        # workspaces and captured graphs hold the operand addresses: they survive a repack unless a buffer had to be (re)allocated or the
+        # configuration changed (first pack, precision switch, new head, new keep schedule)
+        if state["moved"] or old is None or bytes(old["cfg"]) != bytes(cfg):
+            self._ws = {}
         return self._packed
+
+    def _run_fused_pack(self, fused, dev, moved):
+        """All large matrices through ONE tr_cast_pack_bf16 launch; the item table lives on the device and is rebuilt only when an
+        address changed."""
+        tab = self.__dict__.get("_pack_table")
+        sig = tuple((t.data_ptr(), c.data_ptr(), 0 if ct is None else ct.data_ptr(), t.shape[0], t.shape[1]) for t, c, ct in fused)
+        if tab is None or tab["sig"] != sig:
+            items = np.zeros(len(fused), dtype=np.dtype([("src", "<u8"), ("dst", "<u8"), ("dst_t", "<u8"), ("rows", "<i4"), ("cols", "<i4")]))
+            first = np.zeros(len(fused) + 1, dtype=np.int32)
+            for n, (sp, dp, tp_, r, c) in enumerate(sig):
+                items[n] = (sp, dp, tp_, r, c)
+                first[n + 1] = first[n] + ((r + 63) // 64) * ((c + 63) // 64)
+            tab = self._pack_table = dict(sig=sig, items=torch.from_numpy(items.view(np.uint8).copy()).to(dev),
+                                          first=torch.from_numpy(first).to(dev), n=len(fused), tiles=int(first[-1]))
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().tr_cast_pack_bf16(tab["items"].data_ptr(), tab["first"].data_ptr(), tab["n"], tab["tiles"],
+                                                     torch.cuda.current_stream().cuda_stream), "tr_cast_pack_bf16")
 
     def _pack_stages(self, W, w16, f32, keep_alive):
         """Families with learned reduction modules fill W.stage[blk] (tr_stage_weights) here."""

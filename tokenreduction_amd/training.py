@@ -113,8 +113,10 @@ class TrainState:
         return G
 
     def transposed(self, model, pk):
-        """bf16 transposed copies of the block matrices (the dgrad GEMM operands), re-made when the parameters change."""
-        if self.key == pk["key"]:
+        """bf16 transposed copies of the block matrices (the dgrad GEMM operands): made by the model's own repack (models._pack with
+        need_transposed: persistent buffers rewritten by the same fused launch as the operand copies); the reduction modules' few small
+        matrices are transposed here whenever the pack generation changes."""
+        if self.key == pk["gen"]:
             return self.wt
         WT = _lib.TrVitWeights()
         keep = []
@@ -124,12 +126,11 @@ class TrainState:
             keep.append(c)
             return c.data_ptr()
 
-        for i, blk in enumerate(model.blocks):
+        for i, (tq, tp_, t1, t2) in enumerate(pk["tblocks"]):
             b = WT.blocks[i]
-            b.qkv_w, b.proj_w = t16(blk.attn.qkv.weight), t16(blk.attn.proj.weight)
-            b.fc1_w, b.fc2_w = t16(blk.mlp.fc1.weight), t16(blk.mlp.fc2.weight)
+            b.qkv_w, b.proj_w, b.fc1_w, b.fc2_w = tq.data_ptr(), tp_.data_ptr(), t1.data_ptr(), t2.data_ptr()
         model._transposed_stage_weights(WT, t16)
-        self.wt, self.wt_keep, self.key = WT, keep, pk["key"]
+        self.wt, self.wt_keep, self.key = WT, keep, pk["gen"]
         return WT
 
     def buffers(self, model, pk, B, dev):
@@ -234,7 +235,7 @@ class _VitTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, x, model):
         lib = _lib.load()
-        pk = model._pack()
+        pk = model._pack(need_transposed=True)
         cfg = pk["cfg"]
         B = x.shape[0]
         st = model._train_state()
@@ -339,6 +340,7 @@ class _VitTrainFn(torch.autograd.Function):
                 p.grad = st.views[n]
             elif p.grad.data_ptr() != st.views[n].data_ptr():
                 p.grad.add_(st.views[n])
+        model.weights_changed()          # an optimizer step follows; fused optimizers do not bump the version counters the pack cache reads
         return None, None, None
 
 
