@@ -109,7 +109,8 @@ int tr_attention_split(const float* qkv, float* out, float* cls_rows, const floa
 /* a11 (forward only): Policy_Attention.forward dyvit.py:53-67 with softmax_with_policy :39-51 -- the attention of DyViT's
  * TRAINING forward, where pruned tokens stay in the sequence and are masked by policy fp32 [B,N] of 1/0:
  *   attn = (exp(s - max_k s) * pol + eps/N) / (sum_k exp(s - max_k s) * pol + eps),  pol[q][k] = policy[k], 1 for k == q,
- * eps = 1e-6.  N <= 224 (bf16) / 256 (fp32).  Used by the DyViT training executor (backward: tr_attention_policy_bwd_bf16). */
+ * eps = 1e-6.  bf16: any N (beyond 224 tokens -- 384 x 384 inputs -- an online-softmax kernel over 128-key chunks); fp32: N <= 256.
+ * Used by the DyViT training executor (backward: tr_attention_policy_bwd_bf16 / tr_attention_policy_bwd_long_bf16). */
 int tr_attention_policy_bf16(const uint16_t* qkv, uint16_t* out, const float* policy, int B, int N, int H, tr_stream_t s);
 int tr_attention_policy_f32(const float* qkv, float* out, const float* policy, int B, int N, int H, tr_stream_t s);
 
@@ -358,7 +359,11 @@ int tr_dyvit_decide_bwd(const float* dkeep, const float* prev, const float* hard
                         const uint16_t* h2, int ldh, const float* w, uint16_t* dh2, float* dprev, float* dw, float* db, int accumulate,
                         float* ws, size_t ws_floats, int B, int N, int C, tr_stream_t s);
 int tr_attention_policy_bwd_bf16(const uint16_t* qkv, const uint16_t* dout, const float* policy, uint16_t* dqkv, float* dpol_part, int B,
-                                 int N, int H, tr_stream_t s);
+                                 int N, int H, tr_stream_t s);   /* N <= 224; dpol_part fp32 [B,H,N]: sum the heads with tr_head_sum */
+/* The same gradient for any N (the executor uses it beyond 224 tokens: DyViT training at 384 x 384): the key-blocked kernels of
+ * tr_attention_bwd_long_bf16 under the keep policy.  ws: tr_attention_bwd_long_workspace_floats(B,N,H) floats. */
+int tr_attention_policy_bwd_long_bf16(const uint16_t* qkv, const uint16_t* dout, const float* policy, uint16_t* dqkv, float* dpol_part,
+                                      float* ws, size_t ws_floats, int B, int N, int H, tr_stream_t s);
 int tr_head_sum(const float* part, float* dst, int B, int H, int N, tr_stream_t s);
 int tr_fill_f32(float* p, float v, size_t n, tr_stream_t s);
 int tr_add_patch_rows(float* dst, const float* src, int B, int N, tr_stream_t s);

@@ -156,6 +156,9 @@ GOLDEN_CASES = {
     # DyViT TRAINING (dyvit.py:221-229, 257-261) with the distillation outputs: gradient fixtures only (grad_<name>.npz)
     "dyvit_micro_train": dict(family="dyvit", embed_dim=128, depth=4, num_heads=2, num_classes=16, dyvit_distill=True, train_only=True,
                               keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=105, xseed=106, qkv_gain=6.0),
+    # ... and at 384 x 384 (577 tokens under the keep policy: the online-softmax policy attention and its key-blocked backward)
+    "dyvit_micro_train_384": dict(family="dyvit", embed_dim=128, depth=4, num_heads=2, num_classes=16, dyvit_distill=True, train_only=True,
+                                  img_size=384, keep_rate=[0.6], reduction_loc=[1, 2, 3], batch=2, wseed=125, xseed=126, qkv_gain=6.0),
     "dyvit_small_train": dict(family="dyvit", embed_dim=384, depth=12, num_heads=6, num_classes=1000, dyvit_distill=True, train_only=True,
                               keep_rate=[0.7], reduction_loc=[3, 6, 9], batch=2, wseed=107, xseed=108,
                               qkv_gain=4.0, factory="dyvit_small_patch16_224"),
@@ -271,7 +274,7 @@ GRAD_CASES = ["deit_micro", "topk_micro", "evit_micro", "tome_micro", "dpcknn_mi
               "sit_micro", "patchmerger_micro", "sinkhorn_micro", "sit_small_kr07", "patchmerger_small_kr07", "sinkhorn_small_kr07",
               "topk_micro_384", "kmedoids_micro_384", "ats_micro_384", "sinkhorn_micro_384",
               "sinkhorn_micro_384_kr09", "dpcknn_micro_384_kr09", "sit_micro_384_kr07", "patchmerger_micro_384_kr07",
-              "dyvit_tiny_train", "sit_tiny", "topk_micro_dropout", "evit_micro_dropout"]
+              "dyvit_tiny_train", "sit_tiny", "topk_micro_dropout", "evit_micro_dropout", "dyvit_micro_train_384"]
 
 
 def dyvit_token_ratio(case: dict):

@@ -249,6 +249,35 @@ def test_attention_bwd_long(ops, B, N, H, bias):
         assert rel_l2(got.float(), short.float()) <= 8e-3          # two roundings of P / dS apart
 
 
+@pytest.mark.parametrize("B,N,H", [(2, 577, 2), (1, 300, 3), (2, 197, 6), (2, 138, 2), (1, 40, 1), (1, 640, 1)])
+def test_attention_policy_bwd(ops, B, N, H):
+    """Backward of DyViT's training-time attention (Policy_Attention.softmax_with_policy, dyvit.py:39-67) against torch.autograd over
+    the oracle's restatement: d qkv and the per-key policy gradient (the straight-through Gumbel sample upstream makes the policy
+    differentiable, dyvit.py:223-224).  N <= 224: the register-resident kernel; beyond (384 x 384 inputs): the key-blocked one."""
+    import oracle
+    qkv = _randn(40, B * N, 3 * H * 64, dtype=torch.bfloat16)
+    dout = _randn(41, B * N, H * 64, dtype=torch.bfloat16)
+    policy = (torch.rand(B, N, generator=torch.Generator().manual_seed(5)) > 0.4).float()
+    policy[:, 0] = 1.0                                               # CLS is always kept (dyvit.py:226)
+    qf = qkv.float().cpu().requires_grad_(True)
+    pol = policy.clone().requires_grad_(True)
+    q, k, v = qf.view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    attn = oracle.dyvit_softmax_with_policy((q @ k.transpose(-2, -1)) * 0.125, pol.unsqueeze(-1))
+    out = (attn @ v).transpose(1, 2).reshape(B * N, H * 64)
+    out.backward(dout.float().cpu())
+    got, dpart = ops.attention_policy_bwd(qkv, dout, policy.cuda(), B, N, H)
+    want = qf.grad.view(B * N, 3, H * 64)
+    gv = got.float().cpu().view(B * N, 3, H * 64)
+    for i, nm in enumerate("qkv"):
+        r = rel_l2(gv[:, i], want[:, i])
+        assert r <= 1.2e-2, f"d{nm}: rel L2 {r:.3e}"
+    r = rel_l2(dpart.sum(1).cpu(), pol.grad)
+    assert r <= 1.2e-2, f"d policy: rel L2 {r:.3e}"
+    # the forward the executor pairs with it
+    fwd = ops.attention_policy(qkv, policy.cuda(), B, N, H)
+    torch.testing.assert_close(fwd.float().cpu(), out.detach(), atol=3e-2, rtol=2e-2)
+
+
 def test_head_and_embed_bwd(ops):
     B, Cc, D, N = 32, 1000, 384, 68
     dl = _randn(25, B, Cc, scale=0.01)

@@ -689,9 +689,10 @@ def test_softassign_merge_fast(ops, softmax, B, N, K, D, ldl):
         assert soft is None
 
 
-@pytest.mark.parametrize("B,N,H", [(2, 197, 6), (2, 138, 2), (1, 40, 3), (1, 224, 1)])
+@pytest.mark.parametrize("B,N,H", [(2, 197, 6), (2, 138, 2), (1, 40, 3), (1, 224, 1), (2, 577, 2), (1, 257, 1)])
 def test_attention_with_policy(ops, B, N, H):
-    """a11: DyViT's training-time attention (dyvit.py:39-67) against the oracle's restatement of softmax_with_policy."""
+    """a11: DyViT's training-time attention (dyvit.py:39-67) against the oracle's restatement of softmax_with_policy.  Beyond 224
+    tokens (384 x 384 inputs) the bf16 path is the online-softmax kernel; the fp32 twin holds 256."""
     rng = _rng(9000 + N)
     qkv = _bf(_randn(rng, B * N, 3 * H * 64, scale=1.5))
     policy = torch.from_numpy((rng.random((B, N)) > 0.4).astype(np.float32))
@@ -699,10 +700,12 @@ def test_attention_with_policy(ops, B, N, H):
     q, k, v = qkv.reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
     attn = oracle.dyvit_softmax_with_policy((q @ k.transpose(-2, -1)) * 0.125, policy.unsqueeze(-1))
     want = (attn @ v).transpose(1, 2).reshape(B * N, H * 64)
-    got32 = ops.attention_policy(qkv.cuda(), policy.cuda(), B, N, H)
-    torch.testing.assert_close(got32.cpu(), want, atol=2e-5, rtol=2e-5)
     got = ops.attention_policy(qkv.bfloat16().cuda(), policy.cuda(), B, N, H)
     torch.testing.assert_close(got.float().cpu(), want, atol=3e-2, rtol=2e-2)
+    if N > 256:
+        return
+    got32 = ops.attention_policy(qkv.cuda(), policy.cuda(), B, N, H)
+    torch.testing.assert_close(got32.cpu(), want, atol=2e-5, rtol=2e-5)
     # policy of all ones = plain softmax up to the eps smoothing
     ones = torch.ones(B, N)
     plain, _ = ops.attention_f32(qkv.cuda(), B, N, H)

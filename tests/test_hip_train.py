@@ -259,14 +259,12 @@ def test_dropout_draws_its_own_masks_and_every_family_takes_it():
 
 
 def test_unsupported_configuration_raises_in_train_mode():
-    """What the training path does not cover raises up front, never a fallback: DyViT at 384 x 384 (its policy attention holds a whole
-    score row in registers: <= 224 tokens)."""
-    for name in ("dyvit_micro_train",):
-        case = dict(GOLDEN_CASES[name], img_size=384)
-        model, params, cfg = build_model(case)
-        x = make_images(case["batch"], 384, case["xseed"]).cuda()
-        with pytest.raises(NotImplementedError, match="no training path"):
-            model.train()(x)
+    """What the training path does not cover raises up front, never a fallback: more than 640 tokens (448 x 448 inputs: 785)."""
+    case = dict(GOLDEN_CASES["topk_micro"], img_size=448)
+    model, params, cfg = build_model(case)
+    x = make_images(1, 448, case["xseed"]).cuda()
+    with pytest.raises(NotImplementedError, match="no training path"):
+        model.train()(x)
 
 
 @pytest.mark.parametrize("name", ["evit_micro", "ats_micro", "tome_micro", "kmedoids_micro", "sit_micro", "dpcknn_micro", "deit_micro"])

@@ -144,6 +144,7 @@ SIGNATURES = {
     "tr_dyvit_decide_bwd_workspace_floats": (_sz, [_i, _i, _i]),
     "tr_dyvit_decide_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _i, _i, _i, _vp]),
     "tr_attention_policy_bwd_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "tr_attention_policy_bwd_long_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
     "tr_head_sum": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "tr_fill_f32": (_i, [_vp, _f, _sz, _vp]),
     "tr_add_patch_rows": (_i, [_vp, _vp, _i, _i, _vp]),

@@ -827,12 +827,18 @@ constexpr int FRS = FKB * 64 + 16;           // V^T row stride in bytes
 #ifndef TR_FLASH_WGS
 #define TR_FLASH_WGS 3
 #endif
+// POLICY (DyViT training at 384^2, softmax_with_policy dyvit.py:39-51): `size` carries the keep policy [B,N]; with e = exp(s - max),
+//   a = e * pi (pi = policy[key], 1 on the diagonal): out = (sum_k a_k v_k + eps/N sum_k v_k) / (sum_k a_k + eps).  eps is relative to the
+//   TRUE row maximum, the accumulators to the integer reference point m >= max: eps' = eps 2^(max - m); sum_k v_k (all valid keys) is
+//   collected once per workgroup on the vector ALUs while the chunks pass through the LDS.
+template <bool POLICY>
 __global__ __launch_bounds__(256, TR_FLASH_WGS) void attention_flash_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
                                                                  float* __restrict__ cls_rows, const float* __restrict__ size,
                                                                  float* __restrict__ stats, int N, int H, int nqg) {
   __shared__ __attribute__((aligned(16))) unsigned char sK[FKB * 32 * 128];
   __shared__ __attribute__((aligned(16))) unsigned char sVt[64 * FRS];
   __shared__ float sLB[FKB * 32];
+  __shared__ float sVsum[POLICY ? 64 : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.x / nqg, qg = blockIdx.x - bh * nqg;
   const int b = bh / H, h = bh - b * H;
@@ -856,6 +862,7 @@ __global__ __launch_bounds__(256, TR_FLASH_WGS) void attention_flash_kernel(cons
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
   float m = -INFINITY, l = 0.f;                      // m: integer-valued reference point; l: this lane's share of the row sum
+  float mt = -INFINITY, vs = 0.f;                    // POLICY: the row's true maximum; this thread's share of sum_k v_k[d = tid >> 2]
   float* crow = (cls_rows != nullptr && qb == 0 && ql == 0) ? cls_rows + ((size_t)b * H + h) * N : nullptr;
 
   const int nch = (N + FKB * 32 - 1) / (FKB * 32);
@@ -880,7 +887,8 @@ __global__ __launch_bounds__(256, TR_FLASH_WGS) void attention_flash_kernel(cons
       }
       if (tid < FKB * 32) {
         const int key = key0 + tid;
-        sLB[tid] = (size != nullptr && key < N) ? __builtin_amdgcn_logf(size[(size_t)b * N + key]) : 0.f;
+        if (POLICY) sLB[tid] = key < N ? size[(size_t)b * N + key] : 0.f;
+        else sLB[tid] = (size != nullptr && key < N) ? __builtin_amdgcn_logf(size[(size_t)b * N + key]) : 0.f;
       }
 #pragma unroll
       for (int it = 0; it < FKB; ++it) {
@@ -903,6 +911,16 @@ __global__ __launch_bounds__(256, TR_FLASH_WGS) void attention_flash_kernel(cons
       }
     }
     __syncthreads();
+    if (POLICY) {              // sum_k v_k: row d = tid >> 2 of V^T, a quarter of the chunk's keys per thread (rows past N are zero)
+      const unsigned char* vrow = sVt + (tid >> 2) * FRS + (tid & 3) * (FKB * 16);
+#pragma unroll
+      for (int c = 0; c < FKB; ++c) {
+        const uint4 w = *reinterpret_cast<const uint4*>(vrow + 16 * c);
+        const unsigned int ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vs += __builtin_bit_cast(float, ww[e] << 16) + __builtin_bit_cast(float, ww[e] & 0xffff0000u);
+      }
+    }
     if (!live) continue;
 
     f32x16 sacc[FKB];
@@ -923,11 +941,12 @@ __global__ __launch_bounds__(256, TR_FLASH_WGS) void attention_flash_kernel(cons
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        sacc[kb][r] = sacc[kb][r] * c_exp + sLB[kl];          // log2-domain logit (+ log2 size[key]: proportional attention)
+        sacc[kb][r] = POLICY ? sacc[kb][r] * c_exp : sacc[kb][r] * c_exp + sLB[kl];   // log2-domain logit (+ log2 size[key]: proportional attention)
         if (key0 + kl >= N) sacc[kb][r] = -INFINITY;
         mx = fmaxf(mx, sacc[kb][r]);
       }
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (POLICY) mt = fmaxf(mt, mx);
     if (crow != nullptr) {
 #pragma unroll
       for (int kb = 0; kb < FKB; ++kb)
@@ -948,7 +967,11 @@ __global__ __launch_bounds__(256, TR_FLASH_WGS) void attention_flash_kernel(cons
     for (int kb = 0; kb < FKB; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(sacc[kb][r] - m_ref);
+        float pv = __builtin_amdgcn_exp2f(sacc[kb][r] - m_ref);
+        if (POLICY) {                                           // attn_policy = policy + (1 - policy) * eye
+          const int kl = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          pv *= (key0 + kl == q) ? 1.0f : sLB[kl];
+        }
         sacc[kb][r] = pv;
         lsum += pv;
       }
@@ -970,9 +993,24 @@ __global__ __launch_bounds__(256, TR_FLASH_WGS) void attention_flash_kernel(cons
         __builtin_amdgcn_sched_barrier(0);
       }
   }
+  if (POLICY) {
+    vs += __shfl_xor(vs, 1, 64);
+    vs += __shfl_xor(vs, 2, 64);
+    if ((tid & 3) == 0) sVsum[tid >> 2] = vs;
+    __syncthreads();
+  }
   if (!live) return;
   l += __shfl_xor(l, 32, 64);
-  const float inv = 1.0f / l;
+  float inv = 1.0f / l;
+  if (POLICY) {
+    const float eps = 1e-6f * __builtin_amdgcn_exp2f(mt - m);          // (attn + eps/N) / (sum + eps), eps in the accumulators' units
+    const float add = eps / (float)N;
+    inv = 1.0f / (l + eps);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] += add * sVsum[db * 32 + 8 * (r >> 2) + 4 * hh + (r & 3)];
+  }
   if (q < N) {
     uint16_t* orow = out + ((size_t)b * N + q) * (H * 64) + h * 64 + 4 * hh;
 #pragma unroll
@@ -1143,7 +1181,7 @@ extern "C" int tr_attention_bf16(const uint16_t* qkv, uint16_t* out, float* cls_
 #endif
   if (N >= flash_min && (colsum_part == nullptr || size == nullptr)) {
     const int nqg = ((N + 31) / 32 + 3) / 4;
-    hipLaunchKernelGGL(attention_flash_kernel, dim3(B * H * nqg), dim3(256), 0, st, qkv, out, cls_rows, size, colsum_part, N, H, nqg);
+    hipLaunchKernelGGL(attention_flash_kernel<false>, dim3(B * H * nqg), dim3(256), 0, st, qkv, out, cls_rows, size, colsum_part, N, H, nqg);
     if (colsum_part != nullptr) {
       // column sums by a second pass over the keys (rows 2,3 of every [4][N] block), then the per-query statistics the first pass
       // left in rows 0,1 are cleared: the consumer adds all four rows
@@ -1195,12 +1233,20 @@ extern "C" int tr_attention_bf16(const uint16_t* qkv, uint16_t* out, float* cls_
 }
 
 // a11: Policy_Attention.forward dyvit.py:53-67 with softmax_with_policy (:39-51) -- the attention of DyViT's TRAINING forward,
-// where tokens are masked by a keep policy instead of being removed.  Forward only (224^2 inputs).
+// where tokens are masked by a keep policy instead of being removed.  Beyond 224 tokens (384^2 inputs): the online-softmax kernel.
 extern "C" int tr_attention_policy_bf16(const uint16_t* qkv, uint16_t* out, const float* policy, int B, int N, int H, tr_stream_t s) {
   TR_REQUIRE(qkv && out && policy, TR_ERR_NULL, "tr_attention_policy_bf16: null pointer");
-  TR_REQUIRE(B > 0 && H > 0 && N >= 1 && N <= 224, TR_ERR_SHAPE, "tr_attention_policy_bf16: need 1 <= N <= 224 (N=%d)", N);
+  TR_REQUIRE(B > 0 && H > 0 && N >= 1, TR_ERR_SHAPE, "tr_attention_policy_bf16: bad shape B=%d N=%d H=%d", B, N, H);
   TR_REQUIRE(tr_aligned16(qkv) && tr_aligned16(out), TR_ERR_ALIGN, "tr_attention_policy_bf16: pointers must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(s);
+  if (N > 224) {
+    const int nqg = ((N + 31) / 32 + 3) / 4;
+    tr_prof_note("attention_flash_kernel<policy>", 4.0 * B * H * (double)N * N * 64, 2.0 * B * N * 4.0 * H * 64);
+    hipLaunchKernelGGL(attention_flash_kernel<true>, dim3(B * H * nqg), dim3(256), 0, st, qkv, out, static_cast<float*>(nullptr), policy,
+                       static_cast<float*>(nullptr), N, H, nqg);
+    TR_CHECK_LAUNCH("tr_attention_policy_bf16");
+    return TR_OK;
+  }
   switch ((N + 31) / 32) {
     case 1: launch_attention<1>(qkv, out, nullptr, policy, nullptr, B, N, H, st, true); break;
     case 2: launch_attention<2>(qkv, out, nullptr, policy, nullptr, B, N, H, st, true); break;

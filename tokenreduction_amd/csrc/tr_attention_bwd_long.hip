@@ -11,6 +11,12 @@
 // accumulated across workgroups) and of not saving anything N x N or per-row in the forward.  Same arithmetic as the short kernel
 // otherwise (bf16 operands, fp32 accumulate and softmax, P and dS rounded to bf16 for the MFMA products; log-size / key-mask bias
 // of ToMe / ATS / Heuristic; EViT's d cls_attn added to query 0's dP).  t = s * dh^-0.5 * log2 e + log2 size[key].
+//
+// POLICY (DyViT training at 384^2: Policy_Attention.softmax_with_policy dyvit.py:39-51, the backward of tr_attention_policy_bf16; same
+// expressions as the short kernel's POLICY variant, tr_attention_bwd.hip): `size` carries the keep policy [B,N] of 1/0;
+//   e = 2^(t - max), a = e pi (pi[q][k] = policy[k], 1 on the diagonal), L = sum_k a_k + eps, p = (a + eps/N) / L, eps = 1e-6;
+//   delta = sum_k p_k dP_k;  dS = (dP - delta) a / L;  d policy[k] += (dP - delta) e / L over the queries q != k (per head: dpol_part).
+//   stats carries three rows per query: max + log2 L (so that 2^(t - .) = e / L), delta, 1 / L.
 #include "tr_common.h"
 
 namespace {
@@ -92,16 +98,17 @@ __device__ __forceinline__ void scores_block(const unsigned char* sK, const unsi
 }
 
 __device__ __forceinline__ void stage_key_meta(float* sLB, float* sDC, const float* size, const float* dcls, int b, int k0, int N, int H, int tid,
-                                               bool bias) {
+                                               bool bias, bool policy = false) {
   if (tid < LB) {
     const int key = k0 + tid;
-    sLB[tid] = (bias && key < N) ? __builtin_amdgcn_logf(size[(size_t)b * N + key]) : 0.f;      // v_log_f32 = log2; log2(0) = -inf masks the key
+    if (policy) sLB[tid] = key < N ? size[(size_t)b * N + key] : 0.f;                             // the keep policy itself
+    else sLB[tid] = (bias && key < N) ? __builtin_amdgcn_logf(size[(size_t)b * N + key]) : 0.f;      // v_log_f32 = log2; log2(0) = -inf masks the key
     sDC[tid] = (dcls != nullptr && key < N) ? dcls[(size_t)b * N + key] / (float)H : 0.f;
   }
 }
 
 // ---- 1. per-query statistics: stats[(b*H + h)*N + q] = LSE (log2 domain), stats[B*H*N + ...] = delta
-template <bool BIAS>
+template <bool BIAS, bool POLICY>
 __global__ __launch_bounds__(256) void attn_bwd_stats_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dO,
                                                              const float* __restrict__ size, const float* __restrict__ dcls,
                                                              float* __restrict__ stats, int N, int H, int BH) {
@@ -118,6 +125,7 @@ __global__ __launch_bounds__(256) void attn_bwd_stats_kernel(const uint16_t* __r
     of[ks] = *reinterpret_cast<const bf16x8*>(P.dobase + (size_t)min(iq, N - 1) * P.ldo + 32 * ks + 8 * g);
   }
   float m = -INFINITY, l = 0.f, ds = 0.f;            // running maximum (common to the four lanes of a query), this lane's partial sums
+  float sdp = 0.f;                                   // POLICY: sum_k dP_k (the eps/N term of delta)
   uint4 kreg[2], vreg[2];
   for (int k0 = 0; k0 < N; k0 += LB) {
     load_rows(P.base, P.ldq, P.kcol, k0, N, tid, kreg);
@@ -125,10 +133,10 @@ __global__ __launch_bounds__(256) void attn_bwd_stats_kernel(const uint16_t* __r
     __syncthreads();                                  // the previous block's fragments have been read
     put_rows(sK, k0, N, tid, kreg);
     put_rows(sV, k0, N, tid, vreg);
-    stage_key_meta(sLB, sDC, size, dcls, b, k0, N, H, tid, BIAS);
+    stage_key_meta(sLB, sDC, size, dcls, b, k0, N, H, tid, BIAS, POLICY);
     __syncthreads();
     float t[4][4], dp[4][4];
-    scores_block<BIAS>(sK, sV, sLB, sDC, qf, of, k0, N, iq == 0, li, g, t, dp);
+    scores_block<BIAS && !POLICY>(sK, sV, sLB, sDC, qf, of, k0, N, iq == 0, li, g, t, dp);
     float mx = m;
 #pragma unroll
     for (int jt = 0; jt < 4; ++jt)
@@ -144,7 +152,12 @@ __global__ __launch_bounds__(256) void attn_bwd_stats_kernel(const uint16_t* __r
       for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(t[jt][r] - mx);
+          float e = __builtin_amdgcn_exp2f(t[jt][r] - mx);
+          if (POLICY) {
+            const int kl = 16 * jt + 4 * g + r;
+            e *= (k0 + kl == iq) ? 1.0f : sLB[kl];
+            sdp += dp[jt][r];                               // keys past N: zero V rows, dP = 0
+          }
           l += e;
           ds += e * dp[jt][r];
         }
@@ -155,6 +168,17 @@ __global__ __launch_bounds__(256) void attn_bwd_stats_kernel(const uint16_t* __r
   l += __shfl_xor(l, 32, 64);
   ds += __shfl_xor(ds, 16, 64);
   ds += __shfl_xor(ds, 32, 64);
+  if (POLICY) {
+    sdp += __shfl_xor(sdp, 16, 64);
+    sdp += __shfl_xor(sdp, 32, 64);
+    if (g == 0 && iq < N) {
+      const float L = l + 1e-6f, invL = 1.0f / L;
+      stats[(size_t)bh * N + iq] = m + __builtin_amdgcn_logf(L);
+      stats[(size_t)BH * N + (size_t)bh * N + iq] = (ds + (1e-6f / (float)N) * sdp) * invL;
+      stats[(size_t)2 * BH * N + (size_t)bh * N + iq] = invL;
+    }
+    return;
+  }
   if (g == 0 && iq < N) {
     const bool live = l > 0.f;
     stats[(size_t)bh * N + iq] = live ? m + __builtin_amdgcn_logf(l) : 0.f;      // every key masked: p = 2^(-inf - 0) = 0 downstream
@@ -163,14 +187,28 @@ __global__ __launch_bounds__(256) void attn_bwd_stats_kernel(const uint16_t* __r
 }
 
 // p and dS of this wave's queries for the staged key block, written to its own 16 rows of sP / sDS ([64 queries][64 keys], qswz)
+// POLICY: sLB = the staged keys' policy, kdiag = the local key index of this query's own key (or -1), padd = eps/N / L (0 for rows past N),
+// dpol (dK/dV kernel only) += (dP - delta) e / L off the diagonal
+template <bool POLICY = false, bool DPOL = false>
 __device__ __forceinline__ void write_p_ds(unsigned char* sP, unsigned char* sDS, const float (&t)[4][4], const float (&dp)[4][4], float lse,
-                                           float delta, int il, int g) {
+                                           float delta, int il, int g, const float* sLB = nullptr, int kdiag = -1, float padd = 0.f,
+                                           int kvalid = LB, float (*dpol)[4] = nullptr) {
 #pragma unroll
   for (int jt = 0; jt < 4; ++jt) {
     float pv[4], dsv[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       pv[r] = __builtin_amdgcn_exp2f(t[jt][r] - lse);
+      if (POLICY) {
+        const int kl = 16 * jt + 4 * g + r;
+        const float w = pv[r] * (dp[jt][r] - delta);             // (dP - delta) e / L
+        const bool diag = kl == kdiag;
+        if (DPOL) dpol[jt][r] += diag ? 0.f : w;
+        const float pi = diag ? 1.0f : sLB[kl];
+        dsv[r] = w * pi * 0.125f;
+        pv[r] = pv[r] * pi + (kl < kvalid ? padd : 0.f);
+        continue;
+      }
       dsv[r] = pv[r] * (dp[jt][r] - delta) * 0.125f;
     }
     uint2 pp, dd;
@@ -185,7 +223,7 @@ __device__ __forceinline__ void write_p_ds(unsigned char* sP, unsigned char* sDS
 }
 
 // ---- 2. dQ: one workgroup per (64-query block, image, head)
-template <bool BIAS>
+template <bool BIAS, bool POLICY>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dO,
                                                           const float* __restrict__ size, const float* __restrict__ dcls,
                                                           const float* __restrict__ stats, uint16_t* __restrict__ dqkv, int N, int H, int BH) {
@@ -212,11 +250,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
     __syncthreads();
     put_rows(sK, k0, N, tid, kreg);
     put_rows(sV, k0, N, tid, vreg);
-    stage_key_meta(sLB, sDC, size, dcls, b, k0, N, H, tid, BIAS);
+    stage_key_meta(sLB, sDC, size, dcls, b, k0, N, H, tid, BIAS, POLICY);
     __syncthreads();
     float t[4][4], dp[4][4];
-    scores_block<BIAS>(sK, sV, sLB, sDC, qf, of, k0, N, iq == 0, li, g, t, dp);
-    write_p_ds(nullptr, sDS, t, dp, lse, delta, il, g);
+    scores_block<BIAS && !POLICY>(sK, sV, sLB, sDC, qf, of, k0, N, iq == 0, li, g, t, dp);
+    if (POLICY) write_p_ds<true, false>(nullptr, sDS, t, dp, lse, delta, il, g, sLB, iq - k0);
+    else write_p_ds(nullptr, sDS, t, dp, lse, delta, il, g);
     // dQ^T[d][query] += sum_key K[key][d] dS[query][key]: own rows only (LDS operations of one wave are ordered)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -243,10 +282,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
 }
 
 // ---- 3. dK, dV: one workgroup per (64-key block, image, head); wave w accumulates the 16 keys 16 w .. 16 w + 15 of the block
-template <bool BIAS>
+template <bool BIAS, bool POLICY>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dO,
                                                            const float* __restrict__ size, const float* __restrict__ dcls,
-                                                           const float* __restrict__ stats, uint16_t* __restrict__ dqkv, int N, int H, int BH) {
+                                                           const float* __restrict__ stats, uint16_t* __restrict__ dqkv,
+                                                           float* __restrict__ dpol_part, int N, int H, int BH) {
   __shared__ __attribute__((aligned(16))) unsigned char sK[LB * 128], sV[LB * 128], sQ[LB * 128], sDO[LB * 128], sP[LB * 128], sDS[LB * 128];
   __shared__ float sLB[LB], sDC[LB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, g = lane >> 4, q4 = li >> 2, p4 = li & 3;
@@ -259,8 +299,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const uint16_t* __res
     load_rows(P.base, P.ldq, P.vcol, k0, N, tid, vreg);
     put_rows(sK, k0, N, tid, kreg);
     put_rows(sV, k0, N, tid, vreg);
-    stage_key_meta(sLB, sDC, size, dcls, b, k0, N, H, tid, BIAS);
+    stage_key_meta(sLB, sDC, size, dcls, b, k0, N, H, tid, BIAS, POLICY);
   }
+  float dpol[4][4];                                   // POLICY: d policy[key 16 jt + 4 g + r] from this lane's queries
+#pragma unroll
+  for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dpol[jt][r] = 0.f;
   f32x4 dk[4], dv[4];
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
@@ -285,11 +330,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const uint16_t* __res
       of[ks] = *reinterpret_cast<const bf16x8*>(sDO + qswz(il, 4 * ks + g));
     }
     float t[4][4], dp[4][4];
-    scores_block<BIAS>(sK, sV, sLB, sDC, qf, of, k0, N, iq == 0, li, g, t, dp);
+    scores_block<BIAS && !POLICY>(sK, sV, sLB, sDC, qf, of, k0, N, iq == 0, li, g, t, dp);
     // rows beyond N are zero rows of Q and dO: their p must not reach dV / dK -> lse = +inf gives p = 0, dS = 0
     const float lse = iq < N ? stats[(size_t)bh * N + iq] : INFINITY;
     const float delta = iq < N ? stats[(size_t)BH * N + (size_t)bh * N + iq] : 0.f;
-    write_p_ds(sP, sDS, t, dp, lse, delta, il, g);
+    if (POLICY) {
+      const float padd = iq < N ? (1e-6f / (float)N) * stats[(size_t)2 * BH * N + (size_t)bh * N + iq] : 0.f;
+      write_p_ds<true, true>(sP, sDS, t, dp, lse, delta, il, g, sLB, iq - k0, padd, N - k0, dpol);
+    } else {
+      write_p_ds(sP, sDS, t, dp, lse, delta, il, g);
+    }
     __syncthreads();                      // P and dS rows of all four waves are in LDS
     // phase 2: dK^T[d][key] += sum_query Q[query][d] dS[query][key], dV^T[d][key] += sum_query dO[query][d] P[query][key]
 #pragma unroll
@@ -307,6 +357,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const uint16_t* __res
         dv[d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ot, pf, dv[d], 0, 0, 0);
       }
     }
+  }
+  if (POLICY) {
+    // d policy of the block's 64 keys: over the 16 queries of a lane row (DPP / shuffles), then over the four waves through the LDS
+    __syncthreads();                      // sP is free
+    float* red = reinterpret_cast<float*>(sP);                      // [wave][64 keys]
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = dpol[jt][r];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        if (li == 0) red[wave * LB + 16 * jt + 4 * g + r] = v;
+      }
+    __syncthreads();
+    if (tid < LB && k0 + tid < N)
+      dpol_part[(size_t)bh * N + k0 + tid] = (red[tid] + red[LB + tid]) + (red[2 * LB + tid] + red[3 * LB + tid]);
   }
   // accumulator d: rows d-index 16 d + 4 g + r, column key k0 + 16 wave + li
   const int key = k0 + 16 * wave + li;
@@ -328,7 +397,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const uint16_t* __res
 
 }  // namespace
 
-extern "C" size_t tr_attention_bwd_long_workspace_floats(int B, int N, int H) { return (size_t)2 * B * H * N; }
+extern "C" size_t tr_attention_bwd_long_workspace_floats(int B, int N, int H) { return (size_t)3 * B * H * N; }
 
 // Same contract as tr_attention_bwd_bf16 for any N (used beyond 224 tokens); ws: tr_attention_bwd_long_workspace_floats(B,N,H) floats.
 extern "C" int tr_attention_bwd_long_bf16(const uint16_t* qkv, const uint16_t* dout, const float* size, const float* dcls, uint16_t* dqkv,
@@ -342,14 +411,35 @@ extern "C" int tr_attention_bwd_long_bf16(const uint16_t* qkv, const uint16_t* d
   const dim3 grid(nb, BH);
   tr_prof_note("attention_bwd_long", 18.0 * BH * (double)N * N * 64, 2.0 * B * N * 8.0 * H * 64);
   if (size != nullptr) {
-    hipLaunchKernelGGL(attn_bwd_stats_kernel<true>, grid, dim3(256), 0, st, qkv, dout, size, dcls, ws, N, H, BH);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, grid, dim3(256), 0, st, qkv, dout, size, dcls, ws, dqkv, N, H, BH);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, grid, dim3(256), 0, st, qkv, dout, size, dcls, ws, dqkv, N, H, BH);
+    hipLaunchKernelGGL((attn_bwd_stats_kernel<true, false>), grid, dim3(256), 0, st, qkv, dout, size, dcls, ws, N, H, BH);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false>), grid, dim3(256), 0, st, qkv, dout, size, dcls, ws, dqkv, N, H, BH);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false>), grid, dim3(256), 0, st, qkv, dout, size, dcls, ws, dqkv, static_cast<float*>(nullptr), N, H, BH);
   } else {
-    hipLaunchKernelGGL(attn_bwd_stats_kernel<false>, grid, dim3(256), 0, st, qkv, dout, size, dcls, ws, N, H, BH);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, grid, dim3(256), 0, st, qkv, dout, size, dcls, ws, dqkv, N, H, BH);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, grid, dim3(256), 0, st, qkv, dout, size, dcls, ws, dqkv, N, H, BH);
+    hipLaunchKernelGGL((attn_bwd_stats_kernel<false, false>), grid, dim3(256), 0, st, qkv, dout, size, dcls, ws, N, H, BH);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false>), grid, dim3(256), 0, st, qkv, dout, size, dcls, ws, dqkv, N, H, BH);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, false>), grid, dim3(256), 0, st, qkv, dout, size, dcls, ws, dqkv, static_cast<float*>(nullptr), N, H, BH);
   }
   TR_CHECK_LAUNCH("tr_attention_bwd_long_bf16");
+  return TR_OK;
+}
+
+// DyViT training beyond 224 tokens: the backward of tr_attention_policy_bf16 (same contract as tr_attention_policy_bwd_bf16, which
+// forwards here for N > 224).  ws: tr_attention_bwd_long_workspace_floats(B,N,H) floats.
+extern "C" int tr_attention_policy_bwd_long_bf16(const uint16_t* qkv, const uint16_t* dout, const float* policy, uint16_t* dqkv, float* dpol_part,
+                                                 float* ws, size_t ws_floats, int B, int N, int H, tr_stream_t s) {
+  TR_REQUIRE(qkv && dout && policy && dqkv && dpol_part && ws, TR_ERR_NULL, "tr_attention_policy_bwd_long_bf16: null pointer");
+  TR_REQUIRE(B > 0 && H > 0 && N >= 1, TR_ERR_SHAPE, "tr_attention_policy_bwd_long_bf16: bad shape B=%d N=%d H=%d", B, N, H);
+  TR_REQUIRE(ws_floats >= tr_attention_bwd_long_workspace_floats(B, N, H), TR_ERR_SHAPE, "tr_attention_policy_bwd_long_bf16: workspace too small");
+  TR_REQUIRE(tr_aligned16(qkv) && tr_aligned16(dout) && tr_aligned16(dqkv), TR_ERR_ALIGN,
+             "tr_attention_policy_bwd_long_bf16: pointers must be 16-byte aligned");
+  hipStream_t st = static_cast<hipStream_t>(s);
+  const int nb = (N + LB - 1) / LB, BH = B * H;
+  const dim3 grid(nb, BH);
+  const float* none = nullptr;
+  tr_prof_note("attention_bwd_long<policy>", 18.0 * BH * (double)N * N * 64, 2.0 * B * N * 8.0 * H * 64);
+  hipLaunchKernelGGL((attn_bwd_stats_kernel<false, true>), grid, dim3(256), 0, st, qkv, dout, policy, none, ws, N, H, BH);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<false, true>), grid, dim3(256), 0, st, qkv, dout, policy, none, ws, dqkv, N, H, BH);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, true>), grid, dim3(256), 0, st, qkv, dout, policy, none, ws, dqkv, dpol_part, N, H, BH);
+  TR_CHECK_LAUNCH("tr_attention_policy_bwd_long_bf16");
   return TR_OK;
 }

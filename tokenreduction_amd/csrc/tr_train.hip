@@ -308,7 +308,11 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
       for (int j = i; j >= 0; --j)
         if (t.kk[j] > 0) { pol = reinterpret_cast<const float*>(tape + tp.blk[j].pol); break; }
       float* dpart = reinterpret_cast<float*>(ws + bp.dpolpart);
-      TR_TRY(tr_attention_policy_bwd_bf16(U(tape + bt.qkv), dao, pol, dqkv, dpart, B, Na, H, s));
+      if (Na > 224)      // 384 x 384 inputs: the key-blocked kernels' policy variant
+        TR_TRY(tr_attention_policy_bwd_long_bf16(U(tape + bt.qkv), dao, pol, dqkv, dpart, reinterpret_cast<float*>(ws + bp.attn_stats),
+                                                 tr_attention_bwd_long_workspace_floats(B, t.N0, H), B, Na, H, s));
+      else
+        TR_TRY(tr_attention_policy_bwd_bf16(U(tape + bt.qkv), dao, pol, dqkv, dpart, B, Na, H, s));
       TR_TRY(tr_head_sum(dpart, reinterpret_cast<float*>(ws + bp.dpol), B, H, Na, s));
     } else if (Na > 224) {       // 384 x 384 inputs: key-blocked kernels (tr_attention_bwd_long.hip)
       TR_TRY(tr_attention_bwd_long_bf16(U(tape + bt.qkv), dao, size_att, dcls, dqkv, reinterpret_cast<float*>(ws + bp.attn_stats),

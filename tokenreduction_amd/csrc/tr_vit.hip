@@ -733,9 +733,8 @@ extern "C" size_t tr_vit_tape_bytes(const tr_vit_config* cfg, int B) {
   trplan::TokenPlan t;
   trplan::TapePlan tp;
   if (!make_plan(cfg, B, &p) || cfg->precision != TR_PREC_BF16 || !trplan::trainable_family(cfg->family)) return 0;
-  // beyond 224 tokens (384 x 384 inputs) the attention backward runs key-blocked (tr_attention_bwd_long.hip); what does NOT scale:
-  // DyViT's policy attention (N <= 224)
-  if (p.N0 > 640 || (p.N0 > 224 && cfg->family == TR_FAMILY_DYVIT)) return 0;
+  // beyond 224 tokens (384 x 384 inputs) the attention backward runs key-blocked (tr_attention_bwd_long.hip)
+  if (p.N0 > 640) return 0;
   if (!trplan::make_token_plan(cfg, &t) || !trplan::make_tape_plan(cfg, B, t, &tp)) return 0;
   return tp.total;
 }
@@ -772,8 +771,7 @@ extern "C" int tr_vit_forward_train(const tr_vit_config* cfg, const tr_vit_weigh
   TR_REQUIRE(tape_bytes >= tp.total, TR_ERR_SHAPE, "tr_vit_forward_train: tape too small (%zu < %zu)", tape_bytes, tp.total);
   TR_REQUIRE(tr_aligned16(tape), TR_ERR_ALIGN, "tr_vit_forward_train: tape must be 16-byte aligned");
   for (int i = 0; i < cfg->depth; ++i)
-    TR_REQUIRE(t.n_att[i] <= (cfg->family == TR_FAMILY_DYVIT ? 224 : 640), TR_ERR_SHAPE,
-               "tr_vit_forward_train: %d tokens in block %d (the training path holds 640, DyViT's policy attention 224)", t.n_att[i], i);
+    TR_REQUIRE(t.n_att[i] <= 640, TR_ERR_SHAPE, "tr_vit_forward_train: %d tokens in block %d (the training path holds 640)", t.n_att[i], i);
   TR_REQUIRE(features_out == nullptr || cfg->family == TR_FAMILY_DYVIT, TR_ERR_CONFIG, "tr_vit_forward_train: features_out is DyViT's distillation output");
   return vit_forward_impl(cfg, w, img, logits, workspace, workspace_bytes, nullptr, nullptr, nullptr, noise_in, features_out, tokens_out, B, s,
                           static_cast<char*>(tape), &tp, drop_scale, dropout_keep, drop_rate);

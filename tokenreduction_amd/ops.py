@@ -619,6 +619,21 @@ def add_into_bf16(a: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     return y
 
 
+def attention_policy_bwd(qkv: torch.Tensor, dout: torch.Tensor, policy: torch.Tensor, B: int, N: int, H: int):
+    """Backward of attention_policy (bf16): -> (dqkv bf16 [B*N, 3*H*64], d policy fp32 [B,H,N] per head).  Beyond 224 tokens the
+    key-blocked kernels (tr_attention_policy_bwd_long_bf16), as in the training executor."""
+    lib = _lib.load()
+    dqkv = torch.empty_like(qkv)
+    dpart = torch.zeros(B, H, N, dtype=torch.float32, device=qkv.device)
+    args = (_dev(qkv, torch.bfloat16, "qkv"), _dev(dout, torch.bfloat16, "dout"), _dev(policy, torch.float32, "policy"), dqkv.data_ptr(), dpart.data_ptr())
+    if N > 224:
+        ws = _ws(lib.tr_attention_bwd_long_workspace_floats(B, N, H), qkv.device)
+        _lib.check(lib.tr_attention_policy_bwd_long_bf16(*args, ws.data_ptr(), ws.numel(), B, N, H, _stream()), "tr_attention_policy_bwd_long_bf16")
+    else:
+        _lib.check(lib.tr_attention_policy_bwd_bf16(*args, B, N, H, _stream()), "tr_attention_policy_bwd_bf16")
+    return dqkv, dpart
+
+
 def attention_bwd_long(qkv: torch.Tensor, dout: torch.Tensor, B: int, N: int, H: int, size: torch.Tensor = None, dcls: torch.Tensor = None):
     """tr_attention_bwd_bf16's gradient for any sequence length (key-blocked kernels; what the training executor runs beyond 224 tokens)."""
     lib = _lib.load()

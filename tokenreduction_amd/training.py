@@ -141,7 +141,7 @@ class TrainState:
             if nt == 0 or nb == 0:
                 raise NotImplementedError(
                     f"{type(model).__name__}: this configuration has no training path in the HIP executor (built: every family at "
-                    "224x224; at 384x384 every family except DyViT; bf16); call model.eval() for inference")
+                    "224x224 and 384x384, up to 640 tokens; bf16); call model.eval() for inference")
             self.tape = torch.empty(nt, dtype=torch.uint8, device=dev)
             self.bws = torch.empty(nb, dtype=torch.uint8, device=dev)
             self.B = B

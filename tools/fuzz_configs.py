@@ -34,7 +34,7 @@ for it in range(n_cfg):
     if fam == "deit":
         loc, kr = [], [1.0]
     B = int(rng.choice([1, 2, 3, 5, 8]))
-    img = 384 if (it % 7 == 6 and fam not in ("dyvit",)) else 224                 # a few 384 x 384 configurations (577 tokens)
+    img = 384 if it % 7 == 6 else 224                 # a few 384 x 384 configurations (577 tokens)
     pattern = str(rng.choice(["l1", "l2", "linf"]))
     equal = bool(rng.integers(0, 2)) and fam in ("dpcknn", "kmedoids")
     min_radius = float(rng.choice([0.0, 2.0, 4.0])) or None
