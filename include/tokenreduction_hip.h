@@ -61,6 +61,15 @@ int tr_im2col_f32(const float* img, float* cols, int B, int C, int H, int W, int
 /* a2 (topk.py:183-186): x[b*N + 0, :] = cls_token + pos_embed[0] for every image (fp32). */
 int tr_cls_pos_rows(const float* cls_token, const float* pos_embed, float* x, int B, int N, int D, tr_stream_t s);
 
+/* a1 + a2 in one launch (the eval forward's patch embedding; timm PatchEmbed + topk.py:181-186): x fp32 [B, P+1, D] with
+ * x[b,0,:] = cls_token + pos_embed[0], x[b,1+p,:] = W . patch(b,p) + bias + pos_embed[1+p]; W bf16 [D, C*16*16] (Conv2d weight.view(D,-1)),
+ * img fp32 [B,C,HW,HW].  The unfold happens on the way into the LDS (the bf16 column matrix of tr_im2col_bf16 is never written), one
+ * workgroup per image and 384 output columns.  Same arithmetic as tr_im2col_bf16 + tr_gemm_bf16(TR_EPI_PATCH_F32) + tr_cls_pos_rows.
+ * tr_patch_embed_supported: patch 16, HW %% 16 == 0, D %% 384 == 0 (other shapes: the three-launch path). */
+int tr_patch_embed_supported(int C, int HW, int patch, int D);
+int tr_patch_embed_bf16(const float* img, const uint16_t* W, const float* bias, const float* cls_token, const float* pos_embed, float* x,
+                        int B, int C, int HW, int patch, int D, tr_stream_t s);
+
 /* a3/a4 Linear layers (nn.Linear: y = x W^T + b, W is [N,K] row-major like the state dict).
  * A bf16 [M,K], W bf16 [N,K], bias fp32 [N]; K % 64 == 0, N % 4 == 0.  `out` dtype/meaning per epilogue;
  * aux/aux_i only for TR_EPI_PATCH_F32. */

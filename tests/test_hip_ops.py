@@ -129,6 +129,26 @@ def test_patch_embed(ops):
     torch.testing.assert_close(x.cpu().view(B, 197, D), want, atol=1e-4, rtol=1e-5)
 
 
+@pytest.mark.parametrize("B,HW,D,C", [(3, 224, 384, 3), (2, 384, 768, 3), (1, 224, 768, 3), (5, 32, 384, 1), (2, 240, 384, 4)])
+def test_patch_embed_fused(ops, B, HW, D, C):
+    """The eval forward's one-launch patch embedding (unfold on the way into the LDS + GEMM + bias + pos_embed + the CLS row) against
+    the oracle (bf16 operands) and against the three-launch path it replaces (same products; pos_embed joins the sum at a different point)."""
+    rng = _rng(50 + HW + D)
+    P = (HW // 16) ** 2
+    img = _randn(rng, B, C, HW, HW)
+    w, b = _randn(rng, D, C, 16, 16, scale=0.02), _randn(rng, D, scale=0.02)
+    cls, pos = _randn(rng, 1, 1, D, scale=0.02), _randn(rng, 1, P + 1, D, scale=0.02)
+    want = oracle.embed_tokens(oracle.patch_embed(img, w, b, 16, precision="bf16"), cls, pos)
+    w16 = w.reshape(D, -1).cuda().bfloat16()
+    got = ops.patch_embed(img.cuda(), w16, b.cuda(), cls.reshape(-1).cuda(), pos.reshape(P + 1, D).cuda())
+    torch.testing.assert_close(got.cpu(), want, atol=1e-4, rtol=1e-5)
+    cols = ops.im2col(img.cuda(), 16)
+    x = torch.empty(B * (P + 1), D, device="cuda")
+    ops.gemm(cols, w16, b.cuda(), ops.TR_EPI_PATCH_F32, out=x, aux=pos.reshape(P + 1, D).cuda(), aux_i=P)
+    ops.cls_pos_rows(cls.reshape(-1).cuda(), pos.reshape(P + 1, D).cuda(), x, B, P + 1, D)
+    torch.testing.assert_close(got.view(B * (P + 1), D), x, atol=2e-6, rtol=1e-6)
+
+
 # ------------------------------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("M,D", [(7, 128), (394, 384), (33, 768), (5, 192), (3, 1024)])
 def test_layernorm(ops, M, D):

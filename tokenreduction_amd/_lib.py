@@ -79,6 +79,8 @@ SIGNATURES = {
     "tr_tome_merge_layernorm": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "tr_gather_layernorm_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "tr_cls_pos_rows": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "tr_patch_embed_supported": (_i, [_i, _i, _i, _i]),
+    "tr_patch_embed_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tr_gemm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tr_layernorm_bf16": (_i, [_vp, _l, _vp, _l, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "tr_attention_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -274,9 +274,17 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
   const int prec = cfg->precision;
   const bool f32 = prec != TR_PREC_BF16;            // fp32 activations (TR_PREC_FP32 and TR_PREC_BF16X3)
   // a1 + a2: patch embedding, CLS token, position embedding
-  TR_TRY(op_im2col(f32, img, cols, B, cfg->in_chans, cfg->img_size, cfg->img_size, cfg->patch, s));
-  TR_TRY(op_gemm(prec, cols, w->patch_w, w->patch_b, x, w->pos_embed, p.P, B * p.P, D, p.kcols, TR_EPI_PATCH_F32, s));
-  TR_TRY(tr_cls_pos_rows(w->cls_token, w->pos_embed, x, B, p.N0, D, s));
+  static const bool unfused_patch = [] { const char* e = getenv("TR_PATCH_UNFUSED"); return e && atoi(e) != 0; }();   // lab: the three-launch path
+  if (!train && !f32 && !unfused_patch && tr_patch_embed_supported(cfg->in_chans, cfg->img_size, cfg->patch, D)) {
+    // eval: unfold + GEMM + cls/pos in one launch (tr_patch.hip), at every batch size (the two paths differ in the last bit: an image's
+    // tokens must not depend on its batch); training keeps the column matrix (PatchEmbed's weight-gradient operand)
+    TR_TRY(tr_patch_embed_bf16(img, static_cast<const uint16_t*>(w->patch_w), w->patch_b, w->cls_token, w->pos_embed, x, B, cfg->in_chans,
+                               cfg->img_size, cfg->patch, D, s));
+  } else {
+    TR_TRY(op_im2col(f32, img, cols, B, cfg->in_chans, cfg->img_size, cfg->img_size, cfg->patch, s));
+    TR_TRY(op_gemm(prec, cols, w->patch_w, w->patch_b, x, w->pos_embed, p.P, B * p.P, D, p.kcols, TR_EPI_PATCH_F32, s));
+    TR_TRY(tr_cls_pos_rows(w->cls_token, w->pos_embed, x, B, p.N0, D, s));
+  }
   // Dropout (timm's drop_rate: pos_drop topk.py:186, proj_drop :53, the Mlp's two nn.Dropout): training only.  The caller draws the keep
   // masks (1 byte per element, in forward order: tr_vit_dropout_mask_bytes); survivors are scaled by 1 / (1 - p) like nn.Dropout.
   const float drop_mul = drop_keep != nullptr ? 1.0f / (1.0f - drop_rate) : 1.0f;

@@ -52,6 +52,17 @@ def cls_pos_rows(cls_token, pos_embed, x, B, N, D):
                                            _dev(x, torch.float32, "x"), B, N, D, _stream()), "tr_cls_pos_rows")
 
 
+def patch_embed(img: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, cls_token: torch.Tensor, pos_embed: torch.Tensor, patch: int = 16) -> torch.Tensor:
+    """PatchEmbed + cls_token + pos_embed in one launch (topk.py:181-186): img fp32 [B,C,H,H], w bf16 [D, C*p*p] -> x fp32 [B, P+1, D]."""
+    B, Cc, H, _ = img.shape
+    D = w.shape[0]
+    x = torch.empty(B, (H // patch) ** 2 + 1, D, dtype=torch.float32, device=img.device)
+    _lib.check(_lib.load().tr_patch_embed_bf16(_dev(img, torch.float32, "img"), _dev(w, torch.bfloat16, "w"), _dev(bias, torch.float32, "bias"),
+                                               _dev(cls_token, torch.float32, "cls_token"), _dev(pos_embed, torch.float32, "pos_embed"), x.data_ptr(),
+                                               B, Cc, H, patch, D, _stream()), "tr_patch_embed_bf16")
+    return x
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, epilogue: int, out: torch.Tensor = None,
          aux: torch.Tensor = None, aux_i: int = 0) -> torch.Tensor:
     """nn.Linear on MFMA: epilogue(a[M,K] @ w[N,K]^T + bias).  For RESID/PATCH `out` is required (updated in place)."""
