@@ -25,8 +25,8 @@ void tr_set_error(const char* fmt, ...);
     }                                      \
   } while (0)
 
-// Launch profiler (tr_profile_begin / tr_profile_end, csrc/tr_vit.hip): while a recording is active on this thread, every
-// TR_CHECK_LAUNCH drops a HIP event on the recording's stream, so consecutive marks bracket the launches of one entry point (the
+// Launch profiler (tr_profile_begin / tr_profile_end, csrc/tr_vit.hip): while a recording is active (process-wide: autograd runs the
+// backward on its own thread), every TR_CHECK_LAUNCH drops a HIP event on the recording's stream, so consecutive marks bracket the launches of one entry point (the
 // event-bracketed duration: kernel + its dependent-launch boundary).  tr_prof_note() names the next mark and gives it the
 // algorithmic FLOPs / bytes of the launch; without a note the mark carries the entry point's name and zeros.  Inactive: one
 // thread-local load per launch.
