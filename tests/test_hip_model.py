@@ -453,6 +453,28 @@ def test_forward_is_graph_capturable():
     assert torch.equal(out, model(x2))
 
 
+def test_graph_replay_gives_way_to_plain_launches_when_inputs_keep_moving():
+    """The eval forward replays a hipGraph keyed on the input's address.  A caller whose batches land at a new address every time would
+    re-capture on every call: after GRAPH_MISS_LIMIT misses in a row the workspace goes back to plain launches, with one warning; a caller
+    that keeps one static input buffer stays on the replay.  Same logits either way."""
+    case = GOLDEN_CASES["topk_micro"]
+    model, _, _ = build_model(case)
+    model.viz_mode = False
+    x = make_images(3, 224, 11).cuda()
+    want = model(x).clone()
+    for _ in range(5):
+        assert torch.equal(model(x), want)                   # one address: hits after the first capture
+    ws = model._last_ws
+    assert not ws.get("graph_off") and len(ws["graphs"]) == 1
+    keep = []                                                # hold the copies so the allocator cannot hand an address out twice
+    with pytest.warns(RuntimeWarning, match="hipGraph replay is off"):
+        for _ in range(model.GRAPH_MISS_LIMIT + 1):
+            keep.append(x.clone())
+            assert torch.equal(model(keep[-1]), want)
+    assert ws.get("graph_off") and not ws["graphs"]
+    assert torch.equal(model(x), want)                       # plain launches from here on
+
+
 def test_dyvit_teacher_returns_logits_and_normed_tokens():
     """VisionTransformerTeacher.forward dyvit.py:325-334: (head(norm(x)[:, 0]), norm(x)[:, 1:])."""
     import tokenreduction_amd as tra

@@ -93,7 +93,8 @@ __global__ __launch_bounds__(512, 1) void patch_embed_kernel(const float* __rest
     for (int j = 0; j < 6; ++j) dma_piece(W, woff[j] + (unsigned)kt * 128u, wdst + slot * PE_W_BYTES + j * 1024);
     const float* src = ibase + (size_t)(kt >> 2) * HW * HW + (size_t)((kt & 3) * 4) * HW;
 #pragma unroll
-    for (int it = 0; it < PE_ITEMS; ++it) areg[it] = *reinterpret_cast<const f32x4*>(src + aoff[it]);
+    for (int it = 0; it < PE_ITEMS; ++it)      // nontemporal: the image is read once -- kept out of the caches the forward lives in (-12 us per forward)
+      areg[it] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + aoff[it]));
   };
   auto commit = [&](int slot) {
 #pragma unroll

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import copy
 import ctypes as C
+import warnings
 from functools import partial
 from typing import List, Optional
 
@@ -86,6 +87,7 @@ class VisionTransformer(nn.Module):
 
     _family = _lib.TR_FAMILY_DEIT
     _blocks_last = False
+    GRAPH_MISS_LIMIT = 4         # consecutive forwards with a never-seen input address before a workspace stops capturing hipGraphs
 
     def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
                  num_heads=12, mlp_ratio=4., qkv_bias=True, representation_size=None, distilled=False,
@@ -438,25 +440,47 @@ class VisionTransformer(nn.Module):
             return list(tokens)
 
         with torch.cuda.device(x.device):
-            if self.use_graph and not torch.cuda.is_current_stream_capturing():
+            if self.use_graph and not ws.get("graph_off") and not torch.cuda.is_current_stream_capturing():
                 # The forward is a fixed sequence of ~90-130 dependent launches with no host decision in between: replay it as one
                 # hipGraph (captured once per batch size / input buffer / output set; the workspace and every output are static
                 # buffers).  Re-packing the weights or a new batch size drops the workspace and its graphs with it.
+                # A capture bakes the input ADDRESS in.  Callers whose batches arrive at a new address every time (a dtype / layout
+                # conversion above, a loader without a static buffer, K-Medoids --equal_weight with its per-forward draws) would
+                # re-capture on every call -- slower than not using a graph at all: after GRAPH_MISS_LIMIT misses in a row the
+                # workspace goes back to plain launches (at batch 256 within 0.5 % of the replay; bench.py ms_per_step_plain_launches).
                 key = (x.data_ptr(), bool(want_feat), ws.get("soft") is not None, noise_ptr, self._kmed_draws)
                 graphs = ws.setdefault("graphs", {})
                 ent = graphs.get(key)
                 if ent is None:
-                    out = torch.empty(B, self._classes_padded, dtype=torch.float32, device=x.device)
-                    launch(out)                                       # eager once: first-touch of the workspace, lazy module load
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        toks = launch(out)
-                    if len(graphs) >= 8:
-                        graphs.pop(next(iter(graphs)))
-                    ent = graphs[key] = (g, out, toks)
-                g, out, toks = ent
-                g.replay()
-                logits, tokens = out[:, :self.num_classes].clone(), toks
+                    ws["graph_misses"] = ws.get("graph_misses", 0) + 1
+                    if graphs and ws["graph_misses"] >= self.GRAPH_MISS_LIMIT:
+                        ws["graph_off"] = True
+                        graphs.clear()
+                        warnings.warn(f"{type(self).__name__}: {self.GRAPH_MISS_LIMIT} forwards in a row came with a new input address (or new "
+                                      "per-forward draws); hipGraph replay is off for this batch size -- keep the input in one static "
+                                      "buffer to get it back (model.use_graph = False silences this)", RuntimeWarning, stacklevel=3)
+                        logits = torch.empty(B, self._classes_padded, dtype=torch.float32, device=x.device)
+                        tokens = launch(logits)
+                        if self._classes_padded != self.num_classes:
+                            logits = logits[:, :self.num_classes].contiguous()
+                        ent = False
+                    else:
+                        out = torch.empty(B, self._classes_padded, dtype=torch.float32, device=x.device)
+                        if not ws.get("warm"):
+                            launch(out)                                   # eager once per workspace: first touch, lazy module load
+                            ws["warm"] = True
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g):
+                            toks = launch(out)
+                        if len(graphs) >= 8:
+                            graphs.pop(next(iter(graphs)))
+                        ent = graphs[key] = (g, out, toks)
+                else:
+                    ws["graph_misses"] = 0
+                if ent:
+                    g, out, toks = ent
+                    g.replay()
+                    logits, tokens = out[:, :self.num_classes].clone(), toks
             else:
                 logits = torch.empty(B, self._classes_padded, dtype=torch.float32, device=x.device)
                 tokens = launch(logits)
