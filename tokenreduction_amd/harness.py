@@ -103,7 +103,8 @@ class ModelEma:
         for e, m in zip(ema_v, model_v):
             if not e.is_floating_point():
                 e.copy_(m)
-        self.module.weights_changed()                                             # the packed bf16 copies follow the new values
+        if hasattr(self.module, "weights_changed"):                               # (any nn.Module can be averaged; the HIP models repack)
+            self.module.weights_changed()                                         # the packed bf16 copies follow the new values
 
 
 def train_one_epoch(model, criterion, data_loader: Iterable, optimizer, device, epoch: int, lr_scheduler=None, max_norm: float = 0,
