@@ -88,6 +88,12 @@ int tr_layernorm_f32(float* x, long ldx, const float* delta, long ldd, const flo
  * forward uses it so that the input of every norm survives for the backward pass. */
 int tr_layernorm_bf16_to(const float* x, long ldx, float* x_out, long ldxo, const uint16_t* delta, long ldd, const float* gamma,
                          const float* beta, uint16_t* y, int M, int D, float eps, tr_stream_t s);
+/* y = LayerNorm((x + delta) + delta2) with TWO pending residuals (delta2 nullable), the sum written to x_out -- or, x_out == NULL, not
+ * written at all.  The eval executor's "lazy norm2": a norm2 that no reduction follows normalises x + d_attn without storing it, the
+ * next norm1 adds d_attn and d_mlp in the reference's order (topk.py:87, :95) and writes the stream once: bit-identical to two
+ * tr_layernorm_bf16 calls, 22 instead of 24 bytes per element and block. */
+int tr_layernorm2_bf16(const float* x, long ldx, float* x_out, long ldxo, const uint16_t* delta, long ldd, const uint16_t* delta2, long ldd2,
+                       const float* gamma, const float* beta, uint16_t* y, int M, int D, float eps, tr_stream_t s);
 
 /* out[i] = x[i] + delta[i] for n elements (delta nullable; bf16, fp32 when delta_is_f32): the residual stream after a block as
  * the reference's viz_data["Features"] records it (topk.py:197) -- x itself absorbs the pending mlp output only in the next norm. */

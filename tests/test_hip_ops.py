@@ -149,6 +149,24 @@ def test_patch_embed_fused(ops, B, HW, D, C):
     torch.testing.assert_close(got.view(B * (P + 1), D), x, atol=2e-6, rtol=1e-6)
 
 
+@pytest.mark.parametrize("M,D", [(394, 384), (33, 768), (7, 128), (5, 192)])
+def test_layernorm_with_two_pending_residuals(ops, M, D):
+    """The eval executor's lazy norm2: norm2 normalises x + d_attn WITHOUT writing it, the next norm1 takes (x + d_attn) + d_mlp and
+    writes the stream once -- bit for bit what the two eager in-place calls produce (outputs and stream)."""
+    rng = _rng(700 + M + D)
+    x = _randn(rng, M, D) * 2 + 0.3
+    d1, d2 = _randn(rng, M, D).bfloat16(), _randn(rng, M, D).bfloat16()
+    g, b = 1 + _randn(rng, D, scale=0.1), _randn(rng, D, scale=0.1)
+    xe = x.clone().cuda()
+    y2_eager = ops.layernorm(xe, g.cuda(), b.cuda(), 1e-6, delta=d1.cuda())              # x += d1
+    y1_eager = ops.layernorm(xe, g.cuda(), b.cuda(), 1e-6, delta=d2.cuda())              # x += d2
+    xl = x.clone().cuda()
+    y2_lazy = ops.layernorm2(xl, g.cuda(), b.cuda(), 1e-6, d1.cuda(), write_x=False)
+    assert torch.equal(xl.cpu(), x)                                                      # the stream was not touched
+    y1_lazy = ops.layernorm2(xl, g.cuda(), b.cuda(), 1e-6, d1.cuda(), d2.cuda())
+    assert torch.equal(y2_lazy, y2_eager) and torch.equal(y1_lazy, y1_eager) and torch.equal(xl, xe)
+
+
 # ------------------------------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("M,D", [(7, 128), (394, 384), (33, 768), (5, 192), (3, 1024)])
 def test_layernorm(ops, M, D):

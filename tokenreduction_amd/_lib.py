@@ -127,6 +127,7 @@ SIGNATURES = {
     "tr_cluster_merge_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _i, _i, _i, _i, _vp]),
     "tr_ats_scatter": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tr_layernorm_bf16_to": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _vp, _vp, _i, _i, _f, _vp]),
+    "tr_layernorm2_bf16": (_i, [_vp, _l, _vp, _l, _vp, _l, _vp, _l, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "tr_vit_tape_bytes": (_sz, [C.POINTER(TrVitConfig), _i]),
     "tr_vit_forward_train": (_i, [C.POINTER(TrVitConfig), C.POINTER(TrVitWeights), _vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _vp, C.POINTER(_i), _i, _vp,
                                   _vp, _f]),

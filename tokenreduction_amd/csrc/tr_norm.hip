@@ -13,8 +13,13 @@ namespace {
 // x[row] (+= delta[row], written back) -> y[row] = LayerNorm(x[row]).  delta is the bf16 output of the preceding Linear
 // (attn.proj or mlp.fc2): the residual add `x = x + drop_path(...)` (topk.py:87 / :95) is folded into the norm that
 // reads x next, so the GEMMs never read-modify-write the fp32 stream.
+// delta2 (bf16 path only): a SECOND pending residual, added after the first -- and write_x == 0: the sum is normalised but NOT
+// written back.  Together they let the eval executor skip the stream write of a norm2 that no reduction follows: norm2 reads
+// x + d_attn without storing it, the next norm1 reads x + d_attn + d_mlp (same fp32 additions in the same order: bit-identical) and
+// writes the stream once -- 22 instead of 24 bytes per element and block.
 template <bool F32, int NCH>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, long ldx, float* x_out, long ldxo, const void* __restrict__ delta, long ldd,
+                                                        const uint16_t* __restrict__ delta2, long ldd2, int write_x,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         void* __restrict__ y, int M, int D, float eps) {
   const int lane = threadIdx.x & 63;
@@ -27,7 +32,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, long ldx
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
     v[c] = ln_nt_load4(xr + 4 * min(lane + 64 * c, nchunks - 1));     // branch-free: all loads of the row go out in one batch
-  if (delta == nullptr && xo != xr) {
+  if (delta == nullptr && xo != xr && write_x) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
       if (lane + 64 * c < nchunks) ln_nt_store4(v[c], xo + 4 * (lane + 64 * c));
@@ -36,11 +41,21 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, long ldx
     float4 d[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) d[c] = load_delta4<F32>(delta, (size_t)row * ldd + 4 * min(lane + 64 * c, nchunks - 1));
+    if (!F32 && delta2 != nullptr) {
+      float4 e[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) e[c] = load_delta4<false>(delta2, (size_t)row * ldd2 + 4 * min(lane + 64 * c, nchunks - 1));
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        v[c].x += d[c].x; v[c].y += d[c].y; v[c].z += d[c].z; v[c].w += d[c].w;
+        d[c] = e[c];
+      }
+    }
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
       if (lane + 64 * c < nchunks) {
         v[c].x += d[c].x; v[c].y += d[c].y; v[c].z += d[c].z; v[c].w += d[c].w;
-        ln_nt_store4(v[c], xo + 4 * (lane + 64 * c));
+        if (write_x) ln_nt_store4(v[c], xo + 4 * (lane + 64 * c));
       }
   }
   ln_row_store<F32, NCH>(v, nchunks, lane, D, eps, gamma, beta,
@@ -52,6 +67,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x, long ldx
 // Same arithmetic as ln_row_store (two-pass statistics, sums over the row's 32 lanes by xor-shuffles 16..1).
 template <int CPL>
 __global__ __launch_bounds__(256) void layernorm_half_kernel(const float* x, long ldx, float* x_out, long ldxo, const uint16_t* __restrict__ delta, long ldd,
+                                                             const uint16_t* __restrict__ delta2, long ldd2, int write_x,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              uint16_t* __restrict__ y, int M, float eps) {
   constexpr int D = 128 * CPL;
@@ -65,18 +81,32 @@ __global__ __launch_bounds__(256) void layernorm_half_kernel(const float* x, lon
   f4 v[CPL];
 #pragma unroll
   for (int c = 0; c < CPL; ++c) v[c] = LN_LOAD(xr + sub + 32 * c);
-  if (delta == nullptr && xo != xr) {
+  if (delta == nullptr && xo != xr && write_x) {
 #pragma unroll
     for (int c = 0; c < CPL; ++c) LN_STORE(v[c], xo + sub + 32 * c);
   }
   if (delta != nullptr) {
     const u2* dr = reinterpret_cast<const u2*>(delta + (size_t)row * ldd);
+    u2 d[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) d[c] = LN_LOAD(dr + sub + 32 * c);
+    if (delta2 != nullptr) {               // the second pending residual: (x + delta) + delta2
+      const u2* er = reinterpret_cast<const u2*>(delta2 + (size_t)row * ldd2);
+      u2 e[CPL];
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) e[c] = LN_LOAD(er + sub + 32 * c);
+#pragma unroll
+      for (int c = 0; c < CPL; ++c) {
+        v[c][0] += __uint_as_float(d[c][0] << 16); v[c][1] += __uint_as_float(d[c][0] & 0xffff0000u);
+        v[c][2] += __uint_as_float(d[c][1] << 16); v[c][3] += __uint_as_float(d[c][1] & 0xffff0000u);
+        d[c] = e[c];
+      }
+    }
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
-      const u2 d = LN_LOAD(dr + sub + 32 * c);
-      v[c][0] += __uint_as_float(d[0] << 16); v[c][1] += __uint_as_float(d[0] & 0xffff0000u);
-      v[c][2] += __uint_as_float(d[1] << 16); v[c][3] += __uint_as_float(d[1] & 0xffff0000u);
-      LN_STORE(v[c], xo + sub + 32 * c);
+      v[c][0] += __uint_as_float(d[c][0] << 16); v[c][1] += __uint_as_float(d[c][0] & 0xffff0000u);
+      v[c][2] += __uint_as_float(d[c][1] << 16); v[c][3] += __uint_as_float(d[c][1] & 0xffff0000u);
+      if (write_x) LN_STORE(v[c], xo + sub + 32 * c);
     }
   }
   float s = 0.f;
@@ -265,26 +295,31 @@ __global__ __launch_bounds__(256) void cls_pos_kernel(const float* __restrict__ 
 }  // namespace
 
 static int layernorm_impl(bool f32, const float* x, long ldx, float* x_out, long ldxo, const void* delta, long ldd, const float* gamma,
-                          const float* beta, void* y, int M, int D, float eps, tr_stream_t s) {
-  TR_REQUIRE(x && x_out && gamma && beta && y, TR_ERR_NULL, "tr_layernorm: null pointer");
+                          const float* beta, void* y, int M, int D, float eps, tr_stream_t s, const uint16_t* delta2 = nullptr, long ldd2 = 0) {
+  TR_REQUIRE(x && gamma && beta && y, TR_ERR_NULL, "tr_layernorm: null pointer");
+  const int write_x = x_out != nullptr;           // tr_layernorm2_bf16: no stream write
+  if (!write_x) { x_out = const_cast<float*>(x); ldxo = ldx; }
   TR_REQUIRE(ldxo % 4 == 0 && ldxo >= D && tr_aligned16(x_out), TR_ERR_SHAPE, "tr_layernorm: bad x_out stride %ld", ldxo);
+  if (delta2) TR_REQUIRE(!f32 && delta && ldd2 % 4 == 0 && ldd2 >= D && ((uintptr_t)delta2 & 7u) == 0, TR_ERR_SHAPE,
+                         "tr_layernorm: a second residual needs the first, the bf16 path and a stride %% 4 == 0 (ldd2=%ld)", ldd2);
   TR_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 256 * LN_MAX_CHUNKS && ldx % 4 == 0 && ldx >= D, TR_ERR_SHAPE,
              "tr_layernorm: need D %% 4 == 0, D <= 1024, ldx %% 4 == 0 (M=%d D=%d ldx=%ld)", M, D, ldx);
   if (delta) TR_REQUIRE(ldd % 4 == 0 && ldd >= D && ((uintptr_t)delta & 7u) == 0, TR_ERR_SHAPE, "tr_layernorm: bad delta stride %ld", ldd);
   TR_REQUIRE(tr_aligned16(x) && tr_aligned16(gamma) && tr_aligned16(beta) && tr_aligned16(y), TR_ERR_ALIGN,
              "tr_layernorm: pointers must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(s);
-  tr_prof_note("layernorm_kernel", 0.0, (double)M * D * (f32 ? 4.0 : 2.0) + (delta ? (double)M * D * (8.0 + (f32 ? 4.0 : 2.0)) : (double)M * D * 4.0));
+  tr_prof_note("layernorm_kernel", 0.0, (double)M * D * (f32 ? 4.0 : 2.0) + (double)M * D * 4.0 + (delta ? (double)M * D * (f32 ? 4.0 : 2.0) : 0.0) +
+                                            (delta2 ? (double)M * D * 2.0 : 0.0) + ((delta && write_x) ? (double)M * D * 4.0 : 0.0));
 #ifndef TR_LN_NO_HALF
   if (!f32 && D == 384) {
     hipLaunchKernelGGL(layernorm_half_kernel<3>, dim3((M + 7) / 8), dim3(256), 0, st, x, ldx, x_out, ldxo, static_cast<const uint16_t*>(delta), ldd,
-                       gamma, beta, static_cast<uint16_t*>(y), M, eps);
+                       delta2, ldd2, write_x, gamma, beta, static_cast<uint16_t*>(y), M, eps);
     TR_CHECK_LAUNCH("tr_layernorm");
     return TR_OK;
   }
 #endif
-  if (f32) TR_DISPATCH_NCH(D, hipLaunchKernelGGL((layernorm_kernel<true, NCH>), dim3((M + 3) / 4), dim3(256), 0, st, x, ldx, x_out, ldxo, delta, ldd, gamma, beta, y, M, D, eps));
-  else TR_DISPATCH_NCH(D, hipLaunchKernelGGL((layernorm_kernel<false, NCH>), dim3((M + 3) / 4), dim3(256), 0, st, x, ldx, x_out, ldxo, delta, ldd, gamma, beta, y, M, D, eps));
+  if (f32) TR_DISPATCH_NCH(D, hipLaunchKernelGGL((layernorm_kernel<true, NCH>), dim3((M + 3) / 4), dim3(256), 0, st, x, ldx, x_out, ldxo, delta, ldd, delta2, ldd2, write_x, gamma, beta, y, M, D, eps));
+  else TR_DISPATCH_NCH(D, hipLaunchKernelGGL((layernorm_kernel<false, NCH>), dim3((M + 3) / 4), dim3(256), 0, st, x, ldx, x_out, ldxo, delta, ldd, delta2, ldd2, write_x, gamma, beta, y, M, D, eps));
   TR_CHECK_LAUNCH("tr_layernorm");
   return TR_OK;
 }
@@ -296,6 +331,12 @@ extern "C" int tr_layernorm_bf16(float* x, long ldx, const uint16_t* delta, long
 extern "C" int tr_layernorm_bf16_to(const float* x, long ldx, float* x_out, long ldxo, const uint16_t* delta, long ldd, const float* gamma,
                                     const float* beta, uint16_t* y, int M, int D, float eps, tr_stream_t s) {
   return layernorm_impl(false, x, ldx, x_out, ldxo, delta, ldd, gamma, beta, y, M, D, eps, s);
+}
+// y = LayerNorm(x + delta [+ delta2]) with the sum written to x_out -- or, x_out == NULL, not written at all (see layernorm_kernel)
+extern "C" int tr_layernorm2_bf16(const float* x, long ldx, float* x_out, long ldxo, const uint16_t* delta, long ldd, const uint16_t* delta2,
+                                  long ldd2, const float* gamma, const float* beta, uint16_t* y, int M, int D, float eps, tr_stream_t s) {
+  TR_REQUIRE(delta != nullptr, TR_ERR_NULL, "tr_layernorm2_bf16: needs a pending residual");
+  return layernorm_impl(false, x, ldx, x_out, ldxo, delta, ldd, gamma, beta, y, M, D, eps, s, delta2, ldd2);
 }
 extern "C" int tr_layernorm_f32(float* x, long ldx, const float* delta, long ldd, const float* gamma, const float* beta, float* y,
                                 int M, int D, float eps, tr_stream_t s) {

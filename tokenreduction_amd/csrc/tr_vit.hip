@@ -126,7 +126,7 @@ using trplan::align_up;
 
 struct Plan {
   int P, N0, D, H, Hd, C, kcols;
-  size_t off_x0, off_x1, off_xn, off_qkv, off_ao, off_h, off_d, off_cols, off_cls, off_scores, off_idx, off_compl, off_xcls, off_size0, off_size1, off_cluster, off_soft, total;
+  size_t off_x0, off_x1, off_xn, off_qkv, off_ao, off_h, off_d, off_d2, off_cols, off_cls, off_scores, off_idx, off_compl, off_xcls, off_size0, off_size1, off_cluster, off_soft, total;
 };
 
 bool make_plan(const tr_vit_config* c, int B, Plan* p) {
@@ -155,6 +155,7 @@ bool make_plan(const tr_vit_config* c, int B, Plan* p) {
   p->off_ao = o;     o += align_up(T * p->D * es);
   p->off_h = o;      o += align_up(T * p->Hd * es);
   p->off_d = o;      o += align_up(T * p->D * es);
+  p->off_d2 = o;     o += align_up(T * p->D * es);      // second residual buffer (norm2 without a stream write, see vit_forward_impl)
   p->off_cols = o;   o += align_up((size_t)B * p->P * p->kcols * es);
   p->off_cls = o;    o += align_up((size_t)B * p->H * p->N0 * 4);
   p->off_scores = o; o += align_up((size_t)B * p->N0 * 4);
@@ -199,6 +200,14 @@ inline int op_ln(bool f32, float* x, long ldx, const void* d, long ldd, const fl
                  float eps, tr_stream_t s) {
   return f32 ? tr_layernorm_f32(x, ldx, static_cast<const float*>(d), ldd, g, b, static_cast<float*>(y), M, D, eps, s)
              : tr_layernorm_bf16(x, ldx, static_cast<const uint16_t*>(d), ldd, g, b, static_cast<uint16_t*>(y), M, D, eps, s);
+}
+// norm over x + pending residual(s): the plain norm1 of a block and the final norm.  d_attn != nullptr: the previous block's norm2 did
+// not write the stream back (lazy norm2 below), so BOTH of its residuals are still pending -- (x + d_attn) + d, the reference's order
+inline int op_ln_pending(bool f32, float* x, long ldx, const void* d, const void* d_attn, long ldd, const float* g, const float* b, void* y,
+                         int M, int D, float eps, tr_stream_t s) {
+  if (d_attn == nullptr) return op_ln(f32, x, ldx, d, ldd, g, b, y, M, D, eps, s);
+  return tr_layernorm2_bf16(x, ldx, x, ldx, static_cast<const uint16_t*>(d_attn), ldd, static_cast<const uint16_t*>(d), ldd, g, b,
+                            static_cast<uint16_t*>(y), M, D, eps, s);
 }
 inline int op_attn(int prec, const void* qkv, void* out, float* cls_rows, const float* size, float* colsum, int B, int N, int H,
                    tr_stream_t s) {
@@ -257,6 +266,7 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
   void* hbuf = static_cast<void*>(ws + p.off_h);
   void* dbuf = static_cast<void*>(ws + p.off_d);   // bf16 output of proj / fc2, added to x by the NEXT norm
   void* const dbuf_shared = dbuf;
+  void* const dbuf2 = static_cast<void*>(ws + p.off_d2);
   void* cols = train ? static_cast<void*>(tape + tp->cols) : static_cast<void*>(ws + p.off_cols);
   float* cls_rows = reinterpret_cast<float*>(ws + p.off_cls);
   float* scores = reinterpret_cast<float*>(ws + p.off_scores);
@@ -273,6 +283,14 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
   const int D = p.D, H = p.H;
   const int prec = cfg->precision;
   const bool f32 = prec != TR_PREC_BF16;            // fp32 activations (TR_PREC_FP32 and TR_PREC_BF16X3)
+  // Lazy norm2 (eval, bf16, families whose blocks all start with a plain norm1): a norm2 that no reduction follows reads x + d_attn but
+  // does not store it; the next norm1 (or the final norm) adds d_attn and d_mlp in the reference's order and writes the stream once.
+  // Bit-identical to the eager sequence (same fp32 additions), 22 instead of 24 bytes per element and block through the norms.
+  static const bool ln_eager = [] { const char* e = getenv("TR_LN_EAGER"); return e && atoi(e) != 0; }();      // lab: A/B switch
+  const bool lazy_ok = !train && !f32 && !ln_eager && features_out == nullptr &&
+                       (cfg->family == TR_FAMILY_DEIT || cfg->family == TR_FAMILY_TOPK || cfg->family == TR_FAMILY_EVIT ||
+                        cfg->family == TR_FAMILY_ATS);
+  const void* pending_attn = nullptr;      // the attention branch's residual of the previous block, not yet in x (lazy norm2)
   // a1 + a2: patch embedding, CLS token, position embedding
   static const bool unfused_patch = [] { const char* e = getenv("TR_PATCH_UNFUSED"); return e && atoi(e) != 0; }();   // lab: the three-launch path
   if (!train && !f32 && !unfused_patch && tr_patch_embed_supported(cfg->in_chans, cfg->img_size, cfg->patch, D)) {
@@ -591,7 +609,11 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       TR_TRY(tr_layernorm_bf16_to(x, D, x1, D, static_cast<const uint16_t*>(pending), D, bw->ln1_g, bw->ln1_b, static_cast<uint16_t*>(xn), M, D,
                                   cfg->ln_eps, s));
       x = x1;
-    } else if (!have_xn) TR_TRY(op_ln(f32, x, D, pending, D, bw->ln1_g, bw->ln1_b, xn, M, D, cfg->ln_eps, s));
+    } else if (!have_xn) {
+      TR_TRY(op_ln_pending(f32, x, D, pending, pending_attn, D, bw->ln1_g, bw->ln1_b, xn, M, D, cfg->ln_eps, s));
+      pending_attn = nullptr;
+    }
+    TR_REQUIRE(pending_attn == nullptr, TR_ERR_CONFIG, "tr_vit_forward: internal: block %d did not absorb the lazy residual", i);
     TR_TRY(op_gemm(prec, xn, bw->qkv_w, bw->qkv_b, qkv, nullptr, 0, M, 3 * D, D, TR_EPI_BF16, s));
     // ToMe: log(size) bias on the keys; ATS: key mask as a 1/0 "size" (log 0 = -inf -> exactly zero weight, like
     // masked_fill(-finfo.max) underflowing in the reference's softmax, ats.py:117-120)
@@ -676,6 +698,10 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       TR_TRY(tr_layernorm_bf16_to(x, D, x_alt, D, static_cast<const uint16_t*>(dbuf), D, bw->ln2_g, bw->ln2_b, static_cast<uint16_t*>(xn), B * Nn, D,
                                   cfg->ln_eps, s));
       x = x_alt;
+    } else if (lazy_ok) {
+      TR_TRY(tr_layernorm2_bf16(x, D, nullptr, 0, static_cast<const uint16_t*>(dbuf), D, nullptr, 0, bw->ln2_g, bw->ln2_b,
+                                static_cast<uint16_t*>(xn), B * Nn, D, cfg->ln_eps, s));
+      pending_attn = dbuf;
     } else {
       TR_TRY(op_ln(f32, x, D, dbuf, D, bw->ln2_g, bw->ln2_b, xn, B * Nn, D, cfg->ln_eps, s));
     }
@@ -693,7 +719,7 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       TR_TRY(tr_dropout_bf16(static_cast<const uint16_t*>(hbuf), static_cast<uint16_t*>(hbuf), drop_keep, drop_mul, (size_t)M2 * p.Hd, s));
       drop_keep += (size_t)M2 * p.Hd;
     }
-    dbuf = dbuf_shared;
+    dbuf = (pending_attn == dbuf_shared) ? dbuf2 : dbuf_shared;      // the attention residual is still pending: fc2 writes beside it
     TR_TRY(op_gemm(prec, hbuf, bw->fc2_w, bw->fc2_b, dbuf, nullptr, 0, M2, D, p.Hd, TR_EPI_BF16, s));
     if (drop_keep != nullptr) {      // ... and after fc2
       TR_TRY(tr_dropout_bf16(static_cast<const uint16_t*>(dbuf), static_cast<uint16_t*>(dbuf), drop_keep, drop_mul, (size_t)M2 * D, s));
@@ -723,7 +749,7 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
     TR_TRY(tr_layernorm_bf16_to(x, (long)N * D, reinterpret_cast<float*>(tape + tp->xfinal), D, static_cast<const uint16_t*>(pending), (long)N * D,
                                 w->norm_g, w->norm_b, static_cast<uint16_t*>(xcls), B, D, cfg->ln_eps, s));
   } else {
-    TR_TRY(op_ln(f32, x, (long)N * D, pending, (long)N * D, w->norm_g, w->norm_b, xcls, B, D, cfg->ln_eps, s));
+    TR_TRY(op_ln_pending(f32, x, (long)N * D, pending, pending_attn, (long)N * D, w->norm_g, w->norm_b, xcls, B, D, cfg->ln_eps, s));
   }
   TR_TRY(op_gemm(prec, xcls, w->head_w, w->head_b, logits, nullptr, 0, B, p.C, D, TR_EPI_F32, s));
   return TR_OK;

@@ -168,6 +168,19 @@ def gemm_f32(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, epilogue: int
     return out
 
 
+def layernorm2(x: torch.Tensor, gamma, beta, eps: float, delta: torch.Tensor, delta2: torch.Tensor = None, write_x: bool = True) -> torch.Tensor:
+    """y = LayerNorm((x + delta) + delta2) -> bf16 [M,D]; the sum is written back to x unless write_x is False (tr_layernorm2_bf16:
+    the eval executor's norm2 without a stream write, and the norm1 that absorbs both pending residuals after it)."""
+    D = x.shape[-1]
+    M = x.numel() // D
+    y = torch.empty(M, D, dtype=torch.bfloat16, device=x.device)
+    xp = _dev(x, torch.float32, "x")
+    _lib.check(_lib.load().tr_layernorm2_bf16(xp, D, xp if write_x else None, D, _dev(delta, torch.bfloat16, "delta"), D,
+                                              _opt(delta2, torch.bfloat16, "delta2"), D, _dev(gamma, torch.float32, "gamma"),
+                                              _dev(beta, torch.float32, "beta"), y.data_ptr(), M, D, eps, _stream()), "tr_layernorm2_bf16")
+    return y
+
+
 def layernorm_f32(x: torch.Tensor, gamma, beta, eps: float, delta: torch.Tensor = None) -> torch.Tensor:
     D = x.shape[-1]
     M = x.numel() // D
