@@ -453,6 +453,27 @@ def test_forward_is_graph_capturable():
     assert torch.equal(out, model(x2))
 
 
+@pytest.mark.parametrize("name", ["deit_micro", "topk_micro", "evit_micro", "ats_micro", "tome_micro", "dyvit_micro", "sit_micro", "dpcknn_micro",
+                                  "kmedoids_micro", "sinkhorn_micro", "patchmerger_micro", "heuristic_micro_l2", "topk_small_kr07",
+                                  "dpcknn_base_kr05", "topk_micro_384"])
+def test_lazy_norm2_is_bit_identical_to_the_eager_sequence(golden_dir, name):
+    """Without viz_mode the eval executor skips the stream write of every norm2 that no reduction follows and lets the next norm1 (or the
+    final norm) absorb both pending residuals (tr_layernorm2_bf16); with viz_mode (`Features` wants the stream after every block) it
+    runs the eager sequence.  Same fp32 additions in the same order: the logits must agree bit for bit, for every family."""
+    case = GOLDEN_CASES[name]
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    model, _, _ = build_model(case)
+    noise = {int(k.split("_")[1]): torch.from_numpy(g[k]) for k in g.files if k.startswith("noise_")}
+    if noise:
+        model.density_noise = noise
+    x = make_images(case["batch"], case.get("img_size", 224), case["xseed"]).cuda()
+    model.viz_mode = True
+    eager = model(x)[0].clone()
+    model.viz_mode = False
+    lazy = model(x).clone()
+    assert torch.equal(lazy, eager)
+
+
 def test_graph_replay_gives_way_to_plain_launches_when_inputs_keep_moving():
     """The eval forward replays a hipGraph keyed on the input's address.  A caller whose batches land at a new address every time would
     re-capture on every call: after GRAPH_MISS_LIMIT misses in a row the workspace goes back to plain launches, with one warning; a caller

@@ -287,9 +287,16 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
   // does not store it; the next norm1 (or the final norm) adds d_attn and d_mlp in the reference's order and writes the stream once.
   // Bit-identical to the eager sequence (same fp32 additions), 22 instead of 24 bytes per element and block through the norms.
   static const bool ln_eager = [] { const char* e = getenv("TR_LN_EAGER"); return e && atoi(e) != 0; }();      // lab: A/B switch
-  const bool lazy_ok = !train && !f32 && !ln_eager && features_out == nullptr &&
-                       (cfg->family == TR_FAMILY_DEIT || cfg->family == TR_FAMILY_TOPK || cfg->family == TR_FAMILY_EVIT ||
-                        cfg->family == TR_FAMILY_ATS);
+  const bool lazy_base = !train && !f32 && !ln_eager && features_out == nullptr;
+  // what consumes the pending residuals after block j - 1: a plain norm1 (or the final norm) unless a pre-block reducer fires at block j
+  auto starts_plain = [&](int j) {
+    if (j >= cfg->depth) return true;
+    switch (cfg->family) {
+      case TR_FAMILY_DPCKNN: case TR_FAMILY_KMEDOIDS: case TR_FAMILY_PATCHMERGER: case TR_FAMILY_SINKHORN: case TR_FAMILY_DYVIT:
+      case TR_FAMILY_SIT: return cfg->keep[j] <= 0;
+      default: return true;                                   // in-block families (Top-K, EViT, ToMe, ATS), DeiT, Heuristic (masks only)
+    }
+  };
   const void* pending_attn = nullptr;      // the attention branch's residual of the previous block, not yet in x (lazy norm2)
   // a1 + a2: patch embedding, CLS token, position embedding
   static const bool unfused_patch = [] { const char* e = getenv("TR_PATCH_UNFUSED"); return e && atoi(e) != 0; }();   // lab: the three-launch path
@@ -698,7 +705,7 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       TR_TRY(tr_layernorm_bf16_to(x, D, x_alt, D, static_cast<const uint16_t*>(dbuf), D, bw->ln2_g, bw->ln2_b, static_cast<uint16_t*>(xn), B * Nn, D,
                                   cfg->ln_eps, s));
       x = x_alt;
-    } else if (lazy_ok) {
+    } else if (lazy_base && starts_plain(i + 1)) {
       TR_TRY(tr_layernorm2_bf16(x, D, nullptr, 0, static_cast<const uint16_t*>(dbuf), D, nullptr, 0, bw->ln2_g, bw->ln2_b,
                                 static_cast<uint16_t*>(xn), B * Nn, D, cfg->ln_eps, s));
       pending_attn = dbuf;
