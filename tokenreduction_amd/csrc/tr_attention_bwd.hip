@@ -570,7 +570,10 @@ __global__ __launch_bounds__(512, 2) void attention_bwd8_kernel(const uint16_t* 
       pp.y = pack_bf16x2(pv[2], pv[3]);
       ds.x = pack_bf16x2(dsv[0], dsv[1]);
       ds.y = pack_bf16x2(dsv[2], dsv[3]);
-      const int off = pswz(il, 2 * jt + (g >> 1)) + 8 * (g & 1);     // keys 16jt + 4g .. +3 of row il
+      // keys 16jt + 4g .. +3 of row il.  Rows 8..15 of a 16-row group keep the two 8-byte halves of a chunk swapped: with the half fixed,
+      // the 16 lanes of a write group cover 8 of the 16 (chunk mod 8, half) positions twice -- a 2-way conflict on every P / dS write
+      // (10 % of the kernel's LDS cycles in r03_a); the readers below undo the swap (tools/lds_sim.py: 8 -> 4 cycles, reads unchanged)
+      const int off = pswz(il, 2 * jt + (g >> 1)) + 8 * ((g & 1) ^ ((li >> 3) & 1));
       *reinterpret_cast<uint2*>(sP + off) = pp;
       *reinterpret_cast<uint2*>(sDS + off) = ds;
     }
@@ -580,7 +583,8 @@ __global__ __launch_bounds__(512, 2) void attention_bwd8_kernel(const uint16_t* 
       f32x4 dq[2];
 #pragma unroll
       for (int ks = 0; ks < NKB; ++ks) {
-        const bf16x8 dsf = *reinterpret_cast<const bf16x8*>(sDS + pswz(il, 4 * ks + g));          // B[k = key][col = query]
+        bf16x8 dsf = *reinterpret_cast<const bf16x8*>(sDS + pswz(il, 4 * ks + g));          // B[k = key][col = query]
+        if ((li >> 3) & 1) dsf = __builtin_shufflevector(dsf, dsf, 4, 5, 6, 7, 0, 1, 2, 3);  // this row's halves are stored swapped
         const int r0 = 32 * ks + 8 * g + q4;
 #pragma unroll
         for (int dd = 0; dd < 2; ++dd) {
@@ -616,8 +620,9 @@ __global__ __launch_bounds__(512, 2) void attention_bwd8_kernel(const uint16_t* 
         const int jt = wave + 8 * t;
         if (jt < NT) {                  // wave-uniform
           const int ch = 2 * jt + (p4 >> 1);
-          const bf16x8 dsf = lds_tr_pair(sDS + pswz(r0, ch) + 8 * (p4 & 1), sDS + pswz(r0 + 4, ch) + 8 * (p4 & 1));   // B[k = query][col = key]
-          const bf16x8 pf = lds_tr_pair(sP + pswz(r0, ch) + 8 * (p4 & 1), sP + pswz(r0 + 4, ch) + 8 * (p4 & 1));
+          const int hb = 8 * ((p4 & 1) ^ (g & 1));      // rows r0 and r0 + 4 lie in the same half of their 16-row group: bit 3 = g & 1
+          const bf16x8 dsf = lds_tr_pair(sDS + pswz(r0, ch) + hb, sDS + pswz(r0 + 4, ch) + hb);   // B[k = query][col = key]
+          const bf16x8 pf = lds_tr_pair(sP + pswz(r0, ch) + hb, sP + pswz(r0 + 4, ch) + hb);
 #pragma unroll
           for (int d = 0; d < 4; ++d) {
             dk[t][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt[d], dsf, dk[t][d], 0, 0, 0);
