@@ -34,6 +34,18 @@ __device__ __forceinline__ bf16x8 lds_tr_pair(const unsigned char* p0, const uns
 // [rows][64 bf16] image, 128-B rows: conflict-free for 16-byte row reads AND transposed reads (tools/lds_sim.py; tr_attention_bwd.hip)
 __device__ __forceinline__ int qswz(int row, int ch) { return row * 128 + ((ch ^ ((((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2))) << 4); }
 
+// The P / dS images ([64 queries][64 keys]) are WRITTEN 8 bytes per lane by 16 lanes that hold the same keys of 16 consecutive queries;
+// under qswz those 16 rows share 4 chunk positions and one 8-byte half: a 4-way conflict (16 instead of 4 cycles per write).  This
+// swizzle spreads the 16 rows over all 16 (chunk, half) positions of a 128-byte row: chunk ^= row bits {0, 1, 3}, the two halves of a
+// chunk swapped on rows with bit 2 set; 16-byte row reads and the transposed 8-byte reads stay conflict-free (search + check:
+// tools/lds_sim.py).  A 16-byte row read of a swapped row swaps its register halves back.
+__device__ __forceinline__ int dswz(int row, int ch) { return row * 128 + ((ch ^ ((row & 3) | (((row >> 3) & 1) << 2))) << 4); }
+__device__ __forceinline__ int dswz8(int row, int ch, int half) { return dswz(row, ch) + 8 * (half ^ ((row >> 2) & 1)); }
+__device__ __forceinline__ bf16x8 dswz_row_read(const unsigned char* img, int row, int ch) {
+  const bf16x8 v = *reinterpret_cast<const bf16x8*>(img + dswz(row, ch));
+  return ((row >> 2) & 1) ? __builtin_shufflevector(v, v, 4, 5, 6, 7, 0, 1, 2, 3) : v;
+}
+
 constexpr int LB = 64;                                        // keys / queries per block
 constexpr float C_EXP = 0.125f * 1.44269504088896340736f;     // dh^-0.5 * log2(e)
 
@@ -216,7 +228,7 @@ __device__ __forceinline__ void write_p_ds(unsigned char* sP, unsigned char* sDS
     pp.y = pack_bf16x2(pv[2], pv[3]);
     dd.x = pack_bf16x2(dsv[0], dsv[1]);
     dd.y = pack_bf16x2(dsv[2], dsv[3]);
-    const int off = qswz(il, 2 * jt + (g >> 1)) + 8 * (g & 1);        // keys 16 jt + 4 g .. + 3 of row il
+    const int off = dswz8(il, 2 * jt + (g >> 1), g & 1);        // keys 16 jt + 4 g .. + 3 of row il
     if (sP != nullptr) *reinterpret_cast<uint2*>(sP + off) = pp;
     *reinterpret_cast<uint2*>(sDS + off) = dd;
   }
@@ -259,7 +271,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const uint16_t* __rest
     // dQ^T[d][query] += sum_key K[key][d] dS[query][key]: own rows only (LDS operations of one wave are ordered)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      const bf16x8 dsf = *reinterpret_cast<const bf16x8*>(sDS + qswz(il, 4 * ks + g));          // B[k = key][col = query]
+      const bf16x8 dsf = dswz_row_read(sDS, il, 4 * ks + g);          // B[k = key][col = query]
       const int r0 = 32 * ks + 8 * g + q4;
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
@@ -346,8 +358,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const uint16_t* __res
     for (int ks = 0; ks < 2; ++ks) {
       const int r0 = 32 * ks + 8 * g + q4;
       const int chk = 2 * wave + (p4 >> 1);
-      const bf16x8 dsf = lds_tr_pair(sDS + qswz(r0, chk) + 8 * (p4 & 1), sDS + qswz(r0 + 4, chk) + 8 * (p4 & 1));   // B[k = query][col = key]
-      const bf16x8 pf = lds_tr_pair(sP + qswz(r0, chk) + 8 * (p4 & 1), sP + qswz(r0 + 4, chk) + 8 * (p4 & 1));
+      const bf16x8 dsf = lds_tr_pair(sDS + dswz8(r0, chk, p4 & 1), sDS + dswz8(r0 + 4, chk, p4 & 1));   // B[k = query][col = key]
+      const bf16x8 pf = lds_tr_pair(sP + dswz8(r0, chk, p4 & 1), sP + dswz8(r0 + 4, chk, p4 & 1));
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
         const int ch = 2 * d + (p4 >> 1);
