@@ -29,6 +29,7 @@ BATCH = 256
 MODEL = "topk_small_patch16_224"
 KEEP_RATE, REDUCTION_LOC = [0.7], [3, 6, 9]
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md chip table)
+FEED_CEILING_TFLOPS = 1045.0     # gemm_bf16_pc's K-loop ceiling from the L2->LDS feed (see roofline_from)
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -132,6 +133,13 @@ def roofline_from(agg, full=False):
         roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=PEAK_HBM_GBPS, unit="GB/s",
                     frac=round(ach / PEAK_HBM_GBPS, 4), traffic=None,
                     bytes_per_launch=a["bytes"] / a["launches"], avg_launch_us=round(1e3 * a["ms"] / a["launches"], 2))
+    if dom.startswith("gemm_bf16_pc"):
+        # what bounds this kernel before the matrix pipes do (profiles/r01_gemm_lab.md): the K-loop of a 256 x 128 tile
+        # feeds 48 KiB through the CU's L2 -> LDS path (~33 B/clk, measured with the DMA-only ablation) per 4.19 MFLOP = 85 FLOP per
+        # fed byte, and the chip sustains ~1.45 GHz under this load: 85.3 x 33 x 256 CUs x 1.45e9 = ~1045 TFLOP/s for the K-loop alone
+        roof["secondary_bound"] = dict(name="L2->LDS feed of the 256x128x64 tile at the sustained clock", ceiling=FEED_CEILING_TFLOPS,
+                                       unit="TFLOP/s", frac=round(ach / FEED_CEILING_TFLOPS, 4),
+                                       basis="85.3 FLOP per fed byte x 33 B/clk/CU x 256 CUs x 1.45 GHz")
     roof["share_of_step"] = round(a["ms"] / total_ms, 4)
     roof["traffic_source"] = "not collected for this config (PMC passes cover the headline config)"
     if not full:
