@@ -110,7 +110,8 @@ int tr_broadcast_rows(const float* src, float* dst, int B, int N, tr_stream_t s)
  * colsum_part (nullable) fp32 [B,H,4,N]: column sums of the softmax matrix, one partial per wave of the workgroup -- summed
  * over (H, 4) they are K-Medoids' token weights sum_h sum_q attn[b,h,q,:] (kmedoids.py:240); partials keep the summation
  * order fixed (no float atomics).
- * N <= 224 in this round (whole score row in registers); larger N returns TR_ERR_SHAPE. */
+ * Any N: up to 224 tokens a query's whole score row sits in registers (attention16_kernel); beyond (384 x 384 inputs: 577) keys pass
+ * through the LDS in chunks of 128 with an online softmax; column sums together with a key bias need N <= 608. */
 int tr_attention_bf16(const uint16_t* qkv, uint16_t* out, float* cls_rows, const float* size, float* colsum_part, int B, int N,
                       int H, tr_stream_t s);
 /* fp32 validation path (N <= 640; K/V of a head in LDS up to N = 256, read from L2 beyond): same contract in the reference's
@@ -248,7 +249,7 @@ int tr_ats_gather(const float* x, const void* ao, int ao_is_f32, const int32_t* 
  * K third of qkv ([B*N, 3*H*64]; bf16, or fp32 when qkv_is_f32).  Tokens at even positions form set A (CLS = A[0], never
  * merged), odd positions set B.  Outputs (int32): src_idx [B,r] = the r A-tokens with the largest best-match score, in
  * descending order; dst_idx [B,r] = the B-token each is merged into; unm_idx [B, ceil(N/2)-r] = the other A-tokens, ascending.
- * 3 <= N <= 224, 1 <= r <= (N-1)/2 (tome.py:253). */
+ * 3 <= N <= 600, 1 <= r <= (N-1)/2 (tome.py:253). */
 int tr_tome_match(const void* qkv, int qkv_is_f32, int32_t* unm_idx, int32_t* src_idx, int32_t* dst_idx, int B, int N, int H,
                   int r, tr_stream_t s);
 
@@ -486,8 +487,8 @@ int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w, const floa
                    const float* noise_in, float* features_out, int* tokens_out, int B, tr_stream_t s);
 
 /* ---- training: forward that keeps its activations + backward executor (csrc/tr_vit.hip, csrc/tr_train.hip) ----------------------
- * engine.py:50-76: `output = model(samples)` in train mode, `loss.backward()`.  Families: DeiT, Top-K, EViT, ToMe, DPC-KNN, ATS, DyViT
- * (bf16, N <= 224).  DyViT (dyvit.py:221-229): noise_in = the Gumbel noise of every stage, fp32 [B,P,2] back to back (torch's
+ * engine.py:50-76: `output = model(samples)` in train mode, `loss.backward()`.  Every family (bf16 operands, fp32 master weights and
+ * gradients), up to 640 tokens (224 x 224 and 384 x 384 inputs).  DyViT (dyvit.py:221-229): noise_in = the Gumbel noise of every stage, fp32 [B,P,2] back to back (torch's
  * -log(Exp(1)) draws); the stages' policies stay on the tape (tr_vit_tape_layout); features_out (nullable) fp32 [B,N0,D]: the final
  * norm of every row (the distillation features, dyvit.py:252-258); tr_vit_backward takes dpred fp32 [stages,B,P] (gradient wrt each
  * stage's out_pred_prob) and dfeat fp32 [B,N0,D] (gradient wrt features_out), both nullable.
