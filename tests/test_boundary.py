@@ -135,6 +135,20 @@ def test_argument_validation_without_gpu():
     cfg.embed_dim, cfg.depth, cfg.num_heads, cfg.mlp_hidden, cfg.num_classes = 384, 12, 6, 1536, 1000
     n = lib.tr_vit_workspace_bytes(ctypes.byref(cfg), 256)
     assert 0 < n < 2 ** 31
+    # round-3 entry points: host-side checks only
+    assert lib.tr_patch_embed_supported(3, 224, 16, 384) == 1 and lib.tr_patch_embed_supported(3, 384, 16, 768) == 1
+    assert lib.tr_patch_embed_supported(3, 224, 16, 192) == 0 and lib.tr_patch_embed_supported(3, 224, 32, 384) == 0      # DeiT-T width, patch 32
+    assert lib.tr_patch_embed_bf16(p, p, p, p, p, p, 1, 3, 224, 16, 128, None) == -1                                         # embed_dim % 384
+    assert lib.tr_layernorm2_bf16(p, 384, None, 0, None, 384, None, 0, p, p, p, 4, 384, 1e-6, None) == -3                    # needs a residual
+    assert lib.tr_attention_policy_bwd_long_bf16(p, p, p, p, p, p, 8, 1, 300, 1, None) == -1                                 # workspace too small
+    # dropout keep mask: one byte per element the training forward drops -- pos_drop, then per block proj's rows, the hidden layer, fc2's rows
+    # (Top-K reduces inside a block, after attention + proj: proj sees the tokens that entered the block, the Mlp those that are left)
+    n_mlp = [197] * 3 + [138] * 3 + [97] * 3 + [68] * 3
+    n_att = [197] * 4 + [138] * 3 + [97] * 3 + [68] * 2
+    for i, k in ((3, 137), (6, 96), (9, 67)):
+        cfg.keep[i] = k
+    want = 4 * 197 * 384 + sum(4 * (a * 384 + t * (1536 + 384)) for a, t in zip(n_att, n_mlp))
+    assert lib.tr_vit_dropout_mask_bytes(ctypes.byref(cfg), 4) == want
 
 
 def test_reference_finetune_ingest_snippet_runs_unchanged():
