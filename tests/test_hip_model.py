@@ -496,6 +496,48 @@ def test_graph_replay_gives_way_to_plain_launches_when_inputs_keep_moving():
     assert torch.equal(model(x), want)                       # plain launches from here on
 
 
+def test_graph_replay_survives_a_ring_of_static_input_buffers():
+    """A caller that rotates a few static input buffers (prefetch ring) misses once per buffer on its first pass and hits ever after: the
+    first-pass misses must not switch the replay off (GRAPH_MISS_LIMIT used to be 4, below the cache's 8 entries)."""
+    case = GOLDEN_CASES["topk_micro"]
+    model, _, _ = build_model(case)
+    model.viz_mode = False
+    ring = [make_images(3, 224, 20 + i).cuda() for i in range(model.GRAPH_CACHE)]
+    want = [model(x).clone() for x in ring]                  # GRAPH_CACHE consecutive misses
+    ws = model._last_ws
+    assert not ws.get("graph_off") and len(ws["graphs"]) == model.GRAPH_CACHE
+    for _ in range(2):
+        for x, w in zip(ring, want):
+            assert torch.equal(model(x), w)
+    assert not ws.get("graph_off") and ws["graph_misses"] == 0
+
+
+def test_repack_after_a_parameter_moved_drops_the_captured_graphs():
+    """Biases and LayerNorm parameters are read through the parameter's own storage: giving one a NEW storage (p.data = ..., an optimizer
+    that flattens its parameters) must drop the workspaces and their captured graphs, which hold the old address."""
+    case = GOLDEN_CASES["topk_micro"]
+    model, _, _ = build_model(case)
+    model.viz_mode = False
+    x = make_images(3, 224, 12).cuda()
+    before = model(x).clone()
+    assert torch.equal(model(x), before)                     # replayed
+    fresh, _, _ = build_model(case)
+    fresh.viz_mode = False
+    with torch.no_grad():
+        for m in (model, fresh):
+            new_b = m.blocks[1].norm1.bias.data.clone() + 0.25
+            new_fc = m.blocks[0].mlp.fc2.bias.data.clone() - 0.5
+            if m is model:
+                m.blocks[1].norm1.bias.data = new_b          # a NEW storage, same shape: no slot moves, no version bump on the old tensor
+                m.blocks[0].mlp.fc2.bias.data = new_fc
+            else:
+                m.blocks[1].norm1.bias.copy_(new_b)
+                m.blocks[0].mlp.fc2.bias.copy_(new_fc)
+    got, want = model(x), fresh(x)
+    assert not torch.equal(got, before)
+    assert torch.equal(got, want)
+
+
 def test_dyvit_teacher_returns_logits_and_normed_tokens():
     """VisionTransformerTeacher.forward dyvit.py:325-334: (head(norm(x)[:, 0]), norm(x)[:, 1:])."""
     import tokenreduction_amd as tra

@@ -1320,23 +1320,27 @@ __global__ __launch_bounds__(256) void cast_pack_kernel(const tr_cast_item* __re
   const float* src = static_cast<const float*>(I.src);
   uint16_t* dst = static_cast<uint16_t*>(I.dst);
   uint16_t* dst_t = static_cast<uint16_t*>(I.dst_t);
+  // 16-byte loads / 8-byte stores only where every row starts on one: whole vectors per row and aligned bases (item-uniform)
+  const bool vec = (I.cols & 3) == 0 && (reinterpret_cast<uintptr_t>(I.src) & 15u) == 0 && (reinterpret_cast<uintptr_t>(I.dst) & 7u) == 0;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const int r = r0 + ty + 16 * p, c = c0 + 4 * tx;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < I.rows && c + 3 < I.cols) v = *reinterpret_cast<const float4*>(src + (size_t)r * I.cols + c);
+    if (vec && r < I.rows && c + 3 < I.cols) v = *reinterpret_cast<const float4*>(src + (size_t)r * I.cols + c);
     else if (r < I.rows) {
       if (c < I.cols) v.x = src[(size_t)r * I.cols + c];
       if (c + 1 < I.cols) v.y = src[(size_t)r * I.cols + c + 1];
       if (c + 2 < I.cols) v.z = src[(size_t)r * I.cols + c + 2];
+      if (c + 3 < I.cols) v.w = src[(size_t)r * I.cols + c + 3];
     }
     const unsigned lo = pack_bf16x2(v.x, v.y), hi = pack_bf16x2(v.z, v.w);
     if (dst != nullptr && r < I.rows) {
-      if (c + 3 < I.cols) *reinterpret_cast<uint2*>(dst + (size_t)r * I.cols + c) = make_uint2(lo, hi);
+      if (vec && c + 3 < I.cols) *reinterpret_cast<uint2*>(dst + (size_t)r * I.cols + c) = make_uint2(lo, hi);
       else {
         if (c < I.cols) dst[(size_t)r * I.cols + c] = (uint16_t)(lo & 0xffffu);
         if (c + 1 < I.cols) dst[(size_t)r * I.cols + c + 1] = (uint16_t)(lo >> 16);
         if (c + 2 < I.cols) dst[(size_t)r * I.cols + c + 2] = (uint16_t)(hi & 0xffffu);
+        if (c + 3 < I.cols) dst[(size_t)r * I.cols + c + 3] = (uint16_t)(hi >> 16);
       }
     }
     if (dst_t != nullptr) {
@@ -1355,7 +1359,7 @@ __global__ __launch_bounds__(256) void cast_pack_kernel(const tr_cast_item* __re
     const unsigned short a = tile[4 * tx][ty + 16 * p], b = tile[4 * tx + 1][ty + 16 * p], cc = tile[4 * tx + 2][ty + 16 * p],
                          d = tile[4 * tx + 3][ty + 16 * p];
     uint16_t* o = dst_t + (size_t)c * I.rows + r;
-    if (r + 3 < I.rows && (I.rows & 3) == 0) *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)a | ((unsigned)b << 16), (unsigned)cc | ((unsigned)d << 16));
+    if (r + 3 < I.rows && (I.rows & 3) == 0 && (reinterpret_cast<uintptr_t>(dst_t) & 7u) == 0) *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)a | ((unsigned)b << 16), (unsigned)cc | ((unsigned)d << 16));
     else {
       if (r < I.rows) o[0] = a;
       if (r + 1 < I.rows) o[1] = b;

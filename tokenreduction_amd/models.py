@@ -87,7 +87,10 @@ class VisionTransformer(nn.Module):
 
     _family = _lib.TR_FAMILY_DEIT
     _blocks_last = False
-    GRAPH_MISS_LIMIT = 4         # consecutive forwards with a never-seen input address before a workspace stops capturing hipGraphs
+    GRAPH_CACHE = 8              # captured graphs kept per workspace (one per input buffer / output set)
+    # consecutive forwards with a never-seen input address before a workspace stops capturing hipGraphs: one more than the cache holds, so
+    # that a caller rotating up to GRAPH_CACHE static input buffers (prefetch ring, multi-crop eval) gets through its first pass
+    GRAPH_MISS_LIMIT = GRAPH_CACHE + 1
 
     def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
                  num_heads=12, mlp_ratio=4., qkv_bias=True, representation_size=None, distilled=False,
@@ -257,7 +260,8 @@ class VisionTransformer(nn.Module):
                 return c.data_ptr()
             c = slot("w", t.shape, torch.bfloat16)
             ct = slot("t", (t.shape[1], t.shape[0]), torch.bfloat16) if (transposed and want_t) else None
-            if t.dim() == 2 and live(t) and t.numel() >= 4096:
+            # the fused cast kernel moves 16-byte vectors: rows must be whole vectors and start on one
+            if t.dim() == 2 and live(t) and t.numel() >= 4096 and t.shape[1] % 4 == 0 and t.data_ptr() % 16 == 0 and (ct is None or t.shape[0] % 4 == 0):
                 fused.append((t, c, ct))
             else:
                 c.copy_(t)
@@ -325,7 +329,10 @@ class VisionTransformer(nn.Module):
         self._weights_dirty = False
         # workspaces and captured graphs hold the operand addresses: they survive a repack unless a buffer had to be (re)allocated or the
         # configuration changed (first pack, precision switch, new head, new keep schedule)
-        if state["moved"] or old is None or bytes(old["cfg"]) != bytes(cfg):
+        # ... or a LIVE pointer moved: biases, LayerNorm parameters, pos_embed / cls_token (and every weight in fp32 mode) are read through
+        # the parameter's own storage, so `p.data = ...`, load_state_dict(assign=True) or an optimizer that flattens its parameters puts
+        # a new address into W while every slot stays where it was -- a captured graph would keep reading the old (possibly freed) memory
+        if state["moved"] or old is None or bytes(old["cfg"]) != bytes(cfg) or bytes(old["W"]) != bytes(W):
             self._ws = {}
         return self._packed
 
@@ -472,7 +479,7 @@ class VisionTransformer(nn.Module):
                         g = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(g):
                             toks = launch(out)
-                        if len(graphs) >= 8:
+                        if len(graphs) >= self.GRAPH_CACHE:
                             graphs.pop(next(iter(graphs)))
                         ent = graphs[key] = (g, out, toks)
                 else:
