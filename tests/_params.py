@@ -6,6 +6,8 @@ Key names are the reference's state-dict names.
 """
 from __future__ import annotations
 
+import types
+
 import numpy as np
 import torch
 
@@ -275,6 +277,14 @@ GRAD_CASES = ["deit_micro", "topk_micro", "evit_micro", "tome_micro", "dpcknn_mi
               "topk_micro_384", "kmedoids_micro_384", "ats_micro_384", "sinkhorn_micro_384",
               "sinkhorn_micro_384_kr09", "dpcknn_micro_384_kr09", "sit_micro_384_kr07", "patchmerger_micro_384_kr07",
               "dyvit_tiny_train", "sit_tiny", "topk_micro_dropout", "evit_micro_dropout", "dyvit_micro_train_384"]
+
+
+def finetune_ingest_setup():
+    """(224 config, 384 config, synthetic DeiT-layout 224 x 224 checkpoint state dict) of the f3 ingest fixture: a micro trunk trained at
+    224 with 16 classes, to be fine-tuned at 384 with 10 classes (the head must be dropped, the position embedding resized 14 -> 24)."""
+    cfg224 = types.SimpleNamespace(embed_dim=64, depth=3, num_heads=1, mlp_ratio=4, num_classes=16, img_size=224, patch_size=16, in_chans=3)
+    cfg384 = types.SimpleNamespace(embed_dim=64, depth=3, num_heads=1, mlp_ratio=4, num_classes=10, img_size=384, patch_size=16, in_chans=3)
+    return cfg224, cfg384, make_params(cfg224, 777, 1.0)
 
 
 def dyvit_token_ratio(case: dict):

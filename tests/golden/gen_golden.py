@@ -379,8 +379,42 @@ def run_grad_case(name, case):
           f"{sum(float(rec['norm:' + n]) ** 2 for n in names) ** 0.5:.4e}")
 
 
+def run_finetune_ingest():
+    """f3: the checkpoint ingest of a 224 -> 384 fine-tune.  The fixture is produced by EXECUTING the reference's own statements
+    (train.py:343-370, read from /root/reference at generation time, nothing of them is stored) on a reference model object and a
+    seeded synthetic 224 x 224 checkpoint; it records what they leave behind: the resized position embedding, the keys that were
+    dropped / reported missing.  tests/test_boundary.py re-creates the checkpoint from the seed and checks
+    tokenreduction_amd.finetune.load_finetune_checkpoint against these outputs."""
+    import textwrap
+    from tests._params import finetune_ingest_setup
+    cfg224, cfg384, ck = finetune_ingest_setup()
+    args = types.SimpleNamespace(keep_rate=[0.5], reduction_loc=[1, 2], viz_mode=False)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = TopKVisionTransformer(img_size=384, patch_size=16, embed_dim=cfg384.embed_dim, depth=cfg384.depth, num_heads=cfg384.num_heads,
+                                      mlp_ratio=4, qkv_bias=True, num_classes=cfg384.num_classes, args=args)
+    with open("/root/reference/train.py") as f:
+        lines = f.read().splitlines()
+    first = next(i for i, l in enumerate(lines) if "checkpoint_model = checkpoint['model']" in l)
+    last = next(i for i, l in enumerate(lines) if "model.load_state_dict(checkpoint_model, strict=False)" in l)
+    assert (first + 1, last + 1) == (343, 370), (first + 1, last + 1)
+    snippet = textwrap.dedent("\n".join(lines[first:last + 1]))
+    ns = {"checkpoint": {"model": {k: v.clone() for k, v in ck.items()}}, "model": model, "torch": torch}
+    with contextlib.redirect_stdout(io.StringIO()):
+        exec(compile(snippet, "train.py:343-370", "exec"), ns)
+    left = ns["checkpoint_model"]
+    rec = {"pos_embed": model.pos_embed.detach().numpy().copy(), "keys_loaded": np.array(sorted(left.keys())),
+           "fc1_w_block1": model.blocks[1].mlp.fc1.weight.detach().numpy().copy(),
+           "sizes": np.array([ns["orig_size"], ns["new_size"], ns["num_extra_tokens"]])}
+    np.savez_compressed(os.path.join(HERE, "finetune_ingest.npz"), **rec)
+    print(f"finetune_ingest: pos_embed {rec['pos_embed'].shape}, {len(left)} keys loaded, sizes {rec['sizes'].tolist()}")
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
+    if not only or "finetune_ingest" in only:
+        run_finetune_ingest()
+        if only == ["finetune_ingest"]:
+            sys.exit(0)
     for name in GRAD_CASES:
         if only and ("grad_" + name) not in only and "grads" not in only:
             continue

@@ -5,6 +5,7 @@ import os
 import re
 import types
 
+import numpy as np
 import pytest
 import torch
 
@@ -151,38 +152,43 @@ def test_argument_validation_without_gpu():
     assert lib.tr_vit_dropout_mask_bytes(ctypes.byref(cfg), 4) == want
 
 
-def test_reference_finetune_ingest_snippet_runs_unchanged():
-    """train.py:343-369 (drop mismatching head, bicubic-resize the position embedding, load_state_dict(strict=False)) relies on
-    state_dict(), patch_embed.num_patches and pos_embed of the model object: it must run against this build's modules as is
-    (224 -> 384 fine-tuning)."""
-    src = tra.create_model("deit_small_patch16_224_local", pretrained=False, num_classes=1000, img_size=224)
-    checkpoint = {"model": {k: v.clone() for k, v in src.state_dict().items()}}
-    model = tra.create_model("topk_small_patch16_224", pretrained=False, num_classes=10, img_size=384,
-                             args=_args(keep_rate=[0.5], reduction_loc=[3, 6, 9]))
-    # ---- train.py:343-369, verbatim logic
-    checkpoint_model = checkpoint['model']
-    state_dict = model.state_dict()
-    for k in ['head.weight', 'head.bias', 'head_dist.weight', 'head_dist.bias']:
-        if k in checkpoint_model and checkpoint_model[k].shape != state_dict[k].shape:
-            del checkpoint_model[k]
-    pos_embed_checkpoint = checkpoint_model['pos_embed']
-    embedding_size = pos_embed_checkpoint.shape[-1]
-    num_patches = model.patch_embed.num_patches
-    num_extra_tokens = model.pos_embed.shape[-2] - num_patches
-    orig_size = int((pos_embed_checkpoint.shape[-2] - num_extra_tokens) ** 0.5)
-    new_size = int(num_patches ** 0.5)
-    extra_tokens = pos_embed_checkpoint[:, :num_extra_tokens]
-    pos_tokens = pos_embed_checkpoint[:, num_extra_tokens:]
-    pos_tokens = pos_tokens.reshape(-1, orig_size, orig_size, embedding_size).permute(0, 3, 1, 2)
-    pos_tokens = torch.nn.functional.interpolate(pos_tokens, size=(new_size, new_size), mode='bicubic', align_corners=False)
-    pos_tokens = pos_tokens.permute(0, 2, 3, 1).flatten(1, 2)
-    checkpoint_model['pos_embed'] = torch.cat((extra_tokens, pos_tokens), dim=1)
-    missing, unexpected = model.load_state_dict(checkpoint_model, strict=False)
-    # ----
-    assert (orig_size, new_size, num_extra_tokens) == (14, 24, 1)
+def test_finetune_ingest_matches_the_reference(golden_dir):
+    """f3: a DeiT-layout 224 x 224 checkpoint into a 384 x 384 model with another head.  tests/golden/finetune_ingest.npz holds what the
+    REFERENCE's own statements (train.py:343-370, executed by gen_golden.py on a reference model) leave behind for the seeded checkpoint
+    of tests/_params.finetune_ingest_setup; finetune.load_finetune_checkpoint must leave the same: the resized position embedding bit
+    for bit (same torch bicubic kernel), the same keys loaded, the trunk weights in place."""
+    from tests._params import finetune_ingest_setup
+    from tokenreduction_amd.finetune import load_finetune_checkpoint
+    g = np.load(os.path.join(golden_dir, "finetune_ingest.npz"))
+    _, cfg384, ck = finetune_ingest_setup()
+    model = tra.TopKVisionTransformer(img_size=384, patch_size=16, embed_dim=cfg384.embed_dim, depth=cfg384.depth, num_heads=cfg384.num_heads,
+                                      mlp_ratio=4, qkv_bias=True, num_classes=cfg384.num_classes, args=_args(keep_rate=[0.5], reduction_loc=[1, 2]))
+    head_before = model.head.weight.detach().clone()
+    missing, unexpected = load_finetune_checkpoint(model, {"model": {k: v.clone() for k, v in ck.items()}})
     assert sorted(missing) == ["head.bias", "head.weight"] and not unexpected
-    assert torch.equal(model.blocks[5].mlp.fc1.weight, src.blocks[5].mlp.fc1.weight)
-    assert model.pos_embed.shape == (1, 577, 384)
+    assert g["sizes"].tolist() == [14, 24, 1] and model.pos_embed.shape == (1, 577, cfg384.embed_dim)
+    assert np.array_equal(model.pos_embed.detach().numpy(), g["pos_embed"])
+    assert np.array_equal(model.blocks[1].mlp.fc1.weight.detach().numpy(), g["fc1_w_block1"])
+    assert sorted(k for k in ck if k not in ("head.weight", "head.bias")) == g["keys_loaded"].tolist()
+    assert torch.equal(model.head.weight, head_before)             # the new classifier keeps its initialisation
+    # the reference's statements read state_dict(), patch_embed.num_patches and pos_embed of the model object: same attribute surface
+    assert model.patch_embed.num_patches == 576 and "pos_embed" in model.state_dict()
+
+
+def test_pretrained_true_loads_a_deit_checkpoint_from_deit_weights(tmp_path, monkeypatch):
+    """The positive path of models_act.py:1130-1137: with ./deit_weights/<file of the DeiT url> present, create_model(pretrained=True)
+    loads checkpoint["model"] non-strictly -- also into a model with its own classifier-sized head and extra stage modules."""
+    from tokenreduction_amd.registry import deit_url_paths
+    monkeypatch.chdir(tmp_path)
+    src = tra.create_model("deit_tiny_patch16_224_local", pretrained=False, num_classes=1000)
+    sd = {k: v.detach().clone() for k, v in src.state_dict().items()}
+    os.makedirs("deit_weights")
+    torch.save({"model": sd}, os.path.join("deit_weights", os.path.basename(deit_url_paths["deit_tiny_patch16_224"])))
+    for name, extra in (("topk_tiny_patch16_224", {}), ("dpcknn_tiny_patch16_224", {"k_neighbors": 5, "equal_weight": False})):
+        m = tra.create_model(name, pretrained=True, args=_args(keep_rate=[0.7], reduction_loc=[3, 6, 9], **extra))
+        own = m.state_dict()
+        assert all(torch.equal(own[k], v) for k, v in sd.items()), name
+        assert set(own) >= set(sd)
 
 
 @pytest.mark.parametrize("family", ["topk", "evit", "dyvit", "tome", "ats", "sit", "dpcknn", "sinkhorn", "kmedoids", "patchmerger"])

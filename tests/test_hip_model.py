@@ -538,6 +538,34 @@ def test_repack_after_a_parameter_moved_drops_the_captured_graphs():
     assert torch.equal(got, want)
 
 
+def test_pretrained_checkpoint_through_the_factory_runs_on_the_hip_path(tmp_path, monkeypatch):
+    """f3, positive path (models_act.py:1130-1137): a DeiT-layout ./deit_weights/<name>.pth is ingested by
+    create_model(..., pretrained=True) and the HIP forward on the ingested weights agrees with the oracle on the SAME weights --
+    Top-K selections bit-exact on the device's scores, logits teacher-forced within FORCED_TOL."""
+    import tokenreduction_amd as tra
+    from tokenreduction_amd.registry import deit_url_paths
+    from tests._stepwise import forward_stepwise
+    monkeypatch.chdir(tmp_path)
+    cfg = oracle.VitConfig(family="topk", embed_dim=192, depth=12, num_heads=3, num_classes=1000, keep_rate=[0.7], reduction_loc=[3, 6, 9])
+    params = make_params(cfg, 4242, 2.0)
+    os.makedirs("deit_weights")
+    torch.save({"model": params}, os.path.join("deit_weights", os.path.basename(deit_url_paths["deit_tiny_patch16_224"])))
+    args = types.SimpleNamespace(keep_rate=[0.7], reduction_loc=[3, 6, 9], viz_mode=True)
+    model = tra.create_model("topk_tiny_patch16_224", pretrained=True, args=args).cuda().eval()
+    assert all(torch.equal(v.cpu(), params[k]) for k, v in model.state_dict().items())
+    x = make_images(2, 224, 99)
+    logits, viz = model(x.cuda())
+    l2, info = forward_stepwise(model, x.cuda())
+    assert torch.equal(l2, logits)
+    forced = {}
+    for blk, idx in info["kept"].items():
+        assert torch.equal(idx.cpu().long(), oracle.cls_topk_select(info["scores"][blk].cpu(), idx.shape[1]))
+        forced[blk] = idx.cpu().long()
+    want = oracle.vit_forward(params, x, cfg, precision="bf16", forced=forced)
+    err = float((logits.cpu() - want).norm() / want.norm())
+    assert err < FORCED_TOL, err
+
+
 def test_dyvit_teacher_returns_logits_and_normed_tokens():
     """VisionTransformerTeacher.forward dyvit.py:325-334: (head(norm(x)[:, 0]), norm(x)[:, 1:])."""
     import tokenreduction_amd as tra

@@ -11,13 +11,19 @@ Mirrors, for models built by tokenreduction_amd.create_model (same parameter nam
                          restated in CosineSchedule): linear warm-up, cosine to lr_min, counted in optimizer STEPS when
                          `sched_in_steps` (t_in_epochs=False) -- `step_update(num_updates)` -- or in epochs -- `step(epoch)`.
 
-This is bookkeeping only: tokenreduction_amd has no backward pass, so nothing here touches the GPU.
+    train.py:343-370     load_finetune_checkpoint() ingest of a DeiT-layout checkpoint: mismatching classifier dropped, position
+                                                   embedding resized to the model's patch grid
+
+Host-side bookkeeping only -- nothing here touches the GPU; the step it configures (forward, backward, the data-parallel gradient
+mean) is the HIP training path (training.py, dp.py), driven by harness.train_one_epoch.
 The parameter-group membership is pinned against lists recorded from the reference's own function
 (tests/golden/param_groups.json, tests/golden/gen_param_groups.py); the cosine schedule has no reference run behind it (timm is
 not installed here) and is checked against its closed form only.
 """
 import math
 from typing import Iterable, List, Optional, Sequence
+
+import torch
 
 NEW_MODULE_NAMES = ["head.weight", "head.bias", "head_dist.weight", "head_dist.bias", "pos_embed", "patch_embed"]   # optim.py:43
 
@@ -115,3 +121,27 @@ class CosineSchedule:
     def step_update(self, num_updates: int) -> None:          # engine.py:110-111
         if not self.t_in_epochs:
             self._set(self.lr_at(num_updates))
+
+
+def load_finetune_checkpoint(model, checkpoint):
+    """Ingest of a pre-trained checkpoint for fine-tuning (train.py:343-370): `checkpoint` is what torch.load returns for a
+    DeiT-layout .pth ({"model": state_dict}) or the state dict itself.  A classifier whose shape does not fit the model is dropped,
+    the position embedding is resized to the model's patch grid (class / distillation rows kept, the grid bicubically
+    interpolated -- 14 x 14 -> 24 x 24 for a 224 -> 384 fine-tune), everything else is loaded non-strictly.  Returns load_state_dict's
+    (missing_keys, unexpected_keys).  Host-side only: the executor re-packs its operand copies at the next forward (new addresses
+    and values are detected by the packing key)."""
+    import torch.nn.functional as F
+    sd = dict(checkpoint["model"] if isinstance(checkpoint, dict) and "model" in checkpoint else checkpoint)
+    own = model.state_dict()
+    for k in ("head.weight", "head.bias", "head_dist.weight", "head_dist.bias"):
+        if k in sd and k in own and sd[k].shape != own[k].shape:
+            del sd[k]
+    pos = sd.get("pos_embed")
+    if pos is not None and pos.shape != model.pos_embed.shape:
+        n_patches = model.patch_embed.num_patches
+        n_extra = model.pos_embed.shape[-2] - n_patches
+        old, new = int((pos.shape[-2] - n_extra) ** 0.5), int(n_patches ** 0.5)
+        grid = pos[:, n_extra:].reshape(-1, old, old, pos.shape[-1]).permute(0, 3, 1, 2)
+        grid = F.interpolate(grid, size=(new, new), mode="bicubic", align_corners=False)
+        sd["pos_embed"] = torch.cat((pos[:, :n_extra], grid.permute(0, 2, 3, 1).flatten(1, 2)), dim=1)
+    return model.load_state_dict(sd, strict=False)

@@ -11,8 +11,9 @@ load_state_dict / state_dict / optimizers see the reference's key names); `forwa
 them: it hands the image batch to the gfx950 executor (csrc/tr_vit.hip) through the C ABI.
 
 There is no CPU path: forward() on a CPU tensor raises.  In train mode forward() runs the training executor
-(activations kept on a tape) and `loss.backward()` runs the HIP backward executor (training.py); families
-without a backward yet raise NotImplementedError there.
+(activations kept on a tape) and `loss.backward()` runs the HIP backward executor (training.py) -- every family and
+every factory width, 224 x 224 and 384 x 384; what the training path refuses (attn_drop_rate, the distillation token,
+more than 640 tokens) raises there.
 """
 from __future__ import annotations
 
