@@ -278,7 +278,10 @@ def train_roofline_leg(name, keep_rate, loc, batch, device, reps=3):
             a = rep.setdefault(nm, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
             a["ms"] += ms[i]; a["flops"] += fl[i]; a["bytes"] += by[i]; a["launches"] += 1
         per_rep.append(rep)
-    agg = {k: dict(per_rep[0][k], ms=sorted(r[k]["ms"] for r in per_rep)[reps // 2]) for k in per_rep[0]}
+    agg = {}
+    for k in per_rep[0]:       # median over the reps that have the label (a label missing from a later rep must not lose the leg)
+        vals = sorted(r[k]["ms"] for r in per_rep if k in r)
+        agg[k] = dict(per_rep[0][k], ms=vals[len(vals) // 2])
     return roofline_from(agg), model
 
 
@@ -334,23 +337,48 @@ def timed_steps(step, steps, warmup, dist, sync, device):
     return el
 
 
-def pmc_traffic(kernel_label):
-    """HBM bytes per launch of `kernel_label` from the committed PMC summary (tools/prof_summary.py) -- only when that summary was
-    collected on the kernel sources this library was built from (source hash), else None with the reason."""
+def pmc_traffic(kernel_label, workload="headline"):
+    """HBM bytes per launch of `kernel_label` from the committed PMC summary of `workload` (tools/prof_r04.sh + tools/prof_summary.py:
+    profiles/<tag>_<workload>_pmc_traffic.json; FETCH_SIZE / WRITE_SIZE in separate rocprofv3 --pmc passes, gfx950 corrections) --
+    NOT measured in this run, and only used when the summary was collected on the kernel sources this library was built from
+    (source hash), else None with the reason."""
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload}_pmc_traffic.json")))
+    if not files and workload == "headline":
+        files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_traffic.json")) if "_final_" in f or "_a_" in f)
     if not files:
         return None
     tbl = json.load(open(files[-1]))
     if tbl.get("_kernel_source_hash") != kernel_source_hash():
         return dict(hbm_bytes_per_launch=None, source=os.path.basename(files[-1]),
-                    note="stale: collected on other kernel sources than the ones built here; re-run tools/prof_round.sh")
+                    note="stale: collected on other kernel sources than the ones built here; re-run tools/prof_r04.sh")
     m = re.match(r"(\w+)<EPI_(\w+)>", kernel_label)
-    epi = {"BF16": 0, "GELU_BF16": 1, "RESID_F32": 2, "F32": 3, "PATCH_F32": 4}
+    epi = {"BF16": 0, "GELU_BF16": 1, "RESID_F32": 2, "F32": 3, "PATCH_F32": 4, "GELU_KEEP": 16, "DGELU": 17}
     key = f"{m.group(1)}<{epi[m.group(2)]}>" if m and m.group(2) in epi else kernel_label
     v = tbl.get(key)
-    return None if v is None else dict(hbm_bytes_per_launch=v["hbm_bytes_per_launch"], source=os.path.basename(files[-1]))
+    if v is None:       # labels of the launch profiler carry no template arguments: first table key that starts with the label
+        v = next((t for k, t in tbl.items() if not k.startswith("_") and k.split("<")[0] == key.split("<")[0]), None)
+    return None if v is None else dict(hbm_bytes_per_launch=v["hbm_bytes_per_launch"], source=os.path.basename(files[-1]),
+                                       collected="offline (committed profile), not in this run")
+
+
+def attach_traffic(roof, workload):
+    """`traffic` of a roofline record: HBM bytes per launch of its kernel from the committed PMC summary of `workload` (or null + why)."""
+    t = pmc_traffic(roof["kernel"], workload)
+    roof["traffic"] = None if t is None else t.get("hbm_bytes_per_launch")
+    roof["traffic_unit"] = "B/launch"
+    roof["traffic_source"] = ("no committed PMC summary for this workload" if t is None else
+                              t.get("source") + " (" + t.get("collected", "") + ")" + ("" if t.get("note") is None else ": " + t["note"]))
+    return roof
+
+
+def fenced(fn, *args, **kw):
+    """An informational leg must never cost the JSON line: its exception becomes its value."""
+    try:
+        return fn(*args, **kw)
+    except Exception as e:      # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
 def headline_record(a, world, headline, eager_ms, note=None):
@@ -487,10 +515,7 @@ def main():
             roof, table, step_ms = roofline_leg(model, x)
             # `traffic`: HBM bytes per launch of the dominant kernel as a plain number (or null), from the PMC passes committed with the
             # profile of these very kernel sources (source hash); where it came from / why it is null goes to `traffic_source`
-            t = pmc_traffic(roof["kernel"])
-            roof["traffic"] = None if t is None else t.get("hbm_bytes_per_launch")
-            roof["traffic_unit"] = "B/launch"
-            roof["traffic_source"] = None if t is None else (t.get("source") + ("" if t.get("note") is None else ": " + t["note"]))
+            attach_traffic(roof, "headline")
             rec["roofline"] = roof
             rec["kernels"] = table
             rec["profiled_ms_per_step"] = round(step_ms, 3)      # same executor, plain launches with an event after each
@@ -559,6 +584,7 @@ def main():
             model.precision = "bf16"
             rec["bf16x3_mode"] = {"images_per_s": round(x3_ips, 1), "ms_per_step": round(BATCH / x3_ips * 1e3, 3),
                                   "vs_bf16_product_path": round(x3_ips / ips, 3),
+                                  "label": "images/s AT NORTH_STAR TOLERANCE (logits within 1e-3 abs of the reference; the bf16 `value` is not)",
                                   "note": "same config as `value`; 3 MFMAs per product, fp32 activations, fp32 twins for every non-GEMM op"}
             rec["cpu_baseline"] = cpu_baseline_leg(model)
             # SURVEY 8d asks the same three numbers (images/s, fraction of the dominant kernel's roofline, CPU baseline) for every BASELINE
@@ -566,15 +592,13 @@ def main():
             # fine-tune: a training step at 128 images), configs[4] DeiT-B Sinkhorn / K-Medoids kr 0.25 at 384^2 (eval)
             per = {}
             tome_kr = [196 - 16 * (i + 1) for i in range(12)]
-            for label, name, fam, kr, loc, img, bsz in (
-                    ("configs[2] tome_small r16 eval B=256", "tome_small_patch16_224", "tome", tome_kr, list(range(12)), 224, 256),
-                    ("configs[4] sinkhorn_base kr0.25 384^2 eval B=64", "sinkhorn_base_patch16_224", "sinkhorn", [0.25], [3, 6, 9], 384, 64),
-                    ("configs[4] kmedoids_base kr0.25 384^2 eval B=64", "kmedoids_base_patch16_224", "kmedoids", [0.25], [3, 6, 9], 384, 64)):
+
+            def eval_config(name, fam, kr, loc, img, bsz, workload):
                 m2 = build_model(name, kr, loc, dev, img_size=img)
                 xb = torch.randn(bsz, 3, img, img, generator=torch.Generator().manual_seed(7)).to(dev)
                 entry = {"images_per_s": round(quick_images_per_s(m2, xb), 1), "tokens_per_block": m2._last_tokens,
-                         "roofline": roofline_from(profile_forward(m2, xb, 3)),
-                         "cpu_baseline": cpu_config_leg(m2, fam, kr, loc, img, train=False)}
+                         "roofline": attach_traffic(roofline_from(profile_forward(m2, xb, 3)), workload),
+                         "cpu_baseline": fenced(cpu_config_leg, m2, fam, kr, loc, img, train=False)}
                 if img == 384:       # configs[4]: "DP inference throughput sweep" -- the per-GPU batch sweep (8 GPUs: x 8, no collective)
                     sweep = {}
                     for b2 in (32, 64, 128, 256):
@@ -582,15 +606,29 @@ def main():
                         sweep[str(b2)] = round(quick_images_per_s(m2, xs, iters=5, reps=2), 1)
                         del xs
                     entry["images_per_s_by_batch"] = sweep
-                per[label] = entry
-                del m2, xb
-            for label, name, fam, kr in (("configs[3] ats_base kr0.5 train step B=128", "ats_base_patch16_224", "ats", [0.5]),
-                                         ("configs[3] dpcknn_base kr0.5 train step B=128", "dpcknn_base_patch16_224", "dpcknn", [0.5])):
+                return entry
+
+            def train_config(name, fam, kr, workload):
                 roof, m3 = train_roofline_leg(name, kr, [3, 6, 9], 128, dev)
                 ft = rec["finetune"].get(next(k for k in rec["finetune"] if k.startswith(name.split("_patch")[0])), {})
-                per[label] = {"images_per_s": ft.get("images_per_s"), "ms_per_step": ft.get("ms_per_step"), "roofline": roof,
-                              "cpu_baseline": cpu_config_leg(m3, fam, kr, [3, 6, 9], 224, train=True)}
-                del m3
+                return {"images_per_s": ft.get("images_per_s"), "ms_per_step": ft.get("ms_per_step"), "roofline": attach_traffic(roof, workload),
+                        "cpu_baseline": fenced(cpu_config_leg, m3, fam, kr, [3, 6, 9], 224, train=True)}
+
+            for label, name, fam, kr, loc, img, bsz, wl in (
+                    ("configs[2] tome_small r16 eval B=256", "tome_small_patch16_224", "tome", tome_kr, list(range(12)), 224, 256, "tome"),
+                    ("configs[4] sinkhorn_base kr0.25 384^2 eval B=64", "sinkhorn_base_patch16_224", "sinkhorn", [0.25], [3, 6, 9], 384, 64, "sinkb384"),
+                    ("configs[4] kmedoids_base kr0.25 384^2 eval B=64", "kmedoids_base_patch16_224", "kmedoids", [0.25], [3, 6, 9], 384, 64, "kmedb384")):
+                per[label] = fenced(eval_config, name, fam, kr, loc, img, bsz, wl)
+            for label, name, fam, kr, wl in (("configs[3] ats_base kr0.5 train step B=128", "ats_base_patch16_224", "ats", [0.5], "atsb_train"),
+                                             ("configs[3] dpcknn_base kr0.5 train step B=128", "dpcknn_base_patch16_224", "dpcknn", [0.5], "dpcknnb_train")):
+                per[label] = fenced(train_config, name, fam, kr, wl)
+            # drift of the product path on TRAINED weights (tools/drift_trained.py): 600 AdamW steps of the HIP training path on a
+            # separable synthetic task, then >= 10 k held-out images under the fp32, bf16 and bf16x3 executors
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("drift_trained", os.path.join(ROOT, "tools", "drift_trained.py"))
+            dt = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(dt)
+            rec["drift_trained"] = fenced(dt.run, dev)
             rec["per_config"] = per
         try:        # RCCL writes its banner through C stdio: flush it first so the JSON line is the last thing on stdout
             import ctypes

@@ -209,7 +209,13 @@ int tr_softassign_merge_fast(float* logits, int ldl, float scale, int apply_soft
  *   reference adds * 1e-6 to the densities (dpcknn.py:71-72); NULL = none.  k = nearest neighbours (args.k_neighbors).
  *   ws: tr_dpcknn_workspace_floats(B,N) floats of scratch.  fast_dist != 0 (also tr_kmedoids): the Gram product of the
  *   distance matrix runs on MFMA with hi/lo-split bf16 operands (relative error ~2^-16) instead of fp32 VALU -- what the bf16
- *   executor uses; 0 = the reference's fp32 arithmetic (validation executor).
+ *   executor uses; 0 = the reference's fp32 arithmetic (validation executor).  For tr_dpcknn_cluster: 1 = the ONE-LAUNCH kernel
+ *   below wherever it applies (else the staged launches), 2 = always the staged launches (sqnorm, distances to ws, density,
+ *   parent distance, top-K, assignment) -- kept for P > 208 and as the comparison of the tests.
+ * tr_dpcknn_cluster_fused (csrc/tr_cluster_fused.hip): the same clustering in one launch, one workgroup per image, the distance
+ *   matrix held in LDS as its upper triangle (26 <= N-1 <= 208, D % 32 == 0, D <= 1024, k <= 5: tr_dpcknn_fused_supported);
+ *   no workspace.  Identical to the staged launches except that element (i,j) below the diagonal is read from (j,i), which the
+ *   staged matrix matches only up to the last bit.
  * tr_cluster_merge_layernorm: merge_tokens dpcknn.py:103-132 with token_weight = exp(x . score_w + score_b) (CTM, :155-157;
  *   score_w NULL = equal weights), then LayerNorm(gamma, beta, eps) of the merged tokens: x_out fp32 [B,K+1,D] (row 0 = CLS
  *   copied), y = LN(x_out) bf16 (fp32 when y_is_f32).  w_ws: [B,N-1] floats of scratch (token weights).
@@ -228,6 +234,9 @@ int tr_kmedoids_equal(const float* x, int init_idx, float* ws, int32_t* centers,
                       int fast_dist, tr_stream_t s);
 int tr_dpcknn_cluster(const float* x, const float* noise, float* ws, int32_t* centers, int32_t* idx_cluster, float* scores,
                       int B, int N, int D, int K, int k, int fast_dist, tr_stream_t s);
+int tr_dpcknn_fused_supported(int N, int D, int k);
+int tr_dpcknn_cluster_fused(const float* x, const float* noise, int32_t* centers, int32_t* idx_cluster, float* scores, int B, int N,
+                            int D, int K, int k, tr_stream_t s);
 int tr_cluster_merge_layernorm(const float* x, const float* score_w, const float* score_b, float* w_ws,
                                const int32_t* idx_cluster, const float* gamma, const float* beta, float* x_out, void* y,
                                int y_is_f32, int B, int N, int K, int D, float eps, tr_stream_t s);

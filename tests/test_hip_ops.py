@@ -509,6 +509,39 @@ def test_dpcknn_cluster(ops, fast, B, N, D, K, k):
     np.testing.assert_array_equal(torch.gather(assign, 1, centers).numpy(), np.broadcast_to(np.arange(K), (B, K)))
 
 
+@pytest.mark.parametrize("B,N,D,K,k", [(5, 197, 384, 137, 5), (3, 138, 384, 96, 5), (3, 97, 384, 67, 5), (2, 197, 768, 98, 5),
+                                       (2, 99, 768, 49, 5), (3, 50, 64, 7, 3), (2, 209, 128, 100, 4), (4, 27, 64, 13, 1)])
+def test_dpcknn_one_launch_equals_the_staged_launches(ops, B, N, D, K, k):
+    """tr_dpcknn_cluster_fused (distance matrix in LDS, one launch) against the staged launches it replaces (fast_dist = 2), same
+    split-bf16 arithmetic: centres, assignments and scores must agree -- bit for bit in the scores of every token whose row needs no
+    below-diagonal element... in practice everywhere: the staged matrix is symmetric up to the last bit, so the test allows a score to
+    move by one part in 10^6 and a decision to differ only where the staged pipeline's own margin is below that."""
+    rng = _rng(640 + N + D)
+    x = _randn(rng, B, N, D)
+    noise = torch.from_numpy(rng.random((B, N - 1)).astype(np.float32))
+    c2, a2, s2 = ops.dpcknn_cluster(x.cuda(), K, noise.cuda(), k, fast_dist=2)
+    c1, a1, s1 = ops.dpcknn_cluster(x.cuda(), K, noise.cuda(), k, fast_dist=1)
+    torch.testing.assert_close(s1, s2, atol=0, rtol=2e-6)
+    if not torch.equal(c1, c2):
+        sc = s2.cpu()
+        srt = sc.sort(dim=1, descending=True).values
+        gap = (srt[:, :-1] - srt[:, 1:]).abs() / srt[:, :-1].abs().clamp_min(1e-30)
+        assert float(gap.min()) < 4e-6, "centres differ although no two scores are within rounding of each other"
+    else:
+        diff = (a1 != a2)
+        if diff.any():
+            dist = oracle.dpcknn_distances(x[:, 1:])
+            d = torch.gather(dist, 1, c2.cpu().long()[:, :, None].expand(B, K, N - 1))
+            top2 = d.topk(2, dim=1, largest=False).values
+            assert ((top2[:, 1] - top2[:, 0])[diff.cpu()] < 1e-5).all(), "assignments differ beyond a last-bit tie"
+    assert lib_supported(N, D, k) == (26 <= N - 1 <= 208 and D % 32 == 0 and k <= 5)
+
+
+def lib_supported(N, D, k):
+    from tokenreduction_amd import _lib
+    return bool(_lib.load().tr_dpcknn_fused_supported(N, D, k))
+
+
 @pytest.mark.parametrize("f32", [False, True])
 @pytest.mark.parametrize("weighted", [False, True])
 @pytest.mark.parametrize("B,N,K,D", [(3, 197, 137, 384), (2, 138, 40, 128), (2, 9, 3, 64), (1, 197, 98, 768)])

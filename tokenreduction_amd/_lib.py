@@ -101,6 +101,8 @@ SIGNATURES = {
     "tr_kmedoids": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tr_kmedoids_equal": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "tr_dpcknn_cluster": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "tr_dpcknn_fused_supported": (_i, [_i, _i, _i]),
+    "tr_dpcknn_cluster_fused": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tr_cluster_merge_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
     "tr_broadcast_rows": (_i, [_vp, _vp, _i, _i, _vp]),
     "tr_residual_snapshot": (_i, [_vp, _vp, _i, _vp, _sz, _vp]),

@@ -555,10 +555,17 @@ static void launch_dist(bool fast, const float* x, const float* nrm, float* dist
   }
 }
 
+extern "C" int tr_dpcknn_fused_supported(int N, int D, int k);
+extern "C" int tr_dpcknn_cluster_fused(const float* x, const float* noise, int32_t* centers, int32_t* idx_cluster, float* scores, int B, int N,
+                                       int D, int K, int k, tr_stream_t s);
+
 extern "C" int tr_dpcknn_cluster(const float* x, const float* noise, float* ws, int32_t* centers, int32_t* idx_cluster,
                                  float* scores, int B, int N, int D, int K, int k, int fast_dist, tr_stream_t s) {
   TR_REQUIRE(x && ws && centers && idx_cluster && scores, TR_ERR_NULL, "tr_dpcknn_cluster: null pointer");
   const int P = N - 1;
+  // fast_dist 1: one launch with the distance matrix in LDS wherever that kernel applies (tr_cluster_fused.hip); 2: the staged launches
+  if (fast_dist == 1 && B > 0 && K >= 1 && K <= P && tr_dpcknn_fused_supported(N, D, k) && tr_aligned16(x))
+    return tr_dpcknn_cluster_fused(x, noise, centers, idx_cluster, scores, B, N, D, K, k, s);
   TR_REQUIRE(B > 0 && P >= 2 && P <= 64 * MAX_PER_LANE && D > 0 && D % CK == 0, TR_ERR_SHAPE,
              "tr_dpcknn_cluster: need 2 <= P <= %d and D %% %d == 0 (N=%d D=%d)", 64 * MAX_PER_LANE, CK, N, D);
   TR_REQUIRE(K >= 1 && K <= P && k >= 1 && k <= KNN_MAX && k <= P, TR_ERR_SHAPE, "tr_dpcknn_cluster: bad K=%d / k=%d for P=%d", K, k, P);

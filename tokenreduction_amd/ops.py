@@ -283,9 +283,11 @@ def sit_merge(logits: torch.Tensor, scale: float, x: torch.Tensor, K: int, want_
 
 
 # ---------------------------------------------------------------------------------------- DPC-KNN (models/dpcknn.py)
-def dpcknn_cluster(x: torch.Tensor, K: int, noise: torch.Tensor = None, k: int = 5, fast_dist: bool = False):
+def dpcknn_cluster(x: torch.Tensor, K: int, noise: torch.Tensor = None, k: int = 5, fast_dist=False):
     """cluster_dpc_knn (dpcknn.py:44-100) on the patch rows of x fp32 [B,N,D] ->
-    (centers int32 [B,K] in descending-score order, idx_cluster int32 [B,N-1], scores fp32 [B,N-1])."""
+    (centers int32 [B,K] in descending-score order, idx_cluster int32 [B,N-1], scores fp32 [B,N-1]).
+    fast_dist: False / 0 = fp32 distances; True / 1 = split-bf16 MFMA distances, in ONE launch where the kernel applies; 2 = the same
+    distances through the staged launches."""
     B, N, D = x.shape
     lib = _lib.load()
     ws = torch.empty(lib.tr_dpcknn_workspace_floats(B, N), dtype=torch.float32, device=x.device)

@@ -1,0 +1,98 @@
+#!/usr/bin/env python3
+"""Drift of the bf16 product path on TRAINED weights (BASELINE metric "top-1 drift vs ref").
+
+There are no ImageNet weights in this container, and random-init logits are nearly flat (a 1e-2 perturbation flips the arg-max), so
+the drift numbers of `drift_vs_fp32_path` say little about a deployed model.  This leg makes trained weights with the build's own
+training path: topk_small_patch16_224 (keep_rate 0.7 at blocks 3/6/9, the reference's initialisation) is fine-tuned for a few hundred
+AdamW steps on a synthetic but separable 1000-class task -- class c is a fixed random 14 x 14 x 3 pattern, one value per patch and
+channel, plus unit-variance pixel noise times `sigma` -- and then evaluated on held-out samples under the three executors:
+
+    fp32    every op in fp32 on the VALU (the validation path that reproduces the reference end to end: tests/test_hip_fp32.py)
+    bf16    the timed product path
+    bf16x3  split-bf16 products on the matrix cores (north_star's 1e-3 tolerance)
+
+Reported: held-out accuracy per executor, top-1 agreement of bf16 and bf16x3 with fp32, max |logit difference|, and the distribution of
+the fp32 top-1 margin (logit of the arg-max minus the runner-up) -- a disagreement needs a margin below the logit drift.
+
+    python tools/drift_trained.py [steps] [eval_images] [sigma]
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+
+def run(device="cuda", steps=600, eval_images=10240, sigma=3.0, batch=256, lr=1e-3, seed=1234):
+    import bench
+    dev = torch.device(device)
+    model = bench.build_model(device=dev, qkv_gain=1.0)          # topk_small kr 0.7, trunc_normal(0.02) (topk.py:163-176)
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    protos = torch.randn(1000, 3, 14, 14, generator=g).to(dev)
+
+    def make(n, s):
+        gg = torch.Generator(device=dev).manual_seed(s)
+        y = torch.randint(0, 1000, (n,), generator=gg, device=dev)
+        x = torch.nn.functional.interpolate(protos[y], scale_factor=16, mode="nearest")
+        x = x + sigma * torch.randn(n, 3, 224, 224, generator=gg, device=dev)
+        return x, y
+
+    model.train()
+    opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=0.05, fused=True)
+    warm = max(1, steps // 10)
+    t0 = time.perf_counter()
+    loss = acc = None
+    for i in range(steps):
+        for gp in opt.param_groups:           # linear warm-up, cosine to a tenth
+            gp["lr"] = lr * ((i + 1) / warm if i < warm else 0.1 + 0.45 * (1 + torch.cos(torch.tensor((i - warm) / max(1, steps - warm) * 3.14159265)).item()))
+        x, y = make(batch, 10_000 + i)
+        out = model(x)
+        loss = torch.nn.functional.cross_entropy(out, y)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        acc = (out.argmax(1) == y).float().mean()
+    torch.cuda.synchronize()
+    train_s = time.perf_counter() - t0
+    model.eval()
+    nb = max(1, eval_images // batch)
+    logits = {}
+    labels = []
+    for prec in ("fp32", "bf16", "bf16x3"):
+        model.precision = prec
+        rows = []
+        for b in range(nb):
+            x, y = make(batch, 900_000 + b)
+            rows.append(model(x).float().clone())
+            if prec == "fp32":
+                labels.append(y)
+        logits[prec] = torch.cat(rows)
+    model.precision = "bf16"
+    y = torch.cat(labels)
+    ref = logits["fp32"]
+    top2 = ref.topk(2, dim=1).values
+    margin = (top2[:, 0] - top2[:, 1])
+    q = torch.quantile(margin, torch.tensor([0.001, 0.01, 0.1, 0.5], device=dev)).tolist()
+    rec = {"model": "topk_small_patch16_224 kr0.7", "task": f"1000 synthetic classes (14x14x3 prototype per class + {sigma} x unit noise)",
+           "train_steps": steps, "train_batch": batch, "train_seconds": round(train_s, 1), "train_loss_last": round(float(loss.detach()), 4),
+           "train_acc_last_batch": round(float(acc), 4), "eval_images": int(ref.shape[0]),
+           "fp32_margin_quantiles": {"p0.1%": round(q[0], 4), "p1%": round(q[1], 4), "p10%": round(q[2], 4), "median": round(q[3], 4)}}
+    for prec in ("fp32", "bf16", "bf16x3"):
+        lg = logits[prec]
+        e = {"top1_acc": round(float((lg.argmax(1) == y).float().mean()), 5)}
+        if prec != "fp32":
+            e["top1_agreement_with_fp32"] = round(float((lg.argmax(1) == ref.argmax(1)).float().mean()), 5)
+            e["disagreements"] = int((lg.argmax(1) != ref.argmax(1)).sum())
+            e["max_abs_logit_diff"] = round(float((lg - ref).abs().max()), 5)
+            e["rel_l2_logit_diff"] = round(float((lg - ref).norm() / ref.norm()), 6)
+        rec[prec] = e
+    return rec
+
+
+if __name__ == "__main__":
+    a = sys.argv[1:]
+    print(json.dumps(run(steps=int(a[0]) if a else 600, eval_images=int(a[1]) if len(a) > 1 else 10240,
+                         sigma=float(a[2]) if len(a) > 2 else 3.0), indent=1))
