@@ -43,6 +43,28 @@ __global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ x
   if (lane == 0) nrm[row] = acc;
 }
 
+// The same norms in the summation order of the one-launch clustering kernel (tr_cluster_fused.hip), which accumulates them while it
+// streams the 32-float slabs of the Gram product: two threads per row, thread h chains fma over floats 16h .. 16h+15 of every slab, slab
+// after slab; |x|^2 = chain 0 + chain 1.  Used whenever D % 32 == 0, so that the staged launches and the fused kernel see the same
+// norms bit for bit.
+__global__ __launch_bounds__(256) void sqnorm_pair_kernel(const float* __restrict__ x, float* __restrict__ nrm, int B, int N, int D) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  const int P = N - 1;
+  const int row = min(t >> 1, B * P - 1), h = t & 1;
+  const int b = row / P, p = row - b * P;
+  const float* xr = x + ((size_t)b * N + 1 + p) * D + 16 * h;
+  float a = 0.f;
+  for (int k0 = 0; k0 < D; k0 += 32) {
+    float4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(xr + k0 + 4 * q);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { a = fmaf(v[q].x, v[q].x, a); a = fmaf(v[q].y, v[q].y, a); a = fmaf(v[q].z, v[q].z, a); a = fmaf(v[q].w, v[q].w, a); }
+  }
+  const float other = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a), 0xB1, 0xF, 0xF, true));   // lane ^ 1
+  if (h == 0 && (t >> 1) < B * P) nrm[row] = a + other;
+}
+
 // dist[b][i][j] = sqrt(max(|x_i|^2 + |x_j|^2 - 2 x_i.x_j, 1e-30)) / sqrt(D);  grid (tiles, B).
 // DIRECT: sqrt(sum (x_i - x_j)^2) / sqrt(D) -- torch.cdist only takes the matmul form when P > 25
 // (use_mm_for_euclid_dist_if_necessary); small late stages (P <= 25) get exact zeros on the diagonal like the reference.
@@ -536,6 +558,14 @@ __global__ __launch_bounds__(KMT) void kmed_iterate_kernel(const float* __restri
 
 }  // namespace
 
+namespace {
+void launch_sqnorm(const float* x, float* nrm, int B, int N, int D, hipStream_t st) {
+  const int rows = B * (N - 1);
+  if (D % 32 == 0) hipLaunchKernelGGL(sqnorm_pair_kernel, dim3((2 * rows + 255) / 256), dim3(256), 0, st, x, nrm, B, N, D);
+  else hipLaunchKernelGGL(sqnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, nrm, B, N, D);
+}
+}  // namespace
+
 extern "C" size_t tr_dpcknn_workspace_floats(int B, int N) {
   const size_t P = N > 1 ? N - 1 : 0;
   return (size_t)B * P * P + (size_t)B * (3 * P + N) + 64 + (size_t)B;
@@ -577,7 +607,7 @@ extern "C" int tr_dpcknn_cluster(const float* x, const float* noise, float* ws, 
   float* score_rows = density + (size_t)B * P;                  // [B,N]
   float* rowmax = nrm;                                            // the norms are dead once the distances exist
   const int rows = B * P, rb = (rows + 3) / 4;
-  hipLaunchKernelGGL(sqnorm_kernel, dim3(rb), dim3(256), 0, st, x, nrm, B, N, D);
+  launch_sqnorm(x, nrm, B, N, D, st);
   launch_dist(fast_dist != 0, x, nrm, dist, B, N, D, (float)sqrt((double)D), st);
   if (P <= 256) hipLaunchKernelGGL(density_kernel<4>, dim3(rb), dim3(256), 0, st, dist, noise, density, rowmax, B, P, k);
   else hipLaunchKernelGGL(density_kernel<16>, dim3(rb), dim3(256), 0, st, dist, noise, density, rowmax, B, P, k);
@@ -685,7 +715,7 @@ extern "C" int tr_kmedoids_equal(const float* x, int init_idx, float* ws, int32_
   float* wrow = t + (size_t)B * P;                              // [B,N] of ones
   const int rows = B * P, rb = (rows + 3) / 4;
   hipLaunchKernelGGL(fill_kernel, dim3((B * N + 255) / 256), dim3(256), 0, st, wrow, 1.0f, (size_t)B * N);
-  hipLaunchKernelGGL(sqnorm_kernel, dim3(rb), dim3(256), 0, st, x, nrm, B, N, D);
+  launch_sqnorm(x, nrm, B, N, D, st);
   launch_dist(fast_dist != 0, x, nrm, dist, B, N, D, 1.0f, st);
   hipLaunchKernelGGL(kmed_init_equal_kernel, dim3(B), dim3(256), 0, st, dist, centers, P, K, init_idx);
   hipLaunchKernelGGL(kmed_rowcost_kernel, dim3(rb), dim3(256), 0, st, dist, wrow, t, B, P);
@@ -713,7 +743,7 @@ extern "C" int tr_kmedoids(const float* x, const float* colsum_part, float* ws, 
   // cluster_idx = topk(token_weight, K) (kmedoids.py:59); the scores output lands in t and is overwritten below
   int rc = tr_cls_topk(wrow, centers, nullptr, t, B, 1, N, K, s);
   if (rc != TR_OK) return rc;
-  hipLaunchKernelGGL(sqnorm_kernel, dim3(rb), dim3(256), 0, st, x, nrm, B, N, D);
+  launch_sqnorm(x, nrm, B, N, D, st);
   launch_dist(fast_dist != 0, x, nrm, dist, B, N, D, 1.0f, st);                               // torch.cdist(x, x)
   hipLaunchKernelGGL(kmed_rowcost_kernel, dim3(rb), dim3(256), 0, st, dist, wrow, t, B, P);
   hipLaunchKernelGGL(kmed_iterate_kernel, dim3(B), dim3(KMT), (size_t)K * 12, st, dist, t, centers, assign, P, K, iters);

@@ -5,13 +5,14 @@
 // fp32 = 39 MB) + density 33 us + parent_score 11 us + cls_topk 7 us + assign 10 us = 130 us, the matrix read back three times.
 // Here it lives in LDS, as the UPPER TRIANGLE in 16 x 16 tiles (91 tiles x 1088 B = 97 KiB; the matrix is symmetric), next to two
 // 16-KiB operand slabs; only centres, assignments and scores leave the chip:
-//   0. squared norms, one wave per row, the summation order of sqnorm_kernel;
+//   0./1. squared norms ride along with the Gram product's slab loop (two fma chains per row, sqnorm_pair_kernel's order: x is read once);
 //   1. Gram product on the matrix cores with every fp32 operand split into bf16 hi + lo (the arithmetic of dist_mfma_kernel: per
 //      32-deep slab lo.hi' + hi.lo' + hi.hi'), upper-triangle tiles only, tile rows w and 15-w on wave w (13,12,11,11,... tiles);
 //      distance = sqrt(max(|x_i|^2 + |x_j|^2 - 2 g_ij, 1e-30)) / sqrt(D) written into the tile;
 //   2. density = exp(-mean of the k smallest d^2) (+ noise): FOUR rows per wave, 16 lanes per row -- each lane keeps the five smallest
-//      of its 13 elements sorted, four DPP steps merge the lists (min(a_i, b_4-i), then a 9-comparator sort): no index bookkeeping and
-//      no cross-lane LDS traffic (the old kernel spent ~60 ds_bpermute per row);
+//      of its 13 elements sorted (insertion by v_med3), four DPP steps merge the lists (min(a_i, b_4-i), then a 9-comparator sort): no
+//      index bookkeeping and no cross-lane LDS traffic (the old kernel spent ~60 ds_bpermute per row); the row's elements stay in
+//      registers for step 3;
 //   3. distance to the nearest denser token (else the image's maximum), score = distance x density;
 //   4. top-K centres by rank counting on order keys (ties: lower index first -- tr_cls_topk's rule);
 //   5. nearest centre per token: one wave per centre row, (distance bits, centre number) packed into 64 bits and ds_min_u64'ed per token
@@ -60,12 +61,19 @@ __device__ __forceinline__ void ft_split_store(const float4 v, unsigned short* h
   *reinterpret_cast<uint2*>(lo) = make_uint2(l2[0], l2[1]);
 }
 
+#ifdef TR_FUSED_STAMPS
+__device__ unsigned long long ft_stamps[8];        // lab only: s_memtime at the phase boundaries of workgroup 17
+#define FT_STAMP(k) do { if (blockIdx.x == 17 && threadIdx.x == 0) ft_stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FT_STAMP(k) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(512) void dpcknn_fused_kernel(const float* __restrict__ x, const float* __restrict__ noise,
                                                            int32_t* __restrict__ centers, int32_t* __restrict__ idx_cluster,
                                                            float* __restrict__ scores, int N, int D, int K, int k, float sqrt_d) {
   __shared__ __attribute__((aligned(16))) float T[91 * FT_TILE];                      // 99,008 B
   __shared__ __attribute__((aligned(16))) unsigned short sH[FT_PMAX * FT_GLD], sL[FT_PMAX * FT_GLD];   // 2 x 16,640 B
-  __shared__ float s_nrm[FT_PMAX], s_den[FT_PMAX], s_rmax[FT_PMAX];
+  __shared__ float s_nrm[FT_PMAX], s_den[FT_PMAX], s_rmax[FT_PMAX], s_noise[FT_PMAX];
   __shared__ unsigned int s_key[FT_PMAX];
   __shared__ int s_cen[FT_PMAX];
   __shared__ unsigned long long s_best[FT_PMAX];
@@ -76,37 +84,10 @@ __global__ __launch_bounds__(512) void dpcknn_fused_kernel(const float* __restri
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float* xb = x + ((size_t)b * N + 1) * D;
 
-  // ---- 0. squared norms (sqnorm_kernel's order: per-lane fmaf chain over its 16-byte chunks, then the xor butterfly)
-  {
-    const int nch = D >> 2;
-    for (int r0 = wave; r0 < P; r0 += 32) {           // four rows per pass: their shuffles overlap
-      float acc[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int row = min(r0 + 8 * u, P - 1);
-        const float* xr = xb + (size_t)row * D;
-        float4 v[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = *reinterpret_cast<const float4*>(xr + 4 * min(lane + 64 * c, nch - 1));
-        float a = 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if (lane + 64 * c < nch) { a = fmaf(v[c].x, v[c].x, a); a = fmaf(v[c].y, v[c].y, a); a = fmaf(v[c].z, v[c].z, a); a = fmaf(v[c].w, v[c].w, a); }
-        acc[u] = a;
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc[u] += __shfl_xor(acc[u], o, 64);
-      }
-      if (lane == 0) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (r0 + 8 * u < P) s_nrm[r0 + 8 * u] = acc[u];
-      }
-    }
-  }
-
+  FT_STAMP(0);
+  // the density noise of this image goes to LDS up front: a global load inside the density loop stalls its wave for a microsecond per row group
+  if (tid < P) s_noise[tid] = noise ? noise[(size_t)b * P + tid] : 0.f;
+  FT_STAMP(1);
   // ---- 1. Gram product, upper-triangle tiles: wave w owns tile rows w (13 - w tiles at nt = 13) and 15 - w
   const int frow = lane & 15, fq = lane >> 4;
   const int ra = wave, rb2 = 15 - wave;
@@ -120,18 +101,32 @@ __global__ __launch_bounds__(512) void dpcknn_fused_kernel(const float* __restri
     const int lr = tid >> 1, lc = (tid & 1) * 16;                      // staging: row lr (0..255), 16 consecutive floats
     const bool stg = lr < FT_PMAX;
     const float* ap = xb + (size_t)min(lr, P - 1) * D + lc;
-    float4 rv[4];
+    // two slabs of prefetch: the loads of slab s+2 are issued before slab s is split (the per-slab matrix work, ~1.2k cycles, is shorter
+    // than a first-touch load; one slab of prefetch left ~2k cycles of every 3.1k-cycle slab step exposed)
+    float4 rv[4], rw[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const float4*>(ap + 4 * q);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) rw[q] = *reinterpret_cast<const float4*>(ap + min(FT_GK, D - FT_GK) + 4 * q);
+    // |x_row|^2 rides along: each of a row's two threads chains fma over its 16 floats of every slab, slab after slab; the row's norm is
+    // the sum of the two chains (sqnorm_kernel adds in the same order, so the staged launches see the same norms bit for bit)
+    float nacc = 0.f;
     for (int k0 = 0; k0 < D; k0 += FT_GK) {
       lds_barrier();                                                   // the slab before has been read (LDS only: the prefetch stays in flight)
       if (stg) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) ft_split_store(rv[q], sH + lr * FT_GLD + lc + 4 * q, sL + lr * FT_GLD + lc + 4 * q);
       }
-      if (k0 + FT_GK < D) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const float4*>(ap + k0 + FT_GK + 4 * q);
+      for (int q = 0; q < 4; ++q) {
+        nacc = fmaf(rv[q].x, rv[q].x, nacc); nacc = fmaf(rv[q].y, rv[q].y, nacc);
+        nacc = fmaf(rv[q].z, rv[q].z, nacc); nacc = fmaf(rv[q].w, rv[q].w, nacc);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) rv[q] = rw[q];
+      if (k0 + 2 * FT_GK < D) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rw[q] = *reinterpret_cast<const float4*>(ap + k0 + 2 * FT_GK + 4 * q);
       }
       lds_barrier();
       // operand fragments: the A side is the tile ROW (i), the B side the tile COLUMN (j); acc[e] = x_i . x_j, i = frow, j = 4 fq + e
@@ -165,8 +160,13 @@ __global__ __launch_bounds__(512) void dpcknn_fused_kernel(const float* __restri
         }
       }
     }
+    {
+      const float other = ft_dpp<0xB1>(nacc);          // the row's other thread (tid ^ 1)
+      if ((tid & 1) == 0 && lr < P) s_nrm[lr] = nacc + other;
+    }
   }
-  __syncthreads();                                   // s_nrm complete (phase 0 ran before the first slab barrier anyway)
+  FT_STAMP(2);
+  __syncthreads();                                   // s_nrm complete
   {
     auto put = [&](const f32x4 g, int ti, int tj) __attribute__((always_inline)) {
       const int i = ti * 16 + frow;
@@ -188,38 +188,56 @@ __global__ __launch_bounds__(512) void dpcknn_fused_kernel(const float* __restri
   }
   __syncthreads();
 
-  // element (i, j) of the symmetric matrix, j = m * 16 + sl: tile column m, lane column sl
+  FT_STAMP(3);
+  // Element (i, j) of the symmetric matrix for a lane that walks row i with j = m * 16 + sl (tile column m, lane column sl):
+  //   m >= ti: tile (ti, m), row r, column sl      -> baseU + m * 272          baseU = (rowstart(ti) - ti) * 272 + r * 17 + sl
+  //   m <  ti: tile (m, ti), row sl, column r      -> baseL + m * stepL - cL   baseL = ti * 272 + sl * 17 + r, stepL = (nt - 1) * 272,
+  //                                                                             cL = m (m - 1) / 2 * 272  (compile time)
+  // Two adds, a compare and a select per element.  A lane keeps the 13 elements of each of its (up to 7) rows in registers from the
+  // density pass to the parent-distance pass: the matrix is read once.
   const int grp = lane >> 4, sl = lane & 15;
-  auto elem = [&](int i, const int m) __attribute__((always_inline)) {
-    const int ti = i >> 4, r = i & 15;
-    const int off = (m >= ti) ? (ft_rowstart(ti, nt) + (m - ti)) * FT_TILE + r * FT_TROW + sl
-                              : (ft_rowstart(m, nt) + (ti - m)) * FT_TILE + sl * FT_TROW + r;
-    return T[off];
-  };
+  const int stepL = (nt - 1) * FT_TILE;
+  constexpr int NPASS = (FT_PMAX + 31) / 32;           // 7
+  float dv[NPASS][FT_NT];
+  float dj[FT_NT];                                     // densities of this lane's columns (phase 3)
 
   // ---- 2. density and row maximum: four rows per wave and pass, 16 lanes per row
-  for (int i0 = wave * 4; i0 < P; i0 += 32) {
-    const int i = min(i0 + grp, P - 1);
-    float bsm[FT_KSEL];
+  // (two rows per lane group at a time: the sorted insertion is one long dependency chain per row, a second row doubles the work in flight)
+  auto density_pass = [&](const int ps, float (&bsm)[FT_KSEL], float& mx) __attribute__((always_inline)) {
+    const int i = min(ps * 32 + wave * 4 + grp, P - 1);
+    const int ti = i >> 4, r = i & 15;
+    const int baseU = (ft_rowstart(ti, nt) - ti) * FT_TILE + r * FT_TROW + sl;
+    int offL = ti * FT_TILE + sl * FT_TROW + r;          // running: + stepL - m * 272 per tile column
 #pragma unroll
     for (int t = 0; t < FT_KSEL; ++t) bsm[t] = INFINITY;
-    float mx = 0.f;
+    mx = 0.f;
+    // branch-free: every lane loads (a clamped, in-range address where its element does not exist) and selects -- with `if`s around the
+    // load hipcc built an exec-mask branch per element and spilled scalar registers into VGPR lanes (8.5k instructions for this phase)
 #pragma unroll
     for (int m = 0; m < FT_NT; ++m) {
       const int j = m * 16 + sl;
-      float v = INFINITY;
-      if (m < nt) {
-        const float d = elem(i, m);
-        if (j < P) { v = d; mx = fmaxf(mx, d); }
-      }
-      // insert into the sorted five
+      const int mc = min(m, nt - 1);
+      const int offU = baseU + mc * FT_TILE;
+      const int off = (m >= ti) ? offU : offL;
+      const float d = T[off];
+      const bool ok = (m < nt) && (j < P);
+      float v = ok ? d : INFINITY;
+      mx = fmaxf(mx, ok ? d : 0.f);
+      offL += stepL - m * FT_TILE;
+      dv[ps][m] = v;
+      // insert into the sorted five: new[t] = median(old[t-1], old[t], v) -- five INDEPENDENT full-rate ops (a compare-exchange chain is
+      // ten dependent ones)
+      {
+        float nb_[FT_KSEL];
+        nb_[0] = fminf(bsm[0], v);
 #pragma unroll
-      for (int t = 0; t < FT_KSEL; ++t) {
-        const float lo = fminf(bsm[t], v);
-        v = fmaxf(bsm[t], v);
-        bsm[t] = lo;
+        for (int t = 1; t < FT_KSEL; ++t) nb_[t] = __builtin_amdgcn_fmed3f(bsm[t - 1], bsm[t], v);
+#pragma unroll
+        for (int t = 0; t < FT_KSEL; ++t) bsm[t] = nb_[t];
       }
     }
+  };
+  auto density_finish = [&](const int ps, float (&bsm)[FT_KSEL], float mx) __attribute__((always_inline)) {
 #define FT_MERGE(CTRL)                                                                                          \
     {                                                                                                           \
       float o[FT_KSEL];                                                                                         \
@@ -232,16 +250,28 @@ __global__ __launch_bounds__(512) void dpcknn_fused_kernel(const float* __restri
     }
     FT_ROW16_REDUCE(FT_MERGE)
 #undef FT_MERGE
-    if (sl == 0 && i0 + grp < P) {
+    const int i = ps * 32 + wave * 4 + grp;
+    if (sl == 0 && i < P) {
       float ss = 0.f;
 #pragma unroll
       for (int t = 0; t < FT_KSEL; ++t)
         if (t < k) ss += bsm[t] * bsm[t];                                // ascending = torch.topk(largest=False) order
-      s_den[i] = expf(-(ss / (float)k)) + (noise ? noise[(size_t)b * P + i] * 1e-6f : 0.f);
+      s_den[i] = expf(-(ss / (float)k)) + (noise ? s_noise[i] * 1e-6f : 0.f);
       s_rmax[i] = mx;
+    }
+  };
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ps += 2) {
+    if (ps * 32 + wave * 4 < P) {                        // (the second row of the pair may lie beyond P: clamped, computed, not written)
+      float b0[FT_KSEL], b1[FT_KSEL], m0, m1;
+      density_pass(ps, b0, m0);
+      if (ps + 1 < NPASS) density_pass(ps + 1, b1, m1);
+      density_finish(ps, b0, m0);
+      if (ps + 1 < NPASS) density_finish(ps + 1, b1, m1);
     }
   }
   __syncthreads();
+  FT_STAMP(4);
   if (wave == 0) {                                   // dist_matrix.flatten(1).max(): max of the row maxima
     float m = 0.f;
     for (int j = lane; j < P; j += 64) m = fmaxf(m, s_rmax[j]);
@@ -249,61 +279,82 @@ __global__ __launch_bounds__(512) void dpcknn_fused_kernel(const float* __restri
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if (lane == 0) s_dmax = m;
   }
+  for (int p = tid; p < P; p += 512) s_best[p] = ~0ull;
+#pragma unroll
+  for (int m = 0; m < FT_NT; ++m) dj[m] = s_den[min(m * 16 + sl, P - 1)];
   __syncthreads();
 
-  // ---- 3. distance to the nearest denser token, score, order key
+  // ---- 3. distance to the nearest denser token, score, order key (the rows' elements are still in registers)
   const float dmax = s_dmax;
-  for (int i0 = wave * 4; i0 < P; i0 += 32) {
-    const int i = min(i0 + grp, P - 1);
-    const float di = s_den[i];
-    float mn = INFINITY;
 #pragma unroll
-    for (int m = 0; m < FT_NT; ++m) {
-      const int j = m * 16 + sl;
-      if (m < nt && j < P) mn = fminf(mn, s_den[j] > di ? elem(i, m) : dmax);
-    }
+  for (int ps = 0; ps < NPASS; ++ps) {
+    const int i0 = ps * 32 + wave * 4;
+    if (i0 < P) {
+      const int i = min(i0 + grp, P - 1);
+      const float di = s_den[i];
+      float mn = INFINITY;
+#pragma unroll
+      for (int m = 0; m < FT_NT; ++m) {
+        const int j = m * 16 + sl;
+        if (m < nt && j < P) mn = fminf(mn, dj[m] > di ? dv[ps][m] : dmax);
+      }
 #define FT_MIN(CTRL) mn = fminf(mn, ft_dpp<CTRL>(mn));
-    FT_ROW16_REDUCE(FT_MIN)
+      FT_ROW16_REDUCE(FT_MIN)
 #undef FT_MIN
-    if (sl == 0 && i0 + grp < P) {
-      const float sc = mn * di;
-      scores[(size_t)b * P + i] = sc;
-      unsigned int u = __float_as_uint(sc + 0.0f);                       // tr_cls_topk's order key: -0 -> +0, NaN above +inf
-      u = (sc != sc) ? 0xffffffffu : (u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u));
-      s_key[i] = u;
+      if (sl == 0 && i0 + grp < P) {
+        const float sc = mn * di;
+        scores[(size_t)b * P + i] = sc;
+        unsigned int u = __float_as_uint(sc + 0.0f);                       // tr_cls_topk's order key: -0 -> +0, NaN above +inf
+        u = (sc != sc) ? 0xffffffffu : (u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u));
+        s_key[i] = u;
+      }
     }
   }
-  for (int p = tid; p < P; p += 512) s_best[p] = ~0ull;
   __syncthreads();
 
-  // ---- 4. the K highest scores, in descending order (ties: lower index first)
-  for (int i = tid; i < P; i += 512) {
-    const unsigned int si = s_key[i];
+  FT_STAMP(5);
+  // ---- 4. the K highest scores, in descending order (ties: lower index first): two threads per token, half of the scores each
+  {
+    const int i = tid >> 1, hf = tid & 1;
+    const int ic = min(i, P - 1);
+    const unsigned int si = s_key[ic];
+    const int half = (P + 1) >> 1;
+    const int j0 = hf * half, j1 = min(P, j0 + half);
     int rank = 0;
-    for (int j = 0; j < P; ++j) {
+    for (int j = j0; j < j1; ++j) {
       const unsigned int sj = s_key[j];
-      rank += (sj > si) || (sj == si && j < i);
+      rank += (sj > si) || (sj == si && j < ic);
     }
-    if (rank < K) {
+    rank += __builtin_amdgcn_mov_dpp(rank, 0xB1, 0xF, 0xF, true);          // the neighbour lane's half
+    if (hf == 0 && i < P && rank < K) {
       s_cen[rank] = i;
       centers[(size_t)b * K + rank] = i;
     }
   }
   __syncthreads();
 
+  FT_STAMP(6);
   // ---- 5. nearest centre per token: centre c on wave c % 8, its row against every token, (distance, centre) minimum per token in LDS
-  for (int c = wave; c < K; c += 8) {
-    const int ci = s_cen[c];                           // wave-uniform
-    const int ti = ci >> 4, r = ci & 15;
+  {
+    int pu[4], pl[4], pm[4];                              // per lane token p = q * 64 + lane: the lane parts of the two address forms
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int p = q * 64 + lane;
-      if (p < P) {
-        const int m = p >> 4, ps = p & 15;
-        const int off = (m >= ti) ? (ft_rowstart(ti, nt) + (m - ti)) * FT_TILE + r * FT_TROW + ps
-                                  : (ft_rowstart(m, nt) + (ti - m)) * FT_TILE + ps * FT_TROW + r;
-        const unsigned long long key = ((unsigned long long)__float_as_uint(T[off]) << 32) | (unsigned int)c;    // distances are > 0
-        atomicMin(&s_best[p], key);
+      const int p = q * 64 + lane, m = p >> 4, psl = p & 15;
+      pm[q] = p < P ? m : -1;                              // -1: no such token (never >= ti, and skipped below)
+      pu[q] = m * FT_TILE + psl;
+      pl[q] = (ft_rowstart(min(m, nt - 1), nt) - m) * FT_TILE + psl * FT_TROW;
+    }
+    for (int c = wave; c < K; c += 8) {
+      const int ci = s_cen[c];                             // wave-uniform
+      const int ti = ci >> 4, r = ci & 15;
+      const int uU = (ft_rowstart(ti, nt) - ti) * FT_TILE + r * FT_TROW, uL = ti * FT_TILE + r;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (pm[q] >= 0) {
+          const int off = (pm[q] >= ti) ? uU + pu[q] : uL + pl[q];
+          const unsigned long long key = ((unsigned long long)__float_as_uint(T[off]) << 32) | (unsigned int)c;    // distances are > 0
+          atomicMin(&s_best[q * 64 + lane], key);
+        }
       }
     }
   }
@@ -311,9 +362,14 @@ __global__ __launch_bounds__(512) void dpcknn_fused_kernel(const float* __restri
   for (int p = tid; p < P; p += 512) idx_cluster[(size_t)b * P + p] = (int)(unsigned int)(s_best[p] & 0xffffffffu);
   __syncthreads();                                   // the centres' own entries must land after the pass above (same addresses)
   for (int c = tid; c < K; c += 512) idx_cluster[(size_t)b * P + s_cen[c]] = c;
+  FT_STAMP(7);
 }
 
 }  // namespace
+
+#ifdef TR_FUSED_STAMPS
+extern "C" void ftdbg_read(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(ft_stamps), sizeof(unsigned long long) * 8); }
+#endif
 
 // Does the one-launch kernel take this problem?  (fast distances only: the fp32 validation executor keeps the exact VALU pipeline)
 extern "C" int tr_dpcknn_fused_supported(int N, int D, int k) {
