@@ -296,7 +296,8 @@ def finetune_leg(name, keep_rate, loc, batch, device, dist, steps=8, warmup=3, i
     world = dist.get_world_size() if dist is not None else 1
     x = torch.randn(batch, 3, img_size, img_size, generator=torch.Generator().manual_seed(200 + rank)).to(device)
     y = torch.randint(0, 1000, (batch,), generator=torch.Generator().manual_seed(300 + rank)).to(device)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05, fused=True)
+    from tokenreduction_amd.optim import FusedAdamW              # one launch per step, bit-identical to torch.optim.AdamW(fused=True)
+    opt = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.05, model=model)
     if dist is not None:
         from tokenreduction_amd.dp import FlatGradReducer
         red = FlatGradReducer().attach(model)
@@ -313,7 +314,7 @@ def finetune_leg(name, keep_rate, loc, batch, device, dist, steps=8, warmup=3, i
     el = timed_steps(step, steps, warmup, dist, torch.cuda.synchronize, device)
     assert torch.isfinite(last[0]).item()
     return {"images_per_s": round(world * batch * steps / el, 1), "ms_per_step": round(1e3 * el / steps, 3), "batch_per_gpu": batch,
-            "n_gpus": world, "steps": steps, "warmup": warmup, "optimizer": "AdamW(fused)", "loss_last": round(last[0].item(), 4),
+            "n_gpus": world, "steps": steps, "warmup": warmup, "optimizer": "tokenreduction_amd.optim.FusedAdamW (one launch; bit-identical to torch AdamW(fused=True))", "loss_last": round(last[0].item(), 4),
             "tokens_per_block": model._last_tokens}
 
 

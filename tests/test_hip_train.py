@@ -409,6 +409,57 @@ def test_any_number_of_classes_trains_and_evaluates(classes):
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())
 
 
+@pytest.mark.parametrize("name", ["topk_micro", "dpcknn_micro", "topk_small_kr07"])
+def test_one_launch_adamw_is_bit_identical_to_torch_fused_adamw(name):
+    """tokenreduction_amd.optim.FusedAdamW (AdamW + gradient zeroing + bf16 / transposed operand refresh in one launch, csrc/tr_optim.hip)
+    against torch.optim.AdamW(fused=True) -- what the fine-tune leg used before: same start, same batches, two parameter groups with
+    different learning rates and weight decay, a schedule that changes lr every step.  After every one of 10 steps all parameters,
+    exp_avg and exp_avg_sq must be BIT-identical, and so must the training logits (the refreshed operand copies are the parameters,
+    rounded, whoever rounds them)."""
+    from tokenreduction_amd.optim import FusedAdamW
+    case = GOLDEN_CASES[name]
+    x = make_images(case["batch"], 224, case["xseed"]).cuda()
+    y = grad_labels(case).cuda()
+
+    def groups(model):
+        decay = [p for n, p in model.named_parameters() if p.dim() >= 2]
+        rest = [p for n, p in model.named_parameters() if p.dim() < 2]
+        return [dict(params=decay, weight_decay=0.05), dict(params=rest, weight_decay=0.0, lr=3e-3)]
+
+    runs = {}
+    for kind in ("torch", "hip"):
+        model, _, _ = build_model(case)
+        model.viz_mode = False
+        model.train()
+        if case["family"] == "dpcknn":
+            model.density_noise = None
+            torch.manual_seed(7)          # the device-side noise draws: same seed, same draws in both runs
+        opt = (torch.optim.AdamW(groups(model), lr=2e-3, betas=(0.9, 0.98), eps=1e-8, fused=True) if kind == "torch"
+               else FusedAdamW(groups(model), lr=2e-3, betas=(0.9, 0.98), eps=1e-8, model=model))
+        base = [g["lr"] for g in opt.param_groups]
+        trace = []
+        for it in range(10):
+            for g, b in zip(opt.param_groups, base):
+                g["lr"] = b * (1.0 - 0.07 * it)
+            out = model(x)
+            loss = torch.nn.functional.cross_entropy(out, y)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            trace.append((out.detach().clone(), [p.detach().clone() for p in model.parameters()]))
+        states = [(opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone()) for p in model.parameters()]
+        runs[kind] = (trace, states, model)
+    for it, ((lt, pt), (lh, ph)) in enumerate(zip(runs["torch"][0], runs["hip"][0])):
+        assert torch.equal(lt, lh), f"step {it}: training logits differ ({float((lt - lh).abs().max())})"
+        for (n, _), a, b in zip(runs["torch"][2].named_parameters(), pt, ph):
+            assert torch.equal(a, b), f"step {it}: parameter {n} differs by {float((a - b).abs().max())}"
+    for (n, _), (m0, v0), (m1, v1) in zip(runs["torch"][2].named_parameters(), runs["torch"][1], runs["hip"][1]):
+        assert torch.equal(m0, m1) and torch.equal(v0, v1), f"optimizer state of {n} differs"
+    # eval after training: the operands the step refreshed are what a repack would have produced
+    e_t, e_h = runs["torch"][2].eval()(x), runs["hip"][2].eval()(x)
+    assert torch.equal(e_t, e_h)
+
+
 def test_fused_optimizer_steps_reach_the_executor():
     """torch's fused optimizers update parameters without bumping `_version`; the executor's operand copies must follow anyway (round 3:
     they did not -- AdamW(fused=True) trained on the initial bf16 matrices).  Fused and unfused AdamW from the same start must walk the

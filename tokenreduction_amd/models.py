@@ -238,7 +238,7 @@ class VisionTransformer(nn.Module):
         def live(t):
             return t.dtype == torch.float32 and t.is_contiguous() and t.device == dev and t.untyped_storage().data_ptr() in own
 
-        state = {"i": 0, "moved": False}
+        state = {"i": 0, "moved": False, "copied": False}
         fused = []                                                     # (fp32 source, bf16 slot, transposed bf16 slot or None)
 
         def slot(kind, shape, dtype):
@@ -266,6 +266,7 @@ class VisionTransformer(nn.Module):
                 fused.append((t, c, ct))
             else:
                 c.copy_(t)
+                state["copied"] = True        # an operand copy the fused table does not cover (optim.FusedAdamW then leaves the refresh here)
                 if ct is not None:
                     ct.copy_(t.t())
             if ct is not None:
@@ -308,6 +309,10 @@ class VisionTransformer(nn.Module):
             t2 = tslots.get(state["i"] - 1)
             tblocks.append((tq, tp_, t1, t2))
         self._pack_stages(W, w16, f32, keep_alive)
+        # may an optimizer that rewrites the fused table's copies itself declare the operands fresh?  Only if that table is all there is:
+        # no copied operand, and no reduction module whose transposed matrices training.TrainState keys on the pack generation
+        self._pack_all_fused = (not state["copied"] and wdt == torch.bfloat16
+                                and type(self)._transposed_stage_weights is VisionTransformer._transposed_stage_weights)
         if fused:
             self._run_fused_pack(fused, dev, state["moved"])
         cfg = _lib.TrVitConfig()

@@ -308,10 +308,12 @@ class _VitTrainFn(torch.autograd.Function):
         # default), keep accumulating into the others (engine.py:41-84: gradient accumulation over micro-steps)
         fresh = [n for n, p in st.order if p.grad is None or p.grad.data_ptr() != st.views[n].data_ptr()]
         if len(fresh) == len(st.order):
-            st.flat.zero_()
+            if not getattr(st, "flat_clean", False):     # optim.FusedAdamW zeroes what it consumes: nothing to clear behind it
+                st.flat.zero_()
         else:
             for n in fresh:
                 st.views[n].zero_()
+        st.flat_clean = False
         G = st.grads_struct(model)
         WT = st.transposed(model, pk)
         reducer = getattr(model, "_grad_reducer", None)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""One fine-tune workload for profiling: `python tools/train_step.py [model] [batch] [steps]` runs fwd + loss + bwd + AdamW steps of
-the HIP training path (put it after `rocprofv3 --kernel-trace --stats --`)."""
+"""One fine-tune workload for profiling: `python tools/train_step.py [model] [batch] [steps] [torch|hip]` runs fwd + loss + bwd + AdamW
+steps of the HIP training path (put it after `rocprofv3 --kernel-trace --stats --`); the last argument picks torch.optim.AdamW(fused=True)
+or tokenreduction_amd.optim.FusedAdamW (default)."""
 import os
 import sys
 import time
@@ -19,7 +20,12 @@ torch.cuda.set_device(0)
 model = bench.build_model(name, [1.0] if not loc else kr, loc, "cuda").train()
 x = torch.randn(batch, 3, 224, 224, device="cuda")
 y = torch.randint(0, 1000, (batch,), device="cuda")
-opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05, fused=True)
+which = sys.argv[4] if len(sys.argv) > 4 else "hip"
+if which == "hip":
+    from tokenreduction_amd.optim import FusedAdamW
+    opt = FusedAdamW(model.parameters(), lr=1e-4, weight_decay=0.05, model=model)
+else:
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=0.05, fused=True)
 for i in range(steps + 2):
     if i == 2:
         torch.cuda.synchronize()
@@ -31,4 +37,4 @@ for i in range(steps + 2):
     opt.step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
-print(f"{name} B={batch}: {1e3 * dt:.2f} ms/step, {batch / dt:.0f} images/s, loss {loss.item():.4f}")
+print(f"{name} B={batch} AdamW[{which}]: {1e3 * dt:.2f} ms/step, {batch / dt:.0f} images/s, loss {loss.item():.4f}")
