@@ -529,14 +529,16 @@ size_t tr_vit_dropout_mask_bytes(const tr_vit_config* cfg, int B);
 typedef struct tr_cast_item { const void* src; void* dst; void* dst_t; int rows, cols; } tr_cast_item;
 int tr_cast_pack_bf16(const tr_cast_item* items, const int* first, int n_items, int total_tiles, tr_stream_t s);
 /* One launch for the optimizer step of the fine-tune path (csrc/tr_optim.hip): AdamW on every parameter (torch's fused AdamW
- * arithmetic, bit for bit), the gradient zeroed behind it, and the bf16 (+ transposed) operand copies rewritten in the same pass.
+ * arithmetic, bit for bit), the gradient zeroed behind it when `zero_grads` != 0, and the bf16 (+ transposed) operand copies rewritten
+ * in the same pass.
  * Item i: p, g, m (exp_avg), v (exp_avg_sq) fp32 [rows, cols] contiguous; dst bf16 [rows, cols] / dst_t bf16 [cols, rows] nullable;
  * group selects lr8[group] / wd8[group] (up to 8 parameter groups per launch).  items / first: DEVICE arrays, first[i] = tiles before
  * item i (ceil(rows/64) * ceil(cols/64) per item), total_tiles = first[n_items].  bias_correction1 = 1 - beta1^step,
  * bias_correction2_sqrt = sqrt(1 - beta2^step), computed by the caller in double and rounded to float. */
 typedef struct tr_adamw_item { void* p; void* g; void* m; void* v; void* dst; void* dst_t; int rows, cols, group, pad_; } tr_adamw_item;
 int tr_adamw_step(const tr_adamw_item* items, const int* first, int n_items, int total_tiles, double beta1, double beta2, double eps,
-                  float bias_correction1, float bias_correction2_sqrt, const double* lr8, const double* wd8, tr_stream_t s);
+                  float bias_correction1, float bias_correction2_sqrt, const double* lr8, const double* wd8, int zero_grads,
+                  tr_stream_t s);
 int tr_dropout_bf16(const uint16_t* src, uint16_t* dst, const uint8_t* keep, float mul, size_t n, tr_stream_t s);
 int tr_dropout_f32(const float* src, float* dst, const uint8_t* keep, float mul, size_t n, tr_stream_t s);
 /* Byte offsets of block blk's tape slots (x0,x1,xn1,qkv,ao,dattn,x2,xn2,pre,h,idx,idx2,scores,size) followed by its token counts

@@ -105,7 +105,22 @@ def test_wgrad_patch_rows(ops):
     assert float((gotb - wantb).abs().max()) <= 2e-4 * float(wantb.abs().max())
 
 
-@pytest.mark.parametrize("M,N", [(7, 8), (50432, 1536), (1000, 1000), (513, 384)])
+@pytest.mark.parametrize("B,P,D,Kc", [(5, 36, 192, 768), (3, 196, 384, 768), (128, 196, 768, 768)])
+def test_wgrad_patch_rows_producer_consumer_kernel_exact_integers(ops, B, P, D, Kc):
+    """The PatchEmbed weight gradient at widths the LDS-DMA kernel takes (D, 3 * 16 * 16 multiples of 192): the CLS rows of [B, P + 1, D]
+    are stepped over by its loader (row m -> m + m / P + 1), weight and bias gradient exact on small integers up to the DeiT-B size."""
+    g = torch.Generator().manual_seed(B + P)
+    dy = torch.randint(-2, 3, (B, P + 1, D), generator=g).to(torch.bfloat16).cuda()
+    dy[:, 0] = 7.0                                     # a CLS row that leaks into the sums shows at once
+    cols = torch.randint(-2, 3, (B * P, Kc), generator=g).to(torch.bfloat16).cuda()
+    want = dy[:, 1:].reshape(-1, D).float().t() @ cols.float()
+    assert torch.equal(ops.wgrad(dy.view(-1, D), cols, yskip=P, rows=B * P), want)
+    dw, db = ops.linear_bwd_params(dy.view(-1, D), cols, yskip=P)
+    assert torch.equal(dw, want)
+    assert torch.equal(db, dy[:, 1:].reshape(-1, D).float().sum(0))
+
+
+@pytest.mark.parametrize("M,N", [(7, 8), (128, 1000), (50432, 1536), (1000, 1000), (513, 384)])
 def test_colsum(ops, M, N):
     dy = _randn(5, M, N, dtype=torch.bfloat16)
     got = ops.colsum(dy)
@@ -525,11 +540,13 @@ def test_linear_bwd_params2_pairs_two_layers_in_one_launch(ops, shapes):
                                     [(24832, 384, 1536), (24832, 1536, 384), (35328, 384, 384), (35328, 1152, 384)],
                                     [(200, 192, 192), (70, 576, 192), (64, 192, 384)],
                                     [(12672, 768, 3072), (12672, 3072, 768), (12672, 768, 768), (25216, 2304, 768)],
+                                    [(3200, 768, 3072), (3200, 3072, 768), (3200, 768, 768), (3200, 2304, 768)],
                                     [(300, 128, 256), (300, 384, 192), (300, 192, 192)]])
 def test_linear_bwd_group_up_to_four_layers_in_one_launch(ops, shapes):
     """The block's four parameter-gradient products from one weight-gradient launch: exact on small integers (unit -> layer -> tile -> token
     range), layers with different token counts, three layers, a group with a layer the 192-tile kernel does not take (separate calls),
-    accumulate, run-to-run bitwise."""
+    accumulate, run-to-run bitwise.  The short groups (3200 and 200 rows: one token range per layer) store their results in place
+    without a reduce launch when they overwrite, and go through partials + reduce when they accumulate: both asserted here."""
     g = torch.Generator().manual_seed(shapes[0][0] + len(shapes))
     mk = lambda m, n: torch.randint(-2, 3, (m, n), generator=g).to(torch.bfloat16).cuda()
     layers = [(mk(M, N), mk(M, K)) for M, N, K in shapes]

@@ -411,12 +411,14 @@ def test_any_number_of_classes_trains_and_evaluates(classes):
 
 @pytest.mark.parametrize("name", ["topk_micro", "dpcknn_micro", "topk_small_kr07"])
 def test_one_launch_adamw_is_bit_identical_to_torch_fused_adamw(name):
-    """tokenreduction_amd.optim.FusedAdamW (AdamW + gradient zeroing + bf16 / transposed operand refresh in one launch, csrc/tr_optim.hip)
+    """tokenreduction_amd.optim.FusedAdamW (AdamW + bf16 / transposed operand refresh [+ gradient zeroing] in one launch, csrc/tr_optim.hip)
     against torch.optim.AdamW(fused=True) -- what the fine-tune leg used before: same start, same batches, two parameter groups with
     different learning rates and weight decay, a schedule that changes lr every step.  After every one of 10 steps all parameters,
     exp_avg and exp_avg_sq must be BIT-identical, and so must the training logits (the refreshed operand copies are the parameters,
-    rounded, whoever rounds them)."""
+    rounded, whoever rounds them).  One case runs the optimizer with zero_grads=True and keeps the gradient views alive
+    (zero_grad(set_to_none=False)): the backward then ACCUMULATES into what the step zeroed instead of overwriting."""
     from tokenreduction_amd.optim import FusedAdamW
+    keep_views = name == "dpcknn_micro"
     case = GOLDEN_CASES[name]
     x = make_images(case["batch"], 224, case["xseed"]).cuda()
     y = grad_labels(case).cuda()
@@ -435,7 +437,7 @@ def test_one_launch_adamw_is_bit_identical_to_torch_fused_adamw(name):
             model.density_noise = None
             torch.manual_seed(7)          # the device-side noise draws: same seed, same draws in both runs
         opt = (torch.optim.AdamW(groups(model), lr=2e-3, betas=(0.9, 0.98), eps=1e-8, fused=True) if kind == "torch"
-               else FusedAdamW(groups(model), lr=2e-3, betas=(0.9, 0.98), eps=1e-8, model=model))
+               else FusedAdamW(groups(model), lr=2e-3, betas=(0.9, 0.98), eps=1e-8, model=model, zero_grads=keep_views))
         base = [g["lr"] for g in opt.param_groups]
         trace = []
         for it in range(10):
@@ -443,9 +445,11 @@ def test_one_launch_adamw_is_bit_identical_to_torch_fused_adamw(name):
                 g["lr"] = b * (1.0 - 0.07 * it)
             out = model(x)
             loss = torch.nn.functional.cross_entropy(out, y)
-            opt.zero_grad(set_to_none=True)
+            opt.zero_grad(set_to_none=not (keep_views and kind == "hip"))
             loss.backward()
             opt.step()
+            if keep_views and kind == "hip":
+                assert all(not bool(p.grad.any()) for p in model.parameters())
             trace.append((out.detach().clone(), [p.detach().clone() for p in model.parameters()]))
         states = [(opt.state[p]["exp_avg"].clone(), opt.state[p]["exp_avg_sq"].clone()) for p in model.parameters()]
         runs[kind] = (trace, states, model)

@@ -135,7 +135,7 @@ SIGNATURES = {
                                   _vp, _f]),
     "tr_vit_dropout_mask_bytes": (_sz, [C.POINTER(TrVitConfig), _i]),
     "tr_cast_pack_bf16": (_i, [_vp, _vp, _i, _i, _vp]),
-    "tr_adamw_step": (_i, [_vp, _vp, _i, _i, C.c_double, C.c_double, C.c_double, C.c_float, C.c_float, _vp, _vp, _vp]),
+    "tr_adamw_step": (_i, [_vp, _vp, _i, _i, C.c_double, C.c_double, C.c_double, C.c_float, C.c_float, _vp, _vp, _i, _vp]),
     "tr_dropout_bf16": (_i, [_vp, _vp, _vp, _f, _sz, _vp]),
     "tr_dropout_f32": (_i, [_vp, _vp, _vp, _f, _sz, _vp]),
     "tr_vit_tape_layout": (_i, [C.POINTER(TrVitConfig), _i, _i, C.POINTER(_sz)]),

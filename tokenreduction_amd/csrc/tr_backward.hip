@@ -555,29 +555,65 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const uint16_t* __restrict_
   }
 }
 
-// ---- classifier (topk.py:203) backward on the CLS rows.  dxn[b][d] = sum_c dlogits[b][c] W[c][d]: grid (B, D/64), block = 64 d x 4
-// class-partitions combined through LDS in partition order (C = 1000 is not a multiple of the MFMA GEMM's K step; the product is
-// tiny: B x C x D).  The weight gradient goes through tr_wgrad_bf16 / tr_colsum_bf16 on a bf16 copy of dlogits.
+// ---- classifier (topk.py:203) backward on the CLS rows.  dxn[b][d] = sum_c dlogits[b][c] W[c][d]: grid (ceil(B/4), D/64); a block holds
+// 64 columns (32 lanes x 2) of FOUR images and cuts the classes into 8 interleaved parts, combined through LDS in part order (C = 1000
+// is not a multiple of the MFMA GEMM's K step; the product is tiny: B x C x D).  Every weight element a lane loads serves four images,
+// five class steps are in flight per lane.  The weight gradient goes through tr_wgrad_bf16 / tr_colsum_bf16 on a bf16 copy of dlogits.
 __global__ __launch_bounds__(256) void head_dx_kernel(const float* __restrict__ dlogits, const uint16_t* __restrict__ W, uint16_t* __restrict__ dxn,
                                                       int B, int C, int D) {
-  __shared__ float red[3][64];
-  const int b = blockIdx.x, dl = threadIdx.x & 63, part = threadIdx.x >> 6;
-  const int d = min(blockIdx.y * 64 + dl, D - 1);
-  float a0 = 0.f, a1 = 0.f;
+  __shared__ float red[7][4][64];
+  const int b0 = blockIdx.x * 4, lane = threadIdx.x & 31, part = threadIdx.x >> 5;
+  const int d = min(blockIdx.y * 64 + 2 * lane, D - 2);
+  const float* dl[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dl[i] = dlogits + (size_t)min(b0 + i, B - 1) * C;
+  float a[4][2] = {};
   int c = part;
-  for (; c + 4 < C; c += 8) {
-    a0 += dlogits[(size_t)b * C + c] * bf16_bits_to_f32(W[(size_t)c * D + d]);
-    a1 += dlogits[(size_t)b * C + c + 4] * bf16_bits_to_f32(W[(size_t)(c + 4) * D + d]);
+  for (; c + 32 < C; c += 40) {
+    unsigned w[5];
+#pragma unroll
+    for (int u = 0; u < 5; ++u) w[u] = *reinterpret_cast<const unsigned*>(W + (size_t)(c + 8 * u) * D + d);
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const float w0 = __uint_as_float(w[u] << 16), w1 = __uint_as_float(w[u] & 0xffff0000u);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float g = dl[i][c + 8 * u];
+        a[i][0] += g * w0;
+        a[i][1] += g * w1;
+      }
+    }
   }
-  for (; c < C; c += 4) a0 += dlogits[(size_t)b * C + c] * bf16_bits_to_f32(W[(size_t)c * D + d]);
-  float a = a0 + a1;
-  if (part > 0) red[part - 1][dl] = a;
+  for (; c < C; c += 8) {
+    const unsigned w = *reinterpret_cast<const unsigned*>(W + (size_t)c * D + d);
+    const float w0 = __uint_as_float(w << 16), w1 = __uint_as_float(w & 0xffff0000u);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float g = dl[i][c];
+      a[i][0] += g * w0;
+      a[i][1] += g * w1;
+    }
+  }
+  if (part > 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      red[part - 1][i][2 * lane] = a[i][0];
+      red[part - 1][i][2 * lane + 1] = a[i][1];
+    }
+  }
   __syncthreads();
-  if (part > 0 || blockIdx.y * 64 + dl >= D) return;
-  a += red[0][dl];
-  a += red[1][dl];
-  a += red[2][dl];
-  dxn[(size_t)b * D + d] = (uint16_t)(pack_bf16x2(a, 0.f) & 0xffffu);
+  if (part > 0 || blockIdx.y * 64 + 2 * lane >= D) return;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (b0 + i >= B) break;
+    float s0 = a[i][0], s1 = a[i][1];
+#pragma unroll
+    for (int p = 0; p < 7; ++p) {
+      s0 += red[p][i][2 * lane];
+      s1 += red[p][i][2 * lane + 1];
+    }
+    *reinterpret_cast<unsigned*>(dxn + (size_t)(b0 + i) * D + d) = pack_bf16x2(s0, s1);
+  }
 }
 
 // ---- d pos_embed[n][:] = sum_b g[b][n][:], d cls_token = sum_b g[b][0][:]   (topk.py:183-186); block = 64 chunks x 4 batch lanes
@@ -914,7 +950,8 @@ static int wgrad_splits(int M, int N, int K) {
 // tr_wgrad_pc.hip: the producer/consumer weight-gradient kernel (192 x 192 tiles, LDS-DMA ring) for shapes whose N and K are multiples of 192
 bool tr_wgrad_pc_fits(int M, int N, int K, long ldy, long ldx, int yskip);
 int tr_wgrad_pc_splits(int M, int N, int K);
-int tr_wgrad_pc_launch(const uint16_t* dY, long ldy, const uint16_t* X, long ldx, float* part, float* bpart, int M, int N, int K, int S_max, hipStream_t st);
+int tr_wgrad_pc_launch(const uint16_t* dY, long ldy, int yskip, const uint16_t* X, long ldx, float* part, float* bpart, int M, int N, int K, int S_max,
+                       hipStream_t st);
 
 extern "C" size_t tr_wgrad_workspace_floats(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return 0;
@@ -940,7 +977,7 @@ extern "C" int tr_wgrad_bf16(const uint16_t* dY, long ldy, int yskip, const uint
   hipStream_t st = static_cast<hipStream_t>(s);
   if (tr_wgrad_pc_fits(M, N, K, ldy, ldx, yskip)) {
     tr_prof_note("wgrad_pc_kernel", 2.0 * M * N * K, 2.0 * ((double)M * N + (double)M * K) + 4.0 * S * N * K);
-    S = tr_wgrad_pc_launch(dY, ldy, X, ldx, ws, nullptr, M, N, K, (int)min(fit, (size_t)1 << 20), st);
+    S = tr_wgrad_pc_launch(dY, ldy, yskip, X, ldx, ws, nullptr, M, N, K, (int)min(fit, (size_t)1 << 20), st);
   } else {
     tr_prof_note("wgrad_kernel", 2.0 * M * N * K, 2.0 * ((double)M * N + (double)M * K) + 4.0 * S * N * K);
     hipLaunchKernelGGL(wgrad_kernel<false>, dim3(tiles, S), dim3(256), 0, st, dY, ldy, yskip, X, ldx, ws, static_cast<float*>(nullptr), M, N, K, nNt, sps);
@@ -976,7 +1013,7 @@ extern "C" int tr_linear_bwd_params(const uint16_t* dY, long ldy, int yskip, con
     const int S_max = (int)min(fit, (size_t)1 << 20);
     bpart = ws + (size_t)S_max * N * K;
     tr_prof_note("wgrad_pc_kernel", 2.0 * M * N * K, 2.0 * ((double)M * N + (double)M * K) + 4.0 * S * N * K);
-    S = tr_wgrad_pc_launch(dY, ldy, X, ldx, ws, bpart, M, N, K, S_max, st);
+    S = tr_wgrad_pc_launch(dY, ldy, yskip, X, ldx, ws, bpart, M, N, K, S_max, st);
   } else {
     tr_prof_note("wgrad_kernel", 2.0 * M * N * K, 2.0 * ((double)M * N + (double)M * K) + 4.0 * S * N * K);
     hipLaunchKernelGGL(wgrad_kernel<true>, dim3(tiles, S), dim3(256), 0, st, dY, ldy, yskip, X, ldx, ws, bpart, M, N, K, nNt, sps);
@@ -988,8 +1025,8 @@ extern "C" int tr_linear_bwd_params(const uint16_t* dY, long ldy, int yskip, con
 }
 
 void tr_wgrad_pc_group_splits(const int (*mnk)[3], int n, int* S);
-void tr_wgrad_pc_group_launch(const uint16_t* const* dY, const long* ldy, const uint16_t* const* X, const long* ldx, const int (*mnk)[3], int n,
-                              float* ws, int* S, float** part, float** bpart, hipStream_t st);
+bool tr_wgrad_pc_group_launch(const uint16_t* const* dY, const long* ldy, const uint16_t* const* X, const long* ldx, const int (*mnk)[3], int n,
+                              float* ws, int* S, float** part, float** bpart, float* const* direct_w, float* const* direct_b, hipStream_t st);
 
 // Parameter gradients of up to FOUR Linear layers in one weight-gradient launch and one reduce launch (the executor hands over fc2, fc1,
 // proj and qkv of a block together, or pairs of them).  Each layer as in tr_linear_bwd_params (yskip = 0).  Groups the producer/consumer
@@ -1056,8 +1093,13 @@ extern "C" int tr_linear_bwd_group(const tr_linear_grad* layers, int n, int accu
   float* part[4];
   float* bpart[4];
   tr_prof_note("wgrad_pc_kernel", flops, bytes);
-  tr_wgrad_pc_group_launch(dY, ldy, X, ldx, mnk, n, ws, S, part, bpart, st);
+  float* dW[4];
+  float* db[4];
+  for (int i = 0; i < n; ++i) { dW[i] = layers[i].dW; db[i] = layers[i].db; }
+  // overwriting callers with one token range per layer (the short late stages) get their results stored in place: no reduce launch
+  const bool stored = tr_wgrad_pc_group_launch(dY, ldy, X, ldx, mnk, n, ws, S, part, bpart, accumulate ? nullptr : dW, accumulate ? nullptr : db, st);
   TR_CHECK_LAUNCH("tr_linear_bwd_group");
+  if (stored) return TR_OK;
   RSegs segs;
   int nb = 0;
   for (int i = 0; i < 8; ++i) {
@@ -1088,19 +1130,22 @@ extern "C" int tr_linear_bwd_params2(const uint16_t* dY0, long ldy0, const uint1
   return tr_linear_bwd_group(L, 2, accumulate, ws, ws_floats, s);
 }
 
+// row ranges of a column sum: 32 rows at least (the head's 128 x 1000 gradient used to run as ONE range on two workgroups: 15 us)
+static inline int colsum_splits(int M) {
+  int S = (M + 31) / 32;
+  return S > 256 ? 256 : S;
+}
+
 extern "C" size_t tr_colsum_workspace_floats(int M, int N) {
   if (M <= 0 || N <= 0) return 0;
-  int S = (M + 127) / 128;
-  if (S > 256) S = 256;
-  return (size_t)S * N;
+  return (size_t)colsum_splits(M) * N;
 }
 
 extern "C" int tr_colsum_bf16(const uint16_t* dY, long ldy, int yskip, float* db, int accumulate, float* ws, size_t ws_floats, int M,
                               int N, tr_stream_t s) {
   TR_REQUIRE(dY && db && ws, TR_ERR_NULL, "tr_colsum_bf16: null pointer");
   TR_REQUIRE(M > 0 && N > 0 && N % 2 == 0 && ldy % 2 == 0 && ldy >= N && yskip >= 0, TR_ERR_SHAPE, "tr_colsum_bf16: need even N and ldy (M=%d N=%d)", M, N);
-  int S = (M + 127) / 128;
-  if (S > 256) S = 256;
+  int S = colsum_splits(M);
   if ((size_t)S * N > ws_floats) S = (int)(ws_floats / N);
   TR_REQUIRE(S >= 1, TR_ERR_SHAPE, "tr_colsum_bf16: workspace too small");
   const int rps = (M + S - 1) / S;
@@ -1196,7 +1241,7 @@ extern "C" int tr_head_bwd(const float* dlogits, const uint16_t* W, const uint16
   TR_REQUIRE(dlogits && W && xn && dxn && dW && db && dl16 && ws, TR_ERR_NULL, "tr_head_bwd: null pointer");
   TR_REQUIRE(B > 0 && C > 0 && D > 0 && C % 8 == 0 && D % 8 == 0, TR_ERR_SHAPE, "tr_head_bwd: need classes, D multiples of 8 (B=%d C=%d D=%d)", B, C, D);
   hipStream_t st = static_cast<hipStream_t>(s);
-  hipLaunchKernelGGL(head_dx_kernel, dim3(B, (D + 63) / 64), dim3(256), 0, st, dlogits, W, dxn, B, C, D);
+  hipLaunchKernelGGL(head_dx_kernel, dim3((B + 3) / 4, (D + 63) / 64), dim3(256), 0, st, dlogits, W, dxn, B, C, D);
   TR_CHECK_LAUNCH("tr_head_bwd");
   int rc = tr_f32_to_bf16(dlogits, dl16, (size_t)B * C, s);
   if (rc != TR_OK) return rc;

@@ -1,7 +1,7 @@
 // Fused AdamW step of the fine-tune path (engine.py:76-91: loss.backward(); optimizer.step(); the reference's optimizer is
 // torch.optim.AdamW built by optim.py / timm's factory).  ONE launch updates every parameter and leaves the executor ready for the next
 // forward: per 64 x 64 tile of every parameter tensor it reads p, g, exp_avg, exp_avg_sq (fp32), applies the AdamW update, writes the
-// three states back, ZEROES the gradient, and -- for the matrices the bf16 executor reads -- writes the bf16 operand copy and its
+// three states back, ZEROES the gradient when asked to, and -- for the matrices the bf16 executor reads -- writes the bf16 operand copy and its
 // transposed copy (what tr_cast_pack_bf16 did in a second pass over the parameters).  Replaces, per training step of DeiT-B:
 // torch's multi_tensor_apply AdamW kernels (4.9 % of the step), ~69 fill launches and the cast_pack pass (1.1 %).
 //
@@ -22,6 +22,7 @@ namespace {
 
 struct adamw_groups { double lr[8]; double wd[8]; };
 
+template <bool ZERO>
 __global__ __launch_bounds__(256) void adamw_pack_kernel(const tr_adamw_item* __restrict__ items, const int* __restrict__ first, int n_items,
                                                          double beta1, double beta2, double eps, float bc1, float bc2_sqrt, adamw_groups G) {
   __shared__ unsigned short tile[64][66];
@@ -52,7 +53,6 @@ __global__ __launch_bounds__(256) void adamw_pack_kernel(const tr_adamw_item* __
     v = (float)__fma_rn(beta2, (double)v, __dmul_rn(__dmul_rn(w2, (double)g), (double)g));
     const float denom = (float)((double)(sqrtf(v) / bc2_sqrt) + eps);
     p -= step_size * m / denom;
-    g = 0.f;
   };
 #pragma unroll
   for (int ps = 0; ps < 4; ++ps) {
@@ -64,7 +64,8 @@ __global__ __launch_bounds__(256) void adamw_pack_kernel(const tr_adamw_item* __
         float4 p4 = *reinterpret_cast<const float4*>(P + o), g4 = *reinterpret_cast<const float4*>(Gd + o);
         float4 m4 = *reinterpret_cast<const float4*>(Mo + o), v4 = *reinterpret_cast<const float4*>(Vo + o);
         upd(p4.x, g4.x, m4.x, v4.x); upd(p4.y, g4.y, m4.y, v4.y); upd(p4.z, g4.z, m4.z, v4.z); upd(p4.w, g4.w, m4.w, v4.w);
-        *reinterpret_cast<float4*>(P + o) = p4; *reinterpret_cast<float4*>(Gd + o) = g4;
+        *reinterpret_cast<float4*>(P + o) = p4;
+        if (ZERO) *reinterpret_cast<float4*>(Gd + o) = make_float4(0.f, 0.f, 0.f, 0.f);
         *reinterpret_cast<float4*>(Mo + o) = m4; *reinterpret_cast<float4*>(Vo + o) = v4;
         pv[0] = p4.x; pv[1] = p4.y; pv[2] = p4.z; pv[3] = p4.w;
       } else {
@@ -73,7 +74,8 @@ __global__ __launch_bounds__(256) void adamw_pack_kernel(const tr_adamw_item* __
           if (c + e < I.cols) {
             float p = P[o + e], g = Gd[o + e], m = Mo[o + e], v = Vo[o + e];
             upd(p, g, m, v);
-            P[o + e] = p; Gd[o + e] = g; Mo[o + e] = m; Vo[o + e] = v;
+            P[o + e] = p; Mo[o + e] = m; Vo[o + e] = v;
+            if (ZERO) Gd[o + e] = 0.f;
             pv[e] = p;
           }
       }
@@ -119,14 +121,19 @@ __global__ __launch_bounds__(256) void adamw_pack_kernel(const tr_adamw_item* __
 }  // namespace
 
 extern "C" int tr_adamw_step(const tr_adamw_item* items, const int* first, int n_items, int total_tiles, double beta1, double beta2, double eps,
-                             float bias_correction1, float bias_correction2_sqrt, const double* lr8, const double* wd8, tr_stream_t s) {
+                             float bias_correction1, float bias_correction2_sqrt, const double* lr8, const double* wd8, int zero_grads,
+                             tr_stream_t s) {
   TR_REQUIRE(items && first && lr8 && wd8, TR_ERR_NULL, "tr_adamw_step: null pointer");
   TR_REQUIRE(n_items > 0 && total_tiles > 0, TR_ERR_SHAPE, "tr_adamw_step: nothing to update (n_items=%d tiles=%d)", n_items, total_tiles);
   TR_REQUIRE(bias_correction1 > 0.f && bias_correction2_sqrt > 0.f, TR_ERR_SHAPE, "tr_adamw_step: bias corrections must be positive");
   adamw_groups G;
   for (int i = 0; i < 8; ++i) { G.lr[i] = lr8[i]; G.wd[i] = wd8[i]; }
-  hipLaunchKernelGGL(adamw_pack_kernel, dim3((unsigned)total_tiles), dim3(256), 0, static_cast<hipStream_t>(s), items, first, n_items, beta1, beta2,
-                     eps, bias_correction1, bias_correction2_sqrt, G);
+  if (zero_grads)
+    hipLaunchKernelGGL(adamw_pack_kernel<true>, dim3((unsigned)total_tiles), dim3(256), 0, static_cast<hipStream_t>(s), items, first, n_items, beta1,
+                       beta2, eps, bias_correction1, bias_correction2_sqrt, G);
+  else
+    hipLaunchKernelGGL(adamw_pack_kernel<false>, dim3((unsigned)total_tiles), dim3(256), 0, static_cast<hipStream_t>(s), items, first, n_items, beta1,
+                       beta2, eps, bias_correction1, bias_correction2_sqrt, G);
   TR_CHECK_LAUNCH("tr_adamw_step");
   return TR_OK;
 }

@@ -58,7 +58,9 @@ struct QProblem {
   float* bpart;           // [S][N] or nullptr
   long ldy, ldx;
   int M, N, K, nKt, tiles, S, sps, u0;      // u0: first unit of this problem; units u0 + split * tiles + tile (split-major: the workgroups of
-};                                          // one round share their dY / X slabs in L2), tile = nt * nKt + kt
+                                            // one round share their dY / X slabs in L2), tile = nt * nKt + kt
+  int yskip;                                // > 0: dY holds one extra leading row per `yskip` rows (the CLS row of [B, P + 1, D] when the
+};                                          // layer saw only the P patch rows: PatchEmbed): row m of the product is dY row m + m / yskip + 1
 struct QGroup {
   QProblem p[4];          // unused entries: u0 = INT_MAX
   int n, U;
@@ -102,6 +104,7 @@ __global__ __launch_bounds__(768, 3) void wgrad_pc_kernel(const QProblem q0, con
     const uint16_t* Y = nullptr;
     const uint16_t* X = nullptr;
     long ldy = 0, ldx = 0;
+    int yskip = 0;
     auto set_unit = [&](int u) __attribute__((always_inline)) {
       const int uu = toff + u * G;
       const int pi = __builtin_amdgcn_readfirstlane(QPROB(uu));
@@ -116,6 +119,7 @@ __global__ __launch_bounds__(768, 3) void wgrad_pc_kernel(const QProblem q0, con
       X = QSEL(pi, X);
       ldy = QSEL(pi, ldy);
       ldx = QSEL(pi, ldx);
+      yskip = QSEL(pi, yskip);
     };
     const unsigned char* zline = reinterpret_cast<const unsigned char*>(g_zero_line);
     auto issue_group = [&]() __attribute__((always_inline)) {
@@ -128,7 +132,8 @@ __global__ __launch_bounds__(768, 3) void wgrad_pc_kernel(const QProblem q0, con
         const int lch = pc ^ (2 * (((prow >> 1) & 1) | (jj << 1)));      // bit1(row) = bit1(prow), bit3(row) = jj  (16 lw is a multiple of 16)
         const bool in = real && tok < M;
         const size_t ty = (size_t)min(tok, M - 1);
-        const unsigned char* ys = reinterpret_cast<const unsigned char*>(Y + ty * (size_t)ldy + n0 + lch * 8);
+        const size_t tyy = yskip > 0 ? ty + ty / (size_t)yskip + 1 : ty;
+        const unsigned char* ys = reinterpret_cast<const unsigned char*>(Y + tyy * (size_t)ldy + n0 + lch * 8);
         const unsigned char* xs = reinterpret_cast<const unsigned char*>(X + ty * (size_t)ldx + k0 + lch * 8);
 #pragma unroll
         for (int h = 0; h < 3; ++h) dma_piece(in ? ys + 128 * h : zline, dst + h * Q_IMG + jj * 1024);
@@ -328,13 +333,14 @@ void plan_group(QGroup* g) {
 void fill_problem(QProblem* q, const uint16_t* dY, long ldy, const uint16_t* X, long ldx, int M, int N, int K) {
   q->Y = dY; q->X = X; q->part = nullptr; q->bpart = nullptr; q->ldy = ldy; q->ldx = ldx;
   q->M = M; q->N = N; q->K = K; q->nKt = K / QT; q->tiles = (N / QT) * (K / QT); q->S = q->sps = q->u0 = 0;
+  q->yskip = 0;
 }
 
 }  // namespace
 
-// Shapes the producer/consumer kernel takes (everything else stays on wgrad_kernel): both dimensions multiples of 192, plain row layout.
+// Shapes the producer/consumer kernel takes (everything else stays on wgrad_kernel): both dimensions multiples of 192.
 bool tr_wgrad_pc_fits(int M, int N, int K, long ldy, long ldx, int yskip) {
-  return yskip == 0 && N % QT == 0 && K % QT == 0 && ldy % 8 == 0 && ldx % 8 == 0 && M >= QM;
+  return yskip >= 0 && N % QT == 0 && K % QT == 0 && ldy % 8 == 0 && ldx % 8 == 0 && M >= QM;
 }
 
 // Split count a single problem would get (workspace sizing: part[S][N][K] + bpart[S][N]).
@@ -364,11 +370,12 @@ static void pad_group(QGroup* g) {
 
 // Launch of one problem; returns the number of splits written (part[S][N][K], bpart[S][N] when bpart != nullptr).  S_max: what the
 // workspace holds.
-int tr_wgrad_pc_launch(const uint16_t* dY, long ldy, const uint16_t* X, long ldx, float* part, float* bpart, int M, int N, int K, int S_max,
-                       hipStream_t st) {
+int tr_wgrad_pc_launch(const uint16_t* dY, long ldy, int yskip, const uint16_t* X, long ldx, float* part, float* bpart, int M, int N, int K,
+                       int S_max, hipStream_t st) {
   QGroup g;
   g.n = 1;
   fill_problem(&g.p[0], dY, ldy, X, ldx, M, N, K);
+  g.p[0].yskip = yskip;
   plan_group(&g);
   QProblem& q = g.p[0];
   if (q.S > S_max) {
@@ -387,19 +394,24 @@ int tr_wgrad_pc_launch(const uint16_t* dY, long ldy, const uint16_t* X, long ldx
 
 // Launch of n <= 4 problems (weight + bias partials of all); ws must hold sum_i S_i (N_i K_i + N_i) floats for the split counts of
 // tr_wgrad_pc_group_splits.  Layout: part_0 .. part_{n-1}, bpart_0 .. bpart_{n-1}.
-void tr_wgrad_pc_group_launch(const uint16_t* const* dY, const long* ldy, const uint16_t* const* X, const long* ldx, const int (*mnk)[3], int n,
-                              float* ws, int* S, float** part, float** bpart, hipStream_t st) {
+// direct_w / direct_b (nullable): the final destinations.  When EVERY problem runs as one token range (S = 1: the late, short stages) the
+// "partials" are the results: they are stored straight to the destinations and the function returns true -- no reduce launch, no 2 x 28 MB
+// round trip per DeiT-B block.  Only for overwriting callers (a partial store does not add).
+bool tr_wgrad_pc_group_launch(const uint16_t* const* dY, const long* ldy, const uint16_t* const* X, const long* ldx, const int (*mnk)[3], int n,
+                              float* ws, int* S, float** part, float** bpart, float* const* direct_w, float* const* direct_b, hipStream_t st) {
   QGroup g;
   g.n = n;
   for (int i = 0; i < n; ++i) fill_problem(&g.p[i], dY[i], ldy[i], X[i], ldx[i], mnk[i][0], mnk[i][1], mnk[i][2]);
   plan_group(&g);
+  bool direct = direct_w != nullptr && direct_b != nullptr;
+  for (int i = 0; i < n; ++i) direct = direct && g.p[i].S == 1;
   float* at = ws;
   for (int i = 0; i < n; ++i) {
-    g.p[i].part = at;
+    g.p[i].part = direct ? direct_w[i] : at;
     at += (size_t)g.p[i].S * g.p[i].N * g.p[i].K;
   }
   for (int i = 0; i < n; ++i) {
-    g.p[i].bpart = at;
+    g.p[i].bpart = direct ? direct_b[i] : at;
     at += (size_t)g.p[i].S * g.p[i].N;
   }
   for (int i = 0; i < n; ++i) {
@@ -409,4 +421,5 @@ void tr_wgrad_pc_group_launch(const uint16_t* const* dY, const long* ldy, const 
   }
   pad_group(&g);
   hipLaunchKernelGGL(wgrad_pc_kernel<true>, dim3(256), dim3(768), 0, st, g.p[0], g.p[1], g.p[2], g.p[3], g.U);
+  return direct;
 }

@@ -434,8 +434,10 @@ def wgrad(dy: torch.Tensor, x: torch.Tensor, out: torch.Tensor = None, accumulat
     return out
 
 
-def linear_bwd_params(dy: torch.Tensor, x: torch.Tensor, accumulate: bool = False, dw: torch.Tensor = None, db: torch.Tensor = None):
-    """Weight and bias gradient of an nn.Linear in one pass (tr_linear_bwd_params): (dW fp32 [N,K], db fp32 [N])."""
+def linear_bwd_params(dy: torch.Tensor, x: torch.Tensor, accumulate: bool = False, dw: torch.Tensor = None, db: torch.Tensor = None,
+                      yskip: int = 0):
+    """Weight and bias gradient of an nn.Linear in one pass (tr_linear_bwd_params): (dW fp32 [N,K], db fp32 [N]).  yskip > 0: dy holds one
+    extra leading row per `yskip` rows (the CLS row of [B, P + 1, D]) that the layer never saw (PatchEmbed)."""
     M, N, K = x.shape[0], dy.shape[-1], x.shape[-1]
     lib = _lib.load()
     dw = torch.empty(N, K, dtype=torch.float32, device=x.device) if dw is None else dw
@@ -447,7 +449,7 @@ def linear_bwd_params(dy: torch.Tensor, x: torch.Tensor, accumulate: bool = Fals
             return t.data_ptr(), t.stride(0)
         return _dev(t, torch.bfloat16, name), t.shape[-1]
     (py, ldy), (px, ldx) = rows(dy, "dy"), rows(x, "x")
-    _lib.check(lib.tr_linear_bwd_params(py, ldy, 0, px, ldx, _dev(dw, torch.float32, "dw"),
+    _lib.check(lib.tr_linear_bwd_params(py, ldy, yskip, px, ldx, _dev(dw, torch.float32, "dw"),
                                         _dev(db, torch.float32, "db"), int(accumulate), ws.data_ptr(), ws.numel(), M, N, K, _stream()),
                "tr_linear_bwd_params")
     return dw, db

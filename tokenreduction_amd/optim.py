@@ -7,7 +7,8 @@ The reference builds `torch.optim.AdamW` (optim.py:102-140 through timm's factor
 
   * applies torch's fused-AdamW arithmetic, expression by expression (parameters stay bit-identical to
     `torch.optim.AdamW(fused=True)`: tests/test_hip_train.py),
-  * zeroes the gradient it consumed (the flat gradient buffer of training.TrainState stays clean, `zero_grad()` has nothing to do),
+  * optionally (`zero_grads=True`) zeroes the gradient it consumed -- not needed for training.TrainState, whose backward overwrites
+    the flat gradient buffer after `zero_grad(set_to_none=True)`,
   * rewrites the bf16 operand copy and the transposed copy of every matrix the executor reads, when constructed with `model=` -- the
     next forward then finds its operands fresh and skips tr_cast_pack_bf16.
 
@@ -28,11 +29,12 @@ _ITEM = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("dst"
 
 
 class FusedAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False, *, maximize=False, model=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, amsgrad=False, *, maximize=False, model=None, zero_grads=False):
         if amsgrad or maximize:
             raise NotImplementedError("FusedAdamW: amsgrad / maximize are not built")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._model = model
+        self._zero_grads = bool(zero_grads)
         self._table = None
 
     # ---- state: exp_avg / exp_avg_sq of all parameters in two flat buffers (views per parameter, like the gradients)
@@ -121,7 +123,8 @@ class FusedAdamW(torch.optim.Optimizer):
         wd8 = (C.c_double * 8)(*([float(g["weight_decay"]) for g in self.param_groups] + [0.0] * (8 - len(self.param_groups))))
         with torch.cuda.device(dev):
             _lib.check(_lib.load().tr_adamw_step(tab["items"].data_ptr(), tab["first"].data_ptr(), tab["n"], tab["tiles"], float(beta1), float(beta2),
-                                                 float(eps), bc1, bc2_sqrt, lr8, wd8, torch.cuda.current_stream().cuda_stream), "tr_adamw_step")
+                                                 float(eps), bc1, bc2_sqrt, lr8, wd8, 1 if self._zero_grads else 0,
+                                                 torch.cuda.current_stream().cuda_stream), "tr_adamw_step")
         for p in tab["params"]:
             self.state[p]["step"] = step
         m = self._model
@@ -130,14 +133,10 @@ class FusedAdamW(torch.optim.Optimizer):
                 m._weights_dirty = False          # every operand copy was rewritten by the step; fp32 operands are read in place
             else:
                 m.weights_changed()
-            st = m.__dict__.get("_tstate")
-            if st is not None:                    # the step zeroed every gradient it read: clean if that was the whole flat buffer
-                seen = {k[1] for k in tab["key"]}
-                st.flat_clean = all(st.views[n].data_ptr() in seen for n, _p in st.order)
         return loss
 
     def zero_grad(self, set_to_none: bool = True):
-        """The step already zeroed the gradients; with set_to_none (torch's default) the views are dropped as usual."""
+        """With set_to_none (torch's default) the views are dropped: the next backward of training.TrainState overwrites them."""
         if set_to_none:
             for g in self.param_groups:
                 for p in g["params"]:

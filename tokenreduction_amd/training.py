@@ -304,16 +304,15 @@ class _VitTrainFn(torch.autograd.Function):
             if ctx.distill and dextra[ctx.n_pred] is not None:
                 dfeat = torch.zeros(B, P + 1, model.embed_dim, dtype=torch.float32, device=dev)
                 dfeat[:, 1:] = dextra[ctx.n_pred].detach()
-        # gradient views: zero the slices of parameters that hold no gradient yet (zero_grad(set_to_none=True) is torch's
-        # default), keep accumulating into the others (engine.py:41-84: gradient accumulation over micro-steps)
+        # gradient views: when NO parameter holds a gradient yet (zero_grad(set_to_none=True), torch's default) the backward OVERWRITES
+        # the flat buffer -- nothing to clear, nothing to read back; otherwise the slices of the parameters without a gradient are zeroed
+        # and the backward accumulates (engine.py:41-84: gradient accumulation over micro-steps).  Every parameter of the executor is
+        # written exactly once per backward (csrc/tr_train.hip); parameters the executor does not touch keep the zeros they were born with.
         fresh = [n for n, p in st.order if p.grad is None or p.grad.data_ptr() != st.views[n].data_ptr()]
-        if len(fresh) == len(st.order):
-            if not getattr(st, "flat_clean", False):     # optim.FusedAdamW zeroes what it consumes: nothing to clear behind it
-                st.flat.zero_()
-        else:
+        accumulate = 0 if len(fresh) == len(st.order) else 1
+        if accumulate:
             for n in fresh:
                 st.views[n].zero_()
-        st.flat_clean = False
         G = st.grads_struct(model)
         WT = st.transposed(model, pk)
         reducer = getattr(model, "_grad_reducer", None)
@@ -328,7 +327,7 @@ class _VitTrainFn(torch.autograd.Function):
             for hi, lo, start, stop in ranges:
                 rc = lib.tr_vit_backward(C.byref(pk["cfg"]), C.byref(pk["W"]), C.byref(WT), C.byref(G), dl.data_ptr(),
                                          None if dpred is None else dpred.data_ptr(), None if dfeat is None else dfeat.data_ptr(),
-                                         None if ctx.drop is None else ctx.drop.data_ptr(), st.tape.data_ptr(), st.tape.numel(), st.bws.data_ptr(), st.bws.numel(), 1, hi, lo, B, stream,
+                                         None if ctx.drop is None else ctx.drop.data_ptr(), st.tape.data_ptr(), st.tape.numel(), st.bws.data_ptr(), st.bws.numel(), accumulate, hi, lo, B, stream,
                                          None if ctx.keep_mask is None else ctx.keep_mask.data_ptr(), float(model.drop_rate or 0.0))
                 _lib.check(rc, "tr_vit_backward")
                 if reduce_now:
