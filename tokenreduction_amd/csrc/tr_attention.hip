@@ -402,11 +402,9 @@ __global__ __launch_bounds__(A16_NT, (COLSUM || POLICY) ? 2 : 3) void attention1
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int li = lane & 15, g = lane >> 4;
-  // Query blocks are dealt round-robin to four SLOTS; 13 blocks (N = 197) make slot 0 a block longer than the others.  Wave w of every
-  // workgroup sits on SIMD w, so with slot = wave the three co-resident workgroups put 12 blocks on SIMD 0 and 9 on the others.  The slot
-  // is therefore rotated per workgroup -- by the position in the XCD's dispatch order and by the pass over its 32 CUs, which covers
-  // both a CU-round-robin and a CU-filling dispatcher: 10 / 10 / 10 / 9.  Results do not depend on the rotation (slot-indexed outputs).
-  const int wave = __builtin_amdgcn_readfirstlane(((tid >> 6) + (blockIdx.x >> 3) + (blockIdx.x >> 8)) & (A16_NW - 1));
+  // (round 4: rotating the query-block slots per workgroup -- so that the co-resident workgroups' 4-block waves do not meet on one SIMD --
+  // measured 40.3 vs 37.9 us at N = 197 on the same box: not kept, profiles/r04_lab.md)
+  const int wave = tid >> 6;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int ldq = 3 * H * 64;
   const uint16_t* base = qkv + (size_t)b * N * ldq;

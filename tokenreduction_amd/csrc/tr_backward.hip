@@ -309,6 +309,67 @@ __global__ __launch_bounds__(256) void partial_reduce2_tall_kernel(const float* 
   *reinterpret_cast<float4*>(dst + e) = a;
 }
 
+// The LayerNorm parameter gradients of a whole backward pass, reduced in ONE launch: every tr_layernorm_bwd of the pass leaves its
+// [grid][D] partials of d gamma and d beta in its own slice of a region and adds two segments here; the executor flushes after its
+// last block.  The per-call partial_reduce2_tall launch was 4.8 us x 24 per DeiT-B training step for a few hundred KB each.  Same block
+// layout and the same fixed summation order as partial_reduce2_tall_kernel, so the sums are bit-identical to the undeferred ones.
+constexpr int LN_DEFER_SEGS = 32;
+struct TallSegs {
+  const float* part[LN_DEFER_SEGS];
+  float* dst[LN_DEFER_SEGS];
+  int count[LN_DEFER_SEGS], S[LN_DEFER_SEGS], acc[LN_DEFER_SEGS];
+  int blk0[LN_DEFER_SEGS + 1];          // first block of segment i; blk0[n] = blocks in all
+};
+__global__ __launch_bounds__(256) void partial_reduce_tall_segs_kernel(const TallSegs T) {
+  __shared__ float4 red[15][16];
+  // static indices only (a dynamically indexed kernel argument is copied to scratch): walk the table with selects
+  const float* part = T.part[0];
+  float* dst = T.dst[0];
+  int count = T.count[0], S = T.S[0], accumulate = T.acc[0], b0 = 0;
+#pragma unroll
+  for (int i = 1; i < LN_DEFER_SEGS; ++i) {
+    const bool in = (int)blockIdx.x >= T.blk0[i];
+    part = in ? T.part[i] : part;
+    dst = in ? T.dst[i] : dst;
+    count = in ? T.count[i] : count;
+    S = in ? T.S[i] : S;
+    accumulate = in ? T.acc[i] : accumulate;
+    b0 = in ? T.blk0[i] : b0;
+  }
+  const int cx = threadIdx.x & 15, y = threadIdx.x >> 4;
+  const size_t e = ((size_t)(blockIdx.x - b0) * 16 + cx) * 4;
+  const bool ok = e + 4 <= (size_t)count;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (ok) {
+    int s = y;
+    for (; s + 48 < S; s += 64) {
+      const float4 v0 = *reinterpret_cast<const float4*>(part + (size_t)s * count + e);
+      const float4 v1 = *reinterpret_cast<const float4*>(part + (size_t)(s + 16) * count + e);
+      const float4 v2 = *reinterpret_cast<const float4*>(part + (size_t)(s + 32) * count + e);
+      const float4 v3 = *reinterpret_cast<const float4*>(part + (size_t)(s + 48) * count + e);
+      a.x += (v0.x + v1.x) + (v2.x + v3.x); a.y += (v0.y + v1.y) + (v2.y + v3.y);
+      a.z += (v0.z + v1.z) + (v2.z + v3.z); a.w += (v0.w + v1.w) + (v2.w + v3.w);
+    }
+    for (; s < S; s += 16) {
+      const float4 v = *reinterpret_cast<const float4*>(part + (size_t)s * count + e);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+  }
+  if (y > 0) red[y - 1][cx] = a;
+  __syncthreads();
+  if (y > 0 || !ok) return;
+#pragma unroll
+  for (int w = 0; w < 15; ++w) {
+    const float4 v = red[w][cx];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  if (accumulate) {
+    const float4 d = *reinterpret_cast<const float4*>(dst + e);
+    a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+  }
+  *reinterpret_cast<float4*>(dst + e) = a;
+}
+
 // the same for up to EIGHT results with their own partial counts (the weight and bias gradients of up to four Linear layers whose weight
 // gradients ran as one launch): block ranges [0, nb0), [nb0, nb0 + nb1), ...; counts are multiples of 4; unused segments have nb = 0
 struct RSeg {
@@ -1188,6 +1249,50 @@ static inline int ln_bwd_grid(int M) {
 
 extern "C" size_t tr_layernorm_bwd_workspace_floats(int M, int D) { return (size_t)ln_bwd_grid(M) * 2 * D; }
 
+// ---- deferred reduction of the LayerNorm parameter gradients (see partial_reduce_tall_segs_kernel).  One context per host thread: the
+// backward executor opens it around its block loop; calls outside a context, calls whose partials do not fit the region, and calls with
+// few partials or long rows (which the tall layout does not serve) reduce at once as before.
+namespace {
+struct LnDefer {
+  float* region = nullptr;
+  size_t cap = 0, used = 0;
+  TallSegs T;
+  int n = 0;
+  hipStream_t st = nullptr;
+};
+thread_local LnDefer* g_ln_defer = nullptr;
+thread_local LnDefer g_ln_defer_store;
+}  // namespace
+
+int tr_ln_defer_flush() {
+  LnDefer* c = g_ln_defer;
+  if (c == nullptr || c->n == 0) return TR_OK;
+  const int blocks = c->T.blk0[c->n];
+  for (int i = c->n; i < LN_DEFER_SEGS; ++i) {          // unused entries never match a block
+    c->T.part[i] = c->T.part[0]; c->T.dst[i] = c->T.dst[0]; c->T.count[i] = 0; c->T.S[i] = 0; c->T.acc[i] = 0;
+    c->T.blk0[i] = 0x7fffffff;
+  }
+  c->T.blk0[LN_DEFER_SEGS] = blocks;
+  hipLaunchKernelGGL(partial_reduce_tall_segs_kernel, dim3(blocks), dim3(256), 0, c->st, c->T);
+  c->n = 0;
+  c->T.blk0[0] = 0;
+  TR_CHECK_LAUNCH("tr_layernorm_bwd (deferred reduce)");
+  return TR_OK;
+}
+void tr_ln_defer_begin(float* region, size_t floats, hipStream_t st) {
+  LnDefer* c = &g_ln_defer_store;
+  c->region = region; c->cap = floats; c->used = 0; c->n = 0; c->st = st;
+  c->T.blk0[0] = 0;
+  static const bool off = getenv("TR_LN_DEFER_OFF") != nullptr;       // lab switch: same-box A/B against the per-call reduce
+  g_ln_defer = (region != nullptr && floats > 0 && !off) ? c : nullptr;
+}
+void tr_ln_defer_end() { g_ln_defer = nullptr; }           // drops what was not flushed (error paths)
+
+#define TR_TRY_RC(call)             \
+  do {                              \
+    int rc__ = (call);              \
+    if (rc__ != TR_OK) return rc__; \
+  } while (0)
 static int layernorm_bwd_impl(const uint16_t* dy, const float* x, long ldx, const float* gamma, const float* g_in, long ldgi,
                               float* g_out, long ldgo, uint16_t* gb_out, const int32_t* idx, int K, int n_in, int n_out,
                               float* g_fused, float* dgamma, float* dbeta, int accumulate, float* ws, size_t ws_floats, int M, int D,
@@ -1204,6 +1309,14 @@ static int layernorm_bwd_impl(const uint16_t* dy, const float* x, long ldx, cons
                  tr_aligned16(ws) && tr_aligned16(g_fused),
              TR_ERR_ALIGN, "tr_layernorm_bwd: pointers must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(s);
+  LnDefer* dc = g_ln_defer;
+  const size_t need = (size_t)grid * 2 * D;
+  const bool defer = dc != nullptr && dc->st == st && grid >= 64 && D <= 4096 && dc->used + need <= dc->cap;
+  if (defer) {
+    if (dc->n + 2 > LN_DEFER_SEGS) TR_TRY_RC(tr_ln_defer_flush());
+    ws = dc->region + dc->used;
+    dc->used += need;
+  }
   tr_prof_note("ln_bwd_kernel", 0.0, (double)M * D * (2.0 + 4.0 + (g_in ? 4.0 : 0.0) + 4.0 + (gb_out ? 2.0 : 0.0)));
   if (scatter_add)
     TR_DISPATCH_NCH(D, hipLaunchKernelGGL((ln_bwd_kernel<NCH, true>), dim3(grid), dim3(256), 0, st, dy, x, ldx, gamma, g_in, ldgi, g_out, ldgo,
@@ -1212,6 +1325,19 @@ static int layernorm_bwd_impl(const uint16_t* dy, const float* x, long ldx, cons
     TR_DISPATCH_NCH(D, hipLaunchKernelGGL((ln_bwd_kernel<NCH, false>), dim3(grid), dim3(256), 0, st, dy, x, ldx, gamma, g_in, ldgi, g_out, ldgo, gb_out,
                                           idx, K, n_in, n_out, g_fused, ws, M, D, eps));
   TR_CHECK_LAUNCH("tr_layernorm_bwd");
+  if (defer) {
+    const int nb = (D / 4 + 15) / 16;
+    for (int k = 0; k < 2; ++k) {
+      const int i = dc->n++;
+      dc->T.part[i] = ws + (size_t)k * grid * D;
+      dc->T.dst[i] = k ? dbeta : dgamma;
+      dc->T.count[i] = D;
+      dc->T.S[i] = grid;
+      dc->T.acc[i] = accumulate;
+      dc->T.blk0[i + 1] = dc->T.blk0[i] + nb;
+    }
+    return TR_OK;
+  }
   reduce_partials2(ws, (size_t)D, dgamma, ws + (size_t)grid * D, (size_t)D, dbeta, grid, accumulate, st);
   TR_CHECK_LAUNCH("tr_layernorm_bwd (reduce)");
   return TR_OK;

@@ -14,11 +14,16 @@
 
 using trplan::align_up;
 
+// tr_backward.hip: deferred reduction of the LayerNorm parameter gradients (one launch per backward call instead of one per norm)
+void tr_ln_defer_begin(float* region, size_t floats, hipStream_t st);
+int tr_ln_defer_flush();
+void tr_ln_defer_end();
+
 namespace {
 
 struct BwdPlan {
-  size_t g0, g1, gb0, gb1, gb2, dxn, dqkv, dao, dh, zeros, wsf, dscore, gfused, invmap, dxcls, dl16, dpol, dprev, dpolpart, soft_dp, soft_ds, soft_s, attn_stats, total;
-  size_t wsf_floats;
+  size_t g0, g1, gb0, gb1, gb2, dxn, dqkv, dao, dh, zeros, wsf, dscore, gfused, invmap, dxcls, dl16, dpol, dprev, dpolpart, soft_dp, soft_ds, soft_s, attn_stats, lnpart, total;
+  size_t wsf_floats, lnpart_floats;
 };
 
 bool make_bwd_plan(const tr_vit_config* c, int B, const trplan::TokenPlan& t, BwdPlan* p) {
@@ -87,6 +92,9 @@ bool make_bwd_plan(const tr_vit_config* c, int B, const trplan::TokenPlan& t, Bw
     p->soft_ds = take(T * trplan::soft_ld64(soft_k) * 2);
     p->soft_s = take(T * D * 4);
   }
+  // the LayerNorm parameter-gradient partials of a whole pass (reduced by one launch at its end): two norms per block + one per stage
+  p->lnpart_floats = (size_t)(3 * c->depth + 2) * tr_layernorm_bwd_workspace_floats((int)T, (int)D);
+  p->lnpart = take(p->lnpart_floats * 4);
   p->total = o;
   return true;
 }
@@ -204,6 +212,10 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
   size_t drop_off[TR_MAX_DEPTH + 1];
   drop_off[0] = (size_t)B * t.N0 * D;
   for (int i = 0; i < cfg->depth; ++i) drop_off[i + 1] = drop_off[i] + (size_t)B * (trplan::proj_rows(cfg, t, i) * D + (size_t)t.n_mlp[i] * (Hd + D));
+  struct LnDeferScope {       // every norm of the block loop leaves its d gamma / d beta partials in bp.lnpart; one reduce launch after the loop
+    LnDeferScope(float* r, size_t n, hipStream_t st) { tr_ln_defer_begin(r, n, st); }
+    ~LnDeferScope() { tr_ln_defer_end(); }
+  } ln_scope(reinterpret_cast<float*>(ws + bp.lnpart), bp.lnpart_floats, st);
   for (int i = blk_hi; i >= blk_lo; --i) {
     const trplan::BlockTape& bt = tp.blk[i];
     const tr_block_weights* bw = &w->blocks[i];
@@ -440,6 +452,7 @@ extern "C" int tr_vit_backward(const tr_vit_config* cfg, const tr_vit_weights* w
       uint16_t* tb = gb; gb = gb_alt; gb_alt = tb;
     }
   }
+  TR_TRY(tr_ln_defer_flush());
   if (blk_lo > 0) return TR_OK;
   // ---- embedding (topk.py:181-186): g is d x0 [B, N0, D]
   if (dropout_keep != nullptr) {      // pos_drop (topk.py:186): on the stream gradient and on its bf16 copy (the patch projection's dY)
