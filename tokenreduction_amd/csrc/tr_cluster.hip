@@ -159,9 +159,12 @@ __global__ __launch_bounds__(512) void dist_mfma_kernel(const float* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int frow = lane & 15, fq = lane >> 4;
-  const int ntj = (P + GTN - 1) / GTN;
-  const int i0 = (blockIdx.x / ntj) * GT, j0 = (blockIdx.x % ntj) * GTN;
-  const int b = blockIdx.y;
+  const int ntj = (P + GTN - 1) / GTN, nt = ((P + GT - 1) / GT) * ntj;
+  // 1-D grid, XCD-aware: the tiles of one image read the same token rows (15 tiles at P = 576 read them 10 x), so an image's tiles go to
+  // ONE XCD and its L2 serves the re-reads (r04a at 384^2: 299 MB per launch against 80 MB algorithmic with the tiles dealt round-robin)
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int b = lid / nt, tile = lid - b * nt;
+  const int i0 = (tile / ntj) * GT, j0 = (tile % ntj) * GTN;
   const float* xb = x + ((size_t)b * N + 1) * D;
   const int lr = tid >> 1, lc = (tid & 1) * 16;                      // A staging: row lr (0..255), 16 consecutive floats
   const int br = tid >> 2, bc = (tid & 3) * 8;                       // B staging: row br (0..127), 8 consecutive floats
@@ -578,7 +581,7 @@ static void launch_dist(bool fast, const float* x, const float* nrm, float* dist
     hipLaunchKernelGGL(dist_kernel<true>, dim3(nt * nt, B), dim3(256), 0, st, x, nrm, dist, N, D, sqrt_d);
   } else if (fast && D % GK == 0) {
     const int nti = (P + GT - 1) / GT, ntj = (P + GTN - 1) / GTN;
-    hipLaunchKernelGGL(dist_mfma_kernel, dim3(nti * ntj, B), dim3(512), 0, st, x, nrm, dist, N, D, sqrt_d);
+    hipLaunchKernelGGL(dist_mfma_kernel, dim3(nti * ntj * B), dim3(512), 0, st, x, nrm, dist, N, D, sqrt_d);
   } else {
     const int nt = (P + CT - 1) / CT;
     hipLaunchKernelGGL(dist_kernel<false>, dim3(nt * nt, B), dim3(256), 0, st, x, nrm, dist, N, D, sqrt_d);
