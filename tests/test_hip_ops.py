@@ -636,7 +636,8 @@ def test_rownorm(ops):
 
 
 @pytest.mark.parametrize("B,N,K,ldl,iters", [(3, 197, 137, 144, 3), (2, 138, 96, 96, 3), (2, 97, 67, 72, 5), (1, 9, 3, 8, 1), (1, 30, 7, 8, 0),
-                                             (2, 577, 144, 144, 3), (1, 401, 250, 256, 2), (1, 577, 100, 104, 0)])   # K*P beyond the LDS: Z stays in global memory
+                                             (2, 577, 144, 144, 3), (1, 401, 250, 256, 2), (1, 577, 100, 104, 0),      # K*P beyond the LDS: Z stays in global memory ...
+                                             (3, 577, 192, 192, 2), (2, 577, 71, 72, 3), (2, 577, 193, 200, 1)])      # ... or, 576 tokens x <= 192 centres, in registers
 def test_sinkhorn(ops, B, N, K, ldl, iters):
     rng = _rng(40 + N)
     scores = _randn(rng, B, N, ldl, scale=0.5).clamp(-1, 1)

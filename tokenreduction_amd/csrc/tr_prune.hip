@@ -536,6 +536,165 @@ __global__ __launch_bounds__(SGT) void sinkhorn_global_kernel(const float* __res
   }
 }
 
+// The same iterations with the transport plan in REGISTERS (round 4): 384 x 384 inputs at keep_rate 0.25 have K = 144 centres x P = 576
+// tokens = 332 KB per image -- twice the LDS, but 8 waves x 64 lanes x 216 registers hold it.  sinkhorn_global_kernel above re-reads
+// the plan from L2 in every half-iteration (4 passes per iteration, 248 us at B = 64: 5.6 % of the DeiT-B 384^2 forward for one launch).
+// Wave w owns the RPW token rows p = w * RPW + r; a lane holds centre columns lane + 64 c (c < KC) of each: Z is read ONCE, pre-scaled
+// by 1 / eps.  u-step: each lane reduces its columns over the wave's rows, the 8 wave partials meet in LDS (fixed order);
+// v-step: a token row is spread over one wave -- row-wide max and sum by DPP + v_permlane swaps (full-rate VALU; 2 x RPW ds_bpermute
+// reductions per half-iteration would queue on the LDS pipe).  Same max-then-sum formulation as the other two kernels; the v-step's
+// arithmetic is theirs, the u-step's partial order differs (8 row ranges instead of 1024 / ceil64(K) segments): last-bit differences.
+__device__ __forceinline__ float wave_max_valu(float v) {
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)));
+  const auto a = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  const unsigned a0 = a[0], a1 = a[1];
+  v = fmaxf(__builtin_bit_cast(float, a0), __builtin_bit_cast(float, a1));
+  const auto c = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  const unsigned c0 = c[0], c1 = c[1];
+  return fmaxf(__builtin_bit_cast(float, c0), __builtin_bit_cast(float, c1));
+}
+__device__ __forceinline__ float wave_sum_valu(float v) {
+  v = row16_sum(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  const unsigned a0 = a[0], a1 = a[1];
+  v = __builtin_bit_cast(float, a0) + __builtin_bit_cast(float, a1);
+  const auto c = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+  const unsigned c0 = c[0], c1 = c[1];
+  return __builtin_bit_cast(float, c0) + __builtin_bit_cast(float, c1);
+}
+#ifndef TR_SR_RPW
+#define TR_SR_RPW 72
+#endif
+constexpr int SR_NW = 8, SR_RPW = TR_SR_RPW, SR_KC = 3;           // 8 waves x 72 rows = 576 tokens, 3 x 64 = 192 centres: 216 plan registers per lane
+                                                            // (two waves per SIMD: 256 registers each; 12 x 48 spilled 57 of its 168)
+__global__ __launch_bounds__(64 * SR_NW) void sinkhorn_regs_kernel(const float* __restrict__ scores, int ldl, float eps, int iters,
+                                                                   float* __restrict__ wt, float* __restrict__ soft, int N, int K) {
+  constexpr int KW = 64 * SR_KC;
+  __shared__ float s_u[KW], s_v[SR_NW * SR_RPW], s_part[SR_NW][KW];
+  const int P = N - 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x;
+  const float* sc = scores + ((size_t)b * N + 1) * ldl;
+  // everything in the log2 domain (Z / eps, u, v and the normaliser times log2(e)): exp and log are then ONE transcendental instruction
+  // each (v_exp_f32 / v_log_f32) instead of libm's range-checked sequences -- the kernel is bound by VALU issue (1512 exponentials per lane)
+  constexpr float L2E = 1.44269504088896340736f;
+  const float inv_eps = L2E / eps;
+  const float norm = -__builtin_amdgcn_logf((float)K + (float)P);
+  const int p0 = __builtin_amdgcn_readfirstlane(wave * SR_RPW);
+  // Buffer addressing: the row offset is a SCALAR (soffset), the column a per-lane byte offset -- with flat addresses the compiler kept a
+  // 64-bit address pair per row and matrix alive (232 registers for 120 of plan).  The launcher sends exactly P = SR_NW * SR_RPW here (384 x 384 inputs).
+  const __amdgpu_buffer_rsrc_t zsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(sc), 0, (int)((size_t)P * ldl * 4), 0x00020000);
+  unsigned kof[SR_KC];
+#pragma unroll
+  for (int c = 0; c < SR_KC; ++c) kof[c] = 4u * (unsigned)min(lane + 64 * c, K - 1);
+  float z[SR_RPW][SR_KC];
+#pragma unroll
+  for (int r = 0; r < SR_RPW; ++r)
+#pragma unroll
+    for (int c = 0; c < SR_KC; ++c)
+      z[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zsrc, kof[c], (p0 + r) * ldl * 4, 0)) * inv_eps;
+  for (int i = tid; i < SR_NW * SR_RPW; i += 64 * SR_NW) s_v[i] = 0.f;
+  if (tid < KW) s_u[tid] = 0.f;
+  __syncthreads();
+  for (int it = 0; it < iters; ++it) {
+    // ---- u = log_mu - logsumexp_p(Z + v)
+    float m[SR_KC];
+#pragma unroll
+    for (int c = 0; c < SR_KC; ++c) m[c] = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < SR_RPW; ++r) {
+      const float vr = s_v[p0 + r];
+#pragma unroll
+      for (int c = 0; c < SR_KC; ++c) m[c] = fmaxf(m[c], z[r][c] + vr);
+      if ((r & 7) == 7) __builtin_amdgcn_sched_barrier(0);       // bounds what the scheduler hoists: the plan already fills the register file
+    }
+#pragma unroll
+    for (int c = 0; c < SR_KC; ++c) s_part[wave][lane + 64 * c] = m[c];
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < SR_KC; ++c) {
+      float mm = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < SR_NW; ++w) mm = fmaxf(mm, s_part[w][lane + 64 * c]);
+      m[c] = mm;
+    }
+    float t[SR_KC];
+#pragma unroll
+    for (int c = 0; c < SR_KC; ++c) t[c] = 0.f;
+#pragma unroll
+    for (int r = 0; r < SR_RPW; ++r) {
+      const float vr = s_v[p0 + r];
+#pragma unroll
+      for (int c = 0; c < SR_KC; ++c) t[c] += __builtin_amdgcn_exp2f(z[r][c] + vr - m[c]);
+      if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();                          // every wave has read the maxima: the partial buffer can take the sums
+#pragma unroll
+    for (int c = 0; c < SR_KC; ++c) s_part[wave][lane + 64 * c] = t[c];
+    __syncthreads();
+    if (tid < KW) {
+      float tt = 0.f;
+#pragma unroll
+      for (int w = 0; w < SR_NW; ++w) tt += s_part[w][tid];      // fixed order
+      float mk = -INFINITY;                                        // this thread's column is tid = lane + 64 * wave: its maximum again
+      mk = m[0];
+      if (wave == 1) mk = m[1];
+      if (wave == 2) mk = m[2];
+      s_u[tid] = norm - (mk + __builtin_amdgcn_logf(tt));
+    }
+    __syncthreads();
+    // ---- v = log_nu - logsumexp_k(Z + u): a token row is one wave's registers
+    float uk[SR_KC];
+#pragma unroll
+    for (int c = 0; c < SR_KC; ++c) uk[c] = (lane + 64 * c < K) ? s_u[lane + 64 * c] : -INFINITY;
+#pragma unroll
+    for (int r = 0; r < SR_RPW; ++r) {
+      float a[SR_KC], mm = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < SR_KC; ++c) {
+        a[c] = z[r][c] + uk[c];
+        mm = fmaxf(mm, a[c]);
+      }
+      mm = wave_max_valu(mm);
+      float ts = 0.f;
+#pragma unroll
+      for (int c = 0; c < SR_KC; ++c) ts += __builtin_amdgcn_exp2f(a[c] - mm);       // exp2(-inf) = 0 for the padding columns
+      ts = wave_sum_valu(ts);
+      if (lane == 0) s_v[p0 + r] = norm - (mm + __builtin_amdgcn_logf(ts));
+      if ((r & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+  // W = exp(Z + u + v - norm): token-major for the merge, cluster-major for Soft_Assignment_Maps
+  // stores through range-checked buffers: a column past K gets an offset beyond the buffer and is dropped
+  const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(wt + ((size_t)b * N + 1) * ldl, 0, (int)((size_t)P * ldl * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ssrc =
+      __builtin_amdgcn_make_buffer_rsrc(soft != nullptr ? soft + (size_t)b * K * P : wt, 0, soft != nullptr ? (int)((size_t)K * P * 4) : 0, 0x00020000);
+  float uk[SR_KC];
+  unsigned wof[SR_KC], sof[SR_KC];
+#pragma unroll
+  for (int c = 0; c < SR_KC; ++c) {
+    const int k = lane + 64 * c;
+    uk[c] = s_u[min(k, KW - 1)];
+    wof[c] = k < K ? 4u * (unsigned)k : 0x80000000u;
+    sof[c] = k < K ? 4u * (unsigned)k * (unsigned)P : 0x80000000u;
+  }
+#pragma unroll
+  for (int r = 0; r < SR_RPW; ++r) {
+    const float vr = s_v[p0 + r];
+#pragma unroll
+    for (int c = 0; c < SR_KC; ++c) {
+      const float w = __builtin_amdgcn_exp2f(z[r][c] + uk[c] + vr - norm);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, w), wsrc, wof[c], (p0 + r) * ldl * 4, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, w), ssrc, sof[c], (p0 + r) * 4, 0);
+    }
+    if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 }  // namespace
 
 extern "C" int tr_pool_broadcast(void* h, int is_f32, int B, int N, int C, float eps, tr_stream_t s) {
@@ -613,6 +772,12 @@ extern "C" int tr_sinkhorn(const float* scores, int ldl, float eps, int iters, f
   const size_t lds = ((size_t)K * (N - 1) + K + (N - 1)) * sizeof(float);
   hipStream_t st = static_cast<hipStream_t>(s);
   if (lds > 158 * 1024) {
+    static const bool regs_off = getenv("TR_SINKHORN_REGS_OFF") != nullptr;       // lab switch (same-box A/B)
+    if (!regs_off && K <= 64 * SR_KC && N - 1 == SR_NW * SR_RPW) {                   // the plan fits the register file of one CU
+      hipLaunchKernelGGL(sinkhorn_regs_kernel, dim3(B), dim3(64 * SR_NW), 0, st, scores, ldl, eps, iters, wt, soft, N, K);
+      TR_CHECK_LAUNCH("tr_sinkhorn");
+      return TR_OK;
+    }
     TR_REQUIRE(K <= SG_KMAX, TR_ERR_SHAPE, "tr_sinkhorn: K=%d > %d centres with K*P beyond the LDS is not supported", K, SG_KMAX);
     const int kw = (K + 63) & ~63;
     const size_t lds_g = ((size_t)K + (N - 1) + (size_t)(SGT / kw) * kw) * sizeof(float);

@@ -31,11 +31,13 @@ def mean(f, stages):
     return sum(f(n, k) for n, k in stages) / len(stages)
 
 
-def algorithmic(kernel, B, D, H, st):
+def algorithmic(kernel, B, D, H, st, wl=""):
     """Bytes per launch, or None when the kernel is not a reduction kernel of this table.  n = tokens entering the stage, k = leaving it
     (CLS included in both); patch tokens p = n - 1, clusters / kept patches c = k - 1."""
     K = kernel
     if K.startswith("cls_topk_kernel"):          # CLS attention rows [B,H,n] fp32 -> kept ids (+ the complement for EViT), int32
+        if "topk" not in wl and "evit" not in wl and wl != "headline":
+            return None                          # (the clustering families use it as a plain top-K over one score row per image)
         return mean(lambda n, k: B * (4 * H * n + 4 * (n - 1)), st)
     if K.startswith("gather_layernorm_kernel"):  # kept rows: x fp32 in + bf16 delta in, x fp32 out + bf16 y out
         return mean(lambda n, k: B * k * D * 12, st)
@@ -43,8 +45,8 @@ def algorithmic(kernel, B, D, H, st):
         return mean(lambda n, k: B * (4 * H * n + 2 * n * H * 64 + 8 * k), st)
     if K.startswith("ats_gather_kernel"):        # sampled rows of the stream (fp32) + of the attention output (bf16), in and out
         return mean(lambda n, k: B * k * D * (4 + 2) * 2, st)
-    if K.startswith("ats_scatter_kernel"):       # backward of the gather: sampled rows in, full-length rows out
-        return mean(lambda n, k: B * (k + n) * D * (4 + 2), st)
+    if K.startswith("ats_scatter_kernel"):       # backward of the gather: sampled rows in, the same rows out (the zero fill of the rest is a memset)
+        return mean(lambda n, k: B * 2 * k * D * (4 + 2), st)
     if K.startswith("dpcknn_fused_kernel"):      # patch tokens fp32 + noise in; assignment + centres out
         return mean(lambda n, k: B * ((n - 1) * D * 4 + 8 * (n - 1) + 4 * (k - 1)), st)
     if K.startswith("sqnorm"):
@@ -71,7 +73,7 @@ def algorithmic(kernel, B, D, H, st):
         return mean(lambda n, k: B * (4 * H * n + 4 * n), st)
     if K.startswith("attention_colsum_kernel"):  # 384^2 only: column sums of softmax(qk^T): q and k thirds of qkv in, [B,H,4,n] out
         return B * (2 * 2 * st[0][0] * H * 64 + 16 * H * st[0][0])
-    if K.startswith("sinkhorn_global_kernel"):   # the [B, p, c] assignment matrix, in and out (sinkhorn.py:41-62: normalised over the BATCH)
+    if K.startswith("sinkhorn_global_kernel") or K.startswith("sinkhorn_regs_kernel"):   # first stage at 384^2: the [p, c] scores in, the plan out
         return B * (st[0][0] - 1) * (st[0][1] - 1) * 8
     if K.startswith("sinkhorn_kernel"):
         return mean(lambda n, k: B * (n - 1) * (k - 1) * 8, st[1:])
@@ -97,7 +99,7 @@ def main():
         for k, v in json.load(open(f)).items():
             if k.startswith("_"):
                 continue
-            a = algorithmic(k, B, D, H, st)
+            a = algorithmic(k, B, D, H, st, w)
             if a is None:
                 continue
             m = v["hbm_bytes_per_launch"]
