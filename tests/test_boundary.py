@@ -150,6 +150,32 @@ def test_argument_validation_without_gpu():
         cfg.keep[i] = k
     want = 4 * 197 * 384 + sum(4 * (a * 384 + t * (1536 + 384)) for a, t in zip(n_att, n_mlp))
     assert lib.tr_vit_dropout_mask_bytes(ctypes.byref(cfg), 4) == want
+    # round-4 entry points
+    assert lib.tr_dpcknn_fused_supported(197, 384, 5) == 1 and lib.tr_dpcknn_fused_supported(197, 768, 5) == 1       # 224^2 inputs: the matrix fits the LDS
+    assert lib.tr_dpcknn_fused_supported(577, 768, 5) == 0 and lib.tr_dpcknn_fused_supported(197, 100, 5) == 0       # 384^2 inputs; a width that is no multiple of 32
+    z8 = (ctypes.c_double * 8)()
+    assert lib.tr_adamw_step(None, None, 1, 1, 0.9, 0.999, 1e-8, 0.1, 0.03, z8, z8, 0, None) == -3                    # null item table
+    assert lib.tr_adamw_step(p, p, 0, 0, 0.9, 0.999, 1e-8, 0.1, 0.03, z8, z8, 0, None) == -1                          # nothing to update
+    assert lib.tr_adamw_step(p, p, 1, 1, 0.9, 0.999, 1e-8, 0.0, 0.03, z8, z8, 0, None) == -1                          # bias correction 0: a step count of 0
+
+
+def test_fused_adamw_refuses_what_it_does_not_build():
+    """optim.FusedAdamW mirrors torch.optim.AdamW's constructor; the variants it has no kernel for raise at construction, and a CPU model
+    fails loudly at the first step (no CPU fallback)."""
+    import torch
+    from tokenreduction_amd.optim import FusedAdamW
+    w = torch.nn.Parameter(torch.zeros(4, 4))
+    with pytest.raises(NotImplementedError, match="amsgrad"):
+        FusedAdamW([w], amsgrad=True)
+    with pytest.raises(NotImplementedError, match="maximize"):
+        FusedAdamW([w], maximize=True)
+    opt = FusedAdamW([dict(params=[w], weight_decay=0.0)], lr=1e-3, betas=(0.9, 0.98))
+    assert opt.param_groups[0]["lr"] == 1e-3 and opt.param_groups[0]["betas"] == (0.9, 0.98) and opt.param_groups[0]["weight_decay"] == 0.0
+    assert opt.step() is None                                      # no gradients: nothing to do, nothing launched
+    w.grad = torch.ones_like(w)
+    with pytest.raises(Exception):                                 # CPU tensors: the launch is refused (invalid device pointer / no HIP device)
+        opt.step()
+    assert torch.equal(w.detach(), torch.zeros(4, 4))              # ... and nothing was updated on the host behind the library's back
 
 
 def test_finetune_ingest_matches_the_reference(golden_dir):

@@ -464,6 +464,42 @@ def test_one_launch_adamw_is_bit_identical_to_torch_fused_adamw(name):
     assert torch.equal(e_t, e_h)
 
 
+def test_one_launch_adamw_resumes_from_a_state_dict():
+    """train.py:373-383 resumes optimizers with load_state_dict: FusedAdamW carries torch's state layout (step, exp_avg, exp_avg_sq per
+    parameter), so three steps, a state_dict round trip into a NEW optimizer (tensor-valued steps included) and three more steps equal six
+    uninterrupted ones bit for bit -- and the state_dict loads into torch.optim.AdamW as well."""
+    from tokenreduction_amd.optim import FusedAdamW
+    case = GOLDEN_CASES["topk_micro"]
+    x = make_images(case["batch"], 224, case["xseed"]).cuda()
+    y = grad_labels(case).cuda()
+
+    def steps(model, opt, n):
+        for _ in range(n):
+            loss = torch.nn.functional.cross_entropy(model(x), y)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+
+    finals = []
+    for resume in (False, True):
+        model, _, _ = build_model(case)
+        model.viz_mode = False
+        model.train()
+        opt = FusedAdamW(model.parameters(), lr=1e-3, weight_decay=0.05, model=model)
+        steps(model, opt, 3)
+        if resume:
+            sd = opt.state_dict()
+            for st in sd["state"].values():
+                st["step"] = torch.tensor(float(st["step"]))                # what torch's fused AdamW checkpoints hold
+                st["exp_avg"], st["exp_avg_sq"] = st["exp_avg"].clone(), st["exp_avg_sq"].clone()
+            torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=0.05).load_state_dict(sd)     # same layout as torch's
+            opt = FusedAdamW(model.parameters(), lr=1e-3, weight_decay=0.05, model=model)
+            opt.load_state_dict(sd)
+        steps(model, opt, 3)
+        finals.append([p.detach().clone() for p in model.parameters()])
+    assert all(torch.equal(a, b) for a, b in zip(*finals))
+
+
 def test_fused_optimizer_steps_reach_the_executor():
     """torch's fused optimizers update parameters without bumping `_version`; the executor's operand copies must follow anyway (round 3:
     they did not -- AdamW(fused=True) trained on the initial bf16 matrices).  Fused and unfused AdamW from the same start must walk the

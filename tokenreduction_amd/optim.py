@@ -38,22 +38,21 @@ class FusedAdamW(torch.optim.Optimizer):
         self._table = None
 
     # ---- state: exp_avg / exp_avg_sq of all parameters in two flat buffers (views per parameter, like the gradients)
-    def _init_state(self):
-        ps = [p for g in self.param_groups for p in g["params"]]
+    def _init_state(self, ps):
         dev = ps[0].device
         offs, off = [], 0
         for p in ps:
             offs.append(off)
             off += (p.numel() + 63) // 64 * 64
-        self._m = torch.zeros(off, dtype=torch.float32, device=dev)
-        self._v = torch.zeros(off, dtype=torch.float32, device=dev)
+        m = torch.zeros(off, dtype=torch.float32, device=dev)
+        v = torch.zeros(off, dtype=torch.float32, device=dev)
         for p, o in zip(ps, offs):
             if p.dtype != torch.float32 or not p.is_contiguous():
                 raise NotImplementedError("FusedAdamW: fp32 contiguous parameters only")
             st = self.state[p]
             st["step"] = 0
-            st["exp_avg"] = self._m[o: o + p.numel()].view_as(p)
-            st["exp_avg_sq"] = self._v[o: o + p.numel()].view_as(p)
+            st["exp_avg"] = m[o: o + p.numel()].view_as(p)
+            st["exp_avg_sq"] = v[o: o + p.numel()].view_as(p)
 
     def _operand_slots(self):
         """{parameter storage address: (bf16 copy address, transposed copy address or 0)} of the model's packed matrices, if every bf16
@@ -76,10 +75,13 @@ class FusedAdamW(torch.optim.Optimizer):
                 if p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
                     raise NotImplementedError("FusedAdamW: fp32 contiguous gradients only")
                 st = self.state[p]
+                for k in ("exp_avg", "exp_avg_sq"):      # a loaded state_dict brings its own tensors: they are used where they are
+                    if st[k].dtype != torch.float32 or not st[k].is_contiguous() or st[k].device != p.device:
+                        raise NotImplementedError(f"FusedAdamW: optimizer state {k} must be fp32, contiguous and on the parameter's device")
                 rows, cols = (p.shape[0], p.numel() // p.shape[0]) if p.dim() >= 2 else (1, p.numel())
                 dst, dst_t = (slots or {}).get(p.data_ptr(), (0, 0))
                 items.append((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), dst, dst_t, rows, cols, gi, 0))
-                key.append((p.data_ptr(), p.grad.data_ptr(), dst, dst_t, gi))
+                key.append((p.data_ptr(), p.grad.data_ptr(), dst, dst_t, gi, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()))
         key = tuple(key)
         if self._table is not None and self._table["key"] == key:
             return self._table
@@ -98,8 +100,9 @@ class FusedAdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        if not self.state:
-            self._init_state()
+        fresh = [p for g in self.param_groups for p in g["params"] if "exp_avg" not in self.state[p]]
+        if fresh:                                 # first step, or a group added since (add_param_group): their moments start at zero
+            self._init_state(fresh)
         if len(self.param_groups) > 8:
             raise NotImplementedError("FusedAdamW: at most 8 parameter groups")
         betas = {g["betas"] for g in self.param_groups}
@@ -112,7 +115,7 @@ class FusedAdamW(torch.optim.Optimizer):
             return loss
         dev = ps[0].device
         tab = self._build(dev)
-        steps = {self.state[p]["step"] for p in tab["params"]}
+        steps = {int(self.state[p]["step"]) for p in tab["params"]}          # (a loaded state_dict may carry tensors here)
         if len(steps) != 1:
             raise NotImplementedError("FusedAdamW: parameters whose step counts differ (a parameter that had no gradient in some steps)")
         step = next(iter(steps)) + 1
