@@ -9,7 +9,7 @@
 //                             pending residual add (x + attn.proj output, tome.py:84) in front and norm2 (tome.py:101) behind,
 //                             in ONE pass.  Sources are added to their destination in edge order (= the order torch's CPU
 //                             scatter_add applies them), so the fp32 path reproduces the reference's rounding.
-// HBM traffic is the algorithmic minimum: match reads the K third of qkv once (2*N*H*64 B per image, bf16) and writes
+// HBM traffic is the algorithmic minimum (and the matching kernel's first phase runs at 4.4 TB/s on it): match reads the K third of qkv once (2*N*H*64 B per image, bf16) and writes
 // 4*(na + r) B of indices; merge reads each input row once and writes each output row once.
 #include "tr_common.h"
 #include "tr_rowops.h"
@@ -24,6 +24,22 @@ __device__ __forceinline__ unsigned long long score_key(float v, int j) {
   unsigned int u = __float_as_uint(v);
   u ^= (u >> 31) ? 0xffffffffu : 0x80000000u;
   return ((unsigned long long)u << 32) | (unsigned long long)(0xffffffffu - (unsigned int)j);
+}
+
+// sum over heads of one 8-wide bf16 chunk of K (head stride 64 elements): NH loads in flight, added in head order
+template <int NH>
+__device__ __forceinline__ void head_sum_bf16(const uint16_t* kp, int H, float* m) {
+  uint4 u[NH];
+#pragma unroll
+  for (int h = 0; h < NH; ++h) u[h] = *reinterpret_cast<const uint4*>(kp + min(h, H - 1) * 64);
+#pragma unroll
+  for (int h = 0; h < NH; ++h)
+    if (h < H) {
+      m[0] += __uint_as_float(u[h].x << 16); m[1] += __uint_as_float(u[h].x & 0xffff0000u);
+      m[2] += __uint_as_float(u[h].y << 16); m[3] += __uint_as_float(u[h].y & 0xffff0000u);
+      m[4] += __uint_as_float(u[h].z << 16); m[5] += __uint_as_float(u[h].z & 0xffff0000u);
+      m[6] += __uint_as_float(u[h].w << 16); m[7] += __uint_as_float(u[h].w & 0xffff0000u);
+    }
 }
 
 constexpr int TMT = 1024;   // 16 waves per image: the kernel is a chain of short latency-bound phases, one workgroup per CU
@@ -50,17 +66,10 @@ __global__ __launch_bounds__(TMT) void tome_match_kernel(const void* __restrict_
     if (!F32 && H <= 12) {
       // all heads' chunks are requested before the first add (head index clamped: branch-free); summed in head order as before.
       // As a rolled loop over H this was H dependent global round trips per item, half of the kernel's time at N = 197.
-      uint4 u[12];
-#pragma unroll
-      for (int h = 0; h < 12; ++h) u[h] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(qkv) + e0 + min(h, H - 1) * 64);
-#pragma unroll
-      for (int h = 0; h < 12; ++h)
-        if (h < H) {
-          m[0] += __uint_as_float(u[h].x << 16); m[1] += __uint_as_float(u[h].x & 0xffff0000u);
-          m[2] += __uint_as_float(u[h].y << 16); m[3] += __uint_as_float(u[h].y & 0xffff0000u);
-          m[4] += __uint_as_float(u[h].z << 16); m[5] += __uint_as_float(u[h].z & 0xffff0000u);
-          m[6] += __uint_as_float(u[h].w << 16); m[7] += __uint_as_float(u[h].w & 0xffff0000u);
-        }
+      // (Six loads when the model has at most six heads: DeiT-S; twelve otherwise.)
+      const uint16_t* kp = reinterpret_cast<const uint16_t*>(qkv) + e0;
+      if (H <= 6) head_sum_bf16<6>(kp, H, m);
+      else head_sum_bf16<12>(kp, H, m);
     } else
     for (int h = 0; h < H; ++h) {
       if (F32) {
@@ -102,89 +111,151 @@ __global__ __launch_bounds__(TMT) void tome_match_kernel(const void* __restrict_
   }
   for (int i = tid; i < na; i += TMT) s_key[i] = score_key(-INFINITY, 0);    // row 0 (CLS) stays -inf: never merged (tome.py:259)
   __syncthreads();
+  if (!F32) {
+    // scores[i][j] = a_i . b_j (a = even tokens, b = odd tokens) on the matrix cores with FP32 OPERANDS (v_mfma_f32_16x16x4_f32: exact
+    // fp32 products, fp32 accumulation -- the precision class of the fmaf chain it replaces, NOT a bf16 product): one 16 x 16 tile of the
+    // score matrix per wave and step, 16 MFMAs over the 64 metric columns, 32 LDS reads per tile.  (Round 4.  The 4 x 4 register tiles on
+    // the VALU read 8 floats from LDS per 16 FMAs: 1.3 MB of LDS traffic per image, ~10 k cycles with the 2-way conflicts of the row
+    // stride -- the longest phase of the kernel at N = 197.)  Row max / argmax: the 16 lanes that hold a row's columns reduce an
+    // order-preserving (score, lowest j) key with DPP, one ds_max_u64 per row and tile.
+    const int lane = tid & 63, wave = tid >> 6;
+    const int il = lane & 15, kq = lane >> 4;
+    const int nbi = (na + 15) >> 4, nbj = (nb + 15) >> 4;
+    for (int t = wave; t < nbi * nbj; t += TMT / 64) {
+      const int i0 = (t / nbj) * 16, j0 = (t % nbj) * 16;
+      const float* ap = s_m + (size_t)(2 * min(i0 + il, na - 1)) * MST + kq;          // MFMA A: row i0 + il, k = 4 ks + kq
+      const float* bp = s_m + (size_t)(2 * min(j0 + il, nb - 1) + 1) * MST + kq;      // MFMA B: column j0 + il
+      // all 32 fragment values first (one LDS round trip per tile, not one per MFMA), then two independent accumulator chains
+      float av[16], bv[16];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) { av[ks] = ap[4 * ks]; bv[ks] = bp[4 * ks]; }
+      f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 16; ks += 2) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks], bv[ks], acc, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ks + 1], bv[ks + 1], acc1, 0, 0, 0);
+      }
+      acc += acc1;
+      // acc[e]: row i0 + 4 kq + e, column j0 + il
+      const int j = j0 + il;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        unsigned long long key = j < nb ? score_key(acc[e], j) : 0ull;
+#pragma unroll
+        for (int step = 0; step < 4; ++step) {
+          const int ctl = step == 0 ? 0xB1 : step == 1 ? 0x4E : step == 2 ? 0x141 : 0x140;      // quad swaps, half-row mirror, row mirror
+          unsigned lo = (unsigned)key, hi = (unsigned)(key >> 32), olo, ohi;
+          switch (ctl) {
+            case 0xB1: olo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, true); ohi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, true); break;
+            case 0x4E: olo = __builtin_amdgcn_mov_dpp(lo, 0x4E, 0xF, 0xF, true); ohi = __builtin_amdgcn_mov_dpp(hi, 0x4E, 0xF, 0xF, true); break;
+            case 0x141: olo = __builtin_amdgcn_mov_dpp(lo, 0x141, 0xF, 0xF, true); ohi = __builtin_amdgcn_mov_dpp(hi, 0x141, 0xF, 0xF, true); break;
+            default: olo = __builtin_amdgcn_mov_dpp(lo, 0x140, 0xF, 0xF, true); ohi = __builtin_amdgcn_mov_dpp(hi, 0x140, 0xF, 0xF, true); break;
+          }
+          const unsigned long long other = ((unsigned long long)ohi << 32) | olo;
+          key = other > key ? other : key;
+        }
+        const int i = i0 + 4 * kq + e;
+        if (il == 0 && i > 0 && i < na) atomicMax(&s_key[i], key);
+      }
+    }
+  } else {
   // scores[i][j] = a_i . b_j (a = even tokens, b = odd tokens) in 4x4 register tiles, rows/columns STRIDED over the tile grid
-  // (i = ti + nti*ii, j = tj + ntj*jj) so the lanes of a wave read consecutive b rows (conflict-free, a rows broadcast);
-  // row max/argmax (ties -> lowest j, torch's CPU max) through ds_max_u64 on an order-preserving (score, ~j) key
-  const int nti = (na + 3) >> 2, ntj = (nb + 3) >> 2;
-  for (int t = tid; t < nti * ntj; t += TMT) {
-    const int ti = t / ntj, tj = t - ti * ntj;
-    const float* ap[4];
-    const float* bp[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      ap[q] = s_m + (size_t)(2 * min(ti + nti * q, na - 1)) * MST;
-      bp[q] = s_m + (size_t)(2 * min(tj + ntj * q, nb - 1) + 1) * MST;
-    }
-    float best[4];
-    int arg[4];
-    if (F32) {
-      double acc[4][4];
-#pragma unroll
-      for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = 0.0;
-      for (int d = 0; d < 64; ++d) {
-        double av[4], bv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { av[q] = (double)ap[q][d]; bv[q] = (double)bp[q][d]; }
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) acc[ii][jj] += av[ii] * bv[jj];
+    // (i = ti + nti*ii, j = tj + ntj*jj) so the lanes of a wave read consecutive b rows (conflict-free, a rows broadcast);
+    // row max/argmax (ties -> lowest j, torch's CPU max) through ds_max_u64 on an order-preserving (score, ~j) key
+    const int nti = (na + 3) >> 2, ntj = (nb + 3) >> 2;
+    for (int t = tid; t < nti * ntj; t += TMT) {
+      const int ti = t / ntj, tj = t - ti * ntj;
+      const float* ap[4];
+      const float* bp[4];
+  #pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        ap[q] = s_m + (size_t)(2 * min(ti + nti * q, na - 1)) * MST;
+        bp[q] = s_m + (size_t)(2 * min(tj + ntj * q, nb - 1) + 1) * MST;
       }
-#pragma unroll
-      for (int ii = 0; ii < 4; ++ii) {
-        best[ii] = -INFINITY; arg[ii] = 0;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const int j = tj + ntj * jj;
-          const float v = (float)acc[ii][jj];
-          if (j < nb && v > best[ii]) { best[ii] = v; arg[ii] = j; }     // j ascending, strict >: first index wins ties
+      float best[4];
+      int arg[4];
+      if (F32) {
+        double acc[4][4];
+  #pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+  #pragma unroll
+          for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = 0.0;
+        for (int d = 0; d < 64; ++d) {
+          double av[4], bv[4];
+  #pragma unroll
+          for (int q = 0; q < 4; ++q) { av[q] = (double)ap[q][d]; bv[q] = (double)bp[q][d]; }
+  #pragma unroll
+          for (int ii = 0; ii < 4; ++ii)
+  #pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[ii][jj] += av[ii] * bv[jj];
+        }
+  #pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          best[ii] = -INFINITY; arg[ii] = 0;
+  #pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int j = tj + ntj * jj;
+            const float v = (float)acc[ii][jj];
+            if (j < nb && v > best[ii]) { best[ii] = v; arg[ii] = j; }     // j ascending, strict >: first index wins ties
+          }
+        }
+      } else {
+        float acc[4][4];
+  #pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+  #pragma unroll
+          for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = 0.f;
+  #pragma unroll 8
+        for (int d = 0; d < 64; ++d) {
+          float av[4], bv[4];
+  #pragma unroll
+          for (int q = 0; q < 4; ++q) { av[q] = ap[q][d]; bv[q] = bp[q][d]; }
+  #pragma unroll
+          for (int ii = 0; ii < 4; ++ii)
+  #pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = fmaf(av[ii], bv[jj], acc[ii][jj]);
+        }
+  #pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          best[ii] = -INFINITY; arg[ii] = 0;
+  #pragma unroll
+          for (int jj = 0; jj < 4; ++jj) {
+            const int j = tj + ntj * jj;
+            if (j < nb && acc[ii][jj] > best[ii]) { best[ii] = acc[ii][jj]; arg[ii] = j; }
+          }
         }
       }
-    } else {
-      float acc[4][4];
-#pragma unroll
-      for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = 0.f;
-#pragma unroll 8
-      for (int d = 0; d < 64; ++d) {
-        float av[4], bv[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { av[q] = ap[q][d]; bv[q] = bp[q][d]; }
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = fmaf(av[ii], bv[jj], acc[ii][jj]);
-      }
-#pragma unroll
+  #pragma unroll
       for (int ii = 0; ii < 4; ++ii) {
-        best[ii] = -INFINITY; arg[ii] = 0;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const int j = tj + ntj * jj;
-          if (j < nb && acc[ii][jj] > best[ii]) { best[ii] = acc[ii][jj]; arg[ii] = j; }
-        }
+        const int i = ti + nti * ii;
+        if (i > 0 && i < na) atomicMax(&s_key[i], score_key(best[ii], arg[ii]));
       }
-    }
-#pragma unroll
-    for (int ii = 0; ii < 4; ++ii) {
-      const int i = ti + nti * ii;
-      if (i > 0 && i < na) atomicMax(&s_key[i], score_key(best[ii], arg[ii]));
     }
   }
   __syncthreads();
-  // descending rank of the row maxima (ties: lowest index first) = argsort(descending); keys order exactly like the floats
-  for (int i = tid; i < na; i += TMT) {
-    const unsigned int vi = (unsigned int)(s_key[i] >> 32);
-    int rank = 0;
-    for (int j = 0; j < na; ++j) {
-      const unsigned int vj = (unsigned int)(s_key[j] >> 32);
-      rank += (vj > vi) || (vj == vi && j < i);
+  // descending rank of the row maxima (ties: lowest index first) = argsort(descending); keys order exactly like the floats.
+  // Sixteen lanes per row, each counting every sixteenth rival, summed over the DPP row (round 4: one thread per row walked all
+  // na rivals with a dependent LDS read each -- 2 of the 16 waves busy for ~4 us at N = 197).
+  {
+    const int c = tid & 15;
+    for (int i = tid >> 4; i < ((na + 63) & ~63); i += TMT / 16) {           // whole waves stay in the loop: the DPP sum needs its 16 lanes
+      const int ic = min(i, na - 1);
+      const unsigned int vi = (unsigned int)(s_key[ic] >> 32);
+      int cnt = 0;
+      for (int j = c; j < na; j += 16) {
+        const unsigned int vj = (unsigned int)(s_key[j] >> 32);
+        cnt += (vj > vi) || (vj == vi && j < ic);
+      }
+      int tot = cnt;
+      tot += __builtin_amdgcn_mov_dpp(tot, 0xB1, 0xF, 0xF, true);
+      tot += __builtin_amdgcn_mov_dpp(tot, 0x4E, 0xF, 0xF, true);
+      tot += __builtin_amdgcn_mov_dpp(tot, 0x141, 0xF, 0xF, true);
+      tot += __builtin_amdgcn_mov_dpp(tot, 0x140, 0xF, 0xF, true);
+      if (c == 0 && i < na) {
+        s_edge[tot] = i;
+        s_unm[i] = tot >= r;
+      }
     }
-    s_edge[rank] = i;
-    s_unm[i] = rank >= r;
   }
   __syncthreads();
   for (int e = tid; e < r; e += TMT) {
@@ -192,12 +263,19 @@ __global__ __launch_bounds__(TMT) void tome_match_kernel(const void* __restrict_
     src_idx[(size_t)b * r + e] = i;
     dst_idx[(size_t)b * r + e] = (int)(0xffffffffu - (unsigned int)(s_key[i] & 0xffffffffull));
   }
-  // unmerged tokens, ascending (tome.py:275-277: keeps the class token first)
-  for (int i = tid; i < na; i += TMT) {
-    if (!s_unm[i]) continue;
-    int pos = 0;
-    for (int j = 0; j < i; ++j) pos += s_unm[j];
-    unm_idx[(size_t)b * (na - r) + pos] = i;
+  // unmerged tokens, ascending (tome.py:275-277: keeps the class token first): position = unmerged tokens before it, again 16 lanes per row
+  {
+    const int c = tid & 15;
+    for (int i = tid >> 4; i < ((na + 63) & ~63); i += TMT / 16) {
+      const int ic = min(i, na - 1);
+      int cnt = 0;
+      for (int j = c; j < ic; j += 16) cnt += s_unm[j];
+      cnt += __builtin_amdgcn_mov_dpp(cnt, 0xB1, 0xF, 0xF, true);
+      cnt += __builtin_amdgcn_mov_dpp(cnt, 0x4E, 0xF, 0xF, true);
+      cnt += __builtin_amdgcn_mov_dpp(cnt, 0x141, 0xF, 0xF, true);
+      cnt += __builtin_amdgcn_mov_dpp(cnt, 0x140, 0xF, 0xF, true);
+      if (c == 0 && i < na && s_unm[i]) unm_idx[(size_t)b * (na - r) + cnt] = i;
+    }
   }
 }
 
@@ -247,15 +325,23 @@ __global__ __launch_bounds__(256) void tome_merge_layernorm_kernel(const float* 
     add_token(2 * unm_idx[(size_t)b * n_unm + p], true);
   } else {
     const int j = p - n_unm;
-    add_token(2 * j + 1, true);
     // edge order = the order torch's CPU scatter_add applies the sources.  Lane l holds edge 64*blk + l; the edges that end in
     // this dst token come out of one ballot, lowest edge first.  (A scalar loop over the r edges paid one dependent index load
-    // per edge: ~8 us per dst row at r = 16, the kernel's long pole.)
+    // per edge: ~8 us per dst row at r = 16, the kernel's long pole.)  The first 64 edges' indices are requested BEFORE the token's own
+    // row, so that their round trip runs under it instead of after it (round 4).
+    int dl = -1, sl = 0;
+    if (lane < r) {
+      dl = dst_idx[(size_t)b * r + lane];
+      sl = src_idx[(size_t)b * r + lane];
+    }
+    add_token(2 * j + 1, true);
     for (int e0 = 0; e0 < r; e0 += 64) {
-      int dl = -1, sl = 0;
-      if (e0 + lane < r) {
-        dl = dst_idx[(size_t)b * r + e0 + lane];
-        sl = src_idx[(size_t)b * r + e0 + lane];
+      if (e0 > 0) {
+        dl = -1;
+        if (e0 + lane < r) {
+          dl = dst_idx[(size_t)b * r + e0 + lane];
+          sl = src_idx[(size_t)b * r + e0 + lane];
+        }
       }
       unsigned long long m = __ballot(dl == j);
       while (m) {
