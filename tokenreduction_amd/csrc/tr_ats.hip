@@ -25,38 +25,46 @@ __global__ __launch_bounds__(256) void ats_sample_kernel(const float* __restrict
   __shared__ float s_cdf[ATS_MAX_P];
   __shared__ int s_flag[ATS_MAX_P + 1];
   __shared__ float s_total;
+  extern __shared__ float s_part[];                   // [H][P]: one head's term of every token
   const int b = blockIdx.x, tid = threadIdx.x;
   const int P = N - 1;
   const int ldq = 3 * H * 64;
-  // sig[p] = sum_h attn[b,h,0,1+p] * ||v[b,h,1+p,:]||_2     (heads summed in order, ats.py:58-63)
-  for (int p = tid; p < P; p += 256) {
-    float sig = 0.f;
-    for (int h = 0; h < H; ++h) {
-      const size_t e0 = ((size_t)b * N + 1 + p) * ldq + 2 * H * 64 + h * 64;
-      float ss = 0.f;
-      if (F32) {
-        const float4* vp = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(qkv) + e0);
+  // sig[p] = sum_h attn[b,h,0,1+p] * ||v[b,h,1+p,:]||_2     (heads summed in order, ats.py:58-63).  One (token, head) item per thread and
+  // step -- the per-item arithmetic and the head order of the sum are those of the rolled loop over heads this replaces, which waited
+  // for H dependent global round trips per token (round 4: 27-31 us per launch, half of it here).
+  for (int item = tid; item < P * H; item += 256) {
+    const int h = item / P, p = item - h * P;
+    const size_t e0 = ((size_t)b * N + 1 + p) * ldq + 2 * H * 64 + h * 64;
+    float ss = 0.f;
+    if (F32) {
+      const float4* vp = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(qkv) + e0);
+      float4 u[16];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          const float4 u = vp[c];
-          ss = fmaf(u.x, u.x, ss); ss = fmaf(u.y, u.y, ss); ss = fmaf(u.z, u.z, ss); ss = fmaf(u.w, u.w, ss);
-        }
-      } else {
-        const uint4* vp = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(qkv) + e0);
+      for (int c = 0; c < 16; ++c) u[c] = vp[c];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const uint4 u = vp[c];
-          const unsigned int w4[4] = {u.x, u.y, u.z, u.w};
+      for (int c = 0; c < 16; ++c) { ss = fmaf(u[c].x, u[c].x, ss); ss = fmaf(u[c].y, u[c].y, ss); ss = fmaf(u[c].z, u[c].z, ss); ss = fmaf(u[c].w, u[c].w, ss); }
+    } else {
+      const uint4* vp = reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(qkv) + e0);
+      uint4 u[8];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float lo = __uint_as_float(w4[q] << 16), hi = __uint_as_float(w4[q] & 0xffff0000u);
-            ss = fmaf(lo, lo, ss);
-            ss = fmaf(hi, hi, ss);
-          }
+      for (int c = 0; c < 8; ++c) u[c] = vp[c];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const unsigned int w4[4] = {u[c].x, u[c].y, u[c].z, u[c].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float lo = __uint_as_float(w4[q] << 16), hi = __uint_as_float(w4[q] & 0xffff0000u);
+          ss = fmaf(lo, lo, ss);
+          ss = fmaf(hi, hi, ss);
         }
       }
-      sig += cls_rows[((size_t)b * H + h) * N + 1 + p] * sqrtf(ss);
     }
+    s_part[item] = cls_rows[((size_t)b * H + h) * N + 1 + p] * sqrtf(ss);
+  }
+  __syncthreads();
+  for (int p = tid; p < P; p += 256) {
+    float sig = 0.f;
+    for (int h = 0; h < H; ++h) sig += s_part[h * P + p];
     s_sig[p] = sig;
     s_flag[p + 1] = 0;
   }
@@ -70,10 +78,12 @@ __global__ __launch_bounds__(256) void ats_sample_kernel(const float* __restrict
   }
   __syncthreads();
   const float denom = s_total;
+  for (int p = tid; p < P; p += 256) s_cdf[p] = s_sig[p] / denom;      // the quotients in parallel; only the running sum is a chain
+  __syncthreads();
   if (tid == 0) {                                    // cumsum in token order, then +0.1 on masked positions (ats.py:69-70)
     float run = 0.f;
     for (int p = 0; p < P; ++p) {
-      run += s_sig[p] / denom;
+      run += s_cdf[p];
       s_cdf[p] = run;
     }
   }
@@ -86,22 +96,33 @@ __global__ __launch_bounds__(256) void ats_sample_kernel(const float* __restrict
   }
   __syncthreads();
   // nearest cdf entry per grid point; torch.cdist matmul form: [-2s, s^2, 1] . [c, 1, c^2], clamp_min(1e-30), sqrt; argmin
-  // keeps the first minimum
-  for (int t = tid; t < n_steps; t += 256) {
-    const float s = steps[t];
-    const float a0 = -2.0f * s, a1 = __fmul_rn(s, s);
-    float best = INFINITY;
-    int arg = 0;
-    for (int p = 0; p < P; ++p) {
-      const float c = s_cdf[p];
-      // k = 0,1,2 of the 3-term dot product, each product/sum rounded once (no contraction: c^2 is a rounded operand)
-      float r = __fmul_rn(a0, c);
-      r = __fadd_rn(r, a1);
-      r = __fadd_rn(r, __fmul_rn(c, c));
-      const float d = sqrtf(fmaxf(r, 1e-30f));
-      if (d < best) { best = d; arg = p; }
+  // keeps the first minimum.  Four lanes per grid point, each walking every fourth entry; (distance, index) minima combined
+  // lexicographically, which is the first minimum of the whole row.
+  {
+    const int q4 = tid & 3;
+    for (int t = tid >> 2; t < ((n_steps + 63) & ~63); t += 64) {
+      const float s = steps[min(t, n_steps - 1)];
+      const float a0 = -2.0f * s, a1 = __fmul_rn(s, s);
+      float best = INFINITY;
+      int arg = 0x7fffffff;
+      for (int p = q4; p < P; p += 4) {
+        const float c = s_cdf[p];
+        // k = 0,1,2 of the 3-term dot product, each product/sum rounded once (no contraction: c^2 is a rounded operand)
+        float r = __fmul_rn(a0, c);
+        r = __fadd_rn(r, a1);
+        r = __fadd_rn(r, __fmul_rn(c, c));
+        const float d = sqrtf(fmaxf(r, 1e-30f));
+        if (d < best) { best = d; arg = p; }
+      }
+#pragma unroll
+      for (int o = 1; o < 4; o <<= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oa = __shfl_xor(arg, o, 64);
+        if (ob < best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+      }
+      if (arg == 0x7fffffff) arg = 0;                 // every distance NaN: index 0, as a sequential first-minimum scan returns
+      if (q4 == 0 && t < n_steps) s_flag[arg + 1] = 1;                             // sampled_token_ids = argmin + 1
     }
-    s_flag[arg + 1] = 1;                             // sampled_token_ids = argmin + 1
   }
   __syncthreads();
   // sorted unique ids, CLS id 0 in front, zero padding to K; new_mask = ids != 0 (CLS True)   (ats.py:77-84)
@@ -175,11 +196,13 @@ extern "C" int tr_ats_sample(const float* cls_rows, const void* qkv, int qkv_is_
              "tr_ats_sample: %d grid points cannot exceed K-1 = %d (at most one new token per point, ats.py:48)", n_steps, K - 1);
   TR_REQUIRE(tr_aligned16(qkv), TR_ERR_ALIGN, "tr_ats_sample: qkv must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(s);
+  const size_t lds = (size_t)H * (N - 1) * sizeof(float);            // one term per (head, token)
+  TR_REQUIRE(lds <= 48 * 1024, TR_ERR_SHAPE, "tr_ats_sample: %d heads x %d tokens do not fit the per-head scratch", H, N - 1);
   if (qkv_is_f32)
-    hipLaunchKernelGGL(ats_sample_kernel<true>, dim3(B), dim3(256), 0, st, cls_rows, qkv, mask, steps, n_steps, ids, new_mask, cdf_out, N,
+    hipLaunchKernelGGL(ats_sample_kernel<true>, dim3(B), dim3(256), lds, st, cls_rows, qkv, mask, steps, n_steps, ids, new_mask, cdf_out, N,
                        H, K, 1e-6f);
   else
-    hipLaunchKernelGGL(ats_sample_kernel<false>, dim3(B), dim3(256), 0, st, cls_rows, qkv, mask, steps, n_steps, ids, new_mask, cdf_out,
+    hipLaunchKernelGGL(ats_sample_kernel<false>, dim3(B), dim3(256), lds, st, cls_rows, qkv, mask, steps, n_steps, ids, new_mask, cdf_out,
                        N, H, K, 1e-6f);
   TR_CHECK_LAUNCH("tr_ats_sample");
   return TR_OK;

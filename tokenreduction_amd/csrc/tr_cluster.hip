@@ -231,25 +231,56 @@ __global__ __launch_bounds__(512) void dist_mfma_kernel(const float* __restrict_
     if (gi >= P) continue;
     const float ni = ni4[a];
 #pragma unroll
-    for (int bb = 0; bb < 4; ++bb)
+    for (int bb = 0; bb < 4; ++bb) {
+      const int gj0 = j0 + wn * 64 + bb * 16 + 4 * fq;
+      float o[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int gj = j0 + wn * 64 + bb * 16 + 4 * fq + e;
-        if (gj < P) db[(size_t)gi * P + gj] = sqrtf(fmaxf((ni + nj[bb][e]) - 2.0f * acc[bb][a][e], 1e-30f)) / sqrt_d;
+      for (int e = 0; e < 4; ++e) o[e] = sqrtf(fmaxf((ni + nj[bb][e]) - 2.0f * acc[bb][a][e], 1e-30f)) / sqrt_d;
+      // a lane's four values are four consecutive columns of one row: ONE 16-byte store when the row pitch allows (P % 4 == 0), i.e. 16
+      // rows x 64 contiguous bytes per instruction instead of 64 scattered 4-byte writes (round 4)
+      if ((P & 3) == 0 && gj0 + 3 < P) {
+        *reinterpret_cast<float4*>(db + (size_t)gi * P + gj0) = make_float4(o[0], o[1], o[2], o[3]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (gj0 + e < P) db[(size_t)gi * P + gj0 + e] = o[e];
       }
+    }
   }
 }
 
 constexpr int KNN_MAX = 8;
 constexpr int MAX_PER_LANE = 16;  // P <= 1024
 
+// (value, index) minimum over the wave, ties -> smallest index; result in every lane.  Full-rate VALU: four DPP steps inside the 16-lane
+// rows, then v_permlane16_swap / v_permlane32_swap across them (round 4: the ds_bpermute butterfly this replaces -- 12 LDS-pipe round
+// trips per reduction, 48 per step of kmed_iterate_kernel -- was most of that kernel's 214 us at 576 tokens).
 __device__ __forceinline__ void wave_min_pair(float& v, int& i) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(v, o, 64);
-    const int oi = __shfl_xor(i, o, 64);
-    if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+#define TR_MINPAIR_STEP(OV, OI)                                   \
+  do {                                                            \
+    const float ov__ = (OV);                                      \
+    const int oi__ = (OI);                                        \
+    if (ov__ < v || (ov__ == v && oi__ < i)) { v = ov__; i = oi__; } \
+  } while (0)
+  TR_MINPAIR_STEP(__builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true)), __builtin_amdgcn_mov_dpp(i, 0xB1, 0xF, 0xF, true));
+  TR_MINPAIR_STEP(__builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true)), __builtin_amdgcn_mov_dpp(i, 0x4E, 0xF, 0xF, true));
+  TR_MINPAIR_STEP(__builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true)), __builtin_amdgcn_mov_dpp(i, 0x141, 0xF, 0xF, true));
+  TR_MINPAIR_STEP(__builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true)), __builtin_amdgcn_mov_dpp(i, 0x140, 0xF, 0xF, true));
+  {
+    const auto a = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap((unsigned)i, (unsigned)i, false, false);
+    const unsigned a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+    v = __builtin_bit_cast(float, a0); i = (int)b0;                // one of the two is this lane's own pair, the other its partner row's
+    TR_MINPAIR_STEP(__builtin_bit_cast(float, a1), (int)b1);
   }
+  {
+    const auto a = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap((unsigned)i, (unsigned)i, false, false);
+    const unsigned a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+    v = __builtin_bit_cast(float, a0); i = (int)b0;
+    TR_MINPAIR_STEP(__builtin_bit_cast(float, a1), (int)b1);
+  }
+#undef TR_MINPAIR_STEP
 }
 
 // one wave per row: density = exp(-mean(k smallest d^2)) + noise*1e-6; per-image max distance via atomicMax on the bits.
@@ -484,72 +515,52 @@ __device__ __forceinline__ unsigned long long cost_key(float v, int i) {        
   return ((unsigned long long)__float_as_uint(v) << 32) | (unsigned int)i;
 }
 
-// one workgroup (16 waves) per image: iterate {assignment, medoid update}, final assignment.  Assignment = one wave per token,
-// lanes across the K medoid columns of that token's distance row (gathered loads in parallel), wave arg-min with the
-// first-index tie rule of torch.argmin.
+// one workgroup (16 waves) per image: iterate {assignment, medoid update}, final assignment.
+// Assignment (round 4): a token's distances to the K medoids are read from the medoids' ROWS (dist[c_k][p], 64 tokens of a row per
+// wave-load: full 256-byte segments) instead of gathered from the token's own row (dist[p][c_k]: 64 lanes in 64 different sectors of a
+// 2.3-KB row -- 83 k sector accesses per pass at P = 576, K = 144, which was the kernel: 44 us per pass).  The matrix is symmetric up to
+// the last bit of the split-operand Gram product (|x_i|^2 + |x_j|^2 is the same sum, the cross terms are accumulated in the other
+// order), so an arg-min can differ from the column form only between medoids whose distances to the token agree to ~1e-7 relative: the
+// tolerance the medoid comparisons against the oracle already carry.  Work unit = (64 tokens, 16 medoids): 16 row loads in flight, the
+// lane's first minimum over ascending k, then ds_min_u64 on (distance bits, k) per token -- ties -> smallest k, torch.argmin's rule.
 constexpr int KMT = 1024;
 __global__ __launch_bounds__(KMT) void kmed_iterate_kernel(const float* __restrict__ dist, const float* __restrict__ t,
                                                            int32_t* __restrict__ centers, int32_t* __restrict__ assign, int P, int K,
                                                            int iters) {
-  extern __shared__ unsigned long long s_best[];      // [K] packed (cost, index), then int s_c[K]
-  int* s_c = reinterpret_cast<int*>(s_best + K);
+  extern __shared__ unsigned long long s_best[];      // [K] packed (cost, index); then [P] packed (distance, medoid); then int s_c[K]
+  unsigned long long* s_tok = s_best + K;
+  int* s_c = reinterpret_cast<int*>(s_tok + P);
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* db = dist + (size_t)b * P * P;
   const float* tb = t + (size_t)b * P;
   for (int k = tid; k < K; k += KMT) s_c[k] = centers[(size_t)b * K + k];
   __syncthreads();
   const float masked = (float)P * 1000000.0f;         // a row outside cluster k sums to P * 1e6 (kmedoids.py:76-77)
+  const int ng = (P + 63) >> 6, nc = (K + 15) >> 4;
   for (int it = 0; it <= iters; ++it) {
     for (int k = tid; k < K; k += KMT) s_best[k] = cost_key(masked, 0);
+    for (int p = tid; p < P; p += KMT) s_tok[p] = ~0ull;
     __syncthreads();
-    // four tokens per wave and step, all their gathered distances (up to 4 x 4 per lane) requested before the first compare:
-    // as a rolled loop over k every 64 medoids cost one dependent L2 round trip per token (3 x 12 tokens x 4 passes per wave)
-    const int kch = (K + 63) >> 6;
-    for (int p0 = wave * 4; p0 < P; p0 += (KMT / 64) * 4) {
-      if (kch <= 4) {
-        float d[4][4];
-        int ci[4];
+    for (int u = wave; u < ng * nc; u += KMT / 64) {
+      const int g = u / nc, k0 = (u - g * nc) * 16;
+      const int p = min(g * 64 + lane, P - 1);
+      float d[16];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) ci[c] = s_c[min(lane + 64 * c, K - 1)];
+      for (int q = 0; q < 16; ++q) d[q] = db[(size_t)s_c[min(k0 + q, K - 1)] * P + p];
+      float best = INFINITY;
+      int arg = 0x7fffffff;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) d[q][c] = db[(size_t)min(p0 + q, P - 1) * P + ci[c]];
-        float cost[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) cost[q] = tb[min(p0 + q, P - 1)];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float best = INFINITY;
-          int arg = 0;                                  // all-NaN row: index 0, like torch.argmin (never an out-of-range LDS slot)
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {               // ascending k per lane, strict <: the lane's first minimum
-            const int k = lane + 64 * c;
-            if (k < K && d[q][c] < best) { best = d[q][c]; arg = k; }
-          }
-          wave_min_pair(best, arg);                   // smallest distance, ties -> smallest k (torch.argmin)
-          if (lane == 0 && p0 + q < P) {
-            if (it == iters) assign[(size_t)b * P + p0 + q] = arg;
-            else atomicMin(&s_best[arg], cost_key(cost[q], p0 + q));   // smallest cost, ties -> smallest index; empty cluster -> index 0
-          }
-        }
-      } else {
-        for (int q = 0; q < 4 && p0 + q < P; ++q) {
-          const int p = p0 + q;
-          const float* dr = db + (size_t)p * P;
-          float best = INFINITY;
-          int arg = 0;                                  // all-NaN row: index 0, like torch.argmin (never an out-of-range LDS slot)
-          for (int k = lane; k < K; k += 64) {
-            const float dd = dr[s_c[k]];
-            if (dd < best) { best = dd; arg = k; }
-          }
-          wave_min_pair(best, arg);
-          if (lane == 0) {
-            if (it == iters) assign[(size_t)b * P + p] = arg;
-            else atomicMin(&s_best[arg], cost_key(tb[p], p));
-          }
-        }
-      }
+      for (int q = 0; q < 16; ++q)
+        if (k0 + q < K && d[q] < best) { best = d[q]; arg = k0 + q; }       // ascending k, strict <: the first minimum
+      // (all-NaN distances leave arg unset: the token keeps ~0 below and falls to medoid 0, like torch.argmin never returns out of range)
+      if (g * 64 + lane < P && arg != 0x7fffffff) atomicMin(&s_tok[p], ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)arg);
+    }
+    __syncthreads();
+    for (int p = tid; p < P; p += KMT) {
+      const unsigned long long kb = s_tok[p];
+      const int arg = kb == ~0ull ? 0 : (int)(kb & 0xffffffffull);
+      if (it == iters) assign[(size_t)b * P + p] = arg;
+      else atomicMin(&s_best[arg], cost_key(tb[p], p));   // smallest cost, ties -> smallest index; empty cluster -> index 0
     }
     __syncthreads();
     if (it < iters)
@@ -724,7 +735,7 @@ extern "C" int tr_kmedoids_equal(const float* x, int init_idx, float* ws, int32_
   launch_dist(fast_dist != 0, x, nrm, dist, B, N, D, 1.0f, st);
   hipLaunchKernelGGL(kmed_init_equal_kernel, dim3(B), dim3(256), 0, st, dist, centers, P, K, init_idx);
   hipLaunchKernelGGL(kmed_rowcost_kernel, dim3(rb), dim3(256), 0, st, dist, wrow, t, B, P);
-  hipLaunchKernelGGL(kmed_iterate_kernel, dim3(B), dim3(KMT), (size_t)K * 12, st, dist, t, centers, assign, P, K, iters);
+  hipLaunchKernelGGL(kmed_iterate_kernel, dim3(B), dim3(KMT), (size_t)K * 12 + (size_t)P * 8, st, dist, t, centers, assign, P, K, iters);
   TR_CHECK_LAUNCH("tr_kmedoids_equal");
   return TR_OK;
 }
@@ -751,7 +762,7 @@ extern "C" int tr_kmedoids(const float* x, const float* colsum_part, float* ws, 
   launch_sqnorm(x, nrm, B, N, D, st, false);
   launch_dist(fast_dist != 0, x, nrm, dist, B, N, D, 1.0f, st);                               // torch.cdist(x, x)
   hipLaunchKernelGGL(kmed_rowcost_kernel, dim3(rb), dim3(256), 0, st, dist, wrow, t, B, P);
-  hipLaunchKernelGGL(kmed_iterate_kernel, dim3(B), dim3(KMT), (size_t)K * 12, st, dist, t, centers, assign, P, K, iters);
+  hipLaunchKernelGGL(kmed_iterate_kernel, dim3(B), dim3(KMT), (size_t)K * 12 + (size_t)P * 8, st, dist, t, centers, assign, P, K, iters);
   TR_CHECK_LAUNCH("tr_kmedoids");
   return TR_OK;
 }
