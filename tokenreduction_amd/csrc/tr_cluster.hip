@@ -165,6 +165,10 @@ __global__ __launch_bounds__(512) void dist_mfma_kernel(const float* __restrict_
   const int lid = xcd_remap(blockIdx.x, gridDim.x);
   const int b = lid / nt, tile = lid - b * nt;
   const int i0 = (tile / ntj) * GT, j0 = (tile % ntj) * GTN;
+  // The matrix is symmetric: a tile that lies wholly BELOW the diagonal (its last column before its first row) is not computed -- the
+  // tiles above the diagonal also store their elements transposed wherever the mirror image falls into such a tile (round 4: 6 of the 15
+  // tiles at P = 576).  Those pairs are then exactly symmetric; pairs inside the tiles that straddle the diagonal are still computed twice.
+  if (j0 + GTN <= i0) return;
   const float* xb = x + ((size_t)b * N + 1) * D;
   const int lr = tid >> 1, lc = (tid & 1) * 16;                      // A staging: row lr (0..255), 16 consecutive floats
   const int br = tid >> 2, bc = (tid & 3) * 8;                       // B staging: row br (0..127), 8 consecutive floats
@@ -244,6 +248,13 @@ __global__ __launch_bounds__(512) void dist_mfma_kernel(const float* __restrict_
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           if (gj0 + e < P) db[(size_t)gi * P + gj0 + e] = o[e];
+      }
+      // mirror image (row gj, column gi): owned by the tile (gj / GT, gi / GTN); written here when that tile was skipped.  gj0 .. gj0 + 3
+      // share their row tile (gj0 is a multiple of 4, GT of 256); 16 lanes with consecutive gi write 64 contiguous bytes of a row.
+      if ((gi / GTN) * GTN + GTN <= (gj0 / GT) * GT) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (gj0 + e < P) db[(size_t)(gj0 + e) * P + gi] = o[e];
       }
     }
   }
