@@ -213,23 +213,39 @@ __global__ __launch_bounds__(256) void token_softmax_kernel(float* __restrict__ 
 }
 
 // out[b][1+k][:] = sum_p w[b][1+p][k] * src[b][1+p][:] on MFMA: both operands are split into bf16 hi + lo (3 products,
-// relative error ~2^-16) and transposed through LDS so the token axis is the contraction.  Workgroup = one image x 64
-// feature columns, wave = 16 columns x all K (<= 192) outputs; tokens walked in slabs of 32.
-constexpr int MK_MAX = 192, MLD = 40;    // LDS row stride in bf16 (80 B: conflict-free 16-B fragment reads)
-
-__device__ __forceinline__ void split2(float v, unsigned short& hi, unsigned short& lo) {
-  const unsigned int hp = pack_bf16x2(v, 0.f) & 0xffffu;
-  hi = (unsigned short)hp;
-  lo = (unsigned short)(pack_bf16x2(v - __uint_as_float(hp << 16), 0.f) & 0xffffu);
+// relative error ~2^-16).  The token axis is the contraction and the SLOW axis of both operands in memory, so both are staged
+// ROW-major (token rows, 16- and 8-byte LDS writes) and read TRANSPOSED with ds_read_b64_tr_b16 -- the layout and the read pattern of V
+// in attention16_kernel.  (Until round 4 the staging transposed by hand: one 2-byte LDS write per element, 64 per thread and 32-token
+// slab, for 27 MFMAs per wave: 75 us per launch, 7 % of a SiT forward.)  Workgroup = one image x 64 feature columns, wave = 16 of
+// them (the permuted 16 of the transposed read: lane group g, register r <-> column 32 (w >> 1) + 8 g + 4 (w & 1) + r) x all K (<= 192)
+// centres; tokens walked in slabs of 32: k-slot 8 g + j of a fragment <-> token 16 (j >> 2) + 4 g + (j & 3) for BOTH operands.
+constexpr int MK_MAX = 192;
+constexpr int MWS = 544;                 // weight image row pitch in bytes: 272 centres, and 544 = 32 (mod 256): the 16 rows of a transposed
+                                         // read fall into 8 distinct 32-byte windows, two rows each (tools/lds_sim.py's criterion: 2 passes)
+typedef __attribute__((ext_vector_type(4))) short m_s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short m_s16x8_t;
+__device__ __forceinline__ bf16x8 m_lds_tr_pair16(const unsigned char* p0, const unsigned char* p1) {
+  const m_s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) m_s16x4_t*)(p0));
+  const m_s16x4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) m_s16x4_t*)(p1));
+  const m_s16x8_t c = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, c);
+}
+// four fp32 -> four bf16 hi (8 bytes) + four bf16 lo (8 bytes)
+__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
+  const unsigned h0 = pack_bf16x2(v.x, v.y), h1 = pack_bf16x2(v.z, v.w);
+  lo.x = pack_bf16x2(v.x - __uint_as_float(h0 << 16), v.y - __uint_as_float(h0 & 0xffff0000u));
+  lo.y = pack_bf16x2(v.z - __uint_as_float(h1 << 16), v.w - __uint_as_float(h1 & 0xffff0000u));
+  hi.x = h0;
+  hi.y = h1;
 }
 
 __global__ __launch_bounds__(256) void softmerge_mfma_kernel(const float* __restrict__ wt, int ldl, const float* __restrict__ x,
                                                              const float* __restrict__ src, float* __restrict__ x_out, int N, int K,
                                                              int D) {
-  __shared__ __attribute__((aligned(16))) unsigned short sSh[64 * MLD], sSl[64 * MLD], sWh[MK_MAX * MLD], sWl[MK_MAX * MLD];
+  __shared__ __attribute__((aligned(16))) unsigned char sSh[32 * 128], sSl[32 * 128], sWh[32 * MWS], sWl[32 * MWS];
   const int P = N - 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int frow = lane & 15, fq = lane >> 4;
+  const int li = lane & 15, g = lane >> 4, q4 = li >> 2, p4 = li & 3;
   const int b = blockIdx.y, d0 = blockIdx.x * 64;
   const int nkf = (K + 15) >> 4, Kp = nkf * 16;
   const float* sb = src + ((size_t)b * N + 1) * D;
@@ -237,19 +253,18 @@ __global__ __launch_bounds__(256) void softmerge_mfma_kernel(const float* __rest
   f32x4 acc[MK_MAX / 16];
 #pragma unroll
   for (int i = 0; i < MK_MAX / 16; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int sp = tid >> 3, sd = (tid & 7) * 8;                     // src staging: token sp of the slab, 8 feature columns
+  const int sp = tid >> 3, sc = tid & 7;                           // src staging: token sp of the slab, 16-byte chunk sc (8 feature columns)
   // Register-staged prefetch: the loads of slab p0+32 (2 float4 of src, up to 6 float4 of weights per thread) are issued before
-  // the MFMAs of slab p0.  (The weights used to be fetched in a rolled load-wait-split loop: up to six dependent global round
-  // trips per slab, ~35 per workgroup -- the "latency-bound 70 us" of round 1's first profile.)
+  // the MFMAs of slab p0.
   constexpr int WIT = 32 * (MK_MAX / 4) / 256;                     // 6: float4 weight loads per thread and slab, at most
   const int kq4 = Kp >> 2;                                         // float4 groups per token
   float4 s0, s1, w4[WIT];
   auto load_slab = [&](int p0) __attribute__((always_inline)) {
     s0 = make_float4(0.f, 0.f, 0.f, 0.f);
     s1 = s0;
-    if (p0 + sp < P && d0 + sd < D) {
-      s0 = *reinterpret_cast<const float4*>(sb + (size_t)(p0 + sp) * D + d0 + sd);
-      s1 = *reinterpret_cast<const float4*>(sb + (size_t)(p0 + sp) * D + d0 + sd + 4);
+    if (p0 + sp < P && d0 + 8 * sc < D) {
+      s0 = *reinterpret_cast<const float4*>(sb + (size_t)(p0 + sp) * D + d0 + 8 * sc);
+      s1 = *reinterpret_cast<const float4*>(sb + (size_t)(p0 + sp) * D + d0 + 8 * sc + 4);
     }
 #pragma unroll
     for (int it = 0; it < WIT; ++it) {
@@ -259,47 +274,60 @@ __global__ __launch_bounds__(256) void softmerge_mfma_kernel(const float* __rest
       if (idx < 32 * kq4 && p0 + p < P && kq < ldl) w4[it] = *reinterpret_cast<const float4*>(wb + (size_t)(p0 + p) * ldl + kq);
     }
   };
+  // transposed-read addresses (attention16_kernel's V image): src block `wave`; lane 4 q4 + p4 addresses token row 4 g + q4 (+ 16), piece p4
+  const int dbw = wave;
+  const int cS = 4 * (dbw >> 1) + p4, hbS = dbw & 1;
+  const unsigned aoff = (unsigned)((4 * g + q4) * 128 + ((cS ^ (((q4 >> 1) & 1) << 2)) << 4) + ((hbS ^ (g & 1)) << 3));
+  const unsigned woff = (unsigned)((4 * g + q4) * MWS + 8 * p4);    // + 32 kf for the centre block
   load_slab(0);
   for (int p0 = 0; p0 < P; p0 += 32) {
     lds_barrier();                                                 // previous slab's fragment reads are done (LDS only)
     {
-      const float f[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-#pragma unroll
-      for (int e = 0; e < 8; ++e) split2(f[e], sSh[(sd + e) * MLD + sp], sSl[(sd + e) * MLD + sp]);
+      uint2 h0, l0, h1, l1;
+      split4(s0, h0, l0);
+      split4(s1, h1, l1);
+      uint4 hv = make_uint4(h0.x, h0.y, h1.x, h1.y), lv = make_uint4(l0.x, l0.y, l1.x, l1.y);
+      if ((sp >> 2) & 1) { hv = make_uint4(hv.z, hv.w, hv.x, hv.y); lv = make_uint4(lv.z, lv.w, lv.x, lv.y); }     // halves swapped on rows 4..7 (mod 8)
+      const unsigned o = (unsigned)(sp * 128 + ((sc ^ (((sp >> 1) & 1) << 2)) << 4));
+      *reinterpret_cast<uint4*>(sSh + o) = hv;
+      *reinterpret_cast<uint4*>(sSl + o) = lv;
     }
 #pragma unroll
     for (int it = 0; it < WIT; ++it) {                             // weights: 4 consecutive centres of one token per thread
       const int idx = tid + 256 * it;
       if (idx < 32 * kq4) {
         const int p = idx / kq4, kq = (idx - p * kq4) * 4;
-        const float f[4] = {w4[it].x, w4[it].y, w4[it].z, w4[it].w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float v = (kq + e < K) ? f[e] : 0.f;
-          split2(v, sWh[(kq + e) * MLD + p], sWl[(kq + e) * MLD + p]);
-        }
+        float4 v = w4[it];
+        if (kq + 0 >= K) v.x = 0.f;
+        if (kq + 1 >= K) v.y = 0.f;
+        if (kq + 2 >= K) v.z = 0.f;
+        if (kq + 3 >= K) v.w = 0.f;
+        uint2 h, l;
+        split4(v, h, l);
+        *reinterpret_cast<uint2*>(sWh + p * MWS + kq * 2) = h;
+        *reinterpret_cast<uint2*>(sWl + p * MWS + kq * 2) = l;
       }
     }
     if (p0 + 32 < P) load_slab(p0 + 32);
     lds_barrier();                                                 // the prefetch above stays in flight under the MFMAs
-    const bf16x8 sh = *reinterpret_cast<const bf16x8*>(sSh + (wave * 16 + frow) * MLD + fq * 8);
-    const bf16x8 sl = *reinterpret_cast<const bf16x8*>(sSl + (wave * 16 + frow) * MLD + fq * 8);
+    const bf16x8 sh = m_lds_tr_pair16(sSh + aoff, sSh + aoff + 2048);
+    const bf16x8 sl = m_lds_tr_pair16(sSl + aoff, sSl + aoff + 2048);
 #pragma unroll
     for (int kf = 0; kf < MK_MAX / 16; ++kf)
       if (kf < nkf) {
-        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(sWh + (kf * 16 + frow) * MLD + fq * 8);
-        const bf16x8 wl = *reinterpret_cast<const bf16x8*>(sWl + (kf * 16 + frow) * MLD + fq * 8);
+        const bf16x8 wh = m_lds_tr_pair16(sWh + woff + 32 * kf, sWh + woff + 32 * kf + 16 * MWS);
+        const bf16x8 wl = m_lds_tr_pair16(sWl + woff + 32 * kf, sWl + woff + 32 * kf + 16 * MWS);
         acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sl, wh, acc[kf], 0, 0, 0);
         acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sh, wl, acc[kf], 0, 0, 0);
         acc[kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sh, wh, acc[kf], 0, 0, 0);
       }
   }
-  // acc[kf][e]: feature column d0 + wave*16 + 4*fq + e, centre kf*16 + frow
-  const int d = d0 + wave * 16 + 4 * fq;
+  // acc[kf][e]: feature column d0 + 32 (wave >> 1) + 8 g + 4 (wave & 1) + e, centre kf * 16 + li
+  const int d = d0 + 32 * (dbw >> 1) + 8 * g + 4 * (dbw & 1);
   if (d < D) {
 #pragma unroll
     for (int kf = 0; kf < MK_MAX / 16; ++kf) {
-      const int k = kf * 16 + frow;
+      const int k = kf * 16 + li;
       if (kf < nkf && k < K)
         *reinterpret_cast<float4*>(x_out + ((size_t)b * (K + 1) + 1 + k) * D + d) =
             make_float4(acc[kf][0], acc[kf][1], acc[kf][2], acc[kf][3]);
