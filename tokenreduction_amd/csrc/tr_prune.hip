@@ -168,6 +168,10 @@ __global__ __launch_bounds__(256) void sit_merge_kernel(const float* __restrict_
 // ---- fast path of the soft merges (SiT, PatchMerger, Sinkhorn) for the bf16 executor --------------------------------------
 // softmax over the token axis, in place on the token-major logits (F.softmax(weight * scale, dim=1), sit.py:38).
 // grid (ceil(K/32), B): 32 output columns per workgroup (lanes along k: coalesced), 8 token groups reduced through LDS
+// PER > 0: a thread's (at most PER) logits stay in registers -- one read pass with every load in flight, one write pass (round 4: the three
+// rolled passes re-read the column with a dependent load per element: 20 us per launch, 2.1 x the algorithmic bytes).  PER = 0: any length.
+// The max and the sum are taken over the same elements in the same order in both forms (thread's elements ascending, then the 8 groups).
+template <int PER>
 __global__ __launch_bounds__(256) void token_softmax_kernel(float* __restrict__ logits, int ldl, float scale, float* __restrict__ soft,
                                                             int N, int K) {
   __shared__ float s_red[8][32];
@@ -176,10 +180,18 @@ __global__ __launch_bounds__(256) void token_softmax_kernel(float* __restrict__ 
   const int b = blockIdx.y, k = blockIdx.x * 32 + kk;
   const bool kval = k < K;
   const int P = N - 1;
-  float* lg = logits + ((size_t)b * N + 1) * ldl + blockIdx.x * 32 + kk;
+  float* lg = logits + ((size_t)b * N + 1) * ldl + blockIdx.x * 32 + min(kk, K - 1 - (int)blockIdx.x * 32);      // clamped: loads stay branch-free
+  float v[PER > 0 ? PER : 1];
   float mx = -INFINITY;
-  if (kval)
+  if (PER > 0) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) v[i] = lg[(size_t)min(pg + 8 * i, P - 1) * ldl] * scale;
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+      if (pg + 8 * i < P) mx = fmaxf(mx, v[i]);
+  } else if (kval) {
     for (int p = pg; p < P; p += 8) mx = fmaxf(mx, lg[(size_t)p * ldl] * scale);
+  }
   s_red[pg][kk] = mx;
   __syncthreads();
   if (tid < 32) {
@@ -191,8 +203,15 @@ __global__ __launch_bounds__(256) void token_softmax_kernel(float* __restrict__ 
   __syncthreads();
   const float m = s_max[kk];
   float sum = 0.f;
-  if (kval)
+  if (PER > 0) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      v[i] = expf(v[i] - m);
+      if (pg + 8 * i < P) sum += v[i];
+    }
+  } else if (kval) {
     for (int p = pg; p < P; p += 8) sum += expf(lg[(size_t)p * ldl] * scale - m);
+  }
   __syncthreads();
   s_red[pg][kk] = sum;
   __syncthreads();
@@ -204,12 +223,24 @@ __global__ __launch_bounds__(256) void token_softmax_kernel(float* __restrict__ 
   }
   __syncthreads();
   const float inv = s_inv[kk];
-  if (kval)
+  if (!kval) return;
+  if (PER > 0) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int p = pg + 8 * i;
+      if (p < P) {
+        const float w = v[i] * inv;
+        lg[(size_t)p * ldl] = w;
+        if (soft != nullptr) soft[((size_t)b * K + k) * P + p] = w;
+      }
+    }
+  } else {
     for (int p = pg; p < P; p += 8) {
       const float w = expf(lg[(size_t)p * ldl] * scale - m) * inv;
       lg[(size_t)p * ldl] = w;
       if (soft != nullptr) soft[((size_t)b * K + k) * P + p] = w;
     }
+  }
 }
 
 // out[b][1+k][:] = sum_p w[b][1+p][k] * src[b][1+p][:] on MFMA: both operands are split into bf16 hi + lo (3 products,
@@ -856,7 +887,10 @@ extern "C" int tr_softassign_merge_fast(float* logits, int ldl, float scale, int
   TR_REQUIRE(tr_aligned16(logits) && tr_aligned16(x) && tr_aligned16(src) && tr_aligned16(x_out), TR_ERR_ALIGN,
              "tr_softassign_merge_fast: pointers must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(s);
-  if (apply_softmax) hipLaunchKernelGGL(token_softmax_kernel, dim3((K + 31) / 32, B), dim3(256), 0, st, logits, ldl, scale, soft, N, K);
+  if (apply_softmax) {
+    if (N - 1 <= 8 * 25) hipLaunchKernelGGL(token_softmax_kernel<25>, dim3((K + 31) / 32, B), dim3(256), 0, st, logits, ldl, scale, soft, N, K);       // 224^2 inputs
+    else hipLaunchKernelGGL(token_softmax_kernel<0>, dim3((K + 31) / 32, B), dim3(256), 0, st, logits, ldl, scale, soft, N, K);
+  }
   if (K > MK_MAX) {          // more outputs than the MFMA kernel's accumulators hold (384 x 384 inputs at high keep rates): the VALU merge
     TR_CHECK_LAUNCH("tr_softassign_merge_fast");
     return tr_weighted_merge(logits, ldl, x, src, x_out, B, N, K, D, s);
