@@ -65,10 +65,13 @@ def test_gemm_split_patch_epilogue(ops):
     torch.testing.assert_close(got[:, 1:].double(), want, atol=3e-5, rtol=1e-5)
 
 
-@pytest.mark.parametrize("B,N,H", [(2, 197, 6), (2, 138, 2), (1, 69, 3), (1, 7, 1), (1, 224, 1), (2, 97, 12), (1, 17, 2), (1, 257, 1)])
+@pytest.mark.parametrize("B,N,H", [(2, 197, 6), (2, 138, 2), (1, 69, 3), (1, 7, 1), (1, 224, 1), (2, 97, 12), (1, 17, 2), (1, 257, 1),
+                                   (2, 577, 3), (1, 225, 2), (1, 640, 1), (1, 385, 2)])
 @pytest.mark.parametrize("with_size", [False, True])
 def test_attention_split(ops, B, N, H, with_size):
-    """(1, 257, 1): beyond the LDS-resident range the entry point forwards to the VALU twin."""
+    """Beyond 224 tokens (384 x 384 inputs: 577) the keys are walked in chunks of 128, twice (round 4; the fp32 VALU kernel served these
+    lengths before): 225 = the first length of that kernel, 257 / 385 = a chunk boundary plus one key, 640 = five full chunks, and the
+    column sums of several query groups meeting in the per-wave LDS rows."""
     qkv = _randn(N + H, B * N, 3 * H * 64, scale=1.5)
     size = (1 + torch.from_numpy(np.random.default_rng(N).integers(0, 4, (B, N)).astype(np.float32))) if with_size else None
     q, k, v = qkv.double().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
@@ -125,7 +128,7 @@ def _decisions_match(case, g, viz):
     return same
 
 
-@pytest.mark.parametrize("name", [n for n, c in GOLDEN_CASES.items() if not c.get("train_only")])      # 384 x 384: split GEMMs, VALU attention
+@pytest.mark.parametrize("name", [n for n, c in GOLDEN_CASES.items() if not c.get("train_only")])      # 384 x 384: split GEMMs, key-chunked split attention
 def test_model_bf16x3_free_running_against_reference_golden(golden_dir, name):
     case = GOLDEN_CASES[name]
     g = np.load(os.path.join(golden_dir, name + ".npz"))

@@ -312,6 +312,200 @@ int launch_attention_split(const float* qkv, float* out, float* cls_rows, const 
                      : launch_attention_split_<NT, false>(qkv, out, cls_rows, size, colsum_part, B, N, H, st);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Attention beyond 224 tokens (384^2 inputs: N = 577; round 4 -- until then bf16x3 fell back to the fp32 VALU kernel here: 14 ms per
+// launch, 79 % of a 53-ms DeiT-B forward at B = 64).  K and V hi/lo of a head no longer fit the LDS, so the keys are walked in chunks of
+// 128, TWICE per group of 128 queries (8 waves x 16): pass 1 finds every query's row maximum and normaliser (running max / rescaled
+// sum), pass 2 recomputes the scores, turns them into FINAL probabilities p = exp(s - m) / l and feeds P.V -- so the CLS row and the
+// column sums are exact side outputs, as in the one-chunk kernel above, whose fragment layouts and arithmetic this reuses.  One
+// workgroup per (image, head) walks the query groups; column sums are kept per wave in LDS and leave as the four rows the consumer adds.
+constexpr int AL_CH = 128, AL_CT = AL_CH / 16;        // keys per chunk, 16-key tiles per chunk
+constexpr int AL_VROW = AL_CH * 2 + 8;                 // one d row of a V^T chunk: 128 bf16 + 8 B pad
+constexpr int AL_NW = 8;                               // waves
+
+template <bool COLSUM>
+__global__ __launch_bounds__(64 * AL_NW, 1) void attention_split_long_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                                            float* __restrict__ cls_rows, const float* __restrict__ size,
+                                                                            float* __restrict__ colsum_part, int N, int H) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sKh = smem;
+  unsigned char* sKl = sKh + AL_CH * A_KROW;
+  unsigned char* sVh = sKl + AL_CH * A_KROW;
+  unsigned char* sVl = sVh + 64 * AL_VROW;
+  float* sBias = reinterpret_cast<float*>(sVl + 64 * AL_VROW);   // [AL_CH] log size, or -inf for keys past N
+  float* sCol = sBias + AL_CH;                                     // COLSUM: [AL_NW][nch * AL_CH]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frow = lane & 15, fq = lane >> 4;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int ldq = 3 * H * 64;
+  const float* base = qkv + (size_t)b * N * ldq;
+  const int qcol = h * 64, kcol = H * 64 + h * 64, vcol = 2 * H * 64 + h * 64;
+  const int nch = (N + AL_CH - 1) / AL_CH, NPk = nch * AL_CH;
+  if (COLSUM)
+    for (int i = tid; i < AL_NW * NPk; i += 64 * AL_NW) sCol[i] = 0.f;
+
+  // K (and V) of chunk c into the LDS images; every thread passes both barriers
+  auto stage = [&](int c, bool with_v) __attribute__((always_inline)) {
+    __syncthreads();                               // the previous chunk's fragment reads are done
+    for (int e = tid; e < AL_CH * 16; e += 64 * AL_NW) {
+      const int kl_ = e >> 4, d4 = (e & 15) * 4, key = c * AL_CH + kl_;
+      f32x4 kv = f32x4{0.f, 0.f, 0.f, 0.f}, vv = kv;
+      if (key < N) {
+        kv = *reinterpret_cast<const f32x4*>(base + (size_t)key * ldq + kcol + d4);
+        if (with_v) vv = *reinterpret_cast<const f32x4*>(base + (size_t)key * ldq + vcol + d4);
+      }
+      const HiLo k0 = split2(kv[0], kv[1]), k1 = split2(kv[2], kv[3]);
+      *reinterpret_cast<u32x2*>(sKh + kl_ * A_KROW + d4 * 2) = u32x2{k0.hi, k1.hi};
+      *reinterpret_cast<u32x2*>(sKl + kl_ * A_KROW + d4 * 2) = u32x2{k0.lo, k1.lo};
+      if (with_v) {
+        const HiLo v0 = split2(vv[0], vv[1]), v1 = split2(vv[2], vv[3]);
+        unsigned short* th = reinterpret_cast<unsigned short*>(sVh);
+        unsigned short* tl = reinterpret_cast<unsigned short*>(sVl);
+        th[(d4 + 0) * (AL_VROW / 2) + kl_] = (unsigned short)(v0.hi & 0xffff);
+        th[(d4 + 1) * (AL_VROW / 2) + kl_] = (unsigned short)(v0.hi >> 16);
+        th[(d4 + 2) * (AL_VROW / 2) + kl_] = (unsigned short)(v1.hi & 0xffff);
+        th[(d4 + 3) * (AL_VROW / 2) + kl_] = (unsigned short)(v1.hi >> 16);
+        tl[(d4 + 0) * (AL_VROW / 2) + kl_] = (unsigned short)(v0.lo & 0xffff);
+        tl[(d4 + 1) * (AL_VROW / 2) + kl_] = (unsigned short)(v0.lo >> 16);
+        tl[(d4 + 2) * (AL_VROW / 2) + kl_] = (unsigned short)(v1.lo & 0xffff);
+        tl[(d4 + 3) * (AL_VROW / 2) + kl_] = (unsigned short)(v1.lo >> 16);
+      }
+    }
+    for (int kl_ = tid; kl_ < AL_CH; kl_ += 64 * AL_NW) {
+      const int key = c * AL_CH + kl_;
+      sBias[kl_] = key < N ? (size ? logf(size[(size_t)b * N + key]) : 0.f) : -INFINITY;
+    }
+    __syncthreads();
+  };
+
+  const int nqg = (N + 16 * AL_NW - 1) / (16 * AL_NW);
+  for (int qg = 0; qg < nqg; ++qg) {
+    const int q = (qg * AL_NW + wave) * 16 + frow;
+    const bool qok = q < N;
+    bf16x8 qh[2], ql[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f}, c = a;
+      if (qok) {
+        a = *reinterpret_cast<const f32x4*>(base + (size_t)q * ldq + qcol + 32 * ks + 8 * fq);
+        c = *reinterpret_cast<const f32x4*>(base + (size_t)q * ldq + qcol + 32 * ks + 8 * fq + 4);
+      }
+      const HiLo p0 = split2(a[0], a[1]), p1 = split2(a[2], a[3]), p2 = split2(c[0], c[1]), p3 = split2(c[2], c[3]);
+      qh[ks] = __builtin_bit_cast(bf16x8, u32x4{p0.hi, p1.hi, p2.hi, p3.hi});
+      ql[ks] = __builtin_bit_cast(bf16x8, u32x4{p0.lo, p1.lo, p2.lo, p3.lo});
+    }
+    // scores of the staged chunk: s[t][r] = key 16 t + 4 fq + r of the chunk, query frow -- scaled, key bias added (-inf past N)
+    f32x4 s[AL_CT];
+    auto scores = [&]() __attribute__((always_inline)) {
+#pragma unroll
+      for (int t = 0; t < AL_CT; ++t) {
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const unsigned char* p = sKh + (t * 16 + frow) * A_KROW + (4 * ks + fq) * 16;
+          const bf16x8 kh = *reinterpret_cast<const bf16x8*>(p);
+          const bf16x8 kl = *reinterpret_cast<const bf16x8*>(p + AL_CH * A_KROW);
+          a = mfma3(kh, kl, qh[ks], ql[ks], a);
+        }
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(sBias + t * 16 + 4 * fq);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = a[r] * 0.125f + bv[r];
+        s[t] = a;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    // ---- pass 1: row maximum and normaliser
+    float m = -INFINITY, l = 0.f;                  // l: this lane's share (its 4 keys of every tile); summed over fq at the end
+    for (int c = 0; c < nch; ++c) {
+      stage(c, false);
+      scores();
+      float cm = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < AL_CT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cm = fmaxf(cm, s[t][r]);
+      cm = fmaxf(cm, __shfl_xor(cm, 16, 64));
+      cm = fmaxf(cm, __shfl_xor(cm, 32, 64));
+      const float mn = fmaxf(m, cm);
+      float add = 0.f;
+      if (mn != -INFINITY) {
+#pragma unroll
+        for (int t = 0; t < AL_CT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) add += expf(s[t][r] - mn);
+        l = l * expf(m - mn) + add;                // exp(-inf - mn) = 0 on the first chunk
+      }
+      m = mn;
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    // ---- pass 2: final probabilities, side outputs, P.V
+    f32x4 o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < nch; ++c) {
+      stage(c, true);
+      scores();
+#pragma unroll
+      for (int t = 0; t < AL_CT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[t][r] = expf(s[t][r] - m) * inv;       // attn = attn.softmax(-1); 0 on keys past N
+      if (cls_rows != nullptr && q == 0) {
+#pragma unroll
+        for (int t = 0; t < AL_CT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = c * AL_CH + t * 16 + 4 * fq + r;
+            if (key < N) cls_rows[((size_t)b * H + h) * N + key] = s[t][r];
+          }
+      }
+      if (COLSUM) {                                // this wave's 16 queries, summed over the frow lanes; one LDS row per wave
+#pragma unroll
+        for (int t = 0; t < AL_CT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = qok ? s[t][r] : 0.f;
+            v += __shfl_xor(v, 1, 64);
+            v += __shfl_xor(v, 2, 64);
+            v += __shfl_xor(v, 4, 64);
+            v += __shfl_xor(v, 8, 64);
+            if (frow == 0) sCol[wave * NPk + c * AL_CH + t * 16 + 4 * fq + r] += v;
+          }
+      }
+#pragma unroll
+      for (int u = 0; u < AL_CT / 2; ++u) {
+        const f32x4 pa = s[2 * u], pb = s[2 * u + 1];
+        const HiLo p0 = split2(pa[0], pa[1]), p1 = split2(pa[2], pa[3]), p2 = split2(pb[0], pb[1]), p3 = split2(pb[2], pb[3]);
+        const bf16x8 ph = __builtin_bit_cast(bf16x8, u32x4{p0.hi, p1.hi, p2.hi, p3.hi});
+        const bf16x8 pl = __builtin_bit_cast(bf16x8, u32x4{p0.lo, p1.lo, p2.lo, p3.lo});
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const unsigned char* p = sVh + (i * 16 + frow) * AL_VROW + (32 * u + 4 * fq) * 2;
+          const u32x2 a0 = *reinterpret_cast<const u32x2*>(p), a1 = *reinterpret_cast<const u32x2*>(p + 32);
+          const u32x2 b0 = *reinterpret_cast<const u32x2*>(p + 64 * AL_VROW), b1 = *reinterpret_cast<const u32x2*>(p + 64 * AL_VROW + 32);
+          const bf16x8 vh = __builtin_bit_cast(bf16x8, u32x4{a0[0], a0[1], a1[0], a1[1]});
+          const bf16x8 vl = __builtin_bit_cast(bf16x8, u32x4{b0[0], b0[1], b1[0], b1[1]});
+          o[i] = mfma3(vh, vl, ph, pl, o[i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (qok) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<f32x4*>(out + ((size_t)b * N + q) * (H * 64) + h * 64 + i * 16 + 4 * fq) = o[i];
+    }
+  }
+  if (COLSUM) {                                    // rows w and w + 4 of the per-wave sums -> the consumer's four rows (fixed order)
+    __syncthreads();
+    for (int i = tid; i < 4 * N; i += 64 * AL_NW) {
+      const int w = i / N, key = i - w * N;
+      colsum_part[(((size_t)b * H + h) * 4 + w) * N + key] = sCol[w * NPk + key] + sCol[(w + 4) * NPk + key];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int tr_gemm_split(const float* A, const float* W, const float* bias, float* out, const float* aux, int aux_i, int M,
@@ -342,10 +536,24 @@ extern "C" int tr_attention_split(const float* qkv, float* out, float* cls_rows,
                                   int H, tr_stream_t s) {
   TR_REQUIRE(qkv && out, TR_ERR_NULL, "tr_attention_split: null pointer");
   TR_REQUIRE(B > 0 && H > 0 && N >= 1, TR_ERR_SHAPE, "tr_attention_split: need B, H, N >= 1");
-  if (N > 16 * A_MAXT)                       // K/V hi+lo of a head no longer fit the LDS: the VALU twin (N <= 640)
-    return tr_attention_f32(qkv, out, cls_rows, size, colsum_part, B, N, H, s);
   TR_REQUIRE(tr_aligned16(qkv) && tr_aligned16(out), TR_ERR_ALIGN, "tr_attention_split: pointers must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(s);
+  if (N > 16 * A_MAXT) {                     // K/V hi+lo of a head no longer fit the LDS: keys in chunks of 128, two passes
+    static const bool twin = getenv("TR_SPLIT_LONG_OFF") != nullptr;        // lab switch: the fp32 VALU kernel that served these lengths before
+    if (twin || N > 1024) return tr_attention_f32(qkv, out, cls_rows, size, colsum_part, B, N, H, s);
+    tr_prof_note("attention_split_long", 18.0 * B * H * (double)N * N * 64, 16.0 * B * N * H * 64);
+    const int nch = (N + AL_CH - 1) / AL_CH;
+    const size_t lds = (size_t)2 * AL_CH * A_KROW + (size_t)2 * 64 * AL_VROW + (size_t)AL_CH * 4 + (colsum_part ? (size_t)AL_NW * nch * AL_CH * 4 : 0);
+    if (colsum_part) {
+      TR_RESERVE_LDS(reinterpret_cast<const void*>(attention_split_long_kernel<true>), lds, "tr_attention_split");
+      hipLaunchKernelGGL(attention_split_long_kernel<true>, dim3(B * H), dim3(64 * AL_NW), lds, st, qkv, out, cls_rows, size, colsum_part, N, H);
+    } else {
+      TR_RESERVE_LDS(reinterpret_cast<const void*>(attention_split_long_kernel<false>), lds, "tr_attention_split");
+      hipLaunchKernelGGL(attention_split_long_kernel<false>, dim3(B * H), dim3(64 * AL_NW), lds, st, qkv, out, cls_rows, size, colsum_part, N, H);
+    }
+    TR_CHECK_LAUNCH("tr_attention_split");
+    return TR_OK;
+  }
   tr_prof_note("attention_split", 12.0 * B * H * (double)N * N * 64, 16.0 * B * N * H * 64);
   const int nt = (N + 15) / 16;
   int rc;

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Run a few forwards of one registered model (for rocprofv3):  python3 tools/run_model.py tome_small_patch16_224 r16 [batch] [iters] [img_size]
-keep spec: 'r16' (ToMe: 16 merged per block, every block) or a float keep_rate with reduction_loc 3,6,9."""
+"""Run a few forwards of one registered model (for rocprofv3):  python3 tools/run_model.py tome_small_patch16_224 r16 [batch] [iters] [img_size] [precision]
+keep spec: 'r16' (ToMe: 16 merged per block, every block) or a float keep_rate with reduction_loc 3,6,9; precision bf16 (default) | bf16x3 | fp32."""
 import os
 import sys
 import time
@@ -19,6 +19,8 @@ if spec.startswith("r"):
 else:
     kr, loc = [float(spec)], [3, 6, 9]
 m = build_model(name, kr, loc, "cuda", img_size=img)
+if len(sys.argv) > 6:
+    m.precision = sys.argv[6]
 x = torch.randn(B, 3, img, img, generator=torch.Generator().manual_seed(1)).cuda()
 for _ in range(3):
     m(x)
