@@ -76,6 +76,17 @@ int tr_patch_embed_bf16(const float* img, const uint16_t* W, const float* bias, 
 int tr_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* bias, void* out, const float* aux, int aux_i,
                  int M, int N, int K, int epilogue, tr_stream_t s);
 
+/* a4, eval forward: the whole timm Mlp of a block (models/topk.py:78 construction, :95 `x = x + self.mlp(self.norm2(x))`; the residual
+ * add stays in the next LayerNorm) in ONE launch: out bf16 [M,D] = fc2(gelu_erf(fc1(xn))) with the [M,Hd] hidden activation never
+ * leaving the CU (csrc/tr_mlp_fused.hip).  Bit-identical to tr_gemm_bf16(TR_EPI_GELU_BF16) followed by tr_gemm_bf16(TR_EPI_BF16).
+ * `packed`: the two weight matrices in fragment-major order, tr_mlp_pack_bytes(D,Hd) bytes, written by tr_mlp_pack_bf16 from the
+ * bf16 [Hd,D] / [D,Hd] matrices (repack whenever they change).  tr_mlp_fused_supported: D == 384, Hd %% 32 == 0 (other widths: the pair). */
+int tr_mlp_fused_supported(int D, int Hd);
+size_t tr_mlp_pack_bytes(int D, int Hd);
+int tr_mlp_pack_bf16(const uint16_t* fc1_w, const uint16_t* fc2_w, void* packed, int D, int Hd, tr_stream_t s);
+int tr_mlp_fused_bf16(const uint16_t* xn, const void* packed, const float* fc1_b, const float* fc2_b, uint16_t* out, int M, int D, int Hd,
+                      tr_stream_t s);
+
 /* a4 nn.LayerNorm(D, eps) rows of the fp32 residual stream -> bf16 (topk.py:86 norm1, :95 norm2, :201 norm), with the
  * PENDING residual add folded in: if delta != NULL (bf16 rows at stride ldd: the output of attn.proj / mlp.fc2),
  * x[row] += delta[row] is written back first (`x = x + drop_path(...)`, topk.py:87 / :95), then y[row] = LN(x[row]).

@@ -105,6 +105,43 @@ def test_gemm_half_tile_tail_round(ops, M, N, K, why, epi):
     assert torch.equal(out, out2) and not torch.isnan(out2.float()).any()
 
 
+# ------------------------------------------------------------------------------------------ fused eval Mlp (fc1 -> GELU -> fc2, one launch)
+@pytest.mark.parametrize("M", [1, 77, 128, 129, 1000, 197 * 8, 32768 + 5, 50432])
+@pytest.mark.parametrize("Hd", [1536, 64, 96])
+def test_mlp_fused_is_bit_identical_to_the_gemm_pair(ops, M, Hd):
+    """tr_mlp_fused_bf16 (timm Mlp of the eval forward, models/topk.py:95) keeps the hidden activation on the CU; by construction -- same
+    MFMA, same operand maps, accumulators that start at the bias, K in the same 32-deep steps, same GELU fit, hidden rounded to bf16 at the
+    same point -- its output equals tr_gemm_bf16(GELU_BF16) -> tr_gemm_bf16(BF16) BIT FOR BIT, for ragged last blocks, several blocks per
+    workgroup, and hidden widths of 2, 3 and 48 steps.  Sampled rows are also held against the float64 Mlp on the bf16-rounded operands."""
+    if M > 2000 and Hd != 1536:
+        pytest.skip("large M only at the model's hidden width")
+    D = 384
+    rng = _rng(M * 3 + Hd)
+    x = _randn(rng, M, D).bfloat16()
+    w1, w2 = _randn(rng, Hd, D, scale=0.05).bfloat16(), _randn(rng, D, Hd, scale=0.05).bfloat16()
+    b1, b2 = _randn(rng, Hd, scale=0.1), _randn(rng, D, scale=0.1)
+    xd, w1d, w2d, b1d, b2d = x.cuda(), w1.cuda(), w2.cuda(), b1.cuda(), b2.cuda()
+    h = ops.gemm(xd, w1d, b1d, ops.TR_EPI_GELU_BF16)
+    want = ops.gemm(h, w2d, b2d, ops.TR_EPI_BF16)
+    pk = ops.mlp_pack(w1d, w2d)
+    guard = torch.full((M + 3, D), float("nan"), dtype=torch.bfloat16, device="cuda")        # rows M.. must stay untouched
+    got = ops.mlp_fused(xd, pk, b1d, b2d, out=guard[:M])
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16)), \
+        f"{int((got.view(torch.int16) != want.view(torch.int16)).sum())} of {got.numel()} elements differ from the two-launch pair"
+    assert torch.isnan(guard[M:].float()).all(), "rows beyond M were written"
+    rows = torch.cat([torch.arange(0, min(M, 140)), torch.arange(max(0, M - 140), M), torch.arange(0, M, 1009)]).unique()
+    hid = oracle.gelu_erf(x[rows].double() @ w1.double().t() + b1.double())
+    ref = _bf(hid.float()).double() @ w2.double().t() + b2.double()
+    # the hidden layer is rounded to bf16 (a GELU-fit difference of 2.6e-5 can flip that rounding: one bf16 step of one hidden unit, times a weight)
+    torch.testing.assert_close(got[rows.cuda()].cpu().double(), ref, atol=2e-2, rtol=1.2e-2)
+
+
+def test_mlp_fused_rejects_other_widths(ops):
+    w1, w2 = torch.zeros(3072, 768, dtype=torch.bfloat16, device="cuda"), torch.zeros(768, 3072, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(ValueError, match="does not serve"):
+        ops.mlp_pack(w1, w2)
+
+
 def test_gemm_operand_roles_not_transposed(ops):
     """A = I-like probe with an ASYMMETRIC weight: catches a swapped row/col map in the accumulator write."""
     M = N = K = 128

@@ -1,0 +1,487 @@
+// Fused eval MLP for gfx950:  out = fc2(gelu(fc1(x)))  with the hidden activation never leaving the CU.
+//
+// Replaces the timm Mlp of a block as the reference calls it (topk.py:78 construction, :95 `x = x + self.mlp(self.norm2(x))`; the residual add
+// stays in the next LayerNorm kernel like before) for the EVAL forward: fc1 -> GELU -> fc2 in ONE launch instead of
+// tr_gemm_bf16(TR_EPI_GELU_BF16) + tr_gemm_bf16(TR_EPI_BF16) with a [M, 4D] bf16 round trip through HBM between them.
+// Bit-identical to that pair by construction: same MFMA (16x16x32 bf16), same operand-to-lane maps, accumulators that start at the bias,
+// K walked in the same 32-deep steps in the same order, the same GELU fit on the fp32 accumulator, the hidden rounded to bf16 at the same
+// point.  (So the executor may pick either per shape; tests/test_hip_ops.py::test_mlp_fused_* compares them bit for bit.)
+//
+// Structure (one persistent 512-thread workgroup per CU, 128 token rows per block, D = 384):
+//   * Waves 0-3 ("P", one per SIMD) own 32 token rows each and keep their x rows IN REGISTERS as the MFMA B operand (96 VGPRs).
+//     Per 32 hidden units (one "step") they compute h^T = W1_step . x^T (48 MFMAs), apply GELU, round to bf16 -- and because the W1 rows
+//     of a step are fed in the order  tile t2, row r -> hidden 8(r>>2) + 4 t2 + (r&3),  a lane's eight results ARE the B-operand
+//     fragment of fc2's MFMA over those 32 hidden units (the S^T = K.Q^T trick of the attention kernel).  2 KB per wave and step go
+//     through LDS to the partner wave.
+//   * Waves 4-7 ("C", the SIMD partners) own the same 32 token rows and keep the whole 32 x 384 fp32 output accumulator in registers
+//     (192 VGPRs); per step 48 MFMAs  acc += W2[:, step] . h.  One epilogue per 128 x 384 x 1536 x 4 FLOP instead of one per tile.
+//   * The two MFMA streams of a SIMD are independent, so one wave's GELU / LDS waits / DMA issue stalls sit under the partner's MFMAs.
+//   * Weights come from a FRAGMENT-MAJOR packed copy (tr_mlp_pack_bf16: per step 24 KiB of W1 fragments + 24 KiB of W2 fragments, each
+//     fragment 1 KiB in lane order), so a DMA piece is 1 KiB contiguous -> LDS lane-linear, and every fragment read is a linear
+//     conflict-free ds_read_b128.  3-slot ring of 48-KiB entries (entry t = W1 of step t | W2 of step t-1: what time step t consumes),
+//     two entries in flight behind counted vmcnt waits, one s_barrier per step; all eight waves issue 6 of the 48 pieces per step.
+//   * FLOP per byte through the CU's L2 -> LDS feed: 128 (a 256 x 128 GEMM tile: 85); HBM traffic per 128 rows: 96 KB in, 96 KB out.
+#include "tr_common.h"
+
+namespace {
+
+// lab switches (tools/lab/build_variant.sh): TR_ABLATE_NO_DMA (no weight stream), TR_ABLATE_NO_GELU (identity activation), TR_ABLATE_NO_MFMA
+#ifdef TR_ABLATE_NO_MFMA
+#define MF_MFMA(a, b, c) ([&] { asm volatile("" ::"v"(a), "v"(b)); return c; }())
+#else
+#define MF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#endif
+#ifdef TR_ABLATE_NO_GELU
+__device__ __forceinline__ f32x2 mf_gelu2(f32x2 v) { return v; }
+#else
+__device__ __forceinline__ f32x2 mf_gelu2(f32x2 v) { return gelu2(v); }
+#endif
+
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+
+// diagnostic build only (never in the product): s_memtime stamps of workgroup 8, P wave 0 and C wave 4, first 64 steps, written BEHIND the
+// output (the lab allocates the room: tools/mlp_lab.py --stamps)
+#ifdef TR_DIAG_STAMPS
+#define MF_STAMP(k) ts_[k] = __builtin_amdgcn_s_memtime()
+#define MF_STAMP_DECL unsigned long long ts_[4] = {0, 0, 0, 0}
+#define MF_STAMP_DUMP(role, step)                                                                                                     \
+  do {                                                                                                                                \
+    if (bid == 8 && pr == 0 && lane == 0 && (step) < 64) {                                                                            \
+      unsigned long long* st_ = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(outp) + out_bytes) + ((role) * 64 + (step)) * 4; \
+      st_[0] = ts_[0]; st_[1] = ts_[1]; st_[2] = ts_[2]; st_[3] = ts_[3];                                                             \
+    }                                                                                                                                 \
+  } while (0)
+#define MF_CLOCK_BEGIN const unsigned long long ck0_ = __builtin_amdgcn_s_memtime(), rt0_ = __builtin_amdgcn_s_memrealtime()
+#define MF_CLOCK_END                                                                                                                  \
+  do {                                                                                                                                \
+    if (bid == 8 && tid == 0) {                                                                                                       \
+      unsigned long long* st_ = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(outp) + out_bytes) + 512;      \
+      st_[0] = __builtin_amdgcn_s_memtime() - ck0_;                                                                                   \
+      st_[1] = __builtin_amdgcn_s_memrealtime() - rt0_;                                                                               \
+    }                                                                                                                                 \
+  } while (0)
+#else
+#define MF_CLOCK_BEGIN do { } while (0)
+#define MF_CLOCK_END do { } while (0)
+#define MF_STAMP(k) do { } while (0)
+#define MF_STAMP_DECL do { } while (0)
+#define MF_STAMP_DUMP(role, step) do { } while (0)
+#endif
+
+constexpr int MF_D = 384;                      // embed dim this instantiation serves
+constexpr int MF_KS = MF_D / 32;               // 12: 32-deep k-steps of fc1
+constexpr int MF_NI = MF_D / 16;               // 24: 16-column groups of fc2's output
+constexpr int MF_W1FR = 2 * MF_KS;             // 24 W1 fragments per step (2 row tiles x 12 k-steps)
+constexpr int MF_FR = MF_W1FR + MF_NI;         // 48 fragments = DMA pieces per entry
+constexpr int MF_ENTRY = MF_FR * 1024;         // 48 KiB
+constexpr int MF_NSLOT = 3;
+constexpr int MF_HBUF = 2048;                  // one hidden fragment pair (2 token groups x 64 lanes x 16 B)
+constexpr int MF_LDS = MF_NSLOT * MF_ENTRY + 4 * 2 * MF_HBUF;     // 163,840 B: all of the CU's LDS
+constexpr int MF_ROWS = 128;                   // token rows per block (4 wave pairs x 32)
+
+__device__ __forceinline__ void mf_piece(const unsigned char* sbase, unsigned voff, unsigned lds_dst) {
+#ifndef TR_ABLATE_NO_DMA
+  asm volatile(
+      "s_mov_b32 m0, %[ld]\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %[o], %[b]"
+      :
+      : [o] "v"(voff), [b] "s"(sbase), [ld] "s"(lds_dst)
+      : "memory", "m0");
+#endif
+}
+
+template <int IMM>
+__device__ __forceinline__ bf16x8 mf_load_x(const uint16_t* sbase, unsigned voff) {
+  bf16x8 v;
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(sbase), "i"(IMM) : "memory");
+  return v;
+}
+// refill IN PLACE ("+v": input and output share the register, so the not-taken side of the uniform branch around it needs no copy)
+template <int IMM>
+__device__ __forceinline__ void mf_reload_x(bf16x8& v, const uint16_t* sbase, unsigned voff) {
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "+v"(v) : "v"(voff), "s"(sbase), "i"(IMM) : "memory");
+}
+template <int IMM>
+__device__ __forceinline__ f32x4 mf_load_f4(const float* sbase, unsigned voff) {
+  f32x4 v;
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(sbase), "i"(IMM) : "memory");
+  return v;
+}
+
+#define MF_TIE_X(x)                                                                                                                   \
+  "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]), "+v"(x[8]), "+v"(x[9]), "+v"(x[10]), \
+      "+v"(x[11])
+
+// Fragment-major packing of one block's Mlp weights.  pk[step s][fragment f][lane][8 bf16]:
+//   f <  24: W1 fragment (tile t2 = f / 12, k-step ks = f % 12): lane (r = l & 15, q = l >> 4) holds W1[32 s + 8 (r >> 2) + 4 t2 + (r & 3)][32 ks + 8 q ..]
+//   f >= 24: W2 fragment of column group i = f - 24:             lane (r, q) holds W2[16 i + r][32 s + 8 q ..]
+__global__ __launch_bounds__(256) void mlp_pack_kernel(const uint16_t* __restrict__ W1, const uint16_t* __restrict__ W2, u32x4* __restrict__ pk, int D, int Hd) {
+  const int ks_n = D / 32, ni = D / 16, fr = 2 * ks_n + ni;
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);          // (step, fragment)
+  const int lane = threadIdx.x & 63;
+  const int s = g / fr, f = g % fr;
+  if (s >= Hd / 32) return;
+  const int r = lane & 15, q = lane >> 4;
+  const uint16_t* src;
+  if (f < 2 * ks_n) {
+    const int t2 = f / ks_n, ks = f % ks_n;
+    src = W1 + (size_t)(32 * s + 8 * (r >> 2) + 4 * t2 + (r & 3)) * D + 32 * ks + 8 * q;
+  } else {
+    const int i = f - 2 * ks_n;
+    src = W2 + (size_t)(16 * i + r) * Hd + 32 * s + 8 * q;
+  }
+  pk[(size_t)g * 64 + lane] = *reinterpret_cast<const u32x4*>(src);
+}
+
+__global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __restrict__ xn, const unsigned char* __restrict__ pk,
+                                                           const float* __restrict__ b1, const float* __restrict__ b2,
+                                                           uint16_t* __restrict__ outp, int M, int NS, unsigned out_bytes) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[MF_LDS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pr = wave & 3;                                   // wave pair = 32-row slice of the block
+  const int G = gridDim.x, bid = blockIdx.x;
+  const int nblk = (M + MF_ROWS - 1) / MF_ROWS;
+  if (bid >= nblk) return;
+  const int my_blocks = (nblk - bid + G - 1) / G;
+  const int T = my_blocks * NS;                              // time steps: P works in 0..T-1, C in 1..T
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const int frow = lane & 15, fq = lane >> 4;
+  unsigned char* const hb = smem + MF_NSLOT * MF_ENTRY + pr * (2 * MF_HBUF);     // this pair's two hidden buffers
+
+  // ---- DMA cursor: the next entry to issue (e), the steps its two halves come from, its ring slot.  Wave w issues pieces w, w+8, .., w+40.
+  int ld_e = 0, ld_w1 = 0, ld_w2 = NS - 1, ld_slot = 0;
+  auto issue_piece_q = [&](int q) __attribute__((always_inline)) {
+    const int f = wave + 8 * q;
+    const int step = (q < 3) ? ld_w1 : ld_w2;
+    mf_piece(pk + (size_t)step * MF_ENTRY + f * 1024, lane16, lds0 + ld_slot * MF_ENTRY + f * 1024);
+  };
+  auto advance_entry = [&]() __attribute__((always_inline)) {
+    ++ld_e;
+    ld_w2 = ld_w1;
+    ld_w1 = (ld_w1 + 1 == NS) ? 0 : ld_w1 + 1;
+    ld_slot = (ld_slot + 1 == MF_NSLOT) ? 0 : ld_slot + 1;
+  };
+
+  if (wave < 4) {
+    // =============================================================== P: fc1 + GELU
+    bf16x8 x0[MF_KS], x1[MF_KS];                 // B-operand fragments of this wave's two 16-row groups, all 12 k-steps
+    f32x4 bn0, bn1;                              // bias fragments of the NEXT step's two row tiles
+    const unsigned boff = (unsigned)fq * 32u;    // lane (.., q) starts at hidden 8 q of the step: b1[32 s + 8 q + 4 t2 + e]
+    auto x_offsets = [&](int blk, unsigned& o0, unsigned& o1) __attribute__((always_inline)) {
+      const int m = blk * MF_ROWS + pr * 32 + frow;
+      o0 = ((unsigned)min(m, M - 1) * MF_D + 8u * fq) * 2u;
+      o1 = ((unsigned)min(m + 16, M - 1) * MF_D + 8u * fq) * 2u;
+    };
+#define MF_LOAD_X(ks)                          \
+  x0[ks] = mf_load_x<(ks) * 64>(xn, xo0);      \
+  x1[ks] = mf_load_x<(ks) * 64>(xn, xo1)
+#define MF_RELOAD_X(ks)                        \
+  mf_reload_x<(ks) * 64>(x0[ks], xn, xo0);     \
+  mf_reload_x<(ks) * 64>(x1[ks], xn, xo1)
+    {
+      unsigned xo0, xo1;
+      x_offsets(bid, xo0, xo1);
+      MF_LOAD_X(0); MF_LOAD_X(1); MF_LOAD_X(2); MF_LOAD_X(3); MF_LOAD_X(4); MF_LOAD_X(5);
+      MF_LOAD_X(6); MF_LOAD_X(7); MF_LOAD_X(8); MF_LOAD_X(9); MF_LOAD_X(10); MF_LOAD_X(11);
+    }
+    bn0 = mf_load_f4<0>(b1, boff);
+    bn1 = mf_load_f4<16>(b1, boff);
+    // entries 0 and 1 (the loop issues entry t+2 during step t)
+#pragma unroll
+    for (int q = 0; q < 6; ++q) issue_piece_q(q);
+    advance_entry();
+#pragma unroll
+    for (int q = 0; q < 6; ++q) issue_piece_q(q);
+    advance_entry();
+    asm volatile("s_waitcnt vmcnt(6)" : "+v"(bn0), "+v"(bn1), MF_TIE_X(x0), MF_TIE_X(x1)::"memory");
+    __builtin_amdgcn_s_barrier();               // B_0: entry 0 has landed
+    asm volatile("" ::: "memory");
+
+    int t = 0, cslot = 0;
+    MF_CLOCK_BEGIN;
+    // One step.  LAST: the block's last step -- the x registers are dead after their last MFMA and are refilled with the NEXT block's rows
+    // right there (the loads have a whole step to land), at the price of a vmcnt(0) at the end of this one step.
+    auto p_step = [&](int s, const bool last, int next_blk) __attribute__((always_inline)) {
+      const unsigned char* slot = smem + cslot * MF_ENTRY + lane16;
+      MF_STAMP_DECL;
+      MF_STAMP(0);
+      f32x4 a00 = bn0, a01 = bn0, a10 = bn1, a11 = bn1;
+      // the next step's bias: older than this step's DMA pieces, so the counted wait at the end of the step retires it
+      {
+        const int sn = (s + 1 == NS) ? 0 : s + 1;
+        bn0 = mf_load_f4<0>(b1 + 32 * sn, boff);
+        bn1 = mf_load_f4<16>(b1 + 32 * sn, boff);
+      }
+      unsigned xo0 = 0, xo1 = 0;
+      const bool reload = last && next_blk >= 0;
+      if (reload) x_offsets(next_blk, xo0, xo1);
+      const bool dma = ld_e <= T;
+      bf16x8 wA[4], wB[4];
+#define MF_READW(buf, k)                                                                        \
+  buf[0] = *reinterpret_cast<const bf16x8*>(slot + (2 * (k)) * 1024);                          \
+  buf[1] = *reinterpret_cast<const bf16x8*>(slot + (MF_KS + 2 * (k)) * 1024);                  \
+  buf[2] = *reinterpret_cast<const bf16x8*>(slot + (2 * (k) + 1) * 1024);                      \
+  buf[3] = *reinterpret_cast<const bf16x8*>(slot + (MF_KS + 2 * (k) + 1) * 1024)
+#define MF_PWIN(cur, nxt, k)                                                                    \
+  do {                                                                                          \
+    if (dma) issue_piece_q(k);                                                                  \
+    if ((k) < 5) { MF_READW(nxt, (k) + 1); }                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    a00 = MF_MFMA(cur[0], x0[2 * (k)], a00);           \
+    a01 = MF_MFMA(cur[0], x1[2 * (k)], a01);           \
+    a10 = MF_MFMA(cur[1], x0[2 * (k)], a10);           \
+    a11 = MF_MFMA(cur[1], x1[2 * (k)], a11);           \
+    a00 = MF_MFMA(cur[2], x0[2 * (k) + 1], a00);       \
+    a01 = MF_MFMA(cur[2], x1[2 * (k) + 1], a01);       \
+    a10 = MF_MFMA(cur[3], x0[2 * (k) + 1], a10);       \
+    a11 = MF_MFMA(cur[3], x1[2 * (k) + 1], a11);       \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    if (reload) { MF_RELOAD_X(2 * (k)); MF_RELOAD_X(2 * (k) + 1); }                             \
+  } while (0)
+      MF_READW(wA, 0);
+      MF_PWIN(wA, wB, 0);
+      MF_PWIN(wB, wA, 1);
+      MF_PWIN(wA, wB, 2);
+      MF_PWIN(wB, wA, 3);
+      MF_PWIN(wA, wB, 4);
+      MF_PWIN(wB, wA, 5);
+#undef MF_PWIN
+#undef MF_READW
+      if (dma) advance_entry();
+      MF_STAMP(1);
+      // GELU, round, and the lane's eight hidden values are the partner's B fragment: tile 0 gives k = 8q + 0..3, tile 1 k = 8q + 4..7
+      {
+        const f32x2 g0 = mf_gelu2(f32x2{a00[0], a00[1]}), g1 = mf_gelu2(f32x2{a00[2], a00[3]});
+        const f32x2 g2 = mf_gelu2(f32x2{a10[0], a10[1]}), g3 = mf_gelu2(f32x2{a10[2], a10[3]});
+        const u32x4 h0 = {pack_bf16x2(g0[0], g0[1]), pack_bf16x2(g1[0], g1[1]), pack_bf16x2(g2[0], g2[1]), pack_bf16x2(g3[0], g3[1])};
+        const f32x2 g4 = mf_gelu2(f32x2{a01[0], a01[1]}), g5 = mf_gelu2(f32x2{a01[2], a01[3]});
+        const f32x2 g6 = mf_gelu2(f32x2{a11[0], a11[1]}), g7 = mf_gelu2(f32x2{a11[2], a11[3]});
+        const u32x4 h1 = {pack_bf16x2(g4[0], g4[1]), pack_bf16x2(g5[0], g5[1]), pack_bf16x2(g6[0], g6[1]), pack_bf16x2(g7[0], g7[1])};
+        unsigned char* dst = hb + (t & 1) * MF_HBUF + lane16;
+        *reinterpret_cast<u32x4*>(dst) = h0;
+        *reinterpret_cast<u32x4*>(dst + 1024) = h1;
+      }
+      MF_STAMP(2);
+      // end of step t: entry t+1 has landed once only this step's six pieces remain (LAST: the x reload is interleaved with them -> drain)
+      // ONE tied statement on every path (two tied statements on an if/else made hipcc copy the 96 x registers between its two allocations)
+      if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(6)" : "+v"(bn0), "+v"(bn1), MF_TIE_X(x0), MF_TIE_X(x1)::"memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();             // B_{t+1}
+      asm volatile("" ::: "memory");
+      MF_STAMP(3);
+      MF_STAMP_DUMP(0, t);
+      ++t;
+      cslot = (cslot + 1 == MF_NSLOT) ? 0 : cslot + 1;
+    };
+    for (int bi = 0; bi < my_blocks; ++bi) {
+      const int next_blk = bi + 1 < my_blocks ? bid + (bi + 1) * G : -1;
+      for (int s = 0; s < NS; ++s) {
+        int last = __builtin_amdgcn_readfirstlane(s == NS - 1 ? 1 : 0);
+        asm volatile("" : "+s"(last));          // opaque: hipcc must not peel the last step into a second copy of the loop body (a second allocation of the 96 x registers)
+        p_step(s, last != 0, next_blk);
+      }
+    }
+#undef MF_LOAD_X
+#undef MF_RELOAD_X
+    MF_CLOCK_END;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
+
+  // ================================================================= C: fc2, the 32 x 384 accumulator in registers
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(outp, 0, (int)out_bytes, 0x00020000);
+  // fc2's bias lives in six registers (b2[lane + 64 q]); a column group's fragment value b2[16 i + 4 fq + e] is fetched with ds_bpermute
+  // (the LDS crossbar, no LDS memory: the 160 KiB are all taken): register i >> 2, lane 16 (i & 3) + 4 fq + e
+  float b2r[MF_D / 64];
+#pragma unroll
+  for (int q = 0; q < MF_D / 64; ++q) b2r[q] = b2[lane + 64 * q];
+  auto bias_frag = [&](int i, unsigned bp) __attribute__((always_inline)) {
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      v[e] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)(bp + 4u * (16 * (i & 3) + e)), __builtin_bit_cast(int, b2r[i >> 2])));
+    return v;
+  };
+  f32x4 acc[MF_NI][2];
+#pragma unroll
+  for (int i = 0; i < MF_NI; ++i) {
+    const f32x4 v = bias_frag(i, 16u * fq);
+    acc[i][0] = v;
+    acc[i][1] = v;
+  }
+#pragma unroll
+  for (int q = 0; q < 6; ++q) issue_piece_q(q);
+  advance_entry();
+#pragma unroll
+  for (int q = 0; q < 6; ++q) issue_piece_q(q);
+  advance_entry();
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                 // B_0
+  asm volatile("" ::: "memory");
+  // time step 0: nothing to consume yet; entry 2 goes out
+  if (ld_e <= T) {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) issue_piece_q(q);
+    advance_entry();
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();                 // B_1
+  asm volatile("" ::: "memory");
+
+  int t = 1, cslot = 1;
+  // One step at time t: consumes the hidden fragments of time t-1 and the W2 half of entry t.  EPI: that was the block's last step.
+  auto c_step = [&](const bool epi, int blk) __attribute__((always_inline)) {
+    const unsigned char* slot = smem + cslot * MF_ENTRY + MF_W1FR * 1024 + lane16;
+    const unsigned char* hsrc = hb + ((t - 1) & 1) * MF_HBUF + lane16;
+    MF_STAMP_DECL;
+    MF_STAMP(0);
+    const bf16x8 h0 = *reinterpret_cast<const bf16x8*>(hsrc);
+    const bf16x8 h1 = *reinterpret_cast<const bf16x8*>(hsrc + 1024);
+    const bool dma = ld_e <= T;
+    bf16x8 wA[4], wB[4];
+#define MF_READW(buf, k)                                                           \
+  buf[0] = *reinterpret_cast<const bf16x8*>(slot + (4 * (k)) * 1024);              \
+  buf[1] = *reinterpret_cast<const bf16x8*>(slot + (4 * (k) + 1) * 1024);          \
+  buf[2] = *reinterpret_cast<const bf16x8*>(slot + (4 * (k) + 2) * 1024);          \
+  buf[3] = *reinterpret_cast<const bf16x8*>(slot + (4 * (k) + 3) * 1024)
+#define MF_CWIN(cur, nxt, k)                                                                                       \
+  do {                                                                                                             \
+    if (dma) issue_piece_q(k);                                                                                     \
+    if ((k) < 5) { MF_READW(nxt, (k) + 1); }                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) {                                                             \
+      acc[4 * (k) + ii][0] = MF_MFMA(cur[ii], h0, acc[4 * (k) + ii][0]);  \
+      acc[4 * (k) + ii][1] = MF_MFMA(cur[ii], h1, acc[4 * (k) + ii][1]);  \
+    }                                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+  } while (0)
+    MF_READW(wA, 0);
+    MF_CWIN(wA, wB, 0);
+    MF_CWIN(wB, wA, 1);
+    MF_CWIN(wA, wB, 2);
+    MF_CWIN(wB, wA, 3);
+    MF_CWIN(wA, wB, 4);
+    MF_CWIN(wB, wA, 5);
+#undef MF_CWIN
+#undef MF_READW
+    if (dma) advance_entry();
+    MF_STAMP(1);
+    if (epi) {
+      // 32 x 384 fp32 -> bf16 rows.  A 16-row x 64-column slab goes through 2 KiB of LDS (the hidden buffer this step has just consumed;
+      // the partner writes the other one) so that every store covers whole 128-byte lines; swizzle and the one-ahead pipelining are those
+      // of gemm_bf16_pc's epilogue.  The accumulators restart at the bias for the next block.
+      unsigned char* stg = hb + ((t - 1) & 1) * MF_HBUF;
+      const int rrow = lane >> 3, rch = lane & 7;
+      unsigned voff_out = ((unsigned)(blk * MF_ROWS + pr * 32 + rrow) * MF_D + 8u * rch) * 2u;
+      unsigned bp0 = 16u * fq;                   // byte address of lane 4 fq for ds_bpermute
+      // opaque: computed here, once per block, instead of being hoisted out of the step loop as sixteen address registers + twenty-four offsets
+      asm volatile("" : "+v"(voff_out), "+v"(bp0));
+      const unsigned char* rd = stg + rrow * 128 + ((rch ^ rrow) << 4);
+      auto stage = [&](int c, int j) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const int i = 4 * c + ii;
+          const f32x4 v = acc[i][j];
+          u32x2 pk2;
+          pk2[0] = pack_bf16x2(v[0], v[1]);
+          pk2[1] = pack_bf16x2(v[2], v[3]);
+          *reinterpret_cast<u32x2*>(stg + frow * 128 + (((2 * ii + (fq >> 1)) ^ (frow & 7)) << 4) + (((fq & 1) ^ (frow >> 3)) << 3)) = pk2;
+        }
+      };
+      auto read_back = [&](u32x4 (&ln)[2]) __attribute__((always_inline)) {
+        ln[0] = *reinterpret_cast<const u32x4*>(rd);
+        const u32x4 tt = *reinterpret_cast<const u32x4*>(rd + 1024);
+        ln[1] = u32x4{tt[2], tt[3], tt[0], tt[1]};
+      };
+      // rows beyond M need no predicate: num_records = M * 768 bytes, so their offsets fail the descriptor's bounds check and the store is dropped.
+      // One offset register per lane and block; (row group, column chunk) go into the scalar offset.
+      auto store = [&](int c, int j, const u32x4 (&ln)[2]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+          __builtin_amdgcn_raw_buffer_store_b128(ln[r], orsrc, voff_out, ((16 * j + 8 * r) * MF_D + 64 * c) * 2, 0);
+      };
+      u32x4 lnA[2], lnB[2];
+      stage(0, 0); read_back(lnA);
+#pragma unroll
+      for (int c = 0; c < MF_NI / 4; ++c) {
+        // pass (c, 0) is staged and being read back into lnA on entry
+        stage(c, 1); store(c, 0, lnA); read_back(lnB);
+        if (c + 1 < MF_NI / 4) stage(c + 1, 0);
+        store(c, 1, lnB);
+        if (c + 1 < MF_NI / 4) read_back(lnA);
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const f32x4 v = bias_frag(4 * c + ii, bp0);
+          acc[4 * c + ii][0] = v;
+          acc[4 * c + ii][1] = v;
+        }
+      }
+    }
+    MF_STAMP(2);
+    if (t < T) {
+      // entry t+1 has landed once only what was issued after its pieces remains: this step's six pieces (if any went out) and the stores
+      if (!dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (epi) asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();             // B_{t+1}
+      asm volatile("" ::: "memory");
+    }
+    MF_STAMP(3);
+    MF_STAMP_DUMP(1, t);
+    ++t;
+    cslot = (cslot + 1 == MF_NSLOT) ? 0 : cslot + 1;
+  };
+  for (int bi = 0; bi < my_blocks; ++bi) {
+    // time steps bi*NS + 1 .. bi*NS + NS consume the block's steps 0 .. NS-1
+    for (int s = 0; s < NS; ++s) {
+      int last = __builtin_amdgcn_readfirstlane(s == NS - 1 ? 1 : 0);
+      asm volatile("" : "+s"(last));            // opaque, see the P loop: one copy of the step, one allocation of the 192 accumulator registers
+      c_step(last != 0, bid + bi * G);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+}  // namespace
+
+extern "C" int tr_mlp_fused_supported(int D, int Hd) { return (D == MF_D && Hd % 32 == 0 && Hd >= 64) ? 1 : 0; }
+
+extern "C" size_t tr_mlp_pack_bytes(int D, int Hd) {
+  if (D <= 0 || Hd <= 0 || D % 32 || Hd % 32) return 0;
+  return (size_t)(Hd / 32) * (size_t)(2 * (D / 32) + D / 16) * 1024;
+}
+
+extern "C" int tr_mlp_pack_bf16(const uint16_t* fc1_w, const uint16_t* fc2_w, void* packed, int D, int Hd, tr_stream_t s) {
+  TR_REQUIRE(fc1_w && fc2_w && packed, TR_ERR_NULL, "tr_mlp_pack_bf16: null pointer");
+  TR_REQUIRE(D > 0 && Hd > 0 && D % 32 == 0 && Hd % 32 == 0, TR_ERR_SHAPE, "tr_mlp_pack_bf16: D=%d and Hd=%d must be multiples of 32", D, Hd);
+  TR_REQUIRE(tr_aligned16(fc1_w) && tr_aligned16(fc2_w) && tr_aligned16(packed), TR_ERR_ALIGN, "tr_mlp_pack_bf16: pointers must be 16-byte aligned");
+  const int frags = (Hd / 32) * (2 * (D / 32) + D / 16);
+  hipLaunchKernelGGL(mlp_pack_kernel, dim3((frags + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(s), fc1_w, fc2_w, static_cast<u32x4*>(packed), D, Hd);
+  TR_CHECK_LAUNCH("tr_mlp_pack_bf16");
+  return TR_OK;
+}
+
+extern "C" int tr_mlp_fused_bf16(const uint16_t* xn, const void* packed, const float* fc1_b, const float* fc2_b, uint16_t* out, int M, int D, int Hd,
+                                 tr_stream_t s) {
+  TR_REQUIRE(xn && packed && fc1_b && fc2_b && out, TR_ERR_NULL, "tr_mlp_fused_bf16: null pointer");
+  TR_REQUIRE(M > 0 && tr_mlp_fused_supported(D, Hd), TR_ERR_SHAPE, "tr_mlp_fused_bf16: unsupported shape M=%d D=%d Hd=%d (D must be %d, Hd %% 32 == 0)", M, D, Hd,
+             MF_D);
+  TR_REQUIRE(tr_aligned16(xn) && tr_aligned16(packed) && tr_aligned16(fc1_b) && tr_aligned16(fc2_b) && tr_aligned16(out), TR_ERR_ALIGN,
+             "tr_mlp_fused_bf16: pointers must be 16-byte aligned");
+  const size_t out_bytes = (size_t)M * D * 2;
+  TR_REQUIRE(out_bytes < ((size_t)1 << 31), TR_ERR_SHAPE, "tr_mlp_fused_bf16: %zu output bytes exceed the 2 GiB range of the store offsets", out_bytes);
+  tr_prof_note("mlp_fused_kernel", 4.0 * M * D * Hd, 4.0 * M * D + 4.0 * D * Hd);
+  const int nblk = (M + MF_ROWS - 1) / MF_ROWS;
+  hipLaunchKernelGGL(mlp_fused_kernel, dim3(nblk < 256 ? nblk : 256), dim3(512), 0, static_cast<hipStream_t>(s), xn, static_cast<const unsigned char*>(packed),
+                     fc1_b, fc2_b, out, M, Hd / 32, (unsigned)out_bytes);
+  TR_CHECK_LAUNCH("tr_mlp_fused_bf16");
+  return TR_OK;
+}

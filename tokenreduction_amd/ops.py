@@ -89,6 +89,36 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, epilogue: int, ou
     return out
 
 
+def mlp_pack(fc1_w: torch.Tensor, fc2_w: torch.Tensor) -> torch.Tensor:
+    """Fragment-major copy of a block's Mlp weights (bf16 [Hd,D], [D,Hd]) for mlp_fused; repack whenever the matrices change."""
+    Hd, D = fc1_w.shape
+    if tuple(fc2_w.shape) != (D, Hd):
+        raise ValueError(f"mlp_pack: fc2 weight is {tuple(fc2_w.shape)}, expected {(D, Hd)}")
+    _same_device(fc1_w, fc2_w)
+    lib = _lib.load()
+    n = lib.tr_mlp_pack_bytes(D, Hd)
+    if n == 0 or not lib.tr_mlp_fused_supported(D, Hd):
+        raise ValueError(f"mlp_pack: the fused Mlp kernel does not serve D={D}, Hd={Hd}")
+    pk = torch.empty(n, dtype=torch.uint8, device=fc1_w.device)
+    _lib.check(lib.tr_mlp_pack_bf16(_dev(fc1_w, torch.bfloat16, "fc1_w"), _dev(fc2_w, torch.bfloat16, "fc2_w"), pk.data_ptr(), D, Hd,
+                                    _stream(fc1_w)), "tr_mlp_pack_bf16")
+    return pk
+
+
+def mlp_fused(xn: torch.Tensor, packed: torch.Tensor, fc1_b: torch.Tensor, fc2_b: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """timm Mlp (fc1 -> GELU -> fc2, topk.py:95) of the eval forward in one launch: xn bf16 [M,D] -> bf16 [M,D]; bit-identical to
+    gemm(GELU_BF16) followed by gemm(BF16)."""
+    M, D = xn.shape
+    Hd = fc1_b.numel()
+    _same_device(xn, packed, fc1_b, fc2_b, out)
+    if out is None:
+        out = torch.empty(M, D, dtype=torch.bfloat16, device=xn.device)
+    _lib.check(_lib.load().tr_mlp_fused_bf16(_dev(xn, torch.bfloat16, "xn"), _dev(packed, torch.uint8, "packed"), _dev(fc1_b, torch.float32, "fc1_b"),
+                                             _dev(fc2_b, torch.float32, "fc2_b"), _dev(out, torch.bfloat16, "out"), M, D, Hd, _stream(xn)),
+               "tr_mlp_fused_bf16")
+    return out
+
+
 def layernorm(x: torch.Tensor, gamma, beta, eps: float, rows: int = None, ldx: int = None, delta: torch.Tensor = None,
               ldd: int = None) -> torch.Tensor:
     """[x += delta (bf16, written back);] nn.LayerNorm over the last dim of fp32 x -> bf16 [M,D]
