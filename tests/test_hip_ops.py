@@ -136,6 +136,30 @@ def test_mlp_fused_is_bit_identical_to_the_gemm_pair(ops, M, Hd):
     torch.testing.assert_close(got[rows.cuda()].cpu().double(), ref, atol=2e-2, rtol=1.2e-2)
 
 
+def test_mlp_fused_repeated_launches_under_uneven_load(ops):
+    """Race screen (found one: an SGPR-soffset buffer store followed by a VALU write of its data registers, profiles/r05_mlp_lab.md): 60
+    launches at a shape with two blocks per workgroup, every third one beside a copy kernel on a second stream, each compared with the pair."""
+    M, D, Hd = 35328, 384, 1536
+    rng = _rng(7)
+    x = _randn(rng, M, D).bfloat16().cuda()
+    w1, w2 = _randn(rng, Hd, D, scale=0.05).bfloat16().cuda(), _randn(rng, D, Hd, scale=0.05).bfloat16().cuda()
+    b1, b2 = _randn(rng, Hd, scale=0.1).cuda(), _randn(rng, D, scale=0.1).cuda()
+    want = ops.gemm(ops.gemm(x, w1, b1, ops.TR_EPI_GELU_BF16), w2, b2, ops.TR_EPI_BF16)
+    pk = ops.mlp_pack(w1, w2)
+    side, junk = torch.cuda.Stream(), torch.empty(32 << 20, dtype=torch.uint8, device="cuda")
+    out = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+    bad = 0
+    for it in range(60):
+        out.fill_(float("nan"))
+        if it % 3 == 0:
+            with torch.cuda.stream(side):
+                junk.add_(1)
+        ops.mlp_fused(x, pk, b1, b2, out=out)
+        torch.cuda.synchronize()
+        bad += 0 if torch.equal(out.view(torch.int16), want.view(torch.int16)) else 1
+    assert bad == 0, f"{bad} of 60 launches differ from the two-launch pair"
+
+
 def test_mlp_fused_rejects_other_widths(ops):
     w1, w2 = torch.zeros(3072, 768, dtype=torch.bfloat16, device="cuda"), torch.zeros(768, 3072, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(ValueError, match="does not serve"):

@@ -1,25 +1,28 @@
 // Fused eval MLP for gfx950:  out = fc2(gelu(fc1(x)))  with the hidden activation never leaving the CU.
 //
-// Replaces the timm Mlp of a block as the reference calls it (topk.py:78 construction, :95 `x = x + self.mlp(self.norm2(x))`; the residual add
-// stays in the next LayerNorm kernel like before) for the EVAL forward: fc1 -> GELU -> fc2 in ONE launch instead of
-// tr_gemm_bf16(TR_EPI_GELU_BF16) + tr_gemm_bf16(TR_EPI_BF16) with a [M, 4D] bf16 round trip through HBM between them.
-// Bit-identical to that pair by construction: same MFMA (16x16x32 bf16), same operand-to-lane maps, accumulators that start at the bias,
-// K walked in the same 32-deep steps in the same order, the same GELU fit on the fp32 accumulator, the hidden rounded to bf16 at the same
-// point.  (So the executor may pick either per shape; tests/test_hip_ops.py::test_mlp_fused_* compares them bit for bit.)
+// The timm Mlp of a block as the reference calls it (topk.py:78 construction, :95 `x = x + self.mlp(self.norm2(x))`; the residual add stays
+// in the next LayerNorm kernel) in ONE launch instead of tr_gemm_bf16(TR_EPI_GELU_BF16) + tr_gemm_bf16(TR_EPI_BF16) with a [M, 4D] bf16 round
+// trip through HBM between them.  Bit-identical to that pair by construction: same MFMA (16x16x32 bf16), same operand-to-lane maps,
+// accumulators that start at the bias, K walked in the same 32-deep steps in the same order, the same GELU fit on the fp32 accumulator
+// (evaluated with scalar instead of packed VALU instructions: same operations, same contractions), the hidden rounded to bf16 at the same
+// point.  tests/test_hip_ops.py::test_mlp_fused_* compares them bit for bit, tools/mlp_lab.py --stress screens for races.
+//
+// STATUS (round 5): correct and race-free, but NOT faster than the pair on the model's shapes -- 99 vs 95 us at 32768 rows, 150 vs 151 us at
+// 50432 -- so the executor keeps the pair.  Where the cycles go (in-kernel stamps and ablations of this kernel): profiles/r05_mlp_lab.md.
 //
 // Structure (one persistent 512-thread workgroup per CU, 128 token rows per block, D = 384):
 //   * Waves 0-3 ("P", one per SIMD) own 32 token rows each and keep their x rows IN REGISTERS as the MFMA B operand (96 VGPRs).
-//     Per 32 hidden units (one "step") they compute h^T = W1_step . x^T (48 MFMAs), apply GELU, round to bf16 -- and because the W1 rows
-//     of a step are fed in the order  tile t2, row r -> hidden 8(r>>2) + 4 t2 + (r&3),  a lane's eight results ARE the B-operand
-//     fragment of fc2's MFMA over those 32 hidden units (the S^T = K.Q^T trick of the attention kernel).  2 KB per wave and step go
-//     through LDS to the partner wave.
+//     Per 32 hidden units (one "step") they compute h^T = W1_step . x^T (48 MFMAs), apply GELU (one step later, sliced between the next
+//     step's MFMAs), round to bf16 -- and because the W1 rows of a step are fed in the order  tile t2, row r -> hidden 8(r>>2) + 4 t2 + (r&3),
+//     a lane's eight results ARE the B-operand fragment of fc2's MFMA over those 32 hidden units (the S^T = K.Q^T trick of the attention
+//     kernel).  2 KB per wave and step go through LDS to the partner wave.
 //   * Waves 4-7 ("C", the SIMD partners) own the same 32 token rows and keep the whole 32 x 384 fp32 output accumulator in registers
 //     (192 VGPRs); per step 48 MFMAs  acc += W2[:, step] . h.  One epilogue per 128 x 384 x 1536 x 4 FLOP instead of one per tile.
-//   * The two MFMA streams of a SIMD are independent, so one wave's GELU / LDS waits / DMA issue stalls sit under the partner's MFMAs.
 //   * Weights come from a FRAGMENT-MAJOR packed copy (tr_mlp_pack_bf16: per step 24 KiB of W1 fragments + 24 KiB of W2 fragments, each
 //     fragment 1 KiB in lane order), so a DMA piece is 1 KiB contiguous -> LDS lane-linear, and every fragment read is a linear
-//     conflict-free ds_read_b128.  3-slot ring of 48-KiB entries (entry t = W1 of step t | W2 of step t-1: what time step t consumes),
-//     two entries in flight behind counted vmcnt waits, one s_barrier per step; all eight waves issue 6 of the 48 pieces per step.
+//     conflict-free ds_read_b128.  3-slot ring of 48-KiB entries (entry t = W1 of step t | W2 of step t-2: what time step t consumes),
+//     two entries in flight behind counted vmcnt waits, one s_barrier per step, placed BEFORE the step's last window of MFMAs (their
+//     fragments are in registers), so the matrix pipe has work while the next step's first fragments arrive.
 //   * FLOP per byte through the CU's L2 -> LDS feed: 128 (a 256 x 128 GEMM tile: 85); HBM traffic per 128 rows: 96 KB in, 96 KB out.
 #include "tr_common.h"
 
@@ -31,10 +34,29 @@ namespace {
 #else
 #define MF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #endif
-#ifdef TR_ABLATE_NO_GELU
+// gelu2() of tr_common.h element by element: the same operations with the same contractions (bit-identical), but as scalar VALU
+// instructions -- packed f32 arithmetic takes two passes and, beside MFMAs, costs more than the two scalar instructions it replaces
+__device__ __forceinline__ float mf_gelu1(float x) {
+  constexpr float L2E = 1.44269504088896340736f;
+  constexpr float C1 = -1.59501577f * L2E, C3 = -7.40112920e-02f * L2E, C5 = 7.03033576e-04f * L2E;
+  const float xc = __builtin_amdgcn_fmed3f(x, -8.0f, 8.0f);
+  const float x2 = xc * xc;
+  float p = __builtin_fmaf(x2, C5, C3);
+  p = __builtin_fmaf(p, x2, C1);
+  const float z = p * xc;
+  const float e = __builtin_amdgcn_exp2f(z) + 1.0f;
+  return x * __builtin_amdgcn_rcpf(e);
+}
+#if defined(TR_ABLATE_NO_GELU)
 __device__ __forceinline__ f32x2 mf_gelu2(f32x2 v) { return v; }
-#else
+#elif defined(MF_GELU_PACKED)
 __device__ __forceinline__ f32x2 mf_gelu2(f32x2 v) { return gelu2(v); }
+#else
+__device__ __forceinline__ f32x2 mf_gelu2(f32x2 v) {
+  float a = mf_gelu1(v[0]), b = mf_gelu1(v[1]);
+  asm volatile("" : "+v"(a), "+v"(b));         // keeps the SLP vectoriser from re-packing the two chains
+  return f32x2{a, b};
+}
 #endif
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -79,6 +101,14 @@ constexpr int MF_NSLOT = 3;
 constexpr int MF_HBUF = 2048;                  // one hidden fragment pair (2 token groups x 64 lanes x 16 B)
 constexpr int MF_LDS = MF_NSLOT * MF_ENTRY + 4 * 2 * MF_HBUF;     // 163,840 B: all of the CU's LDS
 constexpr int MF_ROWS = 128;                   // token rows per block (4 wave pairs x 32)
+#ifndef MF_PQ
+#define MF_PQ 0                                // DMA pieces of an entry a P wave issues (0..6, lab: -DMF_PQ=..); a C wave issues 12 - MF_PQ.  0: the P
+#endif                                         // wave's instruction stream (GELU) is the step's critical path -- profiles/r05_mlp_lab.md
+#ifndef MF_DMA_BURST
+#define MF_DMA_SPREAD 1                        // a C wave's pieces one at a time between MFMA pairs (lab: -DMF_DMA_BURST issues them window by window)
+#endif
+constexpr int MF_PPW = (MF_PQ + 3) / 4;        // ... behind the MFMAs of a P step's windows 1..4 (window 0 carries the bias loads)
+constexpr int MF_CPW = (12 - MF_PQ + 4) / 5;   // ... and of a C step's windows 0..4
 
 __device__ __forceinline__ void mf_piece(const unsigned char* sbase, unsigned voff, unsigned lds_dst) {
 #ifndef TR_ABLATE_NO_DMA
@@ -146,28 +176,45 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
   const int nblk = (M + MF_ROWS - 1) / MF_ROWS;
   if (bid >= nblk) return;
   const int my_blocks = (nblk - bid + G - 1) / G;
-  const int T = my_blocks * NS;                              // time steps: P works in 0..T-1, C in 1..T
+  const int T = my_blocks * NS;       // P: MFMAs of (block, step) number t at time t = 0..T-1, its GELU at time t+1; C consumes it at time t+2
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const unsigned lane16 = (unsigned)lane * 16u;
   const int frow = lane & 15, fq = lane >> 4;
   unsigned char* const hb = smem + MF_NSLOT * MF_ENTRY + pr * (2 * MF_HBUF);     // this pair's two hidden buffers
 
-  // ---- DMA cursor: the next entry to issue (e), the steps its two halves come from, its ring slot.  Wave w issues pieces w, w+8, .., w+40.
-  int ld_e = 0, ld_w1 = 0, ld_w2 = NS - 1, ld_slot = 0;
+  // ---- the weight ring.  Entry e = [W1 of step e | W2 of step e-2]: what time step e consumes.  During time step t the waves issue the
+  // pieces of entry t+2 into the slot entry t-1 has left; the barrier at the end of step t publishes entry t+1 (issued a step earlier: every
+  // wave waits for its own pieces with a counted vmcnt, this step's stay in flight).
+  // The barrier sits BEFORE a step's last window of MFMAs: its fragments are in registers by then, so the matrix pipe has work the moment the
+  // barrier opens, under which the first fragments of the next step arrive from LDS.
+  int ld_e = 0, ld_w1 = 0, ld_w2 = (2 * NS - 2) % NS, ld_slot = 0;
+  // the 48 pieces of an entry: a P wave issues MF_PQ of them (pieces pr + 4 q), a C wave the other 12 - MF_PQ (pieces 4 MF_PQ + pr + 4 q)
   auto issue_piece_q = [&](int q) __attribute__((always_inline)) {
-    const int f = wave + 8 * q;
-    const int step = (q < 3) ? ld_w1 : ld_w2;
+    const int f = (wave < 4 ? 0 : 4 * MF_PQ) + pr + 4 * q;
+    const int step = (f < MF_W1FR) ? ld_w1 : ld_w2;
     mf_piece(pk + (size_t)step * MF_ENTRY + f * 1024, lane16, lds0 + ld_slot * MF_ENTRY + f * 1024);
+  };
+  auto issue_all = [&]() __attribute__((always_inline)) {
+    if (wave < 4) {
+#pragma unroll
+      for (int q = 0; q < MF_PQ; ++q) issue_piece_q(q);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 12 - MF_PQ; ++q) issue_piece_q(q);
+    }
   };
   auto advance_entry = [&]() __attribute__((always_inline)) {
     ++ld_e;
-    ld_w2 = ld_w1;
     ld_w1 = (ld_w1 + 1 == NS) ? 0 : ld_w1 + 1;
+    ld_w2 = (ld_w2 + 1 == NS) ? 0 : ld_w2 + 1;
     ld_slot = (ld_slot + 1 == MF_NSLOT) ? 0 : ld_slot + 1;
   };
 
   if (wave < 4) {
     // =============================================================== P: fc1 + GELU
+#ifdef MF_PRIO_P
+    __builtin_amdgcn_s_setprio(MF_PRIO_P);
+#endif
     bf16x8 x0[MF_KS], x1[MF_KS];                 // B-operand fragments of this wave's two 16-row groups, all 12 k-steps
     f32x4 bn0, bn1;                              // bias fragments of the NEXT step's two row tiles
     const unsigned boff = (unsigned)fq * 32u;    // lane (.., q) starts at hidden 8 q of the step: b1[32 s + 8 q + 4 t2 + e]
@@ -190,110 +237,154 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
     }
     bn0 = mf_load_f4<0>(b1, boff);
     bn1 = mf_load_f4<16>(b1, boff);
-    // entries 0 and 1 (the loop issues entry t+2 during step t)
-#pragma unroll
-    for (int q = 0; q < 6; ++q) issue_piece_q(q);
+    issue_all();
     advance_entry();
-#pragma unroll
-    for (int q = 0; q < 6; ++q) issue_piece_q(q);
+    issue_all();
     advance_entry();
-    asm volatile("s_waitcnt vmcnt(6)" : "+v"(bn0), "+v"(bn1), MF_TIE_X(x0), MF_TIE_X(x1)::"memory");
-    __builtin_amdgcn_s_barrier();               // B_0: entry 0 has landed
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bn0), "+v"(bn1), MF_TIE_X(x0), MF_TIE_X(x1)::"memory");
+    __builtin_amdgcn_s_barrier();               // entries 0 and 1 have landed
     asm volatile("" ::: "memory");
 
     int t = 0, cslot = 0;
+    f32x4 p00, p01, p10, p11;                   // the previous step's accumulators, waiting for their GELU
+    p00 = p01 = p10 = p11 = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("" : "+v"(p00), "+v"(p01), "+v"(p10), "+v"(p11));      // opaque: no first iteration peeled off to fold GELU(0) (a second copy of the step body)
+    bf16x8 wA[4], wB[4];
+#define MF_READW(buf, base, k)                                                                  \
+  buf[0] = *reinterpret_cast<const bf16x8*>((base) + (2 * (k)) * 1024);                        \
+  buf[1] = *reinterpret_cast<const bf16x8*>((base) + (MF_KS + 2 * (k)) * 1024);                \
+  buf[2] = *reinterpret_cast<const bf16x8*>((base) + (2 * (k) + 1) * 1024);                    \
+  buf[3] = *reinterpret_cast<const bf16x8*>((base) + (MF_KS + 2 * (k) + 1) * 1024)
+    MF_READW(wA, smem + lane16, 0);
     MF_CLOCK_BEGIN;
-    // One step.  LAST: the block's last step -- the x registers are dead after their last MFMA and are refilled with the NEXT block's rows
-    // right there (the loads have a whole step to land), at the price of a vmcnt(0) at the end of this one step.
+    // One time step t: windows 0..4 of its MFMAs with the GELU of step t-1 under them (at t = 0: of zeros, into a buffer nobody reads) -- the
+    // hidden fragments go to the partner through LDS --, the barrier, then window 5 and the first fragment reads of step t+1.
+    // last: the block's last step -- the x registers are dead after their last MFMA and are refilled IN PLACE with the next block's rows.
     auto p_step = [&](int s, const bool last, int next_blk) __attribute__((always_inline)) {
       const unsigned char* slot = smem + cslot * MF_ENTRY + lane16;
+      const int nslot = (cslot + 1 == MF_NSLOT) ? 0 : cslot + 1;
+      const unsigned char* slot_next = smem + nslot * MF_ENTRY + lane16;
       MF_STAMP_DECL;
       MF_STAMP(0);
       f32x4 a00 = bn0, a01 = bn0, a10 = bn1, a11 = bn1;
-      // the next step's bias: older than this step's DMA pieces, so the counted wait at the end of the step retires it
-      {
-        const int sn = (s + 1 == NS) ? 0 : s + 1;
-        bn0 = mf_load_f4<0>(b1 + 32 * sn, boff);
-        bn1 = mf_load_f4<16>(b1 + 32 * sn, boff);
-      }
+      u32x4 h0 = {0u, 0u, 0u, 0u}, h1 = {0u, 0u, 0u, 0u};
       unsigned xo0 = 0, xo1 = 0;
       const bool reload = last && next_blk >= 0;
       if (reload) x_offsets(next_blk, xo0, xo1);
-      const bool dma = ld_e <= T;
-      bf16x8 wA[4], wB[4];
-#define MF_READW(buf, k)                                                                        \
-  buf[0] = *reinterpret_cast<const bf16x8*>(slot + (2 * (k)) * 1024);                          \
-  buf[1] = *reinterpret_cast<const bf16x8*>(slot + (MF_KS + 2 * (k)) * 1024);                  \
-  buf[2] = *reinterpret_cast<const bf16x8*>(slot + (2 * (k) + 1) * 1024);                      \
-  buf[3] = *reinterpret_cast<const bf16x8*>(slot + (MF_KS + 2 * (k) + 1) * 1024)
+      const bool dma = ld_e <= T + 1;
+      // GELU of the previous step in four slices (one per window 0..3; the empty asm pins a slice to its window -- hipcc sinks the whole GELU to
+      // the store otherwise, behind 32 MFMAs), a lane's eight values = the partner's B fragment: tile 0 gives k = 8 q + 0..3, tile 1 k = 8 q + 4..7
+#define MF_GELU_SLICE(k)                                                                                  \
+  do {                                                                                                    \
+    if ((k) == 0) { const f32x2 g0 = mf_gelu2(f32x2{p00[0], p00[1]}), g1 = mf_gelu2(f32x2{p00[2], p00[3]}); h0[0] = pack_bf16x2(g0[0], g0[1]); h0[1] = pack_bf16x2(g1[0], g1[1]); asm volatile("" : "+v"(h0[0]), "+v"(h0[1])); } \
+    if ((k) == 1) { const f32x2 g0 = mf_gelu2(f32x2{p10[0], p10[1]}), g1 = mf_gelu2(f32x2{p10[2], p10[3]}); h0[2] = pack_bf16x2(g0[0], g0[1]); h0[3] = pack_bf16x2(g1[0], g1[1]); asm volatile("" : "+v"(h0[2]), "+v"(h0[3])); } \
+    if ((k) == 2) { const f32x2 g0 = mf_gelu2(f32x2{p01[0], p01[1]}), g1 = mf_gelu2(f32x2{p01[2], p01[3]}); h1[0] = pack_bf16x2(g0[0], g0[1]); h1[1] = pack_bf16x2(g1[0], g1[1]); asm volatile("" : "+v"(h1[0]), "+v"(h1[1])); } \
+    if ((k) == 3) { const f32x2 g0 = mf_gelu2(f32x2{p11[0], p11[1]}), g1 = mf_gelu2(f32x2{p11[2], p11[3]}); h1[2] = pack_bf16x2(g0[0], g0[1]); h1[3] = pack_bf16x2(g1[0], g1[1]); asm volatile("" : "+v"(h1[2]), "+v"(h1[3])); } \
+    if ((k) == 4) {                                                                                       \
+      unsigned char* dst = hb + ((t - 1) & 1) * MF_HBUF + lane16;                                         \
+      *reinterpret_cast<u32x4*>(dst) = h0;                                                                \
+      *reinterpret_cast<u32x4*>(dst + 1024) = h1;                                                         \
+    }                                                                                                     \
+  } while (0)
+#define MF_PMFMA(cur, k)                                                                        \
+  do {                                                                                          \
+    a00 = MF_MFMA(cur[0], x0[2 * (k)], a00);                                                    \
+    a01 = MF_MFMA(cur[0], x1[2 * (k)], a01);                                                    \
+    a10 = MF_MFMA(cur[1], x0[2 * (k)], a10);                                                    \
+    a11 = MF_MFMA(cur[1], x1[2 * (k)], a11);                                                    \
+    a00 = MF_MFMA(cur[2], x0[2 * (k) + 1], a00);                                                \
+    a01 = MF_MFMA(cur[2], x1[2 * (k) + 1], a01);                                                \
+    a10 = MF_MFMA(cur[3], x0[2 * (k) + 1], a10);                                                \
+    a11 = MF_MFMA(cur[3], x1[2 * (k) + 1], a11);                                                \
+  } while (0)
+      // windows 0..4: the next window's fragments are requested first, the DMA pieces and the bias loads go out BEHIND the window's MFMAs
 #define MF_PWIN(cur, nxt, k)                                                                    \
   do {                                                                                          \
-    if (dma) issue_piece_q(k);                                                                  \
-    if ((k) < 5) { MF_READW(nxt, (k) + 1); }                                                    \
+    MF_READW(nxt, slot, (k) + 1);                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                          \
-    a00 = MF_MFMA(cur[0], x0[2 * (k)], a00);           \
-    a01 = MF_MFMA(cur[0], x1[2 * (k)], a01);           \
-    a10 = MF_MFMA(cur[1], x0[2 * (k)], a10);           \
-    a11 = MF_MFMA(cur[1], x1[2 * (k)], a11);           \
-    a00 = MF_MFMA(cur[2], x0[2 * (k) + 1], a00);       \
-    a01 = MF_MFMA(cur[2], x1[2 * (k) + 1], a01);       \
-    a10 = MF_MFMA(cur[3], x0[2 * (k) + 1], a10);       \
-    a11 = MF_MFMA(cur[3], x1[2 * (k) + 1], a11);       \
+    MF_PMFMA(cur, k);                                                                           \
+    MF_GELU_SLICE(k);                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                          \
+    if ((k) == 0) {                                                                             \
+      /* the next step's bias: older than this step's DMA pieces, so the counted wait at the end of the step retires it */ \
+      const int sn = (s + 1 == NS) ? 0 : s + 1;                                                 \
+      bn0 = mf_load_f4<0>(b1 + 32 * sn, boff);                                                  \
+      bn1 = mf_load_f4<16>(b1 + 32 * sn, boff);                                                 \
+    }                                                                                           \
+    if ((k) >= 1 && dma) {                                                                      \
+      _Pragma("unroll") for (int q_ = MF_PPW * ((k) - 1); q_ < MF_PPW * (k); ++q_)              \
+        if (q_ < MF_PQ) issue_piece_q(q_);                                                      \
+    }                                                                                           \
     if (reload) { MF_RELOAD_X(2 * (k)); MF_RELOAD_X(2 * (k) + 1); }                             \
   } while (0)
-      MF_READW(wA, 0);
       MF_PWIN(wA, wB, 0);
       MF_PWIN(wB, wA, 1);
       MF_PWIN(wA, wB, 2);
       MF_PWIN(wB, wA, 3);
-      MF_PWIN(wA, wB, 4);
-      MF_PWIN(wB, wA, 5);
-#undef MF_PWIN
-#undef MF_READW
+      MF_PWIN(wA, wB, 4);       // wB: window 5
       if (dma) advance_entry();
       MF_STAMP(1);
-      // GELU, round, and the lane's eight hidden values are the partner's B fragment: tile 0 gives k = 8q + 0..3, tile 1 k = 8q + 4..7
-      {
-        const f32x2 g0 = mf_gelu2(f32x2{a00[0], a00[1]}), g1 = mf_gelu2(f32x2{a00[2], a00[3]});
-        const f32x2 g2 = mf_gelu2(f32x2{a10[0], a10[1]}), g3 = mf_gelu2(f32x2{a10[2], a10[3]});
-        const u32x4 h0 = {pack_bf16x2(g0[0], g0[1]), pack_bf16x2(g1[0], g1[1]), pack_bf16x2(g2[0], g2[1]), pack_bf16x2(g3[0], g3[1])};
-        const f32x2 g4 = mf_gelu2(f32x2{a01[0], a01[1]}), g5 = mf_gelu2(f32x2{a01[2], a01[3]});
-        const f32x2 g6 = mf_gelu2(f32x2{a11[0], a11[1]}), g7 = mf_gelu2(f32x2{a11[2], a11[3]});
-        const u32x4 h1 = {pack_bf16x2(g4[0], g4[1]), pack_bf16x2(g5[0], g5[1]), pack_bf16x2(g6[0], g6[1]), pack_bf16x2(g7[0], g7[1])};
-        unsigned char* dst = hb + (t & 1) * MF_HBUF + lane16;
-        *reinterpret_cast<u32x4*>(dst) = h0;
-        *reinterpret_cast<u32x4*>(dst + 1024) = h1;
-      }
-      MF_STAMP(2);
-      // end of step t: entry t+1 has landed once only this step's six pieces remain (LAST: the x reload is interleaved with them -> drain)
-      // ONE tied statement on every path (two tied statements on an if/else made hipcc copy the 96 x registers between its two allocations)
+      // end of the step's LDS and DMA business: entry t+1 has landed once only this step's MF_PQ pieces remain (last: the reload is
+      // interleaved with them -> drain); the hidden fragments are written, window 5's fragments are in registers.  ONE tied statement on
+      // every path (two tied statements on an if/else made hipcc copy the 96 x registers between its two allocations).
       if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("s_waitcnt vmcnt(6)" : "+v"(bn0), "+v"(bn1), MF_TIE_X(x0), MF_TIE_X(x1)::"memory");
+      asm volatile("s_waitcnt vmcnt(%26)" : "+v"(bn0), "+v"(bn1), MF_TIE_X(x0), MF_TIE_X(x1) : "n"(MF_PQ) : "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();             // B_{t+1}
+      MF_STAMP(2);
+      __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       MF_STAMP(3);
+      // behind the barrier: the step's last window runs on registers while the first fragments of step t+1 (entry t+1: just published) arrive
+      MF_READW(wA, slot_next, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      MF_PMFMA(wB, 5);
+      __builtin_amdgcn_sched_barrier(0);
+      if (reload) { MF_RELOAD_X(10); MF_RELOAD_X(11); }
+#undef MF_PWIN
+#undef MF_GELU_SLICE
+      p00 = a00; p01 = a01; p10 = a10; p11 = a11;
       MF_STAMP_DUMP(0, t);
       ++t;
-      cslot = (cslot + 1 == MF_NSLOT) ? 0 : cslot + 1;
+      cslot = nslot;
     };
-    for (int bi = 0; bi < my_blocks; ++bi) {
-      const int next_blk = bi + 1 < my_blocks ? bid + (bi + 1) * G : -1;
-      for (int s = 0; s < NS; ++s) {
-        int last = __builtin_amdgcn_readfirstlane(s == NS - 1 ? 1 : 0);
-        asm volatile("" : "+s"(last));          // opaque: hipcc must not peel the last step into a second copy of the loop body (a second allocation of the 96 x registers)
-        p_step(s, last != 0, next_blk);
+    // ONE flat loop over the time steps with (block, step) carried along -- and the block's-last-step test opaque: with a nested
+    // `for (s = 0; s < NS; ++s)` hipcc peels the last iteration off (the bias pointer wraps there), i.e. compiles the step body twice with two
+    // allocations of the 96 x registers and spills between them.
+    {
+      int s = 0, blk_next = bid + G;
+      for (int tt = 0; tt < T; ++tt) {
+        int last = __builtin_amdgcn_readfirstlane((s + 1 == NS) ? 1 : 0);
+        asm volatile("" : "+s"(last));
+        p_step(s, last != 0, blk_next < nblk ? blk_next : -1);
+        if (last) { s = 0; blk_next += G; } else { ++s; }
       }
     }
+    {
+      // time T: only the GELU of the last step is left
+      const f32x2 g0 = mf_gelu2(f32x2{p00[0], p00[1]}), g1 = mf_gelu2(f32x2{p00[2], p00[3]});
+      const f32x2 g2 = mf_gelu2(f32x2{p10[0], p10[1]}), g3 = mf_gelu2(f32x2{p10[2], p10[3]});
+      const u32x4 h0 = {pack_bf16x2(g0[0], g0[1]), pack_bf16x2(g1[0], g1[1]), pack_bf16x2(g2[0], g2[1]), pack_bf16x2(g3[0], g3[1])};
+      const f32x2 g4 = mf_gelu2(f32x2{p01[0], p01[1]}), g5 = mf_gelu2(f32x2{p01[2], p01[3]});
+      const f32x2 g6 = mf_gelu2(f32x2{p11[0], p11[1]}), g7 = mf_gelu2(f32x2{p11[2], p11[3]});
+      const u32x4 h1 = {pack_bf16x2(g4[0], g4[1]), pack_bf16x2(g5[0], g5[1]), pack_bf16x2(g6[0], g6[1]), pack_bf16x2(g7[0], g7[1])};
+      unsigned char* dst = hb + ((t - 1) & 1) * MF_HBUF + lane16;
+      *reinterpret_cast<u32x4*>(dst) = h0;
+      *reinterpret_cast<u32x4*>(dst + 1024) = h1;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+#undef MF_PMFMA
+#undef MF_READW
 #undef MF_LOAD_X
 #undef MF_RELOAD_X
     MF_CLOCK_END;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     return;
   }
 
   // ================================================================= C: fc2, the 32 x 384 accumulator in registers
+#ifdef MF_PRIO_C
+  __builtin_amdgcn_s_setprio(MF_PRIO_C);
+#endif
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(outp, 0, (int)out_bytes, 0x00020000);
   // fc2's bias lives in six registers (b2[lane + 64 q]); a column group's fragment value b2[16 i + 4 fq + e] is fetched with ds_bpermute
   // (the LDS crossbar, no LDS memory: the 160 KiB are all taken): register i >> 2, lane 16 (i & 3) + 4 fq + e
@@ -314,75 +405,124 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
     acc[i][0] = v;
     acc[i][1] = v;
   }
-#pragma unroll
-  for (int q = 0; q < 6; ++q) issue_piece_q(q);
+  issue_all();
   advance_entry();
-#pragma unroll
-  for (int q = 0; q < 6; ++q) issue_piece_q(q);
+  issue_all();
   advance_entry();
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  __builtin_amdgcn_s_barrier();                 // B_0
-  asm volatile("" ::: "memory");
-  // time step 0: nothing to consume yet; entry 2 goes out
-  if (ld_e <= T) {
-#pragma unroll
-    for (int q = 0; q < 6; ++q) issue_piece_q(q);
-    advance_entry();
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  } else {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  __builtin_amdgcn_s_barrier();                 // B_1
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                 // entries 0 and 1 have landed
   asm volatile("" ::: "memory");
 
-  int t = 1, cslot = 1;
-  // One step at time t: consumes the hidden fragments of time t-1 and the W2 half of entry t.  EPI: that was the block's last step.
+  int t = 0, cslot = 0;
+  bf16x8 wA[4], wB[4];
+  bf16x8 h0, h1;
+#define MF_READW(buf, base, k)                                                     \
+  buf[0] = *reinterpret_cast<const bf16x8*>((base) + (4 * (k)) * 1024);            \
+  buf[1] = *reinterpret_cast<const bf16x8*>((base) + (4 * (k) + 1) * 1024);        \
+  buf[2] = *reinterpret_cast<const bf16x8*>((base) + (4 * (k) + 2) * 1024);        \
+  buf[3] = *reinterpret_cast<const bf16x8*>((base) + (4 * (k) + 3) * 1024)
+  // time steps 0 and 1: nothing to consume yet; entries 2 and 3 go out.  Behind the second barrier the hidden fragments of number 0 and the first
+  // weight fragments of time step 2 are fetched.
+  for (; t < 2; ++t) {
+    if (ld_e <= T + 1) {
+      issue_all();
+      advance_entry();
+    }
+    cslot = (cslot + 1 == MF_NSLOT) ? 0 : cslot + 1;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 - MF_PQ) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  {
+    const unsigned char* hsrc = hb + (t & 1) * MF_HBUF + lane16;
+    h0 = *reinterpret_cast<const bf16x8*>(hsrc);
+    h1 = *reinterpret_cast<const bf16x8*>(hsrc + 1024);
+    MF_READW(wA, smem + cslot * MF_ENTRY + MF_W1FR * 1024 + lane16, 0);
+  }
+  // One time step t >= 2: consumes the hidden fragments of number t-2 (in h0, h1 on entry) and the W2 half of entry t: windows 0..4, the barrier,
+  // then -- on registers -- window 5, under which the next step's hidden and weight fragments arrive.  epi: number t-2 was its block's last step.
   auto c_step = [&](const bool epi, int blk) __attribute__((always_inline)) {
     const unsigned char* slot = smem + cslot * MF_ENTRY + MF_W1FR * 1024 + lane16;
-    const unsigned char* hsrc = hb + ((t - 1) & 1) * MF_HBUF + lane16;
+    const int nslot = (cslot + 1 == MF_NSLOT) ? 0 : cslot + 1;
+    const unsigned char* slot_next = smem + nslot * MF_ENTRY + MF_W1FR * 1024 + lane16;
     MF_STAMP_DECL;
     MF_STAMP(0);
-    const bf16x8 h0 = *reinterpret_cast<const bf16x8*>(hsrc);
-    const bf16x8 h1 = *reinterpret_cast<const bf16x8*>(hsrc + 1024);
-    const bool dma = ld_e <= T;
-    bf16x8 wA[4], wB[4];
-#define MF_READW(buf, k)                                                           \
-  buf[0] = *reinterpret_cast<const bf16x8*>(slot + (4 * (k)) * 1024);              \
-  buf[1] = *reinterpret_cast<const bf16x8*>(slot + (4 * (k) + 1) * 1024);          \
-  buf[2] = *reinterpret_cast<const bf16x8*>(slot + (4 * (k) + 2) * 1024);          \
-  buf[3] = *reinterpret_cast<const bf16x8*>(slot + (4 * (k) + 3) * 1024)
+    const bool dma = ld_e <= T + 1;
+#define MF_CMFMA(cur, k)                                                                                           \
+  _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) {                                                               \
+    acc[4 * (k) + ii][0] = MF_MFMA(cur[ii], h0, acc[4 * (k) + ii][0]);                                             \
+    acc[4 * (k) + ii][1] = MF_MFMA(cur[ii], h1, acc[4 * (k) + ii][1]);                                             \
+  }
+#if defined(MF_DMA_SPREAD)
+  /* a piece behind every MFMA pair whose index (0..19 over windows 0..4) crosses a multiple of 20 / (12 - MF_PQ) */           
 #define MF_CWIN(cur, nxt, k)                                                                                       \
   do {                                                                                                             \
-    if (dma) issue_piece_q(k);                                                                                     \
-    if ((k) < 5) { MF_READW(nxt, (k) + 1); }                                                                       \
+    MF_READW(nxt, slot, (k) + 1);                                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                                             \
     _Pragma("unroll") for (int ii = 0; ii < 4; ++ii) {                                                             \
-      acc[4 * (k) + ii][0] = MF_MFMA(cur[ii], h0, acc[4 * (k) + ii][0]);  \
-      acc[4 * (k) + ii][1] = MF_MFMA(cur[ii], h1, acc[4 * (k) + ii][1]);  \
+      acc[4 * (k) + ii][0] = MF_MFMA(cur[ii], h0, acc[4 * (k) + ii][0]);                                           \
+      acc[4 * (k) + ii][1] = MF_MFMA(cur[ii], h1, acc[4 * (k) + ii][1]);                                           \
+      __builtin_amdgcn_sched_barrier(0);                                                                           \
+      const int hk_ = 4 * (k) + ii;                                                                                \
+      if (((hk_ + 1) * (12 - MF_PQ)) / 20 > (hk_ * (12 - MF_PQ)) / 20) {                                           \
+        if (dma) issue_piece_q((hk_ * (12 - MF_PQ)) / 20);                                                         \
+      }                                                                                                            \
     }                                                                                                              \
-    __builtin_amdgcn_sched_barrier(0);                                                                             \
   } while (0)
-    MF_READW(wA, 0);
+#else
+#define MF_CWIN(cur, nxt, k)                                                                                       \
+  do {                                                                                                             \
+    MF_READW(nxt, slot, (k) + 1);                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    MF_CMFMA(cur, k);                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                             \
+    if (dma) {                                                                                                     \
+      _Pragma("unroll") for (int q_ = MF_CPW * (k); q_ < MF_CPW * ((k) + 1); ++q_)                                 \
+        if (q_ < 12 - MF_PQ) issue_piece_q(q_);                                                                    \
+    }                                                                                                              \
+  } while (0)
+#endif
     MF_CWIN(wA, wB, 0);
     MF_CWIN(wB, wA, 1);
     MF_CWIN(wA, wB, 2);
     MF_CWIN(wB, wA, 3);
-    MF_CWIN(wA, wB, 4);
-    MF_CWIN(wB, wA, 5);
+    MF_CWIN(wA, wB, 4);         // wB: window 5
 #undef MF_CWIN
-#undef MF_READW
     if (dma) advance_entry();
     MF_STAMP(1);
+    if (t <= T) {
+      // entry t+1 has landed once only this step's pieces remain (an epilogue's stores, issued before them, are older); every LDS read of this
+      // step is in registers (the ring slot and the hidden buffer may be rewritten behind the barrier)
+      if (dma) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 - MF_PQ) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing younger went out: the count would retire nothing
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    MF_STAMP(2);
+    // behind the barrier: the next step's fragments are requested (entry t+1 and hidden number t-1: just published), window 5 runs on registers
+    // (the hidden fragments only once window 5 has issued: 253 registers leave no room for two sets of them)
+    MF_READW(wA, slot_next, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    MF_CMFMA(wB, 5);
+    __builtin_amdgcn_sched_barrier(0);
+#undef MF_CMFMA
+    {
+      const unsigned char* hsrc = hb + ((t + 1) & 1) * MF_HBUF + lane16;
+      h0 = *reinterpret_cast<const bf16x8*>(hsrc);
+      h1 = *reinterpret_cast<const bf16x8*>(hsrc + 1024);
+    }
     if (epi) {
-      // 32 x 384 fp32 -> bf16 rows.  A 16-row x 64-column slab goes through 2 KiB of LDS (the hidden buffer this step has just consumed;
-      // the partner writes the other one) so that every store covers whole 128-byte lines; swizzle and the one-ahead pipelining are those
-      // of gemm_bf16_pc's epilogue.  The accumulators restart at the bias for the next block.
-      unsigned char* stg = hb + ((t - 1) & 1) * MF_HBUF;
+      // 32 x 384 fp32 -> bf16 rows.  A 16-row x 64-column slab goes through 2 KiB of LDS -- the hidden buffer just read into h0/h1 (its next
+      // writer is the partner's step t+2, two barriers away) -- so that every store covers whole 128-byte lines; swizzle and the one-ahead
+      // pipelining are those of gemm_bf16_pc's epilogue.  The accumulators restart at the bias for the next block.
+      unsigned char* stg = hb + ((t + 1) & 1) * MF_HBUF;
       const int rrow = lane >> 3, rch = lane & 7;
       unsigned voff_out = ((unsigned)(blk * MF_ROWS + pr * 32 + rrow) * MF_D + 8u * rch) * 2u;
       unsigned bp0 = 16u * fq;                   // byte address of lane 4 fq for ds_bpermute
-      // opaque: computed here, once per block, instead of being hoisted out of the step loop as sixteen address registers + twenty-four offsets
-      asm volatile("" : "+v"(voff_out), "+v"(bp0));
+      // opaque: computed here, once per block, instead of being hoisted out of the step loop as sixteen address registers + twenty-four offsets;
+      // and h0/h1 must have ARRIVED before the staging writes overwrite their source
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(voff_out), "+v"(bp0), "+v"(h0), "+v"(h1)::"memory");
       const unsigned char* rd = stg + rrow * 128 + ((rch ^ rrow) << 4);
       auto stage = [&](int c, int j) __attribute__((always_inline)) {
 #pragma unroll
@@ -401,11 +541,14 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
         ln[1] = u32x4{tt[2], tt[3], tt[0], tt[1]};
       };
       // rows beyond M need no predicate: num_records = M * 768 bytes, so their offsets fail the descriptor's bounds check and the store is dropped.
-      // One offset register per lane and block; (row group, column chunk) go into the scalar offset.
+      // The (row group, column chunk) part of the offset is added in a VGPR, NOT passed as an SGPR soffset: with a register soffset hipcc
+      // (ROCm 7.2) omits the wait state between a 16-byte buffer store and a VALU write of its data registers, and on gfx950 that write then
+      // races the store's operand read -- single dwords of single lanes of the stored line came out as the NEXT line's (tools/mlp_lab.py
+      // --stress: 193 of 200 launches differed from the two-GEMM pair, always in the same rows of a slab; profiles/r05_mlp_lab.md).
       auto store = [&](int c, int j, const u32x4 (&ln)[2]) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 2; ++r)
-          __builtin_amdgcn_raw_buffer_store_b128(ln[r], orsrc, voff_out, ((16 * j + 8 * r) * MF_D + 64 * c) * 2, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(ln[r], orsrc, voff_out + (unsigned)(((16 * j + 8 * r) * MF_D + 64 * c) * 2), 0, 0);
       };
       u32x4 lnA[2], lnB[2];
       stage(0, 0); read_back(lnA);
@@ -424,29 +567,21 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
         }
       }
     }
-    MF_STAMP(2);
-    if (t < T) {
-      // entry t+1 has landed once only what was issued after its pieces remains: this step's six pieces (if any went out) and the stores
-      if (!dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (epi) asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();             // B_{t+1}
-      asm volatile("" ::: "memory");
-    }
     MF_STAMP(3);
     MF_STAMP_DUMP(1, t);
     ++t;
-    cslot = (cslot + 1 == MF_NSLOT) ? 0 : cslot + 1;
+    cslot = nslot;
   };
-  for (int bi = 0; bi < my_blocks; ++bi) {
-    // time steps bi*NS + 1 .. bi*NS + NS consume the block's steps 0 .. NS-1
-    for (int s = 0; s < NS; ++s) {
-      int last = __builtin_amdgcn_readfirstlane(s == NS - 1 ? 1 : 0);
-      asm volatile("" : "+s"(last));            // opaque, see the P loop: one copy of the step, one allocation of the 192 accumulator registers
-      c_step(last != 0, bid + bi * G);
+  {
+    int s = 0, blk = bid;                       // flat loop, opaque last-step test: see the P loop
+    for (int tt = 0; tt < T; ++tt) {
+      int last = __builtin_amdgcn_readfirstlane((s + 1 == NS) ? 1 : 0);
+      asm volatile("" : "+s"(last));
+      c_step(last != 0, blk);
+      if (last) { s = 0; blk += G; } else { ++s; }
     }
   }
+#undef MF_READW
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 

@@ -14,6 +14,7 @@ import torch  # noqa: E402
 from tokenreduction_amd import ops  # noqa: E402
 
 D, Hd = 384, 1536
+STRESS = "--stress" in sys.argv            # re-run the fused launch 200 times per shape under uneven load and compare every output (race screen)
 STAMPS = "--stamps" in sys.argv            # a -DTR_DIAG_STAMPS build (TOKENREDUCTION_HIP_LIB=...): print the per-step phase stamps of workgroup 8
 rows = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [50432, 35328, 24832, 17408, 1000, 129, 128, 77, 1]
 dev = torch.device("cuda")
@@ -59,6 +60,25 @@ for M in rows:
     same = torch.equal(o_pair.view(torch.int16), o_fused.view(torch.int16))
     ndiff = int((o_pair.view(torch.int16) != o_fused.view(torch.int16)).sum())
     maxd = float((o_pair.float() - o_fused.float()).abs().max())
+    if STRESS:
+        nbad = 0
+        side = torch.cuda.Stream()
+        junk = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+        for it in range(200):
+            o_fused.fill_(float("nan"))
+            if it % 3 == 0:                       # a copy kernel on a second stream: uneven load on the CUs' memory queues
+                with torch.cuda.stream(side):
+                    junk.add_(1)
+            fused()
+            torch.cuda.synchronize()
+            if not torch.equal(o_pair.view(torch.int16), o_fused.view(torch.int16)):
+                nbad += 1
+                d = (o_pair.view(torch.int16) != o_fused.view(torch.int16))
+                rows_bad = d.any(dim=1).nonzero().flatten()
+                print(f"    stress iteration {it}: {int(d.sum())} elements differ, rows {rows_bad[:6].tolist()}..{int(rows_bad[-1])} ({len(rows_bad)} rows), cols {d.any(dim=0).nonzero().flatten()[:4].tolist()}..")
+        print(f"M={M:6d}  stress: {nbad} of 200 launches differ", flush=True)
+        bad += 1 if nbad else 0
+        continue
     fl = 4.0 * M * D * Hd
     tp, tf = timed(pair), timed(fused)
     print(f"M={M:6d}  bit-identical={same} (differing {ndiff}, max |d| {maxd:.3g})   pair {tp:7.1f} us {fl / tp / 1e6:5.0f} TF   "
