@@ -302,6 +302,8 @@ def finetune_leg(name, keep_rate, loc, batch, device, dist, steps=8, warmup=3, i
         from tokenreduction_amd.dp import FlatGradReducer
         red = FlatGradReducer().attach(model)
         red.broadcast_parameters(model)
+    else:
+        red = None
     last = [None]
 
     def step():
@@ -313,7 +315,21 @@ def finetune_leg(name, keep_rate, loc, batch, device, dist, steps=8, warmup=3, i
 
     el = timed_steps(step, steps, warmup, dist, torch.cuda.synchronize, device)
     assert torch.isfinite(last[0]).item()
-    return {"images_per_s": round(world * batch * steps / el, 1), "ms_per_step": round(1e3 * el / steps, 3), "batch_per_gpu": batch,
+    dp = None
+    if red is not None:
+        # ONE more step, outside the timed region, with events around every bucket: which part of the gradient mean the backward hides
+        # (range_ms vs collective_ms per bucket, exposed_ms at the end) -- DESIGN section 5's 0.2 ms / bucket model is checked against this
+        red.record_timing = True
+        step()
+        dp = red.timing()
+        red.record_timing = False
+        if dp is not None:
+            try:
+                dp["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:          # gloo rigs
+                dp["rccl_version"] = f"n/a ({type(e).__name__})"
+            dp["nccl_env"] = {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_ENABLE_IPC"))}
+    return {"dp": dp, "images_per_s": round(world * batch * steps / el, 1), "ms_per_step": round(1e3 * el / steps, 3), "batch_per_gpu": batch,
             "n_gpus": world, "steps": steps, "warmup": warmup, "optimizer": "tokenreduction_amd.optim.FusedAdamW (one launch; bit-identical to torch AdamW(fused=True))", "loss_last": round(last[0].item(), 4),
             "tokens_per_block": model._last_tokens}
 
@@ -542,6 +558,22 @@ def main():
                 o_ips = quick_images_per_s(m2, x)
                 others[label] = {"images_per_s": round(o_ips, 1), "speedup_vs_dense": round(o_ips / d_ips, 3),
                                  "tokens_per_block": m2._last_tokens}
+                if kr == [0.5]:
+                    # north_star's target line: what the FLOP count allows (the ">= 4 x" target would need 4 x fewer FLOPs than dense: not
+                    # at this schedule), and the drift of this very schedule against the fp32 executor (random-init weights: drift_trained
+                    # has the trained-weight numbers under "keep_rate_0.5")
+                    others[label]["flop_ceiling_vs_dense"] = round(model_flops_per_image([197] * 12) / model_flops_per_image(m2._last_tokens), 3)
+                    m2.precision = "fp32"
+                    l32 = m2(x[:64]).float()
+                    dr = {}
+                    for prec in ("bf16", "bf16x3"):
+                        m2.precision = prec
+                        lb = m2(x[:64]).float()
+                        dr[prec] = {"logit_rel_l2": float(f"{((lb - l32).norm() / l32.norm()).item():.3e}"),
+                                    "logit_max_abs": float(f"{(lb - l32).abs().max().item():.3e}"),
+                                    "top1_agreement": round((lb.argmax(1) == l32.argmax(1)).float().mean().item(), 4)}
+                    m2.precision = "bf16"
+                    others[label]["drift_vs_fp32_path"] = dr
                 del m2
             # forward throughput of the DeiT-B configurations BASELINE names (configs[3] families at 224^2, configs[4] at 384^2);
             # their DP fine-tuning / 8-GPU sweeps are not measured here
@@ -585,7 +617,9 @@ def main():
             model.precision = "bf16"
             rec["bf16x3_mode"] = {"images_per_s": round(x3_ips, 1), "ms_per_step": round(BATCH / x3_ips * 1e3, 3),
                                   "vs_bf16_product_path": round(x3_ips / ips, 3),
-                                  "label": "images/s AT NORTH_STAR TOLERANCE (logits within 1e-3 abs of the reference; the bf16 `value` is not)",
+                                  "label": "images/s of the split-bf16 executor: logits <= 1e-3 abs on every image whose token decisions equal the "
+                                           "reference's (all golden cases: tests/test_hip_split.py); how many images of a trained model flip a "
+                                           "boundary token and then miss 1e-3: drift_trained.bf16x3.images_over_1e-3*.  The bf16 `value` is not within 1e-3.",
                                   "note": "same config as `value`; 3 MFMAs per product, fp32 activations, fp32 twins for every non-GEMM op"}
             rec["cpu_baseline"] = cpu_baseline_leg(model)
             # SURVEY 8d asks the same three numbers (images/s, fraction of the dominant kernel's roofline, CPU baseline) for every BASELINE

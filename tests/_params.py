@@ -129,6 +129,13 @@ GOLDEN_CASES = {
     "evit_small_kr07": dict(family="evit", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
                             keep_rate=[0.7], reduction_loc=[3, 6, 9], batch=2, wseed=71, xseed=72,
                             qkv_gain=4.0, factory="evit_small_patch16_224"),
+    # BASELINE.json north_star's own target line: DeiT-S at keep_rate 0.5 (stages of 99 / 50 / 25 tokens: topk.py:55-56, :141-150)
+    "topk_small_kr05": dict(family="topk", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
+                            keep_rate=[0.5], reduction_loc=[3, 6, 9], batch=2, wseed=63, xseed=64,
+                            qkv_gain=4.0, factory="topk_small_patch16_224"),
+    "evit_small_kr05": dict(family="evit", embed_dim=384, depth=12, num_heads=6, num_classes=1000,
+                            keep_rate=[0.5], reduction_loc=[3, 6, 9], batch=2, wseed=73, xseed=74,
+                            qkv_gain=4.0, factory="evit_small_patch16_224"),
     # ToMe (models/tome.py): geometric keep_rate, and BASELINE configs[2] "r=16 every block" = explicit absolute counts
     "tome_micro": dict(family="tome", embed_dim=128, depth=4, num_heads=2, num_classes=16,
                        keep_rate=[0.7], reduction_loc=[1, 2, 3], batch=3, wseed=91, xseed=92, qkv_gain=6.0),
@@ -272,7 +279,7 @@ GOLDEN_CASES = {
 # cross-entropy criterion) in train mode on the golden case's weights / images, labels from grad_labels().  Too large to store
 # whole (22 M values at DeiT-S), so per parameter: the L2 norm and <= 512 evenly strided entries (grad_sample_index).
 GRAD_CASES = ["deit_micro", "topk_micro", "evit_micro", "tome_micro", "dpcknn_micro", "dpcknn_micro_equal", "ats_micro", "topk_small_kr07",
-              "evit_small_kr07", "tome_small_r16", "deit_base", "dpcknn_base_kr05", "ats_base_kr05", "dyvit_micro_train", "dyvit_small_train", "kmedoids_micro", "heuristic_micro_l2", "topk_micro_droppath",
+              "evit_small_kr07", "topk_small_kr05", "evit_small_kr05", "tome_small_r16", "deit_base", "dpcknn_base_kr05", "ats_base_kr05", "dyvit_micro_train", "dyvit_small_train", "kmedoids_micro", "heuristic_micro_l2", "topk_micro_droppath",
               "sit_micro", "patchmerger_micro", "sinkhorn_micro", "sit_small_kr07", "patchmerger_small_kr07", "sinkhorn_small_kr07",
               "topk_micro_384", "kmedoids_micro_384", "ats_micro_384", "sinkhorn_micro_384",
               "sinkhorn_micro_384_kr09", "dpcknn_micro_384_kr09", "sit_micro_384_kr07", "patchmerger_micro_384_kr07",

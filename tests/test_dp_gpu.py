@@ -93,6 +93,13 @@ def test_bench_runs_its_two_rank_path_on_one_gpu(tmp_path):
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2" and rec["scaling"] == "weak" and rec["value"] > 0
     assert len(rec["finetune"]) == 3 and all("error" not in v and v["n_gpus"] == 2 for v in rec["finetune"].values()), rec["finetune"]
+    # the first real 8-GPU run must explain itself: every fine-tune leg carries the per-bucket timing of its gradient mean
+    for label, v in rec["finetune"].items():
+        dp = v["dp"]
+        assert dp is not None and dp["buckets"] >= 1 and dp["world"] == 2, (label, dp)
+        assert len(dp["bucket_bytes"]) == len(dp["collective_ms"]) == len(dp["range_ms"]) == dp["buckets"], (label, dp)
+        assert all(t >= 0 for t in dp["collective_ms"] + dp["range_ms"]) and dp["exposed_ms"] is not None and dp["exposed_ms"] >= 0, (label, dp)
+        assert dp["algorithm"] in ("rs_ag", "all_reduce") and dp["comm_dtype"] == "float32" and "rccl_version" in dp, (label, dp)
 
 
 @pytest.mark.gpu

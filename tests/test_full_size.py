@@ -65,21 +65,24 @@ def _assert_same(lf, vf, ls, vs, sel, what):
             assert torch.equal(full[sel], t), f"{what}: viz_data[{key}][{blk}] differs"
 
 
-def test_configs1_topk_small_kr07_batch256():
-    """configs[1]: DeiT-S Top-K keep_rate 0.7 at blocks 3/6/9, batch 256 (M = 50,432 / 35,328 / 24,832 / 17,408 token rows) --
-    the headline workload."""
+@pytest.mark.parametrize("name,kr,factory", [("topk_small_kr07", 0.7, "topk_small_patch16_224"), ("topk_small_kr05", 0.5, "topk_small_patch16_224"),
+                                            ("evit_small_kr05", 0.5, "evit_small_patch16_224")])
+def test_configs1_small_batch256(name, kr, factory):
+    """configs[1]: DeiT-S Top-K keep_rate 0.7 at blocks 3/6/9, batch 256 (M = 50,432 / 35,328 / 24,832 / 17,408 token rows) -- the headline
+    workload -- and north_star's own target line, keep_rate 0.5 (Top-K: 99 / 50 / 25 tokens per image, M = 25,344 / 12,800 / 6,400 after
+    the stages, where every kernel of a block sits near its launch floor; EViT: one fused token more; models/topk.py:55-56, :141-150)."""
     import tokenreduction_amd as tra
     from tests._stepwise import forward_stepwise
-    case = GOLDEN_CASES["topk_small_kr07"]
-    args = types.SimpleNamespace(keep_rate=[0.7], reduction_loc=[3, 6, 9], viz_mode=True)
-    model = tra.create_model("topk_small_patch16_224", args=args)
+    case = GOLDEN_CASES[name]
+    args = types.SimpleNamespace(keep_rate=[kr], reduction_loc=[3, 6, 9], viz_mode=True)
+    model = tra.create_model(factory, args=args)
     cfg = case_config(case)
     params = make_params(cfg, case["wseed"], case["qkv_gain"])
     model.load_state_dict(params)
     model = model.cuda().eval()
     B = 256
     x, sel = _images(B, 224, 0), _spread(B)
-    _assert_same(*_eval_pair(model, x, sel), sel, "topk_small kr 0.7 B=256")
+    _assert_same(*_eval_pair(model, x, sel), sel, f"{name} B=256")
     # ... and the batch of 8 against the oracle: decisions bit-exact on the device's own scores, logits teacher-forced
     xs = x[sel].contiguous()
     l2, info = forward_stepwise(model, xs.cuda())

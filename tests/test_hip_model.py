@@ -166,9 +166,18 @@ def test_model_parity(golden_dir, name):
         # top-k, and every flip changes the token set of all later blocks (free-running numbers are informational; the
         # teacher-forced one above and the fp32 path's exact kept sets are the pins)
         tol = 0.35   # measured 0.16-0.22 (micro), 0.2-0.3 (small) across kernel revisions: the flips move with every rounding change
+    ov_floor = 0.60
+    if min(case["keep_rate"]) <= 0.5 and case["embed_dim"] > 128:
+        # north_star's own schedule (DeiT-S keep_rate 0.5: K = 98 / 49 / 24 of 196): the K-th score sits in the dense middle of the CLS-attention
+        # distribution -- the best of eight seed pairs has a minimum relative gap of 2e-2 at the boundary (gen_golden.py prints it), the bf16
+        # scores carry ~1e-2 -- so a boundary token flips at the first stage on some image and the later stages see another token set.
+        # Measured free-running: 0.12 / 0.18 relative L2 vs oracle_bf16 / reference, overlaps 0.99 / 0.69 / 0.63.  The pins of this case are
+        # (2) selections bit-exact on the device's own scores, (5) teacher-forced 1.3e-2 < FORCED_TOL, and the fp32 / bf16x3 executors'
+        # reference-identical sets (tests/test_hip_fp32.py, tests/test_hip_split.py); the free-running bound is informational.
+        tol, ov_floor = 0.25, 0.50
     assert rel_bf < tol, rel_bf
     assert rel_ref < tol, rel_ref
-    assert all(o >= 0.60 for o in ov_bf + ov_ref), (ov_bf, ov_ref)
+    assert all(o >= ov_floor for o in ov_bf + ov_ref), (ov_bf, ov_ref)
     assert all(o[0] >= 0.95 for o in (ov_bf, ov_ref) if o), (ov_bf, ov_ref)
 
 

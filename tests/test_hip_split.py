@@ -66,12 +66,13 @@ def test_gemm_split_patch_epilogue(ops):
 
 
 @pytest.mark.parametrize("B,N,H", [(2, 197, 6), (2, 138, 2), (1, 69, 3), (1, 7, 1), (1, 224, 1), (2, 97, 12), (1, 17, 2), (1, 257, 1),
-                                   (2, 577, 3), (1, 225, 2), (1, 640, 1), (1, 385, 2)])
+                                   (2, 577, 3), (1, 225, 2), (1, 640, 1), (1, 385, 2), (1, 1024, 2), (1, 897, 1)])
 @pytest.mark.parametrize("with_size", [False, True])
 def test_attention_split(ops, B, N, H, with_size):
     """Beyond 224 tokens (384 x 384 inputs: 577) the keys are walked in chunks of 128, twice (round 4; the fp32 VALU kernel served these
-    lengths before): 225 = the first length of that kernel, 257 / 385 = a chunk boundary plus one key, 640 = five full chunks, and the
-    column sums of several query groups meeting in the per-wave LDS rows."""
+    lengths before): 225 = the first length of that kernel, 257 / 385 = a chunk boundary plus one key, 640 = five full chunks, 1024 = the
+    dispatch limit (eight chunks: 105 KB of per-wave column-sum rows in LDS) and 897 = seven chunks plus one key, and the column sums of
+    several query groups meeting in the per-wave LDS rows."""
     qkv = _randn(N + H, B * N, 3 * H * 64, scale=1.5)
     size = (1 + torch.from_numpy(np.random.default_rng(N).integers(0, 4, (B, N)).astype(np.float32))) if with_size else None
     q, k, v = qkv.double().reshape(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)

@@ -14,7 +14,7 @@ import torch
 
 from tests._params import GOLDEN_CASES, GRAD_CASES, grad_sample_index, oracle_param_grads
 
-CPU_CASES = [n for n in GRAD_CASES if GOLDEN_CASES[n]["embed_dim"] <= 192] + ["topk_small_kr07", "dpcknn_base_kr05", "ats_base_kr05", "dyvit_small_train"]
+CPU_CASES = [n for n in GRAD_CASES if GOLDEN_CASES[n]["embed_dim"] <= 192] + ["topk_small_kr07", "topk_small_kr05", "evit_small_kr05", "dpcknn_base_kr05", "ats_base_kr05", "dyvit_small_train"]
 
 
 def fixture_inputs(case, g):

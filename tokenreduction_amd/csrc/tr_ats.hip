@@ -197,7 +197,10 @@ extern "C" int tr_ats_sample(const float* cls_rows, const void* qkv, int qkv_is_
   TR_REQUIRE(tr_aligned16(qkv), TR_ERR_ALIGN, "tr_ats_sample: qkv must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(s);
   const size_t lds = (size_t)H * (N - 1) * sizeof(float);            // one term per (head, token)
-  TR_REQUIRE(lds <= 48 * 1024, TR_ERR_SHAPE, "tr_ats_sample: %d heads x %d tokens do not fit the per-head scratch", H, N - 1);
+  TR_REQUIRE(lds <= 128 * 1024, TR_ERR_SHAPE, "tr_ats_sample: %d heads x %d tokens do not fit the per-head scratch (128 KiB of LDS)", H, N - 1);
+  // more than the default 64 KiB of dynamic LDS (16 heads x 1024 tokens = 64 KiB; the CU has 160): raise the kernel's limit on demand
+  if (qkv_is_f32) TR_RESERVE_LDS(reinterpret_cast<const void*>(ats_sample_kernel<true>), lds, "tr_ats_sample");
+  else TR_RESERVE_LDS(reinterpret_cast<const void*>(ats_sample_kernel<false>), lds, "tr_ats_sample");
   if (qkv_is_f32)
     hipLaunchKernelGGL(ats_sample_kernel<true>, dim3(B), dim3(256), lds, st, cls_rows, qkv, mask, steps, n_steps, ids, new_mask, cdf_out, N,
                        H, K, 1e-6f);

@@ -1275,6 +1275,7 @@ int tr_ln_defer_flush() {
   c->T.blk0[LN_DEFER_SEGS] = blocks;
   hipLaunchKernelGGL(partial_reduce_tall_segs_kernel, dim3(blocks), dim3(256), 0, c->st, c->T);
   c->n = 0;
+  c->used = 0;                 // the reduce is ordered before every later launch of this stream: the slices may be rewritten
   c->T.blk0[0] = 0;
   TR_CHECK_LAUNCH("tr_layernorm_bwd (deferred reduce)");
   return TR_OK;
@@ -1311,9 +1312,9 @@ static int layernorm_bwd_impl(const uint16_t* dy, const float* x, long ldx, cons
   hipStream_t st = static_cast<hipStream_t>(s);
   LnDefer* dc = g_ln_defer;
   const size_t need = (size_t)grid * 2 * D;
-  const bool defer = dc != nullptr && dc->st == st && grid >= 64 && D <= 4096 && dc->used + need <= dc->cap;
+  const bool defer = dc != nullptr && dc->st == st && grid >= 64 && D <= 4096 && need <= dc->cap;
   if (defer) {
-    if (dc->n + 2 > LN_DEFER_SEGS) TR_TRY_RC(tr_ln_defer_flush());
+    if (dc->n + 2 > LN_DEFER_SEGS || dc->used + need > dc->cap) TR_TRY_RC(tr_ln_defer_flush());     // full: reduce what is there, start over
     ws = dc->region + dc->used;
     dc->used += need;
   }

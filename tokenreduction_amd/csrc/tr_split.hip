@@ -539,8 +539,9 @@ extern "C" int tr_attention_split(const float* qkv, float* out, float* cls_rows,
   TR_REQUIRE(tr_aligned16(qkv) && tr_aligned16(out), TR_ERR_ALIGN, "tr_attention_split: pointers must be 16-byte aligned");
   hipStream_t st = static_cast<hipStream_t>(s);
   if (N > 16 * A_MAXT) {                     // K/V hi+lo of a head no longer fit the LDS: keys in chunks of 128, two passes
-    static const bool twin = getenv("TR_SPLIT_LONG_OFF") != nullptr;        // lab switch: the fp32 VALU kernel that served these lengths before
-    if (twin || N > 1024) return tr_attention_f32(qkv, out, cls_rows, size, colsum_part, B, N, H, s);
+    // up to 1024 keys (the length tests/test_hip_split.py covers, with column sums and CLS rows); beyond: the fp32 VALU kernel, which
+    // itself takes N <= 640 and raises above -- one limit, stated in models.py's docstring
+    if (N > 1024) return tr_attention_f32(qkv, out, cls_rows, size, colsum_part, B, N, H, s);
     tr_prof_note("attention_split_long", 18.0 * B * H * (double)N * N * 64, 16.0 * B * N * H * 64);
     const int nch = (N + AL_CH - 1) / AL_CH;
     const size_t lds = (size_t)2 * AL_CH * A_KROW + (size_t)2 * 64 * AL_VROW + (size_t)AL_CH * 4 + (colsum_part ? (size_t)AL_NW * nch * AL_CH * 4 : 0);

@@ -92,8 +92,11 @@ bool make_bwd_plan(const tr_vit_config* c, int B, const trplan::TokenPlan& t, Bw
     p->soft_ds = take(T * trplan::soft_ld64(soft_k) * 2);
     p->soft_s = take(T * D * 4);
   }
-  // the LayerNorm parameter-gradient partials of a whole pass (reduced by one launch at its end): two norms per block + one per stage
-  p->lnpart_floats = (size_t)(3 * c->depth + 2) * tr_layernorm_bwd_workspace_floats((int)T, (int)D);
+  // the LayerNorm parameter-gradient partials of a pass (reduced by one launch at its end; a flush after 16 norms reuses the region from its
+  // start): two norms per block, one per reduction stage that owns a norm, the final norm -- never more than 16 slices in flight
+  int ln_norms = 2 * c->depth + 2;
+  for (int i = 0; i < c->depth; ++i) ln_norms += c->keep[i] > 0 ? 1 : 0;
+  p->lnpart_floats = (size_t)(ln_norms < 16 ? ln_norms : 16) * tr_layernorm_bwd_workspace_floats((int)T, (int)D);
   p->lnpart = take(p->lnpart_floats * 4);
   p->total = o;
   return true;

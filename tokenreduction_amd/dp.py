@@ -52,6 +52,12 @@ class FlatGradReducer:
         self._stage = None
         self._shard = None
         self.launched: List[Tuple[int, int]] = []          # (start, stop) of the buckets of the last backward, in launch order
+        # record_timing: HIP events around every bucket of the LAST backward -- on the compute stream where the bucket's block range ends, on
+        # the side stream around its collective, and around finish() -- so that timing() can tell overlap from exposure (bench.py `dp`)
+        self.record_timing = False
+        self._t_begin = None
+        self._t_events: List[Tuple] = []
+        self._t_finish = None
 
     # ---- model wiring ---------------------------------------------------------------------------------------------------
     def attach(self, model):
@@ -96,6 +102,14 @@ class FlatGradReducer:
         return out
 
     # ---- the collective -------------------------------------------------------------------------------------------------
+    def begin(self, flat: torch.Tensor):
+        """Start of a backward pass that will reduce (training._VitTrainFn.backward): forget the last pass's bucket list and timing events."""
+        self.launched = []
+        self._t_events, self._t_finish, self._t_begin = [], None, None
+        if self.record_timing and flat.is_cuda:
+            self._t_begin = torch.cuda.Event(enable_timing=True)
+            self._t_begin.record(torch.cuda.current_stream(flat.device))
+
     def reduce_slice(self, flat: torch.Tensor, start: int, stop: int):
         """Mean over the ranks of flat[start:stop], in place, on the side stream (GPU) / synchronously (CPU)."""
         sl = flat[start:stop]
@@ -104,15 +118,25 @@ class FlatGradReducer:
             dev = flat.device
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=dev)
-            ev = torch.cuda.Event()
+            timing = self.record_timing
+            ev = torch.cuda.Event(enable_timing=timing)
             ev.record(torch.cuda.current_stream(dev))               # the range's gradient kernels are enqueued before this point
             self._stream.wait_event(ev)
             with torch.cuda.stream(self._stream):
+                if timing:
+                    c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    c0.record(self._stream)
                 self._collective(sl)
+                if timing:
+                    c1.record(self._stream)
+                    self._t_events.append((ev, c0, c1, (stop - start) * 4))
         else:
             self._collective(sl)
 
     def _collective(self, sl: torch.Tensor):
+        # _stage and _shard are shared by all buckets.  That is race-free because every collective of this reducer is enqueued on ONE side
+        # stream (and ProcessGroupNCCL serialises a communicator's collectives on its own stream behind it): bucket k+1's copy into _stage
+        # is ordered after bucket k's copy back out of it.  A second side stream, or async_op=True, would need a staging pair per bucket.
         n = sl.numel()
         buf = sl
         if self.comm_dtype is not None and self.comm_dtype != sl.dtype:            # e.g. bf16 payload: half the bytes on the links
@@ -139,4 +163,32 @@ class FlatGradReducer:
     def finish(self, flat: torch.Tensor):
         """Order the caller's stream after the outstanding bucket reductions (no host wait)."""
         if flat.is_cuda and self._stream is not None:
-            torch.cuda.current_stream(flat.device).wait_stream(self._stream)
+            cur = torch.cuda.current_stream(flat.device)
+            if self.record_timing and self._t_events:
+                f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                f0.record(cur)
+                cur.wait_stream(self._stream)
+                f1.record(cur)
+                self._t_finish = (f0, f1)
+            else:
+                cur.wait_stream(self._stream)
+
+    def timing(self):
+        """Per-bucket timing of the last backward that reduced (record_timing = True), after a device synchronisation.
+        range_ms[k]: compute-stream time of bucket k's block range (range k ends where its collective may start); collective_ms[k]: the
+        bucket's reduction on the side stream; exposed_ms: how long the compute stream waited in finish() -- the part of the collectives
+        the backward did NOT hide (ideally the last bucket's collective only)."""
+        if not self._t_events or self._t_begin is None:
+            return None
+        torch.cuda.synchronize()
+        range_ms, prev = [], self._t_begin
+        for ev, _, _, _ in self._t_events:
+            range_ms.append(round(prev.elapsed_time(ev), 4))
+            prev = ev
+        rec = {"buckets": len(self._t_events), "bucket_bytes": [b for _, _, _, b in self._t_events],
+               "range_ms": range_ms, "collective_ms": [round(c0.elapsed_time(c1), 4) for _, c0, c1, _ in self._t_events],
+               "collective_start_after_range_end_ms": [round(ev.elapsed_time(c0), 4) for ev, c0, _, _ in self._t_events],
+               "exposed_ms": round(self._t_finish[0].elapsed_time(self._t_finish[1]), 4) if self._t_finish else None,
+               "algorithm": self.algorithm, "comm_dtype": str(self.comm_dtype or torch.float32).replace("torch.", ""),
+               "world": self.world, "backend": dist.get_backend(self.group)}
+        return rec

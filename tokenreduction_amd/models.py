@@ -211,6 +211,7 @@ class VisionTransformer(nn.Module):
         round 2's packing cache keyed on: the bf16 operand copies went stale and training silently ran on the initial matrices).  Call it
         yourself after writing into `p.data` through an API that does not bump versions."""
         self._weights_dirty = True
+        self._dirty_by_backward = False          # (training._VitTrainFn.backward sets it after its own call: optim.FusedAdamW may clear only that)
 
     def _pack(self, need_transposed=False):
         """bf16 (or fp32) operand copies of every parameter the executor reads + the C structs.  The copies live in PERSISTENT buffers:

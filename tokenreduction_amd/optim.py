@@ -68,6 +68,7 @@ class FusedAdamW(torch.optim.Optimizer):
     def _build(self, dev):
         slots = self._operand_slots()
         items, key = [], []
+        n_refresh = 0
         for gi, g in enumerate(self.param_groups):
             for p in g["params"]:
                 if p.grad is None:
@@ -80,6 +81,7 @@ class FusedAdamW(torch.optim.Optimizer):
                         raise NotImplementedError(f"FusedAdamW: optimizer state {k} must be fp32, contiguous and on the parameter's device")
                 rows, cols = (p.shape[0], p.numel() // p.shape[0]) if p.dim() >= 2 else (1, p.numel())
                 dst, dst_t = (slots or {}).get(p.data_ptr(), (0, 0))
+                n_refresh += 1 if dst else 0
                 items.append((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), dst, dst_t, rows, cols, gi, 0))
                 key.append((p.data_ptr(), p.grad.data_ptr(), dst, dst_t, gi, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()))
         key = tuple(key)
@@ -90,7 +92,10 @@ class FusedAdamW(torch.optim.Optimizer):
         for n, it in enumerate(items):
             first[n + 1] = first[n] + ((it[6] + 63) // 64) * ((it[7] + 63) // 64)
         self._table = dict(key=key, items=torch.from_numpy(arr.view(np.uint8).copy()).to(dev), first=torch.from_numpy(first).to(dev),
-                           n=len(items), tiles=int(first[-1]), refreshes=slots is not None,
+                           n=len(items), tiles=int(first[-1]),
+                           # does this step rewrite EVERY bf16 operand copy the executor reads?  (a matrix without a gradient this step --
+                           # frozen, or outside this optimizer -- keeps its old copy: the model then refreshes for itself)
+                           refreshes=slots is not None and n_refresh == len(slots),
                            params=[p for g in self.param_groups for p in g["params"] if p.grad is not None])
         return self._table
 
@@ -132,8 +137,12 @@ class FusedAdamW(torch.optim.Optimizer):
             self.state[p]["step"] = step
         m = self._model
         if m is not None:
-            if tab["refreshes"]:
-                m._weights_dirty = False          # every operand copy was rewritten by the step; fp32 operands are read in place
+            # every operand copy was rewritten by the step (fp32 operands are read in place) -- but only the dirt this optimizer's own backward
+            # left may be declared clean: a weights_changed() raised for another reason since (a manual p.data edit, an EMA / teacher copy
+            # into a matrix this step did not touch) must survive
+            if tab["refreshes"] and getattr(m, "_dirty_by_backward", False):
+                m._weights_dirty = False
+                m._dirty_by_backward = False
             else:
                 m.weights_changed()
         return loss

@@ -321,7 +321,7 @@ class _VitTrainFn(torch.autograd.Function):
         # that bucket's in-place reduction on the reducer's stream while the next range runs
         ranges = reducer.plan(st.block_slices, model.depth) if reduce_now else [(model.depth - 1, 0, 0, st.flat.numel())]
         if reduce_now:
-            reducer.launched = []
+            reducer.begin(st.flat) if hasattr(reducer, "begin") else setattr(reducer, "launched", [])
         stream = torch.cuda.current_stream().cuda_stream
         with torch.cuda.device(dl.device):
             for hi, lo, start, stop in ranges:
@@ -341,7 +341,9 @@ class _VitTrainFn(torch.autograd.Function):
                 p.grad = st.views[n]
             elif p.grad.data_ptr() != st.views[n].data_ptr():
                 p.grad.add_(st.views[n])
+        was_dirty = bool(getattr(model, "_weights_dirty", False))
         model.weights_changed()          # an optimizer step follows; fused optimizers do not bump the version counters the pack cache reads
+        model._dirty_by_backward = not was_dirty      # dirt that was there before this backward is somebody else's: only a full repack clears it
         return None, None, None
 
 

@@ -11,8 +11,11 @@ channel, plus unit-variance pixel noise times `sigma` -- and then evaluated on h
     bf16    the timed product path
     bf16x3  split-bf16 products on the matrix cores (north_star's 1e-3 tolerance)
 
-Reported: held-out accuracy per executor, top-1 agreement of bf16 and bf16x3 with fp32, max |logit difference|, and the distribution of
-the fp32 top-1 margin (logit of the arg-max minus the runner-up) -- a disagreement needs a margin below the logit drift.
+Reported: held-out accuracy per executor, top-1 agreement of bf16 and bf16x3 with fp32, max |logit difference|, the distribution of
+the fp32 top-1 margin (logit of the arg-max minus the runner-up) -- a disagreement needs a margin below the logit drift --, and, per
+executor, HOW MANY of the images miss north_star's 1e-3 logit tolerance, split by whether every kept-token set equals the fp32 executor's
+(then the miss is arithmetic) or one differs (a boundary token flipped: every later block sees another token set).  The same again with the
+trained weights run at keep_rate 0.5, north_star's own target schedule.
 
     python tools/drift_trained.py [steps] [eval_images] [sigma]
 """
@@ -59,36 +62,61 @@ def run(device="cuda", steps=600, eval_images=10240, sigma=3.0, batch=256, lr=1e
     train_s = time.perf_counter() - t0
     model.eval()
     nb = max(1, eval_images // batch)
-    logits = {}
-    labels = []
-    for prec in ("fp32", "bf16", "bf16x3"):
-        model.precision = prec
-        rows = []
-        for b in range(nb):
-            x, y = make(batch, 900_000 + b)
-            rows.append(model(x).float().clone())
-            if prec == "fp32":
-                labels.append(y)
-        logits[prec] = torch.cat(rows)
-    model.precision = "bf16"
-    y = torch.cat(labels)
-    ref = logits["fp32"]
-    top2 = ref.topk(2, dim=1).values
-    margin = (top2[:, 0] - top2[:, 1])
-    q = torch.quantile(margin, torch.tensor([0.001, 0.01, 0.1, 0.5], device=dev)).tolist()
     rec = {"model": "topk_small_patch16_224 kr0.7", "task": f"1000 synthetic classes (14x14x3 prototype per class + {sigma} x unit noise)",
            "train_steps": steps, "train_batch": batch, "train_seconds": round(train_s, 1), "train_loss_last": round(float(loss.detach()), 4),
-           "train_acc_last_batch": round(float(acc), 4), "eval_images": int(ref.shape[0]),
-           "fp32_margin_quantiles": {"p0.1%": round(q[0], 4), "p1%": round(q[1], 4), "p10%": round(q[2], 4), "median": round(q[3], 4)}}
-    for prec in ("fp32", "bf16", "bf16x3"):
-        lg = logits[prec]
-        e = {"top1_acc": round(float((lg.argmax(1) == y).float().mean()), 5)}
-        if prec != "fp32":
-            e["top1_agreement_with_fp32"] = round(float((lg.argmax(1) == ref.argmax(1)).float().mean()), 5)
-            e["disagreements"] = int((lg.argmax(1) != ref.argmax(1)).sum())
-            e["max_abs_logit_diff"] = round(float((lg - ref).abs().max()), 5)
-            e["rel_l2_logit_diff"] = round(float((lg - ref).norm() / ref.norm()), 6)
-        rec[prec] = e
+           "train_acc_last_batch": round(float(acc), 4), "eval_images": nb * batch, "tolerance": 1e-3}
+
+    def evaluate(m):
+        """logits and kept-token SETS (one sorted row per image and reduction stage) under the three executors, on the same held-out images"""
+        m.eval()
+        m.viz_mode = True
+        logits, kept, labels = {}, {}, []
+        for prec in ("fp32", "bf16", "bf16x3"):
+            m.precision = prec
+            rows, sets = [], []
+            for b in range(nb):
+                x, y = make(batch, 900_000 + b)
+                lg, viz = m(x)
+                rows.append(lg.float().clone())
+                sets.append(torch.cat([torch.sort(torch.as_tensor(t).to(dev, torch.int64), dim=1).values for _, t in sorted(viz["Kept_Tokens"].items())], dim=1))
+                if prec == "fp32":
+                    labels.append(y)
+            logits[prec], kept[prec] = torch.cat(rows), torch.cat(sets)
+        m.precision = "bf16"
+        m.viz_mode = False
+        return logits, kept, torch.cat(labels)
+
+    def summarise(logits, kept, y):
+        ref = logits["fp32"]
+        top2 = ref.topk(2, dim=1).values
+        q = torch.quantile(top2[:, 0] - top2[:, 1], torch.tensor([0.001, 0.01, 0.1, 0.5], device=dev)).tolist()
+        out = {"fp32_margin_quantiles": {"p0.1%": round(q[0], 4), "p1%": round(q[1], 4), "p10%": round(q[2], 4), "median": round(q[3], 4)}}
+        for prec in ("fp32", "bf16", "bf16x3"):
+            lg = logits[prec]
+            e = {"top1_acc": round(float((lg.argmax(1) == y).float().mean()), 5)}
+            if prec != "fp32":
+                per_image = (lg - ref).abs().amax(dim=1)
+                same_sets = (kept[prec] == kept["fp32"]).all(dim=1)
+                over = per_image > 1e-3
+                e["top1_agreement_with_fp32"] = round(float((lg.argmax(1) == ref.argmax(1)).float().mean()), 5)
+                e["disagreements"] = int((lg.argmax(1) != ref.argmax(1)).sum())
+                e["max_abs_logit_diff"] = round(float(per_image.max()), 5)
+                e["rel_l2_logit_diff"] = round(float((lg - ref).norm() / ref.norm()), 6)
+                # north_star's "logits within 1e-3 abs": how many IMAGES miss it, and whether a token decision differs on them
+                e["images_over_1e-3"] = int(over.sum())
+                e["images_over_1e-3_with_the_reference_token_sets"] = int((over & same_sets).sum())
+                e["images_over_1e-3_where_a_kept_set_differs"] = int((over & ~same_sets).sum())
+                e["images_where_a_kept_set_differs"] = int((~same_sets).sum())
+                e["max_abs_logit_diff_on_images_with_the_reference_token_sets"] = round(float(per_image[same_sets].max()) if bool(same_sets.any()) else 0.0, 6)
+            out[prec] = e
+        return out
+
+    rec.update(summarise(*evaluate(model)))
+    # the same trained weights at north_star's target schedule, keep_rate 0.5 (99 / 50 / 25 tokens; the schedule is not a learned quantity)
+    m05 = bench.build_model(keep_rate=[0.5], device=dev, qkv_gain=1.0)
+    m05.load_state_dict(model.state_dict())
+    rec["keep_rate_0.5"] = summarise(*evaluate(m05))
+    del m05
     return rec
 
 
