@@ -82,6 +82,10 @@ int tr_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* bias, void* 
  * `packed`: the two weight matrices in fragment-major order, tr_mlp_pack_bytes(D,Hd) bytes, written by tr_mlp_pack_bf16 from the
  * bf16 [Hd,D] / [D,Hd] matrices (repack whenever they change).  tr_mlp_fused_supported: D == 384, Hd %% 32 == 0 (other widths: the pair). */
 int tr_mlp_fused_supported(int D, int Hd);
+/* Which Mlp the eval executor runs where tr_block_weights.mlp_pk is given: 1 = the fused launch wherever the shape is supported, 0 = never,
+ * -1 (default) = where its 128-row blocks fill at least three quarters of the last round of 256 workgroups (the two schedules are bit-identical,
+ * so this is a speed choice only).  Process-wide; returns the previous mode. */
+int tr_set_mlp_fused(int mode);
 size_t tr_mlp_pack_bytes(int D, int Hd);
 int tr_mlp_pack_bf16(const uint16_t* fc1_w, const uint16_t* fc2_w, void* packed, int D, int Hd, tr_stream_t s);
 int tr_mlp_fused_bf16(const uint16_t* xn, const void* packed, const float* fc1_b, const float* fc2_b, uint16_t* out, int M, int D, int Hd,
@@ -440,6 +444,8 @@ typedef struct {
   const float* ln2_g; const float* ln2_b;
   const void* fc1_w; const float* fc1_b;     /* [Hd,D], [Hd] */
   const void* fc2_w; const float* fc2_b;     /* [D,Hd], [D] */
+  const void* mlp_pk;                        /* optional (NULL = none): fc1_w / fc2_w in tr_mlp_pack_bf16's fragment-major order; with it the bf16
+                                                EVAL forward may run the block's Mlp as one launch (tr_mlp_fused_bf16: bit-identical to the pair) */
 } tr_block_weights;
 
 /* Learned reduction module of one block (families that own one); unused pointers NULL.

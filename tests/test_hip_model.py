@@ -181,6 +181,44 @@ def test_model_parity(golden_dir, name):
     assert all(o[0] >= 0.95 for o in (ov_bf, ov_ref) if o), (ov_bf, ov_ref)
 
 
+@pytest.mark.parametrize("name", ["topk_small_kr07", "evit_small_kr05", "tome_small_r16", "deit_small"])
+def test_fused_mlp_executor_is_bit_identical(name):
+    """The eval executor runs a block's Mlp either as fc1+GELU / fc2 (two GEMM launches) or as ONE launch that keeps the hidden activation on
+    the CU (csrc/tr_mlp_fused.hip) -- by default wherever the fused kernel's block schedule fills the chip.  The two are the same arithmetic in
+    the same order: logits and every decision must agree BIT FOR BIT with the fused kernel forced on, forced off and on auto -- also after
+    an optimizer step has rewritten the bf16 operand copies behind the packed Mlp matrices' back (optim.FusedAdamW)."""
+    from tokenreduction_amd import ops
+    from tokenreduction_amd.optim import FusedAdamW
+    case = GOLDEN_CASES[name]
+    model, _, _ = build_model(case)
+    model.viz_mode = False
+    x = make_images(9, 224, 5).cuda()
+    prev = ops.set_mlp_fused(0)
+    try:
+        def run():
+            out = {}
+            for mode in (0, 1, -1):
+                ops.set_mlp_fused(mode)
+                model._ws = {}                                  # drop captured graphs: the mode is read when the launches are enqueued
+                out[mode] = model(x).clone()
+            return out
+        a = run()
+        assert torch.isfinite(a[0]).all()
+        assert torch.equal(a[0], a[1]) and torch.equal(a[0], a[-1]), float((a[0] - a[1]).abs().max())
+        # one training step (the optimizer refreshes the bf16 copies itself), then eval again: the packed Mlp copies must have followed
+        model.train()
+        opt = FusedAdamW(model.parameters(), lr=1e-3, weight_decay=0.05, model=model)
+        loss = model(x).square().mean()
+        loss.backward()
+        opt.step()
+        model.eval()
+        b = run()
+        assert not torch.equal(a[0], b[0]), "the step did not change the weights?"
+        assert torch.equal(b[0], b[1]) and torch.equal(b[0], b[-1]), float((b[0] - b[1]).abs().max())
+    finally:
+        ops.set_mlp_fused(prev)
+
+
 def _ats_parity(name, case, g, model, params, cfg, x, logits, viz, info):
     """ATS leg: executor == stepwise ids; the sampling op pinned bit-exact on the device's own cdf; teacher-forced logits."""
     from tests._params import assert_valid_sampling

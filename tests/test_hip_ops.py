@@ -107,12 +107,12 @@ def test_gemm_half_tile_tail_round(ops, M, N, K, why, epi):
 
 # ------------------------------------------------------------------------------------------ fused eval Mlp (fc1 -> GELU -> fc2, one launch)
 @pytest.mark.parametrize("M", [1, 77, 128, 129, 1000, 197 * 8, 32768 + 5, 50432])
-@pytest.mark.parametrize("Hd", [1536, 64, 96])
+@pytest.mark.parametrize("Hd", [1536, 64, 192])
 def test_mlp_fused_is_bit_identical_to_the_gemm_pair(ops, M, Hd):
     """tr_mlp_fused_bf16 (timm Mlp of the eval forward, models/topk.py:95) keeps the hidden activation on the CU; by construction -- same
     MFMA, same operand maps, accumulators that start at the bias, K in the same 32-deep steps, same GELU fit, hidden rounded to bf16 at the
     same point -- its output equals tr_gemm_bf16(GELU_BF16) -> tr_gemm_bf16(BF16) BIT FOR BIT, for ragged last blocks, several blocks per
-    workgroup, and hidden widths of 2, 3 and 48 steps.  Sampled rows are also held against the float64 Mlp on the bf16-rounded operands."""
+    workgroup, and hidden widths of 2, 6 and 48 steps (the pair needs Hd %% 64 == 0).  Sampled rows are also held against the float64 Mlp on the bf16-rounded operands."""
     if M > 2000 and Hd != 1536:
         pytest.skip("large M only at the model's hidden width")
     D = 384

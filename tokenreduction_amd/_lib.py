@@ -24,7 +24,7 @@ _vp, _i, _f, _l, _sz = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_size_t
 
 class TrBlockWeights(C.Structure):
     _fields_ = [(n, _vp) for n in ("ln1_g", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
-                                   "ln2_g", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+                                   "ln2_g", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b", "mlp_pk")]
 
 
 class TrStageWeights(C.Structure):
@@ -83,6 +83,7 @@ SIGNATURES = {
     "tr_patch_embed_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tr_gemm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "tr_mlp_fused_supported": (_i, [_i, _i]),
+    "tr_set_mlp_fused": (_i, [_i]),
     "tr_mlp_pack_bytes": (_sz, [_i, _i]),
     "tr_mlp_pack_bf16": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "tr_mlp_fused_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -589,6 +589,18 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
 
 extern "C" int tr_mlp_fused_supported(int D, int Hd) { return (D == MF_D && Hd % 32 == 0 && Hd >= 64) ? 1 : 0; }
 
+static std::atomic<int> g_mlp_fused_mode{-1};
+extern "C" int tr_set_mlp_fused(int mode) { return g_mlp_fused_mode.exchange(mode < 0 ? -1 : (mode > 0 ? 1 : 0)); }
+// the executor's question (tr_vit.hip): run the fused launch for M rows?  A block is a chain of Hd / 32 sequential steps, so the launch costs
+// ceil(blocks / 256) rounds whatever the last round holds: 394 blocks (M = 50,432) pay 2 rounds for 1.54, 276 blocks 2 for 1.08
+int tr_mlp_fused_wanted(int M, int D, int Hd) {
+  if (!tr_mlp_fused_supported(D, Hd)) return 0;
+  const int mode = g_mlp_fused_mode.load(std::memory_order_relaxed);
+  if (mode >= 0) return mode;
+  const int nblk = (M + MF_ROWS - 1) / MF_ROWS, rounds = (nblk + 255) / 256;
+  return 4 * nblk >= 3 * 256 * rounds;
+}
+
 extern "C" size_t tr_mlp_pack_bytes(int D, int Hd) {
   if (D <= 0 || Hd <= 0 || D % 32 || Hd % 32) return 0;
   return (size_t)(Hd / 32) * (size_t)(2 * (D / 32) + D / 16) * 1024;

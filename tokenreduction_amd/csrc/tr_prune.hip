@@ -277,7 +277,12 @@ __global__ __launch_bounds__(256) void softmerge_mfma_kernel(const float* __rest
   const int P = N - 1;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, g = lane >> 4, q4 = li >> 2, p4 = li & 3;
-  const int b = blockIdx.y, d0 = blockIdx.x * 64;
+  // The feature slices of an image (6 at D = 384, 12 at D = 768) all read the image's whole weight matrix: give them consecutive ids of the
+  // XCD-contiguous order, so that ONE L2 fetches it (r04i: 155.7 MB fetched per launch at SiT-S against 71.7 MB of operands -- 1.75 x the
+  // algorithmic bytes -- with the slices dealt round-robin over the eight L2s)
+  const int nsl = (D + 63) >> 6;
+  const int lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int b = lid / nsl, d0 = (lid - b * nsl) * 64;
   const int nkf = (K + 15) >> 4, Kp = nkf * 16;
   const float* sb = src + ((size_t)b * N + 1) * D;
   const float* wb = wt + ((size_t)b * N + 1) * ldl;
@@ -627,7 +632,10 @@ __device__ __forceinline__ float wave_sum_valu(float v) {
 #ifndef TR_SR_RPW
 #define TR_SR_RPW 72
 #endif
-constexpr int SR_NW = 8, SR_RPW = TR_SR_RPW, SR_KC = 3;           // 8 waves x 72 rows = 576 tokens, 3 x 64 = 192 centres: 216 plan registers per lane
+#ifndef TR_SR_NW
+#define TR_SR_NW 8
+#endif
+constexpr int SR_NW = TR_SR_NW, SR_RPW = TR_SR_RPW, SR_KC = 3;           // 8 waves x 72 rows = 576 tokens, 3 x 64 = 192 centres: 216 plan registers per lane
                                                             // (two waves per SIMD: 256 registers each; 12 x 48 spilled 57 of its 168)
 __global__ __launch_bounds__(64 * SR_NW) void sinkhorn_regs_kernel(const float* __restrict__ scores, int ldl, float eps, int iters,
                                                                    float* __restrict__ wt, float* __restrict__ soft, int N, int K) {
@@ -895,7 +903,7 @@ extern "C" int tr_softassign_merge_fast(float* logits, int ldl, float scale, int
     TR_CHECK_LAUNCH("tr_softassign_merge_fast");
     return tr_weighted_merge(logits, ldl, x, src, x_out, B, N, K, D, s);
   }
-  hipLaunchKernelGGL(softmerge_mfma_kernel, dim3((D + 63) / 64, B), dim3(256), 0, st, logits, ldl, x, src, x_out, N, K, D);
+  hipLaunchKernelGGL(softmerge_mfma_kernel, dim3(((D + 63) / 64) * B), dim3(256), 0, st, logits, ldl, x, src, x_out, N, K, D);
   TR_CHECK_LAUNCH("tr_softassign_merge_fast");
   return TR_OK;
 }

@@ -120,6 +120,8 @@ extern "C" int tr_profile_end(int max, char* labels, float* ms, double* flops, d
 }
 extern "C" int tr_version(void) { return 100; }
 
+int tr_mlp_fused_wanted(int M, int D, int Hd);      // tr_mlp_fused.hip: the schedule policy behind tr_set_mlp_fused
+
 namespace {
 
 using trplan::align_up;
@@ -715,10 +717,15 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
     N = Nn;
     const int M2 = B * N;
     // mlp(norm2(x)) -> dbuf, added to x by the next block's norm1 (or the final norm)
+    bool fused_mlp = false;
     if (train) {
       void* pre = tape + tp->blk[i].pre;
       TR_TRY(tr_gemm_gelu_keep_bf16(static_cast<const uint16_t*>(xn), static_cast<const uint16_t*>(bw->fc1_w), bw->fc1_b, static_cast<uint16_t*>(pre),
                                     static_cast<uint16_t*>(hbuf), M2, p.Hd, D, s));
+    } else if (prec == TR_PREC_BF16 && bw->mlp_pk != nullptr && tr_mlp_fused_wanted(M2, D, p.Hd)) {
+      // eval: fc1 -> GELU -> fc2 in one launch, the hidden activation never leaves the CU (tr_mlp_fused.hip; bit-identical to the pair below,
+      // taken where its block schedule fills the chip)
+      fused_mlp = true;
     } else {
       TR_TRY(op_gemm(prec, xn, bw->fc1_w, bw->fc1_b, hbuf, nullptr, 0, M2, p.Hd, D, TR_EPI_GELU_BF16, s));
     }
@@ -727,7 +734,10 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       drop_keep += (size_t)M2 * p.Hd;
     }
     dbuf = (pending_attn == dbuf_shared) ? dbuf2 : dbuf_shared;      // the attention residual is still pending: fc2 writes beside it
-    TR_TRY(op_gemm(prec, hbuf, bw->fc2_w, bw->fc2_b, dbuf, nullptr, 0, M2, D, p.Hd, TR_EPI_BF16, s));
+    if (fused_mlp)
+      TR_TRY(tr_mlp_fused_bf16(static_cast<const uint16_t*>(xn), bw->mlp_pk, bw->fc1_b, bw->fc2_b, static_cast<uint16_t*>(dbuf), M2, D, p.Hd, s));
+    else
+      TR_TRY(op_gemm(prec, hbuf, bw->fc2_w, bw->fc2_b, dbuf, nullptr, 0, M2, D, p.Hd, TR_EPI_BF16, s));
     if (drop_keep != nullptr) {      // ... and after fc2
       TR_TRY(tr_dropout_bf16(static_cast<const uint16_t*>(dbuf), static_cast<uint16_t*>(dbuf), drop_keep, drop_mul, (size_t)M2 * D, s));
       drop_keep += (size_t)M2 * D;

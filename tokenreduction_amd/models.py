@@ -148,7 +148,7 @@ class VisionTransformer(nn.Module):
     # THIS object's executor, rebuilt on demand.  A copy (copy.deepcopy: ModelEma, torch's swa_utils) starts without them: captured
     # torch.cuda.CUDAGraph objects cannot be deep-copied at all, and a copied workspace would not belong to the copy's own packed weights.
     _EXECUTOR_CACHES = {"_packed": None, "_ws": None, "_last_ws": None, "_tstate": None, "_grad_reducer": None, "_noise_buf": None,
-                        "_gumbel_buf": None, "_kmed_draws": None, "_pack_slots": None, "_pack_table": None}
+                        "_gumbel_buf": None, "_kmed_draws": None, "_pack_slots": None, "_pack_table": None, "_mlp_pack_items": None}
 
     def __deepcopy__(self, memo):
         new = self.__class__.__new__(self.__class__)
@@ -287,6 +287,10 @@ class VisionTransformer(nn.Module):
         tslots = {}
         W = _lib.TrVitWeights()
         D = self.embed_dim
+        Hd = self.blocks[0].mlp.fc1.out_features
+        lib = _lib.load()
+        mlp_pk_bytes = int(lib.tr_mlp_pack_bytes(D, Hd)) if lib.tr_mlp_fused_supported(D, Hd) else 0
+        mlp_items = []
         W.patch_w = w16(self.patch_embed.proj.weight.reshape(D, -1))
         W.patch_b = f32(self.patch_embed.proj.bias)
         W.cls_token = f32(self.cls_token.reshape(-1))
@@ -309,6 +313,13 @@ class VisionTransformer(nn.Module):
             b.fc2_w, b.fc2_b = w16(blk.mlp.fc2.weight, True), f32(blk.mlp.fc2.bias)
             t2 = tslots.get(state["i"] - 1)
             tblocks.append((tq, tp_, t1, t2))
+            if wdt == torch.bfloat16 and mlp_pk_bytes:
+                # the fragment-major copy of the two Mlp matrices the fused eval Mlp kernel streams (csrc/tr_mlp_fused.hip), refreshed below /
+                # by _refresh_mlp_pack() whenever the bf16 copies were rewritten
+                state["i"] += 1
+                pkb = slot("p", (mlp_pk_bytes,), torch.uint8)
+                b.mlp_pk = pkb.data_ptr()
+                mlp_items.append((b.fc1_w, b.fc2_w, pkb))
         self._pack_stages(W, w16, f32, keep_alive)
         # may an optimizer that rewrites the fused table's copies itself declare the operands fresh?  Only if that table is all there is:
         # no copied operand, and no reduction module whose transposed matrices training.TrainState keys on the pack generation
@@ -316,6 +327,8 @@ class VisionTransformer(nn.Module):
                                 and type(self)._transposed_stage_weights is VisionTransformer._transposed_stage_weights)
         if fused:
             self._run_fused_pack(fused, dev, state["moved"])
+        self._mlp_pack_items = (mlp_items, D, Hd)
+        self._refresh_mlp_pack(dev)
         cfg = _lib.TrVitConfig()
         cfg.family = self._family
         cfg.img_size, cfg.patch = self.patch_embed.img_size[0], self.patch_embed.patch_size[0]
@@ -342,6 +355,21 @@ class VisionTransformer(nn.Module):
         if state["moved"] or old is None or bytes(old["cfg"]) != bytes(cfg) or bytes(old["W"]) != bytes(W):
             self._ws = {}
         return self._packed
+
+    def _refresh_mlp_pack(self, dev=None):
+        """Rewrite the fragment-major Mlp copies from the (current) bf16 operand copies: one small launch per block, in place -- after every
+        _pack() refresh and, on the first eval forward after an optim.FusedAdamW step (which rewrites the bf16 copies itself and marks these
+        stale), from forward()."""
+        items, D, Hd = self.__dict__.get("_mlp_pack_items") or ([], 0, 0)
+        self._mlp_pk_stale = False
+        if not items:
+            return
+        lib = _lib.load()
+        dev = dev or items[0][2].device
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream().cuda_stream
+            for w1, w2, pkb in items:
+                _lib.check(lib.tr_mlp_pack_bf16(w1, w2, pkb.data_ptr(), D, Hd, st), "tr_mlp_pack_bf16")
 
     def _run_fused_pack(self, fused, dev, moved):
         """All large matrices through ONE tr_cast_pack_bf16 launch; the item table lives on the device and is rebuilt only when an
@@ -426,6 +454,8 @@ class VisionTransformer(nn.Module):
             raise RuntimeError(f"input is on {x.device}: tokenreduction_amd has no CPU path (HIP kernels only)")
         lib = _lib.load()
         pk = self._pack()
+        if getattr(self, "_mlp_pk_stale", False):
+            self._refresh_mlp_pack(x.device)
         cfg = pk["cfg"]
         B, Cc, Hh, Ww = x.shape
         if (Cc, Hh, Ww) != (cfg.in_chans, cfg.img_size, cfg.img_size):

@@ -89,6 +89,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, epilogue: int, ou
     return out
 
 
+def set_mlp_fused(mode: int) -> int:
+    """Which Mlp the eval executor runs: 1 the fused launch wherever supported, 0 never, -1 (default) where its block schedule fills the chip
+    (tr_set_mlp_fused; the two are bit-identical).  Returns the previous mode."""
+    return int(_lib.load().tr_set_mlp_fused(int(mode)))
+
+
 def mlp_pack(fc1_w: torch.Tensor, fc2_w: torch.Tensor) -> torch.Tensor:
     """Fragment-major copy of a block's Mlp weights (bf16 [Hd,D], [D,Hd]) for mlp_fused; repack whenever the matrices change."""
     Hd, D = fc1_w.shape

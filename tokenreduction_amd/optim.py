@@ -143,6 +143,7 @@ class FusedAdamW(torch.optim.Optimizer):
             if tab["refreshes"] and getattr(m, "_dirty_by_backward", False):
                 m._weights_dirty = False
                 m._dirty_by_backward = False
+                m._mlp_pk_stale = True             # the fused eval Mlp's fragment-major copies derive from the bf16 copies just rewritten
             else:
                 m.weights_changed()
         return loss
