@@ -79,17 +79,21 @@ int tr_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* bias, void* 
 /* a4, eval forward: the whole timm Mlp of a block (models/topk.py:78 construction, :95 `x = x + self.mlp(self.norm2(x))`; the residual
  * add stays in the next LayerNorm) in ONE launch: out bf16 [M,D] = fc2(gelu_erf(fc1(xn))) with the [M,Hd] hidden activation never
  * leaving the CU (csrc/tr_mlp_fused.hip).  Bit-identical to tr_gemm_bf16(TR_EPI_GELU_BF16) followed by tr_gemm_bf16(TR_EPI_BF16).
- * `packed`: the two weight matrices in fragment-major order, tr_mlp_pack_bytes(D,Hd) bytes, written by tr_mlp_pack_bf16 from the
- * bf16 [Hd,D] / [D,Hd] matrices (repack whenever they change).  tr_mlp_fused_supported: D == 384, Hd %% 32 == 0 (other widths: the pair). */
+ * `packed`: the two weight matrices in fragment-major order and fc2's bias as an accumulator image, tr_mlp_pack_bytes(D,Hd) bytes,
+ * written by tr_mlp_pack_bf16 from the bf16 [Hd,D] / [D,Hd] matrices and the fp32 [D] bias (repack whenever they change).  tr_mlp_fused_supported: D == 384, Hd %% 32 == 0 (other widths: the pair). */
 int tr_mlp_fused_supported(int D, int Hd);
 /* Which Mlp the eval executor runs where tr_block_weights.mlp_pk is given: 1 = the fused launch wherever the shape is supported, 0 = never,
- * -1 (default) = where its 128-row blocks fill at least three quarters of the last round of 256 workgroups (the two schedules are bit-identical,
- * so this is a speed choice only).  Process-wide; returns the previous mode. */
+ * -1 (default) = for more than 256 blocks of 128 rows (stream-K schedule) and where a single round of blocks fills at least three quarters
+ * of the 256 workgroups (the two Mlp forms are bit-identical, so this is a speed choice only).  Process-wide; returns the previous mode. */
 int tr_set_mlp_fused(int mode);
 size_t tr_mlp_pack_bytes(int D, int Hd);
-int tr_mlp_pack_bf16(const uint16_t* fc1_w, const uint16_t* fc2_w, void* packed, int D, int Hd, tr_stream_t s);
-int tr_mlp_fused_bf16(const uint16_t* xn, const void* packed, const float* fc1_b, const float* fc2_b, uint16_t* out, int M, int D, int Hd,
-                      tr_stream_t s);
+int tr_mlp_pack_bf16(const uint16_t* fc1_w, const uint16_t* fc2_w, const float* fc2_b, void* packed, int D, int Hd, tr_stream_t s);
+/* scratch (nullable; tr_mlp_fused_scratch_bytes(D,Hd) bytes, 16-byte aligned): with it a launch of more than 256 blocks of 128 rows deals
+ * its steps evenly over the workgroups (stream-K: a block that straddles two workgroups hands its fp32 accumulator over, exactly); without
+ * it whole blocks round-robin.  Same bits either way. */
+size_t tr_mlp_fused_scratch_bytes(int D, int Hd);
+int tr_mlp_fused_bf16(const uint16_t* xn, const void* packed, const float* fc1_b, uint16_t* out, void* scratch, size_t scratch_bytes, int M, int D,
+                      int Hd, tr_stream_t s);
 
 /* a4 nn.LayerNorm(D, eps) rows of the fp32 residual stream -> bf16 (topk.py:86 norm1, :95 norm2, :201 norm), with the
  * PENDING residual add folded in: if delta != NULL (bf16 rows at stride ldd: the output of attn.proj / mlp.fc2),

@@ -105,14 +105,40 @@ def test_gemm_half_tile_tail_round(ops, M, N, K, why, epi):
     assert torch.equal(out, out2) and not torch.isnan(out2.float()).any()
 
 
+# ------------------------------------------------------------------------------------------ fused eval Mlp: stream-K corner cases
+@pytest.mark.parametrize("Hd", [64, 192, 1536])
+@pytest.mark.parametrize("nblk,ragged", [(257, 0), (258, 5), (263, 0), (300, 77), (384, 0), (511, 1), (513, 127), (1100, 0)])
+def test_mlp_fused_stream_k_ranges(ops, nblk, ragged, Hd):
+    """The stream-K schedule at its corners: ranges barely longer than a block (257 blocks on 256 workgroups: head segments and tails of ONE step,
+    a head followed directly by the workgroup's own tail), blocks of 2 and 6 steps (shorter than the two-step lag between the fc1 and the
+    fc2 waves), several whole blocks between head and tail, ragged last blocks -- each launched four times on a scratch whose slots still hold
+    the previous launch's accumulators, every output equal to the two-launch pair bit for bit."""
+    D = 384
+    M = (nblk - 1) * 128 + (ragged if ragged else 128)
+    if Hd == 1536 and nblk > 600:
+        pytest.skip("covered by the 70,001-row case")
+    rng = _rng(nblk * 7 + Hd)
+    x = _randn(rng, M, D).bfloat16().cuda()
+    w1, w2 = _randn(rng, Hd, D, scale=0.05).bfloat16().cuda(), _randn(rng, D, Hd, scale=0.05).bfloat16().cuda()
+    b1, b2 = _randn(rng, Hd, scale=0.1).cuda(), _randn(rng, D, scale=0.1).cuda()
+    want = ops.gemm(ops.gemm(x, w1, b1, ops.TR_EPI_GELU_BF16), w2, b2, ops.TR_EPI_BF16)
+    pk = ops.mlp_pack(w1, w2, b2)
+    for it in range(4):
+        guard = torch.full((M + 3, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+        got = ops.mlp_fused(x, pk, b1, out=guard[:M], streamk=True)
+        d = got.view(torch.int16) != want.view(torch.int16)
+        assert not bool(d.any()), f"launch {it}: {int(d.sum())} elements differ, blocks {(d.any(dim=1).nonzero().flatten() // 128).unique().tolist()[:8]}"
+        assert torch.isnan(guard[M:].float()).all(), "rows beyond M were written"
+
+
 # ------------------------------------------------------------------------------------------ fused eval Mlp (fc1 -> GELU -> fc2, one launch)
-@pytest.mark.parametrize("M", [1, 77, 128, 129, 1000, 197 * 8, 32768 + 5, 50432])
+@pytest.mark.parametrize("M", [1, 77, 128, 129, 1000, 197 * 8, 32768 + 5, 50432, 35328, 257 * 128, 70001])
 @pytest.mark.parametrize("Hd", [1536, 64, 192])
 def test_mlp_fused_is_bit_identical_to_the_gemm_pair(ops, M, Hd):
     """tr_mlp_fused_bf16 (timm Mlp of the eval forward, models/topk.py:95) keeps the hidden activation on the CU; by construction -- same
     MFMA, same operand maps, accumulators that start at the bias, K in the same 32-deep steps, same GELU fit, hidden rounded to bf16 at the
     same point -- its output equals tr_gemm_bf16(GELU_BF16) -> tr_gemm_bf16(BF16) BIT FOR BIT, for ragged last blocks, several blocks per
-    workgroup, and hidden widths of 2, 6 and 48 steps (the pair needs Hd %% 64 == 0).  Sampled rows are also held against the float64 Mlp on the bf16-rounded operands."""
+    workgroup, the stream-K schedule (257 blocks: every workgroup but the first and the last continues its neighbour's accumulator), and hidden widths of 2, 6 and 48 steps (the pair needs Hd %% 64 == 0).  Sampled rows are also held against the float64 Mlp on the bf16-rounded operands."""
     if M > 2000 and Hd != 1536:
         pytest.skip("large M only at the model's hidden width")
     D = 384
@@ -123,12 +149,13 @@ def test_mlp_fused_is_bit_identical_to_the_gemm_pair(ops, M, Hd):
     xd, w1d, w2d, b1d, b2d = x.cuda(), w1.cuda(), w2.cuda(), b1.cuda(), b2.cuda()
     h = ops.gemm(xd, w1d, b1d, ops.TR_EPI_GELU_BF16)
     want = ops.gemm(h, w2d, b2d, ops.TR_EPI_BF16)
-    pk = ops.mlp_pack(w1d, w2d)
-    guard = torch.full((M + 3, D), float("nan"), dtype=torch.bfloat16, device="cuda")        # rows M.. must stay untouched
-    got = ops.mlp_fused(xd, pk, b1d, b2d, out=guard[:M])
-    assert torch.equal(got.view(torch.int16), want.view(torch.int16)), \
-        f"{int((got.view(torch.int16) != want.view(torch.int16)).sum())} of {got.numel()} elements differ from the two-launch pair"
-    assert torch.isnan(guard[M:].float()).all(), "rows beyond M were written"
+    pk = ops.mlp_pack(w1d, w2d, b2d)
+    for streamk in (True, False):       # beyond 256 blocks: steps dealt evenly with the accumulator handed from workgroup to workgroup / whole blocks
+        guard = torch.full((M + 3, D), float("nan"), dtype=torch.bfloat16, device="cuda")        # rows M.. must stay untouched
+        got = ops.mlp_fused(xd, pk, b1d, out=guard[:M], streamk=streamk)
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16)), \
+            f"streamk={streamk}: {int((got.view(torch.int16) != want.view(torch.int16)).sum())} of {got.numel()} elements differ from the two-launch pair"
+        assert torch.isnan(guard[M:].float()).all(), "rows beyond M were written"
     rows = torch.cat([torch.arange(0, min(M, 140)), torch.arange(max(0, M - 140), M), torch.arange(0, M, 1009)]).unique()
     hid = oracle.gelu_erf(x[rows].double() @ w1.double().t() + b1.double())
     ref = _bf(hid.float()).double() @ w2.double().t() + b2.double()
@@ -145,7 +172,7 @@ def test_mlp_fused_repeated_launches_under_uneven_load(ops):
     w1, w2 = _randn(rng, Hd, D, scale=0.05).bfloat16().cuda(), _randn(rng, D, Hd, scale=0.05).bfloat16().cuda()
     b1, b2 = _randn(rng, Hd, scale=0.1).cuda(), _randn(rng, D, scale=0.1).cuda()
     want = ops.gemm(ops.gemm(x, w1, b1, ops.TR_EPI_GELU_BF16), w2, b2, ops.TR_EPI_BF16)
-    pk = ops.mlp_pack(w1, w2)
+    pk = ops.mlp_pack(w1, w2, b2)
     side, junk = torch.cuda.Stream(), torch.empty(32 << 20, dtype=torch.uint8, device="cuda")
     out = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
     bad = 0
@@ -154,7 +181,7 @@ def test_mlp_fused_repeated_launches_under_uneven_load(ops):
         if it % 3 == 0:
             with torch.cuda.stream(side):
                 junk.add_(1)
-        ops.mlp_fused(x, pk, b1, b2, out=out)
+        ops.mlp_fused(x, pk, b1, out=out)
         torch.cuda.synchronize()
         bad += 0 if torch.equal(out.view(torch.int16), want.view(torch.int16)) else 1
     assert bad == 0, f"{bad} of 60 launches differ from the two-launch pair"
@@ -163,7 +190,7 @@ def test_mlp_fused_repeated_launches_under_uneven_load(ops):
 def test_mlp_fused_rejects_other_widths(ops):
     w1, w2 = torch.zeros(3072, 768, dtype=torch.bfloat16, device="cuda"), torch.zeros(768, 3072, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(ValueError, match="does not serve"):
-        ops.mlp_pack(w1, w2)
+        ops.mlp_pack(w1, w2, torch.zeros(768, device="cuda"))
 
 
 def test_gemm_operand_roles_not_transposed(ops):

@@ -147,12 +147,20 @@ __device__ __forceinline__ f32x4 mf_load_f4(const float* sbase, unsigned voff) {
 // Fragment-major packing of one block's Mlp weights.  pk[step s][fragment f][lane][8 bf16]:
 //   f <  24: W1 fragment (tile t2 = f / 12, k-step ks = f % 12): lane (r = l & 15, q = l >> 4) holds W1[32 s + 8 (r >> 2) + 4 t2 + (r & 3)][32 ks + 8 q ..]
 //   f >= 24: W2 fragment of column group i = f - 24:             lane (r, q) holds W2[16 i + r][32 s + 8 q ..]
-__global__ __launch_bounds__(256) void mlp_pack_kernel(const uint16_t* __restrict__ W1, const uint16_t* __restrict__ W2, u32x4* __restrict__ pk, int D, int Hd) {
+// Behind the Hd / 32 steps: fc2's bias as the C wave's accumulator image -- fragment (i, j) [j = 0, 1: the two row groups hold the same values],
+// lane (r, q): b2[16 i + 4 q .. + 3] as fp32 -- so that "the accumulators restart at the bias" is the same 48 loads as "the accumulators
+// continue another workgroup's" (stream-K hand-over), from another base address.
+__global__ __launch_bounds__(256) void mlp_pack_kernel(const uint16_t* __restrict__ W1, const uint16_t* __restrict__ W2, const float* __restrict__ b2,
+                                                       u32x4* __restrict__ pk, int D, int Hd) {
   const int ks_n = D / 32, ni = D / 16, fr = 2 * ks_n + ni;
   const int g = blockIdx.x * 4 + (threadIdx.x >> 6);          // (step, fragment)
   const int lane = threadIdx.x & 63;
   const int s = g / fr, f = g % fr;
-  if (s >= Hd / 32) return;
+  if (s >= Hd / 32) {
+    const int e = g - (Hd / 32) * fr;                          // bias image entry (i, j)
+    if (e < 2 * ni) pk[(size_t)g * 64 + lane] = *reinterpret_cast<const u32x4*>(b2 + 16 * (e >> 1) + 4 * (lane >> 4));
+    return;
+  }
   const int r = lane & 15, q = lane >> 4;
   const uint16_t* src;
   if (f < 2 * ks_n) {
@@ -165,9 +173,43 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const uint16_t* __restric
   pk[(size_t)g * 64 + lane] = *reinterpret_cast<const u32x4*>(src);
 }
 
+// The steps of ONE workgroup in execution order.  Whole-block schedule (scratch == nullptr, or at most one block per workgroup): blocks bid,
+// bid + G, ..  Stream-K schedule (more blocks than workgroups): the launch's nblk * NS steps are cut into G equal contiguous ranges; a range
+// begins inside a block (its TAIL: steps s0..NS-1) and ends inside another (its HEAD: steps 0..s1-1).  A block is a chain -- fc2's K order is
+// kept, so the result stays bit-identical -- hence the workgroup that owns the tail CONTINUES the accumulator of the workgroup that owns the
+// head: the head runs FIRST (its fp32 accumulator is published: write-through stores + a counter), the tail LAST, and since a range is longer
+// than a block the published accumulator has been waiting for at least (range - NS) steps when it is fetched.
+struct MfSeq {
+  int head_len, head_blk;      // steps 0 .. head_len-1 of block head_blk first (0: none)
+  int full0, fstride, nfull;   // then the whole blocks full0 + k * fstride, k < nfull
+  int tail_s0, tail_blk;       // then steps tail_s0 .. NS-1 of block tail_blk (tail_s0 == NS: none)
+};
+struct MfCur {                 // a position in that sequence: segment -1 = head, 0..nfull-1 = whole blocks, nfull = tail
+  int seg, s;
+};
+__device__ __forceinline__ MfCur mf_first(const MfSeq& q, int NS) {
+  if (q.head_len > 0) return MfCur{-1, 0};
+  if (q.nfull > 0) return MfCur{0, 0};
+  return MfCur{q.nfull, q.tail_s0};
+}
+__device__ __forceinline__ bool mf_last_of_segment(const MfSeq& q, const MfCur& c, int NS) { return c.seg == -1 ? c.s == q.head_len - 1 : c.s == NS - 1; }
+__device__ __forceinline__ int mf_block(const MfSeq& q, const MfCur& c) {
+  return c.seg == -1 ? q.head_blk : (c.seg < q.nfull ? q.full0 + c.seg * q.fstride : q.tail_blk);
+}
+__device__ __forceinline__ MfCur mf_next(const MfSeq& q, const MfCur& c, int NS) {        // past the end: keeps returning valid (unused) steps
+  if (!mf_last_of_segment(q, c, NS)) return MfCur{c.seg, c.s + 1};
+  const int seg = c.seg + 1;
+  if (seg < q.nfull) return MfCur{seg, 0};
+  return MfCur{q.nfull, q.tail_s0 < NS ? q.tail_s0 : 0};
+}
+
+constexpr int MF_SK_SLOT = 4 * MF_NI * 2 * 1024;     // one workgroup's published accumulator: 4 C waves x 48 fragments x 1 KiB = 192 KiB
+constexpr int MF_SK_CNT = 128;                       // bytes per counter (its own line)
+
 __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __restrict__ xn, const unsigned char* __restrict__ pk,
-                                                           const float* __restrict__ b1, const float* __restrict__ b2,
-                                                           uint16_t* __restrict__ outp, int M, int NS, unsigned out_bytes) {
+                                                           const float* __restrict__ b1,
+                                                           uint16_t* __restrict__ outp, unsigned char* __restrict__ scratch, int M, int NS,
+                                                           unsigned out_bytes) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[MF_LDS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -175,8 +217,26 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
   const int G = gridDim.x, bid = blockIdx.x;
   const int nblk = (M + MF_ROWS - 1) / MF_ROWS;
   if (bid >= nblk) return;
-  const int my_blocks = (nblk - bid + G - 1) / G;
-  const int T = my_blocks * NS;       // P: MFMAs of (block, step) number t at time t = 0..T-1, its GELU at time t+1; C consumes it at time t+2
+  MfSeq q;
+  int T;                              // P: MFMAs of step number t at time t = 0..T-1, its GELU at time t+1; C consumes it at time t+2
+  const bool streamk = scratch != nullptr && nblk > G;
+  if (!streamk) {
+    q = MfSeq{0, 0, bid, G, (nblk - bid + G - 1) / G, NS, 0};
+    T = q.nfull * NS;
+  } else {
+    const long long U = (long long)nblk * NS;
+    const int u0 = (int)(U * bid / G), u1 = (int)(U * (bid + 1) / G);
+    const int b_first = u0 / NS, s0 = u0 - b_first * NS;          // s0 > 0: this range starts inside block b_first
+    const int b_end = u1 / NS, s1 = u1 - b_end * NS;              // s1 > 0: it ends inside block b_end
+    const int f0 = s0 > 0 ? b_first + 1 : b_first;
+    q = MfSeq{s1, b_end, f0, 1, b_end - f0, s0 > 0 ? s0 : NS, b_first};
+    T = u1 - u0;
+  }
+  q.head_len = __builtin_amdgcn_readfirstlane(q.head_len); q.head_blk = __builtin_amdgcn_readfirstlane(q.head_blk);
+  q.full0 = __builtin_amdgcn_readfirstlane(q.full0); q.fstride = __builtin_amdgcn_readfirstlane(q.fstride);
+  q.nfull = __builtin_amdgcn_readfirstlane(q.nfull); q.tail_s0 = __builtin_amdgcn_readfirstlane(q.tail_s0);
+  q.tail_blk = __builtin_amdgcn_readfirstlane(q.tail_blk);
+  T = __builtin_amdgcn_readfirstlane(T);
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
   const unsigned lane16 = (unsigned)lane * 16u;
   const int frow = lane & 15, fq = lane >> 4;
@@ -187,7 +247,8 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
   // wave waits for its own pieces with a counted vmcnt, this step's stay in flight).
   // The barrier sits BEFORE a step's last window of MFMAs: its fragments are in registers by then, so the matrix pipe has work the moment the
   // barrier opens, under which the first fragments of the next step arrive from LDS.
-  int ld_e = 0, ld_w1 = 0, ld_w2 = (2 * NS - 2) % NS, ld_slot = 0;
+  MfCur ld_cur = mf_first(q, NS);
+  int ld_e = 0, ld_w1 = ld_cur.s, ld_w2 = ld_cur.s, ld_w2n = ld_cur.s, ld_slot = 0;      // W1 step of entry e, W2 step of entries e and e+1 (= W1 steps of e-2, e-1)
   // the 48 pieces of an entry: a P wave issues MF_PQ of them (pieces pr + 4 q), a C wave the other 12 - MF_PQ (pieces 4 MF_PQ + pr + 4 q)
   auto issue_piece_q = [&](int q) __attribute__((always_inline)) {
     const int f = (wave < 4 ? 0 : 4 * MF_PQ) + pr + 4 * q;
@@ -205,8 +266,10 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
   };
   auto advance_entry = [&]() __attribute__((always_inline)) {
     ++ld_e;
-    ld_w1 = (ld_w1 + 1 == NS) ? 0 : ld_w1 + 1;
-    ld_w2 = (ld_w2 + 1 == NS) ? 0 : ld_w2 + 1;
+    ld_w2 = ld_w2n;
+    ld_w2n = ld_w1;
+    ld_cur = mf_next(q, ld_cur, NS);
+    ld_w1 = ld_cur.s;
     ld_slot = (ld_slot + 1 == MF_NSLOT) ? 0 : ld_slot + 1;
   };
 
@@ -231,12 +294,12 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
   mf_reload_x<(ks) * 64>(x1[ks], xn, xo1)
     {
       unsigned xo0, xo1;
-      x_offsets(bid, xo0, xo1);
+      x_offsets(mf_block(q, mf_first(q, NS)), xo0, xo1);
       MF_LOAD_X(0); MF_LOAD_X(1); MF_LOAD_X(2); MF_LOAD_X(3); MF_LOAD_X(4); MF_LOAD_X(5);
       MF_LOAD_X(6); MF_LOAD_X(7); MF_LOAD_X(8); MF_LOAD_X(9); MF_LOAD_X(10); MF_LOAD_X(11);
     }
-    bn0 = mf_load_f4<0>(b1, boff);
-    bn1 = mf_load_f4<16>(b1, boff);
+    bn0 = mf_load_f4<0>(b1 + 32 * mf_first(q, NS).s, boff);
+    bn1 = mf_load_f4<16>(b1 + 32 * mf_first(q, NS).s, boff);
     issue_all();
     advance_entry();
     issue_all();
@@ -260,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
     // One time step t: windows 0..4 of its MFMAs with the GELU of step t-1 under them (at t = 0: of zeros, into a buffer nobody reads) -- the
     // hidden fragments go to the partner through LDS --, the barrier, then window 5 and the first fragment reads of step t+1.
     // last: the block's last step -- the x registers are dead after their last MFMA and are refilled IN PLACE with the next block's rows.
-    auto p_step = [&](int s, const bool last, int next_blk) __attribute__((always_inline)) {
+    auto p_step = [&](int sn, const bool last, int next_blk) __attribute__((always_inline)) {
       const unsigned char* slot = smem + cslot * MF_ENTRY + lane16;
       const int nslot = (cslot + 1 == MF_NSLOT) ? 0 : cslot + 1;
       const unsigned char* slot_next = smem + nslot * MF_ENTRY + lane16;
@@ -307,7 +370,6 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
     __builtin_amdgcn_sched_barrier(0);                                                          \
     if ((k) == 0) {                                                                             \
       /* the next step's bias: older than this step's DMA pieces, so the counted wait at the end of the step retires it */ \
-      const int sn = (s + 1 == NS) ? 0 : s + 1;                                                 \
       bn0 = mf_load_f4<0>(b1 + 32 * sn, boff);                                                  \
       bn1 = mf_load_f4<16>(b1 + 32 * sn, boff);                                                 \
     }                                                                                           \
@@ -347,16 +409,17 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
       ++t;
       cslot = nslot;
     };
-    // ONE flat loop over the time steps with (block, step) carried along -- and the block's-last-step test opaque: with a nested
-    // `for (s = 0; s < NS; ++s)` hipcc peels the last iteration off (the bias pointer wraps there), i.e. compiles the step body twice with two
-    // allocations of the 96 x registers and spills between them.
+    // ONE flat loop over the time steps with the position in the sequence carried along -- and the segment's-last-step test opaque: with a
+    // nested `for (s = 0; s < NS; ++s)` hipcc peels the last iteration off (the bias pointer wraps there), i.e. compiles the step body twice
+    // with two allocations of the 96 x registers and spills between them.
     {
-      int s = 0, blk_next = bid + G;
+      MfCur cur = mf_first(q, NS);
       for (int tt = 0; tt < T; ++tt) {
-        int last = __builtin_amdgcn_readfirstlane((s + 1 == NS) ? 1 : 0);
+        const MfCur nxt = mf_next(q, cur, NS);
+        int last = __builtin_amdgcn_readfirstlane(mf_last_of_segment(q, cur, NS) ? 1 : 0);
         asm volatile("" : "+s"(last));
-        p_step(s, last != 0, blk_next < nblk ? blk_next : -1);
-        if (last) { s = 0; blk_next += G; } else { ++s; }
+        p_step(nxt.s, last != 0, (last && tt + 1 < T) ? mf_block(q, nxt) : -1);        // (the next step's index: its bias is fetched a step ahead)
+        cur = nxt;
       }
     }
     {
@@ -386,24 +449,17 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
   __builtin_amdgcn_s_setprio(MF_PRIO_C);
 #endif
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(outp, 0, (int)out_bytes, 0x00020000);
-  // fc2's bias lives in six registers (b2[lane + 64 q]); a column group's fragment value b2[16 i + 4 fq + e] is fetched with ds_bpermute
-  // (the LDS crossbar, no LDS memory: the 160 KiB are all taken): register i >> 2, lane 16 (i & 3) + 4 fq + e
-  float b2r[MF_D / 64];
-#pragma unroll
-  for (int q = 0; q < MF_D / 64; ++q) b2r[q] = b2[lane + 64 * q];
-  auto bias_frag = [&](int i, unsigned bp) __attribute__((always_inline)) {
-    f32x4 v;
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      v[e] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((int)(bp + 4u * (16 * (i & 3) + e)), __builtin_bit_cast(int, b2r[i >> 2])));
-    return v;
-  };
+  // The accumulators start -- and restart after every block -- at fc2's bias: 48 fragment loads from the bias image behind the packed weights
+  // (tr_mlp_pack_bf16).  The tail segment of a stream-K range loads the previous workgroup's accumulator instead: the same loads, another base.
+  const unsigned char* const bias_img = pk + (size_t)NS * MF_ENTRY;
   f32x4 acc[MF_NI][2];
+  {
+    const __amdgpu_buffer_rsrc_t bsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(bias_img), 0, MF_NI * 2 * 1024, 0x00020000);
 #pragma unroll
-  for (int i = 0; i < MF_NI; ++i) {
-    const f32x4 v = bias_frag(i, 16u * fq);
-    acc[i][0] = v;
-    acc[i][1] = v;
+    for (int i = 0; i < MF_NI; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bsrc, lane16 + (unsigned)((i * 2 + j) * 1024), 0, 0));
   }
   issue_all();
   advance_entry();
@@ -439,9 +495,20 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
     h1 = *reinterpret_cast<const bf16x8*>(hsrc + 1024);
     MF_READW(wA, smem + cslot * MF_ENTRY + MF_W1FR * 1024 + lane16, 0);
   }
+  // stream-K hand-over (MfSeq): this workgroup's slot of `scratch` takes the accumulator of its head segment, the counter behind the slots
+  // says when (MI355X_MICROARCH.md, hand-offs with sc1 loads in place of the acquire, third row: every storing wave adds to the counter
+  // after its own vmcnt(0); the consumer polls with an sc1 load, passes a workgroup barrier, then reads with sc1 loads; whole 128-byte lines
+  // per store instruction, 16-byte accesses)
+  const __amdgpu_buffer_rsrc_t sk_out = __builtin_amdgcn_make_buffer_rsrc(scratch + (size_t)bid * MF_SK_SLOT, 0, MF_SK_SLOT, 0x00020000);
+  unsigned* const sk_cnt_out = reinterpret_cast<unsigned*>(scratch + (size_t)G * MF_SK_SLOT + (size_t)bid * MF_SK_CNT);
+  unsigned* const sk_cnt_in = reinterpret_cast<unsigned*>(scratch + (size_t)G * MF_SK_SLOT + (size_t)(bid > 0 ? bid - 1 : 0) * MF_SK_CNT);
   // One time step t >= 2: consumes the hidden fragments of number t-2 (in h0, h1 on entry) and the W2 half of entry t: windows 0..4, the barrier,
-  // then -- on registers -- window 5, under which the next step's hidden and weight fragments arrive.  epi: number t-2 was its block's last step.
-  auto c_step = [&](const bool epi, int blk) __attribute__((always_inline)) {
+  // then -- on registers -- window 5, under which the next step's hidden and weight fragments arrive.
+  // fin: number t-2 was its segment's last step -- 1: the block is complete (epilogue), 2: a head segment (publish the accumulator);
+  // load_next: the next segment is this workgroup's tail -- its accumulator comes from the previous workgroup.
+  bool publish_pending = false;
+  auto c_step = [&](const int fin, const bool load_next, int blk) __attribute__((always_inline)) {
+    const bool epi = fin == 1;
     const unsigned char* slot = smem + cslot * MF_ENTRY + MF_W1FR * 1024 + lane16;
     const int nslot = (cslot + 1 == MF_NSLOT) ? 0 : cslot + 1;
     const unsigned char* slot_next = smem + nslot * MF_ENTRY + MF_W1FR * 1024 + lane16;
@@ -495,6 +562,11 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
       // step is in registers (the ring slot and the hidden buffer may be rewritten behind the barrier)
       if (dma) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 - MF_PQ) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // nothing younger went out: the count would retire nothing
+      if (publish_pending) {
+        // the 48 write-through stores of the head segment's accumulator (issued before this step's pieces) are done: tell the next workgroup
+        if (lane == 0) __hip_atomic_fetch_add(sk_cnt_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        publish_pending = false;
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -512,17 +584,26 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
       h0 = *reinterpret_cast<const bf16x8*>(hsrc);
       h1 = *reinterpret_cast<const bf16x8*>(hsrc + 1024);
     }
-    if (epi) {
-      // 32 x 384 fp32 -> bf16 rows.  A 16-row x 64-column slab goes through 2 KiB of LDS -- the hidden buffer just read into h0/h1 (its next
-      // writer is the partner's step t+2, two barriers away) -- so that every store covers whole 128-byte lines; swizzle and the one-ahead
-      // pipelining are those of gemm_bf16_pc's epilogue.  The accumulators restart at the bias for the next block.
+    if (fin) {
+      // The segment is complete.  fin == 1: the block is, its 32 x 384 fp32 accumulator leaves as bf16 rows.  A 16-row x 64-column slab goes
+      // through 2 KiB of LDS -- the hidden buffer just read into h0/h1 (its next writer is the partner's step t+2, two barriers away) -- so
+      // that every store covers whole 128-byte lines; swizzle and the one-ahead pipelining are those of gemm_bf16_pc's epilogue.
+      // fin == 2 (a stream-K head segment): the fp32 accumulator goes to this workgroup's slot of the scratch (fragment (i, j) of wave w:
+      // 1 KiB at ((w * 24 + i) * 2 + j) KiB, a lane's 16 bytes at 16 * lane: whole lines per instruction), write-through, then the counter.
+      // Either way the accumulator registers then take their next values chunk by chunk, behind the last read of each: the bias image, or
+      // (load_next) the previous workgroup's published accumulator -- ONE definition site for the 192 registers (three conditional ones made
+      // hipcc keep two copies: 174 spills).
       unsigned char* stg = hb + ((t + 1) & 1) * MF_HBUF;
       const int rrow = lane >> 3, rch = lane & 7;
       unsigned voff_out = ((unsigned)(blk * MF_ROWS + pr * 32 + rrow) * MF_D + 8u * rch) * 2u;
-      unsigned bp0 = 16u * fq;                   // byte address of lane 4 fq for ds_bpermute
-      // opaque: computed here, once per block, instead of being hoisted out of the step loop as sixteen address registers + twenty-four offsets;
+      unsigned voff_sk = (unsigned)(pr * MF_NI * 2) * 1024u + lane16;
+      unsigned voff_new = load_next ? voff_sk : lane16;
+      // opaque: computed here, once per block, instead of being hoisted out of the step loop as address registers;
       // and h0/h1 must have ARRIVED before the staging writes overwrite their source
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(voff_out), "+v"(bp0), "+v"(h0), "+v"(h1)::"memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(voff_out), "+v"(voff_sk), "+v"(voff_new), "+v"(h0), "+v"(h1)::"memory");
+      const __amdgpu_buffer_rsrc_t nsrc = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<unsigned char*>(load_next ? scratch + (size_t)(bid > 0 ? bid - 1 : 0) * MF_SK_SLOT : bias_img), 0,
+          load_next ? MF_SK_SLOT : MF_NI * 2 * 1024, 0x00020000);
       const unsigned char* rd = stg + rrow * 128 + ((rch ^ rrow) << 4);
       auto stage = [&](int c, int j) __attribute__((always_inline)) {
 #pragma unroll
@@ -551,20 +632,49 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
           __builtin_amdgcn_raw_buffer_store_b128(ln[r], orsrc, voff_out + (unsigned)(((16 * j + 8 * r) * MF_D + 64 * c) * 2), 0, 0);
       };
       u32x4 lnA[2], lnB[2];
-      stage(0, 0); read_back(lnA);
+      if (!epi) {
+#pragma unroll
+        for (int i = 0; i < MF_NI; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), sk_out, voff_sk + (unsigned)((i * 2 + j) * 1024), 0,
+                                                   16 /* sc1: write-through */);
+        // The counter is raised once the stores are known to be done.  Normally that is deferred to the next step's DMA wait; when this
+        // workgroup's own tail comes next it is done HERE, before the poll below: a workgroup that waited for its predecessor before
+        // publishing would chain the launch's workgroups one behind the other (ranges barely longer than a block: head, then tail, nothing
+        // between), and a tail of one step would leave no later step to raise the counter in.
+        if (load_next) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) __hip_atomic_fetch_add(sk_cnt_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          publish_pending = true;
+        }
+      }
+      if (load_next) {
+        // the previous workgroup's four C waves have published their parts (it ran that segment first: normally long ago); every wave that
+        // reads polls for itself; bounded spin
+        for (int spin = 0; spin < (1 << 22); ++spin) {
+          if (__hip_atomic_load(sk_cnt_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 4u) break;
+          __builtin_amdgcn_s_sleep(8);
+        }
+        asm volatile("" ::: "memory");
+      }
+      if (epi) { stage(0, 0); read_back(lnA); }
 #pragma unroll
       for (int c = 0; c < MF_NI / 4; ++c) {
-        // pass (c, 0) is staged and being read back into lnA on entry
-        stage(c, 1); store(c, 0, lnA); read_back(lnB);
-        if (c + 1 < MF_NI / 4) stage(c + 1, 0);
-        store(c, 1, lnB);
-        if (c + 1 < MF_NI / 4) read_back(lnA);
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-          const f32x4 v = bias_frag(4 * c + ii, bp0);
-          acc[4 * c + ii][0] = v;
-          acc[4 * c + ii][1] = v;
+        if (epi) {
+          // pass (c, 0) is staged and being read back into lnA on entry
+          stage(c, 1); store(c, 0, lnA); read_back(lnB);
+          if (c + 1 < MF_NI / 4) stage(c + 1, 0);
+          store(c, 1, lnB);
+          if (c + 1 < MF_NI / 4) read_back(lnA);
         }
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[4 * c + ii][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(nsrc, voff_new + (unsigned)(((4 * c + ii) * 2 + j) * 1024), 0,
+                                                                                                 16 /* sc1: past this CU's L1 (the hand-over read) */));
       }
     }
     MF_STAMP(3);
@@ -573,16 +683,19 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
     cslot = nslot;
   };
   {
-    int s = 0, blk = bid;                       // flat loop, opaque last-step test: see the P loop
+    MfCur cur = mf_first(q, NS);                // flat loop, opaque flags: see the P loop
     for (int tt = 0; tt < T; ++tt) {
-      int last = __builtin_amdgcn_readfirstlane((s + 1 == NS) ? 1 : 0);
-      asm volatile("" : "+s"(last));
-      c_step(last != 0, blk);
-      if (last) { s = 0; blk += G; } else { ++s; }
+      const MfCur nxt = mf_next(q, cur, NS);
+      const bool last = mf_last_of_segment(q, cur, NS);
+      int flags = __builtin_amdgcn_readfirstlane((last ? (cur.seg == -1 ? 2 : 1) : 0) | ((last && tt + 1 < T && nxt.seg == q.nfull) ? 4 : 0));
+      asm volatile("" : "+s"(flags));
+      c_step(flags & 3, (flags & 4) != 0, mf_block(q, cur));
+      cur = nxt;
     }
   }
 #undef MF_READW
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (publish_pending && lane == 0) __hip_atomic_fetch_add(sk_cnt_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (a head is never a range's last segment)
 }
 
 }  // namespace
@@ -590,45 +703,73 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
 extern "C" int tr_mlp_fused_supported(int D, int Hd) { return (D == MF_D && Hd % 32 == 0 && Hd >= 64) ? 1 : 0; }
 
 static std::atomic<int> g_mlp_fused_mode{-1};
-extern "C" int tr_set_mlp_fused(int mode) { return g_mlp_fused_mode.exchange(mode < 0 ? -1 : (mode > 0 ? 1 : 0)); }
-// the executor's question (tr_vit.hip): run the fused launch for M rows?  A block is a chain of Hd / 32 sequential steps, so the launch costs
-// ceil(blocks / 256) rounds whatever the last round holds: 394 blocks (M = 50,432) pay 2 rounds for 1.54, 276 blocks 2 for 1.08
-int tr_mlp_fused_wanted(int M, int D, int Hd) {
+static std::atomic<int> g_mlp_sk_min_blocks{257};     // lab (tr_set_mlp_fused(mode >= 2)): fewest blocks for which auto takes the stream-K launch
+extern "C" int tr_set_mlp_fused(int mode) {
+  if (mode >= 2) { g_mlp_sk_min_blocks.store(mode); mode = -1; }
+  return g_mlp_fused_mode.exchange(mode < 0 ? -1 : (mode > 0 ? 1 : 0));
+}
+// the executor's question (tr_vit.hip): run the fused launch for M rows?  A block is a chain of Hd / 32 sequential steps.  With the stream-K
+// scratch and more blocks than workgroups the steps are dealt evenly (no tail round): always; else the launch is ONE round however few blocks
+// it holds: where they fill at least three quarters of the chip.
+int tr_mlp_fused_wanted(int M, int D, int Hd, int have_scratch) {
   if (!tr_mlp_fused_supported(D, Hd)) return 0;
   const int mode = g_mlp_fused_mode.load(std::memory_order_relaxed);
   if (mode >= 0) return mode;
-  const int nblk = (M + MF_ROWS - 1) / MF_ROWS, rounds = (nblk + 255) / 256;
-  return 4 * nblk >= 3 * 256 * rounds;
+  const int nblk = (M + MF_ROWS - 1) / MF_ROWS;
+  if (nblk > 256) {
+    if (have_scratch) return nblk >= g_mlp_sk_min_blocks.load(std::memory_order_relaxed);
+    const int rounds = (nblk + 255) / 256;
+    return 4 * nblk >= 3 * 256 * rounds;
+  }
+  return 4 * nblk >= 3 * 256;
 }
 
 extern "C" size_t tr_mlp_pack_bytes(int D, int Hd) {
   if (D <= 0 || Hd <= 0 || D % 32 || Hd % 32) return 0;
-  return (size_t)(Hd / 32) * (size_t)(2 * (D / 32) + D / 16) * 1024;
+  return ((size_t)(Hd / 32) * (size_t)(2 * (D / 32) + D / 16) + (size_t)(2 * (D / 16))) * 1024;       // the steps' fragments + the bias image
 }
 
-extern "C" int tr_mlp_pack_bf16(const uint16_t* fc1_w, const uint16_t* fc2_w, void* packed, int D, int Hd, tr_stream_t s) {
-  TR_REQUIRE(fc1_w && fc2_w && packed, TR_ERR_NULL, "tr_mlp_pack_bf16: null pointer");
+extern "C" size_t tr_mlp_fused_scratch_bytes(int D, int Hd) {
+  return tr_mlp_fused_supported(D, Hd) ? (size_t)256 * (MF_SK_SLOT + MF_SK_CNT) : 0;
+}
+
+extern "C" int tr_mlp_pack_bf16(const uint16_t* fc1_w, const uint16_t* fc2_w, const float* fc2_b, void* packed, int D, int Hd, tr_stream_t s) {
+  TR_REQUIRE(fc1_w && fc2_w && fc2_b && packed, TR_ERR_NULL, "tr_mlp_pack_bf16: null pointer");
   TR_REQUIRE(D > 0 && Hd > 0 && D % 32 == 0 && Hd % 32 == 0, TR_ERR_SHAPE, "tr_mlp_pack_bf16: D=%d and Hd=%d must be multiples of 32", D, Hd);
-  TR_REQUIRE(tr_aligned16(fc1_w) && tr_aligned16(fc2_w) && tr_aligned16(packed), TR_ERR_ALIGN, "tr_mlp_pack_bf16: pointers must be 16-byte aligned");
-  const int frags = (Hd / 32) * (2 * (D / 32) + D / 16);
-  hipLaunchKernelGGL(mlp_pack_kernel, dim3((frags + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(s), fc1_w, fc2_w, static_cast<u32x4*>(packed), D, Hd);
+  TR_REQUIRE(tr_aligned16(fc1_w) && tr_aligned16(fc2_w) && tr_aligned16(fc2_b) && tr_aligned16(packed), TR_ERR_ALIGN,
+             "tr_mlp_pack_bf16: pointers must be 16-byte aligned");
+  const int frags = (Hd / 32) * (2 * (D / 32) + D / 16) + 2 * (D / 16);
+  hipLaunchKernelGGL(mlp_pack_kernel, dim3((frags + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(s), fc1_w, fc2_w, fc2_b, static_cast<u32x4*>(packed), D,
+                     Hd);
   TR_CHECK_LAUNCH("tr_mlp_pack_bf16");
   return TR_OK;
 }
 
-extern "C" int tr_mlp_fused_bf16(const uint16_t* xn, const void* packed, const float* fc1_b, const float* fc2_b, uint16_t* out, int M, int D, int Hd,
-                                 tr_stream_t s) {
-  TR_REQUIRE(xn && packed && fc1_b && fc2_b && out, TR_ERR_NULL, "tr_mlp_fused_bf16: null pointer");
+extern "C" int tr_mlp_fused_bf16(const uint16_t* xn, const void* packed, const float* fc1_b, uint16_t* out, void* scratch, size_t scratch_bytes, int M,
+                                 int D, int Hd, tr_stream_t s) {
+  TR_REQUIRE(xn && packed && fc1_b && out, TR_ERR_NULL, "tr_mlp_fused_bf16: null pointer");
   TR_REQUIRE(M > 0 && tr_mlp_fused_supported(D, Hd), TR_ERR_SHAPE, "tr_mlp_fused_bf16: unsupported shape M=%d D=%d Hd=%d (D must be %d, Hd %% 32 == 0)", M, D, Hd,
              MF_D);
-  TR_REQUIRE(tr_aligned16(xn) && tr_aligned16(packed) && tr_aligned16(fc1_b) && tr_aligned16(fc2_b) && tr_aligned16(out), TR_ERR_ALIGN,
-             "tr_mlp_fused_bf16: pointers must be 16-byte aligned");
+  TR_REQUIRE(tr_aligned16(xn) && tr_aligned16(packed) && tr_aligned16(fc1_b) && tr_aligned16(out) && tr_aligned16(scratch),
+             TR_ERR_ALIGN, "tr_mlp_fused_bf16: pointers must be 16-byte aligned");
+  TR_REQUIRE(scratch == nullptr || scratch_bytes >= tr_mlp_fused_scratch_bytes(D, Hd), TR_ERR_SHAPE,
+             "tr_mlp_fused_bf16: scratch of %zu bytes, tr_mlp_fused_scratch_bytes says %zu (or pass NULL: whole-block schedule)", scratch_bytes,
+             tr_mlp_fused_scratch_bytes(D, Hd));
   const size_t out_bytes = (size_t)M * D * 2;
   TR_REQUIRE(out_bytes < ((size_t)1 << 31), TR_ERR_SHAPE, "tr_mlp_fused_bf16: %zu output bytes exceed the 2 GiB range of the store offsets", out_bytes);
   tr_prof_note("mlp_fused_kernel", 4.0 * M * D * Hd, 4.0 * M * D + 4.0 * D * Hd);
   const int nblk = (M + MF_ROWS - 1) / MF_ROWS;
-  hipLaunchKernelGGL(mlp_fused_kernel, dim3(nblk < 256 ? nblk : 256), dim3(512), 0, static_cast<hipStream_t>(s), xn, static_cast<const unsigned char*>(packed),
-                     fc1_b, fc2_b, out, M, Hd / 32, (unsigned)out_bytes);
+  const int G = nblk < 256 ? nblk : 256;
+  hipStream_t st = static_cast<hipStream_t>(s);
+  unsigned char* sk = (nblk > G) ? static_cast<unsigned char*>(scratch) : nullptr;
+  if (sk != nullptr) {
+    // the hand-over counters of this launch (one line per workgroup, behind the accumulator slots) start at zero: a memset node ahead of the
+    // kernel node (graph-capturable; a counter that the last consumer reset would fail a first, poisoned launch)
+    hipError_t e = hipMemsetAsync(sk + (size_t)G * MF_SK_SLOT, 0, (size_t)G * MF_SK_CNT, st);
+    TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_mlp_fused_bf16: hipMemsetAsync: %s", hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(mlp_fused_kernel, dim3(G), dim3(512), 0, st, xn, static_cast<const unsigned char*>(packed), fc1_b, out, sk, M, Hd / 32,
+                     (unsigned)out_bytes);
   TR_CHECK_LAUNCH("tr_mlp_fused_bf16");
   return TR_OK;
 }

@@ -120,7 +120,7 @@ extern "C" int tr_profile_end(int max, char* labels, float* ms, double* flops, d
 }
 extern "C" int tr_version(void) { return 100; }
 
-int tr_mlp_fused_wanted(int M, int D, int Hd);      // tr_mlp_fused.hip: the schedule policy behind tr_set_mlp_fused
+int tr_mlp_fused_wanted(int M, int D, int Hd, int have_scratch);      // tr_mlp_fused.hip: the schedule policy behind tr_set_mlp_fused
 
 namespace {
 
@@ -128,7 +128,7 @@ using trplan::align_up;
 
 struct Plan {
   int P, N0, D, H, Hd, C, kcols;
-  size_t off_x0, off_x1, off_xn, off_qkv, off_ao, off_h, off_d, off_d2, off_cols, off_cls, off_scores, off_idx, off_compl, off_xcls, off_size0, off_size1, off_cluster, off_soft, total;
+  size_t off_x0, off_x1, off_xn, off_qkv, off_ao, off_h, off_d, off_d2, off_cols, off_cls, off_scores, off_idx, off_compl, off_xcls, off_size0, off_size1, off_cluster, off_soft, off_mlp_sk, mlp_sk_bytes, total;
 };
 
 bool make_plan(const tr_vit_config* c, int B, Plan* p) {
@@ -177,6 +177,10 @@ bool make_plan(const tr_vit_config* c, int B, Plan* p) {
     for (int i = 0; i < c->depth; ++i) kmax = c->keep[i] > kmax ? c->keep[i] : kmax;
     o += align_up(T * (size_t)trplan::soft_ld(kmax) * 4);
   }
+  // stream-K scratch of the fused eval Mlp (tr_mlp_fused.hip): 256 accumulator slots of 192 KiB + their counters, bf16 executor only
+  p->off_mlp_sk = o;
+  p->mlp_sk_bytes = c->precision == TR_PREC_BF16 ? tr_mlp_fused_scratch_bytes(p->D, p->Hd) : 0;
+  o += align_up(p->mlp_sk_bytes);
   p->total = o;
   return true;
 }
@@ -722,7 +726,7 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       void* pre = tape + tp->blk[i].pre;
       TR_TRY(tr_gemm_gelu_keep_bf16(static_cast<const uint16_t*>(xn), static_cast<const uint16_t*>(bw->fc1_w), bw->fc1_b, static_cast<uint16_t*>(pre),
                                     static_cast<uint16_t*>(hbuf), M2, p.Hd, D, s));
-    } else if (prec == TR_PREC_BF16 && bw->mlp_pk != nullptr && tr_mlp_fused_wanted(M2, D, p.Hd)) {
+    } else if (prec == TR_PREC_BF16 && bw->mlp_pk != nullptr && tr_mlp_fused_wanted(M2, D, p.Hd, p.mlp_sk_bytes > 0)) {
       // eval: fc1 -> GELU -> fc2 in one launch, the hidden activation never leaves the CU (tr_mlp_fused.hip; bit-identical to the pair below,
       // taken where its block schedule fills the chip)
       fused_mlp = true;
@@ -735,7 +739,8 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
     }
     dbuf = (pending_attn == dbuf_shared) ? dbuf2 : dbuf_shared;      // the attention residual is still pending: fc2 writes beside it
     if (fused_mlp)
-      TR_TRY(tr_mlp_fused_bf16(static_cast<const uint16_t*>(xn), bw->mlp_pk, bw->fc1_b, bw->fc2_b, static_cast<uint16_t*>(dbuf), M2, D, p.Hd, s));
+      TR_TRY(tr_mlp_fused_bf16(static_cast<const uint16_t*>(xn), bw->mlp_pk, bw->fc1_b, static_cast<uint16_t*>(dbuf),
+                               p.mlp_sk_bytes ? ws + p.off_mlp_sk : nullptr, p.mlp_sk_bytes, M2, D, p.Hd, s));
     else
       TR_TRY(op_gemm(prec, hbuf, bw->fc2_w, bw->fc2_b, dbuf, nullptr, 0, M2, D, p.Hd, TR_EPI_BF16, s));
     if (drop_keep != nullptr) {      // ... and after fc2

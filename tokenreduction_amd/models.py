@@ -319,7 +319,7 @@ class VisionTransformer(nn.Module):
                 state["i"] += 1
                 pkb = slot("p", (mlp_pk_bytes,), torch.uint8)
                 b.mlp_pk = pkb.data_ptr()
-                mlp_items.append((b.fc1_w, b.fc2_w, pkb))
+                mlp_items.append((b.fc1_w, b.fc2_w, b.fc2_b, pkb))
         self._pack_stages(W, w16, f32, keep_alive)
         # may an optimizer that rewrites the fused table's copies itself declare the operands fresh?  Only if that table is all there is:
         # no copied operand, and no reduction module whose transposed matrices training.TrainState keys on the pack generation
@@ -365,11 +365,11 @@ class VisionTransformer(nn.Module):
         if not items:
             return
         lib = _lib.load()
-        dev = dev or items[0][2].device
+        dev = dev or items[0][3].device
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream().cuda_stream
-            for w1, w2, pkb in items:
-                _lib.check(lib.tr_mlp_pack_bf16(w1, w2, pkb.data_ptr(), D, Hd, st), "tr_mlp_pack_bf16")
+            for w1, w2, b2, pkb in items:
+                _lib.check(lib.tr_mlp_pack_bf16(w1, w2, b2, pkb.data_ptr(), D, Hd, st), "tr_mlp_pack_bf16")
 
     def _run_fused_pack(self, fused, dev, moved):
         """All large matrices through ONE tr_cast_pack_bf16 launch; the item table lives on the device and is rebuilt only when an

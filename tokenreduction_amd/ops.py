@@ -95,32 +95,48 @@ def set_mlp_fused(mode: int) -> int:
     return int(_lib.load().tr_set_mlp_fused(int(mode)))
 
 
-def mlp_pack(fc1_w: torch.Tensor, fc2_w: torch.Tensor) -> torch.Tensor:
-    """Fragment-major copy of a block's Mlp weights (bf16 [Hd,D], [D,Hd]) for mlp_fused; repack whenever the matrices change."""
+def mlp_pack(fc1_w: torch.Tensor, fc2_w: torch.Tensor, fc2_b: torch.Tensor) -> torch.Tensor:
+    """Fragment-major copy of a block's Mlp weights (bf16 [Hd,D], [D,Hd]) and fc2's bias (fp32 [D]: the accumulators' start image) for
+    mlp_fused; repack whenever they change."""
     Hd, D = fc1_w.shape
     if tuple(fc2_w.shape) != (D, Hd):
         raise ValueError(f"mlp_pack: fc2 weight is {tuple(fc2_w.shape)}, expected {(D, Hd)}")
-    _same_device(fc1_w, fc2_w)
+    _same_device(fc1_w, fc2_w, fc2_b)
+    if fc2_b.numel() != D:
+        raise ValueError(f"mlp_pack: fc2 bias has {fc2_b.numel()} entries for {D} output columns")
     lib = _lib.load()
     n = lib.tr_mlp_pack_bytes(D, Hd)
     if n == 0 or not lib.tr_mlp_fused_supported(D, Hd):
         raise ValueError(f"mlp_pack: the fused Mlp kernel does not serve D={D}, Hd={Hd}")
     pk = torch.empty(n, dtype=torch.uint8, device=fc1_w.device)
-    _lib.check(lib.tr_mlp_pack_bf16(_dev(fc1_w, torch.bfloat16, "fc1_w"), _dev(fc2_w, torch.bfloat16, "fc2_w"), pk.data_ptr(), D, Hd,
-                                    _stream(fc1_w)), "tr_mlp_pack_bf16")
+    _lib.check(lib.tr_mlp_pack_bf16(_dev(fc1_w, torch.bfloat16, "fc1_w"), _dev(fc2_w, torch.bfloat16, "fc2_w"), _dev(fc2_b, torch.float32, "fc2_b"),
+                                    pk.data_ptr(), D, Hd, _stream(fc1_w)), "tr_mlp_pack_bf16")
     return pk
 
 
-def mlp_fused(xn: torch.Tensor, packed: torch.Tensor, fc1_b: torch.Tensor, fc2_b: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+_MLP_SCRATCH = {}
+
+
+def mlp_fused(xn: torch.Tensor, packed: torch.Tensor, fc1_b: torch.Tensor, out: torch.Tensor = None, streamk: bool = True) -> torch.Tensor:
     """timm Mlp (fc1 -> GELU -> fc2, topk.py:95) of the eval forward in one launch: xn bf16 [M,D] -> bf16 [M,D]; bit-identical to
-    gemm(GELU_BF16) followed by gemm(BF16)."""
+    gemm(GELU_BF16) followed by gemm(BF16).  streamk: give the launch its hand-over scratch (beyond 256 blocks of 128 rows the steps are then
+    dealt evenly over the workgroups); False: whole blocks round-robin.  Same bits."""
     M, D = xn.shape
     Hd = fc1_b.numel()
-    _same_device(xn, packed, fc1_b, fc2_b, out)
+    _same_device(xn, packed, fc1_b, out)
     if out is None:
         out = torch.empty(M, D, dtype=torch.bfloat16, device=xn.device)
-    _lib.check(_lib.load().tr_mlp_fused_bf16(_dev(xn, torch.bfloat16, "xn"), _dev(packed, torch.uint8, "packed"), _dev(fc1_b, torch.float32, "fc1_b"),
-                                             _dev(fc2_b, torch.float32, "fc2_b"), _dev(out, torch.bfloat16, "out"), M, D, Hd, _stream(xn)),
+    lib = _lib.load()
+    scratch, nbytes = None, 0
+    if streamk:
+        nbytes = int(lib.tr_mlp_fused_scratch_bytes(D, Hd))
+        key = (xn.device, nbytes)
+        if nbytes and key not in _MLP_SCRATCH:
+            _MLP_SCRATCH[key] = torch.empty(nbytes, dtype=torch.uint8, device=xn.device)
+        scratch = _MLP_SCRATCH.get(key)
+    _lib.check(lib.tr_mlp_fused_bf16(_dev(xn, torch.bfloat16, "xn"), _dev(packed, torch.uint8, "packed"), _dev(fc1_b, torch.float32, "fc1_b"),
+                                     _dev(out, torch.bfloat16, "out"),
+                                     None if scratch is None else scratch.data_ptr(), nbytes if scratch is not None else 0, M, D, Hd, _stream(xn)),
                "tr_mlp_fused_bf16")
     return out
 

@@ -3,7 +3,7 @@
 
     python tools/mlp_lab.py [rows ...]        default rows: the four stages of DeiT-S Top-K kr 0.7 at B = 256 + ragged / tiny cases
 
-Per M: out_pair = gemm(gemm(x, W1, b1, GELU_BF16), W2, b2, BF16), out_fused = mlp_fused(x, pack(W1, W2), b1, b2); the two must be equal
+Per M: out_pair = gemm(gemm(x, W1, b1, GELU_BF16), W2, b2, BF16), out_fused = mlp_fused(x, pack(W1, W2, b2), b1); the two must be equal
 bit for bit (same MFMA, same K order, same rounding points: csrc/tr_mlp_fused.hip)."""
 import os
 import sys
@@ -14,6 +14,7 @@ import torch  # noqa: E402
 from tokenreduction_amd import ops  # noqa: E402
 
 D, Hd = 384, 1536
+STREAMK = "--no-streamk" not in sys.argv   # the hand-over scratch (stream-K schedule beyond 256 blocks); --no-streamk: whole blocks round-robin
 STRESS = "--stress" in sys.argv            # re-run the fused launch 200 times per shape under uneven load and compare every output (race screen)
 STAMPS = "--stamps" in sys.argv            # a -DTR_DIAG_STAMPS build (TOKENREDUCTION_HIP_LIB=...): print the per-step phase stamps of workgroup 8
 rows = [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [50432, 35328, 24832, 17408, 1000, 129, 128, 77, 1]
@@ -37,7 +38,7 @@ W1 = (0.05 * torch.randn(Hd, D, device=dev)).to(torch.bfloat16)
 W2 = (0.05 * torch.randn(D, Hd, device=dev)).to(torch.bfloat16)
 b1 = 0.1 * torch.randn(Hd, device=dev)
 b2 = 0.1 * torch.randn(D, device=dev)
-pk = ops.mlp_pack(W1, W2)
+pk = ops.mlp_pack(W1, W2, b2)
 bad = 0
 for M in rows:
     x = torch.randn(M, D, device=dev).to(torch.bfloat16)
@@ -52,7 +53,7 @@ for M in rows:
         ops.gemm(h, W2, b2, ops.TR_EPI_BF16, out=o_pair)
 
     def fused():
-        ops.mlp_fused(x, pk, b1, b2, out=o_fused)
+        ops.mlp_fused(x, pk, b1, out=o_fused, streamk=STREAMK)
 
     pair()
     fused()
@@ -102,5 +103,8 @@ for M in rows:
             wait = sum(int(d[i, 3] - d[i, 2]) for i in rowsel) / len(rowsel)
             per = (int(d[rowsel[-1], 0]) - int(d[rowsel[0], 0])) / (len(rowsel) - 1)
             print(f"    stamps {name}: step {per:7.0f} cycles = MFMA phase {body:6.0f} + {'GELU + h write' if role == 0 else 'epilogue      '} {tail:6.0f} + wait/barrier {wait:6.0f}")
+            if "--steps" in sys.argv:          # every recorded step of workgroup 8: start-to-start cycles (segment switches and hand-overs stand out)
+                live = [i for i in range(64) if int(d[i, 0]) != 0]
+                print("      step lengths:", " ".join(str(int(d[live[k + 1], 0] - d[live[k], 0])) for k in range(len(live) - 1)))
 print("ALL BIT-IDENTICAL" if bad == 0 else f"{bad} SHAPES DIFFER")
 sys.exit(0 if bad == 0 else 1)
