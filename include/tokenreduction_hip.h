@@ -94,6 +94,16 @@ int tr_mlp_pack_bf16(const uint16_t* fc1_w, const uint16_t* fc2_w, const float* 
 size_t tr_mlp_fused_scratch_bytes(int D, int Hd);
 int tr_mlp_fused_bf16(const uint16_t* xn, const void* packed, const float* fc1_b, uint16_t* out, void* scratch, size_t scratch_bytes, int M, int D,
                       int Hd, tr_stream_t s);
+/* The tail of a block and the head of the next in ONE launch (topk.py:95 `x = x + self.mlp(self.norm2(x))`, then the next block's :87
+ * `self.norm1(x)`):  x[M,D] (fp32 stream, already holding the attention branch's residual) += fc2(gelu(fc1(xn))) + fc2_b, IN PLACE, and
+ * xn_next[M,D] (bf16, != xn) = LayerNorm(x; next_g, next_b, eps).  The kernel's fc2 wave owns whole rows in registers: its accumulator
+ * starts at the stream row, so the fc2 output is never rounded to bf16 on its way into the stream, and the row's mean / variance are taken in
+ * registers (two passes, tr_layernorm's formulas).  Replaces fc1, fc2 and the residual-add + LayerNorm launch behind them; not bit-identical
+ * to that sequence (one rounding fewer), same tolerance class.  packed / scratch as for tr_mlp_fused_bf16 (fc2_b is passed again: the bias
+ * image inside `packed` is not used here). */
+int tr_mlp_fused_resid_ln_bf16(const uint16_t* xn, const void* packed, const float* fc1_b, const float* fc2_b, float* x, const float* next_g,
+                               const float* next_b, float eps, uint16_t* xn_next, void* scratch, size_t scratch_bytes, int M, int D, int Hd,
+                               tr_stream_t s);
 
 /* a4 nn.LayerNorm(D, eps) rows of the fp32 residual stream -> bf16 (topk.py:86 norm1, :95 norm2, :201 norm), with the
  * PENDING residual add folded in: if delta != NULL (bf16 rows at stride ldd: the output of attn.proj / mlp.fc2),

@@ -206,10 +206,25 @@ __device__ __forceinline__ MfCur mf_next(const MfSeq& q, const MfCur& c, int NS)
 constexpr int MF_SK_SLOT = 4 * MF_NI * 2 * 1024;     // one workgroup's published accumulator: 4 C waves x 48 fragments x 1 KiB = 192 KiB
 constexpr int MF_SK_CNT = 128;                       // bytes per counter (its own line)
 
+// RL ("residual + LayerNorm" tail of a transformer block, topk.py:95 followed by the next block's :87 norm1): the C wave's accumulator starts at
+// the block's rows of the fp32 residual stream `rl.x` (which already holds x + attention branch) instead of at fc2's bias, so that at the
+// block's end it IS the new stream row  x + fc2(gelu(fc1(norm2 x))) + b2  -- written back in place -- and, the wave owning whole rows, the
+// next block's norm1 of it (two-pass mean / variance over the row's 4 lanes x 96 values, tr_norm.hip's formulas) goes out as bf16 through
+// the same staged whole-line stores.  One launch replaces fc1, fc2 AND the residual-add + LayerNorm kernel behind them; the fc2 output is
+// never rounded to bf16 on the way into the stream.
+struct MfResid {
+  float* x;            // [M, 384] fp32 residual stream, updated in place
+  const float* b2;     // fc2 bias
+  const float* g;      // next norm1: weight, bias, eps
+  const float* b;
+  float eps;
+};
+
+template <bool RL>
 __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __restrict__ xn, const unsigned char* __restrict__ pk,
                                                            const float* __restrict__ b1,
                                                            uint16_t* __restrict__ outp, unsigned char* __restrict__ scratch, int M, int NS,
-                                                           unsigned out_bytes) {
+                                                           unsigned out_bytes, const MfResid rl) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[MF_LDS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -453,13 +468,24 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
   // (tr_mlp_pack_bf16).  The tail segment of a stream-K range loads the previous workgroup's accumulator instead: the same loads, another base.
   const unsigned char* const bias_img = pk + (size_t)NS * MF_ENTRY;
   f32x4 acc[MF_NI][2];
-  {
-    const __amdgpu_buffer_rsrc_t bsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(bias_img), 0, MF_NI * 2 * 1024, 0x00020000);
+  // RL: rows beyond M read as zeros and their stores are dropped (the descriptor's bounds check: num_records = M rows)
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(RL ? reinterpret_cast<unsigned char*>(rl.x) : const_cast<unsigned char*>(bias_img), 0,
+                                                                         RL ? (int)(2u * out_bytes) : MF_NI * 2 * 1024, 0x00020000);
+  // a lane's first element of block blk in the stream: row blk * 128 + pr * 32 + (lane & 15) [+ 16 j], column 4 (lane >> 4) [+ 16 i]
+  auto x_row_off = [&](int blk) __attribute__((always_inline)) { return ((unsigned)(blk * MF_ROWS + pr * 32 + frow) * MF_D + 4u * fq) * 4u; };
+  if constexpr (RL) {
+    const unsigned vo = x_row_off(mf_block(q, mf_first(q, NS)));
 #pragma unroll
     for (int i = 0; i < MF_NI; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        acc[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bsrc, lane16 + (unsigned)((i * 2 + j) * 1024), 0, 0));
+        acc[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, vo + (unsigned)(j * 16 * MF_D * 4), i * 64, 0));
+  } else {
+#pragma unroll
+    for (int i = 0; i < MF_NI; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        acc[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrsrc, lane16 + (unsigned)((i * 2 + j) * 1024), 0, 0));
   }
   issue_all();
   advance_entry();
@@ -507,7 +533,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
   // fin: number t-2 was its segment's last step -- 1: the block is complete (epilogue), 2: a head segment (publish the accumulator);
   // load_next: the next segment is this workgroup's tail -- its accumulator comes from the previous workgroup.
   bool publish_pending = false;
-  auto c_step = [&](const int fin, const bool load_next, int blk) __attribute__((always_inline)) {
+  auto c_step = [&](const int fin, const bool load_next, int blk, int blk_next) __attribute__((always_inline)) {
     const bool epi = fin == 1;
     const unsigned char* slot = smem + cslot * MF_ENTRY + MF_W1FR * 1024 + lane16;
     const int nslot = (cslot + 1 == MF_NSLOT) ? 0 : cslot + 1;
@@ -585,6 +611,14 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
       h1 = *reinterpret_cast<const bf16x8*>(hsrc + 1024);
     }
     if (fin) {
+      // RL: everything lane-dependent in this block is derived HERE from an opaque copy of the lane id -- as loop invariants (row and column
+      // of the lane in three layouts, their products with the row pitch) they cost registers through the step loop, which has none to spare
+      // (hipcc then reloads one of the loop's own addresses from scratch in every step, behind a vmcnt(0) that drains the DMA pieces)
+      int lane_e = lane;
+      if constexpr (RL) asm volatile("" : "+v"(lane_e));
+      const int frow = lane_e & 15, fq = lane_e >> 4;
+      const unsigned lane16 = (unsigned)lane_e * 16u;
+      auto x_row_off = [&](int b_) __attribute__((always_inline)) { return ((unsigned)(b_ * MF_ROWS + pr * 32 + frow) * MF_D + 4u * fq) * 4u; };
       // The segment is complete.  fin == 1: the block is, its 32 x 384 fp32 accumulator leaves as bf16 rows.  A 16-row x 64-column slab goes
       // through 2 KiB of LDS -- the hidden buffer just read into h0/h1 (its next writer is the partner's step t+2, two barriers away) -- so
       // that every store covers whole 128-byte lines; swizzle and the one-ahead pipelining are those of gemm_bf16_pc's epilogue.
@@ -594,16 +628,131 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
       // (load_next) the previous workgroup's published accumulator -- ONE definition site for the 192 registers (three conditional ones made
       // hipcc keep two copies: 174 spills).
       unsigned char* stg = hb + ((t + 1) & 1) * MF_HBUF;
-      const int rrow = lane >> 3, rch = lane & 7;
+      const int rrow = lane_e >> 3, rch = lane_e & 7;
       unsigned voff_out = ((unsigned)(blk * MF_ROWS + pr * 32 + rrow) * MF_D + 8u * rch) * 2u;
       unsigned voff_sk = (unsigned)(pr * MF_NI * 2) * 1024u + lane16;
-      unsigned voff_new = load_next ? voff_sk : lane16;
+      unsigned voff_new = load_next ? voff_sk : (RL ? x_row_off(blk_next) : lane16);
       // opaque: computed here, once per block, instead of being hoisted out of the step loop as address registers;
       // and h0/h1 must have ARRIVED before the staging writes overwrite their source
       asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(voff_out), "+v"(voff_sk), "+v"(voff_new), "+v"(h0), "+v"(h1)::"memory");
       const __amdgpu_buffer_rsrc_t nsrc = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<unsigned char*>(load_next ? scratch + (size_t)(bid > 0 ? bid - 1 : 0) * MF_SK_SLOT : bias_img), 0,
-          load_next ? MF_SK_SLOT : MF_NI * 2 * 1024, 0x00020000);
+          load_next ? scratch + (size_t)(bid > 0 ? bid - 1 : 0) * MF_SK_SLOT
+                    : (RL ? reinterpret_cast<unsigned char*>(rl.x) : const_cast<unsigned char*>(bias_img)),
+          0, load_next ? MF_SK_SLOT : (RL ? (int)(2u * out_bytes) : MF_NI * 2 * 1024), 0x00020000);
+      // where fragment (i, j) of the next accumulator lies behind voff_new: i * si + j * sj (the hand-over slot and the bias image: 2 KiB per i,
+      // 1 KiB per j; RL's stream rows: 16 columns = 64 B per i, 16 rows per j)
+      const int si = (RL && !load_next) ? 64 : 2048, sj = (RL && !load_next) ? 16 * MF_D * 4 : 1024;
+      if constexpr (RL) {
+        if (epi) {
+          // The accumulator (stream row + the sum over the hidden units) + fc2's bias = the new stream row; its mean and variance over the
+          // row (this lane's 96 values of each of its two rows, then the row's other three lanes: lane ^ 16, ^ 32), two passes as in
+          // tr_norm.hip.  The parameter vectors come through asm loads, two 16-byte fragments in flight: hipcc hoists plain loads to the top
+          // (24 x 4 registers beside the 192 of the accumulator: 273 spills, five accumulator fragments living in scratch through the step loop).
+          // The three parameter vectors (fc2 bias, the norm's weight and bias: 1.5 KB each) are read per 16-column fragment in the accumulator's
+          // lane layout.  Through global loads that is 72 dependent L2 round trips per block (measured: 27 us per block); so each C wave
+          // copies them ONCE per block by LDS-DMA into 1-KiB pieces of the ring slot this step has consumed -- pieces pr + 4 k, which only
+          // THIS wave's DMA of the next step writes again: k = 0, 1 the staging slab below, k = 2.. the vectors -- and reads fragments from LDS.
+          unsigned char* const stgA = smem + cslot * MF_ENTRY + pr * 1024;
+          {
+            const unsigned ldsA = lds0 + cslot * MF_ENTRY + pr * 1024;
+            mf_piece(reinterpret_cast<const unsigned char*>(rl.b2), lane16, ldsA + 2 * 4096);
+            mf_piece(reinterpret_cast<const unsigned char*>(rl.g), lane16, ldsA + 4 * 4096);
+            mf_piece(reinterpret_cast<const unsigned char*>(rl.b), lane16, ldsA + 6 * 4096);
+            if (lane_e < 32) {          // floats 256..383
+              mf_piece(reinterpret_cast<const unsigned char*>(rl.b2) + 1024, lane16, ldsA + 3 * 4096);
+              mf_piece(reinterpret_cast<const unsigned char*>(rl.g) + 1024, lane16, ldsA + 5 * 4096);
+              mf_piece(reinterpret_cast<const unsigned char*>(rl.b) + 1024, lane16, ldsA + 7 * 4096);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          const unsigned char* const tab = stgA + fq * 16;
+          // fragment i of vector v (v = 2: fc2 bias, 4: weight, 6: bias): floats 16 i + 4 fq .. + 3
+#define MF_TAB(v, i) (*reinterpret_cast<const f32x4*>(tab + ((v) + ((i) >> 4)) * 4096 + ((i) & 15) * 64))
+#define MF_REP24(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) X(20) X(21) X(22) X(23)
+          float s0 = 0.f, s1 = 0.f;
+          f32x4 nb2 = MF_TAB(2, 0);
+          // (the sched_barriers keep hipcc from hoisting all 24 fragment reads to the top: 96 registers beside the accumulator's 192.  The
+          // bias is added on the fly in each pass, NOT into the accumulator: 192 VALU-redefined registers between the step loop and the
+          // norm cost 158 spilled registers.  And this file is compiled with -fno-slp-vectorize: the SLP vectoriser re-packs these scalar
+          // chains into v_pk_* operations on register pairs it first has to assemble -- 86 spills, and every scratch reload waits on
+          // vmcnt(0) behind the stores in flight: 44,000 cycles per block)
+#define MF_RL_P1(i)                                                                                   \
+  {                                                                                                   \
+    const f32x4 bb = nb2;                                                                             \
+    if ((i) + 1 < MF_NI) nb2 = MF_TAB(2, ((i) + 1) % MF_NI);                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    const f32x4 u0 = acc[i][0] + bb, u1 = acc[i][1] + bb;                                             \
+    s0 += (u0[0] + u0[1]) + (u0[2] + u0[3]);                                                          \
+    s1 += (u1[0] + u1[1]) + (u1[2] + u1[3]);                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+  }
+          MF_REP24(MF_RL_P1)
+#undef MF_RL_P1
+          s0 += __shfl_xor(s0, 16); s1 += __shfl_xor(s1, 16);
+          s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32);
+          const float mean0 = s0 / (float)MF_D, mean1 = s1 / (float)MF_D;
+          float q0 = 0.f, q1 = 0.f;
+          nb2 = MF_TAB(2, 0);
+#define MF_RL_P2(i)                                                                                   \
+  {                                                                                                   \
+    const f32x4 bb = nb2;                                                                             \
+    if ((i) + 1 < MF_NI) nb2 = MF_TAB(2, ((i) + 1) % MF_NI);                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
+      const float d0 = (acc[i][0][e] + bb[e]) - mean0, d1 = (acc[i][1][e] + bb[e]) - mean1;           \
+      q0 = __builtin_fmaf(d0, d0, q0);                                                                \
+      q1 = __builtin_fmaf(d1, d1, q1);                                                                \
+    }                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+  }
+          MF_REP24(MF_RL_P2)
+#undef MF_RL_P2
+          q0 += __shfl_xor(q0, 16); q1 += __shfl_xor(q1, 16);
+          q0 += __shfl_xor(q0, 32); q1 += __shfl_xor(q1, 32);
+          const float rstd0 = rsqrtf(q0 / (float)MF_D + rl.eps), rstd1 = rsqrtf(q1 / (float)MF_D + rl.eps);
+          // norm1 of the next block, as bf16: two 16-column fragments x both row groups = a 32-row x 32-column slab (2 KiB: pieces k = 0, 1) go
+          // through LDS so that a store instruction covers 64-byte row segments (two consecutive slabs complete the lines in L2).
+          {
+            const int r4 = lane_e >> 2, ch4 = lane_e & 3;
+            unsigned vxn = ((unsigned)(blk * MF_ROWS + pr * 32 + r4) * MF_D + 8u * ch4) * 2u;
+            asm volatile("" : "+v"(vxn));
+            const unsigned char* rdp = stgA + r4 * 64 + ((ch4 ^ ((r4 >> 1) & 3)) << 4);
+            unsigned vx0 = x_row_off(blk), vx1 = x_row_off(blk) + (unsigned)(16 * MF_D * 4);
+            asm volatile("" : "+v"(vx0), "+v"(vx1));
+            // (no read-ahead of the next fragment's weight / bias here: with the 192 accumulator registers, the statistics and the slab in flight
+            // there is no room for a second pair -- hipcc then parks accumulator fragments in scratch THROUGH THE STEP LOOP)
+#define MF_RL_P3(i)                                                                                                                  \
+  {                                                                                                                                  \
+    const f32x4 g = MF_TAB(4, i), bb = MF_TAB(6, i), b2f = MF_TAB(2, i);                                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                                                  \
+      const float mean = j ? mean1 : mean0, rstd = j ? rstd1 : rstd0;                                                                \
+      const f32x4 v = acc[i][j] + b2f;                                                                                               \
+      /* the stream row goes back in place (64-byte row segments per instruction, two instructions complete a line in L2); offsets in */ \
+      /* VGPRs / immediates, never an SGPR soffset on a 16-byte store (see below) */                                                 \
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), xrsrc, (j ? vx1 : vx0) + (unsigned)((i) * 64), 0, 0);    \
+      u32x2 pk2;                                                                                                                     \
+      pk2[0] = pack_bf16x2((v[0] - mean) * rstd * g[0] + bb[0], (v[1] - mean) * rstd * g[1] + bb[1]);                                \
+      pk2[1] = pack_bf16x2((v[2] - mean) * rstd * g[2] + bb[2], (v[3] - mean) * rstd * g[3] + bb[3]);                                \
+      *reinterpret_cast<u32x2*>(stgA + j * 4096 + frow * 64 + (((2 * ((i) & 1) + (fq >> 1)) ^ ((frow >> 1) & 3)) << 4) + ((fq & 1) << 3)) = pk2; \
+    }                                                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                                               \
+    if ((i) & 1) {                                                                                                                   \
+      const u32x4 l0 = *reinterpret_cast<const u32x4*>(rdp);                                                                         \
+      __builtin_amdgcn_raw_buffer_store_b128(l0, orsrc, vxn + (unsigned)(((i) >> 1) * 64), 0, 0);                                    \
+      __builtin_amdgcn_sched_barrier(0);                                                                                             \
+      const u32x4 l1 = *reinterpret_cast<const u32x4*>(rdp + 4096);                                                                  \
+      __builtin_amdgcn_raw_buffer_store_b128(l1, orsrc, vxn + (unsigned)(((i) >> 1) * 64 + 16 * MF_D * 2), 0, 0);                    \
+      __builtin_amdgcn_sched_barrier(0);                                                                                             \
+    }                                                                                                                                \
+  }
+            MF_REP24(MF_RL_P3)
+#undef MF_RL_P3
+#undef MF_REP24
+#undef MF_TAB
+          }
+        }
+      }
       const unsigned char* rd = stg + rrow * 128 + ((rch ^ rrow) << 4);
       auto stage = [&](int c, int j) __attribute__((always_inline)) {
 #pragma unroll
@@ -659,10 +808,10 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
         }
         asm volatile("" ::: "memory");
       }
-      if (epi) { stage(0, 0); read_back(lnA); }
+      if (!RL && epi) { stage(0, 0); read_back(lnA); }
 #pragma unroll
       for (int c = 0; c < MF_NI / 4; ++c) {
-        if (epi) {
+        if (!RL && epi) {
           // pass (c, 0) is staged and being read back into lnA on entry
           stage(c, 1); store(c, 0, lnA); read_back(lnB);
           if (c + 1 < MF_NI / 4) stage(c + 1, 0);
@@ -673,8 +822,16 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
         for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            acc[4 * c + ii][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(nsrc, voff_new + (unsigned)(((4 * c + ii) * 2 + j) * 1024), 0,
+            acc[4 * c + ii][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(nsrc, voff_new, (4 * c + ii) * si + j * sj,
                                                                                                  16 /* sc1: past this CU's L1 (the hand-over read) */));
+      }
+      if constexpr (RL) {
+        // the next step's first weight fragments and hidden fragments are fetched AGAIN here: the copies requested above are dead on this path,
+        // which frees their 24 registers for the norm's parameters and statistics (ring slot and hidden buffer stay valid through the next step)
+        MF_READW(wA, slot_next, 0);
+        const unsigned char* hsrc = hb + ((t + 1) & 1) * MF_HBUF + lane16;
+        h0 = *reinterpret_cast<const bf16x8*>(hsrc);
+        h1 = *reinterpret_cast<const bf16x8*>(hsrc + 1024);
       }
     }
     MF_STAMP(3);
@@ -689,7 +846,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
       const bool last = mf_last_of_segment(q, cur, NS);
       int flags = __builtin_amdgcn_readfirstlane((last ? (cur.seg == -1 ? 2 : 1) : 0) | ((last && tt + 1 < T && nxt.seg == q.nfull) ? 4 : 0));
       asm volatile("" : "+s"(flags));
-      c_step(flags & 3, (flags & 4) != 0, mf_block(q, cur));
+      c_step(flags & 3, (flags & 4) != 0, mf_block(q, cur), mf_block(q, nxt));
       cur = nxt;
     }
   }
@@ -745,19 +902,22 @@ extern "C" int tr_mlp_pack_bf16(const uint16_t* fc1_w, const uint16_t* fc2_w, co
   return TR_OK;
 }
 
-extern "C" int tr_mlp_fused_bf16(const uint16_t* xn, const void* packed, const float* fc1_b, uint16_t* out, void* scratch, size_t scratch_bytes, int M,
-                                 int D, int Hd, tr_stream_t s) {
-  TR_REQUIRE(xn && packed && fc1_b && out, TR_ERR_NULL, "tr_mlp_fused_bf16: null pointer");
-  TR_REQUIRE(M > 0 && tr_mlp_fused_supported(D, Hd), TR_ERR_SHAPE, "tr_mlp_fused_bf16: unsupported shape M=%d D=%d Hd=%d (D must be %d, Hd %% 32 == 0)", M, D, Hd,
+static int mlp_fused_launch(const char* who, const uint16_t* xn, const void* packed, const float* fc1_b, uint16_t* out, void* scratch,
+                            size_t scratch_bytes, int M, int D, int Hd, const MfResid* rl, tr_stream_t s) {
+  TR_REQUIRE(xn && packed && fc1_b && out, TR_ERR_NULL, "%s: null pointer", who);
+  TR_REQUIRE(M > 0 && tr_mlp_fused_supported(D, Hd), TR_ERR_SHAPE, "%s: unsupported shape M=%d D=%d Hd=%d (D must be %d, Hd %% 32 == 0)", who, M, D, Hd,
              MF_D);
   TR_REQUIRE(tr_aligned16(xn) && tr_aligned16(packed) && tr_aligned16(fc1_b) && tr_aligned16(out) && tr_aligned16(scratch),
-             TR_ERR_ALIGN, "tr_mlp_fused_bf16: pointers must be 16-byte aligned");
+             TR_ERR_ALIGN, "%s: pointers must be 16-byte aligned", who);
   TR_REQUIRE(scratch == nullptr || scratch_bytes >= tr_mlp_fused_scratch_bytes(D, Hd), TR_ERR_SHAPE,
-             "tr_mlp_fused_bf16: scratch of %zu bytes, tr_mlp_fused_scratch_bytes says %zu (or pass NULL: whole-block schedule)", scratch_bytes,
+             "%s: scratch of %zu bytes, tr_mlp_fused_scratch_bytes says %zu (or pass NULL: whole-block schedule)", who, scratch_bytes,
              tr_mlp_fused_scratch_bytes(D, Hd));
   const size_t out_bytes = (size_t)M * D * 2;
-  TR_REQUIRE(out_bytes < ((size_t)1 << 31), TR_ERR_SHAPE, "tr_mlp_fused_bf16: %zu output bytes exceed the 2 GiB range of the store offsets", out_bytes);
-  tr_prof_note("mlp_fused_kernel", 4.0 * M * D * Hd, 4.0 * M * D + 4.0 * D * Hd);
+  TR_REQUIRE(out_bytes < ((size_t)1 << (rl ? 30 : 31)), TR_ERR_SHAPE, "%s: %zu output bytes exceed the range of the 32-bit store offsets", who, out_bytes);
+  if (rl)       // + the stream's read-modify-write and the norm's parameters; no separate fc2 output
+    tr_prof_note("mlp_fused_kernel<resid_ln>", 4.0 * M * D * Hd, 2.0 * M * D + 8.0 * M * D + 2.0 * M * D + 4.0 * D * Hd);
+  else
+    tr_prof_note("mlp_fused_kernel", 4.0 * M * D * Hd, 4.0 * M * D + 4.0 * D * Hd);
   const int nblk = (M + MF_ROWS - 1) / MF_ROWS;
   const int G = nblk < 256 ? nblk : 256;
   hipStream_t st = static_cast<hipStream_t>(s);
@@ -766,10 +926,33 @@ extern "C" int tr_mlp_fused_bf16(const uint16_t* xn, const void* packed, const f
     // the hand-over counters of this launch (one line per workgroup, behind the accumulator slots) start at zero: a memset node ahead of the
     // kernel node (graph-capturable; a counter that the last consumer reset would fail a first, poisoned launch)
     hipError_t e = hipMemsetAsync(sk + (size_t)G * MF_SK_SLOT, 0, (size_t)G * MF_SK_CNT, st);
-    TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_mlp_fused_bf16: hipMemsetAsync: %s", hipGetErrorString(e));
+    TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "%s: hipMemsetAsync: %s", who, hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(mlp_fused_kernel, dim3(G), dim3(512), 0, st, xn, static_cast<const unsigned char*>(packed), fc1_b, out, sk, M, Hd / 32,
-                     (unsigned)out_bytes);
-  TR_CHECK_LAUNCH("tr_mlp_fused_bf16");
+  if (rl)
+    hipLaunchKernelGGL(mlp_fused_kernel<true>, dim3(G), dim3(512), 0, st, xn, static_cast<const unsigned char*>(packed), fc1_b, out, sk, M, Hd / 32,
+                       (unsigned)out_bytes, *rl);
+  else
+    hipLaunchKernelGGL(mlp_fused_kernel<false>, dim3(G), dim3(512), 0, st, xn, static_cast<const unsigned char*>(packed), fc1_b, out, sk, M, Hd / 32,
+                       (unsigned)out_bytes, MfResid{nullptr, nullptr, nullptr, nullptr, 0.f});
+  TR_CHECK_LAUNCH(who);
   return TR_OK;
+}
+
+extern "C" int tr_mlp_fused_bf16(const uint16_t* xn, const void* packed, const float* fc1_b, uint16_t* out, void* scratch, size_t scratch_bytes, int M,
+                                 int D, int Hd, tr_stream_t s) {
+  return mlp_fused_launch("tr_mlp_fused_bf16", xn, packed, fc1_b, out, scratch, scratch_bytes, M, D, Hd, nullptr, s);
+}
+
+// The tail of a transformer block and the head of the next in one launch (topk.py:95 `x = x + self.mlp(self.norm2(x))`, then the next
+// block's :87 `self.norm1(x)`):  x += fc2(gelu(fc1(xn))) + fc2_b  in place on the fp32 stream,  xn_next = LayerNorm(x; next_g, next_b, eps)
+// as bf16.  x must already hold the attention branch's residual.  xn_next may not alias xn.
+extern "C" int tr_mlp_fused_resid_ln_bf16(const uint16_t* xn, const void* packed, const float* fc1_b, const float* fc2_b, float* x,
+                                          const float* next_g, const float* next_b, float eps, uint16_t* xn_next, void* scratch,
+                                          size_t scratch_bytes, int M, int D, int Hd, tr_stream_t s) {
+  TR_REQUIRE(fc2_b && x && next_g && next_b, TR_ERR_NULL, "tr_mlp_fused_resid_ln_bf16: null pointer");
+  TR_REQUIRE(tr_aligned16(fc2_b) && tr_aligned16(x) && tr_aligned16(next_g) && tr_aligned16(next_b), TR_ERR_ALIGN,
+             "tr_mlp_fused_resid_ln_bf16: pointers must be 16-byte aligned");
+  TR_REQUIRE(xn_next != xn, TR_ERR_CONFIG, "tr_mlp_fused_resid_ln_bf16: xn_next aliases xn");
+  const MfResid rl{x, fc2_b, next_g, next_b, eps};
+  return mlp_fused_launch("tr_mlp_fused_resid_ln_bf16", xn, packed, fc1_b, xn_next, scratch, scratch_bytes, M, D, Hd, &rl, s);
 }

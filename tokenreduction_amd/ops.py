@@ -141,6 +141,33 @@ def mlp_fused(xn: torch.Tensor, packed: torch.Tensor, fc1_b: torch.Tensor, out: 
     return out
 
 
+def mlp_fused_resid_ln(xn: torch.Tensor, packed: torch.Tensor, fc1_b: torch.Tensor, fc2_b: torch.Tensor, x: torch.Tensor, next_g: torch.Tensor,
+                       next_b: torch.Tensor, eps: float, xn_next: torch.Tensor = None, streamk: bool = True) -> torch.Tensor:
+    """Block tail + next block's norm1 in one launch (topk.py:95, then :87): x (fp32 [M,D], updated IN PLACE) += Mlp(xn) and
+    returns LayerNorm(x; next_g, next_b, eps) as bf16 [M,D]."""
+    M, D = xn.shape
+    Hd = fc1_b.numel()
+    _same_device(xn, packed, fc1_b, fc2_b, x, next_g, next_b, xn_next)
+    if tuple(x.shape) != (M, D) or not x.is_contiguous():
+        raise ValueError(f"mlp_fused_resid_ln: x is {tuple(x.shape)}, expected contiguous {(M, D)}")
+    if xn_next is None:
+        xn_next = torch.empty(M, D, dtype=torch.bfloat16, device=xn.device)
+    lib = _lib.load()
+    scratch, nbytes = None, 0
+    if streamk:
+        nbytes = int(lib.tr_mlp_fused_scratch_bytes(D, Hd))
+        key = (xn.device, nbytes)
+        if nbytes and key not in _MLP_SCRATCH:
+            _MLP_SCRATCH[key] = torch.empty(nbytes, dtype=torch.uint8, device=xn.device)
+        scratch = _MLP_SCRATCH.get(key)
+    _lib.check(lib.tr_mlp_fused_resid_ln_bf16(_dev(xn, torch.bfloat16, "xn"), _dev(packed, torch.uint8, "packed"), _dev(fc1_b, torch.float32, "fc1_b"),
+                                              _dev(fc2_b, torch.float32, "fc2_b"), _dev(x, torch.float32, "x"), _dev(next_g, torch.float32, "next_g"),
+                                              _dev(next_b, torch.float32, "next_b"), float(eps), _dev(xn_next, torch.bfloat16, "xn_next"),
+                                              None if scratch is None else scratch.data_ptr(), nbytes if scratch is not None else 0, M, D, Hd,
+                                              _stream(xn)), "tr_mlp_fused_resid_ln_bf16")
+    return xn_next
+
+
 def layernorm(x: torch.Tensor, gamma, beta, eps: float, rows: int = None, ldx: int = None, delta: torch.Tensor = None,
               ldd: int = None) -> torch.Tensor:
     """[x += delta (bf16, written back);] nn.LayerNorm over the last dim of fp32 x -> bf16 [M,D]
