@@ -101,6 +101,10 @@ int tr_mlp_fused_bf16(const uint16_t* xn, const void* packed, const float* fc1_b
  * registers (two passes, tr_layernorm's formulas).  Replaces fc1, fc2 and the residual-add + LayerNorm launch behind them; not bit-identical
  * to that sequence (one rounding fewer), same tolerance class.  packed / scratch as for tr_mlp_fused_bf16 (fc2_b is passed again: the bias
  * image inside `packed` is not used here). */
+/* Whether the eval executor runs that form where it runs the fused Mlp and the next block starts with a plain norm1 (1) or keeps
+ * tr_mlp_fused_bf16 + the LayerNorm launch (0 = default: measured, the one-launch form is 4 % slower on the headline forward -- its
+ * epilogue stalls the workgroup; profiles/r05_mlp_lab.md).  Process-wide; returns the previous setting. */
+int tr_set_mlp_resid_ln(int on);
 int tr_mlp_fused_resid_ln_bf16(const uint16_t* xn, const void* packed, const float* fc1_b, const float* fc2_b, float* x, const float* next_g,
                                const float* next_b, float eps, uint16_t* xn_next, void* scratch, size_t scratch_bytes, int M, int D, int Hd,
                                tr_stream_t s);

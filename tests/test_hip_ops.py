@@ -131,6 +131,47 @@ def test_mlp_fused_stream_k_ranges(ops, nblk, ragged, Hd):
         assert torch.isnan(guard[M:].float()).all(), "rows beyond M were written"
 
 
+# ------------------------------------------------------------------------------------------ fused block tail: Mlp + residual + next norm1
+@pytest.mark.parametrize("M", [1, 77, 129, 1000, 24832, 257 * 128, 35328 + 3, 50432])
+def test_mlp_fused_resid_ln(ops, M):
+    """tr_mlp_fused_resid_ln_bf16 (topk.py:95 `x = x + self.mlp(self.norm2(x))` and the next block's :87 norm1 in one launch): the stream row
+    must equal x + Mlp(xn) up to the bf16 rounding of the Mlp output that this form does NOT do (|diff| <= half a bf16 ulp of the pair's output),
+    sampled rows must match the float64 Mlp on the bf16-rounded operands more closely than the pair does, the norm output must be torch's
+    LayerNorm of the kernel's own stream row to one bf16 ulp, rows beyond M stay untouched, and the stream-K schedule gives the same bits as
+    whole blocks."""
+    D, Hd = 384, 1536
+    rng = _rng(M * 5 + 1)
+    xn = _randn(rng, M, D).bfloat16().cuda()
+    x0 = (2.0 * _randn(rng, M, D)).cuda()
+    w1, w2 = _randn(rng, Hd, D, scale=0.05).bfloat16().cuda(), _randn(rng, D, Hd, scale=0.05).bfloat16().cuda()
+    b1, b2 = _randn(rng, Hd, scale=0.1).cuda(), _randn(rng, D, scale=0.1).cuda()
+    g, bt = (1.0 + 0.2 * _randn(rng, D)).cuda(), (0.1 * _randn(rng, D)).cuda()
+    pk = ops.mlp_pack(w1, w2, b2)
+    d = ops.mlp_fused(xn, pk, b1)                       # bit-identical to the GEMM pair (test above)
+    outs = []
+    for streamk in (True, False):
+        xg = torch.full((M + 2, D), float("nan"), dtype=torch.float32, device="cuda")
+        xg[:M] = x0
+        yg = torch.full((M + 2, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+        ops.mlp_fused_resid_ln(xn, pk, b1, b2, xg[:M], g, bt, 1e-6, xn_next=yg[:M], streamk=streamk)
+        assert torch.isnan(xg[M:]).all() and torch.isnan(yg[M:].float()).all(), "rows beyond M were written"
+        outs.append((xg[:M].clone(), yg[:M].clone()))
+    (xa, ya), (xb, yb) = outs
+    assert torch.equal(xa, xb) and torch.equal(ya.view(torch.int16), yb.view(torch.int16)), "stream-K and whole-block schedules differ"
+    # (+ the fp32 roundings of a sum that is accumulated ON the stream value: 48 steps at ulp(|x| <= 16) ~ 1e-6 each)
+    ulp_half = d.float().abs() * 2.0 ** -8 + 1e-4
+    assert bool(((xa - (x0 + d.float())).abs() <= ulp_half).all()), "stream row is not x + Mlp(xn) to the rounding of the Mlp output"
+    ref_y = torch.nn.functional.layer_norm(xa, (D,), g, bt, 1e-6)
+    err = (ya.float() - ref_y).abs()
+    assert bool((err <= ref_y.abs() * 2.0 ** -7 + 1e-3).all()), float(err.max())
+    rows = torch.cat([torch.arange(0, min(M, 130)), torch.arange(max(0, M - 130), M)]).unique()
+    hid = oracle.gelu_erf(xn[rows.cuda()].cpu().double() @ w1.cpu().double().t() + b1.cpu().double())
+    ref = x0[rows.cuda()].cpu().double() + _bf(hid.float()).double() @ w2.cpu().double().t() + b2.cpu().double()
+    e_new = (xa[rows.cuda()].cpu().double() - ref).abs().max()
+    e_old = ((x0 + d.float())[rows.cuda()].cpu().double() - ref).abs().max()
+    assert e_new <= e_old + 1e-3, (float(e_new), float(e_old))
+
+
 # ------------------------------------------------------------------------------------------ fused eval Mlp (fc1 -> GELU -> fc2, one launch)
 @pytest.mark.parametrize("M", [1, 77, 128, 129, 1000, 197 * 8, 32768 + 5, 50432, 35328, 257 * 128, 70001])
 @pytest.mark.parametrize("Hd", [1536, 64, 192])

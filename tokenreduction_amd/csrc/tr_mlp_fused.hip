@@ -64,6 +64,17 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 
 // diagnostic build only (never in the product): s_memtime stamps of workgroup 8, P wave 0 and C wave 4, first 64 steps, written BEHIND the
 // output (the lab allocates the room: tools/mlp_lab.py --stamps)
+// lab ablations of the residual + LayerNorm epilogue: -DMF_ABL_NO_XSTORE (no stream stores), -DMF_ABL_NO_NSTORE (no norm output stores)
+#ifdef MF_ABL_NO_XSTORE
+#define MF_XSTORE(x) asm volatile("" ::"v"(v))
+#else
+#define MF_XSTORE(x) x
+#endif
+#ifdef MF_ABL_NO_NSTORE
+#define MF_NSTORE(x) do { } while (0)
+#else
+#define MF_NSTORE(x) x
+#endif
 #ifdef TR_DIAG_STAMPS
 #define MF_STAMP(k) ts_[k] = __builtin_amdgcn_s_memtime()
 #define MF_STAMP_DECL unsigned long long ts_[4] = {0, 0, 0, 0}
@@ -72,6 +83,16 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
     if (bid == 8 && pr == 0 && lane == 0 && (step) < 64) {                                                                            \
       unsigned long long* st_ = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(outp) + out_bytes) + ((role) * 64 + (step)) * 4; \
       st_[0] = ts_[0]; st_[1] = ts_[1]; st_[2] = ts_[2]; st_[3] = ts_[3];                                                             \
+    }                                                                                                                                 \
+  } while (0)
+// epilogue of the residual + LayerNorm variant: eight stamps of workgroup 8's C wave 4 into rows 60, 61 of the P role's table
+#define MF_ESTAMP(k) es_[k] = __builtin_amdgcn_s_memtime()
+#define MF_ESTAMP_DECL unsigned long long es_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define MF_ESTAMP_DUMP                                                                                                                \
+  do {                                                                                                                                \
+    if (bid == 8 && pr == 0 && lane == 0) {                                                                                           \
+      unsigned long long* st_ = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(outp) + out_bytes) + 60 * 4;   \
+      for (int k_ = 0; k_ < 8; ++k_) st_[k_] = es_[k_];                                                                               \
     }                                                                                                                                 \
   } while (0)
 #define MF_CLOCK_BEGIN const unsigned long long ck0_ = __builtin_amdgcn_s_memtime(), rt0_ = __builtin_amdgcn_s_memrealtime()
@@ -89,6 +110,9 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
 #define MF_STAMP(k) do { } while (0)
 #define MF_STAMP_DECL do { } while (0)
 #define MF_STAMP_DUMP(role, step) do { } while (0)
+#define MF_ESTAMP(k) do { } while (0)
+#define MF_ESTAMP_DECL do { } while (0)
+#define MF_ESTAMP_DUMP do { } while (0)
 #endif
 
 constexpr int MF_D = 384;                      // embed dim this instantiation serves
@@ -653,6 +677,8 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
           // copies them ONCE per block by LDS-DMA into 1-KiB pieces of the ring slot this step has consumed -- pieces pr + 4 k, which only
           // THIS wave's DMA of the next step writes again: k = 0, 1 the staging slab below, k = 2.. the vectors -- and reads fragments from LDS.
           unsigned char* const stgA = smem + cslot * MF_ENTRY + pr * 1024;
+          MF_ESTAMP_DECL;
+          MF_ESTAMP(0);
           {
             const unsigned ldsA = lds0 + cslot * MF_ENTRY + pr * 1024;
             mf_piece(reinterpret_cast<const unsigned char*>(rl.b2), lane16, ldsA + 2 * 4096);
@@ -665,6 +691,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           }
+          MF_ESTAMP(1);
           const unsigned char* const tab = stgA + fq * 16;
           // fragment i of vector v (v = 2: fc2 bias, 4: weight, 6: bias): floats 16 i + 4 fq .. + 3
 #define MF_TAB(v, i) (*reinterpret_cast<const f32x4*>(tab + ((v) + ((i) >> 4)) * 4096 + ((i) & 15) * 64))
@@ -688,6 +715,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
   }
           MF_REP24(MF_RL_P1)
 #undef MF_RL_P1
+          MF_ESTAMP(2);
           s0 += __shfl_xor(s0, 16); s1 += __shfl_xor(s1, 16);
           s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32);
           const float mean0 = s0 / (float)MF_D, mean1 = s1 / (float)MF_D;
@@ -707,6 +735,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
   }
           MF_REP24(MF_RL_P2)
 #undef MF_RL_P2
+          MF_ESTAMP(3);
           q0 += __shfl_xor(q0, 16); q1 += __shfl_xor(q1, 16);
           q0 += __shfl_xor(q0, 32); q1 += __shfl_xor(q1, 32);
           const float rstd0 = rsqrtf(q0 / (float)MF_D + rl.eps), rstd1 = rsqrtf(q1 / (float)MF_D + rl.eps);
@@ -730,7 +759,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
       const f32x4 v = acc[i][j] + b2f;                                                                                               \
       /* the stream row goes back in place (64-byte row segments per instruction, two instructions complete a line in L2); offsets in */ \
       /* VGPRs / immediates, never an SGPR soffset on a 16-byte store (see below) */                                                 \
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), xrsrc, (j ? vx1 : vx0) + (unsigned)((i) * 64), 0, 0);    \
+      MF_XSTORE(__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), xrsrc, (j ? vx1 : vx0) + (unsigned)((i) * 64), 0, 0)); \
       u32x2 pk2;                                                                                                                     \
       pk2[0] = pack_bf16x2((v[0] - mean) * rstd * g[0] + bb[0], (v[1] - mean) * rstd * g[1] + bb[1]);                                \
       pk2[1] = pack_bf16x2((v[2] - mean) * rstd * g[2] + bb[2], (v[3] - mean) * rstd * g[3] + bb[3]);                                \
@@ -739,14 +768,17 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
     __builtin_amdgcn_sched_barrier(0);                                                                                               \
     if ((i) & 1) {                                                                                                                   \
       const u32x4 l0 = *reinterpret_cast<const u32x4*>(rdp);                                                                         \
-      __builtin_amdgcn_raw_buffer_store_b128(l0, orsrc, vxn + (unsigned)(((i) >> 1) * 64), 0, 0);                                    \
+      MF_NSTORE(__builtin_amdgcn_raw_buffer_store_b128(l0, orsrc, vxn + (unsigned)(((i) >> 1) * 64), 0, 0));                         \
       __builtin_amdgcn_sched_barrier(0);                                                                                             \
       const u32x4 l1 = *reinterpret_cast<const u32x4*>(rdp + 4096);                                                                  \
-      __builtin_amdgcn_raw_buffer_store_b128(l1, orsrc, vxn + (unsigned)(((i) >> 1) * 64 + 16 * MF_D * 2), 0, 0);                    \
+      MF_NSTORE(__builtin_amdgcn_raw_buffer_store_b128(l1, orsrc, vxn + (unsigned)(((i) >> 1) * 64 + 16 * MF_D * 2), 0, 0));         \
       __builtin_amdgcn_sched_barrier(0);                                                                                             \
     }                                                                                                                                \
   }
+            MF_ESTAMP(4);
             MF_REP24(MF_RL_P3)
+            MF_ESTAMP(5);
+            MF_ESTAMP_DUMP;
 #undef MF_RL_P3
 #undef MF_REP24
 #undef MF_TAB
@@ -880,6 +912,12 @@ int tr_mlp_fused_wanted(int M, int D, int Hd, int have_scratch) {
   }
   return 4 * nblk >= 3 * 256;
 }
+
+// default OFF: measured in the model (tools/lab/mlp_model_ab.sh) the fused tail LOSES 4 % of the headline forward against the fused Mlp + the
+// LayerNorm launch -- its epilogue holds the workgroup for ~22,000 cycles per block (profiles/r05_mlp_lab.md)
+static std::atomic<int> g_mlp_resid_ln{0};
+extern "C" int tr_set_mlp_resid_ln(int on) { return g_mlp_resid_ln.exchange(on ? 1 : 0); }
+int tr_mlp_resid_ln_enabled() { return g_mlp_resid_ln.load(std::memory_order_relaxed); }
 
 extern "C" size_t tr_mlp_pack_bytes(int D, int Hd) {
   if (D <= 0 || Hd <= 0 || D % 32 || Hd % 32) return 0;

@@ -121,6 +121,7 @@ extern "C" int tr_profile_end(int max, char* labels, float* ms, double* flops, d
 extern "C" int tr_version(void) { return 100; }
 
 int tr_mlp_fused_wanted(int M, int D, int Hd, int have_scratch);      // tr_mlp_fused.hip: the schedule policy behind tr_set_mlp_fused
+int tr_mlp_resid_ln_enabled();                                        // tr_mlp_fused.hip: tr_set_mlp_resid_ln's switch
 
 namespace {
 
@@ -304,6 +305,13 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
     }
   };
   const void* pending_attn = nullptr;      // the attention branch's residual of the previous block, not yet in x (lazy norm2)
+  // Fused block tail (tr_mlp_fused_resid_ln_bf16): where the fused eval Mlp runs and the next block starts with a plain norm1, ONE launch does
+  // fc1 -> GELU -> fc2, adds the result to the stream in place and writes the next block's norm1 -- into the hidden-activation buffer, which the
+  // fused Mlp leaves unused and which nothing touches until that block's own Mlp (its only reader is the next qkv GEMM).  The block's norm2
+  // then writes the stream (eager): the kernel's accumulators start at the stream row.  OFF by default (tr_set_mlp_resid_ln): measured in the
+  // model it loses 4 % against fused Mlp + LayerNorm launch (the epilogue stalls the workgroup; profiles/r05_mlp_lab.md).
+  const bool rl_base = lazy_base && drop_keep == nullptr && drop_scale == nullptr && tr_mlp_resid_ln_enabled();
+  const void* xn1_ready = nullptr;         // norm1 of the block about to start, written by the previous block's fused tail
   // a1 + a2: patch embedding, CLS token, position embedding
   static const bool unfused_patch = [] { const char* e = getenv("TR_PATCH_UNFUSED"); return e && atoi(e) != 0; }();   // lab: the three-launch path
   if (!train && !f32 && !unfused_patch && tr_patch_embed_supported(cfg->in_chans, cfg->img_size, cfg->patch, D)) {
@@ -622,12 +630,13 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       TR_TRY(tr_layernorm_bf16_to(x, D, x1, D, static_cast<const uint16_t*>(pending), D, bw->ln1_g, bw->ln1_b, static_cast<uint16_t*>(xn), M, D,
                                   cfg->ln_eps, s));
       x = x1;
-    } else if (!have_xn) {
+    } else if (!have_xn && xn1_ready == nullptr) {
       TR_TRY(op_ln_pending(f32, x, D, pending, pending_attn, D, bw->ln1_g, bw->ln1_b, xn, M, D, cfg->ln_eps, s));
       pending_attn = nullptr;
     }
     TR_REQUIRE(pending_attn == nullptr, TR_ERR_CONFIG, "tr_vit_forward: internal: block %d did not absorb the lazy residual", i);
-    TR_TRY(op_gemm(prec, xn, bw->qkv_w, bw->qkv_b, qkv, nullptr, 0, M, 3 * D, D, TR_EPI_BF16, s));
+    TR_TRY(op_gemm(prec, xn1_ready ? xn1_ready : xn, bw->qkv_w, bw->qkv_b, qkv, nullptr, 0, M, 3 * D, D, TR_EPI_BF16, s));
+    xn1_ready = nullptr;
     // ToMe: log(size) bias on the keys; ATS: key mask as a 1/0 "size" (log 0 = -inf -> exactly zero weight, like
     // masked_fill(-finfo.max) underflowing in the reference's softmax, ats.py:117-120)
     // K-Medoids: the NEXT block's clustering is seeded by the column sums of THIS block's attention (kmedoids.py:240)
@@ -711,7 +720,8 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       TR_TRY(tr_layernorm_bf16_to(x, D, x_alt, D, static_cast<const uint16_t*>(dbuf), D, bw->ln2_g, bw->ln2_b, static_cast<uint16_t*>(xn), B * Nn, D,
                                   cfg->ln_eps, s));
       x = x_alt;
-    } else if (lazy_base && starts_plain(i + 1)) {
+    } else if (lazy_base && starts_plain(i + 1) && !(rl_base && i + 1 < cfg->depth && bw->mlp_pk != nullptr &&
+                                                     tr_mlp_fused_wanted(B * Nn, D, p.Hd, p.mlp_sk_bytes > 0))) {
       TR_TRY(tr_layernorm2_bf16(x, D, nullptr, 0, static_cast<const uint16_t*>(dbuf), D, nullptr, 0, bw->ln2_g, bw->ln2_b,
                                 static_cast<uint16_t*>(xn), B * Nn, D, cfg->ln_eps, s));
       pending_attn = dbuf;
@@ -738,7 +748,14 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       drop_keep += (size_t)M2 * p.Hd;
     }
     dbuf = (pending_attn == dbuf_shared) ? dbuf2 : dbuf_shared;      // the attention residual is still pending: fc2 writes beside it
-    if (fused_mlp)
+    const bool fused_tail = fused_mlp && rl_base && pending_attn == nullptr && i + 1 < cfg->depth && starts_plain(i + 1);
+    if (fused_tail) {
+      const tr_block_weights* nb = &w->blocks[i + 1];
+      TR_TRY(tr_mlp_fused_resid_ln_bf16(static_cast<const uint16_t*>(xn), bw->mlp_pk, bw->fc1_b, bw->fc2_b, x, nb->ln1_g, nb->ln1_b, cfg->ln_eps,
+                                        static_cast<uint16_t*>(hbuf), p.mlp_sk_bytes ? ws + p.off_mlp_sk : nullptr, p.mlp_sk_bytes, M2, D, p.Hd,
+                                        s));
+      xn1_ready = hbuf;
+    } else if (fused_mlp)
       TR_TRY(tr_mlp_fused_bf16(static_cast<const uint16_t*>(xn), bw->mlp_pk, bw->fc1_b, static_cast<uint16_t*>(dbuf),
                                p.mlp_sk_bytes ? ws + p.off_mlp_sk : nullptr, p.mlp_sk_bytes, M2, D, p.Hd, s));
     else
@@ -749,7 +766,7 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
     }
     if (drop_scale != nullptr)      // DropPath on the MLP branch (topk.py:95)
       TR_TRY(tr_rowscale_bf16(static_cast<const uint16_t*>(dbuf), static_cast<uint16_t*>(dbuf), drop_scale + (size_t)(2 * i + 1) * B, B, N, D, s));
-    pending = dbuf;
+    pending = fused_tail ? nullptr : dbuf;
     if (features_out && !train) {      // viz_data["Features"][i] (topk.py:197): x + mlp output, which x itself only absorbs in the next norm
       TR_TRY(tr_residual_snapshot(x, pending, f32 ? 1 : 0, features_out, (size_t)M2 * D, s));
       features_out += (size_t)M2 * D;

@@ -91,5 +91,9 @@ for M in rows:
             live = [i for i in range(64) if int(dd_[i, 0]) != 0]
             print(f"    {name} step lengths:", " ".join(str(int(dd_[live[k + 1], 0] - dd_[live[k], 0])) for k in range(len(live) - 1)))
             print(f"    {name} last recorded step: phases", [int(dd_[live[-1], j + 1] - dd_[live[-1], j]) for j in range(3)])
+        es = buf[M * D + 60 * 4 * 4:M * D + 62 * 4 * 4].view(torch.int64).cpu()
+        if int(es[0]):
+            print("    C epilogue of the last block: table copy", int(es[1] - es[0]), " sum pass", int(es[2] - es[1]), " variance pass", int(es[3] - es[2]),
+                  " reduce + rsqrt", int(es[4] - es[3]), " normalise + stores", int(es[5] - es[4]), "cycles")
 print("ALL OK" if bad == 0 else f"{bad} SHAPES FAIL")
 sys.exit(0 if bad == 0 else 1)
