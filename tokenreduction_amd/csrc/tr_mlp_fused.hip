@@ -7,8 +7,11 @@
 // (evaluated with scalar instead of packed VALU instructions: same operations, same contractions), the hidden rounded to bf16 at the same
 // point.  tests/test_hip_ops.py::test_mlp_fused_* compares them bit for bit, tools/mlp_lab.py --stress screens for races.
 //
-// STATUS (round 5): correct and race-free, but NOT faster than the pair on the model's shapes -- 99 vs 95 us at 32768 rows, 150 vs 151 us at
-// 50432 -- so the executor keeps the pair.  Where the cycles go (in-kernel stamps and ablations of this kernel): profiles/r05_mlp_lab.md.
+// STATUS (round 5): per 32-hidden-unit step as fast as the pair, not faster (the fc1 + GELU wave's instruction stream); with the stream-K
+// schedule (MfSeq below) it ties the pair at 1.5 rounds of blocks and wins beyond (70,001 rows: 176 vs 217-238 us, 938 TFLOP/s), and in the
+// model it saves the hidden activation's round trip: headline forward -2 %.  The executor takes it where tr_mlp_fused_wanted says so.
+// A second instantiation (RL) also finishes the block -- residual add + the next block's norm1 -- and is OFF by default: slower in the
+// model.  Where the cycles go, stamps and ablations of every version: profiles/r05_mlp_lab.md.
 //
 // Structure (one persistent 512-thread workgroup per CU, 128 token rows per block, D = 384):
 //   * Waves 0-3 ("P", one per SIMD) own 32 token rows each and keep their x rows IN REGISTERS as the MFMA B operand (96 VGPRs).
