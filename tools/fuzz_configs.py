@@ -22,6 +22,9 @@ bad = 0
 for it in range(n_cfg):
     fam = families[it % len(families)]
     D = int(rng.choice([128, 256])) if fam in ("dyvit", "sit") else int(rng.choice([128, 192, 256]))
+    fused = it % 4 == 3                      # every fourth configuration at D = 384 with the fused eval Mlp FORCED (any row count: single blocks,
+    if fused:                                # ragged last blocks), alternately with the fused block tail (Mlp + residual + next norm1)
+        D = 384
     depth = int(rng.integers(2, 6))
     nloc = int(rng.integers(1, depth + 1))
     loc = sorted(rng.choice(np.arange(1 if fam == "kmedoids" else 0, depth), size=min(nloc, depth - (1 if fam == "kmedoids" else 0)), replace=False).tolist())
@@ -43,7 +46,10 @@ for it in range(n_cfg):
     case = dict(family=fam, embed_dim=D, depth=depth, num_heads=D // 64, num_classes=12, keep_rate=kr, reduction_loc=loc, batch=B, img_size=img,
                 wseed=1000 + it, xseed=2000 + it, qkv_gain=3.0, heuristic_pattern=pattern, not_contiguous=bool(it % 2), min_radius=min_radius,
                 equal_weight=equal)
-    tag = f"{fam:11s} D{D} depth{depth} loc{loc} kr{kr} B{B} img{img}" + (f" {pattern} nc{int(case['not_contiguous'])} mr{min_radius}" if fam == "heuristic" else "") + (" equal" if equal else "")
+    from tokenreduction_amd import ops as _ops
+    _ops.set_mlp_fused(1 if fused else -1)
+    _ops.set_mlp_resid_ln(fused and it % 8 == 7)
+    tag = f"{fam:11s} D{D}{' fusedMlp' if fused else ''}{'+tail' if fused and it % 8 == 7 else ''} depth{depth} loc{loc} kr{kr} B{B} img{img}" + (f" {pattern} nc{int(case['not_contiguous'])} mr{min_radius}" if fam == "heuristic" else "") + (" equal" if equal else "")
     try:
         args = types.SimpleNamespace(keep_rate=list(kr), reduction_loc=list(loc), viz_mode=True, dyvit_distill=False, k_neighbors=5, equal_weight=equal,
                                      sinkhorn_eps=1.0, cluster_iters=3, heuristic_pattern=pattern, not_contiguous=case["not_contiguous"], min_radius=min_radius)
