@@ -585,6 +585,14 @@ def main():
                 xb = torch.randn(bsz, 3, img, img, generator=torch.Generator().manual_seed(7)).to(dev)
                 o_ips = quick_images_per_s(m2, xb)
                 others[label] = {"images_per_s": round(o_ips, 1), "tokens_per_block": m2._last_tokens}
+                if name.startswith("ats_"):
+                    # the reference's dynamic width (ats.py:77-78: every sampling block shrinks to the batch maximum of unique ids): opt-in,
+                    # plain launches with one read-back per sampling block instead of a hipGraph replay
+                    m2.dynamic_width = True
+                    d_ips = quick_images_per_s(m2, xb)
+                    others[label]["dynamic_width"] = {"images_per_s": round(d_ips, 1), "tokens_per_block": m2._last_tokens,
+                                                      "note": "model.dynamic_width = True: rows = batch max of unique sampled ids, as the "
+                                                              "reference; random-init weights -- a trained model's cdf is peakier (fewer unique ids)"}
                 del m2, xb
             rec["other_configs"] = others
             # drift of the bf16 product path against the SAME executor in the reference's fp32 arithmetic (validation kernels):

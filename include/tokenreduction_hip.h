@@ -286,6 +286,12 @@ int tr_ats_sample(const float* cls_rows, const void* qkv, int qkv_is_f32, const 
                   int32_t* ids, float* new_mask, float* cdf_out, int B, int N, int H, int K, tr_stream_t s);
 int tr_ats_gather(const float* x, const void* ao, int ao_is_f32, const int32_t* ids, float* x_out, void* ao_out, int B, int N,
                   int K, int D, tr_stream_t s);
+/* The reference's dynamic width (ats.py:77-78: pad_sequence pads the unique ids to the BATCH maximum, so the token count after a sampling
+ * block is 1 + max unique ids, not the static bound K).  tr_ats_width: *width (device int32) = max over the images of their valid ids
+ * (row sums of new_mask [B,K]); tr_ats_narrow: the first Kw columns of ids / new_mask as contiguous [B,Kw] arrays, the form tr_ats_gather
+ * and the next block's key mask take.  Used by tr_vit_forward when tr_vit_config.ats_dynamic is set. */
+int tr_ats_width(const float* new_mask, int32_t* width, int B, int K, tr_stream_t s);
+int tr_ats_narrow(const int32_t* ids, const float* new_mask, int32_t* ids_out, float* mask_out, int B, int K, int Kw, tr_stream_t s);
 
 /* a13 bipartite_soft_matching (tome.py:230-277, class_token=True) on metric = k.mean(1) (tome.py:58), read straight from the
  * K third of qkv ([B*N, 3*H*64]; bf16, or fp32 when qkv_is_f32).  Tokens at even positions form set A (CLS = A[0], never
@@ -512,6 +518,10 @@ typedef struct {
   float sinkhorn_eps;         /* Sinkhorn temperature (args.sinkhorn_eps, train.py:229 default 1.0) */
   int kmed_init[TR_MAX_DEPTH];/* K-Medoids args.equal_weight: per block, 1 + the first medoid id (the host's np.random.choice draw,
                                  kmedoids.py:45); 0 = the attention-weighted branch */
+  int ats_dynamic;            /* ATS, eval forward only: 1 = every sampling block shrinks to the batch maximum of unique ids like the reference
+                                 (ats.py:77-78) instead of running the static bound keep[blk] with masked rows.  Same valid tokens and logits (to
+                                 the attention kernels' summation order); fewer rows downstream.  tr_vit_forward then reads one int back per
+                                 sampling block: it SYNCHRONISES the stream there and cannot be captured in a hipGraph.  0 = static (default). */
 } tr_vit_config;
 
 /* Bytes of workspace tr_vit_forward needs for batch B (0 on invalid config). */

@@ -234,6 +234,44 @@ def test_fused_mlp_executor_is_bit_identical(name):
         ops.set_mlp_resid_ln(prev_rl)
 
 
+@pytest.mark.parametrize("name", ["ats_micro", "ats_small_kr07", "ats_small_kr05"])
+def test_ats_dynamic_width(name):
+    """model.dynamic_width (opt-in): after every sampling block the executor keeps the BATCH MAXIMUM of unique ids like the reference
+    (ats.py:77-78) instead of the static bound.  The rows it drops are the masked padding rows of the static run, so: the token counts are
+    1 + the Kept_Tokens widths, never above the static counts; the sampled ids are the static run's (later stages: the attention sums run over
+    fewer zero terms, so a near-tie may flip -- none does on these fixtures); the logits agree to the bf16 executor's summation-order noise;
+    and the switch is eval-only and reversible."""
+    from tokenreduction_amd import ops
+    case = GOLDEN_CASES[name]
+    model, _, _ = build_model(case)
+    x = make_images(case["batch"], case.get("img_size", 224), case["xseed"]).cuda()
+    out_s = model(x)
+    logits_s, viz_s = (out_s[0], out_s[1]) if isinstance(out_s, tuple) else (out_s, None)
+    tok_s = list(model._last_tokens)
+    model.dynamic_width = True
+    out_d = model(x)
+    logits_d, viz_d = (out_d[0], out_d[1]) if isinstance(out_d, tuple) else (out_d, None)
+    tok_d = list(model._last_tokens)
+    assert all(d <= s_ for d, s_ in zip(tok_d, tok_s)) and tok_d != tok_s, (tok_d, tok_s)
+    for blk, kept in viz_s["Kept_Tokens"].items():
+        np.testing.assert_array_equal(viz_d["Kept_Tokens"][blk], kept)
+        assert tok_d[blk] == 1 + kept.shape[1], (blk, tok_d[blk], kept.shape)
+    rel = float((logits_d - logits_s).norm() / logits_s.norm())
+    assert torch.isfinite(logits_d).all() and rel < 5e-3, rel
+    model.dynamic_width = False
+    again = model(x)
+    assert torch.equal((again[0] if isinstance(again, tuple) else again), logits_s) and list(model._last_tokens) == tok_s
+    # the two ops behind it
+    m = torch.zeros(5, 9, device="cuda")
+    m[:, 0] = 1
+    m[2, 1:6] = 1
+    m[4, 1:3] = 1
+    assert ops.ats_width(m) == 6
+    ids = torch.arange(45, dtype=torch.int32, device="cuda").view(5, 9)
+    i2, m2 = ops.ats_narrow(ids, m, 6)
+    assert torch.equal(i2, ids[:, :6].contiguous()) and torch.equal(m2, m[:, :6].contiguous())
+
+
 def _ats_parity(name, case, g, model, params, cfg, x, logits, viz, info):
     """ATS leg: executor == stepwise ids; the sampling op pinned bit-exact on the device's own cdf; teacher-forced logits."""
     from tests._params import assert_valid_sampling

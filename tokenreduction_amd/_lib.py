@@ -42,7 +42,7 @@ class TrVitConfig(C.Structure):
     _fields_ = [("family", _i), ("img_size", _i), ("patch", _i), ("in_chans", _i), ("embed_dim", _i),
                 ("depth", _i), ("num_heads", _i), ("mlp_hidden", _i), ("num_classes", _i), ("ln_eps", _f),
                 ("keep", _i * TR_MAX_DEPTH), ("precision", _i), ("knn_k", _i), ("cluster_iters", _i), ("sinkhorn_eps", _f),
-                ("kmed_init", _i * TR_MAX_DEPTH)]
+                ("kmed_init", _i * TR_MAX_DEPTH), ("ats_dynamic", _i)]
 
 
 class TrLinearGrad(C.Structure):     # tr_linear_grad: one layer of tr_linear_bwd_group
@@ -105,6 +105,8 @@ SIGNATURES = {
     "tr_weighted_merge": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tr_ats_sample": (_i, [_vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tr_ats_gather": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "tr_ats_width": (_i, [_vp, _vp, _i, _i, _vp]),
+    "tr_ats_narrow": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "tr_dpcknn_workspace_floats": (_sz, [_i, _i]),
     "tr_kmedoids": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "tr_kmedoids_equal": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

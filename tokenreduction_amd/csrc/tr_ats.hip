@@ -142,6 +142,25 @@ __global__ __launch_bounds__(256) void ats_sample_kernel(const float* __restrict
   }
 }
 
+// Dynamic width (ats.py:77-78: pad_sequence pads the unique ids to the BATCH maximum): width = 1 + max over the images of their unique sampled ids
+// = max row sum of new_mask; one thread per image, atomicMax into a zeroed word.
+__global__ __launch_bounds__(256) void ats_width_kernel(const float* __restrict__ new_mask, int32_t* __restrict__ width, int B, int K) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= B) return;
+  int c = 0;
+  for (int t = 0; t < K; ++t) c += new_mask[(size_t)b * K + t] != 0.f;
+  atomicMax(width, c);
+}
+// the first Kw columns of ids / new_mask [B,K] as contiguous [B,Kw] arrays
+__global__ __launch_bounds__(256) void ats_narrow_kernel(const int32_t* __restrict__ ids, const float* __restrict__ mask,
+                                                         int32_t* __restrict__ ids_out, float* __restrict__ mask_out, int B, int K, int Kw) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * Kw) return;
+  const int b = i / Kw, t = i - b * Kw;
+  ids_out[i] = ids[(size_t)b * K + t];
+  mask_out[i] = mask[(size_t)b * K + t];
+}
+
 // one wave per output row
 template <bool F32>
 __global__ __launch_bounds__(256) void ats_gather_kernel(const float* __restrict__ x, const void* __restrict__ ao,
@@ -223,5 +242,27 @@ extern "C" int tr_ats_gather(const float* x, const void* ao, int ao_is_f32, cons
   if (ao_is_f32) hipLaunchKernelGGL(ats_gather_kernel<true>, dim3(nblocks), dim3(256), 0, st, x, ao, ids, x_out, ao_out, B, N, K, D);
   else hipLaunchKernelGGL(ats_gather_kernel<false>, dim3(nblocks), dim3(256), 0, st, x, ao, ids, x_out, ao_out, B, N, K, D);
   TR_CHECK_LAUNCH("tr_ats_gather");
+  return TR_OK;
+}
+
+extern "C" int tr_ats_width(const float* new_mask, int32_t* width, int B, int K, tr_stream_t s) {
+  TR_REQUIRE(new_mask && width, TR_ERR_NULL, "tr_ats_width: null pointer");
+  TR_REQUIRE(B > 0 && K >= 1, TR_ERR_SHAPE, "tr_ats_width: bad shape B=%d K=%d", B, K);
+  hipStream_t st = static_cast<hipStream_t>(s);
+  hipError_t e = hipMemsetAsync(width, 0, sizeof(int32_t), st);
+  TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_ats_width: hipMemsetAsync: %s", hipGetErrorString(e));
+  hipLaunchKernelGGL(ats_width_kernel, dim3((B + 255) / 256), dim3(256), 0, st, new_mask, width, B, K);
+  TR_CHECK_LAUNCH("tr_ats_width");
+  return TR_OK;
+}
+
+extern "C" int tr_ats_narrow(const int32_t* ids, const float* new_mask, int32_t* ids_out, float* mask_out, int B, int K, int Kw, tr_stream_t s) {
+  TR_REQUIRE(ids && new_mask && ids_out && mask_out, TR_ERR_NULL, "tr_ats_narrow: null pointer");
+  TR_REQUIRE(B > 0 && K >= 1 && Kw >= 1 && Kw <= K, TR_ERR_SHAPE, "tr_ats_narrow: bad shape B=%d K=%d Kw=%d", B, K, Kw);
+  TR_REQUIRE(static_cast<const void*>(ids) != static_cast<const void*>(ids_out) && new_mask != mask_out, TR_ERR_SHAPE,
+             "tr_ats_narrow: needs distinct outputs");
+  hipLaunchKernelGGL(ats_narrow_kernel, dim3((B * Kw + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(s), ids, new_mask, ids_out, mask_out, B, K,
+                     Kw);
+  TR_CHECK_LAUNCH("tr_ats_narrow");
   return TR_OK;
 }

@@ -129,7 +129,7 @@ using trplan::align_up;
 
 struct Plan {
   int P, N0, D, H, Hd, C, kcols;
-  size_t off_x0, off_x1, off_xn, off_qkv, off_ao, off_h, off_d, off_d2, off_cols, off_cls, off_scores, off_idx, off_compl, off_xcls, off_size0, off_size1, off_cluster, off_soft, off_mlp_sk, mlp_sk_bytes, total;
+  size_t off_x0, off_x1, off_xn, off_qkv, off_ao, off_h, off_d, off_d2, off_cols, off_cls, off_scores, off_idx, off_compl, off_xcls, off_size0, off_size1, off_cluster, off_soft, off_mlp_sk, mlp_sk_bytes, off_misc, total;
 };
 
 bool make_plan(const tr_vit_config* c, int B, Plan* p) {
@@ -182,6 +182,8 @@ bool make_plan(const tr_vit_config* c, int B, Plan* p) {
   p->off_mlp_sk = o;
   p->mlp_sk_bytes = c->precision == TR_PREC_BF16 ? tr_mlp_fused_scratch_bytes(p->D, p->Hd) : 0;
   o += align_up(p->mlp_sk_bytes);
+  p->off_misc = o;          // device words read back by the host (ATS dynamic width)
+  o += align_up(256);
   p->total = o;
   return true;
 }
@@ -651,7 +653,8 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
     if (Ks > 0) {
       // a16-a18: sample token ids on the CLS attention x |v|, keep those rows of x and of attn @ v
       const tr_stage_weights* sw = &w->stage[i];
-      TR_REQUIRE(Ks >= 2 && Ks <= N, TR_ERR_CONFIG, "tr_vit_forward: block %d ATS sample_count %d out of range for %d tokens", i, Ks, N);
+      const bool dyn = cfg->ats_dynamic != 0 && !train;
+      TR_REQUIRE(Ks >= 2 && (Ks <= N || dyn), TR_ERR_CONFIG, "tr_vit_forward: block %d ATS sample_count %d out of range for %d tokens", i, Ks, N);
       TR_REQUIRE(sw->w3 && sw->n_pad >= 1, TR_ERR_NULL, "tr_vit_forward: block %d has no ATS sample grid (tr_vit_weights.stage)", i);
       int32_t* ids = kept_idx ? kept_idx + (size_t)i * B * p.N0 : idx_ws;
       float* mask_next = (size_cur == size_a) ? size_b : size_a;
@@ -659,18 +662,36 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
         ids = reinterpret_cast<int32_t*>(tape + tp->blk[i].idx);
         mask_next = reinterpret_cast<float*>(tape + tp->blk[i].size);
       }
-      TR_TRY(tr_ats_sample(cls_rows, qkv, f32 ? 1 : 0, size_cur, sw->w3, sw->n_pad, ids, mask_next, nullptr, B, N, H, Ks, s));
+      int Kg = Ks;             // rows the block keeps
+      if (dyn) {
+        // ats.py:77-78: the reference pads the unique ids to the batch maximum -- sample at the static bound (ids [B,Ks] stay the
+        // Kept_Tokens record), read that maximum back (one int: the stream is synchronised HERE), continue on the first Kg columns
+        float* mask_full = scores;                                   // [B,Ks]; the score buffer is not used by this family
+        int32_t* width_dev = reinterpret_cast<int32_t*>(ws + p.off_misc);
+        TR_TRY(tr_ats_sample(cls_rows, qkv, f32 ? 1 : 0, size_cur, sw->w3, sw->n_pad, ids, mask_full, nullptr, B, N, H, Ks, s));
+        TR_TRY(tr_ats_width(mask_full, width_dev, B, Ks, s));
+        int32_t width = 0;
+        hipError_t e = hipMemcpyAsync(&width, width_dev, sizeof(width), hipMemcpyDeviceToHost, static_cast<hipStream_t>(s));
+        if (e == hipSuccess) e = hipStreamSynchronize(static_cast<hipStream_t>(s));
+        TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_vit_forward: ATS dynamic width read-back at block %d: %s (not capturable in a hipGraph)", i,
+                   hipGetErrorString(e));
+        Kg = width < 2 ? 2 : (width > Ks ? Ks : width);              // CLS + at least one column (an all-masked batch cannot occur: >= 1 sample)
+        TR_TRY(tr_ats_narrow(ids, mask_full, compl_ws, mask_next, B, Ks, Kg, s));
+        ids = compl_ws;
+      } else {
+        TR_TRY(tr_ats_sample(cls_rows, qkv, f32 ? 1 : 0, size_cur, sw->w3, sw->n_pad, ids, mask_next, nullptr, B, N, H, Ks, s));
+      }
       if (train) {          // sampled rows of the stream -> x0 slot, of attn @ v -> ao slot (proj's operand); norm1's input stays in x1
         float* xg = reinterpret_cast<float*>(tape + tp->blk[i].x0);
         xn = tape + tp->blk[i].ao;
         TR_TRY(tr_ats_gather(x, ao, 0, ids, xg, xn, B, N, Ks, D, s));
         x = xg;
       } else {
-        TR_TRY(tr_ats_gather(x, ao, f32 ? 1 : 0, ids, x_alt, xn, B, N, Ks, D, s));
+        TR_TRY(tr_ats_gather(x, ao, f32 ? 1 : 0, ids, x_alt, xn, B, N, Kg, D, s));
         float* t = x; x = x_alt; x_alt = t;
       }
       size_cur = mask_next;
-      Nn = Ks;
+      Nn = Kg;
       TR_TRY(op_gemm(prec, xn, bw->proj_w, bw->proj_b, dbuf, nullptr, 0, B * Nn, D, D, TR_EPI_BF16, s));
     } else {
       TR_TRY(op_gemm(prec, ao, bw->proj_w, bw->proj_b, dbuf, nullptr, 0, M, D, D, TR_EPI_BF16, s));

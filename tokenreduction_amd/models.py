@@ -484,7 +484,8 @@ class VisionTransformer(nn.Module):
             return list(tokens)
 
         with torch.cuda.device(x.device):
-            if self.use_graph and not ws.get("graph_off") and not torch.cuda.is_current_stream_capturing():
+            if (self.use_graph and not ws.get("graph_off") and not torch.cuda.is_current_stream_capturing()
+                    and not getattr(self, "dynamic_width", False)):      # (ATS dynamic width: the executor reads a token count back mid-forward)
                 # The forward is a fixed sequence of ~90-130 dependent launches with no host decision in between: replay it as one
                 # hipGraph (captured once per batch size / input buffer / output set; the workspace and every output are static
                 # buffers).  Re-packing the weights or a new batch size drops the workspace and its graphs with it.
@@ -1049,10 +1050,19 @@ class ATSVisionTransformer(VisionTransformer):
     """models/ats.py:166-271: blocks in reduction_loc sample tokens by inverse-transform sampling on the CLS attention weighted
     by the value norms.  The reference's token count after such a block is data dependent (batch maximum of unique samples,
     ats.py:78); here it is the static bound K = sample_count, the surplus rows being masked keys (zero attention weight), which
-    leaves every valid token and the logits unchanged.  Kept_Tokens is trimmed to the reference's batch-maximum width."""
+    leaves every valid token and the logits unchanged.  Kept_Tokens is trimmed to the reference's batch-maximum width.
+
+    `model.dynamic_width = True` (eval only, opt-in) makes the executor do what the reference does: after every sampling block it reads the
+    batch maximum of unique ids back (one int, a stream synchronisation; no hipGraph replay) and runs the rest of the network on that many
+    tokens -- fewer rows in every later block, the same valid tokens (tr_vit_config.ats_dynamic)."""
     _family = _lib.TR_FAMILY_ATS
 
     _features_every_block = False
+    dynamic_width = False
+
+    def _per_forward_config(self, cfg):
+        super()._per_forward_config(cfg)
+        cfg.ats_dynamic = 1 if (self.dynamic_width and not self.training) else 0
 
     def __init__(self, *a, args=None, **kw):
         super().__init__(*a, args=args, **kw)

@@ -289,6 +289,24 @@ def attention_f32(qkv: torch.Tensor, B: int, N: int, H: int, want_cls: bool = Fa
 
 
 # ---------------------------------------------------------------------------------------- ToMe (models/tome.py)
+def ats_width(new_mask: torch.Tensor) -> int:
+    """ats.py:77-78: the token count the reference keeps after a sampling block = the batch maximum of valid ids (row sums of new_mask)."""
+    B, K = new_mask.shape
+    w = torch.zeros(1, dtype=torch.int32, device=new_mask.device)
+    _lib.check(_lib.load().tr_ats_width(_dev(new_mask, torch.float32, "new_mask"), w.data_ptr(), B, K, _stream(new_mask)), "tr_ats_width")
+    return int(w.item())
+
+
+def ats_narrow(ids: torch.Tensor, new_mask: torch.Tensor, Kw: int):
+    """The first Kw columns of ids / new_mask [B,K] as contiguous [B,Kw] tensors (what ats_gather and the next block's key mask take)."""
+    B, K = ids.shape
+    ids_out = torch.empty(B, Kw, dtype=torch.int32, device=ids.device)
+    mask_out = torch.empty(B, Kw, dtype=torch.float32, device=ids.device)
+    _lib.check(_lib.load().tr_ats_narrow(_dev(ids, torch.int32, "ids"), _dev(new_mask, torch.float32, "new_mask"), ids_out.data_ptr(),
+                                         mask_out.data_ptr(), B, K, int(Kw), _stream(ids)), "tr_ats_narrow")
+    return ids_out, mask_out
+
+
 def tome_match(qkv: torch.Tensor, B: int, N: int, H: int, r: int):
     """bipartite_soft_matching (tome.py:230-277) on metric = k.mean(1): qkv bf16|fp32 [B*N, 3*H*64] ->
     (unm_idx [B, ceil(N/2)-r], src_idx [B,r], dst_idx [B,r]) int32."""
