@@ -83,13 +83,18 @@ def algorithmic(kernel, B, D, H, st, wl=""):
         return mean(lambda n, k: B * (n - 1) * (k - 1) * 8, st)
     if K.startswith("rownorm_kernel"):
         return mean(lambda n, k: B * (n - 1) * D * (4 + 4 + 2), st)
+    if K.startswith("mlp_fused_kernel") and wl == "headline":     # fused eval Mlp: LN2 output in, fc2 output out (bf16), the packed weights once;
+        # launched for the blocks of the first three token counts (nine launches: 197 x 3, 138 x 3, 97 x 3 tokens per image)
+        ms = [B * 197, B * 138, B * 97]
+        return sum(m * D * 2 * 2 + 2 * D * 4 * D * 2 for m in ms) / len(ms)
     return None
 
 
 def main():
     tag = sys.argv[1]
-    print("| workload | kernel | µs | algorithmic MB | HBM MB (fetch + write) | ratio | GB/s |")
-    print("|---|---|---|---|---|---|---|")
+    sq_tag = sys.argv[2] if len(sys.argv) > 2 else None      # profiles/<sq_tag>_pmc_sq_<workload>.json (tools/prof_r05_sq.sh): busy-unit columns
+    print("| workload | kernel | µs | algorithmic MB | HBM MB (fetch + write) | ratio | GB/s |" + (" MFMA busy | LDS busy | VALU issue | waiting on an instruction |" if sq_tag else ""))
+    print("|---|---|---|---|---|---|---|" + ("---|---|---|---|" if sq_tag else ""))
     over = []
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{tag}_*_pmc_traffic.json"))):
         w = os.path.basename(f)[len(tag) + 1:-len("_pmc_traffic.json")]
@@ -105,8 +110,14 @@ def main():
             m = v["hbm_bytes_per_launch"]
             r = m / a
             name = k.split("(")[0]
+            sq = ""
+            if sq_tag:
+                sf = os.path.join(ROOT, "profiles", f"{sq_tag}_pmc_sq_{w}.json")
+                rec = json.load(open(sf)).get(name) if os.path.exists(sf) else None
+                sq = (f" {100 * rec['mfma_busy_frac']:.0f} % | {100 * rec['lds_busy_frac']:.0f} % | {100 * rec['valu_inst_frac']:.0f} % | "
+                      f"{100 * rec['wait_inst_frac']:.0f} % |") if rec else " | | | |"
             print(f"| {w} | `{name}` | {v['avg_us']:.1f} | {a / 1e6:.1f} | {m / 1e6:.1f} ({v['fetch_bytes_per_launch'] / 1e6:.1f} + "
-                  f"{v['write_bytes_per_launch'] / 1e6:.1f}) | {r:.2f} | {v['hbm_gbps']:.0f} |")
+                  f"{v['write_bytes_per_launch'] / 1e6:.1f}) | {r:.2f} | {v['hbm_gbps']:.0f} |" + sq)
             if r > 1.5:
                 over.append((w, name, r))
     print()
