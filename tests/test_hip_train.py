@@ -159,6 +159,39 @@ def test_grad_accumulation_and_zero_grad():
         assert torch.equal(p.grad, g1[n]), n
 
 
+@pytest.mark.parametrize("name", ["deit_micro", "topk_micro", "evit_micro", "tome_micro", "dpcknn_micro", "ats_micro", "kmedoids_micro", "heuristic_micro_l2",
+                                  "dyvit_micro_train", "sinkhorn_micro_384", "ats_base_kr05"])
+def test_a_fresh_backward_overwrites_every_gradient_slot(name):
+    """With no gradient alive the backward passes accumulate = 0 and does NOT clear the flat gradient buffer (training.py): correctness then
+    rests on tr_vit_backward writing every slot of every parameter exactly once per pass.  Enforced here: the buffer is poisoned
+    with NaN before the backward of a fresh step; afterwards every parameter's view must be finite and equal to the gradients of an
+    unpoisoned step, and nothing but the alignment padding between the slices may still hold the poison."""
+    case = GOLDEN_CASES[name]
+    model, *_ = _train_step(case)
+    want = {n: p.grad.clone() for n, p in model.named_parameters()}
+    st = model._train_state()
+    model.zero_grad(set_to_none=True)
+    x = make_images(case["batch"], case.get("img_size", 224), case["xseed"]).cuda()
+    out = model(x)
+    if case["family"] == "dyvit":
+        from tests._params import dyvit_train_loss
+        loss = dyvit_train_loss(out, grad_labels(case).cuda(), case)
+    else:
+        loss = torch.nn.functional.cross_entropy(out, grad_labels(case).cuda())
+    st.flat.fill_(float("nan"))
+    loss.backward()
+    torch.cuda.synchronize()
+    bad = [n for n, p in model.named_parameters() if p.grad is None or not bool(torch.isfinite(p.grad).all())]
+    assert not bad, f"gradient slots the backward did not write: {bad[:6]}"
+    # what may stay poisoned: the alignment padding between the parameter slices, which no kernel reads (the optimizer works through its slot
+    # table, the data-parallel mean reduces it along but nothing consumes it) -- at most as many elements as lie outside every view (some families keep derived gradients there)
+    covered = sum(v.numel() for v in st.views.values())
+    assert int((~torch.isfinite(st.flat)).sum()) <= st.flat.numel() - covered, "an element inside a parameter view was not written"
+    if case["family"] not in ("dyvit", "dpcknn"):          # (these two draw fresh noise per training forward: Gumbel / density tie-break)
+        for n, p in model.named_parameters():
+            assert torch.equal(p.grad, want[n]), n
+
+
 def test_backward_of_an_overwritten_tape_raises():
     """The tape belongs to the model, not to the autograd node: after a second train-mode forward the first one's activations are
     gone, and its backward must say so instead of writing gradients of the wrong forward (round-2 advisor finding)."""
