@@ -99,8 +99,11 @@ class VisionTransformer(nn.Module):
                  act_layer=None, weight_init='', args=None):
         super().__init__()
         if distilled:
-            # the reference's reduction forwards only ever concatenate cls_token
-            raise NotImplementedError("distilled (dist_token) models are not on the hot path")
+            # the reference's forwards only ever concatenate cls_token -- deit_viz.py:186-189 adds the [1, P + 2, D] position
+            # embedding of a distilled model to P + 1 tokens (a broadcast error at the first forward), and head_dist is only created by
+            # reset_classifier (deit_viz.py:178-181): a distilled model cannot run in the reference either
+            raise NotImplementedError("distilled (dist_token) models are not on the hot path: the reference's own forward fails for them "
+                                      "(deit_viz.py:186-189 adds a [1, P + 2, D] position embedding to P + 1 tokens)")
         if representation_size:
             raise NotImplementedError("representation_size / pre_logits is not used by any registered factory")
         if not qkv_bias:
