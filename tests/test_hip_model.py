@@ -234,6 +234,46 @@ def test_fused_mlp_executor_is_bit_identical(name):
         ops.set_mlp_resid_ln(prev_rl)
 
 
+def test_fused_mlp_follows_reloaded_weights():
+    """The packed Mlp copies (tr_mlp_pack_bf16) are derived state: after load_state_dict on a model that has already run, after an in-place edit
+    announced by weights_changed(), and in a deep copy (harness.ModelEma) the fused launch must compute with the CURRENT weights -- each time
+    equal, bit for bit, to the two-GEMM form on the same weights."""
+    import copy
+    from tokenreduction_amd import ops
+    case = GOLDEN_CASES["topk_small_kr07"]
+    model, params, _ = build_model(case)
+    model.viz_mode = False
+    x = make_images(5, 224, 3).cuda()
+    prev = ops.set_mlp_fused(1)
+    try:
+        def both(m):
+            ops.set_mlp_fused(1)
+            m._ws = {}
+            a = m(x).clone()
+            ops.set_mlp_fused(0)
+            m._ws = {}
+            b = m(x).clone()
+            ops.set_mlp_fused(1)
+            return a, b
+        a0, b0 = both(model)
+        assert torch.equal(a0, b0)
+        other = {k: (v + 0.01 * torch.randn(v.shape, generator=torch.Generator().manual_seed(9)).to(v.dtype) if v.is_floating_point() and "mlp" in k else v)
+                 for k, v in params.items()}
+        model.load_state_dict(other, strict=True)
+        a1, b1 = both(model)
+        assert torch.equal(a1, b1) and not torch.equal(a1, a0), "the fused launch kept the old Mlp weights after load_state_dict"
+        with torch.no_grad():
+            model.blocks[0].mlp.fc2.weight.mul_(1.5)
+        model.weights_changed()
+        a2, b2 = both(model)
+        assert torch.equal(a2, b2) and not torch.equal(a2, a1), "the fused launch kept the old Mlp weights after weights_changed()"
+        twin = copy.deepcopy(model)
+        a3, b3 = both(twin)
+        assert torch.equal(a3, b3) and torch.equal(a3, a2), "a deep copy does not compute with its own packed Mlp weights"
+    finally:
+        ops.set_mlp_fused(prev)
+
+
 @pytest.mark.parametrize("name", ["ats_micro", "ats_small_kr07", "ats_small_kr05"])
 def test_ats_dynamic_width(name):
     """model.dynamic_width (opt-in): after every sampling block the executor keeps the BATCH MAXIMUM of unique ids like the reference
