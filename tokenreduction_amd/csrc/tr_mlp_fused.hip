@@ -256,15 +256,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pr = wave & 3;                                   // wave pair = 32-row slice of the block
-#ifdef MF_XCD_RANGES
-  // lab: consecutive stream-K ranges on ONE XCD (workgroup w runs on XCD w % 8): range index = (w % 8) * (G / 8) + w / 8, so that a hand-over
-  // stays behind one L2 except at seven XCD boundaries.  Measured (tools/lab/mlp_xcd_ab.sh): no gain -- 156.5-159.5 vs 154.2-158.2 us at 50,432
-  // rows, 181 vs 177-178.5 at 70,001: the write-through stores and sc1 loads of the hand-over go to memory either way
-  const int G = gridDim.x;
-  const int bid = (G % 8 == 0 && G > 8) ? ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
-#else
   const int G = gridDim.x, bid = blockIdx.x;
-#endif
   const int nblk = (M + MF_ROWS - 1) / MF_ROWS;
   if (bid >= nblk) return;
   MfSeq q;
