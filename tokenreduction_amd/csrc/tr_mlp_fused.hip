@@ -256,7 +256,15 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int pr = wave & 3;                                   // wave pair = 32-row slice of the block
+#ifdef MF_XCD_RANGES
+  // lab: consecutive stream-K ranges on ONE XCD (workgroup w runs on XCD w % 8): range index = (w % 8) * (G / 8) + w / 8, so that a hand-over
+  // stays behind one L2 except at seven XCD boundaries.  Measured (tools/lab/mlp_xcd_ab.sh): no gain -- 156.5-159.5 vs 154.2-158.2 us at 50,432
+  // rows, 181 vs 177-178.5 at 70,001: the write-through stores and sc1 loads of the hand-over go to memory either way
+  const int G = gridDim.x;
+  const int bid = (G % 8 == 0 && G > 8) ? ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+#else
   const int G = gridDim.x, bid = blockIdx.x;
+#endif
   const int nblk = (M + MF_ROWS - 1) / MF_ROWS;
   if (bid >= nblk) return;
   MfSeq q;
@@ -836,11 +844,15 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
       }
       if (load_next) {
         // the previous workgroup's four C waves have published their parts (it ran that segment first: normally long ago); every wave that
-        // reads polls for itself; bounded spin
-        for (int spin = 0; spin < (1 << 22); ++spin) {
-          if (__hip_atomic_load(sk_cnt_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 4u) break;
+        // reads polls for itself.  The predecessor was dispatched BEFORE this workgroup and publishes after its own first segment without
+        // waiting for anybody, so the wait is bounded by dispatch skew; the spin is bounded all the same (seconds), and a poll that runs out
+        // TRAPS -- the launch fails loudly instead of continuing on an accumulator that was never published
+        bool published = false;
+        for (int spin = 0; spin < (1 << 24); ++spin) {
+          if (__hip_atomic_load(sk_cnt_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 4u) { published = true; break; }
           __builtin_amdgcn_s_sleep(8);
         }
+        if (!published) __builtin_trap();
         asm volatile("" ::: "memory");
       }
       if (!RL && epi) { stage(0, 0); read_back(lnA); }
