@@ -40,6 +40,8 @@ def algorithmic(kernel, B, D, H, st, wl=""):
             return None                          # (the clustering families use it as a plain top-K over one score row per image)
         return mean(lambda n, k: B * (4 * H * n + 4 * (n - 1)), st)
     if K.startswith("gather_layernorm_kernel"):  # kept rows: x fp32 in + bf16 delta in, x fp32 out + bf16 y out
+        if wl.startswith("evit"):                # EViT also READS the rows it drops (their weighted mean is the fused token, evit.py:117-124)
+            return mean(lambda n, k: B * (n * D * 6 + k * D * 6), st)
         return mean(lambda n, k: B * k * D * 12, st)
     if K.startswith("ats_sample_kernel"):        # CLS rows + the V third of qkv (value norms, ats.py:60-66) -> ids and masks
         return mean(lambda n, k: B * (4 * H * n + 2 * n * H * 64 + 8 * k), st)
