@@ -2,6 +2,7 @@
 """Headline benchmark: images/s of the DeiT-S Top-K (keep_rate 0.7, reduction_loc 3,6,9) forward pass on MI355X.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W        (self-launching: the parent starts the N ranks below as child processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -416,9 +417,32 @@ def headline_record(a, world, headline, eager_ms, note=None):
         "model_tflops": round(ips * gflop / 1e3, 1),
         "model_mfma_frac": round(ips * gflop / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
     }
+    if headline.get("dp"):
+        rec["dp"] = headline["dp"]
     if note:
         rec["note"] = note
     return rec
+
+
+def self_launch(nproc, argv):
+    """Parent of an N-rank run started as plain `python bench.py --gpus N`: one child (torch.distributed.run, which forks one rank per GPU)
+    on a free local port; stdout is passed through line by line (rank 0's JSON line is the last line), the child's return code is ours.
+    The parent makes no HIP call: `import torch` alone does not initialise the device."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes fails without it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
 
 
 def main():
@@ -433,10 +457,17 @@ def main():
                     help="CPU-only check of the multi-process harness (gloo, no model): each rank's step sleeps 10 ms x (rank+1)")
     a = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: this process becomes the PARENT -- it never touches the device -- and starts the N
+        # ranks as fresh children through torch.distributed.run (a child process, never an exec: a process that has initialised the GPU must
+        # not be replaced), relays rank 0's JSON line and the launcher's exit code.  train.py:405-407 / utils.py:216-238 expect the same
+        # env-variable rendezvous.
+        sys.exit(self_launch(a.gpus, sys.argv[1:]))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: run `python bench.py --gpus {a.gpus}` (self-launching) or torch.distributed.run"
     dist = None
     if world > 1 or a.force_dist:
         import torch.distributed as dist
@@ -445,6 +476,8 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
     if a.selftest_gloo:
+        if os.environ.get("TR_BENCH_SELFTEST_FAIL_RANK") == str(rank):      # test hook: a rank that dies must fail the whole run
+            sys.exit(7)
         if dist is not None:
             dist.init_process_group("gloo")
         el = timed_steps(lambda: time.sleep(0.01 * (rank + 1)), a.steps, a.warmup, dist, lambda: None, torch.device("cpu"))
@@ -490,6 +523,13 @@ def main():
     # prints the headline without them and ends the process if a collective hangs (the legs have only ever run at N = 1 on RCCL).
     finetune = None
     headline = {"el": el, "tokens": list(model._last_tokens)}
+    if dist is not None:
+        # what the process group itself reports (not the command line): rank count, backend, and the device every rank ran on
+        me = torch.tensor([rank, torch.cuda.current_device()], device=dev, dtype=torch.int32)
+        seen = [torch.zeros_like(me) for _ in range(dist.get_world_size())]
+        dist.all_gather(seen, me)
+        headline["dp"] = {"world": dist.get_world_size(), "backend": dist.get_backend(),
+                          "cuda_device_by_rank": {str(int(v[0])): int(v[1]) for v in seen}}
     if not a.no_extra:
         import threading
         done = threading.Event()

@@ -40,3 +40,27 @@ def test_two_ranks_gloo_max_over_ranks_and_aggregate():
 def test_single_process_selftest():
     r = _run(1, steps=3)
     assert r["n_gpus"] == 1 and 9.0 <= r["ms_per_step"] <= 40.0
+
+
+def test_bench_launches_its_own_ranks_when_started_without_a_launcher():
+    """`python bench.py --gpus 2` -- the N = 1 command with another number, no torchrun on the command line: the parent process starts
+    the two ranks itself (children through torch.distributed.run), relays rank 0's line and the exit code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--selftest-gloo"],
+                         capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 4 and 19.0 <= r["ms_per_step"] <= 60.0, r
+
+
+def test_self_launch_relays_a_failing_rank_as_a_non_zero_exit():
+    """A rank that dies (test hook: rank 1 exits 7 before the rendezvous) ends the launcher non-zero, and the parent relays that."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(OMP_NUM_THREADS="1", TR_BENCH_SELFTEST_FAIL_RANK="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--selftest-gloo", "--steps", "2"],
+                         capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")], out.stdout

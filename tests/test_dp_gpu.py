@@ -77,21 +77,25 @@ def test_two_ranks_average_their_hip_gradients(tmp_path, case, algo, comm):
 
 @pytest.mark.gpu
 def test_bench_runs_its_two_rank_path_on_one_gpu(tmp_path):
-    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one rank per process) with both ranks on the box's one GPU
+    """`python bench.py --gpus 2` (self-launching; the watchdog test below uses the driver's torch.distributed.run form) with both ranks on the box's one GPU
     (TR_BENCH_SHARE_GPU=1: gloo collectives): the headline line and all three data-parallel fine-tune legs must come out."""
     import json
     import torch
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", TR_BENCH_SHARE_GPU="1", TR_BENCH_FINETUNE_STEPS="2")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29643", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+    # started WITHOUT a launcher -- `python bench.py --gpus 2`, the N = 1 command with another number: the parent (which never touches the
+    # GPU) starts the ranks itself and relays rank 0's line
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(TR_BENCH_SHARE_GPU="1", TR_BENCH_FINETUNE_STEPS="2")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
                          capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-1500:]
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["config"]["parallelism"] == "dp2" and rec["scaling"] == "weak" and rec["value"] > 0
+    # what the process group reports, not the command line: two ranks, and (shared-GPU rig) both on device 0
+    assert rec["dp"]["world"] == 2 and rec["dp"]["cuda_device_by_rank"] == {"0": 0, "1": 0}, rec["dp"]
     assert len(rec["finetune"]) == 3 and all("error" not in v and v["n_gpus"] == 2 for v in rec["finetune"].values()), rec["finetune"]
     # the first real 8-GPU run must explain itself: every fine-tune leg carries the per-bucket timing of its gradient mean
     for label, v in rec["finetune"].items():
