@@ -83,17 +83,36 @@ int tr_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* bias, void* 
  * written by tr_mlp_pack_bf16 from the bf16 [Hd,D] / [D,Hd] matrices and the fp32 [D] bias (repack whenever they change).  tr_mlp_fused_supported: D == 384, Hd %% 32 == 0 (other widths: the pair). */
 int tr_mlp_fused_supported(int D, int Hd);
 /* Which Mlp the eval executor runs where tr_block_weights.mlp_pk is given: 1 = the fused launch wherever the shape is supported, 0 = never,
- * -1 (default) = for more than 256 blocks of 128 rows (stream-K schedule) and where a single round of blocks fills at least three quarters
- * of the 256 workgroups (the two Mlp forms are bit-identical, so this is a speed choice only).  Process-wide; returns the previous mode. */
+ * -1 (default) = for more blocks of 128 rows than the device has compute units (stream-K schedule) and where a single round of blocks fills
+ * at least three quarters of them (one workgroup per CU: hipDeviceAttributeMultiprocessorCount of the current device, 256 on MI355X; the
+ * two Mlp forms are bit-identical, so this is a speed choice only).  Process-wide; returns the previous mode. */
 int tr_set_mlp_fused(int mode);
 size_t tr_mlp_pack_bytes(int D, int Hd);
 int tr_mlp_pack_bf16(const uint16_t* fc1_w, const uint16_t* fc2_w, const float* fc2_b, void* packed, int D, int Hd, tr_stream_t s);
-/* scratch (nullable; tr_mlp_fused_scratch_bytes(D,Hd) bytes, 16-byte aligned): with it a launch of more than 256 blocks of 128 rows deals
- * its steps evenly over the workgroups (stream-K: a block that straddles two workgroups hands its fp32 accumulator over, exactly); without
- * it whole blocks round-robin.  Same bits either way. */
+/* scratch (nullable; tr_mlp_fused_scratch_bytes(D,Hd) bytes for the CURRENT device, 16-byte aligned): with it a launch of more blocks of
+ * 128 rows than the device has compute units deals its steps evenly over the workgroups (stream-K: a block that straddles two workgroups
+ * hands its fp32 accumulator over, exactly); without it whole blocks round-robin.  Same bits either way.
+ * A scratch belongs to ONE launch at a time: it holds that launch's accumulator slots and hand-over counters (zeroed by a memset node in
+ * front of the kernel), so two launches that may overlap -- other streams, other threads -- need a scratch each.
+ * A consumer workgroup polls for its predecessor's accumulator (bounded: seconds; tr_set_mlp_poll_max(iterations), negative = the default
+ * again, 0 = every hand-over counts as abandoned (tests), returns the previous bound); a poll
+ * that runs out does not stop the process: the launch finishes on whatever the slot held and leaves an error record in the scratch, which
+ * tr_mlp_fused_status (waits for the stream, reads and clears the record) turns into TR_ERR_LAUNCH. */
 size_t tr_mlp_fused_scratch_bytes(int D, int Hd);
+int tr_set_mlp_poll_max(int iterations);
+int tr_mlp_fused_status(void* scratch, size_t scratch_bytes, int D, int Hd, tr_stream_t s);
 int tr_mlp_fused_bf16(const uint16_t* xn, const void* packed, const float* fc1_b, uint16_t* out, void* scratch, size_t scratch_bytes, int M, int D,
                       int Hd, tr_stream_t s);
+/* topk.py:95's `self.mlp(self.norm2(x))` in ONE launch: out bf16 [M,D] = fc2(gelu(fc1(LayerNorm(x + delta; g, b, eps)))) with x the fp32
+ * residual stream [M,D] and delta the pending bf16 residual of the attention branch [M,D] (neither is written): the kernel's fc1 waves
+ * normalise their rows in registers on the way in.  Bit-identical to tr_layernorm2_bf16(x, .., NULL, .., delta, .., NULL, .., g, b, xn, ..)
+ * followed by tr_mlp_fused_bf16(xn, ..): the LayerNorm launch (8 B per element through HBM) and the bf16 rows between the two are gone.
+ * tr_set_mlp_ln: where the eval executor takes this form in place of a lazy norm2 followed by the fused Mlp -- 1 (default): where that launch
+ * is one round of whole blocks (measured faster there, slower under the stream-K schedule, which normalises a block once per workgroup that
+ * touches it), 2: wherever the fused Mlp runs, 0: never; returns the previous setting. */
+int tr_set_mlp_ln(int mode);
+int tr_mlp_fused_ln_bf16(const float* x, const uint16_t* delta, const float* g, const float* b, float eps, const void* packed,
+                         const float* fc1_b, uint16_t* out, void* scratch, size_t scratch_bytes, int M, int D, int Hd, tr_stream_t s);
 /* The tail of a block and the head of the next in ONE launch (topk.py:95 `x = x + self.mlp(self.norm2(x))`, then the next block's :87
  * `self.norm1(x)`):  x[M,D] (fp32 stream, already holding the attention branch's residual) += fc2(gelu(fc1(xn))) + fc2_b, IN PLACE, and
  * xn_next[M,D] (bf16, != xn) = LayerNorm(x; next_g, next_b, eps).  The kernel's fc2 wave owns whole rows in registers: its accumulator
@@ -526,6 +545,11 @@ typedef struct {
 
 /* Bytes of workspace tr_vit_forward needs for batch B (0 on invalid config). */
 size_t tr_vit_workspace_bytes(const tr_vit_config* cfg, int B);
+/* Status check of the forwards that ran on `workspace` (the same cfg and B): waits for the stream and reports what only the device can
+ * know -- today the fused Mlp's stream-K hand-over (tr_mlp_fused_status on the workspace's scratch).  TR_OK, or TR_ERR_LAUNCH when a
+ * forward since the last check produced invalid outputs; the record is cleared.  Not part of the forward itself (it synchronises): call
+ * it where the logits are consumed. */
+int tr_vit_forward_status(const tr_vit_config* cfg, void* workspace, size_t workspace_bytes, int B, tr_stream_t s);
 
 /* img fp32 [B,C,S,S] -> logits fp32 [B,classes].  kept_idx (nullable): device int32 slab of depth*B*(P+1) entries;
  * reduction block blk writes its contiguous [B,K_blk] idx array at offset blk*B*(P+1) (Kept_Tokens, topk.py:196); ToMe

@@ -614,6 +614,29 @@ def test_lazy_norm2_is_bit_identical_to_the_eager_sequence(golden_dir, name):
     assert torch.equal(lazy, eager)
 
 
+@pytest.mark.parametrize("name,batch", [("topk_small_kr07", 256), ("topk_small_kr07", 130), ("evit_small_kr05", 200)])
+def test_norm2_inside_the_fused_mlp_gives_the_same_logits(golden_dir, name, batch):
+    """tr_set_mlp_ln: the executor runs a lazy norm2 inside the fused Mlp launch that follows it (one-round launches by default, everywhere
+    with mode 2) or as its own LayerNorm launch (mode 0) -- bit-identical by construction, on DeiT-S shapes where the fused Mlp is in play
+    (batch 256: stream-K stages and a single-round stage; 130 / 200: single rounds of other fill)."""
+    from tokenreduction_amd import ops
+    case = GOLDEN_CASES[name]
+    x = make_images(batch, 224, case["xseed"]).cuda()
+    outs = []
+    prev = ops.set_mlp_ln(0)
+    try:
+        for mode in (0, 1, 2):
+            ops.set_mlp_ln(mode)
+            model, _, _ = build_model(case)          # a fresh model: a captured graph keeps the form it was captured with
+            model.viz_mode = False
+            outs.append(model(x).clone())
+            model.check_status()
+    finally:
+        ops.set_mlp_ln(prev)
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_graph_replay_gives_way_to_plain_launches_when_inputs_keep_moving():
     """The eval forward replays a hipGraph keyed on the input's address.  A caller whose batches land at a new address every time would
     re-capture on every call: after GRAPH_MISS_LIMIT misses in a row the workspace goes back to plain launches, with one warning; a caller

@@ -15,6 +15,8 @@ import torch
 import oracle
 from tests._params import make_params
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 
 BF16_ULP = 2.0 ** -8
@@ -129,6 +131,125 @@ def test_mlp_fused_stream_k_ranges(ops, nblk, ragged, Hd):
         d = got.view(torch.int16) != want.view(torch.int16)
         assert not bool(d.any()), f"launch {it}: {int(d.sum())} elements differ, blocks {(d.any(dim=1).nonzero().flatten() // 128).unique().tolist()[:8]}"
         assert torch.isnan(guard[M:].float()).all(), "rows beyond M were written"
+
+
+# ------------------------------------------------------------------------------------------ norm2 inside the fused Mlp launch
+@pytest.mark.parametrize("M", [1, 77, 129, 1000, 24832, 257 * 128, 35328 + 3, 50432])
+def test_mlp_fused_ln_is_bit_identical_to_layernorm_then_mlp(ops, M):
+    """tr_mlp_fused_ln_bf16 (topk.py:95 `self.mlp(self.norm2(x))` in one launch: the fc1 waves normalise x + delta in registers) against
+    the two launches it replaces -- tr_layernorm2_bf16 without a stream write-back, then tr_mlp_fused_bf16 -- BIT FOR BIT: the row sums
+    are formed in the LayerNorm kernel's order.  Rows with a large common offset (|mean| >> std), a constant row and rows beyond M
+    (guard) included; the stream and the pending residual must come back unchanged; stream-K and whole-block schedules agree."""
+    D, Hd = 384, 1536
+    rng = _rng(M * 11 + 3)
+    x = (2.0 * _randn(rng, M, D))
+    x[::7] += 300.0                      # rows whose mean dwarfs their spread: the two-pass variance must survive
+    if M > 3:
+        x[3] = 1.25                      # a constant row: variance exactly 0 before the pending residual is added
+    delta = _randn(rng, M, D).bfloat16()
+    x, delta = x.cuda(), delta.cuda()
+    w1, w2 = _randn(rng, Hd, D, scale=0.05).bfloat16().cuda(), _randn(rng, D, Hd, scale=0.05).bfloat16().cuda()
+    b1, b2 = _randn(rng, Hd, scale=0.1).cuda(), _randn(rng, D, scale=0.1).cuda()
+    g, bt = (1.0 + 0.2 * _randn(rng, D)).cuda(), (0.1 * _randn(rng, D)).cuda()
+    pk = ops.mlp_pack(w1, w2, b2)
+    x_before, d_before = x.clone(), delta.clone()
+    xn = ops.layernorm2(x, g, bt, 1e-6, delta, write_x=False)
+    assert torch.equal(x, x_before), "layernorm2(write_x=False) wrote the stream"
+    want = ops.mlp_fused(xn, pk, b1)
+    for streamk in (True, False):
+        guard = torch.full((M + 3, D), float("nan"), dtype=torch.bfloat16, device="cuda")
+        got = ops.mlp_fused_ln(x, delta, g, bt, 1e-6, pk, b1, out=guard[:M], streamk=streamk)
+        diff = got.view(torch.int16) != want.view(torch.int16)
+        assert not bool(diff.any()), (f"streamk={streamk}: {int(diff.sum())} of {got.numel()} elements differ from LayerNorm + fused Mlp, rows "
+                                      f"{diff.any(dim=1).nonzero().flatten()[:8].tolist()}")
+        assert torch.isnan(guard[M:].float()).all(), "rows beyond M were written"
+    assert torch.equal(x, x_before) and torch.equal(delta.view(torch.int16), d_before.view(torch.int16)), "an input was written"
+    ops.mlp_fused_status()
+
+
+def test_mlp_fused_ln_repeated_launches_under_uneven_load(ops):
+    """Race screen of the norm-prologue launch (the plain launch's is below): 40 launches at two blocks per workgroup, every third beside a
+    copy kernel on a second stream, each compared with LayerNorm + fused Mlp."""
+    M, D, Hd = 35328, 384, 1536
+    rng = _rng(17)
+    x, delta = (2.0 * _randn(rng, M, D)).cuda(), _randn(rng, M, D).bfloat16().cuda()
+    w1, w2 = _randn(rng, Hd, D, scale=0.05).bfloat16().cuda(), _randn(rng, D, Hd, scale=0.05).bfloat16().cuda()
+    b1, b2 = _randn(rng, Hd, scale=0.1).cuda(), _randn(rng, D, scale=0.1).cuda()
+    g, bt = (1.0 + 0.2 * _randn(rng, D)).cuda(), (0.1 * _randn(rng, D)).cuda()
+    pk = ops.mlp_pack(w1, w2, b2)
+    want = ops.mlp_fused(ops.layernorm2(x, g, bt, 1e-6, delta, write_x=False), pk, b1)
+    side, junk = torch.cuda.Stream(), torch.empty(32 << 20, dtype=torch.uint8, device="cuda")
+    out = torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+    bad = 0
+    for it in range(40):
+        out.fill_(float("nan"))
+        if it % 3 == 0:
+            with torch.cuda.stream(side):
+                junk.add_(1)
+        ops.mlp_fused_ln(x, delta, g, bt, 1e-6, pk, b1, out=out)
+        torch.cuda.synchronize()
+        bad += 0 if torch.equal(out.view(torch.int16), want.view(torch.int16)) else 1
+    assert bad == 0, f"{bad} of 40 launches differ from LayerNorm + fused Mlp"
+
+
+_GRID_WORKER = r"""
+import os, sys
+sys.path.insert(0, os.environ["TR_ROOT"])
+import torch
+from tokenreduction_amd import ops, _lib
+D, Hd = 384, 1536
+g = torch.Generator().manual_seed(3)
+for nblk, ragged in ((257, 5), (394, 0), (130, 77), (64, 0)):
+    M = (nblk - 1) * 128 + (ragged or 128)
+    x = torch.randn(M, D, generator=g).bfloat16().cuda()
+    w1, w2 = (0.05 * torch.randn(Hd, D, generator=g)).bfloat16().cuda(), (0.05 * torch.randn(D, Hd, generator=g)).bfloat16().cuda()
+    b1, b2 = (0.1 * torch.randn(Hd, generator=g)).cuda(), (0.1 * torch.randn(D, generator=g)).cuda()
+    want = ops.gemm(ops.gemm(x, w1, b1, ops.TR_EPI_GELU_BF16), w2, b2, ops.TR_EPI_BF16)
+    pk = ops.mlp_pack(w1, w2, b2)
+    for it in range(3):
+        got = ops.mlp_fused(x, pk, b1)
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16)), (nblk, it)
+    ops.mlp_fused_status()
+mode = os.environ.get("TR_TEST_MODE")
+if mode == "poll":
+    # a poll bound of ZERO iterations: every consumer of a hand-over gives up at once.  The launch must END (no trap: this process
+    # lives), and the status check must turn the device-side record into an error and clear it
+    ops.set_mlp_poll_max(0)
+    M = 41 * 128                       # 41 blocks on 8 workgroups: every range starts or ends inside a block
+    x = torch.randn(M, D, generator=g).bfloat16().cuda()
+    ops.mlp_fused(x, pk, b1)
+    torch.cuda.synchronize()
+    try:
+        ops.mlp_fused_status()
+    except RuntimeError as e:
+        assert "hand-over" in str(e), str(e)
+        ops.mlp_fused_status()          # the record was cleared by the read
+        ops.set_mlp_poll_max(-1)        # the default bound again: the same launch is clean and correct
+        want = ops.gemm(ops.gemm(x, w1, b1, ops.TR_EPI_GELU_BF16), w2, b2, ops.TR_EPI_BF16)
+        assert torch.equal(ops.mlp_fused(x, pk, b1).view(torch.int16), want.view(torch.int16))
+        ops.mlp_fused_status()
+        print("grid ok")
+        sys.exit(0)
+    print("the status check did not report the abandoned hand-over")
+    sys.exit(5)
+print("grid ok")
+"""
+
+
+@pytest.mark.parametrize("grid,mode", [(96, ""), (37, ""), (8, "poll")])
+def test_mlp_fused_on_a_smaller_grid(ops, tmp_path, grid, mode):
+    """The schedule takes its workgroup count from the device (hipDeviceAttributeMultiprocessorCount), not a literal 256: with another grid
+    (TR_MLP_FUSED_GRID, read at library load -> a subprocess) -- a partitioned or CU-masked device, the workgroups of the stream-K chain
+    running in several rounds -- every output still equals the GEMM pair bit for bit.  mode "poll": with the hand-over poll bound at zero
+    iterations every consumer gives up: the launch ends, tr_mlp_fused_status turns the device-side record into an error (no trap: the
+    process lives) and clears it."""
+    import subprocess
+    import sys
+    script = tmp_path / "grid_worker.py"
+    script.write_text(_GRID_WORKER)
+    env = dict(os.environ, TR_ROOT=ROOT, TR_MLP_FUSED_GRID=str(grid), TR_TEST_MODE=mode)
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0 and "grid ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
 
 
 # ------------------------------------------------------------------------------------------ fused block tail: Mlp + residual + next norm1

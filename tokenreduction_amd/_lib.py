@@ -88,6 +88,10 @@ SIGNATURES = {
     "tr_mlp_pack_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "tr_mlp_fused_scratch_bytes": (_sz, [_i, _i]),
     "tr_mlp_fused_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
+    "tr_set_mlp_poll_max": (_i, [_i]),
+    "tr_mlp_fused_status": (_i, [_vp, _sz, _i, _i, _vp]),
+    "tr_set_mlp_ln": (_i, [_i]),
+    "tr_mlp_fused_ln_bf16": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
     "tr_set_mlp_resid_ln": (_i, [_i]),
     "tr_mlp_fused_resid_ln_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _sz, _i, _i, _i, _vp]),
     "tr_layernorm_bf16": (_i, [_vp, _l, _vp, _l, _vp, _vp, _vp, _i, _i, _f, _vp]),
@@ -95,6 +99,7 @@ SIGNATURES = {
     "tr_cls_topk": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "tr_gather_layernorm_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "tr_vit_workspace_bytes": (_sz, [C.POINTER(TrVitConfig), _i]),
+    "tr_vit_forward_status": (_i, [C.POINTER(TrVitConfig), _vp, _sz, _i, _vp]),
     "tr_pool_broadcast": (_i, [_vp, _i, _i, _i, _i, _f, _vp]),
     "tr_dyvit_score": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _vp]),
     "tr_sit_merge": (_i, [_vp, _i, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -232,6 +232,8 @@ __device__ __forceinline__ MfCur mf_next(const MfSeq& q, const MfCur& c, int NS)
 
 constexpr int MF_SK_SLOT = 4 * MF_NI * 2 * 1024;     // one workgroup's published accumulator: 4 C waves x 48 fragments x 1 KiB = 192 KiB
 constexpr int MF_SK_CNT = 128;                       // bytes per counter (its own line)
+constexpr int MF_SK_ERR = 128;                       // behind the counters: the error record of a hand-over poll that ran out (magic, workgroup + 1)
+constexpr unsigned MF_SK_ERR_MAGIC = 0x4d46534bu;    // "MFSK"
 
 // RL ("residual + LayerNorm" tail of a transformer block, topk.py:95 followed by the next block's :87 norm1): the C wave's accumulator starts at
 // the block's rows of the fp32 residual stream `rl.x` (which already holds x + attention branch) instead of at fc2's bias, so that at the
@@ -247,11 +249,26 @@ struct MfResid {
   float eps;
 };
 
-template <bool RL>
+// NP ("norm prologue": topk.py:95 `self.mlp(self.norm2(x))` with the norm2 INSIDE the launch): the P wave builds its 32 x 384 B operand
+// from the fp32 residual stream and the pending bf16 attention residual -- LayerNorm(x + d; g, b) -- instead of loading a normalised bf16
+// row.  A token row sits in the four lanes (lane & 15, q = 0..3) of a wave, 96 values each: statistics in-lane + two cross-lane steps.
+// Bit-identical to tr_layernorm2_bf16 followed by the plain launch: the sums are formed in layernorm_half_kernel's order (its lane
+// `sub` = 8 (ks & 3) + 2 q + h holds the chunks ks, ks + 4, ks + 8 of half h; its butterfly xor 16, 8 is in-lane here, xor 4, 2 are this
+// wave's lane ^ 32, ^ 16, xor 1 is the in-lane half h), with its contractions spelled out.  Removes the lazy-norm2 launch in front of the
+// Mlp (8 B per element through HBM) and the bf16 round trip of the normalised rows.
+struct MfNorm {
+  const float* x;        // [M, 384] fp32 residual stream (not written)
+  const uint16_t* d;     // [M, 384] bf16 pending residual (the attention branch)
+  const float* g;        // norm2 weight, bias, eps
+  const float* b;
+  float eps;
+};
+
+template <bool RL, bool NP>
 __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __restrict__ xn, const unsigned char* __restrict__ pk,
                                                            const float* __restrict__ b1,
                                                            uint16_t* __restrict__ outp, unsigned char* __restrict__ scratch, int M, int NS,
-                                                           unsigned out_bytes, const MfResid rl) {
+                                                           unsigned out_bytes, int poll_max, const MfResid rl, const MfNorm nm) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[MF_LDS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -342,7 +359,102 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
 #define MF_RELOAD_X(ks)                        \
   mf_reload_x<(ks) * 64>(x0[ks], xn, xo0);     \
   mf_reload_x<(ks) * 64>(x1[ks], xn, xo1)
-    {
+    // NP: x0 / x1 <- LayerNorm(x + d) of block blk's rows, one 16-row group at a time (96 fp32 values per lane live).  The sched_barriers
+    // pin the phases: left alone, hipcc issues both groups' loads and all 48 parameter loads up front (121 spilled registers).
+    auto ln_fill = [&](int blk) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int m = min(blk * MF_ROWS + pr * 32 + frow + 16 * j, M - 1);
+        const float* xr = nm.x + (size_t)m * MF_D + 8 * fq;
+        const uint16_t* dr = nm.d + (size_t)m * MF_D + 8 * fq;
+        f32x4 v[MF_KS][2];
+        u32x4 dq[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dq[0][i] = *reinterpret_cast<const u32x4*>(dr + 32 * i);
+#pragma unroll
+        for (int ks = 0; ks < MF_KS; ++ks) {
+          v[ks][0] = *reinterpret_cast<const f32x4*>(xr + 32 * ks);
+          v[ks][1] = *reinterpret_cast<const f32x4*>(xr + 32 * ks + 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          if (c + 1 < 3) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dq[(c + 1) & 1][i] = *reinterpret_cast<const u32x4*>(dr + 32 * (4 * (c + 1) + i));
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const u32x4 dd = dq[c & 1][i];
+            const int ks = 4 * c + i;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              v[ks][h][0] += __uint_as_float(dd[2 * h] << 16); v[ks][h][1] += __uint_as_float(dd[2 * h] & 0xffff0000u);
+              v[ks][h][2] += __uint_as_float(dd[2 * h + 1] << 16); v[ks][h][3] += __uint_as_float(dd[2 * h + 1] & 0xffff0000u);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // the row sum: per (ks & 3, h) the three chunks in order, then the tree (see the header of MfNorm)
+        float sp[4][2];
+#pragma unroll
+        for (int ks = 0; ks < MF_KS; ++ks)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const float t = (v[ks][h][0] + v[ks][h][1]) + (v[ks][h][2] + v[ks][h][3]);
+            sp[ks & 3][h] = (ks < 4 ? 0.f : sp[ks & 3][h]) + t;
+          }
+        float c0 = (sp[0][0] + sp[2][0]) + (sp[1][0] + sp[3][0]), c1 = (sp[0][1] + sp[2][1]) + (sp[1][1] + sp[3][1]);
+        c0 += __shfl_xor(c0, 32); c1 += __shfl_xor(c1, 32);
+        c0 += __shfl_xor(c0, 16); c1 += __shfl_xor(c1, 16);
+        const float mean = (c0 + c1) / (float)MF_D;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < MF_KS; ++ks)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            f32x4 t = v[ks][h];
+            t[0] -= mean; t[1] -= mean; t[2] -= mean; t[3] -= mean;
+            v[ks][h] = t;
+            const float u = __builtin_fmaf(t[0], t[0], t[1] * t[1]) + __builtin_fmaf(t[2], t[2], t[3] * t[3]);
+            sp[ks & 3][h] = (ks < 4 ? 0.f : sp[ks & 3][h]) + u;
+          }
+        c0 = (sp[0][0] + sp[2][0]) + (sp[1][0] + sp[3][0]); c1 = (sp[0][1] + sp[2][1]) + (sp[1][1] + sp[3][1]);
+        c0 += __shfl_xor(c0, 32); c1 += __shfl_xor(c1, 32);
+        c0 += __shfl_xor(c0, 16); c1 += __shfl_xor(c1, 16);
+        const float rstd = rsqrtf((c0 + c1) / (float)MF_D + nm.eps);
+        const float* gr = nm.g + 8 * fq;
+        const float* br = nm.b + 8 * fq;
+        // normalise, scale, round: the parameters of chunk ks + 1 are requested before chunk ks is computed (two sets of 16 registers)
+        f32x4 gb[2][4];
+        gb[0][0] = *reinterpret_cast<const f32x4*>(gr); gb[0][1] = *reinterpret_cast<const f32x4*>(gr + 4);
+        gb[0][2] = *reinterpret_cast<const f32x4*>(br); gb[0][3] = *reinterpret_cast<const f32x4*>(br + 4);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < MF_KS; ++ks) {
+          if (ks + 1 < MF_KS) {
+            gb[(ks + 1) & 1][0] = *reinterpret_cast<const f32x4*>(gr + 32 * (ks + 1)); gb[(ks + 1) & 1][1] = *reinterpret_cast<const f32x4*>(gr + 32 * (ks + 1) + 4);
+            gb[(ks + 1) & 1][2] = *reinterpret_cast<const f32x4*>(br + 32 * (ks + 1)); gb[(ks + 1) & 1][3] = *reinterpret_cast<const f32x4*>(br + 32 * (ks + 1) + 4);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          u32x4 o;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x4 gg = gb[ks & 1][h], bb = gb[ks & 1][2 + h];
+            const f32x4 t = v[ks][h];
+            o[2 * h] = pack_bf16x2(__builtin_fmaf(rstd * t[0], gg[0], bb[0]), __builtin_fmaf(rstd * t[1], gg[1], bb[1]));
+            o[2 * h + 1] = pack_bf16x2(__builtin_fmaf(rstd * t[2], gg[2], bb[2]), __builtin_fmaf(rstd * t[3], gg[3], bb[3]));
+          }
+          if (j == 0) x0[ks] = __builtin_bit_cast(bf16x8, o);
+          else x1[ks] = __builtin_bit_cast(bf16x8, o);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+    if constexpr (NP) {
+      ln_fill(mf_block(q, mf_first(q, NS)));
+    } else {
       unsigned xo0, xo1;
       x_offsets(mf_block(q, mf_first(q, NS)), xo0, xo1);
       MF_LOAD_X(0); MF_LOAD_X(1); MF_LOAD_X(2); MF_LOAD_X(3); MF_LOAD_X(4); MF_LOAD_X(5);
@@ -427,7 +539,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
       _Pragma("unroll") for (int q_ = MF_PPW * ((k) - 1); q_ < MF_PPW * (k); ++q_)              \
         if (q_ < MF_PQ) issue_piece_q(q_);                                                      \
     }                                                                                           \
-    if (reload) { MF_RELOAD_X(2 * (k)); MF_RELOAD_X(2 * (k) + 1); }                             \
+    if (!NP && reload) { MF_RELOAD_X(2 * (k)); MF_RELOAD_X(2 * (k) + 1); }                      \
   } while (0)
       MF_PWIN(wA, wB, 0);
       MF_PWIN(wB, wA, 1);
@@ -451,7 +563,16 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
       __builtin_amdgcn_sched_barrier(0);
       MF_PMFMA(wB, 5);
       __builtin_amdgcn_sched_barrier(0);
-      if (reload) { MF_RELOAD_X(10); MF_RELOAD_X(11); }
+      if constexpr (NP) {
+        // the block's last MFMA has issued: the next block's rows, normalised, take the x registers (the partner finishes its step and
+        // waits at the next barrier meanwhile)
+        if (reload) {
+          ln_fill(next_blk);
+          MF_READW(wA, slot_next, 0);      // (again: the copy requested in front of window 5 is not kept through the norm)
+        }
+      } else {
+        if (reload) { MF_RELOAD_X(10); MF_RELOAD_X(11); }
+      }
 #undef MF_PWIN
 #undef MF_GELU_SLICE
       p00 = a00; p01 = a01; p10 = a10; p11 = a11;
@@ -845,14 +966,23 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
       if (load_next) {
         // the previous workgroup's four C waves have published their parts (it ran that segment first: normally long ago); every wave that
         // reads polls for itself.  The predecessor was dispatched BEFORE this workgroup and publishes after its own first segment without
-        // waiting for anybody, so the wait is bounded by dispatch skew; the spin is bounded all the same (seconds), and a poll that runs out
-        // TRAPS -- the launch fails loudly instead of continuing on an accumulator that was never published
+        // waiting for anybody, so the wait is bounded by dispatch skew (also when the workgroups run in several rounds: a CU mask, a
+        // partitioned device); the spin is bounded all the same (poll_max: seconds), and a poll that runs out is RECORDED
         bool published = false;
-        for (int spin = 0; spin < (1 << 24); ++spin) {
+        for (int spin = 0; spin < poll_max; ++spin) {
           if (__hip_atomic_load(sk_cnt_in, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 4u) { published = true; break; }
           __builtin_amdgcn_s_sleep(8);
         }
-        if (!published) __builtin_trap();
+        if (!published && lane == 0) {
+          // the launch goes on (on whatever the slot holds) and SAYS so: the error record behind the counters -- a magic word and the
+          // workgroup -- is what tr_mlp_fused_status / tr_vit_forward_status turn into TR_ERR_LAUNCH at the caller's next status check.
+          // (A trap here would take the whole process down, also under a CU mask or GPU sharing where the wait is merely long.)
+          unsigned* err = reinterpret_cast<unsigned*>(scratch + (size_t)G * (MF_SK_SLOT + MF_SK_CNT));
+          int who = bid + 1;
+          asm volatile("" : "+s"(who));        // formed HERE: as a loop invariant it is parked in a VGPR through the step loop, which has none to spare (one spill)
+          __hip_atomic_store(err + 1, (unsigned)who, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(err, MF_SK_ERR_MAGIC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         asm volatile("" ::: "memory");
       }
       if (!RL && epi) { stage(0, 0); read_back(lnA); }
@@ -906,8 +1036,27 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
 
 extern "C" int tr_mlp_fused_supported(int D, int Hd) { return (D == MF_D && Hd % 32 == 0 && Hd >= 64) ? 1 : 0; }
 
+// Workgroups of a launch = compute units of the CURRENT device (one persistent 512-thread workgroup per CU: all of its LDS, half its
+// registers), read once per device -- not a literal 256: a partitioned or smaller device gets its own grid, scratch size and thresholds.
+// TR_MLP_FUSED_GRID=n (lab / tests): another grid, e.g. to run the stream-K hand-over in several rounds of workgroups.
+static int mf_grid() {
+  static const int forced = [] { const char* e = getenv("TR_MLP_FUSED_GRID"); return e ? atoi(e) : 0; }();
+  if (forced > 0) return forced;
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int g = cached[dev].load(std::memory_order_relaxed);
+  if (g == 0) {
+    int n = 0;
+    g = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    cached[dev].store(g, std::memory_order_relaxed);
+  }
+  return g;
+}
+
 static std::atomic<int> g_mlp_fused_mode{-1};
-static std::atomic<int> g_mlp_sk_min_blocks{257};     // lab (tr_set_mlp_fused(mode >= 2)): fewest blocks for which auto takes the stream-K launch
+static std::atomic<int> g_mlp_sk_min_blocks{0};       // lab (tr_set_mlp_fused(mode >= 2)): fewest blocks for which auto takes the stream-K launch (0: grid + 1)
+static std::atomic<int> g_mlp_poll_max{1 << 24};      // hand-over poll bound (iterations of an 8-tick sleep: seconds); tests shorten it
 extern "C" int tr_set_mlp_fused(int mode) {
   if (mode >= 2) { g_mlp_sk_min_blocks.store(mode); mode = -1; }
   return g_mlp_fused_mode.exchange(mode < 0 ? -1 : (mode > 0 ? 1 : 0));
@@ -919,13 +1068,14 @@ int tr_mlp_fused_wanted(int M, int D, int Hd, int have_scratch) {
   if (!tr_mlp_fused_supported(D, Hd)) return 0;
   const int mode = g_mlp_fused_mode.load(std::memory_order_relaxed);
   if (mode >= 0) return mode;
-  const int nblk = (M + MF_ROWS - 1) / MF_ROWS;
-  if (nblk > 256) {
-    if (have_scratch) return nblk >= g_mlp_sk_min_blocks.load(std::memory_order_relaxed);
-    const int rounds = (nblk + 255) / 256;
-    return 4 * nblk >= 3 * 256 * rounds;
+  const int nblk = (M + MF_ROWS - 1) / MF_ROWS, G = mf_grid();
+  if (nblk > G) {
+    const int lo = g_mlp_sk_min_blocks.load(std::memory_order_relaxed);
+    if (have_scratch) return nblk >= (lo > 0 ? lo : G + 1);
+    const int rounds = (nblk + G - 1) / G;
+    return 4 * nblk >= 3 * G * rounds;
   }
-  return 4 * nblk >= 3 * 256;
+  return 4 * nblk >= 3 * G;
 }
 
 // default OFF: measured in the model (tools/lab/mlp_model_ab.sh) the fused tail LOSES 4 % of the headline forward against the fused Mlp + the
@@ -934,13 +1084,28 @@ static std::atomic<int> g_mlp_resid_ln{0};
 extern "C" int tr_set_mlp_resid_ln(int on) { return g_mlp_resid_ln.exchange(on ? 1 : 0); }
 int tr_mlp_resid_ln_enabled() { return g_mlp_resid_ln.load(std::memory_order_relaxed); }
 
+// norm2 inside the fused Mlp launch (tr_mlp_fused_ln_bf16) where the eval executor would run a lazy norm2 followed by the fused Mlp.
+// 1 (default): where the launch is ONE round of whole blocks -- measured (tools/lab/mlp_ln_ab.py, profiles/r06_lab.md): 88.5 vs 93.0 us at
+// 24,832 rows, but under the stream-K schedule every workgroup normalises every block it touches (two or three for 1.1-1.5 blocks of
+// work) and the ~10 us a 128-row prologue holds the workgroup cost more than the LayerNorm launch saved (131 vs 121 us at 35,328 rows);
+// 2 (lab): wherever the fused Mlp runs; 0: never.
+static std::atomic<int> g_mlp_ln{1};
+extern "C" int tr_set_mlp_ln(int mode) { return g_mlp_ln.exchange(mode < 0 ? 0 : (mode > 2 ? 2 : mode)); }
+int tr_mlp_ln_wanted(int M, int D, int Hd, int have_scratch) {
+  const int mode = g_mlp_ln.load(std::memory_order_relaxed);
+  if (mode == 0 || !tr_mlp_fused_wanted(M, D, Hd, have_scratch)) return 0;
+  return mode == 2 || (M + MF_ROWS - 1) / MF_ROWS <= mf_grid();
+}
+
+extern "C" int tr_set_mlp_poll_max(int iterations) { return g_mlp_poll_max.exchange(iterations >= 0 ? iterations : (1 << 24)); }      // 0 (tests): every hand-over is reported as abandoned
+
 extern "C" size_t tr_mlp_pack_bytes(int D, int Hd) {
   if (D <= 0 || Hd <= 0 || D % 32 || Hd % 32) return 0;
   return ((size_t)(Hd / 32) * (size_t)(2 * (D / 32) + D / 16) + (size_t)(2 * (D / 16))) * 1024;       // the steps' fragments + the bias image
 }
 
 extern "C" size_t tr_mlp_fused_scratch_bytes(int D, int Hd) {
-  return tr_mlp_fused_supported(D, Hd) ? (size_t)256 * (MF_SK_SLOT + MF_SK_CNT) : 0;
+  return tr_mlp_fused_supported(D, Hd) ? (size_t)mf_grid() * (MF_SK_SLOT + MF_SK_CNT) + MF_SK_ERR : 0;
 }
 
 extern "C" int tr_mlp_pack_bf16(const uint16_t* fc1_w, const uint16_t* fc2_w, const float* fc2_b, void* packed, int D, int Hd, tr_stream_t s) {
@@ -956,8 +1121,8 @@ extern "C" int tr_mlp_pack_bf16(const uint16_t* fc1_w, const uint16_t* fc2_w, co
 }
 
 static int mlp_fused_launch(const char* who, const uint16_t* xn, const void* packed, const float* fc1_b, uint16_t* out, void* scratch,
-                            size_t scratch_bytes, int M, int D, int Hd, const MfResid* rl, tr_stream_t s) {
-  TR_REQUIRE(xn && packed && fc1_b && out, TR_ERR_NULL, "%s: null pointer", who);
+                            size_t scratch_bytes, int M, int D, int Hd, const MfResid* rl, const MfNorm* nm, tr_stream_t s) {
+  TR_REQUIRE((xn || nm) && packed && fc1_b && out, TR_ERR_NULL, "%s: null pointer", who);
   TR_REQUIRE(M > 0 && tr_mlp_fused_supported(D, Hd), TR_ERR_SHAPE, "%s: unsupported shape M=%d D=%d Hd=%d (D must be %d, Hd %% 32 == 0)", who, M, D, Hd,
              MF_D);
   TR_REQUIRE(tr_aligned16(xn) && tr_aligned16(packed) && tr_aligned16(fc1_b) && tr_aligned16(out) && tr_aligned16(scratch),
@@ -969,31 +1134,53 @@ static int mlp_fused_launch(const char* who, const uint16_t* xn, const void* pac
   TR_REQUIRE(out_bytes < ((size_t)1 << (rl ? 30 : 31)), TR_ERR_SHAPE, "%s: %zu output bytes exceed the range of the 32-bit store offsets", who, out_bytes);
   if (rl)       // + the stream's read-modify-write and the norm's parameters; no separate fc2 output
     tr_prof_note("mlp_fused_kernel<resid_ln>", 4.0 * M * D * Hd, 2.0 * M * D + 8.0 * M * D + 2.0 * M * D + 4.0 * D * Hd);
+  else if (nm)  // the fp32 stream row + the bf16 pending residual in, bf16 out, the packed weights
+    tr_prof_note("mlp_fused_kernel<ln>", 4.0 * M * D * Hd, 6.0 * M * D + 2.0 * M * D + 4.0 * D * Hd);
   else
     tr_prof_note("mlp_fused_kernel", 4.0 * M * D * Hd, 4.0 * M * D + 4.0 * D * Hd);
-  const int nblk = (M + MF_ROWS - 1) / MF_ROWS;
-  const int G = nblk < 256 ? nblk : 256;
+  const int nblk = (M + MF_ROWS - 1) / MF_ROWS, grid = mf_grid();
+  const int G = nblk < grid ? nblk : grid;
   hipStream_t st = static_cast<hipStream_t>(s);
   unsigned char* sk = (nblk > G) ? static_cast<unsigned char*>(scratch) : nullptr;
   if (sk != nullptr) {
     // the hand-over counters of this launch (one line per workgroup, behind the accumulator slots) start at zero: a memset node ahead of the
-    // kernel node (graph-capturable; a counter that the last consumer reset would fail a first, poisoned launch)
+    // kernel node (graph-capturable; a counter that the last consumer reset would fail a first, poisoned launch).  The error record behind
+    // them is NOT touched: it stays until tr_mlp_fused_status reads it.
     hipError_t e = hipMemsetAsync(sk + (size_t)G * MF_SK_SLOT, 0, (size_t)G * MF_SK_CNT, st);
     TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "%s: hipMemsetAsync: %s", who, hipGetErrorString(e));
   }
+  const int poll_max = g_mlp_poll_max.load(std::memory_order_relaxed);
+  const MfResid no_rl{nullptr, nullptr, nullptr, nullptr, 0.f};
+  const MfNorm no_nm{nullptr, nullptr, nullptr, nullptr, 0.f};
   if (rl)
-    hipLaunchKernelGGL(mlp_fused_kernel<true>, dim3(G), dim3(512), 0, st, xn, static_cast<const unsigned char*>(packed), fc1_b, out, sk, M, Hd / 32,
-                       (unsigned)out_bytes, *rl);
+    hipLaunchKernelGGL((mlp_fused_kernel<true, false>), dim3(G), dim3(512), 0, st, xn, static_cast<const unsigned char*>(packed), fc1_b, out, sk, M,
+                       Hd / 32, (unsigned)out_bytes, poll_max, *rl, no_nm);
+  else if (nm)
+    hipLaunchKernelGGL((mlp_fused_kernel<false, true>), dim3(G), dim3(512), 0, st, xn, static_cast<const unsigned char*>(packed), fc1_b, out, sk, M,
+                       Hd / 32, (unsigned)out_bytes, poll_max, no_rl, *nm);
   else
-    hipLaunchKernelGGL(mlp_fused_kernel<false>, dim3(G), dim3(512), 0, st, xn, static_cast<const unsigned char*>(packed), fc1_b, out, sk, M, Hd / 32,
-                       (unsigned)out_bytes, MfResid{nullptr, nullptr, nullptr, nullptr, 0.f});
+    hipLaunchKernelGGL((mlp_fused_kernel<false, false>), dim3(G), dim3(512), 0, st, xn, static_cast<const unsigned char*>(packed), fc1_b, out, sk, M,
+                       Hd / 32, (unsigned)out_bytes, poll_max, no_rl, no_nm);
   TR_CHECK_LAUNCH(who);
   return TR_OK;
 }
 
 extern "C" int tr_mlp_fused_bf16(const uint16_t* xn, const void* packed, const float* fc1_b, uint16_t* out, void* scratch, size_t scratch_bytes, int M,
                                  int D, int Hd, tr_stream_t s) {
-  return mlp_fused_launch("tr_mlp_fused_bf16", xn, packed, fc1_b, out, scratch, scratch_bytes, M, D, Hd, nullptr, s);
+  TR_REQUIRE(xn, TR_ERR_NULL, "tr_mlp_fused_bf16: null pointer");
+  return mlp_fused_launch("tr_mlp_fused_bf16", xn, packed, fc1_b, out, scratch, scratch_bytes, M, D, Hd, nullptr, nullptr, s);
+}
+
+// topk.py:95's `self.mlp(self.norm2(x))` in ONE launch:  out = fc2(gelu(fc1(LayerNorm(x + delta; g, b, eps))))  with x the fp32 stream and
+// delta the pending bf16 residual of the attention branch (neither is written).  Bit-identical to tr_layernorm2_bf16(x, NULL, delta, NULL, ..)
+// followed by tr_mlp_fused_bf16.
+extern "C" int tr_mlp_fused_ln_bf16(const float* x, const uint16_t* delta, const float* g, const float* b, float eps, const void* packed,
+                                    const float* fc1_b, uint16_t* out, void* scratch, size_t scratch_bytes, int M, int D, int Hd, tr_stream_t s) {
+  TR_REQUIRE(x && delta && g && b, TR_ERR_NULL, "tr_mlp_fused_ln_bf16: null pointer");
+  TR_REQUIRE(tr_aligned16(x) && tr_aligned16(delta) && tr_aligned16(g) && tr_aligned16(b), TR_ERR_ALIGN,
+             "tr_mlp_fused_ln_bf16: pointers must be 16-byte aligned");
+  const MfNorm nm{x, delta, g, b, eps};
+  return mlp_fused_launch("tr_mlp_fused_ln_bf16", nullptr, packed, fc1_b, out, scratch, scratch_bytes, M, D, Hd, nullptr, &nm, s);
 }
 
 // The tail of a transformer block and the head of the next in one launch (topk.py:95 `x = x + self.mlp(self.norm2(x))`, then the next
@@ -1002,10 +1189,32 @@ extern "C" int tr_mlp_fused_bf16(const uint16_t* xn, const void* packed, const f
 extern "C" int tr_mlp_fused_resid_ln_bf16(const uint16_t* xn, const void* packed, const float* fc1_b, const float* fc2_b, float* x,
                                           const float* next_g, const float* next_b, float eps, uint16_t* xn_next, void* scratch,
                                           size_t scratch_bytes, int M, int D, int Hd, tr_stream_t s) {
-  TR_REQUIRE(fc2_b && x && next_g && next_b, TR_ERR_NULL, "tr_mlp_fused_resid_ln_bf16: null pointer");
+  TR_REQUIRE(xn && fc2_b && x && next_g && next_b, TR_ERR_NULL, "tr_mlp_fused_resid_ln_bf16: null pointer");
   TR_REQUIRE(tr_aligned16(fc2_b) && tr_aligned16(x) && tr_aligned16(next_g) && tr_aligned16(next_b), TR_ERR_ALIGN,
              "tr_mlp_fused_resid_ln_bf16: pointers must be 16-byte aligned");
   TR_REQUIRE(xn_next != xn, TR_ERR_CONFIG, "tr_mlp_fused_resid_ln_bf16: xn_next aliases xn");
   const MfResid rl{x, fc2_b, next_g, next_b, eps};
-  return mlp_fused_launch("tr_mlp_fused_resid_ln_bf16", xn, packed, fc1_b, xn_next, scratch, scratch_bytes, M, D, Hd, &rl, s);
+  return mlp_fused_launch("tr_mlp_fused_resid_ln_bf16", xn, packed, fc1_b, xn_next, scratch, scratch_bytes, M, D, Hd, &rl, nullptr, s);
+}
+
+// The status check of the stream-K hand-over: waits for the stream, reads the error record behind the scratch's counters and clears it.
+// TR_OK, or TR_ERR_LAUNCH when a workgroup's poll for its predecessor's accumulator ran out in some launch since the last check (the
+// outputs of that launch are not valid).  A scratch that never saw such a launch holds no magic word, whatever else it holds.
+extern "C" int tr_mlp_fused_status(void* scratch, size_t scratch_bytes, int D, int Hd, tr_stream_t s) {
+  TR_REQUIRE(scratch, TR_ERR_NULL, "tr_mlp_fused_status: null pointer");
+  TR_REQUIRE(tr_mlp_fused_supported(D, Hd) && scratch_bytes >= tr_mlp_fused_scratch_bytes(D, Hd), TR_ERR_SHAPE,
+             "tr_mlp_fused_status: scratch of %zu bytes, tr_mlp_fused_scratch_bytes says %zu", scratch_bytes, tr_mlp_fused_scratch_bytes(D, Hd));
+  hipStream_t st = static_cast<hipStream_t>(s);
+  unsigned char* rec = static_cast<unsigned char*>(scratch) + (size_t)mf_grid() * (MF_SK_SLOT + MF_SK_CNT);
+  unsigned host[2] = {0u, 0u};
+  hipError_t e = hipMemcpyAsync(host, rec, sizeof(host), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_mlp_fused_status: %s", hipGetErrorString(e));
+  if (host[0] != MF_SK_ERR_MAGIC || host[1] == 0u || host[1] > 65536u) return TR_OK;
+  e = hipMemsetAsync(rec, 0, MF_SK_ERR, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  TR_REQUIRE(false, TR_ERR_LAUNCH,
+             "fused Mlp: workgroup %u waited in vain for its predecessor's accumulator (stream-K hand-over poll ran out): the outputs of that "
+             "launch are invalid", host[1] - 1u);
+  return TR_ERR_LAUNCH;
 }

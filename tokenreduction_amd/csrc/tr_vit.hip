@@ -122,6 +122,7 @@ extern "C" int tr_version(void) { return 100; }
 
 int tr_mlp_fused_wanted(int M, int D, int Hd, int have_scratch);      // tr_mlp_fused.hip: the schedule policy behind tr_set_mlp_fused
 int tr_mlp_resid_ln_enabled();                                        // tr_mlp_fused.hip: tr_set_mlp_resid_ln's switch
+int tr_mlp_ln_wanted(int M, int D, int Hd, int have_scratch);         // tr_mlp_fused.hip: ... with the norm2 in front of it inside the launch (tr_set_mlp_ln)
 
 namespace {
 
@@ -178,7 +179,7 @@ bool make_plan(const tr_vit_config* c, int B, Plan* p) {
     for (int i = 0; i < c->depth; ++i) kmax = c->keep[i] > kmax ? c->keep[i] : kmax;
     o += align_up(T * (size_t)trplan::soft_ld(kmax) * 4);
   }
-  // stream-K scratch of the fused eval Mlp (tr_mlp_fused.hip): 256 accumulator slots of 192 KiB + their counters, bf16 executor only
+  // stream-K scratch of the fused eval Mlp (tr_mlp_fused.hip): one accumulator slot of 192 KiB + a counter per compute unit, bf16 executor only
   p->off_mlp_sk = o;
   p->mlp_sk_bytes = c->precision == TR_PREC_BF16 ? tr_mlp_fused_scratch_bytes(p->D, p->Hd) : 0;
   o += align_up(p->mlp_sk_bytes);
@@ -650,11 +651,15 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       TR_TRY(op_attn(prec, qkv, ao, (K > 0 || Ks > 0) ? cls_rows : nullptr, (tome || masked) ? size_cur : nullptr,
                      want_colsum ? colsum_part : nullptr, B, N, H, s));
     int Nn = N;
+    bool norm2_in_mlp = false;      // this block's norm2 runs inside its fused Mlp launch
     if (Ks > 0) {
       // a16-a18: sample token ids on the CLS attention x |v|, keep those rows of x and of attn @ v
       const tr_stage_weights* sw = &w->stage[i];
       const bool dyn = cfg->ats_dynamic != 0 && !train;
-      TR_REQUIRE(Ks >= 2 && (Ks <= N || dyn), TR_ERR_CONFIG, "tr_vit_forward: block %d ATS sample_count %d out of range for %d tokens", i, Ks, N);
+      // (dynamic width: N is the batch maximum of the previous stage and may be below the static Ks; the buffers -- ids, the mask in the
+      // score buffer -- are sized for the first stage's N0 rows, which bounds Ks in either mode)
+      TR_REQUIRE(Ks >= 2 && (dyn ? Ks <= p.N0 : Ks <= N), TR_ERR_CONFIG, "tr_vit_forward: block %d ATS sample_count %d out of range for %d tokens", i, Ks,
+                 dyn ? p.N0 : N);
       TR_REQUIRE(sw->w3 && sw->n_pad >= 1, TR_ERR_NULL, "tr_vit_forward: block %d has no ATS sample grid (tr_vit_weights.stage)", i);
       int32_t* ids = kept_idx ? kept_idx + (size_t)i * B * p.N0 : idx_ws;
       float* mask_next = (size_cur == size_a) ? size_b : size_a;
@@ -743,8 +748,14 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       x = x_alt;
     } else if (lazy_base && starts_plain(i + 1) && !(rl_base && i + 1 < cfg->depth && bw->mlp_pk != nullptr &&
                                                      tr_mlp_fused_wanted(B * Nn, D, p.Hd, p.mlp_sk_bytes > 0))) {
-      TR_TRY(tr_layernorm2_bf16(x, D, nullptr, 0, static_cast<const uint16_t*>(dbuf), D, nullptr, 0, bw->ln2_g, bw->ln2_b,
-                                static_cast<uint16_t*>(xn), B * Nn, D, cfg->ln_eps, s));
+      // lazy norm2.  Where the fused Mlp follows as ONE round of blocks, the norm moves INTO that launch (tr_mlp_fused_ln_bf16: its fc1 waves
+      // normalise x + dbuf in registers; bit-identical to the launch below followed by the plain fused Mlp) -- no LayerNorm launch, no bf16
+      // rows in between (tr_set_mlp_ln; under the stream-K schedule the separate launch is faster: tr_mlp_fused.hip)
+      norm2_in_mlp = prec == TR_PREC_BF16 && drop_keep == nullptr && bw->mlp_pk != nullptr &&
+                     tr_mlp_ln_wanted(B * Nn, D, p.Hd, p.mlp_sk_bytes > 0);
+      if (!norm2_in_mlp)
+        TR_TRY(tr_layernorm2_bf16(x, D, nullptr, 0, static_cast<const uint16_t*>(dbuf), D, nullptr, 0, bw->ln2_g, bw->ln2_b,
+                                  static_cast<uint16_t*>(xn), B * Nn, D, cfg->ln_eps, s));
       pending_attn = dbuf;
     } else {
       TR_TRY(op_ln(f32, x, D, dbuf, D, bw->ln2_g, bw->ln2_b, xn, B * Nn, D, cfg->ln_eps, s));
@@ -762,6 +773,7 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       // taken where its block schedule fills the chip)
       fused_mlp = true;
     } else {
+      TR_REQUIRE(!norm2_in_mlp, TR_ERR_CONFIG, "tr_vit_forward: internal: block %d skipped its norm2 launch but does not run the fused Mlp", i);
       TR_TRY(op_gemm(prec, xn, bw->fc1_w, bw->fc1_b, hbuf, nullptr, 0, M2, p.Hd, D, TR_EPI_GELU_BF16, s));
     }
     if (drop_keep != nullptr) {      // timm Mlp: drop after the activation ...
@@ -776,7 +788,10 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
                                         static_cast<uint16_t*>(hbuf), p.mlp_sk_bytes ? ws + p.off_mlp_sk : nullptr, p.mlp_sk_bytes, M2, D, p.Hd,
                                         s));
       xn1_ready = hbuf;
-    } else if (fused_mlp)
+    } else if (fused_mlp && norm2_in_mlp)
+      TR_TRY(tr_mlp_fused_ln_bf16(x, static_cast<const uint16_t*>(pending_attn), bw->ln2_g, bw->ln2_b, cfg->ln_eps, bw->mlp_pk, bw->fc1_b,
+                                  static_cast<uint16_t*>(dbuf), p.mlp_sk_bytes ? ws + p.off_mlp_sk : nullptr, p.mlp_sk_bytes, M2, D, p.Hd, s));
+    else if (fused_mlp)
       TR_TRY(tr_mlp_fused_bf16(static_cast<const uint16_t*>(xn), bw->mlp_pk, bw->fc1_b, static_cast<uint16_t*>(dbuf),
                                p.mlp_sk_bytes ? ws + p.off_mlp_sk : nullptr, p.mlp_sk_bytes, M2, D, p.Hd, s));
     else
@@ -813,6 +828,20 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
   }
   TR_TRY(op_gemm(prec, xcls, w->head_w, w->head_b, logits, nullptr, 0, B, p.C, D, TR_EPI_F32, s));
   return TR_OK;
+}
+
+extern "C" int tr_vit_forward_status(const tr_vit_config* cfg, void* workspace, size_t workspace_bytes, int B, tr_stream_t s) {
+  Plan p;
+  TR_REQUIRE(make_plan(cfg, B, &p), TR_ERR_CONFIG, "tr_vit_forward_status: invalid config");
+  TR_REQUIRE(workspace != nullptr, TR_ERR_NULL, "tr_vit_forward_status: null workspace");
+  TR_REQUIRE(workspace_bytes >= p.total, TR_ERR_SHAPE, "tr_vit_forward_status: workspace of %zu bytes, tr_vit_workspace_bytes says %zu",
+             workspace_bytes, p.total);
+  if (p.mlp_sk_bytes == 0) {      // nothing on this executor keeps a device-side record: the stream's own state is the status
+    hipError_t e = hipStreamSynchronize(static_cast<hipStream_t>(s));
+    TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_vit_forward_status: %s", hipGetErrorString(e));
+    return TR_OK;
+  }
+  return tr_mlp_fused_status(static_cast<unsigned char*>(workspace) + p.off_mlp_sk, p.mlp_sk_bytes, p.D, p.Hd, s);
 }
 
 extern "C" int tr_vit_forward(const tr_vit_config* cfg, const tr_vit_weights* w, const float* img, float* logits, void* workspace,

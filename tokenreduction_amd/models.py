@@ -331,7 +331,12 @@ class VisionTransformer(nn.Module):
         if fused:
             self._run_fused_pack(fused, dev, state["moved"])
         self._mlp_pack_items = (mlp_items, D, Hd)
-        self._refresh_mlp_pack(dev)
+        if self.training:
+            # a repack from the training forward (every step of a non-fused optimizer, every accumulation micro-step): the train executor
+            # never reads the fragment-major Mlp copies -- 12 launches and ~56 MB per step for nothing; the next eval forward refreshes them
+            self._mlp_pk_stale = bool(mlp_items)
+        else:
+            self._refresh_mlp_pack(dev)
         cfg = _lib.TrVitConfig()
         cfg.family = self._family
         cfg.img_size, cfg.patch = self.patch_embed.img_size[0], self.patch_embed.patch_size[0]
@@ -541,6 +546,21 @@ class VisionTransformer(nn.Module):
             viz["Features"] = self._features(ws, B, list(tokens))
             return logits, viz
         return logits
+
+    def check_status(self):
+        """Status check of the eval forwards since the last call (tr_vit_forward_status): waits for the stream and raises RuntimeError if
+        the device recorded a failure that no launch status can show -- the fused Mlp's stream-K hand-over poll running out (the logits
+        of that forward are invalid).  The forward itself never synchronises; call this where the logits are consumed
+        (harness.evaluate_multiclass / validate and bench.py do)."""
+        ws = self.__dict__.get("_last_ws")
+        if not ws or "buf" not in ws or self._packed is None:
+            return
+        B = next((b for b, w in self._ws.items() if w is ws), None)
+        if B is None:
+            return
+        with torch.cuda.device(ws["buf"].device):
+            _lib.check(_lib.load().tr_vit_forward_status(C.byref(self._packed["cfg"]), ws["buf"].data_ptr(), ws["nbytes"], B,
+                                                         torch.cuda.current_stream().cuda_stream), "tr_vit_forward_status")
 
     def _viz_data(self, ws, B, tokens):
         return {}

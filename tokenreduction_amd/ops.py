@@ -91,7 +91,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, epilogue: int, ou
 
 def set_mlp_fused(mode: int) -> int:
     """Which Mlp the eval executor runs: 1 the fused launch wherever supported, 0 never, -1 (default) where its block schedule fills the chip
-    (tr_set_mlp_fused; the two are bit-identical).  Returns the previous mode."""
+    (tr_set_mlp_fused; the two are bit-identical).  Process-wide, read when the launches are enqueued: a captured hipGraph keeps the mode it
+    was captured with (drop `model._ws` to re-capture).  Returns the previous mode."""
     return int(_lib.load().tr_set_mlp_fused(int(mode)))
 
 
@@ -117,34 +118,91 @@ def mlp_pack(fc1_w: torch.Tensor, fc2_w: torch.Tensor, fc2_b: torch.Tensor) -> t
 _MLP_SCRATCH = {}
 
 
+def _mlp_scratch(dev, D, Hd, streamk=True):
+    """The stream-K hand-over scratch of a fused-Mlp launch on the CURRENT stream of `dev`: a scratch belongs to one launch at a time (its
+    counters are zeroed in front of every launch), so launches that may overlap -- other streams -- must not share one: cached per
+    (device, stream).  Returns (tensor | None, nbytes)."""
+    if not streamk:
+        return None, 0
+    nbytes = int(_lib.load().tr_mlp_fused_scratch_bytes(D, Hd))
+    if not nbytes:
+        return None, 0
+    with torch.cuda.device(dev):
+        key = (dev, torch.cuda.current_stream().cuda_stream, nbytes)
+    if key not in _MLP_SCRATCH:
+        _MLP_SCRATCH[key] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    return _MLP_SCRATCH[key], nbytes
+
+
 def mlp_fused(xn: torch.Tensor, packed: torch.Tensor, fc1_b: torch.Tensor, out: torch.Tensor = None, streamk: bool = True) -> torch.Tensor:
     """timm Mlp (fc1 -> GELU -> fc2, topk.py:95) of the eval forward in one launch: xn bf16 [M,D] -> bf16 [M,D]; bit-identical to
-    gemm(GELU_BF16) followed by gemm(BF16).  streamk: give the launch its hand-over scratch (beyond 256 blocks of 128 rows the steps are then
-    dealt evenly over the workgroups); False: whole blocks round-robin.  Same bits."""
+    gemm(GELU_BF16) followed by gemm(BF16).  streamk: give the launch its hand-over scratch (with more blocks of 128 rows than the device
+    has compute units the steps are then dealt evenly over the workgroups); False: whole blocks round-robin.  Same bits."""
     M, D = xn.shape
     Hd = fc1_b.numel()
     _same_device(xn, packed, fc1_b, out)
     if out is None:
         out = torch.empty(M, D, dtype=torch.bfloat16, device=xn.device)
-    lib = _lib.load()
-    scratch, nbytes = None, 0
-    if streamk:
-        nbytes = int(lib.tr_mlp_fused_scratch_bytes(D, Hd))
-        key = (xn.device, nbytes)
-        if nbytes and key not in _MLP_SCRATCH:
-            _MLP_SCRATCH[key] = torch.empty(nbytes, dtype=torch.uint8, device=xn.device)
-        scratch = _MLP_SCRATCH.get(key)
-    _lib.check(lib.tr_mlp_fused_bf16(_dev(xn, torch.bfloat16, "xn"), _dev(packed, torch.uint8, "packed"), _dev(fc1_b, torch.float32, "fc1_b"),
-                                     _dev(out, torch.bfloat16, "out"),
-                                     None if scratch is None else scratch.data_ptr(), nbytes if scratch is not None else 0, M, D, Hd, _stream(xn)),
+    scratch, nbytes = _mlp_scratch(xn.device, D, Hd, streamk)
+    _lib.check(_lib.load().tr_mlp_fused_bf16(_dev(xn, torch.bfloat16, "xn"), _dev(packed, torch.uint8, "packed"), _dev(fc1_b, torch.float32, "fc1_b"),
+                                             _dev(out, torch.bfloat16, "out"),
+                                             None if scratch is None else scratch.data_ptr(), nbytes, M, D, Hd, _stream(xn)),
                "tr_mlp_fused_bf16")
     return out
 
 
+def set_mlp_ln(mode: int) -> int:
+    """Where the eval executor runs a lazy norm2 INSIDE the fused Mlp launch that follows it (mlp_fused_ln) instead of as its own LayerNorm
+    launch -- the two are bit-identical: 1 (default) where that launch is one round of whole blocks, 2 wherever the fused Mlp runs, 0 never.
+    Process-wide, read when the launches are enqueued: a captured hipGraph keeps the form it was captured with (drop `model._ws` to
+    re-capture).  Returns the previous setting."""
+    return int(_lib.load().tr_set_mlp_ln(int(mode)))
+
+
+def mlp_fused_ln(x: torch.Tensor, delta: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, packed: torch.Tensor,
+                 fc1_b: torch.Tensor, out: torch.Tensor = None, streamk: bool = True) -> torch.Tensor:
+    """topk.py:95's `self.mlp(self.norm2(x))` in one launch: Mlp(LayerNorm(x + delta)) with x the fp32 stream [M,D] and delta the pending
+    bf16 attention residual [M,D] (neither is written) -> bf16 [M,D].  Bit-identical to layernorm2 (no write-back) followed by mlp_fused."""
+    M, D = x.shape
+    Hd = fc1_b.numel()
+    _same_device(x, delta, gamma, beta, packed, fc1_b, out)
+    if tuple(delta.shape) != (M, D) or not x.is_contiguous() or not delta.is_contiguous():
+        raise ValueError(f"mlp_fused_ln: x {tuple(x.shape)} and delta {tuple(delta.shape)} must be contiguous [M, D]")
+    if out is None:
+        out = torch.empty(M, D, dtype=torch.bfloat16, device=x.device)
+    scratch, nbytes = _mlp_scratch(x.device, D, Hd, streamk)
+    _lib.check(_lib.load().tr_mlp_fused_ln_bf16(_dev(x, torch.float32, "x"), _dev(delta, torch.bfloat16, "delta"), _dev(gamma, torch.float32, "gamma"),
+                                                _dev(beta, torch.float32, "beta"), float(eps), _dev(packed, torch.uint8, "packed"),
+                                                _dev(fc1_b, torch.float32, "fc1_b"), _dev(out, torch.bfloat16, "out"),
+                                                None if scratch is None else scratch.data_ptr(), nbytes, M, D, Hd, _stream(x)),
+               "tr_mlp_fused_ln_bf16")
+    return out
+
+
+def mlp_fused_status(dev=None, D: int = 384, Hd: int = 1536) -> None:
+    """Status check of the fused-Mlp launches of the current stream of `dev` that went through this module's scratch: waits for the stream and
+    raises if a stream-K hand-over poll ran out in one of them (tr_mlp_fused_status; the record is cleared)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if dev is None else torch.device(dev)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    scratch, nbytes = _mlp_scratch(dev, D, Hd, True)
+    if scratch is None:
+        return
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().tr_mlp_fused_status(scratch.data_ptr(), nbytes, D, Hd, torch.cuda.current_stream().cuda_stream),
+                   "tr_mlp_fused_status")
+
+
+def set_mlp_poll_max(iterations: int) -> int:
+    """Bound of the stream-K hand-over poll (iterations of an 8-tick sleep; default 2^24: seconds).  Tests shorten it.  Returns the previous bound."""
+    return int(_lib.load().tr_set_mlp_poll_max(int(iterations)))
+
+
 def set_mlp_resid_ln(on: bool) -> bool:
     """Whether the eval executor fuses the block tail (Mlp + residual add + the next block's norm1) into one launch where it can, or keeps
-    the fused Mlp and the LayerNorm launch apart (default: the one-launch form measured 4 % slower in the model).  Returns the previous
-    setting."""
+    the fused Mlp and the LayerNorm launch apart (default: the one-launch form measured 4 % slower in the model).  Process-wide, read when
+    the launches are enqueued: a captured hipGraph keeps the form it was captured with (drop `model._ws` to re-capture).  Returns the
+    previous setting."""
     return bool(_lib.load().tr_set_mlp_resid_ln(1 if on else 0))
 
 
@@ -160,17 +218,11 @@ def mlp_fused_resid_ln(xn: torch.Tensor, packed: torch.Tensor, fc1_b: torch.Tens
     if xn_next is None:
         xn_next = torch.empty(M, D, dtype=torch.bfloat16, device=xn.device)
     lib = _lib.load()
-    scratch, nbytes = None, 0
-    if streamk:
-        nbytes = int(lib.tr_mlp_fused_scratch_bytes(D, Hd))
-        key = (xn.device, nbytes)
-        if nbytes and key not in _MLP_SCRATCH:
-            _MLP_SCRATCH[key] = torch.empty(nbytes, dtype=torch.uint8, device=xn.device)
-        scratch = _MLP_SCRATCH.get(key)
+    scratch, nbytes = _mlp_scratch(xn.device, D, Hd, streamk)
     _lib.check(lib.tr_mlp_fused_resid_ln_bf16(_dev(xn, torch.bfloat16, "xn"), _dev(packed, torch.uint8, "packed"), _dev(fc1_b, torch.float32, "fc1_b"),
                                               _dev(fc2_b, torch.float32, "fc2_b"), _dev(x, torch.float32, "x"), _dev(next_g, torch.float32, "next_g"),
                                               _dev(next_b, torch.float32, "next_b"), float(eps), _dev(xn_next, torch.bfloat16, "xn_next"),
-                                              None if scratch is None else scratch.data_ptr(), nbytes if scratch is not None else 0, M, D, Hd,
+                                              None if scratch is None else scratch.data_ptr(), nbytes, M, D, Hd,
                                               _stream(xn)), "tr_mlp_fused_resid_ln_bf16")
     return xn_next
 

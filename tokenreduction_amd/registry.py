@@ -5,9 +5,10 @@ callers train.py:322-331, validate.py:88-94):
                  drop_block_rate=None, img_size=..., args=Namespace(keep_rate, reduction_loc, ...))
 
 Same factory names and fixed dims as models_act.py (tiny 192/3, small 384/6, base 768/12; depth 12,
-mlp_ratio 4, qkv_bias, LayerNorm eps 1e-6): deit_*_local[_viz], topk_*, evit_*, tome_*, dyvit_* (eval) and
-dyvit_*_teacher, sit_*, dpcknn_*, ats_*, sinkhorn_*, kmedoids_*, patchmerger_*, heuristic_*.  Unsupported options
-(training mode, distillation token, K-Medoids' numpy-seeded equal_weight branch) raise instead of silently falling back.
+mlp_ratio 4, qkv_bias, LayerNorm eps 1e-6): deit_*_local[_viz], topk_*, evit_*, tome_*, dyvit_* (eval and train) and
+dyvit_*_teacher, sit_*, dpcknn_*, ats_*, sinkhorn_*, kmedoids_* (both equal_weight branches), patchmerger_*, heuristic_*; every name
+runs in eval and in training mode.  What is not built raises instead of silently falling back: the distillation token (the reference's
+own forward fails for it), attn_drop_rate > 0, CPU tensors.
 """
 from __future__ import annotations
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Lab: the headline forward (and Top-K keep_rate 0.5) with the eval Mlp as two GEMM launches (fused 0), as the fused launch on the auto policy
-# followed by the LayerNorm launch (fused -1, tail 0), and with the fused block tail (Mlp + residual + next norm1 in one launch: tail 1, the
-# product default); twice round-robin on one box
+# followed by the LayerNorm launch (fused -1, tail 0: the library default), and with the fused block tail (Mlp + residual + next norm1 in one
+# launch: tail 1, OFF by default -- it lost 4 % in the model); twice round-robin on one box
 python - <<'PY'
 import os, sys, json, time
 sys.path.insert(0, os.getcwd())
