@@ -113,6 +113,22 @@ int tr_mlp_fused_bf16(const uint16_t* xn, const void* packed, const float* fc1_b
 int tr_set_mlp_ln(int mode);
 int tr_mlp_fused_ln_bf16(const float* x, const uint16_t* delta, const float* g, const float* b, float eps, const void* packed,
                          const float* fc1_b, uint16_t* out, void* scratch, size_t scratch_bytes, int M, int D, int Hd, tr_stream_t s);
+/* a3/a4, eval forward: the START of a block in one launch -- topk.py:86-87 `self.attn(self.norm1(x))` with :44 `self.qkv(x)`, and the previous
+ * block's pending residual adds folded in:  v = (x [+ d1]) [+ d2]  (fp32 stream row [M,D] + pending bf16 residuals [M,D], in that order:
+ * d1 = attention branch, d2 = Mlp branch of the previous block; d2 needs d1),  x_out[M,D] = v  (out of place, x_out != x; NULL exactly when
+ * d1 is NULL: nothing pending, nothing rewritten),  out bf16 [M,N] = LayerNorm(v; g, b, eps) . W^T + bias.
+ * Bit-identical to tr_layernorm_bf16 / tr_layernorm2_bf16 followed by tr_gemm_bf16(TR_EPI_BF16) -- and without the LayerNorm launch's
+ * 12-14 bytes per element at the memory roof: four of the kernel's twelve waves normalise the next 128-row block while the other eight
+ * multiply the current one (csrc/tr_lnlin.hip).  tr_lnlin_supported: D == 384, N %% 64 == 0, 128 <= N <= 4096.
+ * `packed`: W [N,D] (nn.Linear layout, bf16) in fragment-major order, tr_lnlin_pack_bytes(D,N) bytes, written by tr_lnlin_pack_bf16 (repack
+ * whenever W changes).  `scratch`: tr_lnlin_scratch_bytes(D,N) bytes for the current device (two 96-KiB row slots per compute unit), one
+ * launch at a time like tr_mlp_fused_bf16's. */
+int tr_lnlin_supported(int D, int N);
+size_t tr_lnlin_pack_bytes(int D, int N);
+size_t tr_lnlin_scratch_bytes(int D, int N);
+int tr_lnlin_pack_bf16(const uint16_t* W, void* packed, int D, int N, tr_stream_t s);
+int tr_lnlin_bf16(const float* x, const uint16_t* d1, const uint16_t* d2, float* x_out, const float* g, const float* b, float eps,
+                  const void* packed, const float* bias, uint16_t* out, void* scratch, size_t scratch_bytes, int M, int D, int N, tr_stream_t s);
 /* The tail of a block and the head of the next in ONE launch (topk.py:95 `x = x + self.mlp(self.norm2(x))`, then the next block's :87
  * `self.norm1(x)`):  x[M,D] (fp32 stream, already holding the attention branch's residual) += fc2(gelu(fc1(xn))) + fc2_b, IN PLACE, and
  * xn_next[M,D] (bf16, != xn) = LayerNorm(x; next_g, next_b, eps).  The kernel's fc2 wave owns whole rows in registers: its accumulator

@@ -252,6 +252,78 @@ def test_mlp_fused_on_a_smaller_grid(ops, tmp_path, grid, mode):
     assert out.returncode == 0 and "grid ok" in out.stdout, out.stdout[-1500:] + out.stderr[-3000:]
 
 
+# ------------------------------------------------------------------------------------------ LayerNorm + Linear in one launch (norm1 + qkv)
+@pytest.mark.parametrize("M,N,nd", [(1, 1152, 2), (77, 1152, 1), (129, 1152, 0), (1000, 1152, 2), (4321, 384, 2), (5000, 1536, 1), (17408, 1152, 2),
+                                    (24832 + 5, 1152, 2), (35328, 1152, 1), (50432, 1152, 2), (50432, 1152, 0), (3000, 128, 2)])
+def test_lnlin_is_bit_identical_to_layernorm_then_gemm(ops, M, N, nd):
+    """tr_lnlin_bf16 (topk.py:86-87 norm1 + :44 qkv, with the pending residual adds of the previous block) against the launches it
+    replaces -- tr_layernorm_bf16 / tr_layernorm2_bf16, then tr_gemm_bf16 -- BIT FOR BIT, outputs AND the rewritten stream: 0, 1 and 2
+    pending residuals; one row to the headline's stage sizes (ranges of steps that start and end inside blocks, blocks shared by two
+    workgroups, first blocks with a single step in a range); ragged last blocks; rows with |mean| >> std and a constant row; guard rows
+    behind every output; inputs unchanged."""
+    D = 384
+    rng = _rng(M * 13 + N + nd)
+    x = 2.0 * _randn(rng, M, D)
+    x[::7] += 300.0
+    if M > 3:
+        x[3] = 1.25
+    x = x.cuda()
+    d1 = _randn(rng, M, D).bfloat16().cuda() if nd >= 1 else None
+    d2 = _randn(rng, M, D).bfloat16().cuda() if nd >= 2 else None
+    w = _randn(rng, N, D, scale=0.05).bfloat16().cuda()
+    bias = _randn(rng, N, scale=0.1).cuda()
+    g, bt = (1.0 + 0.2 * _randn(rng, D)).cuda(), (0.1 * _randn(rng, D)).cuda()
+    x_before = x.clone()
+    xr = x.clone()
+    if nd == 0:
+        xn = ops.layernorm(xr, g, bt, 1e-6)
+    elif nd == 1:
+        xn = ops.layernorm(xr, g, bt, 1e-6, delta=d1)
+    else:
+        xn = ops.layernorm2(xr, g, bt, 1e-6, d1, d2)
+    want = ops.gemm(xn, w, bias, ops.TR_EPI_BF16)
+    pk = ops.lnlin_pack(w)
+    for it in range(2):
+        guard = torch.full((M + 3, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        got, x_out = ops.lnlin(x, g, bt, 1e-6, pk, bias, d1=d1, d2=d2, out=guard[:M])
+        diff = got.view(torch.int16) != want.view(torch.int16)
+        assert not bool(diff.any()), (f"launch {it}: {int(diff.sum())} of {got.numel()} outputs differ from LayerNorm + GEMM; rows "
+                                      f"{diff.any(dim=1).nonzero().flatten()[:8].tolist()}, columns {diff.any(dim=0).nonzero().flatten()[:8].tolist()}")
+        assert torch.isnan(guard[M:].float()).all(), "rows beyond M were written"
+        if nd:
+            assert torch.equal(x_out, xr), f"launch {it}: the rewritten stream differs in {int((x_out != xr).sum())} elements"
+        else:
+            assert x_out is None
+        assert torch.equal(x, x_before), "the input stream was written"
+
+
+def test_lnlin_repeated_launches_under_uneven_load(ops):
+    """Race screen (the launch hands rows from its LN waves to its MFMA waves through L2, refills registers in place and runs a 3-slot
+    LDS ring behind counted waits): 40 launches at the headline's first-stage shape, every third beside a copy kernel on a second
+    stream, outputs and stream compared with LayerNorm + GEMM each time."""
+    M, D, N = 50432, 384, 1152
+    rng = _rng(23)
+    x = (2.0 * _randn(rng, M, D)).cuda()
+    d1, d2 = _randn(rng, M, D).bfloat16().cuda(), _randn(rng, M, D).bfloat16().cuda()
+    w, bias = _randn(rng, N, D, scale=0.05).bfloat16().cuda(), _randn(rng, N, scale=0.1).cuda()
+    g, bt = (1.0 + 0.2 * _randn(rng, D)).cuda(), (0.1 * _randn(rng, D)).cuda()
+    xr = x.clone()
+    want = ops.gemm(ops.layernorm2(xr, g, bt, 1e-6, d1, d2), w, bias, ops.TR_EPI_BF16)
+    pk = ops.lnlin_pack(w)
+    side, junk = torch.cuda.Stream(), torch.empty(32 << 20, dtype=torch.uint8, device="cuda")
+    out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    bad = 0
+    for it in range(40):
+        out.fill_(float("nan"))
+        if it % 3 == 0:
+            with torch.cuda.stream(side):
+                junk.add_(1)
+        _, x_out = ops.lnlin(x, g, bt, 1e-6, pk, bias, d1=d1, d2=d2, out=out)
+        torch.cuda.synchronize()
+        bad += 0 if (torch.equal(out.view(torch.int16), want.view(torch.int16)) and torch.equal(x_out, xr)) else 1
+    assert bad == 0, f"{bad} of 40 launches differ from LayerNorm + GEMM"
+
+
 # ------------------------------------------------------------------------------------------ fused block tail: Mlp + residual + next norm1
 @pytest.mark.parametrize("M", [1, 77, 129, 1000, 24832, 257 * 128, 35328 + 3, 50432])
 def test_mlp_fused_resid_ln(ops, M):

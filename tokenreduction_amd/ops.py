@@ -198,6 +198,48 @@ def set_mlp_poll_max(iterations: int) -> int:
     return int(_lib.load().tr_set_mlp_poll_max(int(iterations)))
 
 
+_LNLIN_SCRATCH = {}
+
+
+def lnlin_pack(w: torch.Tensor) -> torch.Tensor:
+    """Fragment-major copy of an nn.Linear weight [N, 384] (bf16) for lnlin; repack whenever it changes."""
+    N, D = w.shape
+    lib = _lib.load()
+    n = int(lib.tr_lnlin_pack_bytes(D, N))
+    if n == 0:
+        raise ValueError(f"lnlin_pack: the LayerNorm + Linear kernel does not serve D={D}, N={N}")
+    pk = torch.empty(n, dtype=torch.uint8, device=w.device)
+    _lib.check(lib.tr_lnlin_pack_bf16(_dev(w, torch.bfloat16, "w"), pk.data_ptr(), D, N, _stream(w)), "tr_lnlin_pack_bf16")
+    return pk
+
+
+def lnlin(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, packed: torch.Tensor, bias: torch.Tensor,
+          d1: torch.Tensor = None, d2: torch.Tensor = None, out: torch.Tensor = None):
+    """The start of a block in one launch (topk.py:86-87 norm1 + :44 qkv): v = (x [+ d1]) [+ d2]; returns (out bf16 [M,N] =
+    LayerNorm(v) @ W^T + bias, x_out = v as a NEW fp32 tensor, or None when nothing was pending).  Bit-identical to layernorm / layernorm2
+    followed by gemm(TR_EPI_BF16)."""
+    M, D = x.shape
+    N = bias.numel()
+    _same_device(x, gamma, beta, packed, bias, d1, d2, out)
+    if not x.is_contiguous() or (d1 is not None and not d1.is_contiguous()) or (d2 is not None and not d2.is_contiguous()):
+        raise ValueError("lnlin: x, d1, d2 must be contiguous [M, D]")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    x_out = torch.empty_like(x) if d1 is not None else None
+    lib = _lib.load()
+    nbytes = int(lib.tr_lnlin_scratch_bytes(D, N))
+    with torch.cuda.device(x.device):
+        key = (x.device, torch.cuda.current_stream().cuda_stream, nbytes)
+    if key not in _LNLIN_SCRATCH:
+        _LNLIN_SCRATCH[key] = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    scratch = _LNLIN_SCRATCH[key]
+    _lib.check(lib.tr_lnlin_bf16(_dev(x, torch.float32, "x"), _opt(d1, torch.bfloat16, "d1"), _opt(d2, torch.bfloat16, "d2"),
+                                 None if x_out is None else x_out.data_ptr(), _dev(gamma, torch.float32, "gamma"), _dev(beta, torch.float32, "beta"),
+                                 float(eps), _dev(packed, torch.uint8, "packed"), _dev(bias, torch.float32, "bias"), _dev(out, torch.bfloat16, "out"),
+                                 scratch.data_ptr(), nbytes, M, D, N, _stream(x)), "tr_lnlin_bf16")
+    return out, x_out
+
+
 def set_mlp_resid_ln(on: bool) -> bool:
     """Whether the eval executor fuses the block tail (Mlp + residual add + the next block's norm1) into one launch where it can, or keeps
     the fused Mlp and the LayerNorm launch apart (default: the one-launch form measured 4 % slower in the model).  Process-wide, read when
