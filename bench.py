@@ -30,7 +30,18 @@ BATCH = 256
 MODEL = "topk_small_patch16_224"
 KEEP_RATE, REDUCTION_LOC = [0.7], [3, 6, 9]
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md chip table)
-FEED_CEILING_TFLOPS = 1045.0     # gemm_bf16_pc's K-loop ceiling from the L2->LDS feed (see roofline_from)
+def _in_kernel_clock_ghz(kernel="gemm_bf16_pc", default=2.0):
+    """The shader clock the kernel runs at INSIDE the headline forward, measured in the kernel (s_memtime / s_memrealtime,
+    tools/lab/clock_probe.py -> profiles/r06_clock.json): 2.0 GHz for gemm_bf16_pc, 2.1 GHz for mlp_fused_kernel on the box of round 6."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r06_clock.json")))["in_model_mhz"][kernel] / 1e3
+    except (OSError, KeyError, ValueError):
+        return default
+
+
+# gemm_bf16_pc's K-loop ceiling from the L2 -> LDS feed (see roofline_from): 85.3 FLOP per fed byte x 33 B/clk/CU x 256 CUs x the clock the
+# kernel is MEASURED to run at in the model (round 5 assumed 1.45 GHz from single-kernel lab stamps: 1045; measured in round 6: ~2.0 GHz)
+FEED_CEILING_TFLOPS = round(85.3 * 33.0 * 256 * _in_kernel_clock_ghz() / 1e3, 0)
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -137,10 +148,15 @@ def roofline_from(agg, full=False):
     if dom.startswith("gemm_bf16_pc"):
         # what bounds this kernel before the matrix pipes do (profiles/r01_gemm_lab.md): the K-loop of a 256 x 128 tile
         # feeds 48 KiB through the CU's L2 -> LDS path (~33 B/clk, measured with the DMA-only ablation) per 4.19 MFLOP = 85 FLOP per
-        # fed byte, and the chip sustains ~1.45 GHz under this load: 85.3 x 33 x 256 CUs x 1.45e9 = ~1045 TFLOP/s for the K-loop alone
-        roof["secondary_bound"] = dict(name="L2->LDS feed of the 256x128x64 tile at the sustained clock", ceiling=FEED_CEILING_TFLOPS,
+        # fed byte; at the in-kernel clock measured inside this forward (profiles/r06_clock.json) that is the ceiling below
+        roof["secondary_bound"] = dict(name="L2->LDS feed of the 256x128x64 tile at the measured in-kernel clock", ceiling=FEED_CEILING_TFLOPS,
                                        unit="TFLOP/s", frac=round(ach / FEED_CEILING_TFLOPS, 4),
-                                       basis="85.3 FLOP per fed byte x 33 B/clk/CU x 256 CUs x 1.45 GHz")
+                                       basis=f"85.3 FLOP per fed byte x 33 B/clk/CU x 256 CUs x {_in_kernel_clock_ghz():.2f} GHz (s_memtime / s_memrealtime "
+                                             "inside the kernel, profiles/r06_clock.json)")
+    if dom.startswith("mlp_fused_kernel") or dom.startswith("gemm_bf16_pc"):
+        ghz = _in_kernel_clock_ghz("mlp_fused_kernel" if dom.startswith("mlp") else "gemm_bf16_pc")
+        roof["in_kernel_clock_ghz"] = ghz
+        roof["frac_of_peak_at_that_clock"] = round(ach / (PEAK_BF16_TFLOPS * ghz / 2.4), 4)
     roof["share_of_step"] = round(a["ms"] / total_ms, 4)
     roof["traffic_source"] = "not collected for this config (PMC passes cover the headline config)"
     if not full:

@@ -559,6 +559,11 @@ typedef struct {
                                  sampling block: it SYNCHRONISES the stream there and cannot be captured in a hipGraph.  0 = static (default). */
 } tr_vit_config;
 
+/* Diagnostics (lab, tools/lab/clock_probe.py): the in-kernel clock probes of a library built with -DTR_DIAG_CLOCK -- {shader cycles, 100-MHz
+ * ticks, launches} of workgroup 8 of gemm_bf16_pc / mlp_fused_kernel since the last read (read and reset); all zero in a product build. */
+int tr_gemm_clock_probe_read(unsigned long long* out3);
+int tr_mlp_clock_probe_read(unsigned long long* out3);
+
 /* Bytes of workspace tr_vit_forward needs for batch B (0 on invalid config). */
 size_t tr_vit_workspace_bytes(const tr_vit_config* cfg, int B);
 /* Status check of the forwards that ran on `workspace` (the same cfg and B): waits for the stream and reports what only the device can

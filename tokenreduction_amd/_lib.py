@@ -92,6 +92,8 @@ SIGNATURES = {
     "tr_mlp_fused_status": (_i, [_vp, _sz, _i, _i, _vp]),
     "tr_set_mlp_ln": (_i, [_i]),
     "tr_mlp_fused_ln_bf16": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _sz, _i, _i, _i, _vp]),
+    "tr_gemm_clock_probe_read": (_i, [_vp]),
+    "tr_mlp_clock_probe_read": (_i, [_vp]),
     "tr_lnlin_supported": (_i, [_i, _i]),
     "tr_lnlin_pack_bytes": (_sz, [_i, _i]),
     "tr_lnlin_scratch_bytes": (_sz, [_i, _i]),

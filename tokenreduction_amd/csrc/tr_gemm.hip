@@ -27,6 +27,9 @@
 //     on 32 consecutive tiles (n fastest) at a time, so an activation row panel is fetched into that XCD's L2 once.
 #include "tr_common.h"
 
+// {shader cycles, 100-MHz ticks, launches} of gemm_bf16_pc workgroup 8 since the last tr_clock_probe_read: written by -DTR_DIAG_CLOCK builds only
+__device__ unsigned long long tr_gemm_clock_probe[3];
+
 namespace {
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
@@ -772,10 +775,12 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
     }
   }
 #ifdef TR_DIAG_CLOCK
-  if (bid == 8 && tid == 0) {   // diagnostic build only: shader clock = d(memtime) / d(memrealtime) * 100 MHz (lab allocates 4 B/elem)
-    unsigned long long* st = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(outp) + (size_t)out_bytes);
-    st[0] = __builtin_amdgcn_s_memtime() - ck0;
-    st[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+  // diagnostic build only (tools/lab/clock_probe.py): shader clock = d(s_memtime) / d(s_memrealtime) x 100 MHz of workgroup 8's K-loops, summed
+  // over the launches since the last read -- into a device symbol: no output buffer is touched, so the build runs inside the model
+  if (bid == 8 && tid == 0) {
+    atomicAdd(&tr_gemm_clock_probe[0], __builtin_amdgcn_s_memtime() - ck0);
+    atomicAdd(&tr_gemm_clock_probe[1], __builtin_amdgcn_s_memrealtime() - rt0);
+    atomicAdd(&tr_gemm_clock_probe[2], 1ull);
   }
 #endif
 #undef READ_FRAGS
@@ -882,5 +887,16 @@ extern "C" int tr_gemm_gelu_keep_bf16(const uint16_t* A, const uint16_t* W, cons
   hipLaunchKernelGGL(gemm_bf16_pc<EPI_GELU_KEEP>, dim3(256), dim3(768), 0, static_cast<hipStream_t>(s), A, W, bias, h, pre, M, N, K, nMt, nNt,
                      (unsigned)out_bytes);
   TR_CHECK_LAUNCH("tr_gemm_gelu_keep_bf16");
+  return TR_OK;
+}
+
+// lab (tools/lab/clock_probe.py): read and reset the in-kernel clock probes of a -DTR_DIAG_CLOCK build.  which 0: gemm_bf16_pc.  out[3] = {shader
+// cycles, 100-MHz ticks, launches}; all zero in a product build.
+extern "C" int tr_gemm_clock_probe_read(unsigned long long* out) {
+  TR_REQUIRE(out, TR_ERR_NULL, "tr_gemm_clock_probe_read: null pointer");
+  const unsigned long long zero[3] = {0ull, 0ull, 0ull};
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(tr_gemm_clock_probe), sizeof(zero));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(tr_gemm_clock_probe), zero, sizeof(zero));
+  TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_gemm_clock_probe_read: %s", hipGetErrorString(e));
   return TR_OK;
 }

@@ -29,6 +29,9 @@
 //   * FLOP per byte through the CU's L2 -> LDS feed: 128 (a 256 x 128 GEMM tile: 85); HBM traffic per 128 rows: 96 KB in, 96 KB out.
 #include "tr_common.h"
 
+// {shader cycles, 100-MHz ticks, launches} of mlp_fused_kernel workgroup 8 (its fc1 wave's step loop) since the last read: -DTR_DIAG_CLOCK builds only
+__device__ unsigned long long tr_mlp_clock_probe[3];
+
 namespace {
 
 // lab switches (tools/lab/build_variant.sh): TR_ABLATE_NO_DMA (no weight stream), TR_ABLATE_NO_GELU (identity activation), TR_ABLATE_NO_MFMA
@@ -107,6 +110,23 @@ typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
       st_[1] = __builtin_amdgcn_s_memrealtime() - rt0_;                                                                               \
     }                                                                                                                                 \
   } while (0)
+#elif defined(TR_DIAG_CLOCK)
+// (tools/lab/clock_probe.py: the same stamps summed into a device symbol -- no buffer is touched, so this build runs inside the model)
+#define MF_CLOCK_BEGIN const unsigned long long ck0_ = __builtin_amdgcn_s_memtime(), rt0_ = __builtin_amdgcn_s_memrealtime()
+#define MF_CLOCK_END                                                                                                                  \
+  do {                                                                                                                                \
+    if (bid == 8 && tid == 0) {                                                                                                       \
+      atomicAdd(&tr_mlp_clock_probe[0], __builtin_amdgcn_s_memtime() - ck0_);                                                         \
+      atomicAdd(&tr_mlp_clock_probe[1], __builtin_amdgcn_s_memrealtime() - rt0_);                                                     \
+      atomicAdd(&tr_mlp_clock_probe[2], 1ull);                                                                                        \
+    }                                                                                                                                 \
+  } while (0)
+#define MF_STAMP(k) do { } while (0)
+#define MF_STAMP_DECL do { } while (0)
+#define MF_STAMP_DUMP(role, step) do { } while (0)
+#define MF_ESTAMP(k) do { } while (0)
+#define MF_ESTAMP_DECL do { } while (0)
+#define MF_ESTAMP_DUMP do { } while (0)
 #else
 #define MF_CLOCK_BEGIN do { } while (0)
 #define MF_CLOCK_END do { } while (0)
@@ -1217,4 +1237,15 @@ extern "C" int tr_mlp_fused_status(void* scratch, size_t scratch_bytes, int D, i
              "fused Mlp: workgroup %u waited in vain for its predecessor's accumulator (stream-K hand-over poll ran out): the outputs of that "
              "launch are invalid", host[1] - 1u);
   return TR_ERR_LAUNCH;
+}
+
+// lab (tools/lab/clock_probe.py): read and reset the in-kernel clock probe of a -DTR_DIAG_CLOCK build: out[3] = {shader cycles, 100-MHz ticks,
+// launches} of mlp_fused_kernel's workgroup 8; all zero in a product build.
+extern "C" int tr_mlp_clock_probe_read(unsigned long long* out) {
+  TR_REQUIRE(out, TR_ERR_NULL, "tr_mlp_clock_probe_read: null pointer");
+  const unsigned long long zero[3] = {0ull, 0ull, 0ull};
+  hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(tr_mlp_clock_probe), sizeof(zero));
+  if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(tr_mlp_clock_probe), zero, sizeof(zero));
+  TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_mlp_clock_probe_read: %s", hipGetErrorString(e));
+  return TR_OK;
 }

@@ -28,7 +28,15 @@ constexpr int PE_LDS = 2 * (PE_A_BYTES + PE_W_BYTES);
 static_assert(PE_LDS >= PE_ROWS * PE_STAGE_LD, "the epilogue staging image reuses the operand ring");
 constexpr int PE_ITEMS = 7;                 // float4 loads per thread and K-step (208 rows x 16 / 512 = 6.5)
 
-__device__ __forceinline__ int pswz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int pswz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }      // W slabs (written by LDS-DMA)
+// The A image (fp32 pixels -> bf16, written by ds_write_b64) has a swizzle of its own.  A 16-lane store group holds four consecutive rows x
+// the four float4 of a 16-pixel run, i.e. the 32-byte chunk PAIR {2 r, 2 r + 1} of four rows: with the ring's (row >> 1) & 7 those four rows
+// land on one pair of the 128-byte bank window -- 4-way conflicts on every store (27.7 % of the kernel's LDS cycles, r05 SQ counters;
+// tools/lds_sim.py: 16 cycles per wave-instruction, 4 without).  XOR 2 (row & 3) moves the four rows to four pairs; the per-quad term
+// keeps the fragment reads (16 rows x 4 chunks per ds_read_b128, banks mod 64) conflict-free.  Same bits out: only where a value sits.
+__device__ __forceinline__ int aswz(int row, int chunk) {
+  return row * 128 + ((chunk ^ ((2 * (row & 3)) ^ ((0x1320 >> (4 * ((row >> 2) & 3))) & 3))) << 4);      // quad term {0, 2, 3, 1}
+}
 
 __device__ __forceinline__ void dma_piece(const uint16_t* sbase, unsigned voff, unsigned lds_dst) {
   asm volatile(
@@ -70,7 +78,7 @@ __global__ __launch_bounds__(512, 1) void patch_embed_kernel(const float* __rest
     const int p = min(p0 + m, P - 1);
     const int py = p / gw, px = p - py * gw;
     aoff[it] = (unsigned)((py * 16 + min(r, 3)) * HW + px * 16 + q * 4);
-    adst[it] = live ? pswz(m, 2 * r + (q >> 1)) + (q & 1) * 8 : -1;
+    adst[it] = live ? aswz(m, 2 * r + (q >> 1)) + (q & 1) * 8 : -1;
   }
   // rows of the chunk past the last patch: zero operand rows in both slots (never written again)
   for (int i = tid; i < (PE_ROWS - rows) * 8 * 2; i += 512) {
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(512, 1) void patch_embed_kernel(const float* __rest
       for (int j = 0; j < 3; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(w + pswz(16 * (wave + 8 * j) + li, 4 * ks + g));
 #pragma unroll
       for (int i = 0; i < PE_RB; ++i) {
-        const bf16x8 af = *reinterpret_cast<const bf16x8*>(a + pswz(16 * i + li, 4 * ks + g));
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(a + aswz(16 * i + li, 4 * ks + g));
 #pragma unroll
         for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af, acc[i][j], 0, 0, 0);
       }

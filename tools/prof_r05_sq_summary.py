@@ -40,6 +40,12 @@ def read(path):
     return acc, ids, dur
 
 
+# measured in-kernel clocks (tools/lab/clock_probe.py -> profiles/r06_clock.json), by kernel name
+CLOCKS = {}
+_cj = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r06_clock.json")
+if os.path.exists(_cj):
+    for name, v in json.load(open(_cj)).get("in_model_mhz", {}).items():
+        CLOCKS[name] = v
 acc, ids, dur = read(path_a)
 accb, idsb, _ = read(path_b)
 total = sum(dur.values()) or 1.0
@@ -52,13 +58,19 @@ for k, c in acc.items():
     cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / n / 8.0                     # chip cycles per launch
     mfma = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / n
     wave = c.get("SQ_WAVE_CYCLES", 0.0)
+    # GRBM_GUI_ACTIVE / 8 / wall is NOT a clock for launches this short (MI355X_MICROARCH.md, DVFS: "reads high on dispatches shorter than
+    # about 0.3 ms" -- round 5 printed 2.3-15.8 GHz from it): it is kept as what it is, the counter per microsecond, and nothing is derived
+    # from it.  Busy fractions are given against the launch's wall time at the nominal 2.4 GHz (the clock the 2.5 PFLOP/s peak is quoted
+    # on: the roofline fraction of a pure-MFMA kernel) and, where tools/lab/clock_probe.py measured the kernel's own clock
+    # (profiles/r06_clock.json: s_memtime / s_memrealtime inside the kernel), against the cycles the launch really had.
+    mhz = CLOCKS.get(k.split("<")[0])
     row = dict(launches_profiled=n, share_of_gpu_time=round(dur[k] / total, 4), avg_us_under_pmc=round(us, 1),
-               clock_mhz_under_pmc=round(cyc / us) if us else None,
-               # fraction of the launch during which a SIMD's matrix pipe is busy: at the clock the launch actually ran at, and at the
-               # 2.4 GHz the 2.5 PFLOP/s peak is quoted on (the second is the roofline fraction of a pure bf16-MFMA kernel)
-               mfma_busy_frac=round(mfma / (1024 * cyc), 4) if cyc else None,
+               grbm_gui_active_per_us=round(cyc / us) if us else None,
+               in_kernel_clock_mhz=mhz,
+               mfma_busy_frac=round(mfma / (1024 * us * mhz), 4) if (us and mhz) else None,
                mfma_busy_frac_at_2p4ghz=round(mfma / (1024 * us * 1e-6 * 2.4e9), 4) if us else None,
-               lds_busy_frac=round(c.get("SQ_LDS_IDX_ACTIVE", 0.0) / n / (256 * cyc), 4) if cyc else None)
+               lds_busy_frac_at_2p4ghz=round(c.get("SQ_LDS_IDX_ACTIVE", 0.0) / n / (256 * us * 1e-6 * 2.4e9), 4) if us else None,
+               lds_busy_frac=round(c.get("SQ_LDS_IDX_ACTIVE", 0.0) / n / (256 * us * mhz), 4) if (us and mhz) else None)
     if c.get("SQ_LDS_IDX_ACTIVE"):
         row["lds_bank_conflict_frac"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 4)
     if wave:
@@ -69,13 +81,9 @@ for k, c in acc.items():
         wb = cb["SQ_WAVE_CYCLES"]
         row.update(valu_inst_frac=round(cb.get("SQ_ACTIVE_INST_VALU", 0.0) / wb, 3), lds_inst_frac=round(cb.get("SQ_ACTIVE_INST_LDS", 0.0) / wb, 3),
                    vmem_inst_frac=round(cb.get("SQ_ACTIVE_INST_VMEM", 0.0) / wb, 3), salu_inst_frac=round(cb.get("SQ_ACTIVE_INST_SCA", 0.0) / wb, 3))
-        nb = len(idsb[k]) or 1
-        cycb = cb.get("GRBM_GUI_ACTIVE", 0.0) / nb / 8.0
-        if cycb and cb.get("SQ_BUSY_CYCLES"):
-            row["sq_busy_frac"] = round(cb["SQ_BUSY_CYCLES"] / nb / (cycb * 8 * 32), 3)        # uncalibrated: per-SE sum assumed
     out[k] = row
 os.makedirs(outdir, exist_ok=True)
 json.dump(out, open(os.path.join(outdir, f"{tag}_pmc_sq_{workload}.json"), "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["share_of_gpu_time"]):
-    print(f"{k[:44]:44s} {100 * v['share_of_gpu_time']:5.1f}%  {v['avg_us_under_pmc']:8.1f} us  mfma {v['mfma_busy_frac']}  lds {v['lds_busy_frac']}  "
+    print(f"{k[:44]:44s} {100 * v['share_of_gpu_time']:5.1f}%  {v['avg_us_under_pmc']:8.1f} us  mfma@2.4GHz {v['mfma_busy_frac_at_2p4ghz']}  mfma@own clock {v['mfma_busy_frac']}  lds {v['lds_busy_frac_at_2p4ghz']}  "
           f"valu {v.get('valu_inst_frac')}  wait_any {v.get('wait_any_frac')}  wait_inst {v.get('wait_inst_frac')}")

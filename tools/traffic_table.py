@@ -116,7 +116,11 @@ def main():
             if sq_tag:
                 sf = os.path.join(ROOT, "profiles", f"{sq_tag}_pmc_sq_{w}.json")
                 rec = json.load(open(sf)).get(name) if os.path.exists(sf) else None
-                sq = (f" {100 * rec['mfma_busy_frac']:.0f} % | {100 * rec['lds_busy_frac']:.0f} % | {100 * rec['valu_inst_frac']:.0f} % | "
+                # busy fractions at the nominal 2.4 GHz (round 5's files carry them under the clock-dependent names only)
+                if rec:
+                    mf = rec.get("mfma_busy_frac_at_2p4ghz", rec.get("mfma_busy_frac")) or 0.0
+                    ld = rec.get("lds_busy_frac_at_2p4ghz", rec.get("lds_busy_frac")) or 0.0
+                sq = (f" {100 * mf:.0f} % | {100 * ld:.0f} % | {100 * rec['valu_inst_frac']:.0f} % | "
                       f"{100 * rec['wait_inst_frac']:.0f} % |") if rec else " | | | |"
             print(f"| {w} | `{name}` | {v['avg_us']:.1f} | {a / 1e6:.1f} | {m / 1e6:.1f} ({v['fetch_bytes_per_launch'] / 1e6:.1f} + "
                   f"{v['write_bytes_per_launch'] / 1e6:.1f}) | {r:.2f} | {v['hbm_gbps']:.0f} |" + sq)
