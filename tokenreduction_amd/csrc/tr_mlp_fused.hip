@@ -252,7 +252,8 @@ __device__ __forceinline__ MfCur mf_next(const MfSeq& q, const MfCur& c, int NS)
 
 constexpr int MF_SK_SLOT = 4 * MF_NI * 2 * 1024;     // one workgroup's published accumulator: 4 C waves x 48 fragments x 1 KiB = 192 KiB
 constexpr int MF_SK_CNT = 128;                       // bytes per counter (its own line)
-constexpr int MF_SK_ERR = 128;                       // behind the counters: the error record of a hand-over poll that ran out (magic, workgroup + 1)
+constexpr int MF_SK_ERR = 128;                       // behind the slots: the error record of a hand-over poll that ran out (magic, workgroup + 1)
+constexpr int MF_SK_SETS = 32;                       // counter sets behind that (one per launch of a forward: TR_MAX_DEPTH), each one line per workgroup
 constexpr unsigned MF_SK_ERR_MAGIC = 0x4d46534bu;    // "MFSK"
 
 // RL ("residual + LayerNorm" tail of a transformer block, topk.py:95 followed by the next block's :87 norm1): the C wave's accumulator starts at
@@ -288,7 +289,7 @@ template <bool RL, bool NP>
 __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __restrict__ xn, const unsigned char* __restrict__ pk,
                                                            const float* __restrict__ b1,
                                                            uint16_t* __restrict__ outp, unsigned char* __restrict__ scratch, int M, int NS,
-                                                           unsigned out_bytes, int poll_max, const MfResid rl, const MfNorm nm) {
+                                                           unsigned out_bytes, int poll_max, int cset, const MfResid rl, const MfNorm nm) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[MF_LDS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -702,8 +703,11 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
   // after its own vmcnt(0); the consumer polls with an sc1 load, passes a workgroup barrier, then reads with sc1 loads; whole 128-byte lines
   // per store instruction, 16-byte accesses)
   const __amdgpu_buffer_rsrc_t sk_out = __builtin_amdgcn_make_buffer_rsrc(scratch + (size_t)bid * MF_SK_SLOT, 0, MF_SK_SLOT, 0x00020000);
-  unsigned* const sk_cnt_out = reinterpret_cast<unsigned*>(scratch + (size_t)G * MF_SK_SLOT + (size_t)bid * MF_SK_CNT);
-  unsigned* const sk_cnt_in = reinterpret_cast<unsigned*>(scratch + (size_t)G * MF_SK_SLOT + (size_t)(bid > 0 ? bid - 1 : 0) * MF_SK_CNT);
+  // (scratch layout: G accumulator slots | the error record | MF_SK_SETS counter sets of G lines: a launch uses set `cset`, so that ONE memset
+  // in front of a forward serves all of its launches)
+  unsigned char* const sk_cnt0 = scratch + (size_t)G * MF_SK_SLOT + MF_SK_ERR + (size_t)cset * G * MF_SK_CNT;
+  unsigned* const sk_cnt_out = reinterpret_cast<unsigned*>(sk_cnt0 + (size_t)bid * MF_SK_CNT);
+  unsigned* const sk_cnt_in = reinterpret_cast<unsigned*>(sk_cnt0 + (size_t)(bid > 0 ? bid - 1 : 0) * MF_SK_CNT);
   // One time step t >= 2: consumes the hidden fragments of number t-2 (in h0, h1 on entry) and the W2 half of entry t: windows 0..4, the barrier,
   // then -- on registers -- window 5, under which the next step's hidden and weight fragments arrive.
   // fin: number t-2 was its segment's last step -- 1: the block is complete (epilogue), 2: a head segment (publish the accumulator);
@@ -997,7 +1001,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
           // the launch goes on (on whatever the slot holds) and SAYS so: the error record behind the counters -- a magic word and the
           // workgroup -- is what tr_mlp_fused_status / tr_vit_forward_status turn into TR_ERR_LAUNCH at the caller's next status check.
           // (A trap here would take the whole process down, also under a CU mask or GPU sharing where the wait is merely long.)
-          unsigned* err = reinterpret_cast<unsigned*>(scratch + (size_t)G * (MF_SK_SLOT + MF_SK_CNT));
+          unsigned* err = reinterpret_cast<unsigned*>(scratch + (size_t)G * MF_SK_SLOT);
           int who = bid + 1;
           asm volatile("" : "+s"(who));        // formed HERE: as a loop invariant it is parked in a VGPR through the step loop, which has none to spare (one spill)
           __hip_atomic_store(err + 1, (unsigned)who, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1125,7 +1129,7 @@ extern "C" size_t tr_mlp_pack_bytes(int D, int Hd) {
 }
 
 extern "C" size_t tr_mlp_fused_scratch_bytes(int D, int Hd) {
-  return tr_mlp_fused_supported(D, Hd) ? (size_t)mf_grid() * (MF_SK_SLOT + MF_SK_CNT) + MF_SK_ERR : 0;
+  return tr_mlp_fused_supported(D, Hd) ? (size_t)mf_grid() * (MF_SK_SLOT + (size_t)MF_SK_SETS * MF_SK_CNT) + MF_SK_ERR : 0;
 }
 
 extern "C" int tr_mlp_pack_bf16(const uint16_t* fc1_w, const uint16_t* fc2_w, const float* fc2_b, void* packed, int D, int Hd, tr_stream_t s) {
@@ -1140,8 +1144,11 @@ extern "C" int tr_mlp_pack_bf16(const uint16_t* fc1_w, const uint16_t* fc2_w, co
   return TR_OK;
 }
 
+// cset >= 0: the launch uses counter set cset, which the caller has zeroed (tr_mlp_fused_zero_counters: one memset for a whole forward);
+// cset < 0: set 0, zeroed here by a memset node in front of the kernel
 static int mlp_fused_launch(const char* who, const uint16_t* xn, const void* packed, const float* fc1_b, uint16_t* out, void* scratch,
-                            size_t scratch_bytes, int M, int D, int Hd, const MfResid* rl, const MfNorm* nm, tr_stream_t s) {
+                            size_t scratch_bytes, int M, int D, int Hd, const MfResid* rl, const MfNorm* nm, tr_stream_t s, int cset = -1) {
+  TR_REQUIRE(cset < MF_SK_SETS, TR_ERR_CONFIG, "%s: counter set %d of %d", who, cset, MF_SK_SETS);
   TR_REQUIRE((xn || nm) && packed && fc1_b && out, TR_ERR_NULL, "%s: null pointer", who);
   TR_REQUIRE(M > 0 && tr_mlp_fused_supported(D, Hd), TR_ERR_SHAPE, "%s: unsupported shape M=%d D=%d Hd=%d (D must be %d, Hd %% 32 == 0)", who, M, D, Hd,
              MF_D);
@@ -1162,25 +1169,26 @@ static int mlp_fused_launch(const char* who, const uint16_t* xn, const void* pac
   const int G = nblk < grid ? nblk : grid;
   hipStream_t st = static_cast<hipStream_t>(s);
   unsigned char* sk = (nblk > G) ? static_cast<unsigned char*>(scratch) : nullptr;
-  if (sk != nullptr) {
+  if (sk != nullptr && cset < 0) {
     // the hand-over counters of this launch (one line per workgroup, behind the accumulator slots) start at zero: a memset node ahead of the
-    // kernel node (graph-capturable; a counter that the last consumer reset would fail a first, poisoned launch).  The error record behind
-    // them is NOT touched: it stays until tr_mlp_fused_status reads it.
-    hipError_t e = hipMemsetAsync(sk + (size_t)G * MF_SK_SLOT, 0, (size_t)G * MF_SK_CNT, st);
+    // kernel node (graph-capturable; a counter that the last consumer reset would fail a first, poisoned launch).  The error record in
+    // front of them is NOT touched: it stays until tr_mlp_fused_status reads it.
+    hipError_t e = hipMemsetAsync(sk + (size_t)G * MF_SK_SLOT + MF_SK_ERR, 0, (size_t)G * MF_SK_CNT, st);
     TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "%s: hipMemsetAsync: %s", who, hipGetErrorString(e));
   }
+  const int set = cset < 0 ? 0 : cset;
   const int poll_max = g_mlp_poll_max.load(std::memory_order_relaxed);
   const MfResid no_rl{nullptr, nullptr, nullptr, nullptr, 0.f};
   const MfNorm no_nm{nullptr, nullptr, nullptr, nullptr, 0.f};
   if (rl)
     hipLaunchKernelGGL((mlp_fused_kernel<true, false>), dim3(G), dim3(512), 0, st, xn, static_cast<const unsigned char*>(packed), fc1_b, out, sk, M,
-                       Hd / 32, (unsigned)out_bytes, poll_max, *rl, no_nm);
+                       Hd / 32, (unsigned)out_bytes, poll_max, set, *rl, no_nm);
   else if (nm)
     hipLaunchKernelGGL((mlp_fused_kernel<false, true>), dim3(G), dim3(512), 0, st, xn, static_cast<const unsigned char*>(packed), fc1_b, out, sk, M,
-                       Hd / 32, (unsigned)out_bytes, poll_max, no_rl, *nm);
+                       Hd / 32, (unsigned)out_bytes, poll_max, set, no_rl, *nm);
   else
     hipLaunchKernelGGL((mlp_fused_kernel<false, false>), dim3(G), dim3(512), 0, st, xn, static_cast<const unsigned char*>(packed), fc1_b, out, sk, M,
-                       Hd / 32, (unsigned)out_bytes, poll_max, no_rl, no_nm);
+                       Hd / 32, (unsigned)out_bytes, poll_max, set, no_rl, no_nm);
   TR_CHECK_LAUNCH(who);
   return TR_OK;
 }
@@ -1225,7 +1233,7 @@ extern "C" int tr_mlp_fused_status(void* scratch, size_t scratch_bytes, int D, i
   TR_REQUIRE(tr_mlp_fused_supported(D, Hd) && scratch_bytes >= tr_mlp_fused_scratch_bytes(D, Hd), TR_ERR_SHAPE,
              "tr_mlp_fused_status: scratch of %zu bytes, tr_mlp_fused_scratch_bytes says %zu", scratch_bytes, tr_mlp_fused_scratch_bytes(D, Hd));
   hipStream_t st = static_cast<hipStream_t>(s);
-  unsigned char* rec = static_cast<unsigned char*>(scratch) + (size_t)mf_grid() * (MF_SK_SLOT + MF_SK_CNT);
+  unsigned char* rec = static_cast<unsigned char*>(scratch) + (size_t)mf_grid() * MF_SK_SLOT;
   unsigned host[2] = {0u, 0u};
   hipError_t e = hipMemcpyAsync(host, rec, sizeof(host), hipMemcpyDeviceToHost, st);
   if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -1248,4 +1256,35 @@ extern "C" int tr_mlp_clock_probe_read(unsigned long long* out) {
   if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(tr_mlp_clock_probe), zero, sizeof(zero));
   TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_mlp_clock_probe_read: %s", hipGetErrorString(e));
   return TR_OK;
+}
+
+// ---- the executor's forms (tr_vit.hip; C++ linkage, not part of the C ABI): ONE memset in front of a forward zeroes the counter sets of all
+// its fused-Mlp launches (launch i uses set i) instead of a memset node in front of every launch -- five nodes of ~5 us fewer in the
+// headline forward.  nsets <= MF_SK_SETS (= TR_MAX_DEPTH).
+int tr_mlp_fused_zero_counters(void* scratch, size_t scratch_bytes, int D, int Hd, int nsets, tr_stream_t s) {
+  TR_REQUIRE(scratch && scratch_bytes >= tr_mlp_fused_scratch_bytes(D, Hd) && nsets >= 1 && nsets <= MF_SK_SETS, TR_ERR_SHAPE,
+             "tr_mlp_fused_zero_counters: scratch of %zu bytes / %d sets", scratch_bytes, nsets);
+  const int G = mf_grid();
+  hipError_t e = hipMemsetAsync(static_cast<unsigned char*>(scratch) + (size_t)G * MF_SK_SLOT + MF_SK_ERR, 0, (size_t)nsets * G * MF_SK_CNT,
+                                static_cast<hipStream_t>(s));
+  TR_REQUIRE(e == hipSuccess, TR_ERR_LAUNCH, "tr_mlp_fused_zero_counters: hipMemsetAsync: %s", hipGetErrorString(e));
+  return TR_OK;
+}
+int tr_mlp_fused_bf16_set(const uint16_t* xn, const void* packed, const float* fc1_b, uint16_t* out, void* scratch, size_t scratch_bytes, int M, int D,
+                          int Hd, int cset, tr_stream_t s) {
+  TR_REQUIRE(xn, TR_ERR_NULL, "tr_mlp_fused_bf16: null pointer");
+  return mlp_fused_launch("tr_mlp_fused_bf16", xn, packed, fc1_b, out, scratch, scratch_bytes, M, D, Hd, nullptr, nullptr, s, cset);
+}
+int tr_mlp_fused_ln_bf16_set(const float* x, const uint16_t* delta, const float* g, const float* b, float eps, const void* packed, const float* fc1_b,
+                             uint16_t* out, void* scratch, size_t scratch_bytes, int M, int D, int Hd, int cset, tr_stream_t s) {
+  TR_REQUIRE(x && delta && g && b, TR_ERR_NULL, "tr_mlp_fused_ln_bf16: null pointer");
+  const MfNorm nm{x, delta, g, b, eps};
+  return mlp_fused_launch("tr_mlp_fused_ln_bf16", nullptr, packed, fc1_b, out, scratch, scratch_bytes, M, D, Hd, nullptr, &nm, s, cset);
+}
+int tr_mlp_fused_resid_ln_bf16_set(const uint16_t* xn, const void* packed, const float* fc1_b, const float* fc2_b, float* x, const float* next_g,
+                                   const float* next_b, float eps, uint16_t* xn_next, void* scratch, size_t scratch_bytes, int M, int D, int Hd,
+                                   int cset, tr_stream_t s) {
+  TR_REQUIRE(xn && fc2_b && x && next_g && next_b && xn_next != xn, TR_ERR_NULL, "tr_mlp_fused_resid_ln_bf16: null or aliased pointer");
+  const MfResid rl{x, fc2_b, next_g, next_b, eps};
+  return mlp_fused_launch("tr_mlp_fused_resid_ln_bf16", xn, packed, fc1_b, xn_next, scratch, scratch_bytes, M, D, Hd, &rl, nullptr, s, cset);
 }

@@ -122,6 +122,15 @@ extern "C" int tr_version(void) { return 100; }
 
 int tr_mlp_fused_wanted(int M, int D, int Hd, int have_scratch);      // tr_mlp_fused.hip: the schedule policy behind tr_set_mlp_fused
 int tr_mlp_resid_ln_enabled();                                        // tr_mlp_fused.hip: tr_set_mlp_resid_ln's switch
+// ... and its launches on a counter set that ONE memset in front of the forward has zeroed (block i uses set i)
+int tr_mlp_fused_zero_counters(void* scratch, size_t scratch_bytes, int D, int Hd, int nsets, tr_stream_t s);
+int tr_mlp_fused_bf16_set(const uint16_t* xn, const void* packed, const float* fc1_b, uint16_t* out, void* scratch, size_t scratch_bytes, int M, int D,
+                          int Hd, int cset, tr_stream_t s);
+int tr_mlp_fused_ln_bf16_set(const float* x, const uint16_t* delta, const float* g, const float* b, float eps, const void* packed, const float* fc1_b,
+                             uint16_t* out, void* scratch, size_t scratch_bytes, int M, int D, int Hd, int cset, tr_stream_t s);
+int tr_mlp_fused_resid_ln_bf16_set(const uint16_t* xn, const void* packed, const float* fc1_b, const float* fc2_b, float* x, const float* next_g,
+                                   const float* next_b, float eps, uint16_t* xn_next, void* scratch, size_t scratch_bytes, int M, int D, int Hd,
+                                   int cset, tr_stream_t s);
 int tr_mlp_ln_wanted(int M, int D, int Hd, int have_scratch);         // tr_mlp_fused.hip: ... with the norm2 in front of it inside the launch (tr_set_mlp_ln)
 
 namespace {
@@ -335,6 +344,11 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
     drop_keep += (size_t)B * p.N0 * D;
   }
 
+  // the stream-K hand-over counters of every fused-Mlp launch of this forward (block i: set i) start at zero: ONE memset node here instead
+  // of one in front of each launch
+  static const bool memset_each = [] { const char* e = getenv("TR_MLP_MEMSET_EACH"); return e && atoi(e) != 0; }();      // lab: A/B switch (a memset node per launch)
+  const bool one_memset = !train && prec == TR_PREC_BF16 && p.mlp_sk_bytes > 0 && w->blocks[0].mlp_pk != nullptr && !memset_each;
+  if (one_memset) TR_TRY(tr_mlp_fused_zero_counters(ws + p.off_mlp_sk, p.mlp_sk_bytes, D, p.Hd, cfg->depth, s));
   int N = p.N0;
   const void* pending = nullptr;   // residual not yet added to x (the previous block's fc2 output)
   const float* policy_cur = nullptr;      // DyViT training: the keep policy every block attends under (all ones before the first stage)
@@ -784,16 +798,16 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
     const bool fused_tail = fused_mlp && rl_base && pending_attn == nullptr && i + 1 < cfg->depth && starts_plain(i + 1);
     if (fused_tail) {
       const tr_block_weights* nb = &w->blocks[i + 1];
-      TR_TRY(tr_mlp_fused_resid_ln_bf16(static_cast<const uint16_t*>(xn), bw->mlp_pk, bw->fc1_b, bw->fc2_b, x, nb->ln1_g, nb->ln1_b, cfg->ln_eps,
-                                        static_cast<uint16_t*>(hbuf), p.mlp_sk_bytes ? ws + p.off_mlp_sk : nullptr, p.mlp_sk_bytes, M2, D, p.Hd,
-                                        s));
+      TR_TRY(tr_mlp_fused_resid_ln_bf16_set(static_cast<const uint16_t*>(xn), bw->mlp_pk, bw->fc1_b, bw->fc2_b, x, nb->ln1_g, nb->ln1_b, cfg->ln_eps,
+                                            static_cast<uint16_t*>(hbuf), p.mlp_sk_bytes ? ws + p.off_mlp_sk : nullptr, p.mlp_sk_bytes, M2, D, p.Hd,
+                                            one_memset ? i : -1, s));
       xn1_ready = hbuf;
     } else if (fused_mlp && norm2_in_mlp)
-      TR_TRY(tr_mlp_fused_ln_bf16(x, static_cast<const uint16_t*>(pending_attn), bw->ln2_g, bw->ln2_b, cfg->ln_eps, bw->mlp_pk, bw->fc1_b,
-                                  static_cast<uint16_t*>(dbuf), p.mlp_sk_bytes ? ws + p.off_mlp_sk : nullptr, p.mlp_sk_bytes, M2, D, p.Hd, s));
+      TR_TRY(tr_mlp_fused_ln_bf16_set(x, static_cast<const uint16_t*>(pending_attn), bw->ln2_g, bw->ln2_b, cfg->ln_eps, bw->mlp_pk, bw->fc1_b,
+                                      static_cast<uint16_t*>(dbuf), p.mlp_sk_bytes ? ws + p.off_mlp_sk : nullptr, p.mlp_sk_bytes, M2, D, p.Hd, one_memset ? i : -1, s));
     else if (fused_mlp)
-      TR_TRY(tr_mlp_fused_bf16(static_cast<const uint16_t*>(xn), bw->mlp_pk, bw->fc1_b, static_cast<uint16_t*>(dbuf),
-                               p.mlp_sk_bytes ? ws + p.off_mlp_sk : nullptr, p.mlp_sk_bytes, M2, D, p.Hd, s));
+      TR_TRY(tr_mlp_fused_bf16_set(static_cast<const uint16_t*>(xn), bw->mlp_pk, bw->fc1_b, static_cast<uint16_t*>(dbuf),
+                                   p.mlp_sk_bytes ? ws + p.off_mlp_sk : nullptr, p.mlp_sk_bytes, M2, D, p.Hd, one_memset ? i : -1, s));
     else
       TR_TRY(op_gemm(prec, hbuf, bw->fc2_w, bw->fc2_b, dbuf, nullptr, 0, M2, D, p.Hd, TR_EPI_BF16, s));
     if (drop_keep != nullptr) {      // ... and after fc2
