@@ -528,6 +528,7 @@ def main():
 
     el = timed_steps(step, a.steps, a.warmup, dist, torch.cuda.synchronize, dev)
     assert torch.isfinite(out[0]).all()
+    model.check_status()        # what only the device knows (the fused Mlp's stream-K hand-over record) fails the run here, not silently
     eager_ms = None
     if rank == 0 and not a.no_extra:          # the same forward as plain launches (model.use_graph = False): what the graph replay saves
         model.use_graph = False

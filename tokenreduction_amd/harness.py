@@ -59,6 +59,14 @@ class _Meter:
 
 
 @torch.no_grad()
+def _check_status(model):
+    """What only the device knows about the forwards just run (models.VisionTransformer.check_status: the fused Mlp's stream-K hand-over
+    record) becomes an exception here, where the results are consumed; DDP-style wrappers are looked through."""
+    m = getattr(model, "module", model)
+    if hasattr(m, "check_status"):
+        m.check_status()
+
+
 def evaluate_multiclass(data_loader: Iterable, model, device) -> Dict[str, float]:
     """engine.py:118-151.  `loss` averages the per-batch mean losses (meter weight 1 per batch, as the reference's
     `metric_logger.update(loss=loss.item())` does); acc1/acc5 are weighted by batch size."""
@@ -77,6 +85,7 @@ def evaluate_multiclass(data_loader: Iterable, model, device) -> Dict[str, float
         meters["loss"].update(loss.item())
         meters["acc1"].update(acc1.item(), n=n)
         meters["acc5"].update(acc5.item(), n=n)
+    _check_status(model)
     for m in meters.values():
         m.synchronize_between_processes(device)
     return {k: m.global_avg for k, m in meters.items()}
@@ -233,6 +242,7 @@ def validate(data_loader: Iterable, model, device, model_name: str, image_names:
                 rec.update(image_records(model_name, model.get_reduction_count(), viz_data, i))
             data[image_names[count + i]] = rec
         count += n
+    _check_status(model)
     data["Top1-Acc"] = round(top1.global_avg, 4)
     data["Top5-Acc"] = round(top5.global_avg, 4)
     if hasattr(model, "parameters"):

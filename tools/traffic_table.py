@@ -85,10 +85,19 @@ def algorithmic(kernel, B, D, H, st, wl=""):
         return mean(lambda n, k: B * (n - 1) * (k - 1) * 8, st)
     if K.startswith("rownorm_kernel"):
         return mean(lambda n, k: B * (n - 1) * D * (4 + 4 + 2), st)
-    if K.startswith("mlp_fused_kernel") and wl == "headline":     # fused eval Mlp: LN2 output in, fc2 output out (bf16), the packed weights once;
-        # launched for the blocks of the first three token counts (nine launches: 197 x 3, 138 x 3, 97 x 3 tokens per image)
+    if K.startswith("mlp_fused_kernel") and wl == "headline":     # fused eval Mlp: LN2 output in, fc2 output out (bf16), the packed weights once
+        wts = 2 * D * 4 * D * 2
+        if "true>" in K.split("(")[0] and "<false, true>" in K:
+            # round 6: the norm2 inside the launch (one-round launches: blocks 7, 8 at 97 tokens per image): fp32 stream row + bf16 residual in
+            m = B * 97
+            return m * D * (4 + 2 + 2) + wts
+        if "<false, false>" in K:
+            # round 6: the plain launch serves blocks 0..6 (197 x 3, 138 x 3, 97 x 1 tokens per image)
+            ms = [B * 197] * 3 + [B * 138] * 3 + [B * 97]
+            return sum(m * D * 2 * 2 + wts for m in ms) / len(ms)
+        # round 5: nine launches (197 x 3, 138 x 3, 97 x 3 tokens per image)
         ms = [B * 197, B * 138, B * 97]
-        return sum(m * D * 2 * 2 + 2 * D * 4 * D * 2 for m in ms) / len(ms)
+        return sum(m * D * 2 * 2 + wts for m in ms) / len(ms)
     return None
 
 
