@@ -211,8 +211,17 @@ __global__ __launch_bounds__(256) void mlp_pack_kernel(const uint16_t* __restric
   const int r = lane & 15, q = lane >> 4;
   const uint16_t* src;
   if (f < 2 * ks_n) {
+#ifdef MF_P32
+    // lab (-DMF_P32: fc1 on v_mfma_f32_32x32x16_bf16): fragment f = 16-deep k-step ks; lane (rho = l & 31, kq = l >> 5) holds
+    // W1[32 s + h(rho)][16 ks + 8 kq ..], h(rho = 8 i + 4 g + e) = 8 (g + 2 (i >> 1)) + 4 (i & 1) + e: a lane (token, g) of the 32 x 32 result
+    // then holds the hidden groups q = g (registers 0..7) and q = g + 2 (8..15), each in fc2's B-fragment order
+    const int rho = lane & 31, kq = lane >> 5;
+    const int hh = 8 * (((rho >> 2) & 1) + 2 * (rho >> 4)) + 4 * ((rho >> 3) & 1) + (rho & 3);
+    src = W1 + (size_t)(32 * s + hh) * D + 16 * f + 8 * kq;
+#else
     const int t2 = f / ks_n, ks = f % ks_n;
     src = W1 + (size_t)(32 * s + 8 * (r >> 2) + 4 * t2 + (r & 3)) * D + 32 * ks + 8 * q;
+#endif
   } else {
     const int i = f - 2 * ks_n;
     src = W2 + (size_t)(16 * i + r) * Hd + 32 * s + 8 * q;
@@ -361,6 +370,165 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
     ld_slot = (ld_slot + 1 == MF_NSLOT) ? 0 : ld_slot + 1;
   };
 
+#ifdef MF_P32
+  // =================================================================== lab: P on v_mfma_f32_32x32x16_bf16 (profiles/r06_mlp_lab.md)
+  // The fc1 waves only: h^T (32 hidden x 32 tokens) = W1_step . x^T as 24 MFMAs of 32 x 32 x 16 on ONE 16-register accumulator instead of 48
+  // of 16 x 16 x 32 on four -- half the MFMA issue slots on the wave whose instruction stream bounds the step.  The fc2 waves, the ring, the
+  // hand-over and the epilogue are untouched: the hidden fragments cross LDS anyway, so the P wave writes them where the C wave's
+  // 16 x 16 x 32 B-fragment reads expect them.  Not bit-identical to the GEMM pair (another K order inside the instruction).
+  if (wave < 4) {
+    typedef __attribute__((ext_vector_type(16))) float f32x16;
+    const int tc = lane & 31, hg = lane >> 5;     // token of the slice, hidden-group half
+    bf16x8 xk[2 * MF_KS];                          // B operand: token tc, columns 16 ks + 8 hg .. (24 k-steps)
+    auto x_offset = [&](int blk) __attribute__((always_inline)) {
+      const int m = blk * MF_ROWS + pr * 32 + tc;
+      return ((unsigned)min(m, M - 1) * MF_D + 8u * hg) * 2u;
+    };
+    {
+      const unsigned xo = x_offset(mf_block(q, mf_first(q, NS)));
+#define MF_LX(ks) xk[ks] = mf_load_x<(ks) * 32>(xn, xo)
+      MF_LX(0); MF_LX(1); MF_LX(2); MF_LX(3); MF_LX(4); MF_LX(5); MF_LX(6); MF_LX(7); MF_LX(8); MF_LX(9); MF_LX(10); MF_LX(11);
+      MF_LX(12); MF_LX(13); MF_LX(14); MF_LX(15); MF_LX(16); MF_LX(17); MF_LX(18); MF_LX(19); MF_LX(20); MF_LX(21); MF_LX(22); MF_LX(23);
+#undef MF_LX
+    }
+    // bias of the lane's 16 hidden units of a step: b1[32 s + 8 hg + 0..7] (registers 0..7), b1[32 s + 8 (hg + 2) + 0..7] (8..15)
+    const unsigned boff = (unsigned)hg * 32u;
+    f32x4 bn0, bn1, bn2, bn3;
+    bn0 = mf_load_f4<0>(b1 + 32 * mf_first(q, NS).s, boff);
+    bn1 = mf_load_f4<16>(b1 + 32 * mf_first(q, NS).s, boff);
+    bn2 = mf_load_f4<64>(b1 + 32 * mf_first(q, NS).s, boff);
+    bn3 = mf_load_f4<80>(b1 + 32 * mf_first(q, NS).s, boff);
+    issue_all();
+    advance_entry();
+    issue_all();
+    advance_entry();
+#define MF_TIE_XK(lo) "+v"(xk[lo]), "+v"(xk[lo + 1]), "+v"(xk[lo + 2]), "+v"(xk[lo + 3]), "+v"(xk[lo + 4]), "+v"(xk[lo + 5]), "+v"(xk[lo + 6]), "+v"(xk[lo + 7]), "+v"(xk[lo + 8]), "+v"(xk[lo + 9]), "+v"(xk[lo + 10]), "+v"(xk[lo + 11])
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(bn0), "+v"(bn1), "+v"(bn2), "+v"(bn3), MF_TIE_XK(0), MF_TIE_XK(12)::"memory");
+    __builtin_amdgcn_s_barrier();               // entries 0 and 1 have landed
+    asm volatile("" ::: "memory");
+
+    int t = 0, cslot = 0;
+    f32x4 p0, p1, p2, p3;                       // the previous step's accumulator (registers 0..3, 4..7, 8..11, 12..15), waiting for its GELU
+    p0 = p1 = p2 = p3 = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+    bf16x8 wA[4], wB[4];
+#define MF_READW(buf, base, k)                                                     \
+  buf[0] = *reinterpret_cast<const bf16x8*>((base) + (4 * (k)) * 1024);            \
+  buf[1] = *reinterpret_cast<const bf16x8*>((base) + (4 * (k) + 1) * 1024);        \
+  buf[2] = *reinterpret_cast<const bf16x8*>((base) + (4 * (k) + 2) * 1024);        \
+  buf[3] = *reinterpret_cast<const bf16x8*>((base) + (4 * (k) + 3) * 1024)
+    MF_READW(wA, smem + lane16, 0);
+    MF_CLOCK_BEGIN;
+    // where this lane's two 8-wide groups go in the pair's hidden buffer: fc2's B fragment of token group j = tc >> 4 is read at
+    // j * 1024 + (r + 16 q) * 16 by lane (r = token & 15, q = hidden group)
+    const unsigned hdst = (unsigned)((tc >> 4) * 1024 + ((tc & 15) + 16 * hg) * 16);
+    auto p_step = [&](int sn, const bool last, int next_blk) __attribute__((always_inline)) {
+      const unsigned char* slot = smem + cslot * MF_ENTRY + lane16;
+      const int nslot = (cslot + 1 == MF_NSLOT) ? 0 : cslot + 1;
+      const unsigned char* slot_next = smem + nslot * MF_ENTRY + lane16;
+      MF_STAMP_DECL;
+      MF_STAMP(0);
+      f32x16 a;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a[e] = bn0[e]; a[4 + e] = bn1[e]; a[8 + e] = bn2[e]; a[12 + e] = bn3[e]; }
+      u32x4 h0 = {0u, 0u, 0u, 0u}, h1 = {0u, 0u, 0u, 0u};
+      unsigned xo = 0;
+      const bool reload = last && next_blk >= 0;
+      if (reload) xo = x_offset(next_blk);
+#define MF_GELU_SLICE(k)                                                                                  \
+  do {                                                                                                    \
+    if ((k) == 0) { const f32x2 g0 = mf_gelu2(f32x2{p0[0], p0[1]}), g1 = mf_gelu2(f32x2{p0[2], p0[3]}); h0[0] = pack_bf16x2(g0[0], g0[1]); h0[1] = pack_bf16x2(g1[0], g1[1]); asm volatile("" : "+v"(h0[0]), "+v"(h0[1])); } \
+    if ((k) == 1) { const f32x2 g0 = mf_gelu2(f32x2{p1[0], p1[1]}), g1 = mf_gelu2(f32x2{p1[2], p1[3]}); h0[2] = pack_bf16x2(g0[0], g0[1]); h0[3] = pack_bf16x2(g1[0], g1[1]); asm volatile("" : "+v"(h0[2]), "+v"(h0[3])); } \
+    if ((k) == 2) { const f32x2 g0 = mf_gelu2(f32x2{p2[0], p2[1]}), g1 = mf_gelu2(f32x2{p2[2], p2[3]}); h1[0] = pack_bf16x2(g0[0], g0[1]); h1[1] = pack_bf16x2(g1[0], g1[1]); asm volatile("" : "+v"(h1[0]), "+v"(h1[1])); } \
+    if ((k) == 3) { const f32x2 g0 = mf_gelu2(f32x2{p3[0], p3[1]}), g1 = mf_gelu2(f32x2{p3[2], p3[3]}); h1[2] = pack_bf16x2(g0[0], g0[1]); h1[3] = pack_bf16x2(g1[0], g1[1]); asm volatile("" : "+v"(h1[2]), "+v"(h1[3])); } \
+    if ((k) == 4) {                                                                                       \
+      unsigned char* dst = hb + ((t - 1) & 1) * MF_HBUF + hdst;                                           \
+      *reinterpret_cast<u32x4*>(dst) = h0;                                                                \
+      *reinterpret_cast<u32x4*>(dst + 512) = h1;                                                          \
+    }                                                                                                     \
+  } while (0)
+#define MF_PMFMA(cur, k)                                                                                           \
+  do {                                                                                                             \
+    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[0], xk[4 * (k)], a, 0, 0, 0);                                  \
+    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[1], xk[4 * (k) + 1], a, 0, 0, 0);                              \
+    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[2], xk[4 * (k) + 2], a, 0, 0, 0);                              \
+    a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur[3], xk[4 * (k) + 3], a, 0, 0, 0);                              \
+  } while (0)
+#define MF_RX(ks) mf_reload_x<(ks) * 32>(xk[ks], xn, xo)
+#define MF_PWIN(cur, nxt, k)                                                                    \
+  do {                                                                                          \
+    MF_READW(nxt, slot, (k) + 1);                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    MF_PMFMA(cur, k);                                                                           \
+    MF_GELU_SLICE(k);                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    if ((k) == 0) {                                                                             \
+      bn0 = mf_load_f4<0>(b1 + 32 * sn, boff);                                                  \
+      bn1 = mf_load_f4<16>(b1 + 32 * sn, boff);                                                 \
+      bn2 = mf_load_f4<64>(b1 + 32 * sn, boff);                                                 \
+      bn3 = mf_load_f4<80>(b1 + 32 * sn, boff);                                                 \
+    }                                                                                           \
+    if (reload) { MF_RX(4 * (k)); MF_RX(4 * (k) + 1); MF_RX(4 * (k) + 2); MF_RX(4 * (k) + 3); } \
+  } while (0)
+      MF_PWIN(wA, wB, 0);
+      MF_PWIN(wB, wA, 1);
+      MF_PWIN(wA, wB, 2);
+      MF_PWIN(wB, wA, 3);
+      MF_PWIN(wA, wB, 4);       // wB: window 5
+      if (ld_e <= T + 1) advance_entry();
+      MF_STAMP(1);
+      if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(bn0), "+v"(bn1), "+v"(bn2), "+v"(bn3), MF_TIE_XK(0), MF_TIE_XK(12)::"memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      MF_STAMP(2);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      MF_STAMP(3);
+      MF_READW(wA, slot_next, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      MF_PMFMA(wB, 5);
+      __builtin_amdgcn_sched_barrier(0);
+      if (reload) { MF_RX(20); MF_RX(21); MF_RX(22); MF_RX(23); }
+#undef MF_PWIN
+#undef MF_GELU_SLICE
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { p0[e] = a[e]; p1[e] = a[4 + e]; p2[e] = a[8 + e]; p3[e] = a[12 + e]; }
+      MF_STAMP_DUMP(0, t);
+      ++t;
+      cslot = nslot;
+    };
+    {
+      MfCur cur = mf_first(q, NS);
+      for (int tt = 0; tt < T; ++tt) {
+        const MfCur nxt = mf_next(q, cur, NS);
+        int last = __builtin_amdgcn_readfirstlane(mf_last_of_segment(q, cur, NS) ? 1 : 0);
+        asm volatile("" : "+s"(last));
+        p_step(nxt.s, last != 0, (last && tt + 1 < T) ? mf_block(q, nxt) : -1);
+        cur = nxt;
+      }
+    }
+    {
+      // time T: only the GELU of the last step is left
+      const f32x2 g0 = mf_gelu2(f32x2{p0[0], p0[1]}), g1 = mf_gelu2(f32x2{p0[2], p0[3]});
+      const f32x2 g2 = mf_gelu2(f32x2{p1[0], p1[1]}), g3 = mf_gelu2(f32x2{p1[2], p1[3]});
+      const u32x4 h0 = {pack_bf16x2(g0[0], g0[1]), pack_bf16x2(g1[0], g1[1]), pack_bf16x2(g2[0], g2[1]), pack_bf16x2(g3[0], g3[1])};
+      const f32x2 g4 = mf_gelu2(f32x2{p2[0], p2[1]}), g5 = mf_gelu2(f32x2{p2[2], p2[3]});
+      const f32x2 g6 = mf_gelu2(f32x2{p3[0], p3[1]}), g7 = mf_gelu2(f32x2{p3[2], p3[3]});
+      const u32x4 h1 = {pack_bf16x2(g4[0], g4[1]), pack_bf16x2(g5[0], g5[1]), pack_bf16x2(g6[0], g6[1]), pack_bf16x2(g7[0], g7[1])};
+      unsigned char* dst = hb + ((t - 1) & 1) * MF_HBUF + hdst;
+      *reinterpret_cast<u32x4*>(dst) = h0;
+      *reinterpret_cast<u32x4*>(dst + 512) = h1;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+#undef MF_PMFMA
+#undef MF_READW
+#undef MF_RX
+#undef MF_TIE_XK
+    MF_CLOCK_END;
+    return;
+  }
+#else
   if (wave < 4) {
     // =============================================================== P: fc1 + GELU
 #ifdef MF_PRIO_P
@@ -636,6 +804,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
     return;
   }
 
+#endif      // MF_P32
   // ================================================================= C: fc2, the 32 x 384 accumulator in registers
 #ifdef MF_PRIO_C
   __builtin_amdgcn_s_setprio(MF_PRIO_C);
