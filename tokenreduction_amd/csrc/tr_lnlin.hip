@@ -41,7 +41,6 @@ constexpr int LL_GB_OFF = LL_NSLOT * LL_ENTRY + LL_BIAS_MAX * 4;      // ... in 
 constexpr int LL_LDS = LL_NSLOT * LL_ENTRY + 16384;                // 147,456 + 16,384 = 163,840 B: all of the CU's LDS
 constexpr int LL_ROWS = 128;
 constexpr int LL_SLOT_BYTES = LL_ROWS * LL_D * 2;      // one block of normalised rows: 96 KiB
-constexpr int LL_ITERS = 8;                      // LN iterations per block: 16 rows each (4 per LN wave)
 
 #ifdef TR_ABLATE_NO_MFMA
 #define LL_MFMA(a, b, c) ([&] { asm volatile("" ::"v"(a), "v"(b)); return c; }())
@@ -78,25 +77,6 @@ __device__ __forceinline__ void ll_piece(const unsigned char* sbase, unsigned vo
       :
       : [o] "v"(voff), [b] "s"(sbase), [ld] "s"(lds_dst)
       : "memory", "m0");
-}
-// loads the compiler does not see (no waits of its own in this kernel: every s_waitcnt vmcnt is written out, the LDS-DMA pieces count too)
-template <int IMM>
-__device__ __forceinline__ f32x4 ll_load_f4(const float* sbase, unsigned voff) {
-  f32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(v) : "v"(voff), "s"(sbase), "i"(IMM) : "memory");
-  return v;
-}
-template <int IMM>
-__device__ __forceinline__ f32x4 ll_load_f4_nt(const float* sbase, unsigned voff) {
-  f32x4 v;
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 nt" : "=v"(v) : "v"(voff), "s"(sbase), "i"(IMM) : "memory");
-  return v;
-}
-template <int IMM>
-__device__ __forceinline__ u32x2 ll_load_d2_nt(const uint16_t* sbase, unsigned voff) {
-  u32x2 v;
-  asm volatile("global_load_dwordx2 %0, %1, %2 offset:%3 nt" : "=v"(v) : "v"(voff), "s"(sbase), "i"(IMM) : "memory");
-  return v;
 }
 // the MFMA waves' B fragments from the workgroup's slot: sc1 = past this CU's L1 (the slot's lines are rewritten every other block)
 template <int IMM>

@@ -155,7 +155,7 @@ constexpr int MF_ROWS = 128;                   // token rows per block (4 wave p
 #define MF_DMA_SPREAD 1                        // a C wave's pieces one at a time between MFMA pairs (lab: -DMF_DMA_BURST issues them window by window)
 #endif
 constexpr int MF_PPW = (MF_PQ + 3) / 4;        // ... behind the MFMAs of a P step's windows 1..4 (window 0 carries the bias loads)
-constexpr int MF_CPW = (12 - MF_PQ + 4) / 5;   // ... and of a C step's windows 0..4
+[[maybe_unused]] constexpr int MF_CPW = (12 - MF_PQ + 4) / 5;   // ... and of a C step's windows 0..4
 
 __device__ __forceinline__ void mf_piece(const unsigned char* sbase, unsigned voff, unsigned lds_dst) {
 #ifndef TR_ABLATE_NO_DMA
