@@ -43,6 +43,12 @@ def _in_kernel_clock_ghz(kernel="gemm_bf16_pc", default=2.0):
 # kernel is MEASURED to run at in the model (round 5 assumed 1.45 GHz from single-kernel lab stamps: 1045; measured in round 6: ~2.0 GHz)
 FEED_CEILING_TFLOPS = round(85.3 * 33.0 * 256 * _in_kernel_clock_ghz() / 1e3, 0)
 PEAK_HBM_GBPS = 8000.0
+# Forwards in flight during the timed steps: 2 = every step is enqueued with model.forward_async (two side streams, each with its own
+# workspace and captured graph): step k + 1 starts while step k's last launches drain, the device fills one forward's tails (partial last
+# rounds of the persistent kernels, the short launches of the last stage) with the other's.  Every step is a complete forward of its own
+# batch and all K steps finish inside the timed bracket; `ms_per_step` is wall time / K (throughput), the line also carries the
+# one-forward-at-a-time figure (`ms_per_step_one_in_flight`).  TR_BENCH_IN_FLIGHT=1 times the old way.
+IN_FLIGHT = max(1, int(os.environ.get("TR_BENCH_IN_FLIGHT", "2")))
 
 
 def build_model(name=MODEL, keep_rate=KEEP_RATE, loc=REDUCTION_LOC, device="cuda", img_size=224, qkv_gain=4.0):
@@ -53,23 +59,27 @@ def build_model(name=MODEL, keep_rate=KEEP_RATE, loc=REDUCTION_LOC, device="cuda
                                  min_radius=None)
     m = tra.create_model(name, pretrained=False, num_classes=1000, drop_rate=0.0, drop_path_rate=0.0,
                          drop_block_rate=None, img_size=img_size, args=args)
+    m.pipeline_depth = max(2, IN_FLIGHT)        # side streams of model.forward_async
     with torch.no_grad():                       # "peaky" attention so the Top-K sees a realistic score spread
         for blk in m.blocks:
             blk.attn.qkv.weight.mul_(qkv_gain)
     return m.to(device).eval()
 
 
-def quick_images_per_s(model, x, iters=10, reps=3):
+def quick_images_per_s(model, x, iters=10, reps=3, in_flight=None):
     """Informational legs (dense baseline, other families): best of `reps` timed runs of `iters` forwards -- a one-off stall
-    (allocator growth, first-touch of a fresh workspace) must not halve a number that is only measured once."""
-    for _ in range(3):
-        model(x)
+    (allocator growth, first-touch of a fresh workspace) must not halve a number that is only measured once.  in_flight (default: the
+    headline's IN_FLIGHT): 2 = the forwards go through model.forward_async, two at a time on two streams; 1 = model(x) on one stream."""
+    k = IN_FLIGHT if in_flight is None else in_flight
+    go = (lambda: model.forward_async(x)) if (k > 1 and not getattr(model, "dynamic_width", False)) else (lambda: model(x))
+    for _ in range(4):
+        go()
     best = 0.0
     for _ in range(reps):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(iters):
-            model(x)
+            go()
         torch.cuda.synchronize()
         best = max(best, x.shape[0] * iters / (time.perf_counter() - t1))
     return best
@@ -428,7 +438,13 @@ def headline_record(a, world, headline, eager_ms, note=None):
         "config": {"workload": f"{MODEL} keep_rate=0.7 reduction_loc=3,6,9 batch={BATCH}/GPU 224x224 eval forward "
                                f"(BASELINE.json configs[1])", "global_batch": BATCH * world,
                    "tokens_per_block": tokens, "gflop_per_image": round(gflop, 3), "parallelism": f"dp{world}"},
-        "launch_mode": "hipGraph replay of the executor's launch sequence",
+        "launch_mode": ("hipGraph replay of the executor's launch sequence; " +
+                        (f"{IN_FLIGHT} forwards in flight (model.forward_async: step k + 1 is enqueued on a second stream with its own workspace "
+                         "while step k drains; every step is a complete forward of its batch, all K finish inside the timed bracket)"
+                         if IN_FLIGHT > 1 else "one forward at a time")),
+        "forwards_in_flight": IN_FLIGHT,
+        "ms_per_step_one_in_flight": None if headline.get("one_ms") is None else round(headline["one_ms"], 3),
+        "images_per_s_one_in_flight": None if headline.get("one_ms") is None else round(world * BATCH / headline["one_ms"] * 1e3, 1),
         "ms_per_step_plain_launches": None if eager_ms is None else round(eager_ms, 3),
         "model_tflops": round(ips * gflop / 1e3, 1),
         "model_mfma_frac": round(ips * gflop / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
@@ -522,13 +538,24 @@ def main():
     model = build_model(device=dev)
     x = torch.randn(BATCH, 3, 224, 224, generator=torch.Generator().manual_seed(100 + rank)).to(dev)
     out = [None]
+    pend = []
 
     def step():
         out[0] = model(x)
 
-    el = timed_steps(step, a.steps, a.warmup, dist, torch.cuda.synchronize, dev)
+    def step_in_flight():                    # one step = one forward of the batch, enqueued beside the previous one (see IN_FLIGHT)
+        pend.append(model.forward_async(x))
+        if len(pend) > 4:
+            pend.pop(0)
+
+    el = timed_steps(step_in_flight if IN_FLIGHT > 1 else step, a.steps, a.warmup, dist, torch.cuda.synchronize, dev)
+    if pend:
+        out[0] = pend[-1].result()
+        ref = model(x)                       # the same batch, one forward at a time: the pipelined steps computed the same bits
+        assert torch.equal(out[0], ref), "forward_async and model(x) disagree"
     assert torch.isfinite(out[0]).all()
     model.check_status()        # what only the device knows (the fused Mlp's stream-K hand-over record) fails the run here, not silently
+    one_ms = 1e3 * timed_steps(step, a.steps, 2, dist, torch.cuda.synchronize, dev) / a.steps if IN_FLIGHT > 1 else None
     eager_ms = None
     if rank == 0 and not a.no_extra:          # the same forward as plain launches (model.use_graph = False): what the graph replay saves
         model.use_graph = False
@@ -539,7 +566,7 @@ def main():
     # They must never cost the headline line: every leg is fenced (an exception becomes an "error" entry), and at N > 1 a watchdog
     # prints the headline without them and ends the process if a collective hangs (the legs have only ever run at N = 1 on RCCL).
     finetune = None
-    headline = {"el": el, "tokens": list(model._last_tokens)}
+    headline = {"el": el, "tokens": list(model._last_tokens), "one_ms": one_ms}
     if dist is not None:
         # what the process group itself reports (not the command line): rank count, backend, and the device every rank ran on
         me = torch.tensor([rank, torch.cuda.current_device()], device=dev, dtype=torch.int32)

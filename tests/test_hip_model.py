@@ -642,6 +642,44 @@ def test_norm2_inside_the_fused_mlp_gives_the_same_logits(golden_dir, name, batc
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("name", ["topk_small_kr07", "topk_micro", "tome_small_r16", "dpcknn_micro", "sinkhorn_micro", "ats_micro"])
+def test_forward_async_equals_forward_with_two_forwards_in_flight(name):
+    """model.forward_async enqueues eval forwards on two side streams (own workspace and captured graph each), so that two are in flight;
+    `handle.result()` makes the caller's stream wait and returns what model(x) returns.  Same kernels: the logits of six batches launched
+    back to back -- two alternating inputs, results taken out of order, the caller's stream busy meanwhile -- equal model(x) BIT FOR BIT;
+    the status check covers every slot; a deep copy (ModelEma) starts without the streams; viz_mode runs synchronously."""
+    import copy
+    case = GOLDEN_CASES[name]
+    model, _, _ = build_model(case)
+    model.viz_mode = False
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", name + ".npz"))
+    noise = {int(k.split("_")[1]): torch.from_numpy(g[k]) for k in g.files if k.startswith("noise_")}
+    if noise:
+        model.density_noise = noise
+    B = 64 if case["embed_dim"] >= 384 else case["batch"]
+    if noise:
+        B = case["batch"]                       # (the recorded noise has the fixture's batch size)
+    xa, xb = make_images(B, case.get("img_size", 224), 31).cuda(), make_images(B, case.get("img_size", 224), 32).cuda()
+    want_a, want_b = model(xa).clone(), model(xb).clone()
+    busy = torch.zeros(1 << 22, device="cuda")
+    handles = []
+    for k in range(6):
+        handles.append(model.forward_async(xa if k % 2 == 0 else xb))
+        busy.add_(1.0)                           # work on the caller's stream between the launches
+    for k in (5, 0, 3, 2, 4, 1):                 # results in any order
+        got = handles[k].result()
+        assert torch.equal(got, want_a if k % 2 == 0 else want_b), f"forward {k} differs from model(x)"
+    torch.cuda.synchronize()
+    model.check_status()
+    assert len(model._ws) >= 3                   # slot 0 (model(x)) and the two side slots
+    ema = copy.deepcopy(model)
+    assert not ema.__dict__.get("_pipe_streams") and ema._ws == {}
+    assert torch.equal(ema.cuda().eval().forward_async(xa).result(), want_a)
+    model.viz_mode = True                        # (Features wants every block's stream: the eager, synchronous path)
+    out = model.forward_async(xa).result()
+    assert isinstance(out, tuple) and torch.equal(out[0], want_a)
+
+
 def test_graph_replay_gives_way_to_plain_launches_when_inputs_keep_moving():
     """The eval forward replays a hipGraph keyed on the input's address.  A caller whose batches land at a new address every time would
     re-capture on every call: after GRAPH_MISS_LIMIT misses in a row the workspace goes back to plain launches, with one warning; a caller

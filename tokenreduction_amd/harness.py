@@ -58,7 +58,6 @@ class _Meter:
         return self.total / self.count
 
 
-@torch.no_grad()
 def _check_status(model):
     """What only the device knows about the forwards just run (models.VisionTransformer.check_status: the fused Mlp's stream-K hand-over
     record) becomes an exception here, where the results are consumed; DDP-style wrappers are looked through."""
@@ -67,24 +66,38 @@ def _check_status(model):
         m.check_status()
 
 
+@torch.no_grad()
 def evaluate_multiclass(data_loader: Iterable, model, device) -> Dict[str, float]:
     """engine.py:118-151.  `loss` averages the per-batch mean losses (meter weight 1 per batch, as the reference's
     `metric_logger.update(loss=loss.item())` does); acc1/acc5 are weighted by batch size."""
     meters = {"loss": _Meter(), "acc1": _Meter(), "acc5": _Meter()}
     if hasattr(model, "eval"):
         model.eval()
-    for images, target in data_loader:
-        images = images.to(device, non_blocking=True)
-        target = target.to(device, non_blocking=True)
-        output = model(images)
+    # One batch of lookahead where the model offers it (VisionTransformer.forward_async): batch k + 1 is launched -- on a side stream with its
+    # own workspace -- before batch k's logits are consumed (the .item() calls below synchronise), so that two forwards are in flight and
+    # the device fills the tail of one's launches with the other's.  Same results, in the loader's order.
+    launch = getattr(getattr(model, "module", model), "forward_async", None)
+
+    def consume(pending, target, n):
+        output = pending.result() if launch is not None else pending
         if isinstance(output, (tuple, list)):
             output = output[0]
         loss = F.cross_entropy(output.float(), target)
         acc1, acc5 = accuracy(output, target, topk=(1, 5))
-        n = images.shape[0]
         meters["loss"].update(loss.item())
         meters["acc1"].update(acc1.item(), n=n)
         meters["acc5"].update(acc5.item(), n=n)
+
+    prev = None
+    for images, target in data_loader:
+        images = images.to(device, non_blocking=True)
+        target = target.to(device, non_blocking=True)
+        cur = (launch(images) if launch is not None else model(images), target, images.shape[0])
+        if prev is not None:
+            consume(*prev)
+        prev = cur
+    if prev is not None:
+        consume(*prev)
     _check_status(model)
     for m in meters.values():
         m.synchronize_between_processes(device)
@@ -223,17 +236,18 @@ def validate(data_loader: Iterable, model, device, model_name: str, image_names:
     top1, top5 = _Meter(), _Meter()
     viz_mode = bool(getattr(model, "viz_mode", False))
     count = 0
-    for images, target in data_loader:
-        images = images.to(device, non_blocking=True)
-        target = target.to(device, non_blocking=True)
-        output = model(images)
+    # one batch of lookahead, as in evaluate_multiclass (with viz_mode the forward runs synchronously: forward_async says so itself)
+    launch = getattr(getattr(model, "module", model), "forward_async", None)
+
+    def consume(pending, target, n):
+        nonlocal count
+        output = pending.result() if launch is not None else pending
         viz_data = None
         if viz_mode:
             output, viz_data = output
         loss = F.cross_entropy(output.float(), target)
         acc1, acc5 = accuracy(output, target, topk=(1, 5))
         _, pred = output.topk(min(5, output.shape[1]), 1, True, True)
-        n = images.shape[0]
         top1.update(acc1.item(), n)
         top5.update(acc5.item(), n)
         for i in range(n):
@@ -242,6 +256,17 @@ def validate(data_loader: Iterable, model, device, model_name: str, image_names:
                 rec.update(image_records(model_name, model.get_reduction_count(), viz_data, i))
             data[image_names[count + i]] = rec
         count += n
+
+    prev = None
+    for images, target in data_loader:
+        images = images.to(device, non_blocking=True)
+        target = target.to(device, non_blocking=True)
+        cur = (launch(images) if launch is not None else model(images), target, images.shape[0])
+        if prev is not None:
+            consume(*prev)
+        prev = cur
+    if prev is not None:
+        consume(*prev)
     _check_status(model)
     data["Top1-Acc"] = round(top1.global_avg, 4)
     data["Top5-Acc"] = round(top5.global_avg, 4)

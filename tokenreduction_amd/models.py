@@ -45,6 +45,23 @@ class PatchEmbed(nn.Module):
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.patch_size)
 
 
+class _Pending:
+    """Handle of a forward enqueued by VisionTransformer.forward_async: result() makes the caller's CURRENT stream wait for it."""
+
+    def __init__(self, out, event):
+        self._out, self._event = out, event
+
+    def result(self):
+        if self._event is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(self._event)
+            for t in (self._out if isinstance(self._out, (tuple, list)) else (self._out,)):
+                if torch.is_tensor(t):
+                    t.record_stream(cur)
+            self._event = None
+        return self._out
+
+
 class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features):
         super().__init__()
@@ -151,14 +168,15 @@ class VisionTransformer(nn.Module):
     # THIS object's executor, rebuilt on demand.  A copy (copy.deepcopy: ModelEma, torch's swa_utils) starts without them: captured
     # torch.cuda.CUDAGraph objects cannot be deep-copied at all, and a copied workspace would not belong to the copy's own packed weights.
     _EXECUTOR_CACHES = {"_packed": None, "_ws": None, "_last_ws": None, "_tstate": None, "_grad_reducer": None, "_noise_buf": None,
-                        "_gumbel_buf": None, "_kmed_draws": None, "_pack_slots": None, "_pack_table": None, "_mlp_pack_items": None}
+                        "_gumbel_buf": None, "_kmed_draws": None, "_pack_slots": None, "_pack_table": None, "_mlp_pack_items": None,
+                        "_pipe_streams": None, "_pipe_next": None}
 
     def __deepcopy__(self, memo):
         new = self.__class__.__new__(self.__class__)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
             if k in self._EXECUTOR_CACHES:
-                if k in ("_pack_slots", "_pack_table"):
+                if k in ("_pack_slots", "_pack_table", "_pipe_streams", "_pipe_next"):
                     continue
                 new.__dict__[k] = {} if k == "_ws" else None
             else:
@@ -427,8 +445,11 @@ class VisionTransformer(nn.Module):
         """fp32 elements of the soft-assignment output (SiT), 0 for families without one."""
         return 0
 
-    def _workspace(self, B, dev):
-        ws = self._ws.get(B)
+    def _workspace(self, B, dev, slot=0):
+        """The executor's buffers for batch size B.  slot > 0: a further, independent set (its own workspace, outputs and captured graphs) for
+        a forward that is in flight beside another one (forward_async)."""
+        wkey = B if slot == 0 else (B, slot)
+        ws = self._ws.get(wkey)
         if ws is None:
             pk = self._packed
             nbytes = _lib.load().tr_vit_workspace_bytes(C.byref(pk["cfg"]), B)
@@ -441,7 +462,9 @@ class VisionTransformer(nn.Module):
                       compl=torch.empty(self.depth * B * (P + 1), dtype=torch.int32, device=dev), soft=None)
             if self.viz_mode and self._soft_elems(B):
                 ws["soft"] = torch.empty(self._soft_elems(B), dtype=torch.float32, device=dev)
-            self._ws = {B: ws}   # keep one batch size resident
+            # keep one batch size resident (all of its slots)
+            self._ws = {k: v for k, v in self._ws.items() if (k[0] if isinstance(k, tuple) else k) == B}
+            self._ws[wkey] = ws
         return ws
 
     # ---- training state (flat gradient buffer, tape, workspaces): training.py -----------------------
@@ -458,6 +481,40 @@ class VisionTransformer(nn.Module):
             # engine.py:50-51 `output = model(samples)` in train mode: logits with the HIP backward behind them (training.py)
             from . import training
             return training.train_forward(self, x)
+        return self._forward_eval(x, 0)
+
+    def forward_async(self, x: torch.Tensor):
+        """Eval forward that may run BESIDE the previous one: the call enqueues the forward on one of `pipeline_depth` (default 2) side streams
+        -- each with its own workspace and captured hipGraph -- behind everything already enqueued on the caller's current stream, and
+        returns a handle at once; `handle.result()` makes the caller's current stream wait for that forward and returns what `model(x)`
+        would.  Forwards on different side streams are independent launches sequences, so the device fills the tail of one forward's launches
+        (partial last rounds of the persistent GEMM-class kernels, the short launches of the last stage) with the other's: the headline
+        forward runs 2.65 -> 2.44 ms per batch of 256 with two in flight (tools/lab/two_stream_full.py).  A data loop uses it with one batch
+        of lookahead (harness.evaluate_multiclass does): launch batch k + 1, then consume batch k.  Same kernels, same bits as `model(x)`.
+        Train mode, viz_mode and ATS's dynamic width run synchronously (the handle is already complete)."""
+        if self.training or self.viz_mode or getattr(self, "dynamic_width", False) or not x.is_cuda:
+            return _Pending(self(x), None)
+        depth = max(1, int(getattr(self, "pipeline_depth", 2)))
+        st = self.__dict__.setdefault("_pipe_streams", {})
+        key = x.device
+        if key not in st or len(st[key]) != depth:
+            st[key] = [torch.cuda.Stream(device=x.device) for _ in range(depth)]
+        slot = self.__dict__.get("_pipe_next", 0) % depth
+        self._pipe_next = slot + 1
+        side = st[key][slot]
+        cur = torch.cuda.current_stream(x.device)
+        self._pack()                                   # (re)pack on the caller's stream, where the optimizer / loader wrote
+        if getattr(self, "_mlp_pk_stale", False):
+            self._refresh_mlp_pack(x.device)
+        side.wait_stream(cur)                          # inputs and weights are ready where the forward runs
+        with torch.cuda.stream(side):
+            out = self._forward_eval(x, slot + 1)
+            done = torch.cuda.Event()
+            done.record(side)
+        x.record_stream(side)
+        return _Pending(out, done)
+
+    def _forward_eval(self, x: torch.Tensor, slot: int):
         if not x.is_cuda:
             raise RuntimeError(f"input is on {x.device}: tokenreduction_amd has no CPU path (HIP kernels only)")
         lib = _lib.load()
@@ -469,7 +526,7 @@ class VisionTransformer(nn.Module):
         if (Cc, Hh, Ww) != (cfg.in_chans, cfg.img_size, cfg.img_size):
             raise ValueError(f"expected [B,{cfg.in_chans},{cfg.img_size},{cfg.img_size}], got {tuple(x.shape)}")
         x = x.detach().to(torch.float32).contiguous()
-        ws = self._workspace(B, x.device)
+        ws = self._workspace(B, x.device, slot)
         if self.viz_mode and self._soft_elems(B) and ws.get("soft") is None:      # viz_mode switched on after the first call
             ws["soft"] = torch.empty(self._soft_elems(B), dtype=torch.float32, device=x.device)
         want_feat = self.viz_mode or getattr(self, "_always_features", False)
@@ -552,15 +609,16 @@ class VisionTransformer(nn.Module):
         the device recorded a failure that no launch status can show -- the fused Mlp's stream-K hand-over poll running out (the logits
         of that forward are invalid).  The forward itself never synchronises; call this where the logits are consumed
         (harness.evaluate_multiclass / validate and bench.py do)."""
-        ws = self.__dict__.get("_last_ws")
-        if not ws or "buf" not in ws or self._packed is None:
+        if self._packed is None:
             return
-        B = next((b for b, w in self._ws.items() if w is ws), None)
-        if B is None:
-            return
-        with torch.cuda.device(ws["buf"].device):
-            _lib.check(_lib.load().tr_vit_forward_status(C.byref(self._packed["cfg"]), ws["buf"].data_ptr(), ws["nbytes"], B,
-                                                         torch.cuda.current_stream().cuda_stream), "tr_vit_forward_status")
+        for wkey, ws in list(self._ws.items()):
+            if "buf" not in ws:
+                continue
+            B = wkey[0] if isinstance(wkey, tuple) else wkey
+            with torch.cuda.device(ws["buf"].device):
+                torch.cuda.synchronize()                   # every stream a forward may have run on (forward_async's side streams)
+                _lib.check(_lib.load().tr_vit_forward_status(C.byref(self._packed["cfg"]), ws["buf"].data_ptr(), ws["nbytes"], B,
+                                                             torch.cuda.current_stream().cuda_stream), "tr_vit_forward_status")
 
     def _viz_data(self, ws, B, tokens):
         return {}
