@@ -557,6 +557,12 @@ typedef struct {
                                  (ats.py:77-78) instead of running the static bound keep[blk] with masked rows.  Same valid tokens and logits (to
                                  the attention kernels' summation order); fewer rows downstream.  tr_vit_forward then reads one int back per
                                  sampling block: it SYNCHRONISES the stream there and cannot be captured in a hipGraph.  0 = static (default). */
+  int concurrent;             /* eval forward only, a scheduling hint: 1 = the caller runs other forwards BESIDE this one (other streams, other
+                                 workspaces: models.py forward_async), so a launch need not fill the chip on its own -- the other forward's
+                                 launches take the compute units it leaves idle.  The executor then runs the fused Mlp wherever it is
+                                 supported (also where its blocks fill less than 3/4 of a round) and as whole blocks round-robin (no stream-K
+                                 hand-over traffic): measured +2 ... +3 % with two forwards in flight, -2 ... -4 % one at a time.  Same bits
+                                 either way.  0 = one forward at a time (default). */
 } tr_vit_config;
 
 /* Diagnostics (lab, tools/lab/clock_probe.py): the in-kernel clock probes of a library built with -DTR_DIAG_CLOCK -- {shader cycles, 100-MHz

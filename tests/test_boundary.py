@@ -115,7 +115,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.TrBlockWeights) == 13 * 8          # 12 parameter pointers + mlp_pk
     assert ctypes.sizeof(_lib.TrStageWeights) == 10 * 8 + 16
     assert ctypes.sizeof(_lib.TrVitWeights) == 8 * 8 + 32 * 13 * 8 + 32 * 96
-    assert ctypes.sizeof(_lib.TrVitConfig) == (9 + 1 + 32 + 1 + 1 + 2 + 32 + 1) * 4          # ... + ats_dynamic
+    assert ctypes.sizeof(_lib.TrVitConfig) == (9 + 1 + 32 + 1 + 1 + 2 + 32 + 1 + 1) * 4      # ... + ats_dynamic + concurrent
 
 
 def test_argument_validation_without_gpu():

@@ -42,7 +42,7 @@ class TrVitConfig(C.Structure):
     _fields_ = [("family", _i), ("img_size", _i), ("patch", _i), ("in_chans", _i), ("embed_dim", _i),
                 ("depth", _i), ("num_heads", _i), ("mlp_hidden", _i), ("num_classes", _i), ("ln_eps", _f),
                 ("keep", _i * TR_MAX_DEPTH), ("precision", _i), ("knn_k", _i), ("cluster_iters", _i), ("sinkhorn_eps", _f),
-                ("kmed_init", _i * TR_MAX_DEPTH), ("ats_dynamic", _i)]
+                ("kmed_init", _i * TR_MAX_DEPTH), ("ats_dynamic", _i), ("concurrent", _i)]
 
 
 class TrLinearGrad(C.Structure):     # tr_linear_grad: one layer of tr_linear_bwd_group

@@ -1257,10 +1257,12 @@ extern "C" int tr_set_mlp_fused(int mode) {
 // the executor's question (tr_vit.hip): run the fused launch for M rows?  A block is a chain of Hd / 32 sequential steps.  With the stream-K
 // scratch and more blocks than workgroups the steps are dealt evenly (no tail round): always; else the launch is ONE round however few blocks
 // it holds: where they fill at least three quarters of the chip.
-int tr_mlp_fused_wanted(int M, int D, int Hd, int have_scratch) {
+// concurrent: the forward runs beside others (tr_vit_config.concurrent): an underfilled round costs nothing then -- always.
+int tr_mlp_fused_wanted(int M, int D, int Hd, int have_scratch, int concurrent) {
   if (!tr_mlp_fused_supported(D, Hd)) return 0;
   const int mode = g_mlp_fused_mode.load(std::memory_order_relaxed);
   if (mode >= 0) return mode;
+  if (concurrent) return 1;
   const int nblk = (M + MF_ROWS - 1) / MF_ROWS, G = mf_grid();
   if (nblk > G) {
     const int lo = g_mlp_sk_min_blocks.load(std::memory_order_relaxed);
@@ -1284,9 +1286,9 @@ int tr_mlp_resid_ln_enabled() { return g_mlp_resid_ln.load(std::memory_order_rel
 // 2 (lab): wherever the fused Mlp runs; 0: never.
 static std::atomic<int> g_mlp_ln{1};
 extern "C" int tr_set_mlp_ln(int mode) { return g_mlp_ln.exchange(mode < 0 ? 0 : (mode > 2 ? 2 : mode)); }
-int tr_mlp_ln_wanted(int M, int D, int Hd, int have_scratch) {
+int tr_mlp_ln_wanted(int M, int D, int Hd, int have_scratch, int concurrent) {
   const int mode = g_mlp_ln.load(std::memory_order_relaxed);
-  if (mode == 0 || !tr_mlp_fused_wanted(M, D, Hd, have_scratch)) return 0;
+  if (mode == 0 || !tr_mlp_fused_wanted(M, D, Hd, have_scratch, concurrent)) return 0;
   return mode == 2 || (M + MF_ROWS - 1) / MF_ROWS <= mf_grid();
 }
 

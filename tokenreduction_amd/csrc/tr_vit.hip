@@ -120,7 +120,7 @@ extern "C" int tr_profile_end(int max, char* labels, float* ms, double* flops, d
 }
 extern "C" int tr_version(void) { return 100; }
 
-int tr_mlp_fused_wanted(int M, int D, int Hd, int have_scratch);      // tr_mlp_fused.hip: the schedule policy behind tr_set_mlp_fused
+int tr_mlp_fused_wanted(int M, int D, int Hd, int have_scratch, int concurrent);      // tr_mlp_fused.hip: the schedule policy behind tr_set_mlp_fused
 int tr_mlp_resid_ln_enabled();                                        // tr_mlp_fused.hip: tr_set_mlp_resid_ln's switch
 // ... and its launches on a counter set that ONE memset in front of the forward has zeroed (block i uses set i)
 int tr_mlp_fused_zero_counters(void* scratch, size_t scratch_bytes, int D, int Hd, int nsets, tr_stream_t s);
@@ -131,7 +131,7 @@ int tr_mlp_fused_ln_bf16_set(const float* x, const uint16_t* delta, const float*
 int tr_mlp_fused_resid_ln_bf16_set(const uint16_t* xn, const void* packed, const float* fc1_b, const float* fc2_b, float* x, const float* next_g,
                                    const float* next_b, float eps, uint16_t* xn_next, void* scratch, size_t scratch_bytes, int M, int D, int Hd,
                                    int cset, tr_stream_t s);
-int tr_mlp_ln_wanted(int M, int D, int Hd, int have_scratch);         // tr_mlp_fused.hip: ... with the norm2 in front of it inside the launch (tr_set_mlp_ln)
+int tr_mlp_ln_wanted(int M, int D, int Hd, int have_scratch, int concurrent);         // tr_mlp_fused.hip: ... with the norm2 in front of it inside the launch (tr_set_mlp_ln)
 
 namespace {
 
@@ -347,7 +347,13 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
   // the stream-K hand-over counters of every fused-Mlp launch of this forward (block i: set i) start at zero: ONE memset node here instead
   // of one in front of each launch
   static const bool memset_each = [] { const char* e = getenv("TR_MLP_MEMSET_EACH"); return e && atoi(e) != 0; }();      // lab: A/B switch (a memset node per launch)
-  const bool one_memset = !train && prec == TR_PREC_BF16 && p.mlp_sk_bytes > 0 && w->blocks[0].mlp_pk != nullptr && !memset_each;
+  static const bool no_streamk = [] { const char* e = getenv("TR_MLP_NO_STREAMK"); return e && atoi(e) != 0; }();          // lab: whole blocks round-robin, no hand-over
+  const int conc = (!train && cfg->concurrent) ? 1 : 0;       // other forwards run beside this one: a launch need not fill the chip on its own
+  // the fused Mlp's stream-K scratch is there and wanted.  Beside other forwards it is not: the other forward's launches fill the second
+  // round's idle compute units, and whole blocks round-robin move no accumulators (125 MB per launch at the first stage): measured with two
+  // forwards in flight +0.5 % (Top-K kr 0.7), +1.5 % (kr 0.5), +2 % (dense DeiT-S); one at a time -1.5 ... -4 % (tools/lab/inflight_ab2.py)
+  const bool sk_ok = p.mlp_sk_bytes > 0 && !no_streamk && !conc;
+  const bool one_memset = !train && prec == TR_PREC_BF16 && sk_ok && w->blocks[0].mlp_pk != nullptr && !memset_each;
   if (one_memset) TR_TRY(tr_mlp_fused_zero_counters(ws + p.off_mlp_sk, p.mlp_sk_bytes, D, p.Hd, cfg->depth, s));
   int N = p.N0;
   const void* pending = nullptr;   // residual not yet added to x (the previous block's fc2 output)
@@ -761,12 +767,12 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
                                   cfg->ln_eps, s));
       x = x_alt;
     } else if (lazy_base && starts_plain(i + 1) && !(rl_base && i + 1 < cfg->depth && bw->mlp_pk != nullptr &&
-                                                     tr_mlp_fused_wanted(B * Nn, D, p.Hd, p.mlp_sk_bytes > 0))) {
+                                                     tr_mlp_fused_wanted(B * Nn, D, p.Hd, sk_ok, conc))) {
       // lazy norm2.  Where the fused Mlp follows as ONE round of blocks, the norm moves INTO that launch (tr_mlp_fused_ln_bf16: its fc1 waves
       // normalise x + dbuf in registers; bit-identical to the launch below followed by the plain fused Mlp) -- no LayerNorm launch, no bf16
       // rows in between (tr_set_mlp_ln; under the stream-K schedule the separate launch is faster: tr_mlp_fused.hip)
       norm2_in_mlp = prec == TR_PREC_BF16 && drop_keep == nullptr && bw->mlp_pk != nullptr &&
-                     tr_mlp_ln_wanted(B * Nn, D, p.Hd, p.mlp_sk_bytes > 0);
+                     tr_mlp_ln_wanted(B * Nn, D, p.Hd, sk_ok, conc);
       if (!norm2_in_mlp)
         TR_TRY(tr_layernorm2_bf16(x, D, nullptr, 0, static_cast<const uint16_t*>(dbuf), D, nullptr, 0, bw->ln2_g, bw->ln2_b,
                                   static_cast<uint16_t*>(xn), B * Nn, D, cfg->ln_eps, s));
@@ -782,7 +788,7 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
       void* pre = tape + tp->blk[i].pre;
       TR_TRY(tr_gemm_gelu_keep_bf16(static_cast<const uint16_t*>(xn), static_cast<const uint16_t*>(bw->fc1_w), bw->fc1_b, static_cast<uint16_t*>(pre),
                                     static_cast<uint16_t*>(hbuf), M2, p.Hd, D, s));
-    } else if (prec == TR_PREC_BF16 && bw->mlp_pk != nullptr && tr_mlp_fused_wanted(M2, D, p.Hd, p.mlp_sk_bytes > 0)) {
+    } else if (prec == TR_PREC_BF16 && bw->mlp_pk != nullptr && tr_mlp_fused_wanted(M2, D, p.Hd, sk_ok, conc)) {
       // eval: fc1 -> GELU -> fc2 in one launch, the hidden activation never leaves the CU (tr_mlp_fused.hip; bit-identical to the pair below,
       // taken where its block schedule fills the chip)
       fused_mlp = true;
@@ -799,15 +805,15 @@ static int vit_forward_impl(const tr_vit_config* cfg, const tr_vit_weights* w, c
     if (fused_tail) {
       const tr_block_weights* nb = &w->blocks[i + 1];
       TR_TRY(tr_mlp_fused_resid_ln_bf16_set(static_cast<const uint16_t*>(xn), bw->mlp_pk, bw->fc1_b, bw->fc2_b, x, nb->ln1_g, nb->ln1_b, cfg->ln_eps,
-                                            static_cast<uint16_t*>(hbuf), p.mlp_sk_bytes ? ws + p.off_mlp_sk : nullptr, p.mlp_sk_bytes, M2, D, p.Hd,
+                                            static_cast<uint16_t*>(hbuf), sk_ok ? ws + p.off_mlp_sk : nullptr, p.mlp_sk_bytes, M2, D, p.Hd,
                                             one_memset ? i : -1, s));
       xn1_ready = hbuf;
     } else if (fused_mlp && norm2_in_mlp)
       TR_TRY(tr_mlp_fused_ln_bf16_set(x, static_cast<const uint16_t*>(pending_attn), bw->ln2_g, bw->ln2_b, cfg->ln_eps, bw->mlp_pk, bw->fc1_b,
-                                      static_cast<uint16_t*>(dbuf), p.mlp_sk_bytes ? ws + p.off_mlp_sk : nullptr, p.mlp_sk_bytes, M2, D, p.Hd, one_memset ? i : -1, s));
+                                      static_cast<uint16_t*>(dbuf), sk_ok ? ws + p.off_mlp_sk : nullptr, p.mlp_sk_bytes, M2, D, p.Hd, one_memset ? i : -1, s));
     else if (fused_mlp)
       TR_TRY(tr_mlp_fused_bf16_set(static_cast<const uint16_t*>(xn), bw->mlp_pk, bw->fc1_b, static_cast<uint16_t*>(dbuf),
-                                   p.mlp_sk_bytes ? ws + p.off_mlp_sk : nullptr, p.mlp_sk_bytes, M2, D, p.Hd, one_memset ? i : -1, s));
+                                   sk_ok ? ws + p.off_mlp_sk : nullptr, p.mlp_sk_bytes, M2, D, p.Hd, one_memset ? i : -1, s));
     else
       TR_TRY(op_gemm(prec, hbuf, bw->fc2_w, bw->fc2_b, dbuf, nullptr, 0, M2, D, p.Hd, TR_EPI_BF16, s));
     if (drop_keep != nullptr) {      // ... and after fc2

@@ -537,6 +537,7 @@ class VisionTransformer(nn.Module):
         noise_ptr = self._noise_ptr(B, x.device)
         self._kmed_draws = None
         self._per_forward_config(cfg)
+        cfg.concurrent = 1 if slot > 0 else 0        # forward_async: other forwards run beside this one (a scheduling hint, same bits)
 
         def launch(out):
             tokens = (C.c_int * self.depth)()
@@ -596,6 +597,7 @@ class VisionTransformer(nn.Module):
                 tokens = launch(logits)
                 if self._classes_padded != self.num_classes:
                     logits = logits[:, :self.num_classes].contiguous()
+        cfg.concurrent = 0                           # (the packed configuration is compared byte-wise on a repack: leave no per-call state in it)
         self._last_tokens = list(tokens)
         self._last_ws = ws
         if self.viz_mode:
