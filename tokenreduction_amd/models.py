@@ -226,6 +226,20 @@ class VisionTransformer(nn.Module):
     def _param_key(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
+    def sync_pipeline(self):
+        """Makes the caller's current stream wait for every forward that forward_async has put on its side streams.  Called before the
+        operand copies are rewritten (_pack) and when the model goes to train mode; call it yourself before you modify parameters in place
+        while handles may be outstanding -- like any tensor used on another stream, the weights of a forward in flight must not change under it."""
+        for dev, streams in (self.__dict__.get("_pipe_streams") or {}).items():
+            cur = torch.cuda.current_stream(dev)
+            for st in streams:
+                cur.wait_stream(st)
+
+    def train(self, mode: bool = True):
+        if mode:
+            self.sync_pipeline()
+        return super().train(mode)
+
     def weights_changed(self):
         """Tell the executor that parameter VALUES changed behind autograd's version counters.  Automatic after every backward pass (an
         optimizer step follows: torch's fused optimizers -- AdamW(fused=True) -- update the parameters without bumping `_version`, which
@@ -247,6 +261,7 @@ class VisionTransformer(nn.Module):
         key = (self.precision, want_t) + self._param_key()
         if self._packed is not None and self._packed["key"] == key and not getattr(self, "_weights_dirty", False):
             return self._packed
+        self.sync_pipeline()        # the operand copies are rewritten in place: no forward_async forward may still be reading them
         dev = self.pos_embed.device
         if dev.type != "cuda":
             raise RuntimeError(f"model is on {dev}: tokenreduction_amd runs on MI355X only (no CPU path); call .cuda()")
@@ -534,6 +549,7 @@ class VisionTransformer(nn.Module):
             # viz_data["Features"]: the residual stream after every block (upper bound depth * B * N0 * D fp32)
             n0 = self.patch_embed.num_patches + 1
             ws["feat"] = torch.empty(self.depth * B * n0 * self.embed_dim, dtype=torch.float32, device=x.device)
+        self._noise_slot = slot                      # (a static buffer per workspace slot: two forwards in flight must not share one)
         noise_ptr = self._noise_ptr(B, x.device)
         self._kmed_draws = None
         self._per_forward_config(cfg)
@@ -1110,14 +1126,18 @@ class DPCKNNVisionTransformer(VisionTransformer):
     def _noise_ptr(self, B, dev):
         shapes = self._stage_shapes()
         n = sum(B * P for _, _, P in shapes)
-        if self._noise_buf is None or self._noise_buf.numel() != n or self._noise_buf.device != dev:
-            self._noise_buf = torch.empty(n, dtype=torch.float32, device=dev)      # static: a captured forward reads this address
+        bufs = self._noise_buf if isinstance(self._noise_buf, dict) else {}
+        self._noise_buf = bufs
+        slot = self.__dict__.get("_noise_slot", 0)                                  # forward_async: one buffer per forward in flight
+        buf = bufs.get(slot)
+        if buf is None or buf.numel() != n or buf.device != dev:
+            buf = bufs[slot] = torch.empty(n, dtype=torch.float32, device=dev)      # static: a captured forward reads this address
         if self.density_noise is not None:
             parts = [self.density_noise[blk].to(device=dev, dtype=torch.float32).reshape(B, P) for blk, _, P in shapes]
-            self._noise_buf.copy_(torch.cat([t.reshape(-1) for t in parts]))
+            buf.copy_(torch.cat([t.reshape(-1) for t in parts]))
         else:
-            self._noise_buf.uniform_()                                               # torch.rand: [0, 1)
-        return self._noise_buf.data_ptr()
+            buf.uniform_()                                                           # torch.rand: [0, 1)
+        return buf.data_ptr()
 
     def _viz_data(self, ws, B, tokens):
         P1 = self.patch_embed.num_patches + 1

@@ -248,6 +248,7 @@ class _VitTrainFn(torch.autograd.Function):
         dyvit = model._family == _lib.TR_FAMILY_DYVIT
         distill = dyvit and bool(getattr(model, "dyvit_distillation", False))
         feats = torch.empty(B, model.patch_embed.num_patches + 1, model.embed_dim, dtype=torch.float32, device=x.device) if distill else None
+        model._noise_slot = 0
         noise = model._gumbel_ptr(B, x.device) if dyvit else model._noise_ptr(B, x.device)
         ctx.drop = drop_path_scales(model, B, x.device)
         ctx.keep_mask = dropout_keep_mask(model, pk, B, x.device)
