@@ -169,7 +169,7 @@ class VisionTransformer(nn.Module):
     # torch.cuda.CUDAGraph objects cannot be deep-copied at all, and a copied workspace would not belong to the copy's own packed weights.
     _EXECUTOR_CACHES = {"_packed": None, "_ws": None, "_last_ws": None, "_tstate": None, "_grad_reducer": None, "_noise_buf": None,
                         "_gumbel_buf": None, "_kmed_draws": None, "_pack_slots": None, "_pack_table": None, "_mlp_pack_items": None,
-                        "_pipe_streams": None, "_pipe_next": None}
+                        "_pipe_streams": None, "_pipe_next": None, "_noise_bufs": None}
 
     def __deepcopy__(self, memo):
         new = self.__class__.__new__(self.__class__)
@@ -1126,12 +1126,17 @@ class DPCKNNVisionTransformer(VisionTransformer):
     def _noise_ptr(self, B, dev):
         shapes = self._stage_shapes()
         n = sum(B * P for _, _, P in shapes)
-        bufs = self._noise_buf if isinstance(self._noise_buf, dict) else {}
-        self._noise_buf = bufs
         slot = self.__dict__.get("_noise_slot", 0)                                  # forward_async: one buffer per forward in flight
-        buf = bufs.get(slot)
+        buf = self._noise_buf if slot == 0 else (self.__dict__.get("_noise_bufs") or {}).get(slot)
         if buf is None or buf.numel() != n or buf.device != dev:
-            buf = bufs[slot] = torch.empty(n, dtype=torch.float32, device=dev)      # static: a captured forward reads this address
+            buf = torch.empty(n, dtype=torch.float32, device=dev)                    # static: a captured forward reads this address
+            if slot == 0:
+                self._noise_buf = buf
+            else:
+                self.__dict__.setdefault("_noise_bufs", {})
+                if self._noise_bufs is None:
+                    self._noise_bufs = {}
+                self._noise_bufs[slot] = buf
         if self.density_noise is not None:
             parts = [self.density_noise[blk].to(device=dev, dtype=torch.float32).reshape(B, P) for blk, _, P in shapes]
             buf.copy_(torch.cat([t.reshape(-1) for t in parts]))
