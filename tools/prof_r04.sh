@@ -6,6 +6,7 @@
 TAG=${1:-r04}; shift
 WL=${@:-"headline tome atsb_train dpcknnb_train kmedb384 sinkb384 dpcknn_small ats_small sit_small evit_small"}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export TR_BENCH_IN_FLIGHT=1      # per-kernel numbers are taken one forward at a time (two in flight overlap launches: durations and counters of different kernels would mix)
 mkdir -p gpurun_out/r04_profiles
 for w in $WL; do
   case $w in
