@@ -642,7 +642,9 @@ def test_norm2_inside_the_fused_mlp_gives_the_same_logits(golden_dir, name, batc
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
-@pytest.mark.parametrize("name", ["topk_small_kr07", "topk_micro", "tome_small_r16", "dpcknn_micro", "sinkhorn_micro", "ats_micro"])
+@pytest.mark.parametrize("name", ["topk_small_kr07", "topk_micro", "tome_small_r16", "dpcknn_micro", "sinkhorn_micro", "ats_micro", "deit_micro",
+                                  "evit_micro", "dyvit_micro", "sit_micro", "kmedoids_micro", "patchmerger_micro", "heuristic_micro_l2",
+                                  "evit_small_kr05", "topk_micro_384"])
 def test_forward_async_equals_forward_with_two_forwards_in_flight(name):
     """model.forward_async enqueues eval forwards on two side streams (own workspace and captured graph each), so that two are in flight;
     `handle.result()` makes the caller's stream wait and returns what model(x) returns.  Same kernels: the logits of six batches launched
