@@ -109,7 +109,8 @@ int tr_mlp_fused_bf16(const uint16_t* xn, const void* packed, const float* fc1_b
  * followed by tr_mlp_fused_bf16(xn, ..): the LayerNorm launch (8 B per element through HBM) and the bf16 rows between the two are gone.
  * tr_set_mlp_ln: where the eval executor takes this form in place of a lazy norm2 followed by the fused Mlp -- 1 (default): where that launch
  * is one round of whole blocks (measured faster there, slower under the stream-K schedule, which normalises a block once per workgroup that
- * touches it), 2: wherever the fused Mlp runs, 0: never; returns the previous setting. */
+ * touches it) and everywhere in a forward marked `concurrent` (those launches run whole blocks), 2: wherever the fused Mlp runs, 0: never;
+ * returns the previous setting. */
 int tr_set_mlp_ln(int mode);
 int tr_mlp_fused_ln_bf16(const float* x, const uint16_t* delta, const float* g, const float* b, float eps, const void* packed,
                          const float* fc1_b, uint16_t* out, void* scratch, size_t scratch_bytes, int M, int D, int Hd, tr_stream_t s);

@@ -441,8 +441,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_persistent(const uint16_t* _
 // Barrier protocol (one s_barrier per K-step, all 12 waves): at barrier B_g the loaders have waited for DMA group g
 // (vmcnt(12): group g+1 may still fly) and the MFMA waves have finished READING slot (g-1)%3 (lgkmcnt(0));
 // after it the loaders refill that slot with group g+2 and the MFMA waves read slot g%3.
+#ifndef TR_PC_LOADERS
+#define TR_PC_LOADERS 4     // loader waves per workgroup: 4 (one per SIMD) or 2 (lab: two SIMDs keep 176 registers per lane free for another launch's waves)
+#endif
+constexpr int PC_LW = TR_PC_LOADERS, PC_SL = 4 / PC_LW;      // loader waves; 64-row slices of the tile per loader wave
+constexpr int PC_THREADS = 512 + 64 * PC_LW;
 template <int EPI>
-__global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
+__global__ __launch_bounds__(PC_THREADS, 3) void gemm_bf16_pc(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                                                        const float* __restrict__ bias, uint16_t* __restrict__ outp,
                                                        uint16_t* __restrict__ outp2, int M, int N, int K, int nMt, int nNt,
                                                        unsigned out_bytes) {
@@ -481,45 +486,53 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
   if (wave >= 8) {
-    // ================================ loader wave: 12 pieces per K-step (A rows lw*64.., W rows lw*32..)
-    const int lw = wave - 8;
+    // ================================ loader wave: 12 pieces per K-step and slice (A rows lw*64.., W rows lw*32..), PC_SL slices
+    const int lw0 = wave - 8;
     const int l3 = lane >> 3, pc = lane & 7;
     // LDS position (row, chunk pc) must hold LOGICAL chunk pc ^ ((row>>1)&7); rows lw*64 + 8j + l3 and lw*32 + 8j + l3:
     // (row>>1)&7 = (4j + (l3>>1)) & 7 for both (lw*64, lw*32 are multiples of 16)
-    unsigned o[12];
+    unsigned o[PC_SL][12];
     int l_unit = 0, l_kt = 0, l_slot = 0, l_step = 0;
     auto set_unit = [&](int u) __attribute__((always_inline)) {
       const bool half = u >= my_full;
       const int tile = half ? half_tile : toff + u * G;
       const int tm0 = (tile / nNt) * PBM + (half ? 128 * half_sel : 0), tn0 = (tile % nNt) * PBN;
-      const int rpw = half ? 32 : 64;       // activation rows per loader wave
+      const int rpw = half ? 32 : 64;       // activation rows per slice
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int c = (pc ^ ((4 * j + (l3 >> 1)) & 7)) * 8;
-        o[j] = ((unsigned)min(tm0 + lw * rpw + 8 * j + l3, M - 1) * K + c) * 2u;     // j >= 4 unused by a half tile
-      }
+      for (int q = 0; q < PC_SL; ++q) {
+        const int lw = lw0 + q * PC_LW;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int c = (pc ^ ((4 * j + (l3 >> 1)) & 7)) * 8;
-        o[8 + j] = ((unsigned)min(tn0 + lw * 32 + 8 * j + l3, N - 1) * K + c) * 2u;
+        for (int j = 0; j < 8; ++j) {
+          const int c = (pc ^ ((4 * j + (l3 >> 1)) & 7)) * 8;
+          o[q][j] = ((unsigned)min(tm0 + lw * rpw + 8 * j + l3, M - 1) * K + c) * 2u;     // j >= 4 unused by a half tile
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int c = (pc ^ ((4 * j + (l3 >> 1)) & 7)) * 8;
+          o[q][8 + j] = ((unsigned)min(tn0 + lw * 32 + 8 * j + l3, N - 1) * K + c) * 2u;
+        }
       }
     };
     auto issue_group = [&]() __attribute__((always_inline)) {
       const bool real = l_step < S;
       const bool hmode = has_half && l_step >= S_full;     // the half tile is a workgroup's LAST unit; the dummy groups behind it keep its size
-      const unsigned da = lds0 + l_slot * P_STAGE_BYTES + lw * (hmode ? 4096 : 8192);
-      const unsigned dw = lds0 + l_slot * P_STAGE_BYTES + PBM * 128 + lw * 4096;
       const uint16_t* sW = real ? W : A;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) issue_piece(A, real ? o[j] : 0u, da + j * 1024);
-      if (!hmode) {
+      for (int q = 0; q < PC_SL; ++q) {
+        const int lw = lw0 + q * PC_LW;
+        const unsigned da = lds0 + l_slot * P_STAGE_BYTES + lw * (hmode ? 4096 : 8192);
+        const unsigned dw = lds0 + l_slot * P_STAGE_BYTES + PBM * 128 + lw * 4096;
 #pragma unroll
-        for (int j = 4; j < 8; ++j) issue_piece(A, real ? o[j] : 0u, da + j * 1024);
-      }
+        for (int j = 0; j < 4; ++j) issue_piece(A, real ? o[q][j] : 0u, da + j * 1024);
+        if (!hmode) {
+#pragma unroll
+          for (int j = 4; j < 8; ++j) issue_piece(A, real ? o[q][j] : 0u, da + j * 1024);
+        }
 #ifndef TR_ABLATE_NO_W_DMA    // lab only: what would the K-loop do if the weight panel stayed in LDS (feed 32 KB instead of 48 KB per K-step)?
 #pragma unroll
-      for (int j = 0; j < 4; ++j) issue_piece(sW, real ? o[8 + j] : 0u, dw + j * 1024);
+        for (int j = 0; j < 4; ++j) issue_piece(sW, real ? o[q][8 + j] : 0u, dw + j * 1024);
 #endif
+      }
       if (real) {
         ++l_step;
         l_slot = (l_slot == P_NSTAGE - 1) ? 0 : l_slot + 1;
@@ -529,7 +542,9 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
           if (l_step < S) set_unit(l_unit);
         } else {
 #pragma unroll
-          for (int j = 0; j < 12; ++j) o[j] += 2 * BK;
+          for (int q = 0; q < PC_SL; ++q)
+#pragma unroll
+            for (int j = 0; j < 12; ++j) o[q][j] += 2 * BK;
         }
       }
     };
@@ -537,12 +552,15 @@ __global__ __launch_bounds__(768, 3) void gemm_bf16_pc(const uint16_t* __restric
     issue_group();      // group 0 -> slot 0
     issue_group();      // group 1 -> slot 1   (dummies if S < 2)
     for (int g = 0; g < S; ++g) {
-      // group g landed; group g+1 -- real or dummy, 12 pieces or a half tile's 8 -- may still fly
+      // group g landed; group g+1 -- real or dummy, 12 pieces per slice or a half tile's 8 -- may still fly
 #ifdef TR_ABLATE_NO_W_DMA
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      if (PC_SL == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
 #else
-      if (has_half && g + 1 >= S_full) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      if (has_half && g + 1 >= S_full) {
+        if (PC_SL == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      } else {
+        if (PC_SL == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      }
 #endif
       __builtin_amdgcn_s_barrier();                        // B_g: the MFMA waves are done reading slot (g-1)%3 == (g+2)%3
       if (g + 1 < S) issue_group();                        // group g+2 -> that slot (dummy pieces once nothing is left to load)
@@ -825,10 +843,10 @@ extern "C" int tr_gemm_bf16(const uint16_t* A, const uint16_t* W, const float* b
   if (epilogue == TR_EPI_BF16 || epilogue == TR_EPI_GELU_BF16) {
     // the per-block GEMMs: 8 MFMA waves + 4 loader waves
     if (epilogue == TR_EPI_BF16)
-      hipLaunchKernelGGL(gemm_bf16_pc<TR_EPI_BF16>, grid, dim3(768), 0, st, A, W, bias, static_cast<uint16_t*>(out),
+      hipLaunchKernelGGL(gemm_bf16_pc<TR_EPI_BF16>, grid, dim3(PC_THREADS), 0, st, A, W, bias, static_cast<uint16_t*>(out),
                          static_cast<uint16_t*>(nullptr), M, N, K, nMt, nNt, (unsigned)out_bytes);
     else
-      hipLaunchKernelGGL(gemm_bf16_pc<TR_EPI_GELU_BF16>, grid, dim3(768), 0, st, A, W, bias, static_cast<uint16_t*>(out),
+      hipLaunchKernelGGL(gemm_bf16_pc<TR_EPI_GELU_BF16>, grid, dim3(PC_THREADS), 0, st, A, W, bias, static_cast<uint16_t*>(out),
                          static_cast<uint16_t*>(nullptr), M, N, K, nMt, nNt, (unsigned)out_bytes);
     TR_CHECK_LAUNCH("tr_gemm_bf16");
     return TR_OK;
@@ -862,7 +880,7 @@ extern "C" int tr_gemm_dgelu_bf16(const uint16_t* A, const uint16_t* W, const ui
              "tr_gemm_dgelu_bf16: operands / outputs beyond the 32-bit offset range");
   tr_prof_note("gemm_bf16_pc<EPI_DGELU>", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K) + 4.0 * M * N);
   const int nMt = (M + PBM - 1) / PBM, nNt = (N + PBN - 1) / PBN;
-  hipLaunchKernelGGL(gemm_bf16_pc<EPI_DGELU>, dim3(256), dim3(768), 0, static_cast<hipStream_t>(s), A, W, static_cast<const float*>(nullptr), out,
+  hipLaunchKernelGGL(gemm_bf16_pc<EPI_DGELU>, dim3(256), dim3(PC_THREADS), 0, static_cast<hipStream_t>(s), A, W, static_cast<const float*>(nullptr), out,
                      const_cast<uint16_t*>(pre), M, N, K,
                      nMt, nNt, (unsigned)out_bytes);
   TR_CHECK_LAUNCH("tr_gemm_dgelu_bf16");
@@ -884,7 +902,7 @@ extern "C" int tr_gemm_gelu_keep_bf16(const uint16_t* A, const uint16_t* W, cons
              "tr_gemm_gelu_keep_bf16: operands / outputs beyond the 32-bit offset range");
   tr_prof_note("gemm_bf16_pc<EPI_GELU_KEEP>", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K) + 4.0 * M * N);
   const int nMt = (M + PBM - 1) / PBM, nNt = (N + PBN - 1) / PBN;
-  hipLaunchKernelGGL(gemm_bf16_pc<EPI_GELU_KEEP>, dim3(256), dim3(768), 0, static_cast<hipStream_t>(s), A, W, bias, h, pre, M, N, K, nMt, nNt,
+  hipLaunchKernelGGL(gemm_bf16_pc<EPI_GELU_KEEP>, dim3(256), dim3(PC_THREADS), 0, static_cast<hipStream_t>(s), A, W, bias, h, pre, M, N, K, nMt, nNt,
                      (unsigned)out_bytes);
   TR_CHECK_LAUNCH("tr_gemm_gelu_keep_bf16");
   return TR_OK;

@@ -1289,7 +1289,9 @@ extern "C" int tr_set_mlp_ln(int mode) { return g_mlp_ln.exchange(mode < 0 ? 0 :
 int tr_mlp_ln_wanted(int M, int D, int Hd, int have_scratch, int concurrent) {
   const int mode = g_mlp_ln.load(std::memory_order_relaxed);
   if (mode == 0 || !tr_mlp_fused_wanted(M, D, Hd, have_scratch, concurrent)) return 0;
-  return mode == 2 || (M + MF_ROWS - 1) / MF_ROWS <= mf_grid();
+  // one-round launches, and every launch of a forward that runs beside others: those run whole blocks (no stream-K), so each block is
+  // normalised once, by the workgroup that computes it (profiles/r06_inflight_lab.md: +0.8 % with two forwards in flight)
+  return mode == 2 || concurrent || (M + MF_ROWS - 1) / MF_ROWS <= mf_grid();
 }
 
 extern "C" int tr_set_mlp_poll_max(int iterations) { return g_mlp_poll_max.exchange(iterations >= 0 ? iterations : (1 << 24)); }      // 0 (tests): every hand-over is reported as abandoned

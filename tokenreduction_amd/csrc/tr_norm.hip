@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void layernorm_half_kernel(const float* x, lon
                                                              uint16_t* __restrict__ y, int M, float eps) {
   constexpr int D = 128 * CPL;
   const int sub = threadIdx.x & 31;
-  const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int row = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 5);      // two rows per wave, any number of waves per workgroup
   if (row >= M) return;
   typedef __attribute__((ext_vector_type(4))) float f4;
   typedef __attribute__((ext_vector_type(2))) unsigned u2;
@@ -312,7 +312,9 @@ static int layernorm_impl(bool f32, const float* x, long ldx, float* x_out, long
                                             (delta2 ? (double)M * D * 2.0 : 0.0) + ((delta && write_x) ? (double)M * D * 4.0 : 0.0));
 #ifndef TR_LN_NO_HALF
   if (!f32 && D == 384) {
-    hipLaunchKernelGGL(layernorm_half_kernel<3>, dim3((M + 7) / 8), dim3(256), 0, st, x, ldx, x_out, ldxo, static_cast<const uint16_t*>(delta), ldd,
+    static const int lnb = [] { const char* e = getenv("TR_LN_BLOCK"); const int b = e ? atoi(e) : 0; return (b == 64 || b == 128) ? b : 256; }();   // lab: waves per workgroup
+    const int rpb = lnb / 32;
+    hipLaunchKernelGGL(layernorm_half_kernel<3>, dim3((M + rpb - 1) / rpb), dim3(lnb), 0, st, x, ldx, x_out, ldxo, static_cast<const uint16_t*>(delta), ldd,
                        delta2, ldd2, write_x, gamma, beta, static_cast<uint16_t*>(y), M, eps);
     TR_CHECK_LAUNCH("tr_layernorm");
     return TR_OK;
