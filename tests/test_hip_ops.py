@@ -365,6 +365,32 @@ def test_mlp_fused_resid_ln(ops, M):
     assert e_new <= e_old + 1e-3, (float(e_new), float(e_old))
 
 
+@pytest.mark.parametrize("M", [257 * 128, 35328 + 3])
+def test_mlp_fused_resid_ln_short_tails_race_screen(ops, M):
+    """Race screen for the fused tail under the stream-K schedule where a range ends in a one- or two-step tail (257 / 277 blocks on 256
+    workgroups): the range's last time step has no barrier of its own, and a C wave that left the hand-over poll early used to write its
+    epilogue's vectors over W2 pieces its slower neighbours had yet to read -- 1-4 % of back-to-back launches came out with one 16-column
+    fragment of one block off by a step's contribution (tools/lab/resid_ln_soak.py).  300 back-to-back launches must all equal the
+    whole-block schedule's bits."""
+    D, Hd = 384, 1536
+    rng = _rng(M + 11)
+    xn = _randn(rng, M, D).bfloat16().cuda()
+    x0 = (2.0 * _randn(rng, M, D)).cuda()
+    w1, w2 = _randn(rng, Hd, D, scale=0.05).bfloat16().cuda(), _randn(rng, D, Hd, scale=0.05).bfloat16().cuda()
+    b1, b2 = _randn(rng, Hd, scale=0.1).cuda(), _randn(rng, D, scale=0.1).cuda()
+    g, bt = (1.0 + 0.2 * _randn(rng, D)).cuda(), (0.1 * _randn(rng, D)).cuda()
+    pk = ops.mlp_pack(w1, w2, b2)
+    xw, yw = x0.clone(), torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+    ops.mlp_fused_resid_ln(xn, pk, b1, b2, xw, g, bt, 1e-6, xn_next=yw, streamk=False)
+    bad = 0
+    for _ in range(300):
+        ops.mlp_fused(xn, pk, b1)                      # another stream-K launch through the same scratch in between
+        xg, yg = x0.clone(), torch.empty(M, D, dtype=torch.bfloat16, device="cuda")
+        ops.mlp_fused_resid_ln(xn, pk, b1, b2, xg, g, bt, 1e-6, xn_next=yg, streamk=True)
+        bad += 0 if (torch.equal(xg, xw) and torch.equal(yg.view(torch.int16), yw.view(torch.int16))) else 1
+    assert bad == 0, f"{bad} of 300 stream-K launches differ from the whole-block schedule"
+
+
 # ------------------------------------------------------------------------------------------ fused eval Mlp (fc1 -> GELU -> fc2, one launch)
 @pytest.mark.parametrize("M", [1, 77, 128, 129, 1000, 197 * 8, 32768 + 5, 50432, 35328, 257 * 128, 70001])
 @pytest.mark.parametrize("Hd", [1536, 64, 192])

@@ -525,6 +525,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
 #undef MF_READW
 #undef MF_RX
 #undef MF_TIE_XK
+    if constexpr (RL) __builtin_amdgcn_s_barrier();       // the C waves' barrier in front of the range's last epilogue (see there)
     MF_CLOCK_END;
     return;
   }
@@ -800,6 +801,7 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
 #undef MF_READW
 #undef MF_LOAD_X
 #undef MF_RELOAD_X
+    if constexpr (RL) __builtin_amdgcn_s_barrier();       // the C waves' barrier in front of the range's last epilogue (see there)
     MF_CLOCK_END;
     return;
   }
@@ -1004,6 +1006,16 @@ __global__ __launch_bounds__(512, 2) void mlp_fused_kernel(const uint16_t* __res
           unsigned char* const stgA = smem + cslot * MF_ENTRY + pr * 1024;
           MF_ESTAMP_DECL;
           MF_ESTAMP(0);
+          if (t > T) {
+            // The range's LAST time step has no barrier of its own (nothing is published behind it), so a C wave that is ahead would write
+            // its vectors over W2 pieces 24 + pr and 28 + pr of THIS entry while a slower C wave has yet to read them: fragment pr / pr + 4 of
+            // one step of the block went wrong in the OTHER waves, 1-4 % of the stream-K launches whose range ends in a one- or two-step
+            // tail -- the waves leave the hand-over poll in front of it at different times (tools/lab/resid_ln_soak.py; found by a one-off
+            // failure of test_mlp_fused_resid_ln[32896]).  One more barrier for all eight waves: the P waves run theirs before they return.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+          }
           {
             const unsigned ldsA = lds0 + cslot * MF_ENTRY + pr * 1024;
             mf_piece(reinterpret_cast<const unsigned char*>(rl.b2), lane16, ldsA + 2 * 4096);
