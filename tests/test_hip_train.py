@@ -417,6 +417,42 @@ def test_every_factory_name_takes_a_training_step():
     assert out.stdout.count(" ok ") >= 42 and "raises" not in out.stdout
 
 
+@pytest.mark.parametrize("name", ["topk_small_patch16_224", "dyvit_small_patch16_224", "dpcknn_small_patch16_224", "tome_small_patch16_224",
+                                  "ats_small_patch16_224", "sit_small_patch16_224"])
+def test_training_gradients_are_the_same_bits_run_after_run(name):
+    """Race screen of the training path (tools/lab/train_soak.py is the long form, 12 families x 60 steps at full width): the same forward +
+    loss + backward -- same weights, same batch, same noise seed, no optimizer step -- eight times back to back; every gradient equals the
+    first run's bit for bit.  The backward kernels sum in a fixed order (since round 6 also DyViT's predictor head, whose weight gradient was
+    accumulated with LDS float atomics), so a difference is a race or an uninitialised read."""
+    import tokenreduction_amd as tra
+    from tokenreduction_amd.harness import Args
+    tome = name.startswith("tome")
+    args = Args(keep_rate=[196 - 16 * (i + 1) for i in range(12)] if tome else [0.7], reduction_loc=list(range(12)) if tome else [3, 6, 9])
+    torch.manual_seed(0)
+    model = tra.create_model(name, pretrained=False, num_classes=100, args=args).cuda().train()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(24, 3, 224, 224, generator=g).cuda()
+    y = torch.randint(0, 100, (24,), generator=g).cuda()
+    ref, bad = None, {}
+    for i in range(8):
+        torch.manual_seed(7)
+        torch.cuda.manual_seed(7)
+        out = model(x)
+        loss = torch.nn.functional.cross_entropy(out[0] if isinstance(out, tuple) else out, y)
+        for p_ in model.parameters():
+            p_.grad = None
+        loss.backward()
+        grads = {k: p_.grad.clone() for k, p_ in model.named_parameters() if p_.grad is not None}
+        if ref is None:
+            ref = grads
+            assert len(ref) > 100 and all(bool(torch.isfinite(v).all()) for v in ref.values())
+            continue
+        for k, v in grads.items():
+            if not torch.equal(v, ref[k]):
+                bad[k] = bad.get(k, 0) + 1
+    assert not bad, f"gradients that differed from the first run: {sorted(bad.items())[:6]}"
+
+
 @pytest.mark.parametrize("classes", [555, 81, 10, 1])
 def test_any_number_of_classes_trains_and_evaluates(classes):
     """train.py:334 `model.reset_classifier(args.num_classes)`: NABirds has 555 classes, NUS-WIDE 81.  The kernels see the classifier padded to a

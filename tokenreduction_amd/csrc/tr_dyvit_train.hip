@@ -203,10 +203,8 @@ __global__ __launch_bounds__(256) void dyvit_decide_bwd_kernel(const float* __re
                                                                const float* __restrict__ sm0, const uint16_t* __restrict__ h2, int ldh,
                                                                const float* __restrict__ w, uint16_t* __restrict__ dh2,
                                                                float* __restrict__ dprev, float* __restrict__ part, int N, int M, int C) {
-  extern __shared__ float sacc[];        // [2C + 2] per workgroup
+  __shared__ float sdz[16][2];           // the 16 rows' dz: the weight-gradient partials below are summed over the rows in a FIXED order
   const int sub = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  for (int i = threadIdx.x; i < 2 * C + 2; i += 256) sacc[i] = 0.f;
-  __syncthreads();
   const int row = blockIdx.x * 16 + rl;
   float dz0 = 0.f, dz1 = 0.f;
   if (row < M) {
@@ -223,20 +221,26 @@ __global__ __launch_bounds__(256) void dyvit_decide_bwd_kernel(const float* __re
       dz1 = dl1 - (1.0f - q0) * (dl0 + dl1);
       if (sub == 0) dprev[row] += dk * hard;
     }
-    for (int c = sub; c < C; c += 16) {
-      dh2[(size_t)row * ldh + c] = (uint16_t)(pack_bf16x2(dz0 * w[c] + dz1 * w[C + c], 0.f) & 0xffffu);
-      const float hv = bf16_bits_to_f32(h2[(size_t)row * ldh + c]);
-      atomicAdd(&sacc[c], dz0 * hv);            // LDS float adds: 16 rows per workgroup, order varies run to run at the 1e-7 level
-      atomicAdd(&sacc[C + c], dz1 * hv);
-    }
+    for (int c = sub; c < C; c += 16) dh2[(size_t)row * ldh + c] = (uint16_t)(pack_bf16x2(dz0 * w[c] + dz1 * w[C + c], 0.f) & 0xffffu);
     for (int c = C + sub; c < ldh; c += 16) dh2[(size_t)row * ldh + c] = 0;      // zero-padded columns of the D/4 layer
-    if (sub == 0) {
-      atomicAdd(&sacc[2 * C], dz0);
-      atomicAdd(&sacc[2 * C + 1], dz1);
-    }
   }
+  if (sub == 0) { sdz[rl][0] = dz0; sdz[rl][1] = dz1; }                 // rows beyond M and the class token: zeros
   __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C + 2; i += 256) part[(size_t)blockIdx.x * (2 * C + 4) + i] = sacc[i];
+  // dW3[k][c] partial = sum_r dz[r][k] * h2[r][c], db3[k] partial = sum_r dz[r][k]: one thread per output, rows 0..15 in order (round 6: these
+  // were LDS float atomics -- the only run-to-run variation of the training path, at the 1e-6 level; tools/lab/train_soak.py)
+  const int nrow = min(16, M - blockIdx.x * 16);
+  for (int i = threadIdx.x; i < 2 * C + 2; i += 256) {
+    float a = 0.f;
+    if (i < 2 * C) {
+      const int k = i >= C ? 1 : 0, c = i - k * C;
+      const uint16_t* hp = h2 + (size_t)blockIdx.x * 16 * ldh + c;
+      for (int r = 0; r < nrow; ++r) a += sdz[r][k] * bf16_bits_to_f32(hp[(size_t)r * ldh]);
+    } else {
+      const int k = i - 2 * C;
+      for (int r = 0; r < 16; ++r) a += sdz[r][k];
+    }
+    part[(size_t)blockIdx.x * (2 * C + 4) + i] = a;
+  }
 }
 
 // out[i] (+)= sum over heads of part[b][h][n]
@@ -309,7 +313,7 @@ extern "C" int tr_dyvit_decide_bwd(const float* dkeep, const float* prev, const 
   const int M = B * N, nwg = (M + 15) / 16;
   TR_REQUIRE(ws_floats >= tr_dyvit_decide_bwd_workspace_floats(B, N, C), TR_ERR_SHAPE, "tr_dyvit_decide_bwd: workspace too small");
   hipStream_t st = static_cast<hipStream_t>(s);
-  hipLaunchKernelGGL(dyvit_decide_bwd_kernel, dim3(nwg), dim3(256), (size_t)(2 * C + 2) * sizeof(float), st, dkeep, prev, hard0, ysoft0, sm0, h2,
+  hipLaunchKernelGGL(dyvit_decide_bwd_kernel, dim3(nwg), dim3(256), 0, st, dkeep, prev, hard0, ysoft0, sm0, h2,
                      ldh, w, dh2, dprev, ws, N, M, C);
   TR_CHECK_LAUNCH("tr_dyvit_decide_bwd");
   // reduce the per-workgroup partials [nwg][2C+4] (entries 2C+2, 2C+3 are padding) into one row, then split into dW3 and db3

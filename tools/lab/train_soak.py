@@ -1,19 +1,21 @@
 """Lab: race screen of the TRAINING path -- the same forward + loss + backward (same weights, same batch, no optimizer step) n times back to
-back; every gradient must equal the first run's bit for bit (the backward kernels use no floating-point atomics: a difference is a race or an
-uninitialised read).  tools/lab/train_soak.py [n] [family ...]"""
+back; every gradient must equal the first run's bit for bit (the backward kernels sum in a fixed order -- except DyViT's predictor head, whose two-class Linear accumulates
+its weight gradient with LDS float atomics: differences at the 1e-6 level there, nowhere else -- so a difference is a race or an uninitialised read).  tools/lab/train_soak.py [n] [family ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch, bench
 args = sys.argv[1:]
 n = int(args[0]) if args else 60
 fams = args[1:] or ["topk_small_patch16_224", "evit_small_patch16_224", "tome_small_patch16_224", "dyvit_small_patch16_224", "ats_base_patch16_224",
-                    "dpcknn_base_patch16_224", "sinkhorn_small_patch16_224", "sit_small_patch16_224", "patchmerger_small_patch16_224"]
+                    "dpcknn_base_patch16_224", "sinkhorn_small_patch16_224", "sit_small_patch16_224", "patchmerger_small_patch16_224", "kmedoids_small_patch16_224",
+                    "heuristic_small_patch16_224", "deit_small_patch16_224_local"]
 torch.cuda.set_device(0)
 for name in fams:
     B = 64 if "base" in name else 128
-    kr = ["r16"] if name.startswith("tome") else ([0.5] if "base" in name else [0.7])
+    tome = name.startswith("tome")
+    kr = [196 - 16 * (i + 1) for i in range(12)] if tome else ([0.5] if "base" in name else [0.7])       # ToMe: r = 16 in every block (configs[2])
     try:
-        model = bench.build_model(name, kr, [3, 6, 9], "cuda").train()
+        model = bench.build_model(name, kr, list(range(12)) if tome else [3, 6, 9], "cuda").train()
     except Exception as e:                                                 # a family the factory does not know under this name
         print(f"{name}: skipped ({type(e).__name__}: {str(e)[:80]})", flush=True)
         continue
@@ -40,6 +42,6 @@ for name in fams:
                 bad[k] = bad.get(k, 0) + 1
                 worst = max(worst, float((gk - ref[k]).abs().max() / (ref[k].abs().max() + 1e-30)))
     torch.cuda.synchronize()
-    print(f"{name} B={B}: {n} steps, loss {float(loss):.5f}; parameters whose gradient ever differed from the first run: {len(bad)} of {len(ref)}"
+    print(f"{name} B={B}: {n} steps, loss {float(loss.detach()):.5f}; parameters whose gradient ever differed from the first run: {len(bad)} of {len(ref)}"
           + (f" (worst relative difference {worst:.3g}; e.g. {sorted(bad.items(), key=lambda kv: -kv[1])[:4]})" if bad else ""), flush=True)
     del model
