@@ -424,12 +424,15 @@ def test_training_gradients_are_the_same_bits_run_after_run(name):
     loss + backward -- same weights, same batch, same noise seed, no optimizer step -- eight times back to back; every gradient equals the
     first run's bit for bit.  The backward kernels sum in a fixed order (since round 6 also DyViT's predictor head, whose weight gradient was
     accumulated with LDS float atomics), so a difference is a race or an uninitialised read."""
+    import types
     import tokenreduction_amd as tra
-    from tokenreduction_amd.harness import Args
     tome = name.startswith("tome")
-    args = Args(keep_rate=[196 - 16 * (i + 1) for i in range(12)] if tome else [0.7], reduction_loc=list(range(12)) if tome else [3, 6, 9])
+    args = types.SimpleNamespace(keep_rate=[196 - 16 * (i + 1) for i in range(12)] if tome else [0.7], reduction_loc=list(range(12)) if tome else [3, 6, 9],
+                                 dyvit_distill=False, k_neighbors=5, equal_weight=False, cluster_iters=3, sinkhorn_eps=1.0, heuristic_pattern="l2",
+                                 not_contiguous=False, min_radius=None)
     torch.manual_seed(0)
-    model = tra.create_model(name, pretrained=False, num_classes=100, args=args).cuda().train()
+    model = tra.create_model(name, pretrained=False, num_classes=100, drop_rate=0.0, drop_path_rate=0.0, drop_block_rate=None, img_size=224,
+                             args=args).cuda().train()
     g = torch.Generator().manual_seed(5)
     x = torch.randn(24, 3, 224, 224, generator=g).cuda()
     y = torch.randint(0, 100, (24,), generator=g).cuda()
