@@ -153,7 +153,8 @@ def mlp_fused(xn: torch.Tensor, packed: torch.Tensor, fc1_b: torch.Tensor, out: 
 
 def set_mlp_ln(mode: int) -> int:
     """Where the eval executor runs a lazy norm2 INSIDE the fused Mlp launch that follows it (mlp_fused_ln) instead of as its own LayerNorm
-    launch -- the two are bit-identical: 1 (default) where that launch is one round of whole blocks, 2 wherever the fused Mlp runs, 0 never.
+    launch -- the two are bit-identical: 1 (default) where that launch is one round of whole blocks and in every launch of a forward that
+    runs beside others (model.forward_async: whole-block launches), 2 wherever the fused Mlp runs, 0 never.
     Process-wide, read when the launches are enqueued: a captured hipGraph keeps the form it was captured with (drop `model._ws` to
     re-capture).  Returns the previous setting."""
     return int(_lib.load().tr_set_mlp_ln(int(mode)))
